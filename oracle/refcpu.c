@@ -1,0 +1,518 @@
+/*
+ * refcpu -- CPU ORACLE for the MiniGPT-4 hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (minigpt4.cpp_amd/csrc) never links, imports or calls it.
+ *
+ * PARITY UNPINNED: the reference (Maknee/minigpt4.cpp) delegates all arithmetic to
+ * llama.cpp @ tag master-31cfbb1 (ggml.c / k_quants.c / llama.cpp), fetched by CMake at configure
+ * time (/root/reference/CMakeLists.txt:317-318).  That source is not on this machine and the
+ * reference ships no tests, golden vectors or fixtures, so this file is a restatement of ggml's
+ * published algorithms (block layouts, activation quantisation to Q8_0/Q8_1/Q8_K + integer block
+ * dots, fp16-table GELU/SiLU/exp, eps values) anchored on the reference's own call sites:
+ *
+ *   vision graph           /root/reference/minigpt4.cpp:2094-2363  (encode_image)
+ *   Linear/Conv/LayerNorm  /root/reference/minigpt4.cpp:1014-1092
+ *   BERT attention/layer   /root/reference/minigpt4.cpp:1112-1242, 1345-1461
+ *   ViT attention          /root/reference/minigpt4.cpp:1254-1313
+ *   llama_eval(_embd)      /root/reference/minigpt4.cpp:2373, 2412  (graph: SURVEY.md 3.3)
+ *
+ * Rounding choices where ggml's own code paths differ by ISA (the reference builds with AVX2/F16C
+ * by default, CMakeLists.txt:27-30): activation quantisation rounds half-to-even (the AVX2 path),
+ * fp32<->fp16 conversions are IEEE RNE (F16C), block results are accumulated block-by-block in fp32
+ * with one fma per block.
+ *
+ * Build: see oracle/Makefile (gcc -O3 -mavx2 -mfma -mf16c -fopenmp).
+ */
+#include <immintrin.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ggml_type numbering (LLM file) */
+enum { T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q8_1 = 9,
+       T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15 };
+
+#define QK 32
+#define QK_K 256
+#define RMS_EPS 1e-6f  /* ggml_rms_norm at master-31cfbb1 (hard-coded) */
+#define LN_EPS 1e-5f   /* ggml_norm at master-31cfbb1 (hard-coded) */
+
+typedef uint16_t f16_t;
+static inline float h2f(f16_t h) { return _cvtsh_ss(h); }
+static inline f16_t f2h(float f) { return _cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
+static inline float f16r(float f) { return h2f(f2h(f)); } /* round-trip through fp16 */
+
+/* --------------------------------------------------------------------------------------------
+ * fp16 lookup tables (ggml_table_gelu_f16 / silu_f16 / exp_f16): f evaluated in fp32 on the fp16 value,
+ * stored as fp16.  Exported so the GPU side can be fed *identical* tables in tests if desired.
+ * ------------------------------------------------------------------------------------------ */
+static f16_t tab_gelu[65536], tab_silu[65536], tab_exp[65536];
+static int tabs_ready = 0;
+static float gelu_f32(float x) { return 0.5f * x * (1.0f + tanhf(0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x))); }
+static float silu_f32(float x) { return x / (1.0f + expf(-x)); }
+static void init_tables(void) {
+    if (tabs_ready) return;
+    for (int i = 0; i < 65536; i++) {
+        float x = h2f((f16_t)i);
+        tab_gelu[i] = f2h(gelu_f32(x));
+        tab_silu[i] = f2h(silu_f32(x));
+        tab_exp[i] = f2h(expf(x));
+    }
+    tabs_ready = 1;
+}
+ORC_API const uint16_t *orc_table(int which) {
+    init_tables();
+    return which == 0 ? tab_gelu : which == 1 ? tab_silu : tab_exp;
+}
+static inline float gelu_t(float x) { return h2f(tab_gelu[f2h(x)]); }
+static inline float silu_t(float x) { return h2f(tab_silu[f2h(x)]); }
+static inline float exp_t(float x) { return h2f(tab_exp[f2h(x)]); }
+
+/* --------------------------------------------------------------------------------------------
+ * block layouts
+ * ------------------------------------------------------------------------------------------ */
+#pragma pack(push, 1)
+typedef struct { f16_t d; uint8_t qs[16]; } blk_q4_0;
+typedef struct { f16_t d, m; uint8_t qs[16]; } blk_q4_1;
+typedef struct { f16_t d; uint8_t qh[4]; uint8_t qs[16]; } blk_q5_0;
+typedef struct { f16_t d, m; uint8_t qh[4]; uint8_t qs[16]; } blk_q5_1;
+typedef struct { f16_t d; int8_t qs[32]; } blk_q8_0;
+typedef struct { float d, s; int8_t qs[32]; } blk_q8_1;
+typedef struct { f16_t d, dmin; uint8_t scales[12]; uint8_t qs[128]; } blk_q4_K;
+typedef struct { f16_t d, dmin; uint8_t scales[12]; uint8_t qh[32]; uint8_t qs[128]; } blk_q5_K;
+typedef struct { uint8_t ql[128]; uint8_t qh[64]; int8_t scales[16]; f16_t d; } blk_q6_K;
+typedef struct { float d; int8_t qs[256]; int16_t bsums[16]; } blk_q8_K;
+#pragma pack(pop)
+
+ORC_API int64_t orc_type_block(int type) { switch (type) { case T_F32: case T_F16: return 1; case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_Q8_K: case T_Q2_K: case T_Q3_K: return 256; default: return 32; } }
+ORC_API int64_t orc_type_bytes(int type) {
+    switch (type) {
+        case T_F32: return 4; case T_F16: return 2; case T_Q4_0: return 18; case T_Q4_1: return 20; case T_Q5_0: return 22;
+        case T_Q5_1: return 24; case T_Q8_0: return 34; case T_Q8_1: return 40; case T_Q4_K: return 144; case T_Q5_K: return 176;
+        case T_Q6_K: return 210; case T_Q8_K: return 292; default: return 0; }
+}
+static int64_t row_bytes(int type, int64_t n) { return n / orc_type_block(type) * orc_type_bytes(type); }
+
+static inline void get_scale_min_k4(int j, const uint8_t *q, uint8_t *d, uint8_t *m) {
+    if (j < 4) { *d = q[j] & 63; *m = q[j + 4] & 63; }
+    else { *d = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); *m = (q[j + 4] >> 4) | ((q[j] >> 6) << 4); }
+}
+
+/* ---- dequantize_row_* (ggml_get_rows on tok_embeddings) ---- */
+ORC_API int orc_dequantize_row(int type, const void *src, float *y, int64_t n) {
+    switch (type) {
+    case T_F32: memcpy(y, src, n * 4); return 0;
+    case T_F16: { const f16_t *x = src; for (int64_t i = 0; i < n; i++) y[i] = h2f(x[i]); return 0; }
+    case T_Q4_0: { const blk_q4_0 *x = src; for (int64_t i = 0; i < n / QK; i++) { float d = h2f(x[i].d);
+        for (int j = 0; j < 16; j++) { y[i * QK + j] = ((x[i].qs[j] & 15) - 8) * d; y[i * QK + j + 16] = ((x[i].qs[j] >> 4) - 8) * d; } } return 0; }
+    case T_Q4_1: { const blk_q4_1 *x = src; for (int64_t i = 0; i < n / QK; i++) { float d = h2f(x[i].d), m = h2f(x[i].m);
+        for (int j = 0; j < 16; j++) { y[i * QK + j] = (x[i].qs[j] & 15) * d + m; y[i * QK + j + 16] = (x[i].qs[j] >> 4) * d + m; } } return 0; }
+    case T_Q5_0: { const blk_q5_0 *x = src; for (int64_t i = 0; i < n / QK; i++) { float d = h2f(x[i].d); uint32_t qh; memcpy(&qh, x[i].qh, 4);
+        for (int j = 0; j < 16; j++) { uint8_t xh0 = ((qh >> j) << 4) & 0x10, xh1 = (qh >> (j + 12)) & 0x10;
+            y[i * QK + j] = (((x[i].qs[j] & 15) | xh0) - 16) * d; y[i * QK + j + 16] = (((x[i].qs[j] >> 4) | xh1) - 16) * d; } } return 0; }
+    case T_Q5_1: { const blk_q5_1 *x = src; for (int64_t i = 0; i < n / QK; i++) { float d = h2f(x[i].d), m = h2f(x[i].m); uint32_t qh; memcpy(&qh, x[i].qh, 4);
+        for (int j = 0; j < 16; j++) { uint8_t xh0 = ((qh >> j) << 4) & 0x10, xh1 = (qh >> (j + 12)) & 0x10;
+            y[i * QK + j] = ((x[i].qs[j] & 15) | xh0) * d + m; y[i * QK + j + 16] = ((x[i].qs[j] >> 4) | xh1) * d + m; } } return 0; }
+    case T_Q8_0: { const blk_q8_0 *x = src; for (int64_t i = 0; i < n / QK; i++) { float d = h2f(x[i].d); for (int j = 0; j < 32; j++) y[i * QK + j] = x[i].qs[j] * d; } return 0; }
+    case T_Q4_K: { const blk_q4_K *x = src; for (int64_t i = 0; i < n / QK_K; i++) { const float d = h2f(x[i].d), mn = h2f(x[i].dmin); const uint8_t *q = x[i].qs; int is = 0; uint8_t sc, m;
+        for (int j = 0; j < QK_K; j += 64) { get_scale_min_k4(is, x[i].scales, &sc, &m); float d1 = d * sc, m1 = mn * m; get_scale_min_k4(is + 1, x[i].scales, &sc, &m); float d2 = d * sc, m2 = mn * m;
+            for (int l = 0; l < 32; l++) *y++ = d1 * (q[l] & 0xF) - m1; for (int l = 0; l < 32; l++) *y++ = d2 * (q[l] >> 4) - m2; q += 32; is += 2; } } return 0; }
+    case T_Q5_K: { const blk_q5_K *x = src; for (int64_t i = 0; i < n / QK_K; i++) { const float d = h2f(x[i].d), mn = h2f(x[i].dmin); const uint8_t *ql = x[i].qs, *qh = x[i].qh; int is = 0; uint8_t sc, m, u1 = 1, u2 = 2;
+        for (int j = 0; j < QK_K; j += 64) { get_scale_min_k4(is, x[i].scales, &sc, &m); float d1 = d * sc, m1 = mn * m; get_scale_min_k4(is + 1, x[i].scales, &sc, &m); float d2 = d * sc, m2 = mn * m;
+            for (int l = 0; l < 32; l++) *y++ = d1 * ((ql[l] & 0xF) + (qh[l] & u1 ? 16 : 0)) - m1; for (int l = 0; l < 32; l++) *y++ = d2 * ((ql[l] >> 4) + (qh[l] & u2 ? 16 : 0)) - m2;
+            ql += 32; is += 2; u1 <<= 2; u2 <<= 2; } } return 0; }
+    case T_Q6_K: { const blk_q6_K *x = src; for (int64_t i = 0; i < n / QK_K; i++) { const float d = h2f(x[i].d); const uint8_t *ql = x[i].ql, *qh = x[i].qh; const int8_t *sc = x[i].scales;
+        for (int nn = 0; nn < QK_K; nn += 128) { for (int l = 0; l < 32; l++) { int is = l / 16;
+                const int8_t q1 = (int8_t)((ql[l] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32, q2 = (int8_t)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                const int8_t q3 = (int8_t)((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32, q4 = (int8_t)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+                y[l] = d * sc[is] * q1; y[l + 32] = d * sc[is + 2] * q2; y[l + 64] = d * sc[is + 4] * q3; y[l + 96] = d * sc[is + 6] * q4; }
+            y += 128; ql += 64; qh += 32; sc += 8; } } return 0; }
+    default: return -1;
+    }
+}
+
+/* ---- activation quantisation: the vec_dot_type of each weight type ---- */
+ORC_API int orc_vec_dot_type(int wtype) {
+    switch (wtype) { case T_Q4_0: case T_Q5_0: case T_Q8_0: return T_Q8_0; case T_Q4_1: case T_Q5_1: return T_Q8_1;
+        case T_Q4_K: case T_Q5_K: case T_Q6_K: return T_Q8_K; case T_F16: return T_F16; case T_F32: return T_F32; default: return -1; }
+}
+
+static void quantize_row_q8_0(const float *x, blk_q8_0 *y, int64_t n) {
+    for (int64_t i = 0; i < n / QK; i++) { float amax = 0.0f; for (int j = 0; j < QK; j++) { float v = fabsf(x[i * QK + j]); if (v > amax) amax = v; }
+        const float d = amax / 127.0f, id = d ? 1.0f / d : 0.0f; y[i].d = f2h(d);
+        for (int j = 0; j < QK; j++) y[i].qs[j] = (int8_t)nearbyintf(x[i * QK + j] * id); }
+}
+static void quantize_row_q8_1(const float *x, blk_q8_1 *y, int64_t n) {
+    for (int64_t i = 0; i < n / QK; i++) { float amax = 0.0f; for (int j = 0; j < QK; j++) { float v = fabsf(x[i * QK + j]); if (v > amax) amax = v; }
+        const float d = amax / 127.0f, id = d ? 1.0f / d : 0.0f; y[i].d = d; int sum = 0;
+        for (int j = 0; j < QK; j++) { int8_t q = (int8_t)nearbyintf(x[i * QK + j] * id); y[i].qs[j] = q; sum += q; }
+        y[i].s = d * (float)sum; }
+}
+static void quantize_row_q8_K(const float *x, blk_q8_K *y, int64_t n) {
+    for (int64_t i = 0; i < n / QK_K; i++) { float max = 0, amax = 0; for (int j = 0; j < QK_K; j++) { float ax = fabsf(x[j]); if (ax > amax) { amax = ax; max = x[j]; } }
+        if (!amax) { y[i].d = 0; memset(y[i].qs, 0, QK_K); memset(y[i].bsums, 0, 32); x += QK_K; continue; }
+        const float iscale = -128.f / max;
+        for (int j = 0; j < QK_K; j++) { int v = (int)nearbyintf(iscale * x[j]); y[i].qs[j] = (int8_t)(v > 127 ? 127 : v); }
+        for (int j = 0; j < QK_K / 16; j++) { int s = 0; for (int k = 0; k < 16; k++) s += y[i].qs[j * 16 + k]; y[i].bsums[j] = (int16_t)s; }
+        y[i].d = 1 / iscale; x += QK_K; }
+}
+ORC_API int64_t orc_quantize_row(int qtype, const float *x, void *y, int64_t n) {
+    switch (qtype) {
+    case T_Q8_0: quantize_row_q8_0(x, y, n); return n / QK * (int64_t)sizeof(blk_q8_0);
+    case T_Q8_1: quantize_row_q8_1(x, y, n); return n / QK * (int64_t)sizeof(blk_q8_1);
+    case T_Q8_K: quantize_row_q8_K(x, y, n); return n / QK_K * (int64_t)sizeof(blk_q8_K);
+    case T_F16: { f16_t *o = y; for (int64_t i = 0; i < n; i++) o[i] = f2h(x[i]); return n * 2; }
+    case T_F32: memcpy(y, x, n * 4); return n * 4;
+    default: return -1; }
+}
+
+/* ---- vec_dot: quantised weight row . quantised activation row (integer block dots, fp32 scales) ---- */
+static float vec_dot_q4_0_q8_0(int64_t n, const blk_q4_0 *x, const blk_q8_0 *y) { float sumf = 0;
+    for (int64_t i = 0; i < n / QK; i++) { int sumi = 0; for (int j = 0; j < 16; j++) sumi += ((x[i].qs[j] & 15) - 8) * y[i].qs[j] + ((x[i].qs[j] >> 4) - 8) * y[i].qs[j + 16];
+        sumf = fmaf(h2f(x[i].d) * h2f(y[i].d), (float)sumi, sumf); } return sumf; }
+static float vec_dot_q4_1_q8_1(int64_t n, const blk_q4_1 *x, const blk_q8_1 *y) { float sumf = 0;
+    for (int64_t i = 0; i < n / QK; i++) { int sumi = 0; for (int j = 0; j < 16; j++) sumi += (x[i].qs[j] & 15) * y[i].qs[j] + (x[i].qs[j] >> 4) * y[i].qs[j + 16];
+        sumf = fmaf(h2f(x[i].d) * y[i].d, (float)sumi, sumf); sumf = fmaf(h2f(x[i].m), y[i].s, sumf); } return sumf; }
+static float vec_dot_q5_0_q8_0(int64_t n, const blk_q5_0 *x, const blk_q8_0 *y) { float sumf = 0;
+    for (int64_t i = 0; i < n / QK; i++) { uint32_t qh; memcpy(&qh, x[i].qh, 4); int sumi = 0;
+        for (int j = 0; j < 16; j++) { uint8_t xh0 = ((qh >> j) << 4) & 0x10, xh1 = (qh >> (j + 12)) & 0x10;
+            sumi += (int)(((x[i].qs[j] & 15) | xh0) - 16) * y[i].qs[j] + (int)(((x[i].qs[j] >> 4) | xh1) - 16) * y[i].qs[j + 16]; }
+        sumf = fmaf(h2f(x[i].d) * h2f(y[i].d), (float)sumi, sumf); } return sumf; }
+static float vec_dot_q5_1_q8_1(int64_t n, const blk_q5_1 *x, const blk_q8_1 *y) { float sumf = 0;
+    for (int64_t i = 0; i < n / QK; i++) { uint32_t qh; memcpy(&qh, x[i].qh, 4); int sumi = 0;
+        for (int j = 0; j < 16; j++) { uint8_t xh0 = ((qh >> j) << 4) & 0x10, xh1 = (qh >> (j + 12)) & 0x10;
+            sumi += (int)((x[i].qs[j] & 15) | xh0) * y[i].qs[j] + (int)((x[i].qs[j] >> 4) | xh1) * y[i].qs[j + 16]; }
+        sumf = fmaf(h2f(x[i].d) * y[i].d, (float)sumi, sumf); sumf = fmaf(h2f(x[i].m), y[i].s, sumf); } return sumf; }
+static float vec_dot_q8_0_q8_0(int64_t n, const blk_q8_0 *x, const blk_q8_0 *y) { float sumf = 0;
+    for (int64_t i = 0; i < n / QK; i++) { int sumi = 0; for (int j = 0; j < 32; j++) sumi += x[i].qs[j] * y[i].qs[j];
+        sumf = fmaf(h2f(x[i].d) * h2f(y[i].d), (float)sumi, sumf); } return sumf; }
+static float vec_dot_q4_K_q8_K(int64_t n, const blk_q4_K *x, const blk_q8_K *y) { float sumf = 0;
+    for (int64_t i = 0; i < n / QK_K; i++) { int isum = 0, msum = 0; const uint8_t *q = x[i].qs; const int8_t *a = y[i].qs;
+        for (int j = 0; j < 4; j++) { uint8_t sc0, m0, sc1, m1; get_scale_min_k4(2 * j, x[i].scales, &sc0, &m0); get_scale_min_k4(2 * j + 1, x[i].scales, &sc1, &m1);
+            int s0 = 0, s1 = 0; for (int l = 0; l < 32; l++) { s0 += (q[l] & 15) * a[l]; s1 += (q[l] >> 4) * a[l + 32]; }
+            isum += sc0 * s0 + sc1 * s1; msum += m0 * (y[i].bsums[4 * j] + y[i].bsums[4 * j + 1]) + m1 * (y[i].bsums[4 * j + 2] + y[i].bsums[4 * j + 3]); q += 32; a += 64; }
+        sumf = fmaf(h2f(x[i].d) * y[i].d, (float)isum, sumf); sumf = fmaf(-(h2f(x[i].dmin) * y[i].d), (float)msum, sumf); } return sumf; }
+static float vec_dot_q5_K_q8_K(int64_t n, const blk_q5_K *x, const blk_q8_K *y) { float sumf = 0;
+    for (int64_t i = 0; i < n / QK_K; i++) { int isum = 0, msum = 0; const uint8_t *q = x[i].qs, *qh = x[i].qh; const int8_t *a = y[i].qs;
+        for (int j = 0; j < 4; j++) { uint8_t sc0, m0, sc1, m1; get_scale_min_k4(2 * j, x[i].scales, &sc0, &m0); get_scale_min_k4(2 * j + 1, x[i].scales, &sc1, &m1);
+            int s0 = 0, s1 = 0; for (int l = 0; l < 32; l++) { int w0 = (q[l] & 15) | (((qh[l] >> (2 * j)) & 1) << 4), w1 = (q[l] >> 4) | (((qh[l] >> (2 * j + 1)) & 1) << 4);
+                s0 += w0 * a[l]; s1 += w1 * a[l + 32]; }
+            isum += sc0 * s0 + sc1 * s1; msum += m0 * (y[i].bsums[4 * j] + y[i].bsums[4 * j + 1]) + m1 * (y[i].bsums[4 * j + 2] + y[i].bsums[4 * j + 3]); q += 32; a += 64; }
+        sumf = fmaf(h2f(x[i].d) * y[i].d, (float)isum, sumf); sumf = fmaf(-(h2f(x[i].dmin) * y[i].d), (float)msum, sumf); } return sumf; }
+static float vec_dot_q6_K_q8_K(int64_t n, const blk_q6_K *x, const blk_q8_K *y) { float sumf = 0;
+    for (int64_t i = 0; i < n / QK_K; i++) { int isum = 0; const uint8_t *ql = x[i].ql, *qh = x[i].qh; const int8_t *sc = x[i].scales, *a = y[i].qs;
+        for (int nn = 0; nn < 2; nn++) { int s[8] = {0};
+            for (int l = 0; l < 32; l++) { int is = l / 16;
+                int q1 = (int)((ql[l] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32, q2 = (int)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                int q3 = (int)((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32, q4 = (int)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+                s[is] += q1 * a[l]; s[is + 2] += q2 * a[l + 32]; s[is + 4] += q3 * a[l + 64]; s[is + 6] += q4 * a[l + 96]; }
+            for (int k = 0; k < 8; k++) isum += sc[k] * s[k];
+            ql += 64; qh += 32; sc += 8; a += 128; }
+        sumf = fmaf(h2f(x[i].d) * y[i].d, (float)isum, sumf); } return sumf; }
+static float vec_dot_f16(int64_t n, const f16_t *x, const f16_t *y) { float s = 0; for (int64_t i = 0; i < n; i++) s = fmaf(h2f(x[i]), h2f(y[i]), s); return s; }
+static float vec_dot_f32(int64_t n, const float *x, const float *y) { float s = 0; for (int64_t i = 0; i < n; i++) s = fmaf(x[i], y[i], s); return s; }
+
+ORC_API float orc_vec_dot(int wtype, int64_t n, const void *w, const void *a) {
+    switch (wtype) {
+    case T_Q4_0: return vec_dot_q4_0_q8_0(n, w, a); case T_Q4_1: return vec_dot_q4_1_q8_1(n, w, a);
+    case T_Q5_0: return vec_dot_q5_0_q8_0(n, w, a); case T_Q5_1: return vec_dot_q5_1_q8_1(n, w, a);
+    case T_Q8_0: return vec_dot_q8_0_q8_0(n, w, a); case T_Q4_K: return vec_dot_q4_K_q8_K(n, w, a);
+    case T_Q5_K: return vec_dot_q5_K_q8_K(n, w, a); case T_Q6_K: return vec_dot_q6_K_q8_K(n, w, a);
+    case T_F16: return vec_dot_f16(n, w, a); case T_F32: return vec_dot_f32(n, w, a);
+    default: return NAN; }
+}
+
+/* ggml_mul_mat(W[type; n_in x n_out rows], X[f32; N rows of n_in]) -> Y[N][n_out] (+ optional bias per output) */
+ORC_API int orc_mul_mat(int wtype, const void *W, int64_t n_in, int64_t n_out, const float *X, int64_t N, float *Y) {
+    const int qt = orc_vec_dot_type(wtype);
+    if (qt < 0) return -1;
+    const int64_t arow = qt == T_F32 ? n_in * 4 : qt == T_F16 ? n_in * 2 : row_bytes(qt, n_in);
+    const int64_t wrow = row_bytes(wtype, n_in);
+    uint8_t *aq = malloc((size_t)(arow * N));
+    for (int64_t t = 0; t < N; t++) orc_quantize_row(qt, X + t * n_in, aq + t * arow, n_in);
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n_out; r++) {
+        const uint8_t *wr = (const uint8_t *)W + r * wrow;
+        for (int64_t t = 0; t < N; t++) Y[t * n_out + r] = orc_vec_dot(wtype, n_in, wr, aq + t * arow);
+    }
+    free(aq);
+    return 0;
+}
+
+/* ============================================================================================
+ * LLaMA forward (llama_eval_internal @ master-31cfbb1)
+ * ========================================================================================== */
+typedef struct { int type; const void *data; } wt;
+typedef struct { wt attn_norm, wq, wk, wv, wo, ffn_norm, w1, w2, w3; } llayer;
+typedef struct orc_llama {
+    int n_vocab, n_embd, n_head, n_layer, n_ff, n_ctx, hd;
+    wt tok, norm, output;
+    llayer *layers;
+    f16_t *kc, *vc; /* k: [layer][n_ctx][n_embd]; v: [layer][n_embd][n_ctx] (transposed, as ggml stores it) */
+} orc_llama;
+
+ORC_API orc_llama *orc_llama_new(int n_vocab, int n_embd, int n_head, int n_layer, int n_ff, int n_ctx) {
+    init_tables();
+    orc_llama *m = calloc(1, sizeof(*m));
+    m->n_vocab = n_vocab; m->n_embd = n_embd; m->n_head = n_head; m->n_layer = n_layer; m->n_ff = n_ff; m->n_ctx = n_ctx; m->hd = n_embd / n_head;
+    m->layers = calloc((size_t)n_layer, sizeof(llayer));
+    m->kc = calloc((size_t)n_layer * n_ctx * n_embd, 2);
+    m->vc = calloc((size_t)n_layer * n_ctx * n_embd, 2);
+    return m;
+}
+ORC_API void orc_llama_free(orc_llama *m) { if (!m) return; free(m->layers); free(m->kc); free(m->vc); free(m); }
+ORC_API int orc_llama_set_tensor(orc_llama *m, const char *name, int type, const void *data) {
+    wt w = {type, data};
+    if (!strcmp(name, "tok_embeddings.weight")) { m->tok = w; return 0; }
+    if (!strcmp(name, "norm.weight")) { m->norm = w; return 0; }
+    if (!strcmp(name, "output.weight")) { m->output = w; return 0; }
+    int il; char rest[96];
+    if (sscanf(name, "layers.%d.%95s", &il, rest) == 2 && il >= 0 && il < m->n_layer) {
+        llayer *L = &m->layers[il];
+        if (!strcmp(rest, "attention_norm.weight")) L->attn_norm = w; else if (!strcmp(rest, "attention.wq.weight")) L->wq = w;
+        else if (!strcmp(rest, "attention.wk.weight")) L->wk = w; else if (!strcmp(rest, "attention.wv.weight")) L->wv = w;
+        else if (!strcmp(rest, "attention.wo.weight")) L->wo = w; else if (!strcmp(rest, "ffn_norm.weight")) L->ffn_norm = w;
+        else if (!strcmp(rest, "feed_forward.w1.weight")) L->w1 = w; else if (!strcmp(rest, "feed_forward.w2.weight")) L->w2 = w;
+        else if (!strcmp(rest, "feed_forward.w3.weight")) L->w3 = w; else return -1;
+        return 0;
+    }
+    return -1;
+}
+
+static void rms_norm_mul(const float *x, const float *w, float *y, int n) {
+    double sum = 0.0; for (int i = 0; i < n; i++) sum += (double)(x[i] * x[i]);
+    const float mean = (float)(sum / n); const float scale = 1.0f / sqrtf(mean + RMS_EPS);
+    for (int i = 0; i < n; i++) y[i] = (x[i] * scale) * w[i];
+}
+/* ggml_rope mode 0: interleaved pairs, theta advanced multiplicatively in fp32 */
+static void rope_row(float *x, int n_head, int hd, int pos) {
+    const float theta_scale = powf(10000.0f, -2.0f / hd);
+    for (int h = 0; h < n_head; h++) { float theta = (float)pos; float *p = x + h * hd;
+        for (int i = 0; i < hd; i += 2) { const float c = cosf(theta), s = sinf(theta); theta *= theta_scale;
+            const float x0 = p[i], x1 = p[i + 1]; p[i] = x0 * c - x1 * s; p[i + 1] = x0 * s + x1 * c; } }
+}
+ORC_API void orc_rope_table(int hd, int n_pos, float *cos_out, float *sin_out) { /* [n_pos][hd/2] */
+    const float theta_scale = powf(10000.0f, -2.0f / hd);
+    for (int p = 0; p < n_pos; p++) { float theta = (float)p; for (int i = 0; i < hd / 2; i++) { cos_out[p * (hd / 2) + i] = cosf(theta); sin_out[p * (hd / 2) + i] = sinf(theta); theta *= theta_scale; } }
+}
+static void soft_max_row(float *p, int n) { /* ggml_compute_forward_soft_max_f32 */
+    float mx = -INFINITY; for (int i = 0; i < n; i++) if (p[i] > mx) mx = p[i];
+    double sum = 0.0;
+    for (int i = 0; i < n; i++) { if (p[i] == -INFINITY) p[i] = 0.0f; else { const float v = exp_t(p[i] - mx); sum += (double)v; p[i] = v; } }
+    const float inv = (float)(1.0 / sum); for (int i = 0; i < n; i++) p[i] *= inv;
+}
+
+/* tokens != NULL: ids; else embd [N][n_embd].  logits_out: n_vocab floats of the LAST token.
+ * all_logits (optional): [N][n_vocab].  hidden_out (optional): final normed hidden of every token [N][n_embd]. */
+ORC_API int orc_llama_eval(orc_llama *m, const int *tokens, const float *embd, int N, int n_past, float *logits_out, float *all_logits) {
+    const int E = m->n_embd, H = m->n_head, hd = m->hd, F = m->n_ff, C = m->n_ctx;
+    if (n_past + N > C) return 1;
+    float *inpL = malloc(sizeof(float) * (size_t)N * E), *cur = malloc(sizeof(float) * (size_t)N * E), *q = malloc(sizeof(float) * (size_t)N * E);
+    float *k = malloc(sizeof(float) * (size_t)N * E), *v = malloc(sizeof(float) * (size_t)N * E), *att = malloc(sizeof(float) * (size_t)N * E);
+    float *h1 = malloc(sizeof(float) * (size_t)N * F), *h3 = malloc(sizeof(float) * (size_t)N * F), *tmp = malloc(sizeof(float) * (size_t)N * E);
+    if (tokens) { const int64_t rb = row_bytes(m->tok.type, E); for (int t = 0; t < N; t++) orc_dequantize_row(m->tok.type, (const uint8_t *)m->tok.data + (int64_t)tokens[t] * rb, inpL + (size_t)t * E, E); }
+    else memcpy(inpL, embd, sizeof(float) * (size_t)N * E);
+    const float kq_scale = 1.0f / sqrtf((float)hd);
+    const int T = n_past + N;
+    for (int il = 0; il < m->n_layer; il++) {
+        llayer *L = &m->layers[il];
+        f16_t *kc = m->kc + (size_t)il * C * E, *vc = m->vc + (size_t)il * C * E;
+        for (int t = 0; t < N; t++) rms_norm_mul(inpL + (size_t)t * E, L->attn_norm.data, cur + (size_t)t * E, E);
+        orc_mul_mat(L->wq.type, L->wq.data, E, E, cur, N, q);
+        orc_mul_mat(L->wk.type, L->wk.data, E, E, cur, N, k);
+        orc_mul_mat(L->wv.type, L->wv.data, E, E, cur, N, v);
+        for (int t = 0; t < N; t++) { rope_row(q + (size_t)t * E, H, hd, n_past + t); rope_row(k + (size_t)t * E, H, hd, n_past + t);
+            for (int i = 0; i < E; i++) { kc[(size_t)(n_past + t) * E + i] = f2h(k[(size_t)t * E + i]); vc[(size_t)i * C + n_past + t] = f2h(v[(size_t)t * E + i]); } }
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int h = 0; h < H; h++) for (int t = 0; t < N; t++) {
+            float *sc = malloc(sizeof(float) * (size_t)T); f16_t qh[256]; f16_t *ph = malloc(sizeof(f16_t) * (size_t)T);
+            for (int i = 0; i < hd; i++) qh[i] = f2h(q[(size_t)t * E + h * hd + i]);
+            const int lim = n_past + t; /* causal: keys 0..n_past+t */
+            for (int j = 0; j < T; j++) { if (j > lim) { sc[j] = -INFINITY; continue; } sc[j] = vec_dot_f16(hd, kc + (size_t)j * E + h * hd, qh) * kq_scale; }
+            soft_max_row(sc, T);
+            for (int j = 0; j < T; j++) ph[j] = f2h(sc[j]);
+            for (int i = 0; i < hd; i++) att[(size_t)t * E + h * hd + i] = vec_dot_f16(T, vc + (size_t)(h * hd + i) * C, ph);
+            free(sc); free(ph);
+        }
+        orc_mul_mat(L->wo.type, L->wo.data, E, E, att, N, tmp);
+        for (size_t i = 0; i < (size_t)N * E; i++) inpL[i] = tmp[i] + inpL[i]; /* inpFF */
+        for (int t = 0; t < N; t++) rms_norm_mul(inpL + (size_t)t * E, L->ffn_norm.data, cur + (size_t)t * E, E);
+        orc_mul_mat(L->w1.type, L->w1.data, E, F, cur, N, h1);
+        orc_mul_mat(L->w3.type, L->w3.data, E, F, cur, N, h3);
+        for (size_t i = 0; i < (size_t)N * F; i++) h1[i] = silu_t(h1[i]) * h3[i];
+        orc_mul_mat(L->w2.type, L->w2.data, F, E, h1, N, tmp);
+        for (size_t i = 0; i < (size_t)N * E; i++) inpL[i] = tmp[i] + inpL[i];
+    }
+    for (int t = 0; t < N; t++) rms_norm_mul(inpL + (size_t)t * E, m->norm.data, cur + (size_t)t * E, E);
+    if (all_logits) orc_mul_mat(m->output.type, m->output.data, E, m->n_vocab, cur, N, all_logits);
+    if (logits_out) { if (all_logits) memcpy(logits_out, all_logits + (size_t)(N - 1) * m->n_vocab, sizeof(float) * (size_t)m->n_vocab);
+        else orc_mul_mat(m->output.type, m->output.data, E, m->n_vocab, cur + (size_t)(N - 1) * E, 1, logits_out); }
+    free(inpL); free(cur); free(q); free(k); free(v); free(att); free(h1); free(h3); free(tmp);
+    return 0;
+}
+
+/* ============================================================================================
+ * Vision tower + Q-Former + projection (MiniGPT4::encode_image, minigpt4.cpp:2094-2363)
+ * ========================================================================================== */
+typedef struct { wt w, b; } lin;
+typedef struct { lin norm1, qkv, proj, norm2, fc1, fc2; const float *q_bias, *v_bias; } vblock;
+typedef struct { lin q, k, v, dense, ln; } battn;
+typedef struct { battn self, cross; int has_cross; lin inter, out, out_ln; } qlayer;
+typedef struct orc_vision {
+    int D, depth, M, n_pos, heads, q_layers, q_inter, n_q, n_out;
+    const float *cls, *pos; lin patch; vblock *blocks; lin ln_vision; const float *query_tokens; lin q_emb_ln; qlayer *ql; lin proj;
+} orc_vision;
+
+ORC_API orc_vision *orc_vision_new(int D, int depth, int M, int q_layers, int q_inter, int n_q, int n_out) {
+    init_tables();
+    orc_vision *v = calloc(1, sizeof(*v));
+    v->D = D; v->depth = depth; v->M = M; v->n_pos = 257; v->heads = D / 88; v->q_layers = q_layers; v->q_inter = q_inter; v->n_q = n_q; v->n_out = n_out;
+    v->blocks = calloc((size_t)depth, sizeof(vblock)); v->ql = calloc((size_t)q_layers, sizeof(qlayer));
+    return v;
+}
+ORC_API void orc_vision_free(orc_vision *v) { if (!v) return; free(v->blocks); free(v->ql); free(v); }
+static int set_lin(lin *l, const char *suffix, wt w) { if (!strcmp(suffix, "weight")) l->w = w; else if (!strcmp(suffix, "bias")) l->b = w; else return -1; return 0; }
+/* model = "visual_encoder" | "ln_vision" | "query_tokens" | "Qformer" | "llama_proj" */
+ORC_API int orc_vision_set_tensor(orc_vision *v, const char *model, const char *name, int type, const void *data) {
+    wt w = {type, data}; int i; char rest[128];
+    if (!strcmp(model, "visual_encoder")) {
+        if (!strcmp(name, "cls_token")) { v->cls = data; return 0; } if (!strcmp(name, "pos_embed")) { v->pos = data; return 0; }
+        if (!strncmp(name, "patch_embed.proj.", 17)) return set_lin(&v->patch, name + 17, w);
+        if (sscanf(name, "blocks.%d.%127s", &i, rest) == 2 && i >= 0 && i < v->depth) { vblock *b = &v->blocks[i];
+            if (!strncmp(rest, "norm1.", 6)) return set_lin(&b->norm1, rest + 6, w); if (!strncmp(rest, "norm2.", 6)) return set_lin(&b->norm2, rest + 6, w);
+            if (!strcmp(rest, "attn.q_bias")) { b->q_bias = data; return 0; } if (!strcmp(rest, "attn.v_bias")) { b->v_bias = data; return 0; }
+            if (!strncmp(rest, "attn.qkv.", 9)) return set_lin(&b->qkv, rest + 9, w); if (!strncmp(rest, "attn.proj.", 10)) return set_lin(&b->proj, rest + 10, w);
+            if (!strncmp(rest, "mlp.fc1.", 8)) return set_lin(&b->fc1, rest + 8, w); if (!strncmp(rest, "mlp.fc2.", 8)) return set_lin(&b->fc2, rest + 8, w); }
+        return 1; /* extra tensors are stored but ignored by the reference */
+    }
+    if (!strcmp(model, "ln_vision")) return set_lin(&v->ln_vision, name, w);
+    if (!strcmp(model, "query_tokens")) { v->query_tokens = data; return 0; }
+    if (!strcmp(model, "llama_proj")) return set_lin(&v->proj, name, w);
+    if (!strcmp(model, "Qformer")) {
+        if (!strncmp(name, "bert.embeddings.LayerNorm.", 26)) return set_lin(&v->q_emb_ln, name + 26, w);
+        if (sscanf(name, "bert.encoder.layer.%d.%127s", &i, rest) == 2 && i >= 0 && i < v->q_layers) { qlayer *L = &v->ql[i]; battn *a = NULL; const char *r = rest;
+            if (!strncmp(r, "attention.", 10)) { a = &L->self; r += 10; } else if (!strncmp(r, "crossattention.", 15)) { a = &L->cross; L->has_cross = 1; r += 15; }
+            if (a) { if (!strncmp(r, "self.query.", 11)) return set_lin(&a->q, r + 11, w); if (!strncmp(r, "self.key.", 9)) return set_lin(&a->k, r + 9, w);
+                if (!strncmp(r, "self.value.", 11)) return set_lin(&a->v, r + 11, w); if (!strncmp(r, "output.dense.", 13)) return set_lin(&a->dense, r + 13, w);
+                if (!strncmp(r, "output.LayerNorm.", 17)) return set_lin(&a->ln, r + 17, w); return 1; }
+            if (!strncmp(r, "intermediate_query.dense.", 25)) return set_lin(&L->inter, r + 25, w);
+            if (!strncmp(r, "output_query.dense.", 19)) return set_lin(&L->out, r + 19, w);
+            if (!strncmp(r, "output_query.LayerNorm.", 23)) return set_lin(&L->out_ln, r + 23, w); }
+        return 1;
+    }
+    return -1;
+}
+
+/* NNLayerNorm (minigpt4.cpp:1077-1091): ggml_norm then w*x + b */
+static void layer_norm(const float *x, const lin *l, float *y, int n, int rows) {
+    const float *w = l->w.data, *b = l->b.data;
+    for (int r = 0; r < rows; r++) { const float *xr = x + (size_t)r * n; float *yr = y + (size_t)r * n;
+        double sum = 0.0; for (int i = 0; i < n; i++) sum += (double)xr[i]; const float mean = (float)(sum / n);
+        double sum2 = 0.0; for (int i = 0; i < n; i++) { const float vv = xr[i] - mean; yr[i] = vv; sum2 += (double)(vv * vv); }
+        const float variance = (float)(sum2 / n); const float scale = 1.0f / sqrtf(variance + LN_EPS);
+        for (int i = 0; i < n; i++) { yr[i] *= scale; yr[i] = w[i] * yr[i] + (b ? b[i] : 0.0f); } }
+}
+/* NNLinear (minigpt4.cpp:1020-1030): mul_mat + repeat(bias) add.  bias may be NULL; bias_override replaces it. */
+static void linear(const lin *l, int n_in, int n_out, const float *x, int rows, float *y, const float *bias_override) {
+    orc_mul_mat(l->w.type, l->w.data, n_in, n_out, x, rows, y);
+    const float *b = bias_override ? bias_override : (const float *)l->b.data;
+    if (b) for (int r = 0; r < rows; r++) for (int i = 0; i < n_out; i++) y[(size_t)r * n_out + i] = b[i] + y[(size_t)r * n_out + i];
+}
+/* f32 x f32 attention core shared by ViT (scale q first) and BERT (divide scores): q [nq][stride], k/v [nk][stride] */
+static void attention_f32(const float *q, const float *k, const float *v, int nq, int nk, int heads, int hd, int qs, int ks, float q_prescale, float score_div, float *out, int os) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int h = 0; h < heads; h++) for (int t = 0; t < nq; t++) {
+        float *sc = malloc(sizeof(float) * (size_t)nk); float qv[256];
+        for (int i = 0; i < hd; i++) { qv[i] = q[(size_t)t * qs + h * hd + i]; if (q_prescale != 0.0f) qv[i] *= q_prescale; }
+        for (int j = 0; j < nk; j++) { float s = vec_dot_f32(hd, k + (size_t)j * ks + h * hd, qv); if (score_div != 0.0f) s = s / score_div; sc[j] = s; }
+        soft_max_row(sc, nk);
+        for (int i = 0; i < hd; i++) { float s = 0; for (int j = 0; j < nk; j++) s = fmaf(v[(size_t)j * ks + h * hd + i], sc[j], s); out[(size_t)t * os + h * hd + i] = s; }
+        free(sc);
+    }
+}
+static void bert_attention(const battn *a, const float *hidden, int nq, int Hd, const float *enc, int nk, int Kd, float *out) {
+    /* NNSelfAttention::forward (minigpt4.cpp:1112-1242); masks are all-zero */
+    const float *kv_src = enc ? enc : hidden; const int kv_n = enc ? nk : nq, kv_d = enc ? Kd : Hd;
+    float *K = malloc(sizeof(float) * (size_t)kv_n * Hd), *V = malloc(sizeof(float) * (size_t)kv_n * Hd), *Qm = malloc(sizeof(float) * (size_t)nq * Hd), *ctx = malloc(sizeof(float) * (size_t)nq * Hd), *d = malloc(sizeof(float) * (size_t)nq * Hd);
+    linear(&a->k, kv_d, Hd, kv_src, kv_n, K, NULL); linear(&a->v, kv_d, Hd, kv_src, kv_n, V, NULL); linear(&a->q, Hd, Hd, hidden, nq, Qm, NULL);
+    attention_f32(Qm, K, V, nq, kv_n, 12, 64, Hd, Hd, 0.0f, sqrtf(64.0f), ctx, Hd);
+    linear(&a->dense, Hd, Hd, ctx, nq, d, NULL);
+    for (size_t i = 0; i < (size_t)nq * Hd; i++) d[i] = d[i] + hidden[i];
+    layer_norm(d, &a->ln, out, Hd, nq);
+    free(K); free(V); free(Qm); free(ctx); free(d);
+}
+
+/* image: CHW float32 [3][224][224]; out: [n_q][n_out].  stage_out (optional, debugging/parity):
+ *   which=1 -> embeddings after pos add [257][D]; 2 -> image_embeds after ln_vision [257][D]; 3 -> q-former last hidden [n_q][768] */
+ORC_API int orc_vision_encode(orc_vision *m, const float *image, float *out, int which, float *stage_out) {
+    const int D = m->D, P = 256, NP = m->n_pos, M = m->M;
+    /* patch embed: conv 14x14/14 as f16 im2col GEMM (ggml_conv_2d_sk_p0), + bias */
+    float *patches = malloc(sizeof(float) * (size_t)P * 588), *pe = malloc(sizeof(float) * (size_t)P * D);
+    for (int oh = 0; oh < 16; oh++) for (int ow = 0; ow < 16; ow++) for (int c = 0; c < 3; c++) for (int kh = 0; kh < 14; kh++) for (int kw = 0; kw < 14; kw++)
+        patches[(size_t)(oh * 16 + ow) * 588 + c * 196 + kh * 14 + kw] = image[(size_t)c * 224 * 224 + (size_t)(oh * 14 + kh) * 224 + ow * 14 + kw];
+    linear(&m->patch, 588, D, patches, P, pe, NULL);
+    float *x = malloc(sizeof(float) * (size_t)NP * D), *cur = malloc(sizeof(float) * (size_t)NP * D), *qkv = malloc(sizeof(float) * (size_t)NP * 3 * D);
+    float *att = malloc(sizeof(float) * (size_t)NP * D), *t1 = malloc(sizeof(float) * (size_t)NP * D), *hm = malloc(sizeof(float) * (size_t)NP * M), *qb = malloc(sizeof(float) * 3 * (size_t)D);
+    for (int i = 0; i < D; i++) x[i] = 0.0f + m->cls[i];
+    for (int p = 0; p < P; p++) for (int i = 0; i < D; i++) x[(size_t)(p + 1) * D + i] = 0.0f + pe[(size_t)p * D + i];
+    for (size_t i = 0; i < (size_t)NP * D; i++) x[i] = x[i] + m->pos[i];
+    if (which == 1 && stage_out) memcpy(stage_out, x, sizeof(float) * (size_t)NP * D);
+    const float scale = 1.0f / sqrtf(88.0f);
+    for (int b = 0; b < m->depth; b++) { vblock *B = &m->blocks[b];
+        layer_norm(x, &B->norm1, cur, D, NP);
+        for (int i = 0; i < D; i++) { qb[i] = 0.0f + B->q_bias[i]; qb[D + i] = 0.0f; qb[2 * D + i] = 0.0f + B->v_bias[i]; }
+        linear(&B->qkv, D, 3 * D, cur, NP, qkv, qb);
+        attention_f32(qkv, qkv + D, qkv + 2 * D, NP, NP, m->heads, 88, 3 * D, 3 * D, scale, 0.0f, att, D);
+        linear(&B->proj, D, D, att, NP, t1, NULL);
+        for (size_t i = 0; i < (size_t)NP * D; i++) x[i] = x[i] + t1[i];
+        layer_norm(x, &B->norm2, cur, D, NP);
+        linear(&B->fc1, D, M, cur, NP, hm, NULL);
+        for (size_t i = 0; i < (size_t)NP * M; i++) hm[i] = gelu_t(hm[i]);
+        linear(&B->fc2, M, D, hm, NP, t1, NULL);
+        for (size_t i = 0; i < (size_t)NP * D; i++) x[i] = x[i] + t1[i];
+    }
+    float *img = malloc(sizeof(float) * (size_t)NP * D);
+    layer_norm(x, &m->ln_vision, img, D, NP);
+    if (which == 2 && stage_out) memcpy(stage_out, img, sizeof(float) * (size_t)NP * D);
+    /* Q-Former */
+    const int Hd = 768, NQ = m->n_q, I = m->q_inter;
+    float *hs = malloc(sizeof(float) * (size_t)NQ * Hd), *a1 = malloc(sizeof(float) * (size_t)NQ * Hd), *a2 = malloc(sizeof(float) * (size_t)NQ * Hd), *im = malloc(sizeof(float) * (size_t)NQ * I), *o = malloc(sizeof(float) * (size_t)NQ * Hd);
+    layer_norm(m->query_tokens, &m->q_emb_ln, hs, Hd, NQ);
+    for (int l = 0; l < m->q_layers; l++) { qlayer *L = &m->ql[l];
+        bert_attention(&L->self, hs, NQ, Hd, NULL, 0, 0, a1);
+        const float *ao = a1;
+        if (L->has_cross) { bert_attention(&L->cross, a1, NQ, Hd, img, NP, D, a2); ao = a2; }
+        linear(&L->inter, Hd, I, ao, NQ, im, NULL);
+        for (size_t i = 0; i < (size_t)NQ * I; i++) im[i] = gelu_t(im[i]);
+        linear(&L->out, I, Hd, im, NQ, o, NULL);
+        for (size_t i = 0; i < (size_t)NQ * Hd; i++) o[i] = o[i] + ao[i];
+        layer_norm(o, &L->out_ln, hs, Hd, NQ);
+    }
+    if (which == 3 && stage_out) memcpy(stage_out, hs, sizeof(float) * (size_t)NQ * Hd);
+    linear(&m->proj, Hd, m->n_out, hs, NQ, out, NULL);
+    free(patches); free(pe); free(x); free(cur); free(qkv); free(att); free(t1); free(hm); free(qb); free(img); free(hs); free(a1); free(a2); free(im); free(o);
+    return 0;
+}
+
+ORC_API int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+ORC_API void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
