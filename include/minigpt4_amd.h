@@ -1,0 +1,78 @@
+/*
+ * minigpt4_amd.h -- ADDITIVE entry points of the MI355X build of libminigpt4.so.
+ *
+ * Nothing here changes the reference ABI (include/minigpt4.h).  These symbols exist for
+ *   (1) measurement: device-resident decode loops timed with hipEvents, per-kernel-class timing, image-encode time;
+ *   (2) parity tests through the C-ABI: token-level eval / logits, single kernels (mat-mul, activation quantisation);
+ *   (3) host logic that needs no GPU: file parsing, tokenizer, sampler (run by the CPU-only test tier);
+ *   (4) batched / multi-GPU use: the already-declared-but-unused MiniGPT4Images / MiniGPT4Embeddings carriers
+ *       (reference minigpt4.h:80-90) and access to the weight arenas for a load-time RCCL broadcast.
+ * Plain C types only (pointers + sizes); no torch / HIP types cross this boundary.
+ */
+#pragma once
+#include "minigpt4.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- environment ------------------------------------------------------------------------------------------------ */
+MINIGPT4_API int minigpt4_amd_device_count(void);                      /* 0 when no HIP device is usable */
+MINIGPT4_API const char *minigpt4_amd_last_error(void);                /* thread-local text of the last failure */
+MINIGPT4_API const char *minigpt4_amd_build_info(void);                /* "gfx950 ..." */
+
+/* ---- language path, token level (parity tests; mirrors MiniGPT4::add_tokens / add_embedding / llama_get_logits) -- */
+MINIGPT4_API int minigpt4_amd_n_vocab(struct MiniGPT4Context *ctx);
+MINIGPT4_API int minigpt4_amd_n_embd(struct MiniGPT4Context *ctx);
+MINIGPT4_API int minigpt4_amd_n_past(struct MiniGPT4Context *ctx);
+MINIGPT4_API int minigpt4_amd_eval_tokens(struct MiniGPT4Context *ctx, const int32_t *tokens, int n);    /* 0 / 8 */
+MINIGPT4_API int minigpt4_amd_eval_embd(struct MiniGPT4Context *ctx, const float *embd, int n_rows);      /* 0 / 10 */
+MINIGPT4_API int minigpt4_amd_get_logits(struct MiniGPT4Context *ctx, float *out, size_t n);              /* last token's logits */
+MINIGPT4_API int minigpt4_amd_tokenize(struct MiniGPT4Context *ctx, const char *text, int add_bos, int32_t *out, int cap); /* returns count */
+MINIGPT4_API int minigpt4_amd_sample(struct MiniGPT4Context *ctx, int32_t *token_id, float temp, int32_t top_k, float top_p, float tfs_z, float typical_p,
+                                     int mirostat, float mirostat_tau, float mirostat_eta);                 /* samples, does NOT eval */
+
+/* ---- measurement ---------------------------------------------------------------------------------------------------- */
+/* `steps` greedy decode steps fed back on the device (no host round trip between steps); hipEvent time of steps 1..steps-1. */
+MINIGPT4_API int minigpt4_amd_decode_loop(struct MiniGPT4Context *ctx, int steps, int32_t *tokens_out, float *ms_total);
+/* hipEvent-bracketed timing of every quantised mat-vec launch over `steps` eager decode steps.
+ * out_ms / out_bytes / out_launches are indexed by ggml type id (length 20); other_ms = everything else in the steps. */
+MINIGPT4_API int minigpt4_amd_profile_decode(struct MiniGPT4Context *ctx, int steps, double *out_ms, double *out_bytes, long *out_launches, double *other_ms);
+MINIGPT4_API double minigpt4_amd_weight_bytes_per_token(struct MiniGPT4Context *ctx);
+MINIGPT4_API float minigpt4_amd_last_encode_ms(struct MiniGPT4Context *ctx);     /* hipEvent time of the last minigpt4_encode_image */
+MINIGPT4_API int minigpt4_amd_sync(struct MiniGPT4Context *ctx);
+
+/* ---- batched image encode (data-parallel requests; carriers from reference minigpt4.h:80-90) --------------------- */
+/* Encodes images->n_images images; allocates embeddings->embeddings[i].data like minigpt4_encode_image does. */
+MINIGPT4_API int minigpt4_encode_images(struct MiniGPT4Context *ctx, IN const struct MiniGPT4Images *images, OUT struct MiniGPT4Embeddings *embeddings, size_t n_threads);
+MINIGPT4_API int minigpt4_free_embeddings(struct MiniGPT4Embeddings *embeddings);
+
+/* ---- weight arenas (load-time broadcast rank0 -> others over RCCL) ---------------------------- */
+/* which: 0 = LLM arena, 1 = vision arena.  Returns the device pointer and size in bytes. */
+MINIGPT4_API int minigpt4_amd_weight_arena(struct MiniGPT4Context *ctx, int which, void **device_ptr, size_t *bytes);
+
+/* ---- single-kernel hooks for parity tests (need a GPU; allocate + free their own device memory) ------------------ */
+/* y[N][n_out] = W . x with ggml's quantised-activation arithmetic.  raw_w: the tensor bytes exactly as stored in a model file. */
+MINIGPT4_API int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y);
+/* Activation quantisation (optionally after rms_norm with weight w): returns Q8_K and Q8_0 images of x[N][K].
+ * q8k: int8[N*K], dk: float[N*K/256], bsums: int16[N*K/16], q80: int8[N*K], d0: float[N*K/32] (fp16-rounded). Any may be NULL. */
+MINIGPT4_API int minigpt4_amd_test_quantize(const float *x, const float *rms_w, int64_t N, int64_t K, int8_t *q8k, float *dk, int16_t *bsums, int8_t *q80, float *d0);
+/* C[M][N] = A[M][K] . W[N][K]^T on the MFMA f16 path (inputs given as fp32, rounded to fp16 on the device) + optional bias/GELU */
+MINIGPT4_API int minigpt4_amd_test_gemm_f16(const float *A, const float *W, const float *bias, int M, int N, int K, int gelu, float *C);
+
+/* ---- host-only logic (no GPU needed) -------------------------------------------------------------------------------- */
+struct MiniGPT4Vocab;
+MINIGPT4_API struct MiniGPT4Vocab *minigpt4_amd_vocab_load(const char *llm_path);            /* parses hparams + vocab of a GGJT v3 file */
+MINIGPT4_API void minigpt4_amd_vocab_free(struct MiniGPT4Vocab *v);
+MINIGPT4_API int minigpt4_amd_vocab_size(struct MiniGPT4Vocab *v);
+MINIGPT4_API const char *minigpt4_amd_vocab_piece(struct MiniGPT4Vocab *v, int id, int *len);
+MINIGPT4_API int minigpt4_amd_vocab_tokenize(struct MiniGPT4Vocab *v, const char *text, int add_bos, int32_t *out, int cap);
+/* Parses both files without touching a GPU.  Returns a MiniGPT4Error; fills counts when non-NULL. */
+MINIGPT4_API int minigpt4_amd_inspect_files(const char *vision_path, const char *llm_path, int *n_vision_tensors, int *n_llm_tensors, int64_t *llm_weight_bytes_per_token);
+/* Host sampler with an explicit seed (fresh std::mt19937 per call). */
+MINIGPT4_API int minigpt4_amd_sample_logits(const float *logits, int n_vocab, int seed, float temp, int32_t top_k, float top_p, float tfs_z, float typical_p,
+                                            int mirostat, float mirostat_tau, float mirostat_eta);
+
+#ifdef __cplusplus
+}
+#endif

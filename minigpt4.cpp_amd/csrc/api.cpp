@@ -1,0 +1,315 @@
+// extern "C" boundary of libminigpt4.so: the reference's 18 entry points (include/minigpt4.h, reference minigpt4.cpp:2524-2986)
+// plus the additive measurement / test / host-logic hooks of include/minigpt4_amd.h.
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+#include "minigpt4_amd.h"
+
+using namespace mg4;
+
+namespace {
+// Prompt constants (reference minigpt4.cpp:139, 2680, 2697, 2699, 2743, 2745)
+const char *kSystemPrompt = "Give the following image: <Img>ImageContent</Img>. You will be able to see the image once I provide it to you. Please answer my questions.###";
+constexpr size_t kEmb7B = 32 * 4096, kEmb13B = 32 * 5120;
+
+inline Engine *E_(MiniGPT4Context *c) { return reinterpret_cast<Engine *>(c); }
+bool file_exists(const char *p) { struct stat st; return p && stat(p, &st) == 0; }
+
+template <typename F> int guarded(int on_hip_error, F &&f) {
+    try { return f(); }
+    catch (const HipError &e) {
+        char buf[512]; snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d: %s", (int)e.code, hipGetErrorString(e.code), e.file, e.line, e.what);
+        set_last_error(buf); MG4_ERR("%s", buf); return on_hip_error;
+    } catch (const std::bad_alloc &) { set_last_error("out of host memory"); return on_hip_error; }
+}
+const char *kErrNames[] = {"None", "LoadModelFileHeader", "LoadModelFileVersion", "LoadModelMiniGPT4DataType", "LoadLanguageModel", "OpenImage", "ImageSize", "MmapSupport",
+                           "FailedToAddString", "LLamaProjectionEmbeddingInvalidSize", "FailedToAddEmbedding", "EosToken", "Eos", "ImageNot224_244_3", "ImageNotF32",
+                           "ImageChannelsExpectedRGB", "ImageFormatExpectedU8", "PathDoesNotExist", "DumpModelFileOpen", "OpenCVNotLinked"};
+}  // namespace
+
+namespace {
+struct DevBuf { void *p = nullptr; DevBuf(size_t n) { HIP_CHECK(hipMalloc(&p, n ? n : 1)); } ~DevBuf() { if (p) (void)hipFree(p); } template <typename T> T *as() { return static_cast<T *>(p); } };
+void alloc_act(ActQ &A, std::vector<std::unique_ptr<DevBuf>> &keep, size_t N, size_t K) {
+    auto mk = [&](size_t bytes) { keep.emplace_back(new DevBuf(bytes + 256)); return keep.back()->p; };
+    A.q8k = (int8_t *)mk(N * K); A.q80 = (int8_t *)mk(N * K); A.dk = (float *)mk(N * (K / 256 + 1) * 4); A.bsk = (int16_t *)mk(N * (K / 16 + 1) * 2);
+    A.d0 = (float *)mk(N * (K / 32 + 1) * 4); A.d1 = (float *)mk(N * (K / 32 + 1) * 4); A.s1 = (float *)mk(N * (K / 32 + 1) * 4); A.sum0 = (int *)mk(N * (K / 32 + 1) * 4);
+    A.xh = (__half *)mk(N * K * 2); A.xf = (float *)mk(N * K * 4);
+}
+}  // namespace
+
+extern "C" {
+
+// ======================================================================================================== reference ABI
+struct MiniGPT4Context *minigpt4_model_load(const char *path, const char *llm_model, int verbosity, int seed, int n_ctx, int n_batch, bool /*numa*/) {
+    g_verbosity = verbosity & 0xFF;
+    auto t0 = std::chrono::steady_clock::now();
+    if (!file_exists(path)) { MG4_ERR("%s does not exist", path ? path : "(null)"); return nullptr; }
+    if (!file_exists(llm_model)) { MG4_ERR("%s does not exist", llm_model ? llm_model : "(null)"); return nullptr; }
+    Engine *eng = new (std::nothrow) Engine();
+    if (!eng) return nullptr;
+    const int err = guarded((int)E_LoadLanguageModel, [&] { return eng->init(path, llm_model, seed, n_ctx, n_batch); });
+    if (err) { MG4_ERR("Failed to initialize MiniGPT4: %s", minigpt4_error_code_to_string(err)); delete eng; return nullptr; }
+    MG4_INFO("Load model from file took %lld ms to complete", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count());
+    return reinterpret_cast<MiniGPT4Context *>(eng);
+}
+
+int minigpt4_image_load_from_file(struct MiniGPT4Context *, const char *, struct MiniGPT4Image *, int) { return E_OpenCVNotLinked; }
+int minigpt4_preprocess_image(struct MiniGPT4Context *, const struct MiniGPT4Image *, struct MiniGPT4Image *, int) { return E_OpenCVNotLinked; }
+
+int minigpt4_encode_image(struct MiniGPT4Context *ctx, struct MiniGPT4Image *image, struct MiniGPT4Embedding *embedding, size_t /*n_threads*/) {
+    if (!ctx || !image || !embedding) return E_ImageSize;
+    if ((long long)image->width * image->height * image->channels != 224LL * 224 * 3) return E_ImageNot224_244_3;
+    if (image->format != MINIGPT4_IMAGE_FORMAT_F32) return E_ImageNotF32;
+    Engine *e = E_(ctx);
+    auto t0 = std::chrono::steady_clock::now();
+    const size_t n = (size_t)e->n_query() * e->proj_out();
+    float *out = new (std::nothrow) float[n];
+    if (!out) return E_ImageSize;
+    const int err = guarded((int)E_ImageSize, [&] { return e->encode_image(static_cast<const float *>(image->data), out); });
+    if (err) { delete[] out; return err; }
+    embedding->data = out; embedding->elements = n;
+    MG4_INFO("Encoding image took %lld ms to complete", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count());
+    return E_None;
+}
+
+int minigpt4_begin_chat_image(struct MiniGPT4Context *ctx, struct MiniGPT4Embedding *image_embedding, const char *s, size_t) {
+    if (!ctx || !image_embedding || !s) return E_FailedToAddString;
+    Engine *e = E_(ctx);
+    return guarded((int)E_FailedToAddString, [&]() -> int {
+        if (int err = e->add_string("Human: <Img>")) return err;
+        if (image_embedding->elements != kEmb13B && image_embedding->elements != kEmb7B) { MG4_ERR("LLAMA projection image embedding size not equal %zu != %zu", image_embedding->elements, kEmb13B); return E_LLamaProjectionEmbeddingInvalidSize; }
+        if (int err = e->add_embedding(image_embedding->data, 32)) return err;   // elements := 32 rows of llama_n_embd floats (minigpt4.cpp:2688-2695)
+        if (int err = e->add_string("</Img> ")) return err;
+        if (int err = e->add_string(s)) return err;
+        return e->add_string("### Assistant:");
+    });
+}
+
+int minigpt4_end_chat_image(struct MiniGPT4Context *ctx, const char **token, size_t, float temp, int32_t top_k, float top_p, float tfs_z, float typical_p, int32_t /*repeat_last_n*/,
+                            float /*repeat_penalty*/, float /*alpha_presence*/, float /*alpha_frequency*/, int mirostat, float mirostat_tau, float mirostat_eta, int /*penalize_nl*/) {
+    if (!ctx || !token) return E_None;
+    Engine *e = E_(ctx);
+    guarded(0, [&]() -> int {
+        SampleParams p; p.temp = temp; p.top_k = top_k; p.top_p = top_p; p.tfs_z = tfs_z; p.typical_p = typical_p; p.mirostat = mirostat; p.mirostat_tau = mirostat_tau; p.mirostat_eta = mirostat_eta;
+        const int id = e->sample_token(p);
+        *token = e->id_to_token(id);
+        (void)e->add_tokens({id});   // result discarded, as in the reference (minigpt4.cpp:2715)
+        return 0;
+    });
+    return E_None;
+}
+
+int minigpt4_system_prompt(struct MiniGPT4Context *ctx, size_t) {
+    if (!ctx) return E_FailedToAddString;
+    return guarded((int)E_FailedToAddString, [&] { return E_(ctx)->add_string(kSystemPrompt); });
+}
+
+int minigpt4_begin_chat(struct MiniGPT4Context *ctx, const char *s, size_t) {
+    if (!ctx || !s) return E_FailedToAddString;
+    Engine *e = E_(ctx);
+    return guarded((int)E_FailedToAddString, [&]() -> int {
+        if (int err = e->add_string("Human: ")) return err;
+        if (int err = e->add_string(s)) return err;
+        return e->add_string("### Assistant:");
+    });
+}
+
+int minigpt4_end_chat(struct MiniGPT4Context *ctx, const char **token, size_t n_threads, float temp, int32_t top_k, float top_p, float tfs_z, float typical_p, int32_t repeat_last_n,
+                      float repeat_penalty, float alpha_presence, float alpha_frequency, int mirostat, float mirostat_tau, float mirostat_eta, int penalize_nl) {
+    return minigpt4_end_chat_image(ctx, token, n_threads, temp, top_k, top_p, tfs_z, typical_p, repeat_last_n, repeat_penalty, alpha_presence, alpha_frequency, mirostat, mirostat_tau, mirostat_eta, penalize_nl);
+}
+
+int minigpt4_reset_chat(struct MiniGPT4Context *ctx) { if (ctx) E_(ctx)->reset(); return E_None; }
+int minigpt4_contains_eos_token(const char *s) { return s && strcmp(s, "##") == 0 ? E_EosToken : E_None; }
+int minigpt4_is_eos(const char *s) { if (!s) return E_None; const size_t n = strlen(s); return n >= 3 && memcmp(s + n - 3, "###", 3) == 0 ? E_Eos : E_None; }
+int minigpt4_free(struct MiniGPT4Context *ctx) { delete E_(ctx); return E_None; }
+int minigpt4_free_image(struct MiniGPT4Image *image) { if (image && image->data) { delete[] static_cast<uint8_t *>(image->data); image->data = nullptr; } return E_None; }
+int minigpt4_free_embedding(struct MiniGPT4Embedding *embedding) { if (embedding && embedding->data) { delete[] embedding->data; embedding->data = nullptr; } return E_None; }
+const char *minigpt4_error_code_to_string(int error_code) { return error_code >= 0 && error_code < 20 ? kErrNames[error_code] : ""; }
+int minigpt4_quantize_model(const char *in_path, const char *, int) { return file_exists(in_path) ? E_DumpModelFileOpen : E_PathDoesNotExist; }
+void minigpt4_set_verbosity(int verbosity) { g_verbosity = verbosity & 0xFF; }
+
+// ======================================================================================================== additive API
+int minigpt4_amd_device_count(void) { return device_count_noexcept(); }
+const char *minigpt4_amd_last_error(void) { return last_error().c_str(); }
+const char *minigpt4_amd_build_info(void) { return "minigpt4.cpp_amd: gfx950 (CDNA4) HIP kernels; v_dot4_i32_i8 fused-dequant mat-vec, MFMA f16 GEMM"; }
+int minigpt4_amd_n_vocab(struct MiniGPT4Context *ctx) { return ctx ? E_(ctx)->n_vocab() : 0; }
+int minigpt4_amd_n_embd(struct MiniGPT4Context *ctx) { return ctx ? E_(ctx)->n_embd() : 0; }
+int minigpt4_amd_n_past(struct MiniGPT4Context *ctx) { return ctx ? E_(ctx)->n_past() : 0; }
+int minigpt4_amd_eval_tokens(struct MiniGPT4Context *ctx, const int32_t *tokens, int n) {
+    if (!ctx || !tokens || n < 0) return E_FailedToAddString;
+    return guarded((int)E_FailedToAddString, [&] { return E_(ctx)->add_tokens(std::vector<int>(tokens, tokens + n)); });
+}
+int minigpt4_amd_eval_embd(struct MiniGPT4Context *ctx, const float *embd, int n_rows) {
+    if (!ctx || !embd || n_rows <= 0) return E_FailedToAddEmbedding;
+    return guarded((int)E_FailedToAddEmbedding, [&] { return E_(ctx)->add_embedding(embd, n_rows); });
+}
+int minigpt4_amd_get_logits(struct MiniGPT4Context *ctx, float *out, size_t n) {
+    if (!ctx || !out) return 1;
+    return guarded(1, [&] { const float *l = E_(ctx)->logits_host(); memcpy(out, l, std::min(n, (size_t)E_(ctx)->n_vocab()) * 4); return 0; });
+}
+int minigpt4_amd_tokenize(struct MiniGPT4Context *ctx, const char *text, int add_bos, int32_t *out, int cap) {
+    if (!ctx || !text) return -1;
+    const std::vector<int> t = E_(ctx)->tokenizer().tokenize(text, add_bos != 0);
+    for (int i = 0; i < (int)t.size() && i < cap; i++) out[i] = t[(size_t)i];
+    return (int)t.size();
+}
+int minigpt4_amd_sample(struct MiniGPT4Context *ctx, int32_t *token_id, float temp, int32_t top_k, float top_p, float tfs_z, float typical_p, int mirostat, float mirostat_tau, float mirostat_eta) {
+    if (!ctx || !token_id) return 1;
+    return guarded(1, [&] { SampleParams p; p.temp = temp; p.top_k = top_k; p.top_p = top_p; p.tfs_z = tfs_z; p.typical_p = typical_p; p.mirostat = mirostat; p.mirostat_tau = mirostat_tau; p.mirostat_eta = mirostat_eta;
+        *token_id = E_(ctx)->sample_token(p); return 0; });
+}
+int minigpt4_amd_decode_loop(struct MiniGPT4Context *ctx, int steps, int32_t *tokens_out, float *ms_total) {
+    if (!ctx) return 1;
+    return guarded(1, [&] { return E_(ctx)->decode_loop(steps, tokens_out, ms_total); });
+}
+int minigpt4_amd_profile_decode(struct MiniGPT4Context *ctx, int steps, double *out_ms, double *out_bytes, long *out_launches, double *other_ms) {
+    if (!ctx) return 1;
+    return guarded(1, [&] { ProfStat st[20], other; const int rc = E_(ctx)->profile_decode(steps, st, &other);
+        for (int i = 0; i < 20; i++) { if (out_ms) out_ms[i] = st[i].ms; if (out_bytes) out_bytes[i] = st[i].bytes; if (out_launches) out_launches[i] = st[i].launches; }
+        if (other_ms) *other_ms = other.ms; return rc; });
+}
+double minigpt4_amd_weight_bytes_per_token(struct MiniGPT4Context *ctx) { return ctx ? (double)E_(ctx)->weight_bytes_per_token() : 0.0; }
+float minigpt4_amd_last_encode_ms(struct MiniGPT4Context *ctx) { return ctx ? E_(ctx)->last_encode_ms() : 0.0f; }
+int minigpt4_amd_sync(struct MiniGPT4Context *ctx) { if (!ctx) return 1; return guarded(1, [&] { E_(ctx)->sync(); return 0; }); }
+
+int minigpt4_encode_images(struct MiniGPT4Context *ctx, const struct MiniGPT4Images *images, struct MiniGPT4Embeddings *embeddings, size_t n_threads) {
+    if (!ctx || !images || !embeddings) return E_ImageSize;
+    embeddings->embeddings = new (std::nothrow) MiniGPT4Embedding[images->n_images ? images->n_images : 1]();
+    embeddings->n_embeddings = 0;
+    if (!embeddings->embeddings) return E_ImageSize;
+    for (size_t i = 0; i < images->n_images; i++) {
+        const int err = minigpt4_encode_image(ctx, &images->images[i], &embeddings->embeddings[i], n_threads);
+        if (err) { minigpt4_free_embeddings(embeddings); return err; }
+        embeddings->n_embeddings = i + 1;
+    }
+    return E_None;
+}
+int minigpt4_free_embeddings(struct MiniGPT4Embeddings *embeddings) {
+    if (!embeddings || !embeddings->embeddings) return E_None;
+    for (size_t i = 0; i < embeddings->n_embeddings; i++) minigpt4_free_embedding(&embeddings->embeddings[i]);
+    delete[] embeddings->embeddings; embeddings->embeddings = nullptr; embeddings->n_embeddings = 0;
+    return E_None;
+}
+int minigpt4_amd_weight_arena(struct MiniGPT4Context *ctx, int which, void **device_ptr, size_t *bytes) {
+    if (!ctx || !device_ptr || !bytes) return 1;
+    Engine *e = E_(ctx);
+    *device_ptr = which == 0 ? (void *)e->llm_arena_ptr() : (void *)e->vision_arena_ptr();
+    *bytes = which == 0 ? e->llm_arena_bytes() : e->vision_arena_bytes();
+    return 0;
+}
+
+// ---- single-kernel hooks ---------------------------------------------------------------------------------------------------
+
+int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y) {
+    if (!raw_w || !x || !y || n_in <= 0 || n_out <= 0 || N <= 0 || !qweight_supported(ggml_type) || n_in % gt_block(ggml_type)) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const size_t raw_bytes = gt_nbytes(ggml_type, (size_t)(n_in * n_out));
+        QWeight W, plan;
+        const size_t need = plan_qweight(ggml_type, (int)n_out, (int)n_in, plan, nullptr);
+        DevBuf d_raw(raw_bytes), d_planes(need), d_x((size_t)(N * n_in) * 4), d_y((size_t)(N * n_out) * 4);
+        plan_qweight(ggml_type, (int)n_out, (int)n_in, W, d_planes.as<uint8_t>());
+        HIP_CHECK(hipMemcpy(d_raw.p, raw_w, raw_bytes, hipMemcpyHostToDevice));
+        if (ggml_type == GT_F16 || ggml_type == GT_F32) HIP_CHECK(hipMemcpy(d_planes.p, raw_w, raw_bytes, hipMemcpyHostToDevice)); else launch_repack(d_raw.as<uint8_t>(), W, nullptr);
+        HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)(N * n_in) * 4, hipMemcpyHostToDevice));
+        ActQ A; std::vector<std::unique_ptr<DevBuf>> keep; alloc_act(A, keep, (size_t)N, (size_t)n_in);
+        launch_rms_quant(d_x.as<float>(), nullptr, (int)N, (int)n_in, A, act_mask_for(ggml_type), nullptr);
+        launch_mul_mat(W, A, (int)N, d_y.as<float>(), (int)n_out, nullptr, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(y, d_y.p, (size_t)(N * n_out) * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+
+int minigpt4_amd_test_quantize(const float *x, const float *rms_w, int64_t N, int64_t K, int8_t *q8k, float *dk, int16_t *bsums, int8_t *q80, float *d0) {
+    if (!x || N <= 0 || K <= 0 || K % 256) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        DevBuf d_x((size_t)(N * K) * 4), d_w((size_t)K * 4);
+        HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)(N * K) * 4, hipMemcpyHostToDevice));
+        if (rms_w) HIP_CHECK(hipMemcpy(d_w.p, rms_w, (size_t)K * 4, hipMemcpyHostToDevice));
+        ActQ A; std::vector<std::unique_ptr<DevBuf>> keep; alloc_act(A, keep, (size_t)N, (size_t)K);
+        launch_rms_quant(d_x.as<float>(), rms_w ? d_w.as<float>() : nullptr, (int)N, (int)K, A, ACT_Q8K | ACT_Q80, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        if (q8k) HIP_CHECK(hipMemcpy(q8k, A.q8k, (size_t)(N * K), hipMemcpyDeviceToHost));
+        if (dk) HIP_CHECK(hipMemcpy(dk, A.dk, (size_t)(N * K / 256) * 4, hipMemcpyDeviceToHost));
+        if (bsums) HIP_CHECK(hipMemcpy(bsums, A.bsk, (size_t)(N * K / 16) * 2, hipMemcpyDeviceToHost));
+        if (q80) HIP_CHECK(hipMemcpy(q80, A.q80, (size_t)(N * K), hipMemcpyDeviceToHost));
+        if (d0) HIP_CHECK(hipMemcpy(d0, A.d0, (size_t)(N * K / 32) * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+
+int minigpt4_amd_test_gemm_f16(const float *A, const float *W, const float *bias, int M, int N, int K, int gelu, float *C) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || K % 16) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        DevBuf dA((size_t)M * K * 4), dW((size_t)N * K * 4), dAh((size_t)M * K * 2), dWh((size_t)N * K * 2), dC((size_t)M * N * 4), db((size_t)N * 4), dtab(65536 * 2);
+        HIP_CHECK(hipMemcpy(dA.p, A, (size_t)M * K * 4, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(dW.p, W, (size_t)N * K * 4, hipMemcpyHostToDevice));
+        if (bias) HIP_CHECK(hipMemcpy(db.p, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+        Tables tb;
+        if (gelu) { std::vector<__half> g(65536);
+            for (int i = 0; i < 65536; i++) { const float x = __half2float(__ushort_as_half((unsigned short)i)); g[(size_t)i] = __float2half_rn(0.5f * x * (1.0f + tanhf(0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x)))); }
+            HIP_CHECK(hipMemcpy(dtab.p, g.data(), 131072, hipMemcpyHostToDevice)); tb.gelu = dtab.as<__half>(); }
+        launch_f32_to_f16(dA.as<float>(), dAh.as<__half>(), (size_t)M * K, nullptr); launch_f32_to_f16(dW.as<float>(), dWh.as<__half>(), (size_t)N * K, nullptr);
+        launch_gemm_f16(dAh.as<__half>(), K, dWh.as<__half>(), K, M, N, K, bias ? db.as<float>() : nullptr, nullptr, gelu != 0, tb, dC.as<float>(), nullptr, N, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(C, dC.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+
+// ---- host-only logic -----------------------------------------------------------------------------------------------------------
+struct MiniGPT4Vocab { LLMFile f; Tokenizer t; };
+struct MiniGPT4Vocab *minigpt4_amd_vocab_load(const char *llm_path) {
+    if (!file_exists(llm_path)) return nullptr;
+    MiniGPT4Vocab *v = new (std::nothrow) MiniGPT4Vocab();
+    if (!v) return nullptr;
+    if (v->f.load(llm_path, true)) { delete v; return nullptr; }
+    v->t.init(v->f);
+    return v;
+}
+void minigpt4_amd_vocab_free(struct MiniGPT4Vocab *v) { delete v; }
+int minigpt4_amd_vocab_size(struct MiniGPT4Vocab *v) { return v ? (int)v->f.n_vocab : 0; }
+const char *minigpt4_amd_vocab_piece(struct MiniGPT4Vocab *v, int id, int *len) {
+    if (!v || id < 0 || id >= (int)v->f.pieces.size()) return nullptr;
+    if (len) *len = (int)v->f.pieces[(size_t)id].size();
+    return v->f.pieces[(size_t)id].c_str();
+}
+int minigpt4_amd_vocab_tokenize(struct MiniGPT4Vocab *v, const char *text, int add_bos, int32_t *out, int cap) {
+    if (!v || !text) return -1;
+    const std::vector<int> t = v->t.tokenize(text, add_bos != 0);
+    for (int i = 0; i < (int)t.size() && i < cap; i++) out[i] = t[(size_t)i];
+    return (int)t.size();
+}
+int minigpt4_amd_inspect_files(const char *vision_path, const char *llm_path, int *n_vision_tensors, int *n_llm_tensors, int64_t *llm_weight_bytes_per_token) {
+    if (vision_path) {
+        if (!file_exists(vision_path)) return E_PathDoesNotExist;
+        VisionFile vf; if (int e = vf.load(vision_path)) return e;
+        int n = 0; for (auto &m : vf.models) n += (int)m.second.size();
+        if (n_vision_tensors) *n_vision_tensors = n;
+    }
+    if (llm_path) {
+        if (!file_exists(llm_path)) return E_PathDoesNotExist;
+        LLMFile lf; if (int e = lf.load(llm_path)) return e;
+        if (n_llm_tensors) *n_llm_tensors = (int)lf.tensors.size();
+        if (llm_weight_bytes_per_token) { int64_t b = 0; for (auto &t : lf.tensors) b += t.first == "tok_embeddings.weight" ? (int64_t)gt_nbytes(t.second.type, (size_t)t.second.ne[0]) : (int64_t)t.second.nbytes; *llm_weight_bytes_per_token = b; }
+    }
+    return E_None;
+}
+int minigpt4_amd_sample_logits(const float *logits, int n_vocab, int seed, float temp, int32_t top_k, float top_p, float tfs_z, float typical_p, int mirostat, float mirostat_tau, float mirostat_eta) {
+    if (!logits || n_vocab <= 0) return -1;
+    Sampler s; s.seed(seed);
+    SampleParams p; p.temp = temp; p.top_k = top_k; p.top_p = top_p; p.tfs_z = tfs_z; p.typical_p = typical_p; p.mirostat = mirostat; p.mirostat_tau = mirostat_tau; p.mirostat_eta = mirostat_eta;
+    return s.sample(logits, n_vocab, p);
+}
+
+}  // extern "C"

@@ -1,0 +1,553 @@
+#include "engine.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace mg4 {
+
+// ====================================================================================================================
+// device helpers
+// ====================================================================================================================
+int device_count_noexcept() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+void DeviceArena::alloc(size_t bytes) {
+    release();
+    HIP_CHECK(hipMalloc((void **)&base, bytes));
+    cap = bytes; used = 0;
+}
+void DeviceArena::release() { if (base) (void)hipFree(base); base = nullptr; cap = used = 0; }
+uint8_t *DeviceArena::take(size_t bytes, size_t align) {
+    const size_t off = (used + align - 1) / align * align;
+    if (off + bytes > cap) throw HipError{hipErrorOutOfMemory, "arena overflow", __FILE__, __LINE__};
+    used = off + bytes;
+    return base + off;
+}
+template <typename T> T *Engine::upload_raw(DeviceArena &a, const void *src, size_t bytes) {
+    uint8_t *d = a.take(bytes);
+    HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+    return reinterpret_cast<T *>(d);
+}
+
+Engine::~Engine() {
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (decode_graph_) (void)hipGraphExecDestroy(decode_graph_);
+    for (auto &e : prof_events_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (stage_) (void)hipFree(stage_);
+    if (h_argmax_) (void)hipHostFree(h_argmax_);
+    if (h_logits_) (void)hipHostFree(h_logits_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+void Engine::sync() { HIP_CHECK(hipStreamSynchronize(stream_)); }
+
+// ====================================================================================================================
+// init / load
+// ====================================================================================================================
+int Engine::init(const std::string &vision_path, const std::string &llm_path, int seed, int n_ctx, int n_batch) {
+    const int ndev = device_count_noexcept();
+    if (ndev <= 0) { set_last_error("no HIP device visible: the MI355X engine has no CPU fallback"); MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
+    const char *dv = getenv("MINIGPT4_DEVICE");
+    if (!dv) dv = getenv("LOCAL_RANK");
+    device_ = dv ? atoi(dv) % ndev : 0;
+    HIP_CHECK(hipSetDevice(device_));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device_));
+    MG4_INFO("device %d: %s (%s), %d CUs, %.1f GiB", device_, prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    n_ctx_ = n_ctx > 0 ? n_ctx : 2048;
+    n_batch_ = n_batch > 0 ? n_batch : 512;
+    max_rows_ = std::max(n_batch_, 32);
+    use_graph_ = !(getenv("MINIGPT4_NO_GRAPH") && atoi(getenv("MINIGPT4_NO_GRAPH")));
+    sampler_.seed(seed);
+    auto t0 = std::chrono::steady_clock::now();
+    if (int e = load_llm(llm_path)) return e;
+    auto t1 = std::chrono::steady_clock::now();
+    MG4_INFO("LLM model init took %lld ms to complete", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count());
+    if (int e = load_vision(vision_path)) return e;
+    auto t2 = std::chrono::steady_clock::now();
+    MG4_INFO("Loading minigpt4 model took %lld ms to complete", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count());
+    alloc_buffers();
+    if (stage_) { (void)hipFree(stage_); stage_ = nullptr; stage_cap_ = 0; }
+    return E_None;
+}
+
+void Engine::upload_qweight(const TensorMeta &t, const uint8_t *file_base, QWeight &w) {
+    const int cols = (int)t.ne[0], rows = (int)t.ne[1];
+    QWeight plan;
+    const size_t need = plan_qweight(t.type, rows, cols, plan, nullptr);
+    uint8_t *base = llm_arena_.take(need);
+    plan_qweight(t.type, rows, cols, w, base);
+    if (t.type == GT_F16 || t.type == GT_F32) { HIP_CHECK(hipMemcpy(base, file_base + t.offset, t.nbytes, hipMemcpyHostToDevice)); return; }
+    if (t.nbytes > stage_cap_) throw HipError{hipErrorOutOfMemory, "staging buffer too small", __FILE__, __LINE__};
+    HIP_CHECK(hipMemcpy(stage_, file_base + t.offset, t.nbytes, hipMemcpyHostToDevice));
+    launch_repack(stage_, w, stream_);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+int Engine::load_llm(const std::string &path) {
+    if (int e = llm_.load(path)) { MG4_ERR("failed to parse %s: %s", path.c_str(), last_error().c_str()); return e; }
+    tok_.init(llm_);
+    const int E = (int)llm_.n_embd, L = (int)llm_.n_layer, V = (int)llm_.n_vocab, F = (int)llm_.n_ff();
+    const int hd = E / (int)llm_.n_head;
+    if (hd % 8 || hd > 256 || 256 % (hd / 2)) { set_last_error("unsupported head size"); return E_LoadLanguageModel; }
+    MG4_INFO("llm: n_vocab %d n_embd %d n_head %u n_layer %d n_ff %d n_ctx %d", V, E, llm_.n_head, L, F, n_ctx_);
+    auto need = [&](const std::string &name, int64_t ne0, int64_t ne1) -> const TensorMeta * {
+        const TensorMeta *t = llm_.find(name);
+        if (!t) { set_last_error("LLM file: missing tensor " + name); return nullptr; }
+        if (t->ne[0] != ne0 || (ne1 ? (t->ne.size() != 2 || t->ne[1] != ne1) : t->ne.size() != 1)) { set_last_error("LLM file: bad shape for " + name); return nullptr; }
+        if (ne1 == 0 && t->type != GT_F32) { set_last_error("LLM file: " + name + " must be f32"); return nullptr; }
+        if (ne1 && !qweight_supported(t->type)) { set_last_error(std::string("LLM file: tensor type ") + gt_name(t->type) + " of " + name + " is not supported by the gfx950 kernels"); return nullptr; }
+        return t;
+    };
+    // pass 1: validate + size the arena
+    size_t total = 0, max_raw = 0;
+    QWeight tmp;
+    std::vector<std::pair<std::string, std::pair<int64_t, int64_t>>> mats;
+    mats.push_back({"output.weight", {E, V}});
+    for (int i = 0; i < L; i++) {
+        const std::string p = "layers." + std::to_string(i) + ".";
+        for (const char *w : {"attention.wq.weight", "attention.wk.weight", "attention.wv.weight", "attention.wo.weight"}) mats.push_back({p + w, {E, E}});
+        mats.push_back({p + "feed_forward.w1.weight", {E, F}});
+        mats.push_back({p + "feed_forward.w2.weight", {F, E}});
+        mats.push_back({p + "feed_forward.w3.weight", {E, F}});
+    }
+    wbytes_token_ = 0;
+    for (auto &m : mats) {
+        const TensorMeta *t = need(m.first, m.second.first, m.second.second);
+        if (!t) { MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
+        total += plan_qweight(t->type, (int)t->ne[1], (int)t->ne[0], tmp, nullptr) + 256;
+        if (t->type != GT_F16 && t->type != GT_F32) max_raw = std::max(max_raw, t->nbytes);
+        wbytes_token_ += t->nbytes;
+    }
+    const TensorMeta *tt = llm_.find("tok_embeddings.weight");
+    if (!tt || tt->ne.size() != 2 || tt->ne[0] != E || tt->ne[1] != V || !qweight_supported(tt->type)) { set_last_error("LLM file: bad tok_embeddings.weight"); MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
+    total += tt->nbytes + 256;
+    wbytes_token_ += gt_nbytes(tt->type, (size_t)E);
+    for (int i = 0; i < L; i++) for (const char *n : {"attention_norm.weight", "ffn_norm.weight"}) if (!need("layers." + std::to_string(i) + "." + n, E, 0)) { MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
+    if (!need("norm.weight", E, 0)) { MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
+    total += (size_t)(2 * L + 1) * ((size_t)E * 4 + 256);
+    wbytes_token_ += (size_t)(2 * L + 1) * E * 4;
+    llm_arena_.alloc(total + 4096);
+    if (max_raw) { HIP_CHECK(hipMalloc((void **)&stage_, max_raw)); stage_cap_ = max_raw; }
+    // pass 2: upload + repack
+    const uint8_t *fb = llm_.mf.data;
+    upload_qweight(*llm_.find("output.weight"), fb, output_);
+    layers_.resize((size_t)L);
+    for (int i = 0; i < L; i++) {
+        const std::string p = "layers." + std::to_string(i) + ".";
+        LayerW &lw = layers_[(size_t)i];
+        upload_qweight(*llm_.find(p + "attention.wq.weight"), fb, lw.wq);
+        upload_qweight(*llm_.find(p + "attention.wk.weight"), fb, lw.wk);
+        upload_qweight(*llm_.find(p + "attention.wv.weight"), fb, lw.wv);
+        upload_qweight(*llm_.find(p + "attention.wo.weight"), fb, lw.wo);
+        upload_qweight(*llm_.find(p + "feed_forward.w1.weight"), fb, lw.w1);
+        upload_qweight(*llm_.find(p + "feed_forward.w2.weight"), fb, lw.w2);
+        upload_qweight(*llm_.find(p + "feed_forward.w3.weight"), fb, lw.w3);
+        const TensorMeta *an = llm_.find(p + "attention_norm.weight"), *fn = llm_.find(p + "ffn_norm.weight");
+        lw.attn_norm = upload_raw<float>(llm_arena_, fb + an->offset, an->nbytes);
+        lw.ffn_norm = upload_raw<float>(llm_arena_, fb + fn->offset, fn->nbytes);
+    }
+    const TensorMeta *nt = llm_.find("norm.weight");
+    norm_ = upload_raw<float>(llm_arena_, fb + nt->offset, nt->nbytes);
+    tok_raw_ = upload_raw<uint8_t>(llm_arena_, fb + tt->offset, tt->nbytes);
+    tok_type_ = tt->type;
+    MG4_INFO("llm weights: %.1f MB in HBM, %.3f GB streamed per decoded token", llm_arena_.used / 1048576.0, wbytes_token_ / 1e9);
+    return E_None;
+}
+
+int Engine::load_vision(const std::string &path) {
+    if (int e = vis_.load(path)) { MG4_ERR("failed to parse %s (%s)", path.c_str(), last_error().c_str()); return e; }
+    auto fail = [&](const std::string &msg, int code) { set_last_error("vision file: " + msg); MG4_ERR("%s", last_error().c_str()); return code; };
+    const TensorMeta *pos = vis_.find("visual_encoder", "pos_embed");
+    if (!pos || pos->ne.size() != 2 || pos->type != GT_F32) return fail("missing/bad visual_encoder.pos_embed", E_LoadModelFileHeader);
+    v_D_ = (int)pos->ne[0];
+    if (pos->ne[1] != 257 || v_D_ % 88 || v_D_ % 16) return fail("pos_embed must be [D,257] with D a multiple of 88 and 16 (head size 88 is hard-coded in the reference, minigpt4.cpp:1271)", E_LoadModelFileHeader);
+    v_heads_ = v_D_ / 88;
+    if (vis_.config_int("encoder_width", v_D_) != v_D_) return fail("config Qformer.encoder_width disagrees with pos_embed", E_LoadModelFileHeader);
+    v_depth_ = 0;
+    while (vis_.find("visual_encoder", "blocks." + std::to_string(v_depth_) + ".norm1.weight")) v_depth_++;
+    if (!v_depth_) return fail("no ViT blocks", E_LoadModelFileHeader);
+    const TensorMeta *fc1 = vis_.find("visual_encoder", "blocks.0.mlp.fc1.weight");
+    if (!fc1 || fc1->ne.size() != 2) return fail("missing blocks.0.mlp.fc1.weight", E_LoadModelFileHeader);
+    v_M_ = (int)fc1->ne[1];
+    const TensorMeta *qt = vis_.find("query_tokens", "weight");
+    if (!qt || qt->ne.size() != 2 || qt->ne[0] != 768 || qt->type != GT_F32) return fail("bad query_tokens.weight", E_LoadModelFileHeader);
+    v_nq_ = (int)qt->ne[1];
+    if (vis_.config_int("query_length", v_nq_) != v_nq_) return fail("query_embeds_length != query_length", E_LoadModelFileHeader);   // reference PANICs (minigpt4.cpp:2230)
+    v_ql_ = (int)vis_.config_int("num_hidden_layers", 12);
+    const TensorMeta *lp = vis_.find("llama_proj", "weight");
+    if (!lp || lp->ne.size() != 2 || lp->ne[0] != 768) return fail("bad llama_proj.weight", E_LoadModelFileHeader);
+    v_out_ = (int)lp->ne[1];
+    const TensorMeta *iq = vis_.find("Qformer", "bert.encoder.layer.0.intermediate_query.dense.weight");
+    if (!iq || iq->ne.size() != 2) return fail("missing intermediate_query", E_LoadModelFileHeader);
+    v_qi_ = (int)iq->ne[1];
+    if (v_M_ % 16 || v_qi_ % 16) return fail("MLP widths must be multiples of 16", E_LoadModelFileHeader);
+
+    size_t total = 0;
+    for (auto &m : vis_.models) for (auto &t : m.second) total += t.second.nbytes + 512;
+    total += (size_t)v_D_ * 592 * 2 + (size_t)v_depth_ * 3 * v_D_ * 4 + (1 << 20);
+    vis_arena_.alloc(total);
+    const uint8_t *fb = vis_.mf.data;
+    bool ok = true; std::string bad;
+    auto f32v = [&](const std::string &model, const std::string &name, int64_t n) -> float * {
+        const TensorMeta *t = vis_.find(model, name);
+        if (!t || t->type != GT_F32 || t->nelements() != n) { ok = false; bad = model + "." + name; return nullptr; }
+        return upload_raw<float>(vis_arena_, fb + t->offset, t->nbytes);
+    };
+    auto f16m = [&](const std::string &model, const std::string &name, int64_t n_in, int64_t n_out) -> const TensorMeta * {
+        const TensorMeta *t = vis_.find(model, name);
+        if (!t || t->ne.size() < 2 || t->nelements() != n_in * n_out) { ok = false; bad = model + "." + name; return nullptr; }
+        if (t->type != GT_F16) { ok = false; bad = model + "." + name + " (only f16 vision weights are supported by the gfx950 path; got " + gt_name(t->type) + ")"; return nullptr; }
+        return t;
+    };
+    auto up16 = [&](const TensorMeta *t) -> __half * { return t ? upload_raw<__half>(vis_arena_, fb + t->offset, t->nbytes) : nullptr; };
+    auto concat16 = [&](std::initializer_list<const TensorMeta *> ts) -> __half * {
+        size_t bytes = 0; for (auto t : ts) { if (!t) return nullptr; bytes += t->nbytes; }
+        uint8_t *d = vis_arena_.take(bytes); size_t off = 0;
+        for (auto t : ts) { HIP_CHECK(hipMemcpy(d + off, fb + t->offset, t->nbytes, hipMemcpyHostToDevice)); off += t->nbytes; }
+        return reinterpret_cast<__half *>(d);
+    };
+    auto concat32 = [&](std::initializer_list<std::pair<const char *, std::string>> names, int64_t each) -> float * {
+        uint8_t *d = vis_arena_.take((size_t)each * 4 * names.size()); size_t off = 0;
+        for (auto &nm : names) { const TensorMeta *t = vis_.find(nm.first, nm.second);
+            if (!t || t->type != GT_F32 || t->nelements() != each) { ok = false; bad = nm.second; return nullptr; }
+            HIP_CHECK(hipMemcpy(d + off, fb + t->offset, t->nbytes, hipMemcpyHostToDevice)); off += t->nbytes; }
+        return reinterpret_cast<float *>(d);
+    };
+    const int D = v_D_, M = v_M_;
+    const char *VE = "visual_encoder";
+    v_cls_ = f32v(VE, "cls_token", D);
+    v_pos_ = f32v(VE, "pos_embed", (int64_t)D * 257);
+    v_patch_b_ = f32v(VE, "patch_embed.proj.bias", D);
+    if (const TensorMeta *pw = f16m(VE, "patch_embed.proj.weight", 588, D)) {   // [D][588] -> zero-padded [D][592] (MFMA K multiple of 16)
+        std::vector<uint16_t> padded((size_t)D * 592, 0);
+        const uint16_t *src = reinterpret_cast<const uint16_t *>(fb + pw->offset);
+        for (int r = 0; r < D; r++) memcpy(&padded[(size_t)r * 592], src + (size_t)r * 588, 588 * 2);
+        v_patch_w_ = upload_raw<__half>(vis_arena_, padded.data(), padded.size() * 2);
+    }
+    vblocks_.resize((size_t)v_depth_);
+    for (int i = 0; i < v_depth_ && ok; i++) {
+        const std::string p = "blocks." + std::to_string(i) + ".";
+        VBlock &b = vblocks_[(size_t)i];
+        b.n1w = f32v(VE, p + "norm1.weight", D); b.n1b = f32v(VE, p + "norm1.bias", D);
+        b.n2w = f32v(VE, p + "norm2.weight", D); b.n2b = f32v(VE, p + "norm2.bias", D);
+        // qkv bias = [q_bias, 0, v_bias] (minigpt4.cpp:1259-1262)
+        const TensorMeta *qb = vis_.find(VE, p + "attn.q_bias"), *vb = vis_.find(VE, p + "attn.v_bias");
+        if (!qb || !vb || qb->type != GT_F32 || vb->type != GT_F32 || qb->nelements() != D || vb->nelements() != D) { ok = false; bad = p + "attn.q_bias/v_bias"; break; }
+        std::vector<float> bias3((size_t)3 * D, 0.0f);
+        const float *qsrc = reinterpret_cast<const float *>(fb + qb->offset), *vsrc = reinterpret_cast<const float *>(fb + vb->offset);
+        for (int j = 0; j < D; j++) { bias3[(size_t)j] = 0.0f + qsrc[j]; bias3[(size_t)2 * D + j] = 0.0f + vsrc[j]; }
+        b.qkv_b = upload_raw<float>(vis_arena_, bias3.data(), bias3.size() * 4);
+        b.qkv_w = up16(f16m(VE, p + "attn.qkv.weight", D, 3 * (int64_t)D));
+        b.proj_w = up16(f16m(VE, p + "attn.proj.weight", D, D)); b.proj_b = f32v(VE, p + "attn.proj.bias", D);
+        b.fc1_w = up16(f16m(VE, p + "mlp.fc1.weight", D, M)); b.fc1_b = f32v(VE, p + "mlp.fc1.bias", M);
+        b.fc2_w = up16(f16m(VE, p + "mlp.fc2.weight", M, D)); b.fc2_b = f32v(VE, p + "mlp.fc2.bias", D);
+    }
+    v_lnv_w_ = f32v("ln_vision", "weight", D); v_lnv_b_ = f32v("ln_vision", "bias", D);
+    v_qtok_ = f32v("query_tokens", "weight", (int64_t)768 * v_nq_);
+    const char *QF = "Qformer";
+    v_qeln_w_ = f32v(QF, "bert.embeddings.LayerNorm.weight", 768); v_qeln_b_ = f32v(QF, "bert.embeddings.LayerNorm.bias", 768);
+    qlayers_.resize((size_t)v_ql_);
+    for (int i = 0; i < v_ql_ && ok; i++) {
+        const std::string p = "bert.encoder.layer." + std::to_string(i) + ".";
+        QLayer &L = qlayers_[(size_t)i];
+        {   // self attention: Q,K,V share their input -> one [2304][768] GEMM
+            const std::string a = p + "attention.";
+            L.self.q_w = concat16({f16m(QF, a + "self.query.weight", 768, 768), f16m(QF, a + "self.key.weight", 768, 768), f16m(QF, a + "self.value.weight", 768, 768)});
+            L.self.q_b = concat32({{QF, a + "self.query.bias"}, {QF, a + "self.key.bias"}, {QF, a + "self.value.bias"}}, 768);
+            L.self.dense_w = up16(f16m(QF, a + "output.dense.weight", 768, 768)); L.self.dense_b = f32v(QF, a + "output.dense.bias", 768);
+            L.self.ln_w = f32v(QF, a + "output.LayerNorm.weight", 768); L.self.ln_b = f32v(QF, a + "output.LayerNorm.bias", 768);
+        }
+        L.has_cross = vis_.find(QF, p + "crossattention.self.query.weight") != nullptr;   // detected by name (minigpt4.cpp:2008)
+        if (L.has_cross) {
+            const std::string a = p + "crossattention.";
+            L.cross.q_w = up16(f16m(QF, a + "self.query.weight", 768, 768)); L.cross.q_b = f32v(QF, a + "self.query.bias", 768);
+            L.cross.kv_w = concat16({f16m(QF, a + "self.key.weight", D, 768), f16m(QF, a + "self.value.weight", D, 768)});
+            L.cross.kv_b = concat32({{QF, a + "self.key.bias"}, {QF, a + "self.value.bias"}}, 768);
+            L.cross.dense_w = up16(f16m(QF, a + "output.dense.weight", 768, 768)); L.cross.dense_b = f32v(QF, a + "output.dense.bias", 768);
+            L.cross.ln_w = f32v(QF, a + "output.LayerNorm.weight", 768); L.cross.ln_b = f32v(QF, a + "output.LayerNorm.bias", 768);
+        }
+        L.inter_w = up16(f16m(QF, p + "intermediate_query.dense.weight", 768, v_qi_)); L.inter_b = f32v(QF, p + "intermediate_query.dense.bias", v_qi_);
+        L.out_w = up16(f16m(QF, p + "output_query.dense.weight", v_qi_, 768)); L.out_b = f32v(QF, p + "output_query.dense.bias", 768);
+        L.oln_w = f32v(QF, p + "output_query.LayerNorm.weight", 768); L.oln_b = f32v(QF, p + "output_query.LayerNorm.bias", 768);
+    }
+    v_proj_w_ = up16(f16m("llama_proj", "weight", 768, v_out_)); v_proj_b_ = f32v("llama_proj", "bias", v_out_);
+    if (!ok) return fail("missing or unsupported tensor " + bad, bad.find("only f16") != std::string::npos ? E_LoadModelMiniGPT4DataType : E_LoadModelFileHeader);
+    MG4_INFO("vision weights: %.1f MB in HBM (ViT dim %d x %d blocks, Q-Former %d layers, proj -> %d)", vis_arena_.used / 1048576.0, v_D_, v_depth_, v_ql_, v_out_);
+    return E_None;
+}
+
+void Engine::alloc_buffers() {
+    const size_t E = llm_.n_embd, F = llm_.n_ff(), V = llm_.n_vocab, L = llm_.n_layer, B = (size_t)max_rows_, C = (size_t)n_ctx_;
+    const size_t Kmax = std::max(E, F), hd = E / llm_.n_head;
+    const size_t D = (size_t)v_D_, M = (size_t)v_M_, NQ = (size_t)v_nq_;
+    size_t total = 0;
+    auto sz = [&](size_t b) { total += (b + 255) / 256 * 256 + 256; };
+    sz(2 * L * C * E * 2); sz(2 * C * (hd / 2) * 4 * 2); sz(3 * 65536 * 2);
+    sz(5 * B * E * 4); sz(2 * B * F * 4); sz(V * 4);
+    sz(2 * B * Kmax); sz(B * Kmax / 256 * 4 + 64); sz(B * Kmax / 16 * 2 + 64); sz(4 * (B * Kmax / 32 * 4 + 64)); sz(B * Kmax * 2); sz(B * Kmax * 4);
+    sz(4096);
+    sz(3 * 224 * 224 * 4); sz(256 * 592 * 2); sz(256 * D * 4); sz(257 * D * 4); sz(257 * 3 * D * 4); sz(3 * 257 * D * 2); sz(257 * M * 2);
+    sz(8 * NQ * 2304 * 4); sz(257 * 1536 * 4); sz(NQ * (size_t)std::max(v_qi_, 768) * 2 * 4); sz(NQ * (size_t)v_out_ * 4); sz(1 << 20);
+    buf_arena_.alloc(total);
+    auto takef = [&](size_t n) { return reinterpret_cast<float *>(buf_arena_.take(n * 4)); };
+    auto takeh = [&](size_t n) { return reinterpret_cast<__half *>(buf_arena_.take(n * 2)); };
+    kc_ = takeh(L * C * E); vc_ = takeh(L * C * E);
+    HIP_CHECK(hipMemset(kc_, 0, L * C * E * 2)); HIP_CHECK(hipMemset(vc_, 0, L * C * E * 2));
+    // RoPE table, exactly ggml's iteration: theta = pos; theta *= theta_scale per pair (fp32), cosf/sinf
+    {
+        std::vector<float> c(C * (hd / 2)), s(C * (hd / 2));
+        const float theta_scale = powf(10000.0f, -2.0f / (float)hd);
+        for (size_t p = 0; p < C; p++) { float theta = (float)p; for (size_t i = 0; i < hd / 2; i++) { c[p * (hd / 2) + i] = cosf(theta); s[p * (hd / 2) + i] = sinf(theta); theta *= theta_scale; } }
+        cos_ = takef(c.size()); sin_ = takef(s.size());
+        HIP_CHECK(hipMemcpy(cos_, c.data(), c.size() * 4, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(sin_, s.data(), s.size() * 4, hipMemcpyHostToDevice));
+    }
+    // fp16 lookup tables (ggml_table_gelu_f16 / silu_f16 / exp_f16), evaluated with the host libm like ggml does at init
+    {
+        std::vector<__half> g(65536), si(65536), ex(65536);
+        for (int i = 0; i < 65536; i++) {
+            const float x = __half2float(__ushort_as_half((unsigned short)i));
+            g[(size_t)i] = __float2half_rn(0.5f * x * (1.0f + tanhf(0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x))));
+            si[(size_t)i] = __float2half_rn(x / (1.0f + expf(-x)));
+            ex[(size_t)i] = __float2half_rn(expf(x));
+        }
+        __half *dg = takeh(65536), *ds = takeh(65536), *de = takeh(65536);
+        HIP_CHECK(hipMemcpy(dg, g.data(), 131072, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(ds, si.data(), 131072, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(de, ex.data(), 131072, hipMemcpyHostToDevice));
+        tabs_.gelu = dg; tabs_.silu = ds; tabs_.exp = de;
+    }
+    x_ = takef(B * E); q_ = takef(B * E); k_ = takef(B * E); v_ = takef(B * E); att_ = takef(B * E);
+    h1_ = takef(B * F); h3_ = takef(B * F); logits_ = takef(V);
+    act_.q8k = reinterpret_cast<int8_t *>(buf_arena_.take(B * Kmax)); act_.q80 = reinterpret_cast<int8_t *>(buf_arena_.take(B * Kmax));
+    act_.dk = takef(B * Kmax / 256 + 16); act_.bsk = reinterpret_cast<int16_t *>(buf_arena_.take(B * Kmax / 16 * 2 + 64));
+    act_.d0 = takef(B * Kmax / 32 + 16); act_.d1 = takef(B * Kmax / 32 + 16); act_.s1 = takef(B * Kmax / 32 + 16);
+    act_.sum0 = reinterpret_cast<int *>(buf_arena_.take(B * Kmax / 32 * 4 + 64));
+    act_.xh = takeh(B * Kmax); act_.xf = takef(B * Kmax);
+    d_npast_ = reinterpret_cast<int *>(buf_arena_.take(256)); d_argmax_ = reinterpret_cast<int *>(buf_arena_.take(256));
+    d_tokens_ = reinterpret_cast<int *>(buf_arena_.take(B * 4));
+    HIP_CHECK(hipMemset(d_npast_, 0, 4)); HIP_CHECK(hipMemset(d_argmax_, 0, 4)); HIP_CHECK(hipMemset(d_tokens_, 0, B * 4));
+    HIP_CHECK(hipHostMalloc((void **)&h_argmax_, 64, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&h_logits_, V * 4, hipHostMallocDefault));
+    // vision
+    vi_img_ = takef(3 * 224 * 224); vi_patches_ = takeh(256 * 592); vi_pe_ = takef(256 * D); vi_x_ = takef(257 * D); vi_qkv_ = takef(257 * 3 * D);
+    vi_ln_h_ = takeh(257 * D); vi_att_h_ = takeh(257 * D); vi_img_h_ = takeh(257 * D); vi_mlp_h_ = takeh(257 * M);
+    vi_hs_ = takef(NQ * 768); vi_a1_ = takef(NQ * 768); vi_a2_ = takef(NQ * 768); vi_d_ = takef(NQ * 768); vi_qq_ = takef(NQ * 2304); vi_kv_ = takef(257 * 1536);
+    vi_hs_h_ = takeh(NQ * 768); vi_a1_h_ = takeh(NQ * 768); vi_a2_h_ = takeh(NQ * 768); vi_ctx_h_ = takeh(NQ * 768); vi_im_h_ = takeh(NQ * (size_t)v_qi_);
+    vi_out_ = takef(NQ * (size_t)v_out_);
+    MG4_INFO("KV cache %.1f MB (fp16, n_ctx %d), activation arena %.1f MB", 2.0 * L * C * E * 2 / 1048576.0, n_ctx_, buf_arena_.used / 1048576.0);
+}
+
+// ====================================================================================================================
+// language path
+// ====================================================================================================================
+void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s) {
+    if (prof_on_) {
+        ProfEv ev; HIP_CHECK(hipEventCreate(&ev.a)); HIP_CHECK(hipEventCreate(&ev.b)); ev.type = W.type; ev.bytes = (double)W.bytes;
+        HIP_CHECK(hipEventRecord(ev.a, s));
+        launch_mul_mat(W, act_, N, y, ldy, residual, s);
+        HIP_CHECK(hipEventRecord(ev.b, s));
+        prof_events_.push_back(ev);
+        return;
+    }
+    launch_mul_mat(W, act_, N, y, ldy, residual, s);
+}
+
+// Enqueue one forward pass for N rows already described by d_tokens_ (from_tokens) or x_ (embeddings), at position *d_npast_.
+void Engine::forward(int N, bool from_tokens, hipStream_t s) {
+    const int E = (int)llm_.n_embd, F = (int)llm_.n_ff(), H = (int)llm_.n_head, hd = E / H, V = (int)llm_.n_vocab;
+    const size_t C = (size_t)n_ctx_;
+    if (from_tokens) launch_get_rows(tok_type_, tok_raw_, E, d_tokens_, N, x_, s);
+    for (size_t il = 0; il < layers_.size(); il++) {
+        const LayerW &L = layers_[il];
+        __half *kc = kc_ + il * C * E, *vc = vc_ + il * C * E;
+        launch_rms_quant(x_, L.attn_norm, N, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s);
+        mul_mat(L.wq, N, q_, E, nullptr, s);
+        mul_mat(L.wk, N, k_, E, nullptr, s);
+        mul_mat(L.wv, N, v_, E, nullptr, s);
+        launch_rope_kv(q_, k_, v_, N, H, hd, d_npast_, cos_, sin_, kc, vc, s);
+        launch_attn_llm(q_, kc, vc, N, H, hd, d_npast_, n_ctx_, tabs_, att_, s);
+        launch_silu_mul_quant(att_, nullptr, N, E, act_, act_mask_for(L.wo.type), tabs_, s);
+        mul_mat(L.wo, N, x_, E, x_, s);
+        launch_rms_quant(x_, L.ffn_norm, N, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s);
+        mul_mat(L.w1, N, h1_, F, nullptr, s);
+        mul_mat(L.w3, N, h3_, F, nullptr, s);
+        launch_silu_mul_quant(h1_, h3_, N, F, act_, act_mask_for(L.w2.type), tabs_, s);
+        mul_mat(L.w2, N, x_, E, x_, s);
+    }
+    // only the last token's logits are kept (llama.cpp logits_all = false)
+    launch_rms_quant(x_ + (size_t)(N - 1) * E, norm_, 1, E, act_, act_mask_for(output_.type), s);
+    mul_mat(output_, 1, logits_, V, nullptr, s);
+    launch_argmax(logits_, V, d_argmax_, s);
+    launch_advance(d_npast_, N, d_tokens_, d_argmax_, s);
+    HIP_CHECK(hipMemcpyAsync(h_argmax_, d_argmax_, 4, hipMemcpyDeviceToHost, s));
+}
+
+int Engine::eval(const int *tokens, const float *embd, int N) {
+    if (N <= 0) return 0;
+    if (N > max_rows_ || n_past_ + N > n_ctx_) { set_last_error("context overflow: n_past + n_tokens > n_ctx"); return 1; }
+    const int E = (int)llm_.n_embd;
+    logits_host_valid_ = false;
+    if (tokens) {
+        for (int i = 0; i < N; i++) if (tokens[i] < 0 || tokens[i] >= (int)llm_.n_vocab) { set_last_error("token id out of range"); return 1; }
+    }
+    launch_set_int(d_npast_, n_past_, stream_);
+    if (tokens && N == 1) {
+        launch_set_int(d_tokens_, tokens[0], stream_);
+        if (use_graph_ && !prof_on_) {
+            if (!decode_graph_) {
+                hipGraph_t g = nullptr;
+                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+                forward(1, true, stream_);
+                HIP_CHECK(hipStreamEndCapture(stream_, &g));
+                HIP_CHECK(hipGraphInstantiate(&decode_graph_, g, nullptr, nullptr, 0));
+                HIP_CHECK(hipGraphDestroy(g));
+            }
+            HIP_CHECK(hipGraphLaunch(decode_graph_, stream_));
+        } else {
+            forward(1, true, stream_);
+        }
+    } else {
+        if (tokens) HIP_CHECK(hipMemcpyAsync(d_tokens_, tokens, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
+        else HIP_CHECK(hipMemcpyAsync(x_, embd, (size_t)N * E * 4, hipMemcpyHostToDevice, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));   // pageable source buffers belong to the caller
+        forward(N, tokens != nullptr, stream_);
+    }
+    n_past_ += N;
+    return 0;
+}
+
+int Engine::add_tokens(const std::vector<int> &tokens) {
+    const int start = n_past_;
+    for (size_t i = 0; i < tokens.size(); i += (size_t)n_batch_) {
+        const int n = (int)std::min((size_t)n_batch_, tokens.size() - i);
+        if (eval(tokens.data() + i, nullptr, n)) { n_past_ = start; MG4_ERR("Failed to add string"); return E_FailedToAddString; }
+    }
+    return E_None;
+}
+int Engine::add_string(const std::string &s) { return add_tokens(tok_.tokenize(s, true)); }
+int Engine::add_embedding(const float *data, int n_rows) {
+    if (eval(nullptr, data, n_rows)) { MG4_ERR("Failed to add embedding"); return E_FailedToAddEmbedding; }
+    return E_None;
+}
+const float *Engine::logits_host() {
+    if (!logits_host_valid_) {
+        HIP_CHECK(hipMemcpyAsync(h_logits_, logits_, (size_t)llm_.n_vocab * 4, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        logits_host_valid_ = true;
+    }
+    return h_logits_;
+}
+int Engine::sample_token(const SampleParams &p) {
+    if (p.temp <= 0) { HIP_CHECK(hipStreamSynchronize(stream_)); return *h_argmax_; }   // greedy: argmax computed on the device
+    return sampler_.sample(logits_host(), (int)llm_.n_vocab, p);
+}
+const char *Engine::id_to_token(int id) const {
+    if (id == 2) return "</s>";   // llama_token_eos()
+    if (id < 0 || id >= (int)llm_.pieces.size()) return "";
+    return llm_.pieces[(size_t)id].c_str();
+}
+
+int Engine::decode_loop(int steps, int *tokens_out, float *ms_total) {
+    if (steps <= 0 || n_past_ + steps > n_ctx_) return 1;
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    int first = *h_argmax_;
+    if (eval(&first, nullptr, 1)) return 1;   // builds the graph if needed, d_tokens_[0] <- greedy token afterwards (k_advance)
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    if (tokens_out) tokens_out[0] = first;
+    hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+    HIP_CHECK(hipEventRecord(a, stream_));
+    for (int i = 1; i < steps; i++) {   // step i consumes the greedy token of step i-1, left in d_tokens_[0] by k_advance
+        if (tokens_out) HIP_CHECK(hipMemcpyAsync(&tokens_out[i], d_tokens_, 4, hipMemcpyDeviceToHost, stream_));
+        if (decode_graph_ && use_graph_) HIP_CHECK(hipGraphLaunch(decode_graph_, stream_)); else forward(1, true, stream_);
+    }
+    HIP_CHECK(hipEventRecord(b, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    if (ms_total) *ms_total = ms;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    n_past_ += steps - 1;
+    logits_host_valid_ = false;
+    return 0;
+}
+
+int Engine::profile_decode(int steps, ProfStat *by_type, ProfStat *other) {
+    if (steps <= 0 || n_past_ + steps > n_ctx_) return 1;
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    prof_on_ = true;
+    hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+    HIP_CHECK(hipEventRecord(a, stream_));
+    int tok = *h_argmax_;
+    for (int i = 0; i < steps; i++) { if (eval(&tok, nullptr, 1)) { prof_on_ = false; return 1; } HIP_CHECK(hipStreamSynchronize(stream_)); tok = *h_argmax_; }
+    HIP_CHECK(hipEventRecord(b, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    prof_on_ = false;
+    for (int i = 0; i < 20; i++) by_type[i] = ProfStat{};
+    double mm_ms = 0;
+    for (auto &e : prof_events_) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, e.a, e.b));
+        if (e.type >= 0 && e.type < 20) { by_type[e.type].ms += ms; by_type[e.type].bytes += e.bytes; by_type[e.type].launches++; } mm_ms += ms;
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    prof_events_.clear();
+    float tot = 0; HIP_CHECK(hipEventElapsedTime(&tot, a, b));
+    if (other) { other->ms = tot - mm_ms; other->launches = steps; other->bytes = 0; }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return 0;
+}
+
+// ====================================================================================================================
+// image path
+// ====================================================================================================================
+int Engine::encode_image(const float *chw, float *out) {
+    hipStream_t s = stream_;
+    const int D = v_D_, M = v_M_, NQ = v_nq_, H = 768;
+    hipEvent_t ea, eb; HIP_CHECK(hipEventCreate(&ea)); HIP_CHECK(hipEventCreate(&eb));
+    HIP_CHECK(hipMemcpyAsync(vi_img_, chw, 3 * 224 * 224 * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipEventRecord(ea, s));
+    // patch embedding: conv 14x14/14 as an f16 GEMM over im2col'd patches (ggml_conv_2d, minigpt4.cpp:1059) + bias
+    launch_im2col(vi_img_, vi_patches_, 592, s);
+    launch_gemm_f16(vi_patches_, 592, v_patch_w_, 592, 256, D, 592, v_patch_b_, nullptr, false, tabs_, vi_pe_, nullptr, D, s);
+    launch_assemble_embeddings(v_cls_, vi_pe_, v_pos_, D, vi_x_, s);
+    const float scale = 1.0f / sqrtf(88.0f);
+    for (const VBlock &b : vblocks_) {
+        launch_layernorm(vi_x_, b.n1w, b.n1b, 257, D, nullptr, vi_ln_h_, s);
+        launch_gemm_f16(vi_ln_h_, D, b.qkv_w, D, 257, 3 * D, D, b.qkv_b, nullptr, false, tabs_, vi_qkv_, nullptr, 3 * D, s);
+        launch_attn_f32(vi_qkv_, 3 * D, vi_qkv_ + D, vi_qkv_ + 2 * D, 3 * D, 257, 257, v_heads_, 88, scale, 0.0f, tabs_, nullptr, vi_att_h_, D, s);
+        launch_gemm_f16(vi_att_h_, D, b.proj_w, D, 257, D, D, b.proj_b, vi_x_, false, tabs_, vi_x_, nullptr, D, s);
+        launch_layernorm(vi_x_, b.n2w, b.n2b, 257, D, nullptr, vi_ln_h_, s);
+        launch_gemm_f16(vi_ln_h_, D, b.fc1_w, D, 257, M, D, b.fc1_b, nullptr, true, tabs_, nullptr, vi_mlp_h_, M, s);
+        launch_gemm_f16(vi_mlp_h_, M, b.fc2_w, M, 257, D, M, b.fc2_b, vi_x_, false, tabs_, vi_x_, nullptr, D, s);
+    }
+    launch_layernorm(vi_x_, v_lnv_w_, v_lnv_b_, 257, D, nullptr, vi_img_h_, s);
+    // Q-Former (masks are all-zero)
+    launch_layernorm(v_qtok_, v_qeln_w_, v_qeln_b_, NQ, H, vi_hs_, vi_hs_h_, s);
+    for (const QLayer &L : qlayers_) {
+        launch_gemm_f16(vi_hs_h_, H, L.self.q_w, H, NQ, 3 * H, H, L.self.q_b, nullptr, false, tabs_, vi_qq_, nullptr, 3 * H, s);
+        launch_attn_f32(vi_qq_, 3 * H, vi_qq_ + H, vi_qq_ + 2 * H, 3 * H, NQ, NQ, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s);
+        launch_gemm_f16(vi_ctx_h_, H, L.self.dense_w, H, NQ, H, H, L.self.dense_b, vi_hs_, false, tabs_, vi_d_, nullptr, H, s);
+        launch_layernorm(vi_d_, L.self.ln_w, L.self.ln_b, NQ, H, vi_a1_, vi_a1_h_, s);
+        const float *ao = vi_a1_; const __half *ao_h = vi_a1_h_;
+        if (L.has_cross) {
+            launch_gemm_f16(vi_a1_h_, H, L.cross.q_w, H, NQ, H, H, L.cross.q_b, nullptr, false, tabs_, vi_qq_, nullptr, H, s);
+            launch_gemm_f16(vi_img_h_, D, L.cross.kv_w, D, 257, 2 * H, D, L.cross.kv_b, nullptr, false, tabs_, vi_kv_, nullptr, 2 * H, s);
+            launch_attn_f32(vi_qq_, H, vi_kv_, vi_kv_ + H, 2 * H, NQ, 257, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s);
+            launch_gemm_f16(vi_ctx_h_, H, L.cross.dense_w, H, NQ, H, H, L.cross.dense_b, vi_a1_, false, tabs_, vi_d_, nullptr, H, s);
+            launch_layernorm(vi_d_, L.cross.ln_w, L.cross.ln_b, NQ, H, vi_a2_, vi_a2_h_, s);
+            ao = vi_a2_; ao_h = vi_a2_h_;
+        }
+        launch_gemm_f16(ao_h, H, L.inter_w, H, NQ, v_qi_, H, L.inter_b, nullptr, true, tabs_, nullptr, vi_im_h_, v_qi_, s);
+        launch_gemm_f16(vi_im_h_, v_qi_, L.out_w, v_qi_, NQ, H, v_qi_, L.out_b, ao, false, tabs_, vi_d_, nullptr, H, s);
+        launch_layernorm(vi_d_, L.oln_w, L.oln_b, NQ, H, vi_hs_, vi_hs_h_, s);
+    }
+    launch_gemm_f16(vi_hs_h_, H, v_proj_w_, H, NQ, v_out_, H, v_proj_b_, nullptr, false, tabs_, vi_out_, nullptr, v_out_, s);
+    HIP_CHECK(hipEventRecord(eb, s));
+    HIP_CHECK(hipMemcpyAsync(out, vi_out_, (size_t)NQ * v_out_ * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipEventElapsedTime(&last_encode_ms_, ea, eb));
+    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    return E_None;
+}
+
+}  // namespace mg4

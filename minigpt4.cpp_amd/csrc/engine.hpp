@@ -1,0 +1,125 @@
+// MI355X MiniGPT-4 engine: owns HBM arenas (weights repacked into planes, fp16 KV cache, activation buffers), the HIP stream
+// and the decode hipGraph.  Mirrors the call surface of the reference's `class MiniGPT4` (minigpt4.cpp:1740-2522):
+// init / encode_image / add_tokens / add_strings / add_embedding / sample_token / id_to_token / reset.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "formats.hpp"
+#include "kernels.hpp"
+#include "sampler.hpp"
+
+namespace mg4 {
+
+struct DeviceArena {
+    uint8_t *base = nullptr;
+    size_t cap = 0, used = 0;
+    void alloc(size_t bytes);
+    void release();
+    uint8_t *take(size_t bytes, size_t align = 256);
+    ~DeviceArena() { release(); }
+};
+
+struct ProfStat { double ms = 0; double bytes = 0; long launches = 0; };
+
+class Engine {
+public:
+    Engine() = default;
+    ~Engine();
+    int init(const std::string &vision_path, const std::string &llm_path, int seed, int n_ctx, int n_batch);
+
+    // ---- image path (reference encode_image, minigpt4.cpp:2094-2363)
+    int encode_image(const float *chw, float *out);   // out: [32][proj_out()]
+    int proj_out() const { return v_out_; }
+    int n_query() const { return v_nq_; }
+
+    // ---- language path
+    int add_tokens(const std::vector<int> &tokens);   // chunks of n_batch (minigpt4.cpp:2365-2382)
+    int add_string(const std::string &s);             // BOS + tokenize (minigpt4.cpp:2384-2397)
+    int add_embedding(const float *data, int n_rows); // llama_eval_embd (minigpt4.cpp:2399-2422)
+    int sample_token(const SampleParams &p);          // minigpt4.cpp:2425-2483
+    const char *id_to_token(int id) const;            // minigpt4.cpp:2485-2497 (borrowed pointer)
+    void reset() { n_past_ = 0; }                     // minigpt4.cpp:2499-2502
+    void sync();
+
+    int n_vocab() const { return (int)llm_.n_vocab; }
+    int n_embd() const { return (int)llm_.n_embd; }
+    int n_past() const { return n_past_; }
+    int n_ctx() const { return n_ctx_; }
+    const float *logits_host();                       // syncs, copies the last logits to pinned memory
+    const Tokenizer &tokenizer() const { return tok_; }
+    size_t weight_bytes_per_token() const { return wbytes_token_; }
+    size_t llm_arena_bytes() const { return llm_arena_.used; }
+    size_t vision_arena_bytes() const { return vis_arena_.used; }
+    uint8_t *llm_arena_ptr() { return llm_arena_.base; }
+    uint8_t *vision_arena_ptr() { return vis_arena_.base; }
+
+    // ---- measurement hooks (bench / tests)
+    // K greedy decode steps fed back on the device (no host round trip); returns ms per step via hipEvents.
+    int decode_loop(int steps, int *tokens_out, float *ms_total);
+    // per-launch hipEvent timing of every quantised mat-vec in the next `steps` decode steps (eager launches)
+    int profile_decode(int steps, ProfStat *by_type /*[20]*/, ProfStat *other);
+    float last_encode_ms() const { return last_encode_ms_; }
+
+private:
+    int load_llm(const std::string &path);
+    int load_vision(const std::string &path);
+    void alloc_buffers();
+    int eval(const int *tokens, const float *embd, int N);
+    void forward(int N, bool from_tokens, hipStream_t s);
+    void mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s);
+    void upload_qweight(const TensorMeta &t, const uint8_t *file_base, QWeight &w);
+    template <typename T> T *upload_raw(DeviceArena &a, const void *src, size_t bytes);
+
+    int device_ = 0;
+    hipStream_t stream_ = nullptr;
+    int n_ctx_ = 2048, n_batch_ = 512, max_rows_ = 512;
+    int n_past_ = 0;
+
+    // LLM
+    LLMFile llm_;
+    Tokenizer tok_;
+    Sampler sampler_;
+    struct LayerW { float *attn_norm = nullptr, *ffn_norm = nullptr; QWeight wq, wk, wv, wo, w1, w2, w3; };
+    std::vector<LayerW> layers_;
+    float *norm_ = nullptr;
+    QWeight output_;
+    uint8_t *tok_raw_ = nullptr; int tok_type_ = -1;
+    DeviceArena llm_arena_, vis_arena_, buf_arena_;
+    uint8_t *stage_ = nullptr; size_t stage_cap_ = 0;
+    size_t wbytes_token_ = 0;
+    __half *kc_ = nullptr, *vc_ = nullptr;
+    float *cos_ = nullptr, *sin_ = nullptr;
+    Tables tabs_;
+    // activations
+    float *x_ = nullptr, *q_ = nullptr, *k_ = nullptr, *v_ = nullptr, *att_ = nullptr, *h1_ = nullptr, *h3_ = nullptr, *logits_ = nullptr;
+    ActQ act_;
+    int *d_npast_ = nullptr, *d_tokens_ = nullptr, *d_argmax_ = nullptr;
+    int *h_argmax_ = nullptr; float *h_logits_ = nullptr; bool logits_host_valid_ = false;
+    hipGraphExec_t decode_graph_ = nullptr; bool use_graph_ = true;
+    // profiling
+    bool prof_on_ = false;
+    struct ProfEv { hipEvent_t a, b; int type; double bytes; };
+    std::vector<ProfEv> prof_events_;
+
+    // vision
+    VisionFile vis_;
+    int v_D_ = 0, v_depth_ = 0, v_M_ = 0, v_heads_ = 0, v_ql_ = 0, v_qi_ = 0, v_nq_ = 32, v_out_ = 0;
+    struct VBlock { float *n1w, *n1b, *n2w, *n2b, *qkv_b, *proj_b, *fc1_b, *fc2_b; __half *qkv_w, *proj_w, *fc1_w, *fc2_w; };
+    struct QAtt { __half *q_w = nullptr, *kv_w = nullptr, *dense_w = nullptr; float *q_b = nullptr, *kv_b = nullptr, *dense_b = nullptr, *ln_w = nullptr, *ln_b = nullptr; };
+    struct QLayer { QAtt self, cross; bool has_cross = false; __half *inter_w, *out_w; float *inter_b, *out_b, *oln_w, *oln_b; };
+    std::vector<VBlock> vblocks_;
+    std::vector<QLayer> qlayers_;
+    float *v_cls_ = nullptr, *v_pos_ = nullptr, *v_patch_b_ = nullptr, *v_lnv_w_ = nullptr, *v_lnv_b_ = nullptr, *v_qtok_ = nullptr, *v_qeln_w_ = nullptr, *v_qeln_b_ = nullptr, *v_proj_b_ = nullptr;
+    __half *v_patch_w_ = nullptr, *v_proj_w_ = nullptr;
+    // vision activations
+    float *vi_img_ = nullptr, *vi_pe_ = nullptr, *vi_x_ = nullptr, *vi_qkv_ = nullptr, *vi_hs_ = nullptr, *vi_a1_ = nullptr, *vi_a2_ = nullptr, *vi_d_ = nullptr, *vi_qq_ = nullptr, *vi_kv_ = nullptr, *vi_out_ = nullptr;
+    __half *vi_patches_ = nullptr, *vi_ln_h_ = nullptr, *vi_att_h_ = nullptr, *vi_mlp_h_ = nullptr, *vi_img_h_ = nullptr, *vi_hs_h_ = nullptr, *vi_a1_h_ = nullptr, *vi_a2_h_ = nullptr, *vi_ctx_h_ = nullptr, *vi_im_h_ = nullptr;
+    float last_encode_ms_ = 0;
+};
+
+int device_count_noexcept();
+
+}  // namespace mg4

@@ -1,0 +1,58 @@
+// Host-callable launchers of the gfx950 kernels (llm_kernels.hip, vision_kernels.hip).
+#pragma once
+#include "common.hpp"
+
+namespace mg4 {
+
+struct Tables {               // fp16 lookup tables, 65536 entries each, indexed by the fp16 bit pattern of the argument
+    const __half *gelu = nullptr, *silu = nullptr, *exp = nullptr;
+};
+
+// ---- load-time repack: raw ggml blocks (device copy of the file bytes) -> planes of a QWeight -------------------
+// `dst` planes must already point into the arena (see plan_qweight).  raw/dst may not alias.
+size_t plan_qweight(int type, int rows, int cols, QWeight &w, uint8_t *base);  // assigns plane pointers from `base`, returns bytes used
+void launch_repack(const uint8_t *raw, const QWeight &w, hipStream_t s);
+bool qweight_supported(int type);
+
+// ---- activations -------------------------------------------------------------------------------------------------
+// y = rms_norm(x) * w  (w == nullptr: y = x), quantised into the formats in `mask`; N rows of width K.
+void launch_rms_quant(const float *x, const float *w, int N, int K, const ActQ &A, int mask, hipStream_t s);
+// y = silu(a) * b (fp16-table silu), quantised; or y = a when b == nullptr.
+void launch_silu_mul_quant(const float *a, const float *b, int N, int K, const ActQ &A, int mask, const Tables &tb, hipStream_t s);
+
+// ---- quantised mat-mul: y[t][r] = W[r] . act[t]  (+ residual[t][r]) ------------------------------------------------
+void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s);
+
+// ---- token embedding gather (raw ggml rows, dequantised to f32) -----------------------------------------------------
+void launch_get_rows(int type, const uint8_t *raw_table, int K, const int *tokens, int N, float *out, hipStream_t s);
+
+// ---- RoPE + KV append, attention, argmax ----------------------------------------------------------------------------
+// q,k,v: [N][E] f32.  Rotates q in place, writes rotated k and v as fp16 into the caches at position *n_past + t.
+void launch_rope_kv(float *q, const float *k, const float *v, int N, int n_head, int hd, const int *n_past, const float *cos_tab,
+                    const float *sin_tab, __half *kcache, __half *vcache, hipStream_t s);
+// out[t][h*hd+i] = softmax(K q / sqrt(hd)) V over keys 0..*n_past+t.  caches: [n_ctx][E] fp16.
+void launch_attn_llm(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int n_ctx,
+                     const Tables &tb, float *out, hipStream_t s);
+void launch_argmax(const float *logits, int n, int *out, hipStream_t s);
+void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);
+void launch_set_int(int *p, int v, hipStream_t s);
+void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s);
+
+// ---- vision tower -----------------------------------------------------------------------------------------------------
+// C[M][N] = A[M][K](f16) . W[N][K](f16)^T + bias ; optional fp16-table GELU ; optional residual add (C = residual + C).
+// Writes fp32 `out` (nullable) and/or fp16 `out_h` (nullable).  K must be a multiple of 16.
+void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual,
+                     bool gelu, const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s);
+// LayerNorm (ggml_norm eps 1e-5, then w*x+b); rows x n; writes fp32 (nullable) and fp16 (nullable).
+void launch_layernorm(const float *x, const float *w, const float *b, int rows, int n, float *out, __half *out_h, hipStream_t s);
+// f32 attention: q[nq][ldq], k/v[nk][ldk]; per head h the slice [h*hd, (h+1)*hd).  q_prescale != 0: q *= q_prescale first (ViT);
+// score_div != 0: scores /= score_div (BERT).  Output fp32 (nullable) / fp16 (nullable) [nq][ldo].
+void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale,
+                     float score_div, const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s);
+// image CHW f32 [3][224][224] -> fp16 patches [256][ldp] (k = c*196 + kh*14 + kw, zero padded to ldp)
+void launch_im2col(const float *image, __half *patches, int ldp, hipStream_t s);
+// x[0] = cls + pos[0]; x[1+p] = pe[p] + pos[1+p]
+void launch_assemble_embeddings(const float *cls, const float *pe, const float *pos, int D, float *x, hipStream_t s);
+void launch_f32_to_f16(const float *x, __half *y, size_t n, hipStream_t s);
+
+}  // namespace mg4

@@ -1,0 +1,625 @@
+// gfx950 kernels for the Vicuna (LLaMA) path: fused-dequant integer-dot mat-vec / mat-mul over repacked weight planes,
+// RMSNorm + activation quantisation, RoPE + KV append, causal attention over the fp16 KV cache, argmax, embedding gather.
+//
+// Arithmetic follows the reference's CPU path (ggml @ llama.cpp master-31cfbb1 behind llama_eval, reference
+// minigpt4.cpp:2373/2412): activations are quantised to the weight type's vec_dot_type (Q8_0 / Q8_1 / Q8_K), block dots are
+// exact int32 (v_dot4_i32_i8), block results are scaled and accumulated in fp32.  See DESIGN.md "Numerics".
+#include "kernels.hpp"
+
+namespace mg4 {
+
+// =====================================================================================================================
+// helpers
+// =====================================================================================================================
+__device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+__device__ __forceinline__ float h2f_bits(unsigned short h) { return __half2float(__ushort_as_half(h)); }
+__device__ __forceinline__ unsigned short f2h_bits(float f) { return __half_as_ushort(__float2half_rn(f)); }
+__device__ __forceinline__ float f16r(float f) { return __half2float(__float2half_rn(f)); }
+__device__ __forceinline__ float tab(const __half *t, float x) { return __half2float(t[f2h_bits(x)]); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int4 ld16(const void *p) { return *reinterpret_cast<const int4 *>(p); }
+
+// =====================================================================================================================
+// load-time repack: ggml array-of-blocks -> planes.  One thread per unit (16 bytes of the main plane).
+// =====================================================================================================================
+size_t plan_qweight(int type, int rows, int cols, QWeight &w, uint8_t *base) {
+    w = QWeight{};
+    w.type = type; w.rows = rows; w.cols = cols;
+    const size_t n = (size_t)rows * cols;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { uint8_t *p = base ? base + off : nullptr; off += al(bytes); return p; };
+    switch (type) {
+    case GT_F32: w.qs = take(n * 4); break;
+    case GT_F16: w.qs = take(n * 2); break;
+    case GT_Q4_0: w.qs = take(n / 32 * 16); w.sc = take(n / 32 * 2); break;
+    case GT_Q4_1: w.qs = take(n / 32 * 16); w.sc = take(n / 32 * 4); break;
+    case GT_Q5_0: w.qs = take(n / 32 * 16); w.qh = take(n / 32 * 4); w.sc = take(n / 32 * 2); break;
+    case GT_Q5_1: w.qs = take(n / 32 * 16); w.qh = take(n / 32 * 4); w.sc = take(n / 32 * 4); break;
+    case GT_Q8_0: w.qs = take(n / 32 * 32); w.sc = take(n / 32 * 2); break;
+    case GT_Q4_K: w.qs = take(n / 256 * 128); w.sc = take(n / 256 * 16); break;
+    case GT_Q5_K: w.qs = take(n / 256 * 128); w.qh = take(n / 256 * 32); w.sc = take(n / 256 * 16); break;
+    case GT_Q6_K: w.qs = take(n / 256 * 128); w.qh = take(n / 256 * 64); w.sc = take(n / 256 * 16); w.d = take(n / 256 * 2); break;
+    default: return 0;
+    }
+    w.bytes = gt_nbytes(type, n);
+    return off;
+}
+bool qweight_supported(int type) {
+    switch (type) { case GT_F32: case GT_F16: case GT_Q4_0: case GT_Q4_1: case GT_Q5_0: case GT_Q5_1: case GT_Q8_0: case GT_Q4_K: case GT_Q5_K: case GT_Q6_K: return true; default: return false; }
+}
+
+// high-bit transposition for 5-bit types: element e of 32 (lo: e<16 -> dword k=e/4, byte i=e%4, slot w=k; hi: e>=16 -> w=4+k)
+__device__ __forceinline__ unsigned pack_hb1(const unsigned char hb_lo[16], const unsigned char hb_hi[16]) {
+    unsigned P = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++) { const int k = e >> 2, i = e & 3; P |= (unsigned)(hb_lo[e] & 1) << (8 * i + k); P |= (unsigned)(hb_hi[e] & 1) << (8 * i + 4 + k); }
+    return P;
+}
+
+__global__ void k_repack(const uint8_t *__restrict__ raw, QWeight w, size_t n_units) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_units) return;
+    uint8_t *qs = const_cast<uint8_t *>(w.qs), *qh = const_cast<uint8_t *>(w.qh), *sc = const_cast<uint8_t *>(w.sc), *dd = const_cast<uint8_t *>(w.d);
+    switch (w.type) {
+    case GT_Q4_0: { const uint8_t *b = raw + g * 18; sc[g * 2] = b[0]; sc[g * 2 + 1] = b[1]; for (int i = 0; i < 16; i++) qs[g * 16 + i] = b[2 + i]; break; }
+    case GT_Q4_1: { const uint8_t *b = raw + g * 20; for (int i = 0; i < 4; i++) sc[g * 4 + i] = b[i]; for (int i = 0; i < 16; i++) qs[g * 16 + i] = b[4 + i]; break; }
+    case GT_Q5_0: case GT_Q5_1: {
+        const int hdr = w.type == GT_Q5_0 ? 2 : 4; const uint8_t *b = raw + g * (size_t)(hdr + 20);
+        for (int i = 0; i < hdr; i++) sc[g * hdr + i] = b[i];
+        const unsigned q = (unsigned)b[hdr] | ((unsigned)b[hdr + 1] << 8) | ((unsigned)b[hdr + 2] << 16) | ((unsigned)b[hdr + 3] << 24);
+        unsigned char lo[16], hi[16];
+        for (int e = 0; e < 16; e++) { lo[e] = (q >> e) & 1; hi[e] = (q >> (16 + e)) & 1; }
+        *reinterpret_cast<unsigned *>(qh + g * 4) = pack_hb1(lo, hi);
+        for (int i = 0; i < 16; i++) qs[g * 16 + i] = b[hdr + 4 + i];
+        break; }
+    case GT_Q8_0: { const size_t blk = g >> 1; const int half = (int)(g & 1); const uint8_t *b = raw + blk * 34;
+        if (!half) { sc[blk * 2] = b[0]; sc[blk * 2 + 1] = b[1]; }
+        for (int i = 0; i < 16; i++) qs[g * 16 + i] = b[2 + half * 16 + i];
+        break; }
+    case GT_Q4_K: { const size_t sb = g >> 3; const int u = (int)(g & 7); const uint8_t *b = raw + sb * 144;
+        if (u == 0) for (int i = 0; i < 16; i++) sc[sb * 16 + i] = b[i];
+        for (int i = 0; i < 16; i++) qs[g * 16 + i] = b[16 + u * 16 + i];
+        break; }
+    case GT_Q5_K: { const size_t sb = g >> 3; const int u = (int)(g & 7), j = u >> 1, h = u & 1; const uint8_t *b = raw + sb * 176;
+        if (u == 0) for (int i = 0; i < 16; i++) sc[sb * 16 + i] = b[i];
+        unsigned char lo[16], hi[16];
+        for (int e = 0; e < 16; e++) { const unsigned char v = b[16 + 16 * h + e]; lo[e] = (v >> (2 * j)) & 1; hi[e] = (v >> (2 * j + 1)) & 1; }
+        *reinterpret_cast<unsigned *>(qh + g * 4) = pack_hb1(lo, hi);
+        for (int i = 0; i < 16; i++) qs[g * 16 + i] = b[48 + u * 16 + i];
+        break; }
+    case GT_Q6_K: { const size_t sb = g >> 3; const int u = (int)(g & 7), n = u >> 2, c = (u >> 1) & 1, h = u & 1; const uint8_t *b = raw + sb * 210;
+        if (u == 0) { dd[sb * 2] = b[208]; dd[sb * 2 + 1] = b[209]; }
+        unsigned Plo = 0, Phi = 0;
+        for (int e = 0; e < 16; e++) { const unsigned v = b[128 + 32 * n + 16 * h + e]; const int k = e >> 2, i = e & 3;
+            Plo |= ((v >> (2 * c)) & 3u) << (8 * i + 2 * k); Phi |= ((v >> (4 + 2 * c)) & 3u) << (8 * i + 2 * k); }
+        reinterpret_cast<unsigned *>(qh + g * 8)[0] = Plo; reinterpret_cast<unsigned *>(qh + g * 8)[1] = Phi;
+        sc[g * 2] = b[192 + 8 * n + 2 * c + h]; sc[g * 2 + 1] = b[192 + 8 * n + 4 + 2 * c + h];
+        for (int i = 0; i < 16; i++) qs[g * 16 + i] = b[u * 16 + i];
+        break; }
+    case GT_F16: case GT_F32: { for (int i = 0; i < 16; i++) qs[g * 16 + i] = raw[g * 16 + i]; break; }
+    default: break;
+    }
+}
+void launch_repack(const uint8_t *raw, const QWeight &w, hipStream_t s) {
+    const size_t n = (size_t)w.rows * w.cols;
+    size_t units;
+    switch (w.type) { case GT_F32: units = n / 4; break; case GT_F16: units = n / 8; break; case GT_Q8_0: units = n / 16; break; default: units = n / 32; }
+    const int bs = 256;
+    hipLaunchKernelGGL(k_repack, dim3((unsigned)((units + bs - 1) / bs)), dim3(bs), 0, s, raw, w, units);
+}
+
+// =====================================================================================================================
+// per-type unit traits: how one lane fetches a weight unit / the matching activation unit, and how they dot.
+// =====================================================================================================================
+template <int T> struct Tr;
+
+
+template <> struct Tr<GT_Q4_0> {
+    static constexpr int EPU = 32;
+    struct WU { int4 q; float d; };
+    struct AU { int4 a0, a1; float d; int sum; };
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); w.d = h2f_bits(*reinterpret_cast<const unsigned short *>(W.sc + g * 2)); }
+    static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) {
+        const int8_t *p = A.q80 + (size_t)t * K + (size_t)u * 32; a.a0 = ld16(p); a.a1 = ld16(p + 16);
+        const size_t b = (size_t)t * (K / 32) + u; a.d = A.d0[b]; a.sum = A.sum0[b]; }
+    static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
+        int s = 0;
+        s = dot4(w.q.x & 0x0F0F0F0F, a.a0.x, s); s = dot4(w.q.y & 0x0F0F0F0F, a.a0.y, s); s = dot4(w.q.z & 0x0F0F0F0F, a.a0.z, s); s = dot4(w.q.w & 0x0F0F0F0F, a.a0.w, s);
+        s = dot4((w.q.x >> 4) & 0x0F0F0F0F, a.a1.x, s); s = dot4((w.q.y >> 4) & 0x0F0F0F0F, a.a1.y, s); s = dot4((w.q.z >> 4) & 0x0F0F0F0F, a.a1.z, s); s = dot4((w.q.w >> 4) & 0x0F0F0F0F, a.a1.w, s);
+        s -= 8 * a.sum;
+        acc = fmaf(w.d * a.d, (float)s, acc);
+    }
+};
+template <> struct Tr<GT_Q4_1> {
+    static constexpr int EPU = 32;
+    struct WU { int4 q; float d, m; };
+    struct AU { int4 a0, a1; float d, s; };
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); const unsigned dm = *reinterpret_cast<const unsigned *>(W.sc + g * 4); w.d = h2f_bits(dm & 0xFFFF); w.m = h2f_bits(dm >> 16); }
+    static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) {
+        const int8_t *p = A.q80 + (size_t)t * K + (size_t)u * 32; a.a0 = ld16(p); a.a1 = ld16(p + 16);
+        const size_t b = (size_t)t * (K / 32) + u; a.d = A.d1[b]; a.s = A.s1[b]; }
+    static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
+        int s = 0;
+        s = dot4(w.q.x & 0x0F0F0F0F, a.a0.x, s); s = dot4(w.q.y & 0x0F0F0F0F, a.a0.y, s); s = dot4(w.q.z & 0x0F0F0F0F, a.a0.z, s); s = dot4(w.q.w & 0x0F0F0F0F, a.a0.w, s);
+        s = dot4((w.q.x >> 4) & 0x0F0F0F0F, a.a1.x, s); s = dot4((w.q.y >> 4) & 0x0F0F0F0F, a.a1.y, s); s = dot4((w.q.z >> 4) & 0x0F0F0F0F, a.a1.z, s); s = dot4((w.q.w >> 4) & 0x0F0F0F0F, a.a1.w, s);
+        acc = fmaf(w.d * a.d, (float)s, acc);
+        acc = fmaf(w.m, a.s, acc);
+    }
+};
+// 5-bit: P holds the high bits pre-transposed (see pack_hb1): lo dword k -> (P << (4-k)) & 0x10101010, hi dword k -> (P >> k) & 0x10101010
+#define MG4_Q5_DOT8(q, P, a0, a1, s)                                                                                   \
+    s = dot4((q.x & 0x0F0F0F0F) | ((P << 4) & 0x10101010), a0.x, s); s = dot4((q.y & 0x0F0F0F0F) | ((P << 3) & 0x10101010), a0.y, s); \
+    s = dot4((q.z & 0x0F0F0F0F) | ((P << 2) & 0x10101010), a0.z, s); s = dot4((q.w & 0x0F0F0F0F) | ((P << 1) & 0x10101010), a0.w, s); \
+    s = dot4(((q.x >> 4) & 0x0F0F0F0F) | (P & 0x10101010), a1.x, s); s = dot4(((q.y >> 4) & 0x0F0F0F0F) | ((P >> 1) & 0x10101010), a1.y, s); \
+    s = dot4(((q.z >> 4) & 0x0F0F0F0F) | ((P >> 2) & 0x10101010), a1.z, s); s = dot4(((q.w >> 4) & 0x0F0F0F0F) | ((P >> 3) & 0x10101010), a1.w, s);
+template <> struct Tr<GT_Q5_0> {
+    static constexpr int EPU = 32;
+    struct WU { int4 q; unsigned P; float d; };
+    using AU = Tr<GT_Q4_0>::AU;
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); w.P = *reinterpret_cast<const unsigned *>(W.qh + g * 4); w.d = h2f_bits(*reinterpret_cast<const unsigned short *>(W.sc + g * 2)); }
+    static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { Tr<GT_Q4_0>::loada(A, t, K, u, a); }
+    static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
+        int s = 0; const unsigned P = w.P;
+        MG4_Q5_DOT8(w.q, P, a.a0, a.a1, s)
+        s -= 16 * a.sum;
+        acc = fmaf(w.d * a.d, (float)s, acc);
+    }
+};
+template <> struct Tr<GT_Q5_1> {
+    static constexpr int EPU = 32;
+    struct WU { int4 q; unsigned P; float d, m; };
+    using AU = Tr<GT_Q4_1>::AU;
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); w.P = *reinterpret_cast<const unsigned *>(W.qh + g * 4);
+        const unsigned dm = *reinterpret_cast<const unsigned *>(W.sc + g * 4); w.d = h2f_bits(dm & 0xFFFF); w.m = h2f_bits(dm >> 16); }
+    static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { Tr<GT_Q4_1>::loada(A, t, K, u, a); }
+    static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
+        int s = 0; const unsigned P = w.P;
+        MG4_Q5_DOT8(w.q, P, a.a0, a.a1, s)
+        acc = fmaf(w.d * a.d, (float)s, acc);
+        acc = fmaf(w.m, a.s, acc);
+    }
+};
+template <> struct Tr<GT_Q8_0> {   // unit = half a block (16 int8); the two halves are combined across the lane pair before scaling
+    static constexpr int EPU = 16;
+    struct WU { int4 q; float d; };
+    struct AU { int4 a; float d; };
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); w.d = h2f_bits(*reinterpret_cast<const unsigned short *>(W.sc + (g >> 1) * 2)); }
+    static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { a.a = ld16(A.q80 + (size_t)t * K + (size_t)u * 16); a.d = A.d0[(size_t)t * (K / 32) + (u >> 1)]; }
+    static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
+        int s = 0;
+        s = dot4(w.q.x, a.a.x, s); s = dot4(w.q.y, a.a.y, s); s = dot4(w.q.z, a.a.z, s); s = dot4(w.q.w, a.a.w, s);
+        s += __shfl_xor(s, 1);
+        if (!(threadIdx.x & 1)) acc = fmaf(w.d * a.d, (float)s, acc);
+    }
+};
+// k-quants ---------------------------------------------------------------------------------------------------------------
+struct AK { int4 lo, hi; float d; int bs_lo, bs_hi; };
+__device__ __forceinline__ void scale_min_pair(const int4 &h, int j, int &sc0, int &sc1, int &m0, int &m1) {
+    // h.y,h.z,h.w = the 12 packed 6-bit (scale,min) bytes of a Q4_K/Q5_K super-block; pair j -> sub-blocks 2j, 2j+1
+    const unsigned s0 = (unsigned)h.y, s1 = (unsigned)h.z, s2 = (unsigned)h.w;
+    const unsigned sc_lo = s0 & 0x3f3f3f3fu, m_lo = s1 & 0x3f3f3f3fu;
+    const unsigned sc_hi = (s2 & 0x0f0f0f0fu) | (((s0 >> 6) & 0x03030303u) << 4);
+    const unsigned m_hi = ((s2 >> 4) & 0x0f0f0f0fu) | (((s1 >> 6) & 0x03030303u) << 4);
+    const unsigned scw = (j & 2) ? sc_hi : sc_lo, mw = (j & 2) ? m_hi : m_lo;
+    const int sh = (j & 1) * 16;
+    sc0 = (scw >> sh) & 0xFF; sc1 = (scw >> (sh + 8)) & 0xFF; m0 = (mw >> sh) & 0xFF; m1 = (mw >> (sh + 8)) & 0xFF;
+}
+template <> struct Tr<GT_Q4_K> {
+    static constexpr int EPU = 32;
+    struct WU { int4 q; int4 h; };
+    using AU = AK;
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); w.h = ld16(W.sc + (g >> 3) * 16); }
+    static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) {
+        const int sb = u >> 3, i = u & 7, j = i >> 1, h = i & 1;
+        const int8_t *p = A.q8k + (size_t)t * K + (size_t)sb * 256 + 64 * j + 16 * h; a.lo = ld16(p); a.hi = ld16(p + 32);
+        a.d = A.dk[(size_t)t * (K / 256) + sb]; const int16_t *bs = A.bsk + (size_t)t * (K / 16) + sb * 16 + 4 * j + h; a.bs_lo = bs[0]; a.bs_hi = bs[2]; }
+    static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
+        const int j = (threadIdx.x & 7) >> 1;
+        int sc0, sc1, m0, m1; scale_min_pair(w.h, j, sc0, sc1, m0, m1);
+        int s0 = 0, s1 = 0;
+        s0 = dot4(w.q.x & 0x0F0F0F0F, a.lo.x, s0); s0 = dot4(w.q.y & 0x0F0F0F0F, a.lo.y, s0); s0 = dot4(w.q.z & 0x0F0F0F0F, a.lo.z, s0); s0 = dot4(w.q.w & 0x0F0F0F0F, a.lo.w, s0);
+        s1 = dot4((w.q.x >> 4) & 0x0F0F0F0F, a.hi.x, s1); s1 = dot4((w.q.y >> 4) & 0x0F0F0F0F, a.hi.y, s1); s1 = dot4((w.q.z >> 4) & 0x0F0F0F0F, a.hi.z, s1); s1 = dot4((w.q.w >> 4) & 0x0F0F0F0F, a.hi.w, s1);
+        const float d = h2f_bits((unsigned)w.h.x & 0xFFFF), dmin = h2f_bits((unsigned)w.h.x >> 16);
+        acc = fmaf(d * a.d, (float)(sc0 * s0 + sc1 * s1), acc);
+        acc = fmaf(-(dmin * a.d), (float)(m0 * a.bs_lo + m1 * a.bs_hi), acc);
+    }
+};
+template <> struct Tr<GT_Q5_K> {
+    static constexpr int EPU = 32;
+    struct WU { int4 q; int4 h; unsigned P; };
+    using AU = AK;
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); w.h = ld16(W.sc + (g >> 3) * 16); w.P = *reinterpret_cast<const unsigned *>(W.qh + g * 4); }
+    static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { Tr<GT_Q4_K>::loada(A, t, K, u, a); }
+    static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
+        const int j = (threadIdx.x & 7) >> 1;
+        int sc0, sc1, m0, m1; scale_min_pair(w.h, j, sc0, sc1, m0, m1);
+        const unsigned P = w.P; int s0 = 0, s1 = 0;
+        s0 = dot4((w.q.x & 0x0F0F0F0F) | ((P << 4) & 0x10101010), a.lo.x, s0); s0 = dot4((w.q.y & 0x0F0F0F0F) | ((P << 3) & 0x10101010), a.lo.y, s0);
+        s0 = dot4((w.q.z & 0x0F0F0F0F) | ((P << 2) & 0x10101010), a.lo.z, s0); s0 = dot4((w.q.w & 0x0F0F0F0F) | ((P << 1) & 0x10101010), a.lo.w, s0);
+        s1 = dot4(((w.q.x >> 4) & 0x0F0F0F0F) | (P & 0x10101010), a.hi.x, s1); s1 = dot4(((w.q.y >> 4) & 0x0F0F0F0F) | ((P >> 1) & 0x10101010), a.hi.y, s1);
+        s1 = dot4(((w.q.z >> 4) & 0x0F0F0F0F) | ((P >> 2) & 0x10101010), a.hi.z, s1); s1 = dot4(((w.q.w >> 4) & 0x0F0F0F0F) | ((P >> 3) & 0x10101010), a.hi.w, s1);
+        const float d = h2f_bits((unsigned)w.h.x & 0xFFFF), dmin = h2f_bits((unsigned)w.h.x >> 16);
+        acc = fmaf(d * a.d, (float)(sc0 * s0 + sc1 * s1), acc);
+        acc = fmaf(-(dmin * a.d), (float)(m0 * a.bs_lo + m1 * a.bs_hi), acc);
+    }
+};
+template <> struct Tr<GT_Q6_K> {
+    static constexpr int EPU = 32;
+    struct WU { int4 q; unsigned Plo, Phi; int sc_lo, sc_hi; float d; };
+    using AU = AK;
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) {
+        w.q = ld16(W.qs + g * 16); const uint2 p = *reinterpret_cast<const uint2 *>(W.qh + g * 8); w.Plo = p.x; w.Phi = p.y;
+        const unsigned short s = *reinterpret_cast<const unsigned short *>(W.sc + g * 2); w.sc_lo = (int)(signed char)(s & 0xFF); w.sc_hi = (int)(signed char)(s >> 8);
+        w.d = h2f_bits(*reinterpret_cast<const unsigned short *>(W.d + (g >> 3) * 2)); }
+    static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) {
+        const int sb = u >> 3, i = u & 7, n = i >> 2, c = (i >> 1) & 1, h = i & 1;
+        const int8_t *p = A.q8k + (size_t)t * K + (size_t)sb * 256 + 128 * n + 32 * c + 16 * h; a.lo = ld16(p); a.hi = ld16(p + 64);
+        a.d = A.dk[(size_t)t * (K / 256) + sb]; const int16_t *bs = A.bsk + (size_t)t * (K / 16) + sb * 16 + 8 * n + 2 * c + h; a.bs_lo = bs[0]; a.bs_hi = bs[4]; }
+    static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
+        int s0 = 0, s1 = 0; const unsigned L = w.Plo, H = w.Phi;
+        s0 = dot4((w.q.x & 0x0F0F0F0F) | ((L << 4) & 0x30303030), a.lo.x, s0); s0 = dot4((w.q.y & 0x0F0F0F0F) | ((L << 2) & 0x30303030), a.lo.y, s0);
+        s0 = dot4((w.q.z & 0x0F0F0F0F) | (L & 0x30303030), a.lo.z, s0); s0 = dot4((w.q.w & 0x0F0F0F0F) | ((L >> 2) & 0x30303030), a.lo.w, s0);
+        s1 = dot4(((w.q.x >> 4) & 0x0F0F0F0F) | ((H << 4) & 0x30303030), a.hi.x, s1); s1 = dot4(((w.q.y >> 4) & 0x0F0F0F0F) | ((H << 2) & 0x30303030), a.hi.y, s1);
+        s1 = dot4(((w.q.z >> 4) & 0x0F0F0F0F) | (H & 0x30303030), a.hi.z, s1); s1 = dot4(((w.q.w >> 4) & 0x0F0F0F0F) | ((H >> 2) & 0x30303030), a.hi.w, s1);
+        s0 -= 32 * a.bs_lo; s1 -= 32 * a.bs_hi;
+        acc = fmaf(w.d * a.d, (float)(w.sc_lo * s0 + w.sc_hi * s1), acc);
+    }
+};
+template <> struct Tr<GT_F16> {
+    static constexpr int EPU = 8;
+    struct WU { int4 q; };
+    struct AU { int4 a; };
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); }
+    static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { a.a = ld16(reinterpret_cast<const uint8_t *>(A.xh) + ((size_t)t * K + (size_t)u * 8) * 2); }
+    static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
+        const unsigned wq[4] = {(unsigned)w.q.x, (unsigned)w.q.y, (unsigned)w.q.z, (unsigned)w.q.w}, aq[4] = {(unsigned)a.a.x, (unsigned)a.a.y, (unsigned)a.a.z, (unsigned)a.a.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) { acc = fmaf(h2f_bits(wq[i] & 0xFFFF), h2f_bits(aq[i] & 0xFFFF), acc); acc = fmaf(h2f_bits(wq[i] >> 16), h2f_bits(aq[i] >> 16), acc); }
+    }
+};
+template <> struct Tr<GT_F32> {
+    static constexpr int EPU = 4;
+    struct WU { float4 q; };
+    struct AU { float4 a; };
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = *reinterpret_cast<const float4 *>(W.qs + g * 16); }
+    static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { a.a = *reinterpret_cast<const float4 *>(A.xf + (size_t)t * K + (size_t)u * 4); }
+    static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) { acc = fmaf(w.q.x, a.a.x, acc); acc = fmaf(w.q.y, a.a.y, acc); acc = fmaf(w.q.z, a.a.z, acc); acc = fmaf(w.q.w, a.a.w, acc); }
+};
+
+// =====================================================================================================================
+// y[t][r] = W[r] . act[t] (+ residual).  One wave owns R consecutive rows; its 64 lanes stride over the row's units
+// (16-byte coalesced loads, 1 KiB per wave-instruction); each lane keeps the activation unit in registers and reuses it
+// for the R rows and TN tokens.  Wave-level xor-shuffle reduction at the end; no LDS.
+// =====================================================================================================================
+template <int T, int R, int TN>
+__global__ __launch_bounds__(256) void k_mul_mat(const QWeight W, const ActQ A, const int N, float *y, const int ldy, const float *residual) {
+    using X = Tr<T>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + wave) * R;
+    const int t0 = blockIdx.y * TN;
+    if (row0 >= W.rows) return;          // wave-uniform
+    const int K = W.cols, U = K / X::EPU;
+    float acc[R][TN];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int t = 0; t < TN; t++) acc[r][t] = 0.0f;
+    int rows_i[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) rows_i[r] = min(row0 + r, W.rows - 1);
+    for (int u0 = 0; u0 < U; u0 += 64) {
+        const int u = u0 + lane;
+        const bool ok = u < U;
+        const int uc = ok ? u : 0;       // out-of-range lanes fetch unit 0 (valid address), their result is discarded
+        typename X::AU a[TN];
+#pragma unroll
+        for (int t = 0; t < TN; t++) X::loada(A, min(t0 + t, N - 1), K, uc, a[t]);
+        typename X::WU w[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) X::loadw(W, (size_t)rows_i[r] * U + uc, w[r]);
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int t = 0; t < TN; t++) { float c = acc[r][t]; X::dot(w[r], a[t], c); acc[r][t] = ok ? c : acc[r][t]; }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int t = 0; t < TN; t++) {
+            const float v = wave_sum(acc[r][t]);
+            if (lane == 0 && row0 + r < W.rows && t0 + t < N) {
+                const size_t o = (size_t)(t0 + t) * ldy + row0 + r;
+                y[o] = residual ? v + residual[o] : v;
+            }
+        }
+}
+
+template <int T>
+static void launch_mul_mat_t(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
+    if (N == 1) {
+        constexpr int R = 2;
+        dim3 grid((unsigned)((W.rows + 4 * R - 1) / (4 * R)), 1);
+        hipLaunchKernelGGL((k_mul_mat<T, R, 1>), grid, dim3(256), 0, s, W, A, N, y, ldy, residual);
+    } else {
+        constexpr int R = 2, TN = 4;
+        dim3 grid((unsigned)((W.rows + 4 * R - 1) / (4 * R)), (unsigned)((N + TN - 1) / TN));
+        hipLaunchKernelGGL((k_mul_mat<T, R, TN>), grid, dim3(256), 0, s, W, A, N, y, ldy, residual);
+    }
+}
+void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
+    switch (W.type) {
+    case GT_Q4_0: launch_mul_mat_t<GT_Q4_0>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q4_1: launch_mul_mat_t<GT_Q4_1>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q5_0: launch_mul_mat_t<GT_Q5_0>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q5_1: launch_mul_mat_t<GT_Q5_1>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q8_0: launch_mul_mat_t<GT_Q8_0>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q4_K: launch_mul_mat_t<GT_Q4_K>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q5_K: launch_mul_mat_t<GT_Q5_K>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q6_K: launch_mul_mat_t<GT_Q6_K>(W, A, N, y, ldy, residual, s); break;
+    case GT_F16: launch_mul_mat_t<GT_F16>(W, A, N, y, ldy, residual, s); break;
+    case GT_F32: launch_mul_mat_t<GT_F32>(W, A, N, y, ldy, residual, s); break;
+    default: throw HipError{hipErrorInvalidValue, "unsupported weight type", __FILE__, __LINE__};
+    }
+}
+
+// =====================================================================================================================
+// activation preparation: (rms_norm * w | silu(a)*b | identity) -> {Q8_K, Q8_0/Q8_1, f16, f32}
+// thread t of a 256-thread group owns 4 consecutive values; a wave = one 256-wide Q8_K block, 8 lanes = one 32-wide block.
+// =====================================================================================================================
+__device__ __forceinline__ void quant_emit4(const float v[4], const bool in_range, const int idx /*first element index in the row*/, const size_t row, const int K,
+                                            const ActQ &A, const int mask) {
+    const int lane = threadIdx.x & 63;
+    if (mask & ACT_F32) { if (in_range) *reinterpret_cast<float4 *>(A.xf + row * K + idx) = make_float4(v[0], v[1], v[2], v[3]); }
+    if (mask & ACT_F16) { if (in_range) { __half2 h0 = __floats2half2_rn(v[0], v[1]), h1 = __floats2half2_rn(v[2], v[3]);
+            uint2 o; o.x = *reinterpret_cast<unsigned *>(&h0); o.y = *reinterpret_cast<unsigned *>(&h1); *reinterpret_cast<uint2 *>(A.xh + row * K + idx) = o; } }
+    if (mask & ACT_Q8K) {
+        // signed value of the FIRST element with the largest magnitude in the 256-block (ggml quantize_row_q8_K)
+        float best = 0.0f; unsigned bidx = 0xFFFFFFFFu; float bav = -1.0f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const float av = fabsf(v[e]); if (av > bav) { bav = av; best = v[e]; bidx = (unsigned)(idx + e); } }
+        unsigned long long key = ((unsigned long long)__float_as_uint(bav) << 32) | (unsigned long long)(0xFFFFFFFFu - bidx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(key, o); key = other > key ? other : key; }
+        const unsigned long long mine = ((unsigned long long)__float_as_uint(bav) << 32) | (unsigned long long)(0xFFFFFFFFu - bidx);
+        const unsigned long long m = __ballot(mine == key);
+        const int src = __ffsll((long long)m) - 1;
+        const float maxv = __shfl(best, src);
+        const float amax = __uint_as_float((unsigned)(key >> 32));
+        int q[4] = {0, 0, 0, 0}; float d = 0.0f;
+        if (amax != 0.0f) {
+            const float iscale = -128.f / maxv;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const int r = (int)rintf(iscale * v[e]); q[e] = r > 127 ? 127 : r; }
+            d = 1.0f / iscale;
+        }
+        int s = q[0] + q[1] + q[2] + q[3];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+        if (in_range) {
+            const unsigned pk = (unsigned)(q[0] & 0xFF) | ((unsigned)(q[1] & 0xFF) << 8) | ((unsigned)(q[2] & 0xFF) << 16) | ((unsigned)(q[3] & 0xFF) << 24);
+            *reinterpret_cast<unsigned *>(A.q8k + row * K + idx) = pk;
+            if ((lane & 3) == 0) A.bsk[row * (K / 16) + idx / 16] = (int16_t)s;
+            if (lane == 0) A.dk[row * (K / 256) + idx / 256] = d;
+        }
+    }
+    if (mask & ACT_Q80) {
+        float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+        const float d = amax / 127.0f, id = d != 0.0f ? 1.0f / d : 0.0f;
+        int q[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) q[e] = (int)rintf(v[e] * id);
+        int s = q[0] + q[1] + q[2] + q[3];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        if (in_range) {
+            const unsigned pk = (unsigned)(q[0] & 0xFF) | ((unsigned)(q[1] & 0xFF) << 8) | ((unsigned)(q[2] & 0xFF) << 16) | ((unsigned)(q[3] & 0xFF) << 24);
+            *reinterpret_cast<unsigned *>(A.q80 + row * K + idx) = pk;
+            if ((lane & 7) == 0) { const size_t b = row * (K / 32) + idx / 32; A.d0[b] = f16r(d); A.d1[b] = d; A.s1[b] = d * (float)s; A.sum0[b] = s; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rms_quant(const float *__restrict__ x, const float *__restrict__ w, const int K, const ActQ A, const int mask) {
+    const size_t row = blockIdx.x;
+    const float *xr = x + row * K;
+    __shared__ double red[4];
+    __shared__ float s_scale;
+    float scale = 1.0f;
+    if (w) {
+        double sum = 0.0;
+        for (int i = threadIdx.x * 4; i < K; i += 1024) { const float4 v = *reinterpret_cast<const float4 *>(xr + i);
+            sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) { const double tot = red[0] + red[1] + red[2] + red[3]; const float mean = (float)(tot / (double)K); s_scale = 1.0f / sqrtf(mean + 1e-6f); }
+        __syncthreads();
+        scale = s_scale;
+    }
+    for (int i0 = 0; i0 < K; i0 += 1024) {
+        const int i = i0 + threadIdx.x * 4;
+        const bool in = i < K;
+        float v[4] = {0, 0, 0, 0};
+        if (in) { const float4 xv = *reinterpret_cast<const float4 *>(xr + i);
+            if (w) { const float4 wv = *reinterpret_cast<const float4 *>(w + i); v[0] = (xv.x * scale) * wv.x; v[1] = (xv.y * scale) * wv.y; v[2] = (xv.z * scale) * wv.z; v[3] = (xv.w * scale) * wv.w; }
+            else { v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w; } }
+        quant_emit4(v, in, i, row, K, A, mask);
+    }
+}
+void launch_rms_quant(const float *x, const float *w, int N, int K, const ActQ &A, int mask, hipStream_t s) {
+    hipLaunchKernelGGL(k_rms_quant, dim3((unsigned)N), dim3(256), 0, s, x, w, K, A, mask);
+}
+
+__global__ __launch_bounds__(256) void k_silu_mul_quant(const float *__restrict__ a, const float *__restrict__ b, const int K, const ActQ A, const int mask, const Tables tb) {
+    const size_t row = blockIdx.y;
+    const int i = blockIdx.x * 1024 + threadIdx.x * 4;
+    const bool in = i < K;
+    float v[4] = {0, 0, 0, 0};
+    if (in) { const float4 av = *reinterpret_cast<const float4 *>(a + row * K + i);
+        if (b) { const float4 bv = *reinterpret_cast<const float4 *>(b + row * K + i);
+            v[0] = tab(tb.silu, av.x) * bv.x; v[1] = tab(tb.silu, av.y) * bv.y; v[2] = tab(tb.silu, av.z) * bv.z; v[3] = tab(tb.silu, av.w) * bv.w; }
+        else { v[0] = av.x; v[1] = av.y; v[2] = av.z; v[3] = av.w; } }
+    quant_emit4(v, in, i, row, K, A, mask);
+}
+void launch_silu_mul_quant(const float *a, const float *b, int N, int K, const ActQ &A, int mask, const Tables &tb, hipStream_t s) {
+    hipLaunchKernelGGL(k_silu_mul_quant, dim3((unsigned)((K + 1023) / 1024), (unsigned)N), dim3(256), 0, s, a, b, K, A, mask, tb);
+}
+
+// =====================================================================================================================
+// embedding gather: dequantise rows of the raw (un-repacked) ggml table
+// =====================================================================================================================
+__device__ __forceinline__ void sm_k4(int j, const uint8_t *q, int &d, int &m) {
+    if (j < 4) { d = q[j] & 63; m = q[j + 4] & 63; } else { d = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); m = (q[j + 4] >> 4) | ((q[j] >> 6) << 4); }
+}
+__device__ float dequant_elem(int type, const uint8_t *row, int e) {
+    switch (type) {
+    case GT_F32: return reinterpret_cast<const float *>(row)[e];
+    case GT_F16: return h2f_bits(reinterpret_cast<const unsigned short *>(row)[e]);
+    case GT_Q4_0: { const uint8_t *b = row + (e >> 5) * 18; const int j = e & 31; const float d = h2f_bits(b[0] | (b[1] << 8)); const int q = j < 16 ? (b[2 + j] & 15) : (b[2 + j - 16] >> 4); return (float)(q - 8) * d; }
+    case GT_Q4_1: { const uint8_t *b = row + (e >> 5) * 20; const int j = e & 31; const float d = h2f_bits(b[0] | (b[1] << 8)), m = h2f_bits(b[2] | (b[3] << 8)); const int q = j < 16 ? (b[4 + j] & 15) : (b[4 + j - 16] >> 4); return (float)q * d + m; }
+    case GT_Q5_0: { const uint8_t *b = row + (e >> 5) * 22; const int j = e & 31; const float d = h2f_bits(b[0] | (b[1] << 8)); const unsigned qh = b[2] | (b[3] << 8) | (b[4] << 16) | ((unsigned)b[5] << 24);
+        const int q = (j < 16 ? (b[6 + j] & 15) : (b[6 + j - 16] >> 4)) | (((qh >> j) & 1) << 4); return (float)(q - 16) * d; }
+    case GT_Q5_1: { const uint8_t *b = row + (e >> 5) * 24; const int j = e & 31; const float d = h2f_bits(b[0] | (b[1] << 8)), m = h2f_bits(b[2] | (b[3] << 8)); const unsigned qh = b[4] | (b[5] << 8) | (b[6] << 16) | ((unsigned)b[7] << 24);
+        const int q = (j < 16 ? (b[8 + j] & 15) : (b[8 + j - 16] >> 4)) | (((qh >> j) & 1) << 4); return (float)q * d + m; }
+    case GT_Q8_0: { const uint8_t *b = row + (e >> 5) * 34; const float d = h2f_bits(b[0] | (b[1] << 8)); return (float)(signed char)b[2 + (e & 31)] * d; }
+    case GT_Q4_K: { const uint8_t *b = row + (e >> 8) * 144; const int i = e & 255, s = i >> 5, l = i & 31; const float d = h2f_bits(b[0] | (b[1] << 8)), dm = h2f_bits(b[2] | (b[3] << 8)); int sc, m; sm_k4(s, b + 4, sc, m);
+        const uint8_t qb = b[16 + (s >> 1) * 32 + l]; const int q = (s & 1) ? (qb >> 4) : (qb & 15); return (d * sc) * (float)q - dm * m; }
+    case GT_Q5_K: { const uint8_t *b = row + (e >> 8) * 176; const int i = e & 255, s = i >> 5, l = i & 31; const float d = h2f_bits(b[0] | (b[1] << 8)), dm = h2f_bits(b[2] | (b[3] << 8)); int sc, m; sm_k4(s, b + 4, sc, m);
+        const uint8_t qb = b[48 + (s >> 1) * 32 + l]; const int q = ((s & 1) ? (qb >> 4) : (qb & 15)) + (((b[16 + l] >> s) & 1) ? 16 : 0); return (d * sc) * (float)q - dm * m; }
+    case GT_Q6_K: { const uint8_t *b = row + (e >> 8) * 210; const int i = e & 255, n = i >> 7, a = (i >> 5) & 3, l = i & 31; const float d = h2f_bits(b[208] | (b[209] << 8));
+        const uint8_t qlb = b[64 * n + 32 * (a & 1) + l]; const int lo = (a & 2) ? (qlb >> 4) : (qlb & 15); const int hi = (b[128 + 32 * n + l] >> (2 * a)) & 3;
+        const int q = (lo | (hi << 4)) - 32; const int sc = (signed char)b[192 + 8 * n + 2 * a + (l >> 4)]; return d * (float)sc * (float)q; }
+    default: return 0.0f;
+    }
+}
+__global__ void k_get_rows(int type, const uint8_t *__restrict__ table, int K, size_t row_bytes, const int *__restrict__ tokens, float *__restrict__ out) {
+    const int t = blockIdx.x;
+    const uint8_t *row = table + (size_t)tokens[t] * row_bytes;
+    for (int e = threadIdx.x; e < K; e += blockDim.x) out[(size_t)t * K + e] = dequant_elem(type, row, e);
+}
+void launch_get_rows(int type, const uint8_t *raw_table, int K, const int *tokens, int N, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_get_rows, dim3((unsigned)N), dim3(256), 0, s, type, raw_table, K, gt_nbytes(type, (size_t)K), tokens, out);
+}
+
+// =====================================================================================================================
+// RoPE (ggml mode 0: interleaved pairs; cos/sin table built on the host with ggml's iterative fp32 theta) + KV append
+// =====================================================================================================================
+__global__ void k_rope_kv(float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v, int E, int hd, const int *__restrict__ n_past,
+                          const float *__restrict__ cos_tab, const float *__restrict__ sin_tab, __half *__restrict__ kc, __half *__restrict__ vc) {
+    const int t = blockIdx.x, h = blockIdx.y, i = threadIdx.x;   // i < hd/2
+    const int pos = *n_past + t;
+    const float c = cos_tab[(size_t)pos * (hd / 2) + i], s = sin_tab[(size_t)pos * (hd / 2) + i];
+    const size_t o = (size_t)t * E + (size_t)h * hd + 2 * i;
+    const float q0 = q[o], q1 = q[o + 1];
+    q[o] = q0 * c - q1 * s; q[o + 1] = q0 * s + q1 * c;
+    const float k0 = k[o], k1 = k[o + 1];
+    const size_t co = (size_t)pos * E + (size_t)h * hd + 2 * i;
+    *reinterpret_cast<__half2 *>(kc + co) = __floats2half2_rn(k0 * c - k1 * s, k0 * s + k1 * c);
+    *reinterpret_cast<__half2 *>(vc + co) = __floats2half2_rn(v[o], v[o + 1]);
+}
+void launch_rope_kv(float *q, const float *k, const float *v, int N, int n_head, int hd, const int *n_past, const float *cos_tab, const float *sin_tab,
+                    __half *kcache, __half *vcache, hipStream_t s) {
+    hipLaunchKernelGGL(k_rope_kv, dim3((unsigned)N, (unsigned)n_head), dim3((unsigned)(hd / 2)), 0, s, q, k, v, n_head * hd, hd, n_past, cos_tab, sin_tab, kcache, vcache);
+}
+
+// =====================================================================================================================
+// causal attention over the fp16 KV cache.  One workgroup per (head, query token).
+//   scores: one lane per key, sequential fp32 fma over the head dim (q rounded to fp16 first, like ggml's f16 mul_mat)
+//   softmax: max, exp through the fp16 table, exact double sum, probabilities rounded to fp16
+//   PV: lane per pair of output dims, keys split over 256/(hd/2) partitions
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void k_attn_llm(const float *__restrict__ q, const __half *__restrict__ kc, const __half *__restrict__ vc, int E, int hd,
+                                                  const int *__restrict__ n_past, const Tables tb, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int h = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    const int T = *n_past + t + 1;
+    float *sc = reinterpret_cast<float *>(smem);                 // [Tpad]
+    const int Tpad = (T + 3) & ~3;
+    __half *ph = reinterpret_cast<__half *>(sc + Tpad);          // [Tpad]
+    __half *qh = ph + ((Tpad + 7) & ~7);                         // [hd]
+    float *part = reinterpret_cast<float *>(qh + hd);            // [256/(hd/2)][hd]
+    __shared__ float s_red[8];
+    __shared__ double s_dred[4];
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int i = tid; i < hd; i += 256) qh[i] = __float2half_rn(q[(size_t)t * E + (size_t)h * hd + i]);
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = tid; j < T; j += 256) {
+        const __half *kr = kc + (size_t)j * E + (size_t)h * hd;
+        float s = 0.0f;
+        for (int i = 0; i < hd; i += 8) {
+            const int4 kv = ld16(kr + i); const int4 qv = *reinterpret_cast<const int4 *>(qh + i);
+            const unsigned kk[4] = {(unsigned)kv.x, (unsigned)kv.y, (unsigned)kv.z, (unsigned)kv.w}, qq[4] = {(unsigned)qv.x, (unsigned)qv.y, (unsigned)qv.z, (unsigned)qv.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) { s = fmaf(h2f_bits(kk[e] & 0xFFFF), h2f_bits(qq[e] & 0xFFFF), s); s = fmaf(h2f_bits(kk[e] >> 16), h2f_bits(qq[e] >> 16), s); }
+        }
+        s *= scale;
+        sc[j] = s; mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    double sum = 0.0;
+    for (int j = tid; j < T; j += 256) { const float v = tab(tb.exp, sc[j] - mx); sc[j] = v; sum += (double)v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((tid & 63) == 0) s_dred[tid >> 6] = sum;
+    __syncthreads();
+    const float inv = (float)(1.0 / (s_dred[0] + s_dred[1] + s_dred[2] + s_dred[3]));
+    for (int j = tid; j < T; j += 256) ph[j] = __float2half_rn(sc[j] * inv);
+    __syncthreads();
+    const int hp = hd / 2, P = 256 / hp, p = tid / hp, i2 = (tid % hp) * 2;
+    float o0 = 0.0f, o1 = 0.0f;
+    if (p < P) for (int j = p; j < T; j += P) {
+        const __half2 vv = *reinterpret_cast<const __half2 *>(vc + (size_t)j * E + (size_t)h * hd + i2);
+        const float pj = __half2float(ph[j]);
+        o0 = fmaf(__low2float(vv), pj, o0); o1 = fmaf(__high2float(vv), pj, o1);
+    }
+    if (p < P) { part[p * hd + i2] = o0; part[p * hd + i2 + 1] = o1; }
+    __syncthreads();
+    for (int i = tid; i < hd; i += 256) { float s = 0.0f; for (int pp = 0; pp < P; pp++) s += part[pp * hd + i]; out[(size_t)t * E + (size_t)h * hd + i] = s; }
+}
+void launch_attn_llm(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int n_ctx, const Tables &tb,
+                     float *out, hipStream_t s) {
+    const int Tmax = (n_ctx + 3) & ~3;
+    const int P = 256 / (hd / 2);
+    const size_t lds = (size_t)Tmax * 4 + (size_t)((Tmax + 7) & ~7) * 2 + (size_t)hd * 2 + (size_t)P * hd * 4 + 64;
+    hipLaunchKernelGGL(k_attn_llm, dim3((unsigned)n_head, (unsigned)N), dim3(256), lds, s, q, kcache, vcache, n_head * hd, hd, n_past, tb, out);
+}
+
+// =====================================================================================================================
+// argmax (first maximum wins, like llama_sample_token_greedy) and small elementwise helpers
+// =====================================================================================================================
+__global__ __launch_bounds__(1024) void k_argmax(const float *__restrict__ x, int n, int *__restrict__ out) {
+    float best = -INFINITY; int bi = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < n; i += 1024) { const float v = x[i]; if (v > best) { best = v; bi = i; } }
+    __shared__ float sv[16]; __shared__ int si[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o); if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; } }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int w = 1; w < 16; w++) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; } *out = bi == 0x7FFFFFFF ? 0 : bi; }
+}
+void launch_argmax(const float *logits, int n, int *out, hipStream_t s) { hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, s, logits, n, out); }
+
+__global__ void k_add_inplace(float *__restrict__ x, const float *__restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = x[i] + y[i];
+}
+void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n); }
+
+__global__ void k_set_int(int *p, int v) { *p = v; }
+void launch_set_int(int *p, int v, hipStream_t s) { hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, p, v); }
+// end of a decode step: the KV position advances and the greedy token becomes the next input (the host may overwrite it)
+__global__ void k_advance(int *n_past, int n, int *tok0, const int *argmax) { *n_past += n; if (tok0) *tok0 = *argmax; }
+void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, n_past, n, tok0, argmax); }
+
+}  // namespace mg4

@@ -1,0 +1,382 @@
+"""Host-side mirror of the reference's Python binding for the MI355X build of libminigpt4.so.
+
+Same class and method names, argument meaning and error behaviour as the reference's
+`minigpt4/minigpt4_library.py` (MiniGPT4SharedLibrary :74-523, load_library :525-566, MiniGPT4ChatBot :568-689),
+so code and tests written against the reference binding read the same here.  The reference's *unmodified* binding
+also works against this library; this mirror exists so the repo is self-contained, adds correct
+ctypes prototypes (`size_t` / `bool` instead of int32) and exposes the additive `minigpt4_amd_*` entry points.
+
+There is no CPU fallback: loading a model without a usable gfx950 device raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import enum
+import os
+from typing import Iterator, List, Optional, Sequence
+
+import numpy as np
+
+
+class DataType(enum.IntEnum):
+    F16 = 0; F32 = 1; I32 = 2; L64 = 3; Q4_0 = 4; Q4_1 = 5; Q5_0 = 6; Q5_1 = 7; Q8_0 = 8; Q8_1 = 9   # noqa: E702
+    Q2_K = 10; Q3_K = 11; Q4_K = 12; Q5_K = 13; Q6_K = 14; Q8_K = 15                                   # noqa: E702
+
+    def __str__(self):
+        return str(self.name)
+
+
+class Verbosity(enum.IntEnum):
+    SILENT = 0; ERR = 1; INFO = 2; DEBUG = 3   # noqa: E702
+
+
+class ImageFormat(enum.IntEnum):
+    UNKNOWN = 0; F32 = 1; U8 = 2   # noqa: E702
+
+
+I32, F32, SIZE_T, VOID_PTR = ctypes.c_int32, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+CHAR_PTR = ctypes.c_char_p
+FLOAT_PTR = ctypes.POINTER(ctypes.c_float)
+INT_PTR = ctypes.POINTER(ctypes.c_int32)
+
+
+class MiniGPT4Context:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+
+class MiniGPT4Image(ctypes.Structure):
+    _fields_ = [("data", VOID_PTR), ("width", I32), ("height", I32), ("channels", I32), ("format", I32)]
+
+
+class MiniGPT4Embedding(ctypes.Structure):
+    _fields_ = [("data", FLOAT_PTR), ("n_embeddings", SIZE_T)]   # 2nd field is `elements` in the C header
+
+
+class MiniGPT4Images(ctypes.Structure):
+    _fields_ = [("images", ctypes.POINTER(MiniGPT4Image)), ("n_images", SIZE_T)]
+
+
+class MiniGPT4Embeddings(ctypes.Structure):
+    _fields_ = [("embeddings", ctypes.POINTER(MiniGPT4Embedding)), ("n_embeddings", SIZE_T)]
+
+
+_CHAT_ARGS = [SIZE_T, F32, I32, F32, F32, F32, I32, F32, F32, F32, I32, F32, F32, I32]
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+class MiniGPT4SharedLibrary:
+    """ctypes wrapper around libminigpt4.so (reference class of the same name)."""
+
+    def __init__(self, shared_library_path: str):
+        self.library = ctypes.cdll.LoadLibrary(shared_library_path)
+        L = self.library
+        P = ctypes.POINTER
+        L.minigpt4_model_load.argtypes = [CHAR_PTR, CHAR_PTR, I32, I32, I32, I32, ctypes.c_bool]
+        L.minigpt4_model_load.restype = VOID_PTR
+        L.minigpt4_image_load_from_file.argtypes = [VOID_PTR, CHAR_PTR, P(MiniGPT4Image), I32]
+        L.minigpt4_preprocess_image.argtypes = [VOID_PTR, P(MiniGPT4Image), P(MiniGPT4Image), I32]
+        L.minigpt4_encode_image.argtypes = [VOID_PTR, P(MiniGPT4Image), P(MiniGPT4Embedding), SIZE_T]
+        L.minigpt4_begin_chat_image.argtypes = [VOID_PTR, P(MiniGPT4Embedding), CHAR_PTR, SIZE_T]
+        L.minigpt4_end_chat_image.argtypes = [VOID_PTR, P(ctypes.c_char_p)] + _CHAT_ARGS
+        L.minigpt4_system_prompt.argtypes = [VOID_PTR, SIZE_T]
+        L.minigpt4_begin_chat.argtypes = [VOID_PTR, CHAR_PTR, SIZE_T]
+        L.minigpt4_end_chat.argtypes = [VOID_PTR, P(ctypes.c_char_p)] + _CHAT_ARGS
+        L.minigpt4_reset_chat.argtypes = [VOID_PTR]
+        L.minigpt4_contains_eos_token.argtypes = [CHAR_PTR]
+        L.minigpt4_is_eos.argtypes = [CHAR_PTR]
+        L.minigpt4_free.argtypes = [VOID_PTR]
+        L.minigpt4_free_image.argtypes = [P(MiniGPT4Image)]
+        L.minigpt4_free_embedding.argtypes = [P(MiniGPT4Embedding)]
+        L.minigpt4_error_code_to_string.argtypes = [I32]
+        L.minigpt4_error_code_to_string.restype = CHAR_PTR
+        L.minigpt4_quantize_model.argtypes = [CHAR_PTR, CHAR_PTR, I32]
+        L.minigpt4_set_verbosity.argtypes = [I32]
+        L.minigpt4_set_verbosity.restype = None
+        for name in ("image_load_from_file", "preprocess_image", "encode_image", "begin_chat_image", "end_chat_image", "system_prompt",
+                     "begin_chat", "end_chat", "reset_chat", "contains_eos_token", "is_eos", "free", "free_image", "free_embedding", "quantize_model"):
+            getattr(L, "minigpt4_" + name).restype = I32
+        # additive API (include/minigpt4_amd.h)
+        L.minigpt4_amd_device_count.restype = I32
+        L.minigpt4_amd_last_error.restype = CHAR_PTR
+        L.minigpt4_amd_build_info.restype = CHAR_PTR
+        for name in ("n_vocab", "n_embd", "n_past", "sync"):
+            getattr(L, "minigpt4_amd_" + name).argtypes = [VOID_PTR]
+            getattr(L, "minigpt4_amd_" + name).restype = I32
+        L.minigpt4_amd_eval_tokens.argtypes = [VOID_PTR, INT_PTR, I32]
+        L.minigpt4_amd_eval_embd.argtypes = [VOID_PTR, FLOAT_PTR, I32]
+        L.minigpt4_amd_get_logits.argtypes = [VOID_PTR, FLOAT_PTR, SIZE_T]
+        L.minigpt4_amd_tokenize.argtypes = [VOID_PTR, CHAR_PTR, I32, INT_PTR, I32]
+        L.minigpt4_amd_sample.argtypes = [VOID_PTR, INT_PTR, F32, I32, F32, F32, F32, I32, F32, F32]
+        L.minigpt4_amd_decode_loop.argtypes = [VOID_PTR, I32, INT_PTR, FLOAT_PTR]
+        L.minigpt4_amd_profile_decode.argtypes = [VOID_PTR, I32, P(ctypes.c_double), P(ctypes.c_double), P(ctypes.c_long), P(ctypes.c_double)]
+        L.minigpt4_amd_weight_bytes_per_token.argtypes = [VOID_PTR]
+        L.minigpt4_amd_weight_bytes_per_token.restype = ctypes.c_double
+        L.minigpt4_amd_last_encode_ms.argtypes = [VOID_PTR]
+        L.minigpt4_amd_last_encode_ms.restype = F32
+        L.minigpt4_encode_images.argtypes = [VOID_PTR, P(MiniGPT4Images), P(MiniGPT4Embeddings), SIZE_T]
+        L.minigpt4_free_embeddings.argtypes = [P(MiniGPT4Embeddings)]
+        L.minigpt4_amd_weight_arena.argtypes = [VOID_PTR, I32, P(VOID_PTR), P(SIZE_T)]
+        L.minigpt4_amd_test_mul_mat.argtypes = [I32, VOID_PTR, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, ctypes.c_int64, FLOAT_PTR]
+        L.minigpt4_amd_test_quantize.argtypes = [FLOAT_PTR, FLOAT_PTR, ctypes.c_int64, ctypes.c_int64, VOID_PTR, VOID_PTR, VOID_PTR, VOID_PTR, VOID_PTR]
+        L.minigpt4_amd_test_gemm_f16.argtypes = [FLOAT_PTR, FLOAT_PTR, FLOAT_PTR, I32, I32, I32, I32, FLOAT_PTR]
+        L.minigpt4_amd_vocab_load.argtypes = [CHAR_PTR]
+        L.minigpt4_amd_vocab_load.restype = VOID_PTR
+        L.minigpt4_amd_vocab_free.argtypes = [VOID_PTR]
+        L.minigpt4_amd_vocab_free.restype = None
+        L.minigpt4_amd_vocab_size.argtypes = [VOID_PTR]
+        L.minigpt4_amd_vocab_piece.argtypes = [VOID_PTR, I32, INT_PTR]
+        L.minigpt4_amd_vocab_piece.restype = VOID_PTR
+        L.minigpt4_amd_vocab_tokenize.argtypes = [VOID_PTR, CHAR_PTR, I32, INT_PTR, I32]
+        L.minigpt4_amd_inspect_files.argtypes = [CHAR_PTR, CHAR_PTR, INT_PTR, INT_PTR, P(ctypes.c_int64)]
+        L.minigpt4_amd_sample_logits.argtypes = [FLOAT_PTR, I32, I32, F32, I32, F32, F32, F32, I32, F32, F32]
+
+    # ---------------------------------------------------------------- reference surface
+    def panic_if_error(self, error_code: int) -> None:
+        if error_code != 0:
+            raise RuntimeError(self.library.minigpt4_error_code_to_string(I32(error_code)))
+
+    def minigpt4_model_load(self, model_path: str, llm_model_path: str, verbosity: int = 1, seed: int = 1337, n_ctx: int = 2048,
+                            n_batch: int = 512, numa: int = 0) -> MiniGPT4Context:
+        ptr = self.library.minigpt4_model_load(model_path.encode(), llm_model_path.encode(), int(verbosity), seed, n_ctx, n_batch, bool(numa))
+        if not ptr:
+            raise RuntimeError("minigpt4_model_load failed: " + (self.library.minigpt4_amd_last_error() or b"").decode(errors="replace"))
+        return MiniGPT4Context(ptr)
+
+    def minigpt4_image_load_from_file(self, ctx: MiniGPT4Context, path: str, flags: int = 0) -> MiniGPT4Image:
+        image = MiniGPT4Image()
+        self.panic_if_error(self.library.minigpt4_image_load_from_file(ctx.ptr, path.encode(), ctypes.pointer(image), flags))
+        return image
+
+    def minigpt4_preprocess_image(self, ctx: MiniGPT4Context, image: MiniGPT4Image, flags: int = 0) -> MiniGPT4Image:
+        out = MiniGPT4Image()
+        self.panic_if_error(self.library.minigpt4_preprocess_image(ctx.ptr, ctypes.pointer(image), ctypes.pointer(out), flags))
+        return out
+
+    def minigpt4_encode_image(self, ctx: MiniGPT4Context, image: MiniGPT4Image, n_threads: int = 0) -> MiniGPT4Embedding:
+        embedding = MiniGPT4Embedding()
+        self.panic_if_error(self.library.minigpt4_encode_image(ctx.ptr, ctypes.pointer(image), ctypes.pointer(embedding), n_threads))
+        return embedding
+
+    def minigpt4_begin_chat_image(self, ctx: MiniGPT4Context, image_embedding: MiniGPT4Embedding, s: str, n_threads: int = 0):
+        self.panic_if_error(self.library.minigpt4_begin_chat_image(ctx.ptr, ctypes.pointer(image_embedding), s.encode(), n_threads))
+
+    def _end(self, fn, ctx, n_threads, temp, top_k, top_p, tfs_z, typical_p, repeat_last_n, repeat_penalty, alpha_presence, alpha_frequency,
+             mirostat, mirostat_tau, mirostat_eta, penalize_nl) -> str:
+        token = ctypes.c_char_p()
+        self.panic_if_error(fn(ctx.ptr, ctypes.byref(token), n_threads, temp, top_k, top_p, tfs_z, typical_p, repeat_last_n, repeat_penalty,
+                               alpha_presence, alpha_frequency, mirostat, mirostat_tau, mirostat_eta, penalize_nl))
+        return (token.value or b"").decode("utf-8", errors="replace")
+
+    def minigpt4_end_chat_image(self, ctx, n_threads=0, temp=0.8, top_k=40, top_p=0.9, tfs_z=1.0, typical_p=1.0, repeat_last_n=64,
+                                repeat_penalty=1.1, alpha_presence=1.0, alpha_frequency=1.0, mirostat=0, mirostat_tau=5.0, mirostat_eta=1.0,
+                                penalize_nl=1) -> str:
+        return self._end(self.library.minigpt4_end_chat_image, ctx, n_threads, temp, top_k, top_p, tfs_z, typical_p, repeat_last_n, repeat_penalty,
+                         alpha_presence, alpha_frequency, mirostat, mirostat_tau, mirostat_eta, penalize_nl)
+
+    def minigpt4_system_prompt(self, ctx: MiniGPT4Context, n_threads: int = 0):
+        self.panic_if_error(self.library.minigpt4_system_prompt(ctx.ptr, n_threads))
+
+    def minigpt4_begin_chat(self, ctx: MiniGPT4Context, s: str, n_threads: int = 0):
+        self.panic_if_error(self.library.minigpt4_begin_chat(ctx.ptr, s.encode(), n_threads))
+
+    def minigpt4_end_chat(self, ctx, n_threads=0, temp=0.8, top_k=40, top_p=0.9, tfs_z=1.0, typical_p=1.0, repeat_last_n=64, repeat_penalty=1.1,
+                          alpha_presence=1.0, alpha_frequency=1.0, mirostat=0, mirostat_tau=5.0, mirostat_eta=1.0, penalize_nl=1) -> str:
+        return self._end(self.library.minigpt4_end_chat, ctx, n_threads, temp, top_k, top_p, tfs_z, typical_p, repeat_last_n, repeat_penalty,
+                         alpha_presence, alpha_frequency, mirostat, mirostat_tau, mirostat_eta, penalize_nl)
+
+    def minigpt4_reset_chat(self, ctx: MiniGPT4Context):
+        self.panic_if_error(self.library.minigpt4_reset_chat(ctx.ptr))
+
+    def minigpt4_contains_eos_token(self, s: str) -> bool:
+        return bool(self.library.minigpt4_contains_eos_token(s.encode()))
+
+    def minigpt4_is_eos(self, s: str) -> bool:
+        return bool(self.library.minigpt4_is_eos(s.encode()))
+
+    def minigpt4_free(self, ctx: MiniGPT4Context) -> None:
+        self.panic_if_error(self.library.minigpt4_free(ctx.ptr))
+        ctx.ptr = None
+
+    def minigpt4_free_image(self, image: MiniGPT4Image) -> None:
+        self.panic_if_error(self.library.minigpt4_free_image(ctypes.pointer(image)))
+
+    def minigpt4_free_embedding(self, embedding: MiniGPT4Embedding) -> None:
+        self.panic_if_error(self.library.minigpt4_free_embedding(ctypes.pointer(embedding)))
+
+    def minigpt4_error_code_to_string(self, error_code: int) -> str:
+        return self.library.minigpt4_error_code_to_string(error_code).decode()
+
+    def minigpt4_quantize_model(self, in_path: str, out_path: str, data_type: DataType):
+        self.panic_if_error(self.library.minigpt4_quantize_model(in_path.encode(), out_path.encode(), int(data_type)))
+
+    def minigpt4_set_verbosity(self, verbosity: Verbosity):
+        self.library.minigpt4_set_verbosity(int(verbosity))
+
+    # ---------------------------------------------------------------- additive surface (numpy in / out)
+    def amd_device_count(self) -> int:
+        return int(self.library.minigpt4_amd_device_count())
+
+    def amd_eval_tokens(self, ctx, tokens: Sequence[int]):
+        t = np.ascontiguousarray(tokens, np.int32)
+        self.panic_if_error(self.library.minigpt4_amd_eval_tokens(ctx.ptr, t.ctypes.data_as(INT_PTR), len(t)))
+
+    def amd_eval_embd(self, ctx, embd: np.ndarray):
+        e = np.ascontiguousarray(embd, np.float32)
+        n_embd = self.library.minigpt4_amd_n_embd(ctx.ptr)
+        self.panic_if_error(self.library.minigpt4_amd_eval_embd(ctx.ptr, e.ctypes.data_as(FLOAT_PTR), e.size // n_embd))
+
+    def amd_logits(self, ctx) -> np.ndarray:
+        out = np.empty(self.library.minigpt4_amd_n_vocab(ctx.ptr), np.float32)
+        assert self.library.minigpt4_amd_get_logits(ctx.ptr, out.ctypes.data_as(FLOAT_PTR), out.size) == 0
+        return out
+
+    def amd_tokenize(self, ctx, text: bytes, add_bos: bool = True) -> List[int]:
+        cap = len(text) + 8
+        out = (ctypes.c_int32 * cap)()
+        n = self.library.minigpt4_amd_tokenize(ctx.ptr, text, int(add_bos), out, cap)
+        return list(out[:n])
+
+    def amd_decode_loop(self, ctx, steps: int):
+        toks = np.zeros(steps, np.int32)
+        ms = ctypes.c_float()
+        rc = self.library.minigpt4_amd_decode_loop(ctx.ptr, steps, toks.ctypes.data_as(INT_PTR), ctypes.byref(ms))
+        if rc:
+            raise RuntimeError("decode_loop failed: " + self.library.minigpt4_amd_last_error().decode())
+        return toks, float(ms.value)
+
+    def amd_profile_decode(self, ctx, steps: int):
+        ms = (ctypes.c_double * 20)()
+        by = (ctypes.c_double * 20)()
+        ln = (ctypes.c_long * 20)()
+        other = ctypes.c_double()
+        rc = self.library.minigpt4_amd_profile_decode(ctx.ptr, steps, ms, by, ln, ctypes.byref(other))
+        if rc:
+            raise RuntimeError("profile_decode failed")
+        return {i: {"ms": ms[i], "bytes": by[i], "launches": ln[i]} for i in range(20) if ln[i]}, float(other.value)
+
+    def amd_test_mul_mat(self, ggml_type: int, raw_w: np.ndarray, n_in: int, n_out: int, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, n_in)
+        raw_w = np.ascontiguousarray(raw_w)
+        y = np.empty((x.shape[0], n_out), np.float32)
+        rc = self.library.minigpt4_amd_test_mul_mat(ggml_type, raw_w.ctypes.data_as(VOID_PTR), n_in, n_out, x.ctypes.data_as(FLOAT_PTR), x.shape[0],
+                                                    y.ctypes.data_as(FLOAT_PTR))
+        if rc:
+            raise RuntimeError(f"test_mul_mat rc={rc}: " + self.library.minigpt4_amd_last_error().decode())
+        return y
+
+    def amd_test_quantize(self, x: np.ndarray, rms_w: Optional[np.ndarray] = None):
+        x = np.ascontiguousarray(x, np.float32)
+        N, K = x.shape
+        q8k, dk, bs = np.empty((N, K), np.int8), np.empty((N, K // 256), np.float32), np.empty((N, K // 16), np.int16)
+        q80, d0 = np.empty((N, K), np.int8), np.empty((N, K // 32), np.float32)
+        w = None if rms_w is None else np.ascontiguousarray(rms_w, np.float32)
+        rc = self.library.minigpt4_amd_test_quantize(x.ctypes.data_as(FLOAT_PTR), None if w is None else w.ctypes.data_as(FLOAT_PTR), N, K,
+                                                     q8k.ctypes.data_as(VOID_PTR), dk.ctypes.data_as(VOID_PTR), bs.ctypes.data_as(VOID_PTR),
+                                                     q80.ctypes.data_as(VOID_PTR), d0.ctypes.data_as(VOID_PTR))
+        if rc:
+            raise RuntimeError(f"test_quantize rc={rc}")
+        return q8k, dk, bs, q80, d0
+
+    def amd_test_gemm_f16(self, A: np.ndarray, W: np.ndarray, bias: Optional[np.ndarray] = None, gelu: bool = False) -> np.ndarray:
+        A = np.ascontiguousarray(A, np.float32)
+        W = np.ascontiguousarray(W, np.float32)
+        M, K = A.shape
+        N = W.shape[0]
+        C = np.empty((M, N), np.float32)
+        b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+        rc = self.library.minigpt4_amd_test_gemm_f16(A.ctypes.data_as(FLOAT_PTR), W.ctypes.data_as(FLOAT_PTR), None if b is None else b.ctypes.data_as(FLOAT_PTR),
+                                                     M, N, K, int(gelu), C.ctypes.data_as(FLOAT_PTR))
+        if rc:
+            raise RuntimeError(f"test_gemm_f16 rc={rc}")
+        return C
+
+    def amd_sample_logits(self, logits: np.ndarray, seed: int, temp=0.8, top_k=40, top_p=0.9, tfs_z=1.0, typical_p=1.0, mirostat=0, mirostat_tau=5.0,
+                          mirostat_eta=1.0) -> int:
+        lg = np.ascontiguousarray(logits, np.float32)
+        return int(self.library.minigpt4_amd_sample_logits(lg.ctypes.data_as(FLOAT_PTR), lg.size, seed, temp, top_k, top_p, tfs_z, typical_p, mirostat,
+                                                           mirostat_tau, mirostat_eta))
+
+
+def default_library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libminigpt4.so")
+
+
+def load_library() -> MiniGPT4SharedLibrary:
+    """Reference `load_library` (:525-566) searches a few relative paths for libminigpt4.so; here the in-tree build is used."""
+    path = os.environ.get("MINIGPT4_LIBRARY", default_library_path())
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    return MiniGPT4SharedLibrary(path)
+
+
+def image_to_array(image, size: int = 224) -> np.ndarray:
+    """Preprocessing of the reference's ChatBot (:589-600, 682-687) without torchvision: RGB, bicubic resize to 224x224, /255,
+    CLIP mean/std, HWC -> CHW float32."""
+    from PIL import Image
+    if not isinstance(image, Image.Image):
+        image = Image.open(image)
+    image = image.convert("RGB").resize((size, size), Image.BICUBIC)
+    a = np.asarray(image, np.float32) / 255.0
+    a = (a - np.asarray(CLIP_MEAN, np.float32)) / np.asarray(CLIP_STD, np.float32)
+    return np.ascontiguousarray(a.transpose(2, 0, 1))
+
+
+def array_to_image_struct(chw: np.ndarray) -> MiniGPT4Image:
+    chw = np.ascontiguousarray(chw, np.float32)
+    assert chw.shape == (3, 224, 224)
+    img = MiniGPT4Image(chw.ctypes.data_as(VOID_PTR), 224, 224, 3, int(ImageFormat.F32))
+    img._keepalive = chw
+    return img
+
+
+class MiniGPT4ChatBot:
+    """Reference class of the same name (:568-689): upload_image / generate / reset_chat."""
+
+    def __init__(self, model_path: str, llm_model_path: str, verbosity: Verbosity = Verbosity.SILENT, n_threads: int = 0, library: Optional[MiniGPT4SharedLibrary] = None,
+                 n_ctx: int = 2048, n_batch: int = 512, seed: int = 1337):
+        self.library = library or load_library()
+        self.ctx = self.library.minigpt4_model_load(model_path, llm_model_path, int(verbosity), seed=seed, n_ctx=n_ctx, n_batch=n_batch)
+        self.n_threads = n_threads
+        self.embedding: Optional[MiniGPT4Embedding] = None
+        self.is_image_uploaded = False
+
+    def free(self):
+        if self.ctx is not None and self.ctx.ptr:
+            self.library.minigpt4_free(self.ctx)
+
+    def generate(self, message: str, limit: int = 1024, temp: float = 0.8, top_k: int = 40, top_p: float = 0.9, tfs_z: float = 1.0, typical_p: float = 1.0,
+                 repeat_last_n: int = 64, repeat_penalty: float = 1.1, alpha_presence: float = 1.0, alpha_frequency: float = 1.0, mirostat: int = 0,
+                 mirostat_tau: float = 5.0, mirostat_eta: float = 1.0, penalize_nl: int = 1, ignore_eos: bool = False) -> Iterator[str]:
+        if self.is_image_uploaded:
+            self.library.minigpt4_begin_chat_image(self.ctx, self.embedding, message, self.n_threads)
+            self.is_image_uploaded = False
+        else:
+            self.library.minigpt4_begin_chat(self.ctx, message, self.n_threads)
+        chat = ""
+        for _ in range(limit):
+            token = self.library.minigpt4_end_chat_image(self.ctx, self.n_threads, temp, top_k, top_p, tfs_z, typical_p, repeat_last_n, repeat_penalty,
+                                                          alpha_presence, alpha_frequency, mirostat, mirostat_tau, mirostat_eta, penalize_nl)
+            chat += token
+            if not ignore_eos:
+                if self.library.minigpt4_contains_eos_token(token):
+                    continue
+                if self.library.minigpt4_is_eos(chat):
+                    break
+            yield token
+
+    def reset_chat(self):
+        self.is_image_uploaded = False
+        if self.embedding is not None:
+            self.library.minigpt4_free_embedding(self.embedding)
+            self.embedding = None
+        self.library.minigpt4_reset_chat(self.ctx)
+        self.library.minigpt4_system_prompt(self.ctx, self.n_threads)
+
+    def upload_image(self, image):
+        self.reset_chat()
+        chw = image if isinstance(image, np.ndarray) else image_to_array(image)
+        self.embedding = self.library.minigpt4_encode_image(self.ctx, array_to_image_struct(chw), self.n_threads)
+        self.is_image_uploaded = True

@@ -206,8 +206,28 @@ def synth_vocab(n_vocab: int) -> List[Tuple[bytes, float]]:
 
 
 # =========================================================================== format B writer / reader
+class _Pool:
+    """Gaussian pool for bench-size files: tensors are cut from one 16M-sample pool at rotating offsets
+    (same statistics, ~20x faster than drawing every weight)."""
+
+    def __init__(self, rng, n=1 << 24):
+        self.p = rng.standard_normal(n, dtype=np.float32)
+        self.off = 0
+
+    def take(self, n: int) -> np.ndarray:
+        out = np.empty(n, np.float32)
+        pos = 0
+        while pos < n:
+            self.off = (self.off * 7 + 104729) % (self.p.size - 1)
+            k = min(n - pos, self.p.size - self.off)
+            out[pos:pos + k] = self.p[self.off:self.off + k]
+            pos += k
+        return out
+
+
 def write_llm_file(path: str, cfg: LLMConfig, seed: int = 1234, std: float = 0.02,
-                   unique_layers: Optional[int] = None, vocab: Optional[List[Tuple[bytes, float]]] = None) -> None:
+                   unique_layers: Optional[int] = None, vocab: Optional[List[Tuple[bytes, float]]] = None,
+                   fast: bool = False) -> None:
     """Write a GGJT-v3 file with Gaussian weights.  `unique_layers` < n_layer re-uses the quantised bytes
     of layer (i % unique_layers) for layer i (bench-size files: same byte volume, generation in seconds)."""
     rng = np.random.default_rng(seed)
@@ -216,6 +236,7 @@ def write_llm_file(path: str, cfg: LLMConfig, seed: int = 1234, std: float = 0.0
     assert len(vocab) == cfg.n_vocab
     uniq = unique_layers if unique_layers else cfg.n_layer
     cache: Dict[Tuple[str, int], np.ndarray] = {}
+    pool = _Pool(rng) if fast else None
 
     def gen(name: str) -> np.ndarray:
         ne, t = shapes[name], types[name]
@@ -228,6 +249,9 @@ def write_llm_file(path: str, cfg: LLMConfig, seed: int = 1234, std: float = 0.0
                 return cache[key]
         if name.endswith("norm.weight"):
             x = (1.0 + 0.02 * rng.standard_normal(n)).astype(np.float32)
+        elif pool is not None:
+            x = pool.take(n)
+            x *= np.float32(std)
         else:
             x = (std * rng.standard_normal(n, dtype=np.float32)).astype(np.float32)
         raw = Q.quantize(t, x)
@@ -321,12 +345,16 @@ def read_llm_file(path: str) -> LLMFile:
 
 # =========================================================================== format A writer / reader
 def vision_state(cfg: VisionConfig, seed: int = 4321, std: float = 0.02,
-                 unique_blocks: Optional[int] = None) -> Dict[str, Dict[str, np.ndarray]]:
+                 unique_blocks: Optional[int] = None, fast: bool = False) -> Dict[str, Dict[str, np.ndarray]]:
     """Synthetic state dicts (torch shapes, float32/int64) for the 5 sub-models, in convert.py's order."""
     rng = np.random.default_rng(seed)
     D, M = cfg.embed_dim, cfg.mlp_dim
 
+    pool = _Pool(rng) if fast else None
+
     def w(*shape):
+        if pool is not None:
+            return (pool.take(int(np.prod(shape))) * np.float32(std)).reshape(shape)
         return (std * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
 
     def g(n):
@@ -402,9 +430,9 @@ def qformer_config(cfg: VisionConfig) -> dict:
 
 def write_vision_file(path: str, cfg: VisionConfig, seed: int = 4321, std: float = 0.02,
                       unique_blocks: Optional[int] = None,
-                      state: Optional[Dict[str, Dict[str, np.ndarray]]] = None) -> None:
+                      state: Optional[Dict[str, Dict[str, np.ndarray]]] = None, fast: bool = False) -> None:
     """Byte layout of convert.py:146-180 (`write_file`) + :74-144 (`write_model`), incl. its dtype rule."""
-    state = state if state is not None else vision_state(cfg, seed, std, unique_blocks)
+    state = state if state is not None else vision_state(cfg, seed, std, unique_blocks, fast)
     ftype_id = 0 if cfg.ftype == "f16" else 1
     with open(path, "wb") as f:
         f.write(b"ggml")
@@ -420,13 +448,17 @@ def write_vision_file(path: str, cfg: VisionConfig, seed: int = 4321, std: float
             f.write(nm)
             f.write(struct.pack("i", len(model)))
             arrays = {}
+            conv_cache = {}
             for lname, arr in model.items():
+                src_id = id(arr)
                 arr = np.squeeze(np.asarray(arr))
                 shape = list(reversed(arr.shape))
                 dt = None
                 if cfg.ftype == "f16":
                     if model_name not in ("query_tokens", "ln_vision") and lname.endswith("weight") and len(shape) >= 2:
-                        arr, dt = arr.astype(np.float16), Q.MG4_F16
+                        if src_id not in conv_cache:
+                            conv_cache[src_id] = arr.astype(np.float16)
+                        arr, dt = conv_cache[src_id], Q.MG4_F16
                 elif lname == "patch_embed.proj.weight":
                     arr, dt = arr.astype(np.float16), Q.MG4_F16
                 if dt is None:

@@ -208,7 +208,7 @@ def tokenize(vocab: List[Tuple[bytes, float]], text: bytes, add_bos: bool = True
     adjacent pair with the highest vocab score (ties: leftmost), then map leftovers byte-wise (id = byte + 3)."""
     tok2id = {}
     for i, (p, _) in enumerate(vocab):
-        tok2id.setdefault(p, i)
+        tok2id[p] = i  # later duplicates win, as llama.cpp's token_to_id map is filled
     out: List[int] = [1] if add_bos else []
     if not text:
         return out
@@ -277,7 +277,7 @@ class MT19937:
 
 
 def _softmax_sorted(logits: np.ndarray) -> np.ndarray:
-    mx = logits[0]
+    mx = logits[0]  # llama_sample_softmax uses candidates[0].logit as the maximum once `sorted` is set
     p = np.exp((logits - mx).astype(np.float32)).astype(np.float32)
     s = np.float32(0)
     for v in p:  # sequential fp32 sum, as llama_sample_softmax does
@@ -330,9 +330,7 @@ def sample(logits: np.ndarray, rng: Optional[MT19937], temp: float, top_k: int, 
                 last = i + 1
                 break
         keep = idx[:last]
-        ids, lg = ids[keep], lg[keep]
-        order = np.argsort(-lg, kind="stable")  # later softmax re-sorts when not marked sorted
-        ids, lg = ids[order], lg[order]
+        ids, lg = ids[keep], lg[keep]  # order is NOT restored and `sorted` stays set at this llama.cpp revision
     # top_p
     if top_p < 1.0:
         p = _softmax_sorted(lg)

@@ -1,0 +1,58 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import _pkg  # noqa: E402
+
+_pkg.load_package()
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def tmpdir_models(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("models"))
+
+
+@pytest.fixture(scope="session")
+def lib():
+    from minigpt4_cpp_amd import minigpt4_library as ML
+    so = ML.default_library_path()
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    return ML.load_library()
+
+
+@pytest.fixture(scope="session")
+def gpu_lib(lib):
+    if lib.amd_device_count() <= 0:
+        pytest.fail("GPU test selected but no HIP device is visible (the engine has no CPU fallback)")
+    return lib
+
+
+@pytest.fixture(scope="session")
+def tiny_files(tmpdir_models):
+    """(vision_path, {wtype: llm_path}) -- small models in the reference's two file formats."""
+    from minigpt4_cpp_amd import modelgen as G
+    vp = os.path.join(tmpdir_models, "vision_tiny.bin")
+    G.write_vision_file(vp, G.tiny_vision(n_embd_llm=4096), seed=3, std=0.05)
+    made = {}
+
+    def llm(wtype, mix="none", n_vocab=512, output_type=None, tok_type=None):
+        key = (wtype, mix, n_vocab, output_type, tok_type)
+        if key not in made:
+            p = os.path.join(tmpdir_models, f"llm_{wtype}_{mix}_{n_vocab}_{output_type}_{tok_type}.bin")
+            G.write_llm_file(p, G.tiny_llm(wtype=wtype, n_embd=256, n_layer=2, n_head=4, n_vocab=n_vocab, mix=mix, output_type=output_type,
+                                           tok_type=tok_type), seed=1, std=0.05)
+            made[key] = p
+        return made[key]
+    return vp, llm
