@@ -267,6 +267,56 @@ int minigpt4_amd_test_gemm_f16(const float *A, const float *W, const float *bias
     });
 }
 
+// Micro-benchmark of the decode mat-vec kernels on synthetic planes (random quant bytes, sane fp16 scales).  `n_sets` distinct weight sets
+// are cycled so the 256 MiB Infinity Cache cannot serve repeats.  variant 0 = k_mul_mat per matrix, 1 = persistent-wave v2 (fused set).
+int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int variant, int iters, int n_sets, int waves_per_cu, float *us_per_launch, double *bytes_per_launch) {
+    if (!qweight_supported(ggml_type) || rows <= 0 || cols <= 0 || cols % gt_block(ggml_type) || n_mat < 1 || n_mat > 3 || iters < 1 || n_sets < 1) return 1;
+    if (device_count_noexcept() <= 0) return 2;
+    return guarded(3, [&]() -> int {
+        hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0));
+        set_matvec_tuning(waves_per_cu, prop.multiProcessorCount);
+        QWeight plan; const size_t need = plan_qweight(ggml_type, rows, cols, plan, nullptr);
+        std::vector<std::unique_ptr<DevBuf>> keep;
+        std::vector<QWeight> W((size_t)n_sets * n_mat);
+        for (size_t i = 0; i < W.size(); i++) {
+            keep.emplace_back(new DevBuf(need));
+            uint8_t *base = (uint8_t *)keep.back()->p;
+            plan_qweight(ggml_type, rows, cols, W[i], base);
+            launch_fill_random(base, need, (unsigned)(i * 7919 + 13), nullptr);
+            const size_t n = (size_t)rows * cols;
+            if (W[i].sc) { const size_t sc_bytes = (size_t)((W[i].d ? W[i].d : base + need) - W[i].sc);
+                if (ggml_type == GT_Q4_K || ggml_type == GT_Q5_K) { /* header: d, dmin fp16 then 12 scale bytes: make d/dmin sane, keep scales random */
+                    launch_fill_u16((void *)W[i].sc, std::min(sc_bytes, n / 256 * 16) / 2, 0x1C00, nullptr); }
+                else if (ggml_type != GT_Q6_K) launch_fill_u16((void *)W[i].sc, std::min(sc_bytes, n / 32 * 4) / 2, 0x1C00, nullptr); }
+            if (W[i].d) launch_fill_u16((void *)W[i].d, n / 256, 0x1C00, nullptr);
+            if (ggml_type == GT_F16) launch_fill_u16(base, n, 0x2E66, nullptr);
+            if (ggml_type == GT_F32) { std::vector<float> h(n, 0.01f); HIP_CHECK(hipMemcpy(base, h.data(), n * 4, hipMemcpyHostToDevice)); }
+        }
+        ActQ A; alloc_act(A, keep, 1, (size_t)cols);
+        DevBuf dx((size_t)cols * 4), dy((size_t)rows * 4 * 3);
+        { std::vector<float> hx((size_t)cols); for (int i = 0; i < cols; i++) hx[(size_t)i] = (float)((i * 37 % 201) - 100) / 64.0f; HIP_CHECK(hipMemcpy(dx.p, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); }
+        launch_rms_quant(dx.as<float>(), nullptr, 1, cols, A, act_mask_for(ggml_type), nullptr);
+        auto run = [&](int set) {
+            const QWeight *Wp[3]; float *Yp[3];
+            for (int m = 0; m < n_mat; m++) { Wp[m] = &W[(size_t)set * n_mat + m]; Yp[m] = dy.as<float>() + (size_t)m * rows; }
+            if (variant == 1 && launch_matvec_set(Wp, Yp, nullptr, n_mat, A, nullptr)) return;
+            for (int m = 0; m < n_mat; m++) launch_mul_mat(*Wp[m], A, 1, Yp[m], rows, nullptr, nullptr);
+        };
+        for (int i = 0; i < std::min(n_sets, 4); i++) run(i);
+        HIP_CHECK(hipDeviceSynchronize());
+        hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+        HIP_CHECK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; i++) run(i % n_sets);
+        HIP_CHECK(hipEventRecord(b, nullptr));
+        HIP_CHECK(hipDeviceSynchronize());
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        if (us_per_launch) *us_per_launch = ms * 1e3f / (float)iters;
+        if (bytes_per_launch) *bytes_per_launch = (double)gt_nbytes(ggml_type, (size_t)rows * cols) * n_mat;
+        return 0;
+    });
+}
+
 // ---- host-only logic -----------------------------------------------------------------------------------------------------------
 struct MiniGPT4Vocab { LLMFile f; Tokenizer t; };
 struct MiniGPT4Vocab *minigpt4_amd_vocab_load(const char *llm_path) {

@@ -62,6 +62,8 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     n_batch_ = n_batch > 0 ? n_batch : 512;
     max_rows_ = std::max(n_batch_, 32);
     use_graph_ = !(getenv("MINIGPT4_NO_GRAPH") && atoi(getenv("MINIGPT4_NO_GRAPH")));
+    use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
+    if (getenv("MINIGPT4_MV_WAVES")) set_matvec_tuning(atoi(getenv("MINIGPT4_MV_WAVES")), prop.multiProcessorCount); else set_matvec_tuning(0, prop.multiProcessorCount);
     sampler_.seed(seed);
     auto t0 = std::chrono::steady_clock::now();
     if (int e = load_llm(llm_path)) return e;
@@ -343,16 +345,27 @@ void Engine::alloc_buffers() {
 // ====================================================================================================================
 // language path
 // ====================================================================================================================
-void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s) {
+// One launch for 1..3 same-shape matrices when decoding (v2 persistent-wave kernel); otherwise one k_mul_mat launch per matrix.
+void Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s) {
+    ProfEv ev{};
     if (prof_on_) {
-        ProfEv ev; HIP_CHECK(hipEventCreate(&ev.a)); HIP_CHECK(hipEventCreate(&ev.b)); ev.type = W.type; ev.bytes = (double)W.bytes;
+        HIP_CHECK(hipEventCreate(&ev.a)); HIP_CHECK(hipEventCreate(&ev.b)); ev.type = W[0]->type; ev.bytes = 0;
+        for (int i = 0; i < n; i++) ev.bytes += (double)W[i]->bytes;
         HIP_CHECK(hipEventRecord(ev.a, s));
-        launch_mul_mat(W, act_, N, y, ldy, residual, s);
-        HIP_CHECK(hipEventRecord(ev.b, s));
-        prof_events_.push_back(ev);
-        return;
     }
-    launch_mul_mat(W, act_, N, y, ldy, residual, s);
+    bool same = true;
+    for (int i = 1; i < n; i++) same = same && W[i]->type == W[0]->type && W[i]->rows == W[0]->rows && W[i]->cols == W[0]->cols;
+    if (!(N == 1 && use_v2_ && same && launch_matvec_set(W, y, res, n, act_, s))) {
+        for (int i = 0; i < n; i++) {
+            const QWeight *Wp[1] = {W[i]}; float *Yp[1] = {y[i]}; const float *Rp[1] = {res ? res[i] : nullptr};
+            if (!(N == 1 && use_v2_ && launch_matvec_set(Wp, Yp, Rp, 1, act_, s))) launch_mul_mat(*W[i], act_, N, y[i], ldy, res ? res[i] : nullptr, s);
+        }
+    }
+    if (prof_on_) { HIP_CHECK(hipEventRecord(ev.b, s)); prof_events_.push_back(ev); }
+}
+void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s) {
+    const QWeight *Wp[1] = {&W}; float *Yp[1] = {y}; const float *Rp[1] = {residual};
+    mul_mat_set(Wp, Yp, Rp, 1, N, ldy, s);
 }
 
 // Enqueue one forward pass for N rows already described by d_tokens_ (from_tokens) or x_ (embeddings), at position *d_npast_.
@@ -364,16 +377,17 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s) {
         const LayerW &L = layers_[il];
         __half *kc = kc_ + il * C * E, *vc = vc_ + il * C * E;
         launch_rms_quant(x_, L.attn_norm, N, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s);
-        mul_mat(L.wq, N, q_, E, nullptr, s);
-        mul_mat(L.wk, N, k_, E, nullptr, s);
-        mul_mat(L.wv, N, v_, E, nullptr, s);
+        {
+            const QWeight *W3[3] = {&L.wq, &L.wk, &L.wv}; float *Y3[3] = {q_, k_, v_};
+            if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s);
+            else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s); mul_mat(L.wv, N, v_, E, nullptr, s); }
+        }
         launch_rope_kv(q_, k_, v_, N, H, hd, d_npast_, cos_, sin_, kc, vc, s);
         launch_attn_llm(q_, kc, vc, N, H, hd, d_npast_, n_ctx_, tabs_, att_, s);
         launch_silu_mul_quant(att_, nullptr, N, E, act_, act_mask_for(L.wo.type), tabs_, s);
         mul_mat(L.wo, N, x_, E, x_, s);
         launch_rms_quant(x_, L.ffn_norm, N, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s);
-        mul_mat(L.w1, N, h1_, F, nullptr, s);
-        mul_mat(L.w3, N, h3_, F, nullptr, s);
+        { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; mul_mat_set(W2, Y2, nullptr, 2, N, F, s); }
         launch_silu_mul_quant(h1_, h3_, N, F, act_, act_mask_for(L.w2.type), tabs_, s);
         mul_mat(L.w2, N, x_, E, x_, s);
     }

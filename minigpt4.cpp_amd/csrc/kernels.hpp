@@ -23,6 +23,10 @@ void launch_silu_mul_quant(const float *a, const float *b, int N, int K, const A
 // ---- quantised mat-mul: y[t][r] = W[r] . act[t]  (+ residual[t][r]) ------------------------------------------------
 void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s);
 
+// decode (N = 1) persistent-wave mat-vec over 1..3 same-type, same-shape matrices (wq|wk|wv, w1|w3); false -> caller falls back to launch_mul_mat
+bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s);
+void set_matvec_tuning(int waves_per_cu, int cus);
+
 // ---- token embedding gather (raw ggml rows, dequantised to f32) -----------------------------------------------------
 void launch_get_rows(int type, const uint8_t *raw_table, int K, const int *tokens, int N, float *out, hipStream_t s);
 
@@ -36,6 +40,8 @@ void launch_attn_llm(const float *q, const __half *kcache, const __half *vcache,
 void launch_argmax(const float *logits, int n, int *out, hipStream_t s);
 void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);
 void launch_set_int(int *p, int v, hipStream_t s);
+void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s);
+void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s);
 void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s);
 
 // ---- vision tower -----------------------------------------------------------------------------------------------------

@@ -6,6 +6,8 @@
 // exact int32 (v_dot4_i32_i8), block results are scaled and accumulated in fp32.  See DESIGN.md "Numerics".
 #include "kernels.hpp"
 
+#include <algorithm>
+
 namespace mg4 {
 
 // =====================================================================================================================
@@ -352,6 +354,118 @@ static void launch_mul_mat_t(const QWeight &W, const ActQ &A, int N, float *y, i
         hipLaunchKernelGGL((k_mul_mat<T, R, TN>), grid, dim3(256), 0, s, W, A, N, y, ldy, residual);
     }
 }
+// =====================================================================================================================
+// Decode mat-vec, v2: persistent waves.  The launch covers up to 3 matrices of one type and one K (wq|wk|wv, w1|w3) as one
+// concatenated row space.  A wave walks row groups g = wave, wave + n_waves, ...; each lane owns NU fixed units of a row
+// (u = lane + 64 i), keeps their activation units in registers for the whole kernel, and software-pipelines the weight
+// stream: the R x NU x (2-3) loads of the next row group are issued before the current group's dot products (plain global
+// loads straight to VGPRs, counted vmcnt waits by the compiler; no LDS -- the weights are read once and not shared).
+// =====================================================================================================================
+struct MatSet {
+    QWeight w[3];
+    float *y[3];
+    const float *res[3];
+    int n;            // matrices
+    int rows_each;    // rows of each matrix
+};
+
+template <int T, int NU, int R>
+__global__ __launch_bounds__(256) void k_matvec_v2(const MatSet ms, const ActQ A, const int n_groups, const int n_waves) {
+    using X = Tr<T>;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int K = ms.w[0].cols, U = K / X::EPU, rows_each = ms.rows_each, total_rows = ms.n * rows_each;
+    int uc[NU]; bool ok[NU];
+#pragma unroll
+    for (int i = 0; i < NU; i++) { const int u = lane + 64 * i; ok[i] = u < U; uc[i] = ok[i] ? u : 0; }
+    typename X::AU a[NU];
+#pragma unroll
+    for (int i = 0; i < NU; i++) X::loada(A, 0, K, uc[i], a[i]);
+    typename X::WU wa[R][NU], wb[R][NU];
+    auto fetch = [&](int g, typename X::WU (&w)[R][NU]) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int row = min(g * R + r, total_rows - 1);
+            const int m = row / rows_each, lr = row - m * rows_each;
+            const QWeight &W = ms.w[m];
+#pragma unroll
+            for (int i = 0; i < NU; i++) X::loadw(W, (size_t)lr * U + uc[i], w[r][i]);
+        }
+    };
+    auto consume = [&](int g, typename X::WU (&w)[R][NU]) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NU; i++) { float c = acc; X::dot(w[r][i], a[i], c); acc = ok[i] ? c : acc; }
+            acc = wave_sum(acc);
+            const int row = g * R + r;
+            if (lane == 0 && row < total_rows) {
+                const int m = row / rows_each, lr = row - m * rows_each;
+                ms.y[m][lr] = ms.res[m] ? acc + ms.res[m][lr] : acc;
+            }
+        }
+    };
+    int g = wave;
+    if (g >= n_groups) return;
+    fetch(g, wa);
+    while (true) {
+        const int g1 = g + n_waves;
+        if (g1 < n_groups) fetch(g1, wb);
+        consume(g, wa);
+        if (g1 >= n_groups) break;
+        const int g2 = g1 + n_waves;
+        if (g2 < n_groups) fetch(g2, wa);
+        consume(g1, wb);
+        if (g2 >= n_groups) break;
+        g = g2;
+    }
+}
+
+static int g_mv_waves_per_cu = 8;
+static int g_mv_cus = 256;
+void set_matvec_tuning(int waves_per_cu, int cus) { if (waves_per_cu > 0) g_mv_waves_per_cu = waves_per_cu; if (cus > 0) g_mv_cus = cus; }
+
+template <int T, int NU, int R>
+static void launch_v2_t(const MatSet &ms, const ActQ &A, hipStream_t s) {
+    const int total_rows = ms.n * ms.rows_each;
+    const int n_groups = (total_rows + R - 1) / R;
+    int n_waves = std::min(n_groups, g_mv_cus * g_mv_waves_per_cu);
+    n_waves = (n_waves + 3) & ~3;
+    hipLaunchKernelGGL((k_matvec_v2<T, NU, R>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, s, ms, A, n_groups, n_waves);
+}
+template <int T>
+static bool launch_v2_type(const MatSet &ms, const ActQ &A, hipStream_t s) {
+    const int U = ms.w[0].cols / Tr<T>::EPU;
+    const int nu = (U + 63) / 64;
+    switch (nu) {
+    case 1: launch_v2_t<T, 1, 4>(ms, A, s); return true;
+    case 2: launch_v2_t<T, 2, 2>(ms, A, s); return true;
+    case 3: launch_v2_t<T, 3, 2>(ms, A, s); return true;
+    case 4: launch_v2_t<T, 4, 2>(ms, A, s); return true;
+    case 5: launch_v2_t<T, 5, 1>(ms, A, s); return true;
+    case 6: launch_v2_t<T, 6, 1>(ms, A, s); return true;
+    case 7: launch_v2_t<T, 7, 1>(ms, A, s); return true;
+    default: return false;
+    }
+}
+// Decode (N = 1) mat-vec over 1..3 same-type, same-shape matrices.  Returns false when the shape is outside the v2 kernel's range.
+bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s) {
+    MatSet ms{};
+    ms.n = n; ms.rows_each = W[0]->rows;
+    for (int i = 0; i < n; i++) { if (W[i]->type != W[0]->type || W[i]->rows != W[0]->rows || W[i]->cols != W[0]->cols) return false; ms.w[i] = *W[i]; ms.y[i] = y[i]; ms.res[i] = residual ? residual[i] : nullptr; }
+    switch (W[0]->type) {
+    case GT_Q4_0: return launch_v2_type<GT_Q4_0>(ms, A, s);
+    case GT_Q4_1: return launch_v2_type<GT_Q4_1>(ms, A, s);
+    case GT_Q5_0: return launch_v2_type<GT_Q5_0>(ms, A, s);
+    case GT_Q5_1: return launch_v2_type<GT_Q5_1>(ms, A, s);
+    case GT_Q4_K: return launch_v2_type<GT_Q4_K>(ms, A, s);
+    case GT_Q5_K: return launch_v2_type<GT_Q5_K>(ms, A, s);
+    case GT_Q6_K: return launch_v2_type<GT_Q6_K>(ms, A, s);
+    default: return false;   // Q8_0 / F16 / F32 rows have more units per row: served by k_mul_mat
+    }
+}
+
 void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
     switch (W.type) {
     case GT_Q4_0: launch_mul_mat_t<GT_Q4_0>(W, A, N, y, ldy, residual, s); break;
@@ -616,6 +730,15 @@ __global__ void k_add_inplace(float *__restrict__ x, const float *__restrict__ y
 }
 void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n); }
 
+__global__ void k_fill_random(unsigned *p, size_t n_words, unsigned seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u ^ seed; x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; p[i] = x; }
+}
+void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s) { hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, (unsigned *)p, bytes / 4, seed); }
+__global__ void k_fill_u16(unsigned short *p, size_t n, unsigned short v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s) { hipLaunchKernelGGL(k_fill_u16, dim3(1024), dim3(256), 0, s, (unsigned short *)p, n, v); }
 __global__ void k_set_int(int *p, int v) { *p = v; }
 void launch_set_int(int *p, int v, hipStream_t s) { hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, p, v); }
 // end of a decode step: the KV position advances and the greedy token becomes the next input (the host may overwrite it)

@@ -114,6 +114,27 @@ def test_oracle_llama_vs_float64(tiny_files, wtype, mix):
     assert _rel(o2.logits, o.logits) < 1e-5
 
 
+def test_oracle_sensitivity(tiny_files):
+    """Documents why whole-model parity is a tolerance, not bit-exactness: with ggml's int8 activation quantisation a 1e-6 relative input
+    perturbation (the size of fp32 summation-order noise) moves the oracle's OWN logits by up to ~1e-2 of their range."""
+    import refcpu as R
+    from minigpt4_cpp_amd import modelgen as G
+    _, llm = tiny_files
+    f = G.read_llm_file(llm("q4_0"))
+    tt = f.tensors["tok_embeddings.weight"]
+    table = R.dequantize_row(tt.gtype, f.raw("tok_embeddings.weight"), 512 * 256).reshape(512, 256)
+    toks = [1, 5, 300, 44, 270, 99, 400, 17, 33, 260, 301, 302]
+
+    def run(eps):
+        o = R.OracleLLM(f, n_ctx=64)
+        e = table[toks] * (1 + eps * np.random.default_rng(1).standard_normal((len(toks), 256))).astype(np.float32)
+        return o.eval_embd(e)
+    base = run(0.0)
+    amp = [(_rel(run(eps), base), eps) for eps in (1e-6, 3e-6, 1e-5, 3e-5)]
+    assert all(d < 5e-2 for d, _ in amp), amp
+    assert any(d > 50 * eps for d, eps in amp), amp      # rounding flips amplify the perturbation by orders of magnitude
+
+
 def test_oracle_vision_vs_float64(tiny_files):
     import f64ref as F
     import refcpu as R

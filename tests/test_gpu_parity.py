@@ -123,6 +123,13 @@ def test_encode_image_matches_oracle(gpu_lib, tiny_files):
         gpu_lib.minigpt4_free(ctx)
 
 
+# Whole-model tolerance.  ggml's arithmetic quantises every activation row to int8 before each mat-mul, which makes the *reference
+# arithmetic itself* discontinuous: a 1e-6 relative perturbation of the inputs (i.e. fp32 summation-order noise) flips a few int8
+# roundings and moves the oracle's own logits by ~1e-2 of their range (measured: tests/test_cpu_host.py::test_oracle_sensitivity).
+# Hence: logits within 5e-2 of the range, and identical greedy ids wherever the oracle's top-2 margin exceeds that noise.
+LOGIT_TOL = 5e-2
+
+
 @pytest.mark.parametrize("wtype,mix", [("q4_0", "none"), ("q5_k", "q5_k_m"), ("q4_1", "none"), ("q8_0", "none"), ("q6_k", "none"), ("q5_0", "none"),
                                        ("q5_1", "none"), ("q4_k", "none"), ("f16", "none")])
 def test_llm_logits_and_greedy_tokens(gpu_lib, tiny_files, wtype, mix):
@@ -138,18 +145,24 @@ def test_llm_logits_and_greedy_tokens(gpu_lib, tiny_files, wtype, mix):
         o.eval_tokens(toks[:16])
         want = o.eval_tokens(toks[16:])
         got = gpu_lib.amd_logits(ctx)
-        assert _rel(got, want) < 2e-3, _rel(got, want)
-        assert int(got.argmax()) == int(want.argmax())
-        # 24 greedy decode steps (graph-replayed on the GPU), ids identical
-        ids_gpu, ids_cpu = [], []
+        errs = [_rel(got, want)]
+        # 24 teacher-forced decode steps (graph-replayed on the GPU): both sides consume the oracle's greedy token
+        decided = agree = 0
         for _ in range(24):
-            piece = gpu_lib.minigpt4_end_chat(ctx, temp=0.0)
-            ids_gpu.append(piece)
-            tid = int(np.argmax(o.logits))
-            ids_cpu.append(b"</s>".decode() if tid == 2 else o.f.vocab[tid][0].decode("utf-8", errors="replace"))
-            o.eval_tokens([tid])
-        assert ids_gpu == ids_cpu
-        assert _rel(gpu_lib.amd_logits(ctx), o.logits) < 2e-3
+            srt = np.sort(want)
+            margin = (srt[-1] - srt[-2]) / (np.abs(want).max() + 1e-30)
+            if margin > LOGIT_TOL:
+                decided += 1
+                agree += int(got.argmax() == want.argmax())
+            tid = int(want.argmax())
+            gpu_lib.amd_eval_tokens(ctx, [tid])
+            want = o.eval_tokens([tid])
+            got = gpu_lib.amd_logits(ctx)
+            errs.append(_rel(got, want))
+        assert max(errs) < LOGIT_TOL, errs
+        assert agree == decided, (agree, decided)
+        if wtype == "f16":   # no int8 activation quantisation on this path: the whole model agrees tightly
+            assert max(errs) < 3e-3, errs
     finally:
         gpu_lib.minigpt4_free(ctx)
 
