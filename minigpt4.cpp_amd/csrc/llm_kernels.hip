@@ -19,10 +19,19 @@ __device__ __forceinline__ unsigned short f2h_bits(float f) { return __half_as_u
 __device__ __forceinline__ float f16r(float f) { return __half2float(__float2half_rn(f)); }
 __device__ __forceinline__ float tab(const __half *t, float x) { return __half2float(t[f2h_bits(x)]); }
 
+// wave64 sum on the DPP crossbar (no LDS round trips): quad_perm x2, row_half_mirror, row_mirror leave every lane of a 16-lane row with
+// the row sum; the four row sums are then combined through v_readlane.  The result is wave-uniform.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);   // row_half_mirror
+    v += dpp_f<0x140>(v);   // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
 }
 __device__ __forceinline__ int4 ld16(const void *p) { return *reinterpret_cast<const int4 *>(p); }
 
@@ -362,11 +371,12 @@ static void launch_mul_mat_t(const QWeight &W, const ActQ &A, int N, float *y, i
 // loads straight to VGPRs, counted vmcnt waits by the compiler; no LDS -- the weights are read once and not shared).
 // =====================================================================================================================
 struct MatSet {
-    QWeight w[3];
-    float *y[3];
-    const float *res[3];
-    int n;            // matrices
-    int rows_each;    // rows of each matrix
+    QWeight w0;            // matrix 0; matrix m has every plane shifted by m * dmat bytes
+    long long dmat;        // byte distance between consecutive matrices (identical for all planes)
+    float *y0; long long dy;            // outputs: y_m = y0 + m * dy
+    const float *res0; long long dres;  // optional residual inputs
+    int n;                 // matrices in the set
+    int rows_each;         // rows of each matrix
 };
 
 template <int T, int NU, int R>
@@ -374,57 +384,59 @@ __global__ __launch_bounds__(256) void k_matvec_v2(const MatSet ms, const ActQ A
     using X = Tr<T>;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int K = ms.w[0].cols, U = K / X::EPU, rows_each = ms.rows_each, total_rows = ms.n * rows_each;
+    const int K = ms.w0.cols, U = K / X::EPU, rows_each = ms.rows_each, total_rows = ms.n * rows_each;
     int uc[NU]; bool ok[NU];
 #pragma unroll
     for (int i = 0; i < NU; i++) { const int u = lane + 64 * i; ok[i] = u < U; uc[i] = ok[i] ? u : 0; }
     typename X::AU a[NU];
 #pragma unroll
     for (int i = 0; i < NU; i++) X::loada(A, 0, K, uc[i], a[i]);
-    typename X::WU wa[R][NU], wb[R][NU];
-    auto fetch = [&](int g, typename X::WU (&w)[R][NU]) {
+    // NOTE: every load of the pipeline is unconditional (indices are clamped instead of branching): a load inside an exec-masked branch
+    // makes hipcc's counted s_waitcnt fall back to (near) vmcnt(0), which drains the prefetch -- see DESIGN.md "mat-vec pipeline".
+    struct Grp { typename X::WU w[R][NU]; float res[R]; };
+    const int last_group = n_groups - 1;
+    auto fetch = [&](int g, Grp &G) {
+        g = min(g, last_group);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int row = min(g * R + r, total_rows - 1);
-            const int m = row / rows_each, lr = row - m * rows_each;
-            const QWeight &W = ms.w[m];
+            const int m = (row >= rows_each) + (row >= 2 * rows_each), lr = row - m * rows_each;
+            QWeight W = ms.w0;
+            const long long d = (long long)m * ms.dmat;
+            W.qs += d; W.qh += d; W.sc += d; W.d += d;
 #pragma unroll
-            for (int i = 0; i < NU; i++) X::loadw(W, (size_t)lr * U + uc[i], w[r][i]);
+            for (int i = 0; i < NU; i++) X::loadw(W, (size_t)lr * U + uc[i], G.w[r][i]);
+            G.res[r] = ms.res0 ? ms.res0[(long long)m * ms.dres + lr] : 0.0f;
         }
     };
-    auto consume = [&](int g, typename X::WU (&w)[R][NU]) {
+    auto consume = [&](int g, const Grp &G) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             float acc = 0.0f;
 #pragma unroll
-            for (int i = 0; i < NU; i++) { float c = acc; X::dot(w[r][i], a[i], c); acc = ok[i] ? c : acc; }
+            for (int i = 0; i < NU; i++) { float c = acc; X::dot(G.w[r][i], a[i], c); acc = ok[i] ? c : acc; }
             acc = wave_sum(acc);
             const int row = g * R + r;
             if (lane == 0 && row < total_rows) {
-                const int m = row / rows_each, lr = row - m * rows_each;
-                ms.y[m][lr] = ms.res[m] ? acc + ms.res[m][lr] : acc;
+                const int m = (row >= rows_each) + (row >= 2 * rows_each), lr = row - m * rows_each;
+                ms.y0[(long long)m * ms.dy + lr] = acc + G.res[r];
             }
         }
     };
-    int g = wave;
-    if (g >= n_groups) return;
-    fetch(g, wa);
-    while (true) {
-        const int g1 = g + n_waves;
-        if (g1 < n_groups) fetch(g1, wb);
-        consume(g, wa);
-        if (g1 >= n_groups) break;
-        const int g2 = g1 + n_waves;
-        if (g2 < n_groups) fetch(g2, wa);
-        consume(g1, wb);
-        if (g2 >= n_groups) break;
-        g = g2;
+    if (wave >= n_groups) return;
+    Grp cur, nxt;
+    fetch(wave, cur);
+#pragma unroll 2
+    for (int g = wave; g < n_groups; g += n_waves) {
+        fetch(g + n_waves, nxt);
+        consume(g, cur);
+        cur = nxt;
     }
 }
 
 static int g_mv_waves_per_cu = 8;
 static int g_mv_cus = 256;
-void set_matvec_tuning(int waves_per_cu, int cus) { if (waves_per_cu > 0) g_mv_waves_per_cu = waves_per_cu; if (cus > 0) g_mv_cus = cus; }
+void set_matvec_tuning(int waves_per_cu, int cus) { if (waves_per_cu > 0) g_mv_waves_per_cu = waves_per_cu % 100; if (cus > 0) g_mv_cus = cus; extern void set_mv_r1(int); set_mv_r1(waves_per_cu >= 100); }
 
 template <int T, int NU, int R>
 static void launch_v2_t(const MatSet &ms, const ActQ &A, hipStream_t s) {
@@ -434,10 +446,17 @@ static void launch_v2_t(const MatSet &ms, const ActQ &A, hipStream_t s) {
     n_waves = (n_waves + 3) & ~3;
     hipLaunchKernelGGL((k_matvec_v2<T, NU, R>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, s, ms, A, n_groups, n_waves);
 }
+static int g_mv_r1 = 0;
+void set_mv_r1(int v) { g_mv_r1 = v; }
 template <int T>
 static bool launch_v2_type(const MatSet &ms, const ActQ &A, hipStream_t s) {
-    const int U = ms.w[0].cols / Tr<T>::EPU;
+    const int U = ms.w0.cols / Tr<T>::EPU;
     const int nu = (U + 63) / 64;
+    if (g_mv_r1) {
+        switch (nu) {
+        case 1: launch_v2_t<T, 1, 1>(ms, A, s); return true; case 2: launch_v2_t<T, 2, 1>(ms, A, s); return true; case 3: launch_v2_t<T, 3, 1>(ms, A, s); return true;
+        case 4: launch_v2_t<T, 4, 1>(ms, A, s); return true; default: break; }
+    }
     switch (nu) {
     case 1: launch_v2_t<T, 1, 4>(ms, A, s); return true;
     case 2: launch_v2_t<T, 2, 2>(ms, A, s); return true;
@@ -449,11 +468,20 @@ static bool launch_v2_type(const MatSet &ms, const ActQ &A, hipStream_t s) {
     default: return false;
     }
 }
-// Decode (N = 1) mat-vec over 1..3 same-type, same-shape matrices.  Returns false when the shape is outside the v2 kernel's range.
+// Decode (N = 1) mat-vec over 1..3 same-type, same-shape, equally spaced matrices.  Returns false when the set is outside the v2 kernel's range.
 bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s) {
     MatSet ms{};
-    ms.n = n; ms.rows_each = W[0]->rows;
-    for (int i = 0; i < n; i++) { if (W[i]->type != W[0]->type || W[i]->rows != W[0]->rows || W[i]->cols != W[0]->cols) return false; ms.w[i] = *W[i]; ms.y[i] = y[i]; ms.res[i] = residual ? residual[i] : nullptr; }
+    ms.n = n; ms.rows_each = W[0]->rows; ms.w0 = *W[0]; ms.y0 = y[0]; ms.res0 = residual ? residual[0] : nullptr;
+    if (n > 1) {
+        ms.dmat = (long long)(W[1]->qs - W[0]->qs); ms.dy = (long long)(y[1] - y[0]); ms.dres = residual && residual[0] ? (long long)(residual[1] - residual[0]) : 0;
+        for (int i = 1; i < n; i++) {
+            if (W[i]->type != W[0]->type || W[i]->rows != W[0]->rows || W[i]->cols != W[0]->cols) return false;
+            if ((long long)(W[i]->qs - W[0]->qs) != i * ms.dmat || (W[0]->qh && (long long)(W[i]->qh - W[0]->qh) != i * ms.dmat) ||
+                (W[0]->sc && (long long)(W[i]->sc - W[0]->sc) != i * ms.dmat) || (W[0]->d && (long long)(W[i]->d - W[0]->d) != i * ms.dmat)) return false;
+            if ((long long)(y[i] - y[0]) != i * ms.dy) return false;
+            if (residual && residual[0] && (long long)(residual[i] - residual[0]) != i * ms.dres) return false;
+        }
+    }
     switch (W[0]->type) {
     case GT_Q4_0: return launch_v2_type<GT_Q4_0>(ms, A, s);
     case GT_Q4_1: return launch_v2_type<GT_Q4_1>(ms, A, s);
