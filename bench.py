@@ -81,10 +81,14 @@ def cpu_baseline(lp: str, prompt_tokens, budget_s: float = 20.0):
         native = True
     except Exception as e:   # no compiler on the box: use the prebuilt x86-64-v3 library
         log(f"[bench] native oracle build unavailable ({e}); using prebuilt")
-    f = G.read_llm_file(lp)
+    f = G.read_llm_file(lp, in_memory=True)
+    L = R.lib(native)
+    ncpu = os.cpu_count() or 1
+    if "OMP_NUM_THREADS" not in os.environ and ncpu > 64:
+        L.orc_set_threads(ncpu // 2)          # one thread per physical core on SMT hosts (the path is DRAM-bandwidth bound)
     o = R.OracleLLM(f, n_ctx=64, native=native)
-    cores = int(R.lib(native).orc_num_threads())
-    o.eval_tokens(list(prompt_tokens[:4]))   # tiny context: the sample is weight-streaming bound like the GPU metric
+    cores = int(L.orc_num_threads())
+    o.eval_tokens(list(prompt_tokens[:4]))   # untimed warm-up; tiny context: the sample is weight-streaming bound like the GPU metric
     n, t0 = 0, time.time()
     tok = 5
     while True:

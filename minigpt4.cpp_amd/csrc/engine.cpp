@@ -95,7 +95,7 @@ int Engine::load_llm(const std::string &path) {
     tok_.init(llm_);
     const int E = (int)llm_.n_embd, L = (int)llm_.n_layer, V = (int)llm_.n_vocab, F = (int)llm_.n_ff();
     const int hd = E / (int)llm_.n_head;
-    if (hd % 8 || hd > 256 || 256 % (hd / 2)) { set_last_error("unsupported head size"); return E_LoadLanguageModel; }
+    if (!attn_head_size_supported(hd)) { set_last_error("unsupported head size (supported: 32, 64, 128)"); return E_LoadLanguageModel; }
     MG4_INFO("llm: n_vocab %d n_embd %d n_head %u n_layer %d n_ff %d n_ctx %d", V, E, llm_.n_head, L, F, n_ctx_);
     auto need = [&](const std::string &name, int64_t ne0, int64_t ne1) -> const TensorMeta * {
         const TensorMeta *t = llm_.find(name);
@@ -330,6 +330,7 @@ void Engine::alloc_buffers() {
     act_.xh = takeh(B * Kmax); act_.xf = takef(B * Kmax);
     d_npast_ = reinterpret_cast<int *>(buf_arena_.take(256)); d_argmax_ = reinterpret_cast<int *>(buf_arena_.take(256));
     d_tokens_ = reinterpret_cast<int *>(buf_arena_.take(B * 4));
+    d_scratch_ = buf_arena_.take(4096);
     HIP_CHECK(hipMemset(d_npast_, 0, 4)); HIP_CHECK(hipMemset(d_argmax_, 0, 4)); HIP_CHECK(hipMemset(d_tokens_, 0, B * 4));
     HIP_CHECK(hipHostMalloc((void **)&h_argmax_, 64, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **)&h_logits_, V * 4, hipHostMallocDefault));
@@ -382,8 +383,8 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s) {
             if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s);
             else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s); mul_mat(L.wv, N, v_, E, nullptr, s); }
         }
-        launch_rope_kv(q_, k_, v_, N, H, hd, d_npast_, cos_, sin_, kc, vc, s);
-        launch_attn_llm(q_, kc, vc, N, H, hd, d_npast_, n_ctx_, tabs_, att_, s);
+        if (N == 1) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast_, n_ctx_, cos_, sin_, tabs_, att_, true, s);
+        else { launch_rope_kv(q_, k_, v_, N, H, hd, d_npast_, cos_, sin_, kc, vc, s); launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast_, n_ctx_, cos_, sin_, tabs_, att_, false, s); }
         launch_silu_mul_quant(att_, nullptr, N, E, act_, act_mask_for(L.wo.type), tabs_, s);
         mul_mat(L.wo, N, x_, E, x_, s);
         launch_rms_quant(x_, L.ffn_norm, N, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s);
@@ -394,7 +395,7 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s) {
     // only the last token's logits are kept (llama.cpp logits_all = false)
     launch_rms_quant(x_ + (size_t)(N - 1) * E, norm_, 1, E, act_, act_mask_for(output_.type), s);
     mul_mat(output_, 1, logits_, V, nullptr, s);
-    launch_argmax(logits_, V, d_argmax_, s);
+    launch_argmax(logits_, V, d_argmax_, d_scratch_, s);
     launch_advance(d_npast_, N, d_tokens_, d_argmax_, s);
     HIP_CHECK(hipMemcpyAsync(h_argmax_, d_argmax_, 4, hipMemcpyDeviceToHost, s));
 }

@@ -97,7 +97,7 @@ private:
     // activations
     float *x_ = nullptr, *q_ = nullptr, *k_ = nullptr, *v_ = nullptr, *att_ = nullptr, *h1_ = nullptr, *h3_ = nullptr, *logits_ = nullptr;
     ActQ act_;
-    int *d_npast_ = nullptr, *d_tokens_ = nullptr, *d_argmax_ = nullptr;
+    int *d_npast_ = nullptr, *d_tokens_ = nullptr, *d_argmax_ = nullptr; void *d_scratch_ = nullptr;
     int *h_argmax_ = nullptr; float *h_logits_ = nullptr; bool logits_host_valid_ = false;
     hipGraphExec_t decode_graph_ = nullptr; bool use_graph_ = true, use_v2_ = true;
     // profiling

@@ -35,9 +35,12 @@ void launch_get_rows(int type, const uint8_t *raw_table, int K, const int *token
 void launch_rope_kv(float *q, const float *k, const float *v, int N, int n_head, int hd, const int *n_past, const float *cos_tab,
                     const float *sin_tab, __half *kcache, __half *vcache, hipStream_t s);
 // out[t][h*hd+i] = softmax(K q / sqrt(hd)) V over keys 0..*n_past+t.  caches: [n_ctx][E] fp16.
-void launch_attn_llm(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int n_ctx,
-                     const Tables &tb, float *out, hipStream_t s);
-void launch_argmax(const float *logits, int n, int *out, hipStream_t s);
+// fused (decode, N == 1): q,k,v are the raw projections; RoPE of q/k and the KV append happen inside the kernel.
+// !fused: launch_rope_kv must have run (q rotated in place, caches appended).
+void launch_attn_llm(float *q, const float *k, const float *v, __half *kcache, __half *vcache, int N, int n_head, int hd, const int *n_past, int n_ctx,
+                     const float *cos_tab, const float *sin_tab, const Tables &tb, float *out, bool fused, hipStream_t s);
+bool attn_head_size_supported(int hd);
+void launch_argmax(const float *logits, int n, int *out, void *scratch /*>= 512 bytes*/, hipStream_t s);
 void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);
 void launch_set_int(int *p, int v, hipStream_t s);
 void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s);

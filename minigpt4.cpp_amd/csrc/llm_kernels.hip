@@ -33,6 +33,28 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
 }
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)dpp_i<CTRL>((int)(unsigned)b), hi = (unsigned)dpp_i<CTRL>((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ float readlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    v += dpp_d<0xB1>(v); v += dpp_d<0x4E>(v); v += dpp_d<0x141>(v); v += dpp_d<0x140>(v);
+    const long long b = __builtin_bit_cast(long long, v);
+    double r = 0.0;
+#pragma unroll
+    for (int l = 0; l < 64; l += 16) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+        r += __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+    }
+    return r;
+}
 __device__ __forceinline__ int4 ld16(const void *p) { return *reinterpret_cast<const int4 *>(p); }
 
 // =====================================================================================================================
@@ -521,18 +543,14 @@ __device__ __forceinline__ void quant_emit4(const float v[4], const bool in_rang
     if (mask & ACT_F16) { if (in_range) { __half2 h0 = __floats2half2_rn(v[0], v[1]), h1 = __floats2half2_rn(v[2], v[3]);
             uint2 o; o.x = *reinterpret_cast<unsigned *>(&h0); o.y = *reinterpret_cast<unsigned *>(&h1); *reinterpret_cast<uint2 *>(A.xh + row * K + idx) = o; } }
     if (mask & ACT_Q8K) {
-        // signed value of the FIRST element with the largest magnitude in the 256-block (ggml quantize_row_q8_K)
-        float best = 0.0f; unsigned bidx = 0xFFFFFFFFu; float bav = -1.0f;
+        // signed value of the FIRST element with the largest magnitude in the 256-block (ggml quantize_row_q8_K): the wave = one block,
+        // lanes are in element order, so it is the first maximum of the lowest lane whose local maximum equals the wave maximum.
+        float best = 0.0f, bav = -1.0f;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { const float av = fabsf(v[e]); if (av > bav) { bav = av; best = v[e]; bidx = (unsigned)(idx + e); } }
-        unsigned long long key = ((unsigned long long)__float_as_uint(bav) << 32) | (unsigned long long)(0xFFFFFFFFu - bidx);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(key, o); key = other > key ? other : key; }
-        const unsigned long long mine = ((unsigned long long)__float_as_uint(bav) << 32) | (unsigned long long)(0xFFFFFFFFu - bidx);
-        const unsigned long long m = __ballot(mine == key);
-        const int src = __ffsll((long long)m) - 1;
-        const float maxv = __shfl(best, src);
-        const float amax = __uint_as_float((unsigned)(key >> 32));
+        for (int e = 0; e < 4; e++) { const float av = fabsf(v[e]); if (av > bav) { bav = av; best = v[e]; } }
+        const float amax = wave_max(bav);
+        const unsigned long long m = __ballot(bav == amax);
+        const float maxv = readlane_f(best, __ffsll((long long)m) - 1);
         int q[4] = {0, 0, 0, 0}; float d = 0.0f;
         if (amax != 0.0f) {
             const float iscale = -128.f / maxv;
@@ -541,7 +559,7 @@ __device__ __forceinline__ void quant_emit4(const float v[4], const bool in_rang
             d = 1.0f / iscale;
         }
         int s = q[0] + q[1] + q[2] + q[3];
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+        s += dpp_i<0xB1>(s); s += dpp_i<0x4E>(s);
         if (in_range) {
             const unsigned pk = (unsigned)(q[0] & 0xFF) | ((unsigned)(q[1] & 0xFF) << 8) | ((unsigned)(q[2] & 0xFF) << 16) | ((unsigned)(q[3] & 0xFF) << 24);
             *reinterpret_cast<unsigned *>(A.q8k + row * K + idx) = pk;
@@ -551,13 +569,13 @@ __device__ __forceinline__ void quant_emit4(const float v[4], const bool in_rang
     }
     if (mask & ACT_Q80) {
         float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-        amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+        amax = fmaxf(amax, dpp_f<0xB1>(amax)); amax = fmaxf(amax, dpp_f<0x4E>(amax)); amax = fmaxf(amax, dpp_f<0x141>(amax));   // 8 lanes = one 32-block
         const float d = amax / 127.0f, id = d != 0.0f ? 1.0f / d : 0.0f;
         int q[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) q[e] = (int)rintf(v[e] * id);
         int s = q[0] + q[1] + q[2] + q[3];
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        s += dpp_i<0xB1>(s); s += dpp_i<0x4E>(s); s += dpp_i<0x141>(s);
         if (in_range) {
             const unsigned pk = (unsigned)(q[0] & 0xFF) | ((unsigned)(q[1] & 0xFF) << 8) | ((unsigned)(q[2] & 0xFF) << 16) | ((unsigned)(q[3] & 0xFF) << 24);
             *reinterpret_cast<unsigned *>(A.q80 + row * K + idx) = pk;
@@ -566,25 +584,26 @@ __device__ __forceinline__ void quant_emit4(const float v[4], const bool in_rang
     }
 }
 
-__global__ __launch_bounds__(256) void k_rms_quant(const float *__restrict__ x, const float *__restrict__ w, const int K, const ActQ A, const int mask) {
+constexpr int RQ_THREADS = 1024;
+__global__ __launch_bounds__(RQ_THREADS) void k_rms_quant(const float *__restrict__ x, const float *__restrict__ w, const int K, const ActQ A, const int mask) {
     const size_t row = blockIdx.x;
     const float *xr = x + row * K;
-    __shared__ double red[4];
-    __shared__ float s_scale;
+    __shared__ double red[RQ_THREADS / 64];
     float scale = 1.0f;
     if (w) {
         double sum = 0.0;
-        for (int i = threadIdx.x * 4; i < K; i += 1024) { const float4 v = *reinterpret_cast<const float4 *>(xr + i);
+        for (int i = threadIdx.x * 4; i < K; i += RQ_THREADS * 4) { const float4 v = *reinterpret_cast<const float4 *>(xr + i);
             sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w); }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        sum = wave_sum_d(sum);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
         __syncthreads();
-        if (threadIdx.x == 0) { const double tot = red[0] + red[1] + red[2] + red[3]; const float mean = (float)(tot / (double)K); s_scale = 1.0f / sqrtf(mean + 1e-6f); }
-        __syncthreads();
-        scale = s_scale;
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < RQ_THREADS / 64; i++) tot += red[i];
+        const float mean = (float)(tot / (double)K);
+        scale = 1.0f / sqrtf(mean + 1e-6f);
     }
-    for (int i0 = 0; i0 < K; i0 += 1024) {
+    for (int i0 = 0; i0 < K; i0 += RQ_THREADS * 4) {
         const int i = i0 + threadIdx.x * 4;
         const bool in = i < K;
         float v[4] = {0, 0, 0, 0};
@@ -595,7 +614,7 @@ __global__ __launch_bounds__(256) void k_rms_quant(const float *__restrict__ x, 
     }
 }
 void launch_rms_quant(const float *x, const float *w, int N, int K, const ActQ &A, int mask, hipStream_t s) {
-    hipLaunchKernelGGL(k_rms_quant, dim3((unsigned)N), dim3(256), 0, s, x, w, K, A, mask);
+    hipLaunchKernelGGL(k_rms_quant, dim3((unsigned)N), dim3(RQ_THREADS), 0, s, x, w, K, A, mask);
 }
 
 __global__ __launch_bounds__(256) void k_silu_mul_quant(const float *__restrict__ a, const float *__restrict__ b, const int K, const ActQ A, const int mask, const Tables tb) {
@@ -643,10 +662,11 @@ __device__ float dequant_elem(int type, const uint8_t *row, int e) {
 __global__ void k_get_rows(int type, const uint8_t *__restrict__ table, int K, size_t row_bytes, const int *__restrict__ tokens, float *__restrict__ out) {
     const int t = blockIdx.x;
     const uint8_t *row = table + (size_t)tokens[t] * row_bytes;
-    for (int e = threadIdx.x; e < K; e += blockDim.x) out[(size_t)t * K + e] = dequant_elem(type, row, e);
+    const int e = blockIdx.y * blockDim.x + threadIdx.x;
+    if (e < K) out[(size_t)t * K + e] = dequant_elem(type, row, e);
 }
 void launch_get_rows(int type, const uint8_t *raw_table, int K, const int *tokens, int N, float *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_get_rows, dim3((unsigned)N), dim3(256), 0, s, type, raw_table, K, gt_nbytes(type, (size_t)K), tokens, out);
+    hipLaunchKernelGGL(k_get_rows, dim3((unsigned)N, (unsigned)((K + 255) / 256)), dim3(256), 0, s, type, raw_table, K, gt_nbytes(type, (size_t)K), tokens, out);
 }
 
 // =====================================================================================================================
@@ -671,86 +691,161 @@ void launch_rope_kv(float *q, const float *k, const float *v, int N, int n_head,
 }
 
 // =====================================================================================================================
-// causal attention over the fp16 KV cache.  One workgroup per (head, query token).
-//   scores: one lane per key, sequential fp32 fma over the head dim (q rounded to fp16 first, like ggml's f16 mul_mat)
+// causal attention over the fp16 KV cache.  One 512-thread workgroup per (head, query token).
+//   FUSED (decode, N = 1): RoPE of q/k and the KV append happen in the prologue; the new key/value are also kept in LDS.
+//   scores : one lane per key, the whole head row in registers (HD/8 independent 16-byte loads), sequential fp32 fma over the
+//            head dim; q is rounded to fp16 first, like ggml's f16 x f32 mul_mat
 //   softmax: max, exp through the fp16 table, exact double sum, probabilities rounded to fp16
-//   PV: lane per pair of output dims, keys split over 256/(hd/2) partitions
+//   PV     : thread = (key partition, 8-dim chunk): 16-byte V loads, 4 in flight; partitions reduced through LDS
 // =====================================================================================================================
-__global__ __launch_bounds__(256) void k_attn_llm(const float *__restrict__ q, const __half *__restrict__ kc, const __half *__restrict__ vc, int E, int hd,
-                                                  const int *__restrict__ n_past, const Tables tb, float *__restrict__ out) {
+constexpr int AT_THREADS = 512;
+template <int HD, bool FUSED>
+__global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, const float *__restrict__ kin, const float *__restrict__ vin, __half *__restrict__ kc,
+                                                         __half *__restrict__ vc, int E, const int *__restrict__ n_past, const float *__restrict__ cos_tab,
+                                                         const float *__restrict__ sin_tab, const Tables tb, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int CH = HD / 8, P = AT_THREADS / CH;
     const int h = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
-    const int T = *n_past + t + 1;
-    float *sc = reinterpret_cast<float *>(smem);                 // [Tpad]
-    const int Tpad = (T + 3) & ~3;
-    __half *ph = reinterpret_cast<__half *>(sc + Tpad);          // [Tpad]
-    __half *qh = ph + ((Tpad + 7) & ~7);                         // [hd]
-    float *part = reinterpret_cast<float *>(qh + hd);            // [256/(hd/2)][hd]
-    __shared__ float s_red[8];
-    __shared__ double s_dred[4];
-    const float scale = 1.0f / sqrtf((float)hd);
-    for (int i = tid; i < hd; i += 256) qh[i] = __float2half_rn(q[(size_t)t * E + (size_t)h * hd + i]);
-    __syncthreads();
-    float mx = -INFINITY;
-    for (int j = tid; j < T; j += 256) {
-        const __half *kr = kc + (size_t)j * E + (size_t)h * hd;
-        float s = 0.0f;
-        for (int i = 0; i < hd; i += 8) {
-            const int4 kv = ld16(kr + i); const int4 qv = *reinterpret_cast<const int4 *>(qh + i);
-            const unsigned kk[4] = {(unsigned)kv.x, (unsigned)kv.y, (unsigned)kv.z, (unsigned)kv.w}, qq[4] = {(unsigned)qv.x, (unsigned)qv.y, (unsigned)qv.z, (unsigned)qv.w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) { s = fmaf(h2f_bits(kk[e] & 0xFFFF), h2f_bits(qq[e] & 0xFFFF), s); s = fmaf(h2f_bits(kk[e] >> 16), h2f_bits(qq[e] >> 16), s); }
+    const int pos = *n_past + t, T = pos + 1;
+    const int Tg = FUSED ? pos : T;                               // keys read from the global cache
+    const int Tpad = (T + 7) & ~7;
+    float *sc = reinterpret_cast<float *>(smem);                  // [Tpad]
+    __half *ph = reinterpret_cast<__half *>(sc + Tpad);           // [Tpad]
+    __half *qh = ph + Tpad;                                       // [HD]
+    __half *knew = qh + HD, *vnew = knew + HD;                    // [HD] each
+    float *part = reinterpret_cast<float *>(vnew + HD);           // [P][HD]
+    __shared__ float s_red[AT_THREADS / 64];
+    __shared__ double s_dred[AT_THREADS / 64];
+    const float scale = 1.0f / sqrtf((float)HD);
+    const size_t qo = (size_t)t * E + (size_t)h * HD;
+    if (FUSED) {
+        if (tid < HD / 2) {
+            const int i = tid;
+            const float c = cos_tab[(size_t)pos * (HD / 2) + i], s = sin_tab[(size_t)pos * (HD / 2) + i];
+            const float q0 = q[qo + 2 * i], q1 = q[qo + 2 * i + 1], k0 = kin[qo + 2 * i], k1 = kin[qo + 2 * i + 1];
+            const __half2 qr = __floats2half2_rn(q0 * c - q1 * s, q0 * s + q1 * c), kr = __floats2half2_rn(k0 * c - k1 * s, k0 * s + k1 * c);
+            const __half2 vr = __floats2half2_rn(vin[qo + 2 * i], vin[qo + 2 * i + 1]);
+            *reinterpret_cast<__half2 *>(qh + 2 * i) = qr; *reinterpret_cast<__half2 *>(knew + 2 * i) = kr; *reinterpret_cast<__half2 *>(vnew + 2 * i) = vr;
+            const size_t co = (size_t)pos * E + (size_t)h * HD + 2 * i;
+            *reinterpret_cast<__half2 *>(kc + co) = kr; *reinterpret_cast<__half2 *>(vc + co) = vr;
         }
-        s *= scale;
-        sc[j] = s; mx = fmaxf(mx, s);
+    } else {
+        for (int i = tid; i < HD; i += AT_THREADS) qh[i] = __float2half_rn(q[qo + i]);
     }
+    __syncthreads();
+    unsigned qreg[HD / 2];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    for (int i = 0; i < HD / 8; i++) { const int4 v4 = *reinterpret_cast<const int4 *>(qh + 8 * i); qreg[4 * i] = (unsigned)v4.x; qreg[4 * i + 1] = (unsigned)v4.y; qreg[4 * i + 2] = (unsigned)v4.z; qreg[4 * i + 3] = (unsigned)v4.w; }
+    auto dot_row = [&](const __half *kr) {
+        int4 kk[HD / 8];
+#pragma unroll
+        for (int i = 0; i < HD / 8; i++) kk[i] = ld16(kr + 8 * i);
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < HD / 8; i++) {
+            const unsigned w[4] = {(unsigned)kk[i].x, (unsigned)kk[i].y, (unsigned)kk[i].z, (unsigned)kk[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) { s = fmaf(h2f_bits(w[e] & 0xFFFF), h2f_bits(qreg[4 * i + e] & 0xFFFF), s); s = fmaf(h2f_bits(w[e] >> 16), h2f_bits(qreg[4 * i + e] >> 16), s); }
+        }
+        return s * scale;
+    };
+    float mx = -INFINITY;
+    for (int j = tid; j < Tg; j += AT_THREADS) { const float s = dot_row(kc + (size_t)j * E + (size_t)h * HD); sc[j] = s; mx = fmaxf(mx, s); }
+    if (FUSED && tid == AT_THREADS - 1) { const float s = dot_row(knew); sc[pos] = s; mx = fmaxf(mx, s); }
+    mx = wave_max(mx);
     if ((tid & 63) == 0) s_red[tid >> 6] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    double sum = 0.0;
-    for (int j = tid; j < T; j += 256) { const float v = tab(tb.exp, sc[j] - mx); sc[j] = v; sum += (double)v; }
+    mx = s_red[0];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    for (int i = 1; i < AT_THREADS / 64; i++) mx = fmaxf(mx, s_red[i]);
+    double sum = 0.0;
+    for (int j = tid; j < T; j += AT_THREADS) { const float v = tab(tb.exp, sc[j] - mx); sc[j] = v; sum += (double)v; }
+    sum = wave_sum_d(sum);
     if ((tid & 63) == 0) s_dred[tid >> 6] = sum;
     __syncthreads();
-    const float inv = (float)(1.0 / (s_dred[0] + s_dred[1] + s_dred[2] + s_dred[3]));
-    for (int j = tid; j < T; j += 256) ph[j] = __float2half_rn(sc[j] * inv);
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < AT_THREADS / 64; i++) tot += s_dred[i];
+    const float inv = (float)(1.0 / tot);
+    for (int j = tid; j < T; j += AT_THREADS) ph[j] = __float2half_rn(sc[j] * inv);
     __syncthreads();
-    const int hp = hd / 2, P = 256 / hp, p = tid / hp, i2 = (tid % hp) * 2;
-    float o0 = 0.0f, o1 = 0.0f;
-    if (p < P) for (int j = p; j < T; j += P) {
-        const __half2 vv = *reinterpret_cast<const __half2 *>(vc + (size_t)j * E + (size_t)h * hd + i2);
+    const int c = tid % CH, p = tid / CH;
+    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const __half *vb = vc + (size_t)h * HD + 8 * c;
+#pragma unroll 4
+    for (int j = p; j < Tg; j += P) {
+        const int4 vv = ld16(vb + (size_t)j * E);
         const float pj = __half2float(ph[j]);
-        o0 = fmaf(__low2float(vv), pj, o0); o1 = fmaf(__high2float(vv), pj, o1);
+        const unsigned w[4] = {(unsigned)vv.x, (unsigned)vv.y, (unsigned)vv.z, (unsigned)vv.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) { o[2 * e] = fmaf(h2f_bits(w[e] & 0xFFFF), pj, o[2 * e]); o[2 * e + 1] = fmaf(h2f_bits(w[e] >> 16), pj, o[2 * e + 1]); }
     }
-    if (p < P) { part[p * hd + i2] = o0; part[p * hd + i2 + 1] = o1; }
+    if (FUSED && p == P - 1) {
+        const float pj = __half2float(ph[pos]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = fmaf(__half2float(vnew[8 * c + e]), pj, o[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) part[p * HD + 8 * c + e] = o[e];
     __syncthreads();
-    for (int i = tid; i < hd; i += 256) { float s = 0.0f; for (int pp = 0; pp < P; pp++) s += part[pp * hd + i]; out[(size_t)t * E + (size_t)h * hd + i] = s; }
+    for (int i = tid; i < HD; i += AT_THREADS) { float s = 0.0f;
+#pragma unroll 8
+        for (int pp = 0; pp < P; pp++) s += part[pp * HD + i];
+        out[qo + i] = s; }
 }
-void launch_attn_llm(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int n_ctx, const Tables &tb,
-                     float *out, hipStream_t s) {
-    const int Tmax = (n_ctx + 3) & ~3;
-    const int P = 256 / (hd / 2);
-    const size_t lds = (size_t)Tmax * 4 + (size_t)((Tmax + 7) & ~7) * 2 + (size_t)hd * 2 + (size_t)P * hd * 4 + 64;
-    hipLaunchKernelGGL(k_attn_llm, dim3((unsigned)n_head, (unsigned)N), dim3(256), lds, s, q, kcache, vcache, n_head * hd, hd, n_past, tb, out);
+
+template <int HD>
+static void launch_attn_hd(float *q, const float *k, const float *v, __half *kc, __half *vc, int N, int n_head, const int *n_past, int n_ctx, const float *cos_tab,
+                           const float *sin_tab, const Tables &tb, float *out, bool fused, hipStream_t s) {
+    const int Tpad = (n_ctx + 7) & ~7;
+    const size_t lds = (size_t)Tpad * 6 + (size_t)HD * 6 + (size_t)(AT_THREADS / (HD / 8)) * HD * 4 + 64;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (fused) hipLaunchKernelGGL((k_attn_llm<HD, true>), dim3((unsigned)n_head, 1), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out);
+    else hipLaunchKernelGGL((k_attn_llm<HD, false>), dim3((unsigned)n_head, (unsigned)N), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out);
+}
+bool attn_head_size_supported(int hd) { return hd == 32 || hd == 64 || hd == 128; }
+// fused = true (N must be 1): q,k,v are the raw projections; RoPE + KV append happen inside.  fused = false: launch_rope_kv must have run.
+void launch_attn_llm(float *q, const float *k, const float *v, __half *kcache, __half *vcache, int N, int n_head, int hd, const int *n_past, int n_ctx,
+                     const float *cos_tab, const float *sin_tab, const Tables &tb, float *out, bool fused, hipStream_t s) {
+    switch (hd) {
+    case 32: launch_attn_hd<32>(q, k, v, kcache, vcache, N, n_head, n_past, n_ctx, cos_tab, sin_tab, tb, out, fused, s); break;
+    case 64: launch_attn_hd<64>(q, k, v, kcache, vcache, N, n_head, n_past, n_ctx, cos_tab, sin_tab, tb, out, fused, s); break;
+    case 128: launch_attn_hd<128>(q, k, v, kcache, vcache, N, n_head, n_past, n_ctx, cos_tab, sin_tab, tb, out, fused, s); break;
+    default: throw HipError{hipErrorInvalidValue, "unsupported head size", __FILE__, __LINE__};
+    }
 }
 
 // =====================================================================================================================
 // argmax (first maximum wins, like llama_sample_token_greedy) and small elementwise helpers
 // =====================================================================================================================
-__global__ __launch_bounds__(1024) void k_argmax(const float *__restrict__ x, int n, int *__restrict__ out) {
-    float best = -INFINITY; int bi = 0x7FFFFFFF;
-    for (int i = threadIdx.x; i < n; i += 1024) { const float v = x[i]; if (v > best) { best = v; bi = i; } }
-    __shared__ float sv[16]; __shared__ int si[16];
+constexpr int AM_BLOCKS = 64;
+__device__ __forceinline__ void argmax_combine(float &best, int &bi, float ov, int oi) { if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; } }
+__device__ __forceinline__ void argmax_wave(float &best, int &bi) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o); if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; } }
+    for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o); argmax_combine(best, bi, ov, oi); }
+}
+__global__ __launch_bounds__(256) void k_argmax_part(const float *__restrict__ x, int n, float *__restrict__ pv, int *__restrict__ pi) {
+    float best = -INFINITY; int bi = 0x7FFFFFFF;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += AM_BLOCKS * 256) { const float v = x[i]; if (v > best) { best = v; bi = i; } }
+    __shared__ float sv[4]; __shared__ int si[4];
+    argmax_wave(best, bi);
     if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
     __syncthreads();
-    if (threadIdx.x == 0) { for (int w = 1; w < 16; w++) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; } *out = bi == 0x7FFFFFFF ? 0 : bi; }
+    if (threadIdx.x == 0) { for (int w = 1; w < 4; w++) argmax_combine(best, bi, sv[w], si[w]); pv[blockIdx.x] = best; pi[blockIdx.x] = bi; }
 }
-void launch_argmax(const float *logits, int n, int *out, hipStream_t s) { hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, s, logits, n, out); }
+__global__ __launch_bounds__(64) void k_argmax_final(const float *__restrict__ pv, const int *__restrict__ pi, int *__restrict__ out) {
+    float best = pv[threadIdx.x]; int bi = pi[threadIdx.x];
+    argmax_wave(best, bi);
+    if (threadIdx.x == 0) *out = bi == 0x7FFFFFFF ? 0 : bi;
+}
+// first maximum wins, like llama_sample_token_greedy.  `scratch` holds AM_BLOCKS floats + AM_BLOCKS ints.
+void launch_argmax(const float *logits, int n, int *out, void *scratch, hipStream_t s) {
+    float *pv = static_cast<float *>(scratch); int *pi = reinterpret_cast<int *>(pv + AM_BLOCKS);
+    hipLaunchKernelGGL(k_argmax_part, dim3(AM_BLOCKS), dim3(256), 0, s, logits, n, pv, pi);
+    hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(64), 0, s, pv, pi, out);
+}
 
 __global__ void k_add_inplace(float *__restrict__ x, const float *__restrict__ y, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -307,8 +307,9 @@ class LLMFile:
         return Q.dequantize(t.gtype, self.raw(name), n).reshape(tuple(reversed(t.ne)))
 
 
-def read_llm_file(path: str) -> LLMFile:
-    mm = np.memmap(path, dtype=np.uint8, mode="r")
+def read_llm_file(path: str, in_memory: bool = False) -> LLMFile:
+    """in_memory=True reads the whole file into anonymous memory (no page-fault storm when many threads stream it)."""
+    mm = np.fromfile(path, dtype=np.uint8) if in_memory else np.memmap(path, dtype=np.uint8, mode="r")
     pos = 0
 
     def u32(k=1):
