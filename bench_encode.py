@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Image-encode micro-benchmark on the 13B-shaped vision file (synthetic); prints ms per encode (hipEvents)."""
+import os, sys, time
+import _pkg
+_pkg.load_package()
+from minigpt4_cpp_amd import minigpt4_library as ML, modelgen as G
+d = "/dev/shm/mg4_bench" if os.path.isdir("/dev/shm") else "/tmp/mg4_bench"
+os.makedirs(d, exist_ok=True)
+vp, lp = os.path.join(d, "vision_13b.bin"), os.path.join(d, "llm_enc_tiny.bin")
+if not os.path.exists(vp + ".ok"):
+    G.write_vision_file(vp, G.vision_13b(), unique_blocks=1, fast=True); open(vp + ".ok", "w").write("ok")
+if not os.path.exists(lp):
+    G.write_llm_file(lp, G.tiny_llm(wtype="q4_0", n_embd=256, n_layer=1, n_head=4, n_vocab=512))
+lib = ML.load_library()
+ctx = lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=64, n_batch=32)
+img = ML.array_to_image_struct(G.synth_image(1))
+ms = []
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
+    e = lib.minigpt4_encode_image(ctx, img); ms.append(lib.library.minigpt4_amd_last_encode_ms(ctx.ptr)); lib.minigpt4_free_embedding(e)
+print("encode ms (device):", ["%.2f" % m for m in ms], "best %.2f" % min(ms))
+lib.minigpt4_free(ctx)

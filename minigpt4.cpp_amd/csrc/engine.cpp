@@ -62,6 +62,8 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     n_batch_ = n_batch > 0 ? n_batch : 512;
     max_rows_ = std::max(n_batch_, 32);
     use_graph_ = !(getenv("MINIGPT4_NO_GRAPH") && atoi(getenv("MINIGPT4_NO_GRAPH")));
+    if (getenv("MINIGPT4_ATTN_MFMA")) set_attn_mfma(atoi(getenv("MINIGPT4_ATTN_MFMA")));
+    if (getenv("MINIGPT4_GEMM_BK")) set_gemm_bk(atoi(getenv("MINIGPT4_GEMM_BK")));
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
     if (getenv("MINIGPT4_MV_WAVES")) set_matvec_tuning(atoi(getenv("MINIGPT4_MV_WAVES")), prop.multiProcessorCount); else set_matvec_tuning(0, prop.multiProcessorCount);
     sampler_.seed(seed);

@@ -52,6 +52,8 @@ void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_
 // Writes fp32 `out` (nullable) and/or fp16 `out_h` (nullable).  K must be a multiple of 16.
 void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual,
                      bool gelu, const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s);
+void set_attn_mfma(int v);   // 1: f32-MFMA attention kernel (default), 0: VALU/LDS kernel
+void set_gemm_bk(int bk);   // tuning knob: K-tile depth of k_gemm_f16 (64 / 128 / 256)
 // LayerNorm (ggml_norm eps 1e-5, then w*x+b); rows x n; writes fp32 (nullable) and fp16 (nullable).
 void launch_layernorm(const float *x, const float *w, const float *b, int rows, int n, float *out, __half *out_h, hipStream_t s);
 // f32 attention: q[nq][ldq], k/v[nk][ldk]; per head h the slice [h*hd, (h+1)*hd).  q_prescale != 0: q *= q_prescale first (ViT);

@@ -5,6 +5,7 @@
 // minigpt4.cpp:2373/2412): activations are quantised to the weight type's vec_dot_type (Q8_0 / Q8_1 / Q8_K), block dots are
 // exact int32 (v_dot4_i32_i8), block results are scaled and accumulated in fp32.  See DESIGN.md "Numerics".
 #include "kernels.hpp"
+#include "devutil.hpp"
 
 #include <algorithm>
 
@@ -19,42 +20,6 @@ __device__ __forceinline__ unsigned short f2h_bits(float f) { return __half_as_u
 __device__ __forceinline__ float f16r(float f) { return __half2float(__float2half_rn(f)); }
 __device__ __forceinline__ float tab(const __half *t, float x) { return __half2float(t[f2h_bits(x)]); }
 
-// wave64 sum on the DPP crossbar (no LDS round trips): quad_perm x2, row_half_mirror, row_mirror leave every lane of a 16-lane row with
-// the row sum; the four row sums are then combined through v_readlane.  The result is wave-uniform.
-template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
-    v += dpp_f<0x141>(v);   // row_half_mirror
-    v += dpp_f<0x140>(v);   // row_mirror
-    const int b = __builtin_bit_cast(int, v);
-    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
-           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
-}
-template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
-template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
-    const long long b = __builtin_bit_cast(long long, v);
-    const unsigned lo = (unsigned)dpp_i<CTRL>((int)(unsigned)b), hi = (unsigned)dpp_i<CTRL>((int)(unsigned)(b >> 32));
-    return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
-}
-__device__ __forceinline__ float readlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-__device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
-    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-    v += dpp_d<0xB1>(v); v += dpp_d<0x4E>(v); v += dpp_d<0x141>(v); v += dpp_d<0x140>(v);
-    const long long b = __builtin_bit_cast(long long, v);
-    double r = 0.0;
-#pragma unroll
-    for (int l = 0; l < 64; l += 16) {
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
-        r += __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
-    }
-    return r;
-}
 __device__ __forceinline__ int4 ld16(const void *p) { return *reinterpret_cast<const int4 *>(p); }
 
 // =====================================================================================================================
@@ -458,7 +423,7 @@ __global__ __launch_bounds__(256) void k_matvec_v2(const MatSet ms, const ActQ A
 
 static int g_mv_waves_per_cu = 8;
 static int g_mv_cus = 256;
-void set_matvec_tuning(int waves_per_cu, int cus) { if (waves_per_cu > 0) g_mv_waves_per_cu = waves_per_cu % 100; if (cus > 0) g_mv_cus = cus; extern void set_mv_r1(int); set_mv_r1(waves_per_cu >= 100); }
+void set_matvec_tuning(int waves_per_cu, int cus);
 
 template <int T, int NU, int R>
 static void launch_v2_t(const MatSet &ms, const ActQ &A, hipStream_t s) {
@@ -468,28 +433,32 @@ static void launch_v2_t(const MatSet &ms, const ActQ &A, hipStream_t s) {
     n_waves = (n_waves + 3) & ~3;
     hipLaunchKernelGGL((k_matvec_v2<T, NU, R>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, s, ms, A, n_groups, n_waves);
 }
-static int g_mv_r1 = 0;
-void set_mv_r1(int v) { g_mv_r1 = v; }
+// Launch geometry (measured, profiles/r01a_matvec_microbench.log): one row per group (R = 1) keeps the kernel at ~108 VGPRs -> 4 waves/SIMD;
+// 16 waves per CU for big row spaces (fused qkv / w1w3), 8 otherwise; rows with >= 5 units per lane (K >= 8192) stay at 8 waves per CU.
+static int g_mv_force_waves = 0;
+void set_mv_r1(int) {}
 template <int T>
 static bool launch_v2_type(const MatSet &ms, const ActQ &A, hipStream_t s) {
     const int U = ms.w0.cols / Tr<T>::EPU;
     const int nu = (U + 63) / 64;
-    if (g_mv_r1) {
-        switch (nu) {
-        case 1: launch_v2_t<T, 1, 1>(ms, A, s); return true; case 2: launch_v2_t<T, 2, 1>(ms, A, s); return true; case 3: launch_v2_t<T, 3, 1>(ms, A, s); return true;
-        case 4: launch_v2_t<T, 4, 1>(ms, A, s); return true; default: break; }
-    }
+    const int total_rows = ms.n * ms.rows_each;
+    const int saved = g_mv_waves_per_cu;
+    g_mv_waves_per_cu = g_mv_force_waves ? g_mv_force_waves : (nu <= 4 && total_rows >= 10000 ? 16 : 8);
+    bool ok = true;
     switch (nu) {
-    case 1: launch_v2_t<T, 1, 4>(ms, A, s); return true;
-    case 2: launch_v2_t<T, 2, 2>(ms, A, s); return true;
-    case 3: launch_v2_t<T, 3, 2>(ms, A, s); return true;
-    case 4: launch_v2_t<T, 4, 2>(ms, A, s); return true;
-    case 5: launch_v2_t<T, 5, 1>(ms, A, s); return true;
-    case 6: launch_v2_t<T, 6, 1>(ms, A, s); return true;
-    case 7: launch_v2_t<T, 7, 1>(ms, A, s); return true;
-    default: return false;
+    case 1: launch_v2_t<T, 1, 2>(ms, A, s); break;
+    case 2: launch_v2_t<T, 2, 1>(ms, A, s); break;
+    case 3: launch_v2_t<T, 3, 1>(ms, A, s); break;
+    case 4: launch_v2_t<T, 4, 1>(ms, A, s); break;
+    case 5: launch_v2_t<T, 5, 1>(ms, A, s); break;
+    case 6: launch_v2_t<T, 6, 1>(ms, A, s); break;
+    case 7: launch_v2_t<T, 7, 1>(ms, A, s); break;
+    default: ok = false;
     }
+    g_mv_waves_per_cu = saved;
+    return ok;
 }
+void set_matvec_tuning(int waves_per_cu, int cus) { g_mv_force_waves = waves_per_cu > 0 ? waves_per_cu % 100 : 0; if (cus > 0) g_mv_cus = cus; }
 // Decode (N = 1) mat-vec over 1..3 same-type, same-shape, equally spaced matrices.  Returns false when the set is outside the v2 kernel's range.
 bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s) {
     MatSet ms{};

@@ -4,6 +4,7 @@
 //   * LayerNorm with ggml_norm's double-precision statistics, eps 1e-5.
 //   * fp32 attention (ViT 16 x 88, BERT 12 x 64) staged through LDS; exact-sum softmax through the fp16 exp table.
 #include "kernels.hpp"
+#include "devutil.hpp"
 
 namespace mg4 {
 
@@ -17,100 +18,154 @@ __device__ __forceinline__ float tab_v(const __half *t, float x) { return __half
 // C[M][N] = A[M][K] . W[N][K]^T  (+bias, GELU, +residual).  64x64 tile per 256-thread workgroup, 4 waves of 32x32,
 // BK = 32 staged through LDS (80-byte padded rows: conflict-free ds_read_b128), register prefetch of the next tile.
 // =====================================================================================================================
-constexpr int GB_M = 64, GB_N = 64, GB_K = 32, G_LD = GB_K + 8;
+// Deep K tiles (BK = 128/256): with M = 257 a launch has only ~1-2 workgroups per CU, so the exposed global-load latency per k-iteration
+// dominates; fewer, fatter iterations (8-16 MFMAs per wave each) amortise it.  One LDS buffer, next tile prefetched into registers.
+// (A 3-stage register ring + LDS double buffer was measured 3x SLOWER: hipcc's counted waits degenerate around the ring, see DESIGN.md.)
+constexpr int GB_M = 64;
 
-__global__ __launch_bounds__(256) void k_gemm_f16(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K,
-                                                  const float *__restrict__ bias, const float *residual, int gelu, const Tables tb,
+template <int BK, int BN, bool GELU, bool RES>
+__global__ __launch_bounds__(BN * 4) void k_gemm_f16(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K,
+                                                  const float *__restrict__ bias, const float *residual, const Tables tb,
                                                   float *out, __half *__restrict__ out_h, int ldo) {
-    __shared__ __attribute__((aligned(16))) __half As[GB_M * G_LD];
-    __shared__ __attribute__((aligned(16))) __half Ws[GB_N * G_LD];
+    constexpr int LD = BK + 8;                 // +16 bytes per row: conflict-free ds_read_b128 for BK = 32/64/128/256
+    constexpr int CPR = BK / 8;                // 16-byte chunks per row
+    constexpr int NT = BN * 4;                 // 256 threads (2x2 waves) for BN = 64, 128 threads (2x1 waves) for BN = 32
+    constexpr int NCA = GB_M * CPR / NT, NCW = BN * CPR / NT;   // 16-byte chunks per thread: A tile, W tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
+    __half *As = reinterpret_cast<__half *>(smem_g), *Ws = As + GB_M * LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
-    const int wm = wave >> 1, wn = wave & 1;
-    // staging assignment: one 16-byte chunk of A and one of W per thread per k-tile
-    const int srow = tid >> 2, schunk = tid & 3;
-    const __half *a_src = A + (size_t)min(m0 + srow, M - 1) * lda + schunk * 8;
-    const __half *w_src = W + (size_t)min(n0 + srow, N - 1) * ldw + schunk * 8;
-    const int4 zero4 = make_int4(0, 0, 0, 0);
-    int4 ra = (schunk * 8 < K) ? *reinterpret_cast<const int4 *>(a_src) : zero4;
-    int4 rw = (schunk * 8 < K) ? *reinterpret_cast<const int4 *>(w_src) : zero4;
+    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * BN;
+    const int wm = BN == 64 ? wave >> 1 : wave, wn = BN == 64 ? wave & 1 : 0;
+    const int nk = (K + BK - 1) / BK;
+    int4 ra[NCA], rw[NCW];
+    // per-thread source pointers (row clamped) and LDS offsets of its chunks
+    const __half *asrc[NCA], *wsrc[NCW]; int lofa[NCA], kofa[NCA], lofw[NCW], kofw[NCW];
+#pragma unroll
+    for (int i = 0; i < NCA; i++) { const int c = tid + NT * i, row = c / CPR; kofa[i] = (c % CPR) * 8; lofa[i] = row * LD + kofa[i]; asrc[i] = A + (size_t)min(m0 + row, M - 1) * lda + kofa[i]; }
+#pragma unroll
+    for (int i = 0; i < NCW; i++) { const int c = tid + NT * i, row = c / CPR; kofw[i] = (c % CPR) * 8; lofw[i] = row * LD + kofw[i]; wsrc[i] = W + (size_t)min(n0 + row, N - 1) * ldw + kofw[i]; }
     float16_t acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-    const int nk = (K + GB_K - 1) / GB_K;
+    // K is a multiple of 8: a 16-byte chunk is either fully inside or fully outside; outside chunks load chunk 0 of the row and are zeroed
+#define MG4_GLOAD(kt)                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < NCA; i++) {                                                           \
+        const bool valid = (kt) * BK + kofa[i] < K; const int ko = valid ? (kt) * BK : -kofa[i];                \
+        int4 va = *reinterpret_cast<const int4 *>(asrc[i] + ko);                                                \
+        if (!valid) { va.x = va.y = va.z = va.w = 0; }                                                          \
+        ra[i] = va; }                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < NCW; i++) {                                                           \
+        const bool valid = (kt) * BK + kofw[i] < K; const int ko = valid ? (kt) * BK : -kofw[i];                \
+        int4 vw = *reinterpret_cast<const int4 *>(wsrc[i] + ko);                                                \
+        if (!valid) { vw.x = vw.y = vw.z = vw.w = 0; }                                                          \
+        rw[i] = vw; }
+    MG4_GLOAD(0)
     for (int kt = 0; kt < nk; kt++) {
-        *reinterpret_cast<int4 *>(&As[srow * G_LD + schunk * 8]) = ra;
-        *reinterpret_cast<int4 *>(&Ws[srow * G_LD + schunk * 8]) = rw;
-        __syncthreads();
-        if (kt + 1 < nk) {
-            const int ko = (kt + 1) * GB_K + schunk * 8;
-            ra = ko < K ? *reinterpret_cast<const int4 *>(a_src + (size_t)(kt + 1) * GB_K) : zero4;
-            rw = ko < K ? *reinterpret_cast<const int4 *>(w_src + (size_t)(kt + 1) * GB_K) : zero4;
-        }
 #pragma unroll
-        for (int ks = 0; ks < GB_K / 16; ks++) {
-            const half8_t af = *reinterpret_cast<const half8_t *>(&As[(wm * 32 + (lane & 31)) * G_LD + ks * 16 + (lane >> 5) * 8]);
-            const half8_t bf = *reinterpret_cast<const half8_t *>(&Ws[(wn * 32 + (lane & 31)) * G_LD + ks * 16 + (lane >> 5) * 8]);
+        for (int i = 0; i < NCA; i++) *reinterpret_cast<int4 *>(&As[lofa[i]]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NCW; i++) *reinterpret_cast<int4 *>(&Ws[lofw[i]]) = rw[i];
+        __syncthreads();
+        MG4_GLOAD(kt + 1)            // past the end: zeroed, never stored
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ks++) {
+            const half8_t af = *reinterpret_cast<const half8_t *>(&As[(wm * 32 + (lane & 31)) * LD + ks * 16 + (lane >> 5) * 8]);
+            const half8_t bf = *reinterpret_cast<const half8_t *>(&Ws[(wn * 32 + (lane & 31)) * LD + ks * 16 + (lane >> 5) * 8]);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
         }
         __syncthreads();
     }
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col < N) {
-        const float bv = bias ? bias[col] : 0.0f;
+#undef MG4_GLOAD
+    // epilogue: all gathers of one kind are issued together (no per-element branches around loads)
+    const int col = n0 + wn * 32 + (lane & 31), colc = min(col, N - 1);
+    const float bv = bias ? bias[colc] : 0.0f;
+    float v[16]; size_t o[16]; bool okr[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < M) {
-                float v = acc[r];
-                if (bias) v = bv + v;
-                if (gelu) v = tab_v(tb.gelu, v);
-                const size_t o = (size_t)row * ldo + col;
-                if (residual) v = residual[o] + v;
-                if (out) out[o] = v;
-                if (out_h) out_h[o] = __float2half_rn(v);
-            }
-        }
+    for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        okr[r] = row < M && col < N; o[r] = (size_t)min(row, M - 1) * ldo + colc;
+        v[r] = bias ? bv + acc[r] : acc[r];
     }
+    if (GELU) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = tab_v(tb.gelu, v[r]);
+    }
+    if (RES) {
+        float rr[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) rr[r] = residual[o[r]];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = rr[r] + v[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) if (okr[r]) { if (out) out[o[r]] = v[r]; if (out_h) out_h[o[r]] = __float2half_rn(v[r]); }
 }
+template <int BK, int BN>
+static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
+                          float *out, __half *out_h, int ldo, hipStream_t s) {
+    dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + GB_M - 1) / GB_M)), block(BN * 4);
+    const size_t lds = (size_t)(GB_M + BN) * (BK + 8) * 2;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16<BK, BN, true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+    else if (gelu) hipLaunchKernelGGL((k_gemm_f16<BK, BN, true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+    else if (residual) hipLaunchKernelGGL((k_gemm_f16<BK, BN, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+    else hipLaunchKernelGGL((k_gemm_f16<BK, BN, false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+}
+static int g_gemm_bk = 128, g_gemm_narrow = 400;
+void set_gemm_bk(int bk) { if (bk == 64 || bk == 128) g_gemm_bk = bk; else if (bk >= 1000) g_gemm_narrow = bk - 1000; }
 void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
                      float *out, __half *out_h, int ldo, hipStream_t s) {
-    dim3 grid((unsigned)((N + GB_N - 1) / GB_N), (unsigned)((M + GB_M - 1) / GB_M));
-    hipLaunchKernelGGL(k_gemm_f16, grid, dim3(256), 0, s, A, lda, W, ldw, M, N, K, bias, residual, gelu ? 1 : 0, tb, out, out_h, ldo);
+    // 64x64 tiles unless that leaves most CUs without a workgroup; then 64x32 tiles (twice the workgroups, 2 waves each)
+    const long wgs64 = (long)((N + 63) / 64) * ((M + GB_M - 1) / GB_M);
+    const bool narrow = wgs64 < g_gemm_narrow;
+    if (g_gemm_bk == 64) { if (narrow) launch_gemm_t<64, 32>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); else launch_gemm_t<64, 64>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); }
+    else { if (narrow) launch_gemm_t<128, 32>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); else launch_gemm_t<128, 64>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); }
 }
 
 // =====================================================================================================================
 // LayerNorm: one workgroup per row
 // =====================================================================================================================
 __device__ __forceinline__ double block_sum_d(double v, double *red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = wave_sum_d(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    return (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b, int n, float *__restrict__ out,
                                                    __half *__restrict__ out_h) {
     __shared__ double red[4];
     const size_t row = blockIdx.x;
     const float *xr = x + row * n;
+    constexpr int MAXE = 8;                       // n <= 2048
+    float xv[MAXE];
     double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += (double)xr[i];
+#pragma unroll
+    for (int e = 0; e < MAXE; e++) { const int i = threadIdx.x + 256 * e; xv[e] = i < n ? xr[i] : 0.0f; s += (double)xv[e]; }
     const float mean = (float)(block_sum_d(s, red) / (double)n);
     double s2 = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) { const float v = xr[i] - mean; s2 += (double)(v * v); }
+#pragma unroll
+    for (int e = 0; e < MAXE; e++) { const int i = threadIdx.x + 256 * e; if (i < n) { const float v = xv[e] - mean; s2 += (double)(v * v); } }
     const float variance = (float)(block_sum_d(s2, red) / (double)n);
     const float scale = 1.0f / sqrtf(variance + 1e-5f);
-    for (int i = threadIdx.x; i < n; i += 256) {
-        float v = (xr[i] - mean) * scale;
-        v = w[i] * v;
-        if (b) v = v + b[i];
-        if (out) out[row * n + i] = v;
-        if (out_h) out_h[row * n + i] = __float2half_rn(v);
+#pragma unroll
+    for (int e = 0; e < MAXE; e++) {
+        const int i = threadIdx.x + 256 * e;
+        if (i < n) {
+            float v = (xv[e] - mean) * scale;
+            v = w[i] * v;
+            if (b) v = v + b[i];
+            if (out) out[row * n + i] = v;
+            if (out_h) out_h[row * n + i] = __float2half_rn(v);
+        }
     }
 }
 void launch_layernorm(const float *x, const float *w, const float *b, int rows, int n, float *out, __half *out_h, hipStream_t s) {
+    if (n > 2048) throw HipError{hipErrorInvalidValue, "layernorm: row longer than 2048", __FILE__, __LINE__};
     hipLaunchKernelGGL(k_layernorm, dim3((unsigned)rows), dim3(256), 0, s, x, w, b, n, out, out_h);
 }
 
@@ -162,19 +217,119 @@ __global__ __launch_bounds__(256) void k_attn_f32(const float *__restrict__ q, i
         }
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 attention on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, a k-ordered fma chain -> the same summation order
+// as the sequential CPU dot products).  Workgroup = (head, 32 queries), 4 waves.
+//   A: S = Q K^T   16x16 tiles: wave w owns q-tile (w & 1) and key tiles (w >> 1) + 2i; Q fragments live in registers, K in LDS
+//   B: softmax over LDS rows (8 lanes per query row; max, fp16-table exp, exact double sum)
+//   C: O = P V     16x16 tiles (2 q-tiles x ceil(HD/16) dim tiles over the 4 waves); each tile runs over all keys in order
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float float4_t __attribute__((ext_vector_type(4)));
+// copy rows [0, nk) of one head (HD floats each, 16-byte aligned in global memory) into LDS rows of HD+1 floats; rows [nk, nkp) are zeroed.
+// 8 float4 loads are kept in flight per thread.
+template <int HD>
+__device__ __forceinline__ void stage_head(float *kv, const float *__restrict__ src, int ld, int h, int nk, int nkp, int tid) {
+    constexpr int C4 = HD / 4, LDV = HD + 1, B = 8;
+    const int total = nk * C4;
+    for (int e0 = 0; e0 < total; e0 += 256 * B) {
+        float4 x[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) { const int e = min(e0 + tid + 256 * u, total - 1), j = e / C4, c = e - j * C4; x[u] = *reinterpret_cast<const float4 *>(src + (size_t)j * ld + h * HD + 4 * c); }
+#pragma unroll
+        for (int u = 0; u < B; u++) { const int e = e0 + tid + 256 * u; if (e < total) { const int j = e / C4, c = e - j * C4; float *d = kv + j * LDV + 4 * c; d[0] = x[u].x; d[1] = x[u].y; d[2] = x[u].z; d[3] = x[u].w; } }
+    }
+    for (int e = nk * LDV + tid; e < nkp * LDV; e += 256) kv[e] = 0.0f;
+}
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_mfma(const float *__restrict__ q, int ldq, const float *__restrict__ k, const float *__restrict__ v, int ldk, int nq, int nk,
+                                                   float q_prescale, float score_div, const Tables tb, float *__restrict__ out, __half *__restrict__ out_h, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LDV = HD + 1, DT = (HD + 15) / 16, KS = HD / 4;
+    const int nkp = (nk + 15) & ~15, LS = nkp + 1;
+    float *kv = reinterpret_cast<float *>(smem);               // [nkp][LDV]
+    float *S = kv + (size_t)nkp * LDV;                           // [32][LS]
+    const int h = blockIdx.x, q0 = blockIdx.y * 32, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // stage K_h (zero rows past nk)
+    stage_head<HD>(kv, k, ldk, h, nk, nkp, tid);
+    // Q fragments of this wave's q-tile: A[i = lane & 15][kk = lane >> 4] per k-step
+    const int qt = wave & 1;
+    float qf[KS];
+    {
+        const int qrow = min(q0 + qt * 16 + (lane & 15), nq - 1);
+        const float *qp = q + (size_t)qrow * ldq + h * HD + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) { float t = qp[4 * ks]; if (q_prescale != 0.0f) t *= q_prescale; qf[ks] = t; }
+    }
+    __syncthreads();
+    const int KT = nkp / 16;
+    for (int kt = wave >> 1; kt < KT; kt += 2) {
+        float4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float *kb = kv + (size_t)(kt * 16 + (lane & 15)) * LDV + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[ks], kb[4 * ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { float sv = acc[r]; if (score_div != 0.0f) sv = sv / score_div; S[(qt * 16 + (lane >> 4) * 4 + r) * LS + kt * 16 + (lane & 15)] = sv; }
+    }
+    __syncthreads();
+    // softmax: 8 lanes per query row
+    {
+        const int row = tid >> 3, sub = tid & 7;
+        float *sr = S + (size_t)row * LS;
+        float mx = -INFINITY;
+        for (int j = sub; j < nk; j += 8) mx = fmaxf(mx, sr[j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+        double sum = 0.0;
+        for (int j = sub; j < nk; j += 8) { const float e = tab_v(tb.exp, sr[j] - mx); sr[j] = e; sum += (double)e; }
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+        const float inv = (float)(1.0 / sum);
+        for (int j = sub; j < nkp; j += 8) sr[j] = j < nk ? sr[j] * inv : 0.0f;
+    }
+    __syncthreads();
+    // stage V_h over K_h
+    stage_head<HD>(kv, v, ldk, h, nk, nkp, tid);
+    __syncthreads();
+    const int nks = (nk + 3) / 4;
+    for (int tile = wave; tile < 2 * DT; tile += 4) {
+        const int pqt = tile & 1, dt = tile >> 1;
+        float4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float *pa = S + (size_t)(pqt * 16 + (lane & 15)) * LS + (lane >> 4);
+        const int dim = min(dt * 16 + (lane & 15), HD);                     // column HD of kv is the (finite) pad column; its results are discarded
+        const float *vb = kv + (size_t)(lane >> 4) * LDV + dim;
+        for (int ks = 0; ks < nks; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * ks], vb[(size_t)4 * ks * LDV], acc, 0, 0, 0);
+        const int d = dt * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int qrow = q0 + pqt * 16 + (lane >> 4) * 4 + r;
+            if (qrow < nq && d < HD) { const size_t oo = (size_t)qrow * ldo + h * HD + d; if (out) out[oo] = acc[r]; if (out_h) out_h[oo] = __float2half_rn(acc[r]); }
+        }
+    }
+}
+
+static int g_attn_mfma = 1;
+void set_attn_mfma(int v) { g_attn_mfma = v; }
 void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale, float score_div,
                      const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s) {
-    dim3 grid((unsigned)heads, (unsigned)((nq + 15) / 16));
-    const size_t lds = ((size_t)nk * (hd + 1) + 16 * (size_t)((nk + 3) & ~3)) * 4;
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_f32<88>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_f32<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_mfma<88>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_mfma<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    if (hd != 88 && hd != 64) throw HipError{hipErrorInvalidValue, "attn_f32: head size must be 88 or 64", __FILE__, __LINE__};
+    const int nkp = (nk + 15) & ~15;
+    const size_t lds_m = ((size_t)nkp * (hd + 1) + 32 * (size_t)(nkp + 1)) * 4;
+    if (g_attn_mfma && lds_m <= 160 * 1024) {
+        dim3 grid((unsigned)heads, (unsigned)((nq + 31) / 32));
+        if (hd == 88) hipLaunchKernelGGL((k_attn_mfma<88>), grid, dim3(256), lds_m, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
+        else hipLaunchKernelGGL((k_attn_mfma<64>), grid, dim3(256), lds_m, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
+        return;
+    }
+    dim3 grid((unsigned)heads, (unsigned)((nq + 15) / 16));
+    const size_t lds = ((size_t)nk * (hd + 1) + 16 * (size_t)((nk + 3) & ~3)) * 4;
     if (hd == 88) hipLaunchKernelGGL((k_attn_f32<88>), grid, dim3(256), lds, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
-    else if (hd == 64) hipLaunchKernelGGL((k_attn_f32<64>), grid, dim3(256), lds, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
-    else throw HipError{hipErrorInvalidValue, "attn_f32: head size must be 88 or 64", __FILE__, __LINE__};
+    else hipLaunchKernelGGL((k_attn_f32<64>), grid, dim3(256), lds, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
 }
 
 // =====================================================================================================================
