@@ -64,6 +64,9 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     use_graph_ = !(getenv("MINIGPT4_NO_GRAPH") && atoi(getenv("MINIGPT4_NO_GRAPH")));
     if (getenv("MINIGPT4_ATTN_MFMA")) set_attn_mfma(atoi(getenv("MINIGPT4_ATTN_MFMA")));
     if (getenv("MINIGPT4_GEMM_BK")) set_gemm_bk(atoi(getenv("MINIGPT4_GEMM_BK")));
+    // Fusing the activation preparation into the mat-vec prologue was measured SLOWER (262 vs 302 tok/s, profiles/r01e): every workgroup repeats
+    // the 5120-element norm + quantisation and the kernel start is delayed by it.  Kept as an opt-in experiment.
+    use_fused_pro_ = getenv("MINIGPT4_FUSED_PRO") && atoi(getenv("MINIGPT4_FUSED_PRO"));
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
     if (getenv("MINIGPT4_MV_WAVES")) set_matvec_tuning(atoi(getenv("MINIGPT4_MV_WAVES")), prop.multiProcessorCount); else set_matvec_tuning(0, prop.multiProcessorCount);
     sampler_.seed(seed);
@@ -349,7 +352,9 @@ void Engine::alloc_buffers() {
 // language path
 // ====================================================================================================================
 // One launch for 1..3 same-shape matrices when decoding (v2 persistent-wave kernel); otherwise one k_mul_mat launch per matrix.
-void Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s) {
+// prep != null: the activation row still has to be prepared (rms_norm*w | identity | silu(a)*b + quantisation); when decoding it is fused into
+// the mat-vec prologue, otherwise the standalone preparation kernel runs first.
+void Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep) {
     ProfEv ev{};
     if (prof_on_) {
         HIP_CHECK(hipEventCreate(&ev.a)); HIP_CHECK(hipEventCreate(&ev.b)); ev.type = W[0]->type; ev.bytes = 0;
@@ -357,18 +362,28 @@ void Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
         HIP_CHECK(hipEventRecord(ev.a, s));
     }
     bool same = true;
-    for (int i = 1; i < n; i++) same = same && W[i]->type == W[0]->type && W[i]->rows == W[0]->rows && W[i]->cols == W[0]->cols;
-    if (!(N == 1 && use_v2_ && same && launch_matvec_set(W, y, res, n, act_, s))) {
-        for (int i = 0; i < n; i++) {
-            const QWeight *Wp[1] = {W[i]}; float *Yp[1] = {y[i]}; const float *Rp[1] = {res ? res[i] : nullptr};
-            if (!(N == 1 && use_v2_ && launch_matvec_set(Wp, Yp, Rp, 1, act_, s))) launch_mul_mat(*W[i], act_, N, y[i], ldy, res ? res[i] : nullptr, s);
+    int mask = 0;
+    for (int i = 0; i < n; i++) { mask |= act_mask_for(W[i]->type); if (i) same = same && W[i]->type == W[0]->type && W[i]->rows == W[0]->rows && W[i]->cols == W[0]->cols; }
+    bool done = false;
+    if (N == 1 && use_v2_ && same && prep && use_fused_pro_)
+        done = launch_matvec_set(W, y, res, n, act_, s, prep->kind, prep->x, prep->w, &tabs_);
+    if (!done) {
+        if (prep) {   // standalone preparation
+            if (prep->kind == 1) launch_rms_quant(prep->x, prep->w, N, W[0]->cols, act_, mask, s);
+            else launch_silu_mul_quant(prep->x, prep->kind == 3 ? prep->w : nullptr, N, W[0]->cols, act_, mask, tabs_, s);
+        }
+        if (!(N == 1 && use_v2_ && same && launch_matvec_set(W, y, res, n, act_, s))) {
+            for (int i = 0; i < n; i++) {
+                const QWeight *Wp[1] = {W[i]}; float *Yp[1] = {y[i]}; const float *Rp[1] = {res ? res[i] : nullptr};
+                if (!(N == 1 && use_v2_ && launch_matvec_set(Wp, Yp, Rp, 1, act_, s))) launch_mul_mat(*W[i], act_, N, y[i], ldy, res ? res[i] : nullptr, s);
+            }
         }
     }
     if (prof_on_) { HIP_CHECK(hipEventRecord(ev.b, s)); prof_events_.push_back(ev); }
 }
-void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s) {
+void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep) {
     const QWeight *Wp[1] = {&W}; float *Yp[1] = {y}; const float *Rp[1] = {residual};
-    mul_mat_set(Wp, Yp, Rp, 1, N, ldy, s);
+    mul_mat_set(Wp, Yp, Rp, 1, N, ldy, s, prep);
 }
 
 // Enqueue one forward pass for N rows already described by d_tokens_ (from_tokens) or x_ (embeddings), at position *d_npast_.
@@ -379,24 +394,25 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s) {
     for (size_t il = 0; il < layers_.size(); il++) {
         const LayerW &L = layers_[il];
         __half *kc = kc_ + il * C * E, *vc = vc_ + il * C * E;
-        launch_rms_quant(x_, L.attn_norm, N, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s);
+        const Prep p_attn{1, x_, L.attn_norm}, p_att{2, att_, nullptr}, p_ffn{1, x_, L.ffn_norm}, p_silu{3, h1_, h3_};
         {
             const QWeight *W3[3] = {&L.wq, &L.wk, &L.wv}; float *Y3[3] = {q_, k_, v_};
-            if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s);
-            else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s); mul_mat(L.wv, N, v_, E, nullptr, s); }
+            if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s, &p_attn);
+            else if (act_mask_for(L.wv.type) == act_mask_for(L.wq.type) && !(N == 1 && use_fused_pro_)) {   // one preparation serves both launches
+                launch_rms_quant(x_, L.attn_norm, N, E, act_, act_mask_for(L.wq.type), s);
+                mul_mat_set(W3, Y3, nullptr, 2, N, E, s, nullptr); mul_mat(L.wv, N, v_, E, nullptr, s, nullptr);
+            } else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s, &p_attn); mul_mat(L.wv, N, v_, E, nullptr, s, &p_attn); }
         }
         if (N == 1) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast_, n_ctx_, cos_, sin_, tabs_, att_, true, s);
         else { launch_rope_kv(q_, k_, v_, N, H, hd, d_npast_, cos_, sin_, kc, vc, s); launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast_, n_ctx_, cos_, sin_, tabs_, att_, false, s); }
-        launch_silu_mul_quant(att_, nullptr, N, E, act_, act_mask_for(L.wo.type), tabs_, s);
-        mul_mat(L.wo, N, x_, E, x_, s);
-        launch_rms_quant(x_, L.ffn_norm, N, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s);
-        { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; mul_mat_set(W2, Y2, nullptr, 2, N, F, s); }
-        launch_silu_mul_quant(h1_, h3_, N, F, act_, act_mask_for(L.w2.type), tabs_, s);
-        mul_mat(L.w2, N, x_, E, x_, s);
+        mul_mat(L.wo, N, x_, E, x_, s, &p_att);
+        if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn); }
+        else { mul_mat(L.w1, N, h1_, F, nullptr, s, &p_ffn); mul_mat(L.w3, N, h3_, F, nullptr, s, &p_ffn); }
+        mul_mat(L.w2, N, x_, E, x_, s, &p_silu);
     }
     // only the last token's logits are kept (llama.cpp logits_all = false)
-    launch_rms_quant(x_ + (size_t)(N - 1) * E, norm_, 1, E, act_, act_mask_for(output_.type), s);
-    mul_mat(output_, 1, logits_, V, nullptr, s);
+    const Prep p_out{1, x_ + (size_t)(N - 1) * E, norm_};
+    mul_mat(output_, 1, logits_, V, nullptr, s, &p_out);
     launch_argmax(logits_, V, d_argmax_, d_scratch_, s);
     launch_advance(d_npast_, N, d_tokens_, d_argmax_, s);
     HIP_CHECK(hipMemcpyAsync(h_argmax_, d_argmax_, 4, hipMemcpyDeviceToHost, s));

@@ -69,8 +69,9 @@ private:
     void alloc_buffers();
     int eval(const int *tokens, const float *embd, int N);
     void forward(int N, bool from_tokens, hipStream_t s);
-    void mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s);
-    void mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s);
+    struct Prep { int kind; const float *x; const float *w; };   // 1: rms_norm(x)*w, 2: x, 3: silu(x)*w -- then quantised for the consumer's type
+    void mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep);
+    void mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep);
     void upload_qweight(const TensorMeta &t, const uint8_t *file_base, QWeight &w);
     template <typename T> T *upload_raw(DeviceArena &a, const void *src, size_t bytes);
 
@@ -99,7 +100,7 @@ private:
     ActQ act_;
     int *d_npast_ = nullptr, *d_tokens_ = nullptr, *d_argmax_ = nullptr; void *d_scratch_ = nullptr;
     int *h_argmax_ = nullptr; float *h_logits_ = nullptr; bool logits_host_valid_ = false;
-    hipGraphExec_t decode_graph_ = nullptr; bool use_graph_ = true, use_v2_ = true;
+    hipGraphExec_t decode_graph_ = nullptr; bool use_graph_ = true, use_v2_ = true, use_fused_pro_ = false;
     // profiling
     bool prof_on_ = false;
     struct ProfEv { hipEvent_t a, b; int type; double bytes; };

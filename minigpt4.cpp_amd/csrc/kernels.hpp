@@ -24,7 +24,10 @@ void launch_silu_mul_quant(const float *a, const float *b, int N, int K, const A
 void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s);
 
 // decode (N = 1) persistent-wave mat-vec over 1..3 same-type, same-shape matrices (wq|wk|wv, w1|w3); false -> caller falls back to launch_mul_mat
-bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s);
+// pro: 0 = activations come from `A` (prepared by launch_rms_quant / launch_silu_mul_quant); 1 = rms_norm(px) * pw, 2 = px, 3 = silu(px) * pw are
+// prepared and quantised inside the kernel prologue (one launch less per use).
+bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s, int pro = 0, const float *px = nullptr,
+                       const float *pw = nullptr, const Tables *tb = nullptr);
 void set_matvec_tuning(int waves_per_cu, int cus);
 
 // ---- token embedding gather (raw ggml rows, dequantised to f32) -----------------------------------------------------

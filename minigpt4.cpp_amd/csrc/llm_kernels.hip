@@ -357,6 +357,12 @@ static void launch_mul_mat_t(const QWeight &W, const ActQ &A, int N, float *y, i
 // stream: the R x NU x (2-3) loads of the next row group are issued before the current group's dot products (plain global
 // loads straight to VGPRs, counted vmcnt waits by the compiler; no LDS -- the weights are read once and not shared).
 // =====================================================================================================================
+// Activation preparation fused into the mat-vec prologue (decode): every workgroup redundantly prepares the (tiny, L2-resident) activation
+// row in LDS -- rms_norm * w | identity | silu(a) * b, then ggml's Q8_K / Q8_0 quantisation -- while its first weight loads are in flight.
+enum ProKind : int { PRO_NONE = 0, PRO_RMS = 1, PRO_PLAIN = 2, PRO_SILU = 3 };
+struct ProArgs { const float *x; const float *w; Tables tb; };   // RMS: x, norm weight; PLAIN: x; SILU: a = x, b = w
+__device__ __forceinline__ void quant_emit4(const float v[4], const bool in_range, const int idx, const size_t row, const int K, const ActQ &A, const int mask);
+
 struct MatSet {
     QWeight w0;            // matrix 0; matrix m has every plane shifted by m * dmat bytes
     long long dmat;        // byte distance between consecutive matrices (identical for all planes)
@@ -366,8 +372,8 @@ struct MatSet {
     int rows_each;         // rows of each matrix
 };
 
-template <int T, int NU, int R>
-__global__ __launch_bounds__(256) void k_matvec_v2(const MatSet ms, const ActQ A, const int n_groups, const int n_waves) {
+template <int T, int NU, int R, int PRO>
+__global__ __launch_bounds__(256) void k_matvec_v2(const MatSet ms, const ActQ A, const ProArgs pa, const int n_groups, const int n_waves) {
     using X = Tr<T>;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -375,9 +381,6 @@ __global__ __launch_bounds__(256) void k_matvec_v2(const MatSet ms, const ActQ A
     int uc[NU]; bool ok[NU];
 #pragma unroll
     for (int i = 0; i < NU; i++) { const int u = lane + 64 * i; ok[i] = u < U; uc[i] = ok[i] ? u : 0; }
-    typename X::AU a[NU];
-#pragma unroll
-    for (int i = 0; i < NU; i++) X::loada(A, 0, K, uc[i], a[i]);
     // NOTE: every load of the pipeline is unconditional (indices are clamped instead of branching): a load inside an exec-masked branch
     // makes hipcc's counted s_waitcnt fall back to (near) vmcnt(0), which drains the prefetch -- see DESIGN.md "mat-vec pipeline".
     struct Grp { typename X::WU w[R][NU]; float res[R]; };
@@ -396,6 +399,57 @@ __global__ __launch_bounds__(256) void k_matvec_v2(const MatSet ms, const ActQ A
             G.res[r] = ms.res0 ? ms.res0[(long long)m * ms.dres + lr] : 0.0f;
         }
     };
+    Grp cur, nxt;
+    fetch(wave, cur);                         // first weights are in flight while the activation row is prepared
+    typename X::AU a[NU];
+    if (PRO == PRO_NONE) {
+#pragma unroll
+        for (int i = 0; i < NU; i++) X::loada(A, 0, K, uc[i], a[i]);
+    } else {
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem_mv[];
+        // LDS image of the quantised row (only the planes this weight type reads are written)
+        ActQ L;
+        unsigned char *p = smem_mv;
+        L.q8k = reinterpret_cast<int8_t *>(p); p += (size_t)K;
+        L.q80 = reinterpret_cast<int8_t *>(p); p += (size_t)K;
+        L.dk = reinterpret_cast<float *>(p); p += (size_t)(K / 256 + 1) * 4;
+        L.d0 = reinterpret_cast<float *>(p); p += (size_t)(K / 32) * 4;
+        L.d1 = reinterpret_cast<float *>(p); p += (size_t)(K / 32) * 4;
+        L.s1 = reinterpret_cast<float *>(p); p += (size_t)(K / 32) * 4;
+        L.sum0 = reinterpret_cast<int *>(p); p += (size_t)(K / 32) * 4;
+        L.bsk = reinterpret_cast<int16_t *>(p); p += (size_t)(K / 16) * 2;
+        L.xh = nullptr; L.xf = nullptr;
+        __shared__ double red[4];
+        const int mask = (T == GT_Q4_K || T == GT_Q5_K || T == GT_Q6_K) ? ACT_Q8K : ACT_Q80;
+        float scale = 1.0f;
+        if (PRO == PRO_RMS) {
+            double sum = 0.0;
+            for (int i = threadIdx.x * 4; i < K; i += 1024) { const float4 v = *reinterpret_cast<const float4 *>(pa.x + i);
+                sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w); }
+            sum = wave_sum_d(sum);
+            if (lane == 0) red[threadIdx.x >> 6] = sum;
+            __syncthreads();
+            const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+            const float mean = (float)(tot / (double)K);
+            scale = 1.0f / sqrtf(mean + 1e-6f);
+        }
+        for (int i0 = 0; i0 < K; i0 += 1024) {
+            const int i = i0 + threadIdx.x * 4;
+            const bool in = i < K;
+            float v[4] = {0, 0, 0, 0};
+            if (in) {
+                const float4 xv = *reinterpret_cast<const float4 *>(pa.x + i);
+                if (PRO == PRO_RMS) { const float4 wv = *reinterpret_cast<const float4 *>(pa.w + i); v[0] = (xv.x * scale) * wv.x; v[1] = (xv.y * scale) * wv.y; v[2] = (xv.z * scale) * wv.z; v[3] = (xv.w * scale) * wv.w; }
+                else if (PRO == PRO_SILU) { const float4 bv = *reinterpret_cast<const float4 *>(pa.w + i);
+                    v[0] = tab(pa.tb.silu, xv.x) * bv.x; v[1] = tab(pa.tb.silu, xv.y) * bv.y; v[2] = tab(pa.tb.silu, xv.z) * bv.z; v[3] = tab(pa.tb.silu, xv.w) * bv.w; }
+                else { v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w; }
+            }
+            quant_emit4(v, in, i, 0, K, L, mask);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NU; i++) X::loada(L, 0, K, uc[i], a[i]);
+    }
     auto consume = [&](int g, const Grp &G) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -410,9 +464,6 @@ __global__ __launch_bounds__(256) void k_matvec_v2(const MatSet ms, const ActQ A
             }
         }
     };
-    if (wave >= n_groups) return;
-    Grp cur, nxt;
-    fetch(wave, cur);
 #pragma unroll 2
     for (int g = wave; g < n_groups; g += n_waves) {
         fetch(g + n_waves, nxt);
@@ -420,25 +471,30 @@ __global__ __launch_bounds__(256) void k_matvec_v2(const MatSet ms, const ActQ A
         cur = nxt;
     }
 }
-
 static int g_mv_waves_per_cu = 8;
 static int g_mv_cus = 256;
-void set_matvec_tuning(int waves_per_cu, int cus);
-
 template <int T, int NU, int R>
-static void launch_v2_t(const MatSet &ms, const ActQ &A, hipStream_t s) {
+static void launch_v2_t(const MatSet &ms, const ActQ &A, int pro, const ProArgs &pa, hipStream_t s) {
     const int total_rows = ms.n * ms.rows_each;
     const int n_groups = (total_rows + R - 1) / R;
     int n_waves = std::min(n_groups, g_mv_cus * g_mv_waves_per_cu);
     n_waves = (n_waves + 3) & ~3;
-    hipLaunchKernelGGL((k_matvec_v2<T, NU, R>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, s, ms, A, n_groups, n_waves);
+    const dim3 grid((unsigned)(n_waves / 4)), block(256);
+    const int K = ms.w0.cols;
+    const size_t lds = (size_t)2 * K + (size_t)(K / 256 + 1) * 4 + (size_t)4 * (K / 32) * 4 + (size_t)(K / 16) * 2 + 64;
+    switch (pro) {
+    case PRO_RMS: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_RMS>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
+    case PRO_PLAIN: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_PLAIN>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
+    case PRO_SILU: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_SILU>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
+    default: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_NONE>), grid, block, 0, s, ms, A, pa, n_groups, n_waves); break;
+    }
 }
 // Launch geometry (measured, profiles/r01a_matvec_microbench.log): one row per group (R = 1) keeps the kernel at ~108 VGPRs -> 4 waves/SIMD;
 // 16 waves per CU for big row spaces (fused qkv / w1w3), 8 otherwise; rows with >= 5 units per lane (K >= 8192) stay at 8 waves per CU.
 static int g_mv_force_waves = 0;
 void set_mv_r1(int) {}
 template <int T>
-static bool launch_v2_type(const MatSet &ms, const ActQ &A, hipStream_t s) {
+static bool launch_v2_type(const MatSet &ms, const ActQ &A, int pro, const ProArgs &pa, hipStream_t s) {
     const int U = ms.w0.cols / Tr<T>::EPU;
     const int nu = (U + 63) / 64;
     const int total_rows = ms.n * ms.rows_each;
@@ -446,13 +502,13 @@ static bool launch_v2_type(const MatSet &ms, const ActQ &A, hipStream_t s) {
     g_mv_waves_per_cu = g_mv_force_waves ? g_mv_force_waves : (nu <= 4 && total_rows >= 10000 ? 16 : 8);
     bool ok = true;
     switch (nu) {
-    case 1: launch_v2_t<T, 1, 2>(ms, A, s); break;
-    case 2: launch_v2_t<T, 2, 1>(ms, A, s); break;
-    case 3: launch_v2_t<T, 3, 1>(ms, A, s); break;
-    case 4: launch_v2_t<T, 4, 1>(ms, A, s); break;
-    case 5: launch_v2_t<T, 5, 1>(ms, A, s); break;
-    case 6: launch_v2_t<T, 6, 1>(ms, A, s); break;
-    case 7: launch_v2_t<T, 7, 1>(ms, A, s); break;
+    case 1: launch_v2_t<T, 1, 2>(ms, A, pro, pa, s); break;
+    case 2: launch_v2_t<T, 2, 1>(ms, A, pro, pa, s); break;
+    case 3: launch_v2_t<T, 3, 1>(ms, A, pro, pa, s); break;
+    case 4: launch_v2_t<T, 4, 1>(ms, A, pro, pa, s); break;
+    case 5: launch_v2_t<T, 5, 1>(ms, A, pro, pa, s); break;
+    case 6: launch_v2_t<T, 6, 1>(ms, A, pro, pa, s); break;
+    case 7: launch_v2_t<T, 7, 1>(ms, A, pro, pa, s); break;
     default: ok = false;
     }
     g_mv_waves_per_cu = saved;
@@ -460,7 +516,9 @@ static bool launch_v2_type(const MatSet &ms, const ActQ &A, hipStream_t s) {
 }
 void set_matvec_tuning(int waves_per_cu, int cus) { g_mv_force_waves = waves_per_cu > 0 ? waves_per_cu % 100 : 0; if (cus > 0) g_mv_cus = cus; }
 // Decode (N = 1) mat-vec over 1..3 same-type, same-shape, equally spaced matrices.  Returns false when the set is outside the v2 kernel's range.
-bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s) {
+bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s, int pro, const float *px, const float *pw,
+                       const Tables *tb) {
+    ProArgs pa{}; pa.x = px; pa.w = pw; if (tb) pa.tb = *tb;
     MatSet ms{};
     ms.n = n; ms.rows_each = W[0]->rows; ms.w0 = *W[0]; ms.y0 = y[0]; ms.res0 = residual ? residual[0] : nullptr;
     if (n > 1) {
@@ -474,13 +532,13 @@ bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *co
         }
     }
     switch (W[0]->type) {
-    case GT_Q4_0: return launch_v2_type<GT_Q4_0>(ms, A, s);
-    case GT_Q4_1: return launch_v2_type<GT_Q4_1>(ms, A, s);
-    case GT_Q5_0: return launch_v2_type<GT_Q5_0>(ms, A, s);
-    case GT_Q5_1: return launch_v2_type<GT_Q5_1>(ms, A, s);
-    case GT_Q4_K: return launch_v2_type<GT_Q4_K>(ms, A, s);
-    case GT_Q5_K: return launch_v2_type<GT_Q5_K>(ms, A, s);
-    case GT_Q6_K: return launch_v2_type<GT_Q6_K>(ms, A, s);
+    case GT_Q4_0: return launch_v2_type<GT_Q4_0>(ms, A, pro, pa, s);
+    case GT_Q4_1: return launch_v2_type<GT_Q4_1>(ms, A, pro, pa, s);
+    case GT_Q5_0: return launch_v2_type<GT_Q5_0>(ms, A, pro, pa, s);
+    case GT_Q5_1: return launch_v2_type<GT_Q5_1>(ms, A, pro, pa, s);
+    case GT_Q4_K: return launch_v2_type<GT_Q4_K>(ms, A, pro, pa, s);
+    case GT_Q5_K: return launch_v2_type<GT_Q5_K>(ms, A, pro, pa, s);
+    case GT_Q6_K: return launch_v2_type<GT_Q6_K>(ms, A, pro, pa, s);
     default: return false;   // Q8_0 / F16 / F32 rows have more units per row: served by k_mul_mat
     }
 }

@@ -115,7 +115,7 @@ static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, in
     else if (residual) hipLaunchKernelGGL((k_gemm_f16<BK, BN, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
     else hipLaunchKernelGGL((k_gemm_f16<BK, BN, false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
 }
-static int g_gemm_bk = 128, g_gemm_narrow = 400;
+static int g_gemm_bk = 128, g_gemm_narrow = 0;   // 64x32 tiles measured slower than 64x64 even at 110 workgroups (profiles/r01c): off by default
 void set_gemm_bk(int bk) { if (bk == 64 || bk == 128) g_gemm_bk = bk; else if (bk >= 1000) g_gemm_narrow = bk - 1000; }
 void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
                      float *out, __half *out_h, int ldo, hipStream_t s) {
