@@ -102,6 +102,25 @@ def cpu_baseline(lp: str, prompt_tokens, budget_s: float = 20.0):
             "sample": f"{n} greedy decode steps of the same LLM file at context<64 on the CPU oracle (ggml-equivalent restatement, {'-march=native' if native else 'x86-64-v3'}, OpenMP {cores} threads), {dt:.1f}s"}
 
 
+def pmc_traffic(type_name: str):
+    """HBM read bytes per launch of the dominant mat-vec kernel from the committed rocprofv3 PMC pass of this same command
+    (profiles/r01d_pmc_fetch_size_summary.csv: FETCH_SIZE x 1024 x 2, the gfx950 correction of MI355X_MICROARCH.md).  PMC counters cannot be
+    read from inside the process, so this is the profile's number, not a live one; None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01d_pmc_fetch_size_summary.csv")
+    tid = {"q5_k": 13, "q6_k": 14, "q4_0": 2, "q4_k": 12}.get(type_name)
+    if tid is None or not os.path.exists(path):
+        return None, None
+    calls, byts = 0, 0.0
+    for line in open(path):
+        if line.startswith('"') and f"k_matvec_v2<{tid}," in line:
+            parts = line.rsplit('",', 1)[1].strip().split(",")
+            calls += int(parts[0])
+            byts += int(parts[0]) * float(parts[2]) * 1e6
+    if not calls:
+        return None, None
+    return byts / calls, "profiles/r01d_pmc_fetch_size_summary.csv (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction; avg over k_matvec_v2 launches of this type)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,7 +128,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default=os.environ.get("MG4_BENCH_CONFIG", "13b"), choices=["13b", "7b", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--n-ctx", type=int, default=2048)
+    ap.add_argument("--n-ctx", type=int, default=0, help="context size; default: 2048 or whatever --steps needs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -138,6 +157,8 @@ def main():
         raise SystemExit("bench.py: no HIP device visible (the engine has no CPU fallback)")
 
     vp, lp, vcfg, lcfg = make_models(args.config, rank, world, barrier)
+    if args.n_ctx <= 0:   # the reference default is 2048; grow it only when the requested run does not fit
+        args.n_ctx = max(2048, (200 + args.steps + args.warmup + 64 + 255) // 256 * 256)
     t0 = time.time()
     ctx = lib.minigpt4_model_load(vp, lp, verbosity=1, seed=1337, n_ctx=args.n_ctx, n_batch=512)
     load_s = time.time() - t0
@@ -212,8 +233,9 @@ def main():
     dom = stats[dom_t]
     names = {0: "f32", 1: "f16", 2: "q4_0", 3: "q4_1", 6: "q5_0", 7: "q5_1", 8: "q8_0", 12: "q4_k", 13: "q5_k", 14: "q6_k"}
     achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+    pmc = pmc_traffic(names.get(dom_t, ""))
     roofline = {"bound": "hbm", "kernel": f"k_mul_mat<{names.get(dom_t, dom_t)}> (fused-dequant int8-dot mat-vec)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc[0], "traffic_source": pmc[1],
                 "avg_launch_us": dom["ms"] * 1e3 / dom["launches"], "bytes_per_launch_avg": dom["bytes"] / dom["launches"],
                 "all_matvec_GBps": sum(s["bytes"] for s in stats.values()) / (sum(s["ms"] for s in stats.values()) * 1e-3) / 1e9,
                 "per_type": {names.get(k, str(k)): {"GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "launches": v["launches"]} for k, v in stats.items()},

@@ -100,7 +100,7 @@ int minigpt4_end_chat_image(struct MiniGPT4Context *ctx, const char **token, siz
         SampleParams p; p.temp = temp; p.top_k = top_k; p.top_p = top_p; p.tfs_z = tfs_z; p.typical_p = typical_p; p.mirostat = mirostat; p.mirostat_tau = mirostat_tau; p.mirostat_eta = mirostat_eta;
         const int id = e->sample_token(p);
         *token = e->id_to_token(id);
-        (void)e->add_tokens({id});   // result discarded, as in the reference (minigpt4.cpp:2715)
+        (void)e->add_tokens({id}, /*flush_now=*/true);   // launched asynchronously; result discarded, as in the reference (minigpt4.cpp:2715)
         return 0;
     });
     return E_None;

@@ -40,9 +40,12 @@ Engine::~Engine() {
     if (stage_) (void)hipFree(stage_);
     if (h_argmax_) (void)hipHostFree(h_argmax_);
     if (h_logits_) (void)hipHostFree(h_logits_);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (side_) (void)hipStreamDestroy(side_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
-void Engine::sync() { HIP_CHECK(hipStreamSynchronize(stream_)); }
+void Engine::sync() { (void)flush(); HIP_CHECK(hipStreamSynchronize(stream_)); }
 
 // ====================================================================================================================
 // init / load
@@ -58,10 +61,19 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     HIP_CHECK(hipGetDeviceProperties(&prop, device_));
     MG4_INFO("device %d: %s (%s), %d CUs, %.1f GiB", device_, prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    // Infinity-Cache prefetch on a side stream: measured a LOSS (173 vs 298 tok/s): graph fork/join costs ~12 us each, and a fully cache-resident
+    // mat-vec is only ~15 % faster than an HBM-streamed one (profiles/r01f_mall_probe.log).  Opt-in experiment.
+    use_prefetch_ = getenv("MINIGPT4_PREFETCH") && atoi(getenv("MINIGPT4_PREFETCH"));
+    if (const char *pm = getenv("MINIGPT4_PF_MB")) sscanf(pm, "%lf,%lf,%lf,%lf", &pf_mb_[0], &pf_mb_[1], &pf_mb_[2], &pf_mb_[3]);
     n_ctx_ = n_ctx > 0 ? n_ctx : 2048;
     n_batch_ = n_batch > 0 ? n_batch : 512;
     max_rows_ = std::max(n_batch_, 32);
     use_graph_ = !(getenv("MINIGPT4_NO_GRAPH") && atoi(getenv("MINIGPT4_NO_GRAPH")));
+    defer_ = !(getenv("MINIGPT4_NO_DEFER") && atoi(getenv("MINIGPT4_NO_DEFER")));
+    max_chunk_ = max_rows_;
+    if (getenv("MINIGPT4_NO_MMQ")) set_mmq_enabled(!atoi(getenv("MINIGPT4_NO_MMQ")));
     if (getenv("MINIGPT4_ATTN_MFMA")) set_attn_mfma(atoi(getenv("MINIGPT4_ATTN_MFMA")));
     if (getenv("MINIGPT4_GEMM_BK")) set_gemm_bk(atoi(getenv("MINIGPT4_GEMM_BK")));
     // Fusing the activation preparation into the mat-vec prologue was measured SLOWER (262 vs 302 tok/s, profiles/r01e): every workgroup repeats
@@ -351,6 +363,43 @@ void Engine::alloc_buffers() {
 // ====================================================================================================================
 // language path
 // ====================================================================================================================
+// ---- Infinity-Cache prefetch ---------------------------------------------------------------------------------------------------------
+// The decode chain alternates HBM-saturating mat-vecs with latency-bound kernels (norm + quantise, attention) during which HBM idles.
+// While such a kernel runs, a side stream touches the first part of the NEXT mat-vec's planes so that they are resident in the 256 MiB
+// Infinity Cache when it starts (the mat-vec's access front moves linearly through every plane, so "the first x %" of each plane is
+// exactly what it reads first).  fork/join are plain events; under stream capture they become parallel branches of the decode graph.
+void Engine::pf_add(PrefetchSet &ps, const QWeight &W, double from_frac, double to_frac) const {
+    const size_t n = (size_t)W.rows * W.cols;
+    auto add = [&](const uint8_t *p, size_t bytes) {
+        if (!p || !bytes || ps.n >= 16) return;
+        size_t a = (size_t)(bytes * from_frac) & ~(size_t)255, b = std::min(bytes, ((size_t)(bytes * to_frac) + 255) & ~(size_t)255);
+        if (b > a) { ps.ptr[ps.n] = p + a; ps.bytes[ps.n] = b - a; ps.n++; }
+    };
+    switch (W.type) {
+    case GT_Q4_0: add(W.qs, n / 32 * 16); add(W.sc, n / 32 * 2); break;
+    case GT_Q4_1: add(W.qs, n / 32 * 16); add(W.sc, n / 32 * 4); break;
+    case GT_Q5_0: add(W.qs, n / 32 * 16); add(W.qh, n / 32 * 4); add(W.sc, n / 32 * 2); break;
+    case GT_Q5_1: add(W.qs, n / 32 * 16); add(W.qh, n / 32 * 4); add(W.sc, n / 32 * 4); break;
+    case GT_Q4_K: add(W.qs, n / 256 * 128); add(W.sc, n / 256 * 16); break;
+    case GT_Q5_K: add(W.qs, n / 256 * 128); add(W.qh, n / 256 * 32); add(W.sc, n / 256 * 16); break;
+    case GT_Q6_K: add(W.qs, n / 256 * 128); add(W.qh, n / 256 * 64); add(W.sc, n / 256 * 16); add(W.d, n / 256 * 2); break;
+    default: add(W.qs, W.bytes); break;
+    }
+}
+void Engine::pf_fork(const PrefetchSet &ps, hipStream_t s) {
+    if (!use_prefetch_ || ps.n == 0) return;
+    HIP_CHECK(hipEventRecord(ev_fork_, s));
+    HIP_CHECK(hipStreamWaitEvent(side_, ev_fork_, 0));
+    launch_prefetch(ps, side_);
+    HIP_CHECK(hipEventRecord(ev_join_, side_));
+    pf_pending_ = true;
+}
+void Engine::pf_join(hipStream_t s) {
+    if (!pf_pending_) return;
+    HIP_CHECK(hipStreamWaitEvent(s, ev_join_, 0));
+    pf_pending_ = false;
+}
+
 // One launch for 1..3 same-shape matrices when decoding (v2 persistent-wave kernel); otherwise one k_mul_mat launch per matrix.
 // prep != null: the activation row still has to be prepared (rms_norm*w | identity | silu(a)*b + quantisation); when decoding it is fused into
 // the mat-vec prologue, otherwise the standalone preparation kernel runs first.
@@ -395,40 +444,72 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s) {
         const LayerW &L = layers_[il];
         __half *kc = kc_ + il * C * E, *vc = vc_ + il * C * E;
         const Prep p_attn{1, x_, L.attn_norm}, p_att{2, att_, nullptr}, p_ffn{1, x_, L.ffn_norm}, p_silu{3, h1_, h3_};
+        const bool dec = N == 1 && !use_fused_pro_;
+        auto frac = [](double mb, size_t bytes) { return bytes ? std::min(1.0, mb * 1e6 / (double)bytes) : 0.0; };
+        const size_t qkv_b = L.wq.bytes + L.wk.bytes + L.wv.bytes, w13_b = L.w1.bytes + L.w3.bytes;
+        const double f13a = frac(pf_mb_[1], w13_b), f13b = std::min(1.0, f13a + frac(pf_mb_[2], w13_b));
+        if (dec) {   // the previous layer's w2 has just saturated HBM; the norm/quantise kernel below leaves it idle
+            PrefetchSet ps; const double f = frac(pf_mb_[0], qkv_b);
+            pf_add(ps, L.wq, 0, f); pf_add(ps, L.wk, 0, f); pf_add(ps, L.wv, 0, f); pf_fork(ps, s);
+            launch_rms_quant(x_, L.attn_norm, 1, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s);
+            pf_join(s);
+        }
         {
             const QWeight *W3[3] = {&L.wq, &L.wk, &L.wv}; float *Y3[3] = {q_, k_, v_};
-            if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s, &p_attn);
-            else if (act_mask_for(L.wv.type) == act_mask_for(L.wq.type) && !(N == 1 && use_fused_pro_)) {   // one preparation serves both launches
+            const Prep *pp = dec ? nullptr : &p_attn;
+            if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s, pp);
+            else if (!dec && act_mask_for(L.wv.type) == act_mask_for(L.wq.type) && !(N == 1 && use_fused_pro_)) {   // one preparation serves both launches
                 launch_rms_quant(x_, L.attn_norm, N, E, act_, act_mask_for(L.wq.type), s);
                 mul_mat_set(W3, Y3, nullptr, 2, N, E, s, nullptr); mul_mat(L.wv, N, v_, E, nullptr, s, nullptr);
-            } else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s, &p_attn); mul_mat(L.wv, N, v_, E, nullptr, s, &p_attn); }
+            } else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s, pp); mul_mat(L.wv, N, v_, E, nullptr, s, pp); }
+        }
+        if (dec) {   // attention + its quantisation: prefetch all of wo and the head of w1|w3
+            PrefetchSet ps; pf_add(ps, L.wo, 0, 1.0); pf_add(ps, L.w1, 0, f13a); pf_add(ps, L.w3, 0, f13a); pf_fork(ps, s);
         }
         if (N == 1) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast_, n_ctx_, cos_, sin_, tabs_, att_, true, s);
         else { launch_rope_kv(q_, k_, v_, N, H, hd, d_npast_, cos_, sin_, kc, vc, s); launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast_, n_ctx_, cos_, sin_, tabs_, att_, false, s); }
-        mul_mat(L.wo, N, x_, E, x_, s, &p_att);
-        if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn); }
-        else { mul_mat(L.w1, N, h1_, F, nullptr, s, &p_ffn); mul_mat(L.w3, N, h3_, F, nullptr, s, &p_ffn); }
-        mul_mat(L.w2, N, x_, E, x_, s, &p_silu);
+        if (dec) { launch_silu_mul_quant(att_, nullptr, 1, E, act_, act_mask_for(L.wo.type), tabs_, s); pf_join(s); mul_mat(L.wo, N, x_, E, x_, s, nullptr); }
+        else mul_mat(L.wo, N, x_, E, x_, s, &p_att);
+        if (dec) {
+            PrefetchSet ps; pf_add(ps, L.w1, f13a, f13b); pf_add(ps, L.w3, f13a, f13b); pf_fork(ps, s);
+            launch_rms_quant(x_, L.ffn_norm, 1, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s);
+            pf_join(s);
+        }
+        {
+            const Prep *pp = dec ? nullptr : &p_ffn;
+            if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; mul_mat_set(W2, Y2, nullptr, 2, N, F, s, pp); }
+            else { mul_mat(L.w1, N, h1_, F, nullptr, s, pp); mul_mat(L.w3, N, h3_, F, nullptr, s, pp); }
+        }
+        if (dec) {
+            PrefetchSet ps; pf_add(ps, L.w2, 0, frac(pf_mb_[3], L.w2.bytes)); pf_fork(ps, s);
+            launch_silu_mul_quant(h1_, h3_, 1, F, act_, act_mask_for(L.w2.type), tabs_, s);
+            pf_join(s);
+            mul_mat(L.w2, N, x_, E, x_, s, nullptr);
+        } else mul_mat(L.w2, N, x_, E, x_, s, &p_silu);
     }
     // only the last token's logits are kept (llama.cpp logits_all = false)
-    const Prep p_out{1, x_ + (size_t)(N - 1) * E, norm_};
-    mul_mat(output_, 1, logits_, V, nullptr, s, &p_out);
+    if (N == 1 && !use_fused_pro_) {
+        PrefetchSet ps; pf_add(ps, output_, 0, std::min(1.0, pf_mb_[0] * 1e6 / (double)std::max<size_t>(1, output_.bytes))); pf_fork(ps, s);
+        launch_rms_quant(x_, norm_, 1, E, act_, act_mask_for(output_.type), s);
+        pf_join(s);
+        mul_mat(output_, 1, logits_, V, nullptr, s, nullptr);
+    } else {
+        const Prep p_out{1, x_ + (size_t)(N - 1) * E, norm_};
+        mul_mat(output_, 1, logits_, V, nullptr, s, &p_out);
+    }
     launch_argmax(logits_, V, d_argmax_, d_scratch_, s);
     launch_advance(d_npast_, N, d_tokens_, d_argmax_, s);
     HIP_CHECK(hipMemcpyAsync(h_argmax_, d_argmax_, 4, hipMemcpyDeviceToHost, s));
 }
 
-int Engine::eval(const int *tokens, const float *embd, int N) {
+// Evaluate one chunk of N rows at position n_committed_.  row_tok[i] >= 0: token id; -1: the next packed embedding row of `embd`.
+int Engine::eval_chunk(const int *row_tok, int N, const float *embd) {
     if (N <= 0) return 0;
-    if (N > max_rows_ || n_past_ + N > n_ctx_) { set_last_error("context overflow: n_past + n_tokens > n_ctx"); return 1; }
     const int E = (int)llm_.n_embd;
     logits_host_valid_ = false;
-    if (tokens) {
-        for (int i = 0; i < N; i++) if (tokens[i] < 0 || tokens[i] >= (int)llm_.n_vocab) { set_last_error("token id out of range"); return 1; }
-    }
-    launch_set_int(d_npast_, n_past_, stream_);
-    if (tokens && N == 1) {
-        launch_set_int(d_tokens_, tokens[0], stream_);
+    launch_set_int(d_npast_, n_committed_, stream_);
+    if (N == 1 && row_tok[0] >= 0) {
+        launch_set_int(d_tokens_, row_tok[0], stream_);
         if (use_graph_ && !prof_on_) {
             if (!decode_graph_) {
                 hipGraph_t g = nullptr;
@@ -443,29 +524,59 @@ int Engine::eval(const int *tokens, const float *embd, int N) {
             forward(1, true, stream_);
         }
     } else {
-        if (tokens) HIP_CHECK(hipMemcpyAsync(d_tokens_, tokens, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
-        else HIP_CHECK(hipMemcpyAsync(x_, embd, (size_t)N * E * 4, hipMemcpyHostToDevice, stream_));
-        HIP_CHECK(hipStreamSynchronize(stream_));   // pageable source buffers belong to the caller
-        forward(N, tokens != nullptr, stream_);
+        HIP_CHECK(hipMemcpyAsync(d_tokens_, row_tok, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
+        size_t er = 0;
+        for (int i = 0; i < N;) {   // contiguous runs of embedding rows go straight into the residual stream
+            if (row_tok[i] >= 0) { i++; continue; }
+            int j = i; while (j < N && row_tok[j] < 0) j++;
+            HIP_CHECK(hipMemcpyAsync(x_ + (size_t)i * E, embd + er * E, (size_t)(j - i) * E * 4, hipMemcpyHostToDevice, stream_));
+            er += (size_t)(j - i); i = j;
+        }
+        HIP_CHECK(hipStreamSynchronize(stream_));   // the (pageable) staging vectors may be reused right after this call
+        forward(N, true, stream_);                   // k_get_rows skips rows whose id is negative
     }
-    n_past_ += N;
+    n_committed_ += N;
     return 0;
 }
 
-int Engine::add_tokens(const std::vector<int> &tokens) {
-    const int start = n_past_;
-    for (size_t i = 0; i < tokens.size(); i += (size_t)n_batch_) {
-        const int n = (int)std::min((size_t)n_batch_, tokens.size() - i);
-        if (eval(tokens.data() + i, nullptr, n)) { n_past_ = start; MG4_ERR("Failed to add string"); return E_FailedToAddString; }
+// Deferred prefill batching.  The reference evaluates every prompt fragment separately (system prompt, "Human: <Img>", the 32 image rows,
+// "</Img> ", the question, "### Assistant:" -- six passes over the weights for one image turn, minigpt4.cpp:2671-2702).  Token rows do not
+// depend on how they are batched (causal attention, per-row quantisation), so fragments are queued and evaluated in one pass when logits are
+// needed (sampling) -- the weights are streamed once.  Context overflow is still reported by the call that would overflow.
+int Engine::flush() {
+    if (pend_tok_.empty()) return 0;
+    const int E = (int)llm_.n_embd;
+    size_t er = 0;
+    for (size_t i = 0; i < pend_tok_.size(); i += (size_t)max_chunk_) {
+        const int n = (int)std::min((size_t)max_chunk_, pend_tok_.size() - i);
+        size_t ne = 0; for (int k = 0; k < n; k++) ne += pend_tok_[i + k] < 0;
+        const int rc = eval_chunk(pend_tok_.data() + i, n, pend_embd_.data() + er * E);
+        er += ne;
+        if (rc) { pend_tok_.clear(); pend_embd_.clear(); n_past_ = n_committed_; return rc; }
     }
+    pend_tok_.clear(); pend_embd_.clear();
+    return 0;
+}
+
+int Engine::add_tokens(const std::vector<int> &tokens, bool flush_now) {
+    if (n_past_ + (int)tokens.size() > n_ctx_) { set_last_error("context overflow: n_past + n_tokens > n_ctx"); MG4_ERR("Failed to add string"); return E_FailedToAddString; }
+    for (int t : tokens) if (t < 0 || t >= (int)llm_.n_vocab) { set_last_error("token id out of range"); MG4_ERR("Failed to add string"); return E_FailedToAddString; }
+    pend_tok_.insert(pend_tok_.end(), tokens.begin(), tokens.end());
+    n_past_ += (int)tokens.size();
+    if (flush_now || !defer_) { if (flush()) return E_FailedToAddString; }
     return E_None;
 }
 int Engine::add_string(const std::string &s) { return add_tokens(tok_.tokenize(s, true)); }
 int Engine::add_embedding(const float *data, int n_rows) {
-    if (eval(nullptr, data, n_rows)) { MG4_ERR("Failed to add embedding"); return E_FailedToAddEmbedding; }
+    if (n_rows <= 0 || n_past_ + n_rows > n_ctx_) { set_last_error("context overflow: n_past + n_rows > n_ctx"); MG4_ERR("Failed to add embedding"); return E_FailedToAddEmbedding; }
+    pend_tok_.insert(pend_tok_.end(), (size_t)n_rows, -1);
+    pend_embd_.insert(pend_embd_.end(), data, data + (size_t)n_rows * llm_.n_embd);
+    n_past_ += n_rows;
+    if (!defer_) { if (flush()) return E_FailedToAddEmbedding; }
     return E_None;
 }
 const float *Engine::logits_host() {
+    if (flush()) throw HipError{hipErrorUnknown, "deferred evaluation failed", __FILE__, __LINE__};
     if (!logits_host_valid_) {
         HIP_CHECK(hipMemcpyAsync(h_logits_, logits_, (size_t)llm_.n_vocab * 4, hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipStreamSynchronize(stream_));
@@ -474,6 +585,7 @@ const float *Engine::logits_host() {
     return h_logits_;
 }
 int Engine::sample_token(const SampleParams &p) {
+    if (flush()) throw HipError{hipErrorUnknown, "deferred evaluation failed", __FILE__, __LINE__};
     if (p.temp <= 0) { HIP_CHECK(hipStreamSynchronize(stream_)); return *h_argmax_; }   // greedy: argmax computed on the device
     return sampler_.sample(logits_host(), (int)llm_.n_vocab, p);
 }
@@ -484,10 +596,12 @@ const char *Engine::id_to_token(int id) const {
 }
 
 int Engine::decode_loop(int steps, int *tokens_out, float *ms_total) {
+    if (flush()) return 1;
     if (steps <= 0 || n_past_ + steps > n_ctx_) return 1;
     HIP_CHECK(hipStreamSynchronize(stream_));
     int first = *h_argmax_;
-    if (eval(&first, nullptr, 1)) return 1;   // builds the graph if needed, d_tokens_[0] <- greedy token afterwards (k_advance)
+    if (eval_chunk(&first, 1, nullptr)) return 1;   // builds the graph if needed, d_tokens_[0] <- greedy token afterwards (k_advance)
+    n_past_ += 1;
     HIP_CHECK(hipStreamSynchronize(stream_));
     if (tokens_out) tokens_out[0] = first;
     hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
@@ -501,19 +615,20 @@ int Engine::decode_loop(int steps, int *tokens_out, float *ms_total) {
     float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
     if (ms_total) *ms_total = ms;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    n_past_ += steps - 1;
+    n_past_ += steps - 1; n_committed_ += steps - 1;
     logits_host_valid_ = false;
     return 0;
 }
 
 int Engine::profile_decode(int steps, ProfStat *by_type, ProfStat *other) {
+    if (flush()) return 1;
     if (steps <= 0 || n_past_ + steps > n_ctx_) return 1;
     HIP_CHECK(hipStreamSynchronize(stream_));
     prof_on_ = true;
     hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
     HIP_CHECK(hipEventRecord(a, stream_));
     int tok = *h_argmax_;
-    for (int i = 0; i < steps; i++) { if (eval(&tok, nullptr, 1)) { prof_on_ = false; return 1; } HIP_CHECK(hipStreamSynchronize(stream_)); tok = *h_argmax_; }
+    for (int i = 0; i < steps; i++) { if (eval_chunk(&tok, 1, nullptr)) { prof_on_ = false; return 1; } n_past_ += 1; HIP_CHECK(hipStreamSynchronize(stream_)); tok = *h_argmax_; }
     HIP_CHECK(hipEventRecord(b, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
     prof_on_ = false;

@@ -36,12 +36,13 @@ public:
     int n_query() const { return v_nq_; }
 
     // ---- language path
-    int add_tokens(const std::vector<int> &tokens);   // chunks of n_batch (minigpt4.cpp:2365-2382)
+    int add_tokens(const std::vector<int> &tokens, bool flush_now = false);   // queued; evaluated in chunks of n_batch (minigpt4.cpp:2365-2382)
+    int flush();                                      // evaluate everything queued by add_tokens / add_embedding
     int add_string(const std::string &s);             // BOS + tokenize (minigpt4.cpp:2384-2397)
     int add_embedding(const float *data, int n_rows); // llama_eval_embd (minigpt4.cpp:2399-2422)
     int sample_token(const SampleParams &p);          // minigpt4.cpp:2425-2483
     const char *id_to_token(int id) const;            // minigpt4.cpp:2485-2497 (borrowed pointer)
-    void reset() { n_past_ = 0; }                     // minigpt4.cpp:2499-2502
+    void reset() { pend_tok_.clear(); pend_embd_.clear(); n_past_ = 0; n_committed_ = 0; }   // minigpt4.cpp:2499-2502
     void sync();
 
     int n_vocab() const { return (int)llm_.n_vocab; }
@@ -67,7 +68,7 @@ private:
     int load_llm(const std::string &path);
     int load_vision(const std::string &path);
     void alloc_buffers();
-    int eval(const int *tokens, const float *embd, int N);
+    int eval_chunk(const int *row_tok, int N, const float *embd);
     void forward(int N, bool from_tokens, hipStream_t s);
     struct Prep { int kind; const float *x; const float *w; };   // 1: rms_norm(x)*w, 2: x, 3: silu(x)*w -- then quantised for the consumer's type
     void mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep);
@@ -75,10 +76,20 @@ private:
     void upload_qweight(const TensorMeta &t, const uint8_t *file_base, QWeight &w);
     template <typename T> T *upload_raw(DeviceArena &a, const void *src, size_t bytes);
 
+    // Infinity-Cache prefetch of upcoming weight planes on a side stream (fork/join with events; captured into the decode graph)
+    void pf_add(PrefetchSet &ps, const QWeight &W, double from_frac, double to_frac) const;
+    void pf_fork(const PrefetchSet &ps, hipStream_t s);
+    void pf_join(hipStream_t s);
+    hipStream_t side_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr; bool pf_pending_ = false, use_prefetch_ = false;
+    double pf_mb_[4] = {22, 45, 22, 23};
+
     int device_ = 0;
     hipStream_t stream_ = nullptr;
     int n_ctx_ = 2048, n_batch_ = 512, max_rows_ = 512;
-    int n_past_ = 0;
+    int n_past_ = 0;        // logical position: evaluated + queued rows
+    int n_committed_ = 0;   // rows already evaluated on the device
+    bool defer_ = true; int max_chunk_ = 512;
+    std::vector<int> pend_tok_; std::vector<float> pend_embd_;
 
     // LLM
     LLMFile llm_;

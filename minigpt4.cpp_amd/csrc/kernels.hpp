@@ -23,6 +23,11 @@ void launch_silu_mul_quant(const float *a, const float *b, int N, int K, const A
 // ---- quantised mat-mul: y[t][r] = W[r] . act[t]  (+ residual[t][r]) ------------------------------------------------
 void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s);
 
+// prefill (N >= 16) on the int8 matrix cores for Q4_K / Q5_K / Q6_K / Q4_0; launch_mul_mat dispatches to it automatically
+bool mmq_supported(int type);
+void launch_mmq(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s);
+void set_mmq_enabled(int v);
+
 // decode (N = 1) persistent-wave mat-vec over 1..3 same-type, same-shape matrices (wq|wk|wv, w1|w3); false -> caller falls back to launch_mul_mat
 // pro: 0 = activations come from `A` (prepared by launch_rms_quant / launch_silu_mul_quant); 1 = rms_norm(px) * pw, 2 = px, 3 = silu(px) * pw are
 // prepared and quantised inside the kernel prologue (one launch less per use).
@@ -45,6 +50,8 @@ void launch_attn_llm(float *q, const float *k, const float *v, __half *kcache, _
 bool attn_head_size_supported(int hd);
 void launch_argmax(const float *logits, int n, int *out, void *scratch /*>= 512 bytes*/, hipStream_t s);
 void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);
+struct PrefetchSet { const void *ptr[16]; size_t bytes[16]; int n = 0; };
+void launch_prefetch(const PrefetchSet &ps, hipStream_t s);   // touches the ranges (fills the Infinity Cache); results are discarded
 void launch_set_int(int *p, int v, hipStream_t s);
 void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s);
 void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s);

@@ -543,7 +543,10 @@ bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *co
     }
 }
 
+static int g_mmq_enabled = 1;
+void set_mmq_enabled(int v) { g_mmq_enabled = v; }
 void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
+    if (g_mmq_enabled && N >= 5 && mmq_supported(W.type)) { launch_mmq(W, A, N, y, ldy, residual, s); return; }
     switch (W.type) {
     case GT_Q4_0: launch_mul_mat_t<GT_Q4_0>(W, A, N, y, ldy, residual, s); break;
     case GT_Q4_1: launch_mul_mat_t<GT_Q4_1>(W, A, N, y, ldy, residual, s); break;
@@ -688,6 +691,7 @@ __device__ float dequant_elem(int type, const uint8_t *row, int e) {
 }
 __global__ void k_get_rows(int type, const uint8_t *__restrict__ table, int K, size_t row_bytes, const int *__restrict__ tokens, float *__restrict__ out) {
     const int t = blockIdx.x;
+    if (tokens[t] < 0) return;                     // embedding row: already written by the host copy
     const uint8_t *row = table + (size_t)tokens[t] * row_bytes;
     const int e = blockIdx.y * blockDim.x + threadIdx.x;
     if (e < K) out[(size_t)t * K + e] = dequant_elem(type, row, e);
@@ -889,6 +893,29 @@ __global__ void k_fill_u16(unsigned short *p, size_t n, unsigned short v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s) { hipLaunchKernelGGL(k_fill_u16, dim3(1024), dim3(256), 0, s, (unsigned short *)p, n, v); }
+// MALL prefetch: touch byte ranges of upcoming weight planes so they sit in the 256 MiB Infinity Cache when the next mat-vec starts.
+// Launched on a side stream while a latency-bound kernel (norm/quantise, attention) leaves HBM idle.
+__global__ __launch_bounds__(256) void k_prefetch(const PrefetchSet ps) {
+    const size_t nthreads = (size_t)gridDim.x * 256, gtid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int acc = 0;
+    for (int r = 0; r < ps.n; r++) {
+        const int4 *p = reinterpret_cast<const int4 *>(ps.ptr[r]);
+        const size_t n16 = ps.bytes[r] / 16;
+        size_t i = gtid;
+        for (; i + 3 * nthreads < n16; i += 4 * nthreads) {
+            const int4 a = p[i], b = p[i + nthreads], c = p[i + 2 * nthreads], d = p[i + 3 * nthreads];
+            acc ^= a.x ^ b.y ^ c.z ^ d.w;
+        }
+        for (; i < n16; i += nthreads) acc ^= p[i].x;
+    }
+    asm volatile("" ::"v"(acc));
+}
+void launch_prefetch(const PrefetchSet &ps, hipStream_t s) {
+    if (ps.n <= 0) return;
+    size_t total = 0; for (int i = 0; i < ps.n; i++) total += ps.bytes[i];
+    const unsigned blocks = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, total / (256 * 16 * 4)));
+    hipLaunchKernelGGL(k_prefetch, dim3(blocks), dim3(256), 0, s, ps);
+}
 __global__ void k_set_int(int *p, int v) { *p = v; }
 void launch_set_int(int *p, int v, hipStream_t s) { hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, p, v); }
 // end of a decode step: the KV position advances and the greedy token becomes the next input (the host may overwrite it)

@@ -37,7 +37,6 @@ __global__ __launch_bounds__(BN * 4) void k_gemm_f16(const __half *__restrict__ 
     const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * BN;
     const int wm = BN == 64 ? wave >> 1 : wave, wn = BN == 64 ? wave & 1 : 0;
     const int nk = (K + BK - 1) / BK;
-    int4 ra[NCA], rw[NCW];
     // per-thread source pointers (row clamped) and LDS offsets of its chunks
     const __half *asrc[NCA], *wsrc[NCW]; int lofa[NCA], kofa[NCA], lofw[NCW], kofw[NCW];
 #pragma unroll
@@ -47,34 +46,40 @@ __global__ __launch_bounds__(BN * 4) void k_gemm_f16(const __half *__restrict__ 
     float16_t acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-    // K is a multiple of 8: a 16-byte chunk is either fully inside or fully outside; outside chunks load chunk 0 of the row and are zeroed
-#define MG4_GLOAD(kt)                                                                                           \
+    // Three statically named register stages: while tile k is multiplied out of LDS, the loads of tiles k+1 and k+2 are in flight and tile
+    // k+3 is issued.  No lambdas / structs / register copies around the stages (each of those made hipcc spill to scratch or wait on the
+    // in-flight loads); all loads unconditional (clamped + zeroed).  K is a multiple of 8, so a 16-byte chunk is entirely in or out.
+    int4 ra0[NCA], rw0[NCW], ra1[NCA], rw1[NCW], ra2[NCA], rw2[NCW];
+#define MG4_GLOAD(kt, RA, RW)                                                                                   \
     _Pragma("unroll") for (int i = 0; i < NCA; i++) {                                                           \
         const bool valid = (kt) * BK + kofa[i] < K; const int ko = valid ? (kt) * BK : -kofa[i];                \
         int4 va = *reinterpret_cast<const int4 *>(asrc[i] + ko);                                                \
         if (!valid) { va.x = va.y = va.z = va.w = 0; }                                                          \
-        ra[i] = va; }                                                                                           \
+        RA[i] = va; }                                                                                           \
     _Pragma("unroll") for (int i = 0; i < NCW; i++) {                                                           \
         const bool valid = (kt) * BK + kofw[i] < K; const int ko = valid ? (kt) * BK : -kofw[i];                \
         int4 vw = *reinterpret_cast<const int4 *>(wsrc[i] + ko);                                                \
         if (!valid) { vw.x = vw.y = vw.z = vw.w = 0; }                                                          \
-        rw[i] = vw; }
-    MG4_GLOAD(0)
-    for (int kt = 0; kt < nk; kt++) {
-#pragma unroll
-        for (int i = 0; i < NCA; i++) *reinterpret_cast<int4 *>(&As[lofa[i]]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NCW; i++) *reinterpret_cast<int4 *>(&Ws[lofw[i]]) = rw[i];
-        __syncthreads();
-        MG4_GLOAD(kt + 1)            // past the end: zeroed, never stored
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ks++) {
-            const half8_t af = *reinterpret_cast<const half8_t *>(&As[(wm * 32 + (lane & 31)) * LD + ks * 16 + (lane >> 5) * 8]);
-            const half8_t bf = *reinterpret_cast<const half8_t *>(&Ws[(wn * 32 + (lane & 31)) * LD + ks * 16 + (lane >> 5) * 8]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
-        }
-        __syncthreads();
+        RW[i] = vw; }
+#define MG4_STEP(kt, RA, RW)                                                                                    \
+    {   _Pragma("unroll") for (int i = 0; i < NCA; i++) *reinterpret_cast<int4 *>(&As[lofa[i]]) = RA[i];        \
+        _Pragma("unroll") for (int i = 0; i < NCW; i++) *reinterpret_cast<int4 *>(&Ws[lofw[i]]) = RW[i];        \
+        __syncthreads();                                                                                        \
+        MG4_GLOAD((kt) + 3, RA, RW)      /* past the end: zeroed */                                             \
+        _Pragma("unroll") for (int ks = 0; ks < BK / 16; ks++) {                                                \
+            const half8_t af = *reinterpret_cast<const half8_t *>(&As[(wm * 32 + (lane & 31)) * LD + ks * 16 + (lane >> 5) * 8]); \
+            const half8_t bf = *reinterpret_cast<const half8_t *>(&Ws[(wn * 32 + (lane & 31)) * LD + ks * 16 + (lane >> 5) * 8]); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0); }                               \
+        __syncthreads(); }
+    MG4_GLOAD(0, ra0, rw0)
+    MG4_GLOAD(1, ra1, rw1)
+    MG4_GLOAD(2, ra2, rw2)
+    for (int kt = 0; kt < nk; kt += 3) {      // whole triples: steps past nk multiply zero tiles (accumulators unchanged)
+        MG4_STEP(kt, ra0, rw0)
+        MG4_STEP(kt + 1, ra1, rw1)
+        MG4_STEP(kt + 2, ra2, rw2)
     }
+#undef MG4_STEP
 #undef MG4_GLOAD
     // epilogue: all gathers of one kind are issued together (no per-element branches around loads)
     const int col = n0 + wn * 32 + (lane & 31), colc = min(col, N - 1);
@@ -279,7 +284,14 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float *__restrict__ q, 
         for (int j = sub; j < nk; j += 8) mx = fmaxf(mx, sr[j]);
         mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
         double sum = 0.0;
-        for (int j = sub; j < nk; j += 8) { const float e = tab_v(tb.exp, sr[j] - mx); sr[j] = e; sum += (double)e; }
+        // the fp16-table gathers are L2 round trips: issue them in batches of 8 instead of one dependent gather per iteration
+        for (int j0 = sub; j0 < nk; j0 += 64) {
+            float e[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int j = j0 + 8 * u; e[u] = tab_v(tb.exp, sr[min(j, nk - 1)] - mx); }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int j = j0 + 8 * u; if (j < nk) { sr[j] = e[u]; sum += (double)e[u]; } }
+        }
         sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
         const float inv = (float)(1.0 / sum);
         for (int j = sub; j < nkp; j += 8) sr[j] = j < nk ? sr[j] * inv : 0.0f;
@@ -295,6 +307,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float *__restrict__ q, 
         const float *pa = S + (size_t)(pqt * 16 + (lane & 15)) * LS + (lane >> 4);
         const int dim = min(dt * 16 + (lane & 15), HD);                     // column HD of kv is the (finite) pad column; its results are discarded
         const float *vb = kv + (size_t)(lane >> 4) * LDV + dim;
+#pragma unroll 8
         for (int ks = 0; ks < nks; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * ks], vb[(size_t)4 * ks * LDV], acc, 0, 0, 0);
         const int d = dt * 16 + (lane & 15);
 #pragma unroll

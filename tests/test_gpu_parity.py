@@ -56,7 +56,7 @@ def test_activation_quantisation_bit_exact(gpu_lib, rms):
 
 
 @pytest.mark.parametrize("wtype", QTYPES)
-@pytest.mark.parametrize("shape", [(1, 512, 96), (5, 768, 70), (1, 5120, 64)])
+@pytest.mark.parametrize("shape", [(1, 512, 96), (5, 768, 70), (1, 5120, 64), (33, 768, 70), (70, 1024, 130), (142, 2048, 256)])   # N >= 16: int8-MFMA prefill path
 def test_mul_mat_matches_oracle(gpu_lib, wtype, shape):
     import refcpu as R
     from minigpt4_cpp_amd import quants as Q
