@@ -234,7 +234,7 @@ def main():
     names = {0: "f32", 1: "f16", 2: "q4_0", 3: "q4_1", 6: "q5_0", 7: "q5_1", 8: "q8_0", 12: "q4_k", 13: "q5_k", 14: "q6_k"}
     achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
     pmc = pmc_traffic(names.get(dom_t, ""))
-    roofline = {"bound": "hbm", "kernel": f"k_mul_mat<{names.get(dom_t, dom_t)}> (fused-dequant int8-dot mat-vec)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": f"k_matvec_v2<{names.get(dom_t, dom_t)}> (persistent-wave fused-dequant int8-dot mat-vec)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc[0], "traffic_source": pmc[1],
                 "avg_launch_us": dom["ms"] * 1e3 / dom["launches"], "bytes_per_launch_avg": dom["bytes"] / dom["launches"],
                 "all_matvec_GBps": sum(s["bytes"] for s in stats.values()) / (sum(s["ms"] for s in stats.values()) * 1e-3) / 1e9,

@@ -229,6 +229,58 @@ int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int64_t n_in, in
     });
 }
 
+// The decode mat-vec launches exactly as Engine::forward issues them: n1 equally spaced matrices of type1 (+ optionally n2 of type2 in the same,
+// mixed-type launch), activation preparation either standalone (fuse = 0) or in the kernel prologue, optional residual, optional SiLU row-pair
+// epilogue.  prep: 1 = rms_norm(x) * x2, 2 = x, 3 = silu(x) * x2.  y: (n1 + n2) * n_out floats (epi = 1: n_out floats).
+int minigpt4_amd_test_matvec(int type1, const void *raw1, int n1, int type2, const void *raw2, int n2, int64_t n_in, int64_t n_out, const float *x, const float *x2, int prep,
+                             int fuse, int epi, const float *residual, float *y) {
+    if (!raw1 || !x || !y || n_in <= 0 || n_out <= 0 || n1 < 1 || n1 > 3 || n2 < 0 || n2 > 1 || prep < 1 || prep > 3 || (prep != 2 && !x2)) return 1;
+    if (!qweight_supported(type1) || n_in % gt_block(type1) || (n2 && (!raw2 || !qweight_supported(type2) || n_in % gt_block(type2)))) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const int K = (int)n_in, R = (int)n_out, nt = n1 + n2;
+        std::vector<std::unique_ptr<DevBuf>> keep;
+        std::vector<QWeight> W((size_t)nt);
+        auto upload = [&](int type, const void *raw, int n, QWeight *dst) {
+            QWeight plan; const size_t need = plan_qweight(type, R, K, plan, nullptr), raw_bytes = gt_nbytes(type, (size_t)R * K);
+            keep.emplace_back(new DevBuf(need * (size_t)n)); uint8_t *base = (uint8_t *)keep.back()->p;   // one allocation: equal spacing
+            DevBuf d_raw(raw_bytes);
+            for (int m = 0; m < n; m++) {
+                plan_qweight(type, R, K, dst[m], base + (size_t)m * need);
+                HIP_CHECK(hipMemcpy(d_raw.p, (const uint8_t *)raw + (size_t)m * raw_bytes, raw_bytes, hipMemcpyHostToDevice));
+                if (type == GT_F16 || type == GT_F32) HIP_CHECK(hipMemcpy(base + (size_t)m * need, d_raw.p, raw_bytes, hipMemcpyDeviceToDevice)); else launch_repack(d_raw.as<uint8_t>(), dst[m], nullptr);
+                HIP_CHECK(hipDeviceSynchronize());
+            }
+        };
+        upload(type1, raw1, n1, W.data());
+        if (n2) upload(type2, raw2, n2, W.data() + n1);
+        DevBuf d_x((size_t)K * 4), d_x2((size_t)K * 4), d_y((size_t)nt * R * 4), d_res((size_t)nt * R * 4), d_tab(65536 * 2);
+        HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)K * 4, hipMemcpyHostToDevice));
+        if (x2) HIP_CHECK(hipMemcpy(d_x2.p, x2, (size_t)K * 4, hipMemcpyHostToDevice));
+        if (residual) HIP_CHECK(hipMemcpy(d_res.p, residual, (size_t)nt * R * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(d_y.p, 0xFF, (size_t)nt * R * 4));
+        Tables tb;
+        { std::vector<__half> si(65536);
+          for (int i = 0; i < 65536; i++) { const float v = __half2float(__ushort_as_half((unsigned short)i)); si[(size_t)i] = __float2half_rn(v / (1.0f + expf(-v))); }
+          HIP_CHECK(hipMemcpy(d_tab.p, si.data(), 131072, hipMemcpyHostToDevice)); tb.silu = d_tab.as<__half>(); }
+        ActQ A; alloc_act(A, keep, 1, (size_t)K);
+        int mask = 0; for (int m = 0; m < nt; m++) mask |= act_mask_for(W[(size_t)m].type);
+        if (!fuse) {
+            if (prep == 1) launch_rms_quant(d_x.as<float>(), d_x2.as<float>(), 1, K, A, mask, nullptr);
+            else launch_silu_mul_quant(d_x.as<float>(), prep == 3 ? d_x2.as<float>() : nullptr, 1, K, A, mask, tb, nullptr);
+        }
+        const QWeight *Wp[4]; float *Yp[4]; const float *Rp[4];
+        for (int m = 0; m < nt; m++) { Wp[m] = &W[(size_t)m]; Yp[m] = d_y.as<float>() + (size_t)m * R; Rp[m] = d_res.as<float>() + (size_t)m * R; }
+        bool ok;
+        if (n2) ok = launch_matvec_mixed(Wp, Yp, n1, Wp + n1, Yp + n1, n2, A, nullptr, fuse ? prep : 0, d_x.as<float>(), d_x2.as<float>());
+        else ok = launch_matvec_set(Wp, Yp, residual ? Rp : nullptr, n1, A, nullptr, fuse ? prep : 0, d_x.as<float>(), d_x2.as<float>(), &tb, epi);
+        if (!ok) { set_last_error("shape / type outside the decode mat-vec kernel's range"); return 4; }
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(y, d_y.p, (size_t)(epi ? 1 : nt) * R * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+
 int minigpt4_amd_test_quantize(const float *x, const float *rms_w, int64_t N, int64_t K, int8_t *q8k, float *dk, int16_t *bsums, int8_t *q80, float *d0) {
     if (!x || N <= 0 || K <= 0 || K % 256) return 1;
     if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
@@ -274,7 +326,7 @@ int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int 
     if (device_count_noexcept() <= 0) return 2;
     return guarded(3, [&]() -> int {
         hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0));
-        set_matvec_tuning(waves_per_cu, prop.multiProcessorCount);
+        set_matvec_tuning(waves_per_cu, 0, prop.multiProcessorCount);
         QWeight plan; const size_t need = plan_qweight(ggml_type, rows, cols, plan, nullptr);
         std::vector<std::unique_ptr<DevBuf>> keep;
         std::vector<QWeight> W((size_t)n_sets * n_mat);

@@ -40,9 +40,6 @@ Engine::~Engine() {
     if (stage_) (void)hipFree(stage_);
     if (h_argmax_) (void)hipHostFree(h_argmax_);
     if (h_logits_) (void)hipHostFree(h_logits_);
-    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
-    if (ev_join_) (void)hipEventDestroy(ev_join_);
-    if (side_) (void)hipStreamDestroy(side_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 void Engine::sync() { (void)flush(); HIP_CHECK(hipStreamSynchronize(stream_)); }
@@ -61,12 +58,6 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     HIP_CHECK(hipGetDeviceProperties(&prop, device_));
     MG4_INFO("device %d: %s (%s), %d CUs, %.1f GiB", device_, prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
-    HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-    // Infinity-Cache prefetch on a side stream: measured a LOSS (173 vs 298 tok/s): graph fork/join costs ~12 us each, and a fully cache-resident
-    // mat-vec is only ~15 % faster than an HBM-streamed one (profiles/r01f_mall_probe.log).  Opt-in experiment.
-    use_prefetch_ = getenv("MINIGPT4_PREFETCH") && atoi(getenv("MINIGPT4_PREFETCH"));
-    if (const char *pm = getenv("MINIGPT4_PF_MB")) sscanf(pm, "%lf,%lf,%lf,%lf", &pf_mb_[0], &pf_mb_[1], &pf_mb_[2], &pf_mb_[3]);
     n_ctx_ = n_ctx > 0 ? n_ctx : 2048;
     n_batch_ = n_batch > 0 ? n_batch : 512;
     max_rows_ = std::max(n_batch_, 32);
@@ -76,12 +67,13 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (getenv("MINIGPT4_NO_MMQ")) set_mmq_enabled(!atoi(getenv("MINIGPT4_NO_MMQ")));
     if (getenv("MINIGPT4_ATTN_MFMA")) set_attn_mfma(atoi(getenv("MINIGPT4_ATTN_MFMA")));
     if (getenv("MINIGPT4_GEMM_BK")) set_gemm_bk(atoi(getenv("MINIGPT4_GEMM_BK")));
-    // Fusing the activation preparation into the mat-vec prologue was measured SLOWER (262 vs 302 tok/s, profiles/r01e): every workgroup repeats
-    // the 5120-element norm + quantisation and the kernel start is delayed by it.  Kept as an opt-in experiment.
-    use_fused_pro_ = getenv("MINIGPT4_FUSED_PRO") && atoi(getenv("MINIGPT4_FUSED_PRO")) == 1;
-    fuse_plain_ = getenv("MINIGPT4_FUSED_PRO") && atoi(getenv("MINIGPT4_FUSED_PRO")) == 2;   // only the reduction-free preparation (attention output -> wo)
+    // Decode: which activation preparations run inside the consuming mat-vec's prologue (one fat workgroup per CU repeats the row preparation while
+    // its first weight tiles are in flight) instead of as their own launch.  bit 0: attn_norm -> wq|wk|wv, 1: attention output -> wo,
+    // 2: ffn_norm -> w1|w3, 3: silu(w1 x) * (w3 x) -> w2, 4: final norm -> output; bit 5: w1|w3 launch writes silu(w1 x) * (w3 x) itself
+    // (row-pair epilogue); bit 6: wq|wk and a differently typed wv in one launch.  See DESIGN.md "mat-vec prologue".
+    fuse_mask_ = getenv("MINIGPT4_FUSE") ? atoi(getenv("MINIGPT4_FUSE")) : FUSE_DEFAULT;
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
-    if (getenv("MINIGPT4_MV_WAVES")) set_matvec_tuning(atoi(getenv("MINIGPT4_MV_WAVES")), prop.multiProcessorCount); else set_matvec_tuning(0, prop.multiProcessorCount);
+    set_matvec_tuning(getenv("MINIGPT4_MV_WAVES") ? atoi(getenv("MINIGPT4_MV_WAVES")) : 0, getenv("MINIGPT4_FAT_LB") ? atoi(getenv("MINIGPT4_FAT_LB")) : 0, prop.multiProcessorCount);
     sampler_.seed(seed);
     auto t0 = std::chrono::steady_clock::now();
     if (int e = load_llm(llm_path)) return e;
@@ -364,76 +356,62 @@ void Engine::alloc_buffers() {
 // ====================================================================================================================
 // language path
 // ====================================================================================================================
-// ---- Infinity-Cache prefetch ---------------------------------------------------------------------------------------------------------
-// The decode chain alternates HBM-saturating mat-vecs with latency-bound kernels (norm + quantise, attention) during which HBM idles.
-// While such a kernel runs, a side stream touches the first part of the NEXT mat-vec's planes so that they are resident in the 256 MiB
-// Infinity Cache when it starts (the mat-vec's access front moves linearly through every plane, so "the first x %" of each plane is
-// exactly what it reads first).  fork/join are plain events; under stream capture they become parallel branches of the decode graph.
-void Engine::pf_add(PrefetchSet &ps, const QWeight &W, double from_frac, double to_frac) const {
-    const size_t n = (size_t)W.rows * W.cols;
-    auto add = [&](const uint8_t *p, size_t bytes) {
-        if (!p || !bytes || ps.n >= 16) return;
-        size_t a = (size_t)(bytes * from_frac) & ~(size_t)255, b = std::min(bytes, ((size_t)(bytes * to_frac) + 255) & ~(size_t)255);
-        if (b > a) { ps.ptr[ps.n] = p + a; ps.bytes[ps.n] = b - a; ps.n++; }
-    };
-    switch (W.type) {
-    case GT_Q4_0: add(W.qs, n / 32 * 16); add(W.sc, n / 32 * 2); break;
-    case GT_Q4_1: add(W.qs, n / 32 * 16); add(W.sc, n / 32 * 4); break;
-    case GT_Q5_0: add(W.qs, n / 32 * 16); add(W.qh, n / 32 * 4); add(W.sc, n / 32 * 2); break;
-    case GT_Q5_1: add(W.qs, n / 32 * 16); add(W.qh, n / 32 * 4); add(W.sc, n / 32 * 4); break;
-    case GT_Q4_K: add(W.qs, n / 256 * 128); add(W.sc, n / 256 * 16); break;
-    case GT_Q5_K: add(W.qs, n / 256 * 128); add(W.qh, n / 256 * 32); add(W.sc, n / 256 * 16); break;
-    case GT_Q6_K: add(W.qs, n / 256 * 128); add(W.qh, n / 256 * 64); add(W.sc, n / 256 * 16); add(W.d, n / 256 * 2); break;
-    default: add(W.qs, W.bytes); break;
-    }
-}
-void Engine::pf_fork(const PrefetchSet &ps, hipStream_t s) {
-    if (!use_prefetch_ || ps.n == 0) return;
-    HIP_CHECK(hipEventRecord(ev_fork_, s));
-    HIP_CHECK(hipStreamWaitEvent(side_, ev_fork_, 0));
-    launch_prefetch(ps, side_);
-    HIP_CHECK(hipEventRecord(ev_join_, side_));
-    pf_pending_ = true;
-}
-void Engine::pf_join(hipStream_t s) {
-    if (!pf_pending_) return;
-    HIP_CHECK(hipStreamWaitEvent(s, ev_join_, 0));
-    pf_pending_ = false;
-}
-
 // One launch for 1..3 same-shape matrices when decoding (v2 persistent-wave kernel); otherwise one k_mul_mat launch per matrix.
 // prep != null: the activation row still has to be prepared (rms_norm*w | identity | silu(a)*b + quantisation); when decoding it is fused into
 // the mat-vec prologue, otherwise the standalone preparation kernel runs first.
-void Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep) {
+bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair) {
+    bool same = true;
+    int mask = 0;
+    for (int i = 0; i < n; i++) { mask |= act_mask_for(W[i]->type); if (i) same = same && W[i]->type == W[0]->type && W[i]->rows == W[0]->rows && W[i]->cols == W[0]->cols; }
+    const bool v2 = N == 1 && use_v2_ && same;
+    fuse = fuse && v2 && prep && matvec_prologue_supported(W[0]->type, W[0]->cols);
+    silu_pair = silu_pair && v2 && n == 2 && !res && matvec_silu_pair_supported(W[0]->type, W[0]->cols) && (!fuse || prep->kind == 1);
+    if (prep && !fuse) {   // standalone preparation
+        if (prep->kind == 1) launch_rms_quant(prep->x, prep->w, N, W[0]->cols, act_, mask, s);
+        else launch_silu_mul_quant(prep->x, prep->kind == 3 ? prep->w : nullptr, N, W[0]->cols, act_, mask, tabs_, s);
+    }
     ProfEv ev{};
     if (prof_on_) {
         HIP_CHECK(hipEventCreate(&ev.a)); HIP_CHECK(hipEventCreate(&ev.b)); ev.type = W[0]->type; ev.bytes = 0;
         for (int i = 0; i < n; i++) ev.bytes += (double)W[i]->bytes;
         HIP_CHECK(hipEventRecord(ev.a, s));
     }
-    bool same = true;
-    int mask = 0;
-    for (int i = 0; i < n; i++) { mask |= act_mask_for(W[i]->type); if (i) same = same && W[i]->type == W[0]->type && W[i]->rows == W[0]->rows && W[i]->cols == W[0]->cols; }
     bool done = false;
-    if (N == 1 && use_v2_ && same && prep && use_fused_pro_)
-        done = launch_matvec_set(W, y, res, n, act_, s, prep->kind, prep->x, prep->w, &tabs_);
+    if (silu_pair) {   // the pair epilogue needs the two matrices equally spaced; launch_matvec_set refuses otherwise and the plain launch below runs
+        done = fuse ? launch_matvec_set(W, y, res, n, act_, s, prep->kind, prep->x, prep->w, &tabs_, 1) : launch_matvec_set(W, y, res, n, act_, s, 0, nullptr, nullptr, &tabs_, 1);
+        silu_pair = done;
+    }
     if (!done) {
-        if (prep) {   // standalone preparation
-            if (prep->kind == 1) launch_rms_quant(prep->x, prep->w, N, W[0]->cols, act_, mask, s);
-            else launch_silu_mul_quant(prep->x, prep->kind == 3 ? prep->w : nullptr, N, W[0]->cols, act_, mask, tabs_, s);
-        }
-        if (!(N == 1 && use_v2_ && same && launch_matvec_set(W, y, res, n, act_, s))) {
-            for (int i = 0; i < n; i++) {
-                const QWeight *Wp[1] = {W[i]}; float *Yp[1] = {y[i]}; const float *Rp[1] = {res ? res[i] : nullptr};
-                if (!(N == 1 && use_v2_ && launch_matvec_set(Wp, Yp, Rp, 1, act_, s))) launch_mul_mat(*W[i], act_, N, y[i], ldy, res ? res[i] : nullptr, s);
-            }
+        if (fuse) done = launch_matvec_set(W, y, res, n, act_, s, prep->kind, prep->x, prep->w, &tabs_);
+        else if (v2) done = launch_matvec_set(W, y, res, n, act_, s);
+    }
+    if (!done) {
+        if (fuse) throw HipError{hipErrorInvalidValue, "fused mat-vec prologue rejected a supported shape", __FILE__, __LINE__};
+        for (int i = 0; i < n; i++) {
+            const QWeight *Wp[1] = {W[i]}; float *Yp[1] = {y[i]}; const float *Rp[1] = {res ? res[i] : nullptr};
+            if (!(N == 1 && use_v2_ && launch_matvec_set(Wp, Yp, Rp, 1, act_, s))) launch_mul_mat(*W[i], act_, N, y[i], ldy, res ? res[i] : nullptr, s);
         }
     }
     if (prof_on_) { HIP_CHECK(hipEventRecord(ev.b, s)); prof_events_.push_back(ev); }
+    return silu_pair;
 }
-void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep) {
+void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse) {
     const QWeight *Wp[1] = {&W}; float *Yp[1] = {y}; const float *Rp[1] = {residual};
-    mul_mat_set(Wp, Yp, Rp, 1, N, ldy, s, prep);
+    mul_mat_set(Wp, Yp, Rp, 1, N, ldy, s, prep, fuse);
+}
+
+// wq|wk and a differently typed wv (k-quant "more bits" layers) in one launch; returns false when the shapes / types are outside the mixed kernel's range.
+bool Engine::mixed_qkv(const LayerW &L, hipStream_t s, bool fuse) {
+    if (!use_v2_ || prof_on_) return false;   // the per-type profile wants one type per launch
+    const int E = (int)llm_.n_embd;
+    const QWeight *W1[2] = {&L.wq, &L.wk}, *W2[1] = {&L.wv}; float *Y1[2] = {q_, k_}, *Y2[1] = {v_};
+    if (act_mask_for(L.wq.type) != ACT_Q8K || act_mask_for(L.wv.type) != ACT_Q8K) return false;
+    if (fuse && matvec_prologue_supported(L.wq.type, E)) { if (launch_matvec_mixed(W1, Y1, 2, W2, Y2, 1, act_, s, 1, x_, L.attn_norm)) return true; }
+    // standalone preparation, then the mixed launch; if that is refused the caller's per-type launches find the row already prepared
+    launch_rms_quant(x_, L.attn_norm, 1, E, act_, ACT_Q8K, s);
+    if (launch_matvec_mixed(W1, Y1, 2, W2, Y2, 1, act_, s)) return true;
+    mul_mat_set(W1, Y1, nullptr, 2, 1, E, s, nullptr, false); mul_mat(L.wv, 1, v_, E, nullptr, s, nullptr, false);
+    return true;
 }
 
 // Enqueue one forward pass for N rows already described by d_tokens_ (from_tokens) or x_ (embeddings), at position *d_npast_.
@@ -441,64 +419,36 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s) {
     const int E = (int)llm_.n_embd, F = (int)llm_.n_ff(), H = (int)llm_.n_head, hd = E / H, V = (int)llm_.n_vocab;
     const size_t C = (size_t)n_ctx_;
     if (from_tokens) launch_get_rows(tok_type_, tok_raw_, E, d_tokens_, N, x_, s);
+    const bool dec = N == 1;
+    auto fz = [&](int bit) { return dec && (fuse_mask_ >> bit & 1); };
     for (size_t il = 0; il < layers_.size(); il++) {
         const LayerW &L = layers_[il];
         __half *kc = kc_ + il * C * E, *vc = vc_ + il * C * E;
         const Prep p_attn{1, x_, L.attn_norm}, p_att{2, att_, nullptr}, p_ffn{1, x_, L.ffn_norm}, p_silu{3, h1_, h3_};
-        const bool dec = N == 1 && !use_fused_pro_;
-        auto frac = [](double mb, size_t bytes) { return bytes ? std::min(1.0, mb * 1e6 / (double)bytes) : 0.0; };
-        const size_t qkv_b = L.wq.bytes + L.wk.bytes + L.wv.bytes, w13_b = L.w1.bytes + L.w3.bytes;
-        const double f13a = frac(pf_mb_[1], w13_b), f13b = std::min(1.0, f13a + frac(pf_mb_[2], w13_b));
-        if (dec) {   // the previous layer's w2 has just saturated HBM; the norm/quantise kernel below leaves it idle
-            PrefetchSet ps; const double f = frac(pf_mb_[0], qkv_b);
-            pf_add(ps, L.wq, 0, f); pf_add(ps, L.wk, 0, f); pf_add(ps, L.wv, 0, f); pf_fork(ps, s);
-            launch_rms_quant(x_, L.attn_norm, 1, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s);
-            pf_join(s);
-        }
         {
             const QWeight *W3[3] = {&L.wq, &L.wk, &L.wv}; float *Y3[3] = {q_, k_, v_};
-            const Prep *pp = dec ? nullptr : &p_attn;
-            if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s, pp);
-            else if (!dec && act_mask_for(L.wv.type) == act_mask_for(L.wq.type) && !(N == 1 && use_fused_pro_)) {   // one preparation serves both launches
+            if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s, &p_attn, fz(0));
+            else if (fz(6) && L.wk.type == L.wq.type && mixed_qkv(L, s, fz(0))) {}
+            else if (act_mask_for(L.wv.type) == act_mask_for(L.wq.type) && !fz(0)) {   // one standalone preparation serves both launches
                 launch_rms_quant(x_, L.attn_norm, N, E, act_, act_mask_for(L.wq.type), s);
-                mul_mat_set(W3, Y3, nullptr, 2, N, E, s, nullptr); mul_mat(L.wv, N, v_, E, nullptr, s, nullptr);
-            } else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s, pp); mul_mat(L.wv, N, v_, E, nullptr, s, pp); }
+                mul_mat_set(W3, Y3, nullptr, 2, N, E, s, nullptr, false); mul_mat(L.wv, N, v_, E, nullptr, s, nullptr, false);
+            } else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s, &p_attn, fz(0)); mul_mat(L.wv, N, v_, E, nullptr, s, &p_attn, fz(0)); }
         }
-        if (dec) {   // attention + its quantisation: prefetch all of wo and the head of w1|w3
-            PrefetchSet ps; pf_add(ps, L.wo, 0, 1.0); pf_add(ps, L.w1, 0, f13a); pf_add(ps, L.w3, 0, f13a); pf_fork(ps, s);
-        }
-        if (N == 1) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast_, n_ctx_, cos_, sin_, tabs_, att_, true, s);
+        if (dec) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast_, n_ctx_, cos_, sin_, tabs_, att_, true, s);
         else { launch_rope_kv(q_, k_, v_, N, H, hd, d_npast_, cos_, sin_, kc, vc, s); launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast_, n_ctx_, cos_, sin_, tabs_, att_, false, s); }
-        if (dec && fuse_plain_) { pf_join(s); use_fused_pro_ = true; mul_mat(L.wo, N, x_, E, x_, s, &p_att); use_fused_pro_ = false; }
-        else if (dec) { launch_silu_mul_quant(att_, nullptr, 1, E, act_, act_mask_for(L.wo.type), tabs_, s); pf_join(s); mul_mat(L.wo, N, x_, E, x_, s, nullptr); }
-        else mul_mat(L.wo, N, x_, E, x_, s, &p_att);
-        if (dec) {
-            PrefetchSet ps; pf_add(ps, L.w1, f13a, f13b); pf_add(ps, L.w3, f13a, f13b); pf_fork(ps, s);
-            launch_rms_quant(x_, L.ffn_norm, 1, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s);
-            pf_join(s);
-        }
-        {
-            const Prep *pp = dec ? nullptr : &p_ffn;
-            if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; mul_mat_set(W2, Y2, nullptr, 2, N, F, s, pp); }
-            else { mul_mat(L.w1, N, h1_, F, nullptr, s, pp); mul_mat(L.w3, N, h3_, F, nullptr, s, pp); }
-        }
-        if (dec) {
-            PrefetchSet ps; pf_add(ps, L.w2, 0, frac(pf_mb_[3], L.w2.bytes)); pf_fork(ps, s);
-            launch_silu_mul_quant(h1_, h3_, 1, F, act_, act_mask_for(L.w2.type), tabs_, s);
-            pf_join(s);
-            mul_mat(L.w2, N, x_, E, x_, s, nullptr);
-        } else mul_mat(L.w2, N, x_, E, x_, s, &p_silu);
+        mul_mat(L.wo, N, x_, E, x_, s, &p_att, fz(1));
+        bool paired = false;   // h1_ already holds silu(w1 x) * (w3 x)
+        if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5)); }
+        else if (act_mask_for(L.w1.type) == act_mask_for(L.w3.type) && !fz(2)) {
+            launch_rms_quant(x_, L.ffn_norm, N, E, act_, act_mask_for(L.w1.type), s);
+            mul_mat(L.w1, N, h1_, F, nullptr, s, nullptr, false); mul_mat(L.w3, N, h3_, F, nullptr, s, nullptr, false);
+        } else { mul_mat(L.w1, N, h1_, F, nullptr, s, &p_ffn, fz(2)); mul_mat(L.w3, N, h3_, F, nullptr, s, &p_ffn, fz(2)); }
+        const Prep p_h{2, h1_, nullptr};
+        mul_mat(L.w2, N, x_, E, x_, s, paired ? &p_h : &p_silu, fz(3));
     }
     // only the last token's logits are kept (llama.cpp logits_all = false)
-    if (N == 1 && !use_fused_pro_) {
-        PrefetchSet ps; pf_add(ps, output_, 0, std::min(1.0, pf_mb_[0] * 1e6 / (double)std::max<size_t>(1, output_.bytes))); pf_fork(ps, s);
-        launch_rms_quant(x_, norm_, 1, E, act_, act_mask_for(output_.type), s);
-        pf_join(s);
-        mul_mat(output_, 1, logits_, V, nullptr, s, nullptr);
-    } else {
-        const Prep p_out{1, x_ + (size_t)(N - 1) * E, norm_};
-        mul_mat(output_, 1, logits_, V, nullptr, s, &p_out);
-    }
+    const Prep p_out{1, x_ + (size_t)(N - 1) * E, norm_};
+    mul_mat(output_, 1, logits_, V, nullptr, s, &p_out, fz(4));
     launch_argmax(logits_, V, d_argmax_, d_scratch_, s);
     launch_advance(d_npast_, N, d_tokens_, d_argmax_, s);
     HIP_CHECK(hipMemcpyAsync(h_argmax_, d_argmax_, 4, hipMemcpyDeviceToHost, s));

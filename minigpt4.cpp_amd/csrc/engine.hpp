@@ -71,17 +71,11 @@ private:
     int eval_chunk(const int *row_tok, int N, const float *embd);
     void forward(int N, bool from_tokens, hipStream_t s);
     struct Prep { int kind; const float *x; const float *w; };   // 1: rms_norm(x)*w, 2: x, 3: silu(x)*w -- then quantised for the consumer's type
-    void mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep);
-    void mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep);
+    void mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse);
+    bool mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair = false);
     void upload_qweight(const TensorMeta &t, const uint8_t *file_base, QWeight &w);
     template <typename T> T *upload_raw(DeviceArena &a, const void *src, size_t bytes);
 
-    // Infinity-Cache prefetch of upcoming weight planes on a side stream (fork/join with events; captured into the decode graph)
-    void pf_add(PrefetchSet &ps, const QWeight &W, double from_frac, double to_frac) const;
-    void pf_fork(const PrefetchSet &ps, hipStream_t s);
-    void pf_join(hipStream_t s);
-    hipStream_t side_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr; bool pf_pending_ = false, use_prefetch_ = false;
-    double pf_mb_[4] = {22, 45, 22, 23};
 
     int device_ = 0;
     hipStream_t stream_ = nullptr;
@@ -96,6 +90,7 @@ private:
     Tokenizer tok_;
     Sampler sampler_;
     struct LayerW { float *attn_norm = nullptr, *ffn_norm = nullptr; QWeight wq, wk, wv, wo, w1, w2, w3; };
+    bool mixed_qkv(const LayerW &L, hipStream_t s, bool fuse);
     std::vector<LayerW> layers_;
     float *norm_ = nullptr;
     QWeight output_;
@@ -111,7 +106,8 @@ private:
     ActQ act_;
     int *d_npast_ = nullptr, *d_tokens_ = nullptr, *d_argmax_ = nullptr; void *d_scratch_ = nullptr;
     int *h_argmax_ = nullptr; float *h_logits_ = nullptr; bool logits_host_valid_ = false;
-    hipGraphExec_t decode_graph_ = nullptr; bool use_graph_ = true, use_v2_ = true, use_fused_pro_ = false, fuse_plain_ = false;
+    hipGraphExec_t decode_graph_ = nullptr; bool use_graph_ = true, use_v2_ = true;
+    static constexpr int FUSE_DEFAULT = 87; int fuse_mask_ = FUSE_DEFAULT;
     // profiling
     bool prof_on_ = false;
     struct ProfEv { hipEvent_t a, b; int type; double bytes; };

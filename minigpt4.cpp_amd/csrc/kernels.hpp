@@ -25,6 +25,7 @@ void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, c
 
 // prefill (N >= 16) on the int8 matrix cores for Q4_K / Q5_K / Q6_K / Q4_0; launch_mul_mat dispatches to it automatically
 bool mmq_supported(int type);
+bool matvec_prologue_supported(int type, int cols);   // the fused row-preparation variants of the decode mat-vec
 void launch_mmq(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s);
 void set_mmq_enabled(int v);
 
@@ -32,8 +33,12 @@ void set_mmq_enabled(int v);
 // pro: 0 = activations come from `A` (prepared by launch_rms_quant / launch_silu_mul_quant); 1 = rms_norm(px) * pw, 2 = px, 3 = silu(px) * pw are
 // prepared and quantised inside the kernel prologue (one launch less per use).
 bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s, int pro = 0, const float *px = nullptr,
-                       const float *pw = nullptr, const Tables *tb = nullptr);
-void set_matvec_tuning(int waves_per_cu, int cus);
+                       const float *pw = nullptr, const Tables *tb = nullptr, int epi = 0);   // epi 1: y[0][g] = silu(W0[g].x) * (W1[g].x) (n == 2)
+bool matvec_silu_pair_supported(int type, int cols);
+// two k-quant types (Q4_K|Q5_K + Q6_K) with the same K in one launch; pro: 0 or 1 (rms_norm prologue)
+bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, hipStream_t s, int pro = 0,
+                         const float *px = nullptr, const float *pw = nullptr);
+void set_matvec_tuning(int waves_per_cu, int fat_threads, int cus);   // 0 = choose per launch
 
 // ---- token embedding gather (raw ggml rows, dequantised to f32) -----------------------------------------------------
 void launch_get_rows(int type, const uint8_t *raw_table, int K, const int *tokens, int N, float *out, hipStream_t s);
@@ -50,8 +55,6 @@ void launch_attn_llm(float *q, const float *k, const float *v, __half *kcache, _
 bool attn_head_size_supported(int hd);
 void launch_argmax(const float *logits, int n, int *out, void *scratch /*>= 512 bytes*/, hipStream_t s);
 void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);
-struct PrefetchSet { const void *ptr[16]; size_t bytes[16]; int n = 0; };
-void launch_prefetch(const PrefetchSet &ps, hipStream_t s);   // touches the ranges (fills the Infinity Cache); results are discarded
 void launch_set_int(int *p, int v, hipStream_t s);
 void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s);
 void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s);

@@ -21,6 +21,37 @@ __device__ __forceinline__ float f16r(float f) { return __half2float(__float2hal
 __device__ __forceinline__ float tab(const __half *t, float x) { return __half2float(t[f2h_bits(x)]); }
 
 __device__ __forceinline__ int4 ld16(const void *p) { return *reinterpret_cast<const int4 *>(p); }
+// weight-plane loads: streamed once per token by exactly one wave -> non-temporal (MG4_NT_WEIGHTS=0 builds the default-policy variant for A/B runs)
+#ifndef MG4_NT_WEIGHTS
+#define MG4_NT_WEIGHTS 1
+#endif
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+template <typename N> __device__ __forceinline__ N ldw_raw(const void *p) {
+#if MG4_NT_WEIGHTS
+    return __builtin_nontemporal_load(reinterpret_cast<const N *>(p));
+#else
+    return *reinterpret_cast<const N *>(p);
+#endif
+}
+template <typename V> __device__ __forceinline__ V ldw(const void *p) { return ldw_raw<V>(p); }
+template <> __device__ __forceinline__ int4 ldw<int4>(const void *p) { const v4i_t v = ldw_raw<v4i_t>(p); return make_int4(v.x, v.y, v.z, v.w); }
+template <> __device__ __forceinline__ uint2 ldw<uint2>(const void *p) { const v2u_t v = ldw_raw<v2u_t>(p); return make_uint2(v.x, v.y); }
+template <> __device__ __forceinline__ float4 ldw<float4>(const void *p) { const v4f_t v = ldw_raw<v4f_t>(p); return make_float4(v.x, v.y, v.z, v.w); }
+
+// Buffer-descriptor form of the weight-plane loads (decode mat-vec): the descriptor is built from wave-uniform values (the row's plane
+// addresses, SGPRs), the lane's byte offset within the row is a loop-invariant VGPR -> no per-load vector address arithmetic, so no VALU
+// temporary can alias (and therefore wait for) the destination of a load that is still in flight.
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+typedef unsigned v2ub_t __attribute__((ext_vector_type(2)));
+constexpr int WAUX = MG4_NT_WEIGHTS ? 2 : 0;
+struct WBuf { __amdgpu_buffer_rsrc_t qs, qh, sc, d; };
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mkbuf(const uint8_t *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p), 0, 0x7FFFFFFF, 0x00020000); }
+__device__ __forceinline__ int4 bld16(__amdgpu_buffer_rsrc_t r, int off) { const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, WAUX); return make_int4((int)v.x, (int)v.y, (int)v.z, (int)v.w); }
+__device__ __forceinline__ uint2 bld8(__amdgpu_buffer_rsrc_t r, int off) { const v2ub_t v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, WAUX); return make_uint2(v.x, v.y); }
+__device__ __forceinline__ unsigned bld4(__amdgpu_buffer_rsrc_t r, int off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, WAUX); }
+__device__ __forceinline__ unsigned short bld2(__amdgpu_buffer_rsrc_t r, int off) { return __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, WAUX); }
 
 // =====================================================================================================================
 // load-time repack: ggml array-of-blocks -> planes.  One thread per unit (16 bytes of the main plane).
@@ -120,9 +151,11 @@ template <int T> struct Tr;
 
 template <> struct Tr<GT_Q4_0> {
     static constexpr int EPU = 32;
-    struct WU { int4 q; float d; };
+    struct WU { int4 q; unsigned short dh; };
     struct AU { int4 a0, a1; float d; int sum; };
-    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); w.d = h2f_bits(*reinterpret_cast<const unsigned short *>(W.sc + g * 2)); }
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g0, int u, WU &w) { w.q = ldw<int4>(W.qs + g0 * 16 + (unsigned)(u * 16)); w.dh = ldw<unsigned short>(W.sc + g0 * 2 + (unsigned)(u * 2)); }
+    static __device__ __forceinline__ void mkb(const QWeight &W, size_t g0, WBuf &B) { B.qs = mkbuf(W.qs + g0 * 16); B.sc = mkbuf(W.sc + g0 * 2); }
+    static __device__ __forceinline__ void loadb(const WBuf &B, int u, WU &w) { w.q = bld16(B.qs, u * 16); w.dh = bld2(B.sc, u * 2); }
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) {
         const int8_t *p = A.q80 + (size_t)t * K + (size_t)u * 32; a.a0 = ld16(p); a.a1 = ld16(p + 16);
         const size_t b = (size_t)t * (K / 32) + u; a.d = A.d0[b]; a.sum = A.sum0[b]; }
@@ -131,14 +164,16 @@ template <> struct Tr<GT_Q4_0> {
         s = dot4(w.q.x & 0x0F0F0F0F, a.a0.x, s); s = dot4(w.q.y & 0x0F0F0F0F, a.a0.y, s); s = dot4(w.q.z & 0x0F0F0F0F, a.a0.z, s); s = dot4(w.q.w & 0x0F0F0F0F, a.a0.w, s);
         s = dot4((w.q.x >> 4) & 0x0F0F0F0F, a.a1.x, s); s = dot4((w.q.y >> 4) & 0x0F0F0F0F, a.a1.y, s); s = dot4((w.q.z >> 4) & 0x0F0F0F0F, a.a1.z, s); s = dot4((w.q.w >> 4) & 0x0F0F0F0F, a.a1.w, s);
         s -= 8 * a.sum;
-        acc = fmaf(w.d * a.d, (float)s, acc);
+        acc = fmaf(h2f_bits(w.dh) * a.d, (float)s, acc);
     }
 };
 template <> struct Tr<GT_Q4_1> {
     static constexpr int EPU = 32;
-    struct WU { int4 q; float d, m; };
+    struct WU { int4 q; unsigned dm; };
     struct AU { int4 a0, a1; float d, s; };
-    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); const unsigned dm = *reinterpret_cast<const unsigned *>(W.sc + g * 4); w.d = h2f_bits(dm & 0xFFFF); w.m = h2f_bits(dm >> 16); }
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g0, int u, WU &w) { w.q = ldw<int4>(W.qs + g0 * 16 + (unsigned)(u * 16)); w.dm = ldw<unsigned>(W.sc + g0 * 4 + (unsigned)(u * 4)); }
+    static __device__ __forceinline__ void mkb(const QWeight &W, size_t g0, WBuf &B) { B.qs = mkbuf(W.qs + g0 * 16); B.sc = mkbuf(W.sc + g0 * 4); }
+    static __device__ __forceinline__ void loadb(const WBuf &B, int u, WU &w) { w.q = bld16(B.qs, u * 16); w.dm = bld4(B.sc, u * 4); }
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) {
         const int8_t *p = A.q80 + (size_t)t * K + (size_t)u * 32; a.a0 = ld16(p); a.a1 = ld16(p + 16);
         const size_t b = (size_t)t * (K / 32) + u; a.d = A.d1[b]; a.s = A.s1[b]; }
@@ -146,8 +181,8 @@ template <> struct Tr<GT_Q4_1> {
         int s = 0;
         s = dot4(w.q.x & 0x0F0F0F0F, a.a0.x, s); s = dot4(w.q.y & 0x0F0F0F0F, a.a0.y, s); s = dot4(w.q.z & 0x0F0F0F0F, a.a0.z, s); s = dot4(w.q.w & 0x0F0F0F0F, a.a0.w, s);
         s = dot4((w.q.x >> 4) & 0x0F0F0F0F, a.a1.x, s); s = dot4((w.q.y >> 4) & 0x0F0F0F0F, a.a1.y, s); s = dot4((w.q.z >> 4) & 0x0F0F0F0F, a.a1.z, s); s = dot4((w.q.w >> 4) & 0x0F0F0F0F, a.a1.w, s);
-        acc = fmaf(w.d * a.d, (float)s, acc);
-        acc = fmaf(w.m, a.s, acc);
+        acc = fmaf(h2f_bits(w.dm & 0xFFFF) * a.d, (float)s, acc);
+        acc = fmaf(h2f_bits(w.dm >> 16), a.s, acc);
     }
 };
 // 5-bit: P holds the high bits pre-transposed (see pack_hb1): lo dword k -> (P << (4-k)) & 0x10101010, hi dword k -> (P >> k) & 0x10101010
@@ -158,42 +193,46 @@ template <> struct Tr<GT_Q4_1> {
     s = dot4(((q.z >> 4) & 0x0F0F0F0F) | ((P >> 2) & 0x10101010), a1.z, s); s = dot4(((q.w >> 4) & 0x0F0F0F0F) | ((P >> 3) & 0x10101010), a1.w, s);
 template <> struct Tr<GT_Q5_0> {
     static constexpr int EPU = 32;
-    struct WU { int4 q; unsigned P; float d; };
+    struct WU { int4 q; unsigned P; unsigned short dh; };
     using AU = Tr<GT_Q4_0>::AU;
-    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); w.P = *reinterpret_cast<const unsigned *>(W.qh + g * 4); w.d = h2f_bits(*reinterpret_cast<const unsigned short *>(W.sc + g * 2)); }
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g0, int u, WU &w) { w.q = ldw<int4>(W.qs + g0 * 16 + (unsigned)(u * 16)); w.P = ldw<unsigned>(W.qh + g0 * 4 + (unsigned)(u * 4)); w.dh = ldw<unsigned short>(W.sc + g0 * 2 + (unsigned)(u * 2)); }
+    static __device__ __forceinline__ void mkb(const QWeight &W, size_t g0, WBuf &B) { B.qs = mkbuf(W.qs + g0 * 16); B.qh = mkbuf(W.qh + g0 * 4); B.sc = mkbuf(W.sc + g0 * 2); }
+    static __device__ __forceinline__ void loadb(const WBuf &B, int u, WU &w) { w.q = bld16(B.qs, u * 16); w.P = bld4(B.qh, u * 4); w.dh = bld2(B.sc, u * 2); }
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { Tr<GT_Q4_0>::loada(A, t, K, u, a); }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
         int s = 0; const unsigned P = w.P;
         MG4_Q5_DOT8(w.q, P, a.a0, a.a1, s)
         s -= 16 * a.sum;
-        acc = fmaf(w.d * a.d, (float)s, acc);
+        acc = fmaf(h2f_bits(w.dh) * a.d, (float)s, acc);
     }
 };
 template <> struct Tr<GT_Q5_1> {
     static constexpr int EPU = 32;
-    struct WU { int4 q; unsigned P; float d, m; };
+    struct WU { int4 q; unsigned P; unsigned dm; };
     using AU = Tr<GT_Q4_1>::AU;
-    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); w.P = *reinterpret_cast<const unsigned *>(W.qh + g * 4);
-        const unsigned dm = *reinterpret_cast<const unsigned *>(W.sc + g * 4); w.d = h2f_bits(dm & 0xFFFF); w.m = h2f_bits(dm >> 16); }
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g0, int u, WU &w) { w.q = ldw<int4>(W.qs + g0 * 16 + (unsigned)(u * 16)); w.P = ldw<unsigned>(W.qh + g0 * 4 + (unsigned)(u * 4));
+        w.dm = ldw<unsigned>(W.sc + g0 * 4 + (unsigned)(u * 4)); }
+    static __device__ __forceinline__ void mkb(const QWeight &W, size_t g0, WBuf &B) { B.qs = mkbuf(W.qs + g0 * 16); B.qh = mkbuf(W.qh + g0 * 4); B.sc = mkbuf(W.sc + g0 * 4); }
+    static __device__ __forceinline__ void loadb(const WBuf &B, int u, WU &w) { w.q = bld16(B.qs, u * 16); w.P = bld4(B.qh, u * 4); w.dm = bld4(B.sc, u * 4); }
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { Tr<GT_Q4_1>::loada(A, t, K, u, a); }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
         int s = 0; const unsigned P = w.P;
         MG4_Q5_DOT8(w.q, P, a.a0, a.a1, s)
-        acc = fmaf(w.d * a.d, (float)s, acc);
-        acc = fmaf(w.m, a.s, acc);
+        acc = fmaf(h2f_bits(w.dm & 0xFFFF) * a.d, (float)s, acc);
+        acc = fmaf(h2f_bits(w.dm >> 16), a.s, acc);
     }
 };
 template <> struct Tr<GT_Q8_0> {   // unit = half a block (16 int8); the two halves are combined across the lane pair before scaling
     static constexpr int EPU = 16;
-    struct WU { int4 q; float d; };
+    struct WU { int4 q; unsigned short dh; };
     struct AU { int4 a; float d; };
-    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); w.d = h2f_bits(*reinterpret_cast<const unsigned short *>(W.sc + (g >> 1) * 2)); }
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g0, int u, WU &w) { w.q = ldw<int4>(W.qs + g0 * 16 + (unsigned)(u * 16)); w.dh = ldw<unsigned short>(W.sc + (g0 >> 1) * 2 + (unsigned)((u >> 1) * 2)); }
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { a.a = ld16(A.q80 + (size_t)t * K + (size_t)u * 16); a.d = A.d0[(size_t)t * (K / 32) + (u >> 1)]; }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
         int s = 0;
         s = dot4(w.q.x, a.a.x, s); s = dot4(w.q.y, a.a.y, s); s = dot4(w.q.z, a.a.z, s); s = dot4(w.q.w, a.a.w, s);
         s += __shfl_xor(s, 1);
-        if (!(threadIdx.x & 1)) acc = fmaf(w.d * a.d, (float)s, acc);
+        if (!(threadIdx.x & 1)) acc = fmaf(h2f_bits(w.dh) * a.d, (float)s, acc);
     }
 };
 // k-quants ---------------------------------------------------------------------------------------------------------------
@@ -212,7 +251,9 @@ template <> struct Tr<GT_Q4_K> {
     static constexpr int EPU = 32;
     struct WU { int4 q; int4 h; };
     using AU = AK;
-    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); w.h = ld16(W.sc + (g >> 3) * 16); }
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g0, int u, WU &w) { w.q = ldw<int4>(W.qs + g0 * 16 + (unsigned)(u * 16)); w.h = ldw<int4>(W.sc + (g0 >> 3) * 16 + (unsigned)((u >> 3) * 16)); }
+    static __device__ __forceinline__ void mkb(const QWeight &W, size_t g0, WBuf &B) { B.qs = mkbuf(W.qs + g0 * 16); B.sc = mkbuf(W.sc + (g0 >> 3) * 16); }
+    static __device__ __forceinline__ void loadb(const WBuf &B, int u, WU &w) { w.q = bld16(B.qs, u * 16); w.h = bld16(B.sc, (u >> 3) * 16); }
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) {
         const int sb = u >> 3, i = u & 7, j = i >> 1, h = i & 1;
         const int8_t *p = A.q8k + (size_t)t * K + (size_t)sb * 256 + 64 * j + 16 * h; a.lo = ld16(p); a.hi = ld16(p + 32);
@@ -232,7 +273,9 @@ template <> struct Tr<GT_Q5_K> {
     static constexpr int EPU = 32;
     struct WU { int4 q; int4 h; unsigned P; };
     using AU = AK;
-    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); w.h = ld16(W.sc + (g >> 3) * 16); w.P = *reinterpret_cast<const unsigned *>(W.qh + g * 4); }
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g0, int u, WU &w) { w.q = ldw<int4>(W.qs + g0 * 16 + (unsigned)(u * 16)); w.h = ldw<int4>(W.sc + (g0 >> 3) * 16 + (unsigned)((u >> 3) * 16)); w.P = ldw<unsigned>(W.qh + g0 * 4 + (unsigned)(u * 4)); }
+    static __device__ __forceinline__ void mkb(const QWeight &W, size_t g0, WBuf &B) { B.qs = mkbuf(W.qs + g0 * 16); B.sc = mkbuf(W.sc + (g0 >> 3) * 16); B.qh = mkbuf(W.qh + g0 * 4); }
+    static __device__ __forceinline__ void loadb(const WBuf &B, int u, WU &w) { w.q = bld16(B.qs, u * 16); w.h = bld16(B.sc, (u >> 3) * 16); w.P = bld4(B.qh, u * 4); }
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { Tr<GT_Q4_K>::loada(A, t, K, u, a); }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
         const int j = (threadIdx.x & 7) >> 1;
@@ -249,13 +292,18 @@ template <> struct Tr<GT_Q5_K> {
 };
 template <> struct Tr<GT_Q6_K> {
     static constexpr int EPU = 32;
-    struct WU { int4 q; unsigned Plo, Phi; int sc_lo, sc_hi; float d; };
+    struct WU { int4 q; unsigned Plo, Phi; unsigned short sc, dh; };
     using AU = AK;
-    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) {
-        w.q = ld16(W.qs + g * 16); const uint2 p = *reinterpret_cast<const uint2 *>(W.qh + g * 8); w.Plo = p.x; w.Phi = p.y;
-        const unsigned short s = *reinterpret_cast<const unsigned short *>(W.sc + g * 2); w.sc_lo = (int)(signed char)(s & 0xFF); w.sc_hi = (int)(signed char)(s >> 8);
-        w.d = h2f_bits(*reinterpret_cast<const unsigned short *>(W.d + (g >> 3) * 2)); }
-    static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) {
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g0, int u, WU &w) {
+        w.q = ldw<int4>(W.qs + g0 * 16 + (unsigned)(u * 16)); const uint2 p = ldw<uint2>(W.qh + g0 * 8 + (unsigned)(u * 8)); w.Plo = p.x; w.Phi = p.y;
+        w.sc = ldw<unsigned short>(W.sc + g0 * 2 + (unsigned)(u * 2));
+        w.dh = ldw<unsigned short>(W.d + (g0 >> 3) * 2 + (unsigned)((u >> 3) * 2)); }
+    static __device__ __forceinline__ void mkb(const QWeight &W, size_t g0, WBuf &B) { B.qs = mkbuf(W.qs + g0 * 16); B.qh = mkbuf(W.qh + g0 * 8); B.sc = mkbuf(W.sc + g0 * 2); B.d = mkbuf(W.d + (g0 >> 3) * 2); }
+    static __device__ __forceinline__ void loadb(const WBuf &B, int u, WU &w) {
+        w.q = bld16(B.qs, u * 16); const uint2 p = bld8(B.qh, u * 8); w.Plo = p.x; w.Phi = p.y;
+        w.sc = bld2(B.sc, u * 2);
+        w.dh = bld2(B.d, (u >> 3) * 2); }
+static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) {
         const int sb = u >> 3, i = u & 7, n = i >> 2, c = (i >> 1) & 1, h = i & 1;
         const int8_t *p = A.q8k + (size_t)t * K + (size_t)sb * 256 + 128 * n + 32 * c + 16 * h; a.lo = ld16(p); a.hi = ld16(p + 64);
         a.d = A.dk[(size_t)t * (K / 256) + sb]; const int16_t *bs = A.bsk + (size_t)t * (K / 16) + sb * 16 + 8 * n + 2 * c + h; a.bs_lo = bs[0]; a.bs_hi = bs[4]; }
@@ -266,14 +314,14 @@ template <> struct Tr<GT_Q6_K> {
         s1 = dot4(((w.q.x >> 4) & 0x0F0F0F0F) | ((H << 4) & 0x30303030), a.hi.x, s1); s1 = dot4(((w.q.y >> 4) & 0x0F0F0F0F) | ((H << 2) & 0x30303030), a.hi.y, s1);
         s1 = dot4(((w.q.z >> 4) & 0x0F0F0F0F) | (H & 0x30303030), a.hi.z, s1); s1 = dot4(((w.q.w >> 4) & 0x0F0F0F0F) | ((H >> 2) & 0x30303030), a.hi.w, s1);
         s0 -= 32 * a.bs_lo; s1 -= 32 * a.bs_hi;
-        acc = fmaf(w.d * a.d, (float)(w.sc_lo * s0 + w.sc_hi * s1), acc);
+        acc = fmaf(h2f_bits(w.dh) * a.d, (float)((int)(signed char)(w.sc & 0xFF) * s0 + (int)(signed char)(w.sc >> 8) * s1), acc);
     }
 };
 template <> struct Tr<GT_F16> {
     static constexpr int EPU = 8;
     struct WU { int4 q; };
     struct AU { int4 a; };
-    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = ld16(W.qs + g * 16); }
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g0, int u, WU &w) { w.q = ldw<int4>(W.qs + g0 * 16 + (unsigned)(u * 16)); }
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { a.a = ld16(reinterpret_cast<const uint8_t *>(A.xh) + ((size_t)t * K + (size_t)u * 8) * 2); }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
         const unsigned wq[4] = {(unsigned)w.q.x, (unsigned)w.q.y, (unsigned)w.q.z, (unsigned)w.q.w}, aq[4] = {(unsigned)a.a.x, (unsigned)a.a.y, (unsigned)a.a.z, (unsigned)a.a.w};
@@ -285,7 +333,7 @@ template <> struct Tr<GT_F32> {
     static constexpr int EPU = 4;
     struct WU { float4 q; };
     struct AU { float4 a; };
-    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g, WU &w) { w.q = *reinterpret_cast<const float4 *>(W.qs + g * 16); }
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g0, int u, WU &w) { w.q = ldw<float4>(W.qs + g0 * 16 + (unsigned)(u * 16)); }
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { a.a = *reinterpret_cast<const float4 *>(A.xf + (size_t)t * K + (size_t)u * 4); }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) { acc = fmaf(w.q.x, a.a.x, acc); acc = fmaf(w.q.y, a.a.y, acc); acc = fmaf(w.q.z, a.a.z, acc); acc = fmaf(w.q.w, a.a.w, acc); }
 };
@@ -320,7 +368,7 @@ __global__ __launch_bounds__(256) void k_mul_mat(const QWeight W, const ActQ A, 
         for (int t = 0; t < TN; t++) X::loada(A, min(t0 + t, N - 1), K, uc, a[t]);
         typename X::WU w[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) X::loadw(W, (size_t)rows_i[r] * U + uc, w[r]);
+        for (int r = 0; r < R; r++) X::loadw(W, (size_t)rows_i[r] * U, uc, w[r]);
 #pragma unroll
         for (int r = 0; r < R; r++)
 #pragma unroll
@@ -372,11 +420,23 @@ struct MatSet {
     int rows_each;         // rows of each matrix
 };
 
-template <int T, int NU, int R, int PRO>
-__global__ __launch_bounds__(256) void k_matvec_v2(const MatSet ms, const ActQ A, const ProArgs pa, const int n_groups, const int n_waves) {
+// Workgroup size of the prologue variants: one fat workgroup per CU (as many waves as the register budget of NU admits), so that the redundant
+// row preparation is done once per CU instead of once per 4 waves.
+// Prologue variants run as ONE fat workgroup per CU of 8..12 waves (512..768 threads): the row preparation is repeated per workgroup, so fewer, fatter
+// workgroups repeat it less.  The kernel is compiled for the largest size its register budget admits and launched with the size whose
+// rows-per-wave division is the most even (see pick_fat_threads).
+constexpr int MV_FAT_MIN = 512;
+template <int NU> constexpr int mv_fat_max_threads() { return NU <= 4 ? 768 : 512; }
+
+// EPI_SILU_PAIR (w1|w3 of the feed-forward block; ms.n == 2, R == 2): group g = the row pair (w1[g], w3[g]); the wave writes
+// h[g] = silu_table(w1[g] . x) * (w3[g] . x) instead of the two dot products.  The table lookup of a group is consumed one group later, so
+// that it never stalls the weight stream.
+enum EpiKind : int { EPI_STORE = 0, EPI_SILU_PAIR = 1 };
+template <int T, int NU, int R, int PRO, int EPI>
+__device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, const ProArgs &pa, const int n_groups, const int n_waves, const int wave) {
+    static_assert(EPI == EPI_STORE || R == 2, "the SiLU pair epilogue works on row pairs");
     using X = Tr<T>;
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int K = ms.w0.cols, U = K / X::EPU, rows_each = ms.rows_each, total_rows = ms.n * rows_each;
     int uc[NU]; bool ok[NU];
 #pragma unroll
@@ -384,32 +444,40 @@ __global__ __launch_bounds__(256) void k_matvec_v2(const MatSet ms, const ActQ A
     // NOTE: every load of the pipeline is unconditional (indices are clamped instead of branching): a load inside an exec-masked branch
     // makes hipcc's counted s_waitcnt fall back to (near) vmcnt(0), which drains the prefetch -- see DESIGN.md "mat-vec pipeline".
     struct Grp { typename X::WU w[R][NU]; float res[R]; };
-    const int last_group = n_groups - 1;
+    const bool has_res = ms.res0 != nullptr;
+    const float *res_base = has_res ? ms.res0 : ms.y0;                     // always a valid address; the value is dropped when there is no residual
+    const long long res_stride = has_res ? ms.dres : ms.dy;
     auto fetch = [&](int g, Grp &G) {
-        g = min(g, last_group);
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const int row = min(g * R + r, total_rows - 1);
-            const int m = (row >= rows_each) + (row >= 2 * rows_each), lr = row - m * rows_each;
+            // wave-uniform (scalar) row, clamped instead of branching; the matrix of the row is selected on the operands themselves (a
+            // bool -> int conversion would be done on the vector ALU)
+            const int row = EPI == EPI_SILU_PAIR ? min(g, rows_each - 1) + r * rows_each : min(g * R + r, total_rows - 1);
+            const bool m1 = row >= rows_each, m2 = row >= 2 * rows_each;
+            const int lr = row - (m2 ? 2 * rows_each : (m1 ? rows_each : 0));
+            const long long d = m2 ? 2 * ms.dmat : (m1 ? ms.dmat : 0ll);
             QWeight W = ms.w0;
-            const long long d = (long long)m * ms.dmat;
             W.qs += d; W.qh += d; W.sc += d; W.d += d;
+            WBuf B;
+            X::mkb(W, (size_t)lr * U, B);
 #pragma unroll
-            for (int i = 0; i < NU; i++) X::loadw(W, (size_t)lr * U + uc[i], G.w[r][i]);
-            G.res[r] = ms.res0 ? ms.res0[(long long)m * ms.dres + lr] : 0.0f;
+            for (int i = 0; i < NU; i++) X::loadb(B, uc[i], G.w[r][i]);
+            G.res[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mkbuf(reinterpret_cast<const uint8_t *>(res_base + (m2 ? 2 * res_stride : (m1 ? res_stride : 0ll)) + lr)), 0, 0, 0));
         }
     };
     Grp cur, nxt;
-    fetch(wave, cur);                         // first weights are in flight while the activation row is prepared
     typename X::AU a[NU];
     if (PRO == PRO_NONE) {
+        fetch(wave, cur);
 #pragma unroll
         for (int i = 0; i < NU; i++) X::loada(A, 0, K, uc[i], a[i]);
     } else {
+        // Row preparation in the prologue.  Order matters (vector-memory results return in issue order): the row (and, for SiLU, the table
+        // gathers) is requested BEFORE the first weight tiles, so the preparation runs while those tiles are in flight.
         extern __shared__ __attribute__((aligned(16))) unsigned char smem_mv[];
-        // LDS image of the quantised row (only the planes this weight type reads are written)
-        ActQ L;
-        unsigned char *p = smem_mv;
+        ActQ L;                                     // LDS image of the quantised row (only the planes this weight type reads are written)
+        double *red = reinterpret_cast<double *>(smem_mv);               // [waves] partial sums (dynamic LDS: shared by both halves of k_matvec_mix)
+        unsigned char *p = smem_mv + 128;
         L.q8k = reinterpret_cast<int8_t *>(p); p += (size_t)K;
         L.q80 = reinterpret_cast<int8_t *>(p); p += (size_t)K;
         L.dk = reinterpret_cast<float *>(p); p += (size_t)(K / 256 + 1) * 4;
@@ -419,107 +487,182 @@ __global__ __launch_bounds__(256) void k_matvec_v2(const MatSet ms, const ActQ A
         L.sum0 = reinterpret_cast<int *>(p); p += (size_t)(K / 32) * 4;
         L.bsk = reinterpret_cast<int16_t *>(p); p += (size_t)(K / 16) * 2;
         L.xh = nullptr; L.xf = nullptr;
-        __shared__ double red[4];
-        const int mask = (T == GT_Q4_K || T == GT_Q5_K || T == GT_Q6_K) ? ACT_Q8K : ACT_Q80;
+        constexpr int RND = (NU * 512 + MV_FAT_MIN - 1) / MV_FAT_MIN;    // K <= NU * 2048 elements, 4 per thread per round, >= MV_FAT_MIN threads
+        const int nthr = (int)blockDim.x;
+        constexpr int mask = (T == GT_Q4_K || T == GT_Q5_K || T == GT_Q6_K) ? ACT_Q8K : ACT_Q80;
+        float4 xv[RND], yv[RND];
+        bool in[RND];
+#pragma unroll
+        for (int r = 0; r < RND; r++) {
+            const int i = (r * nthr + (int)threadIdx.x) * 4;
+            in[r] = i < K;
+            const int ic = in[r] ? i : 0;
+            xv[r] = *reinterpret_cast<const float4 *>(pa.x + ic);
+            if (PRO != PRO_PLAIN) yv[r] = *reinterpret_cast<const float4 *>(pa.w + ic);
+        }
+        if (PRO == PRO_SILU) {
+#pragma unroll
+            for (int r = 0; r < RND; r++) { xv[r].x = tab(pa.tb.silu, xv[r].x); xv[r].y = tab(pa.tb.silu, xv[r].y); xv[r].z = tab(pa.tb.silu, xv[r].z); xv[r].w = tab(pa.tb.silu, xv[r].w); }
+        }
+        fetch(wave, cur);
         float scale = 1.0f;
         if (PRO == PRO_RMS) {
             double sum = 0.0;
-            for (int i = threadIdx.x * 4; i < K; i += 1024) { const float4 v = *reinterpret_cast<const float4 *>(pa.x + i);
-                sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w); }
+#pragma unroll
+            for (int r = 0; r < RND; r++) {
+                const float4 v = xv[r];
+                double q = 0.0;
+                q += (double)(v.x * v.x); q += (double)(v.y * v.y); q += (double)(v.z * v.z); q += (double)(v.w * v.w);
+                sum += in[r] ? q : 0.0;
+            }
             sum = wave_sum_d(sum);
             if (lane == 0) red[threadIdx.x >> 6] = sum;
             __syncthreads();
-            const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+            double tot = 0.0;
+            for (int w = 0; w < nthr / 64; w++) tot += red[w];
             const float mean = (float)(tot / (double)K);
             scale = 1.0f / sqrtf(mean + 1e-6f);
         }
-        for (int i0 = 0; i0 < K; i0 += 1024) {
-            const int i = i0 + threadIdx.x * 4;
-            const bool in = i < K;
-            float v[4] = {0, 0, 0, 0};
-            if (in) {
-                const float4 xv = *reinterpret_cast<const float4 *>(pa.x + i);
-                if (PRO == PRO_RMS) { const float4 wv = *reinterpret_cast<const float4 *>(pa.w + i); v[0] = (xv.x * scale) * wv.x; v[1] = (xv.y * scale) * wv.y; v[2] = (xv.z * scale) * wv.z; v[3] = (xv.w * scale) * wv.w; }
-                else if (PRO == PRO_SILU) { const float4 bv = *reinterpret_cast<const float4 *>(pa.w + i);
-                    v[0] = tab(pa.tb.silu, xv.x) * bv.x; v[1] = tab(pa.tb.silu, xv.y) * bv.y; v[2] = tab(pa.tb.silu, xv.z) * bv.z; v[3] = tab(pa.tb.silu, xv.w) * bv.w; }
-                else { v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w; }
-            }
-            quant_emit4(v, in, i, 0, K, L, mask);
+#pragma unroll
+        for (int r = 0; r < RND; r++) {
+            const int i = (r * nthr + (int)threadIdx.x) * 4;
+            float v[4];
+            if (PRO == PRO_RMS) { v[0] = (xv[r].x * scale) * yv[r].x; v[1] = (xv[r].y * scale) * yv[r].y; v[2] = (xv[r].z * scale) * yv[r].z; v[3] = (xv[r].w * scale) * yv[r].w; }
+            else if (PRO == PRO_SILU) { v[0] = xv[r].x * yv[r].x; v[1] = xv[r].y * yv[r].y; v[2] = xv[r].z * yv[r].z; v[3] = xv[r].w * yv[r].w; }
+            else { v[0] = xv[r].x; v[1] = xv[r].y; v[2] = xv[r].z; v[3] = xv[r].w; }
+            if (!in[r]) { v[0] = 0.0f; v[1] = 0.0f; v[2] = 0.0f; v[3] = 0.0f; }
+            quant_emit4(v, in[r], i, 0, K, L, mask);
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NU; i++) X::loada(L, 0, K, uc[i], a[i]);
     }
+    unsigned short pend_t = 0; float pend_b = 0.0f; int pend_row = -1;          // EPI_SILU_PAIR: the previous group's table lookup, not yet consumed
+    auto flush_pending = [&]() { if (pend_row >= 0 && lane == 0) ms.y0[pend_row] = h2f_bits(pend_t) * pend_b; };
     auto consume = [&](int g, const Grp &G) {
+        float out[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             float acc = 0.0f;
 #pragma unroll
             for (int i = 0; i < NU; i++) { float c = acc; X::dot(G.w[r][i], a[i], c); acc = ok[i] ? c : acc; }
-            acc = wave_sum(acc);
-            const int row = g * R + r;
-            if (lane == 0 && row < total_rows) {
-                const int m = (row >= rows_each) + (row >= 2 * rows_each), lr = row - m * rows_each;
-                ms.y0[(long long)m * ms.dy + lr] = acc + G.res[r];
+            out[r] = wave_sum(acc);
+        }
+        if (EPI == EPI_SILU_PAIR) {
+            flush_pending();
+            pend_t = reinterpret_cast<const unsigned short *>(pa.tb.silu)[f2h_bits(out[0])]; pend_b = out[R - 1]; pend_row = g;
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int row = g * R + r;
+                if (lane == 0 && row < total_rows) {
+                    const int m = row >= 2 * rows_each ? 2 : (row >= rows_each ? 1 : 0), lr = row - m * rows_each;
+                    ms.y0[(long long)m * ms.dy + lr] = has_res ? out[r] + G.res[r] : out[r];
+                }
             }
         }
     };
-#pragma unroll 2
-    for (int g = wave; g < n_groups; g += n_waves) {
+    // two statically named stages (a `cur = nxt` copy would have to wait for the loads in flight; the requested unroll is refused by the compiler)
+    // The sched_barriers keep the next group's loads ahead of the current group's dot products (the scheduler otherwise hoists the arithmetic, and
+    // with it the wait for the current tiles, above the loads: one tile in flight instead of two).
+    for (int g = wave; g < n_groups;) {
         fetch(g + n_waves, nxt);
+        __builtin_amdgcn_sched_barrier(0);
         consume(g, cur);
-        cur = nxt;
+        __builtin_amdgcn_sched_barrier(0);
+        g += n_waves;
+        if (g >= n_groups) break;
+        fetch(g + n_waves, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(g, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        g += n_waves;
     }
+    if (EPI == EPI_SILU_PAIR) flush_pending();
 }
-static int g_mv_waves_per_cu = 8;
+template <int T, int NU, int R, int PRO, int EPI>
+__global__ __launch_bounds__(PRO == PRO_NONE ? 256 : mv_fat_max_threads<NU>()) void k_matvec_v2(const MatSet ms, const ActQ A, const ProArgs pa, const int n_groups, const int n_waves) {
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));   // wave-uniform: scalar loop control
+    matvec_run<T, NU, R, PRO, EPI>(ms, A, pa, n_groups, n_waves, wave);
+}
+// Two weight types in one launch (llama.cpp's k-quant mixes give wv more bits than wq|wk): waves [0, n_waves1) stream set 1, the rest set 2.  Both
+// sets share K and the prepared activation row (both types read the Q8_K image); every wave passes the same number of workgroup barriers.
+template <int T1, int T2, int NU, int PRO>
+__global__ __launch_bounds__(PRO == PRO_NONE ? 256 : mv_fat_max_threads<NU>()) void k_matvec_mix(const MatSet ms1, const MatSet ms2, const ActQ A, const ProArgs pa, const int n_groups1,
+                                                                                                 const int n_waves1, const int n_groups2, const int n_waves2) {
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (wave < n_waves1) matvec_run<T1, NU, 1, PRO, EPI_STORE>(ms1, A, pa, n_groups1, n_waves1, wave);
+    else matvec_run<T2, NU, 1, PRO, EPI_STORE>(ms2, A, pa, n_groups2, n_waves2, wave - n_waves1);
+}
 static int g_mv_cus = 256;
-template <int T, int NU, int R>
+static int g_mv_force_waves = 0;    // MINIGPT4_MV_WAVES: waves per CU of the prologue-free launches (0 = choose)
+static int g_mv_force_fat = 0;      // MINIGPT4_FAT_LB: threads of the fat workgroups (0 = choose)
+// Launch geometry (measured on the 13B decode, profiles/r01g_ab_geometry.log): 8 waves per CU everywhere.  More waves lose even where they divide
+// the rows more evenly (5120 rows: 2048 waves = 3 | 2 rows per wave, 2560 waves = 2 each, yet 640-thread workgroups are 6 % slower end to
+// end than 512-thread ones; 1024-thread ones 5 % slower; 5 / 7 waves per CU for the K = 13824 mat-vec 4 % / 1 % slower than 8).
+static int pick_waves_per_cu(int /*groups*/, int max_wpc) { return std::min(g_mv_force_waves ? g_mv_force_waves : 8, max_wpc); }
+static int pick_fat_threads(int /*groups*/, int max_threads) { return g_mv_force_fat ? std::max(MV_FAT_MIN, std::min(g_mv_force_fat / 64 * 64, max_threads)) : MV_FAT_MIN; }
+static size_t mv_prologue_lds(int K) { return 128 + (size_t)2 * K + (size_t)(K / 256 + 1) * 4 + (size_t)4 * (K / 32) * 4 + (size_t)(K / 16) * 2 + 64; }
+template <int NU> constexpr int mv_max_wpc() { return NU <= 3 ? 16 : NU == 4 ? 12 : 8; }      // register budget of the two-stage pipeline
+template <int T, int NU, int R, int EPI>
 static void launch_v2_t(const MatSet &ms, const ActQ &A, int pro, const ProArgs &pa, hipStream_t s) {
     const int total_rows = ms.n * ms.rows_each;
-    const int n_groups = (total_rows + R - 1) / R;
-    int n_waves = std::min(n_groups, g_mv_cus * g_mv_waves_per_cu);
-    n_waves = (n_waves + 3) & ~3;
-    const dim3 grid((unsigned)(n_waves / 4)), block(256);
+    const int n_groups = EPI == EPI_SILU_PAIR ? ms.rows_each : (total_rows + R - 1) / R;
+    if (pro == PRO_NONE) {
+        int n_waves = std::min(n_groups, g_mv_cus * pick_waves_per_cu(n_groups, mv_max_wpc<NU>()));
+        n_waves = (n_waves + 3) & ~3;
+        hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_NONE, EPI>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, s, ms, A, pa, n_groups, n_waves);
+        return;
+    }
+    const int LB = pick_fat_threads(n_groups, mv_fat_max_threads<NU>()), WPB = LB / 64;
+    const int n_blocks = std::min((n_groups + WPB - 1) / WPB, g_mv_cus);
+    const int n_waves = n_blocks * WPB;
+    const dim3 grid((unsigned)n_blocks), block((unsigned)LB);
     const int K = ms.w0.cols;
-    const size_t lds = (size_t)2 * K + (size_t)(K / 256 + 1) * 4 + (size_t)4 * (K / 32) * 4 + (size_t)(K / 16) * 2 + 64;
-    switch (pro) {
-    case PRO_RMS: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_RMS>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
-    case PRO_PLAIN: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_PLAIN>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
-    case PRO_SILU: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_SILU>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
-    default: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_NONE>), grid, block, 0, s, ms, A, pa, n_groups, n_waves); break;
+    const size_t lds = mv_prologue_lds(K);
+    if constexpr (EPI == EPI_SILU_PAIR) {   // w1|w3 follow the ffn norm: only that prologue is instantiated for the pair epilogue
+        hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_RMS, EPI>), grid, block, lds, s, ms, A, pa, n_groups, n_waves);
+    } else switch (pro) {
+    case PRO_RMS: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_RMS, EPI_STORE>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
+    case PRO_PLAIN: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_PLAIN, EPI_STORE>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
+    default: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_SILU, EPI_STORE>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
     }
 }
-// Launch geometry (measured, profiles/r01a_matvec_microbench.log): one row per group (R = 1) keeps the kernel at ~108 VGPRs -> 4 waves/SIMD;
-// 16 waves per CU for big row spaces (fused qkv / w1w3), 8 otherwise; rows with >= 5 units per lane (K >= 8192) stay at 8 waves per CU.
-static int g_mv_force_waves = 0;
-void set_mv_r1(int) {}
+#ifndef MG4_R_NU3
+#define MG4_R_NU3 1
+#endif
+#ifndef MG4_R_NU2
+#define MG4_R_NU2 1
+#endif
 template <int T>
-static bool launch_v2_type(const MatSet &ms, const ActQ &A, int pro, const ProArgs &pa, hipStream_t s) {
+static bool launch_v2_type(const MatSet &ms, const ActQ &A, int pro, const ProArgs &pa, int epi, hipStream_t s) {
     const int U = ms.w0.cols / Tr<T>::EPU;
     const int nu = (U + 63) / 64;
-    const int total_rows = ms.n * ms.rows_each;
-    const int saved = g_mv_waves_per_cu;
-    g_mv_waves_per_cu = g_mv_force_waves ? g_mv_force_waves : (nu <= 4 && total_rows >= 10000 ? 16 : 8);
     bool ok = true;
-    switch (nu) {
-    case 1: launch_v2_t<T, 1, 2>(ms, A, pro, pa, s); break;
-    case 2: launch_v2_t<T, 2, 1>(ms, A, pro, pa, s); break;
-    case 3: launch_v2_t<T, 3, 1>(ms, A, pro, pa, s); break;
-    case 4: launch_v2_t<T, 4, 1>(ms, A, pro, pa, s); break;
-    case 5: launch_v2_t<T, 5, 1>(ms, A, pro, pa, s); break;
-    case 6: launch_v2_t<T, 6, 1>(ms, A, pro, pa, s); break;
-    case 7: launch_v2_t<T, 7, 1>(ms, A, pro, pa, s); break;
+    if (epi == EPI_SILU_PAIR) {
+        if (ms.n != 2 || (pro != PRO_NONE && pro != PRO_RMS)) ok = false;
+        else switch (nu) {
+        case 1: launch_v2_t<T, 1, 2, EPI_SILU_PAIR>(ms, A, pro, pa, s); break;
+        case 2: launch_v2_t<T, 2, 2, EPI_SILU_PAIR>(ms, A, pro, pa, s); break;
+        case 3: launch_v2_t<T, 3, 2, EPI_SILU_PAIR>(ms, A, pro, pa, s); break;
+        default: ok = false;
+        }
+    } else switch (nu) {
+    case 1: launch_v2_t<T, 1, 2, EPI_STORE>(ms, A, pro, pa, s); break;
+    case 2: launch_v2_t<T, 2, MG4_R_NU2, EPI_STORE>(ms, A, pro, pa, s); break;
+    case 3: launch_v2_t<T, 3, MG4_R_NU3, EPI_STORE>(ms, A, pro, pa, s); break;
+    case 4: launch_v2_t<T, 4, 1, EPI_STORE>(ms, A, pro, pa, s); break;
+    case 5: launch_v2_t<T, 5, 1, EPI_STORE>(ms, A, pro, pa, s); break;
+    case 6: launch_v2_t<T, 6, 1, EPI_STORE>(ms, A, pro, pa, s); break;
+    case 7: launch_v2_t<T, 7, 1, EPI_STORE>(ms, A, pro, pa, s); break;
     default: ok = false;
     }
-    g_mv_waves_per_cu = saved;
     return ok;
 }
-void set_matvec_tuning(int waves_per_cu, int cus) { g_mv_force_waves = waves_per_cu > 0 ? waves_per_cu % 100 : 0; if (cus > 0) g_mv_cus = cus; }
-// Decode (N = 1) mat-vec over 1..3 same-type, same-shape, equally spaced matrices.  Returns false when the set is outside the v2 kernel's range.
-bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s, int pro, const float *px, const float *pw,
-                       const Tables *tb) {
-    ProArgs pa{}; pa.x = px; pa.w = pw; if (tb) pa.tb = *tb;
-    MatSet ms{};
+bool matvec_silu_pair_supported(int type, int cols) { return matvec_prologue_supported(type, cols) && cols / 32 <= 3 * 64; }
+
+static bool fill_matset(MatSet &ms, const QWeight *const *W, float *const *y, const float *const *residual, int n) {
+    ms = MatSet{};
     ms.n = n; ms.rows_each = W[0]->rows; ms.w0 = *W[0]; ms.y0 = y[0]; ms.res0 = residual ? residual[0] : nullptr;
     if (n > 1) {
         ms.dmat = (long long)(W[1]->qs - W[0]->qs); ms.dy = (long long)(y[1] - y[0]); ms.dres = residual && residual[0] ? (long long)(residual[1] - residual[0]) : 0;
@@ -531,14 +674,75 @@ bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *co
             if (residual && residual[0] && (long long)(residual[i] - residual[0]) != i * ms.dres) return false;
         }
     }
+    return true;
+}
+template <int T1, int T2, int NU>
+static void launch_mix_t(const MatSet &m1, const MatSet &m2, double bytes1, double bytes2, const ActQ &A, int pro, const ProArgs &pa, hipStream_t s) {
+    const int ng1 = m1.n * m1.rows_each, ng2 = m2.n * m2.rows_each;
+    // split the workgroups so that the busiest wave of either set finishes earliest: cost = rows per wave x bytes per row
+    const double bpr1 = bytes1 / ng1, bpr2 = bytes2 / ng2;
+    int best_t = 0, best_b1 = 0, best_total = 0; double best_cost = 1e300;
+    const int t_fix = pro == PRO_NONE ? 256 : pick_fat_threads(ng1, mv_fat_max_threads<NU>());
+    for (int t = t_fix; t <= t_fix; t += 64) {
+        const int wpb = t / 64;
+        const int total = pro == PRO_NONE ? g_mv_cus * pick_waves_per_cu(ng1 + ng2, mv_max_wpc<NU>()) / 4 : g_mv_cus;
+        for (int b1 = 1; b1 < total; b1++) {
+            const int w1 = b1 * wpb, w2 = (total - b1) * wpb;
+            const double c = std::max((double)((ng1 + w1 - 1) / w1) * bpr1, (double)((ng2 + w2 - 1) / w2) * bpr2);
+            if (c < best_cost) { best_cost = c; best_t = t; best_b1 = b1; best_total = total; }
+        }
+    }
+    const int wpb = best_t / 64, nw1 = best_b1 * wpb, nw2 = (best_total - best_b1) * wpb;
+    const dim3 grid((unsigned)best_total), block((unsigned)best_t);
+    if (pro == PRO_NONE) hipLaunchKernelGGL((k_matvec_mix<T1, T2, NU, PRO_NONE>), grid, block, 0, s, m1, m2, A, pa, ng1, nw1, ng2, nw2);
+    else hipLaunchKernelGGL((k_matvec_mix<T1, T2, NU, PRO_RMS>), grid, block, mv_prologue_lds(m1.w0.cols), s, m1, m2, A, pa, ng1, nw1, ng2, nw2);
+}
+template <int T1, int T2>
+static bool launch_mix_nu(const MatSet &m1, const MatSet &m2, double b1, double b2, const ActQ &A, int pro, const ProArgs &pa, hipStream_t s) {
+    const int nu = (m1.w0.cols / 32 + 63) / 64;
+    switch (nu) {
+    case 1: launch_mix_t<T1, T2, 1>(m1, m2, b1, b2, A, pro, pa, s); return true;
+    case 2: launch_mix_t<T1, T2, 2>(m1, m2, b1, b2, A, pro, pa, s); return true;
+    case 3: launch_mix_t<T1, T2, 3>(m1, m2, b1, b2, A, pro, pa, s); return true;
+    case 4: launch_mix_t<T1, T2, 4>(m1, m2, b1, b2, A, pro, pa, s); return true;
+    default: return false;
+    }
+}
+// Decode mat-vec over two sets of different k-quant types with the same K (wq|wk + wv of a "more bits" layer) in ONE launch.  pro: PRO_NONE or PRO_RMS.
+bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, hipStream_t s, int pro,
+                         const float *px, const float *pw) {
+    if (pro != PRO_NONE && pro != PRO_RMS) return false;
+    if (W1[0]->cols != W2[0]->cols || W1[0]->cols % 256) return false;
+    MatSet m1, m2;
+    if (!fill_matset(m1, W1, y1, nullptr, n1) || !fill_matset(m2, W2, y2, nullptr, n2)) return false;
+    ProArgs pa{}; pa.x = px; pa.w = pw;
+    double b1 = 0, b2 = 0;
+    for (int i = 0; i < n1; i++) b1 += (double)W1[i]->bytes;
+    for (int i = 0; i < n2; i++) b2 += (double)W2[i]->bytes;
+    const int t1 = W1[0]->type, t2 = W2[0]->type;
+    if (t1 == GT_Q5_K && t2 == GT_Q6_K) return launch_mix_nu<GT_Q5_K, GT_Q6_K>(m1, m2, b1, b2, A, pro, pa, s);
+    if (t1 == GT_Q4_K && t2 == GT_Q6_K) return launch_mix_nu<GT_Q4_K, GT_Q6_K>(m1, m2, b1, b2, A, pro, pa, s);
+    return false;
+}
+bool matvec_prologue_supported(int type, int cols) {
+    switch (type) { case GT_Q4_0: case GT_Q4_1: case GT_Q5_0: case GT_Q5_1: case GT_Q4_K: case GT_Q5_K: case GT_Q6_K: break; default: return false; }
+    return cols % 32 == 0 && cols / 32 <= 7 * 64 && ((type != GT_Q4_K && type != GT_Q5_K && type != GT_Q6_K) || cols % 256 == 0);
+}
+void set_matvec_tuning(int waves_per_cu, int fat_threads, int cus) { g_mv_force_waves = std::max(0, waves_per_cu); g_mv_force_fat = std::max(0, fat_threads); if (cus > 0) g_mv_cus = cus; }
+// Decode (N = 1) mat-vec over 1..3 same-type, same-shape, equally spaced matrices.  Returns false when the set is outside the v2 kernel's range.
+bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s, int pro, const float *px, const float *pw,
+                       const Tables *tb, int epi) {
+    ProArgs pa{}; pa.x = px; pa.w = pw; if (tb) pa.tb = *tb;
+    MatSet ms;
+    if (!fill_matset(ms, W, y, residual, n)) return false;
     switch (W[0]->type) {
-    case GT_Q4_0: return launch_v2_type<GT_Q4_0>(ms, A, pro, pa, s);
-    case GT_Q4_1: return launch_v2_type<GT_Q4_1>(ms, A, pro, pa, s);
-    case GT_Q5_0: return launch_v2_type<GT_Q5_0>(ms, A, pro, pa, s);
-    case GT_Q5_1: return launch_v2_type<GT_Q5_1>(ms, A, pro, pa, s);
-    case GT_Q4_K: return launch_v2_type<GT_Q4_K>(ms, A, pro, pa, s);
-    case GT_Q5_K: return launch_v2_type<GT_Q5_K>(ms, A, pro, pa, s);
-    case GT_Q6_K: return launch_v2_type<GT_Q6_K>(ms, A, pro, pa, s);
+    case GT_Q4_0: return launch_v2_type<GT_Q4_0>(ms, A, pro, pa, epi, s);
+    case GT_Q4_1: return launch_v2_type<GT_Q4_1>(ms, A, pro, pa, epi, s);
+    case GT_Q5_0: return launch_v2_type<GT_Q5_0>(ms, A, pro, pa, epi, s);
+    case GT_Q5_1: return launch_v2_type<GT_Q5_1>(ms, A, pro, pa, epi, s);
+    case GT_Q4_K: return launch_v2_type<GT_Q4_K>(ms, A, pro, pa, epi, s);
+    case GT_Q5_K: return launch_v2_type<GT_Q5_K>(ms, A, pro, pa, epi, s);
+    case GT_Q6_K: return launch_v2_type<GT_Q6_K>(ms, A, pro, pa, epi, s);
     default: return false;   // Q8_0 / F16 / F32 rows have more units per row: served by k_mul_mat
     }
 }
@@ -783,6 +987,13 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
     float mx = -INFINITY;
     for (int j = tid; j < Tg; j += AT_THREADS) { const float s = dot_row(kc + (size_t)j * E + (size_t)h * HD); sc[j] = s; mx = fmaxf(mx, s); }
     if (FUSED && tid == AT_THREADS - 1) { const float s = dot_row(knew); sc[pos] = s; mx = fmaxf(mx, s); }
+    // The value rows do not depend on the scores: request the first NPRE of this thread's rows now, so that they arrive during the softmax.
+    const int c = tid % CH, p = tid / CH;
+    const __half *vb = vc + (size_t)h * HD + 8 * c;
+    constexpr int NPRE = 12;
+    int4 vpre[NPRE];
+#pragma unroll
+    for (int i = 0; i < NPRE; i++) vpre[i] = ld16(vb + (size_t)min(p + i * P, max(Tg - 1, 0)) * E);   // clamped: never branches, never out of the cache
     mx = wave_max(mx);
     if ((tid & 63) == 0) s_red[tid >> 6] = mx;
     __syncthreads();
@@ -800,17 +1011,17 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
     const float inv = (float)(1.0 / tot);
     for (int j = tid; j < T; j += AT_THREADS) ph[j] = __float2half_rn(sc[j] * inv);
     __syncthreads();
-    const int c = tid % CH, p = tid / CH;
     float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const __half *vb = vc + (size_t)h * HD + 8 * c;
-#pragma unroll 4
-    for (int j = p; j < Tg; j += P) {
-        const int4 vv = ld16(vb + (size_t)j * E);
+    auto pv_acc = [&](const int4 &vv, const int j) {
         const float pj = __half2float(ph[j]);
         const unsigned w[4] = {(unsigned)vv.x, (unsigned)vv.y, (unsigned)vv.z, (unsigned)vv.w};
 #pragma unroll
         for (int e = 0; e < 4; e++) { o[2 * e] = fmaf(h2f_bits(w[e] & 0xFFFF), pj, o[2 * e]); o[2 * e + 1] = fmaf(h2f_bits(w[e] >> 16), pj, o[2 * e + 1]); }
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < NPRE; i++) { const int j = p + i * P; if (j < Tg) pv_acc(vpre[i], j); }
+#pragma unroll 4
+    for (int j = p + NPRE * P; j < Tg; j += P) pv_acc(ld16(vb + (size_t)j * E), j);
     if (FUSED && p == P - 1) {
         const float pj = __half2float(ph[pos]);
 #pragma unroll
@@ -893,29 +1104,6 @@ __global__ void k_fill_u16(unsigned short *p, size_t n, unsigned short v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s) { hipLaunchKernelGGL(k_fill_u16, dim3(1024), dim3(256), 0, s, (unsigned short *)p, n, v); }
-// MALL prefetch: touch byte ranges of upcoming weight planes so they sit in the 256 MiB Infinity Cache when the next mat-vec starts.
-// Launched on a side stream while a latency-bound kernel (norm/quantise, attention) leaves HBM idle.
-__global__ __launch_bounds__(256) void k_prefetch(const PrefetchSet ps) {
-    const size_t nthreads = (size_t)gridDim.x * 256, gtid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    int acc = 0;
-    for (int r = 0; r < ps.n; r++) {
-        const int4 *p = reinterpret_cast<const int4 *>(ps.ptr[r]);
-        const size_t n16 = ps.bytes[r] / 16;
-        size_t i = gtid;
-        for (; i + 3 * nthreads < n16; i += 4 * nthreads) {
-            const int4 a = p[i], b = p[i + nthreads], c = p[i + 2 * nthreads], d = p[i + 3 * nthreads];
-            acc ^= a.x ^ b.y ^ c.z ^ d.w;
-        }
-        for (; i < n16; i += nthreads) acc ^= p[i].x;
-    }
-    asm volatile("" ::"v"(acc));
-}
-void launch_prefetch(const PrefetchSet &ps, hipStream_t s) {
-    if (ps.n <= 0) return;
-    size_t total = 0; for (int i = 0; i < ps.n; i++) total += ps.bytes[i];
-    const unsigned blocks = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, total / (256 * 16 * 4)));
-    hipLaunchKernelGGL(k_prefetch, dim3(blocks), dim3(256), 0, s, ps);
-}
 __global__ void k_set_int(int *p, int v) { *p = v; }
 void launch_set_int(int *p, int v, hipStream_t s) { hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, p, v); }
 // end of a decode step: the KV position advances and the greedy token becomes the next input (the host may overwrite it)

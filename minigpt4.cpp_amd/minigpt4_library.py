@@ -120,6 +120,7 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_free_embeddings.argtypes = [P(MiniGPT4Embeddings)]
         L.minigpt4_amd_weight_arena.argtypes = [VOID_PTR, I32, P(VOID_PTR), P(SIZE_T)]
         L.minigpt4_amd_test_mul_mat.argtypes = [I32, VOID_PTR, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, ctypes.c_int64, FLOAT_PTR]
+        L.minigpt4_amd_test_matvec.argtypes = [I32, VOID_PTR, I32, I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, FLOAT_PTR, I32, I32, I32, FLOAT_PTR, FLOAT_PTR]
         L.minigpt4_amd_test_quantize.argtypes = [FLOAT_PTR, FLOAT_PTR, ctypes.c_int64, ctypes.c_int64, VOID_PTR, VOID_PTR, VOID_PTR, VOID_PTR, VOID_PTR]
         L.minigpt4_amd_test_gemm_f16.argtypes = [FLOAT_PTR, FLOAT_PTR, FLOAT_PTR, I32, I32, I32, I32, FLOAT_PTR]
         L.minigpt4_amd_vocab_load.argtypes = [CHAR_PTR]
@@ -265,6 +266,23 @@ class MiniGPT4SharedLibrary:
                                                     y.ctypes.data_as(FLOAT_PTR))
         if rc:
             raise RuntimeError(f"test_mul_mat rc={rc}: " + self.library.minigpt4_amd_last_error().decode())
+        return y
+
+    def amd_test_matvec(self, type1: int, raw1: np.ndarray, n1: int, n_in: int, n_out: int, x: np.ndarray, x2: Optional[np.ndarray] = None, prep: int = 2,
+                        fuse: bool = False, epi: int = 0, residual: Optional[np.ndarray] = None, type2: int = 0, raw2: Optional[np.ndarray] = None) -> np.ndarray:
+        """Decode mat-vec launches exactly as the engine issues them (see include/minigpt4_amd.h)."""
+        x = np.ascontiguousarray(x, np.float32).reshape(n_in)
+        x2c = None if x2 is None else np.ascontiguousarray(x2, np.float32).reshape(n_in)
+        raw1 = np.ascontiguousarray(raw1)
+        n2 = 0 if raw2 is None else 1
+        raw2c = None if raw2 is None else np.ascontiguousarray(raw2)
+        res = None if residual is None else np.ascontiguousarray(residual, np.float32).reshape(-1)
+        y = np.empty(((1 if epi else n1 + n2), n_out), np.float32)
+        rc = self.library.minigpt4_amd_test_matvec(type1, raw1.ctypes.data_as(VOID_PTR), n1, type2, None if raw2c is None else raw2c.ctypes.data_as(VOID_PTR), n2,
+                                                   n_in, n_out, x.ctypes.data_as(FLOAT_PTR), None if x2c is None else x2c.ctypes.data_as(FLOAT_PTR), prep, int(fuse), epi,
+                                                   None if res is None else res.ctypes.data_as(FLOAT_PTR), y.ctypes.data_as(FLOAT_PTR))
+        if rc:
+            raise RuntimeError(f"test_matvec rc={rc}: " + self.library.minigpt4_amd_last_error().decode())
         return y
 
     def amd_test_quantize(self, x: np.ndarray, rms_w: Optional[np.ndarray] = None):

@@ -1,6 +1,11 @@
 import os
 import sys
 
+# The oracle is OpenMP code; the GPU boxes have 256 hardware threads and the test problems are tiny -- a parallel region per op with 256
+# spinning threads costs far more than the op.  (bench.py's cpu_baseline leg sets its own thread count.)
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 import numpy as np
 import pytest
 

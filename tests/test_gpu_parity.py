@@ -75,6 +75,96 @@ def test_mul_mat_matches_oracle(gpu_lib, wtype, shape):
     assert _rel(got, f64) < 3e-2
 
 
+def _prepared_row(prep, x, x2, silu_tab):
+    """The activation row a decode mat-vec consumes, computed the way ggml does (fp32 ops, double sum of squares, fp16 SiLU table)."""
+    if prep == 1:
+        s = np.float64(0)
+        for v in x:
+            s += np.float64(np.float32(v * v))
+        scale = np.float32(1.0) / np.sqrt(np.float32(np.float32(s / len(x)) + np.float32(1e-6)), dtype=np.float32)
+        return (x * scale) * x2
+    if prep == 3:
+        return silu_tab[x.astype(np.float16).view(np.uint16)].astype(np.float32) * x2
+    return x
+
+
+def _silu_table():
+    import refcpu as R
+    return R.table(1).view(np.float16)          # uint16 bit patterns of ggml's table_silu_f16
+
+
+# (type, K): K / 32 / 64 = units per lane: 1, 2, 3, 6, 7 -> every register-tiling of the persistent-wave kernel; rows > 2048 waves -> several groups per wave
+MATVEC_CASES = [("q4_0", 512), ("q5_k", 512), ("q4_1", 4096), ("q4_k", 4096), ("q5_0", 5120), ("q5_k", 5120), ("q6_k", 5120), ("q5_1", 5120), ("q4_0", 11008),
+                ("q4_k", 11008), ("q5_k", 13824), ("q6_k", 13824)]
+
+
+@pytest.mark.parametrize("wtype,K", MATVEC_CASES)
+@pytest.mark.parametrize("prep,fuse", [(2, False), (1, True), (2, True), (3, True), (1, False)])
+def test_decode_matvec_variants_match_oracle(gpu_lib, wtype, K, prep, fuse):
+    """The decode path's own kernel (k_matvec_v2; amd_test_mul_mat exercises the prefill kernels): 1 / 3 matrices per launch, standalone and
+    in-prologue activation preparation, residual add -- against the oracle's quantise + mul_mat on the identically prepared row."""
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    t = Q.NAME_TO_TYPE[wtype]
+    rng = np.random.default_rng(K * 7 + prep * 3 + int(fuse) + sum(map(ord, wtype)))
+    n_mat = 3 if prep == 1 else 1
+    rows = 2300 if K <= 5120 else 1100           # > 2048 waves x 1 row for the small K, ragged against the wave count for all
+    w = (0.03 * rng.standard_normal((n_mat * rows, K))).astype(np.float32)
+    raw = Q.quantize(t, w)
+    x = (rng.standard_normal(K) * (3.0 if prep == 3 else 1.0)).astype(np.float32)
+    x2 = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float32) if prep != 2 else None
+    res = rng.standard_normal(n_mat * rows).astype(np.float32) if prep == 2 else None
+    got = gpu_lib.amd_test_matvec(t, raw, n_mat, K, rows, x, x2, prep=prep, fuse=fuse, residual=res).reshape(-1)
+    row = _prepared_row(prep, x, x2, _silu_table())
+    want = R.mul_mat(t, raw, K, n_mat * rows, row[None, :])[0]
+    if res is not None:
+        want = want + res
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), (wtype, K, prep, fuse)
+
+
+@pytest.mark.parametrize("wtype,K", [("q5_k", 512), ("q4_0", 4096), ("q4_k", 4096), ("q5_k", 5120), ("q6_k", 5120)])
+@pytest.mark.parametrize("fuse", [False, True])
+def test_decode_matvec_silu_pair_epilogue(gpu_lib, wtype, K, fuse):
+    """w1|w3 in one launch writing silu(w1 x) * (w3 x): equals the oracle's two mat-vecs pushed through the fp16 SiLU table."""
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    t = Q.NAME_TO_TYPE[wtype]
+    rng = np.random.default_rng(K + int(fuse))
+    rows = 2500
+    w = (0.05 * rng.standard_normal((2 * rows, K))).astype(np.float32)
+    raw = Q.quantize(t, w)
+    x = rng.standard_normal(K).astype(np.float32)
+    nw = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float32)
+    got = gpu_lib.amd_test_matvec(t, raw, 2, K, rows, x, nw, prep=1, fuse=fuse, epi=1).reshape(-1)
+    ab = R.mul_mat(t, raw, K, 2 * rows, _prepared_row(1, x, nw, None)[None, :])[0]
+    tab = _silu_table()
+    want = tab[ab[:rows].astype(np.float16).view(np.uint16)].astype(np.float32) * ab[rows:]
+    # the table index is the fp16 rounding of a value that itself carries 2e-5 of summation-order noise: allow a neighbouring table entry
+    assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max()
+    assert np.mean(np.abs(got - want) <= 2e-5 * np.abs(want).max()) > 0.97
+
+
+@pytest.mark.parametrize("t1,K", [("q5_k", 5120), ("q4_k", 4096), ("q5_k", 512), ("q4_k", 8192)])
+@pytest.mark.parametrize("fuse", [False, True])
+def test_decode_matvec_mixed_types_one_launch(gpu_lib, t1, K, fuse):
+    """wq|wk (Q4_K / Q5_K) and a Q6_K wv (llama.cpp's "more bits" layers) streamed by one launch."""
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    ta, tb = Q.NAME_TO_TYPE[t1], Q.NAME_TO_TYPE["q6_k"]
+    rng = np.random.default_rng(K * 3 + int(fuse))
+    rows = 1500
+    wa = (0.03 * rng.standard_normal((2 * rows, K))).astype(np.float32)
+    wb = (0.03 * rng.standard_normal((rows, K))).astype(np.float32)
+    ra, rb = Q.quantize(ta, wa), Q.quantize(tb, wb)
+    x = rng.standard_normal(K).astype(np.float32)
+    nw = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float32)
+    got = gpu_lib.amd_test_matvec(ta, ra, 2, K, rows, x, nw, prep=1, fuse=fuse, type2=tb, raw2=rb).reshape(-1)
+    row = _prepared_row(1, x, nw, None)[None, :]
+    want = np.concatenate([R.mul_mat(ta, ra, K, 2 * rows, row)[0], R.mul_mat(tb, rb, K, rows, row)[0]])
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+
+
 @pytest.mark.parametrize("shape", [(257, 176, 528), (32, 768, 100), (256, 592, 176), (70, 48, 33)])
 @pytest.mark.parametrize("gelu", [False, True])
 def test_gemm_f16_mfma(gpu_lib, shape, gelu):
