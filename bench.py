@@ -103,22 +103,24 @@ def cpu_baseline(lp: str, prompt_tokens, budget_s: float = 20.0):
 
 
 def pmc_traffic(type_name: str):
-    """HBM read bytes per launch of the dominant mat-vec kernel from the committed rocprofv3 PMC pass of this same command
-    (profiles/r01d_pmc_fetch_size_summary.csv: FETCH_SIZE x 1024 x 2, the gfx950 correction of MI355X_MICROARCH.md).  PMC counters cannot be
-    read from inside the process, so this is the profile's number, not a live one; None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01d_pmc_fetch_size_summary.csv")
+    """HBM read bytes per launch of the dominant mat-vec kernel from the newest committed rocprofv3 PMC pass of the decode loop
+    (profiles/*pmc_fetch_size_summary.csv, written by tools/pmc_summary.py: FETCH_SIZE x 1024 x 2, the gfx950 correction of MI355X_MICROARCH.md).
+    PMC counters cannot be read from inside the process, so this is the profile's number, not a live one; None when no summary is committed."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_size_summary.csv")))
     tid = {"q5_k": 13, "q6_k": 14, "q4_0": 2, "q4_k": 12}.get(type_name)
-    if tid is None or not os.path.exists(path):
+    if tid is None or not paths:
         return None, None
+    path = paths[-1]
     calls, byts = 0, 0.0
     for line in open(path):
         if line.startswith('"') and f"k_matvec_v2<{tid}," in line:
             parts = line.rsplit('",', 1)[1].strip().split(",")
             calls += int(parts[0])
-            byts += int(parts[0]) * float(parts[2]) * 1e6
+            byts += int(parts[0]) * float(parts[-1]) * 1e6
     if not calls:
         return None, None
-    return byts / calls, "profiles/r01d_pmc_fetch_size_summary.csv (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction; avg over k_matvec_v2 launches of this type)"
+    return byts / calls, f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction; avg over the k_matvec_v2 launches of this type)"
 
 
 def main():
