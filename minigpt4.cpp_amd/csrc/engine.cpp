@@ -66,13 +66,13 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     max_chunk_ = max_rows_;
     if (getenv("MINIGPT4_NO_MMQ")) set_mmq_enabled(!atoi(getenv("MINIGPT4_NO_MMQ")));
     if (getenv("MINIGPT4_ATTN_MFMA")) set_attn_mfma(atoi(getenv("MINIGPT4_ATTN_MFMA")));
-    if (getenv("MINIGPT4_GEMM_BK")) set_gemm_bk(atoi(getenv("MINIGPT4_GEMM_BK")));
     // Decode: which activation preparations run inside the consuming mat-vec's prologue (one fat workgroup per CU repeats the row preparation while
     // its first weight tiles are in flight) instead of as their own launch.  bit 0: attn_norm -> wq|wk|wv, 1: attention output -> wo,
     // 2: ffn_norm -> w1|w3, 3: silu(w1 x) * (w3 x) -> w2, 4: final norm -> output; bit 5: w1|w3 launch writes silu(w1 x) * (w3 x) itself
     // (row-pair epilogue); bit 6: wq|wk and a differently typed wv in one launch.  See DESIGN.md "mat-vec prologue".
     fuse_mask_ = getenv("MINIGPT4_FUSE") ? atoi(getenv("MINIGPT4_FUSE")) : FUSE_DEFAULT;
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
+    if (const char *sk = getenv("MINIGPT4_SPLITK")) { sscanf(sk, "%d,%d", &splitk_proj_, &splitk_fc2_); splitk_proj_ = std::max(1, std::min(SPLITK_MAX, splitk_proj_)); splitk_fc2_ = std::max(1, std::min(SPLITK_MAX, splitk_fc2_)); }
     set_matvec_tuning(getenv("MINIGPT4_MV_WAVES") ? atoi(getenv("MINIGPT4_MV_WAVES")) : 0, getenv("MINIGPT4_FAT_LB") ? atoi(getenv("MINIGPT4_FAT_LB")) : 0, prop.multiProcessorCount);
     sampler_.seed(seed);
     auto t0 = std::chrono::steady_clock::now();
@@ -303,7 +303,7 @@ void Engine::alloc_buffers() {
     sz(5 * B * E * 4); sz(2 * B * F * 4); sz(V * 4);
     sz(2 * B * Kmax); sz(B * Kmax / 256 * 4 + 64); sz(B * Kmax / 16 * 2 + 64); sz(4 * (B * Kmax / 32 * 4 + 64)); sz(B * Kmax * 2); sz(B * Kmax * 4);
     sz(4096);
-    sz(3 * 224 * 224 * 4); sz(256 * 592 * 2); sz(256 * D * 4); sz(257 * D * 4); sz(257 * 3 * D * 4); sz(3 * 257 * D * 2); sz(257 * M * 2);
+    sz(3 * 224 * 224 * 4); sz(256 * 592 * 2); sz(256 * D * 4); sz(257 * D * 4); sz(257 * 3 * D * 4); sz(3 * 257 * D * 2); sz(257 * M * 2); sz((size_t)SPLITK_MAX * 257 * D * 4);
     sz(8 * NQ * 2304 * 4); sz(257 * 1536 * 4); sz(NQ * (size_t)std::max(v_qi_, 768) * 2 * 4); sz(NQ * (size_t)v_out_ * 4); sz(1 << 20);
     buf_arena_.alloc(total);
     auto takef = [&](size_t n) { return reinterpret_cast<float *>(buf_arena_.take(n * 4)); };
@@ -346,6 +346,7 @@ void Engine::alloc_buffers() {
     HIP_CHECK(hipHostMalloc((void **)&h_logits_, V * 4, hipHostMallocDefault));
     // vision
     vi_img_ = takef(3 * 224 * 224); vi_patches_ = takeh(256 * 592); vi_pe_ = takef(256 * D); vi_x_ = takef(257 * D); vi_qkv_ = takef(257 * 3 * D);
+    vi_slab_ = takef((size_t)SPLITK_MAX * 257 * D);
     vi_ln_h_ = takeh(257 * D); vi_att_h_ = takeh(257 * D); vi_img_h_ = takeh(257 * D); vi_mlp_h_ = takeh(257 * M);
     vi_hs_ = takef(NQ * 768); vi_a1_ = takef(NQ * 768); vi_a2_ = takef(NQ * 768); vi_d_ = takef(NQ * 768); vi_qq_ = takef(NQ * 2304); vi_kv_ = takef(257 * 1536);
     vi_hs_h_ = takeh(NQ * 768); vi_a1_h_ = takeh(NQ * 768); vi_a2_h_ = takeh(NQ * 768); vi_ctx_h_ = takeh(NQ * 768); vi_im_h_ = takeh(NQ * (size_t)v_qi_);
@@ -611,16 +612,35 @@ int Engine::encode_image(const float *chw, float *out) {
     launch_gemm_f16(vi_patches_, 592, v_patch_w_, 592, 256, D, 592, v_patch_b_, nullptr, false, tabs_, vi_pe_, nullptr, D, s);
     launch_assemble_embeddings(v_cls_, vi_pe_, v_pos_, D, vi_x_, s);
     const float scale = 1.0f / sqrtf(88.0f);
-    for (const VBlock &b : vblocks_) {
-        launch_layernorm(vi_x_, b.n1w, b.n1b, 257, D, nullptr, vi_ln_h_, s);
+    // ViT blocks.  attn.proj and mlp.fc2 (N = D: fewer 64x64 tiles than CUs, and fc2 has the longest K) run split-K; their deterministic reduce
+    // also adds bias + residual and applies the LayerNorm that follows (norm2, the next block's norm1, ln_vision after the last block).
+    const int sp = gemm_split_slices(D, splitk_proj_), sf = gemm_split_slices(M, splitk_fc2_);
+    const size_t slab = (size_t)257 * D;
+    if (!vblocks_.empty()) launch_layernorm(vi_x_, vblocks_[0].n1w, vblocks_[0].n1b, 257, D, nullptr, vi_ln_h_, s);
+    for (size_t ib = 0; ib < vblocks_.size(); ib++) {
+        const VBlock &b = vblocks_[ib];
+        const bool last = ib + 1 == vblocks_.size();
+        const float *nw = last ? v_lnv_w_ : vblocks_[ib + 1].n1w, *nb = last ? v_lnv_b_ : vblocks_[ib + 1].n1b;
+        __half *nout = last ? vi_img_h_ : vi_ln_h_;
         launch_gemm_f16(vi_ln_h_, D, b.qkv_w, D, 257, 3 * D, D, b.qkv_b, nullptr, false, tabs_, vi_qkv_, nullptr, 3 * D, s);
         launch_attn_f32(vi_qkv_, 3 * D, vi_qkv_ + D, vi_qkv_ + 2 * D, 3 * D, 257, 257, v_heads_, 88, scale, 0.0f, tabs_, nullptr, vi_att_h_, D, s);
-        launch_gemm_f16(vi_att_h_, D, b.proj_w, D, 257, D, D, b.proj_b, vi_x_, false, tabs_, vi_x_, nullptr, D, s);
-        launch_layernorm(vi_x_, b.n2w, b.n2b, 257, D, nullptr, vi_ln_h_, s);
+        if (sp > 1) {
+            launch_gemm_f16_splitk(vi_att_h_, D, b.proj_w, D, 257, D, D, sp, vi_slab_, slab, D, s);
+            launch_splitk_reduce_ln(vi_slab_, sp, slab, b.proj_b, vi_x_, 257, D, vi_x_, b.n2w, b.n2b, nullptr, vi_ln_h_, s);
+        } else {
+            launch_gemm_f16(vi_att_h_, D, b.proj_w, D, 257, D, D, b.proj_b, vi_x_, false, tabs_, vi_x_, nullptr, D, s);
+            launch_layernorm(vi_x_, b.n2w, b.n2b, 257, D, nullptr, vi_ln_h_, s);
+        }
         launch_gemm_f16(vi_ln_h_, D, b.fc1_w, D, 257, M, D, b.fc1_b, nullptr, true, tabs_, nullptr, vi_mlp_h_, M, s);
-        launch_gemm_f16(vi_mlp_h_, M, b.fc2_w, M, 257, D, M, b.fc2_b, vi_x_, false, tabs_, vi_x_, nullptr, D, s);
+        if (sf > 1) {
+            launch_gemm_f16_splitk(vi_mlp_h_, M, b.fc2_w, M, 257, D, M, sf, vi_slab_, slab, D, s);
+            launch_splitk_reduce_ln(vi_slab_, sf, slab, b.fc2_b, vi_x_, 257, D, vi_x_, nw, nb, nullptr, nout, s);
+        } else {
+            launch_gemm_f16(vi_mlp_h_, M, b.fc2_w, M, 257, D, M, b.fc2_b, vi_x_, false, tabs_, vi_x_, nullptr, D, s);
+            launch_layernorm(vi_x_, nw, nb, 257, D, nullptr, nout, s);
+        }
     }
-    launch_layernorm(vi_x_, v_lnv_w_, v_lnv_b_, 257, D, nullptr, vi_img_h_, s);
+    if (vblocks_.empty()) launch_layernorm(vi_x_, v_lnv_w_, v_lnv_b_, 257, D, nullptr, vi_img_h_, s);
     // Q-Former (masks are all-zero)
     launch_layernorm(v_qtok_, v_qeln_w_, v_qeln_b_, NQ, H, vi_hs_, vi_hs_h_, s);
     for (const QLayer &L : qlayers_) {

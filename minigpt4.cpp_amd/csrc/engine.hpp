@@ -124,6 +124,8 @@ private:
     float *v_cls_ = nullptr, *v_pos_ = nullptr, *v_patch_b_ = nullptr, *v_lnv_w_ = nullptr, *v_lnv_b_ = nullptr, *v_qtok_ = nullptr, *v_qeln_w_ = nullptr, *v_qeln_b_ = nullptr, *v_proj_b_ = nullptr;
     __half *v_patch_w_ = nullptr, *v_proj_w_ = nullptr;
     // vision activations
+    static constexpr int SPLITK_MAX = 12; int splitk_proj_ = 1, splitk_fc2_ = 4;   // MINIGPT4_SPLITK=proj,fc2 (1 = off)
+    float *vi_slab_ = nullptr;
     float *vi_img_ = nullptr, *vi_pe_ = nullptr, *vi_x_ = nullptr, *vi_qkv_ = nullptr, *vi_hs_ = nullptr, *vi_a1_ = nullptr, *vi_a2_ = nullptr, *vi_d_ = nullptr, *vi_qq_ = nullptr, *vi_kv_ = nullptr, *vi_out_ = nullptr;
     __half *vi_patches_ = nullptr, *vi_ln_h_ = nullptr, *vi_att_h_ = nullptr, *vi_mlp_h_ = nullptr, *vi_img_h_ = nullptr, *vi_hs_h_ = nullptr, *vi_a1_h_ = nullptr, *vi_a2_h_ = nullptr, *vi_ctx_h_ = nullptr, *vi_im_h_ = nullptr;
     float last_encode_ms_ = 0;

@@ -66,9 +66,13 @@ void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_
 void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual,
                      bool gelu, const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s);
 void set_attn_mfma(int v);   // 1: f32-MFMA attention kernel (default), 0: VALU/LDS kernel
-void set_gemm_bk(int bk);   // tuning knob: K-tile depth of k_gemm_f16 (64 / 128 / 256)
 // LayerNorm (ggml_norm eps 1e-5, then w*x+b); rows x n; writes fp32 (nullable) and fp16 (nullable).
 void launch_layernorm(const float *x, const float *w, const float *b, int rows, int n, float *out, __half *out_h, hipStream_t s);
+// split-K GEMM (raw fp32 partial sums into `slices` slabs) + the deterministic reduce fused with bias / residual / the following LayerNorm
+int gemm_split_slices(int K, int want);   // slices actually used for a K (whole 128-wide k tiles per slice)
+void launch_gemm_f16_splitk(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, int slices, float *slabs, size_t slab_stride, int ldo, hipStream_t s);
+void launch_splitk_reduce_ln(const float *slabs, int n_slabs, size_t slab_stride, const float *bias, const float *residual, int rows, int n, float *x_out, const float *ln_w,
+                             const float *ln_b, float *ln_out, __half *ln_out_h, hipStream_t s);
 // f32 attention: q[nq][ldq], k/v[nk][ldk]; per head h the slice [h*hd, (h+1)*hd).  q_prescale != 0: q *= q_prescale first (ViT);
 // score_div != 0: scores /= score_div (BERT).  Output fp32 (nullable) / fp16 (nullable) [nq][ldo].
 void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale,

@@ -6,6 +6,8 @@
 #include "kernels.hpp"
 #include "devutil.hpp"
 
+#include <algorithm>
+
 namespace mg4 {
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
@@ -21,21 +23,29 @@ __device__ __forceinline__ float tab_v(const __half *t, float x) { return __half
 // Deep K tiles (BK = 128/256): with M = 257 a launch has only ~1-2 workgroups per CU, so the exposed global-load latency per k-iteration
 // dominates; fewer, fatter iterations (8-16 MFMAs per wave each) amortise it.  One LDS buffer, next tile prefetched into registers.
 // (A 3-stage register ring + LDS double buffer was measured 3x SLOWER: hipcc's counted waits degenerate around the ring, see DESIGN.md.)
-constexpr int GB_M = 64;
-
-template <int BK, int BN, bool GELU, bool RES>
-__global__ __launch_bounds__(BN * 4) void k_gemm_f16(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K,
+template <int BK, int GB_M, int BN, bool GELU, bool RES>
+__global__ __launch_bounds__(GB_M / 32 * BN / 32 * 64) void k_gemm_f16(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K,
                                                   const float *__restrict__ bias, const float *residual, const Tables tb,
-                                                  float *out, __half *__restrict__ out_h, int ldo) {
+                                                  float *out, __half *__restrict__ out_h, int ldo, int k_per_slice, size_t slab_stride) {
     constexpr int LD = BK + 8;                 // +16 bytes per row: conflict-free ds_read_b128 for BK = 32/64/128/256
     constexpr int CPR = BK / 8;                // 16-byte chunks per row
-    constexpr int NT = BN * 4;                 // 256 threads (2x2 waves) for BN = 64, 128 threads (2x1 waves) for BN = 32
+    constexpr int WN = BN / 32, NT = GB_M / 32 * WN * 64;   // one 32x32 MFMA tile per wave: 4 waves for 64x64, 8 for 128x64, 16 for 128x128
     constexpr int NCA = GB_M * CPR / NT, NCW = BN * CPR / NT;   // 16-byte chunks per thread: A tile, W tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
     __half *As = reinterpret_cast<__half *>(smem_g), *Ws = As + GB_M * LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * BN;
-    const int wm = BN == 64 ? wave >> 1 : wave, wn = BN == 64 ? wave & 1 : 0;
+    // XCD-aware tile order (blocks are dealt round-robin to the 8 XCDs, each with its own L2): the row tiles that share a weight tile get
+    // consecutive slots of ONE XCD, so the weight tile is fetched from HBM once instead of once per XCD (measured 4x re-fetch without this).
+    const int ntx = (N + BN - 1) / BN, rt = (M + GB_M - 1) / GB_M;
+    const int bslot = blockIdx.x >> 3, bx = (bslot / rt) * 8 + (blockIdx.x & 7), by = bslot % rt;
+    if (bx >= ntx) return;
+    const int m0 = by * GB_M, n0 = bx * BN;
+    const int wm = wave / WN, wn = wave % WN;
+    if (k_per_slice > 0) {   // split-K: slice z multiplies columns [z * k_per_slice, ...) and writes its raw fp32 partial sums into slab z
+        const int k0 = blockIdx.z * k_per_slice;
+        A += k0; W += k0; K = min(K - k0, k_per_slice);
+        out += (size_t)blockIdx.z * slab_stride;
+    }
     const int nk = (K + BK - 1) / BK;
     // per-thread source pointers (row clamped) and LDS offsets of its chunks
     const __half *asrc[NCA], *wsrc[NCW]; int lofa[NCA], kofa[NCA], lofw[NCW], kofw[NCW];
@@ -105,30 +115,29 @@ __global__ __launch_bounds__(BN * 4) void k_gemm_f16(const __half *__restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; r++) if (okr[r]) { if (out) out[o[r]] = v[r]; if (out_h) out_h[o[r]] = __float2half_rn(v[r]); }
 }
-template <int BK, int BN>
+template <int BK, int BM, int BN>
 static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
-                          float *out, __half *out_h, int ldo, hipStream_t s) {
-    dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + GB_M - 1) / GB_M)), block(BN * 4);
-    const size_t lds = (size_t)(GB_M + BN) * (BK + 8) * 2;
+                          float *out, __half *out_h, int ldo, hipStream_t s, int slices = 1, size_t slab_stride = 0) {
+    const int k_per_slice = slices > 1 ? ((K + BK - 1) / BK + slices - 1) / slices * BK : 0;
+    const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
+    dim3 grid((unsigned)((ntx + 7) / 8 * 8 * rt), 1, (unsigned)slices), block(BM / 32 * BN / 32 * 64);
+    const size_t lds = (size_t)(BM + BN) * (BK + 8) * 2;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16<BK, BN, true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
-    else if (gelu) hipLaunchKernelGGL((k_gemm_f16<BK, BN, true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
-    else if (residual) hipLaunchKernelGGL((k_gemm_f16<BK, BN, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
-    else hipLaunchKernelGGL((k_gemm_f16<BK, BN, false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
+    else if (gelu) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
+    else if (residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
+    else hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
 }
-static int g_gemm_bk = 128, g_gemm_narrow = 0;   // 64x32 tiles measured slower than 64x64 even at 110 workgroups (profiles/r01c): off by default
-void set_gemm_bk(int bk) { if (bk == 64 || bk == 128) g_gemm_bk = bk; else if (bk >= 1000) g_gemm_narrow = bk - 1000; }
+// Tile shape experiments at M = 257 (profiles/r01i_ab_encode.log): 128x64 (8 waves) and 128x128 (16 waves) tiles halve the bytes moved per flop but are
+// 16 % / 28 % SLOWER end to end than 64x64; 64x32 tiles (more workgroups) are slower too; an XCD-aware tile order removes a 4x weight re-fetch from
+// HBM (PMC FETCH_SIZE) without changing the time.  The launches are bound by the serial per-k-tile chain of each workgroup, not by traffic.
 void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
                      float *out, __half *out_h, int ldo, hipStream_t s) {
-    // 64x64 tiles unless that leaves most CUs without a workgroup; then 64x32 tiles (twice the workgroups, 2 waves each)
-    const long wgs64 = (long)((N + 63) / 64) * ((M + GB_M - 1) / GB_M);
-    const bool narrow = wgs64 < g_gemm_narrow;
-    if (g_gemm_bk == 64) { if (narrow) launch_gemm_t<64, 32>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); else launch_gemm_t<64, 64>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); }
-    else { if (narrow) launch_gemm_t<128, 32>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); else launch_gemm_t<128, 64>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); }
+    launch_gemm_t<128, 64, 64>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);
 }
 
 // =====================================================================================================================
@@ -141,6 +150,62 @@ __device__ __forceinline__ double block_sum_d(double v, double *red) {
     __syncthreads();
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
+// Split-K form for the GEMMs whose N gives fewer 64x64 tiles than CUs (ViT attn.proj / mlp.fc2, the Q-Former's 768-wide layers): `slices` workgroups
+// share an output tile, each multiplies a contiguous K range and writes raw fp32 partial sums into its own slab [M][ldo]; k_splitk_reduce_ln adds
+// the slabs in a fixed order (deterministic) together with bias / residual and the LayerNorm that follows in the graph.
+int gemm_split_slices(int K, int want) { const int nk = (K + 127) / 128; int s = std::max(1, std::min(want, nk)); const int per = (nk + s - 1) / s; return (nk + per - 1) / per; }
+void launch_gemm_f16_splitk(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, int slices, float *slabs, size_t slab_stride, int ldo, hipStream_t s) {
+    Tables tb{};
+    launch_gemm_t<128, 64, 64>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride);
+}
+// x = residual + (bias + sum_z slab_z)   [x_out, fp32];   then, when ln_w is given, ggml_norm(x) * ln_w + ln_b -> ln_out (fp32) / ln_out_h (fp16).
+// One workgroup per row, n <= 2048.
+__global__ __launch_bounds__(256) void k_splitk_reduce_ln(const float *__restrict__ slabs, int n_slabs, size_t slab_stride, const float *__restrict__ bias, const float *residual, int n,
+                                                          float *x_out, const float *__restrict__ ln_w, const float *__restrict__ ln_b, float *__restrict__ ln_out,
+                                                          __half *__restrict__ ln_out_h) {
+    __shared__ double red[4];
+    const size_t row = blockIdx.x;
+    constexpr int MAXE = 8;
+    float xv[MAXE];
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < MAXE; e++) {
+        const int i = threadIdx.x + 256 * e;
+        float v = 0.0f;
+        if (i < n) {
+            float a = slabs[row * n + i];
+            for (int z = 1; z < n_slabs; z++) a += slabs[(size_t)z * slab_stride + row * n + i];
+            v = bias ? bias[i] + a : a;
+            if (residual) v = residual[row * n + i] + v;
+            if (x_out) x_out[row * n + i] = v;
+        }
+        xv[e] = v; s += (double)v;
+    }
+    if (!ln_w) return;
+    const float mean = (float)(block_sum_d(s, red) / (double)n);
+    double s2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < MAXE; e++) { const int i = threadIdx.x + 256 * e; if (i < n) { const float v = xv[e] - mean; s2 += (double)(v * v); } }
+    const float variance = (float)(block_sum_d(s2, red) / (double)n);
+    const float scale = 1.0f / sqrtf(variance + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < MAXE; e++) {
+        const int i = threadIdx.x + 256 * e;
+        if (i < n) {
+            float v = (xv[e] - mean) * scale;
+            v = ln_w[i] * v;
+            if (ln_b) v = v + ln_b[i];
+            if (ln_out) ln_out[row * n + i] = v;
+            if (ln_out_h) ln_out_h[row * n + i] = __float2half_rn(v);
+        }
+    }
+}
+void launch_splitk_reduce_ln(const float *slabs, int n_slabs, size_t slab_stride, const float *bias, const float *residual, int rows, int n, float *x_out, const float *ln_w,
+                             const float *ln_b, float *ln_out, __half *ln_out_h, hipStream_t s) {
+    if (n > 2048) throw HipError{hipErrorInvalidValue, "splitk reduce: row longer than 2048", __FILE__, __LINE__};
+    hipLaunchKernelGGL(k_splitk_reduce_ln, dim3((unsigned)rows), dim3(256), 0, s, slabs, n_slabs, slab_stride, bias, residual, n, x_out, ln_w, ln_b, ln_out, ln_out_h);
+}
+
 __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b, int n, float *__restrict__ out,
                                                    __half *__restrict__ out_h) {
     __shared__ double red[4];
