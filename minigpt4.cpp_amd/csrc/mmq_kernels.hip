@@ -71,6 +71,10 @@ __global__ __launch_bounds__(256) void k_mmq_q45k(const QWeight W, const ActQ A,
         for (int jp = 0; jp < 4; jp++) { w.q[jp] = ldv4(W.qs + (g0 + 2 * jp) * 16); w.P[jp] = Q5 ? *reinterpret_cast<const unsigned *>(W.qh + (g0 + 2 * jp) * 4) : 0u; }
         w.h = ldv4(W.sc + ((size_t)row * NSB + sb) * 16);
     };
+    // the activation super-block scales of this workgroup's 64 tokens: one LDS image instead of 32 dependent global loads per super-block
+    extern __shared__ float dkl[];                  // [64][NSB]
+    for (int e = threadIdx.x; e < 64 * NSB; e += 256) { const int t = e / NSB, b = e - t * NSB; dkl[e] = A.dk[(size_t)min(t0 + t, N - 1) * NSB + b]; }
+    __syncthreads();
     Wsb cur, nxt;
     fetch(wv, cur);
     for (int sb = wv; sb < NSB; sb += 4) {
@@ -114,8 +118,7 @@ __global__ __launch_bounds__(256) void k_mmq_q45k(const QWeight W, const ActQ A,
         for (int tt = 0; tt < MMQ_TT; tt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int tok = min(t0 + tt * 32 + tok_of(r, hh), N - 1);
-                const float da = A.dk[(size_t)tok * NSB + sb];
+                const float da = dkl[(tt * 32 + tok_of(r, hh)) * NSB + sb];
                 acc[tt][r] = fmaf(d * da, (float)isum[tt][r], acc[tt][r]);
                 acc[tt][r] = fmaf(-(dmin * da), (float)msum[tt][r], acc[tt][r]);
             }
@@ -160,6 +163,9 @@ __global__ __launch_bounds__(256) void k_mmq_q6k(const QWeight W, const ActQ A, 
         }
         w.d = *reinterpret_cast<const unsigned short *>(W.d + ((size_t)row * NSB + sb) * 2);
     };
+    extern __shared__ float dkl[];                  // [64][NSB] activation super-block scales of this workgroup's tokens
+    for (int e = threadIdx.x; e < 64 * NSB; e += 256) { const int t = e / NSB, b = e - t * NSB; dkl[e] = A.dk[(size_t)min(t0 + t, N - 1) * NSB + b]; }
+    __syncthreads();
     Wsb cur, nxt;
     fetch(wv, cur);
     const v4i z4 = {0, 0, 0, 0};
@@ -200,8 +206,7 @@ __global__ __launch_bounds__(256) void k_mmq_q6k(const QWeight W, const ActQ A, 
         for (int tt = 0; tt < MMQ_TT; tt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int tok = min(t0 + tt * 32 + tok_of(r, hh), N - 1);
-                acc[tt][r] = fmaf(d * A.dk[(size_t)tok * NSB + sb], (float)isum[tt][r], acc[tt][r]);
+                acc[tt][r] = fmaf(d * dkl[(tt * 32 + tok_of(r, hh)) * NSB + sb], (float)isum[tt][r], acc[tt][r]);
             }
         cur = nxt;
     }
@@ -269,10 +274,11 @@ bool mmq_supported(int type) { return type == GT_Q4_K || type == GT_Q5_K || type
 
 void launch_mmq(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
     const dim3 grid((unsigned)((W.rows + 31) / 32), (unsigned)((N + 32 * MMQ_TT - 1) / (32 * MMQ_TT))), block(256);
+    const size_t dk_lds = (size_t)64 * (W.cols / 256) * 4;   // 32 * MMQ_TT tokens x super-blocks
     switch (W.type) {
-    case GT_Q4_K: hipLaunchKernelGGL((k_mmq_q45k<false>), grid, block, 0, s, W, A, N, y, ldy, residual); break;
-    case GT_Q5_K: hipLaunchKernelGGL((k_mmq_q45k<true>), grid, block, 0, s, W, A, N, y, ldy, residual); break;
-    case GT_Q6_K: hipLaunchKernelGGL(k_mmq_q6k, grid, block, 0, s, W, A, N, y, ldy, residual); break;
+    case GT_Q4_K: hipLaunchKernelGGL((k_mmq_q45k<false>), grid, block, dk_lds, s, W, A, N, y, ldy, residual); break;
+    case GT_Q5_K: hipLaunchKernelGGL((k_mmq_q45k<true>), grid, block, dk_lds, s, W, A, N, y, ldy, residual); break;
+    case GT_Q6_K: hipLaunchKernelGGL(k_mmq_q6k, grid, block, dk_lds, s, W, A, N, y, ldy, residual); break;
     case GT_Q4_0: hipLaunchKernelGGL(k_mmq_q40, grid, block, 0, s, W, A, N, y, ldy, residual); break;
     default: throw HipError{hipErrorInvalidValue, "mmq: unsupported type", __FILE__, __LINE__};
     }
