@@ -134,7 +134,9 @@ static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, in
 }
 // Tile shape experiments at M = 257 (profiles/r01i_ab_encode.log): 128x64 (8 waves) and 128x128 (16 waves) tiles halve the bytes moved per flop but are
 // 16 % / 28 % SLOWER end to end than 64x64; 64x32 tiles (more workgroups) are slower too; an XCD-aware tile order removes a 4x weight re-fetch from
-// HBM (PMC FETCH_SIZE) without changing the time.  The launches are bound by the serial per-k-tile chain of each workgroup, not by traffic.
+// HBM (PMC FETCH_SIZE) without changing the time; 64x128 tiles with two accumulators per wave (fewer LDS reads per MFMA) are 26 % slower.  Every
+// variant with fewer workgroups loses: the launches are bound by the serial per-k-tile chain of each workgroup (global -> register -> LDS ->
+// MFMA, two barriers per tile), not by traffic, LDS bandwidth or the matrix cores -- the next step is an LDS-DMA ring per workgroup.
 void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
                      float *out, __half *out_h, int ldo, hipStream_t s) {
     launch_gemm_t<128, 64, 64>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);
