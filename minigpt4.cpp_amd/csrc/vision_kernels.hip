@@ -32,7 +32,7 @@ __global__ __launch_bounds__(GB_M / 32 * BN / 32 * 64) void k_gemm_f16(const __h
     constexpr int WN = BN / 32, NT = GB_M / 32 * WN * 64;   // one 32x32 MFMA tile per wave: 4 waves for 64x64, 8 for 128x64, 16 for 128x128
     constexpr int NCA = GB_M * CPR / NT, NCW = BN * CPR / NT;   // 16-byte chunks per thread: A tile, W tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
-    __half *As = reinterpret_cast<__half *>(smem_g), *Ws = As + GB_M * LD;
+    __half *As = reinterpret_cast<__half *>(smem_g), *Ws = As + GB_M * LD, *As1 = Ws + BN * LD, *Ws1 = As1 + GB_M * LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order (blocks are dealt round-robin to the 8 XCDs, each with its own L2): the row tiles that share a weight tile get
     // consecutive slots of ONE XCD, so the weight tile is fetched from HBM once instead of once per XCD (measured 4x re-fetch without this).
@@ -71,23 +71,28 @@ __global__ __launch_bounds__(GB_M / 32 * BN / 32 * 64) void k_gemm_f16(const __h
         int4 vw = *reinterpret_cast<const int4 *>(wsrc[i] + ko);                                                \
         if (!valid) { vw.x = vw.y = vw.z = vw.w = 0; }                                                          \
         RW[i] = vw; }
-#define MG4_STEP(kt, RA, RW)                                                                                    \
-    {   _Pragma("unroll") for (int i = 0; i < NCA; i++) *reinterpret_cast<int4 *>(&As[lofa[i]]) = RA[i];        \
-        _Pragma("unroll") for (int i = 0; i < NCW; i++) *reinterpret_cast<int4 *>(&Ws[lofw[i]]) = RW[i];        \
+#define MG4_STEP(kt, RA, RW, AS, WS)                                                                            \
+    {   _Pragma("unroll") for (int i = 0; i < NCA; i++) *reinterpret_cast<int4 *>(&AS[lofa[i]]) = RA[i];        \
+        _Pragma("unroll") for (int i = 0; i < NCW; i++) *reinterpret_cast<int4 *>(&WS[lofw[i]]) = RW[i];        \
         __syncthreads();                                                                                        \
         MG4_GLOAD((kt) + 3, RA, RW)      /* past the end: zeroed */                                             \
         _Pragma("unroll") for (int ks = 0; ks < BK / 16; ks++) {                                                \
-            const half8_t af = *reinterpret_cast<const half8_t *>(&As[(wm * 32 + (lane & 31)) * LD + ks * 16 + (lane >> 5) * 8]); \
-            const half8_t bf = *reinterpret_cast<const half8_t *>(&Ws[(wn * 32 + (lane & 31)) * LD + ks * 16 + (lane >> 5) * 8]); \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0); }                               \
-        __syncthreads(); }
+            const half8_t af = *reinterpret_cast<const half8_t *>(&AS[(wm * 32 + (lane & 31)) * LD + ks * 16 + (lane >> 5) * 8]); \
+            const half8_t bf = *reinterpret_cast<const half8_t *>(&WS[(wn * 32 + (lane & 31)) * LD + ks * 16 + (lane >> 5) * 8]); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0); } }
+    // Two LDS buffers, ONE barrier per k tile: tile k+1 is written into the other buffer while slower waves still multiply tile k; a wave can only
+    // reach the barrier of step k+1 after its own reads of step k, so the buffer written in step k+2 is free.  (3 register stages x 2 LDS buffers
+    // -> the loop body is unrolled 6 times with statically named stages and buffers.)
     MG4_GLOAD(0, ra0, rw0)
     MG4_GLOAD(1, ra1, rw1)
     MG4_GLOAD(2, ra2, rw2)
-    for (int kt = 0; kt < nk; kt += 3) {      // whole triples: steps past nk multiply zero tiles (accumulators unchanged)
-        MG4_STEP(kt, ra0, rw0)
-        MG4_STEP(kt + 1, ra1, rw1)
-        MG4_STEP(kt + 2, ra2, rw2)
+    for (int kt = 0; kt < nk; kt += 6) {      // whole sextuples: steps past nk multiply zero tiles (accumulators unchanged)
+        MG4_STEP(kt, ra0, rw0, As, Ws)
+        MG4_STEP(kt + 1, ra1, rw1, As1, Ws1)
+        MG4_STEP(kt + 2, ra2, rw2, As, Ws)
+        MG4_STEP(kt + 3, ra0, rw0, As1, Ws1)
+        MG4_STEP(kt + 4, ra1, rw1, As, Ws)
+        MG4_STEP(kt + 5, ra2, rw2, As1, Ws1)
     }
 #undef MG4_STEP
 #undef MG4_GLOAD
@@ -121,7 +126,7 @@ static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, in
     const int k_per_slice = slices > 1 ? ((K + BK - 1) / BK + slices - 1) / slices * BK : 0;
     const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
     dim3 grid((unsigned)((ntx + 7) / 8 * 8 * rt), 1, (unsigned)slices), block(BM / 32 * BN / 32 * 64);
-    const size_t lds = (size_t)(BM + BN) * (BK + 8) * 2;
+    const size_t lds = (size_t)2 * (BM + BN) * (BK + 8) * 2;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
