@@ -74,9 +74,13 @@ enum MiniGPT4ImageLoadFlags { MINIGPT4_IMAGE_LOAD_FLAG_NONE };
 /* minigpt4.h:97, impl minigpt4.cpp:2543-2574.  NULL when a path is missing, a file is malformed, or no
  * gfx950 device is usable (the library never falls back to a CPU path).  `numa` is ignored. */
 MINIGPT4_API struct MiniGPT4Context *minigpt4_model_load(const char *path, const char *llm_model, int verbosity, int seed, int n_ctx, int n_batch, bool numa);
-/* minigpt4.h:98, impl minigpt4.cpp:2576-2595.  Like the reference's default (non-OpenCV) build: returns 19. */
+/* minigpt4.h:98, impl minigpt4.cpp:2576-2595 (OpenCV build: cv::imread(IMREAD_COLOR) + BGR2RGB).  Native here (no OpenCV): PNG / JPEG /
+ * BMP / binary PNM -> U8 HWC RGB, library-allocated image->data (free with minigpt4_free_image).  0, 17 (missing file) or 5 (OpenImage).
+ * ctx is not used (may be NULL).  Host work, as in the reference. */
 MINIGPT4_API int minigpt4_image_load_from_file(struct MiniGPT4Context *ctx, const char *path, IN struct MiniGPT4Image *image, int flags);
-/* minigpt4.h:99, impl minigpt4.cpp:2597-2651.  Default build behaviour: returns 19. */
+/* minigpt4.h:99, impl minigpt4.cpp:2597-2651 (OpenCV build: PillowResize bicubic 224x224, 1/255, CLIP mean/std, HWC->CHW).  Native here, as
+ * HIP kernels: needs a GPU (no CPU fallback; 6 when none).  Errors 15 (channels != 3) / 16 (format != U8).  Output as the reference reports it:
+ * F32, width = 1, height = 150528, channels = 1, library-allocated (free with minigpt4_free_image).  ctx may be NULL (default stream). */
 MINIGPT4_API int minigpt4_preprocess_image(struct MiniGPT4Context *ctx, IN const struct MiniGPT4Image *image, OUT struct MiniGPT4Image *preprocessed_image, int flags);
 /* minigpt4.h:100, impl minigpt4.cpp:2653-2662 -> MiniGPT4::encode_image :2094-2363.  image: F32 CHW 3x224x224
  * (errors 13/14).  The library allocates embedding->data (32*n_embd floats); free with minigpt4_free_embedding. */

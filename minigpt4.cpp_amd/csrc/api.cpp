@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "engine.hpp"
+#include "imageio.hpp"
 #include "minigpt4_amd.h"
 
 using namespace mg4;
@@ -60,8 +61,38 @@ struct MiniGPT4Context *minigpt4_model_load(const char *path, const char *llm_mo
     return reinterpret_cast<MiniGPT4Context *>(eng);
 }
 
-int minigpt4_image_load_from_file(struct MiniGPT4Context *, const char *, struct MiniGPT4Image *, int) { return E_OpenCVNotLinked; }
-int minigpt4_preprocess_image(struct MiniGPT4Context *, const struct MiniGPT4Image *, struct MiniGPT4Image *, int) { return E_OpenCVNotLinked; }
+// Native replacement of the reference's OpenCV-only path (minigpt4.cpp:2576-2595: cv::imread(IMREAD_COLOR) + BGR->RGB, U8 HWC).  Host work, like imread.
+int minigpt4_image_load_from_file(struct MiniGPT4Context *, const char *path, struct MiniGPT4Image *image, int /*flags*/) {
+    if (!image) return E_OpenImage;
+    return guarded((int)E_OpenImage, [&]() -> int {
+        ImageRGB8 im;
+        if (int err = load_image_file(path, im)) { MG4_ERR("%s", last_error().c_str()); return err; }
+        uint8_t *data = new uint8_t[im.px.size()];
+        memcpy(data, im.px.data(), im.px.size());
+        image->data = data; image->width = im.w; image->height = im.h; image->channels = 3; image->format = MINIGPT4_IMAGE_FORMAT_U8;
+        return E_None;
+    });
+}
+
+// minigpt4.cpp:2597-2651 (OpenCV build): Pillow-bicubic resize to 224x224, 1/255, CLIP mean/std, HWC -> CHW -- as HIP kernels (image_kernels.hip).
+// Output geometry is the reference's: after its split/reshape/hconcat the matrix is 1 x 150528 single-channel, reported as width = rows = 1,
+// height = cols = 150528, channels = 1 (:2639-2641); minigpt4_encode_image only checks the product (:2130).
+int minigpt4_preprocess_image(struct MiniGPT4Context *ctx, const struct MiniGPT4Image *image, struct MiniGPT4Image *preprocessed_image, int /*flags*/) {
+    if (!image || !preprocessed_image || !image->data) return E_ImageSize;
+    if (image->channels != 3) { MG4_ERR("Image must have 3 channels"); return E_ImageChannelsExpectedRGB; }
+    if (image->format != MINIGPT4_IMAGE_FORMAT_U8) { MG4_ERR("Image must be in U8 format"); return E_ImageFormatExpectedU8; }
+    if (image->width <= 0 || image->height <= 0 || image->width > 65535 || image->height > 65535) return E_ImageSize;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device visible: image preprocessing runs on the GPU and has no CPU fallback"); MG4_ERR("%s", last_error().c_str()); return E_ImageSize; }
+    return guarded((int)E_ImageSize, [&]() -> int {
+        const size_t n = (size_t)3 * 224 * 224;
+        float *out = reinterpret_cast<float *>(new uint8_t[n * sizeof(float)]);   // released by minigpt4_free_image (delete[] of a byte array)
+        try { preprocess_image_device(ctx ? E_(ctx)->stream() : nullptr, static_cast<const uint8_t *>(image->data), image->width, image->height, out); }
+        catch (...) { delete[] reinterpret_cast<uint8_t *>(out); throw; }
+        preprocessed_image->data = out; preprocessed_image->width = 1; preprocessed_image->height = (int)n; preprocessed_image->channels = 1;
+        preprocessed_image->format = MINIGPT4_IMAGE_FORMAT_F32;
+        return E_None;
+    });
+}
 
 int minigpt4_encode_image(struct MiniGPT4Context *ctx, struct MiniGPT4Image *image, struct MiniGPT4Embedding *embedding, size_t /*n_threads*/) {
     if (!ctx || !image || !embedding) return E_ImageSize;
@@ -406,6 +437,25 @@ int minigpt4_amd_inspect_files(const char *vision_path, const char *llm_path, in
         if (llm_weight_bytes_per_token) { int64_t b = 0; for (auto &t : lf.tensors) b += t.first == "tok_embeddings.weight" ? (int64_t)gt_nbytes(t.second.type, (size_t)t.second.ne[0]) : (int64_t)t.second.nbytes; *llm_weight_bytes_per_token = b; }
     }
     return E_None;
+}
+int minigpt4_amd_decode_image(const void *bytes, size_t n, struct MiniGPT4Image *image) {
+    if (!bytes || !image) return E_OpenImage;
+    ImageRGB8 im; std::string err;
+    if (!decode_image(static_cast<const uint8_t *>(bytes), n, im, err)) { set_last_error(err); return E_OpenImage; }
+    uint8_t *data = new (std::nothrow) uint8_t[im.px.size()];
+    if (!data) return E_OpenImage;
+    memcpy(data, im.px.data(), im.px.size());
+    image->data = data; image->width = im.w; image->height = im.h; image->channels = 3; image->format = MINIGPT4_IMAGE_FORMAT_U8;
+    return E_None;
+}
+int minigpt4_amd_resample_coeffs(int in_size, int out_size, int *ksize, int *first, int *count, int *kk, size_t kk_cap) {
+    if (in_size <= 0 || out_size <= 0 || in_size > (1 << 24) || out_size > (1 << 16)) return -1;
+    ResampleCoeffs c; precompute_bicubic_8bpc(in_size, out_size, c);
+    if (ksize) *ksize = c.ksize;
+    if (first) memcpy(first, c.first.data(), (size_t)out_size * 4);
+    if (count) memcpy(count, c.count.data(), (size_t)out_size * 4);
+    if (kk) { if (kk_cap < c.kk.size()) return -2; memcpy(kk, c.kk.data(), c.kk.size() * 4); }
+    return 0;
 }
 int minigpt4_amd_sample_logits(const float *logits, int n_vocab, int seed, float temp, int32_t top_k, float top_p, float tfs_z, float typical_p, int mirostat, float mirostat_tau, float mirostat_eta) {
     if (!logits || n_vocab <= 0) return -1;

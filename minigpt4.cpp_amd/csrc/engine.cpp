@@ -1,4 +1,5 @@
 #include "engine.hpp"
+#include "imageio.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -31,6 +32,37 @@ template <typename T> T *Engine::upload_raw(DeviceArena &a, const void *src, siz
     uint8_t *d = a.take(bytes);
     HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
     return reinterpret_cast<T *>(d);
+}
+
+// ====================================================================================================================
+// image preprocess (standalone: needs a device, not a loaded model)
+// ====================================================================================================================
+void preprocess_image_device(hipStream_t s, const uint8_t *rgb, int w, int h, float *out_chw) {
+    constexpr int OUT = 224;                                                   // IMAGE_RESIZE (reference minigpt4.cpp:2620)
+    const float mean[3] = {(float)0.48145466, (float)0.4578275, (float)0.40821073}, sd[3] = {(float)0.26862954, (float)0.26130258, (float)0.27577711};   // :2621-2622
+    // Pillow skips a pass that keeps the size; an identity table (one tap of 2^22) is the same thing: (2^21 + p * 2^22) >> 22 == p
+    auto table = [&](int in, ResampleCoeffs &c) {
+        if (in != OUT) { precompute_bicubic_8bpc(in, OUT, c); return; }
+        c.in_size = c.out_size = OUT; c.ksize = 1; c.first.resize(OUT); c.count.assign(OUT, 1); c.kk.assign(OUT, 1 << 22);
+        for (int i = 0; i < OUT; i++) c.first[(size_t)i] = i;
+    };
+    ResampleCoeffs ch, cv;
+    table(w, ch); table(h, cv);
+    struct Dev { void *p = nullptr; ~Dev() { if (p) (void)hipFree(p); } };
+    Dev d_src, d_tmp, d_out, d_tab;
+    const size_t src_bytes = (size_t)w * h * 3, tmp_bytes = (size_t)h * OUT * 3, out_bytes = (size_t)3 * OUT * OUT * 4;
+    std::vector<int> tab;                                                      // [first_h | count_h | kk_h | first_v | count_v | kk_v]
+    tab.insert(tab.end(), ch.first.begin(), ch.first.end()); tab.insert(tab.end(), ch.count.begin(), ch.count.end()); tab.insert(tab.end(), ch.kk.begin(), ch.kk.end());
+    const size_t voff = tab.size();
+    tab.insert(tab.end(), cv.first.begin(), cv.first.end()); tab.insert(tab.end(), cv.count.begin(), cv.count.end()); tab.insert(tab.end(), cv.kk.begin(), cv.kk.end());
+    HIP_CHECK(hipMalloc(&d_src.p, src_bytes)); HIP_CHECK(hipMalloc(&d_tmp.p, tmp_bytes)); HIP_CHECK(hipMalloc(&d_out.p, out_bytes)); HIP_CHECK(hipMalloc(&d_tab.p, tab.size() * 4));
+    HIP_CHECK(hipMemcpyAsync(d_src.p, rgb, src_bytes, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
+    const int *t = static_cast<const int *>(d_tab.p);
+    launch_resample_h(static_cast<const uint8_t *>(d_src.p), w, h, t, t + OUT, t + 2 * OUT, ch.ksize, static_cast<uint8_t *>(d_tmp.p), OUT, s);
+    launch_resample_v_norm(static_cast<const uint8_t *>(d_tmp.p), OUT, t + voff, t + voff + OUT, t + voff + 2 * OUT, cv.ksize, static_cast<float *>(d_out.p), OUT, mean, sd, s);
+    HIP_CHECK(hipMemcpyAsync(out_chw, d_out.p, out_bytes, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
 }
 
 Engine::~Engine() {

@@ -44,6 +44,7 @@ public:
     const char *id_to_token(int id) const;            // minigpt4.cpp:2485-2497 (borrowed pointer)
     void reset() { pend_tok_.clear(); pend_embd_.clear(); n_past_ = 0; n_committed_ = 0; }   // minigpt4.cpp:2499-2502
     void sync();
+    hipStream_t stream() const { return stream_; }
 
     int n_vocab() const { return (int)llm_.n_vocab; }
     int n_embd() const { return (int)llm_.n_embd; }
@@ -132,5 +133,9 @@ private:
 };
 
 int device_count_noexcept();
+
+// minigpt4_preprocess_image on the device (reference minigpt4.cpp:2597-2651): u8 HWC RGB of any size -> f32 [3][224][224], Pillow-bicubic resized and
+// CLIP-normalised.  Host buffers in and out; the resample + normalisation run as HIP kernels on `s`.  Throws HipError.
+void preprocess_image_device(hipStream_t s, const uint8_t *rgb, int w, int h, float *out_chw);
 
 }  // namespace mg4

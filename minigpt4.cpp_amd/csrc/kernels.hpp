@@ -83,4 +83,11 @@ void launch_im2col(const float *image, __half *patches, int ldp, hipStream_t s);
 void launch_assemble_embeddings(const float *cls, const float *pe, const float *pos, int D, float *x, hipStream_t s);
 void launch_f32_to_f16(const float *x, __half *y, size_t n, hipStream_t s);
 
+// ---- image preprocess (image_kernels.hip): Pillow's 8-bit bicubic resample, horizontal then vertical pass, all pointers device ---------------
+// dst[y][xx][c] = clip8(2^21 + sum_i src[y][first[xx] + i][c] * kk[xx * ksize + i] >> 22); src [H][W][3], dst [H][OW][3]
+void launch_resample_h(const uint8_t *src, int W, int H, const int *first, const int *count, const int *kk, int ksize, uint8_t *dst, int OW, hipStream_t s);
+// vertical pass over src [*][OW][3] fused with x * (1/255), (x - mean) / std and HWC -> CHW: out [3][OH][OW] f32
+void launch_resample_v_norm(const uint8_t *src, int OW, const int *first, const int *count, const int *kk, int ksize, float *out, int OH, const float mean[3], const float std[3],
+                            hipStream_t s);
+
 }  // namespace mg4
