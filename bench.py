@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--config", default=os.environ.get("MG4_BENCH_CONFIG", "13b"), choices=["13b", "7b", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n-ctx", type=int, default=0, help="context size; default: 2048 or whatever --steps needs")
+    ap.add_argument("--conversations", type=int, default=4, help="extra leg: batched decode of this many conversations per GPU in one weight pass (BASELINE.json configs[3] "
+                    "has 4 requests per replica); reported as `batched_decode`, never as `value`.  0/1 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -256,6 +258,28 @@ def main():
         "model_load_s": load_s, "weight_bcast_ms": bcast_ms,
         "roofline": roofline,
     }
+    # ---- extra leg (not the headline): B conversations per replica decoded in ONE weight pass per step (include/minigpt4_amd.h)
+    if args.conversations > 1:
+        try:
+            B, KB = args.conversations, 64
+            lib.amd_set_conversations(ctx, B)                      # reallocates the KV caches: after every other measurement
+            for sl in range(B):
+                lib.amd_select_conversation(ctx, sl)
+                lib.minigpt4_system_prompt(ctx)
+                lib.minigpt4_begin_chat_image(ctx, emb, PROMPT)
+            lib.amd_select_conversation(ctx, 0)
+            for _ in range(4):                                     # the first step also runs the B prefills
+                lib.amd_end_chat_batch(ctx, list(range(B)), temp=0.0)
+            lib.library.minigpt4_amd_sync(ctx.ptr)
+            t0 = time.perf_counter()
+            for _ in range(KB):
+                lib.amd_end_chat_batch(ctx, list(range(B)), temp=0.0)
+            lib.library.minigpt4_amd_sync(ctx.ptr)
+            dtb = time.perf_counter() - t0
+            out["batched_decode"] = {"conversations_per_gpu": B, "steps": KB, "tokens_per_s_per_gpu": B * KB / dtb, "ms_per_step": dtb * 1e3 / KB,
+                                     "weight_GBps": wbytes * KB / dtb / 1e9, "note": "eager launches (no hipGraph yet); every conversation has its own KV cache and position"}
+        except Exception as e:   # never lose the headline line to the extra leg
+            out["batched_decode"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             toks = lib.amd_tokenize(ctx, PROMPT.encode())

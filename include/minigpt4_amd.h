@@ -47,6 +47,19 @@ MINIGPT4_API int minigpt4_amd_sync(struct MiniGPT4Context *ctx);
 MINIGPT4_API int minigpt4_encode_images(struct MiniGPT4Context *ctx, IN const struct MiniGPT4Images *images, OUT struct MiniGPT4Embeddings *embeddings, size_t n_threads);
 MINIGPT4_API int minigpt4_free_embeddings(struct MiniGPT4Embeddings *embeddings);
 
+/* ---- several conversations per context: batched decode ---------------------------------------------------------
+ * The reference keeps ONE conversation per context (minigpt4.cpp:2513-2521).  Here a context can own n of them -- each with its own fp16 KV cache region,
+ * position and prompt queue, all sharing one copy of the weights.  Every reference entry point (minigpt4_system_prompt, minigpt4_begin_chat(_image),
+ * minigpt4_end_chat(_image), minigpt4_reset_chat) acts on the SELECTED conversation (0 after load), so existing callers see no change. */
+MINIGPT4_API int minigpt4_amd_set_conversations(struct MiniGPT4Context *ctx, int n);        /* 1..64; reallocates the KV caches and resets every conversation; 0 / 1 */
+MINIGPT4_API int minigpt4_amd_select_conversation(struct MiniGPT4Context *ctx, int slot);   /* 0 / 1 (out of range) */
+MINIGPT4_API int minigpt4_amd_n_conversations(struct MiniGPT4Context *ctx);
+/* One minigpt4_end_chat step for n DISTINCT conversations at once: each is sampled with the given parameters (temp <= 0: greedy) and the n sampled tokens are
+ * evaluated in ONE pass over the weights.  tokens[i]: borrowed piece for slots[i], as minigpt4_end_chat returns it.  A conversation whose context is full is
+ * sampled but not advanced.  0, or 1 on bad arguments / device error. */
+MINIGPT4_API int minigpt4_amd_end_chat_batch(struct MiniGPT4Context *ctx, const int32_t *slots, int n, const char **tokens, float temp, int32_t top_k, float top_p, float tfs_z,
+                                             float typical_p, int mirostat, float mirostat_tau, float mirostat_eta);
+
 /* ---- weight arenas (load-time broadcast rank0 -> others over RCCL) ---------------------------- */
 /* which: 0 = LLM arena, 1 = vision arena.  Returns the device pointer and size in bytes. */
 MINIGPT4_API int minigpt4_amd_weight_arena(struct MiniGPT4Context *ctx, int which, void **device_ptr, size_t *bytes);

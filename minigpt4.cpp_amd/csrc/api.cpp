@@ -229,6 +229,25 @@ int minigpt4_free_embeddings(struct MiniGPT4Embeddings *embeddings) {
     delete[] embeddings->embeddings; embeddings->embeddings = nullptr; embeddings->n_embeddings = 0;
     return E_None;
 }
+// ---- several conversations per context ---------------------------------------------------------------------------
+int minigpt4_amd_set_conversations(struct MiniGPT4Context *ctx, int n) {
+    if (!ctx) return 1;
+    return guarded(1, [&] { return E_(ctx)->set_conversations(n); });
+}
+int minigpt4_amd_select_conversation(struct MiniGPT4Context *ctx, int slot) { return ctx ? E_(ctx)->select_conversation(slot) : 1; }
+int minigpt4_amd_n_conversations(struct MiniGPT4Context *ctx) { return ctx ? E_(ctx)->n_conversations() : 0; }
+int minigpt4_amd_end_chat_batch(struct MiniGPT4Context *ctx, const int32_t *slots, int n, const char **tokens, float temp, int32_t top_k, float top_p, float tfs_z, float typical_p,
+                                int mirostat, float mirostat_tau, float mirostat_eta) {
+    if (!ctx || !slots || !tokens || n < 1 || n > Engine::MAX_CONVERSATIONS) return 1;
+    Engine *e = E_(ctx);
+    return guarded(1, [&]() -> int {
+        SampleParams p; p.temp = temp; p.top_k = top_k; p.top_p = top_p; p.tfs_z = tfs_z; p.typical_p = typical_p; p.mirostat = mirostat; p.mirostat_tau = mirostat_tau; p.mirostat_eta = mirostat_eta;
+        int ids[Engine::MAX_CONVERSATIONS];
+        if (int rc = e->decode_batch(slots, n, p, ids)) return rc;
+        for (int i = 0; i < n; i++) tokens[i] = e->id_to_token(ids[i]);
+        return 0;
+    });
+}
 int minigpt4_amd_weight_arena(struct MiniGPT4Context *ctx, int which, void **device_ptr, size_t *bytes) {
     if (!ctx || !device_ptr || !bytes) return 1;
     Engine *e = E_(ctx);

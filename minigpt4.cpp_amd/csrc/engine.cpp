@@ -65,13 +65,19 @@ void preprocess_image_device(hipStream_t s, const uint8_t *rgb, int w, int h, fl
     HIP_CHECK(hipStreamSynchronize(s));
 }
 
+void Engine::release_buffers() {
+    for (Conversation &c : conv_) { if (c.graph) (void)hipGraphExecDestroy(c.graph); c.graph = nullptr; }
+    if (h_argmax_) (void)hipHostFree(h_argmax_);
+    if (h_bstage_) (void)hipHostFree(h_bstage_);
+    if (h_logits_) (void)hipHostFree(h_logits_);
+    h_argmax_ = nullptr; h_bstage_ = nullptr; h_logits_ = nullptr; logits_host_slot_ = -1;
+    buf_arena_.release();
+}
 Engine::~Engine() {
     if (stream_) (void)hipStreamSynchronize(stream_);
-    if (decode_graph_) (void)hipGraphExecDestroy(decode_graph_);
     for (auto &e : prof_events_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (stage_) (void)hipFree(stage_);
-    if (h_argmax_) (void)hipHostFree(h_argmax_);
-    if (h_logits_) (void)hipHostFree(h_logits_);
+    release_buffers();
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 void Engine::sync() { (void)flush(); HIP_CHECK(hipStreamSynchronize(stream_)); }
@@ -106,6 +112,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
     if (const char *sk = getenv("MINIGPT4_SPLITK")) { sscanf(sk, "%d,%d", &splitk_proj_, &splitk_fc2_); splitk_proj_ = std::max(1, std::min(SPLITK_MAX, splitk_proj_)); splitk_fc2_ = std::max(1, std::min(SPLITK_MAX, splitk_fc2_)); }
     set_matvec_tuning(getenv("MINIGPT4_MV_WAVES") ? atoi(getenv("MINIGPT4_MV_WAVES")) : 0, getenv("MINIGPT4_FAT_LB") ? atoi(getenv("MINIGPT4_FAT_LB")) : 0, prop.multiProcessorCount);
+    if (const char *ns = getenv("MINIGPT4_CONVERSATIONS")) conv_.assign((size_t)std::max(1, std::min(MAX_CONVERSATIONS, atoi(ns))), Conversation{});
     sampler_.seed(seed);
     auto t0 = std::chrono::steady_clock::now();
     if (int e = load_llm(llm_path)) return e;
@@ -326,13 +333,15 @@ int Engine::load_vision(const std::string &path) {
 }
 
 void Engine::alloc_buffers() {
+    const size_t S = conv_.size();
+    max_rows_ = std::max(std::max(n_batch_, 32), (int)S);
     const size_t E = llm_.n_embd, F = llm_.n_ff(), V = llm_.n_vocab, L = llm_.n_layer, B = (size_t)max_rows_, C = (size_t)n_ctx_;
     const size_t Kmax = std::max(E, F), hd = E / llm_.n_head;
     const size_t D = (size_t)v_D_, M = (size_t)v_M_, NQ = (size_t)v_nq_;
     size_t total = 0;
     auto sz = [&](size_t b) { total += (b + 255) / 256 * 256 + 256; };
-    sz(2 * L * C * E * 2); sz(2 * C * (hd / 2) * 4 * 2); sz(3 * 65536 * 2);
-    sz(5 * B * E * 4); sz(2 * B * F * 4); sz(V * 4);
+    sz(S * L * C * E * 2); sz(S * L * C * E * 2); sz(2 * C * (hd / 2) * 4 * 2); sz(3 * 65536 * 2);
+    sz(5 * B * E * 4); sz(2 * B * F * 4); sz(S * V * 4); sz(S * V * 4); sz(8 * 256 + 2 * B * 4);
     sz(2 * B * Kmax); sz(B * Kmax / 256 * 4 + 64); sz(B * Kmax / 16 * 2 + 64); sz(4 * (B * Kmax / 32 * 4 + 64)); sz(B * Kmax * 2); sz(B * Kmax * 4);
     sz(4096);
     sz(3 * 224 * 224 * 4); sz(256 * 592 * 2); sz(256 * D * 4); sz(257 * D * 4); sz(257 * 3 * D * 4); sz(3 * 257 * D * 2); sz(257 * M * 2); sz((size_t)SPLITK_MAX * 257 * D * 4);
@@ -340,8 +349,8 @@ void Engine::alloc_buffers() {
     buf_arena_.alloc(total);
     auto takef = [&](size_t n) { return reinterpret_cast<float *>(buf_arena_.take(n * 4)); };
     auto takeh = [&](size_t n) { return reinterpret_cast<__half *>(buf_arena_.take(n * 2)); };
-    kc_ = takeh(L * C * E); vc_ = takeh(L * C * E);
-    HIP_CHECK(hipMemset(kc_, 0, L * C * E * 2)); HIP_CHECK(hipMemset(vc_, 0, L * C * E * 2));
+    kc_ = takeh(S * L * C * E); vc_ = takeh(S * L * C * E);                // [conversation][layer][n_ctx][n_embd]
+    HIP_CHECK(hipMemset(kc_, 0, S * L * C * E * 2)); HIP_CHECK(hipMemset(vc_, 0, S * L * C * E * 2));
     // RoPE table, exactly ggml's iteration: theta = pos; theta *= theta_scale per pair (fp32), cosf/sinf
     {
         std::vector<float> c(C * (hd / 2)), s(C * (hd / 2));
@@ -364,18 +373,23 @@ void Engine::alloc_buffers() {
         tabs_.gelu = dg; tabs_.silu = ds; tabs_.exp = de;
     }
     x_ = takef(B * E); q_ = takef(B * E); k_ = takef(B * E); v_ = takef(B * E); att_ = takef(B * E);
-    h1_ = takef(B * F); h3_ = takef(B * F); logits_ = takef(V);
+    h1_ = takef(B * F); h3_ = takef(B * F); logits_ = takef(S * V); blogits_ = takef(S * V);
     act_.q8k = reinterpret_cast<int8_t *>(buf_arena_.take(B * Kmax)); act_.q80 = reinterpret_cast<int8_t *>(buf_arena_.take(B * Kmax));
     act_.dk = takef(B * Kmax / 256 + 16); act_.bsk = reinterpret_cast<int16_t *>(buf_arena_.take(B * Kmax / 16 * 2 + 64));
     act_.d0 = takef(B * Kmax / 32 + 16); act_.d1 = takef(B * Kmax / 32 + 16); act_.s1 = takef(B * Kmax / 32 + 16);
     act_.sum0 = reinterpret_cast<int *>(buf_arena_.take(B * Kmax / 32 * 4 + 64));
     act_.xh = takeh(B * Kmax); act_.xf = takef(B * Kmax);
-    d_npast_ = reinterpret_cast<int *>(buf_arena_.take(256)); d_argmax_ = reinterpret_cast<int *>(buf_arena_.take(256));
+    static_assert(MAX_CONVERSATIONS * 4 <= 256, "per-conversation scalars live in 256-byte slabs");
+    d_npast_ = reinterpret_cast<int *>(buf_arena_.take(256)); d_argmax_ = reinterpret_cast<int *>(buf_arena_.take(256)); d_feed_ = reinterpret_cast<int *>(buf_arena_.take(256));
+    d_btok_ = reinterpret_cast<int *>(buf_arena_.take(256)); d_bslot_ = reinterpret_cast<int *>(buf_arena_.take(256));
     d_tokens_ = reinterpret_cast<int *>(buf_arena_.take(B * 4));
     d_scratch_ = buf_arena_.take(4096);
-    HIP_CHECK(hipMemset(d_npast_, 0, 4)); HIP_CHECK(hipMemset(d_argmax_, 0, 4)); HIP_CHECK(hipMemset(d_tokens_, 0, B * 4));
-    HIP_CHECK(hipHostMalloc((void **)&h_argmax_, 64, hipHostMallocDefault));
+    HIP_CHECK(hipMemset(d_npast_, 0, 256)); HIP_CHECK(hipMemset(d_argmax_, 0, 256)); HIP_CHECK(hipMemset(d_feed_, 0, 256)); HIP_CHECK(hipMemset(d_btok_, 0, 256));
+    HIP_CHECK(hipMemset(d_bslot_, 0, 256)); HIP_CHECK(hipMemset(d_tokens_, 0, B * 4));
+    HIP_CHECK(hipHostMalloc((void **)&h_argmax_, 256, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&h_bstage_, 512, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **)&h_logits_, V * 4, hipHostMallocDefault));
+    memset(h_argmax_, 0, 256);
     // vision
     vi_img_ = takef(3 * 224 * 224); vi_patches_ = takeh(256 * 592); vi_pe_ = takef(256 * D); vi_x_ = takef(257 * D); vi_qkv_ = takef(257 * 3 * D);
     vi_slab_ = takef((size_t)SPLITK_MAX * 257 * D);
@@ -383,7 +397,7 @@ void Engine::alloc_buffers() {
     vi_hs_ = takef(NQ * 768); vi_a1_ = takef(NQ * 768); vi_a2_ = takef(NQ * 768); vi_d_ = takef(NQ * 768); vi_qq_ = takef(NQ * 2304); vi_kv_ = takef(257 * 1536);
     vi_hs_h_ = takeh(NQ * 768); vi_a1_h_ = takeh(NQ * 768); vi_a2_h_ = takeh(NQ * 768); vi_ctx_h_ = takeh(NQ * 768); vi_im_h_ = takeh(NQ * (size_t)v_qi_);
     vi_out_ = takef(NQ * (size_t)v_out_);
-    MG4_INFO("KV cache %.1f MB (fp16, n_ctx %d), activation arena %.1f MB", 2.0 * L * C * E * 2 / 1048576.0, n_ctx_, buf_arena_.used / 1048576.0);
+    MG4_INFO("KV cache %.1f MB (fp16, n_ctx %d, %zu conversation%s), activation arena %.1f MB", 2.0 * S * L * C * E * 2 / 1048576.0, n_ctx_, S, S == 1 ? "" : "s", buf_arena_.used / 1048576.0);
 }
 
 // ====================================================================================================================
@@ -450,13 +464,15 @@ bool Engine::mixed_qkv(const LayerW &L, hipStream_t s, bool fuse) {
 // Enqueue one forward pass for N rows already described by d_tokens_ (from_tokens) or x_ (embeddings), at position *d_npast_.
 void Engine::forward(int N, bool from_tokens, hipStream_t s) {
     const int E = (int)llm_.n_embd, F = (int)llm_.n_ff(), H = (int)llm_.n_head, hd = E / H, V = (int)llm_.n_vocab;
-    const size_t C = (size_t)n_ctx_;
-    if (from_tokens) launch_get_rows(tok_type_, tok_raw_, E, d_tokens_, N, x_, s);
+    const size_t C = (size_t)n_ctx_, sl = (size_t)cur_;                     // everything below addresses the selected conversation's cache / scalars
+    int *const d_npast = d_npast_ + sl, *const d_argmax = d_argmax_ + sl, *const d_feed = d_feed_ + sl;
+    float *const logits = logits_ + sl * (size_t)V;
     const bool dec = N == 1;
+    if (from_tokens) launch_get_rows(tok_type_, tok_raw_, E, dec ? d_feed : d_tokens_, N, x_, s);
     auto fz = [&](int bit) { return dec && (fuse_mask_ >> bit & 1); };
     for (size_t il = 0; il < layers_.size(); il++) {
         const LayerW &L = layers_[il];
-        __half *kc = kc_ + il * C * E, *vc = vc_ + il * C * E;
+        __half *kc = kc_ + (sl * layers_.size() + il) * C * E, *vc = vc_ + (sl * layers_.size() + il) * C * E;
         const Prep p_attn{1, x_, L.attn_norm}, p_att{2, att_, nullptr}, p_ffn{1, x_, L.ffn_norm}, p_silu{3, h1_, h3_};
         {
             const QWeight *W3[3] = {&L.wq, &L.wk, &L.wv}; float *Y3[3] = {q_, k_, v_};
@@ -467,8 +483,8 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s) {
                 mul_mat_set(W3, Y3, nullptr, 2, N, E, s, nullptr, false); mul_mat(L.wv, N, v_, E, nullptr, s, nullptr, false);
             } else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s, &p_attn, fz(0)); mul_mat(L.wv, N, v_, E, nullptr, s, &p_attn, fz(0)); }
         }
-        if (dec) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast_, n_ctx_, cos_, sin_, tabs_, att_, true, s);
-        else { launch_rope_kv(q_, k_, v_, N, H, hd, d_npast_, cos_, sin_, kc, vc, s); launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast_, n_ctx_, cos_, sin_, tabs_, att_, false, s); }
+        if (dec) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, true, s);
+        else { launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, false, s); }
         mul_mat(L.wo, N, x_, E, x_, s, &p_att, fz(1));
         bool paired = false;   // h1_ already holds silu(w1 x) * (w3 x)
         if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5)); }
@@ -481,30 +497,56 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s) {
     }
     // only the last token's logits are kept (llama.cpp logits_all = false)
     const Prep p_out{1, x_ + (size_t)(N - 1) * E, norm_};
-    mul_mat(output_, 1, logits_, V, nullptr, s, &p_out, fz(4));
-    launch_argmax(logits_, V, d_argmax_, d_scratch_, s);
-    launch_advance(d_npast_, N, d_tokens_, d_argmax_, s);
-    HIP_CHECK(hipMemcpyAsync(h_argmax_, d_argmax_, 4, hipMemcpyDeviceToHost, s));
+    mul_mat(output_, 1, logits, V, nullptr, s, &p_out, fz(4));
+    launch_argmax(logits, V, d_argmax, d_scratch_, s);
+    launch_advance(d_npast, N, d_feed, d_argmax, s);
+    HIP_CHECK(hipMemcpyAsync(h_argmax_ + sl, d_argmax, 4, hipMemcpyDeviceToHost, s));
 }
 
-// Evaluate one chunk of N rows at position n_committed_.  row_tok[i] >= 0: token id; -1: the next packed embedding row of `embd`.
+// One decode step for B conversations at once: row r carries token d_btok_[r] of conversation d_bslot_[r].  The weights are streamed once for the B rows
+// (k_mul_mat's 4-token tiles up to B = 4, the int8-MFMA kernels from B = 5); attention runs per row against its conversation's cache.  Same arithmetic per
+// row as forward(1): per-row activation quantisation, exact integer block dots, the same attention kernel body.
+void Engine::forward_batch(int B, hipStream_t s) {
+    const int E = (int)llm_.n_embd, F = (int)llm_.n_ff(), H = (int)llm_.n_head, hd = E / H, V = (int)llm_.n_vocab;
+    const size_t C = (size_t)n_ctx_, seq_stride = layers_.size() * C * (size_t)E;
+    launch_get_rows(tok_type_, tok_raw_, E, d_btok_, B, x_, s);
+    for (size_t il = 0; il < layers_.size(); il++) {
+        const LayerW &L = layers_[il];
+        __half *kc = kc_ + il * C * E, *vc = vc_ + il * C * E;            // conversation 0's layer; the kernel adds slot * seq_stride
+        launch_rms_quant(x_, L.attn_norm, B, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s);
+        launch_mul_mat(L.wq, act_, B, q_, E, nullptr, s); launch_mul_mat(L.wk, act_, B, k_, E, nullptr, s); launch_mul_mat(L.wv, act_, B, v_, E, nullptr, s);
+        launch_attn_llm_batched(q_, k_, v_, kc, vc, B, H, hd, d_npast_, d_bslot_, seq_stride, n_ctx_, cos_, sin_, tabs_, att_, s);
+        launch_silu_mul_quant(att_, nullptr, B, E, act_, act_mask_for(L.wo.type), tabs_, s);
+        launch_mul_mat(L.wo, act_, B, x_, E, x_, s);
+        launch_rms_quant(x_, L.ffn_norm, B, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s);
+        launch_mul_mat(L.w1, act_, B, h1_, F, nullptr, s); launch_mul_mat(L.w3, act_, B, h3_, F, nullptr, s);
+        launch_silu_mul_quant(h1_, h3_, B, F, act_, act_mask_for(L.w2.type), tabs_, s);
+        launch_mul_mat(L.w2, act_, B, x_, E, x_, s);
+    }
+    launch_rms_quant(x_, norm_, B, E, act_, act_mask_for(output_.type), s);
+    launch_mul_mat(output_, act_, B, blogits_, V, nullptr, s);
+    launch_batch_finish(blogits_, V, B, d_bslot_, d_npast_, d_argmax_, d_feed_, s);
+}
+
+// Evaluate one chunk of N rows of the selected conversation at its position n_committed.  row_tok[i] >= 0: token id; -1: the next packed embedding row of `embd`.
 int Engine::eval_chunk(const int *row_tok, int N, const float *embd) {
     if (N <= 0) return 0;
     const int E = (int)llm_.n_embd;
-    logits_host_valid_ = false;
-    launch_set_int(d_npast_, n_committed_, stream_);
+    Conversation &cv = conv_[(size_t)cur_];
+    if (logits_host_slot_ == cur_) logits_host_slot_ = -1;
+    launch_set_int(d_npast_ + cur_, cv.n_committed, stream_);
     if (N == 1 && row_tok[0] >= 0) {
-        launch_set_int(d_tokens_, row_tok[0], stream_);
+        launch_set_int(d_feed_ + cur_, row_tok[0], stream_);
         if (use_graph_ && !prof_on_) {
-            if (!decode_graph_) {
+            if (!cv.graph) {
                 hipGraph_t g = nullptr;
                 HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
                 forward(1, true, stream_);
                 HIP_CHECK(hipStreamEndCapture(stream_, &g));
-                HIP_CHECK(hipGraphInstantiate(&decode_graph_, g, nullptr, nullptr, 0));
+                HIP_CHECK(hipGraphInstantiate(&cv.graph, g, nullptr, nullptr, 0));
                 HIP_CHECK(hipGraphDestroy(g));
             }
-            HIP_CHECK(hipGraphLaunch(decode_graph_, stream_));
+            HIP_CHECK(hipGraphLaunch(cv.graph, stream_));
         } else {
             forward(1, true, stream_);
         }
@@ -520,7 +562,7 @@ int Engine::eval_chunk(const int *row_tok, int N, const float *embd) {
         HIP_CHECK(hipStreamSynchronize(stream_));   // the (pageable) staging vectors may be reused right after this call
         forward(N, true, stream_);                   // k_get_rows skips rows whose id is negative
     }
-    n_committed_ += N;
+    cv.n_committed += N;
     return 0;
 }
 
@@ -529,49 +571,52 @@ int Engine::eval_chunk(const int *row_tok, int N, const float *embd) {
 // depend on how they are batched (causal attention, per-row quantisation), so fragments are queued and evaluated in one pass when logits are
 // needed (sampling) -- the weights are streamed once.  Context overflow is still reported by the call that would overflow.
 int Engine::flush() {
-    if (pend_tok_.empty()) return 0;
+    Conversation &cv = conv_[(size_t)cur_];
+    if (cv.pend_tok.empty()) return 0;
     const int E = (int)llm_.n_embd;
     size_t er = 0;
-    for (size_t i = 0; i < pend_tok_.size(); i += (size_t)max_chunk_) {
-        const int n = (int)std::min((size_t)max_chunk_, pend_tok_.size() - i);
-        size_t ne = 0; for (int k = 0; k < n; k++) ne += pend_tok_[i + k] < 0;
-        const int rc = eval_chunk(pend_tok_.data() + i, n, pend_embd_.data() + er * E);
+    for (size_t i = 0; i < cv.pend_tok.size(); i += (size_t)max_chunk_) {
+        const int n = (int)std::min((size_t)max_chunk_, cv.pend_tok.size() - i);
+        size_t ne = 0; for (int k = 0; k < n; k++) ne += cv.pend_tok[i + k] < 0;
+        const int rc = eval_chunk(cv.pend_tok.data() + i, n, cv.pend_embd.data() + er * E);
         er += ne;
-        if (rc) { pend_tok_.clear(); pend_embd_.clear(); n_past_ = n_committed_; return rc; }
+        if (rc) { cv.pend_tok.clear(); cv.pend_embd.clear(); cv.n_past = cv.n_committed; return rc; }
     }
-    pend_tok_.clear(); pend_embd_.clear();
+    cv.pend_tok.clear(); cv.pend_embd.clear();
     return 0;
 }
 
 int Engine::add_tokens(const std::vector<int> &tokens, bool flush_now) {
-    if (n_past_ + (int)tokens.size() > n_ctx_) { set_last_error("context overflow: n_past + n_tokens > n_ctx"); MG4_ERR("Failed to add string"); return E_FailedToAddString; }
+    Conversation &cv = conv_[(size_t)cur_];
+    if (cv.n_past + (int)tokens.size() > n_ctx_) { set_last_error("context overflow: n_past + n_tokens > n_ctx"); MG4_ERR("Failed to add string"); return E_FailedToAddString; }
     for (int t : tokens) if (t < 0 || t >= (int)llm_.n_vocab) { set_last_error("token id out of range"); MG4_ERR("Failed to add string"); return E_FailedToAddString; }
-    pend_tok_.insert(pend_tok_.end(), tokens.begin(), tokens.end());
-    n_past_ += (int)tokens.size();
+    cv.pend_tok.insert(cv.pend_tok.end(), tokens.begin(), tokens.end());
+    cv.n_past += (int)tokens.size();
     if (flush_now || !defer_) { if (flush()) return E_FailedToAddString; }
     return E_None;
 }
 int Engine::add_string(const std::string &s) { return add_tokens(tok_.tokenize(s, true)); }
 int Engine::add_embedding(const float *data, int n_rows) {
-    if (n_rows <= 0 || n_past_ + n_rows > n_ctx_) { set_last_error("context overflow: n_past + n_rows > n_ctx"); MG4_ERR("Failed to add embedding"); return E_FailedToAddEmbedding; }
-    pend_tok_.insert(pend_tok_.end(), (size_t)n_rows, -1);
-    pend_embd_.insert(pend_embd_.end(), data, data + (size_t)n_rows * llm_.n_embd);
-    n_past_ += n_rows;
+    Conversation &cv = conv_[(size_t)cur_];
+    if (n_rows <= 0 || cv.n_past + n_rows > n_ctx_) { set_last_error("context overflow: n_past + n_rows > n_ctx"); MG4_ERR("Failed to add embedding"); return E_FailedToAddEmbedding; }
+    cv.pend_tok.insert(cv.pend_tok.end(), (size_t)n_rows, -1);
+    cv.pend_embd.insert(cv.pend_embd.end(), data, data + (size_t)n_rows * llm_.n_embd);
+    cv.n_past += n_rows;
     if (!defer_) { if (flush()) return E_FailedToAddEmbedding; }
     return E_None;
 }
 const float *Engine::logits_host() {
     if (flush()) throw HipError{hipErrorUnknown, "deferred evaluation failed", __FILE__, __LINE__};
-    if (!logits_host_valid_) {
-        HIP_CHECK(hipMemcpyAsync(h_logits_, logits_, (size_t)llm_.n_vocab * 4, hipMemcpyDeviceToHost, stream_));
+    if (logits_host_slot_ != cur_) {
+        HIP_CHECK(hipMemcpyAsync(h_logits_, logits_ + (size_t)cur_ * llm_.n_vocab, (size_t)llm_.n_vocab * 4, hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipStreamSynchronize(stream_));
-        logits_host_valid_ = true;
+        logits_host_slot_ = cur_;
     }
     return h_logits_;
 }
 int Engine::sample_token(const SampleParams &p) {
     if (flush()) throw HipError{hipErrorUnknown, "deferred evaluation failed", __FILE__, __LINE__};
-    if (p.temp <= 0) { HIP_CHECK(hipStreamSynchronize(stream_)); return *h_argmax_; }   // greedy: argmax computed on the device
+    if (p.temp <= 0) { HIP_CHECK(hipStreamSynchronize(stream_)); return h_argmax_[cur_]; }   // greedy: argmax computed on the device
     return sampler_.sample(logits_host(), (int)llm_.n_vocab, p);
 }
 const char *Engine::id_to_token(int id) const {
@@ -582,38 +627,40 @@ const char *Engine::id_to_token(int id) const {
 
 int Engine::decode_loop(int steps, int *tokens_out, float *ms_total) {
     if (flush()) return 1;
-    if (steps <= 0 || n_past_ + steps > n_ctx_) return 1;
+    Conversation &cv = conv_[(size_t)cur_];
+    if (steps <= 0 || cv.n_past + steps > n_ctx_) return 1;
     HIP_CHECK(hipStreamSynchronize(stream_));
-    int first = *h_argmax_;
-    if (eval_chunk(&first, 1, nullptr)) return 1;   // builds the graph if needed, d_tokens_[0] <- greedy token afterwards (k_advance)
-    n_past_ += 1;
+    int first = h_argmax_[cur_];
+    if (eval_chunk(&first, 1, nullptr)) return 1;   // builds the graph if needed, d_feed_[slot] <- greedy token afterwards (k_advance)
+    cv.n_past += 1;
     HIP_CHECK(hipStreamSynchronize(stream_));
     if (tokens_out) tokens_out[0] = first;
     hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
     HIP_CHECK(hipEventRecord(a, stream_));
     for (int i = 1; i < steps; i++) {   // step i consumes the greedy token of step i-1, left in d_tokens_[0] by k_advance
-        if (tokens_out) HIP_CHECK(hipMemcpyAsync(&tokens_out[i], d_tokens_, 4, hipMemcpyDeviceToHost, stream_));
-        if (decode_graph_ && use_graph_) HIP_CHECK(hipGraphLaunch(decode_graph_, stream_)); else forward(1, true, stream_);
+        if (tokens_out) HIP_CHECK(hipMemcpyAsync(&tokens_out[i], d_feed_ + cur_, 4, hipMemcpyDeviceToHost, stream_));
+        if (cv.graph && use_graph_) HIP_CHECK(hipGraphLaunch(cv.graph, stream_)); else forward(1, true, stream_);
     }
     HIP_CHECK(hipEventRecord(b, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
     float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
     if (ms_total) *ms_total = ms;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    n_past_ += steps - 1; n_committed_ += steps - 1;
-    logits_host_valid_ = false;
+    cv.n_past += steps - 1; cv.n_committed += steps - 1;
+    if (logits_host_slot_ == cur_) logits_host_slot_ = -1;
     return 0;
 }
 
 int Engine::profile_decode(int steps, ProfStat *by_type, ProfStat *other) {
     if (flush()) return 1;
-    if (steps <= 0 || n_past_ + steps > n_ctx_) return 1;
+    Conversation &cv = conv_[(size_t)cur_];
+    if (steps <= 0 || cv.n_past + steps > n_ctx_) return 1;
     HIP_CHECK(hipStreamSynchronize(stream_));
     prof_on_ = true;
     hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
     HIP_CHECK(hipEventRecord(a, stream_));
-    int tok = *h_argmax_;
-    for (int i = 0; i < steps; i++) { if (eval_chunk(&tok, 1, nullptr)) { prof_on_ = false; return 1; } n_past_ += 1; HIP_CHECK(hipStreamSynchronize(stream_)); tok = *h_argmax_; }
+    int tok = h_argmax_[cur_];
+    for (int i = 0; i < steps; i++) { if (eval_chunk(&tok, 1, nullptr)) { prof_on_ = false; return 1; } cv.n_past += 1; HIP_CHECK(hipStreamSynchronize(stream_)); tok = h_argmax_[cur_]; }
     HIP_CHECK(hipEventRecord(b, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
     prof_on_ = false;
@@ -626,6 +673,58 @@ int Engine::profile_decode(int steps, ProfStat *by_type, ProfStat *other) {
     float tot = 0; HIP_CHECK(hipEventElapsedTime(&tot, a, b));
     if (other) { other->ms = tot - mm_ms; other->launches = steps; other->bytes = 0; }
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return 0;
+}
+
+// ====================================================================================================================
+// several conversations per replica
+// ====================================================================================================================
+int Engine::set_conversations(int n) {
+    if (n < 1 || n > MAX_CONVERSATIONS) { set_last_error("conversation count out of range"); return 1; }
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    release_buffers();
+    conv_.assign((size_t)n, Conversation{});
+    cur_ = 0;
+    alloc_buffers();
+    return 0;
+}
+int Engine::select_conversation(int slot) {
+    if (slot < 0 || slot >= (int)conv_.size()) { set_last_error("conversation index out of range"); return 1; }
+    cur_ = slot;
+    return 0;
+}
+int Engine::decode_batch(const int *slots, int n, const SampleParams &p, int *ids_out) {
+    if (!slots || !ids_out || n < 1 || n > (int)conv_.size()) { set_last_error("decode_batch: bad slot list"); return 1; }
+    bool seen[MAX_CONVERSATIONS] = {false};
+    for (int i = 0; i < n; i++) { if (slots[i] < 0 || slots[i] >= (int)conv_.size() || seen[slots[i]]) { set_last_error("decode_batch: conversations must be distinct and in range"); return 1; } seen[slots[i]] = true; }
+    const int keep = cur_;
+    struct Restore { Engine *e; int v; ~Restore() { e->cur_ = v; } } restore{this, keep};
+    // 1. pending prompt rows of each conversation (its own prefill pass), then sample
+    for (int i = 0; i < n; i++) { cur_ = slots[i]; ids_out[i] = sample_token(p); }
+    // 2. one weight pass for the conversations that still have room
+    HIP_CHECK(hipStreamSynchronize(stream_));                                // h_bstage_ may still feed the previous step's copies
+    int B = 0;
+    for (int i = 0; i < n; i++) {
+        Conversation &cv = conv_[(size_t)slots[i]];
+        if (cv.n_past + 1 > n_ctx_) continue;                               // context full: sampled, not advanced
+        h_bstage_[B] = ids_out[i]; h_bstage_[MAX_CONVERSATIONS + B] = slots[i]; B++;
+    }
+    if (!B) return 0;
+    HIP_CHECK(hipMemcpyAsync(d_btok_, h_bstage_, (size_t)B * 4, hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_bslot_, h_bstage_ + MAX_CONVERSATIONS, (size_t)B * 4, hipMemcpyHostToDevice, stream_));
+    // the device positions of these conversations are current (k_advance / k_batch_finish keep them), but a reset or a failed flush may have
+    // moved the host's view: write them explicitly, like eval_chunk does
+    for (int r = 0; r < B; r++) launch_set_int(d_npast_ + h_bstage_[MAX_CONVERSATIONS + r], conv_[(size_t)h_bstage_[MAX_CONVERSATIONS + r]].n_committed, stream_);
+    forward_batch(B, stream_);
+    const size_t V = llm_.n_vocab;
+    for (int r = 0; r < B; r++) {
+        const int sl = h_bstage_[MAX_CONVERSATIONS + r];
+        HIP_CHECK(hipMemcpyAsync(logits_ + (size_t)sl * V, blogits_ + (size_t)r * V, V * 4, hipMemcpyDeviceToDevice, stream_));
+        Conversation &cv = conv_[(size_t)sl];
+        cv.n_past += 1; cv.n_committed += 1;
+        if (logits_host_slot_ == sl) logits_host_slot_ = -1;
+    }
+    HIP_CHECK(hipMemcpyAsync(h_argmax_, d_argmax_, conv_.size() * 4, hipMemcpyDeviceToHost, stream_));
     return 0;
 }
 

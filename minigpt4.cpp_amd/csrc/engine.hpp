@@ -42,13 +42,13 @@ public:
     int add_embedding(const float *data, int n_rows); // llama_eval_embd (minigpt4.cpp:2399-2422)
     int sample_token(const SampleParams &p);          // minigpt4.cpp:2425-2483
     const char *id_to_token(int id) const;            // minigpt4.cpp:2485-2497 (borrowed pointer)
-    void reset() { pend_tok_.clear(); pend_embd_.clear(); n_past_ = 0; n_committed_ = 0; }   // minigpt4.cpp:2499-2502
+    void reset() { Conversation &c = conv_[(size_t)cur_]; c.pend_tok.clear(); c.pend_embd.clear(); c.n_past = 0; c.n_committed = 0; }   // minigpt4.cpp:2499-2502 (the selected conversation)
     void sync();
     hipStream_t stream() const { return stream_; }
 
     int n_vocab() const { return (int)llm_.n_vocab; }
     int n_embd() const { return (int)llm_.n_embd; }
-    int n_past() const { return n_past_; }
+    int n_past() const { return conv_[(size_t)cur_].n_past; }
     int n_ctx() const { return n_ctx_; }
     const float *logits_host();                       // syncs, copies the last logits to pinned memory
     const Tokenizer &tokenizer() const { return tok_; }
@@ -57,6 +57,18 @@ public:
     size_t vision_arena_bytes() const { return vis_arena_.used; }
     uint8_t *llm_arena_ptr() { return llm_arena_.base; }
     uint8_t *vision_arena_ptr() { return vis_arena_.base; }
+
+    // ---- several conversations per replica.  The reference holds ONE conversation per context (minigpt4.cpp:2513-2521); here a context owns
+    // n >= 1 of them -- each with its own KV cache region, position and pending queue, sharing the weights -- so that a decode step of B conversations
+    // streams the weights once instead of B times.  All reference entry points act on the selected conversation (0 by default).
+    int set_conversations(int n);                      // (re)allocates the KV caches; every conversation is reset.  1 <= n <= MAX_CONVERSATIONS
+    int select_conversation(int slot);
+    int n_conversations() const { return (int)conv_.size(); }
+    int current_conversation() const { return cur_; }
+    // one decode step for `n` distinct conversations: sample each (like sample_token), evaluate the n sampled tokens in ONE weight pass.
+    // ids_out[i] = the token sampled for slots[i]; a conversation whose context is full is sampled but not advanced (the reference discards the error too).
+    int decode_batch(const int *slots, int n, const SampleParams &p, int *ids_out);
+    static constexpr int MAX_CONVERSATIONS = 64;
 
     // ---- measurement hooks (bench / tests)
     // K greedy decode steps fed back on the device (no host round trip); returns ms per step via hipEvents.
@@ -71,6 +83,7 @@ private:
     void alloc_buffers();
     int eval_chunk(const int *row_tok, int N, const float *embd);
     void forward(int N, bool from_tokens, hipStream_t s);
+    void forward_batch(int B, hipStream_t s);          // B decode rows of B conversations: tokens d_btok_[r], conversations d_bslot_[r]
     struct Prep { int kind; const float *x; const float *w; };   // 1: rms_norm(x)*w, 2: x, 3: silu(x)*w -- then quantised for the consumer's type
     void mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse);
     bool mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair = false);
@@ -81,10 +94,16 @@ private:
     int device_ = 0;
     hipStream_t stream_ = nullptr;
     int n_ctx_ = 2048, n_batch_ = 512, max_rows_ = 512;
-    int n_past_ = 0;        // logical position: evaluated + queued rows
-    int n_committed_ = 0;   // rows already evaluated on the device
+    struct Conversation {
+        int n_past = 0;        // logical position: evaluated + queued rows
+        int n_committed = 0;   // rows already evaluated on the device
+        std::vector<int> pend_tok; std::vector<float> pend_embd;
+        hipGraphExec_t graph = nullptr;   // decode step captured with this conversation's cache / position / token addresses
+    };
+    std::vector<Conversation> conv_ = std::vector<Conversation>(1);
+    int cur_ = 0;
     bool defer_ = true; int max_chunk_ = 512;
-    std::vector<int> pend_tok_; std::vector<float> pend_embd_;
+    void release_buffers();
 
     // LLM
     LLMFile llm_;
@@ -105,9 +124,12 @@ private:
     // activations
     float *x_ = nullptr, *q_ = nullptr, *k_ = nullptr, *v_ = nullptr, *att_ = nullptr, *h1_ = nullptr, *h3_ = nullptr, *logits_ = nullptr;
     ActQ act_;
-    int *d_npast_ = nullptr, *d_tokens_ = nullptr, *d_argmax_ = nullptr; void *d_scratch_ = nullptr;
-    int *h_argmax_ = nullptr; float *h_logits_ = nullptr; bool logits_host_valid_ = false;
-    hipGraphExec_t decode_graph_ = nullptr; bool use_graph_ = true, use_v2_ = true;
+    // per conversation (indexed by slot): position, greedy token of the last evaluation, next input token; logits_ is [slots][n_vocab]
+    int *d_npast_ = nullptr, *d_argmax_ = nullptr, *d_feed_ = nullptr;
+    int *d_tokens_ = nullptr; void *d_scratch_ = nullptr;
+    int *d_btok_ = nullptr, *d_bslot_ = nullptr; float *blogits_ = nullptr;   // batched decode: row tokens / row conversations / [rows][n_vocab] logits
+    int *h_argmax_ = nullptr, *h_bstage_ = nullptr; float *h_logits_ = nullptr; int logits_host_slot_ = -1;
+    bool use_graph_ = true, use_v2_ = true;
     static constexpr int FUSE_DEFAULT = 87; int fuse_mask_ = FUSE_DEFAULT;
     // profiling
     bool prof_on_ = false;

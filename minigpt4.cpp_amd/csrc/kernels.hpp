@@ -52,6 +52,12 @@ void launch_rope_kv(float *q, const float *k, const float *v, int N, int n_head,
 // !fused: launch_rope_kv must have run (q rotated in place, caches appended).
 void launch_attn_llm(float *q, const float *k, const float *v, __half *kcache, __half *vcache, int N, int n_head, int hd, const int *n_past, int n_ctx,
                      const float *cos_tab, const float *sin_tab, const Tables &tb, float *out, bool fused, hipStream_t s);
+// decode of B different conversations in one pass (RoPE + KV append fused): row t -> conversation row_slot[t] at position n_past[row_slot[t]], caches at
+// kcache / vcache + row_slot[t] * seq_stride elements.
+void launch_attn_llm_batched(float *q, const float *k, const float *v, __half *kcache, __half *vcache, int B, int n_head, int hd, const int *n_past, const int *row_slot,
+                             size_t seq_stride, int n_ctx, const float *cos_tab, const float *sin_tab, const Tables &tb, float *out, hipStream_t s);
+// per row r: argmax[slot] = feed[slot] = argmax(logits[r]), n_past[slot] += 1 with slot = row_slot[r]
+void launch_batch_finish(const float *logits, int n_vocab, int B, const int *row_slot, int *n_past, int *argmax, int *feed, hipStream_t s);
 bool attn_head_size_supported(int hd);
 void launch_argmax(const float *logits, int n, int *out, void *scratch /*>= 512 bytes*/, hipStream_t s);
 void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);

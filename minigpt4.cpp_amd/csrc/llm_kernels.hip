@@ -749,8 +749,16 @@ bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *co
 
 static int g_mmq_enabled = 1;
 void set_mmq_enabled(int v) { g_mmq_enabled = v; }
+// Unquantised (F16) weights, prefill: ggml converts the activation rows to fp16 and accumulates exact fp16 products in fp32 (ggml_vec_dot_f16) -- which is
+// precisely the vision tower's MFMA GEMM (v_mfma_f32_32x32x16_f16, fp32 accumulators), so rows >= 16 go there: BASELINE.json configs[4]
+// (13B f16, 512-token prefill) is MFMA-bound instead of re-streaming 25 GB of weights once per 4 tokens.  MINIGPT4_F16_GEMM=0 keeps the v_dot path.
+static int g_f16_gemm = -1;
 void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
     if (g_mmq_enabled && N >= 5 && mmq_supported(W.type)) { launch_mmq(W, A, N, y, ldy, residual, s); return; }
+    if (W.type == GT_F16 && N >= 16 && W.cols % 8 == 0) {
+        if (g_f16_gemm < 0) { const char *e = getenv("MINIGPT4_F16_GEMM"); g_f16_gemm = e ? atoi(e) != 0 : 1; }
+        if (g_f16_gemm) { launch_gemm_f16(A.xh, W.cols, reinterpret_cast<const __half *>(W.qs), W.cols, N, W.rows, W.cols, nullptr, residual, false, Tables{}, y, nullptr, ldy, s); return; }
+    }
     switch (W.type) {
     case GT_Q4_0: launch_mul_mat_t<GT_Q4_0>(W, A, N, y, ldy, residual, s); break;
     case GT_Q4_1: launch_mul_mat_t<GT_Q4_1>(W, A, N, y, ldy, residual, s); break;
@@ -934,14 +942,20 @@ void launch_rope_kv(float *q, const float *k, const float *v, int N, int n_head,
 //   PV     : thread = (key partition, 8-dim chunk): 16-byte V loads, 4 in flight; partitions reduced through LDS
 // =====================================================================================================================
 constexpr int AT_THREADS = 512;
-template <int HD, bool FUSED>
+//   BATCHED (decode of several conversations in one pass; implies FUSED): row t belongs to conversation row_slot[t], whose position is
+//            n_past[row_slot[t]] and whose caches start seq_stride * row_slot[t] elements behind kc / vc.
+template <int HD, bool FUSED, bool BATCHED = false>
 __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, const float *__restrict__ kin, const float *__restrict__ vin, __half *__restrict__ kc,
                                                          __half *__restrict__ vc, int E, const int *__restrict__ n_past, const float *__restrict__ cos_tab,
-                                                         const float *__restrict__ sin_tab, const Tables tb, float *__restrict__ out) {
+                                                         const float *__restrict__ sin_tab, const Tables tb, float *__restrict__ out, const int *__restrict__ row_slot = nullptr,
+                                                         size_t seq_stride = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CH = HD / 8, P = AT_THREADS / CH;
     const int h = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
-    const int pos = *n_past + t, T = pos + 1;
+    int pos_;
+    if (BATCHED) { const int slot = row_slot[t]; pos_ = n_past[slot]; kc += (size_t)slot * seq_stride; vc += (size_t)slot * seq_stride; }
+    else pos_ = *n_past + t;
+    const int pos = pos_, T = pos + 1;
     const int Tg = FUSED ? pos : T;                               // keys read from the global cache
     const int Tpad = (T + 7) & ~7;
     float *sc = reinterpret_cast<float *>(smem);                  // [Tpad]
@@ -1047,6 +1061,26 @@ static void launch_attn_hd(float *q, const float *k, const float *v, __half *kc,
     if (fused) hipLaunchKernelGGL((k_attn_llm<HD, true>), dim3((unsigned)n_head, 1), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out);
     else hipLaunchKernelGGL((k_attn_llm<HD, false>), dim3((unsigned)n_head, (unsigned)N), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out);
 }
+template <int HD>
+static void launch_attn_batched_hd(float *q, const float *k, const float *v, __half *kc, __half *vc, int B, int n_head, const int *n_past, const int *row_slot, size_t seq_stride,
+                                   int n_ctx, const float *cos_tab, const float *sin_tab, const Tables &tb, float *out, hipStream_t s) {
+    const int Tpad = (n_ctx + 7) & ~7;
+    const size_t lds = (size_t)Tpad * 6 + (size_t)HD * 6 + (size_t)(AT_THREADS / (HD / 8)) * HD * 4 + 64;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((k_attn_llm<HD, true, true>), dim3((unsigned)n_head, (unsigned)B), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out, row_slot,
+                       seq_stride);
+}
+// Decode attention for B rows of B different conversations (RoPE + KV append fused): row t uses position n_past[row_slot[t]] and the caches of that conversation.
+void launch_attn_llm_batched(float *q, const float *k, const float *v, __half *kcache, __half *vcache, int B, int n_head, int hd, const int *n_past, const int *row_slot,
+                             size_t seq_stride, int n_ctx, const float *cos_tab, const float *sin_tab, const Tables &tb, float *out, hipStream_t s) {
+    switch (hd) {
+    case 32: launch_attn_batched_hd<32>(q, k, v, kcache, vcache, B, n_head, n_past, row_slot, seq_stride, n_ctx, cos_tab, sin_tab, tb, out, s); break;
+    case 64: launch_attn_batched_hd<64>(q, k, v, kcache, vcache, B, n_head, n_past, row_slot, seq_stride, n_ctx, cos_tab, sin_tab, tb, out, s); break;
+    case 128: launch_attn_batched_hd<128>(q, k, v, kcache, vcache, B, n_head, n_past, row_slot, seq_stride, n_ctx, cos_tab, sin_tab, tb, out, s); break;
+    default: throw HipError{hipErrorInvalidValue, "unsupported head size", __FILE__, __LINE__};
+    }
+}
 bool attn_head_size_supported(int hd) { return hd == 32 || hd == 64 || hd == 128; }
 // fused = true (N must be 1): q,k,v are the raw projections; RoPE + KV append happen inside.  fused = false: launch_rope_kv must have run.
 void launch_attn_llm(float *q, const float *k, const float *v, __half *kcache, __half *vcache, int N, int n_head, int hd, const int *n_past, int n_ctx,
@@ -1106,6 +1140,27 @@ __global__ void k_fill_u16(unsigned short *p, size_t n, unsigned short v) {
 void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s) { hipLaunchKernelGGL(k_fill_u16, dim3(1024), dim3(256), 0, s, (unsigned short *)p, n, v); }
 __global__ void k_set_int(int *p, int v) { *p = v; }
 void launch_set_int(int *p, int v, hipStream_t s) { hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, p, v); }
+// Batched decode epilogue, one workgroup per row: greedy argmax of the row's logits (first maximum wins), stored with the logits' owner slot; the
+// conversation's position advances by one and the greedy token becomes its next input.
+__global__ __launch_bounds__(256) void k_batch_finish(const float *__restrict__ logits, int n_vocab, const int *__restrict__ row_slot, int *__restrict__ n_past, int *__restrict__ argmax,
+                                                      int *__restrict__ feed) {
+    const int r = blockIdx.x, slot = row_slot[r];
+    const float *x = logits + (size_t)r * n_vocab;
+    float best = -INFINITY; int bi = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < n_vocab; i += 256) { const float v = x[i]; if (v > best) { best = v; bi = i; } }
+    __shared__ float sv[4]; __shared__ int si[4];
+    argmax_wave(best, bi);
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) argmax_combine(best, bi, sv[w], si[w]);
+        const int id = bi == 0x7FFFFFFF ? 0 : bi;
+        argmax[slot] = id; feed[slot] = id; n_past[slot] += 1;
+    }
+}
+void launch_batch_finish(const float *logits, int n_vocab, int B, const int *row_slot, int *n_past, int *argmax, int *feed, hipStream_t s) {
+    hipLaunchKernelGGL(k_batch_finish, dim3((unsigned)B), dim3(256), 0, s, logits, n_vocab, row_slot, n_past, argmax, feed);
+}
 // end of a decode step: the KV position advances and the greedy token becomes the next input (the host may overwrite it)
 __global__ void k_advance(int *n_past, int n, int *tok0, const int *argmax) { *n_past += n; if (tok0) *tok0 = *argmax; }
 void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, n_past, n, tok0, argmax); }

@@ -133,6 +133,12 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_vocab_tokenize.argtypes = [VOID_PTR, CHAR_PTR, I32, INT_PTR, I32]
         L.minigpt4_amd_inspect_files.argtypes = [CHAR_PTR, CHAR_PTR, INT_PTR, INT_PTR, P(ctypes.c_int64)]
         L.minigpt4_amd_sample_logits.argtypes = [FLOAT_PTR, I32, I32, F32, I32, F32, F32, F32, I32, F32, F32]
+        L.minigpt4_amd_decode_image.argtypes = [CHAR_PTR, SIZE_T, P(MiniGPT4Image)]
+        L.minigpt4_amd_resample_coeffs.argtypes = [I32, I32, INT_PTR, INT_PTR, INT_PTR, INT_PTR, SIZE_T]
+        L.minigpt4_amd_set_conversations.argtypes = [VOID_PTR, I32]
+        L.minigpt4_amd_select_conversation.argtypes = [VOID_PTR, I32]
+        L.minigpt4_amd_n_conversations.argtypes = [VOID_PTR]
+        L.minigpt4_amd_end_chat_batch.argtypes = [VOID_PTR, INT_PTR, I32, P(ctypes.c_char_p), F32, I32, F32, F32, F32, I32, F32, F32]
 
     # ---------------------------------------------------------------- reference surface
     def panic_if_error(self, error_code: int) -> None:
@@ -219,6 +225,30 @@ class MiniGPT4SharedLibrary:
     # ---------------------------------------------------------------- additive surface (numpy in / out)
     def amd_device_count(self) -> int:
         return int(self.library.minigpt4_amd_device_count())
+
+    # several conversations per context (include/minigpt4_amd.h): the reference calls act on the selected one
+    def amd_set_conversations(self, ctx, n: int):
+        if self.library.minigpt4_amd_set_conversations(ctx.ptr, n):
+            raise RuntimeError("set_conversations failed: " + self.library.minigpt4_amd_last_error().decode())
+
+    def amd_select_conversation(self, ctx, slot: int):
+        if self.library.minigpt4_amd_select_conversation(ctx.ptr, slot):
+            raise RuntimeError("select_conversation: index out of range")
+
+    def amd_end_chat_batch(self, ctx, slots: Sequence[int], temp=0.8, top_k=40, top_p=0.9, tfs_z=1.0, typical_p=1.0, mirostat=0, mirostat_tau=5.0,
+                           mirostat_eta=1.0) -> List[str]:
+        """One minigpt4_end_chat step for several conversations in one pass over the weights; returns one piece per conversation."""
+        sl = np.ascontiguousarray(slots, np.int32)
+        toks = (ctypes.c_char_p * len(sl))()
+        rc = self.library.minigpt4_amd_end_chat_batch(ctx.ptr, sl.ctypes.data_as(INT_PTR), len(sl), toks, temp, top_k, top_p, tfs_z, typical_p, mirostat, mirostat_tau, mirostat_eta)
+        if rc:
+            raise RuntimeError("end_chat_batch failed: " + self.library.minigpt4_amd_last_error().decode())
+        return [(t or b"").decode("utf-8", errors="replace") for t in toks]
+
+    def amd_decode_image(self, data: bytes) -> MiniGPT4Image:
+        image = MiniGPT4Image()
+        self.panic_if_error(self.library.minigpt4_amd_decode_image(data, len(data), ctypes.pointer(image)))
+        return image
 
     def amd_eval_tokens(self, ctx, tokens: Sequence[int]):
         t = np.ascontiguousarray(tokens, np.int32)

@@ -1,0 +1,188 @@
+"""GPU parity of the several-conversations-per-context path (include/minigpt4_amd.h "batched decode"):
+B conversations with their own KV caches share one pass over the weights per decode step.  Every conversation must behave exactly like the
+reference's single conversation (minigpt4.cpp:2513-2521 holds one per context): greedy pieces identical to an independent oracle chat, logits equal to
+the single-conversation path of the same engine up to the fp32 summation order of a different mat-mul kernel (2e-3 of the logit range, the bar the
+other whole-model tests use).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PROMPTS = [b"what is the text in the picture?", b"describe the colours", b"hello", b"and now something longer to shift the positions apart", b"a", b"b c d", b"zzz", b"tell me more"]
+
+
+def oracle_chats(lp, prompts, n_ctx):
+    import refcpu as R
+    from minigpt4_cpp_amd import modelgen as G
+    f = G.read_llm_file(lp)
+    chats = []
+    for p in prompts:
+        c = R.OracleChat(R.OracleLLM(f, n_ctx=n_ctx), n_batch=32)
+        c.system_prompt()
+        c.begin_chat(p)
+        chats.append(c)
+    return chats
+
+
+def start(lib, ctx, prompts):
+    lib.amd_set_conversations(ctx, len(prompts))
+    for s, p in enumerate(prompts):
+        lib.amd_select_conversation(ctx, s)
+        lib.minigpt4_system_prompt(ctx)
+        lib.minigpt4_begin_chat(ctx, p.decode())
+    lib.amd_select_conversation(ctx, 0)
+
+
+@pytest.mark.parametrize("wtype,mix", [("q4_0", "none"), ("q5_k", "q5_k_m"), ("f16", "none")])
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8])        # <= 4: v_dot4 4-token tiles; >= 5: int8-MFMA tiles (k-quants / Q4_0)
+def test_batched_greedy_equals_independent_oracle_chats(gpu_lib, tiny_files, wtype, mix, B):
+    vp, llm = tiny_files
+    lp = llm(wtype, mix)
+    prompts = PROMPTS[:B]
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=256, n_batch=32)
+    try:
+        start(gpu_lib, ctx, prompts)
+        assert gpu_lib.library.minigpt4_amd_n_conversations(ctx.ptr) == B
+        got = [[] for _ in range(B)]
+        for _ in range(6):
+            for s, piece in enumerate(gpu_lib.amd_end_chat_batch(ctx, list(range(B)), temp=0.0)):
+                got[s].append(piece)
+        chats = oracle_chats(lp, prompts, 256)
+        want = [[c.end_chat(temp=0.0)[1].decode("utf-8", errors="replace") for _ in range(6)] for c in chats]
+        assert got == want
+        for s in range(B):                                 # positions advanced per conversation
+            gpu_lib.amd_select_conversation(ctx, s)
+            assert gpu_lib.library.minigpt4_amd_n_past(ctx.ptr) == chats[s].llm.n_past
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+
+
+def test_batch_logits_equal_single_conversation_path(gpu_lib, tiny_files):
+    vp, llm = tiny_files
+    lp = llm("q5_k", "q5_k_m")
+    prompts = PROMPTS[:3]
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=256, n_batch=32)
+    ref = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=256, n_batch=32)
+    try:
+        start(gpu_lib, ctx, prompts)
+        for _ in range(3):
+            gpu_lib.amd_end_chat_batch(ctx, [0, 1, 2], temp=0.0)
+        for s, p in enumerate(prompts):
+            gpu_lib.minigpt4_reset_chat(ref)
+            gpu_lib.minigpt4_system_prompt(ref)
+            gpu_lib.minigpt4_begin_chat(ref, p.decode())
+            for _ in range(3):
+                gpu_lib.minigpt4_end_chat(ref, temp=0.0)
+            want = gpu_lib.amd_logits(ref)
+            gpu_lib.amd_select_conversation(ctx, s)
+            got = gpu_lib.amd_logits(ctx)
+            assert float(np.abs(got - want).max() / (want.max() - want.min())) < 2e-3
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+        gpu_lib.minigpt4_free(ref)
+
+
+def test_interleaving_single_and_batched_steps_reset_and_subsets(gpu_lib, tiny_files):
+    """Batched steps, single-conversation steps (the reference entry points on the selected conversation), a subset batch in a different order and a
+    reset of one conversation interleave freely; each conversation still equals its own oracle chat."""
+    vp, llm = tiny_files
+    lp = llm("q4_0")
+    prompts = PROMPTS[:4]
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=256, n_batch=32)
+    try:
+        start(gpu_lib, ctx, prompts)
+        chats = oracle_chats(lp, prompts, 256)
+        got = [[] for _ in range(4)]
+        want = [[] for _ in range(4)]
+
+        def step_oracle(slots):
+            for s in slots:
+                want[s].append(chats[s].end_chat(temp=0.0)[1].decode("utf-8", errors="replace"))
+
+        def step_batch(slots):
+            for s, piece in zip(slots, gpu_lib.amd_end_chat_batch(ctx, slots, temp=0.0)):
+                got[s].append(piece)
+            step_oracle(slots)
+
+        step_batch([0, 1, 2, 3])
+        step_batch([3, 1])                                  # subset, permuted
+        gpu_lib.amd_select_conversation(ctx, 2)
+        for _ in range(2):                                  # single-conversation decode through the reference ABI (hipGraph of conversation 2)
+            got[2].append(gpu_lib.minigpt4_end_chat(ctx, temp=0.0))
+        step_oracle([2])
+        step_oracle([2])
+        step_batch([0, 1, 2, 3])
+        # conversation 1 starts over; the others keep their caches
+        gpu_lib.amd_select_conversation(ctx, 1)
+        gpu_lib.minigpt4_reset_chat(ctx)
+        gpu_lib.minigpt4_system_prompt(ctx)
+        gpu_lib.minigpt4_begin_chat(ctx, "fresh start")
+        import refcpu as R
+        from minigpt4_cpp_amd import modelgen as G
+        chats[1] = R.OracleChat(R.OracleLLM(G.read_llm_file(lp), n_ctx=256), n_batch=32)
+        chats[1].system_prompt()
+        chats[1].begin_chat(b"fresh start")
+        step_batch([0, 1, 2, 3])
+        step_batch([2, 0, 1])
+        assert got == want
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+
+
+def test_full_context_is_sampled_but_not_advanced_and_bad_arguments(gpu_lib, tiny_files):
+    vp, llm = tiny_files
+    ctx = gpu_lib.minigpt4_model_load(vp, llm("q4_0"), verbosity=0, n_ctx=64, n_batch=32)
+    try:
+        gpu_lib.amd_set_conversations(ctx, 2)
+        gpu_lib.amd_select_conversation(ctx, 0)
+        gpu_lib.amd_eval_tokens(ctx, [1] + [5] * 62)        # one free position
+        gpu_lib.amd_select_conversation(ctx, 1)
+        gpu_lib.amd_eval_tokens(ctx, [1, 7, 9])
+        for k in range(3):
+            gpu_lib.amd_end_chat_batch(ctx, [0, 1], temp=0.0)
+        gpu_lib.amd_select_conversation(ctx, 0)
+        assert gpu_lib.library.minigpt4_amd_n_past(ctx.ptr) == 64           # filled by the first step, then left alone
+        gpu_lib.amd_select_conversation(ctx, 1)
+        assert gpu_lib.library.minigpt4_amd_n_past(ctx.ptr) == 6
+        with pytest.raises(RuntimeError):
+            gpu_lib.amd_end_chat_batch(ctx, [0, 0], temp=0.0)                # duplicates
+        with pytest.raises(RuntimeError):
+            gpu_lib.amd_end_chat_batch(ctx, [0, 2], temp=0.0)                # out of range
+        with pytest.raises(RuntimeError):
+            gpu_lib.amd_select_conversation(ctx, 2)
+        with pytest.raises(RuntimeError):
+            gpu_lib.amd_set_conversations(ctx, 65)
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+
+
+def test_seeded_sampling_in_a_batch_uses_the_host_sampler_per_conversation(gpu_lib, tiny_files):
+    """temp > 0: every conversation's logits go through the same sampler chain as minigpt4_end_chat (one mt19937 stream per context, consumed in
+    slot-list order) -- equal to sampling the same logits with the host-only hook."""
+    vp, llm = tiny_files
+    lp = llm("q4_0")
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, seed=77, n_ctx=256, n_batch=32)
+    try:
+        start(gpu_lib, ctx, PROMPTS[:2])
+        gpu_lib.amd_select_conversation(ctx, 0)
+        gpu_lib.library.minigpt4_amd_sync(ctx.ptr)
+        lg = []
+        for s in range(2):
+            gpu_lib.amd_select_conversation(ctx, s)
+            lg.append(gpu_lib.amd_logits(ctx))
+        pieces = gpu_lib.amd_end_chat_batch(ctx, [0, 1], temp=0.7, top_k=20, top_p=0.95)
+        assert len(pieces) == 2 and all(isinstance(p, str) for p in pieces)
+        # the first draw of a fresh context with seed 77 on conversation 0's logits
+        first = gpu_lib.amd_sample_logits(lg[0], 77, temp=0.7, top_k=20, top_p=0.95)
+        voc = gpu_lib.library.minigpt4_amd_vocab_load(lp.encode())
+        try:
+            n = np.zeros(1, np.int32)
+            import ctypes
+            ptr = gpu_lib.library.minigpt4_amd_vocab_piece(voc, first, n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+            want = "</s>" if first == 2 else ctypes.string_at(ptr, int(n[0])).decode("utf-8", errors="replace")
+        finally:
+            gpu_lib.library.minigpt4_amd_vocab_free(voc)
+        assert pieces[0] == want
+    finally:
+        gpu_lib.minigpt4_free(ctx)
