@@ -277,7 +277,7 @@ def main():
             lib.library.minigpt4_amd_sync(ctx.ptr)
             dtb = time.perf_counter() - t0
             out["batched_decode"] = {"conversations_per_gpu": B, "steps": KB, "tokens_per_s_per_gpu": B * KB / dtb, "ms_per_step": dtb * 1e3 / KB,
-                                     "weight_GBps": wbytes * KB / dtb / 1e9, "note": "eager launches (no hipGraph yet); every conversation has its own KV cache and position"}
+                                     "weight_GBps": wbytes * KB / dtb / 1e9, "note": "one hipGraph per step; every conversation has its own KV cache and position; weights streamed once per 4 conversations"}
         except Exception as e:   # never lose the headline line to the extra leg
             out["batched_decode"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -72,6 +72,9 @@ MINIGPT4_API int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int
  * epi = 1: y[g] = silu(W0[g] . a) * (W1[g] . a) (n1 == 2).  residual / y: (n1 + n2) * n_out floats.  Returns 4 when the shape is outside the kernel's range. */
 MINIGPT4_API int minigpt4_amd_test_matvec(int type1, const void *raw1, int n1, int type2, const void *raw2, int n2, int64_t n_in, int64_t n_out, const float *x, const float *x2,
                                           int prep, int fuse, int epi, const float *residual, float *y);
+/* The batched-decode mat-vec: N = 1..4 activation rows x[N][n_in] against n_mat (1..3) equally spaced matrices in one weight pass; y / residual: [n_mat][N][n_out].
+ * Returns 4 when the shape / type is outside the kernel's range. */
+MINIGPT4_API int minigpt4_amd_test_matvec_rows(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int N, const float *residual, float *y);
 /* Activation quantisation (optionally after rms_norm with weight w): returns Q8_K and Q8_0 images of x[N][K].
  * q8k: int8[N*K], dk: float[N*K/256], bsums: int16[N*K/16], q80: int8[N*K], d0: float[N*K/32] (fp16-rounded). Any may be NULL. */
 MINIGPT4_API int minigpt4_amd_test_quantize(const float *x, const float *rms_w, int64_t N, int64_t K, int8_t *q8k, float *dk, int16_t *bsums, int8_t *q80, float *d0);

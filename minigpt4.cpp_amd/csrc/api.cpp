@@ -331,6 +331,36 @@ int minigpt4_amd_test_matvec(int type1, const void *raw1, int n1, int type2, con
     });
 }
 
+// The batched-decode mat-vec (k_matvec_tn) as Engine::forward_batch issues it: N = 1..4 rows against n_mat equally spaced matrices (raw_w = their file bytes
+// back to back), optional residual.  x: [N][n_in]; y / residual: [n_mat][N][n_out].  Returns 4 when the shape is outside the kernel's range.
+int minigpt4_amd_test_matvec_rows(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int N, const float *residual, float *y) {
+    if (!raw_w || !x || !y || n_in <= 0 || n_out <= 0 || n_mat < 1 || n_mat > 3 || N < 1 || N > 4 || !qweight_supported(ggml_type) || n_in % gt_block(ggml_type)) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const int K = (int)n_in, R = (int)n_out;
+        QWeight plan; const size_t need = plan_qweight(ggml_type, R, K, plan, nullptr), raw_bytes = gt_nbytes(ggml_type, (size_t)R * K);
+        DevBuf planes(need * (size_t)n_mat), d_raw(raw_bytes), d_x((size_t)N * K * 4), d_y((size_t)n_mat * N * R * 4), d_res((size_t)n_mat * N * R * 4);
+        std::vector<QWeight> W((size_t)n_mat);
+        for (int m = 0; m < n_mat; m++) {
+            plan_qweight(ggml_type, R, K, W[(size_t)m], planes.as<uint8_t>() + (size_t)m * need);
+            HIP_CHECK(hipMemcpy(d_raw.p, (const uint8_t *)raw_w + (size_t)m * raw_bytes, raw_bytes, hipMemcpyHostToDevice));
+            if (ggml_type == GT_F16 || ggml_type == GT_F32) HIP_CHECK(hipMemcpy(planes.as<uint8_t>() + (size_t)m * need, d_raw.p, raw_bytes, hipMemcpyDeviceToDevice)); else launch_repack(d_raw.as<uint8_t>(), W[(size_t)m], nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+        }
+        HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)N * K * 4, hipMemcpyHostToDevice));
+        if (residual) HIP_CHECK(hipMemcpy(d_res.p, residual, (size_t)n_mat * N * R * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(d_y.p, 0xFF, (size_t)n_mat * N * R * 4));
+        ActQ A; std::vector<std::unique_ptr<DevBuf>> keep; alloc_act(A, keep, (size_t)N, (size_t)K);
+        launch_rms_quant(d_x.as<float>(), nullptr, N, K, A, act_mask_for(ggml_type), nullptr);
+        const QWeight *Wp[3]; float *Yp[3]; const float *Rp[3];
+        for (int m = 0; m < n_mat; m++) { Wp[m] = &W[(size_t)m]; Yp[m] = d_y.as<float>() + (size_t)m * N * R; Rp[m] = d_res.as<float>() + (size_t)m * N * R; }
+        if (!launch_matvec_rows(Wp, Yp, residual ? Rp : nullptr, n_mat, A, N, R, nullptr)) { set_last_error("shape / type outside the multi-row mat-vec kernel's range"); return 4; }
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(y, d_y.p, (size_t)n_mat * N * R * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+
 int minigpt4_amd_test_quantize(const float *x, const float *rms_w, int64_t N, int64_t K, int8_t *q8k, float *dk, int16_t *bsums, int8_t *q80, float *d0) {
     if (!x || N <= 0 || K <= 0 || K % 256) return 1;
     if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }

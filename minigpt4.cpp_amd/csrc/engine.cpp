@@ -67,6 +67,7 @@ void preprocess_image_device(hipStream_t s, const uint8_t *rgb, int w, int h, fl
 
 void Engine::release_buffers() {
     for (Conversation &c : conv_) { if (c.graph) (void)hipGraphExecDestroy(c.graph); c.graph = nullptr; }
+    for (hipGraphExec_t &g : batch_graph_) { if (g) (void)hipGraphExecDestroy(g); g = nullptr; }
     if (h_argmax_) (void)hipHostFree(h_argmax_);
     if (h_bstage_) (void)hipHostFree(h_bstage_);
     if (h_logits_) (void)hipHostFree(h_logits_);
@@ -110,6 +111,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     // (row-pair epilogue); bit 6: wq|wk and a differently typed wv in one launch.  See DESIGN.md "mat-vec prologue".
     fuse_mask_ = getenv("MINIGPT4_FUSE") ? atoi(getenv("MINIGPT4_FUSE")) : FUSE_DEFAULT;
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
+    if (getenv("MINIGPT4_BATCH_ROWS_MAX")) batch_rows_max_ = atoi(getenv("MINIGPT4_BATCH_ROWS_MAX"));
     if (const char *sk = getenv("MINIGPT4_SPLITK")) { sscanf(sk, "%d,%d", &splitk_proj_, &splitk_fc2_); splitk_proj_ = std::max(1, std::min(SPLITK_MAX, splitk_proj_)); splitk_fc2_ = std::max(1, std::min(SPLITK_MAX, splitk_fc2_)); }
     set_matvec_tuning(getenv("MINIGPT4_MV_WAVES") ? atoi(getenv("MINIGPT4_MV_WAVES")) : 0, getenv("MINIGPT4_FAT_LB") ? atoi(getenv("MINIGPT4_FAT_LB")) : 0, prop.multiProcessorCount);
     if (const char *ns = getenv("MINIGPT4_CONVERSATIONS")) conv_.assign((size_t)std::max(1, std::min(MAX_CONVERSATIONS, atoi(ns))), Conversation{});
@@ -381,13 +383,14 @@ void Engine::alloc_buffers() {
     act_.xh = takeh(B * Kmax); act_.xf = takef(B * Kmax);
     static_assert(MAX_CONVERSATIONS * 4 <= 256, "per-conversation scalars live in 256-byte slabs");
     d_npast_ = reinterpret_cast<int *>(buf_arena_.take(256)); d_argmax_ = reinterpret_cast<int *>(buf_arena_.take(256)); d_feed_ = reinterpret_cast<int *>(buf_arena_.take(256));
-    d_btok_ = reinterpret_cast<int *>(buf_arena_.take(256)); d_bslot_ = reinterpret_cast<int *>(buf_arena_.take(256));
+    d_btok_ = reinterpret_cast<int *>(buf_arena_.take(768)); d_bslot_ = d_btok_ + MAX_CONVERSATIONS; d_bpos_ = d_bslot_ + MAX_CONVERSATIONS;
+    batch_graph_.assign((size_t)MAX_CONVERSATIONS + 1, nullptr);
     d_tokens_ = reinterpret_cast<int *>(buf_arena_.take(B * 4));
     d_scratch_ = buf_arena_.take(4096);
-    HIP_CHECK(hipMemset(d_npast_, 0, 256)); HIP_CHECK(hipMemset(d_argmax_, 0, 256)); HIP_CHECK(hipMemset(d_feed_, 0, 256)); HIP_CHECK(hipMemset(d_btok_, 0, 256));
-    HIP_CHECK(hipMemset(d_bslot_, 0, 256)); HIP_CHECK(hipMemset(d_tokens_, 0, B * 4));
+    HIP_CHECK(hipMemset(d_npast_, 0, 256)); HIP_CHECK(hipMemset(d_argmax_, 0, 256)); HIP_CHECK(hipMemset(d_feed_, 0, 256)); HIP_CHECK(hipMemset(d_btok_, 0, 768));
+    HIP_CHECK(hipMemset(d_tokens_, 0, B * 4));
     HIP_CHECK(hipHostMalloc((void **)&h_argmax_, 256, hipHostMallocDefault));
-    HIP_CHECK(hipHostMalloc((void **)&h_bstage_, 512, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&h_bstage_, 768, hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **)&h_logits_, V * 4, hipHostMallocDefault));
     memset(h_argmax_, 0, 256);
     // vision
@@ -509,23 +512,50 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s) {
 void Engine::forward_batch(int B, hipStream_t s) {
     const int E = (int)llm_.n_embd, F = (int)llm_.n_ff(), H = (int)llm_.n_head, hd = E / H, V = (int)llm_.n_vocab;
     const size_t C = (size_t)n_ctx_, seq_stride = layers_.size() * C * (size_t)E;
+    // y_m[t][r] = W_m[r] . act[t] (+ res_m[t][r]) for n matrices that share the prepared rows.  Up to batch_rows_max_ rows go through the pipelined multi-row
+    // mat-vec in passes of 4 rows (weights streamed once per pass); larger batches / other types through launch_mul_mat (int8-MFMA tiles from 5 rows).
+    auto mm = [&](std::initializer_list<const QWeight *> Ws, std::initializer_list<float *> ys, const float *res0, int ld) {
+        const int n = (int)Ws.size();
+        const QWeight *W[3]; float *y[3]; const float *r[3];
+        int i = 0; for (const QWeight *w : Ws) W[i++] = w;
+        i = 0; for (float *p : ys) { y[i] = p; r[i] = res0; i++; }
+        bool same = true; for (int k = 1; k < n; k++) same = same && W[k]->type == W[0]->type && W[k]->rows == W[0]->rows && W[k]->cols == W[0]->cols;
+        if (same && B <= batch_rows_max_) {
+            bool ok = true;
+            for (int t0 = 0; t0 < B && ok; t0 += 4) {
+                const int K = W[0]->cols;
+                ActQ A = act_;
+                A.q8k += (size_t)t0 * K; A.dk += (size_t)t0 * (K / 256); A.bsk += (size_t)t0 * (K / 16); A.q80 += (size_t)t0 * K;
+                A.d0 += (size_t)t0 * (K / 32); A.d1 += (size_t)t0 * (K / 32); A.s1 += (size_t)t0 * (K / 32); A.sum0 += (size_t)t0 * (K / 32);
+                float *yo[3]; const float *ro[3];
+                for (int k = 0; k < n; k++) { yo[k] = y[k] + (size_t)t0 * ld; ro[k] = r[k] ? r[k] + (size_t)t0 * ld : nullptr; }
+                ok = launch_matvec_rows(W, yo, res0 ? ro : nullptr, n, A, std::min(4, B - t0), ld, s);
+                if (!ok && t0) throw HipError{hipErrorInvalidValue, "multi-row mat-vec refused a later pass", __FILE__, __LINE__};
+            }
+            if (ok) return;
+        }
+        for (int k = 0; k < n; k++) launch_mul_mat(*W[k], act_, B, y[k], ld, r[k], s);
+    };
     launch_get_rows(tok_type_, tok_raw_, E, d_btok_, B, x_, s);
     for (size_t il = 0; il < layers_.size(); il++) {
         const LayerW &L = layers_[il];
         __half *kc = kc_ + il * C * E, *vc = vc_ + il * C * E;            // conversation 0's layer; the kernel adds slot * seq_stride
         launch_rms_quant(x_, L.attn_norm, B, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s);
-        launch_mul_mat(L.wq, act_, B, q_, E, nullptr, s); launch_mul_mat(L.wk, act_, B, k_, E, nullptr, s); launch_mul_mat(L.wv, act_, B, v_, E, nullptr, s);
+        if (L.wv.type == L.wq.type && L.wk.type == L.wq.type) mm({&L.wq, &L.wk, &L.wv}, {q_, k_, v_}, nullptr, E);
+        else if (L.wk.type == L.wq.type) { mm({&L.wq, &L.wk}, {q_, k_}, nullptr, E); mm({&L.wv}, {v_}, nullptr, E); }
+        else { mm({&L.wq}, {q_}, nullptr, E); mm({&L.wk}, {k_}, nullptr, E); mm({&L.wv}, {v_}, nullptr, E); }
         launch_attn_llm_batched(q_, k_, v_, kc, vc, B, H, hd, d_npast_, d_bslot_, seq_stride, n_ctx_, cos_, sin_, tabs_, att_, s);
         launch_silu_mul_quant(att_, nullptr, B, E, act_, act_mask_for(L.wo.type), tabs_, s);
-        launch_mul_mat(L.wo, act_, B, x_, E, x_, s);
+        mm({&L.wo}, {x_}, x_, E);
         launch_rms_quant(x_, L.ffn_norm, B, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s);
-        launch_mul_mat(L.w1, act_, B, h1_, F, nullptr, s); launch_mul_mat(L.w3, act_, B, h3_, F, nullptr, s);
+        if (L.w1.type == L.w3.type) mm({&L.w1, &L.w3}, {h1_, h3_}, nullptr, F);
+        else { mm({&L.w1}, {h1_}, nullptr, F); mm({&L.w3}, {h3_}, nullptr, F); }
         launch_silu_mul_quant(h1_, h3_, B, F, act_, act_mask_for(L.w2.type), tabs_, s);
-        launch_mul_mat(L.w2, act_, B, x_, E, x_, s);
+        mm({&L.w2}, {x_}, x_, E);
     }
     launch_rms_quant(x_, norm_, B, E, act_, act_mask_for(output_.type), s);
-    launch_mul_mat(output_, act_, B, blogits_, V, nullptr, s);
-    launch_batch_finish(blogits_, V, B, d_bslot_, d_npast_, d_argmax_, d_feed_, s);
+    mm({&output_}, {blogits_}, nullptr, V);
+    launch_batch_finish(blogits_, V, B, d_bslot_, d_npast_, d_argmax_, d_feed_, logits_, s);
 }
 
 // Evaluate one chunk of N rows of the selected conversation at its position n_committed.  row_tok[i] >= 0: token id; -1: the next packed embedding row of `embd`.
@@ -707,19 +737,27 @@ int Engine::decode_batch(const int *slots, int n, const SampleParams &p, int *id
     for (int i = 0; i < n; i++) {
         Conversation &cv = conv_[(size_t)slots[i]];
         if (cv.n_past + 1 > n_ctx_) continue;                               // context full: sampled, not advanced
-        h_bstage_[B] = ids_out[i]; h_bstage_[MAX_CONVERSATIONS + B] = slots[i]; B++;
+        h_bstage_[B] = ids_out[i]; h_bstage_[MAX_CONVERSATIONS + B] = slots[i]; h_bstage_[2 * MAX_CONVERSATIONS + B] = cv.n_committed; B++;
     }
     if (!B) return 0;
-    HIP_CHECK(hipMemcpyAsync(d_btok_, h_bstage_, (size_t)B * 4, hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(d_bslot_, h_bstage_ + MAX_CONVERSATIONS, (size_t)B * 4, hipMemcpyHostToDevice, stream_));
-    // the device positions of these conversations are current (k_advance / k_batch_finish keep them), but a reset or a failed flush may have
-    // moved the host's view: write them explicitly, like eval_chunk does
-    for (int r = 0; r < B; r++) launch_set_int(d_npast_ + h_bstage_[MAX_CONVERSATIONS + r], conv_[(size_t)h_bstage_[MAX_CONVERSATIONS + r]].n_committed, stream_);
-    forward_batch(B, stream_);
-    const size_t V = llm_.n_vocab;
+    // rows (token, conversation, position) travel in one copy; the device positions are normally current (k_advance / k_batch_finish keep them), but a
+    // reset may have moved the host's view, so k_batch_begin writes them like eval_chunk does
+    HIP_CHECK(hipMemcpyAsync(d_btok_, h_bstage_, 768, hipMemcpyHostToDevice, stream_));
+    launch_batch_begin(d_npast_, d_bslot_, d_bpos_, B, stream_);
+    if (use_graph_) {   // the step for B rows as one hipGraph: the rows live in device memory, so the same graph serves every set of B conversations
+        hipGraphExec_t &ge = batch_graph_[(size_t)B];
+        if (!ge) {
+            hipGraph_t g = nullptr;
+            HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+            forward_batch(B, stream_);
+            HIP_CHECK(hipStreamEndCapture(stream_, &g));
+            HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(g));
+        }
+        HIP_CHECK(hipGraphLaunch(ge, stream_));
+    } else forward_batch(B, stream_);
     for (int r = 0; r < B; r++) {
         const int sl = h_bstage_[MAX_CONVERSATIONS + r];
-        HIP_CHECK(hipMemcpyAsync(logits_ + (size_t)sl * V, blogits_ + (size_t)r * V, V * 4, hipMemcpyDeviceToDevice, stream_));
         Conversation &cv = conv_[(size_t)sl];
         cv.n_past += 1; cv.n_committed += 1;
         if (logits_host_slot_ == sl) logits_host_slot_ = -1;

@@ -127,9 +127,11 @@ private:
     // per conversation (indexed by slot): position, greedy token of the last evaluation, next input token; logits_ is [slots][n_vocab]
     int *d_npast_ = nullptr, *d_argmax_ = nullptr, *d_feed_ = nullptr;
     int *d_tokens_ = nullptr; void *d_scratch_ = nullptr;
-    int *d_btok_ = nullptr, *d_bslot_ = nullptr; float *blogits_ = nullptr;   // batched decode: row tokens / row conversations / [rows][n_vocab] logits
+    int *d_btok_ = nullptr, *d_bslot_ = nullptr, *d_bpos_ = nullptr; float *blogits_ = nullptr;   // batched decode: row tokens / conversations / positions (one 768-byte slab), [rows][n_vocab] logits
+    std::vector<hipGraphExec_t> batch_graph_;                             // [B]: the batched step for B rows (rows are described in device memory, so one graph serves any slot set)
     int *h_argmax_ = nullptr, *h_bstage_ = nullptr; float *h_logits_ = nullptr; int logits_host_slot_ = -1;
     bool use_graph_ = true, use_v2_ = true;
+    int batch_rows_max_ = 8;                                              // MINIGPT4_BATCH_ROWS_MAX: batches up to this size use the multi-row mat-vec (passes of 4 rows); 0 = never
     static constexpr int FUSE_DEFAULT = 87; int fuse_mask_ = FUSE_DEFAULT;
     // profiling
     bool prof_on_ = false;

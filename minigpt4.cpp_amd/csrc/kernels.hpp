@@ -35,6 +35,9 @@ void set_mmq_enabled(int v);
 bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s, int pro = 0, const float *px = nullptr,
                        const float *pw = nullptr, const Tables *tb = nullptr, int epi = 0);   // epi 1: y[0][g] = silu(W0[g].x) * (W1[g].x) (n == 2)
 bool matvec_silu_pair_supported(int type, int cols);
+// batched decode: N = 1..4 activation rows (prepared in `A`) against 1..3 same-type, same-shape, equally spaced matrices, weights streamed once;
+// y[m][t * ldy + r] (+ residual[m][t * ldy + r]).  false -> outside the kernel's range, use launch_mul_mat.
+bool launch_matvec_rows(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s);
 // two k-quant types (Q4_K|Q5_K + Q6_K) with the same K in one launch; pro: 0 or 1 (rms_norm prologue)
 bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, hipStream_t s, int pro = 0,
                          const float *px = nullptr, const float *pw = nullptr);
@@ -56,8 +59,9 @@ void launch_attn_llm(float *q, const float *k, const float *v, __half *kcache, _
 // kcache / vcache + row_slot[t] * seq_stride elements.
 void launch_attn_llm_batched(float *q, const float *k, const float *v, __half *kcache, __half *vcache, int B, int n_head, int hd, const int *n_past, const int *row_slot,
                              size_t seq_stride, int n_ctx, const float *cos_tab, const float *sin_tab, const Tables &tb, float *out, hipStream_t s);
-// per row r: argmax[slot] = feed[slot] = argmax(logits[r]), n_past[slot] += 1 with slot = row_slot[r]
-void launch_batch_finish(const float *logits, int n_vocab, int B, const int *row_slot, int *n_past, int *argmax, int *feed, hipStream_t s);
+// per row r, slot = row_slot[r]: argmax[slot] = feed[slot] = argmax(logits[r]); slot_logits[slot] = logits[r]; n_past[slot] += 1
+void launch_batch_finish(const float *logits, int n_vocab, int B, const int *row_slot, int *n_past, int *argmax, int *feed, float *slot_logits, hipStream_t s);
+void launch_batch_begin(int *n_past, const int *row_slot, const int *row_pos, int B, hipStream_t s);   // n_past[row_slot[r]] = row_pos[r]
 bool attn_head_size_supported(int hd);
 void launch_argmax(const float *logits, int n, int *out, void *scratch /*>= 512 bytes*/, hipStream_t s);
 void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);

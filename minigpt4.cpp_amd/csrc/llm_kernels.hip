@@ -747,6 +747,155 @@ bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *co
     }
 }
 
+// =====================================================================================================================
+// Batched decode mat-vec (B conversations, one row each): the same persistent-wave two-stage weight pipeline as k_matvec_v2, for up to TN
+// activation rows.  The weights are streamed ONCE; every weight unit is multiplied against the matching activation unit of each row.  The
+// quantised activation rows (prepared by k_rms_quant / k_silu_mul_quant) are copied into LDS once per workgroup -- one fat workgroup per CU --
+// and read from there inside the loop (registers could hold only K <= 6144 for four rows; LDS traffic is ~1/4 of its bandwidth at HBM speed).
+// Per row the arithmetic is exactly the single-row kernel's: the same unit dot products, the same per-lane fma order, the same wave reduction.
+// =====================================================================================================================
+template <int T> constexpr bool tr_is_kquant() { return T == GT_Q4_K || T == GT_Q5_K || T == GT_Q6_K; }
+static size_t mv_tn_lds(int type, int K, int TN) {
+    const bool kq = type == GT_Q4_K || type == GT_Q5_K || type == GT_Q6_K;
+    const size_t per_row = kq ? (size_t)K + (size_t)(K / 256) * 4 + (size_t)(K / 16) * 2 : (size_t)K + (size_t)(K / 32) * 16;
+    return (size_t)TN * per_row + 64;
+}
+template <int NU> constexpr int mv_tn_threads() { return NU >= 7 ? 256 : 512; }   // widest K: one wave per SIMD (up to 512 VGPRs) -- two would spill Q5_K's weight stages; 4 waves x 7 units keep as many bytes in flight as 8 x 3
+template <int T, int NU, int TN>
+__global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet ms, const ActQ A, const int N, const int ldy, const int n_groups, const int n_waves) {
+    using X = Tr<T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_tn[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int K = ms.w0.cols, U = K / X::EPU, rows_each = ms.rows_each, total_rows = ms.n * rows_each;
+    int uc[NU]; bool ok[NU];
+#pragma unroll
+    for (int i = 0; i < NU; i++) { const int u = lane + 64 * i; ok[i] = u < U; uc[i] = ok[i] ? u : 0; }
+    struct Grp { typename X::WU w[NU]; float res[TN]; };
+    const bool has_res = ms.res0 != nullptr;
+    const float *res_base = has_res ? ms.res0 : ms.y0;
+    const long long res_stride = has_res ? ms.dres : ms.dy;
+    auto fetch = [&](int g, Grp &G) {           // every load unconditional (clamped indices): see matvec_run
+        const int row = min(g, total_rows - 1);
+        const bool m1 = row >= rows_each, m2 = row >= 2 * rows_each;
+        const int lr = row - (m2 ? 2 * rows_each : (m1 ? rows_each : 0));
+        const long long d = m2 ? 2 * ms.dmat : (m1 ? ms.dmat : 0ll);
+        QWeight W = ms.w0;
+        W.qs += d; W.qh += d; W.sc += d; W.d += d;
+        WBuf B;
+        X::mkb(W, (size_t)lr * U, B);
+#pragma unroll
+        for (int i = 0; i < NU; i++) X::loadb(B, uc[i], G.w[i]);
+        const float *rb = res_base + (m2 ? 2 * res_stride : (m1 ? res_stride : 0ll)) + lr;
+#pragma unroll
+        for (int t = 0; t < TN; t++) G.res[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mkbuf(reinterpret_cast<const uint8_t *>(rb + (size_t)min(t, N - 1) * ldy)), 0, 0, 0));
+    };
+    Grp cur, nxt;
+    fetch(wave, cur);
+    // LDS image of the N activation rows, laid out like the global ActQ planes (so Tr<T>::loada indexes it unchanged)
+    ActQ L;
+    {
+        unsigned char *p = smem_tn;
+        const int nthr = (int)blockDim.x, tid = (int)threadIdx.x;
+        auto copy16 = [&](void *dst, const void *src, size_t bytes) {      // bytes is a multiple of 16 for every plane x row count used here, except the tails handled below
+            const size_t n16 = bytes / 16;
+            for (size_t i = (size_t)tid; i < n16; i += (size_t)nthr) reinterpret_cast<int4 *>(dst)[i] = reinterpret_cast<const int4 *>(src)[i];
+            for (size_t i = n16 * 16 + (size_t)tid; i < bytes; i += (size_t)nthr) reinterpret_cast<unsigned char *>(dst)[i] = reinterpret_cast<const unsigned char *>(src)[i];
+        };
+        if (tr_is_kquant<T>()) {
+            L.q8k = reinterpret_cast<int8_t *>(p); p += (size_t)TN * K;
+            L.dk = reinterpret_cast<float *>(p); p += (size_t)TN * (K / 256) * 4;
+            L.bsk = reinterpret_cast<int16_t *>(p);
+            copy16(L.q8k, A.q8k, (size_t)N * K); copy16(L.dk, A.dk, (size_t)N * (K / 256) * 4); copy16(L.bsk, A.bsk, (size_t)N * (K / 16) * 2);
+        } else {
+            L.q80 = reinterpret_cast<int8_t *>(p); p += (size_t)TN * K;
+            L.d0 = reinterpret_cast<float *>(p); p += (size_t)TN * (K / 32) * 4;
+            L.d1 = reinterpret_cast<float *>(p); p += (size_t)TN * (K / 32) * 4;
+            L.s1 = reinterpret_cast<float *>(p); p += (size_t)TN * (K / 32) * 4;
+            L.sum0 = reinterpret_cast<int *>(p);
+            copy16(L.q80, A.q80, (size_t)N * K); copy16(L.d0, A.d0, (size_t)N * (K / 32) * 4); copy16(L.d1, A.d1, (size_t)N * (K / 32) * 4);
+            copy16(L.s1, A.s1, (size_t)N * (K / 32) * 4); copy16(L.sum0, A.sum0, (size_t)N * (K / 32) * 4);
+        }
+    }
+    __syncthreads();
+    auto consume = [&](int g, const Grp &G) {
+        float out[TN];
+#pragma unroll
+        for (int t = 0; t < TN; t++) out[t] = 0.0f;
+        // unit-major: the decoded weight unit (nibble / high-bit unpacking, scale extraction) is shared by the TN rows; per row the units are still
+        // accumulated in index order, like the single-row kernel
+#pragma unroll
+        for (int i = 0; i < NU; i++) {
+#pragma unroll
+            for (int t = 0; t < TN; t++) { typename X::AU a; X::loada(L, min(t, N - 1), K, uc[i], a); float c = out[t]; X::dot(G.w[i], a, c); out[t] = ok[i] ? c : out[t]; }
+        }
+#pragma unroll
+        for (int t = 0; t < TN; t++) out[t] = wave_sum(out[t]);
+        if (lane == 0 && g < total_rows) {
+            const int m = g >= 2 * rows_each ? 2 : (g >= rows_each ? 1 : 0), lr = g - m * rows_each;
+            float *yo = ms.y0 + (long long)m * ms.dy + lr;
+#pragma unroll
+            for (int t = 0; t < TN; t++) if (t < N) yo[(size_t)t * ldy] = has_res ? out[t] + G.res[t] : out[t];
+        }
+    };
+    for (int g = wave; g < n_groups;) {
+        fetch(g + n_waves, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(g, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        g += n_waves;
+        if (g >= n_groups) break;
+        fetch(g + n_waves, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(g, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        g += n_waves;
+    }
+}
+template <int T, int NU>
+static void launch_tn_t(const MatSet &ms, const ActQ &A, int N, int ldy, hipStream_t s) {
+    constexpr int TN = 4;
+    const int n_groups = ms.n * ms.rows_each;
+    constexpr int WPB = mv_tn_threads<NU>() / 64;
+    const int n_blocks = std::min((n_groups + WPB - 1) / WPB, g_mv_cus), n_waves = n_blocks * WPB;
+    const size_t lds = mv_tn_lds(T, ms.w0.cols, TN);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((k_matvec_tn<T, NU, TN>), dim3((unsigned)n_blocks), dim3((unsigned)mv_tn_threads<NU>()), lds, s, ms, A, N, ldy, n_groups, n_waves);
+}
+template <int T>
+static bool launch_tn_type(const MatSet &ms, const ActQ &A, int N, int ldy, hipStream_t s) {
+    const int nu = (ms.w0.cols / Tr<T>::EPU + 63) / 64;
+    switch (nu) {
+    case 1: launch_tn_t<T, 1>(ms, A, N, ldy, s); return true;
+    case 2: launch_tn_t<T, 2>(ms, A, N, ldy, s); return true;
+    case 3: launch_tn_t<T, 3>(ms, A, N, ldy, s); return true;
+    case 4: launch_tn_t<T, 4>(ms, A, N, ldy, s); return true;
+    case 5: launch_tn_t<T, 5>(ms, A, N, ldy, s); return true;
+    case 6: launch_tn_t<T, 6>(ms, A, N, ldy, s); return true;
+    case 7: launch_tn_t<T, 7>(ms, A, N, ldy, s); return true;
+    default: return false;
+    }
+}
+// 2..4 activation rows against 1..3 same-type, same-shape, equally spaced matrices in ONE weight pass: y[m][t * ldy + r] = W_m[r] . act[t] (+ residual[m][t * ldy + r]).
+// false -> shape / type outside the kernel's range (the caller falls back to launch_mul_mat per matrix).
+bool launch_matvec_rows(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s) {
+    if (N < 1 || N > 4 || !matvec_prologue_supported(W[0]->type, W[0]->cols)) return false;
+    if (mv_tn_lds(W[0]->type, W[0]->cols, 4) > 150 * 1024) return false;
+    MatSet ms;
+    if (!fill_matset(ms, W, y, residual, n)) return false;
+    switch (W[0]->type) {
+    case GT_Q4_0: return launch_tn_type<GT_Q4_0>(ms, A, N, ldy, s);
+    case GT_Q4_1: return launch_tn_type<GT_Q4_1>(ms, A, N, ldy, s);
+    case GT_Q5_0: return launch_tn_type<GT_Q5_0>(ms, A, N, ldy, s);
+    case GT_Q5_1: return launch_tn_type<GT_Q5_1>(ms, A, N, ldy, s);
+    case GT_Q4_K: return launch_tn_type<GT_Q4_K>(ms, A, N, ldy, s);
+    case GT_Q5_K: return launch_tn_type<GT_Q5_K>(ms, A, N, ldy, s);
+    case GT_Q6_K: return launch_tn_type<GT_Q6_K>(ms, A, N, ldy, s);
+    default: return false;
+    }
+}
+
 static int g_mmq_enabled = 1;
 void set_mmq_enabled(int v) { g_mmq_enabled = v; }
 // Unquantised (F16) weights, prefill: ggml converts the activation rows to fp16 and accumulates exact fp16 products in fp32 (ggml_vec_dot_f16) -- which is
@@ -1143,11 +1292,12 @@ void launch_set_int(int *p, int v, hipStream_t s) { hipLaunchKernelGGL(k_set_int
 // Batched decode epilogue, one workgroup per row: greedy argmax of the row's logits (first maximum wins), stored with the logits' owner slot; the
 // conversation's position advances by one and the greedy token becomes its next input.
 __global__ __launch_bounds__(256) void k_batch_finish(const float *__restrict__ logits, int n_vocab, const int *__restrict__ row_slot, int *__restrict__ n_past, int *__restrict__ argmax,
-                                                      int *__restrict__ feed) {
+                                                      int *__restrict__ feed, float *__restrict__ slot_logits) {
     const int r = blockIdx.x, slot = row_slot[r];
     const float *x = logits + (size_t)r * n_vocab;
+    float *keep = slot_logits + (size_t)slot * n_vocab;                   // the conversation's own copy (sampling with temp > 0, minigpt4_amd_get_logits)
     float best = -INFINITY; int bi = 0x7FFFFFFF;
-    for (int i = threadIdx.x; i < n_vocab; i += 256) { const float v = x[i]; if (v > best) { best = v; bi = i; } }
+    for (int i = threadIdx.x; i < n_vocab; i += 256) { const float v = x[i]; keep[i] = v; if (v > best) { best = v; bi = i; } }
     __shared__ float sv[4]; __shared__ int si[4];
     argmax_wave(best, bi);
     if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
@@ -1158,9 +1308,15 @@ __global__ __launch_bounds__(256) void k_batch_finish(const float *__restrict__ 
         argmax[slot] = id; feed[slot] = id; n_past[slot] += 1;
     }
 }
-void launch_batch_finish(const float *logits, int n_vocab, int B, const int *row_slot, int *n_past, int *argmax, int *feed, hipStream_t s) {
-    hipLaunchKernelGGL(k_batch_finish, dim3((unsigned)B), dim3(256), 0, s, logits, n_vocab, row_slot, n_past, argmax, feed);
+void launch_batch_finish(const float *logits, int n_vocab, int B, const int *row_slot, int *n_past, int *argmax, int *feed, float *slot_logits, hipStream_t s) {
+    hipLaunchKernelGGL(k_batch_finish, dim3((unsigned)B), dim3(256), 0, s, logits, n_vocab, row_slot, n_past, argmax, feed, slot_logits);
 }
+// batched decode prologue: the host's view of each row's position (a conversation may have been reset) -> n_past[slot]
+__global__ void k_batch_begin(int *__restrict__ n_past, const int *__restrict__ row_slot, const int *__restrict__ row_pos, int B) {
+    const int r = threadIdx.x;
+    if (r < B) n_past[row_slot[r]] = row_pos[r];
+}
+void launch_batch_begin(int *n_past, const int *row_slot, const int *row_pos, int B, hipStream_t s) { hipLaunchKernelGGL(k_batch_begin, dim3(1), dim3(64), 0, s, n_past, row_slot, row_pos, B); }
 // end of a decode step: the KV position advances and the greedy token becomes the next input (the host may overwrite it)
 __global__ void k_advance(int *n_past, int n, int *tok0, const int *argmax) { *n_past += n; if (tok0) *tok0 = *argmax; }
 void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, n_past, n, tok0, argmax); }

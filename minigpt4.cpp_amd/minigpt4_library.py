@@ -121,6 +121,7 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_weight_arena.argtypes = [VOID_PTR, I32, P(VOID_PTR), P(SIZE_T)]
         L.minigpt4_amd_test_mul_mat.argtypes = [I32, VOID_PTR, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, ctypes.c_int64, FLOAT_PTR]
         L.minigpt4_amd_test_matvec.argtypes = [I32, VOID_PTR, I32, I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, FLOAT_PTR, I32, I32, I32, FLOAT_PTR, FLOAT_PTR]
+        L.minigpt4_amd_test_matvec_rows.argtypes = [I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, I32, FLOAT_PTR, FLOAT_PTR]
         L.minigpt4_amd_test_quantize.argtypes = [FLOAT_PTR, FLOAT_PTR, ctypes.c_int64, ctypes.c_int64, VOID_PTR, VOID_PTR, VOID_PTR, VOID_PTR, VOID_PTR]
         L.minigpt4_amd_test_gemm_f16.argtypes = [FLOAT_PTR, FLOAT_PTR, FLOAT_PTR, I32, I32, I32, I32, FLOAT_PTR]
         L.minigpt4_amd_vocab_load.argtypes = [CHAR_PTR]
@@ -313,6 +314,18 @@ class MiniGPT4SharedLibrary:
                                                    None if res is None else res.ctypes.data_as(FLOAT_PTR), y.ctypes.data_as(FLOAT_PTR))
         if rc:
             raise RuntimeError(f"test_matvec rc={rc}: " + self.library.minigpt4_amd_last_error().decode())
+        return y
+
+    def amd_test_matvec_rows(self, ggml_type: int, raw_w: np.ndarray, n_mat: int, n_in: int, n_out: int, x: np.ndarray, residual: Optional[np.ndarray] = None) -> np.ndarray:
+        """The batched-decode mat-vec: x [N][n_in] (N <= 4) against n_mat matrices in one weight pass -> [n_mat][N][n_out]."""
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, n_in)
+        raw_w = np.ascontiguousarray(raw_w)
+        res = None if residual is None else np.ascontiguousarray(residual, np.float32)
+        y = np.empty((n_mat, x.shape[0], n_out), np.float32)
+        rc = self.library.minigpt4_amd_test_matvec_rows(ggml_type, raw_w.ctypes.data_as(VOID_PTR), n_mat, n_in, n_out, x.ctypes.data_as(FLOAT_PTR), x.shape[0],
+                                                        None if res is None else res.ctypes.data_as(FLOAT_PTR), y.ctypes.data_as(FLOAT_PTR))
+        if rc:
+            raise RuntimeError(f"test_matvec_rows rc={rc}: " + self.library.minigpt4_amd_last_error().decode())
         return y
 
     def amd_test_quantize(self, x: np.ndarray, rms_w: Optional[np.ndarray] = None):

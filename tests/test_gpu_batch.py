@@ -9,6 +9,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+LOGIT_TOL = 5e-2   # the whole-model bar of tests/test_gpu_parity.py
+
 PROMPTS = [b"what is the text in the picture?", b"describe the colours", b"hello", b"and now something longer to shift the positions apart", b"a", b"b c d", b"zzz", b"tell me more"]
 
 
@@ -49,8 +51,22 @@ def test_batched_greedy_equals_independent_oracle_chats(gpu_lib, tiny_files, wty
             for s, piece in enumerate(gpu_lib.amd_end_chat_batch(ctx, list(range(B)), temp=0.0)):
                 got[s].append(piece)
         chats = oracle_chats(lp, prompts, 256)
-        want = [[c.end_chat(temp=0.0)[1].decode("utf-8", errors="replace") for _ in range(6)] for c in chats]
-        assert got == want
+        exact = 0
+        for s, c in enumerate(chats):
+            # The reference arithmetic rounds every activation row to int8, so fp32 summation-order noise can move logits by ~1e-2 of their range
+            # (DESIGN.md "Whole-model tolerance"): a conversation may leave the oracle's greedy path only at a step where the oracle's own top-2 margin
+            # is inside that noise; after such a step the two are different conversations and are not compared further.
+            diverged = False
+            for i in range(6):
+                lg = c.llm.logits
+                srt = np.sort(lg)
+                margin = float((srt[-1] - srt[-2]) / (np.abs(lg).max() + 1e-30))
+                want = c.end_chat(temp=0.0)[1].decode("utf-8", errors="replace")
+                if not diverged and got[s][i] != want:
+                    assert margin <= LOGIT_TOL, (s, i, got[s], want, margin)
+                    diverged = True
+            exact += not diverged
+        assert exact * 2 >= B, (exact, B)                  # near-ties are the exception, not the rule
         for s in range(B):                                 # positions advanced per conversation
             gpu_lib.amd_select_conversation(ctx, s)
             assert gpu_lib.library.minigpt4_amd_n_past(ctx.ptr) == chats[s].llm.n_past
@@ -186,3 +202,30 @@ def test_seeded_sampling_in_a_batch_uses_the_host_sampler_per_conversation(gpu_l
         assert pieces[0] == want
     finally:
         gpu_lib.minigpt4_free(ctx)
+
+
+# (type, K): K / 32 / 64 = units per lane 1, 2, 3, 6, 7 -> every register tiling of k_matvec_tn (7: the 4-wave variant); both activation formats (Q8_0 / Q8_K)
+ROWS_CASES = [("q4_0", 512), ("q5_k", 512), ("q4_1", 4096), ("q4_k", 4096), ("q5_0", 5120), ("q5_k", 5120), ("q6_k", 5120), ("q5_1", 5120), ("q4_0", 11008), ("q5_k", 13824), ("q6_k", 13824)]
+
+
+@pytest.mark.parametrize("wtype,K", ROWS_CASES)
+@pytest.mark.parametrize("N,n_mat,with_res", [(1, 1, True), (2, 3, False), (3, 2, False), (4, 1, True), (4, 3, False)])
+def test_multi_row_matvec_matches_oracle(gpu_lib, wtype, K, N, n_mat, with_res):
+    """k_matvec_tn against the oracle's quantise + mul_mat, row by row: integer block dots exact, fp32 order differs -> 2e-5 of the row maximum (the bar of
+    test_mul_mat_matches_oracle); rows > waves so that every wave pipelines several groups; ragged row counts."""
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    t = Q.NAME_TO_TYPE[wtype]
+    rng = np.random.default_rng(K * 11 + N * 5 + n_mat + sum(map(ord, wtype)))
+    rows = 2300 if K <= 5120 else 1100
+    w = (0.03 * rng.standard_normal((n_mat * rows, K))).astype(np.float32)
+    raw = Q.quantize(t, w)
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    x[0, :min(K, 256)] = 0.0                                  # an all-zero activation block
+    res = rng.standard_normal((n_mat, N, rows)).astype(np.float32) if with_res else None
+    got = gpu_lib.amd_test_matvec_rows(t, raw, n_mat, K, rows, x, res)
+    want = R.mul_mat(t, raw, K, n_mat * rows, x).reshape(N, n_mat, rows).transpose(1, 0, 2)
+    if res is not None:
+        want = want + res
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), (wtype, K, N, n_mat)
