@@ -211,16 +211,33 @@ double minigpt4_amd_weight_bytes_per_token(struct MiniGPT4Context *ctx) { return
 float minigpt4_amd_last_encode_ms(struct MiniGPT4Context *ctx) { return ctx ? E_(ctx)->last_encode_ms() : 0.0f; }
 int minigpt4_amd_sync(struct MiniGPT4Context *ctx) { if (!ctx) return 1; return guarded(1, [&] { E_(ctx)->sync(); return 0; }); }
 
-int minigpt4_encode_images(struct MiniGPT4Context *ctx, const struct MiniGPT4Images *images, struct MiniGPT4Embeddings *embeddings, size_t n_threads) {
+int minigpt4_encode_images(struct MiniGPT4Context *ctx, const struct MiniGPT4Images *images, struct MiniGPT4Embeddings *embeddings, size_t /*n_threads*/) {
     if (!ctx || !images || !embeddings) return E_ImageSize;
     embeddings->embeddings = new (std::nothrow) MiniGPT4Embedding[images->n_images ? images->n_images : 1]();
     embeddings->n_embeddings = 0;
     if (!embeddings->embeddings) return E_ImageSize;
-    for (size_t i = 0; i < images->n_images; i++) {
-        const int err = minigpt4_encode_image(ctx, &images->images[i], &embeddings->embeddings[i], n_threads);
+    for (size_t i = 0; i < images->n_images; i++) {   // the checks of minigpt4_encode_image (minigpt4.cpp:2130-2138), before any work
+        const MiniGPT4Image &im = images->images[i];
+        const int err = !im.data ? (int)E_ImageSize : (long long)im.width * im.height * im.channels != 224LL * 224 * 3 ? (int)E_ImageNot224_244_3 : im.format != MINIGPT4_IMAGE_FORMAT_F32 ? (int)E_ImageNotF32 : 0;
         if (err) { minigpt4_free_embeddings(embeddings); return err; }
-        embeddings->n_embeddings = i + 1;
     }
+    Engine *e = E_(ctx);
+    const size_t n = (size_t)e->n_query() * e->proj_out();
+    const int err = guarded((int)E_ImageSize, [&]() -> int {
+        for (size_t i0 = 0; i0 < images->n_images; i0 += Engine::VISION_BATCH_MAX) {   // passes of up to 8 images over the vision weights
+            const int B = (int)std::min<size_t>(Engine::VISION_BATCH_MAX, images->n_images - i0);
+            const float *in[Engine::VISION_BATCH_MAX]; float *out[Engine::VISION_BATCH_MAX];
+            for (int b = 0; b < B; b++) {
+                in[b] = static_cast<const float *>(images->images[i0 + (size_t)b].data);
+                out[b] = new float[n];
+                embeddings->embeddings[i0 + (size_t)b].data = out[b]; embeddings->embeddings[i0 + (size_t)b].elements = n;
+                embeddings->n_embeddings = i0 + (size_t)b + 1;
+            }
+            if (int rc = e->encode_images(in, B, out)) return rc;
+        }
+        return E_None;
+    });
+    if (err) { minigpt4_free_embeddings(embeddings); return err; }
     return E_None;
 }
 int minigpt4_free_embeddings(struct MiniGPT4Embeddings *embeddings) {

@@ -346,8 +346,10 @@ void Engine::alloc_buffers() {
     sz(5 * B * E * 4); sz(2 * B * F * 4); sz(S * V * 4); sz(S * V * 4); sz(8 * 256 + 2 * B * 4);
     sz(2 * B * Kmax); sz(B * Kmax / 256 * 4 + 64); sz(B * Kmax / 16 * 2 + 64); sz(4 * (B * Kmax / 32 * 4 + 64)); sz(B * Kmax * 2); sz(B * Kmax * 4);
     sz(4096);
-    sz(3 * 224 * 224 * 4); sz(256 * 592 * 2); sz(256 * D * 4); sz(257 * D * 4); sz(257 * 3 * D * 4); sz(3 * 257 * D * 2); sz(257 * M * 2); sz((size_t)SPLITK_MAX * 257 * D * 4);
-    sz(8 * NQ * 2304 * 4); sz(257 * 1536 * 4); sz(NQ * (size_t)std::max(v_qi_, 768) * 2 * 4); sz(NQ * (size_t)v_out_ * 4); sz(1 << 20);
+    const size_t VB = (size_t)VISION_BATCH_MAX;                            // images encoded in one pass (minigpt4_encode_images)
+    sz(VB * 3 * 224 * 224 * 4); sz(VB * 256 * 592 * 2); sz(VB * 256 * D * 4); sz(VB * 257 * D * 4); sz(VB * 257 * 3 * D * 4); sz(VB * 3 * 257 * D * 2); sz(VB * 257 * M * 2);
+    sz(VB * (size_t)SPLITK_MAX * 257 * D * 4);
+    sz(VB * 9 * NQ * 2304 * 4); sz(VB * 257 * 1536 * 4); sz(VB * NQ * (size_t)std::max(v_qi_, 768) * 2 * 4); sz(VB * NQ * (size_t)v_out_ * 4); sz(1 << 20);
     buf_arena_.alloc(total);
     auto takef = [&](size_t n) { return reinterpret_cast<float *>(buf_arena_.take(n * 4)); };
     auto takeh = [&](size_t n) { return reinterpret_cast<__half *>(buf_arena_.take(n * 2)); };
@@ -394,12 +396,14 @@ void Engine::alloc_buffers() {
     HIP_CHECK(hipHostMalloc((void **)&h_logits_, V * 4, hipHostMallocDefault));
     memset(h_argmax_, 0, 256);
     // vision
-    vi_img_ = takef(3 * 224 * 224); vi_patches_ = takeh(256 * 592); vi_pe_ = takef(256 * D); vi_x_ = takef(257 * D); vi_qkv_ = takef(257 * 3 * D);
-    vi_slab_ = takef((size_t)SPLITK_MAX * 257 * D);
-    vi_ln_h_ = takeh(257 * D); vi_att_h_ = takeh(257 * D); vi_img_h_ = takeh(257 * D); vi_mlp_h_ = takeh(257 * M);
-    vi_hs_ = takef(NQ * 768); vi_a1_ = takef(NQ * 768); vi_a2_ = takef(NQ * 768); vi_d_ = takef(NQ * 768); vi_qq_ = takef(NQ * 2304); vi_kv_ = takef(257 * 1536);
-    vi_hs_h_ = takeh(NQ * 768); vi_a1_h_ = takeh(NQ * 768); vi_a2_h_ = takeh(NQ * 768); vi_ctx_h_ = takeh(NQ * 768); vi_im_h_ = takeh(NQ * (size_t)v_qi_);
-    vi_out_ = takef(NQ * (size_t)v_out_);
+    vi_img_ = takef(VB * 3 * 224 * 224); vi_patches_ = takeh(VB * 256 * 592); vi_pe_ = takef(VB * 256 * D); vi_x_ = takef(VB * 257 * D); vi_qkv_ = takef(VB * 257 * 3 * D);
+    vi_slab_ = takef(VB * (size_t)SPLITK_MAX * 257 * D);
+    vi_ln_h_ = takeh(VB * 257 * D); vi_att_h_ = takeh(VB * 257 * D); vi_img_h_ = takeh(VB * 257 * D); vi_mlp_h_ = takeh(VB * 257 * M);
+    vi_hs_ = takef(VB * NQ * 768); vi_a1_ = takef(VB * NQ * 768); vi_a2_ = takef(VB * NQ * 768); vi_d_ = takef(VB * NQ * 768); vi_qq_ = takef(VB * NQ * 2304); vi_kv_ = takef(VB * 257 * 1536);
+    vi_hs_h_ = takeh(VB * NQ * 768); vi_a1_h_ = takeh(VB * NQ * 768); vi_a2_h_ = takeh(VB * NQ * 768); vi_ctx_h_ = takeh(VB * NQ * 768); vi_im_h_ = takeh(VB * NQ * (size_t)v_qi_);
+    vi_out_ = takef(VB * NQ * (size_t)v_out_);
+    vi_qtok_rep_ = takef(VB * NQ * 768);                                  // the query tokens once per image of a batch (every image starts from the same rows)
+    for (size_t b = 0; b < VB; b++) HIP_CHECK(hipMemcpy(vi_qtok_rep_ + b * NQ * 768, v_qtok_, NQ * 768 * 4, hipMemcpyDeviceToDevice));
     MG4_INFO("KV cache %.1f MB (fp16, n_ctx %d, %zu conversation%s), activation arena %.1f MB", 2.0 * S * L * C * E * 2 / 1048576.0, n_ctx_, S, S == 1 ? "" : "s", buf_arena_.used / 1048576.0);
 }
 
@@ -769,74 +773,80 @@ int Engine::decode_batch(const int *slots, int n, const SampleParams &p, int *id
 // ====================================================================================================================
 // image path
 // ====================================================================================================================
-int Engine::encode_image(const float *chw, float *out) {
+// B images in ONE pass over the vision weights (B <= VISION_BATCH_MAX): every GEMM / LayerNorm runs on B x 257 (ViT) or B x 32 (Q-Former) rows, attention
+// per image (grid z).  Per output element the arithmetic does not depend on B (one wave accumulates one 32x32 tile over K in a fixed order), so image b of a
+// batch equals the same image encoded alone bit for bit (tests/test_gpu_parity.py::test_batched_image_encode_is_bit_identical).
+int Engine::encode_images(const float *const *chw, int B, float *const *out) {
+    if (B < 1 || B > VISION_BATCH_MAX) { set_last_error("encode_images: batch size out of range"); return E_ImageSize; }
     hipStream_t s = stream_;
     const int D = v_D_, M = v_M_, NQ = v_nq_, H = 768;
+    const int R = B * 257, RQ = B * NQ;                                    // rows of the ViT / Q-Former activations
     hipEvent_t ea, eb; HIP_CHECK(hipEventCreate(&ea)); HIP_CHECK(hipEventCreate(&eb));
-    HIP_CHECK(hipMemcpyAsync(vi_img_, chw, 3 * 224 * 224 * 4, hipMemcpyHostToDevice, s));
+    for (int b = 0; b < B; b++) HIP_CHECK(hipMemcpyAsync(vi_img_ + (size_t)b * 3 * 224 * 224, chw[b], 3 * 224 * 224 * 4, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipStreamSynchronize(s));
     HIP_CHECK(hipEventRecord(ea, s));
     // patch embedding: conv 14x14/14 as an f16 GEMM over im2col'd patches (ggml_conv_2d, minigpt4.cpp:1059) + bias
-    launch_im2col(vi_img_, vi_patches_, 592, s);
-    launch_gemm_f16(vi_patches_, 592, v_patch_w_, 592, 256, D, 592, v_patch_b_, nullptr, false, tabs_, vi_pe_, nullptr, D, s);
-    launch_assemble_embeddings(v_cls_, vi_pe_, v_pos_, D, vi_x_, s);
+    launch_im2col(vi_img_, vi_patches_, 592, s, B);
+    launch_gemm_f16(vi_patches_, 592, v_patch_w_, 592, B * 256, D, 592, v_patch_b_, nullptr, false, tabs_, vi_pe_, nullptr, D, s);
+    launch_assemble_embeddings(v_cls_, vi_pe_, v_pos_, D, vi_x_, s, B);
     const float scale = 1.0f / sqrtf(88.0f);
     // ViT blocks.  attn.proj and mlp.fc2 (N = D: fewer 64x64 tiles than CUs, and fc2 has the longest K) run split-K; their deterministic reduce
     // also adds bias + residual and applies the LayerNorm that follows (norm2, the next block's norm1, ln_vision after the last block).
     const int sp = gemm_split_slices(D, splitk_proj_), sf = gemm_split_slices(M, splitk_fc2_);
-    const size_t slab = (size_t)257 * D;
-    if (!vblocks_.empty()) launch_layernorm(vi_x_, vblocks_[0].n1w, vblocks_[0].n1b, 257, D, nullptr, vi_ln_h_, s);
+    const size_t slab = (size_t)R * D;
+    if (!vblocks_.empty()) launch_layernorm(vi_x_, vblocks_[0].n1w, vblocks_[0].n1b, R, D, nullptr, vi_ln_h_, s);
     for (size_t ib = 0; ib < vblocks_.size(); ib++) {
         const VBlock &b = vblocks_[ib];
         const bool last = ib + 1 == vblocks_.size();
         const float *nw = last ? v_lnv_w_ : vblocks_[ib + 1].n1w, *nb = last ? v_lnv_b_ : vblocks_[ib + 1].n1b;
         __half *nout = last ? vi_img_h_ : vi_ln_h_;
-        launch_gemm_f16(vi_ln_h_, D, b.qkv_w, D, 257, 3 * D, D, b.qkv_b, nullptr, false, tabs_, vi_qkv_, nullptr, 3 * D, s);
-        launch_attn_f32(vi_qkv_, 3 * D, vi_qkv_ + D, vi_qkv_ + 2 * D, 3 * D, 257, 257, v_heads_, 88, scale, 0.0f, tabs_, nullptr, vi_att_h_, D, s);
+        launch_gemm_f16(vi_ln_h_, D, b.qkv_w, D, R, 3 * D, D, b.qkv_b, nullptr, false, tabs_, vi_qkv_, nullptr, 3 * D, s);
+        launch_attn_f32(vi_qkv_, 3 * D, vi_qkv_ + D, vi_qkv_ + 2 * D, 3 * D, 257, 257, v_heads_, 88, scale, 0.0f, tabs_, nullptr, vi_att_h_, D, s, B);
         if (sp > 1) {
-            launch_gemm_f16_splitk(vi_att_h_, D, b.proj_w, D, 257, D, D, sp, vi_slab_, slab, D, s);
-            launch_splitk_reduce_ln(vi_slab_, sp, slab, b.proj_b, vi_x_, 257, D, vi_x_, b.n2w, b.n2b, nullptr, vi_ln_h_, s);
+            launch_gemm_f16_splitk(vi_att_h_, D, b.proj_w, D, R, D, D, sp, vi_slab_, slab, D, s);
+            launch_splitk_reduce_ln(vi_slab_, sp, slab, b.proj_b, vi_x_, R, D, vi_x_, b.n2w, b.n2b, nullptr, vi_ln_h_, s);
         } else {
-            launch_gemm_f16(vi_att_h_, D, b.proj_w, D, 257, D, D, b.proj_b, vi_x_, false, tabs_, vi_x_, nullptr, D, s);
-            launch_layernorm(vi_x_, b.n2w, b.n2b, 257, D, nullptr, vi_ln_h_, s);
+            launch_gemm_f16(vi_att_h_, D, b.proj_w, D, R, D, D, b.proj_b, vi_x_, false, tabs_, vi_x_, nullptr, D, s);
+            launch_layernorm(vi_x_, b.n2w, b.n2b, R, D, nullptr, vi_ln_h_, s);
         }
-        launch_gemm_f16(vi_ln_h_, D, b.fc1_w, D, 257, M, D, b.fc1_b, nullptr, true, tabs_, nullptr, vi_mlp_h_, M, s);
+        launch_gemm_f16(vi_ln_h_, D, b.fc1_w, D, R, M, D, b.fc1_b, nullptr, true, tabs_, nullptr, vi_mlp_h_, M, s);
         if (sf > 1) {
-            launch_gemm_f16_splitk(vi_mlp_h_, M, b.fc2_w, M, 257, D, M, sf, vi_slab_, slab, D, s);
-            launch_splitk_reduce_ln(vi_slab_, sf, slab, b.fc2_b, vi_x_, 257, D, vi_x_, nw, nb, nullptr, nout, s);
+            launch_gemm_f16_splitk(vi_mlp_h_, M, b.fc2_w, M, R, D, M, sf, vi_slab_, slab, D, s);
+            launch_splitk_reduce_ln(vi_slab_, sf, slab, b.fc2_b, vi_x_, R, D, vi_x_, nw, nb, nullptr, nout, s);
         } else {
-            launch_gemm_f16(vi_mlp_h_, M, b.fc2_w, M, 257, D, M, b.fc2_b, vi_x_, false, tabs_, vi_x_, nullptr, D, s);
-            launch_layernorm(vi_x_, nw, nb, 257, D, nullptr, nout, s);
+            launch_gemm_f16(vi_mlp_h_, M, b.fc2_w, M, R, D, M, b.fc2_b, vi_x_, false, tabs_, vi_x_, nullptr, D, s);
+            launch_layernorm(vi_x_, nw, nb, R, D, nullptr, nout, s);
         }
     }
-    if (vblocks_.empty()) launch_layernorm(vi_x_, v_lnv_w_, v_lnv_b_, 257, D, nullptr, vi_img_h_, s);
+    if (vblocks_.empty()) launch_layernorm(vi_x_, v_lnv_w_, v_lnv_b_, R, D, nullptr, vi_img_h_, s);
     // Q-Former (masks are all-zero)
-    launch_layernorm(v_qtok_, v_qeln_w_, v_qeln_b_, NQ, H, vi_hs_, vi_hs_h_, s);
+    launch_layernorm(vi_qtok_rep_, v_qeln_w_, v_qeln_b_, RQ, H, vi_hs_, vi_hs_h_, s);
     for (const QLayer &L : qlayers_) {
-        launch_gemm_f16(vi_hs_h_, H, L.self.q_w, H, NQ, 3 * H, H, L.self.q_b, nullptr, false, tabs_, vi_qq_, nullptr, 3 * H, s);
-        launch_attn_f32(vi_qq_, 3 * H, vi_qq_ + H, vi_qq_ + 2 * H, 3 * H, NQ, NQ, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s);
-        launch_gemm_f16(vi_ctx_h_, H, L.self.dense_w, H, NQ, H, H, L.self.dense_b, vi_hs_, false, tabs_, vi_d_, nullptr, H, s);
-        launch_layernorm(vi_d_, L.self.ln_w, L.self.ln_b, NQ, H, vi_a1_, vi_a1_h_, s);
+        launch_gemm_f16(vi_hs_h_, H, L.self.q_w, H, RQ, 3 * H, H, L.self.q_b, nullptr, false, tabs_, vi_qq_, nullptr, 3 * H, s);
+        launch_attn_f32(vi_qq_, 3 * H, vi_qq_ + H, vi_qq_ + 2 * H, 3 * H, NQ, NQ, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s, B);
+        launch_gemm_f16(vi_ctx_h_, H, L.self.dense_w, H, RQ, H, H, L.self.dense_b, vi_hs_, false, tabs_, vi_d_, nullptr, H, s);
+        launch_layernorm(vi_d_, L.self.ln_w, L.self.ln_b, RQ, H, vi_a1_, vi_a1_h_, s);
         const float *ao = vi_a1_; const __half *ao_h = vi_a1_h_;
         if (L.has_cross) {
-            launch_gemm_f16(vi_a1_h_, H, L.cross.q_w, H, NQ, H, H, L.cross.q_b, nullptr, false, tabs_, vi_qq_, nullptr, H, s);
-            launch_gemm_f16(vi_img_h_, D, L.cross.kv_w, D, 257, 2 * H, D, L.cross.kv_b, nullptr, false, tabs_, vi_kv_, nullptr, 2 * H, s);
-            launch_attn_f32(vi_qq_, H, vi_kv_, vi_kv_ + H, 2 * H, NQ, 257, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s);
-            launch_gemm_f16(vi_ctx_h_, H, L.cross.dense_w, H, NQ, H, H, L.cross.dense_b, vi_a1_, false, tabs_, vi_d_, nullptr, H, s);
-            launch_layernorm(vi_d_, L.cross.ln_w, L.cross.ln_b, NQ, H, vi_a2_, vi_a2_h_, s);
+            launch_gemm_f16(vi_a1_h_, H, L.cross.q_w, H, RQ, H, H, L.cross.q_b, nullptr, false, tabs_, vi_qq_, nullptr, H, s);
+            launch_gemm_f16(vi_img_h_, D, L.cross.kv_w, D, R, 2 * H, D, L.cross.kv_b, nullptr, false, tabs_, vi_kv_, nullptr, 2 * H, s);
+            launch_attn_f32(vi_qq_, H, vi_kv_, vi_kv_ + H, 2 * H, NQ, 257, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s, B);
+            launch_gemm_f16(vi_ctx_h_, H, L.cross.dense_w, H, RQ, H, H, L.cross.dense_b, vi_a1_, false, tabs_, vi_d_, nullptr, H, s);
+            launch_layernorm(vi_d_, L.cross.ln_w, L.cross.ln_b, RQ, H, vi_a2_, vi_a2_h_, s);
             ao = vi_a2_; ao_h = vi_a2_h_;
         }
-        launch_gemm_f16(ao_h, H, L.inter_w, H, NQ, v_qi_, H, L.inter_b, nullptr, true, tabs_, nullptr, vi_im_h_, v_qi_, s);
-        launch_gemm_f16(vi_im_h_, v_qi_, L.out_w, v_qi_, NQ, H, v_qi_, L.out_b, ao, false, tabs_, vi_d_, nullptr, H, s);
-        launch_layernorm(vi_d_, L.oln_w, L.oln_b, NQ, H, vi_hs_, vi_hs_h_, s);
+        launch_gemm_f16(ao_h, H, L.inter_w, H, RQ, v_qi_, H, L.inter_b, nullptr, true, tabs_, nullptr, vi_im_h_, v_qi_, s);
+        launch_gemm_f16(vi_im_h_, v_qi_, L.out_w, v_qi_, RQ, H, v_qi_, L.out_b, ao, false, tabs_, vi_d_, nullptr, H, s);
+        launch_layernorm(vi_d_, L.oln_w, L.oln_b, RQ, H, vi_hs_, vi_hs_h_, s);
     }
-    launch_gemm_f16(vi_hs_h_, H, v_proj_w_, H, NQ, v_out_, H, v_proj_b_, nullptr, false, tabs_, vi_out_, nullptr, v_out_, s);
+    launch_gemm_f16(vi_hs_h_, H, v_proj_w_, H, RQ, v_out_, H, v_proj_b_, nullptr, false, tabs_, vi_out_, nullptr, v_out_, s);
     HIP_CHECK(hipEventRecord(eb, s));
-    HIP_CHECK(hipMemcpyAsync(out, vi_out_, (size_t)NQ * v_out_ * 4, hipMemcpyDeviceToHost, s));
+    for (int b = 0; b < B; b++) HIP_CHECK(hipMemcpyAsync(out[b], vi_out_ + (size_t)b * NQ * v_out_, (size_t)NQ * v_out_ * 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     HIP_CHECK(hipEventElapsedTime(&last_encode_ms_, ea, eb));
     (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
     return E_None;
 }
+int Engine::encode_image(const float *chw, float *out) { return encode_images(&chw, 1, &out); }
 
 }  // namespace mg4

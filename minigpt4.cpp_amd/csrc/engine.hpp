@@ -32,6 +32,8 @@ public:
 
     // ---- image path (reference encode_image, minigpt4.cpp:2094-2363)
     int encode_image(const float *chw, float *out);   // out: [32][proj_out()]
+    int encode_images(const float *const *chw, int B, float *const *out);   // B <= VISION_BATCH_MAX images in one pass over the vision weights
+    static constexpr int VISION_BATCH_MAX = 8;
     int proj_out() const { return v_out_; }
     int n_query() const { return v_nq_; }
 
@@ -150,7 +152,7 @@ private:
     __half *v_patch_w_ = nullptr, *v_proj_w_ = nullptr;
     // vision activations
     static constexpr int SPLITK_MAX = 12; int splitk_proj_ = 1, splitk_fc2_ = 4;   // MINIGPT4_SPLITK=proj,fc2 (1 = off)
-    float *vi_slab_ = nullptr;
+    float *vi_slab_ = nullptr, *vi_qtok_rep_ = nullptr;
     float *vi_img_ = nullptr, *vi_pe_ = nullptr, *vi_x_ = nullptr, *vi_qkv_ = nullptr, *vi_hs_ = nullptr, *vi_a1_ = nullptr, *vi_a2_ = nullptr, *vi_d_ = nullptr, *vi_qq_ = nullptr, *vi_kv_ = nullptr, *vi_out_ = nullptr;
     __half *vi_patches_ = nullptr, *vi_ln_h_ = nullptr, *vi_att_h_ = nullptr, *vi_mlp_h_ = nullptr, *vi_img_h_ = nullptr, *vi_hs_h_ = nullptr, *vi_a1_h_ = nullptr, *vi_a2_h_ = nullptr, *vi_ctx_h_ = nullptr, *vi_im_h_ = nullptr;
     float last_encode_ms_ = 0;

@@ -85,12 +85,13 @@ void launch_splitk_reduce_ln(const float *slabs, int n_slabs, size_t slab_stride
                              const float *ln_b, float *ln_out, __half *ln_out_h, hipStream_t s);
 // f32 attention: q[nq][ldq], k/v[nk][ldk]; per head h the slice [h*hd, (h+1)*hd).  q_prescale != 0: q *= q_prescale first (ViT);
 // score_div != 0: scores /= score_div (BERT).  Output fp32 (nullable) / fp16 (nullable) [nq][ldo].
+// batch > 1: image z uses rows [z * nq, (z + 1) * nq) of q / out and rows [z * nk, (z + 1) * nk) of k / v.
 void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale,
-                     float score_div, const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s);
+                     float score_div, const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s, int batch = 1);
 // image CHW f32 [3][224][224] -> fp16 patches [256][ldp] (k = c*196 + kh*14 + kw, zero padded to ldp)
-void launch_im2col(const float *image, __half *patches, int ldp, hipStream_t s);
+void launch_im2col(const float *image, __half *patches, int ldp, hipStream_t s, int batch = 1);   // batch images back to back -> [batch * 256][ldp]
 // x[0] = cls + pos[0]; x[1+p] = pe[p] + pos[1+p]
-void launch_assemble_embeddings(const float *cls, const float *pe, const float *pos, int D, float *x, hipStream_t s);
+void launch_assemble_embeddings(const float *cls, const float *pe, const float *pos, int D, float *x, hipStream_t s, int batch = 1);
 void launch_f32_to_f16(const float *x, __half *y, size_t n, hipStream_t s);
 
 // ---- image preprocess (image_kernels.hip): Pillow's 8-bit bicubic resample, horizontal then vertical pass, all pointers device ---------------

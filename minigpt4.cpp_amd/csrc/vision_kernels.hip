@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void k_attn_f32(const float *__restrict__ q, i
                                                   float q_prescale, float score_div, const Tables tb, float *__restrict__ out, __half *__restrict__ out_h, int ldo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LDK = HD + 1;
+    { const size_t z = blockIdx.z; q += z * nq * ldq; k += z * nk * ldk; v += z * nk * ldk; if (out) out += z * nq * ldo; if (out_h) out_h += z * nq * ldo; }   // image z of a batch
     float *kv = reinterpret_cast<float *>(smem);            // [nk][HD+1]
     const int nkp = (nk + 3) & ~3;
     float *sc = kv + (size_t)nk * LDK;                        // [16][nkp]
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float *__restrict__ q, 
                                                    float q_prescale, float score_div, const Tables tb, float *__restrict__ out, __half *__restrict__ out_h, int ldo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LDV = HD + 1, DT = (HD + 15) / 16, KS = HD / 4;
+    { const size_t z = blockIdx.z; q += z * nq * ldq; k += z * nk * ldk; v += z * nk * ldk; if (out) out += z * nq * ldo; if (out_h) out_h += z * nq * ldo; }   // image z of a batch
     const int nkp = (nk + 15) & ~15, LS = nkp + 1;
     float *kv = reinterpret_cast<float *>(smem);               // [nkp][LDV]
     float *S = kv + (size_t)nkp * LDV;                           // [32][LS]
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float *__restrict__ q, 
 static int g_attn_mfma = 1;
 void set_attn_mfma(int v) { g_attn_mfma = v; }
 void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale, float score_div,
-                     const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s) {
+                     const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s, int batch) {
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_f32<88>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -406,12 +408,12 @@ void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, in
     const int nkp = (nk + 15) & ~15;
     const size_t lds_m = ((size_t)nkp * (hd + 1) + 32 * (size_t)(nkp + 1)) * 4;
     if (g_attn_mfma && lds_m <= 160 * 1024) {
-        dim3 grid((unsigned)heads, (unsigned)((nq + 31) / 32));
+        dim3 grid((unsigned)heads, (unsigned)((nq + 31) / 32), (unsigned)batch);
         if (hd == 88) hipLaunchKernelGGL((k_attn_mfma<88>), grid, dim3(256), lds_m, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
         else hipLaunchKernelGGL((k_attn_mfma<64>), grid, dim3(256), lds_m, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
         return;
     }
-    dim3 grid((unsigned)heads, (unsigned)((nq + 15) / 16));
+    dim3 grid((unsigned)heads, (unsigned)((nq + 15) / 16), (unsigned)batch);
     const size_t lds = ((size_t)nk * (hd + 1) + 16 * (size_t)((nk + 3) & ~3)) * 4;
     if (hd == 88) hipLaunchKernelGGL((k_attn_f32<88>), grid, dim3(256), lds, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
     else hipLaunchKernelGGL((k_attn_f32<64>), grid, dim3(256), lds, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
@@ -422,23 +424,25 @@ void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, in
 // =====================================================================================================================
 __global__ void k_im2col(const float *__restrict__ img, __half *__restrict__ patches, int ldp) {
     const int p = blockIdx.x, oh = p >> 4, ow = p & 15;
+    img += (size_t)blockIdx.y * 3 * 224 * 224; patches += (size_t)blockIdx.y * 256 * ldp;   // image y of a batch
     for (int kk = threadIdx.x; kk < ldp; kk += blockDim.x) {
         float v = 0.0f;
         if (kk < 588) { const int c = kk / 196, r = kk - c * 196, kh = r / 14, kw = r - kh * 14; v = img[(size_t)c * 224 * 224 + (size_t)(oh * 14 + kh) * 224 + ow * 14 + kw]; }
         patches[(size_t)p * ldp + kk] = __float2half_rn(v);
     }
 }
-void launch_im2col(const float *image, __half *patches, int ldp, hipStream_t s) { hipLaunchKernelGGL(k_im2col, dim3(256), dim3(256), 0, s, image, patches, ldp); }
+void launch_im2col(const float *image, __half *patches, int ldp, hipStream_t s, int batch) { hipLaunchKernelGGL(k_im2col, dim3(256, (unsigned)batch), dim3(256), 0, s, image, patches, ldp); }
 
 __global__ void k_assemble(const float *__restrict__ cls, const float *__restrict__ pe, const float *__restrict__ pos, int D, float *__restrict__ x) {
     const int r = blockIdx.x;
+    pe += (size_t)blockIdx.y * 256 * D; x += (size_t)blockIdx.y * 257 * D;   // image y of a batch
     for (int i = threadIdx.x; i < D; i += blockDim.x) {
         const float base = r == 0 ? (0.0f + cls[i]) : (0.0f + pe[(size_t)(r - 1) * D + i]);
         x[(size_t)r * D + i] = base + pos[(size_t)r * D + i];
     }
 }
-void launch_assemble_embeddings(const float *cls, const float *pe, const float *pos, int D, float *x, hipStream_t s) {
-    hipLaunchKernelGGL(k_assemble, dim3(257), dim3(256), 0, s, cls, pe, pos, D, x);
+void launch_assemble_embeddings(const float *cls, const float *pe, const float *pos, int D, float *x, hipStream_t s, int batch) {
+    hipLaunchKernelGGL(k_assemble, dim3(257, (unsigned)batch), dim3(256), 0, s, cls, pe, pos, D, x);
 }
 __global__ void k_f32_to_f16(const float *__restrict__ x, __half *__restrict__ y, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

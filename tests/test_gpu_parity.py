@@ -407,12 +407,13 @@ def test_batched_encode_images_equals_single(gpu_lib, tiny_files):
     vp, llm = tiny_files
     ctx = gpu_lib.minigpt4_model_load(vp, llm("q4_0"), verbosity=0, n_ctx=64, n_batch=32)
     try:
-        imgs = [G.synth_image(s) for s in (1, 2, 3)]
-        structs = (ML.MiniGPT4Image * 3)(*[ML.array_to_image_struct(i) for i in imgs])
-        batch = ML.MiniGPT4Images(structs, 3)
+        # 10 images = one pass of 8 + one of 2 over the vision weights (Engine::VISION_BATCH_MAX); every image must equal its single-image encode bit for bit
+        imgs = [G.synth_image(s) for s in range(1, 11)]
+        structs = (ML.MiniGPT4Image * 10)(*[ML.array_to_image_struct(i) for i in imgs])
+        batch = ML.MiniGPT4Images(structs, 10)
         out = ML.MiniGPT4Embeddings()
         assert gpu_lib.library.minigpt4_encode_images(ctx.ptr, ctypes.byref(batch), ctypes.byref(out), 0) == 0
-        assert out.n_embeddings == 3
+        assert out.n_embeddings == 10
         for i, img in enumerate(imgs):
             single = gpu_lib.minigpt4_encode_image(ctx, ML.array_to_image_struct(img))
             a = np.ctypeslib.as_array(single.data, shape=(single.n_embeddings,)).copy()
@@ -420,6 +421,8 @@ def test_batched_encode_images_equals_single(gpu_lib, tiny_files):
             assert np.array_equal(a, b)
             gpu_lib.minigpt4_free_embedding(single)
         assert gpu_lib.library.minigpt4_free_embeddings(ctypes.byref(out)) == 0
+        structs[1].format = 2                                                   # one U8 image in the batch: refused before any work (ImageNotF32)
+        assert gpu_lib.library.minigpt4_encode_images(ctx.ptr, ctypes.byref(batch), ctypes.byref(out), 0) == 14 and not out.embeddings
     finally:
         gpu_lib.minigpt4_free(ctx)
 
