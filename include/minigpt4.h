@@ -107,8 +107,9 @@ MINIGPT4_API int minigpt4_free_image(struct MiniGPT4Image *image);
 MINIGPT4_API int minigpt4_free_embedding(struct MiniGPT4Embedding *embedding);
 /* minigpt4.h:112, impl minigpt4.cpp:2811-2815: the enum identifier as static text. */
 MINIGPT4_API const char *minigpt4_error_code_to_string(int error_code);
-/* minigpt4.h:113, impl minigpt4.cpp:2817-2982.  Offline tool, out of this tier's scope: 17 if the input is
- * missing (as the reference), otherwise 18 (DumpModelFileOpen) without writing anything. */
+/* minigpt4.h:113, impl minigpt4.cpp:2817-2982.  Host-only offline tool: rewrites a vision file with its eligible Linear weights re-quantised by ggml's
+ * reference quantisers (data_type: MiniGPT4DataType Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q4_K Q5_K Q6_K; 3 for any other).  17 if the input is missing, 18 if the output
+ * cannot be written.  Tensors whose row length is not a whole number of blocks keep their type (the reference would write a file ggml cannot load). */
 MINIGPT4_API int minigpt4_quantize_model(const char *in_path, const char *out_path, int data_type);
 /* minigpt4.h:114, impl minigpt4.cpp:2984-2986. */
 MINIGPT4_API void minigpt4_set_verbosity(int verbosity);

@@ -84,6 +84,10 @@ MINIGPT4_API int minigpt4_amd_test_gemm_f16(const float *A, const float *W, cons
 /* Micro-benchmark of the decode mat-vec kernels on synthetic weight planes (see bench_kernels.py). variant 0: one launch per matrix, 1: fused persistent-wave launch */
 MINIGPT4_API int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int variant, int iters, int n_sets, int waves_per_cu, float *us_per_launch, double *bytes_per_launch);
 
+/* Average latency (microseconds) of a device-wide barrier across n_blocks co-resident 512-thread workgroups (atomic counter + agent-scope fences); *errors
+ * counts visibility failures of a neighbour-word check.  Measurement for DESIGN.md's launch-gap-vs-barrier analysis. */
+MINIGPT4_API float minigpt4_amd_probe_grid_barrier(int n_blocks, int iters, unsigned *errors);
+
 /* ---- host-only logic (no GPU needed) -------------------------------------------------------------------------------- */
 struct MiniGPT4Vocab;
 MINIGPT4_API struct MiniGPT4Vocab *minigpt4_amd_vocab_load(const char *llm_path);            /* parses hparams + vocab of a GGJT v3 file */
@@ -99,6 +103,9 @@ MINIGPT4_API int minigpt4_amd_decode_image(const void *bytes, size_t n, OUT stru
 /* Pillow's 8-bit bicubic resample tables for in_size -> out_size (what the preprocess kernels consume): first/count: int[out_size],
  * kk: int[out_size * ksize] (22-bit fixed point).  Call with kk = NULL to learn ksize.  0, -1 (bad sizes) or -2 (kk_cap too small). */
 MINIGPT4_API int minigpt4_amd_resample_coeffs(int in_size, int out_size, int *ksize, int *first, int *count, int *kk, size_t kk_cap);
+/* ggml's reference block quantisers as minigpt4_quantize_model applies them (ggml_quantize_chunk): n floats (a whole number of blocks) -> dst; returns the
+ * bytes written, 0 for an unsupported type (supported: Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q4_K Q5_K Q6_K, ggml type ids) or a ragged n. */
+MINIGPT4_API int64_t minigpt4_amd_quantize_chunk(int ggml_type, const float *x, void *dst, int64_t n);
 /* Host sampler with an explicit seed (fresh std::mt19937 per call). */
 MINIGPT4_API int minigpt4_amd_sample_logits(const float *logits, int n_vocab, int seed, float temp, int32_t top_k, float top_p, float tfs_z, float typical_p,
                                             int mirostat, float mirostat_tau, float mirostat_eta);

@@ -11,6 +11,7 @@
 
 #include "engine.hpp"
 #include "imageio.hpp"
+#include "quantize.hpp"
 #include "minigpt4_amd.h"
 
 using namespace mg4;
@@ -164,7 +165,11 @@ int minigpt4_free(struct MiniGPT4Context *ctx) { delete E_(ctx); return E_None; 
 int minigpt4_free_image(struct MiniGPT4Image *image) { if (image && image->data) { delete[] static_cast<uint8_t *>(image->data); image->data = nullptr; } return E_None; }
 int minigpt4_free_embedding(struct MiniGPT4Embedding *embedding) { if (embedding && embedding->data) { delete[] embedding->data; embedding->data = nullptr; } return E_None; }
 const char *minigpt4_error_code_to_string(int error_code) { return error_code >= 0 && error_code < 20 ? kErrNames[error_code] : ""; }
-int minigpt4_quantize_model(const char *in_path, const char *, int) { return file_exists(in_path) ? E_DumpModelFileOpen : E_PathDoesNotExist; }
+int minigpt4_quantize_model(const char *in_path, const char *out_path, int data_type) {
+    if (!file_exists(in_path)) return E_PathDoesNotExist;                        // minigpt4.cpp:2823-2826
+    try { return quantize_vision_file(in_path, out_path, data_type); }
+    catch (const std::exception &e) { set_last_error(std::string("minigpt4_quantize_model: ") + e.what()); return E_DumpModelFileOpen; }
+}
 void minigpt4_set_verbosity(int verbosity) { g_verbosity = verbosity & 0xFF; }
 
 // ======================================================================================================== additive API
@@ -466,6 +471,13 @@ int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int 
     });
 }
 
+float minigpt4_amd_probe_grid_barrier(int n_blocks, int iters, unsigned *errors) {
+    if (n_blocks < 1 || n_blocks > 1024 || iters < 1 || device_count_noexcept() <= 0) return -1.0f;
+    float us = -1.0f;
+    guarded(1, [&] { us = probe_grid_barrier_us(n_blocks, iters, errors); return 0; });
+    return us;
+}
+
 // ---- host-only logic -----------------------------------------------------------------------------------------------------------
 struct MiniGPT4Vocab { LLMFile f; Tokenizer t; };
 struct MiniGPT4Vocab *minigpt4_amd_vocab_load(const char *llm_path) {
@@ -522,6 +534,10 @@ int minigpt4_amd_resample_coeffs(int in_size, int out_size, int *ksize, int *fir
     if (count) memcpy(count, c.count.data(), (size_t)out_size * 4);
     if (kk) { if (kk_cap < c.kk.size()) return -2; memcpy(kk, c.kk.data(), c.kk.size() * 4); }
     return 0;
+}
+int64_t minigpt4_amd_quantize_chunk(int ggml_type, const float *x, void *dst, int64_t n) {
+    if (!x || !dst || n <= 0) return 0;
+    return (int64_t)quantize_chunk(ggml_type, x, static_cast<uint8_t *>(dst), (size_t)n);
 }
 int minigpt4_amd_sample_logits(const float *logits, int n_vocab, int seed, float temp, int32_t top_k, float top_p, float tfs_z, float typical_p, int mirostat, float mirostat_tau, float mirostat_eta) {
     if (!logits || n_vocab <= 0) return -1;

@@ -240,8 +240,16 @@ int Engine::load_vision(const std::string &path) {
     v_qi_ = (int)iq->ne[1];
     if (v_M_ % 16 || v_qi_ % 16) return fail("MLP widths must be multiples of 16", E_LoadModelFileHeader);
 
+    // Linear weights: all F16 (the reference's published f16 files) -> the MFMA f16 GEMM path below; anything else -> the generic path (engine_vision_generic.cpp)
+    v_generic_ = false;
+    for (auto &m : vis_.models) for (auto &t : m.second) {
+        const TensorMeta &tm = t.second;
+        const bool is_lin = tm.ne.size() == 2 && tm.name.size() >= 6 && tm.name.compare(tm.name.size() - 6, 6, "weight") == 0 && m.first != "query_tokens" && tm.name != "pos_embed" &&
+                            tm.name.find("orm") == std::string::npos && tm.name != "patch_embed.proj.weight" && tm.name.find("embeddings") == std::string::npos;
+        if (is_lin && tm.type != GT_F16) v_generic_ = true;
+    }
     size_t total = 0;
-    for (auto &m : vis_.models) for (auto &t : m.second) total += t.second.nbytes + 512;
+    for (auto &m : vis_.models) for (auto &t : m.second) total += t.second.nbytes + 512 + (v_generic_ ? 2048 : 0);
     total += (size_t)v_D_ * 592 * 2 + (size_t)v_depth_ * 3 * v_D_ * 4 + (1 << 20);
     vis_arena_.alloc(total);
     const uint8_t *fb = vis_.mf.data;
@@ -254,11 +262,13 @@ int Engine::load_vision(const std::string &path) {
     auto f16m = [&](const std::string &model, const std::string &name, int64_t n_in, int64_t n_out) -> const TensorMeta * {
         const TensorMeta *t = vis_.find(model, name);
         if (!t || t->ne.size() < 2 || t->nelements() != n_in * n_out) { ok = false; bad = model + "." + name; return nullptr; }
-        if (t->type != GT_F16) { ok = false; bad = model + "." + name + " (only f16 vision weights are supported by the gfx950 path; got " + gt_name(t->type) + ")"; return nullptr; }
+        if (t->type != GT_F16 && !v_generic_) { ok = false; bad = model + "." + name + " (unexpected type " + gt_name(t->type) + ")"; return nullptr; }
         return t;
     };
-    auto up16 = [&](const TensorMeta *t) -> __half * { return t ? upload_raw<__half>(vis_arena_, fb + t->offset, t->nbytes) : nullptr; };
+    // generic mode: the Linear weights are uploaded as QWeights by load_vision_generic(); the fp16 pointers of this path stay null
+    auto up16 = [&](const TensorMeta *t) -> __half * { return t && !v_generic_ ? upload_raw<__half>(vis_arena_, fb + t->offset, t->nbytes) : nullptr; };
     auto concat16 = [&](std::initializer_list<const TensorMeta *> ts) -> __half * {
+        if (v_generic_) return nullptr;
         size_t bytes = 0; for (auto t : ts) { if (!t) return nullptr; bytes += t->nbytes; }
         uint8_t *d = vis_arena_.take(bytes); size_t off = 0;
         for (auto t : ts) { HIP_CHECK(hipMemcpy(d + off, fb + t->offset, t->nbytes, hipMemcpyHostToDevice)); off += t->nbytes; }
@@ -276,7 +286,9 @@ int Engine::load_vision(const std::string &path) {
     v_cls_ = f32v(VE, "cls_token", D);
     v_pos_ = f32v(VE, "pos_embed", (int64_t)D * 257);
     v_patch_b_ = f32v(VE, "patch_embed.proj.bias", D);
-    if (const TensorMeta *pw = f16m(VE, "patch_embed.proj.weight", 588, D)) {   // [D][588] -> zero-padded [D][592] (MFMA K multiple of 16)
+    const TensorMeta *pw = f16m(VE, "patch_embed.proj.weight", 588, D);
+    if (pw && pw->type != GT_F16) { ok = false; bad = "visual_encoder.patch_embed.proj.weight (the conv kernel is always F16: convert.py:113-117, and minigpt4_quantize_model skips it)"; pw = nullptr; }
+    if (pw) {   // [D][588] -> zero-padded [D][592] (MFMA K multiple of 16)
         std::vector<uint16_t> padded((size_t)D * 592, 0);
         const uint16_t *src = reinterpret_cast<const uint16_t *>(fb + pw->offset);
         for (int r = 0; r < D; r++) memcpy(&padded[(size_t)r * 592], src + (size_t)r * 588, 588 * 2);
@@ -329,7 +341,8 @@ int Engine::load_vision(const std::string &path) {
         L.oln_w = f32v(QF, p + "output_query.LayerNorm.weight", 768); L.oln_b = f32v(QF, p + "output_query.LayerNorm.bias", 768);
     }
     v_proj_w_ = up16(f16m("llama_proj", "weight", 768, v_out_)); v_proj_b_ = f32v("llama_proj", "bias", v_out_);
-    if (!ok) return fail("missing or unsupported tensor " + bad, bad.find("only f16") != std::string::npos ? E_LoadModelMiniGPT4DataType : E_LoadModelFileHeader);
+    if (!ok) return fail("missing or unsupported tensor " + bad, E_LoadModelFileHeader);
+    if (v_generic_) { if (int e = load_vision_generic()) return e; }
     MG4_INFO("vision weights: %.1f MB in HBM (ViT dim %d x %d blocks, Q-Former %d layers, proj -> %d)", vis_arena_.used / 1048576.0, v_D_, v_depth_, v_ql_, v_out_);
     return E_None;
 }
@@ -404,6 +417,7 @@ void Engine::alloc_buffers() {
     vi_out_ = takef(VB * NQ * (size_t)v_out_);
     vi_qtok_rep_ = takef(VB * NQ * 768);                                  // the query tokens once per image of a batch (every image starts from the same rows)
     for (size_t b = 0; b < VB; b++) HIP_CHECK(hipMemcpy(vi_qtok_rep_ + b * NQ * 768, v_qtok_, NQ * 768 * 4, hipMemcpyDeviceToDevice));
+    if (v_generic_) alloc_vision_generic();
     MG4_INFO("KV cache %.1f MB (fp16, n_ctx %d, %zu conversation%s), activation arena %.1f MB", 2.0 * S * L * C * E * 2 / 1048576.0, n_ctx_, S, S == 1 ? "" : "s", buf_arena_.used / 1048576.0);
 }
 
@@ -778,6 +792,7 @@ int Engine::decode_batch(const int *slots, int n, const SampleParams &p, int *id
 // batch equals the same image encoded alone bit for bit (tests/test_gpu_parity.py::test_batched_image_encode_is_bit_identical).
 int Engine::encode_images(const float *const *chw, int B, float *const *out) {
     if (B < 1 || B > VISION_BATCH_MAX) { set_last_error("encode_images: batch size out of range"); return E_ImageSize; }
+    if (v_generic_) return encode_images_generic(chw, B, out);
     hipStream_t s = stream_;
     const int D = v_D_, M = v_M_, NQ = v_nq_, H = 768;
     const int R = B * 257, RQ = B * NQ;                                    // rows of the ViT / Q-Former activations

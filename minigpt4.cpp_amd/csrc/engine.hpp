@@ -156,6 +156,22 @@ private:
     float *vi_img_ = nullptr, *vi_pe_ = nullptr, *vi_x_ = nullptr, *vi_qkv_ = nullptr, *vi_hs_ = nullptr, *vi_a1_ = nullptr, *vi_a2_ = nullptr, *vi_d_ = nullptr, *vi_qq_ = nullptr, *vi_kv_ = nullptr, *vi_out_ = nullptr;
     __half *vi_patches_ = nullptr, *vi_ln_h_ = nullptr, *vi_att_h_ = nullptr, *vi_mlp_h_ = nullptr, *vi_img_h_ = nullptr, *vi_hs_h_ = nullptr, *vi_a1_h_ = nullptr, *vi_a2_h_ = nullptr, *vi_ctx_h_ = nullptr, *vi_im_h_ = nullptr;
     float last_encode_ms_ = 0;
+
+    // ---- vision files whose Linear weights are not all F16 (an `--ftype f32` conversion, or a file written by minigpt4_quantize_model): every Linear is a
+    // QWeight served by the LLM mat-mul kernels (activations quantised to the weight type's vec_dot_type, exactly ggml's mul_mat), activations stay fp32.
+    bool v_generic_ = false;
+    struct GLin { QWeight w; };
+    struct GBlock { GLin qkv, proj, fc1, fc2; };
+    struct GAtt { GLin q, k, v, dense; };
+    struct GQLayer { GAtt self, cross; GLin inter, out; };
+    std::vector<GBlock> gblocks_; std::vector<GQLayer> gql_; GLin gproj_;
+    DeviceArena vgen_arena_;
+    ActQ vact_;
+    float *vg_ln_ = nullptr, *vg_att_ = nullptr, *vg_mlp_ = nullptr, *vg_img_ = nullptr, *vg_tmp_ = nullptr, *vg_ctx_ = nullptr, *vg_im_ = nullptr;
+    int load_vision_generic();
+    void alloc_vision_generic();
+    int encode_images_generic(const float *const *chw, int B, float *const *out);
+    void glinear(const GLin &L, const float *x, int rows, const float *bias, bool gelu, const float *residual, float *out, hipStream_t s);
 };
 
 int device_count_noexcept();

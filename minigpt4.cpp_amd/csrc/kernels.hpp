@@ -66,6 +66,7 @@ bool attn_head_size_supported(int hd);
 void launch_argmax(const float *logits, int n, int *out, void *scratch /*>= 512 bytes*/, hipStream_t s);
 void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);
 void launch_set_int(int *p, int v, hipStream_t s);
+float probe_grid_barrier_us(int n_blocks, int iters, unsigned *errors_out);   // average latency of a device-wide barrier across n_blocks co-resident 512-thread workgroups
 void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s);
 void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s);
 void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s);
@@ -75,6 +76,8 @@ void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_
 // Writes fp32 `out` (nullable) and/or fp16 `out_h` (nullable).  K must be a multiple of 16.
 void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual,
                      bool gelu, const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s);
+// out = [residual +] gelu?(bias + y) over [rows][n] contiguous fp32 (y may alias out); writes fp32 (nullable) and / or fp16 (nullable)
+void launch_lin_epilogue(const float *y, const float *bias, const float *residual, bool gelu, const Tables &tb, int rows, int n, float *out, __half *out_h, hipStream_t s);
 void set_attn_mfma(int v);   // 1: f32-MFMA attention kernel (default), 0: VALU/LDS kernel
 // LayerNorm (ggml_norm eps 1e-5, then w*x+b); rows x n; writes fp32 (nullable) and fp16 (nullable).
 void launch_layernorm(const float *x, const float *w, const float *b, int rows, int n, float *out, __half *out_h, hipStream_t s);

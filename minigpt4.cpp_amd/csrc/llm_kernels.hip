@@ -1287,6 +1287,48 @@ __global__ void k_fill_u16(unsigned short *p, size_t n, unsigned short v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s) { hipLaunchKernelGGL(k_fill_u16, dim3(1024), dim3(256), 0, s, (unsigned short *)p, n, v); }
+// Device-wide barrier latency probe (is a persistent multi-phase decode kernel worth building?): `n_blocks` co-resident workgroups pass `iters` barriers.
+// Between barriers every workgroup writes one word and reads its neighbour's (so the fences have something to make visible).
+__device__ __forceinline__ void grid_sync(unsigned *bar, unsigned &target, unsigned n_blocks) {
+    target += n_blocks;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(bar, 1u);
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        __threadfence();
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(512) void k_barrier_probe(unsigned *bar, unsigned *words, int iters, unsigned *errors) {
+    unsigned target = 0;
+    const unsigned nb = gridDim.x, me = blockIdx.x, nxt = (me + 1) % nb;
+    unsigned bad = 0;
+    for (int i = 0; i < iters; i++) {
+        if (threadIdx.x == 0) words[me] = (unsigned)i * 2654435761u + me;
+        grid_sync(bar, target, nb);
+        if (threadIdx.x == 0) bad += words[nxt] != (unsigned)i * 2654435761u + nxt;
+        grid_sync(bar, target, nb);
+    }
+    if (threadIdx.x == 0 && bad) atomicAdd(errors, bad);
+}
+float probe_grid_barrier_us(int n_blocks, int iters, unsigned *errors_out) {
+    unsigned *d = nullptr;
+    HIP_CHECK(hipMalloc((void **)&d, (size_t)(n_blocks + 2) * 4));
+    HIP_CHECK(hipMemset(d, 0, (size_t)(n_blocks + 2) * 4));
+    hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(k_barrier_probe, dim3((unsigned)n_blocks), dim3(512), 0, nullptr, d, d + 2, 4, d + 1);       // warm-up
+    HIP_CHECK(hipMemset(d, 0, 8));
+    HIP_CHECK(hipEventRecord(a, nullptr));
+    hipLaunchKernelGGL(k_barrier_probe, dim3((unsigned)n_blocks), dim3(512), 0, nullptr, d, d + 2, iters, d + 1);
+    HIP_CHECK(hipEventRecord(b, nullptr));
+    HIP_CHECK(hipDeviceSynchronize());
+    float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    unsigned err = 0; HIP_CHECK(hipMemcpy(&err, d + 1, 4, hipMemcpyDeviceToHost));
+    if (errors_out) *errors_out = err;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipFree(d);
+    return ms * 1e3f / (float)(2 * iters);
+}
 __global__ void k_set_int(int *p, int v) { *p = v; }
 void launch_set_int(int *p, int v, hipStream_t s) { hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, p, v); }
 // Batched decode epilogue, one workgroup per row: greedy argmax of the row's logits (first maximum wins), stored with the logits' owner slot; the

@@ -420,6 +420,26 @@ void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, in
 }
 
 // =====================================================================================================================
+// generic Linear epilogue (vision files whose Linear weights are not F16: the product W.x comes from the LLM mat-mul kernels as plain fp32):
+// v = bias + y ; optional fp16-table GELU ; optional residual + v  -- the same order as the fused GEMM epilogue above (NNLinear: repeat(bias) + mul_mat).
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void k_lin_epilogue(const float *__restrict__ y, const float *__restrict__ bias, const float *residual, const Tables tb, int gelu, size_t total, int n,
+                                                      float *out, __half *__restrict__ out_h) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float v = y[i];
+    if (bias) v = bias[i % (size_t)n] + v;
+    if (gelu) v = tab_v(tb.gelu, v);
+    if (residual) v = residual[i] + v;
+    if (out) out[i] = v;
+    if (out_h) out_h[i] = __float2half_rn(v);
+}
+void launch_lin_epilogue(const float *y, const float *bias, const float *residual, bool gelu, const Tables &tb, int rows, int n, float *out, __half *out_h, hipStream_t s) {
+    const size_t total = (size_t)rows * n;
+    hipLaunchKernelGGL(k_lin_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, y, bias, residual, tb, gelu ? 1 : 0, total, n, out, out_h);
+}
+
+// =====================================================================================================================
 // small data-movement kernels
 // =====================================================================================================================
 __global__ void k_im2col(const float *__restrict__ img, __half *__restrict__ patches, int ldp) {

@@ -56,12 +56,15 @@ def test_activation_quantisation_bit_exact(gpu_lib, rms):
 
 
 @pytest.mark.parametrize("wtype", QTYPES)
-@pytest.mark.parametrize("shape", [(1, 512, 96), (5, 768, 70), (1, 5120, 64), (33, 768, 70), (70, 1024, 130), (142, 2048, 256)])   # N >= 16: int8-MFMA prefill path
+@pytest.mark.parametrize("shape", [(1, 512, 96), (5, 768, 70), (1, 5120, 64), (33, 768, 70), (70, 1024, 130), (142, 2048, 256),    # N >= 16: int8-MFMA prefill path
+                                   (257, 352, 100), (40, 1408, 64)])     # the ViT's row lengths (11 / 44 blocks of 32; 32-element block types only)
 def test_mul_mat_matches_oracle(gpu_lib, wtype, shape):
     import refcpu as R
     from minigpt4_cpp_amd import quants as Q
     N, n_in, n_out = shape
     t = Q.NAME_TO_TYPE[wtype]
+    if n_in % Q.BLOCK[t][0]:
+        pytest.skip("row length is not a whole number of blocks of this type")
     rng = np.random.default_rng(sum(map(ord, wtype)) * 1000 + sum(shape))
     w = (0.05 * rng.standard_normal((n_out, n_in))).astype(np.float32)
     raw = Q.quantize(t, w)
