@@ -86,7 +86,7 @@ int VisionFile::load(const std::string &path) {
         if (!r.ok || nlen < 0 || nlen > 4096) return E_LoadModelFileHeader;
         const std::string mname = r.str((size_t)nlen);
         const int32_t nt = r.s4();
-        if (!r.ok || nt < 0) return E_LoadModelFileHeader;
+        if (!r.ok || nt < 0 || (size_t)nt > (r.size - r.pos) / 12) return E_LoadModelFileHeader;   // a tensor header is at least 12 bytes: a corrupt count cannot make us allocate
         std::vector<TensorMeta> metas((size_t)nt);
         for (auto &t : metas) {
             const int32_t l = r.s4();
@@ -94,7 +94,8 @@ int VisionFile::load(const std::string &path) {
             t.name = r.str((size_t)l);
             const int32_t nd = r.s4();
             if (!r.ok || nd < 0 || nd > 8) return E_LoadModelFileHeader;
-            for (int i = 0; i < nd; i++) t.ne.push_back(r.s4());
+            int64_t prod = 1;
+            for (int i = 0; i < nd; i++) { const int32_t d = r.s4(); if (d < 0 || (prod *= (int64_t)d) > ((int64_t)1 << 40)) return E_LoadModelFileHeader; t.ne.push_back(d); }
             t.type = mg4_to_ggml(r.s4());
             if (!r.ok) return E_LoadModelFileHeader;
             if (t.type < 0) return E_LoadModelMiniGPT4DataType;
@@ -140,7 +141,8 @@ int LLMFile::load(const std::string &path, bool vocab_only) {
     const uint32_t magic = r.u4(), ver = r.u4();
     if (!r.ok || magic != 0x67676a74u || ver != 3) { set_last_error("LLM file: expected GGJT v3 (magic 0x67676a74, version 3)"); return E_LoadLanguageModel; }
     n_vocab = r.u4(); n_embd = r.u4(); n_mult = r.u4(); n_head = r.u4(); n_layer = r.u4(); n_rot = r.u4(); ftype = r.u4();
-    if (!r.ok || !n_vocab || !n_embd || !n_mult || !n_head || !n_layer || n_embd % n_head || n_vocab > (1u << 24)) { set_last_error("LLM file: bad hparams"); return E_LoadLanguageModel; }
+    if (!r.ok || !n_vocab || !n_embd || !n_mult || !n_head || !n_layer || n_embd % n_head || n_vocab > (1u << 24) || (size_t)n_vocab > (r.size - r.pos) / 8 || n_embd > (1u << 20) ||
+        n_layer > (1u << 16) || n_mult > (1u << 20)) { set_last_error("LLM file: bad hparams"); return E_LoadLanguageModel; }   // a vocab entry is at least 8 bytes
     pieces.resize(n_vocab); scores.resize(n_vocab);
     for (uint32_t i = 0; i < n_vocab; i++) {
         const uint32_t len = r.u4();
@@ -153,7 +155,8 @@ int LLMFile::load(const std::string &path, bool vocab_only) {
         const uint32_t nd = r.u4(), nl = r.u4(), ty = r.u4();
         if (!r.ok || nd < 1 || nd > 2 || nl > 4096) { set_last_error("LLM file: bad tensor header"); return E_LoadLanguageModel; }
         TensorMeta t; t.type = (int)ty;
-        for (uint32_t i = 0; i < nd; i++) t.ne.push_back(r.u4());
+        for (uint32_t i = 0; i < nd; i++) { const uint32_t d = r.u4(); if (d > (1u << 30)) { set_last_error("LLM file: absurd tensor shape"); return E_LoadLanguageModel; } t.ne.push_back(d); }
+        if (t.nelements() > ((int64_t)1 << 40)) { set_last_error("LLM file: absurd tensor shape"); return E_LoadLanguageModel; }   // two dims <= 2^30: the product cannot overflow
         t.name = r.str(nl);
         if (!r.ok || gt_bytes(t.type) == 0 || t.ne[0] % gt_block(t.type)) { set_last_error("LLM file: tensor " + t.name + " has an unusable type/shape"); return E_LoadLanguageModel; }
         r.pos = (r.pos + 31) & ~(size_t)31;

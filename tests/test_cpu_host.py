@@ -204,6 +204,26 @@ def test_product_loaders_parse_both_files_without_gpu(lib, tiny_files, tmp_path)
     bad.write_bytes(open(lp, "rb").read()[:3000])
     assert lib.library.minigpt4_amd_inspect_files(None, str(bad).encode(), None, None, None) == 4      # LoadLanguageModel
     assert lib.library.minigpt4_amd_inspect_files(b"/nonexistent", None, None, None, None) == 17       # PathDoesNotExist
+    # corrupt counts / shapes must be refused before they size an allocation (found by fuzzing the parsers under ASAN: a tensor count of 2^31 - 1,
+    # a vocabulary larger than the file, dimensions whose product overflows)
+    raw = bytearray(open(vp, "rb").read()[:20000])
+    clen = struct.unpack_from("i", raw, 12)[0]
+    mname_len = struct.unpack_from("i", raw, 16 + clen)[0]
+    struct.pack_into("i", raw, 16 + clen + 4 + mname_len, 0x7FFFFFFF)                                   # tensor count of the first model
+    bad.write_bytes(bytes(raw))
+    assert lib.library.minigpt4_amd_inspect_files(str(bad).encode(), None, None, None, None) == 1
+    raw = bytearray(open(lp, "rb").read()[:20000])
+    struct.pack_into("I", raw, 8, 1 << 24)                                                             # n_vocab far beyond the file
+    bad.write_bytes(bytes(raw))
+    assert lib.library.minigpt4_amd_inspect_files(None, str(bad).encode(), None, None, None) == 4
+    full = bytearray(open(lp, "rb").read())
+    lf2 = G.read_llm_file(lp)
+    first = min(lf2.tensors.values(), key=lambda t: t.offset)
+    hdr = bytes(full).rfind(first.name.encode(), 0, first.offset)                                      # its header: nd, name_len, type, ne[nd], name
+    nd = len(first.ne)
+    struct.pack_into("II", full, hdr - 4 * nd, 0xFFFFFFFF, 0xFFFFFFFF) if nd == 2 else struct.pack_into("I", full, hdr - 4, 0xFFFFFFFF)
+    bad.write_bytes(bytes(full))
+    assert lib.library.minigpt4_amd_inspect_files(None, str(bad).encode(), None, None, None) == 4
 
 
 # ------------------------------------------------------------------------------------------------ tokenizer / sampler / templating
