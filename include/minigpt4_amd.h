@@ -103,6 +103,9 @@ MINIGPT4_API int minigpt4_amd_decode_image(const void *bytes, size_t n, OUT stru
 /* Pillow's 8-bit bicubic resample tables for in_size -> out_size (what the preprocess kernels consume): first/count: int[out_size],
  * kk: int[out_size * ksize] (22-bit fixed point).  Call with kk = NULL to learn ksize.  0, -1 (bad sizes) or -2 (kk_cap too small). */
 MINIGPT4_API int minigpt4_amd_resample_coeffs(int in_size, int out_size, int *ksize, int *first, int *count, int *kk, size_t kk_cap);
+/* Digest (FNV-1a 64) of what the engine takes from an LLM file -- hyper-parameters, vocabulary, every tensor's name / type / shape (and bytes when
+ * with_data != 0).  GGJT v3 and GGUF v2 / v3 files of the same model digest equally.  Returns a MiniGPT4Error. */
+MINIGPT4_API int minigpt4_amd_llm_file_digest(const char *llm_path, uint64_t *digest, int with_data);
 /* ggml's reference block quantisers as minigpt4_quantize_model applies them (ggml_quantize_chunk): n floats (a whole number of blocks) -> dst; returns the
  * bytes written, 0 for an unsupported type (supported: Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q4_K Q5_K Q6_K, ggml type ids) or a ragged n. */
 MINIGPT4_API int64_t minigpt4_amd_quantize_chunk(int ggml_type, const float *x, void *dst, int64_t n);

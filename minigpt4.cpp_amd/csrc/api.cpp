@@ -535,6 +535,27 @@ int minigpt4_amd_resample_coeffs(int in_size, int out_size, int *ksize, int *fir
     if (kk) { if (kk_cap < c.kk.size()) return -2; memcpy(kk, c.kk.data(), c.kk.size() * 4); }
     return 0;
 }
+// FNV-1a digest of everything the engine takes from an LLM file: hyper-parameters, vocabulary (pieces + scores) and every tensor (name, type, shape, bytes),
+// tensors in name order.  A GGUF file and the GGJT v3 file of the same model must give the same digest.
+int minigpt4_amd_llm_file_digest(const char *llm_path, uint64_t *digest, int with_data) {
+    if (!llm_path || !digest) return E_LoadLanguageModel;
+    if (!file_exists(llm_path)) return E_PathDoesNotExist;
+    LLMFile f;
+    if (int e = f.load(llm_path)) return e;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) { const uint8_t *b = static_cast<const uint8_t *>(p); for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+    const uint32_t hp[5] = {f.n_vocab, f.n_embd, f.n_head, f.n_layer, f.n_ff()};
+    mix(hp, sizeof(hp));
+    for (size_t i = 0; i < f.pieces.size(); i++) { const uint32_t n = (uint32_t)f.pieces[i].size(); mix(&n, 4); mix(f.pieces[i].data(), n); mix(&f.scores[i], 4); }
+    for (auto &kv : f.tensors) {
+        const TensorMeta &t = kv.second;
+        mix(kv.first.data(), kv.first.size()); mix(&t.type, 4);
+        for (int64_t d : t.ne) mix(&d, 8);
+        if (with_data) mix(f.mf.data + t.offset, t.nbytes);
+    }
+    *digest = h;
+    return E_None;
+}
 int64_t minigpt4_amd_quantize_chunk(int ggml_type, const float *x, void *dst, int64_t n) {
     if (!x || !dst || n <= 0) return 0;
     return (int64_t)quantize_chunk(ggml_type, x, static_cast<uint8_t *>(dst), (size_t)n);

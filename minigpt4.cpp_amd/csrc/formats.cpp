@@ -6,6 +6,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstring>
 #include <queue>
@@ -139,7 +140,8 @@ int LLMFile::load(const std::string &path, bool vocab_only) {
     if (!mf.open(path)) { set_last_error("cannot mmap " + path); return E_LoadLanguageModel; }
     Reader r(mf.data, mf.size);
     const uint32_t magic = r.u4(), ver = r.u4();
-    if (!r.ok || magic != 0x67676a74u || ver != 3) { set_last_error("LLM file: expected GGJT v3 (magic 0x67676a74, version 3)"); return E_LoadLanguageModel; }
+    if (r.ok && magic == 0x46554747u) return load_gguf(vocab_only);   // "GGUF"
+    if (!r.ok || magic != 0x67676a74u || ver != 3) { set_last_error("LLM file: expected GGJT v3 (magic 0x67676a74, version 3) or GGUF v2/v3"); return E_LoadLanguageModel; }
     n_vocab = r.u4(); n_embd = r.u4(); n_mult = r.u4(); n_head = r.u4(); n_layer = r.u4(); n_rot = r.u4(); ftype = r.u4();
     if (!r.ok || !n_vocab || !n_embd || !n_mult || !n_head || !n_layer || n_embd % n_head || n_vocab > (1u << 24) || (size_t)n_vocab > (r.size - r.pos) / 8 || n_embd > (1u << 20) ||
         n_layer > (1u << 16) || n_mult > (1u << 20)) { set_last_error("LLM file: bad hparams"); return E_LoadLanguageModel; }   // a vocab entry is at least 8 bytes
@@ -163,6 +165,137 @@ int LLMFile::load(const std::string &path, bool vocab_only) {
         t.offset = r.pos; t.nbytes = gt_nbytes(t.type, (size_t)t.nelements());
         if (!r.need(t.nbytes)) { set_last_error("LLM file: tensor " + t.name + " runs past EOF"); return E_LoadLanguageModel; }
         r.pos += t.nbytes;
+        tensors[t.name] = t;
+    }
+    return E_None;
+}
+
+// ---------------------------------------------------------------------------------------------------- format B': GGUF
+// The reference pins llama.cpp at a GGJT-v3-era commit (CMakeLists.txt:318) and cannot read GGUF; current converters only write GGUF.  A GGUF file of a
+// LLaMA-1 / Vicuna-v0 style model (no grouped-query attention, RMS eps 1e-6, rope base 10000) holds exactly the tensors of the GGJT file under new names, so it
+// is mapped onto the same LLMFile view and everything downstream (repack, kernels, tokenizer of the pinned llama.cpp) is unchanged:
+//   token_embd -> tok_embeddings, output_norm -> norm, output -> output, blk.N.{attn_norm, attn_q, attn_k, attn_v, attn_output, ffn_norm, ffn_gate, ffn_down,
+//   ffn_up} -> layers.N.{attention_norm, attention.wq, .wk, .wv, .wo, ffn_norm, feed_forward.w1, .w2, .w3};  vocabulary pieces: U+2581 -> ' ' and "<0xXX>" byte
+//   tokens -> the raw byte, which is the form the GGJT converter of that era stored.
+int LLMFile::load_gguf(bool vocab_only) {
+    auto fail = [&](const std::string &m) { set_last_error("GGUF file: " + m); return (int)E_LoadLanguageModel; };
+    Reader r(mf.data, mf.size);
+    r.u4();
+    const uint32_t ver = r.u4();
+    if (ver != 2 && ver != 3) return fail("only versions 2 and 3 are supported");
+    auto u8 = [&]() -> uint64_t { uint64_t v = 0; if (r.need(8)) { memcpy(&v, r.p + r.pos, 8); r.pos += 8; } return v; };
+    auto gstr = [&]() -> std::string { const uint64_t n = u8(); if (!r.ok || n > (1u << 24)) { r.ok = false; return std::string(); } return r.str((size_t)n); };
+    const uint64_t n_tensors = u8(), n_kv = u8();
+    if (!r.ok || n_tensors > (r.size - r.pos) / 24 || n_kv > (r.size - r.pos) / 12) return fail("absurd counts");
+    static const size_t scalar_size[13] = {1, 1, 2, 2, 4, 4, 4, 1, 0, 0, 8, 8, 8};
+    uint64_t alignment = 32, head_kv = 0, head = 0;
+    double eps = 1e-6, rope_base = 10000.0;
+    std::string arch, tok_model;
+    std::vector<int32_t> token_type;
+    bool have_tokens = false;
+    for (uint64_t i = 0; i < n_kv && r.ok; i++) {
+        const std::string key = gstr();
+        const uint32_t vt = r.u4();
+        auto scalar_u = [&](uint32_t t) -> uint64_t {          // integer-valued scalar of type t
+            uint64_t v = 0;
+            if (t > 12 || !scalar_size[t] || !r.need(scalar_size[t])) { r.ok = false; return 0; }
+            memcpy(&v, r.p + r.pos, scalar_size[t]); r.pos += scalar_size[t];
+            return v;
+        };
+        if (vt == 8) { const std::string v = gstr(); if (key == "general.architecture") arch = v; else if (key == "tokenizer.ggml.model") tok_model = v; continue; }
+        if (vt == 9) {
+            const uint32_t et = r.u4(); const uint64_t cnt = u8();
+            if (!r.ok || cnt > (r.size - r.pos)) return fail("absurd array length");
+            if (key == "tokenizer.ggml.tokens" && et == 8) {
+                if (cnt > (1u << 24)) return fail("absurd vocabulary");
+                pieces.resize((size_t)cnt);
+                for (uint64_t k = 0; k < cnt && r.ok; k++) pieces[(size_t)k] = gstr();
+                have_tokens = true;
+            } else if (key == "tokenizer.ggml.scores" && et == 6) {
+                scores.resize((size_t)cnt);
+                if (!r.need((size_t)cnt * 4)) return fail("truncated scores");
+                memcpy(scores.data(), r.p + r.pos, (size_t)cnt * 4); r.pos += (size_t)cnt * 4;
+            } else if (key == "tokenizer.ggml.token_type" && (et == 5 || et == 4)) {
+                token_type.resize((size_t)cnt);
+                if (!r.need((size_t)cnt * 4)) return fail("truncated token types");
+                memcpy(token_type.data(), r.p + r.pos, (size_t)cnt * 4); r.pos += (size_t)cnt * 4;
+            } else if (et == 8) { for (uint64_t k = 0; k < cnt && r.ok; k++) gstr(); }
+            else { if (et > 12 || !scalar_size[et] || !r.need((size_t)cnt * scalar_size[et])) return fail("bad array"); r.pos += (size_t)cnt * scalar_size[et]; }
+            continue;
+        }
+        if (vt == 6 || vt == 12) {                                // f32 / f64
+            double v = 0;
+            if (vt == 6) v = r.f4(); else { if (r.need(8)) { memcpy(&v, r.p + r.pos, 8); r.pos += 8; } }
+            if (key == "llama.attention.layer_norm_rms_epsilon") eps = v; else if (key == "llama.rope.freq_base") rope_base = v;
+            continue;
+        }
+        const uint64_t v = scalar_u(vt);
+        if (key == "general.alignment") alignment = v;
+        else if (key == "llama.embedding_length") n_embd = (uint32_t)v;
+        else if (key == "llama.block_count") n_layer = (uint32_t)v;
+        else if (key == "llama.feed_forward_length") n_ff_explicit = (uint32_t)v;
+        else if (key == "llama.attention.head_count") head = v;
+        else if (key == "llama.attention.head_count_kv") head_kv = v;
+        else if (key == "llama.rope.dimension_count") n_rot = (uint32_t)v;
+        else if (key == "general.file_type") ftype = (uint32_t)v;
+    }
+    if (!r.ok) return fail("truncated metadata");
+    if (arch != "llama") return fail("general.architecture must be \"llama\"");
+    if (!tok_model.empty() && tok_model != "llama") return fail("only the SentencePiece (\"llama\") tokenizer model is supported");
+    n_head = (uint32_t)head;
+    if (!have_tokens || scores.size() != pieces.size() || pieces.empty()) return fail("missing tokenizer.ggml.tokens / scores");
+    if (!n_embd || !n_layer || !n_head || !n_ff_explicit || n_embd % n_head || n_embd > (1u << 20) || n_layer > (1u << 16) || n_ff_explicit > (1u << 22)) return fail("bad hyper-parameters");
+    if (head_kv && head_kv != head) return fail("grouped-query attention (head_count_kv != head_count) is not supported: the reference's LLaMA-1 / Vicuna-v0 graph has none");
+    if (fabs(eps - 1e-6) > 1e-9) return fail("layer_norm_rms_epsilon must be 1e-6 (the value of the reference's pinned llama.cpp)");
+    if (fabs(rope_base - 10000.0) > 1e-3) return fail("rope.freq_base must be 10000");
+    if (alignment == 0 || alignment > 4096 || (alignment & (alignment - 1))) return fail("bad general.alignment");
+    n_vocab = (uint32_t)pieces.size(); n_mult = 1;
+    for (size_t i = 0; i < pieces.size(); i++) {                   // SentencePiece pieces -> the GGJT-era form
+        std::string &p = pieces[i];
+        const bool is_byte = (i < token_type.size() && token_type[i] == 6) || (p.size() == 6 && p.compare(0, 3, "<0x") == 0 && p[5] == '>');
+        if (is_byte && p.size() == 6 && p.compare(0, 3, "<0x") == 0) { p = std::string(1, (char)strtol(p.substr(3, 2).c_str(), nullptr, 16)); continue; }
+        std::string q; q.reserve(p.size());
+        for (size_t k = 0; k < p.size();) {
+            if (k + 2 < p.size() && (unsigned char)p[k] == 0xE2 && (unsigned char)p[k + 1] == 0x96 && (unsigned char)p[k + 2] == 0x81) { q.push_back(' '); k += 3; }   // U+2581
+            else q.push_back(p[k++]);
+        }
+        p.swap(q);
+    }
+    if (vocab_only) return E_None;
+    struct Info { std::string name; TensorMeta t; uint64_t rel; };
+    std::vector<Info> infos((size_t)n_tensors);
+    for (auto &in : infos) {
+        in.name = gstr();
+        const uint32_t nd = r.u4();
+        if (!r.ok || nd < 1 || nd > 2) return fail("tensor " + in.name + ": only 1-D / 2-D tensors are expected");
+        for (uint32_t d = 0; d < nd; d++) { const uint64_t v = u8(); if (v > (1u << 30)) return fail("absurd tensor shape"); in.t.ne.push_back((int64_t)v); }
+        in.t.type = (int)r.u4();
+        in.rel = u8();
+        if (!r.ok || gt_bytes(in.t.type) == 0 || in.t.ne[0] % gt_block(in.t.type)) return fail("tensor " + in.name + " has an unusable type / shape");
+    }
+    const size_t data0 = (r.pos + (size_t)alignment - 1) & ~((size_t)alignment - 1);
+    auto rename = [&](const std::string &g) -> std::string {
+        if (g == "token_embd.weight") return "tok_embeddings.weight";
+        if (g == "output_norm.weight") return "norm.weight";
+        if (g == "output.weight") return "output.weight";
+        if (g.compare(0, 4, "blk.") == 0) {
+            const size_t dot = g.find('.', 4);
+            if (dot == std::string::npos) return "";
+            const std::string idx = g.substr(4, dot - 4), rest = g.substr(dot + 1);
+            static const char *map[][2] = {{"attn_norm.weight", "attention_norm.weight"}, {"attn_q.weight", "attention.wq.weight"}, {"attn_k.weight", "attention.wk.weight"},
+                {"attn_v.weight", "attention.wv.weight"}, {"attn_output.weight", "attention.wo.weight"}, {"ffn_norm.weight", "ffn_norm.weight"}, {"ffn_gate.weight", "feed_forward.w1.weight"},
+                {"ffn_down.weight", "feed_forward.w2.weight"}, {"ffn_up.weight", "feed_forward.w3.weight"}};
+            for (auto &m : map) if (rest == m[0]) return "layers." + idx + "." + m[1];
+        }
+        return "";
+    };
+    for (auto &in : infos) {
+        TensorMeta t = in.t;
+        t.nbytes = gt_nbytes(t.type, (size_t)t.nelements());
+        if (in.rel % alignment || in.rel > mf.size || data0 > mf.size - in.rel || t.nbytes > mf.size - data0 - in.rel) return fail("tensor " + in.name + " runs past EOF");
+        t.offset = data0 + (size_t)in.rel;
+        t.name = rename(in.name);
+        if (t.name.empty()) continue;                              // e.g. rope_freqs: not part of this graph
         tensors[t.name] = t;
     }
     return E_None;

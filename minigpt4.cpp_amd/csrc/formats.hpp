@@ -1,6 +1,7 @@
 // Readers for the two on-disk formats the reference consumes (host only, no GPU dependency).
 //   format A: MiniGPT-4 vision container, "ggml" magic v1   (reference reader minigpt4.cpp:1478-1596, writer convert.py:74-180)
 //   format B: Vicuna LLM file, GGJT v3                        (read by llama.cpp behind minigpt4.cpp:1783; layout SURVEY.md 2.5)
+//   format B': the same model as a GGUF v2/v3 file (what current llama.cpp converters write) -- mapped onto the GGJT view below
 #pragma once
 #include <cstdint>
 #include <map>
@@ -47,8 +48,10 @@ struct LLMFile {
     std::vector<std::string> pieces;
     std::vector<float> scores;
     std::map<std::string, TensorMeta> tensors;
-    int load(const std::string &path, bool vocab_only = false);   // returns MiniGPT4Error (LoadLanguageModel on malformed input)
-    uint32_t n_ff() const { return ((2 * (4 * n_embd) / 3 + n_mult - 1) / n_mult) * n_mult; }
+    uint32_t n_ff_explicit = 0;                                   // GGUF files state the feed-forward width; GGJT files derive it from n_mult
+    int load(const std::string &path, bool vocab_only = false);   // returns MiniGPT4Error (LoadLanguageModel on malformed input); GGJT v3 or GGUF v2/v3 by magic
+    int load_gguf(bool vocab_only);                               // mf already mapped
+    uint32_t n_ff() const { return n_ff_explicit ? n_ff_explicit : ((2 * (4 * n_embd) / 3 + n_mult - 1) / n_mult) * n_mult; }
     const TensorMeta *find(const std::string &name) const { auto it = tensors.find(name); return it == tensors.end() ? nullptr : &it->second; }
 };
 

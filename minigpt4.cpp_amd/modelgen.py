@@ -279,6 +279,70 @@ def write_llm_file(path: str, cfg: LLMConfig, seed: int = 1234, std: float = 0.0
             raw.tofile(f)
 
 
+def ggjt_to_gguf(src: str, dst: str, version: int = 3, alignment: int = 32, extra_tensor: bool = True) -> None:
+    """Re-container a GGJT v3 LLM file as GGUF (the layout current llama.cpp converters write): same tensor bytes under the GGUF names, SentencePiece-form
+    vocabulary (U+2581 for spaces, "<0xXX>" byte tokens with token_type 6), llama.* metadata.  Test tooling for the GGUF reader (csrc/formats.cpp)."""
+    f = read_llm_file(src)
+    hp = f.hparams
+    n_ff = ((2 * (4 * hp["n_embd"]) // 3 + hp["n_mult"] - 1) // hp["n_mult"]) * hp["n_mult"]
+
+    def gs(b: bytes) -> bytes:
+        return struct.pack("<Q", len(b)) + b
+
+    def kv(key: str, vt: int, payload: bytes) -> bytes:
+        return gs(key.encode()) + struct.pack("<I", vt) + payload
+    toks, types = [], []
+    for i, (piece, _) in enumerate(f.vocab):
+        if 3 <= i < 259 and len(piece) == 1:
+            toks.append(b"<0x%02X>" % piece[0])
+            types.append(6)
+        else:
+            toks.append(piece.replace(b" ", "\u2581".encode()))
+            types.append(3 if i < 3 else 1)
+    meta = [kv("general.architecture", 8, gs(b"llama")), kv("general.name", 8, gs(b"synthetic")), kv("general.alignment", 4, struct.pack("<I", alignment)),
+            kv("llama.context_length", 4, struct.pack("<I", 2048)), kv("llama.embedding_length", 4, struct.pack("<I", hp["n_embd"])),
+            kv("llama.block_count", 4, struct.pack("<I", hp["n_layer"])), kv("llama.feed_forward_length", 4, struct.pack("<I", n_ff)),
+            kv("llama.rope.dimension_count", 4, struct.pack("<I", hp["n_embd"] // hp["n_head"])), kv("llama.attention.head_count", 4, struct.pack("<I", hp["n_head"])),
+            kv("llama.attention.head_count_kv", 4, struct.pack("<I", hp["n_head"])), kv("llama.attention.layer_norm_rms_epsilon", 6, struct.pack("<f", 1e-6)),
+            kv("llama.rope.freq_base", 6, struct.pack("<f", 10000.0)), kv("general.file_type", 4, struct.pack("<I", hp["ftype"])),
+            kv("tokenizer.ggml.model", 8, gs(b"llama")),
+            kv("tokenizer.ggml.tokens", 9, struct.pack("<IQ", 8, len(toks)) + b"".join(gs(t) for t in toks)),
+            kv("tokenizer.ggml.scores", 9, struct.pack("<IQ", 6, len(toks)) + struct.pack(f"<{len(toks)}f", *[s for _, s in f.vocab])),
+            kv("tokenizer.ggml.token_type", 9, struct.pack("<IQ", 5, len(toks)) + struct.pack(f"<{len(toks)}i", *types)),
+            kv("tokenizer.ggml.bos_token_id", 4, struct.pack("<I", 1)), kv("tokenizer.ggml.eos_token_id", 4, struct.pack("<I", 2)),
+            kv("some.unknown.array", 9, struct.pack("<IQ", 2, 3) + struct.pack("<3H", 1, 2, 3)), kv("some.bool", 7, b"\x01"), kv("some.u64", 10, struct.pack("<Q", 7))]
+    ren = {"tok_embeddings.weight": "token_embd.weight", "norm.weight": "output_norm.weight", "output.weight": "output.weight"}
+    sub = {"attention_norm.weight": "attn_norm.weight", "attention.wq.weight": "attn_q.weight", "attention.wk.weight": "attn_k.weight", "attention.wv.weight": "attn_v.weight",
+           "attention.wo.weight": "attn_output.weight", "ffn_norm.weight": "ffn_norm.weight", "feed_forward.w1.weight": "ffn_gate.weight", "feed_forward.w2.weight": "ffn_down.weight",
+           "feed_forward.w3.weight": "ffn_up.weight"}
+    infos, blobs, off = [], [], 0
+    items = list(f.tensors.items())
+    if extra_tensor:
+        items.append(("rope_freqs.weight", None))                  # a tensor the graph does not use: must be skipped by the reader
+    for name, t in items:
+        if t is None:
+            raw, ne, gt, gname = np.zeros(16, np.float32).view(np.uint8), (16,), Q.GGML_F32, name
+        else:
+            raw, ne, gt = f.raw(name), t.ne, t.gtype
+            if name.startswith("layers."):
+                _, idx, rest = name.split(".", 2)
+                gname = f"blk.{idx}.{sub[rest]}"
+            else:
+                gname = ren[name]
+        infos.append(gs(gname.encode()) + struct.pack("<I", len(ne)) + struct.pack(f"<{len(ne)}Q", *ne) + struct.pack("<IQ", gt, off))
+        blobs.append((off, raw))
+        off = _align(off + raw.nbytes, alignment)
+    head = struct.pack("<IIQQ", 0x46554747, version, len(infos), len(meta)) + b"".join(meta) + b"".join(infos)
+    with open(dst, "wb") as out:
+        out.write(head)
+        out.write(b"\0" * (_align(len(head), alignment) - len(head)))
+        base = out.tell()
+        for o, raw in blobs:
+            out.seek(base + o)
+            out.write(bytes(raw))
+        out.truncate(base + off)
+
+
 @dataclass
 class TensorInfo:
     name: str
