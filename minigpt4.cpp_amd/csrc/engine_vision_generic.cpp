@@ -87,7 +87,7 @@ void Engine::glinear(const GLin &L, const float *x, int rows, const float *bias,
 
 int Engine::encode_images_generic(const float *const *chw, int B, float *const *out) {
     hipStream_t s = stream_;
-    const int D = v_D_, M = v_M_, NQ = v_nq_, H = 768;
+    const int D = v_D_, NQ = v_nq_, H = 768;
     const int R = B * 257, RQ = B * NQ;
     hipEvent_t ea, eb; HIP_CHECK(hipEventCreate(&ea)); HIP_CHECK(hipEventCreate(&eb));
     for (int b = 0; b < B; b++) HIP_CHECK(hipMemcpyAsync(vi_img_ + (size_t)b * 3 * 224 * 224, chw[b], 3 * 224 * 224 * 4, hipMemcpyHostToDevice, s));

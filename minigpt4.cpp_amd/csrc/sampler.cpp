@@ -92,7 +92,10 @@ int Sampler::mirostat_v1(Candidates &c, float tau, float eta, int m, float *mu) 
     s_hat = sum_ti_bi / sum_ti_sq;
     const float epsilon_hat = s_hat - 1;
     const float k = powf((epsilon_hat * powf(2, *mu)) / (1 - powf(N, -epsilon_hat)), 1 / s_hat);
-    top_k(c, int(k), 1);
+    // int(k) of llama.cpp: k is inf / NaN for degenerate distributions (one candidate, all-equal or infinite logits); the x86 conversion the reference's build performs
+    // yields INT_MIN there, which top_k then raises to min_keep -- made explicit instead of relying on undefined behaviour
+    const int k_int = (k > -2147483648.0f && k < 2147483648.0f) ? (int)k : (-2147483647 - 1);
+    top_k(c, k_int, 1);
     const int X = token(c);
     const size_t xi = std::distance(c.data.begin(), std::find_if(c.data.begin(), c.data.end(), [&](const TokenData &t) { return t.id == X; }));
     const float observed = -log2f(c.data[xi].p);

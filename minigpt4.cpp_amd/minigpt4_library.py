@@ -437,7 +437,21 @@ class MiniGPT4ChatBot:
         self.library.minigpt4_system_prompt(self.ctx, self.n_threads)
 
     def upload_image(self, image):
+        """image: a preprocessed f32 [3][224][224] array, a file path / encoded bytes (decoded and preprocessed by the library itself:
+        minigpt4_image_load_from_file + minigpt4_preprocess_image, the reference's `test_native_image_implementation` path, minigpt4_library.py:722-724),
+        or a PIL image (the reference's torchvision-style path, via Pillow)."""
         self.reset_chat()
-        chw = image if isinstance(image, np.ndarray) else image_to_array(image)
-        self.embedding = self.library.minigpt4_encode_image(self.ctx, array_to_image_struct(chw), self.n_threads)
+        if isinstance(image, (str, bytes, bytearray)):
+            raw = self.library.amd_decode_image(bytes(image)) if not isinstance(image, str) else self.library.minigpt4_image_load_from_file(self.ctx, image)
+            pre = None
+            try:
+                pre = self.library.minigpt4_preprocess_image(self.ctx, raw)
+                self.embedding = self.library.minigpt4_encode_image(self.ctx, pre, self.n_threads)
+            finally:
+                self.library.minigpt4_free_image(raw)
+                if pre is not None:
+                    self.library.minigpt4_free_image(pre)
+        else:
+            chw = image if isinstance(image, np.ndarray) else image_to_array(image)
+            self.embedding = self.library.minigpt4_encode_image(self.ctx, array_to_image_struct(chw), self.n_threads)
         self.is_image_uploaded = True

@@ -45,3 +45,26 @@ def test_batched_requests_equal_requests_served_alone(gpu_lib, tmpdir_models):
             assert "###" not in a and len(a) <= len(b)
     finally:
         srv.close()
+
+
+def test_chatbot_uploads_a_file_through_the_native_image_path(gpu_lib, tmpdir_models):
+    """MiniGPT4ChatBot.upload_image(path): decode + Pillow-exact preprocess inside the library; same answer as uploading the oracle-preprocessed array."""
+    import refimage as RI
+    from test_cpu_image import GOLD
+    from minigpt4_cpp_amd import minigpt4_library as ML, modelgen as G
+    vp = os.path.join(tmpdir_models, "vision_serve.bin")
+    lp = os.path.join(tmpdir_models, "llm_serve.bin")
+    if not os.path.exists(vp):
+        G.write_vision_file(vp, G.tiny_vision(n_embd_llm=4096), seed=31, std=0.05)
+        G.write_llm_file(lp, G.tiny_llm(wtype="q4_0", n_embd=4096, n_layer=1, n_head=32, n_vocab=512, output_type="q6_k"), seed=4, std=0.02)
+    bot = ML.MiniGPT4ChatBot(vp, lp, library=gpu_lib, n_ctx=512, n_batch=64)
+    try:
+        bot.upload_image(os.path.join(IMG_DIR, "png_llama_small.png"))
+        a = [t for _, t in zip(range(6), bot.generate("what is it?", limit=6, temp=0.0, ignore_eos=True))]
+        bot.upload_image(RI.preprocess(GOLD["decoded/png_llama_small.png"]))
+        b = [t for _, t in zip(range(6), bot.generate("what is it?", limit=6, temp=0.0, ignore_eos=True))]
+        bot.upload_image(open(os.path.join(IMG_DIR, "png_llama_small.png"), "rb").read())
+        c = [t for _, t in zip(range(6), bot.generate("what is it?", limit=6, temp=0.0, ignore_eos=True))]
+        assert a == b == c and len(a) == 6
+    finally:
+        bot.free()
