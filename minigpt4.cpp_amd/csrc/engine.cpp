@@ -111,6 +111,9 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     // (row-pair epilogue); bit 6: wq|wk and a differently typed wv in one launch.  See DESIGN.md "mat-vec prologue".
     fuse_mask_ = getenv("MINIGPT4_FUSE") ? atoi(getenv("MINIGPT4_FUSE")) : FUSE_DEFAULT;
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
+    // Opt-in experiment (unmeasured at the time of writing): the w1|w3 launch also prepares w2's activation row (last-arriver per 256-row block),
+    // one launch less per layer.
+    tailq_ = getenv("MINIGPT4_TAILQ") && atoi(getenv("MINIGPT4_TAILQ"));
     if (getenv("MINIGPT4_BATCH_ROWS_MAX")) batch_rows_max_ = atoi(getenv("MINIGPT4_BATCH_ROWS_MAX"));
     if (const char *sk = getenv("MINIGPT4_SPLITK")) { sscanf(sk, "%d,%d", &splitk_proj_, &splitk_fc2_); splitk_proj_ = std::max(1, std::min(SPLITK_MAX, splitk_proj_)); splitk_fc2_ = std::max(1, std::min(SPLITK_MAX, splitk_fc2_)); }
     set_matvec_tuning(getenv("MINIGPT4_MV_WAVES") ? atoi(getenv("MINIGPT4_MV_WAVES")) : 0, getenv("MINIGPT4_FAT_LB") ? atoi(getenv("MINIGPT4_FAT_LB")) : 0, prop.multiProcessorCount);
@@ -358,7 +361,7 @@ void Engine::alloc_buffers() {
     sz(S * L * C * E * 2); sz(S * L * C * E * 2); sz(2 * C * (hd / 2) * 4 * 2); sz(3 * 65536 * 2);
     sz(5 * B * E * 4); sz(2 * B * F * 4); sz(S * V * 4); sz(S * V * 4); sz(8 * 256 + 2 * B * 4);
     sz(2 * B * Kmax); sz(B * Kmax / 256 * 4 + 64); sz(B * Kmax / 16 * 2 + 64); sz(4 * (B * Kmax / 32 * 4 + 64)); sz(B * Kmax * 2); sz(B * Kmax * 4);
-    sz(4096);
+    sz(8192);
     const size_t VB = (size_t)VISION_BATCH_MAX;                            // images encoded in one pass (minigpt4_encode_images)
     sz(VB * 3 * 224 * 224 * 4); sz(VB * 256 * 592 * 2); sz(VB * 256 * D * 4); sz(VB * 257 * D * 4); sz(VB * 257 * 3 * D * 4); sz(VB * 3 * 257 * D * 2); sz(VB * 257 * M * 2);
     sz(VB * (size_t)SPLITK_MAX * 257 * D * 4);
@@ -401,7 +404,9 @@ void Engine::alloc_buffers() {
     d_btok_ = reinterpret_cast<int *>(buf_arena_.take(768)); d_bslot_ = d_btok_ + MAX_CONVERSATIONS; d_bpos_ = d_bslot_ + MAX_CONVERSATIONS;
     batch_graph_.assign((size_t)MAX_CONVERSATIONS + 1, nullptr);
     d_tokens_ = reinterpret_cast<int *>(buf_arena_.take(B * 4));
-    d_scratch_ = buf_arena_.take(4096);
+    d_scratch_ = buf_arena_.take(8192);
+    d_tq_cnt_ = reinterpret_cast<unsigned *>(reinterpret_cast<uint8_t *>(d_scratch_) + 4096);   // arrival counters of the tail-fused quantisation (MINIGPT4_TAILQ)
+    HIP_CHECK(hipMemset(d_tq_cnt_, 0, 4096));
     HIP_CHECK(hipMemset(d_npast_, 0, 256)); HIP_CHECK(hipMemset(d_argmax_, 0, 256)); HIP_CHECK(hipMemset(d_feed_, 0, 256)); HIP_CHECK(hipMemset(d_btok_, 0, 768));
     HIP_CHECK(hipMemset(d_tokens_, 0, B * 4));
     HIP_CHECK(hipHostMalloc((void **)&h_argmax_, 256, hipHostMallocDefault));
@@ -508,13 +513,19 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s) {
         else { launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, false, s); }
         mul_mat(L.wo, N, x_, E, x_, s, &p_att, fz(1));
         bool paired = false;   // h1_ already holds silu(w1 x) * (w3 x)
-        if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5)); }
+        bool h_ready = false;  // act_ already holds the quantised silu(w1 x) * (w3 x) (tail-fused preparation)
+        if (dec && tailq_ && fz(2) && L.w1.type == L.w3.type && !prof_on_) {
+            const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_};
+            h_ready = launch_matvec_tailq(W2, Y2, act_, s, x_, L.ffn_norm, tabs_, d_tq_cnt_, 1024, act_, act_mask_for(L.w2.type));
+        }
+        if (h_ready) {}
+        else if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5)); }
         else if (act_mask_for(L.w1.type) == act_mask_for(L.w3.type) && !fz(2)) {
             launch_rms_quant(x_, L.ffn_norm, N, E, act_, act_mask_for(L.w1.type), s);
             mul_mat(L.w1, N, h1_, F, nullptr, s, nullptr, false); mul_mat(L.w3, N, h3_, F, nullptr, s, nullptr, false);
         } else { mul_mat(L.w1, N, h1_, F, nullptr, s, &p_ffn, fz(2)); mul_mat(L.w3, N, h3_, F, nullptr, s, &p_ffn, fz(2)); }
         const Prep p_h{2, h1_, nullptr};
-        mul_mat(L.w2, N, x_, E, x_, s, paired ? &p_h : &p_silu, fz(3));
+        mul_mat(L.w2, N, x_, E, x_, s, h_ready ? nullptr : (paired ? &p_h : &p_silu), fz(3));
     }
     // only the last token's logits are kept (llama.cpp logits_all = false)
     const Prep p_out{1, x_ + (size_t)(N - 1) * E, norm_};

@@ -35,6 +35,10 @@ void set_mmq_enabled(int v);
 bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s, int pro = 0, const float *px = nullptr,
                        const float *pw = nullptr, const Tables *tb = nullptr, int epi = 0);   // epi 1: y[0][g] = silu(W0[g].x) * (W1[g].x) (n == 2)
 bool matvec_silu_pair_supported(int type, int cols);
+// opt-in: w1|w3 (ffn-norm prologue) + tail-fused preparation of the next mat-vec's row: out planes receive quant(silu(W0 x) * (W1 x)) in `out_mask` form; cnt = zeroed
+// arrival counters (>= rows / 256, left zeroed).  false -> nothing launched.
+bool launch_matvec_tailq(const QWeight *const *W, float *const *y, const ActQ &A, hipStream_t s, const float *px, const float *pw, const Tables &tb, unsigned *cnt, int cnt_capacity,
+                         const ActQ &out, int out_mask);
 // batched decode: N = 1..4 activation rows (prepared in `A`) against 1..3 same-type, same-shape, equally spaced matrices, weights streamed once;
 // y[m][t * ldy + r] (+ residual[m][t * ldy + r]).  false -> outside the kernel's range, use launch_mul_mat.
 bool launch_matvec_rows(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s);

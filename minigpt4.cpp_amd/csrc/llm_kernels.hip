@@ -432,9 +432,21 @@ template <int NU> constexpr int mv_fat_max_threads() { return NU <= 4 ? 768 : 51
 // h[g] = silu_table(w1[g] . x) * (w3[g] . x) instead of the two dot products.  The table lookup of a group is consumed one group later, so
 // that it never stalls the weight stream.
 enum EpiKind : int { EPI_STORE = 0, EPI_SILU_PAIR = 1 };
-template <int T, int NU, int R, int PRO, int EPI>
-__device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, const ProArgs &pa, const int n_groups, const int n_waves, const int wave) {
+// Tail-fused quantisation (TQ, opt-in: MINIGPT4_TAILQ=1; w1|w3 launch only).  The launch that produces h1 = w1 x and h3 = w3 x also prepares the NEXT mat-vec's
+// activation row, so the standalone k_silu_mul_quant launch between w1|w3 and w2 disappears: every wave owns a CONTIGUOUS range of rows, publishes its
+// results write-through (agent-scope stores), drains them and adds its row count to the arrival counter of each 256-row block it touched; the wave whose
+// add completes a block (256 rows of w1 + 256 of w3 = 512 arrivals) reads the block back with agent-scope loads and writes silu(h1) * h3 in ggml's
+// Q8_K / Q8_0 form into the activation planes -- the same quant_emit4 the standalone kernel runs, on the same values, hence bit-identical.  No wave ever
+// waits for another (last-arriver, no spinning), the last arriver zeroes the counter again (graph replay needs no memset node).
+struct TqArgs { unsigned *cnt; ActQ out; int mask; };
+template <int T, int NU, int R, int PRO, int EPI, bool TQ = false>
+__device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, const ProArgs &pa, const int n_groups, const int n_waves, const int wave, const TqArgs *tq = nullptr) {
     static_assert(EPI == EPI_STORE || R == 2, "the SiLU pair epilogue works on row pairs");
+    static_assert(!TQ || (EPI == EPI_STORE && PRO == PRO_RMS), "tail-fused quantisation: plain stores, input row prepared in LDS (the global planes are the OUTPUT)");
+    // groups of this wave: g = g_first, g_first + g_step, ... < g_last
+    const int g_first = TQ ? (int)((unsigned)wave * (unsigned)n_groups / (unsigned)n_waves) : wave;
+    const int g_last = TQ ? (int)((unsigned)(wave + 1) * (unsigned)n_groups / (unsigned)n_waves) : n_groups;
+    const int g_step = TQ ? 1 : n_waves;
     using X = Tr<T>;
     const int lane = threadIdx.x & 63;
     const int K = ms.w0.cols, U = K / X::EPU, rows_each = ms.rows_each, total_rows = ms.n * rows_each;
@@ -468,7 +480,7 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
     Grp cur, nxt;
     typename X::AU a[NU];
     if (PRO == PRO_NONE) {
-        fetch(wave, cur);
+        fetch(g_first, cur);
 #pragma unroll
         for (int i = 0; i < NU; i++) X::loada(A, 0, K, uc[i], a[i]);
     } else {
@@ -504,7 +516,7 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
 #pragma unroll
             for (int r = 0; r < RND; r++) { xv[r].x = tab(pa.tb.silu, xv[r].x); xv[r].y = tab(pa.tb.silu, xv[r].y); xv[r].z = tab(pa.tb.silu, xv[r].z); xv[r].w = tab(pa.tb.silu, xv[r].w); }
         }
-        fetch(wave, cur);
+        fetch(g_first, cur);
         float scale = 1.0f;
         if (PRO == PRO_RMS) {
             double sum = 0.0;
@@ -557,7 +569,9 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
                 const int row = g * R + r;
                 if (lane == 0 && row < total_rows) {
                     const int m = row >= 2 * rows_each ? 2 : (row >= rows_each ? 1 : 0), lr = row - m * rows_each;
-                    ms.y0[(long long)m * ms.dy + lr] = has_res ? out[r] + G.res[r] : out[r];
+                    const float val = has_res ? out[r] + G.res[r] : out[r];
+                    if (TQ) __hip_atomic_store(ms.y0 + ((long long)m * ms.dy + lr), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through: read by the block's last arriver
+                    else ms.y0[(long long)m * ms.dy + lr] = val;
                 }
             }
         }
@@ -565,25 +579,59 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
     // two statically named stages (a `cur = nxt` copy would have to wait for the loads in flight; the requested unroll is refused by the compiler)
     // The sched_barriers keep the next group's loads ahead of the current group's dot products (the scheduler otherwise hoists the arithmetic, and
     // with it the wait for the current tiles, above the loads: one tile in flight instead of two).
-    for (int g = wave; g < n_groups;) {
-        fetch(g + n_waves, nxt);
+    for (int g = g_first; g < g_last;) {
+        fetch(g + g_step, nxt);
         __builtin_amdgcn_sched_barrier(0);
         consume(g, cur);
         __builtin_amdgcn_sched_barrier(0);
-        g += n_waves;
-        if (g >= n_groups) break;
-        fetch(g + n_waves, cur);
+        g += g_step;
+        if (g >= g_last) break;
+        fetch(g + g_step, cur);
         __builtin_amdgcn_sched_barrier(0);
         consume(g, nxt);
         __builtin_amdgcn_sched_barrier(0);
-        g += n_waves;
+        g += g_step;
     }
     if (EPI == EPI_SILU_PAIR) flush_pending();
+    if constexpr (TQ) {
+        // Arrival.  Lane 0 issued every result store of this wave; drain them (write-through stores are acknowledged by memory) before the counter moves.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int r = g_first * R;
+        const int r_end = min(g_last * R, total_rows);
+        while (r < r_end) {                                               // wave-uniform: one pass per 256-row block the range touches (usually 1, at most 2-3)
+            const int lr = r >= rows_each ? r - rows_each : r;            // ms.n == 2, rows_each % 256 == 0 (checked by the host)
+            const int blk = lr >> 8;
+            const int seg_end = min(r_end, r - (lr & 255) + 256);
+            const unsigned n = (unsigned)(seg_end - r);
+            unsigned old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(tq->cnt + blk, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+            if (old + n == 512u) {                                        // 256 rows of w1 and 256 rows of w3 are in memory: this wave prepares the block
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const int i = blk * 256 + lane * 4;
+                // agent-scope (sc1) 16-byte loads: both in flight together, then the four table gathers
+                const __amdgpu_buffer_rsrc_t hb = mkbuf(reinterpret_cast<const uint8_t *>(ms.y0 + blk * 256));       // one descriptor: h3 sits dy floats (< 2 GB) behind h1
+                const v4u_t ua = __builtin_amdgcn_raw_buffer_load_b128(hb, lane * 16, 0, 16);
+                const v4u_t ub = __builtin_amdgcn_raw_buffer_load_b128(hb, lane * 16, (int)ms.dy * 4, 16);
+                float v[4];
+                v[0] = tab(pa.tb.silu, __uint_as_float(ua.x)) * __uint_as_float(ub.x); v[1] = tab(pa.tb.silu, __uint_as_float(ua.y)) * __uint_as_float(ub.y);
+                v[2] = tab(pa.tb.silu, __uint_as_float(ua.z)) * __uint_as_float(ub.z); v[3] = tab(pa.tb.silu, __uint_as_float(ua.w)) * __uint_as_float(ub.w);
+                quant_emit4(v, true, i, 0, rows_each, tq->out, tq->mask);
+                if (lane == 0) __hip_atomic_store(tq->cnt + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            r = seg_end;
+        }
+    }
 }
 template <int T, int NU, int R, int PRO, int EPI>
 __global__ __launch_bounds__(PRO == PRO_NONE ? 256 : mv_fat_max_threads<NU>()) void k_matvec_v2(const MatSet ms, const ActQ A, const ProArgs pa, const int n_groups, const int n_waves) {
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));   // wave-uniform: scalar loop control
     matvec_run<T, NU, R, PRO, EPI>(ms, A, pa, n_groups, n_waves, wave);
+}
+template <int T, int NU, int R>
+__global__ __launch_bounds__(mv_fat_max_threads<NU>()) void k_matvec_tq(const MatSet ms, const ActQ A, const ProArgs pa, const TqArgs tq, const int n_groups, const int n_waves) {
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    matvec_run<T, NU, R, PRO_RMS, EPI_STORE, true>(ms, A, pa, n_groups, n_waves, wave, &tq);
 }
 // Two weight types in one launch (llama.cpp's k-quant mixes give wv more bits than wq|wk): waves [0, n_waves1) stream set 1, the rest set 2.  Both
 // sets share K and the prepared activation row (both types read the Q8_K image); every wave passes the same number of workgroup barriers.
@@ -744,6 +792,43 @@ bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *co
     case GT_Q5_K: return launch_v2_type<GT_Q5_K>(ms, A, pro, pa, epi, s);
     case GT_Q6_K: return launch_v2_type<GT_Q6_K>(ms, A, pro, pa, epi, s);
     default: return false;   // Q8_0 / F16 / F32 rows have more units per row: served by k_mul_mat
+    }
+}
+
+// w1|w3 with the ffn-norm prologue AND the tail-fused preparation of w2's activation row (see TqArgs).  cnt: >= rows / 256 zeroed arrival counters (left zeroed).
+// Returns false (nothing launched) when the shape / type is outside the variant's range; the caller then takes the ordinary path.
+template <int T, int NU, int R>
+static void launch_tq_t(const MatSet &ms, const ActQ &A, const ProArgs &pa, const TqArgs &tq, hipStream_t s) {
+    const int n_groups = (ms.n * ms.rows_each + R - 1) / R;
+    const int LB = pick_fat_threads(n_groups, mv_fat_max_threads<NU>()), WPB = LB / 64;
+    const int n_blocks = std::min((n_groups + WPB - 1) / WPB, g_mv_cus);
+    hipLaunchKernelGGL((k_matvec_tq<T, NU, R>), dim3((unsigned)n_blocks), dim3((unsigned)LB), mv_prologue_lds(ms.w0.cols), s, ms, A, pa, tq, n_groups, n_blocks * WPB);
+}
+template <int T>
+static bool launch_tq_type(const MatSet &ms, const ActQ &A, const ProArgs &pa, const TqArgs &tq, hipStream_t s) {
+    const int nu = (ms.w0.cols / Tr<T>::EPU + 63) / 64;
+    switch (nu) {
+    case 1: launch_tq_t<T, 1, 2>(ms, A, pa, tq, s); return true;
+    case 2: launch_tq_t<T, 2, MG4_R_NU2>(ms, A, pa, tq, s); return true;
+    case 3: launch_tq_t<T, 3, MG4_R_NU3>(ms, A, pa, tq, s); return true;
+    case 4: launch_tq_t<T, 4, 1>(ms, A, pa, tq, s); return true;
+    default: return false;
+    }
+}
+bool launch_matvec_tailq(const QWeight *const *W, float *const *y, const ActQ &A, hipStream_t s, const float *px, const float *pw, const Tables &tb, unsigned *cnt, int cnt_capacity,
+                         const ActQ &out, int out_mask) {
+    if (!matvec_prologue_supported(W[0]->type, W[0]->cols) || W[0]->rows % 256 || W[0]->rows / 256 > cnt_capacity || !cnt) return false;
+    if (out_mask != ACT_Q8K && out_mask != ACT_Q80) return false;
+    MatSet ms;
+    if (!fill_matset(ms, W, y, nullptr, 2)) return false;
+    ProArgs pa{}; pa.x = px; pa.w = pw; pa.tb = tb;
+    TqArgs tq{cnt, out, out_mask};
+    switch (W[0]->type) {
+    case GT_Q4_0: return launch_tq_type<GT_Q4_0>(ms, A, pa, tq, s);
+    case GT_Q4_K: return launch_tq_type<GT_Q4_K>(ms, A, pa, tq, s);
+    case GT_Q5_K: return launch_tq_type<GT_Q5_K>(ms, A, pa, tq, s);
+    case GT_Q6_K: return launch_tq_type<GT_Q6_K>(ms, A, pa, tq, s);
+    default: return false;
     }
 }
 
