@@ -113,7 +113,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
     // Opt-in experiment (unmeasured at the time of writing): the w1|w3 launch also prepares w2's activation row (last-arriver per 256-row block),
     // one launch less per layer.
-    tailq_ = getenv("MINIGPT4_TAILQ") && atoi(getenv("MINIGPT4_TAILQ"));
+    tailq_ = getenv("MINIGPT4_TAILQ") ? atoi(getenv("MINIGPT4_TAILQ")) : 0;   // 1: tail-fused preparation; 2: only its contiguous row order (the standalone preparation still runs)
     if (getenv("MINIGPT4_BATCH_ROWS_MAX")) batch_rows_max_ = atoi(getenv("MINIGPT4_BATCH_ROWS_MAX"));
     if (const char *sk = getenv("MINIGPT4_SPLITK")) { sscanf(sk, "%d,%d", &splitk_proj_, &splitk_fc2_); splitk_proj_ = std::max(1, std::min(SPLITK_MAX, splitk_proj_)); splitk_fc2_ = std::max(1, std::min(SPLITK_MAX, splitk_fc2_)); }
     set_matvec_tuning(getenv("MINIGPT4_MV_WAVES") ? atoi(getenv("MINIGPT4_MV_WAVES")) : 0, getenv("MINIGPT4_FAT_LB") ? atoi(getenv("MINIGPT4_FAT_LB")) : 0, prop.multiProcessorCount);
@@ -516,9 +516,11 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s) {
         bool h_ready = false;  // act_ already holds the quantised silu(w1 x) * (w3 x) (tail-fused preparation)
         if (dec && tailq_ && fz(2) && L.w1.type == L.w3.type && !prof_on_) {
             const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_};
-            h_ready = launch_matvec_tailq(W2, Y2, act_, s, x_, L.ffn_norm, tabs_, d_tq_cnt_, 1024, act_, act_mask_for(L.w2.type));
+            h_ready = launch_matvec_tailq(W2, Y2, act_, s, x_, L.ffn_norm, tabs_, tailq_ == 1 ? d_tq_cnt_ : nullptr, 1024, act_, act_mask_for(L.w2.type));
         }
-        if (h_ready) {}
+        const bool w13_done = h_ready;
+        if (tailq_ != 1) h_ready = false;
+        if (w13_done) {}
         else if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5)); }
         else if (act_mask_for(L.w1.type) == act_mask_for(L.w3.type) && !fz(2)) {
             launch_rms_quant(x_, L.ffn_norm, N, E, act_, act_mask_for(L.w1.type), s);

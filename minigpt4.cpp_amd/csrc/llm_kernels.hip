@@ -570,7 +570,7 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
                 if (lane == 0 && row < total_rows) {
                     const int m = row >= 2 * rows_each ? 2 : (row >= rows_each ? 1 : 0), lr = row - m * rows_each;
                     const float val = has_res ? out[r] + G.res[r] : out[r];
-                    if (TQ) __hip_atomic_store(ms.y0 + ((long long)m * ms.dy + lr), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through: read by the block's last arriver
+                    if (TQ && tq->cnt) __hip_atomic_store(ms.y0 + ((long long)m * ms.dy + lr), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through: read by the block's last arriver
                     else ms.y0[(long long)m * ms.dy + lr] = val;
                 }
             }
@@ -597,7 +597,7 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
         // Arrival.  Lane 0 issued every result store of this wave; drain them (write-through stores are acknowledged by memory) before the counter moves.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int r = g_first * R;
-        const int r_end = min(g_last * R, total_rows);
+        const int r_end = tq->cnt ? min(g_last * R, total_rows) : 0;      // cnt == nullptr: only the contiguous row order is exercised (A/B of the mapping alone)
         while (r < r_end) {                                               // wave-uniform: one pass per 256-row block the range touches (usually 1, at most 2-3)
             const int lr = r >= rows_each ? r - rows_each : r;            // ms.n == 2, rows_each % 256 == 0 (checked by the host)
             const int blk = lr >> 8;
@@ -817,7 +817,7 @@ static bool launch_tq_type(const MatSet &ms, const ActQ &A, const ProArgs &pa, c
 }
 bool launch_matvec_tailq(const QWeight *const *W, float *const *y, const ActQ &A, hipStream_t s, const float *px, const float *pw, const Tables &tb, unsigned *cnt, int cnt_capacity,
                          const ActQ &out, int out_mask) {
-    if (!matvec_prologue_supported(W[0]->type, W[0]->cols) || W[0]->rows % 256 || W[0]->rows / 256 > cnt_capacity || !cnt) return false;
+    if (!matvec_prologue_supported(W[0]->type, W[0]->cols) || W[0]->rows % 256 || (cnt && W[0]->rows / 256 > cnt_capacity)) return false;
     if (out_mask != ACT_Q8K && out_mask != ACT_Q80) return false;
     MatSet ms;
     if (!fill_matset(ms, W, y, nullptr, 2)) return false;
