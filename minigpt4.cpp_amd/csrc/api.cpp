@@ -280,7 +280,18 @@ int minigpt4_amd_weight_arena(struct MiniGPT4Context *ctx, int which, void **dev
 
 // ---- single-kernel hooks ---------------------------------------------------------------------------------------------------
 
+int minigpt4_amd_convert_q3k_q6k(const void *src, void *dst, int64_t n_blocks) {
+    if (!src || !dst || n_blocks < 0) return 1;
+    q3k_to_q6k(static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), (size_t)n_blocks);
+    return 0;
+}
+
 int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y) {
+    if (ggml_type == GT_Q3_K && raw_w && n_in > 0 && n_out > 0 && n_in % 256 == 0) {   // the engine's load path: exact Q6_K image (quantize.hpp)
+        std::vector<uint8_t> q6((size_t)(n_in / 256 * n_out) * 210);
+        q3k_to_q6k(static_cast<const uint8_t *>(raw_w), q6.data(), (size_t)(n_in / 256 * n_out));
+        return minigpt4_amd_test_mul_mat(GT_Q6_K, q6.data(), n_in, n_out, x, N, y);
+    }
     if (!raw_w || !x || !y || n_in <= 0 || n_out <= 0 || N <= 0 || !qweight_supported(ggml_type) || n_in % gt_block(ggml_type)) return 1;
     if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
     return guarded(3, [&]() -> int {

@@ -1,4 +1,5 @@
 #include "engine.hpp"
+#include "quantize.hpp"
 #include "imageio.hpp"
 
 #include <algorithm>
@@ -131,7 +132,21 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     return E_None;
 }
 
-void Engine::upload_qweight(const TensorMeta &t, const uint8_t *file_base, QWeight &w) {
+// Tensor types the kernels do not stream natively but that have an exact image in one they do: Q3_K -> Q6_K (quantize.hpp).  The conversion runs on the host at load.
+static int effective_type(int t) { return t == GT_Q3_K ? GT_Q6_K : t; }
+static bool tensor_type_loadable(int t) { return qweight_supported(effective_type(t)); }
+// bytes of a tensor as the GPU holds it
+static size_t effective_nbytes(const TensorMeta &t) { return t.type == GT_Q3_K ? t.nbytes / 110 * 210 : t.nbytes; }
+
+void Engine::upload_qweight(const TensorMeta &t0, const uint8_t *file_base0, QWeight &w) {
+    TensorMeta t = t0;
+    const uint8_t *file_base = file_base0;
+    std::vector<uint8_t> conv;
+    if (t0.type == GT_Q3_K) {
+        conv.resize(effective_nbytes(t0));
+        q3k_to_q6k(file_base0 + t0.offset, conv.data(), t0.nbytes / 110);
+        t.type = GT_Q6_K; t.nbytes = conv.size(); t.offset = 0; file_base = conv.data();
+    }
     const int cols = (int)t.ne[0], rows = (int)t.ne[1];
     QWeight plan;
     const size_t need = plan_qweight(t.type, rows, cols, plan, nullptr);
@@ -156,7 +171,7 @@ int Engine::load_llm(const std::string &path) {
         if (!t) { set_last_error("LLM file: missing tensor " + name); return nullptr; }
         if (t->ne[0] != ne0 || (ne1 ? (t->ne.size() != 2 || t->ne[1] != ne1) : t->ne.size() != 1)) { set_last_error("LLM file: bad shape for " + name); return nullptr; }
         if (ne1 == 0 && t->type != GT_F32) { set_last_error("LLM file: " + name + " must be f32"); return nullptr; }
-        if (ne1 && !qweight_supported(t->type)) { set_last_error(std::string("LLM file: tensor type ") + gt_name(t->type) + " of " + name + " is not supported by the gfx950 kernels"); return nullptr; }
+        if (ne1 && !tensor_type_loadable(t->type)) { set_last_error(std::string("LLM file: tensor type ") + gt_name(t->type) + " of " + name + " is not supported by the gfx950 kernels"); return nullptr; }
         return t;
     };
     // pass 1: validate + size the arena
@@ -175,14 +190,14 @@ int Engine::load_llm(const std::string &path) {
     for (auto &m : mats) {
         const TensorMeta *t = need(m.first, m.second.first, m.second.second);
         if (!t) { MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
-        total += plan_qweight(t->type, (int)t->ne[1], (int)t->ne[0], tmp, nullptr) + 256;
-        if (t->type != GT_F16 && t->type != GT_F32) max_raw = std::max(max_raw, t->nbytes);
-        wbytes_token_ += t->nbytes;
+        total += plan_qweight(effective_type(t->type), (int)t->ne[1], (int)t->ne[0], tmp, nullptr) + 256;
+        if (t->type != GT_F16 && t->type != GT_F32) max_raw = std::max(max_raw, effective_nbytes(*t));
+        wbytes_token_ += effective_nbytes(*t);                             // what a decoded token streams from HBM
     }
     const TensorMeta *tt = llm_.find("tok_embeddings.weight");
-    if (!tt || tt->ne.size() != 2 || tt->ne[0] != E || tt->ne[1] != V || !qweight_supported(tt->type)) { set_last_error("LLM file: bad tok_embeddings.weight"); MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
-    total += tt->nbytes + 256;
-    wbytes_token_ += gt_nbytes(tt->type, (size_t)E);
+    if (!tt || tt->ne.size() != 2 || tt->ne[0] != E || tt->ne[1] != V || !tensor_type_loadable(tt->type)) { set_last_error("LLM file: bad tok_embeddings.weight"); MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
+    total += effective_nbytes(*tt) + 256;
+    wbytes_token_ += gt_nbytes(effective_type(tt->type), (size_t)E);
     for (int i = 0; i < L; i++) for (const char *n : {"attention_norm.weight", "ffn_norm.weight"}) if (!need("layers." + std::to_string(i) + "." + n, E, 0)) { MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
     if (!need("norm.weight", E, 0)) { MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
     total += (size_t)(2 * L + 1) * ((size_t)E * 4 + 256);
@@ -209,8 +224,12 @@ int Engine::load_llm(const std::string &path) {
     }
     const TensorMeta *nt = llm_.find("norm.weight");
     norm_ = upload_raw<float>(llm_arena_, fb + nt->offset, nt->nbytes);
-    tok_raw_ = upload_raw<uint8_t>(llm_arena_, fb + tt->offset, tt->nbytes);
-    tok_type_ = tt->type;
+    if (tt->type == GT_Q3_K) {   // the embedding gather dequantises raw ggml rows: give it the (value-identical) Q6_K rows
+        std::vector<uint8_t> conv(effective_nbytes(*tt));
+        q3k_to_q6k(fb + tt->offset, conv.data(), tt->nbytes / 110);
+        tok_raw_ = upload_raw<uint8_t>(llm_arena_, conv.data(), conv.size());
+    } else tok_raw_ = upload_raw<uint8_t>(llm_arena_, fb + tt->offset, tt->nbytes);
+    tok_type_ = effective_type(tt->type);
     MG4_INFO("llm weights: %.1f MB in HBM, %.3f GB streamed per decoded token", llm_arena_.used / 1048576.0, wbytes_token_ / 1e9);
     return E_None;
 }

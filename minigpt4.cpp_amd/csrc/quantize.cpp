@@ -367,4 +367,36 @@ int quantize_vision_file(const char *in_path, const char *out_path, int mg4_data
     return E_None;
 }
 
+
+// ---- Q3_K -> Q6_K (load time; see quantize.hpp).  block_q3_K = hmask[32] | qs[64] | scales[12] (sixteen 6-bit values) | d; element 128 n + 32 j + l of a super-block is
+// ((qs[32 n + l] >> 2 j) & 3) - (hmask[l] bit (4 n + j) ? 0 : 4) with scale index 8 n + 2 j + l / 16 (k_quants.c dequantize_row_q3_K); block_q6_K = ql[128] | qh[64] |
+// scales[16] int8 | d with element 128 n + 32 a + l in ql[64 n + 32 (a & 1) + l] (nibble a >> 1) and bits 2 a of qh[32 n + l], the same scale index.
+static void q3k_to_q6k_range(const uint8_t *src, uint8_t *dst, size_t b0, size_t b1) {
+    for (size_t b = b0; b < b1; b++) {
+        const uint8_t *x = src + b * 110, *hm = x, *qs = x + 32, *sb = x + 96;
+        uint8_t *y = dst + b * 210, *ql = y, *qh = y + 128;
+        memset(y, 0, 192);
+        for (int n = 0; n < 2; n++) for (int a = 0; a < 4; a++) for (int l = 0; l < 32; l++) {
+            const int q3 = ((qs[32 * n + l] >> (2 * a)) & 3) - (((hm[l] >> (4 * n + a)) & 1) ? 0 : 4);
+            const unsigned v = (unsigned)(q3 + 32);                                            // 6-bit field of Q6_K: value + 32
+            ql[64 * n + 32 * (a & 1) + l] |= (uint8_t)((v & 15) << ((a >> 1) * 4));
+            qh[32 * n + l] |= (uint8_t)((v >> 4) << (2 * a));
+        }
+        int8_t *sc = reinterpret_cast<int8_t *>(y + 192);
+        for (int j = 0; j < 4; j++) {
+            const int hi = sb[8 + j];
+            sc[j] = (int8_t)(((sb[j] & 15) | (((hi >> 0) & 3) << 4)) - 32); sc[4 + j] = (int8_t)(((sb[4 + j] & 15) | (((hi >> 2) & 3) << 4)) - 32);
+            sc[8 + j] = (int8_t)(((sb[j] >> 4) | (((hi >> 4) & 3) << 4)) - 32); sc[12 + j] = (int8_t)(((sb[4 + j] >> 4) | (((hi >> 6) & 3) << 4)) - 32);
+        }
+        y[208] = x[108]; y[209] = x[109];
+    }
+}
+void q3k_to_q6k(const uint8_t *src, uint8_t *dst, size_t n_blocks) {
+    const size_t nthr = n_blocks < 4096 ? 1 : std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), 32));
+    if (nthr == 1) { q3k_to_q6k_range(src, dst, 0, n_blocks); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nthr; t++) th.emplace_back(q3k_to_q6k_range, src, dst, n_blocks * t / nthr, n_blocks * (t + 1) / nthr);
+    for (auto &t : th) t.join();
+}
+
 }  // namespace mg4

@@ -119,6 +119,7 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_encode_images.argtypes = [VOID_PTR, P(MiniGPT4Images), P(MiniGPT4Embeddings), SIZE_T]
         L.minigpt4_free_embeddings.argtypes = [P(MiniGPT4Embeddings)]
         L.minigpt4_amd_weight_arena.argtypes = [VOID_PTR, I32, P(VOID_PTR), P(SIZE_T)]
+        L.minigpt4_amd_convert_q3k_q6k.argtypes = [VOID_PTR, VOID_PTR, ctypes.c_int64]
         L.minigpt4_amd_test_mul_mat.argtypes = [I32, VOID_PTR, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, ctypes.c_int64, FLOAT_PTR]
         L.minigpt4_amd_test_matvec.argtypes = [I32, VOID_PTR, I32, I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, FLOAT_PTR, I32, I32, I32, FLOAT_PTR, FLOAT_PTR]
         L.minigpt4_amd_test_matvec_rows.argtypes = [I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, I32, FLOAT_PTR, FLOAT_PTR]

@@ -345,6 +345,101 @@ def dequantize_q6_k(buf: np.ndarray, n: int) -> np.ndarray:
     return y.reshape(-1)
 
 
+# --------------------------------------------------------------------------- Q3_K (110 bytes: hmask[32], qs[64], scales[12] (16 x 6 bit), d fp16)
+def _q3k_unpack_scales(sb: np.ndarray) -> np.ndarray:
+    """[nb, 12] uint8 -> [nb, 16] int (0..63), ggml's kmask1/kmask2 shuffle (k_quants.c dequantize_row_q3_K)."""
+    sb = sb.astype(np.int32)
+    out = np.zeros((sb.shape[0], 16), np.int32)
+    for j in range(4):
+        hi = sb[:, 8 + j]
+        out[:, j] = (sb[:, j] & 15) | (((hi >> 0) & 3) << 4)
+        out[:, 4 + j] = (sb[:, 4 + j] & 15) | (((hi >> 2) & 3) << 4)
+        out[:, 8 + j] = (sb[:, j] >> 4) | (((hi >> 4) & 3) << 4)
+        out[:, 12 + j] = (sb[:, 4 + j] >> 4) | (((hi >> 6) & 3) << 4)
+    return out
+
+
+def _q3k_values(b: np.ndarray) -> np.ndarray:
+    """[nb, 110] -> signed 3-bit values [nb, 256] in element order (q - 4 when the hmask bit is clear)."""
+    nb = b.shape[0]
+    hm, qs = b[:, 0:32].astype(np.int32), b[:, 32:96].astype(np.int32)
+    v = np.zeros((nb, 256), np.int32)
+    for n_ in range(2):
+        for j in range(4):
+            lo = (qs[:, 32 * n_:32 * n_ + 32] >> (2 * j)) & 3
+            hb = (hm >> (4 * n_ + j)) & 1
+            v[:, 128 * n_ + 32 * j:128 * n_ + 32 * j + 32] = lo - np.where(hb != 0, 0, 4)
+    return v
+
+
+def dequantize_q3_k(buf: np.ndarray, n: int) -> np.ndarray:
+    b = np.frombuffer(buf, np.uint8, n // 256 * 110).reshape(-1, 110)
+    sc = _q3k_unpack_scales(b[:, 96:108]).astype(np.float64) - 32.0
+    d = b[:, 108:110].copy().view(np.float16).astype(np.float64)
+    y = _q3k_values(b).reshape(-1, 16, 16).astype(np.float64) * (d * sc)[:, :, None]
+    return y.reshape(-1)
+
+
+def quantize_q3_k(x: np.ndarray) -> np.ndarray:
+    """Valid Q3_K blocks (sub-block scale from the signed maximum, 6-bit scales against the largest one); not ggml's rmse search."""
+    x = np.asarray(x, np.float32).reshape(-1, 16, 16)
+    nb = x.shape[0]
+    idx = np.argmax(np.abs(x), axis=2)
+    mx = np.take_along_axis(x, idx[:, :, None], axis=2)[:, :, 0]
+    s = mx / -4.0                                        # signed per-sub-block scale: the extreme value maps to -4
+    sidx = np.argmax(np.abs(s), axis=1)
+    smax = s[np.arange(nb), sidx]
+    d = (smax / -32.0).astype(np.float32)                # the largest scale maps to -32
+    dh = _f16(d)
+    df = dh.astype(np.float32)
+    inv_d = np.where(df != 0, 1.0 / np.where(df != 0, df, 1), 0)
+    l6 = np.rint(s * inv_d[:, None]).clip(-32, 31).astype(np.int32)       # scale - 32
+    eff = df[:, None] * l6.astype(np.float32)
+    inv_eff = np.where(eff != 0, 1.0 / np.where(eff != 0, eff, 1), 0)
+    q = (np.rint(x * inv_eff[:, :, None]).clip(-4, 3) + 4).astype(np.int32).reshape(nb, 256)   # 0..7
+    out = np.zeros((nb, 110), np.uint8)
+    hm = np.zeros((nb, 32), np.int32)
+    qs = np.zeros((nb, 64), np.int32)
+    for n_ in range(2):
+        for j in range(4):
+            w = q[:, 128 * n_ + 32 * j:128 * n_ + 32 * j + 32]
+            hm |= (w >> 2) << (4 * n_ + j)               # bit set <=> value >= 0 (nothing subtracted)
+            qs[:, 32 * n_:32 * n_ + 32] |= (w & 3) << (2 * j)
+    L = l6 + 32
+    sb = np.zeros((nb, 12), np.int32)
+    for j in range(16):
+        lo, hi = L[:, j] & 15, L[:, j] >> 4
+        if j < 8:
+            sb[:, j] |= lo
+        else:
+            sb[:, j - 8] |= lo << 4
+        sb[:, 8 + j % 4] |= hi << (2 * (j // 4))
+    out[:, 0:32] = hm.astype(np.uint8)
+    out[:, 32:96] = qs.astype(np.uint8)
+    out[:, 96:108] = sb.astype(np.uint8)
+    out[:, 108:110] = dh.view(np.uint8).reshape(-1, 2)
+    return out.reshape(-1)
+
+
+def q3_k_to_q6_k(buf: np.ndarray, n: int) -> np.ndarray:
+    """Lossless re-encoding of Q3_K blocks as Q6_K blocks: both are d * scale_16 * q with 16 sub-blocks of 16, so q6 = q3 (in [-4, 3]),
+    int8 scale = scale6 - 32, same d -- every dequantised value and every integer block dot product is unchanged.  Numpy twin of the product's
+    load-time conversion (csrc/quantize.cpp: q3k_to_q6k)."""
+    b = np.frombuffer(buf, np.uint8, n // 256 * 110).reshape(-1, 110)
+    nb = b.shape[0]
+    q = (_q3k_values(b) + 32).astype(np.uint8)           # 6-bit field, 28..35
+    sc = (_q3k_unpack_scales(b[:, 96:108]) - 32).astype(np.int8)
+    out = np.zeros((nb, 210), np.uint8)
+    for n_ in range(2):
+        w = q[:, 128 * n_:128 * n_ + 128].reshape(nb, 4, 32)
+        out[:, 64 * n_:64 * n_ + 32] = (w[:, 0] & 15) | ((w[:, 2] & 15) << 4)
+        out[:, 64 * n_ + 32:64 * n_ + 64] = (w[:, 1] & 15) | ((w[:, 3] & 15) << 4)
+        out[:, 128 + 32 * n_:128 + 32 * n_ + 32] = (w[:, 0] >> 4) | ((w[:, 1] >> 4) << 2) | ((w[:, 2] >> 4) << 4) | ((w[:, 3] >> 4) << 6)
+    out[:, 192:208] = sc.view(np.uint8)
+    out[:, 208:210] = b[:, 108:110]
+    return out.reshape(-1)
+
+
 # --------------------------------------------------------------------------- dispatch
 def quantize(gtype: int, x: np.ndarray) -> np.ndarray:
     """float array -> raw bytes (uint8) in ggml block layout, row-major over the flattened array."""
@@ -356,7 +451,7 @@ def quantize(gtype: int, x: np.ndarray) -> np.ndarray:
     fn = {
         GGML_Q4_0: quantize_q4_0, GGML_Q4_1: quantize_q4_1, GGML_Q5_0: quantize_q5_0,
         GGML_Q5_1: quantize_q5_1, GGML_Q8_0: quantize_q8_0, GGML_Q4_K: quantize_q4_k,
-        GGML_Q5_K: quantize_q5_k, GGML_Q6_K: quantize_q6_k,
+        GGML_Q5_K: quantize_q5_k, GGML_Q6_K: quantize_q6_k, GGML_Q3_K: quantize_q3_k,
     }[gtype]
     return fn(x)
 
@@ -370,6 +465,6 @@ def dequantize(gtype: int, buf, n: int) -> np.ndarray:
     fn = {
         GGML_Q4_0: dequantize_q4_0, GGML_Q4_1: dequantize_q4_1, GGML_Q5_0: dequantize_q5_0,
         GGML_Q5_1: dequantize_q5_1, GGML_Q8_0: dequantize_q8_0, GGML_Q4_K: dequantize_q4_k,
-        GGML_Q5_K: dequantize_q5_k, GGML_Q6_K: dequantize_q6_k,
+        GGML_Q5_K: dequantize_q5_k, GGML_Q6_K: dequantize_q6_k, GGML_Q3_K: dequantize_q3_k,
     }[gtype]
     return fn(np.frombuffer(buf, np.uint8), n)

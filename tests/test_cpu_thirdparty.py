@@ -123,7 +123,7 @@ def _hf_llama(f):
     return torch, m
 
 
-@pytest.mark.parametrize("wtype,tol", [("f16", 3e-3), ("f32", 3e-3), ("q8_0", 4e-2), ("q5_k", 6e-2)])
+@pytest.mark.parametrize("wtype,tol", [("f16", 3e-3), ("f32", 3e-3), ("q8_0", 4e-2), ("q5_k", 6e-2), ("q3_k", 6e-2)])
 def test_oracle_llama_matches_transformers(tiny_files, wtype, tol):
     """Prefill of 24 tokens (every row's logits), then 6 teacher-forced decode steps against the KV cache.  f16 / f32 weights: ggml rounds the
     activations to fp16 for the mat-mul -> 3e-3; quantised weights: HF runs on the dequantised weights, ggml additionally rounds every activation
