@@ -22,6 +22,10 @@
  * fp32<->fp16 conversions are IEEE RNE (F16C), block results are accumulated block-by-block in fp32
  * with one fma per block.
  *
+ * What pins it instead (tests/test_cpu_host.py, tests/test_cpu_thirdparty.py): hand-computed block vectors, an independent numpy implementation of every block
+ * format, a float64 forward of both models, and -- as tolerance pins against real third-party code present in this image -- Hugging Face LlamaForCausalLM, Hugging
+ * Face BLIP-2 (vision tower + Q-Former) and Google's sentencepiece BPE encoder.  None of these is ggml itself, hence still "unpinned" at ggml's bit level.
+ *
  * Build: see oracle/Makefile (gcc -O3 -mavx2 -mfma -mf16c -fopenmp).
  */
 #include <immintrin.h>
