@@ -109,6 +109,9 @@ MINIGPT4_API int minigpt4_amd_llm_file_digest(const char *llm_path, uint64_t *di
 /* ggml's reference block quantisers as minigpt4_quantize_model applies them (ggml_quantize_chunk): n floats (a whole number of blocks) -> dst; returns the
  * bytes written, 0 for an unsupported type (supported: Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q4_K Q5_K Q6_K, ggml type ids) or a ragged n. */
 MINIGPT4_API int64_t minigpt4_amd_quantize_chunk(int ggml_type, const float *x, void *dst, int64_t n);
+/* Diagnostic builds only (-DMG4_TIMELINE): 8 x uint64 constant-clock (100 MHz) stamps per workgroup of the LAST decode mat-vec launch -- entry, first weight
+ * request, activation row ready, first row group done, last row group done, results stored.  Returns the workgroups copied, 0 for a normal build, -1 on error. */
+MINIGPT4_API int minigpt4_amd_timeline(unsigned long long *out, int max_workgroups);
 /* load-time re-encoding of Q3_K super-blocks (110 B) as value-identical Q6_K super-blocks (210 B); host only.  0 / 1 */
 MINIGPT4_API int minigpt4_amd_convert_q3k_q6k(const void *src, void *dst, int64_t n_blocks);
 /* Host sampler with an explicit seed (fresh std::mt19937 per call). */

@@ -280,6 +280,8 @@ int minigpt4_amd_weight_arena(struct MiniGPT4Context *ctx, int which, void **dev
 
 // ---- single-kernel hooks ---------------------------------------------------------------------------------------------------
 
+int minigpt4_amd_timeline(unsigned long long *out, int max_workgroups) { return (out && max_workgroups > 0) ? read_matvec_timeline(out, max_workgroups) : -1; }
+
 int minigpt4_amd_convert_q3k_q6k(const void *src, void *dst, int64_t n_blocks) {
     if (!src || !dst || n_blocks < 0) return 1;
     q3k_to_q6k(static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), (size_t)n_blocks);
@@ -465,6 +467,7 @@ int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int 
             const QWeight *Wp[3]; float *Yp[3];
             for (int m = 0; m < n_mat; m++) { Wp[m] = &W[(size_t)set * n_mat + m]; Yp[m] = dy.as<float>() + (size_t)m * rows; }
             if (variant == 1 && launch_matvec_set(Wp, Yp, nullptr, n_mat, A, nullptr)) return;
+            if (variant == 2 && launch_matvec_set(Wp, Yp, nullptr, n_mat, A, nullptr, 1, dx.as<float>(), dx.as<float>())) return;   // rms-norm prologue, as the decode's qkv / w1|w3 launches
             for (int m = 0; m < n_mat; m++) launch_mul_mat(*Wp[m], A, 1, Yp[m], rows, nullptr, nullptr);
         };
         for (int i = 0; i < std::min(n_sets, 4); i++) run(i);

@@ -432,6 +432,15 @@ template <int NU> constexpr int mv_fat_max_threads() { return NU <= 4 ? 768 : 51
 // h[g] = silu_table(w1[g] . x) * (w3[g] . x) instead of the two dot products.  The table lookup of a group is consumed one group later, so
 // that it never stalls the weight stream.
 enum EpiKind : int { EPI_STORE = 0, EPI_SILU_PAIR = 1 };
+// In-kernel timeline (diagnostic builds only: make EXTRA=-DMG4_TIMELINE OUT=../libminigpt4_tl.so OBJ=build_tl).  Thread 0 of every workgroup of a decode mat-vec
+// stamps the 100 MHz constant clock at: 0 entry, 1 first weight tiles requested, 2 activation row ready (prologue done), 3 first row group finished, 4 last row
+// group finished, 5 results stored.  The last launch wins; read with minigpt4_amd_timeline after a single-launch micro-benchmark (tools/timeline.py).
+#ifdef MG4_TIMELINE
+__device__ unsigned long long g_tl[1024 * 8];
+#define MG4_TL(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_tl[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MG4_TL(i) do {} while (0)
+#endif
 // Tail-fused quantisation (TQ, opt-in: MINIGPT4_TAILQ=1; w1|w3 launch only).  The launch that produces h1 = w1 x and h3 = w3 x also prepares the NEXT mat-vec's
 // activation row, so the standalone k_silu_mul_quant launch between w1|w3 and w2 disappears: every wave owns a CONTIGUOUS range of rows, publishes its
 // results write-through (agent-scope stores), drains them and adds its row count to the arrival counter of each 256-row block it touched; the wave whose
@@ -447,6 +456,7 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
     const int g_first = TQ ? (int)((unsigned)wave * (unsigned)n_groups / (unsigned)n_waves) : wave;
     const int g_last = TQ ? (int)((unsigned)(wave + 1) * (unsigned)n_groups / (unsigned)n_waves) : n_groups;
     const int g_step = TQ ? 1 : n_waves;
+    MG4_TL(0);
     using X = Tr<T>;
     const int lane = threadIdx.x & 63;
     const int K = ms.w0.cols, U = K / X::EPU, rows_each = ms.rows_each, total_rows = ms.n * rows_each;
@@ -481,8 +491,10 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
     typename X::AU a[NU];
     if (PRO == PRO_NONE) {
         fetch(g_first, cur);
+        MG4_TL(1);
 #pragma unroll
         for (int i = 0; i < NU; i++) X::loada(A, 0, K, uc[i], a[i]);
+        MG4_TL(2);
     } else {
         // Row preparation in the prologue.  Order matters (vector-memory results return in issue order): the row (and, for SiLU, the table
         // gathers) is requested BEFORE the first weight tiles, so the preparation runs while those tiles are in flight.
@@ -517,6 +529,7 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
             for (int r = 0; r < RND; r++) { xv[r].x = tab(pa.tb.silu, xv[r].x); xv[r].y = tab(pa.tb.silu, xv[r].y); xv[r].z = tab(pa.tb.silu, xv[r].z); xv[r].w = tab(pa.tb.silu, xv[r].w); }
         }
         fetch(g_first, cur);
+        MG4_TL(1);
         float scale = 1.0f;
         if (PRO == PRO_RMS) {
             double sum = 0.0;
@@ -548,6 +561,7 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NU; i++) X::loada(L, 0, K, uc[i], a[i]);
+        MG4_TL(2);
     }
     unsigned short pend_t = 0; float pend_b = 0.0f; int pend_row = -1;          // EPI_SILU_PAIR: the previous group's table lookup, not yet consumed
     auto flush_pending = [&]() { if (pend_row >= 0 && lane == 0) ms.y0[pend_row] = h2f_bits(pend_t) * pend_b; };
@@ -584,6 +598,9 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
         __builtin_amdgcn_sched_barrier(0);
         consume(g, cur);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef MG4_TIMELINE
+        if (g == g_first) MG4_TL(3);
+#endif
         g += g_step;
         if (g >= g_last) break;
         fetch(g + g_step, cur);
@@ -592,7 +609,12 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
         __builtin_amdgcn_sched_barrier(0);
         g += g_step;
     }
+    MG4_TL(4);
     if (EPI == EPI_SILU_PAIR) flush_pending();
+#ifdef MG4_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MG4_TL(5);
+#endif
     if constexpr (TQ) {
         // Arrival.  Lane 0 issued every result store of this wave; drain them (write-through stores are acknowledged by memory) before the counter moves.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -706,6 +728,16 @@ static bool launch_v2_type(const MatSet &ms, const ActQ &A, int pro, const ProAr
     default: ok = false;
     }
     return ok;
+}
+// copies the timeline stamps of the last decode mat-vec launch (8 x u64 per workgroup); 0 when the library was built without MG4_TIMELINE
+int read_matvec_timeline(unsigned long long *out, int max_workgroups) {
+#ifdef MG4_TIMELINE
+    const int n = std::min(max_workgroups, 1024);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl), (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return n;
+#else
+    (void)out; (void)max_workgroups; return 0;
+#endif
 }
 bool matvec_silu_pair_supported(int type, int cols) { return matvec_prologue_supported(type, cols) && cols / 32 <= 3 * 64; }
 
