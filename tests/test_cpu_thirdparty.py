@@ -88,6 +88,39 @@ def test_tokenizer_equals_sentencepiece(lib, tmpdir_models, n_vocab):
     lib.library.minigpt4_amd_vocab_free(v)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_tokenizer_equals_sentencepiece_on_random_vocabularies(lib, tmpdir_models, seed):
+    """Random piece sets with random (partly tied) scores: merge order, leftmost tie-break and byte fallback must agree with SentencePiece's BPE encoder."""
+    import refcpu as R
+    from minigpt4_cpp_amd import modelgen as G
+    rng = np.random.default_rng(1000 + seed)
+    chars = list("abcdefgh ") + ["é", "世"]
+    vocab = [(b"<unk>", 0.0), (b"<s>", 0.0), (b"</s>", 0.0)] + [(bytes([b]), 0.0) for b in range(256)]
+    seen = set()
+    while len(seen) < 220:
+        seen.add("".join(chars[int(i)] for i in rng.integers(0, len(chars), int(rng.integers(2, 6)))))
+    for pce in sorted(seen):
+        vocab.append((pce.encode(), float(-int(rng.integers(1, 40)))))          # few distinct scores: many ties
+    for c in chars[:-1]:                                                          # every character but one has a piece; "世" falls back to bytes
+        vocab.append((c.encode(), -100.0 - float(len(vocab))))
+    n_vocab = len(vocab)
+    lp = os.path.join(tmpdir_models, f"llm_rndvocab_{seed}.bin")
+    G.write_llm_file(lp, G.tiny_llm(wtype="q4_0", n_embd=64, n_layer=1, n_head=2, n_vocab=n_vocab, n_mult=32), seed=1, std=0.05, vocab=vocab)
+    vocab = G.read_llm_file(lp).vocab
+    proc = _sentencepiece_model(vocab)
+    v = lib.library.minigpt4_amd_vocab_load(lp.encode())
+    assert v
+    for _ in range(400):
+        t = "".join(chars[int(i)] for i in rng.integers(0, len(chars), int(rng.integers(1, 50))))
+        want = proc.encode(t)
+        b = t.encode()
+        assert R.tokenize(vocab, b, False) == want, t
+        out = (ctypes.c_int32 * (len(b) + 4))()
+        n = lib.library.minigpt4_amd_vocab_tokenize(v, b, 0, out, len(b) + 4)
+        assert list(out[:n]) == want, t
+    lib.library.minigpt4_amd_vocab_free(v)
+
+
 # ------------------------------------------------------------------------------------------------ LLaMA vs transformers
 def _hf_llama(f):
     torch = pytest.importorskip("torch")
