@@ -33,7 +33,8 @@ def main():
     for t, rows, cols, n_mat, variant in cases:
         per = Q.nbytes(Q.NAME_TO_TYPE[t], rows * cols) * n_mat
         us, by = ctypes.c_float(), ctypes.c_double()
-        rc = L.minigpt4_amd_bench_matvec(Q.NAME_TO_TYPE[t], rows, cols, n_mat, variant, 50, max(2, int(700e6 // per) + 1), 0, ctypes.byref(us), ctypes.byref(by))
+        n_sets = int(os.environ.get("TL_SETS", "0")) or max(2, int(700e6 // per) + 1)      # TL_SETS=1: the same weights every launch (Infinity-Cache resident when they fit)
+        rc = L.minigpt4_amd_bench_matvec(Q.NAME_TO_TYPE[t], rows, cols, n_mat, variant, 50, n_sets, 0, ctypes.byref(us), ctypes.byref(by))
         assert rc == 0, rc
         buf = (ctypes.c_ulonglong * (1024 * 8))()
         n = L.minigpt4_amd_timeline(buf, 1024)
