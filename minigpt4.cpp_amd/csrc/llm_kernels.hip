@@ -489,8 +489,14 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
     };
     Grp cur, nxt;
     typename X::AU a[NU];
+    // MG4_PRIME2 (alternate build for A/B, see profiles/r01p_matvec_timeline.log): BOTH pipeline stages are requested before the activation row is prepared / loaded.
+    // The default requests the second stage only at the top of the loop, i.e. after the 2.6 us prologue of a fat-workgroup launch, during which only one stage
+    // (7 MB chip-wide) keeps the memory system busy.  Same loads, same arithmetic, same order of results.
     if (PRO == PRO_NONE) {
         fetch(g_first, cur);
+#ifdef MG4_PRIME2
+        fetch(g_first + g_step, nxt);
+#endif
         MG4_TL(1);
 #pragma unroll
         for (int i = 0; i < NU; i++) X::loada(A, 0, K, uc[i], a[i]);
@@ -529,6 +535,9 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
             for (int r = 0; r < RND; r++) { xv[r].x = tab(pa.tb.silu, xv[r].x); xv[r].y = tab(pa.tb.silu, xv[r].y); xv[r].z = tab(pa.tb.silu, xv[r].z); xv[r].w = tab(pa.tb.silu, xv[r].w); }
         }
         fetch(g_first, cur);
+#ifdef MG4_PRIME2
+        fetch(g_first + g_step, nxt);
+#endif
         MG4_TL(1);
         float scale = 1.0f;
         if (PRO == PRO_RMS) {
@@ -593,6 +602,25 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
     // two statically named stages (a `cur = nxt` copy would have to wait for the loads in flight; the requested unroll is refused by the compiler)
     // The sched_barriers keep the next group's loads ahead of the current group's dot products (the scheduler otherwise hoists the arithmetic, and
     // with it the wait for the current tiles, above the loads: one tile in flight instead of two).
+#ifdef MG4_PRIME2
+    for (int g = g_first; g < g_last;) {                      // cur = group g, nxt = group g + step: both already requested
+        consume(g, cur);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef MG4_TIMELINE
+        if (g == g_first) MG4_TL(3);
+#endif
+        g += g_step;
+        if (g >= g_last) break;
+        fetch(g + g_step, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(g, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        g += g_step;
+        if (g >= g_last) break;
+        fetch(g + g_step, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
     for (int g = g_first; g < g_last;) {
         fetch(g + g_step, nxt);
         __builtin_amdgcn_sched_barrier(0);
@@ -609,6 +637,7 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
         __builtin_amdgcn_sched_barrier(0);
         g += g_step;
     }
+#endif
     MG4_TL(4);
     if (EPI == EPI_SILU_PAIR) flush_pending();
 #ifdef MG4_TIMELINE
