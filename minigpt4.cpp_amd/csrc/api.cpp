@@ -459,14 +459,16 @@ int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int 
             if (ggml_type == GT_F16) launch_fill_u16(base, n, 0x2E66, nullptr);
             if (ggml_type == GT_F32) { std::vector<float> h(n, 0.01f); HIP_CHECK(hipMemcpy(base, h.data(), n * 4, hipMemcpyHostToDevice)); }
         }
-        ActQ A; alloc_act(A, keep, 1, (size_t)cols);
-        DevBuf dx((size_t)cols * 4), dy((size_t)rows * 4 * 3);
-        { std::vector<float> hx((size_t)cols); for (int i = 0; i < cols; i++) hx[(size_t)i] = (float)((i * 37 % 201) - 100) / 64.0f; HIP_CHECK(hipMemcpy(dx.p, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); }
-        launch_rms_quant(dx.as<float>(), nullptr, 1, cols, A, act_mask_for(ggml_type), nullptr);
+        const int NR = variant == 3 ? 4 : 1;                               // variant 3: the batched decode's multi-row launch (4 activation rows, weights streamed once)
+        ActQ A; alloc_act(A, keep, (size_t)NR, (size_t)cols);
+        DevBuf dx((size_t)NR * cols * 4), dy((size_t)rows * 4 * 3 * NR);
+        { std::vector<float> hx((size_t)NR * cols); for (size_t i = 0; i < hx.size(); i++) hx[i] = (float)((int)(i * 37 % 201) - 100) / 64.0f; HIP_CHECK(hipMemcpy(dx.p, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); }
+        launch_rms_quant(dx.as<float>(), nullptr, NR, cols, A, act_mask_for(ggml_type), nullptr);
         auto run = [&](int set) {
             const QWeight *Wp[3]; float *Yp[3];
-            for (int m = 0; m < n_mat; m++) { Wp[m] = &W[(size_t)set * n_mat + m]; Yp[m] = dy.as<float>() + (size_t)m * rows; }
+            for (int m = 0; m < n_mat; m++) { Wp[m] = &W[(size_t)set * n_mat + m]; Yp[m] = dy.as<float>() + (size_t)m * rows * NR; }
             if (variant == 1 && launch_matvec_set(Wp, Yp, nullptr, n_mat, A, nullptr)) return;
+            if (variant == 3 && launch_matvec_rows(Wp, Yp, nullptr, n_mat, A, NR, rows, nullptr)) return;
             if (variant == 2 && launch_matvec_set(Wp, Yp, nullptr, n_mat, A, nullptr, 1, dx.as<float>(), dx.as<float>())) return;   // rms-norm prologue, as the decode's qkv / w1|w3 launches
             for (int m = 0; m < n_mat; m++) launch_mul_mat(*Wp[m], A, 1, Yp[m], rows, nullptr, nullptr);
         };

@@ -937,7 +937,12 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
         for (int t = 0; t < TN; t++) G.res[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mkbuf(reinterpret_cast<const uint8_t *>(rb + (size_t)min(t, N - 1) * ldy)), 0, 0, 0));
     };
     Grp cur, nxt;
+    MG4_TL(0);
     fetch(wave, cur);
+#ifdef MG4_PRIME2
+    fetch(wave + n_waves, nxt);
+#endif
+    MG4_TL(1);
     // LDS image of the N activation rows, laid out like the global ActQ planes (so Tr<T>::loada indexes it unchanged)
     ActQ L;
     {
@@ -964,6 +969,7 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
         }
     }
     __syncthreads();
+    MG4_TL(2);
     auto consume = [&](int g, const Grp &G) {
         float out[TN];
 #pragma unroll
@@ -984,11 +990,33 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
             for (int t = 0; t < TN; t++) if (t < N) yo[(size_t)t * ldy] = has_res ? out[t] + G.res[t] : out[t];
         }
     };
+#ifdef MG4_PRIME2
+    for (int g = wave; g < n_groups;) {                       // see matvec_run: both stages were requested before the LDS copy
+        consume(g, cur);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef MG4_TIMELINE
+        if (g == wave) MG4_TL(3);
+#endif
+        g += n_waves;
+        if (g >= n_groups) break;
+        fetch(g + n_waves, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(g, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        g += n_waves;
+        if (g >= n_groups) break;
+        fetch(g + n_waves, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
     for (int g = wave; g < n_groups;) {
         fetch(g + n_waves, nxt);
         __builtin_amdgcn_sched_barrier(0);
         consume(g, cur);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef MG4_TIMELINE
+        if (g == wave) MG4_TL(3);
+#endif
         g += n_waves;
         if (g >= n_groups) break;
         fetch(g + n_waves, cur);
@@ -997,6 +1025,12 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
         __builtin_amdgcn_sched_barrier(0);
         g += n_waves;
     }
+#endif
+    MG4_TL(4);
+#ifdef MG4_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MG4_TL(5);
+#endif
 }
 template <int T, int NU>
 static void launch_tn_t(const MatSet &ms, const ActQ &A, int N, int ldy, hipStream_t s) {

@@ -3,7 +3,8 @@
 
   MINIGPT4_LIBRARY=minigpt4.cpp_amd/libminigpt4_tl.so python tools/timeline.py [type rows cols n_mat variant]...
 
-variant 1 = activation row prepared by its own launch, 2 = rms-norm prologue inside the mat-vec (the decode's qkv / w1|w3 flavour).  Thread 0 of every workgroup
+variant 1 = activation row prepared by its own launch, 2 = rms-norm prologue inside the mat-vec (the decode's qkv / w1|w3 flavour), 3 = the batched decode's
+multi-row launch (4 activation rows in LDS, k_matvec_tn).  Thread 0 of every workgroup
 stamps the 100 MHz constant clock at entry / first weight request / row ready / first group done / last group done / results stored; printed per stage as the
 min / median / max over workgroups, in microseconds after the EARLIEST workgroup's entry, next to the hipEvent time of the launch (which additionally holds the
 dispatch + end-of-kernel cost).  GPU only."""
