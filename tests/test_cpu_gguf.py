@@ -14,7 +14,7 @@ def digest(lib, path, with_data=1):
     return rc, d.value
 
 
-@pytest.mark.parametrize("wtype,mix", [("q4_0", "none"), ("q5_k", "q5_k_m"), ("f16", "none")])
+@pytest.mark.parametrize("wtype,mix", [("q4_0", "none"), ("q5_k", "q5_k_m"), ("f16", "none"), ("q3_k", "none")])
 @pytest.mark.parametrize("version,alignment", [(3, 32), (2, 64)])
 def test_gguf_gives_the_same_view_as_ggjt(lib, tiny_files, tmp_path, wtype, mix, version, alignment):
     from minigpt4_cpp_amd import modelgen as G
