@@ -16,6 +16,9 @@ ctx = lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=64, n_batch=32)
 img = ML.array_to_image_struct(G.synth_image(1))
 ms = []
 for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
-    e = lib.minigpt4_encode_image(ctx, img); ms.append(lib.library.minigpt4_amd_last_encode_ms(ctx.ptr)); lib.minigpt4_free_embedding(e)
-print("encode ms (device):", ["%.2f" % m for m in ms], "best %.2f" % min(ms))
+    e = lib.minigpt4_encode_image(ctx, img); ms.append(lib.library.minigpt4_amd_last_encode_ms(ctx.ptr))
+    import ctypes, zlib
+    sig = zlib.crc32(ctypes.string_at(e.data, e.n_embeddings * 4))        # identical embeddings <=> identical signature (bit-exactness of A/B arms)
+    lib.minigpt4_free_embedding(e)
+print("encode ms (device):", ["%.2f" % m for m in ms], "best %.2f" % min(ms), "sig %08x" % sig)
 lib.minigpt4_free(ctx)

@@ -392,6 +392,119 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const float *__restrict__ q, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_attn_mfma2 -- opt-in re-scheduling of k_attn_mfma (MINIGPT4_ATTN_MFMA=2; written after the GPU budget of round 1 was spent: UNMEASURED).  Same workgroup shape, LDS
+// layout and per-element arithmetic (every accumulator sees the same operands in the same order, so results are bit-identical to k_attn_mfma); what changes is where the
+// memory latencies sit (a dependent global round trip costs ~2 us at kernel start, profiles/r01p_matvec_timeline.log):
+//   (i)   the head's K AND V rows are requested at kernel entry and held in registers (one wave per SIMD here: 512 VGPRs each); V goes to LDS as soon as the scores
+//         are done -- before the softmax -- so the second staging latency and one barrier disappear;
+//   (ii)  a staging pass is ONE batch of loads per thread instead of three;
+//   (iii) the fp16-table gathers of a softmax row are one batch per lane;
+//   (iv)  a wave interleaves its independent MFMA chains (two key tiles in S = Q K^T; its dim tiles in O = P V, which share the P fragment): the 40-cycle
+//         dependent-accumulator latency of v_mfma_f32_16x16x4_f32 is hidden behind the 32-cycle issue of the other chain.
+// NB = float4 loads per thread and operand: needs nk * HD / 4 <= 256 * NB (the launcher checks; otherwise k_attn_mfma runs).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int HD, int NB>
+__global__ __launch_bounds__(256) void k_attn_mfma2(const float *__restrict__ q, int ldq, const float *__restrict__ k, const float *__restrict__ v, int ldk, int nq, int nk,
+                                                    float q_prescale, float score_div, const Tables tb, float *__restrict__ out, __half *__restrict__ out_h, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LDV = HD + 1, DT = (HD + 15) / 16, KS = HD / 4, C4 = HD / 4, NT = DT / 2, NE = (NB * 256 / C4 + 7) / 8 + 1;
+    static_assert(DT % 2 == 0, "dim tiles are split over wave pairs");
+    { const size_t z = blockIdx.z; q += z * nq * ldq; k += z * nk * ldk; v += z * nk * ldk; if (out) out += z * nq * ldo; if (out_h) out_h += z * nq * ldo; }
+    const int nkp = (nk + 15) & ~15, LS = nkp + 1;
+    float *kv = reinterpret_cast<float *>(smem);               // [nkp][LDV]
+    float *S = kv + (size_t)nkp * LDV;                           // [32][LS]
+    const int h = blockIdx.x, q0 = blockIdx.y * 32, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = nk * C4;
+    // (i) + (ii): all K and V loads of this thread, K first (results return in issue order)
+    float4 kx[NB], vx[NB];
+#pragma unroll
+    for (int u = 0; u < NB; u++) { const int e = min(tid + 256 * u, total - 1), j = e / C4, c = e - j * C4; kx[u] = *reinterpret_cast<const float4 *>(k + (size_t)j * ldk + h * HD + 4 * c); }
+#pragma unroll
+    for (int u = 0; u < NB; u++) { const int e = min(tid + 256 * u, total - 1), j = e / C4, c = e - j * C4; vx[u] = *reinterpret_cast<const float4 *>(v + (size_t)j * ldk + h * HD + 4 * c); }
+    const int qt = wave & 1;
+    float qf[KS];
+    {
+        const int qrow = min(q0 + qt * 16 + (lane & 15), nq - 1);
+        const float *qp = q + (size_t)qrow * ldq + h * HD + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) { float t = qp[4 * ks]; if (q_prescale != 0.0f) t *= q_prescale; qf[ks] = t; }
+    }
+#pragma unroll
+    for (int u = 0; u < NB; u++) { const int e = tid + 256 * u; if (e < total) { const int j = e / C4, c = e - j * C4; float *d = kv + j * LDV + 4 * c; d[0] = kx[u].x; d[1] = kx[u].y; d[2] = kx[u].z; d[3] = kx[u].w; } }
+    for (int e = nk * LDV + tid; e < nkp * LDV; e += 256) kv[e] = 0.0f;          // rows [nk, nkp) stay zero for V as well
+    __syncthreads();
+    // S = Q K^T: key tiles (wave >> 1) + 2 i of q-tile (wave & 1), two tiles at a time
+    const int KT = nkp / 16;
+    for (int kt = wave >> 1; kt < KT; kt += 4) {
+        const bool two = kt + 2 < KT;                             // wave-uniform
+        const int kt2 = two ? kt + 2 : kt;
+        float4_t acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float *kb0 = kv + (size_t)(kt * 16 + (lane & 15)) * LDV + (lane >> 4);
+        const float *kb1 = kv + (size_t)(kt2 * 16 + (lane & 15)) * LDV + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[ks], kb0[4 * ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[ks], kb1[4 * ks], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float s0 = acc0[r], s1 = acc1[r];
+            if (score_div != 0.0f) { s0 = s0 / score_div; s1 = s1 / score_div; }
+            float *srow = S + (size_t)(qt * 16 + (lane >> 4) * 4 + r) * LS + (lane & 15);
+            srow[kt * 16] = s0;
+            if (two) srow[kt2 * 16] = s1;
+        }
+    }
+    __syncthreads();                                              // every wave is done with K: V takes its place while the softmax runs on S
+#pragma unroll
+    for (int u = 0; u < NB; u++) { const int e = tid + 256 * u; if (e < total) { const int j = e / C4, c = e - j * C4; float *d = kv + j * LDV + 4 * c; d[0] = vx[u].x; d[1] = vx[u].y; d[2] = vx[u].z; d[3] = vx[u].w; } }
+    // softmax: 8 lanes per query row; (iii) one batch of table gathers per lane, summed in the same (ascending j) order as k_attn_mfma
+    {
+        const int row = tid >> 3, sub = tid & 7;
+        float *sr = S + (size_t)row * LS;
+        float mx = -INFINITY;
+        for (int j = sub; j < nk; j += 8) mx = fmaxf(mx, sr[j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+        float e[NE];
+#pragma unroll
+        for (int u = 0; u < NE; u++) { const int j = sub + 8 * u; e[u] = tab_v(tb.exp, sr[min(j, nk - 1)] - mx); }
+        double sum = 0.0;
+#pragma unroll
+        for (int u = 0; u < NE; u++) { const int j = sub + 8 * u; if (j < nk) { sr[j] = e[u]; sum += (double)e[u]; } }
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+        const float inv = (float)(1.0 / sum);
+        for (int j = sub; j < nkp; j += 8) sr[j] = j < nk ? sr[j] * inv : 0.0f;
+    }
+    __syncthreads();
+    // O = P V: this wave's q-tile (wave & 1) and dim tiles (wave >> 1) + 2 j, all chains interleaved over the shared P fragment
+    const int nks = (nk + 3) / 4, pqt = wave & 1;
+    float4_t acc[NT];
+    const float *vb[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        acc[j] = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        const int dim = min(((wave >> 1) + 2 * j) * 16 + (lane & 15), HD);              // column HD of kv is the (finite) pad column; its results are discarded
+        vb[j] = kv + (size_t)(lane >> 4) * LDV + dim;
+    }
+    const float *pa = S + (size_t)(pqt * 16 + (lane & 15)) * LS + (lane >> 4);
+#pragma unroll 4
+    for (int ks = 0; ks < nks; ks++) {
+        const float pv = pa[4 * ks];
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vb[j][(size_t)4 * ks * LDV], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        const int d = ((wave >> 1) + 2 * j) * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int qrow = q0 + pqt * 16 + (lane >> 4) * 4 + r;
+            if (qrow < nq && d < HD) { const size_t oo = (size_t)qrow * ldo + h * HD + d; if (out) out[oo] = acc[j][r]; if (out_h) out_h[oo] = __float2half_rn(acc[j][r]); }
+        }
+    }
+}
+
 static int g_attn_mfma = 1;
 void set_attn_mfma(int v) { g_attn_mfma = v; }
 void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale, float score_div,
@@ -409,6 +522,17 @@ void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, in
     const size_t lds_m = ((size_t)nkp * (hd + 1) + 32 * (size_t)(nkp + 1)) * 4;
     if (g_attn_mfma && lds_m <= 160 * 1024) {
         dim3 grid((unsigned)heads, (unsigned)((nq + 31) / 32), (unsigned)batch);
+        if (g_attn_mfma == 2 && nk * (hd / 4) <= 256 * (hd == 88 ? 24 : 17)) {       // opt-in re-scheduled variant (bit-identical by construction, unmeasured)
+            static bool attr2 = false;
+            if (!attr2) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_mfma2<88, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_mfma2<64, 17>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr2 = true;
+            }
+            if (hd == 88) hipLaunchKernelGGL((k_attn_mfma2<88, 24>), grid, dim3(256), lds_m, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
+            else hipLaunchKernelGGL((k_attn_mfma2<64, 17>), grid, dim3(256), lds_m, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
+            return;
+        }
         if (hd == 88) hipLaunchKernelGGL((k_attn_mfma<88>), grid, dim3(256), lds_m, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
         else hipLaunchKernelGGL((k_attn_mfma<64>), grid, dim3(256), lds_m, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
         return;
