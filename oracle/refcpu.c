@@ -244,7 +244,71 @@ static float vec_dot_q3_K_q8_K(int64_t n, const blk_q3_K *x, const blk_q8_K *y) 
 static float vec_dot_f16(int64_t n, const f16_t *x, const f16_t *y) { float s = 0; for (int64_t i = 0; i < n; i++) s = fmaf(h2f(x[i]), h2f(y[i]), s); return s; }
 static float vec_dot_f32(int64_t n, const float *x, const float *y) { float s = 0; for (int64_t i = 0; i < n; i++) s = fmaf(x[i], y[i], s); return s; }
 
+/* ---- AVX2 forms of the dot products that dominate the timed CPU baseline (Q4_0, Q4_K, Q5_K, Q6_K).  The integer sums are exact in either form and the fp32 part is
+ * the same expression, so every result is bit-identical to the scalar functions above (tests/test_cpu_host.py::test_oracle_simd_dots_equal_scalar); ggml's own AVX2
+ * kernels use the same maddubs / madd pattern.  orc_set_simd(0) selects the scalar forms. ---- */
+static int g_simd = 1;
+ORC_API void orc_set_simd(int on) { g_simd = on; }
+#ifdef __AVX2__
+static inline int hsum_i32_8(__m256i v) {
+    __m128i s = _mm_add_epi32(_mm256_castsi256_si128(v), _mm256_extracti128_si256(v, 1));
+    s = _mm_add_epi32(s, _mm_shuffle_epi32(s, 0x4E)); s = _mm_add_epi32(s, _mm_shuffle_epi32(s, 0xB1));
+    return _mm_cvtsi128_si32(s);
+}
+static float vec_dot_q4_0_q8_0_avx2(int64_t n, const blk_q4_0 *x, const blk_q8_0 *y) { float sumf = 0;
+    const __m128i m4 = _mm_set1_epi8(0x0F); const __m256i ones8 = _mm256_set1_epi8(1), ones16 = _mm256_set1_epi16(1);
+    for (int64_t i = 0; i < n / QK; i++) {
+        const __m128i q = _mm_loadu_si128((const __m128i *)x[i].qs);
+        const __m256i w = _mm256_set_m128i(_mm_and_si128(_mm_srli_epi16(q, 4), m4), _mm_and_si128(q, m4));      /* elements 0..15 = low nibbles, 16..31 = high nibbles */
+        const __m256i a = _mm256_loadu_si256((const __m256i *)y[i].qs);
+        const int wa = hsum_i32_8(_mm256_madd_epi16(_mm256_maddubs_epi16(w, a), ones16));                         /* sum nibble * a   (|pair| <= 2 * 15 * 128) */
+        const int sa = hsum_i32_8(_mm256_madd_epi16(_mm256_maddubs_epi16(ones8, a), ones16));                     /* sum a */
+        sumf = fmaf(h2f(x[i].d) * h2f(y[i].d), (float)(wa - 8 * sa), sumf); } return sumf; }
+static float vec_dot_q45_K_q8_K_avx2(int64_t n, const void *xv, const blk_q8_K *y, int q5) { float sumf = 0;
+    const __m256i m4 = _mm256_set1_epi8(0x0F), one8 = _mm256_set1_epi8(1);
+    for (int64_t i = 0; i < n / QK_K; i++) {
+        const uint8_t *scales, *qs, *qh = NULL; f16_t d, dmin;
+        if (q5) { const blk_q5_K *x = (const blk_q5_K *)xv + i; scales = x->scales; qs = x->qs; qh = x->qh; d = x->d; dmin = x->dmin; }
+        else { const blk_q4_K *x = (const blk_q4_K *)xv + i; scales = x->scales; qs = x->qs; d = x->d; dmin = x->dmin; }
+        const int8_t *a = y[i].qs;
+        const __m256i hb = q5 ? _mm256_loadu_si256((const __m256i *)qh) : _mm256_setzero_si256();
+        __m256i acc = _mm256_setzero_si256(); int msum = 0;
+        for (int j = 0; j < 4; j++) { uint8_t sc0, m0, sc1, m1; get_scale_min_k4(2 * j, scales, &sc0, &m0); get_scale_min_k4(2 * j + 1, scales, &sc1, &m1);
+            const __m256i q = _mm256_loadu_si256((const __m256i *)(qs + 32 * j));
+            __m256i w0 = _mm256_and_si256(q, m4), w1 = _mm256_and_si256(_mm256_srli_epi16(q, 4), m4);
+            if (q5) { w0 = _mm256_or_si256(w0, _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(hb, 2 * j), one8), 4));
+                      w1 = _mm256_or_si256(w1, _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(hb, 2 * j + 1), one8), 4)); }
+            const __m256i a0 = _mm256_loadu_si256((const __m256i *)(a + 64 * j)), a1 = _mm256_loadu_si256((const __m256i *)(a + 64 * j + 32));
+            acc = _mm256_add_epi32(acc, _mm256_madd_epi16(_mm256_maddubs_epi16(w0, a0), _mm256_set1_epi16(sc0)));   /* |pair| <= 2 * 31 * 128 < 2^15 */
+            acc = _mm256_add_epi32(acc, _mm256_madd_epi16(_mm256_maddubs_epi16(w1, a1), _mm256_set1_epi16(sc1)));
+            msum += m0 * (y[i].bsums[4 * j] + y[i].bsums[4 * j + 1]) + m1 * (y[i].bsums[4 * j + 2] + y[i].bsums[4 * j + 3]); }
+        sumf = fmaf(h2f(d) * y[i].d, (float)hsum_i32_8(acc), sumf); sumf = fmaf(-(h2f(dmin) * y[i].d), (float)msum, sumf); } return sumf; }
+static float vec_dot_q6_K_q8_K_avx2(int64_t n, const blk_q6_K *x, const blk_q8_K *y) { float sumf = 0;
+    const __m256i m4 = _mm256_set1_epi8(0x0F), m2 = _mm256_set1_epi8(3);
+    for (int64_t i = 0; i < n / QK_K; i++) { const uint8_t *ql = x[i].ql, *qh = x[i].qh; const int8_t *sc = x[i].scales, *a = y[i].qs;
+        __m256i acc = _mm256_setzero_si256(); int off = 0;                  /* sum sc * (q6 . a) with q6 in 0..63; the -32 offset goes through the bsums */
+        for (int is = 0; is < 16; is++) off += sc[is] * y[i].bsums[is];
+        for (int nn = 0; nn < 2; nn++) {
+            const __m256i l0 = _mm256_loadu_si256((const __m256i *)ql), l1 = _mm256_loadu_si256((const __m256i *)(ql + 32)), h = _mm256_loadu_si256((const __m256i *)qh);
+            const __m256i w[4] = { _mm256_or_si256(_mm256_and_si256(l0, m4), _mm256_slli_epi16(_mm256_and_si256(h, m2), 4)),
+                                   _mm256_or_si256(_mm256_and_si256(l1, m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(h, 2), m2), 4)),
+                                   _mm256_or_si256(_mm256_and_si256(_mm256_srli_epi16(l0, 4), m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(h, 4), m2), 4)),
+                                   _mm256_or_si256(_mm256_and_si256(_mm256_srli_epi16(l1, 4), m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(h, 6), m2), 4)) };
+            for (int g = 0; g < 4; g++) {                                    /* group g = elements 32 g .. 32 g + 31: sub-blocks 2 g (low 128 bits) and 2 g + 1 (high 128 bits) */
+                const __m256i av = _mm256_loadu_si256((const __m256i *)(a + 32 * g));
+                const __m256i scv = _mm256_set_m128i(_mm_set1_epi16(sc[2 * g + 1]), _mm_set1_epi16(sc[2 * g]));
+                acc = _mm256_add_epi32(acc, _mm256_madd_epi16(_mm256_maddubs_epi16(w[g], av), scv)); }               /* |pair| <= 2 * 63 * 128 < 2^15 */
+            ql += 64; qh += 32; sc += 8; a += 128; }
+        sumf = fmaf(h2f(x[i].d) * y[i].d, (float)(hsum_i32_8(acc) - 32 * off), sumf); } return sumf; }
+#endif
+
 ORC_API float orc_vec_dot(int wtype, int64_t n, const void *w, const void *a) {
+#ifdef __AVX2__
+    if (g_simd) switch (wtype) {
+        case T_Q4_0: return vec_dot_q4_0_q8_0_avx2(n, w, a); case T_Q4_K: return vec_dot_q45_K_q8_K_avx2(n, w, a, 0);
+        case T_Q5_K: return vec_dot_q45_K_q8_K_avx2(n, w, a, 1); case T_Q6_K: return vec_dot_q6_K_q8_K_avx2(n, w, a);
+        default: break; }
+#endif
     switch (wtype) {
     case T_Q4_0: return vec_dot_q4_0_q8_0(n, w, a); case T_Q4_1: return vec_dot_q4_1_q8_1(n, w, a);
     case T_Q5_0: return vec_dot_q5_0_q8_0(n, w, a); case T_Q5_1: return vec_dot_q5_1_q8_1(n, w, a);

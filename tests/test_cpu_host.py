@@ -226,6 +226,39 @@ def test_product_loaders_parse_both_files_without_gpu(lib, tiny_files, tmp_path)
     assert lib.library.minigpt4_amd_inspect_files(None, str(bad).encode(), None, None, None) == 4
 
 
+def test_oracle_simd_dots_equal_scalar():
+    """The AVX2 dot products of the oracle (the timed CPU baseline) against its scalar restatement: bit-identical, on quantised Gaussian weights and on arbitrary
+    block bytes (every bit pattern of the quant fields, sane fp16 scales), for activations of very different magnitudes."""
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    L = R.lib()
+    rng = np.random.default_rng(11)
+    n_in, n_out = 2048, 48
+    try:
+        for name in ("q4_0", "q4_k", "q5_k", "q6_k"):
+            t = Q.NAME_TO_TYPE[name]
+            be, bb = Q.BLOCK[t]
+            raws = [Q.quantize(t, (0.05 * rng.standard_normal((n_out, n_in))).astype(np.float32))]
+            arb = rng.integers(0, 256, (n_in // be * n_out, bb), dtype=np.uint8)
+            f16 = (rng.standard_normal((arb.shape[0], 2)) * 0.01).astype(np.float16).view(np.uint8).reshape(-1, 4)
+            if name == "q4_0":
+                arb[:, 0:2] = f16[:, 0:2]
+            elif name == "q6_k":
+                arb[:, 208:210] = f16[:, 0:2]
+            else:
+                arb[:, 0:4] = f16
+            raws.append(arb.reshape(-1))
+            x = (rng.standard_normal((4, n_in)) * np.array([1.0, 37.0, 1e-3, 0.0])[:, None]).astype(np.float32)
+            for raw in raws:
+                L.orc_set_simd(1)
+                a = R.mul_mat(t, raw, n_in, n_out, x)
+                L.orc_set_simd(0)
+                b = R.mul_mat(t, raw, n_in, n_out, x)
+                assert np.array_equal(a, b), name
+    finally:
+        L.orc_set_simd(1)
+
+
 # ------------------------------------------------------------------------------------------------ tokenizer / sampler / templating
 def test_tokenizer_matches_oracle(lib, tiny_files):
     import refcpu as R
