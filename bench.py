@@ -70,6 +70,16 @@ def make_models(config: str, rank: int, world: int, barrier):
     return vp, lp, vcfg, lcfg
 
 
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(lp: str, prompt_tokens, budget_s: float = 20.0):
     """Oracle (ggml-equivalent restatement) decode rate on this host's cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -132,7 +142,7 @@ def cpu_baseline(lp: str, prompt_tokens, budget_s: float = 20.0):
             break
     dt = time.time() - t0
     return {"value": n / dt, "unit": "tokens/s", "cores": cores, "kind": "port", "threads_tried_s_per_step": {str(k): round(v, 3) for k, v in tried.items()},
-            "scalar_dots_tokens_per_s": (1.0 / scalar_s) if scalar_s else None,
+            "scalar_dots_tokens_per_s": (1.0 / scalar_s) if scalar_s else None, "host_cpu": _cpu_model(), "host_hw_threads": os.cpu_count(), "usable_cpus": usable,
             "sample": f"{n} greedy decode steps of the same LLM file at context<{o.n_past + 1} on the CPU oracle (ggml-equivalent restatement with AVX2 maddubs dot products as ggml's own x86 "
                       f"kernels use, bit-identical to its scalar form; {'-march=native' if native else 'x86-64-v3'}, OpenMP {cores} threads), {dt:.1f}s"}
 
