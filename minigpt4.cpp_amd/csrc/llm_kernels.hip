@@ -1296,6 +1296,23 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
     __shared__ double s_dred[AT_THREADS / 64];
     const float scale = 1.0f / sqrtf((float)HD);
     const size_t qo = (size_t)t * E + (size_t)h * HD;
+#ifdef MG4_ATTN_EARLY
+    // Alternate build for A/B (same arithmetic, same order): the cached key row and the first cached value rows of this thread do not depend on this step's q / k / v, so
+    // they are requested BEFORE the RoPE prologue (whose q / k / v loads wait for the previous launch's results) instead of after it and after the scores.
+    constexpr int CH_E = HD / 8, P_E = AT_THREADS / CH_E, NPRE_E = 12;
+    int4 kk0[HD / 8];
+    {
+        const __half *kr0 = kc + (size_t)min(tid, max(Tg - 1, 0)) * E + (size_t)h * HD;
+#pragma unroll
+        for (int i = 0; i < HD / 8; i++) kk0[i] = ld16(kr0 + 8 * i);
+    }
+    int4 vpre[NPRE_E];
+    {
+        const __half *vb0 = vc + (size_t)h * HD + 8 * (tid % CH_E);
+#pragma unroll
+        for (int i = 0; i < NPRE_E; i++) vpre[i] = ld16(vb0 + (size_t)min(tid / CH_E + i * P_E, max(Tg - 1, 0)) * E);
+    }
+#endif
     if (FUSED) {
         if (tid < HD / 2) {
             const int i = tid;
@@ -1314,6 +1331,18 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
     unsigned qreg[HD / 2];
 #pragma unroll
     for (int i = 0; i < HD / 8; i++) { const int4 v4 = *reinterpret_cast<const int4 *>(qh + 8 * i); qreg[4 * i] = (unsigned)v4.x; qreg[4 * i + 1] = (unsigned)v4.y; qreg[4 * i + 2] = (unsigned)v4.z; qreg[4 * i + 3] = (unsigned)v4.w; }
+#ifdef MG4_ATTN_EARLY
+    auto dot_kk = [&](const int4 (&kk)[HD / 8]) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < HD / 8; i++) {
+            const unsigned w[4] = {(unsigned)kk[i].x, (unsigned)kk[i].y, (unsigned)kk[i].z, (unsigned)kk[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) { s = fmaf(h2f_bits(w[e] & 0xFFFF), h2f_bits(qreg[4 * i + e] & 0xFFFF), s); s = fmaf(h2f_bits(w[e] >> 16), h2f_bits(qreg[4 * i + e] >> 16), s); }
+        }
+        return s * scale;
+    };
+#endif
     auto dot_row = [&](const __half *kr) {
         int4 kk[HD / 8];
 #pragma unroll
@@ -1328,15 +1357,22 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
         return s * scale;
     };
     float mx = -INFINITY;
+#ifdef MG4_ATTN_EARLY
+    if (tid < Tg) { const float s = dot_kk(kk0); sc[tid] = s; mx = fmaxf(mx, s); }
+    for (int j = tid + AT_THREADS; j < Tg; j += AT_THREADS) { const float s = dot_row(kc + (size_t)j * E + (size_t)h * HD); sc[j] = s; mx = fmaxf(mx, s); }
+#else
     for (int j = tid; j < Tg; j += AT_THREADS) { const float s = dot_row(kc + (size_t)j * E + (size_t)h * HD); sc[j] = s; mx = fmaxf(mx, s); }
+#endif
     if (FUSED && tid == AT_THREADS - 1) { const float s = dot_row(knew); sc[pos] = s; mx = fmaxf(mx, s); }
     // The value rows do not depend on the scores: request the first NPRE of this thread's rows now, so that they arrive during the softmax.
     const int c = tid % CH, p = tid / CH;
     const __half *vb = vc + (size_t)h * HD + 8 * c;
     constexpr int NPRE = 12;
+#ifndef MG4_ATTN_EARLY
     int4 vpre[NPRE];
 #pragma unroll
     for (int i = 0; i < NPRE; i++) vpre[i] = ld16(vb + (size_t)min(p + i * P, max(Tg - 1, 0)) * E);   // clamped: never branches, never out of the cache
+#endif
     mx = wave_max(mx);
     if ((tid & 63) == 0) s_red[tid >> 6] = mx;
     __syncthreads();
