@@ -22,7 +22,10 @@ __device__ __forceinline__ v16i zero16() { v16i z; for (int i = 0; i < 16; i++) 
 __device__ __forceinline__ v4i bcast_byte(int b) { const int w = b * 0x01010101; v4i r = {w, w, w, w}; return r; }
 __device__ __forceinline__ int tok_of(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
-constexpr int MMQ_TT = 2;   // token tiles (of 32) per wave
+#ifndef MG4_MMQ_TT
+#define MG4_MMQ_TT 2        // -DMG4_MMQ_TT=1 (alternate build libminigpt4_tt1.so): half the accumulators / activation fragments per wave -> more waves per SIMD, weights re-read per 32 tokens
+#endif
+constexpr int MMQ_TT = MG4_MMQ_TT;   // token tiles (of 32) per wave
 
 // Combine the 4 K-slices of a workgroup (fixed order: deterministic) and store.  Wave w finalises accumulator registers 4w..4w+3.
 __device__ __forceinline__ void mmq_reduce_store(float (&acc)[MMQ_TT][16], int wv, int lane, int r0, int t0, int rows, int N, float *y, int ldy, const float *residual) {
