@@ -26,6 +26,7 @@ __device__ __forceinline__ int tok_of(int reg, int hh) { return (reg & 3) + 8 * 
 #define MG4_MMQ_TT 2        // -DMG4_MMQ_TT=1 (alternate build libminigpt4_tt1.so): half the accumulators / activation fragments per wave -> more waves per SIMD, weights re-read per 32 tokens
 #endif
 constexpr int MMQ_TT = MG4_MMQ_TT;   // token tiles (of 32) per wave
+#define MMQ_BOUNDS __launch_bounds__(256)      // (256, 2) makes hipcc spill the Q4_K / Q5_K kernel to scratch in the TT = 1 builds: not used
 
 // Combine the 4 K-slices of a workgroup (fixed order: deterministic) and store.  Wave w finalises accumulator registers 4w..4w+3.
 __device__ __forceinline__ void mmq_reduce_store(float (&acc)[MMQ_TT][16], int wv, int lane, int r0, int t0, int rows, int N, float *y, int ldy, const float *residual) {
@@ -51,7 +52,7 @@ __device__ __forceinline__ void mmq_reduce_store(float (&acc)[MMQ_TT][16], int w
 // Q4_K / Q5_K
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool Q5>
-__global__ __launch_bounds__(256) void k_mmq_q45k(const QWeight W, const ActQ A, const int N, float *y, const int ldy, const float *residual) {
+__global__ MMQ_BOUNDS void k_mmq_q45k(const QWeight W, const ActQ A, const int N, float *y, const int ldy, const float *residual) {
     const int lane = threadIdx.x & 63, hh = lane >> 5;
     const int wv = threadIdx.x >> 6;               // the 4 waves of a workgroup split K; partial sums are combined through LDS
     const int r0 = blockIdx.x * 32;
@@ -80,14 +81,32 @@ __global__ __launch_bounds__(256) void k_mmq_q45k(const QWeight W, const ActQ A,
     __syncthreads();
     Wsb cur, nxt;
     fetch(wv, cur);
+#ifdef MG4_MMQ_APF
+    // alternate build: the activation fragments of the NEXT super-block are requested together with its weights (one L2 round trip per iteration leaves the critical path)
+    v4i alo[MMQ_TT][4], ahi[MMQ_TT][4], alo_n[MMQ_TT][4], ahi_n[MMQ_TT][4];
+#pragma unroll
+    for (int tt = 0; tt < MMQ_TT; tt++)
+#pragma unroll
+        for (int jp = 0; jp < 4; jp++) { const int8_t *p = A.q8k + (size_t)tokc[tt] * K + (size_t)wv * 256 + 64 * jp + 16 * hh; alo[tt][jp] = ldv4(p); ahi[tt][jp] = ldv4(p + 32); }
+#endif
     for (int sb = wv; sb < NSB; sb += 4) {
         fetch(sb + 4, nxt);
+#ifdef MG4_MMQ_APF
+        {
+            const int sbn = min(sb + 4, NSB - 1);
+#pragma unroll
+            for (int tt = 0; tt < MMQ_TT; tt++)
+#pragma unroll
+                for (int jp = 0; jp < 4; jp++) { const int8_t *p = A.q8k + (size_t)tokc[tt] * K + (size_t)sbn * 256 + 64 * jp + 16 * hh; alo_n[tt][jp] = ldv4(p); ahi_n[tt][jp] = ldv4(p + 32); }
+        }
+#else
         // activation fragments of this super-block (L2-resident): per token tile 4 x {lo, hi}
         v4i alo[MMQ_TT][4], ahi[MMQ_TT][4];
 #pragma unroll
         for (int tt = 0; tt < MMQ_TT; tt++)
 #pragma unroll
             for (int jp = 0; jp < 4; jp++) { const int8_t *p = A.q8k + (size_t)tokc[tt] * K + (size_t)sb * 256 + 64 * jp + 16 * hh; alo[tt][jp] = ldv4(p); ahi[tt][jp] = ldv4(p + 32); }
+#endif
         // 6-bit scales / mins of this lane's weight row
         const unsigned s0 = (unsigned)cur.h[1], s1 = (unsigned)cur.h[2], s2 = (unsigned)cur.h[3];
         const unsigned scw[2] = {s0 & 0x3f3f3f3fu, (s2 & 0x0f0f0f0fu) | (((s0 >> 6) & 0x03030303u) << 4)};
@@ -126,6 +145,12 @@ __global__ __launch_bounds__(256) void k_mmq_q45k(const QWeight W, const ActQ A,
                 acc[tt][r] = fmaf(-(dmin * da), (float)msum[tt][r], acc[tt][r]);
             }
         cur = nxt;
+#ifdef MG4_MMQ_APF
+#pragma unroll
+        for (int tt = 0; tt < MMQ_TT; tt++)
+#pragma unroll
+            for (int jp = 0; jp < 4; jp++) { alo[tt][jp] = alo_n[tt][jp]; ahi[tt][jp] = ahi_n[tt][jp]; }
+#endif
     }
     mmq_reduce_store(acc, wv, lane, r0, t0, W.rows, N, y, ldy, residual);
 }
@@ -136,7 +161,7 @@ __global__ __launch_bounds__(256) void k_mmq_q45k(const QWeight W, const ActQ A,
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int sext6(int x) { const int yv = x ^ 0x20202020; const int s = yv & 0x20202020; return yv | (s << 1) | (s << 2); }
 
-__global__ __launch_bounds__(256) void k_mmq_q6k(const QWeight W, const ActQ A, const int N, float *y, const int ldy, const float *residual) {
+__global__ MMQ_BOUNDS void k_mmq_q6k(const QWeight W, const ActQ A, const int N, float *y, const int ldy, const float *residual) {
     const int lane = threadIdx.x & 63, hh = lane >> 5;
     const int wv = threadIdx.x >> 6;               // the 4 waves of a workgroup split K; partial sums are combined through LDS
     const int r0 = blockIdx.x * 32;
@@ -172,13 +197,30 @@ __global__ __launch_bounds__(256) void k_mmq_q6k(const QWeight W, const ActQ A, 
     Wsb cur, nxt;
     fetch(wv, cur);
     const v4i z4 = {0, 0, 0, 0};
+#ifdef MG4_MMQ_APF
+    v4i alo[MMQ_TT][4], ahi[MMQ_TT][4], alo_n[MMQ_TT][4], ahi_n[MMQ_TT][4];
+#pragma unroll
+    for (int tt = 0; tt < MMQ_TT; tt++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) { const int n = p >> 1, c = p & 1; const int8_t *ap = A.q8k + (size_t)tokc[tt] * K + (size_t)wv * 256 + 128 * n + 32 * c + 16 * hh; alo[tt][p] = ldv4(ap); ahi[tt][p] = ldv4(ap + 64); }
+#endif
     for (int sb = wv; sb < NSB; sb += 4) {
         fetch(sb + 4, nxt);
+#ifdef MG4_MMQ_APF
+        {
+            const int sbn = min(sb + 4, NSB - 1);
+#pragma unroll
+            for (int tt = 0; tt < MMQ_TT; tt++)
+#pragma unroll
+                for (int p = 0; p < 4; p++) { const int n = p >> 1, c = p & 1; const int8_t *ap = A.q8k + (size_t)tokc[tt] * K + (size_t)sbn * 256 + 128 * n + 32 * c + 16 * hh; alo_n[tt][p] = ldv4(ap); ahi_n[tt][p] = ldv4(ap + 64); }
+        }
+#else
         v4i alo[MMQ_TT][4], ahi[MMQ_TT][4];
 #pragma unroll
         for (int tt = 0; tt < MMQ_TT; tt++)
 #pragma unroll
             for (int p = 0; p < 4; p++) { const int n = p >> 1, c = p & 1; const int8_t *ap = A.q8k + (size_t)tokc[tt] * K + (size_t)sb * 256 + 128 * n + 32 * c + 16 * hh; alo[tt][p] = ldv4(ap); ahi[tt][p] = ldv4(ap + 64); }
+#endif
         v16i isum[MMQ_TT];
 #pragma unroll
         for (int tt = 0; tt < MMQ_TT; tt++) isum[tt] = zero16();
@@ -212,6 +254,12 @@ __global__ __launch_bounds__(256) void k_mmq_q6k(const QWeight W, const ActQ A, 
                 acc[tt][r] = fmaf(d * dkl[(tt * 32 + tok_of(r, hh)) * NSB + sb], (float)isum[tt][r], acc[tt][r]);
             }
         cur = nxt;
+#ifdef MG4_MMQ_APF
+#pragma unroll
+        for (int tt = 0; tt < MMQ_TT; tt++)
+#pragma unroll
+            for (int p = 0; p < 4; p++) { alo[tt][p] = alo_n[tt][p]; ahi[tt][p] = ahi_n[tt][p]; }
+#endif
     }
     mmq_reduce_store(acc, wv, lane, r0, t0, W.rows, N, y, ldy, residual);
 }
@@ -222,7 +270,7 @@ __global__ __launch_bounds__(256) void k_mmq_q6k(const QWeight W, const ActQ A, 
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int sext4m8(int x) { const int yv = x ^ 0x08080808; return yv | ((yv & 0x08080808) * 30); }   // nibble - 8 as int8
 
-__global__ __launch_bounds__(256) void k_mmq_q40(const QWeight W, const ActQ A, const int N, float *y, const int ldy, const float *residual) {
+__global__ MMQ_BOUNDS void k_mmq_q40(const QWeight W, const ActQ A, const int N, float *y, const int ldy, const float *residual) {
     const int lane = threadIdx.x & 63, hh = lane >> 5;
     const int wv = threadIdx.x >> 6;               // the 4 waves of a workgroup split K; partial sums are combined through LDS
     const int r0 = blockIdx.x * 32;
