@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU call that answers the questions round 1 left open (run as the gpurun command, from the repo root; ~6 minutes of box time):
 #   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/next_round_gpu.sh'
-# BEFORE the call, in the dev container:  python -c "import __graft_entry__ as g; g.build()" && make -C minigpt4.cpp_amd/csrc variants
+# BEFORE the call, in the dev container:  python -c "import __graft_entry__ as g; g.build()" && make -C minigpt4.cpp_amd/csrc -j8 variants   (~8 min: start it in the background)
 # Everything lands in gpurun_out/next_round/ (copy what should be judged into profiles/).
 set -u
 export TMPDIR=/tmp
