@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default=os.environ.get("MG4_BENCH_CONFIG", "13b"), choices=["13b", "7b", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-steps", type=int, default=16, help="greedy steps compared with the CPU oracle on the measured file (part of the cpu_baseline leg)")
     ap.add_argument("--n-ctx", type=int, default=0, help="context size; default: 2048 or whatever --steps needs")
     ap.add_argument("--conversations", type=int, default=4, help="extra leg: batched decode of this many conversations per GPU in one weight pass (BASELINE.json configs[3] "
                     "has 4 requests per replica); reported as `batched_decode`, never as `value`.  0/1 = skip")
@@ -342,10 +343,31 @@ def main():
         except Exception as e:   # never lose the headline line to the extra leg
             out["batched_decode"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- parity on the measured file (checker use of the oracle, inside the cpu_baseline leg): the reference call sequence on both engines, same image
+        # embedding, same prompt -- free-running greedy pieces + teacher-forced logits of every step (oracle/headline.py)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import headline as H
+            if args.conversations > 1:
+                lib.amd_set_conversations(ctx, 1)
+            emb_np = np.ctypeslib.as_array(emb.data, shape=(emb.n_embeddings,)).copy().reshape(32, -1)
+            usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            orc = H.oracle_run(lp, emb_np, args.parity_steps, n_ctx=320, threads=max(1, min(usable, 32)))
+            gp = H.gpu_free_run(lib, ctx, emb, args.parity_steps)
+            gl = H.gpu_teacher_forced(lib, ctx, emb, orc["ids"])
+            out["parity"] = H.compare(orc, gp, gl)
+            out["parity"]["oracle_prefill_s"] = orc["prefill_s"]
+            out["parity"]["note"] = ("GPU vs CPU oracle on THIS run's files: system_prompt + begin_chat_image + greedy steps; `identical` counts free-running pieces, `decided` = steps whose "
+                                     "oracle top-2 margin exceeds 2x the largest observed logit difference; max_logit_rel_range = max |delta| / (max - min) of the oracle's logits")
+            del orc
+        except Exception as e:
+            out["parity"] = {"error": repr(e)}
         try:
             toks = lib.amd_tokenize(ctx, PROMPT.encode())
             lib.minigpt4_free(ctx)
             ctx = None
+            import gc
+            gc.collect()
             out["cpu_baseline"] = cpu_baseline(lp, toks)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         except Exception as e:

@@ -4,6 +4,7 @@
 
 #include <chrono>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <new>
 #include <string>
@@ -30,6 +31,9 @@ template <typename F> int guarded(int on_hip_error, F &&f) {
         char buf[512]; snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d: %s", (int)e.code, hipGetErrorString(e.code), e.file, e.line, e.what);
         set_last_error(buf); MG4_ERR("%s", buf); return on_hip_error;
     } catch (const std::bad_alloc &) { set_last_error("out of host memory"); return on_hip_error; }
+    // nothing may unwind through the extern "C" boundary into a ctypes / C caller (a malformed file can make a container throw std::length_error etc.)
+    catch (const std::exception &e) { set_last_error(std::string("internal error: ") + e.what()); MG4_ERR("%s", last_error().c_str()); return on_hip_error; }
+    catch (...) { set_last_error("internal error: unknown exception"); MG4_ERR("%s", last_error().c_str()); return on_hip_error; }
 }
 const char *kErrNames[] = {"None", "LoadModelFileHeader", "LoadModelFileVersion", "LoadModelMiniGPT4DataType", "LoadLanguageModel", "OpenImage", "ImageSize", "MmapSupport",
                            "FailedToAddString", "LLamaProjectionEmbeddingInvalidSize", "FailedToAddEmbedding", "EosToken", "Eos", "ImageNot224_244_3", "ImageNotF32",

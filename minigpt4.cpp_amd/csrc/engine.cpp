@@ -165,6 +165,8 @@ int Engine::load_llm(const std::string &path) {
     const int E = (int)llm_.n_embd, L = (int)llm_.n_layer, V = (int)llm_.n_vocab, F = (int)llm_.n_ff();
     const int hd = E / (int)llm_.n_head;
     if (!attn_head_size_supported(hd)) { set_last_error("unsupported head size (supported: 32, 64, 128)"); return E_LoadLanguageModel; }
+    // k_attn_llm keeps one fp32 score + one fp16 probability per key of the context in LDS (6 bytes per key, 160 KiB per workgroup): refuse what cannot launch
+    if (n_ctx_ > attn_max_ctx(hd)) { set_last_error("n_ctx " + std::to_string(n_ctx_) + " exceeds what the attention kernel's LDS score buffer holds (" + std::to_string(attn_max_ctx(hd)) + ")"); MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
     MG4_INFO("llm: n_vocab %d n_embd %d n_head %u n_layer %d n_ff %d n_ctx %d", V, E, llm_.n_head, L, F, n_ctx_);
     auto need = [&](const std::string &name, int64_t ne0, int64_t ne1) -> const TensorMeta * {
         const TensorMeta *t = llm_.find(name);
@@ -253,7 +255,11 @@ int Engine::load_vision(const std::string &path) {
     if (!qt || qt->ne.size() != 2 || qt->ne[0] != 768 || qt->type != GT_F32) return fail("bad query_tokens.weight", E_LoadModelFileHeader);
     v_nq_ = (int)qt->ne[1];
     if (vis_.config_int("query_length", v_nq_) != v_nq_) return fail("query_embeds_length != query_length", E_LoadModelFileHeader);   // reference PANICs (minigpt4.cpp:2230)
-    v_ql_ = (int)vis_.config_int("num_hidden_layers", 12);
+    {   // sizes read from an untrusted header feed container sizes below
+        const long long ql = vis_.config_int("num_hidden_layers", 12);
+        if (ql < 1 || ql > 64 || v_nq_ < 1 || v_nq_ > 256) return fail("num_hidden_layers / query_length out of range", E_LoadModelFileHeader);
+        v_ql_ = (int)ql;
+    }
     const TensorMeta *lp = vis_.find("llama_proj", "weight");
     if (!lp || lp->ne.size() != 2 || lp->ne[0] != 768) return fail("bad llama_proj.weight", E_LoadModelFileHeader);
     v_out_ = (int)lp->ne[1];
@@ -507,13 +513,15 @@ bool Engine::mixed_qkv(const LayerW &L, hipStream_t s, bool fuse) {
 }
 
 // Enqueue one forward pass for N rows already described by d_tokens_ (from_tokens) or x_ (embeddings), at position *d_npast_.
-void Engine::forward(int N, bool from_tokens, hipStream_t s) {
+void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
     const int E = (int)llm_.n_embd, F = (int)llm_.n_ff(), H = (int)llm_.n_head, hd = E / H, V = (int)llm_.n_vocab;
     const size_t C = (size_t)n_ctx_, sl = (size_t)cur_;                     // everything below addresses the selected conversation's cache / scalars
     int *const d_npast = d_npast_ + sl, *const d_argmax = d_argmax_ + sl, *const d_feed = d_feed_ + sl;
     float *const logits = logits_ + sl * (size_t)V;
     const bool dec = N == 1;
-    if (from_tokens) launch_get_rows(tok_type_, tok_raw_, E, dec ? d_feed : d_tokens_, N, x_, s);
+    // feed: the row is the decode token kept in d_feed (greedy feedback / set by eval_chunk); otherwise the rows are described by d_tokens_ (id, or -1 = an
+    // embedding row already sitting in x_) -- a chunk of exactly ONE embedding row must not pick up the stale decode token
+    if (from_tokens) launch_get_rows(tok_type_, tok_raw_, E, feed ? d_feed : d_tokens_, N, x_, s);
     auto fz = [&](int bit) { return dec && (fuse_mask_ >> bit & 1); };
     for (size_t il = 0; il < layers_.size(); il++) {
         const LayerW &L = layers_[il];
@@ -621,14 +629,14 @@ int Engine::eval_chunk(const int *row_tok, int N, const float *embd) {
             if (!cv.graph) {
                 hipGraph_t g = nullptr;
                 HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-                forward(1, true, stream_);
+                forward(1, true, stream_, true);
                 HIP_CHECK(hipStreamEndCapture(stream_, &g));
                 HIP_CHECK(hipGraphInstantiate(&cv.graph, g, nullptr, nullptr, 0));
                 HIP_CHECK(hipGraphDestroy(g));
             }
             HIP_CHECK(hipGraphLaunch(cv.graph, stream_));
         } else {
-            forward(1, true, stream_);
+            forward(1, true, stream_, true);
         }
     } else {
         HIP_CHECK(hipMemcpyAsync(d_tokens_, row_tok, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
@@ -719,7 +727,7 @@ int Engine::decode_loop(int steps, int *tokens_out, float *ms_total) {
     HIP_CHECK(hipEventRecord(a, stream_));
     for (int i = 1; i < steps; i++) {   // step i consumes the greedy token of step i-1, left in d_tokens_[0] by k_advance
         if (tokens_out) HIP_CHECK(hipMemcpyAsync(&tokens_out[i], d_feed_ + cur_, 4, hipMemcpyDeviceToHost, stream_));
-        if (cv.graph && use_graph_) HIP_CHECK(hipGraphLaunch(cv.graph, stream_)); else forward(1, true, stream_);
+        if (cv.graph && use_graph_) HIP_CHECK(hipGraphLaunch(cv.graph, stream_)); else forward(1, true, stream_, true);
     }
     HIP_CHECK(hipEventRecord(b, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));

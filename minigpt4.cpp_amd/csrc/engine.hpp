@@ -84,7 +84,7 @@ private:
     int load_vision(const std::string &path);
     void alloc_buffers();
     int eval_chunk(const int *row_tok, int N, const float *embd);
-    void forward(int N, bool from_tokens, hipStream_t s);
+    void forward(int N, bool from_tokens, hipStream_t s, bool feed = false);   // feed: N == 1 and the token comes from d_feed_ (decode)
     void forward_batch(int B, hipStream_t s);          // B decode rows of B conversations: tokens d_btok_[r], conversations d_bslot_[r]
     struct Prep { int kind; const float *x; const float *w; };   // 1: rms_norm(x)*w, 2: x, 3: silu(x)*w -- then quantised for the consumer's type
     void mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse);

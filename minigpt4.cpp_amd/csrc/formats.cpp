@@ -310,8 +310,8 @@ void Tokenizer::init(const LLMFile &f) {
 }
 std::vector<int> Tokenizer::tokenize(const std::string &text, bool add_bos) const {
     std::vector<int> out;
+    if (text.empty()) return out;        // llama_tokenize (llama.cpp master-31cfbb1) returns before the BOS push for an empty text
     if (add_bos) out.push_back(1);
-    if (text.empty()) return out;
     struct Sym { size_t start, n; int prev, next; };
     std::vector<Sym> syms;
     for (size_t i = 0; i < text.size();) {

@@ -68,6 +68,7 @@ void launch_attn_llm_batched(float *q, const float *k, const float *v, __half *k
 void launch_batch_finish(const float *logits, int n_vocab, int B, const int *row_slot, int *n_past, int *argmax, int *feed, float *slot_logits, hipStream_t s);
 void launch_batch_begin(int *n_past, const int *row_slot, const int *row_pos, int B, hipStream_t s);   // n_past[row_slot[r]] = row_pos[r]
 bool attn_head_size_supported(int hd);
+int attn_max_ctx(int hd);   // largest n_ctx whose score / probability rows fit the attention kernel's LDS
 void launch_argmax(const float *logits, int n, int *out, void *scratch /*>= 512 bytes*/, hipStream_t s);
 void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);
 void launch_set_int(int *p, int v, hipStream_t s);

@@ -1447,6 +1447,8 @@ void launch_attn_llm_batched(float *q, const float *k, const float *v, __half *k
     }
 }
 bool attn_head_size_supported(int hd) { return hd == 32 || hd == 64 || hd == 128; }
+static size_t attn_lds_bytes(int n_ctx, int hd) { const int Tpad = (n_ctx + 7) & ~7; return (size_t)Tpad * 6 + (size_t)hd * 6 + (size_t)(AT_THREADS / (hd / 8)) * hd * 4 + 64; }
+int attn_max_ctx(int hd) { int n = 0; while (attn_lds_bytes(n + 8, hd) + 256 /* static reduction arrays */ <= 160 * 1024) n += 8; return n; }
 // fused = true (N must be 1): q,k,v are the raw projections; RoPE + KV append happen inside.  fused = false: launch_rope_kv must have run.
 void launch_attn_llm(float *q, const float *k, const float *v, __half *kcache, __half *vcache, int N, int n_head, int hd, const int *n_past, int n_ctx,
                      const float *cos_tab, const float *sin_tab, const Tables &tb, float *out, bool fused, hipStream_t s) {

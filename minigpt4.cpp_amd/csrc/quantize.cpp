@@ -309,6 +309,10 @@ int quantize_vision_file(const char *in_path, const char *out_path, int mg4_data
     const int out_type = mg4_to_ggml_q(mg4_data_type);
     if (!quantize_supported(out_type)) { set_last_error("minigpt4_quantize_model: target type must be one of Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q4_K Q5_K Q6_K"); return E_LoadModelMiniGPT4DataType; }
     if (!out_path) return E_DumpModelFileOpen;
+    {   // the input stays mmap'd while the output is written: truncating it through a second name (same path or a hard link) would SIGBUS the next tensor read
+        struct stat so;
+        if (stat(out_path, &so) == 0 && so.st_dev == st.st_dev && so.st_ino == st.st_ino) { set_last_error("quantize: the output path is the input file"); return E_DumpModelFileOpen; }
+    }
     FILE *f = fopen(out_path, "wb");
     if (!f) { set_last_error(std::string("cannot open ") + out_path); return E_DumpModelFileOpen; }
     auto w32 = [&](int32_t v) { fwrite(&v, 4, 1, f); };

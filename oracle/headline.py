@@ -1,0 +1,117 @@
+"""TEST INFRASTRUCTURE (never imported by the product): GPU-vs-oracle comparison at the BASELINE.json headline shapes.
+
+Used by tests/test_gpu_headline.py and by bench.py's `cpu_baseline` leg (the `parity` object of the bench line).  The reference call sequence is
+`minigpt4_system_prompt -> minigpt4_begin_chat_image -> K x minigpt4_end_chat_image(temp 0)` (reference minigpt4.cpp:2671-2718, 2720-2732;
+examples/main.cpp:207-293); the oracle side is OracleChat over OracleLLM (oracle/refcpu.py, oracle/refcpu.c).
+
+Two comparisons on the same file, the same image embedding and the same prompt:
+  * free-running: both sides decode greedily on their own; the piece sequences are compared (north_star: "bit-exact token ids under greedy sampling");
+  * teacher-forced: the GPU is fed the ORACLE's token at every step, so every step's logits are comparable even after a near-tie would have made the
+    free-running sequences part ways; reported as max |delta| / (max - min of the oracle's logits) per step, plus whether the argmax agrees and whether the
+    oracle's own top-2 margin exceeds the observed noise ("decided" steps).
+"""
+import os
+import time
+from typing import Dict, List, Optional
+
+import numpy as np
+
+PROMPT = "what is the text in the picture?"   # reference examples/main.cpp:61
+
+
+def model_dir() -> str:
+    for d in ("/dev/shm", "/tmp"):
+        try:
+            st = os.statvfs(d)
+            if st.f_bavail * st.f_frsize > 14e9:
+                p = os.path.join(d, "mg4_bench")
+                os.makedirs(p, exist_ok=True)
+                return p
+        except OSError:
+            pass
+    p = os.path.join("/tmp", "mg4_bench")
+    os.makedirs(p, exist_ok=True)
+    return p
+
+
+def headline_files(config: str):
+    """The synthetic files bench.py measures (same generator arguments, same cache directory): returns (vision_path, llm_path)."""
+    from minigpt4_cpp_amd import modelgen as G
+    d = model_dir()
+    if config == "13b":
+        vcfg, lcfg = G.vision_13b(), G.llm_13b()
+    elif config == "7b":
+        vcfg, lcfg = G.vision_7b(), G.llm_7b("q4_0")
+    else:
+        raise ValueError(config)
+    vp, lp = os.path.join(d, f"vision_{config}.bin"), os.path.join(d, f"llm_{config}.bin")
+    if not os.path.exists(vp + ".ok"):
+        G.write_vision_file(vp, vcfg, seed=4321, std=0.02, unique_blocks=1, fast=True)
+        open(vp + ".ok", "w").write("ok")
+    if not os.path.exists(lp + ".ok"):
+        G.write_llm_file(lp, lcfg, seed=1234, std=0.02, unique_layers=1, fast=True)
+        open(lp + ".ok", "w").write("ok")
+    return vp, lp
+
+
+def oracle_run(lp: str, embedding: np.ndarray, steps: int, prompt: str = PROMPT, n_ctx: int = 512, native: bool = False, threads: Optional[int] = None) -> Dict:
+    """Oracle side of the chat flow: per-step logits (before sampling), greedy ids and pieces."""
+    import refcpu as R
+    from minigpt4_cpp_amd import modelgen as G
+    f = G.read_llm_file(lp, in_memory=True)
+    if threads:
+        R.lib(native).orc_set_threads(int(threads))
+    llm = R.OracleLLM(f, n_ctx=n_ctx, native=native)
+    chat = R.OracleChat(llm, n_batch=512)
+    t0 = time.time()
+    chat.system_prompt()
+    chat.begin_chat_image(embedding, prompt.encode())
+    prefill_s = time.time() - t0
+    n_prompt = llm.n_past
+    logits, ids, pieces = [], [], []
+    t0 = time.time()
+    for _ in range(steps):
+        logits.append(llm.logits.copy())
+        tid, piece = chat.end_chat(temp=0.0)
+        ids.append(int(tid))
+        pieces.append(piece.decode("utf-8", errors="replace"))
+    return {"logits": np.stack(logits), "ids": ids, "pieces": pieces, "n_prompt": n_prompt, "prefill_s": prefill_s, "decode_s": time.time() - t0}
+
+
+def gpu_free_run(lib, ctx, emb_struct, steps: int, prompt: str = PROMPT) -> List[str]:
+    """The reference API flow on the GPU: pieces of `steps` greedy tokens (EOS ignored)."""
+    lib.minigpt4_reset_chat(ctx)
+    lib.minigpt4_system_prompt(ctx)
+    lib.minigpt4_begin_chat_image(ctx, emb_struct, prompt)
+    return [lib.minigpt4_end_chat_image(ctx, temp=0.0) for _ in range(steps)]
+
+
+def gpu_teacher_forced(lib, ctx, emb_struct, ids: List[int], prompt: str = PROMPT) -> np.ndarray:
+    """Logits of every decode step with the ORACLE's ids fed back (the same decode path as minigpt4_end_chat_image: one-row eval through the decode graph)."""
+    lib.minigpt4_reset_chat(ctx)
+    lib.minigpt4_system_prompt(ctx)
+    lib.minigpt4_begin_chat_image(ctx, emb_struct, prompt)
+    out = []
+    for tid in ids:
+        out.append(lib.amd_logits(ctx).copy())
+        lib.amd_eval_tokens(ctx, [int(tid)])
+    return np.stack(out)
+
+
+def compare(oracle: Dict, gpu_pieces: List[str], gpu_logits: np.ndarray) -> Dict:
+    ol = oracle["logits"].astype(np.float64)
+    gl = gpu_logits.astype(np.float64)
+    rng = ol.max(axis=1) - ol.min(axis=1)
+    rel = np.abs(gl - ol).max(axis=1) / rng                                   # per step, relative to the oracle's logit range
+    rel_max = np.abs(gl - ol).max(axis=1) / np.abs(ol).max(axis=1)            # per step, relative to the largest |logit| (north_star's "1e-2 relative")
+    noise = float(np.abs(gl - ol).max())
+    srt = np.sort(ol, axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    decided = margin > 2.0 * noise                                            # the oracle's top-2 gap exceeds twice the largest observed logit difference
+    arg_eq = gl.argmax(axis=1) == ol.argmax(axis=1)
+    n = len(oracle["ids"])
+    first_div = next((i for i in range(n) if gpu_pieces[i] != oracle["pieces"][i]), n)
+    return {"tokens_compared": n, "free_running_identical": int(sum(a == b for a, b in zip(gpu_pieces, oracle["pieces"]))), "free_running_first_divergence": first_div,
+            "teacher_forced_argmax_identical": int(arg_eq.sum()), "decided": int(decided.sum()), "decided_argmax_identical": int((arg_eq & decided).sum()),
+            "max_logit_rel_range": float(rel.max()), "max_logit_rel": float(rel_max.max()), "mean_logit_rel_range": float(rel.mean()),
+            "min_top2_margin_over_range": float((margin / rng).min()), "prompt_tokens": int(oracle["n_prompt"])}

@@ -211,9 +211,9 @@ def tokenize(vocab: List[Tuple[bytes, float]], text: bytes, add_bos: bool = True
     tok2id = {}
     for i, (p, _) in enumerate(vocab):
         tok2id[p] = i  # later duplicates win, as llama.cpp's token_to_id map is filled
+    if not text:                 # llama_tokenize returns an empty vector for an empty text BEFORE it would push BOS
+        return []
     out: List[int] = [1] if add_bos else []
-    if not text:
-        return out
     # symbols
     syms: List[List] = []  # [start, length, prev, next]
     i = 0

@@ -279,6 +279,9 @@ def test_tokenizer_matches_oracle(lib, tiny_files):
             # decoding the pieces gives back the text (byte-fallback ids are byte + 3)
             dec = b"".join(vocab[i][0] for i in want if i != 1 or not bos)
             assert dec == t
+    # llama_tokenize returns nothing for an empty text, BOS included (llama.cpp master-31cfbb1: `if (text.empty()) return output;` precedes the BOS push)
+    out = (ctypes.c_int32 * 4)()
+    assert lib.library.minigpt4_amd_vocab_tokenize(v, b"", 1, out, 4) == 0 and R.tokenize(vocab, b"", True) == []
     lib.library.minigpt4_amd_vocab_free(v)
 
 

@@ -154,6 +154,14 @@ def test_quantize_model_error_codes(lib, tmp_path):
     assert L.minigpt4_quantize_model(src.encode(), b"/nonexistent_dir/out.bin", MG4["q4_0"]) == 18   # DumpModelFileOpen (:1636-1640)
     for bad in (MG4["f16"], MG4["f32"], MG4["q2_k"], 2, 99, -1):
         assert L.minigpt4_quantize_model(src.encode(), str(tmp_path / "o.bin").encode(), bad) == 3  # LoadModelMiniGPT4DataType
+    # output == input (same path, or a hard link to it): refused before the mmap'd input could be truncated, and the input survives intact
+    import hashlib, os
+    before = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    link = str(tmp_path / "v_link.bin")
+    os.link(src, link)
+    assert L.minigpt4_quantize_model(src.encode(), src.encode(), MG4["q4_0"]) == 18
+    assert L.minigpt4_quantize_model(src.encode(), link.encode(), MG4["q4_0"]) == 18
+    assert hashlib.sha256(open(src, "rb").read()).hexdigest() == before
     garbage = tmp_path / "g.bin"
     garbage.write_bytes(b"not a model")
     assert L.minigpt4_quantize_model(str(garbage).encode(), str(tmp_path / "o.bin").encode(), MG4["q4_0"]) == 1   # LoadModelFileHeader

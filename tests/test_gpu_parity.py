@@ -279,6 +279,30 @@ def test_eval_embd_matches_oracle(gpu_lib, tiny_files):
         gpu_lib.minigpt4_free(ctx)
 
 
+@pytest.mark.parametrize("n_batch,rows", [(16, 1), (32, 33), (8, 1)])
+def test_single_embedding_row_chunk(gpu_lib, tiny_files, n_batch, rows):
+    """A chunk that is exactly ONE embedding row (a 1-row llama_eval_embd, or pending rows == 1 mod n_batch ending in an embedding row) must read the
+    embedding, not the previous decode token (round-1 advisor finding: forward(1) used to gather the stale d_feed token over it)."""
+    import refcpu as R
+    from minigpt4_cpp_amd import modelgen as G
+    vp, llm = tiny_files
+    lp = llm("q5_k", "q5_k_m")
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=96, n_batch=n_batch)
+    try:
+        o = R.OracleLLM(G.read_llm_file(lp), n_ctx=96)
+        emb = (0.05 * np.random.default_rng(30 + rows).standard_normal((rows, 256))).astype(np.float32)
+        gpu_lib.amd_eval_tokens(ctx, [1, 7, 9])
+        o.eval_tokens([1, 7, 9])
+        _ = gpu_lib.amd_logits(ctx)                   # forces the evaluation: the decode-token slot now holds a stale greedy id
+        if n_batch == 8:                              # also leave a real decode step behind (d_feed = its token)
+            gpu_lib.amd_eval_tokens(ctx, [11]); o.eval_tokens([11]); _ = gpu_lib.amd_logits(ctx)
+        gpu_lib.amd_eval_embd(ctx, emb)
+        want = o.eval_embd(emb)
+        assert _rel(gpu_lib.amd_logits(ctx), want) < 2e-3
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+
+
 def test_chat_flow_with_image_end_to_end(gpu_lib, tmpdir_models):
     """Reference call sequence (examples/main.cpp:207-293): load -> encode_image -> system_prompt -> begin_chat_image -> end_chat_image x K,
     on a model whose LLM width (4096) the C API accepts for image embeddings; greedy pieces identical to the oracle."""
