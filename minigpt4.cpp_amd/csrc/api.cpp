@@ -44,7 +44,7 @@ namespace {
 struct DevBuf { void *p = nullptr; DevBuf(size_t n) { HIP_CHECK(hipMalloc(&p, n ? n : 1)); } ~DevBuf() { if (p) (void)hipFree(p); } template <typename T> T *as() { return static_cast<T *>(p); } };
 void alloc_act(ActQ &A, std::vector<std::unique_ptr<DevBuf>> &keep, size_t N, size_t K) {
     auto mk = [&](size_t bytes) { keep.emplace_back(new DevBuf(bytes + 256)); return keep.back()->p; };
-    A.q8k = (int8_t *)mk(N * K); A.q80 = (int8_t *)mk(N * K); A.dk = (float *)mk(N * (K / 256 + 1) * 4); A.bsk = (int16_t *)mk(N * (K / 16 + 1) * 2);
+    A.q8k = (int8_t *)mk(N * K); A.q80 = (int8_t *)mk(N * K); A.dk = (float *)mk(N * (K / 256 + 1) * 4); A.bsk = (int16_t *)mk(N * (K / 16 + 1) * 2); A.bsq = (int8_t *)mk(N * (K / 16 + 16));
     A.d0 = (float *)mk(N * (K / 32 + 1) * 4); A.d1 = (float *)mk(N * (K / 32 + 1) * 4); A.s1 = (float *)mk(N * (K / 32 + 1) * 4); A.sum0 = (int *)mk(N * (K / 32 + 1) * 4);
     A.xh = (__half *)mk(N * K * 2); A.xf = (float *)mk(N * K * 4);
 }
@@ -314,6 +314,41 @@ int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int64_t n_in, in
         launch_mul_mat(W, A, (int)N, d_y.as<float>(), (int)n_out, nullptr, nullptr);
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemcpy(y, d_y.p, (size_t)(N * n_out) * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+
+// The prefill launch of Engine::forward for N > 4 rows (mmq2_kernels.hip): n_mat equally shaped matrices (rows of `raw_w` back to back) against N rows in ONE launch, optional
+// residual ([n_mat][N][n_out]), optional forced K split (ks > 1: partial sums combined in fixed order).  y: [n_mat][N][n_out].  Returns 4 when the kernels refuse the shape.
+int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int64_t N, const float *residual, int ks, float *y) {
+    if (!raw_w || !x || !y || n_in <= 0 || n_out <= 0 || N <= 0 || n_mat < 1 || n_mat > 3 || !qweight_supported(ggml_type) || n_in % gt_block(ggml_type)) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const size_t raw_each = gt_nbytes(ggml_type, (size_t)(n_in * n_out)), out_each = (size_t)(N * n_out);
+        QWeight W[3], plan;
+        const size_t need = plan_qweight(ggml_type, (int)n_out, (int)n_in, plan, nullptr);
+        DevBuf d_raw(raw_each), d_planes(need * (size_t)n_mat + 1024), d_x((size_t)(N * n_in) * 4), d_y(out_each * n_mat * 4), d_res(out_each * n_mat * 4), d_ws(out_each * n_mat * 16 * 4);
+        for (int i = 0; i < n_mat; i++) {
+            plan_qweight(ggml_type, (int)n_out, (int)n_in, W[i], d_planes.as<uint8_t>() + (size_t)i * need);
+            HIP_CHECK(hipMemcpy(d_raw.p, static_cast<const uint8_t *>(raw_w) + (size_t)i * raw_each, raw_each, hipMemcpyHostToDevice));
+            launch_repack(d_raw.as<uint8_t>(), W[i], nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+        }
+        HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)(N * n_in) * 4, hipMemcpyHostToDevice));
+        if (residual) HIP_CHECK(hipMemcpy(d_res.p, residual, out_each * n_mat * 4, hipMemcpyHostToDevice));
+        ActQ A; std::vector<std::unique_ptr<DevBuf>> keep; alloc_act(A, keep, (size_t)N, (size_t)n_in);
+        launch_rms_quant(d_x.as<float>(), nullptr, (int)N, (int)n_in, A, act_mask_for(ggml_type), nullptr);
+        const QWeight *Wp[3]; float *Yp[3]; const float *Rp[3];
+        for (int i = 0; i < n_mat; i++) { Wp[i] = &W[i]; Yp[i] = d_y.as<float>() + (size_t)i * out_each; Rp[i] = d_res.as<float>() + (size_t)i * out_each; }
+        float *old_ws; size_t old_n; get_mmq2_workspace(&old_ws, &old_n);
+        set_mmq2_workspace(d_ws.as<float>(), out_each * n_mat * 16, 0);
+        if (ks > 0) setenv("MINIGPT4_MMQ2_KS", std::to_string(ks).c_str(), 1);
+        const bool ok = launch_mmq2_set(Wp, Yp, residual ? Rp : nullptr, n_mat, A, (int)N, (int)n_out, nullptr);
+        unsetenv("MINIGPT4_MMQ2_KS");
+        HIP_CHECK(hipDeviceSynchronize());
+        set_mmq2_workspace(old_ws, old_n, 0);
+        if (!ok) return 4;
+        HIP_CHECK(hipMemcpy(y, d_y.p, out_each * n_mat * 4, hipMemcpyDeviceToHost));
         return 0;
     });
 }

@@ -66,6 +66,7 @@ struct ActQ {
     int8_t *q8k = nullptr;   // [N][K]     Q8_K values
     float *dk = nullptr;     // [N][K/256]
     int16_t *bsk = nullptr;  // [N][K/16]  Q8_K bsums
+    int8_t *bsq = nullptr;   // [N][K/256][16] (optional) per-32 sums of the Q8_K values split for the int8 matrix cores: bytes 0..7 = s & 127, bytes 8..15 = s >> 7 (s = 128 hi + lo)
     int8_t *q80 = nullptr;   // [N][K]     Q8_0 / Q8_1 values (identical)
     float *d0 = nullptr;     // [N][K/32]  Q8_0 d, fp16-rounded
     float *d1 = nullptr;     // [N][K/32]  Q8_1 d (float)

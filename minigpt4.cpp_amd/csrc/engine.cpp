@@ -104,7 +104,8 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     use_graph_ = !(getenv("MINIGPT4_NO_GRAPH") && atoi(getenv("MINIGPT4_NO_GRAPH")));
     defer_ = !(getenv("MINIGPT4_NO_DEFER") && atoi(getenv("MINIGPT4_NO_DEFER")));
     max_chunk_ = max_rows_;
-    if (getenv("MINIGPT4_NO_MMQ")) set_mmq_enabled(!atoi(getenv("MINIGPT4_NO_MMQ")));
+    if (getenv("MINIGPT4_NO_MMQ")) set_mmq_enabled(atoi(getenv("MINIGPT4_NO_MMQ")) ? 0 : 2);
+    if (getenv("MINIGPT4_MMQ")) set_mmq_enabled(atoi(getenv("MINIGPT4_MMQ")));   // 0: v_dot4 tiles, 1: round-1 int8-MFMA prefill kernels, 2 (default): LDS-staged second generation
     if (getenv("MINIGPT4_ATTN_MFMA")) set_attn_mfma(atoi(getenv("MINIGPT4_ATTN_MFMA")));
     // Decode: which activation preparations run inside the consuming mat-vec's prologue (one fat workgroup per CU repeats the row preparation while
     // its first weight tiles are in flight) instead of as their own launch.  bit 0: attn_norm -> wq|wk|wv, 1: attention output -> wo,
@@ -385,8 +386,8 @@ void Engine::alloc_buffers() {
     auto sz = [&](size_t b) { total += (b + 255) / 256 * 256 + 256; };
     sz(S * L * C * E * 2); sz(S * L * C * E * 2); sz(2 * C * (hd / 2) * 4 * 2); sz(3 * 65536 * 2);
     sz(5 * B * E * 4); sz(2 * B * F * 4); sz(S * V * 4); sz(S * V * 4); sz(8 * 256 + 2 * B * 4);
-    sz(2 * B * Kmax); sz(B * Kmax / 256 * 4 + 64); sz(B * Kmax / 16 * 2 + 64); sz(4 * (B * Kmax / 32 * 4 + 64)); sz(B * Kmax * 2); sz(B * Kmax * 4);
-    sz(8192);
+    sz(2 * B * Kmax); sz(B * Kmax / 256 * 4 + 64); sz(B * Kmax / 16 * 2 + 64); sz(B * Kmax / 16 + 64); sz(4 * (B * Kmax / 32 * 4 + 64)); sz(B * Kmax * 2); sz(B * Kmax * 4);
+    sz(8192); sz((size_t)64 << 20);
     const size_t VB = (size_t)VISION_BATCH_MAX;                            // images encoded in one pass (minigpt4_encode_images)
     sz(VB * 3 * 224 * 224 * 4); sz(VB * 256 * 592 * 2); sz(VB * 256 * D * 4); sz(VB * 257 * D * 4); sz(VB * 257 * 3 * D * 4); sz(VB * 3 * 257 * D * 2); sz(VB * 257 * M * 2);
     sz(VB * (size_t)SPLITK_MAX * 257 * D * 4);
@@ -421,6 +422,7 @@ void Engine::alloc_buffers() {
     h1_ = takef(B * F); h3_ = takef(B * F); logits_ = takef(S * V); blogits_ = takef(S * V);
     act_.q8k = reinterpret_cast<int8_t *>(buf_arena_.take(B * Kmax)); act_.q80 = reinterpret_cast<int8_t *>(buf_arena_.take(B * Kmax));
     act_.dk = takef(B * Kmax / 256 + 16); act_.bsk = reinterpret_cast<int16_t *>(buf_arena_.take(B * Kmax / 16 * 2 + 64));
+    act_.bsq = reinterpret_cast<int8_t *>(buf_arena_.take(B * Kmax / 16 + 64));
     act_.d0 = takef(B * Kmax / 32 + 16); act_.d1 = takef(B * Kmax / 32 + 16); act_.s1 = takef(B * Kmax / 32 + 16);
     act_.sum0 = reinterpret_cast<int *>(buf_arena_.take(B * Kmax / 32 * 4 + 64));
     act_.xh = takeh(B * Kmax); act_.xf = takef(B * Kmax);
@@ -430,6 +432,11 @@ void Engine::alloc_buffers() {
     batch_graph_.assign((size_t)MAX_CONVERSATIONS + 1, nullptr);
     d_tokens_ = reinterpret_cast<int *>(buf_arena_.take(B * 4));
     d_scratch_ = buf_arena_.take(8192);
+    {   // K-split partial sums of the prefill mat-mul (only prompts short enough to need the extra parallelism use them)
+        const size_t slab_floats = (size_t)16 << 20;
+        hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, device_));
+        set_mmq2_workspace(reinterpret_cast<float *>(buf_arena_.take(slab_floats * 4)), slab_floats, prop.multiProcessorCount);
+    }
     d_tq_cnt_ = reinterpret_cast<unsigned *>(reinterpret_cast<uint8_t *>(d_scratch_) + 4096);   // arrival counters of the tail-fused quantisation (MINIGPT4_TAILQ)
     HIP_CHECK(hipMemset(d_tq_cnt_, 0, 4096));
     HIP_CHECK(hipMemset(d_npast_, 0, 256)); HIP_CHECK(hipMemset(d_argmax_, 0, 256)); HIP_CHECK(hipMemset(d_feed_, 0, 256)); HIP_CHECK(hipMemset(d_btok_, 0, 768));
@@ -475,7 +482,8 @@ bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
         HIP_CHECK(hipEventRecord(ev.a, s));
     }
     bool done = false;
-    if (silu_pair) {   // the pair epilogue needs the two matrices equally spaced; launch_matvec_set refuses otherwise and the plain launch below runs
+    if (N >= 5 && same && mmq_enabled() >= 2) done = launch_mmq2_set(W, y, res, n, act_, N, ldy, s);   // prefill: one launch for the set, weights streamed once per <= 128 rows
+    if (!done && silu_pair) {   // the pair epilogue needs the two matrices equally spaced; launch_matvec_set refuses otherwise and the plain launch below runs
         done = fuse ? launch_matvec_set(W, y, res, n, act_, s, prep->kind, prep->x, prep->w, &tabs_, 1) : launch_matvec_set(W, y, res, n, act_, s, 0, nullptr, nullptr, &tabs_, 1);
         silu_pair = done;
     }
@@ -583,7 +591,7 @@ void Engine::forward_batch(int B, hipStream_t s) {
             for (int t0 = 0; t0 < B && ok; t0 += 4) {
                 const int K = W[0]->cols;
                 ActQ A = act_;
-                A.q8k += (size_t)t0 * K; A.dk += (size_t)t0 * (K / 256); A.bsk += (size_t)t0 * (K / 16); A.q80 += (size_t)t0 * K;
+                A.q8k += (size_t)t0 * K; A.dk += (size_t)t0 * (K / 256); A.bsk += (size_t)t0 * (K / 16); A.bsq += (size_t)t0 * (K / 16); A.q80 += (size_t)t0 * K;
                 A.d0 += (size_t)t0 * (K / 32); A.d1 += (size_t)t0 * (K / 32); A.s1 += (size_t)t0 * (K / 32); A.sum0 += (size_t)t0 * (K / 32);
                 float *yo[3]; const float *ro[3];
                 for (int k = 0; k < n; k++) { yo[k] = y[k] + (size_t)t0 * ld; ro[k] = r[k] ? r[k] + (size_t)t0 * ld : nullptr; }

@@ -67,12 +67,13 @@ void Engine::alloc_vision_generic() {
     size_t total = 1 << 20;
     auto sz = [&](size_t b) { total += (b + 255) / 256 * 256 + 256; };
     sz(R * D * 4); sz(R * D * 4); sz(R * M * 4); sz(R * D * 4); sz(R * Nmax * 4); sz(RQ * 768 * 4); sz(RQ * (size_t)v_qi_ * 4);
-    sz(2 * R * Kmax); sz(R * (Kmax / 256 + 1) * 4); sz(R * (Kmax / 16 + 1) * 2); sz(4 * R * (Kmax / 32 + 1) * 4); sz(R * Kmax * 2); sz(R * Kmax * 4);
+    sz(2 * R * Kmax); sz(R * (Kmax / 256 + 1) * 4); sz(R * (Kmax / 16 + 1) * 2); sz(R * (Kmax / 16 + 16)); sz(4 * R * (Kmax / 32 + 1) * 4); sz(R * Kmax * 2); sz(R * Kmax * 4);
     vgen_arena_.alloc(total);
     auto takef = [&](size_t n) { return reinterpret_cast<float *>(vgen_arena_.take(n * 4)); };
     vg_ln_ = takef(R * D); vg_att_ = takef(R * D); vg_mlp_ = takef(R * M); vg_img_ = takef(R * D); vg_tmp_ = takef(R * Nmax); vg_ctx_ = takef(RQ * 768); vg_im_ = takef(RQ * (size_t)v_qi_);
     vact_.q8k = reinterpret_cast<int8_t *>(vgen_arena_.take(R * Kmax)); vact_.q80 = reinterpret_cast<int8_t *>(vgen_arena_.take(R * Kmax));
     vact_.dk = takef(R * (Kmax / 256 + 1)); vact_.bsk = reinterpret_cast<int16_t *>(vgen_arena_.take(R * (Kmax / 16 + 1) * 2));
+    vact_.bsq = reinterpret_cast<int8_t *>(vgen_arena_.take(R * (Kmax / 16 + 16)));
     vact_.d0 = takef(R * (Kmax / 32 + 1)); vact_.d1 = takef(R * (Kmax / 32 + 1)); vact_.s1 = takef(R * (Kmax / 32 + 1));
     vact_.sum0 = reinterpret_cast<int *>(vgen_arena_.take(R * (Kmax / 32 + 1) * 4));
     vact_.xh = reinterpret_cast<__half *>(vgen_arena_.take(R * Kmax * 2)); vact_.xf = takef(R * Kmax);

@@ -1076,13 +1076,18 @@ bool launch_matvec_rows(const QWeight *const *W, float *const *y, const float *c
     }
 }
 
-static int g_mmq_enabled = 1;
+static int g_mmq_enabled = 2;   // 0: v_dot4 tiles only, 1: round-1 int8-MFMA kernels (mmq_kernels.hip), 2: + the LDS-staged kernels of mmq2_kernels.hip
 void set_mmq_enabled(int v) { g_mmq_enabled = v; }
+int mmq_enabled() { return g_mmq_enabled; }
 // Unquantised (F16) weights, prefill: ggml converts the activation rows to fp16 and accumulates exact fp16 products in fp32 (ggml_vec_dot_f16) -- which is
 // precisely the vision tower's MFMA GEMM (v_mfma_f32_32x32x16_f16, fp32 accumulators), so rows >= 16 go there: BASELINE.json configs[4]
 // (13B f16, 512-token prefill) is MFMA-bound instead of re-streaming 25 GB of weights once per 4 tokens.  MINIGPT4_F16_GEMM=0 keeps the v_dot path.
 static int g_f16_gemm = -1;
 void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
+    if (g_mmq_enabled >= 2 && N >= 5 && A.bsq && mmq2_supported(W.type, W.rows, W.cols)) {
+        const QWeight *Wp[1] = {&W}; float *Yp[1] = {y}; const float *Rp[1] = {residual};
+        if (launch_mmq2_set(Wp, Yp, residual ? Rp : nullptr, 1, A, N, ldy, s)) return;
+    }
     if (g_mmq_enabled && N >= 5 && mmq_supported(W.type)) { launch_mmq(W, A, N, y, ldy, residual, s); return; }
     if (W.type == GT_F16 && N >= 16 && W.cols % 8 == 0) {
         if (g_f16_gemm < 0) { const char *e = getenv("MINIGPT4_F16_GEMM"); g_f16_gemm = e ? atoi(e) != 0 : 1; }
@@ -1136,6 +1141,10 @@ __device__ __forceinline__ void quant_emit4(const float v[4], const bool in_rang
             *reinterpret_cast<unsigned *>(A.q8k + row * K + idx) = pk;
             if ((lane & 3) == 0) A.bsk[row * (K / 16) + idx / 16] = (int16_t)s;
             if (lane == 0) A.dk[row * (K / 256) + idx / 256] = d;
+        }
+        if (A.bsq) {   // prefill (csrc/mmq2_kernels.hip): the per-32 sums as two int8 digits, so that sum_j m_j * bsum_j runs on the int8 matrix cores
+            const int s32 = s + dpp_i<0x141>(s);                              // row_half_mirror: the other 16-group of this 32-block
+            if (in_range && (lane & 7) == 0) { int8_t *o = A.bsq + (row * (K / 256) + idx / 256) * 16 + ((idx & 255) >> 5); o[0] = (int8_t)(s32 & 127); o[8] = (int8_t)(s32 >> 7); }
         }
     }
     if (mask & ACT_Q80) {

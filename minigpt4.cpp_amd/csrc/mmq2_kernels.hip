@@ -1,0 +1,403 @@
+// Prefill mat-mul on the int8 matrix cores, second generation (round 2): y[t][r] = W[r] . act[t] for N >= 5 activation rows against k-quant weights,
+// with ggml's arithmetic (reference minigpt4.cpp:2373 / 2412 -> llama_eval -> ggml_mul_mat: activations in Q8_K, exact int32 sub-block dots, integer
+// sub-block scales, fp32 super-block scales accumulated super-block by super-block).
+//
+// Structure (what round 1's k_mmq_* lacked -- weights re-read once per 64 tokens, one wave per SIMD, activation fragments fetched from L2 with the full latency
+// exposed at the top of every super-block):
+//   * workgroup = 4 waves = 4 row tiles of 32 weight rows (128 rows) x one chunk of up to 4 token tiles of 32 tokens x one K range (grid.z);
+//     the weights of a row tile are loaded ONCE per chunk, unpacked ONCE per super-block into MFMA B operands and reused for every token tile;
+//   * the chunk's activation super-block (int8 values, fp32 scale, the per-32 sums as two int8 digits) is staged through LDS with global_load_lds
+//     (LDS-DMA, 16 bytes per lane, no VGPR staging), double buffered, shared by the 4 waves; the 16-byte chunks of a token's 256-byte row are XOR-swizzled
+//     on the SOURCE side (the DMA destination is lane-linear) so that the A-fragment ds_read_b128 of 32 consecutive tokens is bank-conflict free;
+//   * one barrier per super-block: [wait own DMA + weight loads] barrier [unpack weights] [request next weights + next stage] [MFMAs on the current stage];
+//   * v_mfma_i32_32x32x32_i8: activations are the A side (lane = token), weights the B side (lane = weight row), so a lane's 16 accumulators belong to ONE
+//     weight row and its sub-block scales are per-lane scalars;  the Q4_K / Q5_K min term sum_j m_j * bsum_j runs as two MFMAs on the digit split
+//     bsum = 128 hi + lo (exact) instead of round 1's eight MFMAs against a broadcast byte;
+//   * <= 256 VGPRs: two workgroups (8 waves) per CU, so one wave's scale arithmetic (VALU) overlaps another's MFMAs.
+// Per (row tile, super-block, token tile): 8 + 2 MFMAs (Q4_K / Q5_K) or 16 (Q6_K) and ~16 VALU operations per accumulator -- the kernel is VALU-bound by
+// the integer sub-block scale multiply-adds ggml's format requires (one per output element per 32 weights), not by the matrix cores.
+#include "kernels.hpp"
+#include "devutil.hpp"
+
+namespace mg4 {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ float h2f_b(unsigned short h) { return __half2float(__ushort_as_half(h)); }
+__device__ __forceinline__ v4i ldg16(const void *p) { return *reinterpret_cast<const v4i *>(p); }
+__device__ __forceinline__ v16i zero16() { v16i z; for (int i = 0; i < 16; i++) z[i] = 0; return z; }
+__device__ __forceinline__ int tok_of(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }   // MFMA 32x32 C layout: row (= token) of accumulator register `reg`
+__device__ __forceinline__ int sext6(int x) { const int yv = x ^ 0x20202020; const int s = yv & 0x20202020; return yv | (s << 1) | (s << 2); }   // 4 x (6-bit q - 32) as int8
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+__device__ __forceinline__ void dma16(const void *src, unsigned char *lds_wave_base) {   // LDS[lds_wave_base + lane * 16 .. +16) <- src (per lane)
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const void *src, unsigned char *lds_wave_base) {    // LDS[lds_wave_base + lane * 4 .. +4) <- src
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 4, 0, 0);
+}
+}  // namespace
+
+// LDS image of one activation stage (TT token tiles of one super-block):
+//   q8 [TT * 32 tokens][16 chunks of 16 B], chunk c of token t stored at slot c ^ (t & 15)
+//   bs [TTP * 32][16 B]  digit-split per-32 sums (TTP = TT rounded up to 2: one DMA instruction covers 64 tokens)
+//   dk [TTP * 32] fp32   activation super-block scale
+template <int TT> struct Mmq2Stage {
+    static constexpr int TTP = (TT + 1) & ~1;
+    static constexpr int Q8 = TT * 32 * 256, BS = TTP * 32 * 16, DK = TTP * 32 * 4;
+    static constexpr int BYTES = Q8 + BS + DK;
+};
+
+struct Mmq2Args {
+    QWeight w[3];                 // 1..3 matrices of one type and one shape; row group g belongs to matrix g / groups_each
+    float *y[3];                  // outputs, [N][ldy] each (K split: slab z at y + z * slab_stride)
+    const float *res[3];          // optional residual inputs (only without a K split)
+    int n_mat, groups_each;       // row groups (of 128 rows) per matrix
+    int N, ldy;
+    int n_tiles, tiles_per_chunk; // token tiles of 32 in total / per grid.y chunk
+    int sb_per_split;             // super-blocks per grid.z slice
+    long long slab_stride;        // floats between K-split slabs
+};
+
+// Requests stage `sb` of this chunk into LDS buffer `st` (all 4 waves take part; every request is unconditional, indices clamped).
+template <int TT>
+__device__ __forceinline__ void mmq2_stage_load(const ActQ &A, int K, int NSB, int N, int t0, int sb, unsigned char *st, int wv, int lane) {
+    using S = Mmq2Stage<TT>;
+    // q8: TT * 8 wave-instructions of 4 tokens x 16 chunks; wave wv issues instructions wv * 2 TT .. + 2 TT - 1
+#pragma unroll
+    for (int k = 0; k < 2 * TT; k++) {
+        const int ii = wv * 2 * TT + k;
+        const int tl = 4 * ii + (lane >> 4);                 // token within the chunk
+        const int c = (lane & 15) ^ (tl & 15);               // logical chunk that lands in slot (lane & 15)
+        const int tok = min(t0 + tl, N - 1);
+        dma16(A.q8k + (size_t)tok * K + (size_t)sb * 256 + c * 16, st + ii * 1024);
+    }
+    if (wv == 0) {
+#pragma unroll
+        for (int j = 0; j < S::TTP / 2; j++) { const int tok = min(t0 + 64 * j + lane, N - 1); dma16(A.bsq + ((size_t)tok * NSB + sb) * 16, st + S::Q8 + j * 1024); }
+    } else if (wv == 1) {
+#pragma unroll
+        for (int j = 0; j < S::TTP / 2; j++) { const int tok = min(t0 + 64 * j + lane, N - 1); dma4(A.dk + (size_t)tok * NSB + sb, st + S::Q8 + S::BS + j * 256); }
+    }
+}
+
+// Result store: lane = weight row, accumulator register = token -> 32 consecutive floats per (register, lane half).  The residual values of a token tile are
+// requested together (clamped addresses, no branch around a load) before any of them is used.
+template <int TT>
+__device__ __forceinline__ void mmq2_store(const float (&acc)[TT][16], const Mmq2Args &a, int m, int orow, int rows, int t0, int my_tiles, int hh) {
+    float *y = a.y[m] + (size_t)blockIdx.z * a.slab_stride;
+    const bool has_res = gridDim.z == 1 && a.res[m] != nullptr;
+    const float *rb = has_res ? a.res[m] : y;
+    const int rowc = min(orow, rows - 1);
+#pragma unroll
+    for (int tt = 0; tt < TT; tt++) {
+        if (tt < my_tiles) {
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) rv[r] = rb[(size_t)min(t0 + tt * 32 + tok_of(r, hh), a.N - 1) * a.ldy + rowc];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int tok = t0 + tt * 32 + tok_of(r, hh);
+                if (tok < a.N && orow < rows) y[(size_t)tok * a.ldy + orow] = has_res ? acc[tt][r] + rv[r] : acc[tt][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Q4_K / Q5_K.  Unit u of a super-block (16 bytes of the repacked main plane): low nibbles = elements 64 (u >> 1) + 16 (u & 1) + i of sub-block 2 (u >> 1),
+// high nibbles = the same elements of sub-block 2 (u >> 1) + 1.  Pair jp: lanes hh = 0 / 1 hold units 2 jp / 2 jp + 1 -> one K = 32 MFMA per sub-block.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool Q5, int TT>
+__global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const ActQ A) {
+    using S = Mmq2Stage<TT>;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_mmq2[];
+    const int lane = threadIdx.x & 63, hh = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = blockIdx.x / a.groups_each, g = blockIdx.x - m * a.groups_each;
+    const QWeight W = a.w[m];
+    const int K = W.cols, U = K / 32, NSB = K / 256, N = a.N;
+    const int r0 = (g * 4 + wv) * 32;
+    const int row = min(r0 + l31, W.rows - 1);
+    const int tile0 = blockIdx.y * a.tiles_per_chunk, my_tiles = min(TT, a.n_tiles - tile0), t0 = tile0 * 32;
+    const int sb0 = blockIdx.z * a.sb_per_split, sb1 = min(NSB, sb0 + a.sb_per_split);
+
+    float acc[TT][16];
+#pragma unroll
+    for (int tt = 0; tt < TT; tt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[tt][r] = 0.0f;
+
+    struct Raw { v4i q[4]; unsigned P[4]; v4i h; };
+    const unsigned char *wq = W.qs + ((size_t)row * U + hh) * 16, *wp = W.qh + ((size_t)row * U + hh) * 4, *wh = W.sc + (size_t)row * NSB * 16;
+    auto fetch = [&](int sb, Raw &w) {
+#pragma unroll
+        for (int jp = 0; jp < 4; jp++) { w.q[jp] = ldg16(wq + ((size_t)sb * 8 + 2 * jp) * 16); w.P[jp] = Q5 ? *reinterpret_cast<const unsigned *>(wp + ((size_t)sb * 8 + 2 * jp) * 4) : 0u; }
+        w.h = ldg16(wh + (size_t)sb * 16);
+    };
+    // per-lane LDS read addresses (stage 0): A fragment of chunk C = 4 jp + 2 x (x = 0: low-nibble sub-block, 1: high) for token l31 of tile 0
+    const int v = hh ^ (lane & 15);
+    unsigned a_addr[8];
+#pragma unroll
+    for (int c8 = 0; c8 < 8; c8++) a_addr[c8] = (unsigned)(l31 * 256 + (((2 * c8) ^ v) << 4));
+    const unsigned bs_addr = (unsigned)(S::Q8 + l31 * 16), dk_addr = (unsigned)(S::Q8 + S::BS + 16 * hh);
+
+    Raw raw;
+    fetch(sb0, raw);
+    mmq2_stage_load<TT>(A, K, NSB, N, t0, sb0, smem_mmq2, wv, lane);
+    for (int sb = sb0; sb < sb1; sb++) {
+        const int buf = (sb - sb0) & 1;
+        unsigned char *st = smem_mmq2 + buf * S::BYTES;
+        __syncthreads();                                           // own DMA + weight loads done (vmcnt(0) is part of the barrier's fence), then everybody's
+        // ---- unpack this super-block's weights into MFMA B operands (once; reused by every token tile)
+        v4i wlo[4], whi[4];
+#pragma unroll
+        for (int jp = 0; jp < 4; jp++) {
+            const v4i q = raw.q[jp]; const unsigned P = raw.P[jp];
+            wlo[jp][0] = (q[0] & 0x0F0F0F0F) | (int)((P << 4) & 0x10101010u); wlo[jp][1] = (q[1] & 0x0F0F0F0F) | (int)((P << 3) & 0x10101010u);
+            wlo[jp][2] = (q[2] & 0x0F0F0F0F) | (int)((P << 2) & 0x10101010u); wlo[jp][3] = (q[3] & 0x0F0F0F0F) | (int)((P << 1) & 0x10101010u);
+            whi[jp][0] = ((q[0] >> 4) & 0x0F0F0F0F) | (int)(P & 0x10101010u); whi[jp][1] = ((q[1] >> 4) & 0x0F0F0F0F) | (int)((P >> 1) & 0x10101010u);
+            whi[jp][2] = ((q[2] >> 4) & 0x0F0F0F0F) | (int)((P >> 2) & 0x10101010u); whi[jp][3] = ((q[3] >> 4) & 0x0F0F0F0F) | (int)((P >> 3) & 0x10101010u);
+        }
+        const unsigned s0 = (unsigned)raw.h[1], s1 = (unsigned)raw.h[2], s2 = (unsigned)raw.h[3];
+        const unsigned scw0 = s0 & 0x3f3f3f3fu, scw1 = (s2 & 0x0f0f0f0fu) | (((s0 >> 6) & 0x03030303u) << 4);          // scales of sub-blocks 0..3 / 4..7, one byte each
+        const unsigned mw0 = s1 & 0x3f3f3f3fu, mw1 = ((s2 >> 4) & 0x0f0f0f0fu) | (((s1 >> 6) & 0x03030303u) << 4);     // mins
+        const float dw = h2f_b((unsigned)raw.h[0] & 0xFFFF), ndmin = -h2f_b((unsigned)raw.h[0] >> 16);
+        // min term operands: A bytes = {lo_0..7, hi_0..7} of the token (lanes hh = 0), B = {m_0..7, 0} resp. {0, m_0..7}; lanes hh = 1 contribute nothing
+        const v4i bm_lo = {hh ? 0 : (int)mw0, hh ? 0 : (int)mw1, 0, 0}, bm_hi = {0, 0, hh ? 0 : (int)mw0, hh ? 0 : (int)mw1};
+        __builtin_amdgcn_sched_barrier(0);                         // the raw registers are dead from here: the next super-block's loads reuse them (no second register stage)
+        // ---- request the next super-block (weights into the now free raw registers, activations into the other LDS buffer: every wave has passed the barrier,
+        // so nobody still reads it)
+        {
+            const int sbn = min(sb + 1, sb1 - 1);
+            fetch(sbn, raw);
+            mmq2_stage_load<TT>(A, K, NSB, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- token tiles
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++) {
+            if (tt < my_tiles) {
+                const unsigned char *sq = st + tt * 8192;
+                v16i isum = zero16();
+#pragma unroll
+                for (int jp = 0; jp < 4; jp++) {
+                    const v4i alo = *reinterpret_cast<const v4i *>(sq + a_addr[2 * jp]), ahi = *reinterpret_cast<const v4i *>(sq + a_addr[2 * jp + 1]);
+                    const int sc0 = (int)(((jp & 2) ? scw1 : scw0) >> (16 * (jp & 1))) & 0xFF, sc1 = (int)(((jp & 2) ? scw1 : scw0) >> (16 * (jp & 1) + 8)) & 0xFF;
+                    const v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, wlo[jp], zero16(), 0, 0, 0);
+                    const v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, whi[jp], zero16(), 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) isum[r] = __mul24(d1[r], sc1) + (__mul24(d0[r], sc0) + isum[r]);
+                    // keep the sub-block pairs in program order: integer adds reassociate, and without the pin LLVM sinks all 128 multiply-adds of a token tile behind
+                    // its 8 MFMAs (128 live result registers -> scratch)
+                    asm volatile("" : "+v"(isum));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const v4i abs_ = *reinterpret_cast<const v4i *>(st + bs_addr + tt * 512);
+                const v16i mlo = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, bm_lo, zero16(), 0, 0, 0);
+                const v16i mhi = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, bm_hi, zero16(), 0, 0, 0);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    const v4f da = *reinterpret_cast<const v4f *>(st + dk_addr + tt * 128 + q4 * 32);   // tokens 8 q4 + 4 hh + 0..3 = accumulator registers 4 q4 .. 4 q4 + 3
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int r = 4 * q4 + e;
+                        acc[tt][r] = fmaf(dw * da[e], (float)isum[r], acc[tt][r]);
+                        acc[tt][r] = fmaf(ndmin * da[e], (float)(mhi[r] * 128 + mlo[r]), acc[tt][r]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // ---- store: lane = weight row, register = token -> 32 consecutive floats per (register, lane half)
+    mmq2_store<TT>(acc, a, m, r0 + l31, W.rows, t0, my_tiles, hh);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Q6_K.  Unit u = 4 n + 2 c + h: low nibbles (+ 2 high bits) = elements 128 n + 32 c + 16 h + i, high nibbles = the same + 64; int8 scale per 16 elements.
+// Pair p = 2 n + c: lanes hh = 0 / 1 hold units (.., h = 0) / (.., h = 1); the two 16-wide halves of an MFMA's K = 32 carry different scales, so each
+// operand is multiplied twice with the other lane half zeroed.  Weights are q - 32 in int8; no min term.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TT>
+__global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const ActQ A) {
+    using S = Mmq2Stage<TT>;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_mmq2[];
+    const int lane = threadIdx.x & 63, hh = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = blockIdx.x / a.groups_each, g = blockIdx.x - m * a.groups_each;
+    const QWeight W = a.w[m];
+    const int K = W.cols, U = K / 32, NSB = K / 256, N = a.N;
+    const int r0 = (g * 4 + wv) * 32;
+    const int row = min(r0 + l31, W.rows - 1);
+    const int tile0 = blockIdx.y * a.tiles_per_chunk, my_tiles = min(TT, a.n_tiles - tile0), t0 = tile0 * 32;
+    const int sb0 = blockIdx.z * a.sb_per_split, sb1 = min(NSB, sb0 + a.sb_per_split);
+
+    float acc[TT][16];
+#pragma unroll
+    for (int tt = 0; tt < TT; tt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[tt][r] = 0.0f;
+
+    struct Raw { v4i q[4]; uint2 P[4]; unsigned sc[4]; unsigned short d; };     // sc[p] = {unit h = 0: lo, hi scale | unit h = 1: lo, hi scale} (4 int8)
+    const unsigned char *wq = W.qs + ((size_t)row * U + hh) * 16, *wp = W.qh + ((size_t)row * U + hh) * 8, *ws = W.sc + (size_t)row * U * 2, *wd = W.d + (size_t)row * NSB * 2;
+    auto fetch = [&](int sb, Raw &w) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            w.q[p] = ldg16(wq + ((size_t)sb * 8 + 2 * p) * 16);
+            w.P[p] = *reinterpret_cast<const uint2 *>(wp + ((size_t)sb * 8 + 2 * p) * 8);
+            w.sc[p] = *reinterpret_cast<const unsigned *>(ws + ((size_t)sb * 8 + 2 * p) * 2);
+        }
+        w.d = *reinterpret_cast<const unsigned short *>(wd + (size_t)sb * 2);
+    };
+    // A fragments: low part of pair p = 2 n + c at element 128 n + 32 c + 16 hh -> chunk 8 n + 2 c + hh, high part 4 chunks further
+    const int v = hh ^ (lane & 15);
+    unsigned a_addr[8];                                        // [2 p + x]: chunk base (8 n + 2 c + 4 x), bit 0 (hh) folded into v
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int x = 0; x < 2; x++) a_addr[2 * p + x] = (unsigned)(l31 * 256 + (((8 * (p >> 1) + 2 * (p & 1) + 4 * x) ^ v) << 4));
+    const unsigned dk_addr = (unsigned)(S::Q8 + S::BS + 16 * hh);
+
+    Raw raw;
+    fetch(sb0, raw);
+    mmq2_stage_load<TT>(A, K, NSB, N, t0, sb0, smem_mmq2, wv, lane);
+    const v4i z4 = {0, 0, 0, 0};
+    for (int sb = sb0; sb < sb1; sb++) {
+        const int buf = (sb - sb0) & 1;
+        unsigned char *st = smem_mmq2 + buf * S::BYTES;
+        __syncthreads();
+        v4i wlo0[4], wlo1[4], whi0[4], whi1[4];
+        int s_lo0[4], s_lo1[4], s_hi0[4], s_hi1[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const v4i q = raw.q[p]; const unsigned L = raw.P[p].x, H = raw.P[p].y;
+            v4i wlo, whi;
+            wlo[0] = sext6((q[0] & 0x0F0F0F0F) | (int)((L << 4) & 0x30303030u)); wlo[1] = sext6((q[1] & 0x0F0F0F0F) | (int)((L << 2) & 0x30303030u));
+            wlo[2] = sext6((q[2] & 0x0F0F0F0F) | (int)(L & 0x30303030u)); wlo[3] = sext6((q[3] & 0x0F0F0F0F) | (int)((L >> 2) & 0x30303030u));
+            whi[0] = sext6(((q[0] >> 4) & 0x0F0F0F0F) | (int)((H << 4) & 0x30303030u)); whi[1] = sext6(((q[1] >> 4) & 0x0F0F0F0F) | (int)((H << 2) & 0x30303030u));
+            whi[2] = sext6(((q[2] >> 4) & 0x0F0F0F0F) | (int)(H & 0x30303030u)); whi[3] = sext6(((q[3] >> 4) & 0x0F0F0F0F) | (int)((H >> 2) & 0x30303030u));
+            wlo0[p] = hh ? z4 : wlo; wlo1[p] = hh ? wlo : z4; whi0[p] = hh ? z4 : whi; whi1[p] = hh ? whi : z4;
+            const unsigned sc = raw.sc[p];
+            s_lo0[p] = (int)(signed char)(sc & 0xFF); s_hi0[p] = (int)(signed char)((sc >> 8) & 0xFF); s_lo1[p] = (int)(signed char)((sc >> 16) & 0xFF); s_hi1[p] = (int)(signed char)(sc >> 24);
+        }
+        const float dw = h2f_b(raw.d);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int sbn = min(sb + 1, sb1 - 1);
+            fetch(sbn, raw);
+            mmq2_stage_load<TT>(A, K, NSB, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++) {
+            if (tt < my_tiles) {
+                const unsigned char *sq = st + tt * 8192;
+                v16i isum = zero16();
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const v4i alo = *reinterpret_cast<const v4i *>(sq + a_addr[2 * p]), ahi = *reinterpret_cast<const v4i *>(sq + a_addr[2 * p + 1]);
+                    const v16i a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, wlo0[p], zero16(), 0, 0, 0);
+                    const v16i a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, wlo1[p], zero16(), 0, 0, 0);
+                    const v16i b0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, whi0[p], zero16(), 0, 0, 0);
+                    const v16i b1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, whi1[p], zero16(), 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) isum[r] = __mul24(b1[r], s_hi1[p]) + (__mul24(b0[r], s_hi0[p]) + (__mul24(a1[r], s_lo1[p]) + (__mul24(a0[r], s_lo0[p]) + isum[r])));
+                    asm volatile("" : "+v"(isum));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    const v4f da = *reinterpret_cast<const v4f *>(st + dk_addr + tt * 128 + q4 * 32);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { const int r = 4 * q4 + e; acc[tt][r] = fmaf(dw * da[e], (float)isum[r], acc[tt][r]); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    mmq2_store<TT>(acc, a, m, r0 + l31, W.rows, t0, my_tiles, hh);
+}
+
+// y[t][r] = (residual[t][r] +) sum_z slab_z[t][r], z in fixed order (deterministic); rows x cols floats per slab
+__global__ __launch_bounds__(256) void k_mmq2_reduce(const float *__restrict__ slabs, int n_slabs, long long slab_stride, const float *__restrict__ residual, float *__restrict__ y, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = reinterpret_cast<const float4 *>(slabs)[i];
+    for (int z = 1; z < n_slabs; z++) { const float4 t = reinterpret_cast<const float4 *>(slabs + (size_t)z * slab_stride)[i]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    if (residual) { const float4 t = reinterpret_cast<const float4 *>(residual)[i]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    reinterpret_cast<float4 *>(y)[i] = s;
+}
+
+bool mmq2_supported(int type, int rows, int cols) { return (type == GT_Q4_K || type == GT_Q5_K || type == GT_Q6_K) && cols % 256 == 0 && rows >= 32; }
+
+static int g_mmq2_cus = 256;
+static float *g_mmq2_slabs = nullptr; static size_t g_mmq2_slab_floats = 0;
+void get_mmq2_workspace(float **slabs, size_t *n_floats) { *slabs = g_mmq2_slabs; *n_floats = g_mmq2_slab_floats; }
+void set_mmq2_workspace(float *slabs, size_t n_floats, int cus) { g_mmq2_slabs = slabs; g_mmq2_slab_floats = n_floats; if (cus > 0) g_mmq2_cus = cus; }
+
+template <int TT>
+static void mmq2_launch_tt(int type, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
+    static bool attr[3] = {false, false, false};
+    const int ti = type == GT_Q4_K ? 0 : type == GT_Q5_K ? 1 : 2;
+    if (!attr[ti]) {
+        if (ti == 0) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mmq2_q45k<false, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        else if (ti == 1) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mmq2_q45k<true, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        else if constexpr (TT <= 2) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mmq2_q6k<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr[ti] = true;
+    }
+    if (ti == 0) hipLaunchKernelGGL((k_mmq2_q45k<false, TT>), grid, dim3(256), lds, s, a, A);
+    else if (ti == 1) hipLaunchKernelGGL((k_mmq2_q45k<true, TT>), grid, dim3(256), lds, s, a, A);
+    else if constexpr (TT <= 2) hipLaunchKernelGGL((k_mmq2_q6k<TT>), grid, dim3(256), lds, s, a, A);
+    else throw HipError{hipErrorInvalidValue, "mmq2: Q6_K runs at most 2 token tiles per chunk", __FILE__, __LINE__};
+}
+
+// 1..3 same-type, same-shape matrices against the N prepared activation rows in one launch.  y[m][t * ldy + r] (+ residual[m][..]).  false -> shape outside the
+// kernel's range (nothing launched).
+bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s) {
+    if (n < 1 || n > 3 || !A.bsq || N < 1) return false;
+    for (int i = 0; i < n; i++) if (!mmq2_supported(W[i]->type, W[i]->rows, W[i]->cols) || W[i]->type != W[0]->type || W[i]->rows != W[0]->rows || W[i]->cols != W[0]->cols) return false;
+    Mmq2Args a{};
+    for (int i = 0; i < n; i++) { a.w[i] = *W[i]; a.y[i] = y[i]; a.res[i] = residual ? residual[i] : nullptr; }
+    a.n_mat = n; a.groups_each = (W[0]->rows + 127) / 128; a.N = N; a.ldy = ldy;
+    a.n_tiles = (N + 31) / 32;
+    const int max_tt = W[0]->type == GT_Q6_K ? 2 : 4;          // Q6_K keeps four half-masked operand sets per pair: 2 token tiles fill its 256 registers
+    const int n_chunks = (a.n_tiles + max_tt - 1) / max_tt;
+    a.tiles_per_chunk = (a.n_tiles + n_chunks - 1) / n_chunks;
+    const int NSB = W[0]->cols / 256;
+    // K split: enough workgroups for two per CU, at least 4 super-blocks per slice, slabs must fit the workspace; the slices are combined in fixed order by k_mmq2_reduce
+    const int wgs = n * a.groups_each * n_chunks;
+    int ks = 1;
+    const size_t out_floats = (size_t)N * ldy;
+    while (wgs * ks < 2 * g_mmq2_cus && NSB / (ks + 1) >= 4 && g_mmq2_slabs && (size_t)(ks + 1) * out_floats * n <= g_mmq2_slab_floats) ks++;
+    if (getenv("MINIGPT4_MMQ2_KS")) ks = std::max(1, std::min(atoi(getenv("MINIGPT4_MMQ2_KS")), std::min(NSB, g_mmq2_slabs ? (int)(g_mmq2_slab_floats / std::max<size_t>(1, out_floats * n)) : 1)));
+    a.sb_per_split = (NSB + ks - 1) / ks;
+    ks = (NSB + a.sb_per_split - 1) / a.sb_per_split;
+    if (ks > 1) {
+        if ((size_t)ldy % 4 || out_floats % 4) return false;
+        a.slab_stride = (long long)out_floats;
+        for (int i = 0; i < n; i++) { a.y[i] = g_mmq2_slabs + (size_t)i * ks * out_floats; a.res[i] = nullptr; }
+    }
+    const dim3 grid((unsigned)(n * a.groups_each), (unsigned)n_chunks, (unsigned)ks);
+    const int type = W[0]->type;
+    switch (a.tiles_per_chunk) {
+    case 1: mmq2_launch_tt<1>(type, grid, 2 * Mmq2Stage<1>::BYTES, s, a, A); break;
+    case 2: mmq2_launch_tt<2>(type, grid, 2 * Mmq2Stage<2>::BYTES, s, a, A); break;
+    case 3: mmq2_launch_tt<3>(type, grid, 2 * Mmq2Stage<3>::BYTES, s, a, A); break;
+    default: mmq2_launch_tt<4>(type, grid, 2 * Mmq2Stage<4>::BYTES, s, a, A); break;
+    }
+    if (ks > 1) {
+        for (int i = 0; i < n; i++) {
+            const size_t n4 = out_floats / 4;
+            hipLaunchKernelGGL(k_mmq2_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g_mmq2_slabs + (size_t)i * ks * out_floats, ks, (long long)out_floats, residual ? residual[i] : nullptr, y[i], n4);
+        }
+    }
+    return true;
+}
+
+}  // namespace mg4

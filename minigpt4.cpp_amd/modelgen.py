@@ -227,9 +227,13 @@ class _Pool:
 
 def write_llm_file(path: str, cfg: LLMConfig, seed: int = 1234, std: float = 0.02,
                    unique_layers: Optional[int] = None, vocab: Optional[List[Tuple[bytes, float]]] = None,
-                   fast: bool = False) -> None:
+                   fast: bool = False, resid_scale: float = 1.0) -> None:
     """Write a GGJT-v3 file with Gaussian weights.  `unique_layers` < n_layer re-uses the quantised bytes
-    of layer (i % unique_layers) for layer i (bench-size files: same byte volume, generation in seconds)."""
+    of layer (i % unique_layers) for layer i (bench-size files: same byte volume, generation in seconds).
+    `resid_scale` multiplies the two matrices that write into the residual stream (attention.wo, feed_forward.w2) -- the
+    GPT-2 / Megatron "scaled init" 1 / sqrt(2 n_layer): without it a deep random-weight stack amplifies a 1e-6 input
+    perturbation to percents of the logit range (the int8 activation roundings of the two runs decorrelate), which drowns
+    any GPU-vs-oracle comparison in the arithmetic's own noise."""
     rng = np.random.default_rng(seed)
     types, shapes = llm_tensor_types(cfg), llm_tensor_shapes(cfg)
     vocab = vocab if vocab is not None else synth_vocab(cfg.n_vocab)
@@ -254,6 +258,8 @@ def write_llm_file(path: str, cfg: LLMConfig, seed: int = 1234, std: float = 0.0
             x *= np.float32(std)
         else:
             x = (std * rng.standard_normal(n, dtype=np.float32)).astype(np.float32)
+        if resid_scale != 1.0 and (name.endswith("attention.wo.weight") or name.endswith("feed_forward.w2.weight")):
+            x = x * np.float32(resid_scale)
         raw = Q.quantize(t, x)
         if key is not None:
             cache[key] = raw

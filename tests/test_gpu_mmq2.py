@@ -1,0 +1,56 @@
+"""GPU parity of the second-generation prefill kernels (csrc/mmq2_kernels.hip) against the oracle's ggml mul_mat (Q8_K activations, exact integer sub-block dots):
+every token-tile count (1..4 tiles per chunk, several chunks), ragged row / token counts, 1..3 matrices per launch, residual add, forced K splits (fixed-order
+combination).  Integer dots are exact; only the order in which the per-super-block fp32 terms are added differs -> 2e-5 of the row maximum, like test_mul_mat_matches_oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # N, n_in, n_out, n_mat, ks, residual
+    (5, 768, 70, 1, 0, False),
+    (31, 256, 32, 1, 0, True),          # one super-block, one partial tile
+    (33, 1024, 130, 2, 0, True),        # 2 tiles, ragged rows across the 4 waves of a workgroup
+    (64, 512, 128, 3, 0, False),
+    (97, 2048, 256, 1, 0, False),       # 4 tiles (last one 1 token)
+    (142, 2048, 256, 3, 0, False),      # the image-turn prompt length: 5 tiles -> 2 chunks of 3 + 2
+    (142, 5120, 384, 1, 4, True),       # forced K split with residual (combined in fixed order)
+    (300, 1024, 200, 2, 2, False),      # 10 tiles -> 3 chunks, K split
+    (512, 2560, 128, 1, 0, True),       # n_batch rows
+    (129, 13824, 160, 1, 3, False),     # the w2 row length (54 super-blocks), ragged K split
+]
+
+
+@pytest.mark.parametrize("wtype", ["q4_k", "q5_k", "q6_k"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "N%d_K%d_R%d_m%d_ks%d_res%d" % c)
+def test_mmq2_matches_oracle(gpu_lib, wtype, case):
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    N, n_in, n_out, n_mat, ks, with_res = case
+    t = Q.NAME_TO_TYPE[wtype]
+    rng = np.random.default_rng(sum(map(ord, wtype)) * 977 + sum(case))
+    w = (0.05 * rng.standard_normal((n_mat * n_out, n_in))).astype(np.float32)
+    raw = Q.quantize(t, w)
+    x = rng.standard_normal((N, n_in)).astype(np.float32)
+    x[N // 2, : min(256, n_in)] = 0.0                                   # an all-zero Q8_K block (d = 0)
+    res = rng.standard_normal((n_mat, N, n_out)).astype(np.float32) if with_res else None
+    got = gpu_lib.amd_test_mmq2(t, raw, n_mat, n_in, n_out, x, residual=res, ks=ks)
+    want = R.mul_mat(t, raw, n_in, n_mat * n_out, x).reshape(N, n_mat, n_out).transpose(1, 0, 2)
+    scale = np.abs(want).max()
+    if with_res:
+        want = want + res
+    assert got.shape == want.shape and np.isfinite(got).all()
+    err = float(np.abs(got - want).max() / scale)
+    assert err < 2e-5, (wtype, case, err)
+
+
+def test_mmq2_is_deterministic_with_k_split(gpu_lib):
+    """The K-split partial sums are combined in a fixed order: two runs give identical bits."""
+    from minigpt4_cpp_amd import quants as Q
+    rng = np.random.default_rng(11)
+    t = Q.NAME_TO_TYPE["q5_k"]
+    raw = Q.quantize(t, (0.05 * rng.standard_normal((256, 5120))).astype(np.float32))
+    x = rng.standard_normal((142, 5120)).astype(np.float32)
+    a = gpu_lib.amd_test_mmq2(t, raw, 1, 5120, 256, x, ks=5)
+    b = gpu_lib.amd_test_mmq2(t, raw, 1, 5120, 256, x, ks=5)
+    assert np.array_equal(a, b)
