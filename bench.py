@@ -357,8 +357,10 @@ def main():
             gl = H.gpu_teacher_forced(lib, ctx, emb, orc["ids"])
             out["parity"] = H.compare(orc, gp, gl)
             out["parity"]["oracle_prefill_s"] = orc["prefill_s"]
+            out["parity"]["oracle_self_noise"] = H.oracle_self_noise(lp, emb_np, orc, eps=1e-6, n_ctx=320, threads=max(1, min(usable, 32)))
             out["parity"]["note"] = ("GPU vs CPU oracle on THIS run's files: system_prompt + begin_chat_image + greedy steps; `identical` counts free-running pieces, `decided` = steps whose "
-                                     "oracle top-2 margin exceeds 2x the largest observed logit difference; max_logit_rel_range = max |delta| / (max - min) of the oracle's logits")
+                                     "oracle top-2 margin exceeds 2x the largest observed logit difference; max_logit_rel_range = max |delta| / (max - min) of the oracle's logits; oracle_self_noise = the same "
+                                     "quantity for the oracle against ITSELF with the image embedding perturbed by 1e-6 relative (int8 activation re-rounding: the floor any other summation order hits)")
             del orc
         except Exception as e:
             out["parity"] = {"error": repr(e)}

@@ -113,6 +113,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     // (row-pair epilogue); bit 6: wq|wk and a differently typed wv in one launch.  See DESIGN.md "mat-vec prologue".
     fuse_mask_ = getenv("MINIGPT4_FUSE") ? atoi(getenv("MINIGPT4_FUSE")) : FUSE_DEFAULT;
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
+    attn_prefill_ = !(getenv("MINIGPT4_ATTN_PREFILL") && !atoi(getenv("MINIGPT4_ATTN_PREFILL")));   // 0: the per-token attention kernel also for prompt rows (A/B, tests)
     // Opt-in experiment (unmeasured at the time of writing): the w1|w3 launch also prepares w2's activation row (last-arriver per 256-row block),
     // one launch less per layer.
     tailq_ = getenv("MINIGPT4_TAILQ") ? atoi(getenv("MINIGPT4_TAILQ")) : 0;   // 1: tail-fused preparation; 2: only its contiguous row order (the standalone preparation still runs)
@@ -545,7 +546,11 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
             } else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s, &p_attn, fz(0)); mul_mat(L.wv, N, v_, E, nullptr, s, &p_attn, fz(0)); }
         }
         if (dec) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, true, s);
-        else { launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, false, s); }
+        else {
+            launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s);
+            if (!(attn_prefill_ && launch_attn_prefill(q_, kc, vc, N, H, hd, d_npast, conv_[sl].n_committed + N, tabs_, att_, s)))
+                launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, false, s);
+        }
         mul_mat(L.wo, N, x_, E, x_, s, &p_att, fz(1));
         bool paired = false;   // h1_ already holds silu(w1 x) * (w3 x)
         bool h_ready = false;  // act_ already holds the quantised silu(w1 x) * (w3 x) (tail-fused preparation)

@@ -132,7 +132,7 @@ private:
     int *d_btok_ = nullptr, *d_bslot_ = nullptr, *d_bpos_ = nullptr; float *blogits_ = nullptr;   // batched decode: row tokens / conversations / positions (one 768-byte slab), [rows][n_vocab] logits
     std::vector<hipGraphExec_t> batch_graph_;                             // [B]: the batched step for B rows (rows are described in device memory, so one graph serves any slot set)
     int *h_argmax_ = nullptr, *h_bstage_ = nullptr; float *h_logits_ = nullptr; int logits_host_slot_ = -1;
-    bool use_graph_ = true, use_v2_ = true;
+    bool use_graph_ = true, use_v2_ = true, attn_prefill_ = true;
     int batch_rows_max_ = 8;                                              // MINIGPT4_BATCH_ROWS_MAX: batches up to this size use the multi-row mat-vec (passes of 4 rows); 0 = never
     static constexpr int FUSE_DEFAULT = 87; int fuse_mask_ = FUSE_DEFAULT;
     // profiling

@@ -74,6 +74,9 @@ void launch_attn_llm_batched(float *q, const float *k, const float *v, __half *k
 // per row r, slot = row_slot[r]: argmax[slot] = feed[slot] = argmax(logits[r]); slot_logits[slot] = logits[r]; n_past[slot] += 1
 void launch_batch_finish(const float *logits, int n_vocab, int B, const int *row_slot, int *n_past, int *argmax, int *feed, float *slot_logits, hipStream_t s);
 void launch_batch_begin(int *n_past, const int *row_slot, const int *row_pos, int B, hipStream_t s);   // n_past[row_slot[r]] = row_pos[r]
+// prefill (N > 1 rows of one conversation, after launch_rope_kv): workgroup = (head, 16 queries), keys streamed through LDS in tiles, exact-f32 MFMA; t_max >= *n_past + N
+// sizes the LDS score rows; false -> does not fit (the caller uses launch_attn_llm)
+bool launch_attn_prefill(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s);
 bool attn_head_size_supported(int hd);
 int attn_max_ctx(int hd);   // largest n_ctx whose score / probability rows fit the attention kernel's LDS
 void launch_argmax(const float *logits, int n, int *out, void *scratch /*>= 512 bytes*/, hipStream_t s);

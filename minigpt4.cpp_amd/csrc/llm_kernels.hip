@@ -1455,6 +1455,139 @@ void launch_attn_llm_batched(float *q, const float *k, const float *v, __half *k
     default: throw HipError{hipErrorInvalidValue, "unsupported head size", __FILE__, __LINE__};
     }
 }
+// =====================================================================================================================
+// Prefill attention (N > 1 query rows of one conversation) on the exact-f32 matrix cores.  The per-token kernel above re-reads a head's whole K and V once per
+// query (142 x 40 workgroups per layer for the image-turn prompt: 82 us per layer); here a workgroup owns (head, 16 consecutive queries) and streams the keys the
+// LAST of its queries may see through LDS in tiles of 64 -- K once for the scores, V once for the output.
+//   scores : v_mfma_f32_16x16x4_f32 over the head dim; operands are the fp16 values (q rounded to fp16, cached k) widened to fp32, so every product is exact and
+//            the accumulator is the k-ordered fp32 fma chain of k_attn_llm's dot_row -- bit-identical scores; then * 1/sqrt(hd)
+//   softmax: per query over its own causal range: max, fp16-table exp, exact double sum, probabilities rounded to fp16 (as k_attn_llm)
+//   output : P V on the same MFMA, keys in index order (k_attn_llm adds key partitions in another order: fp32 rounding only)
+// =====================================================================================================================
+typedef float pf4_t __attribute__((ext_vector_type(4)));
+constexpr int AP_QT = 16, AP_KT = 64;
+template <int HD>
+__device__ __forceinline__ void ap_stage(float *kv, const __half *__restrict__ cache, int E, int h, int key0, int T, int tid) {
+    constexpr int C8 = HD / 8, LDV = HD + 1, PER = AP_KT * C8 / 256;     // 16-byte pieces per thread
+    int4 x[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) { const int e = tid + 256 * u, j = e / C8, c = e - j * C8; x[u] = ld16(cache + (size_t)min(key0 + j, T - 1) * E + (size_t)h * HD + 8 * c); }
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int e = tid + 256 * u, j = e / C8, c = e - j * C8;
+        const bool live = key0 + j < T;
+        const unsigned w[4] = {(unsigned)x[u].x, (unsigned)x[u].y, (unsigned)x[u].z, (unsigned)x[u].w};
+        float *d = kv + j * LDV + 8 * c;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { d[2 * i] = live ? h2f_bits(w[i] & 0xFFFF) : 0.0f; d[2 * i + 1] = live ? h2f_bits(w[i] >> 16) : 0.0f; }
+    }
+}
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_prefill(const float *__restrict__ q, const __half *__restrict__ kc, const __half *__restrict__ vc, int E, int N, const int *__restrict__ n_past,
+                                                      const Tables tb, float *__restrict__ out, int LS) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ap[];
+    constexpr int LDV = HD + 1, KS = HD / 4, DT = HD / 16;
+    static_assert(DT % 4 == 0 || DT == 2, "dim tiles are dealt to the 4 waves");
+    float *S = reinterpret_cast<float *>(smem_ap);                // [16][LS]
+    float *kv = S + (size_t)AP_QT * LS;                           // [64][LDV]
+    const int h = blockIdx.x, q0 = blockIdx.y * AP_QT, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int np = *n_past;
+    const int T = np + min(q0 + AP_QT - 1, N - 1) + 1;            // keys the last query of this tile sees
+    const int nkt = (T + AP_KT - 1) / AP_KT;
+    const float scale = 1.0f / sqrtf((float)HD);
+    // Q fragments: A[i = lane & 15 (query)][kk = lane >> 4] per k-step, rounded to fp16 like ggml's f16 x f32 mul_mat
+    float qf[KS];
+    {
+        const float *qp = q + (size_t)min(q0 + (lane & 15), N - 1) * E + (size_t)h * HD + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) qf[ks] = f16r(qp[4 * ks]);
+    }
+    for (int kt = 0; kt < nkt; kt++) {
+        __syncthreads();
+        ap_stage<HD>(kv, kc, E, h, kt * AP_KT, T, tid);
+        __syncthreads();
+        const int key0 = kt * AP_KT + 16 * wave;
+        if (key0 < T) {
+            pf4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float *kb = kv + (size_t)(16 * wave + (lane & 15)) * LDV + (lane >> 4);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[ks], kb[4 * ks], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) S[(size_t)((lane >> 4) * 4 + r) * LS + key0 + (lane & 15)] = acc[r] * scale;
+        }
+    }
+    __syncthreads();
+    {   // softmax: 16 lanes per query row; row r sees keys 0 .. np + q0 + r
+        const int row = tid >> 4, sub = tid & 15;
+        const int Tq = min(np + q0 + row + 1, T);
+        float *sr = S + (size_t)row * LS;
+        float mx = -INFINITY;
+        for (int j = sub; j < Tq; j += 16) mx = fmaxf(mx, sr[j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 8));
+        double sum = 0.0;
+        for (int j0 = sub; j0 < Tq; j0 += 64) {                  // table gathers in batches of 4
+            float e[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = tab(tb.exp, sr[min(j0 + 16 * u, Tq - 1)] - mx);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int j = j0 + 16 * u; if (j < Tq) { sr[j] = e[u]; sum += (double)e[u]; } }
+        }
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+        const float inv = (float)(1.0 / sum);
+        for (int j = sub; j < nkt * AP_KT; j += 16) sr[j] = j < Tq ? f16r(sr[j] * inv) : 0.0f;
+    }
+    // O = P V: wave w owns dim tiles w, w + 4, ..; accumulators persist across the key tiles
+    constexpr int DPW = (DT + 3) / 4;
+    pf4_t oacc[DPW];
+#pragma unroll
+    for (int i = 0; i < DPW; i++) oacc[i] = pf4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int kt = 0; kt < nkt; kt++) {
+        __syncthreads();
+        ap_stage<HD>(kv, vc, E, h, kt * AP_KT, T, tid);
+        __syncthreads();
+        const float *pa = S + (size_t)(lane & 15) * LS + kt * AP_KT + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < DPW; i++) {
+            const int dt = wave + 4 * i;
+            if (dt < DT) {
+                const float *vb = kv + (size_t)(lane >> 4) * LDV + dt * 16 + (lane & 15);
+#pragma unroll
+                for (int ks = 0; ks < AP_KT / 4; ks++) oacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * ks], vb[(size_t)4 * ks * LDV], oacc[i], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DPW; i++) {
+        const int dt = wave + 4 * i;
+        if (dt < DT) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int qrow = q0 + (lane >> 4) * 4 + r;
+                if (qrow < N) out[(size_t)qrow * E + (size_t)h * HD + dt * 16 + (lane & 15)] = oacc[i][r];
+            }
+        }
+    }
+}
+template <int HD>
+static bool launch_attn_prefill_hd(const float *q, const __half *kc, const __half *vc, int N, int n_head, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
+    const int LS = ((t_max + AP_KT - 1) / AP_KT) * AP_KT + 1;
+    const size_t lds = ((size_t)AP_QT * LS + (size_t)AP_KT * (HD + 1)) * 4;
+    if (lds > 160 * 1024 - 512) return false;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((k_attn_prefill<HD>), dim3((unsigned)n_head, (unsigned)((N + AP_QT - 1) / AP_QT)), dim3(256), lds, s, q, kc, vc, n_head * HD, N, n_past, tb, out, LS);
+    return true;
+}
+// N > 1 query rows at positions *n_past .. *n_past + N - 1 (launch_rope_kv has run); t_max >= *n_past + N (the host's view, sizes the LDS score rows).
+// false -> the score rows do not fit LDS (very long contexts): the caller runs launch_attn_llm instead.
+bool launch_attn_prefill(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
+    switch (hd) {
+    case 32: return launch_attn_prefill_hd<32>(q, kcache, vcache, N, n_head, n_past, t_max, tb, out, s);
+    case 64: return launch_attn_prefill_hd<64>(q, kcache, vcache, N, n_head, n_past, t_max, tb, out, s);
+    case 128: return launch_attn_prefill_hd<128>(q, kcache, vcache, N, n_head, n_past, t_max, tb, out, s);
+    default: return false;
+    }
+}
 bool attn_head_size_supported(int hd) { return hd == 32 || hd == 64 || hd == 128; }
 static size_t attn_lds_bytes(int n_ctx, int hd) { const int Tpad = (n_ctx + 7) & ~7; return (size_t)Tpad * 6 + (size_t)hd * 6 + (size_t)(AT_THREADS / (hd / 8)) * hd * 4 + 64; }
 int attn_max_ctx(int hd) { int n = 0; while (attn_lds_bytes(n + 8, hd) + 256 /* static reduction arrays */ <= 160 * 1024) n += 8; return n; }

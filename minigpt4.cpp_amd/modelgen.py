@@ -68,6 +68,7 @@ class LLMConfig:
     mix: str = "q5_k_m"            # "none" | "q5_k_m" (wv/w2 -> q6_k in the 'more bits' layers, output q6_k)
     output_type: Optional[str] = None
     tok_type: Optional[str] = None
+    more_bits_layers: Optional[Tuple[int, ...]] = None   # mix "q5_k_m": explicit 'more bits' layers instead of llama.cpp's use_more_bits(i, n_layer) rule
 
     @property
     def n_rot(self) -> int:
@@ -113,7 +114,7 @@ def llm_tensor_types(cfg: LLMConfig) -> Dict[str, int]:
     out["output.weight"] = otype
     for i in range(cfg.n_layer):
         p = f"layers.{i}."
-        more = cfg.mix == "q5_k_m" and use_more_bits(i, cfg.n_layer)
+        more = cfg.mix == "q5_k_m" and (i in cfg.more_bits_layers if cfg.more_bits_layers is not None else use_more_bits(i, cfg.n_layer))
         out[p + "attention_norm.weight"] = Q.GGML_F32
         out[p + "attention.wq.weight"] = base
         out[p + "attention.wk.weight"] = base

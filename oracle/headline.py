@@ -38,24 +38,35 @@ def headline_files(config: str):
     """The synthetic files bench.py measures (same generator arguments, same cache directory): returns (vision_path, llm_path)."""
     from minigpt4_cpp_amd import modelgen as G
     d = model_dir()
+    ul = 1
     if config == "13b":
         vcfg, lcfg = G.vision_13b(), G.llm_13b()
     elif config == "7b":
         vcfg, lcfg = G.vision_7b(), G.llm_7b("q4_0")
+    elif config == "13b_l2":
+        # the 13B graph at full width, two layers deep: layer 0 a "more bits" layer (wv / w2 in Q6_K: the mixed-type qkv launch, the Q6_K NU = 7 tiling), layer 1 a
+        # plain Q5_K layer, output Q6_K -- every kernel instantiation / tiling / launch geometry of the 40-layer headline model, without the depth that turns the
+        # reference arithmetic's int8 re-roundings into percent-level logit noise (see compare())
+        vcfg = G.vision_13b()
+        lcfg = G.LLMConfig(n_vocab=32000, n_embd=5120, n_head=40, n_layer=2, wtype="q5_k", mix="q5_k_m", ftype=17, more_bits_layers=(0,))
+        ul = None
     else:
         raise ValueError(config)
-    vp, lp = os.path.join(d, f"vision_{config}.bin"), os.path.join(d, f"llm_{config}.bin")
+    vname = "13b" if config == "13b_l2" else config
+    vp, lp = os.path.join(d, f"vision_{vname}.bin"), os.path.join(d, f"llm_{config}.bin")
     if not os.path.exists(vp + ".ok"):
         G.write_vision_file(vp, vcfg, seed=4321, std=0.02, unique_blocks=1, fast=True)
         open(vp + ".ok", "w").write("ok")
     if not os.path.exists(lp + ".ok"):
-        G.write_llm_file(lp, lcfg, seed=1234, std=0.02, unique_layers=1, fast=True)
+        G.write_llm_file(lp, lcfg, seed=1234, std=0.02, unique_layers=ul, fast=True)
         open(lp + ".ok", "w").write("ok")
     return vp, lp
 
 
-def oracle_run(lp: str, embedding: np.ndarray, steps: int, prompt: str = PROMPT, n_ctx: int = 512, native: bool = False, threads: Optional[int] = None) -> Dict:
-    """Oracle side of the chat flow: per-step logits (before sampling), greedy ids and pieces."""
+def oracle_run(lp: str, embedding: np.ndarray, steps: int, prompt: str = PROMPT, n_ctx: int = 512, native: bool = False, threads: Optional[int] = None,
+               teacher_ids: Optional[List[int]] = None) -> Dict:
+    """Oracle side of the chat flow: per-step logits (before sampling), greedy ids and pieces.  teacher_ids: feed these ids instead of the run's own greedy ones
+    (the self-noise run of oracle_self_noise)."""
     import refcpu as R
     from minigpt4_cpp_amd import modelgen as G
     f = G.read_llm_file(lp, in_memory=True)
@@ -70,12 +81,30 @@ def oracle_run(lp: str, embedding: np.ndarray, steps: int, prompt: str = PROMPT,
     n_prompt = llm.n_past
     logits, ids, pieces = [], [], []
     t0 = time.time()
-    for _ in range(steps):
+    for i in range(steps):
         logits.append(llm.logits.copy())
-        tid, piece = chat.end_chat(temp=0.0)
+        if teacher_ids is not None:
+            tid, piece = int(teacher_ids[i]), b""
+            llm.eval_tokens([tid])
+        else:
+            tid, piece = chat.end_chat(temp=0.0)
         ids.append(int(tid))
         pieces.append(piece.decode("utf-8", errors="replace"))
     return {"logits": np.stack(logits), "ids": ids, "pieces": pieces, "n_prompt": n_prompt, "prefill_s": prefill_s, "decode_s": time.time() - t0}
+
+
+def oracle_self_noise(lp: str, embedding: np.ndarray, base: Dict, eps: float = 1e-6, **kw) -> Dict:
+    """The reference arithmetic's own conditioning on this file: the oracle against ITSELF with the image embedding perturbed by `eps` relative (the size of fp32
+    summation-order differences), teacher-forced on the unperturbed run's ids.  Every activation row is rounded to int8 before every mat-mul (ggml's Q8_K / Q8_0),
+    so a 1e-6 perturbation flips a few roundings, the flips decorrelate the rounding errors of the two runs layer by layer, and a deep stack ends up differing by its
+    whole accumulated quantisation noise.  Any implementation that does not add the fp32 terms in ggml's exact order differs from it by this much; a GPU-vs-oracle
+    difference can only be judged against it."""
+    rng = np.random.default_rng(12345)
+    emb2 = (np.asarray(embedding, np.float32) * (1.0 + eps * rng.standard_normal(embedding.shape))).astype(np.float32)
+    pert = oracle_run(lp, emb2, len(base["ids"]), teacher_ids=base["ids"], **kw)
+    ol, pl = base["logits"].astype(np.float64), pert["logits"].astype(np.float64)
+    rel = np.abs(pl - ol).max(axis=1) / (ol.max(axis=1) - ol.min(axis=1))
+    return {"eps": eps, "max_logit_rel_range": float(rel.max()), "mean_logit_rel_range": float(rel.mean()), "argmax_identical": int((pl.argmax(axis=1) == ol.argmax(axis=1)).sum())}
 
 
 def gpu_free_run(lib, ctx, emb_struct, steps: int, prompt: str = PROMPT) -> List[str]:
