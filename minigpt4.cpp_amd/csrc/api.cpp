@@ -526,6 +526,58 @@ int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int 
     });
 }
 
+// Prefill mat-mul micro-benchmark (tools/mmq2_bench.py): n_mat matrices of random blocks against N random rows, `iters` launches of the engine's prefill launch
+// (generation 2: mmq2_kernels.hip; generation 1: the round-1 kernels, one launch per matrix); ks: forced K split (0 = the launcher's choice).
+int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, int iters, int ks, int generation, float *us_per_launch) {
+    if (!qweight_supported(ggml_type) || rows <= 0 || cols <= 0 || cols % gt_block(ggml_type) || n_mat < 1 || n_mat > 3 || iters < 1 || N < 1) return 1;
+    if (device_count_noexcept() <= 0) return 2;
+    return guarded(3, [&]() -> int {
+        hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0));
+        QWeight plan; const size_t need = plan_qweight(ggml_type, rows, cols, plan, nullptr);
+        std::vector<std::unique_ptr<DevBuf>> keep;
+        QWeight W[3];
+        for (int i = 0; i < n_mat; i++) {
+            keep.emplace_back(new DevBuf(need));
+            uint8_t *base = (uint8_t *)keep.back()->p;
+            plan_qweight(ggml_type, rows, cols, W[i], base);
+            launch_fill_random(base, need, (unsigned)(i * 7919 + 13), nullptr);
+            const size_t n = (size_t)rows * cols;
+            if (ggml_type == GT_Q4_K || ggml_type == GT_Q5_K) launch_fill_u16((void *)W[i].sc, n / 256 * 16 / 2, 0x1C00, nullptr);
+            if (W[i].d) launch_fill_u16((void *)W[i].d, n / 256, 0x1C00, nullptr);
+        }
+        ActQ A; alloc_act(A, keep, (size_t)N, (size_t)cols);
+        const size_t out_each = (size_t)N * rows;
+        DevBuf dx((size_t)N * cols * 4), dy(out_each * n_mat * 4), dws(out_each * n_mat * 16 * 4);
+        { std::vector<float> hx((size_t)N * cols); for (size_t i = 0; i < hx.size(); i++) hx[i] = (float)((int)(i * 37 % 201) - 100) / 64.0f; HIP_CHECK(hipMemcpy(dx.p, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); }
+        launch_rms_quant(dx.as<float>(), nullptr, N, cols, A, act_mask_for(ggml_type), nullptr);
+        float *old_ws; size_t old_n; get_mmq2_workspace(&old_ws, &old_n);
+        set_mmq2_workspace(dws.as<float>(), out_each * n_mat * 16, prop.multiProcessorCount);
+        if (ks > 0) setenv("MINIGPT4_MMQ2_KS", std::to_string(ks).c_str(), 1);
+        const int keep_gen = mmq_enabled();
+        set_mmq_enabled(generation);
+        const QWeight *Wp[3]; float *Yp[3];
+        for (int m = 0; m < n_mat; m++) { Wp[m] = &W[m]; Yp[m] = dy.as<float>() + (size_t)m * out_each; }
+        auto run = [&]() {
+            if (generation >= 2 && launch_mmq2_set(Wp, Yp, nullptr, n_mat, A, N, rows, nullptr)) return;
+            for (int m = 0; m < n_mat; m++) launch_mul_mat(*Wp[m], A, N, Yp[m], rows, nullptr, nullptr);
+        };
+        run(); run();
+        HIP_CHECK(hipDeviceSynchronize());
+        hipEvent_t ea, eb; HIP_CHECK(hipEventCreate(&ea)); HIP_CHECK(hipEventCreate(&eb));
+        HIP_CHECK(hipEventRecord(ea, nullptr));
+        for (int i = 0; i < iters; i++) run();
+        HIP_CHECK(hipEventRecord(eb, nullptr));
+        HIP_CHECK(hipDeviceSynchronize());
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ea, eb));
+        (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+        unsetenv("MINIGPT4_MMQ2_KS");
+        set_mmq_enabled(keep_gen);
+        set_mmq2_workspace(old_ws, old_n, 0);
+        if (us_per_launch) *us_per_launch = ms * 1e3f / (float)iters;
+        return 0;
+    });
+}
+
 float minigpt4_amd_probe_grid_barrier(int n_blocks, int iters, unsigned *errors) {
     if (n_blocks < 1 || n_blocks > 1024 || iters < 1 || device_count_noexcept() <= 0) return -1.0f;
     float us = -1.0f;

@@ -61,6 +61,7 @@ struct Mmq2Args {
     int n_tiles, tiles_per_chunk; // token tiles of 32 in total / per grid.y chunk
     int sb_per_split;             // super-blocks per grid.z slice
     long long slab_stride;        // floats between K-split slabs
+    int dbg;                      // diagnostics (tools/mmq2_bench.py): bit 0 skip the token-tile arithmetic, bit 1 skip the integer scale multiply-adds, bit 2 skip the MFMAs
 };
 
 // Requests stage `sb` of this chunk into LDS buffer `st` (all 4 waves take part; every request is unconditional, indices clamped).
@@ -181,15 +182,18 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
         // ---- token tiles
 #pragma unroll
         for (int tt = 0; tt < TT; tt++) {
-            if (tt < my_tiles) {
+            if (tt < my_tiles && !(a.dbg & 1)) {
                 const unsigned char *sq = st + tt * 8192;
                 v16i isum = zero16();
 #pragma unroll
                 for (int jp = 0; jp < 4; jp++) {
                     const v4i alo = *reinterpret_cast<const v4i *>(sq + a_addr[2 * jp]), ahi = *reinterpret_cast<const v4i *>(sq + a_addr[2 * jp + 1]);
                     const int sc0 = (int)(((jp & 2) ? scw1 : scw0) >> (16 * (jp & 1))) & 0xFF, sc1 = (int)(((jp & 2) ? scw1 : scw0) >> (16 * (jp & 1) + 8)) & 0xFF;
-                    const v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, wlo[jp], zero16(), 0, 0, 0);
-                    const v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, whi[jp], zero16(), 0, 0, 0);
+                    v16i d0, d1;
+                    if (a.dbg & 4) { d0 = zero16(); d1 = zero16(); d0[0] = alo[0] + wlo[jp][1]; d1[0] = ahi[2] + whi[jp][3]; }
+                    else { d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, wlo[jp], zero16(), 0, 0, 0); d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, whi[jp], zero16(), 0, 0, 0); }
+                    if (a.dbg & 2) { isum[jp] += d0[jp] + d1[jp + 4]; asm volatile("" :: "v"(d0), "v"(d1)); }
+                    else
 #pragma unroll
                     for (int r = 0; r < 16; r++) isum[r] = __mul24(d1[r], sc1) + (__mul24(d0[r], sc0) + isum[r]);
                     // keep the sub-block pairs in program order: integer adds reassociate, and without the pin LLVM sinks all 128 multiply-adds of a token tile behind
@@ -365,6 +369,7 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     Mmq2Args a{};
     for (int i = 0; i < n; i++) { a.w[i] = *W[i]; a.y[i] = y[i]; a.res[i] = residual ? residual[i] : nullptr; }
     a.n_mat = n; a.groups_each = (W[0]->rows + 127) / 128; a.N = N; a.ldy = ldy;
+    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("MINIGPT4_MMQ2_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     a.n_tiles = (N + 31) / 32;
     const int max_tt = W[0]->type == GT_Q6_K ? 2 : 4;          // Q6_K keeps four half-masked operand sets per pair: 2 token tiles fill its 256 registers
     const int n_chunks = (a.n_tiles + max_tt - 1) / max_tt;

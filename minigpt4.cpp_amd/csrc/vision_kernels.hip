@@ -137,6 +137,124 @@ static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, in
     else if (residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
     else hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
 }
+// =====================================================================================================================
+// Large-M form (M >= 512: the unquantised LLM's prompt rows -- BASELINE.json configs[4] -- and batched image encodes): 128x128 tile per 256-thread workgroup,
+// wave = 64x64 = 2x2 MFMA tiles (four MFMAs per four 16-byte LDS fragment reads), BK = 64.  Both operands are K-contiguous fp16 rows, staged with
+// global_load_lds (LDS-DMA: no staging registers, no ds_write pass) into two LDS buffers; the 16-byte chunks of a 128-byte tile row are XOR-swizzled by
+// ((row >> 1) & 7) on the SOURCE side (the DMA destination is lane-linear), which makes the fragment ds_read_b128 of 32 consecutive rows bank-conflict free.
+// One barrier per k tile: [own DMA landed] barrier [request tile k + 1 into the other buffer] [16 MFMAs on tile k].
+// Same arithmetic as k_gemm_f16: exact fp16 products, fp32 accumulation over k in index order per 16-wide MFMA step.
+// =====================================================================================================================
+typedef __attribute__((address_space(3))) void *g_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *g_glb_ptr_t;
+template <bool GELU, bool RES>
+__global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K, const float *__restrict__ bias,
+                                                         const float *residual, const Tables tb, float *out, __half *__restrict__ out_h, int ldo) {
+    constexpr int BM = 128, BN = 128, BK = 64, TILE = BM * BK * 2;       // 16 KiB per operand tile
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_gb[];   // [2 buffers][A tile | W tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware order: the row tiles that share a weight tile run on ONE XCD (blocks are dealt round-robin to the 8 XCDs, each with its own L2)
+    const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
+    const int bslot = blockIdx.x >> 3, bx = (bslot / rt) * 8 + (blockIdx.x & 7), by = bslot % rt;
+    if (bx >= ntx) return;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int wm = wave >> 1, wn = wave & 1;
+    // DMA sources: instruction j (0..15) of a tile covers rows 8 j .. 8 j + 7; wave w issues j = 4 w .. 4 w + 3 for each operand.  lane -> (row = 8 j + lane / 8, slot = lane % 8),
+    // source chunk = slot ^ ((row >> 1) & 7)
+    const __half *asrc[4], *wsrc[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int row = 8 * (4 * wave + u) + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+        asrc[u] = A + (size_t)min(m0 + row, M - 1) * lda + 8 * c;
+        wsrc[u] = W + (size_t)min(n0 + row, N - 1) * ldw + 8 * c;
+    }
+    auto stage = [&](int kt, int buf) {
+        unsigned char *base = smem_gb + buf * 2 * TILE;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(asrc[u] + (size_t)kt * BK), (g_lds_ptr_t)(base + (4 * wave + u) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(wsrc[u] + (size_t)kt * BK), (g_lds_ptr_t)(base + TILE + (4 * wave + u) * 1024), 16, 0, 0);
+        }
+    };
+    // fragment read offsets: row r = (lane & 31) (+ 32 for the second tile), chunk c = 2 ks + (lane >> 5) at slot c ^ ((r >> 1) & 7); r + 32 has the same swizzle key
+    const int l31 = lane & 31, key = (l31 >> 1) & 7, hh = lane >> 5;
+    unsigned fa[4];                                                   // per ks: byte offset of this lane's chunk within a 32-row band
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) fa[ks] = (unsigned)(l31 * 128 + (((2 * ks + hh) ^ key) << 4));
+    float16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+    const int nk = K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        __syncthreads();                                              // tile kt landed (the barrier's fence waits for this wave's DMA), everybody left the other buffer
+        stage(min(kt + 1, nk - 1), buf ^ 1);
+        const unsigned char *at = smem_gb + buf * 2 * TILE + (wm * 64) * 128, *wt = smem_gb + buf * 2 * TILE + TILE + (wn * 64) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const half8_t a0 = *reinterpret_cast<const half8_t *>(at + fa[ks]), a1 = *reinterpret_cast<const half8_t *>(at + 32 * 128 + fa[ks]);
+            const half8_t b0 = *reinterpret_cast<const half8_t *>(wt + fa[ks]), b1 = *reinterpret_cast<const half8_t *>(wt + 32 * 128 + fa[ks]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // epilogue (as k_gemm_f16): all gathers of one kind issued together
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int col = n0 + wn * 64 + j * 32 + l31, colc = min(col, N - 1);
+        const float bv = bias ? bias[colc] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            float v[16]; size_t o[16]; bool okr[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                okr[r] = row < M && col < N; o[r] = (size_t)min(row, M - 1) * ldo + colc;
+                v[r] = bias ? bv + acc[i][j][r] : acc[i][j][r];
+            }
+            if (GELU) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = tab_v(tb.gelu, v[r]);
+            }
+            if (RES) {
+                float rr[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) rr[r] = residual[o[r]];
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = rr[r] + v[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) if (okr[r]) { if (out) out[o[r]] = v[r]; if (out_h) out_h[o[r]] = __float2half_rn(v[r]); }
+        }
+    }
+}
+static int g_gemm_big_min_m = 512;   // MINIGPT4_GEMM_BIG_M: smallest M that takes the 128x128 kernel (0 = never)
+static bool launch_gemm_big(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
+                            float *out, __half *out_h, int ldo, hipStream_t s) {
+    static bool init = false;
+    if (!init) { if (const char *e = getenv("MINIGPT4_GEMM_BIG_M")) g_gemm_big_min_m = atoi(e); init = true;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); }
+    if (g_gemm_big_min_m <= 0 || M < g_gemm_big_min_m || K % 64 || K < 64 || lda % 8 || ldw % 8 || (reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) % 16) return false;
+    const int ntx = (N + 127) / 128, rt = (M + 127) / 128;
+    const dim3 grid((unsigned)((ntx + 7) / 8 * 8 * rt)), block(256);
+    const size_t lds = 64 * 1024;
+    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16_big<true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+    else if (gelu) hipLaunchKernelGGL((k_gemm_f16_big<true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+    else if (residual) hipLaunchKernelGGL((k_gemm_f16_big<false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+    else hipLaunchKernelGGL((k_gemm_f16_big<false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+    return true;
+}
+
 // Tile shape experiments at M = 257 (profiles/r01i_ab_encode.log): 128x64 (8 waves) and 128x128 (16 waves) tiles halve the bytes moved per flop but are
 // 16 % / 28 % SLOWER end to end than 64x64; 64x32 tiles (more workgroups) are slower too; an XCD-aware tile order removes a 4x weight re-fetch from
 // HBM (PMC FETCH_SIZE) without changing the time; 64x128 tiles with two accumulators per wave (fewer LDS reads per MFMA) are 26 % slower.  Every
@@ -144,6 +262,7 @@ static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, in
 // MFMA, two barriers per tile), not by traffic, LDS bandwidth or the matrix cores -- the next step is an LDS-DMA ring per workgroup.
 void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
                      float *out, __half *out_h, int ldo, hipStream_t s) {
+    if (launch_gemm_big(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;
     launch_gemm_t<128, 64, 64>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);
 }
 

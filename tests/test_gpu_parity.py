@@ -168,7 +168,8 @@ def test_decode_matvec_mixed_types_one_launch(gpu_lib, t1, K, fuse):
     assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
 
 
-@pytest.mark.parametrize("shape", [(257, 176, 528), (32, 768, 100), (256, 592, 176), (70, 48, 33)])
+@pytest.mark.parametrize("shape", [(257, 176, 528), (32, 768, 100), (256, 592, 176), (70, 48, 33),
+                                   (512, 1408, 256), (640, 704, 130), (1028, 6144, 384), (513, 64, 128)])   # M >= 512: the 128x128 LDS-DMA kernel (ragged M / N, one and many k tiles)
 @pytest.mark.parametrize("gelu", [False, True])
 def test_gemm_f16_mfma(gpu_lib, shape, gelu):
     import refcpu as R
