@@ -61,7 +61,6 @@ struct Mmq2Args {
     int n_tiles, tiles_per_chunk; // token tiles of 32 in total / per grid.y chunk
     int sb_per_split;             // super-blocks per grid.z slice
     long long slab_stride;        // floats between K-split slabs
-    int dbg;                      // diagnostics (tools/mmq2_bench.py): bit 0 skip the token-tile arithmetic, bit 1 skip the integer scale multiply-adds, bit 2 skip the MFMAs
 };
 
 // Requests stage `sb` of this chunk into LDS buffer `st` (all 4 waves take part; every request is unconditional, indices clamped).
@@ -116,7 +115,7 @@ __device__ __forceinline__ void mmq2_store(const float (&acc)[TT][16], const Mmq
 template <bool Q5, int TT>
 __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const ActQ A) {
     using S = Mmq2Stage<TT>;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_mmq2[];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_mmq2[];   // [2 activation stages][4 waves x 4 KiB weight transpose scratch]
     const int lane = threadIdx.x & 63, hh = lane >> 5, l31 = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = blockIdx.x / a.groups_each, g = blockIdx.x - m * a.groups_each;
@@ -126,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
     const int row = min(r0 + l31, W.rows - 1);
     const int tile0 = blockIdx.y * a.tiles_per_chunk, my_tiles = min(TT, a.n_tiles - tile0), t0 = tile0 * 32;
     const int sb0 = blockIdx.z * a.sb_per_split, sb1 = min(NSB, sb0 + a.sb_per_split);
+    unsigned char *scratch = smem_mmq2 + 2 * S::BYTES + wv * 4096;
 
     float acc[TT][16];
 #pragma unroll
@@ -133,13 +133,26 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[tt][r] = 0.0f;
 
-    struct Raw { v4i q[4]; unsigned P[4]; v4i h; };
-    const unsigned char *wq = W.qs + ((size_t)row * U + hh) * 16, *wp = W.qh + ((size_t)row * U + hh) * 4, *wh = W.sc + (size_t)row * NSB * 16;
+    // Weight requests of one super-block, COALESCED (a lane-per-row gather costs 32 cache-line requests per instruction and the address path, not HBM, becomes the
+    // bound -- measured: the staging loop alone took 58 % of the round-2a kernel): main plane: instruction n reads rows 8 n .. 8 n + 7 x the super-block's 8 units
+    // (128 contiguous bytes per row); high-bit plane: lane (row, hh) reads the 16 bytes of units 4 hh .. 4 hh + 3; header: 16 bytes per row.
+    struct Raw { v4i q[4]; v4i p; v4i h; };
+    const unsigned char *wq[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) wq[n] = W.qs + ((size_t)min(r0 + 8 * n + (lane >> 3), W.rows - 1) * U + (lane & 7)) * 16;
+    const unsigned char *wp = W.qh + (size_t)row * U * 4 + hh * 16, *wh = W.sc + (size_t)row * NSB * 16;
     auto fetch = [&](int sb, Raw &w) {
 #pragma unroll
-        for (int jp = 0; jp < 4; jp++) { w.q[jp] = ldg16(wq + ((size_t)sb * 8 + 2 * jp) * 16); w.P[jp] = Q5 ? *reinterpret_cast<const unsigned *>(wp + ((size_t)sb * 8 + 2 * jp) * 4) : 0u; }
+        for (int n = 0; n < 4; n++) w.q[n] = ldg16(wq[n] + (size_t)sb * 128);
+        if (Q5) w.p = ldg16(wp + (size_t)sb * 32);
         w.h = ldg16(wh + (size_t)sb * 16);
     };
+    // transpose scratch: [32 rows][8 units x 16 B], unit u of row r at slot u ^ ((r >> 1) & 7) (conflict-free for the row-per-lane fragment reads)
+    unsigned sw_addr[4], sr_addr[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) sw_addr[n] = (unsigned)((8 * n + (lane >> 3)) * 128 + (((lane & 7) ^ ((4 * n + (lane >> 4)) & 7)) << 4));
+#pragma unroll
+    for (int jp = 0; jp < 4; jp++) sr_addr[jp] = (unsigned)(l31 * 128 + (((2 * jp + hh) ^ ((l31 >> 1) & 7)) << 4));
     // per-lane LDS read addresses (stage 0): A fragment of chunk C = 4 jp + 2 x (x = 0: low-nibble sub-block, 1: high) for token l31 of tile 0
     const int v = hh ^ (lane & 15);
     unsigned a_addr[8];
@@ -154,15 +167,23 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
         const int buf = (sb - sb0) & 1;
         unsigned char *st = smem_mmq2 + buf * S::BYTES;
         __syncthreads();                                           // own DMA + weight loads done (vmcnt(0) is part of the barrier's fence), then everybody's
-        // ---- unpack this super-block's weights into MFMA B operands (once; reused by every token tile)
+        // ---- this super-block's weights: transpose through LDS (same wave writes and reads: LDS operations of a wave execute in order), unpack into MFMA B operands
+#pragma unroll
+        for (int n = 0; n < 4; n++) *reinterpret_cast<v4i *>(scratch + sw_addr[n]) = raw.q[n];
+        unsigned P[4] = {0u, 0u, 0u, 0u};
+        if (Q5) {   // lanes hh = 0 hold the high bits of units 0..3, hh = 1 of units 4..7: lane (row, hh) needs units 2 jp + hh
+            const auto s01 = __builtin_amdgcn_permlane32_swap((unsigned)raw.p[0], (unsigned)raw.p[1], false, false);
+            const auto s23 = __builtin_amdgcn_permlane32_swap((unsigned)raw.p[2], (unsigned)raw.p[3], false, false);
+            P[0] = s01[0]; P[2] = s01[1]; P[1] = s23[0]; P[3] = s23[1];
+        }
         v4i wlo[4], whi[4];
 #pragma unroll
         for (int jp = 0; jp < 4; jp++) {
-            const v4i q = raw.q[jp]; const unsigned P = raw.P[jp];
-            wlo[jp][0] = (q[0] & 0x0F0F0F0F) | (int)((P << 4) & 0x10101010u); wlo[jp][1] = (q[1] & 0x0F0F0F0F) | (int)((P << 3) & 0x10101010u);
-            wlo[jp][2] = (q[2] & 0x0F0F0F0F) | (int)((P << 2) & 0x10101010u); wlo[jp][3] = (q[3] & 0x0F0F0F0F) | (int)((P << 1) & 0x10101010u);
-            whi[jp][0] = ((q[0] >> 4) & 0x0F0F0F0F) | (int)(P & 0x10101010u); whi[jp][1] = ((q[1] >> 4) & 0x0F0F0F0F) | (int)((P >> 1) & 0x10101010u);
-            whi[jp][2] = ((q[2] >> 4) & 0x0F0F0F0F) | (int)((P >> 2) & 0x10101010u); whi[jp][3] = ((q[3] >> 4) & 0x0F0F0F0F) | (int)((P >> 3) & 0x10101010u);
+            const v4i q = *reinterpret_cast<const v4i *>(scratch + sr_addr[jp]); const unsigned Pj = P[jp];
+            wlo[jp][0] = (q[0] & 0x0F0F0F0F) | (int)((Pj << 4) & 0x10101010u); wlo[jp][1] = (q[1] & 0x0F0F0F0F) | (int)((Pj << 3) & 0x10101010u);
+            wlo[jp][2] = (q[2] & 0x0F0F0F0F) | (int)((Pj << 2) & 0x10101010u); wlo[jp][3] = (q[3] & 0x0F0F0F0F) | (int)((Pj << 1) & 0x10101010u);
+            whi[jp][0] = ((q[0] >> 4) & 0x0F0F0F0F) | (int)(Pj & 0x10101010u); whi[jp][1] = ((q[1] >> 4) & 0x0F0F0F0F) | (int)((Pj >> 1) & 0x10101010u);
+            whi[jp][2] = ((q[2] >> 4) & 0x0F0F0F0F) | (int)((Pj >> 2) & 0x10101010u); whi[jp][3] = ((q[3] >> 4) & 0x0F0F0F0F) | (int)((Pj >> 3) & 0x10101010u);
         }
         const unsigned s0 = (unsigned)raw.h[1], s1 = (unsigned)raw.h[2], s2 = (unsigned)raw.h[3];
         const unsigned scw0 = s0 & 0x3f3f3f3fu, scw1 = (s2 & 0x0f0f0f0fu) | (((s0 >> 6) & 0x03030303u) << 4);          // scales of sub-blocks 0..3 / 4..7, one byte each
@@ -170,6 +191,9 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
         const float dw = h2f_b((unsigned)raw.h[0] & 0xFFFF), ndmin = -h2f_b((unsigned)raw.h[0] >> 16);
         // min term operands: A bytes = {lo_0..7, hi_0..7} of the token (lanes hh = 0), B = {m_0..7, 0} resp. {0, m_0..7}; lanes hh = 1 contribute nothing
         const v4i bm_lo = {hh ? 0 : (int)mw0, hh ? 0 : (int)mw1, 0, 0}, bm_hi = {0, 0, hh ? 0 : (int)mw0, hh ? 0 : (int)mw1};
+        int sc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) sc[j] = (int)(((j & 4) ? scw1 : scw0) >> (8 * (j & 3))) & 0xFF;
         __builtin_amdgcn_sched_barrier(0);                         // the raw registers are dead from here: the next super-block's loads reuse them (no second register stage)
         // ---- request the next super-block (weights into the now free raw registers, activations into the other LDS buffer: every wave has passed the barrier,
         // so nobody still reads it)
@@ -179,32 +203,38 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
             mmq2_stage_load<TT>(A, K, NSB, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- token tiles
+        // ---- token tiles.  Within a tile the five MFMA pairs (4 sub-block pairs + the min term) run one step ahead of the integer scale multiply-adds that
+        // consume them (two result sets): an in-order wave otherwise sits out every MFMA's result latency before its 32 dependent VALU operations.
 #pragma unroll
         for (int tt = 0; tt < TT; tt++) {
-            if (tt < my_tiles && !(a.dbg & 1)) {
+            if (tt < my_tiles) {
                 const unsigned char *sq = st + tt * 8192;
                 v16i isum = zero16();
-#pragma unroll
-                for (int jp = 0; jp < 4; jp++) {
-                    const v4i alo = *reinterpret_cast<const v4i *>(sq + a_addr[2 * jp]), ahi = *reinterpret_cast<const v4i *>(sq + a_addr[2 * jp + 1]);
-                    const int sc0 = (int)(((jp & 2) ? scw1 : scw0) >> (16 * (jp & 1))) & 0xFF, sc1 = (int)(((jp & 2) ? scw1 : scw0) >> (16 * (jp & 1) + 8)) & 0xFF;
-                    v16i d0, d1;
-                    if (a.dbg & 4) { d0 = zero16(); d1 = zero16(); d0[0] = alo[0] + wlo[jp][1]; d1[0] = ahi[2] + whi[jp][3]; }
-                    else { d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, wlo[jp], zero16(), 0, 0, 0); d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, whi[jp], zero16(), 0, 0, 0); }
-                    if (a.dbg & 2) { isum[jp] += d0[jp] + d1[jp + 4]; asm volatile("" :: "v"(d0), "v"(d1)); }
-                    else
-#pragma unroll
-                    for (int r = 0; r < 16; r++) isum[r] = __mul24(d1[r], sc1) + (__mul24(d0[r], sc0) + isum[r]);
-                    // keep the sub-block pairs in program order: integer adds reassociate, and without the pin LLVM sinks all 128 multiply-adds of a token tile behind
-                    // its 8 MFMAs (128 live result registers -> scratch)
-                    asm volatile("" : "+v"(isum));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                v16i D[2][2];
+#define MMQ2_ISSUE(jp, b) { const v4i alo_ = *reinterpret_cast<const v4i *>(sq + a_addr[2 * (jp)]), ahi_ = *reinterpret_cast<const v4i *>(sq + a_addr[2 * (jp) + 1]);     \
+                            D[b][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo_, wlo[jp], zero16(), 0, 0, 0); D[b][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi_, whi[jp], zero16(), 0, 0, 0); }
+#define MMQ2_MADS(jp, b) { _Pragma("unroll") for (int r = 0; r < 16; r++) isum[r] = __mul24(D[b][1][r], sc[2 * (jp) + 1]) + (__mul24(D[b][0][r], sc[2 * (jp)]) + isum[r]);   \
+                           asm volatile("" : "+v"(isum)); }
+                MMQ2_ISSUE(0, 0)
                 __builtin_amdgcn_sched_barrier(0);
-                const v4i abs_ = *reinterpret_cast<const v4i *>(st + bs_addr + tt * 512);
-                const v16i mlo = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, bm_lo, zero16(), 0, 0, 0);
-                const v16i mhi = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, bm_hi, zero16(), 0, 0, 0);
+                MMQ2_ISSUE(1, 1)
+                MMQ2_MADS(0, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE(2, 0)
+                MMQ2_MADS(1, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE(3, 1)
+                MMQ2_MADS(2, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const v4i abs_ = *reinterpret_cast<const v4i *>(st + bs_addr + tt * 512);
+                    D[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, bm_lo, zero16(), 0, 0, 0);
+                    D[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, bm_hi, zero16(), 0, 0, 0);
+                }
+                MMQ2_MADS(3, 1)
+                __builtin_amdgcn_sched_barrier(0);
+#undef MMQ2_ISSUE
+#undef MMQ2_MADS
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++) {
                     const v4f da = *reinterpret_cast<const v4f *>(st + dk_addr + tt * 128 + q4 * 32);   // tokens 8 q4 + 4 hh + 0..3 = accumulator registers 4 q4 .. 4 q4 + 3
@@ -212,14 +242,13 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
                     for (int e = 0; e < 4; e++) {
                         const int r = 4 * q4 + e;
                         acc[tt][r] = fmaf(dw * da[e], (float)isum[r], acc[tt][r]);
-                        acc[tt][r] = fmaf(ndmin * da[e], (float)(mhi[r] * 128 + mlo[r]), acc[tt][r]);
+                        acc[tt][r] = fmaf(ndmin * da[e], (float)(D[0][1][r] * 128 + D[0][0][r]), acc[tt][r]);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-    // ---- store: lane = weight row, register = token -> 32 consecutive floats per (register, lane half)
     mmq2_store<TT>(acc, a, m, r0 + l31, W.rows, t0, my_tiles, hh);
 }
 
@@ -231,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
 template <int TT>
 __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const ActQ A) {
     using S = Mmq2Stage<TT>;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_mmq2[];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_mmq2[];   // [2 activation stages][4 waves x 4 KiB weight transpose scratch]
     const int lane = threadIdx.x & 63, hh = lane >> 5, l31 = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = blockIdx.x / a.groups_each, g = blockIdx.x - m * a.groups_each;
@@ -241,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
     const int row = min(r0 + l31, W.rows - 1);
     const int tile0 = blockIdx.y * a.tiles_per_chunk, my_tiles = min(TT, a.n_tiles - tile0), t0 = tile0 * 32;
     const int sb0 = blockIdx.z * a.sb_per_split, sb1 = min(NSB, sb0 + a.sb_per_split);
+    unsigned char *scratch = smem_mmq2 + 2 * S::BYTES + wv * 4096;
 
     float acc[TT][16];
 #pragma unroll
@@ -248,17 +278,25 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[tt][r] = 0.0f;
 
-    struct Raw { v4i q[4]; uint2 P[4]; unsigned sc[4]; unsigned short d; };     // sc[p] = {unit h = 0: lo, hi scale | unit h = 1: lo, hi scale} (4 int8)
-    const unsigned char *wq = W.qs + ((size_t)row * U + hh) * 16, *wp = W.qh + ((size_t)row * U + hh) * 8, *ws = W.sc + (size_t)row * U * 2, *wd = W.d + (size_t)row * NSB * 2;
+    // coalesced weight requests (see k_mmq2_q45k): main plane 8 rows x 128 B per instruction; high-bit plane (8 B per unit): lane (row, hh) reads the 32 bytes of units
+    // 4 hh .. 4 hh + 3; scale plane: the row's 8 x {lo, hi} int8 scales of the super-block in one 16-byte load
+    struct Raw { v4i q[4]; v4i p[2]; v4i sc; unsigned short d; };
+    const unsigned char *wq[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) wq[n] = W.qs + ((size_t)min(r0 + 8 * n + (lane >> 3), W.rows - 1) * U + (lane & 7)) * 16;
+    const unsigned char *wp = W.qh + (size_t)row * U * 8 + hh * 32, *ws = W.sc + (size_t)row * U * 2, *wd = W.d + (size_t)row * NSB * 2;
     auto fetch = [&](int sb, Raw &w) {
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            w.q[p] = ldg16(wq + ((size_t)sb * 8 + 2 * p) * 16);
-            w.P[p] = *reinterpret_cast<const uint2 *>(wp + ((size_t)sb * 8 + 2 * p) * 8);
-            w.sc[p] = *reinterpret_cast<const unsigned *>(ws + ((size_t)sb * 8 + 2 * p) * 2);
-        }
+        for (int n = 0; n < 4; n++) w.q[n] = ldg16(wq[n] + (size_t)sb * 128);
+        w.p[0] = ldg16(wp + (size_t)sb * 64); w.p[1] = ldg16(wp + (size_t)sb * 64 + 16);
+        w.sc = ldg16(ws + (size_t)sb * 16);
         w.d = *reinterpret_cast<const unsigned short *>(wd + (size_t)sb * 2);
     };
+    unsigned sw_addr[4], sr_addr[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) sw_addr[n] = (unsigned)((8 * n + (lane >> 3)) * 128 + (((lane & 7) ^ ((4 * n + (lane >> 4)) & 7)) << 4));
+#pragma unroll
+    for (int p = 0; p < 4; p++) sr_addr[p] = (unsigned)(l31 * 128 + (((2 * p + hh) ^ ((l31 >> 1) & 7)) << 4));
     // A fragments: low part of pair p = 2 n + c at element 128 n + 32 c + 16 hh -> chunk 8 n + 2 c + hh, high part 4 chunks further
     const int v = hh ^ (lane & 15);
     unsigned a_addr[8];                                        // [2 p + x]: chunk base (8 n + 2 c + 4 x), bit 0 (hh) folded into v
@@ -276,18 +314,30 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
         const int buf = (sb - sb0) & 1;
         unsigned char *st = smem_mmq2 + buf * S::BYTES;
         __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 4; n++) *reinterpret_cast<v4i *>(scratch + sw_addr[n]) = raw.q[n];
+        // high bits: lanes hh = 0 hold units 0..3 as {lo0, hi0, lo1, hi1 | lo2, hi2, lo3, hi3}, lanes hh = 1 units 4..7; lane (row, hh) needs units 2 p + hh
+        unsigned PL[4], PH[4];
+        {
+            const auto l01 = __builtin_amdgcn_permlane32_swap((unsigned)raw.p[0][0], (unsigned)raw.p[0][2], false, false);   // lo of units (0|4) x (1|5) -> (0|1), (4|5)
+            const auto h01 = __builtin_amdgcn_permlane32_swap((unsigned)raw.p[0][1], (unsigned)raw.p[0][3], false, false);
+            const auto l23 = __builtin_amdgcn_permlane32_swap((unsigned)raw.p[1][0], (unsigned)raw.p[1][2], false, false);   // (2|6) x (3|7) -> (2|3), (6|7)
+            const auto h23 = __builtin_amdgcn_permlane32_swap((unsigned)raw.p[1][1], (unsigned)raw.p[1][3], false, false);
+            PL[0] = l01[0]; PL[2] = l01[1]; PL[1] = l23[0]; PL[3] = l23[1];
+            PH[0] = h01[0]; PH[2] = h01[1]; PH[1] = h23[0]; PH[3] = h23[1];
+        }
         v4i wlo0[4], wlo1[4], whi0[4], whi1[4];
         int s_lo0[4], s_lo1[4], s_hi0[4], s_hi1[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const v4i q = raw.q[p]; const unsigned L = raw.P[p].x, H = raw.P[p].y;
+            const v4i q = *reinterpret_cast<const v4i *>(scratch + sr_addr[p]); const unsigned L = PL[p], H = PH[p];
             v4i wlo, whi;
             wlo[0] = sext6((q[0] & 0x0F0F0F0F) | (int)((L << 4) & 0x30303030u)); wlo[1] = sext6((q[1] & 0x0F0F0F0F) | (int)((L << 2) & 0x30303030u));
             wlo[2] = sext6((q[2] & 0x0F0F0F0F) | (int)(L & 0x30303030u)); wlo[3] = sext6((q[3] & 0x0F0F0F0F) | (int)((L >> 2) & 0x30303030u));
             whi[0] = sext6(((q[0] >> 4) & 0x0F0F0F0F) | (int)((H << 4) & 0x30303030u)); whi[1] = sext6(((q[1] >> 4) & 0x0F0F0F0F) | (int)((H << 2) & 0x30303030u));
             whi[2] = sext6(((q[2] >> 4) & 0x0F0F0F0F) | (int)(H & 0x30303030u)); whi[3] = sext6(((q[3] >> 4) & 0x0F0F0F0F) | (int)((H >> 2) & 0x30303030u));
             wlo0[p] = hh ? z4 : wlo; wlo1[p] = hh ? wlo : z4; whi0[p] = hh ? z4 : whi; whi1[p] = hh ? whi : z4;
-            const unsigned sc = raw.sc[p];
+            const unsigned sc = (unsigned)raw.sc[p];                  // units 2 p, 2 p + 1: {lo, hi} int8 scales each
             s_lo0[p] = (int)(signed char)(sc & 0xFF); s_hi0[p] = (int)(signed char)((sc >> 8) & 0xFF); s_lo1[p] = (int)(signed char)((sc >> 16) & 0xFF); s_hi1[p] = (int)(signed char)(sc >> 24);
         }
         const float dw = h2f_b(raw.d);
@@ -298,23 +348,38 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
             mmq2_stage_load<TT>(A, K, NSB, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
+        // eight half-pair steps per tile (low / high nibble part of pair p), MFMAs one step ahead of the scale multiply-adds
 #pragma unroll
         for (int tt = 0; tt < TT; tt++) {
             if (tt < my_tiles) {
                 const unsigned char *sq = st + tt * 8192;
                 v16i isum = zero16();
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const v4i alo = *reinterpret_cast<const v4i *>(sq + a_addr[2 * p]), ahi = *reinterpret_cast<const v4i *>(sq + a_addr[2 * p + 1]);
-                    const v16i a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, wlo0[p], zero16(), 0, 0, 0);
-                    const v16i a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, wlo1[p], zero16(), 0, 0, 0);
-                    const v16i b0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, whi0[p], zero16(), 0, 0, 0);
-                    const v16i b1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, whi1[p], zero16(), 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 16; r++) isum[r] = __mul24(b1[r], s_hi1[p]) + (__mul24(b0[r], s_hi0[p]) + (__mul24(a1[r], s_lo1[p]) + (__mul24(a0[r], s_lo0[p]) + isum[r])));
-                    asm volatile("" : "+v"(isum));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                v16i D[2][2];
+#define MMQ2_ISSUE6(p, x, b) { const v4i af_ = *reinterpret_cast<const v4i *>(sq + a_addr[2 * (p) + (x)]);                                                  \
+                               D[b][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_, (x) ? whi0[p] : wlo0[p], zero16(), 0, 0, 0);                                \
+                               D[b][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_, (x) ? whi1[p] : wlo1[p], zero16(), 0, 0, 0); }
+#define MMQ2_MADS6(p, x, b) { const int sa_ = (x) ? s_hi0[p] : s_lo0[p], sb_ = (x) ? s_hi1[p] : s_lo1[p];                                                   \
+                              _Pragma("unroll") for (int r = 0; r < 16; r++) isum[r] = __mul24(D[b][1][r], sb_) + (__mul24(D[b][0][r], sa_) + isum[r]);        \
+                              asm volatile("" : "+v"(isum)); }
+                MMQ2_ISSUE6(0, 0, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE6(0, 1, 1) MMQ2_MADS6(0, 0, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE6(1, 0, 0) MMQ2_MADS6(0, 1, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE6(1, 1, 1) MMQ2_MADS6(1, 0, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE6(2, 0, 0) MMQ2_MADS6(1, 1, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE6(2, 1, 1) MMQ2_MADS6(2, 0, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE6(3, 0, 0) MMQ2_MADS6(2, 1, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE6(3, 1, 1) MMQ2_MADS6(3, 0, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_MADS6(3, 1, 1)
+#undef MMQ2_ISSUE6
+#undef MMQ2_MADS6
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++) {
                     const v4f da = *reinterpret_cast<const v4f *>(st + dk_addr + tt * 128 + q4 * 32);
@@ -345,20 +410,22 @@ static float *g_mmq2_slabs = nullptr; static size_t g_mmq2_slab_floats = 0;
 void get_mmq2_workspace(float **slabs, size_t *n_floats) { *slabs = g_mmq2_slabs; *n_floats = g_mmq2_slab_floats; }
 void set_mmq2_workspace(float *slabs, size_t n_floats, int cus) { g_mmq2_slabs = slabs; g_mmq2_slab_floats = n_floats; if (cus > 0) g_mmq2_cus = cus; }
 
+template <typename KernelT>
+static void mmq2_launch_kernel(KernelT kernel, bool &attr_done, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_done = true; }
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a, A);
+}
 template <int TT>
 static void mmq2_launch_tt(int type, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
     static bool attr[3] = {false, false, false};
-    const int ti = type == GT_Q4_K ? 0 : type == GT_Q5_K ? 1 : 2;
-    if (!attr[ti]) {
-        if (ti == 0) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mmq2_q45k<false, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        else if (ti == 1) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mmq2_q45k<true, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        else if constexpr (TT <= 2) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mmq2_q6k<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr[ti] = true;
+    if constexpr (TT <= 3) {
+        if (type == GT_Q4_K) { mmq2_launch_kernel(&k_mmq2_q45k<false, TT>, attr[0], grid, lds, s, a, A); return; }
+        if (type == GT_Q5_K) { mmq2_launch_kernel(&k_mmq2_q45k<true, TT>, attr[1], grid, lds, s, a, A); return; }
     }
-    if (ti == 0) hipLaunchKernelGGL((k_mmq2_q45k<false, TT>), grid, dim3(256), lds, s, a, A);
-    else if (ti == 1) hipLaunchKernelGGL((k_mmq2_q45k<true, TT>), grid, dim3(256), lds, s, a, A);
-    else if constexpr (TT <= 2) hipLaunchKernelGGL((k_mmq2_q6k<TT>), grid, dim3(256), lds, s, a, A);
-    else throw HipError{hipErrorInvalidValue, "mmq2: Q6_K runs at most 2 token tiles per chunk", __FILE__, __LINE__};
+    if constexpr (TT <= 2) {
+        if (type == GT_Q6_K) { mmq2_launch_kernel(&k_mmq2_q6k<TT>, attr[2], grid, lds, s, a, A); return; }
+    }
+    throw HipError{hipErrorInvalidValue, "mmq2: token tiles per chunk outside the kernel's register budget", __FILE__, __LINE__};
 }
 
 // 1..3 same-type, same-shape matrices against the N prepared activation rows in one launch.  y[m][t * ldy + r] (+ residual[m][..]).  false -> shape outside the
@@ -369,9 +436,8 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     Mmq2Args a{};
     for (int i = 0; i < n; i++) { a.w[i] = *W[i]; a.y[i] = y[i]; a.res[i] = residual ? residual[i] : nullptr; }
     a.n_mat = n; a.groups_each = (W[0]->rows + 127) / 128; a.N = N; a.ldy = ldy;
-    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("MINIGPT4_MMQ2_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     a.n_tiles = (N + 31) / 32;
-    const int max_tt = W[0]->type == GT_Q6_K ? 2 : 4;          // Q6_K keeps four half-masked operand sets per pair: 2 token tiles fill its 256 registers
+    const int max_tt = W[0]->type == GT_Q6_K ? 2 : 3;          // token tiles per chunk the 256-register budget (two waves per SIMD) admits: Q6_K keeps four half-masked operand sets per pair
     const int n_chunks = (a.n_tiles + max_tt - 1) / max_tt;
     a.tiles_per_chunk = (a.n_tiles + n_chunks - 1) / n_chunks;
     const int NSB = W[0]->cols / 256;
@@ -391,10 +457,10 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     const dim3 grid((unsigned)(n * a.groups_each), (unsigned)n_chunks, (unsigned)ks);
     const int type = W[0]->type;
     switch (a.tiles_per_chunk) {
-    case 1: mmq2_launch_tt<1>(type, grid, 2 * Mmq2Stage<1>::BYTES, s, a, A); break;
-    case 2: mmq2_launch_tt<2>(type, grid, 2 * Mmq2Stage<2>::BYTES, s, a, A); break;
-    case 3: mmq2_launch_tt<3>(type, grid, 2 * Mmq2Stage<3>::BYTES, s, a, A); break;
-    default: mmq2_launch_tt<4>(type, grid, 2 * Mmq2Stage<4>::BYTES, s, a, A); break;
+    case 1: mmq2_launch_tt<1>(type, grid, 2 * Mmq2Stage<1>::BYTES + 16384, s, a, A); break;
+    case 2: mmq2_launch_tt<2>(type, grid, 2 * Mmq2Stage<2>::BYTES + 16384, s, a, A); break;
+    case 3: mmq2_launch_tt<3>(type, grid, 2 * Mmq2Stage<3>::BYTES + 16384, s, a, A); break;
+    default: throw HipError{hipErrorInvalidValue, "mmq2: bad chunking", __FILE__, __LINE__};
     }
     if (ks > 1) {
         for (int i = 0; i < n; i++) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Prefill mat-mul micro-benchmark on the 13B layer shapes (GPU only):  tools/mmq2_bench.py [N ...]
 Prints microseconds per launch of the layer's four prefill launches for generation 2 (mmq2_kernels.hip) and generation 1 (round-1 kernels, one launch per matrix),
-and the ablations MINIGPT4_MMQ2_DBG=1 (no token-tile arithmetic: staging + barriers only), 2 (no integer scale multiply-adds), 4 (no MFMAs) -- each in its own process."""
+with the launcher's own K split and with KS=1 (no split) -- each in its own process."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -32,8 +32,8 @@ if __name__ == "__main__":
         child([int(x) for x in sys.argv[2:]])
     else:
         ns = sys.argv[1:] or ["142", "512"]
-        for dbg in ("0", "1", "2", "4", "6"):
+        for ks in ("0", "1"):
             env = dict(os.environ)
-            if dbg != "0":
-                env["MINIGPT4_MMQ2_DBG"] = dbg
+            if ks != "0":
+                env["KS"] = ks
             subprocess.run([sys.executable, os.path.abspath(__file__), "--child"] + ns, env=env)
