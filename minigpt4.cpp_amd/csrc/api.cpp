@@ -340,13 +340,11 @@ int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t 
         launch_rms_quant(d_x.as<float>(), nullptr, (int)N, (int)n_in, A, act_mask_for(ggml_type), nullptr);
         const QWeight *Wp[3]; float *Yp[3]; const float *Rp[3];
         for (int i = 0; i < n_mat; i++) { Wp[i] = &W[i]; Yp[i] = d_y.as<float>() + (size_t)i * out_each; Rp[i] = d_res.as<float>() + (size_t)i * out_each; }
-        float *old_ws; size_t old_n; get_mmq2_workspace(&old_ws, &old_n);
-        set_mmq2_workspace(d_ws.as<float>(), out_each * n_mat * 16, 0);
+        A.ws = d_ws.as<float>(); A.ws_floats = out_each * n_mat * 16;
         if (ks > 0) setenv("MINIGPT4_MMQ2_KS", std::to_string(ks).c_str(), 1);
         const bool ok = launch_mmq2_set(Wp, Yp, residual ? Rp : nullptr, n_mat, A, (int)N, (int)n_out, nullptr);
         unsetenv("MINIGPT4_MMQ2_KS");
         HIP_CHECK(hipDeviceSynchronize());
-        set_mmq2_workspace(old_ws, old_n, 0);
         if (!ok) return 4;
         HIP_CHECK(hipMemcpy(y, d_y.p, out_each * n_mat * 4, hipMemcpyDeviceToHost));
         return 0;
@@ -550,8 +548,8 @@ int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, 
         DevBuf dx((size_t)N * cols * 4), dy(out_each * n_mat * 4), dws(out_each * n_mat * 16 * 4);
         { std::vector<float> hx((size_t)N * cols); for (size_t i = 0; i < hx.size(); i++) hx[i] = (float)((int)(i * 37 % 201) - 100) / 64.0f; HIP_CHECK(hipMemcpy(dx.p, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); }
         launch_rms_quant(dx.as<float>(), nullptr, N, cols, A, act_mask_for(ggml_type), nullptr);
-        float *old_ws; size_t old_n; get_mmq2_workspace(&old_ws, &old_n);
-        set_mmq2_workspace(dws.as<float>(), out_each * n_mat * 16, prop.multiProcessorCount);
+        A.ws = dws.as<float>(); A.ws_floats = out_each * n_mat * 16;
+        set_mmq2_cus(prop.multiProcessorCount);
         if (ks > 0) setenv("MINIGPT4_MMQ2_KS", std::to_string(ks).c_str(), 1);
         const int keep_gen = mmq_enabled();
         set_mmq_enabled(generation);
@@ -572,7 +570,6 @@ int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, 
         (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
         unsetenv("MINIGPT4_MMQ2_KS");
         set_mmq_enabled(keep_gen);
-        set_mmq2_workspace(old_ws, old_n, 0);
         if (us_per_launch) *us_per_launch = ms * 1e3f / (float)iters;
         return 0;
     });

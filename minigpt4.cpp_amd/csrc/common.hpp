@@ -74,6 +74,7 @@ struct ActQ {
     int *sum0 = nullptr;     // [N][K/32]  sum(q) per block
     __half *xh = nullptr;    // [N][K]     fp16-rounded activations (F16 weights)
     float *xf = nullptr;     // [N][K]     fp32 activations (F32 weights)
+    float *ws = nullptr; size_t ws_floats = 0;   // (optional) workspace that travels with the planes: K-split partial sums of the prefill mat-mul (mmq2_kernels.hip)
 };
 enum ActMask : int { ACT_Q8K = 1, ACT_Q80 = 2, ACT_F16 = 4, ACT_F32 = 8 };
 inline int act_mask_for(int wtype) {

@@ -436,7 +436,8 @@ void Engine::alloc_buffers() {
     {   // K-split partial sums of the prefill mat-mul (only prompts short enough to need the extra parallelism use them)
         const size_t slab_floats = (size_t)16 << 20;
         hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, device_));
-        set_mmq2_workspace(reinterpret_cast<float *>(buf_arena_.take(slab_floats * 4)), slab_floats, prop.multiProcessorCount);
+        act_.ws = reinterpret_cast<float *>(buf_arena_.take(slab_floats * 4)); act_.ws_floats = slab_floats;
+        set_mmq2_cus(prop.multiProcessorCount);
     }
     d_tq_cnt_ = reinterpret_cast<unsigned *>(reinterpret_cast<uint8_t *>(d_scratch_) + 4096);   // arrival counters of the tail-fused quantisation (MINIGPT4_TAILQ)
     HIP_CHECK(hipMemset(d_tq_cnt_, 0, 4096));

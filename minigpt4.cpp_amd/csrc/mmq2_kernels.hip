@@ -30,6 +30,9 @@ __device__ __forceinline__ float h2f_b(unsigned short h) { return __half2float(_
 __device__ __forceinline__ v4i ldg16(const void *p) { return *reinterpret_cast<const v4i *>(p); }
 __device__ __forceinline__ v16i zero16() { v16i z; for (int i = 0; i < 16; i++) z[i] = 0; return z; }
 __device__ __forceinline__ int tok_of(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }   // MFMA 32x32 C layout: row (= token) of accumulator register `reg`
+// v_mad_i32_i24: |block dot| < 2^23 (32 x 31 x 127), |scale| < 2^7.  Written as inline asm: from `__mul24(a, b) + c` LLVM emits two v_mul_i32_i24 + one v_add3_u32 per pair
+// (three instructions where two multiply-adds do), and the kernel is bound by exactly these instructions.
+__device__ __forceinline__ int mad24i(int a, int b, int c) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ int sext6(int x) { const int yv = x ^ 0x20202020; const int s = yv & 0x20202020; return yv | (s << 1) | (s << 2); }   // 4 x (6-bit q - 32) as int8
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
                 v16i D[2][2];
 #define MMQ2_ISSUE(jp, b) { const v4i alo_ = *reinterpret_cast<const v4i *>(sq + a_addr[2 * (jp)]), ahi_ = *reinterpret_cast<const v4i *>(sq + a_addr[2 * (jp) + 1]);     \
                             D[b][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo_, wlo[jp], zero16(), 0, 0, 0); D[b][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi_, whi[jp], zero16(), 0, 0, 0); }
-#define MMQ2_MADS(jp, b) { _Pragma("unroll") for (int r = 0; r < 16; r++) isum[r] = __mul24(D[b][1][r], sc[2 * (jp) + 1]) + (__mul24(D[b][0][r], sc[2 * (jp)]) + isum[r]);   \
+#define MMQ2_MADS(jp, b) { _Pragma("unroll") for (int r = 0; r < 16; r++) isum[r] = mad24i(D[b][1][r], sc[2 * (jp) + 1], mad24i(D[b][0][r], sc[2 * (jp)], isum[r]));   \
                            asm volatile("" : "+v"(isum)); }
                 MMQ2_ISSUE(0, 0)
                 __builtin_amdgcn_sched_barrier(0);
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
             PH[0] = h01[0]; PH[2] = h01[1]; PH[1] = h23[0]; PH[3] = h23[1];
         }
         v4i wlo0[4], wlo1[4], whi0[4], whi1[4];
-        int s_lo0[4], s_lo1[4], s_hi0[4], s_hi1[4];
+        unsigned scp[4];                                          // per pair: {unit h = 0: lo, hi | unit h = 1: lo, hi} int8 scales, extracted where they are used (registers)
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const v4i q = *reinterpret_cast<const v4i *>(scratch + sr_addr[p]); const unsigned L = PL[p], H = PH[p];
@@ -337,8 +340,7 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
             whi[0] = sext6(((q[0] >> 4) & 0x0F0F0F0F) | (int)((H << 4) & 0x30303030u)); whi[1] = sext6(((q[1] >> 4) & 0x0F0F0F0F) | (int)((H << 2) & 0x30303030u));
             whi[2] = sext6(((q[2] >> 4) & 0x0F0F0F0F) | (int)(H & 0x30303030u)); whi[3] = sext6(((q[3] >> 4) & 0x0F0F0F0F) | (int)((H >> 2) & 0x30303030u));
             wlo0[p] = hh ? z4 : wlo; wlo1[p] = hh ? wlo : z4; whi0[p] = hh ? z4 : whi; whi1[p] = hh ? whi : z4;
-            const unsigned sc = (unsigned)raw.sc[p];                  // units 2 p, 2 p + 1: {lo, hi} int8 scales each
-            s_lo0[p] = (int)(signed char)(sc & 0xFF); s_hi0[p] = (int)(signed char)((sc >> 8) & 0xFF); s_lo1[p] = (int)(signed char)((sc >> 16) & 0xFF); s_hi1[p] = (int)(signed char)(sc >> 24);
+            scp[p] = (unsigned)raw.sc[p];                             // units 2 p, 2 p + 1: {lo, hi} int8 scales each
         }
         const float dw = h2f_b(raw.d);
         __builtin_amdgcn_sched_barrier(0);
@@ -358,8 +360,8 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
 #define MMQ2_ISSUE6(p, x, b) { const v4i af_ = *reinterpret_cast<const v4i *>(sq + a_addr[2 * (p) + (x)]);                                                  \
                                D[b][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_, (x) ? whi0[p] : wlo0[p], zero16(), 0, 0, 0);                                \
                                D[b][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_, (x) ? whi1[p] : wlo1[p], zero16(), 0, 0, 0); }
-#define MMQ2_MADS6(p, x, b) { const int sa_ = (x) ? s_hi0[p] : s_lo0[p], sb_ = (x) ? s_hi1[p] : s_lo1[p];                                                   \
-                              _Pragma("unroll") for (int r = 0; r < 16; r++) isum[r] = __mul24(D[b][1][r], sb_) + (__mul24(D[b][0][r], sa_) + isum[r]);        \
+#define MMQ2_MADS6(p, x, b) { const int sa_ = (int)(signed char)((scp[p] >> (8 * (x))) & 0xFF), sb_ = (int)(signed char)((scp[p] >> (16 + 8 * (x))) & 0xFF);                                                   \
+                              _Pragma("unroll") for (int r = 0; r < 16; r++) isum[r] = mad24i(D[b][1][r], sb_, mad24i(D[b][0][r], sa_, isum[r]));        \
                               asm volatile("" : "+v"(isum)); }
                 MMQ2_ISSUE6(0, 0, 0)
                 __builtin_amdgcn_sched_barrier(0);
@@ -406,9 +408,7 @@ __global__ __launch_bounds__(256) void k_mmq2_reduce(const float *__restrict__ s
 bool mmq2_supported(int type, int rows, int cols) { return (type == GT_Q4_K || type == GT_Q5_K || type == GT_Q6_K) && cols % 256 == 0 && rows >= 32; }
 
 static int g_mmq2_cus = 256;
-static float *g_mmq2_slabs = nullptr; static size_t g_mmq2_slab_floats = 0;
-void get_mmq2_workspace(float **slabs, size_t *n_floats) { *slabs = g_mmq2_slabs; *n_floats = g_mmq2_slab_floats; }
-void set_mmq2_workspace(float *slabs, size_t n_floats, int cus) { g_mmq2_slabs = slabs; g_mmq2_slab_floats = n_floats; if (cus > 0) g_mmq2_cus = cus; }
+void set_mmq2_cus(int cus) { if (cus > 0) g_mmq2_cus = cus; }
 
 template <typename KernelT>
 static void mmq2_launch_kernel(KernelT kernel, bool &attr_done, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
@@ -445,14 +445,14 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     const int wgs = n * a.groups_each * n_chunks;
     int ks = 1;
     const size_t out_floats = (size_t)N * ldy;
-    while (wgs * ks < 2 * g_mmq2_cus && NSB / (ks + 1) >= 4 && g_mmq2_slabs && (size_t)(ks + 1) * out_floats * n <= g_mmq2_slab_floats) ks++;
-    if (getenv("MINIGPT4_MMQ2_KS")) ks = std::max(1, std::min(atoi(getenv("MINIGPT4_MMQ2_KS")), std::min(NSB, g_mmq2_slabs ? (int)(g_mmq2_slab_floats / std::max<size_t>(1, out_floats * n)) : 1)));
+    while (wgs * ks < 2 * g_mmq2_cus && NSB / (ks + 1) >= 4 && A.ws && (size_t)(ks + 1) * out_floats * n <= A.ws_floats) ks++;
+    if (getenv("MINIGPT4_MMQ2_KS")) ks = std::max(1, std::min(atoi(getenv("MINIGPT4_MMQ2_KS")), std::min(NSB, A.ws ? (int)(A.ws_floats / std::max<size_t>(1, out_floats * n)) : 1)));
     a.sb_per_split = (NSB + ks - 1) / ks;
     ks = (NSB + a.sb_per_split - 1) / a.sb_per_split;
     if (ks > 1) {
         if ((size_t)ldy % 4 || out_floats % 4) return false;
         a.slab_stride = (long long)out_floats;
-        for (int i = 0; i < n; i++) { a.y[i] = g_mmq2_slabs + (size_t)i * ks * out_floats; a.res[i] = nullptr; }
+        for (int i = 0; i < n; i++) { a.y[i] = A.ws + (size_t)i * ks * out_floats; a.res[i] = nullptr; }
     }
     const dim3 grid((unsigned)(n * a.groups_each), (unsigned)n_chunks, (unsigned)ks);
     const int type = W[0]->type;
@@ -465,7 +465,7 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     if (ks > 1) {
         for (int i = 0; i < n; i++) {
             const size_t n4 = out_floats / 4;
-            hipLaunchKernelGGL(k_mmq2_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g_mmq2_slabs + (size_t)i * ks * out_floats, ks, (long long)out_floats, residual ? residual[i] : nullptr, y[i], n4);
+            hipLaunchKernelGGL(k_mmq2_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, A.ws + (size_t)i * ks * out_floats, ks, (long long)out_floats, residual ? residual[i] : nullptr, y[i], n4);
         }
     }
     return true;
