@@ -37,7 +37,7 @@ MINIGPT4_API int minigpt4_amd_sample(struct MiniGPT4Context *ctx, int32_t *token
 MINIGPT4_API int minigpt4_amd_decode_loop(struct MiniGPT4Context *ctx, int steps, int32_t *tokens_out, float *ms_total);
 /* hipEvent-bracketed timing of every quantised mat-vec launch over `steps` eager decode steps.
  * out_ms / out_bytes / out_launches are indexed by ggml type id (length 20); other_ms = everything else in the steps. */
-MINIGPT4_API int minigpt4_amd_profile_decode(struct MiniGPT4Context *ctx, int steps, double *out_ms, double *out_bytes, long *out_launches, double *other_ms);
+MINIGPT4_API int minigpt4_amd_profile_sites(struct MiniGPT4Context *ctx, int steps, char *json_out, size_t capacity);   /* per-launch-site table of `steps` eager decode steps (the captured graph's launch set): JSON, see Engine::profile_sites; 2 = buffer too small */
 MINIGPT4_API double minigpt4_amd_weight_bytes_per_token(struct MiniGPT4Context *ctx);
 MINIGPT4_API float minigpt4_amd_last_encode_ms(struct MiniGPT4Context *ctx);     /* hipEvent time of the last minigpt4_encode_image */
 MINIGPT4_API int minigpt4_amd_sync(struct MiniGPT4Context *ctx);

@@ -210,11 +210,9 @@ int minigpt4_amd_decode_loop(struct MiniGPT4Context *ctx, int steps, int32_t *to
     if (!ctx) return 1;
     return guarded(1, [&] { return E_(ctx)->decode_loop(steps, tokens_out, ms_total); });
 }
-int minigpt4_amd_profile_decode(struct MiniGPT4Context *ctx, int steps, double *out_ms, double *out_bytes, long *out_launches, double *other_ms) {
-    if (!ctx) return 1;
-    return guarded(1, [&] { ProfStat st[20], other; const int rc = E_(ctx)->profile_decode(steps, st, &other);
-        for (int i = 0; i < 20; i++) { if (out_ms) out_ms[i] = st[i].ms; if (out_bytes) out_bytes[i] = st[i].bytes; if (out_launches) out_launches[i] = st[i].launches; }
-        if (other_ms) *other_ms = other.ms; return rc; });
+int minigpt4_amd_profile_sites(struct MiniGPT4Context *ctx, int steps, char *json_out, size_t capacity) {
+    if (!ctx || !json_out || capacity < 2) return 1;
+    return guarded(1, [&] { std::string js; const int rc = E_(ctx)->profile_sites(steps, js); if (rc) return rc; if (js.size() + 1 > capacity) return 2; memcpy(json_out, js.c_str(), js.size() + 1); return 0; });
 }
 double minigpt4_amd_weight_bytes_per_token(struct MiniGPT4Context *ctx) { return ctx ? (double)E_(ctx)->weight_bytes_per_token() : 0.0; }
 float minigpt4_amd_last_encode_ms(struct MiniGPT4Context *ctx) { return ctx ? E_(ctx)->last_encode_ms() : 0.0f; }

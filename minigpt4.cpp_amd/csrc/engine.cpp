@@ -77,7 +77,7 @@ void Engine::release_buffers() {
 }
 Engine::~Engine() {
     if (stream_) (void)hipStreamSynchronize(stream_);
-    for (auto &e : prof_events_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &e : site_events_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (stage_) (void)hipFree(stage_);
     release_buffers();
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -466,7 +466,21 @@ void Engine::alloc_buffers() {
 // One launch for 1..3 same-shape matrices when decoding (v2 persistent-wave kernel); otherwise one k_mul_mat launch per matrix.
 // prep != null: the activation row still has to be prepared (rms_norm*w | identity | silu(a)*b + quantisation); when decoding it is fused into
 // the mat-vec prologue, otherwise the standalone preparation kernel runs first.
-bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair) {
+void Engine::site_begin(const char *site, double bytes, hipStream_t s) {
+    if (!prof_on_) return;
+    SiteEv ev{}; ev.site = site; ev.bytes = bytes;
+    HIP_CHECK(hipEventCreate(&ev.a)); HIP_CHECK(hipEventCreate(&ev.b));
+    reset_kernel_name();
+    HIP_CHECK(hipEventRecord(ev.a, s));
+    site_events_.push_back(ev);
+}
+void Engine::site_end(hipStream_t s) {
+    if (!prof_on_ || site_events_.empty()) return;
+    SiteEv &ev = site_events_.back();
+    HIP_CHECK(hipEventRecord(ev.b, s));
+    ev.kernel = last_kernel_name();
+}
+bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair, const char *site) {
     bool same = true;
     int mask = 0;
     for (int i = 0; i < n; i++) { mask |= act_mask_for(W[i]->type); if (i) same = same && W[i]->type == W[0]->type && W[i]->rows == W[0]->rows && W[i]->cols == W[0]->cols; }
@@ -474,15 +488,13 @@ bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
     fuse = fuse && v2 && prep && matvec_prologue_supported(W[0]->type, W[0]->cols);
     silu_pair = silu_pair && v2 && n == 2 && !res && matvec_silu_pair_supported(W[0]->type, W[0]->cols) && (!fuse || prep->kind == 1);
     if (prep && !fuse) {   // standalone preparation
+        SiteScope sc(this, "prepare", 0.0, s);
         if (prep->kind == 1) launch_rms_quant(prep->x, prep->w, N, W[0]->cols, act_, mask, s);
         else launch_silu_mul_quant(prep->x, prep->kind == 3 ? prep->w : nullptr, N, W[0]->cols, act_, mask, tabs_, s);
     }
-    ProfEv ev{};
-    if (prof_on_) {
-        HIP_CHECK(hipEventCreate(&ev.a)); HIP_CHECK(hipEventCreate(&ev.b)); ev.type = W[0]->type; ev.bytes = 0;
-        for (int i = 0; i < n; i++) ev.bytes += (double)W[i]->bytes;
-        HIP_CHECK(hipEventRecord(ev.a, s));
-    }
+    double wbytes = 0;
+    for (int i = 0; i < n; i++) wbytes += (double)W[i]->bytes;
+    SiteScope sc(this, site, wbytes, s);
     bool done = false;
     if (N >= 5 && same && mmq_enabled() >= 2) done = launch_mmq2_set(W, y, res, n, act_, N, ldy, s);   // prefill: one launch for the set, weights streamed once per <= 128 rows
     if (!done && silu_pair) {   // the pair epilogue needs the two matrices equally spaced; launch_matvec_set refuses otherwise and the plain launch below runs
@@ -500,25 +512,27 @@ bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
             if (!(N == 1 && use_v2_ && launch_matvec_set(Wp, Yp, Rp, 1, act_, s))) launch_mul_mat(*W[i], act_, N, y[i], ldy, res ? res[i] : nullptr, s);
         }
     }
-    if (prof_on_) { HIP_CHECK(hipEventRecord(ev.b, s)); prof_events_.push_back(ev); }
     return silu_pair;
 }
-void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse) {
+void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse, const char *site) {
     const QWeight *Wp[1] = {&W}; float *Yp[1] = {y}; const float *Rp[1] = {residual};
-    mul_mat_set(Wp, Yp, Rp, 1, N, ldy, s, prep, fuse);
+    mul_mat_set(Wp, Yp, Rp, 1, N, ldy, s, prep, fuse, false, site);
 }
 
 // wq|wk and a differently typed wv (k-quant "more bits" layers) in one launch; returns false when the shapes / types are outside the mixed kernel's range.
 bool Engine::mixed_qkv(const LayerW &L, hipStream_t s, bool fuse) {
-    if (!use_v2_ || prof_on_) return false;   // the per-type profile wants one type per launch
+    if (!use_v2_) return false;
     const int E = (int)llm_.n_embd;
+    SiteScope sc(this, "qkv", (double)(L.wq.bytes + L.wk.bytes + L.wv.bytes), s);
     const QWeight *W1[2] = {&L.wq, &L.wk}, *W2[1] = {&L.wv}; float *Y1[2] = {q_, k_}, *Y2[1] = {v_};
     if (act_mask_for(L.wq.type) != ACT_Q8K || act_mask_for(L.wv.type) != ACT_Q8K) return false;
     if (fuse && matvec_prologue_supported(L.wq.type, E)) { if (launch_matvec_mixed(W1, Y1, 2, W2, Y2, 1, act_, s, 1, x_, L.attn_norm)) return true; }
     // standalone preparation, then the mixed launch; if that is refused the caller's per-type launches find the row already prepared
     launch_rms_quant(x_, L.attn_norm, 1, E, act_, ACT_Q8K, s);
     if (launch_matvec_mixed(W1, Y1, 2, W2, Y2, 1, act_, s)) return true;
+    const bool keep = prof_on_; prof_on_ = false;                          // the enclosing site already covers these launches
     mul_mat_set(W1, Y1, nullptr, 2, 1, E, s, nullptr, false); mul_mat(L.wv, 1, v_, E, nullptr, s, nullptr, false);
+    prof_on_ = keep;
     return true;
 }
 
@@ -531,7 +545,7 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
     const bool dec = N == 1;
     // feed: the row is the decode token kept in d_feed (greedy feedback / set by eval_chunk); otherwise the rows are described by d_tokens_ (id, or -1 = an
     // embedding row already sitting in x_) -- a chunk of exactly ONE embedding row must not pick up the stale decode token
-    if (from_tokens) launch_get_rows(tok_type_, tok_raw_, E, feed ? d_feed : d_tokens_, N, x_, s);
+    if (from_tokens) { SiteScope sc(this, "embed", (double)gt_nbytes(tok_type_, (size_t)E) * N, s); launch_get_rows(tok_type_, tok_raw_, E, feed ? d_feed : d_tokens_, N, x_, s); }
     auto fz = [&](int bit) { return dec && (fuse_mask_ >> bit & 1); };
     for (size_t il = 0; il < layers_.size(); il++) {
         const LayerW &L = layers_[il];
@@ -539,42 +553,46 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
         const Prep p_attn{1, x_, L.attn_norm}, p_att{2, att_, nullptr}, p_ffn{1, x_, L.ffn_norm}, p_silu{3, h1_, h3_};
         {
             const QWeight *W3[3] = {&L.wq, &L.wk, &L.wv}; float *Y3[3] = {q_, k_, v_};
-            if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s, &p_attn, fz(0));
+            if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s, &p_attn, fz(0), false, "qkv");
             else if (fz(6) && L.wk.type == L.wq.type && mixed_qkv(L, s, fz(0))) {}
             else if (act_mask_for(L.wv.type) == act_mask_for(L.wq.type) && !fz(0)) {   // one standalone preparation serves both launches
                 launch_rms_quant(x_, L.attn_norm, N, E, act_, act_mask_for(L.wq.type), s);
-                mul_mat_set(W3, Y3, nullptr, 2, N, E, s, nullptr, false); mul_mat(L.wv, N, v_, E, nullptr, s, nullptr, false);
-            } else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s, &p_attn, fz(0)); mul_mat(L.wv, N, v_, E, nullptr, s, &p_attn, fz(0)); }
+                mul_mat_set(W3, Y3, nullptr, 2, N, E, s, nullptr, false, false, "qk"); mul_mat(L.wv, N, v_, E, nullptr, s, nullptr, false, "v");
+            } else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s, &p_attn, fz(0), false, "qk"); mul_mat(L.wv, N, v_, E, nullptr, s, &p_attn, fz(0), "v"); }
         }
+        // algorithmic bytes of the attention site: the cached fp16 K and V rows of every head up to the current position
+        SiteScope *att_sc = prof_on_ ? new SiteScope(this, "attention", 4.0 * (double)E * (double)(conv_[sl].n_committed + N), s) : nullptr;
         if (dec) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, true, s);
         else {
             launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s);
             if (!(attn_prefill_ && launch_attn_prefill(q_, kc, vc, N, H, hd, d_npast, conv_[sl].n_committed + N, tabs_, att_, s)))
                 launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, false, s);
         }
-        mul_mat(L.wo, N, x_, E, x_, s, &p_att, fz(1));
+        delete att_sc;
+        mul_mat(L.wo, N, x_, E, x_, s, &p_att, fz(1), "wo");
         bool paired = false;   // h1_ already holds silu(w1 x) * (w3 x)
         bool h_ready = false;  // act_ already holds the quantised silu(w1 x) * (w3 x) (tail-fused preparation)
-        if (dec && tailq_ && fz(2) && L.w1.type == L.w3.type && !prof_on_) {
+        if (dec && tailq_ && fz(2) && L.w1.type == L.w3.type) {
             const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_};
+            SiteScope sc(this, "w1w3", (double)(L.w1.bytes + L.w3.bytes), s);
             h_ready = launch_matvec_tailq(W2, Y2, act_, s, x_, L.ffn_norm, tabs_, tailq_ == 1 ? d_tq_cnt_ : nullptr, 1024, act_, act_mask_for(L.w2.type));
         }
         const bool w13_done = h_ready;
         if (tailq_ != 1) h_ready = false;
         if (w13_done) {}
-        else if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5)); }
+        else if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5), "w1w3"); }
         else if (act_mask_for(L.w1.type) == act_mask_for(L.w3.type) && !fz(2)) {
             launch_rms_quant(x_, L.ffn_norm, N, E, act_, act_mask_for(L.w1.type), s);
-            mul_mat(L.w1, N, h1_, F, nullptr, s, nullptr, false); mul_mat(L.w3, N, h3_, F, nullptr, s, nullptr, false);
-        } else { mul_mat(L.w1, N, h1_, F, nullptr, s, &p_ffn, fz(2)); mul_mat(L.w3, N, h3_, F, nullptr, s, &p_ffn, fz(2)); }
+            mul_mat(L.w1, N, h1_, F, nullptr, s, nullptr, false, "w1"); mul_mat(L.w3, N, h3_, F, nullptr, s, nullptr, false, "w3");
+        } else { mul_mat(L.w1, N, h1_, F, nullptr, s, &p_ffn, fz(2), "w1"); mul_mat(L.w3, N, h3_, F, nullptr, s, &p_ffn, fz(2), "w3"); }
         const Prep p_h{2, h1_, nullptr};
-        mul_mat(L.w2, N, x_, E, x_, s, h_ready ? nullptr : (paired ? &p_h : &p_silu), fz(3));
+        mul_mat(L.w2, N, x_, E, x_, s, h_ready ? nullptr : (paired ? &p_h : &p_silu), fz(3), "w2");
     }
     // only the last token's logits are kept (llama.cpp logits_all = false)
     const Prep p_out{1, x_ + (size_t)(N - 1) * E, norm_};
-    mul_mat(output_, 1, logits, V, nullptr, s, &p_out, fz(4));
-    launch_argmax(logits, V, d_argmax, d_scratch_, s);
-    launch_advance(d_npast, N, d_feed, d_argmax, s);
+    mul_mat(output_, 1, logits, V, nullptr, s, &p_out, fz(4), "output");
+    { SiteScope sc(this, "argmax", (double)V * 4, s); launch_argmax(logits, V, d_argmax, d_scratch_, s); }
+    { SiteScope sc(this, "advance", 0.0, s); launch_advance(d_npast, N, d_feed, d_argmax, s); }
     HIP_CHECK(hipMemcpyAsync(h_argmax_ + sl, d_argmax, 4, hipMemcpyDeviceToHost, s));
 }
 
@@ -753,28 +771,45 @@ int Engine::decode_loop(int steps, int *tokens_out, float *ms_total) {
     return 0;
 }
 
-int Engine::profile_decode(int steps, ProfStat *by_type, ProfStat *other) {
+int Engine::profile_sites(int steps, std::string &json) {
     if (flush()) return 1;
     Conversation &cv = conv_[(size_t)cur_];
     if (steps <= 0 || cv.n_past + steps > n_ctx_) return 1;
     HIP_CHECK(hipStreamSynchronize(stream_));
-    prof_on_ = true;
+    prof_on_ = true; kernel_name_tracing(true);
     hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
     HIP_CHECK(hipEventRecord(a, stream_));
     int tok = h_argmax_[cur_];
-    for (int i = 0; i < steps; i++) { if (eval_chunk(&tok, 1, nullptr)) { prof_on_ = false; return 1; } cv.n_past += 1; HIP_CHECK(hipStreamSynchronize(stream_)); tok = h_argmax_[cur_]; }
+    for (int i = 0; i < steps; i++) {
+        if (eval_chunk(&tok, 1, nullptr)) { prof_on_ = false; kernel_name_tracing(false); return 1; }
+        cv.n_past += 1;
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        tok = h_argmax_[cur_];
+    }
     HIP_CHECK(hipEventRecord(b, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
-    prof_on_ = false;
-    for (int i = 0; i < 20; i++) by_type[i] = ProfStat{};
-    double mm_ms = 0;
-    for (auto &e : prof_events_) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, e.a, e.b));
-        if (e.type >= 0 && e.type < 20) { by_type[e.type].ms += ms; by_type[e.type].bytes += e.bytes; by_type[e.type].launches++; } mm_ms += ms;
-        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    prof_events_.clear();
+    prof_on_ = false; kernel_name_tracing(false);
+    struct Agg { std::string site, kernel; double us = 0, bytes = 0; long calls = 0; };
+    std::vector<Agg> agg;                                                    // first-seen order = launch order within the step
+    for (auto &e : site_events_) {
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, e.a, e.b));
+        size_t k = 0;
+        while (k < agg.size() && !(agg[k].site == e.site && agg[k].kernel == e.kernel)) k++;
+        if (k == agg.size()) { agg.push_back(Agg{}); agg[k].site = e.site; agg[k].kernel = e.kernel; }
+        agg[k].us += ms * 1e3; agg[k].bytes += e.bytes; agg[k].calls++;
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    site_events_.clear();
     float tot = 0; HIP_CHECK(hipEventElapsedTime(&tot, a, b));
-    if (other) { other->ms = tot - mm_ms; other->launches = steps; other->bytes = 0; }
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    char buf[768];
+    json = "{\"steps\": " + std::to_string(steps) + ", \"eager_ms_per_step\": " + std::to_string(tot / steps) + ", \"sites\": [";
+    for (size_t k = 0; k < agg.size(); k++) {
+        snprintf(buf, sizeof(buf), "%s{\"site\": \"%s\", \"kernel\": \"%s\", \"calls_per_step\": %.3f, \"avg_us\": %.3f, \"bytes_per_call\": %.1f}", k ? ", " : "", agg[k].site.c_str(),
+                 agg[k].kernel.c_str(), (double)agg[k].calls / steps, agg[k].us / (double)agg[k].calls, agg[k].bytes / (double)agg[k].calls);
+        json += buf;
+    }
+    json += "]}";
     return 0;
 }
 

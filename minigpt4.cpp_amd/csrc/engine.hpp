@@ -22,7 +22,6 @@ struct DeviceArena {
     ~DeviceArena() { release(); }
 };
 
-struct ProfStat { double ms = 0; double bytes = 0; long launches = 0; };
 
 class Engine {
 public:
@@ -75,8 +74,11 @@ public:
     // ---- measurement hooks (bench / tests)
     // K greedy decode steps fed back on the device (no host round trip); returns ms per step via hipEvents.
     int decode_loop(int steps, int *tokens_out, float *ms_total);
-    // per-launch hipEvent timing of every quantised mat-vec in the next `steps` decode steps (eager launches)
-    int profile_decode(int steps, ProfStat *by_type /*[20]*/, ProfStat *other);
+    // Per-launch-site table of the decode step: `steps` eager decode steps issuing EXACTLY the launch set the captured hipGraph replays, a hipEvent pair around every site;
+    // JSON array of {site, kernel (symbol as rocprofv3 prints it), calls_per_step, avg_us, bytes_per_call (algorithmic: weight planes / KV rows the site reads)} + the
+    // whole-step time.  The events serialise nothing (one in-order stream) but add their own record cost between launches, so the table is for attribution; the step time
+    // of record is the graph replay's.
+    int profile_sites(int steps, std::string &json);
     float last_encode_ms() const { return last_encode_ms_; }
 
 private:
@@ -87,8 +89,8 @@ private:
     void forward(int N, bool from_tokens, hipStream_t s, bool feed = false);   // feed: N == 1 and the token comes from d_feed_ (decode)
     void forward_batch(int B, hipStream_t s);          // B decode rows of B conversations: tokens d_btok_[r], conversations d_bslot_[r]
     struct Prep { int kind; const float *x; const float *w; };   // 1: rms_norm(x)*w, 2: x, 3: silu(x)*w -- then quantised for the consumer's type
-    void mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse);
-    bool mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair = false);
+    void mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse, const char *site = "matmul");
+    bool mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair = false, const char *site = "matmul");
     void upload_qweight(const TensorMeta &t, const uint8_t *file_base, QWeight &w);
     template <typename T> T *upload_raw(DeviceArena &a, const void *src, size_t bytes);
 
@@ -135,10 +137,13 @@ private:
     bool use_graph_ = true, use_v2_ = true, attn_prefill_ = true;
     int batch_rows_max_ = 8;                                              // MINIGPT4_BATCH_ROWS_MAX: batches up to this size use the multi-row mat-vec (passes of 4 rows); 0 = never
     static constexpr int FUSE_DEFAULT = 87; int fuse_mask_ = FUSE_DEFAULT;
-    // profiling
+    // profiling (profile_sites)
     bool prof_on_ = false;
-    struct ProfEv { hipEvent_t a, b; int type; double bytes; };
-    std::vector<ProfEv> prof_events_;
+    struct SiteEv { hipEvent_t a, b; const char *site; std::string kernel; double bytes; };
+    std::vector<SiteEv> site_events_;
+    void site_begin(const char *site, double bytes, hipStream_t s);
+    void site_end(hipStream_t s);
+    struct SiteScope { Engine *e; hipStream_t s; SiteScope(Engine *e_, const char *site, double bytes, hipStream_t s_) : e(e_), s(s_) { e->site_begin(site, bytes, s); } ~SiteScope() { e->site_end(s); } };
 
     // vision
     VisionFile vis_;

@@ -52,6 +52,10 @@ bool launch_matvec_rows(const QWeight *const *W, float *const *y, const float *c
 bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, hipStream_t s, int pro = 0,
                          const float *px = nullptr, const float *pw = nullptr);
 void set_matvec_tuning(int waves_per_cu, int fat_threads, int cus);   // 0 = choose per launch
+// measurement: while tracing is on, every launcher of llm_kernels.hip notes the kernel symbol it launched (as rocprofv3 prints it, without the argument list)
+void kernel_name_tracing(bool on);
+const char *last_kernel_name();          // "" when nothing was launched since the last reset
+void reset_kernel_name();
 int read_matvec_timeline(unsigned long long *out, int max_workgroups);   // diagnostic builds (MG4_TIMELINE): stamps of the last decode mat-vec launch; 0 otherwise
 
 // ---- token embedding gather (raw ggml rows, dequantised to f32) -----------------------------------------------------

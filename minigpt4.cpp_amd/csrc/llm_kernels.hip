@@ -8,12 +8,29 @@
 #include "devutil.hpp"
 
 #include <algorithm>
+#include <cstdarg>
+#include <cstring>
 
 namespace mg4 {
 
 // =====================================================================================================================
 // helpers
 // =====================================================================================================================
+// ---- measurement: kernel symbols of the launches (Engine::profile_sites) -----------------------------------------------------------------------------------------
+static bool g_kname_on = false;
+static char g_kname[192] = "";
+void kernel_name_tracing(bool on) { g_kname_on = on; g_kname[0] = 0; }
+void reset_kernel_name() { g_kname[0] = 0; }
+const char *last_kernel_name() { return g_kname; }
+static void note_kernel(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+static void note_kernel(const char *fmt, ...) {
+    if (!g_kname_on) return;
+    char one[128]; va_list ap; va_start(ap, fmt); vsnprintf(one, sizeof(one), fmt, ap); va_end(ap);
+    const size_t have = strlen(g_kname);
+    if (have && have + 3 < sizeof(g_kname)) strcat(g_kname, " + ");
+    strncat(g_kname, one, sizeof(g_kname) - strlen(g_kname) - 1);
+}
+
 __device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 __device__ __forceinline__ float h2f_bits(unsigned short h) { return __half2float(__ushort_as_half(h)); }
 __device__ __forceinline__ unsigned short f2h_bits(float f) { return __half_as_ushort(__float2half_rn(f)); }
@@ -388,6 +405,7 @@ __global__ __launch_bounds__(256) void k_mul_mat(const QWeight W, const ActQ A, 
 
 template <int T>
 static void launch_mul_mat_t(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
+    note_kernel("k_mul_mat<%d, 2, %d>", T, N == 1 ? 1 : 4);
     if (N == 1) {
         constexpr int R = 2;
         dim3 grid((unsigned)((W.rows + 4 * R - 1) / (4 * R)), 1);
@@ -707,6 +725,7 @@ template <int T, int NU, int R, int EPI>
 static void launch_v2_t(const MatSet &ms, const ActQ &A, int pro, const ProArgs &pa, hipStream_t s) {
     const int total_rows = ms.n * ms.rows_each;
     const int n_groups = EPI == EPI_SILU_PAIR ? ms.rows_each : (total_rows + R - 1) / R;
+    note_kernel("k_matvec_v2<%d, %d, %d, %d, %d>", T, NU, R, EPI == EPI_SILU_PAIR && pro != PRO_NONE ? (int)PRO_RMS : pro, (int)EPI);
     if (pro == PRO_NONE) {
         int n_waves = std::min(n_groups, g_mv_cus * pick_waves_per_cu(n_groups, mv_max_wpc<NU>()));
         n_waves = (n_waves + 3) & ~3;
@@ -801,6 +820,7 @@ static void launch_mix_t(const MatSet &m1, const MatSet &m2, double bytes1, doub
             if (c < best_cost) { best_cost = c; best_t = t; best_b1 = b1; best_total = total; }
         }
     }
+    note_kernel("k_matvec_mix<%d, %d, %d, %d>", T1, T2, NU, pro == PRO_NONE ? 0 : 1);
     const int wpb = best_t / 64, nw1 = best_b1 * wpb, nw2 = (best_total - best_b1) * wpb;
     const dim3 grid((unsigned)best_total), block((unsigned)best_t);
     if (pro == PRO_NONE) hipLaunchKernelGGL((k_matvec_mix<T1, T2, NU, PRO_NONE>), grid, block, 0, s, m1, m2, A, pa, ng1, nw1, ng2, nw2);
@@ -1035,6 +1055,7 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
 template <int T, int NU>
 static void launch_tn_t(const MatSet &ms, const ActQ &A, int N, int ldy, hipStream_t s) {
     constexpr int TN = 4;
+    note_kernel("k_matvec_tn<%d, %d, 4>", T, NU);
     const int n_groups = ms.n * ms.rows_each;
     constexpr int WPB = mv_tn_threads<NU>() / 64;
     const int n_blocks = std::min((n_groups + WPB - 1) / WPB, g_mv_cus), n_waves = n_blocks * WPB;
@@ -1194,6 +1215,7 @@ __global__ __launch_bounds__(RQ_THREADS) void k_rms_quant(const float *__restric
     }
 }
 void launch_rms_quant(const float *x, const float *w, int N, int K, const ActQ &A, int mask, hipStream_t s) {
+    note_kernel("k_rms_quant");
     hipLaunchKernelGGL(k_rms_quant, dim3((unsigned)N), dim3(RQ_THREADS), 0, s, x, w, K, A, mask);
 }
 
@@ -1209,6 +1231,7 @@ __global__ __launch_bounds__(256) void k_silu_mul_quant(const float *__restrict_
     quant_emit4(v, in, i, row, K, A, mask);
 }
 void launch_silu_mul_quant(const float *a, const float *b, int N, int K, const ActQ &A, int mask, const Tables &tb, hipStream_t s) {
+    note_kernel("k_silu_mul_quant");
     hipLaunchKernelGGL(k_silu_mul_quant, dim3((unsigned)((K + 1023) / 1024), (unsigned)N), dim3(256), 0, s, a, b, K, A, mask, tb);
 }
 
@@ -1247,6 +1270,7 @@ __global__ void k_get_rows(int type, const uint8_t *__restrict__ table, int K, s
     if (e < K) out[(size_t)t * K + e] = dequant_elem(type, row, e);
 }
 void launch_get_rows(int type, const uint8_t *raw_table, int K, const int *tokens, int N, float *out, hipStream_t s) {
+    note_kernel("k_get_rows");
     hipLaunchKernelGGL(k_get_rows, dim3((unsigned)N, (unsigned)((K + 255) / 256)), dim3(256), 0, s, type, raw_table, K, gt_nbytes(type, (size_t)K), tokens, out);
 }
 
@@ -1432,6 +1456,7 @@ static void launch_attn_hd(float *q, const float *k, const float *v, __half *kc,
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    note_kernel("k_attn_llm<%d, %s, false>", HD, fused ? "true" : "false");
     if (fused) hipLaunchKernelGGL((k_attn_llm<HD, true>), dim3((unsigned)n_head, 1), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out);
     else hipLaunchKernelGGL((k_attn_llm<HD, false>), dim3((unsigned)n_head, (unsigned)N), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out);
 }
@@ -1627,6 +1652,7 @@ __global__ __launch_bounds__(64) void k_argmax_final(const float *__restrict__ p
 }
 // first maximum wins, like llama_sample_token_greedy.  `scratch` holds AM_BLOCKS floats + AM_BLOCKS ints.
 void launch_argmax(const float *logits, int n, int *out, void *scratch, hipStream_t s) {
+    note_kernel("k_argmax_part"); note_kernel("k_argmax_final");
     float *pv = static_cast<float *>(scratch); int *pi = reinterpret_cast<int *>(pv + AM_BLOCKS);
     hipLaunchKernelGGL(k_argmax_part, dim3(AM_BLOCKS), dim3(256), 0, s, logits, n, pv, pi);
     hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(64), 0, s, pv, pi, out);
@@ -1721,6 +1747,6 @@ __global__ void k_batch_begin(int *__restrict__ n_past, const int *__restrict__ 
 void launch_batch_begin(int *n_past, const int *row_slot, const int *row_pos, int B, hipStream_t s) { hipLaunchKernelGGL(k_batch_begin, dim3(1), dim3(64), 0, s, n_past, row_slot, row_pos, B); }
 // end of a decode step: the KV position advances and the greedy token becomes the next input (the host may overwrite it)
 __global__ void k_advance(int *n_past, int n, int *tok0, const int *argmax) { *n_past += n; if (tok0) *tok0 = *argmax; }
-void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, n_past, n, tok0, argmax); }
+void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s) { note_kernel("k_advance"); hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, n_past, n, tok0, argmax); }
 
 }  // namespace mg4

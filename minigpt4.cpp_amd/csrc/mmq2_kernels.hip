@@ -33,6 +33,7 @@ __device__ __forceinline__ int tok_of(int reg, int hh) { return (reg & 3) + 8 * 
 // v_mad_i32_i24: |block dot| < 2^23 (32 x 31 x 127), |scale| < 2^7.  Written as inline asm: from `__mul24(a, b) + c` LLVM emits two v_mul_i32_i24 + one v_add3_u32 per pair
 // (three instructions where two multiply-adds do), and the kernel is bound by exactly these instructions.
 __device__ __forceinline__ int mad24i(int a, int b, int c) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ long pack64(int lo, int hi) { return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo); }
 __device__ __forceinline__ int sext6(int x) { const int yv = x ^ 0x20202020; const int s = yv & 0x20202020; return yv | (s << 1) | (s << 2); }   // 4 x (6-bit q - 32) as int8
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -216,7 +217,10 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
                 v16i D[2][2];
 #define MMQ2_ISSUE(jp, b) { const v4i alo_ = *reinterpret_cast<const v4i *>(sq + a_addr[2 * (jp)]), ahi_ = *reinterpret_cast<const v4i *>(sq + a_addr[2 * (jp) + 1]);     \
                             D[b][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo_, wlo[jp], zero16(), 0, 0, 0); D[b][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi_, whi[jp], zero16(), 0, 0, 0); }
-#define MMQ2_MADS(jp, b) { _Pragma("unroll") for (int r = 0; r < 16; r++) isum[r] = mad24i(D[b][1][r], sc[2 * (jp) + 1], mad24i(D[b][0][r], sc[2 * (jp)], isum[r]));   \
+#define MMQ2_MADS(jp, b) { v16i t_;                                                                                                                                  \
+                           _Pragma("unroll") for (int r = 0; r < 16; r++) t_[r] = __mul24(D[b][0][r], sc[2 * (jp)]) + isum[r];                                        \
+                           asm volatile("" : "+v"(t_));      /* one v_mad_i32_i24 per element: without the pin LLVM emits mul, mul, add3 (3 instructions for 2) */      \
+                           _Pragma("unroll") for (int r = 0; r < 16; r++) isum[r] = __mul24(D[b][1][r], sc[2 * (jp) + 1]) + t_[r];                                    \
                            asm volatile("" : "+v"(isum)); }
                 MMQ2_ISSUE(0, 0)
                 __builtin_amdgcn_sched_barrier(0);
@@ -257,8 +261,9 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Q6_K.  Unit u = 4 n + 2 c + h: low nibbles (+ 2 high bits) = elements 128 n + 32 c + 16 h + i, high nibbles = the same + 64; int8 scale per 16 elements.
-// Pair p = 2 n + c: lanes hh = 0 / 1 hold units (.., h = 0) / (.., h = 1); the two 16-wide halves of an MFMA's K = 32 carry different scales, so each
-// operand is multiplied twice with the other lane half zeroed.  Weights are q - 32 in int8; no min term.
+// Pair p = 2 n + c: lanes hh = 0 / 1 load units (.., h = 0) / (.., h = 1).  A scale group is 16 weights, so the products run on v_mfma_i32_32x32x16_i8 (K = 16: one group per
+// instruction, 8 bytes per lane; round 1 multiplied K = 32 operands twice with one lane half zeroed, which costs two 4-register operand copies per pair and token tile
+// budget).  Weights are q - 32 in int8; no min term.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int TT>
 __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const ActQ A) {
@@ -300,19 +305,21 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
     for (int n = 0; n < 4; n++) sw_addr[n] = (unsigned)((8 * n + (lane >> 3)) * 128 + (((lane & 7) ^ ((4 * n + (lane >> 4)) & 7)) << 4));
 #pragma unroll
     for (int p = 0; p < 4; p++) sr_addr[p] = (unsigned)(l31 * 128 + (((2 * p + hh) ^ ((l31 >> 1) & 7)) << 4));
-    // A fragments: low part of pair p = 2 n + c at element 128 n + 32 c + 16 hh -> chunk 8 n + 2 c + hh, high part 4 chunks further
-    const int v = hh ^ (lane & 15);
-    unsigned a_addr[8];                                        // [2 p + x]: chunk base (8 n + 2 c + 4 x), bit 0 (hh) folded into v
+    // A fragments (8 bytes per lane): group gsel of the low (x = 0) / high (x = 1) part of pair p = 2 n + c = elements 128 n + 32 c + 64 x + 16 gsel + 8 hh .. + 7
+    // -> chunk 8 n + 2 c + 4 x + gsel of the token's row (stored at slot chunk ^ (token & 15)), byte 8 hh within it
+    const int tk = lane & 15;
+    unsigned a_addr[16];                                       // [4 p + 2 x + gsel]
 #pragma unroll
     for (int p = 0; p < 4; p++)
 #pragma unroll
-        for (int x = 0; x < 2; x++) a_addr[2 * p + x] = (unsigned)(l31 * 256 + (((8 * (p >> 1) + 2 * (p & 1) + 4 * x) ^ v) << 4));
+        for (int x = 0; x < 2; x++)
+#pragma unroll
+            for (int gs = 0; gs < 2; gs++) a_addr[4 * p + 2 * x + gs] = (unsigned)(l31 * 256 + (((8 * (p >> 1) + 2 * (p & 1) + 4 * x + gs) ^ tk) << 4) + 8 * hh);
     const unsigned dk_addr = (unsigned)(S::Q8 + S::BS + 16 * hh);
 
     Raw raw;
     fetch(sb0, raw);
     mmq2_stage_load<TT>(A, K, NSB, N, t0, sb0, smem_mmq2, wv, lane);
-    const v4i z4 = {0, 0, 0, 0};
     for (int sb = sb0; sb < sb1; sb++) {
         const int buf = (sb - sb0) & 1;
         unsigned char *st = smem_mmq2 + buf * S::BYTES;
@@ -329,7 +336,10 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
             PL[0] = l01[0]; PL[2] = l01[1]; PL[1] = l23[0]; PL[3] = l23[1];
             PH[0] = h01[0]; PH[2] = h01[1]; PH[1] = h23[0]; PH[3] = h23[1];
         }
-        v4i wlo0[4], wlo1[4], whi0[4], whi1[4];
+        // MFMA B operands (v_mfma_i32_32x32x16_i8: 8 bytes per lane, one 16-weight scale group per instruction): after the unpack lane (row, h) holds the 16 weights of
+        // group h; one permlane32_swap per dword pair leaves lane (row, 0) with elements 0..7 and lane (row, 1) with elements 8..15 of BOTH groups:
+        // wl[p] = {group h = 0: 2 dwords | group h = 1: 2 dwords} of the low-nibble part, wh[p] of the high-nibble part
+        v4i wl[4], wh[4];
         unsigned scp[4];                                          // per pair: {unit h = 0: lo, hi | unit h = 1: lo, hi} int8 scales, extracted where they are used (registers)
 #pragma unroll
         for (int p = 0; p < 4; p++) {
@@ -339,7 +349,15 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
             wlo[2] = sext6((q[2] & 0x0F0F0F0F) | (int)(L & 0x30303030u)); wlo[3] = sext6((q[3] & 0x0F0F0F0F) | (int)((L >> 2) & 0x30303030u));
             whi[0] = sext6(((q[0] >> 4) & 0x0F0F0F0F) | (int)((H << 4) & 0x30303030u)); whi[1] = sext6(((q[1] >> 4) & 0x0F0F0F0F) | (int)((H << 2) & 0x30303030u));
             whi[2] = sext6(((q[2] >> 4) & 0x0F0F0F0F) | (int)(H & 0x30303030u)); whi[3] = sext6(((q[3] >> 4) & 0x0F0F0F0F) | (int)((H >> 2) & 0x30303030u));
-            wlo0[p] = hh ? z4 : wlo; wlo1[p] = hh ? wlo : z4; whi0[p] = hh ? z4 : whi; whi1[p] = hh ? whi : z4;
+            {   // permlane32_swap(X, Y) exchanges X's lanes 32..63 with Y's lanes 0..31.  X = w[0] = (hh = 0: g0[0..3] | hh = 1: g1[0..3]), Y = w[2] = (g0[8..11] | g1[8..11])
+                // -> X' = (g0[0..3] | g0[8..11]) = group 0, Y' = (g1[0..3] | g1[8..11]) = group 1; likewise w[1] / w[3] for elements 4..7 / 12..15
+                const auto l0 = __builtin_amdgcn_permlane32_swap((unsigned)wlo[0], (unsigned)wlo[2], false, false);
+                const auto l1 = __builtin_amdgcn_permlane32_swap((unsigned)wlo[1], (unsigned)wlo[3], false, false);
+                const auto h0 = __builtin_amdgcn_permlane32_swap((unsigned)whi[0], (unsigned)whi[2], false, false);
+                const auto h1 = __builtin_amdgcn_permlane32_swap((unsigned)whi[1], (unsigned)whi[3], false, false);
+                wl[p] = v4i{(int)l0[0], (int)l1[0], (int)l0[1], (int)l1[1]};
+                wh[p] = v4i{(int)h0[0], (int)h1[0], (int)h0[1], (int)h1[1]};
+            }
             scp[p] = (unsigned)raw.sc[p];                             // units 2 p, 2 p + 1: {lo, hi} int8 scales each
         }
         const float dw = h2f_b(raw.d);
@@ -357,11 +375,15 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
                 const unsigned char *sq = st + tt * 8192;
                 v16i isum = zero16();
                 v16i D[2][2];
-#define MMQ2_ISSUE6(p, x, b) { const v4i af_ = *reinterpret_cast<const v4i *>(sq + a_addr[2 * (p) + (x)]);                                                  \
-                               D[b][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_, (x) ? whi0[p] : wlo0[p], zero16(), 0, 0, 0);                                \
-                               D[b][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_, (x) ? whi1[p] : wlo1[p], zero16(), 0, 0, 0); }
+#define MMQ2_ISSUE6(p, x, b) { const long a0_ = *reinterpret_cast<const long *>(sq + a_addr[4 * (p) + 2 * (x)]), a1_ = *reinterpret_cast<const long *>(sq + a_addr[4 * (p) + 2 * (x) + 1]); \
+                               const v4i w_ = (x) ? wh[p] : wl[p];                                                                                               \
+                               D[b][0] = __builtin_amdgcn_mfma_i32_32x32x16_i8(a0_, pack64(w_[0], w_[1]), zero16(), 0, 0, 0);                                    \
+                               D[b][1] = __builtin_amdgcn_mfma_i32_32x32x16_i8(a1_, pack64(w_[2], w_[3]), zero16(), 0, 0, 0); }
 #define MMQ2_MADS6(p, x, b) { const int sa_ = (int)(signed char)((scp[p] >> (8 * (x))) & 0xFF), sb_ = (int)(signed char)((scp[p] >> (16 + 8 * (x))) & 0xFF);                                                   \
-                              _Pragma("unroll") for (int r = 0; r < 16; r++) isum[r] = mad24i(D[b][1][r], sb_, mad24i(D[b][0][r], sa_, isum[r]));        \
+                              v16i t_;                                                                                                                        \
+                              _Pragma("unroll") for (int r = 0; r < 16; r++) t_[r] = __mul24(D[b][0][r], sa_) + isum[r];                                            \
+                              asm volatile("" : "+v"(t_));                                                                                                          \
+                              _Pragma("unroll") for (int r = 0; r < 16; r++) isum[r] = __mul24(D[b][1][r], sb_) + t_[r];                                            \
                               asm volatile("" : "+v"(isum)); }
                 MMQ2_ISSUE6(0, 0, 0)
                 __builtin_amdgcn_sched_barrier(0);
@@ -437,7 +459,8 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     for (int i = 0; i < n; i++) { a.w[i] = *W[i]; a.y[i] = y[i]; a.res[i] = residual ? residual[i] : nullptr; }
     a.n_mat = n; a.groups_each = (W[0]->rows + 127) / 128; a.N = N; a.ldy = ldy;
     a.n_tiles = (N + 31) / 32;
-    const int max_tt = W[0]->type == GT_Q6_K ? 2 : 3;          // token tiles per chunk the 256-register budget (two waves per SIMD) admits: Q6_K keeps four half-masked operand sets per pair
+    int max_tt = W[0]->type == GT_Q6_K ? 2 : 3;          // token tiles per chunk the 256-register budget (two waves per SIMD) admits: Q6_K keeps four half-masked operand sets per pair
+    { static int tt_env = -1; if (tt_env < 0) { const char *e = getenv("MINIGPT4_MMQ2_TT"); tt_env = e ? atoi(e) : 0; } if (tt_env > 0) max_tt = std::min(max_tt, tt_env); }   // experiments
     const int n_chunks = (a.n_tiles + max_tt - 1) / max_tt;
     a.tiles_per_chunk = (a.n_tiles + n_chunks - 1) / n_chunks;
     const int NSB = W[0]->cols / 256;

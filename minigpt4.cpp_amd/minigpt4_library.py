@@ -111,7 +111,7 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_tokenize.argtypes = [VOID_PTR, CHAR_PTR, I32, INT_PTR, I32]
         L.minigpt4_amd_sample.argtypes = [VOID_PTR, INT_PTR, F32, I32, F32, F32, F32, I32, F32, F32]
         L.minigpt4_amd_decode_loop.argtypes = [VOID_PTR, I32, INT_PTR, FLOAT_PTR]
-        L.minigpt4_amd_profile_decode.argtypes = [VOID_PTR, I32, P(ctypes.c_double), P(ctypes.c_double), P(ctypes.c_long), P(ctypes.c_double)]
+        L.minigpt4_amd_profile_sites.argtypes = [VOID_PTR, I32, ctypes.c_char_p, SIZE_T]
         L.minigpt4_amd_weight_bytes_per_token.argtypes = [VOID_PTR]
         L.minigpt4_amd_weight_bytes_per_token.restype = ctypes.c_double
         L.minigpt4_amd_last_encode_ms.argtypes = [VOID_PTR]
@@ -281,15 +281,14 @@ class MiniGPT4SharedLibrary:
             raise RuntimeError("decode_loop failed: " + self.library.minigpt4_amd_last_error().decode())
         return toks, float(ms.value)
 
-    def amd_profile_decode(self, ctx, steps: int):
-        ms = (ctypes.c_double * 20)()
-        by = (ctypes.c_double * 20)()
-        ln = (ctypes.c_long * 20)()
-        other = ctypes.c_double()
-        rc = self.library.minigpt4_amd_profile_decode(ctx.ptr, steps, ms, by, ln, ctypes.byref(other))
+    def amd_profile_sites(self, ctx, steps: int) -> dict:
+        """Per-launch-site table of `steps` eager decode steps (the launch set of the captured graph): {"steps", "eager_ms_per_step", "sites": [{site, kernel, calls_per_step, avg_us, bytes_per_call}]}"""
+        import json as _json
+        buf = ctypes.create_string_buffer(1 << 16)
+        rc = self.library.minigpt4_amd_profile_sites(ctx.ptr, steps, buf, len(buf))
         if rc:
-            raise RuntimeError("profile_decode failed")
-        return {i: {"ms": ms[i], "bytes": by[i], "launches": ln[i]} for i in range(20) if ln[i]}, float(other.value)
+            raise RuntimeError("profile_sites failed")
+        return _json.loads(buf.value.decode())
 
     def amd_test_mul_mat(self, ggml_type: int, raw_w: np.ndarray, n_in: int, n_out: int, x: np.ndarray) -> np.ndarray:
         x = np.ascontiguousarray(x, np.float32).reshape(-1, n_in)

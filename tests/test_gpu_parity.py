@@ -351,8 +351,10 @@ def test_decode_loop_device_feedback_equals_api_path(gpu_lib, tiny_files):
             ids.append(int(tid[0]))
             gpu_lib.amd_eval_tokens(ctx, [int(tid[0])])
         assert ids == [int(t) for t in toks]
-        stats, other = gpu_lib.amd_profile_decode(ctx, 2)
-        assert stats and all(v["ms"] > 0 for v in stats.values())
+        prof = gpu_lib.amd_profile_sites(ctx, 2)                   # the eager launch set with a hipEvent pair per site: same tokens as the graph, a kernel symbol per site
+        sites = {r["site"] for r in prof["sites"]}
+        assert {"embed", "attention", "wo", "w2", "output", "argmax"} <= sites and all(r["avg_us"] > 0 and r["kernel"] for r in prof["sites"])
+        assert any(r["site"] in ("qkv", "qk") for r in prof["sites"]) and prof["eager_ms_per_step"] > 0
     finally:
         gpu_lib.minigpt4_free(ctx)
 
