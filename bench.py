@@ -147,25 +147,19 @@ def cpu_baseline(lp: str, prompt_tokens, budget_s: float = 20.0):
                       f"kernels use, bit-identical to its scalar form; {'-march=native' if native else 'x86-64-v3'}, OpenMP {cores} threads), {dt:.1f}s"}
 
 
-def pmc_traffic(type_name: str):
-    """HBM read bytes per launch of the dominant mat-vec kernel from the newest committed rocprofv3 PMC pass of the decode loop
-    (profiles/*pmc_fetch_size_summary.csv, written by tools/pmc_summary.py: FETCH_SIZE x 1024 x 2, the gfx950 correction of MI355X_MICROARCH.md).
-    PMC counters cannot be read from inside the process, so this is the profile's number, not a live one; None when no summary is committed."""
-    import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_size_summary.csv")))
-    tid = {"q5_k": 13, "q6_k": 14, "q4_0": 2, "q4_k": 12}.get(type_name)
-    if tid is None or not paths:
+def pmc_traffic(kernel_symbol: str):
+    """HBM read bytes per launch of `kernel_symbol` from the NAMED PMC record profiles/pmc_traffic.json (written by tools/roofline_from_profile.py --pmc from a
+    `rocprofv3 --pmc FETCH_SIZE` pass of the decode loop; FETCH_SIZE x 1024 x 2, the gfx950 correction of MI355X_MICROARCH.md; the file records the pass's CSV and command).
+    PMC counters cannot be read from inside the process: this is the committed pass's number for the same kernel symbol, or None when the record has no such kernel."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
         return None, None
-    path = paths[-1]
-    calls, byts = 0, 0.0
-    for line in open(path):
-        if line.startswith('"') and f"k_matvec_v2<{tid}," in line:
-            parts = line.rsplit('",', 1)[1].strip().split(",")
-            calls += int(parts[0])
-            byts += int(parts[0]) * float(parts[-1]) * 1e6
-    if not calls:
-        return None, None
-    return byts / calls, f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction; avg over the k_matvec_v2 launches of this type)"
+    ent = rec.get("kernels", {}).get(kernel_symbol)
+    if not ent:
+        return None, f"profiles/pmc_traffic.json has no entry for {kernel_symbol}"
+    return ent["bytes_per_launch"], f"profiles/pmc_traffic.json <- {rec.get('source_csv')} ({rec.get('command')}); FETCH_SIZE x 1024 x 2 (gfx950), avg over {ent['launches']} launches"
 
 
 def main():
@@ -291,21 +285,40 @@ def main():
         dt = float(tt.item())
     ctx_mid = n_prompt + W + K // 2
 
-    # ---- device-side numbers: graph-replayed decode loop (no host round trip) and per-launch hipEvent timing of the mat-vec kernels
+    # ---- device-side numbers: graph-replayed decode loop (no host round trip), and the per-launch-site table of the SAME launch set the graph replays (eager, a hipEvent
+    # pair around every site on the engine's stream; Engine::profile_sites).  The roofline object is computed from that table, per kernel SYMBOL (a symbol that serves
+    # several sites -- wq|wk|wv and w1|w3 share one -- is aggregated exactly as `rocprofv3 --stats` aggregates it, so tools/roofline_from_profile.py reproduces `frac`
+    # from a committed profiles/*kernel_stats.csv and this table).
     _, loop_ms = lib.amd_decode_loop(ctx, 17)
     dev_ms_per_tok = loop_ms / 16.0
-    stats, other_ms = lib.amd_profile_decode(ctx, 4)
-    dom_t = max(stats, key=lambda k: stats[k]["bytes"])
-    dom = stats[dom_t]
-    names = {0: "f32", 1: "f16", 2: "q4_0", 3: "q4_1", 6: "q5_0", 7: "q5_1", 8: "q8_0", 12: "q4_k", 13: "q5_k", 14: "q6_k"}
-    achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-    pmc = pmc_traffic(names.get(dom_t, ""))
-    roofline = {"bound": "hbm", "kernel": f"k_matvec_v2<{names.get(dom_t, dom_t)}> (persistent-wave fused-dequant int8-dot mat-vec)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc[0], "traffic_source": pmc[1],
-                "avg_launch_us": dom["ms"] * 1e3 / dom["launches"], "bytes_per_launch_avg": dom["bytes"] / dom["launches"],
-                "all_matvec_GBps": sum(s["bytes"] for s in stats.values()) / (sum(s["ms"] for s in stats.values()) * 1e-3) / 1e9,
-                "per_type": {names.get(k, str(k)): {"GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "launches": v["launches"]} for k, v in stats.items()},
-                "non_matvec_ms_per_token": other_ms / 4.0}
+    prof = lib.amd_profile_sites(ctx, 8)
+    by_kernel = {}
+    for r in prof["sites"]:
+        k = by_kernel.setdefault(r["kernel"], {"kernel": r["kernel"], "sites": [], "calls_per_token": 0.0, "us_per_token": 0.0, "bytes_per_token": 0.0})
+        k["sites"].append(r["site"])
+        k["calls_per_token"] += r["calls_per_step"]
+        k["us_per_token"] += r["calls_per_step"] * r["avg_us"]
+        k["bytes_per_token"] += r["calls_per_step"] * r["bytes_per_call"]
+    table = []
+    for k in by_kernel.values():
+        k["avg_us"] = k["us_per_token"] / k["calls_per_token"]
+        k["bytes_per_call"] = k["bytes_per_token"] / k["calls_per_token"]
+        k["GBps"] = k["bytes_per_call"] / (k["avg_us"] * 1e-6) / 1e9 if k["avg_us"] > 0 else 0.0
+        k["sites"] = sorted(set(k["sites"]))
+        table.append(k)
+    table.sort(key=lambda k: -k["us_per_token"])
+    dom = table[0]
+    traffic, traffic_src = pmc_traffic(dom["kernel"])
+    kv_bytes_mid = 4.0 * lcfg.n_embd * lcfg.n_layer * ctx_mid        # fp16 K + V rows of every layer up to the mid-run position
+    roofline = {"bound": "hbm", "kernel": dom["kernel"], "sites": dom["sites"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBPS,
+                "frac_of_measured_copy_peak": dom["GBps"] / 6290.0, "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_us": dom["avg_us"], "bytes_per_launch": dom["bytes_per_call"], "calls_per_token": dom["calls_per_token"],
+                "method": "hipEvent pairs around every launch site of 8 eager decode steps issuing the captured graph's launch set (same kernels, same geometry); algorithmic bytes = the "
+                          "weight planes (or cached K/V rows) the launch reads; per-symbol aggregation like rocprofv3 --stats",
+                "whole_step": {"bytes": wbytes + kv_bytes_mid, "ms": dt * 1e3 / K, "GBps": (wbytes + kv_bytes_mid) / (dt / K) / 1e9, "frac": (wbytes + kv_bytes_mid) / (dt / K) / 1e9 / HBM_PEAK_GBPS},
+                "eager_ms_per_token_with_events": prof["eager_ms_per_step"],
+                "kernel_table": [{"kernel": k["kernel"], "sites": k["sites"], "calls_per_token": round(k["calls_per_token"], 3), "avg_us": round(k["avg_us"], 3),
+                                  "bytes_per_call": round(k["bytes_per_call"], 1), "GBps": round(k["GBps"], 1), "us_per_token": round(k["us_per_token"], 2)} for k in table]}
 
     out = {
         "metric": "decode tokens/sec", "value": K * world / dt, "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,

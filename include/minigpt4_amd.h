@@ -69,9 +69,9 @@ MINIGPT4_API int minigpt4_amd_weight_arena(struct MiniGPT4Context *ctx, int whic
 MINIGPT4_API int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y);
 /* prefill launch as the engine issues it for N > 4 rows: n_mat (1..3) equally shaped k-quant matrices (raw blocks back to back) against N rows in ONE launch of the LDS-staged
  * int8-MFMA kernels; residual ([n_mat][N][n_out]) optional; ks > 1 forces that K split (0 = the launcher's choice).  y: [n_mat][N][n_out].  4 = shape refused. */
-/* prefill mat-mul micro-benchmark: n_mat random matrices [rows][cols] against N random rows, average microseconds per (set) launch; generation 2 = mmq2_kernels.hip, 1 = round-1 kernels */
+/* prefill mat-mul micro-benchmark: n_mat random matrices [rows][cols] against N random rows, average microseconds per (set) launch; generation 3 = pre-scaled prefill planes (k_mmq3), 2 = compact planes (k_mmq2_*), 1 = round-1 kernels */
 MINIGPT4_API int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, int iters, int ks, int generation, float *us_per_launch);
-MINIGPT4_API int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int64_t N, const float *residual, int ks, float *y);
+MINIGPT4_API int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int64_t N, const float *residual, int ks, int generation, float *y);
 /* The decode (N = 1) mat-vec launches as the engine issues them: n1 equally spaced matrices of type1 (raw1 = their file bytes back to back), optionally one more of
  * type2 in the same mixed-type launch; prep 1 = rms_norm(x) * x2, 2 = x, 3 = silu(x) * x2, run standalone (fuse = 0) or in the kernel prologue (fuse = 1);
  * epi = 1: y[g] = silu(W0[g] . a) * (W1[g] . a) (n1 == 2).  residual / y: (n1 + n2) * n_out floats.  Returns 4 when the shape is outside the kernel's range. */

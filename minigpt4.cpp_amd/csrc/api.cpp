@@ -318,7 +318,7 @@ int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int64_t n_in, in
 
 // The prefill launch of Engine::forward for N > 4 rows (mmq2_kernels.hip): n_mat equally shaped matrices (rows of `raw_w` back to back) against N rows in ONE launch, optional
 // residual ([n_mat][N][n_out]), optional forced K split (ks > 1: partial sums combined in fixed order).  y: [n_mat][N][n_out].  Returns 4 when the kernels refuse the shape.
-int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int64_t N, const float *residual, int ks, float *y) {
+int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int64_t N, const float *residual, int ks, int generation, float *y) {
     if (!raw_w || !x || !y || n_in <= 0 || n_out <= 0 || N <= 0 || n_mat < 1 || n_mat > 3 || !qweight_supported(ggml_type) || n_in % gt_block(ggml_type)) return 1;
     if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
     return guarded(3, [&]() -> int {
@@ -326,10 +326,13 @@ int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t 
         QWeight W[3], plan;
         const size_t need = plan_qweight(ggml_type, (int)n_out, (int)n_in, plan, nullptr);
         DevBuf d_raw(raw_each), d_planes(need * (size_t)n_mat + 1024), d_x((size_t)(N * n_in) * 4), d_y(out_each * n_mat * 4), d_res(out_each * n_mat * 4), d_ws(out_each * n_mat * 16 * 4);
+        const size_t pf_each = generation >= 3 ? (prefill_plane_bytes(ggml_type, (int)n_out, (int)n_in) + 1023) / 1024 * 1024 : 0;
+        DevBuf d_pf(pf_each * (size_t)n_mat + 1024);
         for (int i = 0; i < n_mat; i++) {
             plan_qweight(ggml_type, (int)n_out, (int)n_in, W[i], d_planes.as<uint8_t>() + (size_t)i * need);
             HIP_CHECK(hipMemcpy(d_raw.p, static_cast<const uint8_t *>(raw_w) + (size_t)i * raw_each, raw_each, hipMemcpyHostToDevice));
             launch_repack(d_raw.as<uint8_t>(), W[i], nullptr);
+            if (pf_each) { uint8_t *pp = d_pf.as<uint8_t>() + (size_t)i * pf_each; launch_build_prefill_plane(W[i], pp, nullptr); W[i].pf = pp; }
             HIP_CHECK(hipDeviceSynchronize());
         }
         HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)(N * n_in) * 4, hipMemcpyHostToDevice));
@@ -540,6 +543,8 @@ int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, 
             const size_t n = (size_t)rows * cols;
             if (ggml_type == GT_Q4_K || ggml_type == GT_Q5_K) launch_fill_u16((void *)W[i].sc, n / 256 * 16 / 2, 0x1C00, nullptr);
             if (W[i].d) launch_fill_u16((void *)W[i].d, n / 256, 0x1C00, nullptr);
+            const size_t pfb = generation >= 3 ? prefill_plane_bytes(ggml_type, rows, cols) : 0;
+            if (pfb) { keep.emplace_back(new DevBuf(pfb + 1024)); uint8_t *pp = (uint8_t *)keep.back()->p; launch_build_prefill_plane(W[i], pp, nullptr); W[i].pf = pp; }
         }
         ActQ A; alloc_act(A, keep, (size_t)N, (size_t)cols);
         const size_t out_each = (size_t)N * rows;
@@ -550,7 +555,7 @@ int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, 
         set_mmq2_cus(prop.multiProcessorCount);
         if (ks > 0) setenv("MINIGPT4_MMQ2_KS", std::to_string(ks).c_str(), 1);
         const int keep_gen = mmq_enabled();
-        set_mmq_enabled(generation);
+        set_mmq_enabled(std::min(generation, 2));
         const QWeight *Wp[3]; float *Yp[3];
         for (int m = 0; m < n_mat; m++) { Wp[m] = &W[m]; Yp[m] = dy.as<float>() + (size_t)m * out_each; }
         auto run = [&]() {

@@ -235,7 +235,34 @@ int Engine::load_llm(const std::string &path) {
     } else tok_raw_ = upload_raw<uint8_t>(llm_arena_, fb + tt->offset, tt->nbytes);
     tok_type_ = effective_type(tt->type);
     MG4_INFO("llm weights: %.1f MB in HBM, %.3f GB streamed per decoded token", llm_arena_.used / 1048576.0, wbytes_token_ / 1e9);
+    build_prefill_planes();
     return E_None;
+}
+
+// Pre-scaled prefill planes (mmq2_kernels.hip, "third generation"): 2 bytes per k-quant layer weight, derived on the device from the repacked planes (so a rank that
+// RECEIVED its weight arena builds them the same way).  On by default when they fit comfortably (<= 40 % of the free HBM: 25 GB of 288 GB for the 13B model);
+// MINIGPT4_PREFILL_PLANES=0 / 1 forces them off / on.  Without them prefill runs on the compact planes (k_mmq2_*).
+void Engine::build_prefill_planes() {
+    const char *e = getenv("MINIGPT4_PREFILL_PLANES");
+    const int mode = e ? atoi(e) : -1;
+    if (mode == 0) return;
+    size_t total = 0;
+    auto each = [&](auto &&f) { for (LayerW &L : layers_) for (QWeight *w : {&L.wq, &L.wk, &L.wv, &L.wo, &L.w1, &L.w2, &L.w3}) f(*w); };
+    each([&](QWeight &w) { total += (prefill_plane_bytes(w.type, w.rows, w.cols) + 1023) / 1024 * 1024; });
+    if (!total) return;
+    size_t free_b = 0, tot_b = 0;
+    HIP_CHECK(hipMemGetInfo(&free_b, &tot_b));
+    if (mode < 0 && (double)total > 0.4 * (double)free_b) { MG4_INFO("prefill planes (%.1f GB) skipped: more than 40 %% of the free HBM (%.1f GB)", total / 1e9, free_b / 1e9); return; }
+    pf_arena_.alloc(total + 4096);
+    each([&](QWeight &w) {
+        const size_t b = prefill_plane_bytes(w.type, w.rows, w.cols);
+        if (!b) return;
+        uint8_t *p = pf_arena_.take(b, 1024);
+        launch_build_prefill_plane(w, p, stream_);
+        w.pf = p;
+    });
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    MG4_INFO("prefill planes: %.1f MB in HBM (sub-block scale x quant as two int8 digits: the int8 matrix cores apply ggml's sub-block scales)", pf_arena_.used / 1048576.0);
 }
 
 int Engine::load_vision(const std::string &path) {

@@ -119,7 +119,8 @@ private:
     float *norm_ = nullptr;
     QWeight output_;
     uint8_t *tok_raw_ = nullptr; int tok_type_ = -1;
-    DeviceArena llm_arena_, vis_arena_, buf_arena_;
+    DeviceArena llm_arena_, vis_arena_, buf_arena_, pf_arena_;   // pf_arena_: derived prefill planes (never broadcast: every rank rebuilds them from its weight arena)
+    void build_prefill_planes();
     uint8_t *stage_ = nullptr; size_t stage_cap_ = 0;
     size_t wbytes_token_ = 0;
     __half *kc_ = nullptr, *vc_ = nullptr;

@@ -121,7 +121,7 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_weight_arena.argtypes = [VOID_PTR, I32, P(VOID_PTR), P(SIZE_T)]
         L.minigpt4_amd_convert_q3k_q6k.argtypes = [VOID_PTR, VOID_PTR, ctypes.c_int64]
         L.minigpt4_amd_test_mul_mat.argtypes = [I32, VOID_PTR, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, ctypes.c_int64, FLOAT_PTR]
-        L.minigpt4_amd_test_mmq2.argtypes = [I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, ctypes.c_int64, FLOAT_PTR, I32, FLOAT_PTR]
+        L.minigpt4_amd_test_mmq2.argtypes = [I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, ctypes.c_int64, FLOAT_PTR, I32, I32, FLOAT_PTR]
         L.minigpt4_amd_test_matvec.argtypes = [I32, VOID_PTR, I32, I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, FLOAT_PTR, I32, I32, I32, FLOAT_PTR, FLOAT_PTR]
         L.minigpt4_amd_test_matvec_rows.argtypes = [I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, I32, FLOAT_PTR, FLOAT_PTR]
         L.minigpt4_amd_test_quantize.argtypes = [FLOAT_PTR, FLOAT_PTR, ctypes.c_int64, ctypes.c_int64, VOID_PTR, VOID_PTR, VOID_PTR, VOID_PTR, VOID_PTR]
@@ -300,14 +300,15 @@ class MiniGPT4SharedLibrary:
             raise RuntimeError(f"test_mul_mat rc={rc}: " + self.library.minigpt4_amd_last_error().decode())
         return y
 
-    def amd_test_mmq2(self, ggml_type: int, raw_w: np.ndarray, n_mat: int, n_in: int, n_out: int, x: np.ndarray, residual: Optional[np.ndarray] = None, ks: int = 0) -> np.ndarray:
+    def amd_test_mmq2(self, ggml_type: int, raw_w: np.ndarray, n_mat: int, n_in: int, n_out: int, x: np.ndarray, residual: Optional[np.ndarray] = None, ks: int = 0,
+                      generation: int = 2) -> np.ndarray:
         x = np.ascontiguousarray(x, np.float32).reshape(-1, n_in)
         raw_w = np.ascontiguousarray(raw_w)
         N = x.shape[0]
         y = np.empty((n_mat, N, n_out), np.float32)
         r = np.ascontiguousarray(residual, np.float32) if residual is not None else None
         rc = self.library.minigpt4_amd_test_mmq2(ggml_type, raw_w.ctypes.data_as(VOID_PTR), n_mat, n_in, n_out, x.ctypes.data_as(FLOAT_PTR), N,
-                                                 r.ctypes.data_as(FLOAT_PTR) if r is not None else None, ks, y.ctypes.data_as(FLOAT_PTR))
+                                                 r.ctypes.data_as(FLOAT_PTR) if r is not None else None, ks, generation, y.ctypes.data_as(FLOAT_PTR))
         if rc:
             raise RuntimeError(f"amd_test_mmq2 failed ({rc}): " + self.library.minigpt4_amd_last_error().decode())
         return y
