@@ -203,30 +203,21 @@ def main():
     vp, lp, vcfg, lcfg = make_models(args.config, rank, world, barrier)
     if args.n_ctx <= 0:   # the reference default is 2048; grow it only when the requested run does not fit
         args.n_ctx = max(2048, (200 + args.steps + args.warmup + 64 + 255) // 256 * 256)
-    t0 = time.time()
-    ctx = lib.minigpt4_model_load(vp, lp, verbosity=1, seed=1337, n_ctx=args.n_ctx, n_batch=512)
-    load_s = time.time() - t0
-    wbytes = lib.library.minigpt4_amd_weight_bytes_per_token(ctx.ptr)
-    log(f"[bench r{rank}] model loaded in {load_s:.1f}s; {wbytes / 1e9:.3f} GB of weights streamed per token")
-
-    # optional: exercise the load-time RCCL broadcast of the weight arenas (rank 0 -> all) -- correctness never depends on it
-    bcast_ms = None
+    # ---- load: rank 0 reads the files; with N > 1 every other rank loads in receive mode (headers only) and gets both weight arenas by RCCL broadcast over xGMI
+    # (minigpt4.cpp_amd/dist.py::load_replica checks that the arena layouts agree before and the arena checksums after)
+    from minigpt4_cpp_amd import dist as D
+    dev = None
     if dist is not None:
-        try:
-            import torch
-            t0 = time.time()
-            for which in (0, 1):
-                ptr, nb = ctypes.c_void_p(), ctypes.c_size_t()
-                assert lib.library.minigpt4_amd_weight_arena(ctx.ptr, which, ctypes.byref(ptr), ctypes.byref(nb)) == 0
-
-                class _Arena:
-                    __cuda_array_interface__ = {"shape": (nb.value,), "typestr": "|u1", "data": (ptr.value, False), "version": 2}
-                t = torch.as_tensor(_Arena(), device=f"cuda:{local_rank}")
-                dist.broadcast(t, src=0)
-            torch.cuda.synchronize()
-            bcast_ms = (time.time() - t0) * 1e3
-        except Exception as e:
-            log(f"[bench r{rank}] weight-arena broadcast skipped: {e}")
+        import torch
+        dev = torch.device("cuda", local_rank)
+    ctx, lstats = D.load_replica(lib, vp, lp, rank, world, device=dev, verbosity=1, seed=1337, n_ctx=args.n_ctx, n_batch=512)
+    load_s, bcast_ms = lstats["load_s"], lstats["bcast_ms"]
+    recv_load_s = None
+    if dist is not None:
+        recv_load_s = max(x["load_s"] for x in D.gather_objects({"load_s": load_s if rank else 0.0}, world))
+        load_s = D.gather_objects(load_s, world)[0]                       # the file-loading rank's time
+    wbytes = lib.library.minigpt4_amd_weight_bytes_per_token(ctx.ptr)
+    log(f"[bench r{rank}] model loaded in {lstats['load_s']:.1f}s ({lstats['mode']}); {wbytes / 1e9:.3f} GB of weights streamed per token")
 
     # ---- image encode (every rank encodes its own request's image)
     img = G.synth_image(42 + rank)
@@ -330,7 +321,7 @@ def main():
         "image_encode_ms": image_encode_ms, "image_encode_device_ms": image_encode_dev_ms, "image_encode_batched": enc_batch, "prefill_ms": prefill_ms, "prefill_tokens": n_prompt,
         "device_ms_per_token_graph_loop": dev_ms_per_tok, "device_tokens_per_s_graph_loop": 1e3 / dev_ms_per_tok,
         "weight_bytes_per_token": wbytes, "decode_weight_GBps_end_to_end": wbytes * K / dt / 1e9,
-        "model_load_s": load_s, "weight_bcast_ms": bcast_ms,
+        "model_load_s": load_s, "recv_load_s": recv_load_s, "weight_bcast_ms": bcast_ms,
         "roofline": roofline,
     }
     # ---- extra leg (not the headline): B conversations per replica decoded in ONE weight pass per step (include/minigpt4_amd.h)

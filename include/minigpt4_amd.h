@@ -63,13 +63,23 @@ MINIGPT4_API int minigpt4_amd_end_chat_batch(struct MiniGPT4Context *ctx, const 
 /* ---- weight arenas (load-time broadcast rank0 -> others over RCCL) ---------------------------- */
 /* which: 0 = LLM arena, 1 = vision arena.  Returns the device pointer and size in bytes. */
 MINIGPT4_API int minigpt4_amd_weight_arena(struct MiniGPT4Context *ctx, int which, void **device_ptr, size_t *bytes);
+/* Multi-GPU load (replicas; the only exchange is the load-time broadcast of the two weight arenas from rank 0).  Rank 0 loads normally; the other ranks
+ * set MINIGPT4_LOAD=recv before minigpt4_model_load: headers are parsed, both arenas are laid out and allocated exactly as rank 0's (compare minigpt4_amd_arena_plan), no
+ * tensor data is read, uploaded or repacked; after the arenas have been received (minigpt4_amd_weight_arena gives the device ranges) minigpt4_amd_weights_received builds
+ * what is derived from them on the device.  minigpt4_amd_plan_arenas computes the same layout from the files alone, without a GPU. */
+MINIGPT4_API int minigpt4_amd_plan_arenas(const char *vision_path, const char *llm_path, size_t *llm_bytes, size_t *vision_bytes, uint64_t *llm_hash, uint64_t *vision_hash);
+MINIGPT4_API int minigpt4_amd_arena_plan(struct MiniGPT4Context *ctx, size_t *llm_bytes, size_t *vision_bytes, uint64_t *llm_hash, uint64_t *vision_hash);
+MINIGPT4_API int minigpt4_amd_load_mode(struct MiniGPT4Context *ctx);              /* 0 full, 1 waiting for the arenas */
+MINIGPT4_API int minigpt4_amd_weights_received(struct MiniGPT4Context *ctx);
+MINIGPT4_API int minigpt4_amd_copy_arenas(struct MiniGPT4Context *dst, struct MiniGPT4Context *src);   /* tests: device-to-device stand-in for the broadcast on one GPU */
+MINIGPT4_API int minigpt4_amd_arena_checksum(struct MiniGPT4Context *ctx, int which, uint64_t *sum);   /* 64-bit sum of the arena's 32-bit words (device reduction) */
 
 /* ---- single-kernel hooks for parity tests (need a GPU; allocate + free their own device memory) ------------------ */
 /* y[N][n_out] = W . x with ggml's quantised-activation arithmetic.  raw_w: the tensor bytes exactly as stored in a model file. */
 MINIGPT4_API int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y);
 /* prefill launch as the engine issues it for N > 4 rows: n_mat (1..3) equally shaped k-quant matrices (raw blocks back to back) against N rows in ONE launch of the LDS-staged
  * int8-MFMA kernels; residual ([n_mat][N][n_out]) optional; ks > 1 forces that K split (0 = the launcher's choice).  y: [n_mat][N][n_out].  4 = shape refused. */
-/* prefill mat-mul micro-benchmark: n_mat random matrices [rows][cols] against N random rows, average microseconds per (set) launch; generation 3 = pre-scaled prefill planes (k_mmq3), 2 = compact planes (k_mmq2_*), 1 = round-1 kernels */
+/* prefill mat-mul micro-benchmark: n_mat random matrices [rows][cols] against N random rows, average microseconds per (set) launch; generation 2 = mmq2_kernels.hip, 1 = round-1 kernels */
 MINIGPT4_API int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, int iters, int ks, int generation, float *us_per_launch);
 MINIGPT4_API int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int64_t N, const float *residual, int ks, int generation, float *y);
 /* The decode (N = 1) mat-vec launches as the engine issues them: n1 equally spaced matrices of type1 (raw1 = their file bytes back to back), optionally one more of

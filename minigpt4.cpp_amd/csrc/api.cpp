@@ -280,6 +280,50 @@ int minigpt4_amd_weight_arena(struct MiniGPT4Context *ctx, int which, void **dev
     return 0;
 }
 
+// ---- multi-GPU load: arena layout plan (host only), receive-mode completion, arena checksum ------------------------------
+int minigpt4_amd_plan_arenas(const char *vision_path, const char *llm_path, size_t *llm_bytes, size_t *vision_bytes, uint64_t *llm_hash, uint64_t *vision_hash) {
+    if (!vision_path || !llm_path) return 1;
+    return guarded(3, [&]() -> int {
+        Engine::ArenaPlan p;
+        if (int e = Engine::plan_arenas(vision_path, llm_path, p)) return e;
+        if (llm_bytes) *llm_bytes = p.llm_bytes; if (vision_bytes) *vision_bytes = p.vision_bytes;
+        if (llm_hash) *llm_hash = p.llm_hash; if (vision_hash) *vision_hash = p.vision_hash;
+        return 0;
+    });
+}
+int minigpt4_amd_arena_plan(struct MiniGPT4Context *ctx, size_t *llm_bytes, size_t *vision_bytes, uint64_t *llm_hash, uint64_t *vision_hash) {
+    if (!ctx) return 1;
+    const Engine::ArenaPlan p = E_(ctx)->arena_plan();
+    if (llm_bytes) *llm_bytes = p.llm_bytes; if (vision_bytes) *vision_bytes = p.vision_bytes;
+    if (llm_hash) *llm_hash = p.llm_hash; if (vision_hash) *vision_hash = p.vision_hash;
+    return 0;
+}
+int minigpt4_amd_load_mode(struct MiniGPT4Context *ctx) { return ctx ? (int)E_(ctx)->load_mode() : -1; }
+int minigpt4_amd_weights_received(struct MiniGPT4Context *ctx) {
+    if (!ctx) return 1;
+    return guarded(3, [&] { return E_(ctx)->weights_received(); });
+}
+int minigpt4_amd_copy_arenas(struct MiniGPT4Context *dst, struct MiniGPT4Context *src) {   // single-GPU stand-in for the broadcast (tests): both weight arenas, device to device
+    if (!dst || !src) return 1;
+    return guarded(3, [&]() -> int {
+        Engine *d = E_(dst), *s = E_(src);
+        if (d->llm_arena_bytes() != s->llm_arena_bytes() || d->vision_arena_bytes() != s->vision_arena_bytes()) { set_last_error("arena sizes differ"); return 2; }
+        HIP_CHECK(hipMemcpy(d->llm_arena_ptr(), s->llm_arena_ptr(), s->llm_arena_bytes(), hipMemcpyDeviceToDevice));
+        HIP_CHECK(hipMemcpy(d->vision_arena_ptr(), s->vision_arena_ptr(), s->vision_arena_bytes(), hipMemcpyDeviceToDevice));
+        return 0;
+    });
+}
+int minigpt4_amd_arena_checksum(struct MiniGPT4Context *ctx, int which, uint64_t *sum) {
+    if (!ctx || !sum) return 1;
+    return guarded(3, [&]() -> int {
+        Engine *e = E_(ctx);
+        const uint8_t *p = which == 0 ? e->llm_arena_ptr() : e->vision_arena_ptr();
+        const size_t n = which == 0 ? e->llm_arena_bytes() : e->vision_arena_bytes();
+        *sum = device_checksum(p, n, e->stream());
+        return 0;
+    });
+}
+
 // ---- single-kernel hooks ---------------------------------------------------------------------------------------------------
 
 int minigpt4_amd_timeline(unsigned long long *out, int max_workgroups) { return (out && max_workgroups > 0) ? read_matvec_timeline(out, max_workgroups) : -1; }
@@ -326,13 +370,11 @@ int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t 
         QWeight W[3], plan;
         const size_t need = plan_qweight(ggml_type, (int)n_out, (int)n_in, plan, nullptr);
         DevBuf d_raw(raw_each), d_planes(need * (size_t)n_mat + 1024), d_x((size_t)(N * n_in) * 4), d_y(out_each * n_mat * 4), d_res(out_each * n_mat * 4), d_ws(out_each * n_mat * 16 * 4);
-        const size_t pf_each = generation >= 3 ? (prefill_plane_bytes(ggml_type, (int)n_out, (int)n_in) + 1023) / 1024 * 1024 : 0;
-        DevBuf d_pf(pf_each * (size_t)n_mat + 1024);
+        (void)generation;
         for (int i = 0; i < n_mat; i++) {
             plan_qweight(ggml_type, (int)n_out, (int)n_in, W[i], d_planes.as<uint8_t>() + (size_t)i * need);
             HIP_CHECK(hipMemcpy(d_raw.p, static_cast<const uint8_t *>(raw_w) + (size_t)i * raw_each, raw_each, hipMemcpyHostToDevice));
             launch_repack(d_raw.as<uint8_t>(), W[i], nullptr);
-            if (pf_each) { uint8_t *pp = d_pf.as<uint8_t>() + (size_t)i * pf_each; launch_build_prefill_plane(W[i], pp, nullptr); W[i].pf = pp; }
             HIP_CHECK(hipDeviceSynchronize());
         }
         HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)(N * n_in) * 4, hipMemcpyHostToDevice));
@@ -543,8 +585,6 @@ int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, 
             const size_t n = (size_t)rows * cols;
             if (ggml_type == GT_Q4_K || ggml_type == GT_Q5_K) launch_fill_u16((void *)W[i].sc, n / 256 * 16 / 2, 0x1C00, nullptr);
             if (W[i].d) launch_fill_u16((void *)W[i].d, n / 256, 0x1C00, nullptr);
-            const size_t pfb = generation >= 3 ? prefill_plane_bytes(ggml_type, rows, cols) : 0;
-            if (pfb) { keep.emplace_back(new DevBuf(pfb + 1024)); uint8_t *pp = (uint8_t *)keep.back()->p; launch_build_prefill_plane(W[i], pp, nullptr); W[i].pf = pp; }
         }
         ActQ A; alloc_act(A, keep, (size_t)N, (size_t)cols);
         const size_t out_each = (size_t)N * rows;

@@ -58,7 +58,6 @@ struct QWeight {
     const uint8_t *sc = nullptr;     // scale plane: Q4_0/Q5_0/Q8_0: f16 d per block; Q4_1/Q5_1: {d,m}; Q4_K/Q5_K: 16 B {d,dmin,scales12} per
                                      //   super-block; Q6_K: 2 int8 per unit
     const uint8_t *d = nullptr;      // Q6_K: f16 d per super-block
-    const uint8_t *pf = nullptr;     // (optional, k-quants) prefill plane: int8 digits of scale x quant, MFMA-fragment order (mmq2_kernels.hip: build_prefill_plane), 2 bytes per weight
     size_t bytes = 0;                // HBM bytes of all planes (== file bytes of the tensor)
 };
 

@@ -19,19 +19,21 @@ int device_count_noexcept() {
 }
 void DeviceArena::alloc(size_t bytes) {
     release();
-    HIP_CHECK(hipMalloc((void **)&base, bytes));
-    cap = bytes; used = 0;
+    if (virt) base = reinterpret_cast<uint8_t *>((uintptr_t)1 << 40);      // never dereferenced
+    else HIP_CHECK(hipMalloc((void **)&base, bytes));
+    cap = bytes; used = 0; layout_hash = 1469598103934665603ull;
 }
-void DeviceArena::release() { if (base) (void)hipFree(base); base = nullptr; cap = used = 0; }
+void DeviceArena::release() { if (base && !virt) (void)hipFree(base); base = nullptr; cap = used = 0; }
 uint8_t *DeviceArena::take(size_t bytes, size_t align) {
     const size_t off = (used + align - 1) / align * align;
     if (off + bytes > cap) throw HipError{hipErrorOutOfMemory, "arena overflow", __FILE__, __LINE__};
     used = off + bytes;
+    for (uint64_t v : {(uint64_t)off, (uint64_t)bytes}) for (int i = 0; i < 8; i++) { layout_hash ^= (v >> (8 * i)) & 0xFF; layout_hash *= 1099511628211ull; }
     return base + off;
 }
 template <typename T> T *Engine::upload_raw(DeviceArena &a, const void *src, size_t bytes) {
     uint8_t *d = a.take(bytes);
-    HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+    if (moves_data()) HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
     return reinterpret_cast<T *>(d);
 }
 
@@ -122,6 +124,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     set_matvec_tuning(getenv("MINIGPT4_MV_WAVES") ? atoi(getenv("MINIGPT4_MV_WAVES")) : 0, getenv("MINIGPT4_FAT_LB") ? atoi(getenv("MINIGPT4_FAT_LB")) : 0, prop.multiProcessorCount);
     if (const char *ns = getenv("MINIGPT4_CONVERSATIONS")) conv_.assign((size_t)std::max(1, std::min(MAX_CONVERSATIONS, atoi(ns))), Conversation{});
     sampler_.seed(seed);
+    if (const char *lm = getenv("MINIGPT4_LOAD")) load_mode_ = !strcmp(lm, "recv") ? LOAD_RECV : LOAD_FULL;
     auto t0 = std::chrono::steady_clock::now();
     if (int e = load_llm(llm_path)) return e;
     auto t1 = std::chrono::steady_clock::now();
@@ -132,6 +135,25 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     alloc_buffers();
     if (stage_) { (void)hipFree(stage_); stage_ = nullptr; stage_cap_ = 0; }
     return E_None;
+}
+
+// LOAD_RECV: the two weight arenas have been filled from rank 0 (broadcast): everything derived from them on the device
+int Engine::weights_received() {
+    if (load_mode_ != LOAD_RECV) return 0;
+    load_mode_ = LOAD_FULL;
+    const size_t NQ = (size_t)v_nq_;
+    for (size_t b = 0; b < (size_t)VISION_BATCH_MAX; b++) HIP_CHECK(hipMemcpy(vi_qtok_rep_ + b * NQ * 768, v_qtok_, NQ * 768 * 4, hipMemcpyDeviceToDevice));
+    return 0;
+}
+// Host only: the arena layout (sizes + layout hashes) the two files produce, without a device: what a receiving rank must reproduce (tests/test_cpu_dist.py).
+int Engine::plan_arenas(const std::string &vision_path, const std::string &llm_path, ArenaPlan &out) {
+    Engine e;
+    e.load_mode_ = LOAD_PLAN;
+    e.llm_arena_.virt = e.vis_arena_.virt = true;
+    if (int err = e.load_llm(llm_path)) return err;
+    if (int err = e.load_vision(vision_path)) return err;
+    out = e.arena_plan();
+    return 0;
 }
 
 // Tensor types the kernels do not stream natively but that have an exact image in one they do: Q3_K -> Q6_K (quantize.hpp).  The conversion runs on the host at load.
@@ -145,15 +167,16 @@ void Engine::upload_qweight(const TensorMeta &t0, const uint8_t *file_base0, QWe
     const uint8_t *file_base = file_base0;
     std::vector<uint8_t> conv;
     if (t0.type == GT_Q3_K) {
-        conv.resize(effective_nbytes(t0));
-        q3k_to_q6k(file_base0 + t0.offset, conv.data(), t0.nbytes / 110);
-        t.type = GT_Q6_K; t.nbytes = conv.size(); t.offset = 0; file_base = conv.data();
+        conv.resize(moves_data() ? effective_nbytes(t0) : 0);
+        if (moves_data()) q3k_to_q6k(file_base0 + t0.offset, conv.data(), t0.nbytes / 110);
+        t.type = GT_Q6_K; t.nbytes = effective_nbytes(t0); t.offset = 0; file_base = conv.data();
     }
     const int cols = (int)t.ne[0], rows = (int)t.ne[1];
     QWeight plan;
     const size_t need = plan_qweight(t.type, rows, cols, plan, nullptr);
     uint8_t *base = llm_arena_.take(need);
     plan_qweight(t.type, rows, cols, w, base);
+    if (!moves_data()) return;                                              // LOAD_RECV / LOAD_PLAN: layout only
     if (t.type == GT_F16 || t.type == GT_F32) { HIP_CHECK(hipMemcpy(base, file_base + t.offset, t.nbytes, hipMemcpyHostToDevice)); return; }
     if (t.nbytes > stage_cap_) throw HipError{hipErrorOutOfMemory, "staging buffer too small", __FILE__, __LINE__};
     HIP_CHECK(hipMemcpy(stage_, file_base + t.offset, t.nbytes, hipMemcpyHostToDevice));
@@ -207,7 +230,7 @@ int Engine::load_llm(const std::string &path) {
     total += (size_t)(2 * L + 1) * ((size_t)E * 4 + 256);
     wbytes_token_ += (size_t)(2 * L + 1) * E * 4;
     llm_arena_.alloc(total + 4096);
-    if (max_raw) { HIP_CHECK(hipMalloc((void **)&stage_, max_raw)); stage_cap_ = max_raw; }
+    if (max_raw && moves_data()) { HIP_CHECK(hipMalloc((void **)&stage_, max_raw)); stage_cap_ = max_raw; }
     // pass 2: upload + repack
     const uint8_t *fb = llm_.mf.data;
     upload_qweight(*llm_.find("output.weight"), fb, output_);
@@ -229,40 +252,13 @@ int Engine::load_llm(const std::string &path) {
     const TensorMeta *nt = llm_.find("norm.weight");
     norm_ = upload_raw<float>(llm_arena_, fb + nt->offset, nt->nbytes);
     if (tt->type == GT_Q3_K) {   // the embedding gather dequantises raw ggml rows: give it the (value-identical) Q6_K rows
-        std::vector<uint8_t> conv(effective_nbytes(*tt));
-        q3k_to_q6k(fb + tt->offset, conv.data(), tt->nbytes / 110);
-        tok_raw_ = upload_raw<uint8_t>(llm_arena_, conv.data(), conv.size());
+        std::vector<uint8_t> conv(moves_data() ? effective_nbytes(*tt) : 0);
+        if (moves_data()) q3k_to_q6k(fb + tt->offset, conv.data(), tt->nbytes / 110);
+        tok_raw_ = upload_raw<uint8_t>(llm_arena_, conv.data(), effective_nbytes(*tt));
     } else tok_raw_ = upload_raw<uint8_t>(llm_arena_, fb + tt->offset, tt->nbytes);
     tok_type_ = effective_type(tt->type);
     MG4_INFO("llm weights: %.1f MB in HBM, %.3f GB streamed per decoded token", llm_arena_.used / 1048576.0, wbytes_token_ / 1e9);
-    build_prefill_planes();
     return E_None;
-}
-
-// Pre-scaled prefill planes (mmq2_kernels.hip, "third generation"): 2 bytes per k-quant layer weight, derived on the device from the repacked planes (so a rank that
-// RECEIVED its weight arena builds them the same way).  On by default when they fit comfortably (<= 40 % of the free HBM: 25 GB of 288 GB for the 13B model);
-// MINIGPT4_PREFILL_PLANES=0 / 1 forces them off / on.  Without them prefill runs on the compact planes (k_mmq2_*).
-void Engine::build_prefill_planes() {
-    const char *e = getenv("MINIGPT4_PREFILL_PLANES");
-    const int mode = e ? atoi(e) : -1;
-    if (mode == 0) return;
-    size_t total = 0;
-    auto each = [&](auto &&f) { for (LayerW &L : layers_) for (QWeight *w : {&L.wq, &L.wk, &L.wv, &L.wo, &L.w1, &L.w2, &L.w3}) f(*w); };
-    each([&](QWeight &w) { total += (prefill_plane_bytes(w.type, w.rows, w.cols) + 1023) / 1024 * 1024; });
-    if (!total) return;
-    size_t free_b = 0, tot_b = 0;
-    HIP_CHECK(hipMemGetInfo(&free_b, &tot_b));
-    if (mode < 0 && (double)total > 0.4 * (double)free_b) { MG4_INFO("prefill planes (%.1f GB) skipped: more than 40 %% of the free HBM (%.1f GB)", total / 1e9, free_b / 1e9); return; }
-    pf_arena_.alloc(total + 4096);
-    each([&](QWeight &w) {
-        const size_t b = prefill_plane_bytes(w.type, w.rows, w.cols);
-        if (!b) return;
-        uint8_t *p = pf_arena_.take(b, 1024);
-        launch_build_prefill_plane(w, p, stream_);
-        w.pf = p;
-    });
-    HIP_CHECK(hipStreamSynchronize(stream_));
-    MG4_INFO("prefill planes: %.1f MB in HBM (sub-block scale x quant as two int8 digits: the int8 matrix cores apply ggml's sub-block scales)", pf_arena_.used / 1048576.0);
 }
 
 int Engine::load_vision(const std::string &path) {
@@ -328,14 +324,14 @@ int Engine::load_vision(const std::string &path) {
         if (v_generic_) return nullptr;
         size_t bytes = 0; for (auto t : ts) { if (!t) return nullptr; bytes += t->nbytes; }
         uint8_t *d = vis_arena_.take(bytes); size_t off = 0;
-        for (auto t : ts) { HIP_CHECK(hipMemcpy(d + off, fb + t->offset, t->nbytes, hipMemcpyHostToDevice)); off += t->nbytes; }
+        for (auto t : ts) { if (moves_data()) HIP_CHECK(hipMemcpy(d + off, fb + t->offset, t->nbytes, hipMemcpyHostToDevice)); off += t->nbytes; }
         return reinterpret_cast<__half *>(d);
     };
     auto concat32 = [&](std::initializer_list<std::pair<const char *, std::string>> names, int64_t each) -> float * {
         uint8_t *d = vis_arena_.take((size_t)each * 4 * names.size()); size_t off = 0;
         for (auto &nm : names) { const TensorMeta *t = vis_.find(nm.first, nm.second);
             if (!t || t->type != GT_F32 || t->nelements() != each) { ok = false; bad = nm.second; return nullptr; }
-            HIP_CHECK(hipMemcpy(d + off, fb + t->offset, t->nbytes, hipMemcpyHostToDevice)); off += t->nbytes; }
+            if (moves_data()) HIP_CHECK(hipMemcpy(d + off, fb + t->offset, t->nbytes, hipMemcpyHostToDevice)); off += t->nbytes; }
         return reinterpret_cast<float *>(d);
     };
     const int D = v_D_, M = v_M_;
@@ -399,7 +395,10 @@ int Engine::load_vision(const std::string &path) {
     }
     v_proj_w_ = up16(f16m("llama_proj", "weight", 768, v_out_)); v_proj_b_ = f32v("llama_proj", "bias", v_out_);
     if (!ok) return fail("missing or unsupported tensor " + bad, E_LoadModelFileHeader);
-    if (v_generic_) { if (int e = load_vision_generic()) return e; }
+    if (v_generic_) {
+        if (load_mode_ != LOAD_FULL) return fail("quantised / f32 vision files keep a third arena that the multi-GPU receive path does not cover: load them with LOAD_FULL on every rank", E_LoadModelFileHeader);
+        if (int e = load_vision_generic()) return e;
+    }
     MG4_INFO("vision weights: %.1f MB in HBM (ViT dim %d x %d blocks, Q-Former %d layers, proj -> %d)", vis_arena_.used / 1048576.0, v_D_, v_depth_, v_ql_, v_out_);
     return E_None;
 }
@@ -482,7 +481,7 @@ void Engine::alloc_buffers() {
     vi_hs_h_ = takeh(VB * NQ * 768); vi_a1_h_ = takeh(VB * NQ * 768); vi_a2_h_ = takeh(VB * NQ * 768); vi_ctx_h_ = takeh(VB * NQ * 768); vi_im_h_ = takeh(VB * NQ * (size_t)v_qi_);
     vi_out_ = takef(VB * NQ * (size_t)v_out_);
     vi_qtok_rep_ = takef(VB * NQ * 768);                                  // the query tokens once per image of a batch (every image starts from the same rows)
-    for (size_t b = 0; b < VB; b++) HIP_CHECK(hipMemcpy(vi_qtok_rep_ + b * NQ * 768, v_qtok_, NQ * 768 * 4, hipMemcpyDeviceToDevice));
+    if (load_mode_ == LOAD_FULL) for (size_t b = 0; b < VB; b++) HIP_CHECK(hipMemcpy(vi_qtok_rep_ + b * NQ * 768, v_qtok_, NQ * 768 * 4, hipMemcpyDeviceToDevice));   // LOAD_RECV: weights_received()
     if (v_generic_) alloc_vision_generic();
     MG4_INFO("KV cache %.1f MB (fp16, n_ctx %d, %zu conversation%s), activation arena %.1f MB", 2.0 * S * L * C * E * 2 / 1048576.0, n_ctx_, S, S == 1 ? "" : "s", buf_arena_.used / 1048576.0);
 }

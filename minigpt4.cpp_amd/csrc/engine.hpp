@@ -16,6 +16,8 @@ namespace mg4 {
 struct DeviceArena {
     uint8_t *base = nullptr;
     size_t cap = 0, used = 0;
+    bool virt = false;                       // planning only (Engine::plan_arenas): no device memory, `base` is a fake non-null address that is never dereferenced
+    uint64_t layout_hash = 1469598103934665603ull;   // FNV-1a over the (offset, bytes) sequence of take(): two loads with the same hash laid the arena out identically
     void alloc(size_t bytes);
     void release();
     uint8_t *take(size_t bytes, size_t align = 256);
@@ -28,6 +30,15 @@ public:
     Engine() = default;
     ~Engine();
     int init(const std::string &vision_path, const std::string &llm_path, int seed, int n_ctx, int n_batch);
+    // ---- multi-GPU load: rank 0 loads the files (LOAD_FULL) and broadcasts its two weight arenas; the other ranks run LOAD_RECV: parse the HEADERS only,
+    // lay the arenas out identically (same take() sequence -> same layout hash), allocate them, skip every file read / upload / repack, receive the bytes, then call
+    // weights_received() for what is derived on the device (prefill planes, the replicated query tokens).  LOAD_PLAN does the layout without any device (CPU tests).
+    enum LoadMode { LOAD_FULL = 0, LOAD_RECV = 1, LOAD_PLAN = 2 };
+    int weights_received();
+    struct ArenaPlan { size_t llm_bytes = 0, vision_bytes = 0; uint64_t llm_hash = 0, vision_hash = 0; };
+    static int plan_arenas(const std::string &vision_path, const std::string &llm_path, ArenaPlan &out);   // host only
+    ArenaPlan arena_plan() const { ArenaPlan p; p.llm_bytes = llm_arena_.used; p.vision_bytes = vis_arena_.used; p.llm_hash = llm_arena_.layout_hash; p.vision_hash = vis_arena_.layout_hash; return p; }
+    LoadMode load_mode() const { return load_mode_; }
 
     // ---- image path (reference encode_image, minigpt4.cpp:2094-2363)
     int encode_image(const float *chw, float *out);   // out: [32][proj_out()]
@@ -95,6 +106,8 @@ private:
     template <typename T> T *upload_raw(DeviceArena &a, const void *src, size_t bytes);
 
 
+    LoadMode load_mode_ = LOAD_FULL;
+    bool moves_data() const { return load_mode_ == LOAD_FULL; }
     int device_ = 0;
     hipStream_t stream_ = nullptr;
     int n_ctx_ = 2048, n_batch_ = 512, max_rows_ = 512;
@@ -119,8 +132,7 @@ private:
     float *norm_ = nullptr;
     QWeight output_;
     uint8_t *tok_raw_ = nullptr; int tok_type_ = -1;
-    DeviceArena llm_arena_, vis_arena_, buf_arena_, pf_arena_;   // pf_arena_: derived prefill planes (never broadcast: every rank rebuilds them from its weight arena)
-    void build_prefill_planes();
+    DeviceArena llm_arena_, vis_arena_, buf_arena_;
     uint8_t *stage_ = nullptr; size_t stage_cap_ = 0;
     size_t wbytes_token_ = 0;
     __half *kc_ = nullptr, *vc_ = nullptr;

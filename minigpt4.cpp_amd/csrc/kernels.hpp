@@ -33,9 +33,6 @@ int mmq_enabled();
 // chunk of <= 128 tokens, activations staged through LDS, optional K split (partial sums in A.ws) combined in fixed order.  false -> outside the kernels' range, nothing launched.
 bool mmq2_supported(int type, int rows, int cols);
 bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s);
-// third generation (pre-scaled prefill planes, 2 bytes per weight, built on the device from the repacked planes): W.pf != nullptr on every matrix of a set routes launch_mmq2_set to it
-size_t prefill_plane_bytes(int type, int rows, int cols);   // 0: the type / shape has no plane
-void launch_build_prefill_plane(const QWeight &W, uint8_t *out, hipStream_t s);
 void set_mmq2_cus(int cus);   // CU count the K-split heuristic aims at (the K-split partial sums live in ActQ::ws, owned by whoever owns the activation planes)
 
 // decode (N = 1) persistent-wave mat-vec over 1..3 same-type, same-shape matrices (wq|wk|wv, w1|w3); false -> caller falls back to launch_mul_mat
@@ -90,6 +87,7 @@ void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);
 void launch_set_int(int *p, int v, hipStream_t s);
 float probe_grid_barrier_us(int n_blocks, int iters, unsigned *errors_out);   // average latency of a device-wide barrier across n_blocks co-resident 512-thread workgroups
 void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s);
+uint64_t device_checksum(const void *p, size_t bytes, hipStream_t s);   // sum of the 32-bit words (bytes rounded down to 4), mod 2^64; synchronises the stream
 void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s);
 void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s);
 

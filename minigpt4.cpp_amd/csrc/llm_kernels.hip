@@ -1669,6 +1669,22 @@ __global__ void k_fill_random(unsigned *p, size_t n_words, unsigned seed) {
         unsigned x = (unsigned)i * 2654435761u ^ seed; x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; p[i] = x; }
 }
 void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s) { hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, (unsigned *)p, bytes / 4, seed); }
+__global__ __launch_bounds__(256) void k_checksum(const unsigned *__restrict__ p, size_t n_words, unsigned long long *out) {
+    unsigned long long s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) s += p[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);                      // integer sum: order does not matter
+}
+uint64_t device_checksum(const void *p, size_t bytes, hipStream_t s) {
+    unsigned long long *d = nullptr, h = 0;
+    HIP_CHECK(hipMalloc((void **)&d, 8));
+    HIP_CHECK(hipMemsetAsync(d, 0, 8, s));
+    hipLaunchKernelGGL(k_checksum, dim3(2048), dim3(256), 0, s, static_cast<const unsigned *>(p), bytes / 4, d);
+    HIP_CHECK(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(d);
+    return (uint64_t)h;
+}
 __global__ void k_fill_u16(unsigned short *p, size_t n, unsigned short v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }

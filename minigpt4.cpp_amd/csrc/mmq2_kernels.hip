@@ -14,8 +14,12 @@
 //     weight row and its sub-block scales are per-lane scalars;  the Q4_K / Q5_K min term sum_j m_j * bsum_j runs as two MFMAs on the digit split
 //     bsum = 128 hi + lo (exact) instead of round 1's eight MFMAs against a broadcast byte;
 //   * <= 256 VGPRs: two workgroups (8 waves) per CU, so one wave's scale arithmetic (VALU) overlaps another's MFMAs.
-// Per (row tile, super-block, token tile): 8 + 2 MFMAs (Q4_K / Q5_K) or 16 (Q6_K) and ~16 VALU operations per accumulator -- the kernel is VALU-bound by
-// the integer sub-block scale multiply-adds ggml's format requires (one per output element per 32 weights), not by the matrix cores.
+// Per (row tile, super-block, token tile): 8 + 2 MFMAs (Q4_K / Q5_K) or 16 (Q6_K) and ~300 VALU instructions per wave -- the kernel is VALU-bound by the integer
+// sub-block scale multiply-adds ggml's format requires (one per output element per 32 weights: 1 VALU operation per 32 MFMA multiply-accumulates on a chip whose matrix
+// pipe is 64 x wider than its vector pipe), not by the matrix cores (PMC, profiles/r02e_pmc_mmq2.txt: two waves per SIMD issue 84 % of the time, MFMA 9 % busy).
+// Measured and removed (profiles/r02g_prefill_generations_microbench.log): pre-scaled "prefill planes" -- sub-block scale x quant stored as two int8 digits,
+// 2 bytes per weight, so that the scales ride inside the MFMA accumulation (exact, bit-identical results, 41 % fewer VALU instructions) -- lost on Q4_K / Q5_K
+// (w1|w3 at 142 rows: 155 vs 100 us): 2.8 x the weight bytes per chunk of <= 96 tokens turned the kernel into a latency-bound HBM stream; it won only on Q6_K.
 #include "kernels.hpp"
 #include "devutil.hpp"
 
@@ -414,215 +418,6 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
     mmq2_store<TT>(acc, a, m, r0 + l31, W.rows, t0, my_tiles, hh);
 }
 
-// =====================================================================================================================
-// Third generation: PRE-SCALED prefill planes.  Counters on the kernels above (profiles/r02e_pmc_mmq2.txt): two waves per SIMD issue VALU instructions 84 % of the time
-// and the matrix cores are 9 % busy -- ggml's k-quant formats need one integer multiply-add per output element and 32-weight sub-block (sub-block scale x sub-block dot),
-// 1 VALU operation per 32 MFMA multiply-accumulates, on a machine whose matrix pipe is 64 x wider than its vector pipe.  The sub-block scale can ride INSIDE the matrix
-// product if it is folded into the weights:   sum_j sc_j * (sum_k q_jk a_jk)  ==  sum_jk (sc_j q_jk) a_jk   exactly (int32), but sc * q needs 11 bits (Q5_K: <= 63 * 31;
-// Q6_K: |int8 scale * (q - 32)| <= 4096), so it is stored as two int8 digits w' = 128 hi + lo and multiplied by two MFMAs whose accumulators run over the whole
-// super-block:  isum = 128 * (A . HI) + (A . LO).  That costs 2 bytes per weight (25 GB for the 13B model) next to the 0.7 bytes per weight the decode path streams --
-// HBM capacity the MI355X has (288 GB) traded for the VALU operations it lacks; built on the device at load time from the repacked planes (nothing new in the files),
-// MINIGPT4_PREFILL_PLANES=0 turns it off (the kernels above then serve prefill).
-//   plane layout: [row tile of 32][super-block][sub-block j = 0..7][digit: hi, lo][lane 0..63][16 B]: lane l holds row (l & 31), elements 32 j + 16 (l >> 5) .. + 15 of the
-//   super-block -- exactly one v_mfma_i32_32x32x32_i8 B operand, so a wave's load instruction reads 1 KiB contiguous and nothing is unpacked.
-// Q6_K's 16-wide scale groups need no special case any more (each weight carries its own group's scale).
-// =====================================================================================================================
-size_t prefill_plane_bytes(int type, int rows, int cols) {
-    if (!(type == GT_Q4_K || type == GT_Q5_K || type == GT_Q6_K) || cols % 256) return 0;
-    return (size_t)((rows + 31) / 32) * 32 * (size_t)cols * 2;
-}
-__global__ __launch_bounds__(256) void k_build_prefill_plane(const QWeight W, uint8_t *__restrict__ out, size_t n_items) {
-    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;        // item = (row tile, super-block, sub-block j, lane): 16 weights
-    if (g >= n_items) return;
-    const int lane = (int)(g & 63), j = (int)((g >> 6) & 7);
-    const size_t tsb = g >> 9;                                       // row tile * NSB + sb
-    const int K = W.cols, U = K / 32, NSB = K / 256;
-    const int sb = (int)(tsb % NSB), rt = (int)(tsb / NSB);
-    const int row = rt * 32 + (lane & 31), hh = lane >> 5;
-    int wv[16];
-    if (row >= W.rows) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) wv[i] = 0;
-    } else if (W.type == GT_Q6_K) {
-        const int E0 = 32 * j + 16 * hh;                             // first element within the super-block
-        const int n = E0 >> 7, rem = E0 & 127, x = rem >> 6, c = (rem & 63) >> 5, h = (rem & 31) >> 4;
-        const size_t unit = (size_t)row * U + (size_t)sb * 8 + 4 * n + 2 * c + h;
-        const uint8_t *qs = W.qs + unit * 16;
-        const unsigned Px = reinterpret_cast<const unsigned *>(W.qh + unit * 8)[x];
-        const int scale = (int)(signed char)W.sc[unit * 2 + x];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int nib = x ? (qs[i] >> 4) : (qs[i] & 15);
-            const int hb = (int)((Px >> (8 * (i & 3) + 2 * (i >> 2))) & 3u);
-            wv[i] = scale * ((nib | (hb << 4)) - 32);
-        }
-    } else {
-        const int jp = j >> 1, x = j & 1;
-        const size_t unit = (size_t)row * U + (size_t)sb * 8 + 2 * jp + hh;
-        const uint8_t *qs = W.qs + unit * 16;
-        const unsigned P = W.type == GT_Q5_K ? *reinterpret_cast<const unsigned *>(W.qh + unit * 4) : 0u;
-        const uint8_t *hd = W.sc + ((size_t)row * NSB + sb) * 16 + 4;   // the 12 packed 6-bit (scale, min) bytes
-        const int sc = j < 4 ? (hd[j] & 63) : ((hd[j + 4] & 0xF) | ((hd[j - 4] >> 6) << 4));
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int nib = x ? (qs[i] >> 4) : (qs[i] & 15);
-            const int hb = (int)((P >> (8 * (i & 3) + 4 * x + (i >> 2))) & 1u);
-            wv[i] = sc * (nib | (hb << 4));
-        }
-    }
-    uint8_t *o = out + ((tsb * 8 + j) * 2) * 1024 + (size_t)lane * 16;
-    unsigned hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 16; i++) { hi[i >> 2] |= (unsigned)((wv[i] >> 7) & 0xFF) << (8 * (i & 3)); lo[i >> 2] |= (unsigned)(wv[i] & 127) << (8 * (i & 3)); }
-    *reinterpret_cast<uint4 *>(o) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    *reinterpret_cast<uint4 *>(o + 1024) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-}
-void launch_build_prefill_plane(const QWeight &W, uint8_t *out, hipStream_t s) {
-    const size_t n_items = (size_t)((W.rows + 31) / 32) * (W.cols / 256) * 8 * 64;
-    hipLaunchKernelGGL(k_build_prefill_plane, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, W, out, n_items);
-}
-
-// Workgroup = 4 waves = 4 row tiles x one chunk of TT token tiles x one K slice, like k_mmq2_*.  All global loads are plain loads (activation staging through registers
-// into the double-buffered LDS image, weight fragments straight into a 4-deep register ring) so that hipcc's counted vmcnt waits keep the ring streaming; mixing LDS-DMA
-// into the same loop would turn every wait into vmcnt(0).
-template <bool KQ45, int TT>
-__global__ __launch_bounds__(256, 2) void k_mmq3(const Mmq2Args a, const ActQ A, const int n_chunks, const int n_units) {
-    using S = Mmq2Stage<TT>;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_mmq3[];   // [2 stages]
-    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, l31 = lane & 31;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware order: the chunks that share a (row group, K slice) get consecutive slots of ONE XCD (blocks are dealt round-robin to the 8 XCDs), so their common
-    // weights come from HBM once and from that XCD's L2 afterwards
-    const int slot = blockIdx.x >> 3, unit = (slot / n_chunks) * 8 + (blockIdx.x & 7), chunk = slot % n_chunks;
-    if (unit >= n_units) return;
-    const int ksl = unit / (a.n_mat * a.groups_each), gm = unit - ksl * (a.n_mat * a.groups_each);
-    const int m = gm / a.groups_each, g = gm - m * a.groups_each;
-    const QWeight W = a.w[m];
-    const int K = W.cols, NSB = K / 256, N = a.N;
-    const int rt = g * 4 + wv, r0 = rt * 32;
-    const int rtc = min(rt, (W.rows + 31) / 32 - 1);
-    const int row = min(r0 + l31, W.rows - 1);
-    const int tile0 = chunk * a.tiles_per_chunk, my_tiles = min(TT, a.n_tiles - tile0), t0 = tile0 * 32;
-    const int sb0 = ksl * a.sb_per_split, sb1 = min(NSB, sb0 + a.sb_per_split);
-
-    float acc[TT][16];
-#pragma unroll
-    for (int tt = 0; tt < TT; tt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[tt][r] = 0.0f;
-
-    // ---- activation staging (registers -> LDS at the end of the iteration)
-    constexpr int NQ = 2 * TT;                                       // 16-byte pieces of the int8 image per thread
-    const int8_t *qsrc[NQ]; unsigned qdst[NQ];
-#pragma unroll
-    for (int u = 0; u < NQ; u++) { const int cid = tid + 256 * u, tl = cid >> 4, c = cid & 15; qsrc[u] = A.q8k + (size_t)min(t0 + tl, N - 1) * K + c * 16; qdst[u] = (unsigned)(tl * 256 + ((c ^ (tl & 15)) << 4)); }
-    const int stl = min(tid, S::TTP * 32 - 1);                       // threads < TTP * 32 also stage one token's digit-split sums and scale
-    const int8_t *bsrc = A.bsq + (size_t)min(t0 + stl, N - 1) * NSB * 16;
-    const float *dsrc = A.dk + (size_t)min(t0 + stl, N - 1) * NSB;
-    struct Stage { v4i q[NQ]; v4i bs; float dk; };
-    auto stage_fetch = [&](int sb, Stage &st) {
-#pragma unroll
-        for (int u = 0; u < NQ; u++) st.q[u] = ldg16(qsrc[u] + (size_t)sb * 256);
-        st.bs = ldg16(bsrc + (size_t)sb * 16); st.dk = dsrc[sb];
-    };
-    auto stage_write = [&](const Stage &st, unsigned char *base) {
-#pragma unroll
-        for (int u = 0; u < NQ; u++) *reinterpret_cast<v4i *>(base + qdst[u]) = st.q[u];
-        if (tid < S::TTP * 32) { *reinterpret_cast<v4i *>(base + S::Q8 + tid * 16) = st.bs; *reinterpret_cast<float *>(base + S::Q8 + S::BS + tid * 4) = st.dk; }
-    };
-    // ---- weight fragments: ring of 4 sub-blocks x {hi, lo}
-    const unsigned char *wbase = W.pf + ((size_t)rtc * NSB * 16) * 1024 + (size_t)lane * 16;   // + sb * 16 KiB + (j * 2 + digit) * 1 KiB
-    constexpr int RING = 2;                                         // sub-blocks of weight fragments in flight (2 x {hi, lo} x 4 registers each)
-    v4i Bh[RING], Bl[RING];
-    auto bfetch = [&](int sb, int j, int slot_) { const unsigned char *p = wbase + ((size_t)sb * 16 + j * 2) * 1024; Bh[slot_] = ldg16(p); Bl[slot_] = ldg16(p + 1024); };
-    const unsigned char *hsrc = KQ45 ? W.sc + (size_t)row * NSB * 16 : W.d + (size_t)row * NSB * 2;
-    // A fragment addresses: sub-block j, lane half hh -> chunk 2 j + hh of token l31 (slot chunk ^ (token & 15))
-    unsigned a_addr[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) a_addr[j] = (unsigned)(l31 * 256 + (((2 * j + hh) ^ (lane & 15)) << 4));
-    const unsigned bs_addr = (unsigned)(S::Q8 + l31 * 16), dk_addr = (unsigned)(S::Q8 + S::BS + 16 * hh);
-
-    {   // prologue: stage sb0, first four weight fragments, header
-        Stage st; stage_fetch(sb0, st); stage_write(st, smem_mmq3);
-    }
-#pragma unroll
-    for (int j = 0; j < RING; j++) bfetch(sb0, j, j);
-    v4i hdr = KQ45 ? ldg16(hsrc + (size_t)sb0 * 16) : v4i{(int)*reinterpret_cast<const unsigned short *>(hsrc + (size_t)sb0 * 2), 0, 0, 0};
-    __syncthreads();
-    for (int sb = sb0; sb < sb1; sb++) {
-        const int buf = (sb - sb0) & 1, sbn = min(sb + 1, sb1 - 1);
-        const unsigned char *st = smem_mmq3 + buf * S::BYTES;
-        Stage nxt; stage_fetch(sbn, nxt);                            // lands during this iteration's MFMAs
-        const v4i h = hdr;
-        hdr = KQ45 ? ldg16(hsrc + (size_t)sbn * 16) : v4i{(int)*reinterpret_cast<const unsigned short *>(hsrc + (size_t)sbn * 2), 0, 0, 0};
-        v16i Dh[TT], Dl[TT];
-#pragma unroll
-        for (int tt = 0; tt < TT; tt++) { Dh[tt] = zero16(); Dl[tt] = zero16(); }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const v4i bh = Bh[j % RING], bl = Bl[j % RING];
-            if (j + RING < 8) bfetch(sb, j + RING, j % RING); else bfetch(sbn, j + RING - 8, j % RING);       // refill the slot just copied out: RING sub-blocks stay in flight
-#pragma unroll
-            for (int tt = 0; tt < TT; tt++) {                     // every tile of the chunk, also past the prompt's end (clamped rows, results dropped by the store): no branch
-                const v4i af = *reinterpret_cast<const v4i *>(st + tt * 8192 + a_addr[j]);   // around the accumulator chains
-                Dh[tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bh, Dh[tt], 0, 0, 0);
-                Dl[tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bl, Dl[tt], 0, 0, 0);
-            }
-        }
-        stage_write(nxt, smem_mmq3 + (buf ^ 1) * S::BYTES);          // the other buffer: everybody left it at the previous barrier; frees the staging registers for the epilogue
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- per super-block: isum = 128 Dh + Dl (exact), fp32 scales, the Q4_K / Q5_K min term on two more MFMAs (digit-split per-32 sums)
-        float dw, ndmin = 0.0f; v4i bm_lo = {0, 0, 0, 0}, bm_hi = {0, 0, 0, 0};
-        if (KQ45) {
-            const unsigned s1 = (unsigned)h[2], s2 = (unsigned)h[3];
-            const unsigned mw0 = s1 & 0x3f3f3f3fu, mw1 = ((s2 >> 4) & 0x0f0f0f0fu) | (((s1 >> 6) & 0x03030303u) << 4);
-            dw = h2f_b((unsigned)h[0] & 0xFFFF); ndmin = -h2f_b((unsigned)h[0] >> 16);
-            bm_lo = v4i{hh ? 0 : (int)mw0, hh ? 0 : (int)mw1, 0, 0}; bm_hi = v4i{0, 0, hh ? 0 : (int)mw0, hh ? 0 : (int)mw1};
-        } else dw = h2f_b((unsigned short)h[0]);
-#pragma unroll
-        for (int tt = 0; tt < TT; tt++) {
-            v16i mlo = zero16(), mhi = zero16();
-            if (KQ45) {
-                const v4i abs_ = *reinterpret_cast<const v4i *>(st + bs_addr + tt * 512);
-                mlo = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, bm_lo, zero16(), 0, 0, 0);
-                mhi = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, bm_hi, zero16(), 0, 0, 0);
-            }
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) {
-                const v4f da = *reinterpret_cast<const v4f *>(st + dk_addr + tt * 128 + q4 * 32);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int r = 4 * q4 + e;
-                    acc[tt][r] = fmaf(dw * da[e], (float)(Dh[tt][r] * 128 + Dl[tt][r]), acc[tt][r]);
-                    if (KQ45) acc[tt][r] = fmaf(ndmin * da[e], (float)(mhi[r] * 128 + mlo[r]), acc[tt][r]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-    }
-    // store (blockIdx.z is not used by this grid: hand the slice index to the common store through a local copy of the arguments' slab base)
-    {
-        float *y = a.y[m] + (size_t)ksl * a.slab_stride;
-        const bool has_res = a.sb_per_split >= NSB && a.res[m] != nullptr;
-        const float *rb = has_res ? a.res[m] : y;
-        const int orow = r0 + l31, rowc = min(orow, W.rows - 1);
-#pragma unroll
-        for (int tt = 0; tt < TT; tt++) {
-            if (tt < my_tiles) {
-                float rv[16];
-#pragma unroll
-                for (int r = 0; r < 16; r++) rv[r] = rb[(size_t)min(t0 + tt * 32 + tok_of(r, hh), N - 1) * a.ldy + rowc];
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int tok = t0 + tt * 32 + tok_of(r, hh);
-                    if (tok < N && orow < W.rows) y[(size_t)tok * a.ldy + orow] = has_res ? acc[tt][r] + rv[r] : acc[tt][r];
-                }
-            }
-        }
-    }
-}
-
 // y[t][r] = (residual[t][r] +) sum_z slab_z[t][r], z in fixed order (deterministic); rows x cols floats per slab
 __global__ __launch_bounds__(256) void k_mmq2_reduce(const float *__restrict__ slabs, int n_slabs, long long slab_stride, const float *__restrict__ residual, float *__restrict__ y, size_t n4) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -656,61 +451,13 @@ static void mmq2_launch_tt(int type, dim3 grid, size_t lds, hipStream_t s, const
     throw HipError{hipErrorInvalidValue, "mmq2: token tiles per chunk outside the kernel's register budget", __FILE__, __LINE__};
 }
 
-template <typename KernelT>
-static void mmq3_launch_kernel(KernelT kernel, bool &attr_done, unsigned n_blocks, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A, int n_chunks, int n_units) {
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_done = true; }
-    hipLaunchKernelGGL(kernel, dim3(n_blocks), dim3(256), lds, s, a, A, n_chunks, n_units);
-}
-constexpr int MMQ3_TT = 3;                                     // token tiles per chunk: two int32 accumulator sets + the fp32 accumulators per tile
-static bool launch_mmq3(Mmq2Args &a, const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s) {
-    a.n_mat = n; a.groups_each = (W[0]->rows + 127) / 128; a.N = N; a.ldy = ldy;
-    a.n_tiles = (N + 31) / 32;
-    int max_tt = MMQ3_TT;
-    { static int tt_env = -1; if (tt_env < 0) { const char *e = getenv("MINIGPT4_MMQ3_TT"); tt_env = e ? atoi(e) : 0; } if (tt_env > 0) max_tt = std::min(max_tt, tt_env); }   // experiments
-    const int n_chunks = (a.n_tiles + max_tt - 1) / max_tt;
-    a.tiles_per_chunk = (a.n_tiles + n_chunks - 1) / n_chunks;
-    const int NSB = W[0]->cols / 256;
-    const int wgs = n * a.groups_each * n_chunks;
-    int ks = 1;
-    const size_t out_floats = (size_t)N * ldy;
-    while (wgs * ks < 2 * g_mmq2_cus && NSB / (ks + 1) >= 4 && A.ws && (size_t)(ks + 1) * out_floats * n <= A.ws_floats) ks++;
-    if (getenv("MINIGPT4_MMQ2_KS")) ks = std::max(1, std::min(atoi(getenv("MINIGPT4_MMQ2_KS")), std::min(NSB, A.ws ? (int)(A.ws_floats / std::max<size_t>(1, out_floats * n)) : 1)));
-    a.sb_per_split = (NSB + ks - 1) / ks;
-    ks = (NSB + a.sb_per_split - 1) / a.sb_per_split;
-    if (ks > 1) {
-        if ((size_t)ldy % 4 || out_floats % 4) return false;
-        a.slab_stride = (long long)out_floats;
-        for (int i = 0; i < n; i++) { a.y[i] = A.ws + (size_t)i * ks * out_floats; a.res[i] = nullptr; }
-    }
-    const int n_units = n * a.groups_each * ks;
-    const unsigned n_blocks = (unsigned)((n_units + 7) / 8 * 8 * n_chunks);
-    static bool attr[6] = {false, false, false, false, false, false};
-    const bool kq45 = W[0]->type != GT_Q6_K;
-    switch (a.tiles_per_chunk) {
-    case 1: if (kq45) mmq3_launch_kernel(&k_mmq3<true, 1>, attr[0], n_blocks, 2 * Mmq2Stage<1>::BYTES, s, a, A, n_chunks, n_units); else mmq3_launch_kernel(&k_mmq3<false, 1>, attr[1], n_blocks, 2 * Mmq2Stage<1>::BYTES, s, a, A, n_chunks, n_units); break;
-    case 2: if (kq45) mmq3_launch_kernel(&k_mmq3<true, 2>, attr[2], n_blocks, 2 * Mmq2Stage<2>::BYTES, s, a, A, n_chunks, n_units); else mmq3_launch_kernel(&k_mmq3<false, 2>, attr[3], n_blocks, 2 * Mmq2Stage<2>::BYTES, s, a, A, n_chunks, n_units); break;
-    default: if (kq45) mmq3_launch_kernel(&k_mmq3<true, 3>, attr[4], n_blocks, 2 * Mmq2Stage<3>::BYTES, s, a, A, n_chunks, n_units); else mmq3_launch_kernel(&k_mmq3<false, 3>, attr[5], n_blocks, 2 * Mmq2Stage<3>::BYTES, s, a, A, n_chunks, n_units); break;
-    }
-    if (ks > 1) {
-        for (int i = 0; i < n; i++) {
-            const size_t n4 = out_floats / 4;
-            hipLaunchKernelGGL(k_mmq2_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, A.ws + (size_t)i * ks * out_floats, ks, (long long)out_floats, residual ? residual[i] : nullptr, y[i], n4);
-        }
-    }
-    return true;
-}
-
 // 1..3 same-type, same-shape matrices against the N prepared activation rows in one launch.  y[m][t * ldy + r] (+ residual[m][..]).  false -> shape outside the
 // kernel's range (nothing launched).
 bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s) {
     if (n < 1 || n > 3 || !A.bsq || N < 1) return false;
     for (int i = 0; i < n; i++) if (!mmq2_supported(W[i]->type, W[i]->rows, W[i]->cols) || W[i]->type != W[0]->type || W[i]->rows != W[0]->rows || W[i]->cols != W[0]->cols) return false;
-    bool planes = true;
-    for (int i = 0; i < n; i++) planes = planes && W[i]->pf != nullptr;
-    { static int en = -1; if (en < 0) { const char *e = getenv("MINIGPT4_MMQ3"); en = e ? atoi(e) : 1; } planes = planes && en; }
     Mmq2Args a{};
     for (int i = 0; i < n; i++) { a.w[i] = *W[i]; a.y[i] = y[i]; a.res[i] = residual ? residual[i] : nullptr; }
-    if (planes) return launch_mmq3(a, W, y, residual, n, A, N, ldy, s);
     a.n_mat = n; a.groups_each = (W[0]->rows + 127) / 128; a.N = N; a.ldy = ldy;
     a.n_tiles = (N + 31) / 32;
     int max_tt = W[0]->type == GT_Q6_K ? 2 : 3;          // token tiles per chunk the 256-register budget (two waves per SIMD) admits: Q6_K keeps four half-masked operand sets per pair

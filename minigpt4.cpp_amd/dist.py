@@ -1,8 +1,14 @@
-"""Data-parallel request sharding + load-time weight broadcast (host-side plumbing over torch.distributed).
+"""Data-parallel replicas: request sharding + the load-time weight broadcast (host-side orchestration over torch.distributed).
 
 The path shards as independent requests: a request = (image, prompt) owns its embedding, KV cache and n_past, so ranks
 never exchange anything per token.  The only collective is the load-time broadcast of the two weight arenas from rank 0
-(`ncclBroadcast` over xGMI on the GPU box; the same code runs on `gloo` in the CPU tests).
+(`ncclBroadcast` over xGMI on the GPU box; the same code runs on `gloo` in the CPU tests):
+
+  rank 0        : minigpt4_model_load reads both files, repacks, fills its arenas                     (LOAD_FULL)
+  ranks 1..N-1  : MINIGPT4_LOAD=recv -> headers only: the arenas are laid out and allocated, nothing is read / uploaded / repacked   (LOAD_RECV)
+  all           : the layout plans (sizes + take()-sequence hashes) must agree; both arenas are broadcast in <= 1 GiB pieces;
+                  receivers call minigpt4_amd_weights_received; the arena checksums must agree
+so the 11.4 GB of the 13B pair cross the file system once per node instead of once per GPU.
 """
 from __future__ import annotations
 
@@ -38,3 +44,56 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def arena_tensor(lib, ctx, which: int, device):
+    """A flat uint8 torch view of weight arena `which` (0: LLM, 1: vision) of a loaded context -- no copy (the engine owns the memory)."""
+    import ctypes
+
+    import torch
+    ptr, nb = ctypes.c_void_p(), ctypes.c_size_t()
+    assert lib.library.minigpt4_amd_weight_arena(ctx.ptr, which, ctypes.byref(ptr), ctypes.byref(nb)) == 0
+
+    class _Arena:
+        __cuda_array_interface__ = {"shape": (nb.value,), "typestr": "|u1", "data": (ptr.value, False), "version": 2}
+    return torch.as_tensor(_Arena(), device=device)
+
+
+def load_replica(lib, vision_path: str, llm_path: str, rank: int, world: int, device=None, **load_kw):
+    """Load this rank's replica: rank 0 from the files, every other rank by receiving rank 0's arenas.  Returns (ctx, stats) with
+    stats = {"mode", "load_s" (file load on rank 0 / header-only load elsewhere), "bcast_ms", "plan", "checksums"}; raises if the ranks disagree."""
+    import os
+    import time
+
+    import torch
+    import torch.distributed as dist
+    recv = world > 1 and rank != 0
+    t0 = time.time()
+    if recv:
+        os.environ["MINIGPT4_LOAD"] = "recv"
+    try:
+        ctx = lib.minigpt4_model_load(vision_path, llm_path, **load_kw)
+    finally:
+        os.environ.pop("MINIGPT4_LOAD", None)
+    load_s = time.time() - t0
+    stats = {"mode": "recv" if recv else "full", "load_s": load_s, "bcast_ms": None, "plan": lib.amd_arena_plan(ctx)}
+    if world > 1:
+        plans = gather_objects(stats["plan"], world)
+        if any(p != plans[0] for p in plans):
+            raise RuntimeError(f"rank {rank}: arena layouts differ between ranks: {plans}")
+        if device is not None:
+            torch.cuda.synchronize(device)
+        dist.barrier()
+        t0 = time.time()
+        for which in (0, 1):
+            broadcast_arena(arena_tensor(lib, ctx, which, device), src=0)
+        if device is not None:
+            torch.cuda.synchronize(device)
+        stats["bcast_ms"] = (time.time() - t0) * 1e3
+        if recv:
+            assert lib.library.minigpt4_amd_weights_received(ctx.ptr) == 0
+        sums = gather_objects([lib.amd_arena_checksum(ctx, 0), lib.amd_arena_checksum(ctx, 1)], world)
+        if any(c != sums[0] for c in sums):
+            raise RuntimeError(f"rank {rank}: arena contents differ after the broadcast: {sums}")
+        stats["checksums"] = sums[0]
+    return ctx, stats

@@ -138,6 +138,13 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_sample_logits.argtypes = [FLOAT_PTR, I32, I32, F32, I32, F32, F32, F32, I32, F32, F32]
         L.minigpt4_amd_decode_image.argtypes = [CHAR_PTR, SIZE_T, P(MiniGPT4Image)]
         L.minigpt4_amd_resample_coeffs.argtypes = [I32, I32, INT_PTR, INT_PTR, INT_PTR, INT_PTR, SIZE_T]
+        U64P, SZP = P(ctypes.c_uint64), P(ctypes.c_size_t)
+        L.minigpt4_amd_plan_arenas.argtypes = [CHAR_PTR, CHAR_PTR, SZP, SZP, U64P, U64P]
+        L.minigpt4_amd_arena_plan.argtypes = [VOID_PTR, SZP, SZP, U64P, U64P]
+        L.minigpt4_amd_load_mode.argtypes = [VOID_PTR]
+        L.minigpt4_amd_weights_received.argtypes = [VOID_PTR]
+        L.minigpt4_amd_copy_arenas.argtypes = [VOID_PTR, VOID_PTR]
+        L.minigpt4_amd_arena_checksum.argtypes = [VOID_PTR, I32, U64P]
         L.minigpt4_amd_set_conversations.argtypes = [VOID_PTR, I32]
         L.minigpt4_amd_select_conversation.argtypes = [VOID_PTR, I32]
         L.minigpt4_amd_n_conversations.argtypes = [VOID_PTR]
@@ -228,6 +235,25 @@ class MiniGPT4SharedLibrary:
     # ---------------------------------------------------------------- additive surface (numpy in / out)
     def amd_device_count(self) -> int:
         return int(self.library.minigpt4_amd_device_count())
+
+    # multi-GPU load (include/minigpt4_amd.h)
+    def amd_plan_arenas(self, vision_path: str, llm_path: str) -> dict:
+        """Arena layout the two files produce, computed on the host (no GPU): {"llm_bytes", "vision_bytes", "llm_hash", "vision_hash"}."""
+        lb, vb, lh, vh = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_uint64(), ctypes.c_uint64()
+        rc = self.library.minigpt4_amd_plan_arenas(vision_path.encode(), llm_path.encode(), ctypes.byref(lb), ctypes.byref(vb), ctypes.byref(lh), ctypes.byref(vh))
+        if rc:
+            raise RuntimeError(f"plan_arenas failed ({rc}): " + self.library.minigpt4_amd_last_error().decode())
+        return {"llm_bytes": lb.value, "vision_bytes": vb.value, "llm_hash": lh.value, "vision_hash": vh.value}
+
+    def amd_arena_plan(self, ctx) -> dict:
+        lb, vb, lh, vh = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_uint64(), ctypes.c_uint64()
+        assert self.library.minigpt4_amd_arena_plan(ctx.ptr, ctypes.byref(lb), ctypes.byref(vb), ctypes.byref(lh), ctypes.byref(vh)) == 0
+        return {"llm_bytes": lb.value, "vision_bytes": vb.value, "llm_hash": lh.value, "vision_hash": vh.value}
+
+    def amd_arena_checksum(self, ctx, which: int) -> int:
+        v = ctypes.c_uint64()
+        assert self.library.minigpt4_amd_arena_checksum(ctx.ptr, which, ctypes.byref(v)) == 0
+        return int(v.value)
 
     # several conversations per context (include/minigpt4_amd.h): the reference calls act on the selected one
     def amd_set_conversations(self, ctx, n: int):

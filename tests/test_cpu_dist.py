@@ -33,6 +33,26 @@ def _worker(rank, world, port, out_dir):
         assert sorted(merged) == list(range(7))
         t = D.max_over_ranks(1.0 + rank)
         assert t == float(world)
+        # the receive path's planner, metadata only (no GPU): every rank derives the arena layout from the file HEADERS; the layouts must agree before any byte moves,
+        # and a rank that only planned can size its receive buffers from the plan (here: CPU tensors standing in for the two HBM arenas)
+        from minigpt4_cpp_amd import minigpt4_library as ML, modelgen as G
+        lib = ML.load_library()
+        vp, lp = os.path.join(out_dir, "vision.bin"), os.path.join(out_dir, "llm.bin")
+        if rank == 0:
+            G.write_vision_file(vp, G.tiny_vision(n_embd_llm=4096), seed=3, std=0.05)
+            G.write_llm_file(lp, G.tiny_llm(wtype="q5_k", n_embd=256, n_layer=2, n_head=4, n_vocab=512, mix="q5_k_m"), seed=1, std=0.05)
+        dist.barrier()
+        plan = lib.amd_plan_arenas(vp, lp)
+        plans = D.gather_objects(plan, world)
+        assert plans[0] == plans[1] and plan["llm_bytes"] > 0 and plan["vision_bytes"] > 0
+        assert plan["llm_bytes"] >= os.path.getsize(lp) * 0.9 and plan["vision_bytes"] >= os.path.getsize(vp) * 0.9   # planes have the files' byte volume
+        for nbytes in (plan["llm_bytes"], plan["vision_bytes"]):
+            buf = torch.zeros(nbytes, dtype=torch.uint8)
+            if rank == 0:
+                buf.copy_(torch.from_numpy(np.random.default_rng(nbytes % 1000).integers(0, 256, nbytes, dtype=np.uint8)))
+            D.broadcast_arena(buf, src=0, chunk_bytes=1 << 20)
+            sums = D.gather_objects(int(buf.to(torch.int64).sum()), world)
+            assert sums[0] == sums[1]
         with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
             f.write("ok")
     finally:

@@ -1,0 +1,106 @@
+"""Boundary, GPU side (round-1 verdict item 8): the library driven the way the reference's clients drive it --
+  * through the reference binding's EFFECTIVE ABI (tests/ref_abi.py: int32 for size_t / bool, POINTER(c_char) strings), the whole MiniGPT4ChatBot flow of
+    minigpt4_library.py:568-689 (reset_chat + system_prompt, encode_image, begin_chat_image, end_chat_image loop with the two EOS predicates), also with garbage in the
+    upper register halves of the int32-declared size_t arguments;
+  * as a C program compiled against include/minigpt4.h that replays examples/main.cpp:207-293.
+Both must produce the pieces the product's own wrapper produces on the same files."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROMPT = "what is the text in the picture?"
+
+
+@pytest.fixture(scope="module")
+def e2e_files(tmp_path_factory):
+    from minigpt4_cpp_amd import modelgen as G
+    d = tmp_path_factory.mktemp("boundary")
+    vp, lp = str(d / "vision.bin"), str(d / "llm.bin")
+    G.write_vision_file(vp, G.tiny_vision(n_embd_llm=4096), seed=11, std=0.05)
+    G.write_llm_file(lp, G.tiny_llm(wtype="q4_0", n_embd=4096, n_layer=1, n_head=32, n_vocab=512, output_type="q6_k"), seed=2, std=0.02)
+    img = G.synth_image(42)
+    raw = str(d / "image.raw")
+    img.astype(np.float32).tofile(raw)
+    return vp, lp, img, raw
+
+
+def _product_pieces(gpu_lib, vp, lp, img, n):
+    from minigpt4_cpp_amd import minigpt4_library as ML
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=256, n_batch=64)
+    try:
+        emb = gpu_lib.minigpt4_encode_image(ctx, ML.array_to_image_struct(img))
+        gpu_lib.minigpt4_system_prompt(ctx)
+        gpu_lib.minigpt4_begin_chat_image(ctx, emb, PROMPT)
+        return [gpu_lib.minigpt4_end_chat_image(ctx, temp=0.0) for _ in range(n)]
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+
+
+@pytest.mark.parametrize("poison", [False, True])
+def test_chatbot_flow_through_the_reference_abi(gpu_lib, e2e_files, poison):
+    import ref_abi as RA
+    from minigpt4_cpp_amd import minigpt4_library as ML
+    vp, lp, img, _ = e2e_files
+    n = 12
+    want = _product_pieces(gpu_lib, vp, lp, img, n)
+    L = RA.bind(ML.default_library_path())
+    if poison:
+        # the reference declares size_t n_threads as int32: the upper half of the 64-bit argument register is whatever the caller left there.  Re-declare those
+        # parameters as uint64 and put garbage in the upper half -- the library must behave identically (it reads n_threads as a hint and ignores it).
+        G64 = ctypes.c_uint64
+        L.minigpt4_encode_image.argtypes = [RA.VOID_PTR, RA.ImageP, RA.EmbeddingP, G64]
+        L.minigpt4_begin_chat_image.argtypes = [RA.VOID_PTR, RA.EmbeddingP, RA.CHAR_PTR, G64]
+        L.minigpt4_system_prompt.argtypes = [RA.VOID_PTR, G64]
+        L.minigpt4_end_chat_image.argtypes = [RA.VOID_PTR, RA.CHAR_PTR_PTR, G64] + RA._END[3:]
+    nt = (0xDEADBEEF << 32) | 4 if poison else 4
+    ctx = L.minigpt4_model_load(RA.cstr(vp), RA.cstr(lp), 1, 1337, 256, 64, 0x100 if poison else 0)   # numa: a C bool read from the low byte
+    assert ctx
+    try:
+        # MiniGPT4ChatBot.upload_image (:676-689): reset_chat -> system_prompt, then encode_image on the caller's float CHW buffer
+        assert L.minigpt4_reset_chat(ctx) == 0
+        assert L.minigpt4_system_prompt(ctx, nt) == 0
+        buf = np.ascontiguousarray(img[None], np.float32)
+        image = RA.MiniGPT4Image(buf.ctypes.data_as(ctypes.c_void_p), 224, 224, 3, 1)
+        emb = RA.MiniGPT4Embedding()
+        assert L.minigpt4_encode_image(ctx, ctypes.byref(image), ctypes.byref(emb), nt) == 0
+        assert emb.n_embeddings == 32 * 4096
+        # MiniGPT4ChatBot.generate (:624-641)
+        assert L.minigpt4_begin_chat_image(ctx, ctypes.byref(emb), RA.cstr(PROMPT), nt) == 0
+        got, chat = [], ""
+        for _ in range(n):
+            tok = ctypes.POINTER(ctypes.c_char)()
+            assert L.minigpt4_end_chat_image(ctx, ctypes.byref(tok), nt, 0.0, 40, 0.9, 1.0, 1.0, 64, 1.1, 1.0, 1.0, 0, 5.0, 1.0, 1) == 0
+            piece = ctypes.cast(tok, ctypes.c_char_p).value.decode("utf-8", errors="replace")
+            chat += piece
+            got.append(piece)
+            assert L.minigpt4_contains_eos_token(RA.cstr(piece)) in (0, 11) and L.minigpt4_is_eos(RA.cstr(chat)) in (0, 12)
+        assert got == want
+        assert L.minigpt4_free_embedding(ctypes.byref(emb)) == 0 and not emb.data
+        assert ctypes.cast(L.minigpt4_error_code_to_string(9), ctypes.c_char_p).value == b"LLamaProjectionEmbeddingInvalidSize"
+    finally:
+        assert L.minigpt4_free(ctx) == 0
+
+
+def test_c_client_replays_examples_main(gpu_lib, e2e_files, tmp_path):
+    from minigpt4_cpp_amd import minigpt4_library as ML
+    vp, lp, img, raw = e2e_files
+    so = ML.default_library_path()
+    exe = str(tmp_path / "replay_main")
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "replay_main.c"), "-o", exe,
+                         "-L", os.path.dirname(so), "-l:" + os.path.basename(so), "-Wl,-rpath," + os.path.dirname(so)], capture_output=True, text=True)
+    if cc.returncode != 0 and "not found" in (cc.stderr or "") and "gcc" in (cc.stderr or ""):
+        pytest.skip("no C compiler on this box")
+    assert cc.returncode == 0, cc.stderr
+    n = 10
+    run = subprocess.run([exe, vp, lp, raw, str(n), PROMPT], capture_output=True, timeout=300)
+    assert run.returncode == 0, run.stderr.decode(errors="replace")[-500:]
+    out = run.stdout.decode("utf-8", errors="replace")
+    body = out.split("BEGIN\n", 1)[1].rsplit("END\n", 1)[0]
+    want = _product_pieces(gpu_lib, vp, lp, img, n)
+    assert body == "".join(p + "\n" for p in want)

@@ -1,6 +1,6 @@
 """GPU parity of the second-generation prefill kernels (csrc/mmq2_kernels.hip) against the oracle's ggml mul_mat (Q8_K activations, exact integer sub-block dots):
-both generations -- compact planes (k_mmq2_*: sub-block scales applied by VALU multiply-adds) and pre-scaled prefill planes (k_mmq3: the scales ride in the weights as two
-int8 digits, exact) -- at every token-tile count, several chunks, ragged row / token counts, 1..3 matrices per launch, residual add, forced K splits (fixed-order combination).  Integer dots are exact; only the order in which the per-super-block fp32 terms are added differs -> 2e-5 of the row maximum, like test_mul_mat_matches_oracle."""
+every token-tile count (1..3 tiles per chunk, several chunks), ragged row / token counts, 1..3 matrices per launch, residual add, forced K splits (fixed-order
+combination).  Integer dots are exact; only the order in which the per-super-block fp32 terms are added differs -> 2e-5 of the row maximum, like test_mul_mat_matches_oracle."""
 import numpy as np
 import pytest
 
@@ -21,10 +21,9 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("generation", [2, 3], ids=["compact", "prescaled"])
 @pytest.mark.parametrize("wtype", ["q4_k", "q5_k", "q6_k"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "N%d_K%d_R%d_m%d_ks%d_res%d" % c)
-def test_mmq2_matches_oracle(gpu_lib, wtype, case, generation):
+def test_mmq2_matches_oracle(gpu_lib, wtype, case):
     import refcpu as R
     from minigpt4_cpp_amd import quants as Q
     N, n_in, n_out, n_mat, ks, with_res = case
@@ -35,7 +34,7 @@ def test_mmq2_matches_oracle(gpu_lib, wtype, case, generation):
     x = rng.standard_normal((N, n_in)).astype(np.float32)
     x[N // 2, : min(256, n_in)] = 0.0                                   # an all-zero Q8_K block (d = 0)
     res = rng.standard_normal((n_mat, N, n_out)).astype(np.float32) if with_res else None
-    got = gpu_lib.amd_test_mmq2(t, raw, n_mat, n_in, n_out, x, residual=res, ks=ks, generation=generation)
+    got = gpu_lib.amd_test_mmq2(t, raw, n_mat, n_in, n_out, x, residual=res, ks=ks)
     want = R.mul_mat(t, raw, n_in, n_mat * n_out, x).reshape(N, n_mat, n_out).transpose(1, 0, 2)
     scale = np.abs(want).max()
     if with_res:
@@ -52,20 +51,6 @@ def test_mmq2_is_deterministic_with_k_split(gpu_lib):
     t = Q.NAME_TO_TYPE["q5_k"]
     raw = Q.quantize(t, (0.05 * rng.standard_normal((256, 5120))).astype(np.float32))
     x = rng.standard_normal((142, 5120)).astype(np.float32)
-    for gen in (2, 3):
-        a = gpu_lib.amd_test_mmq2(t, raw, 1, 5120, 256, x, ks=5, generation=gen)
-        b = gpu_lib.amd_test_mmq2(t, raw, 1, 5120, 256, x, ks=5, generation=gen)
-        assert np.array_equal(a, b)
-
-
-def test_prescaled_planes_equal_compact_planes_bit_for_bit(gpu_lib):
-    """sum_j sc_j (q_j . a_j) == (sc q) . a in int32: with the same K split the two generations accumulate identical fp32 terms in the same order."""
-    from minigpt4_cpp_amd import quants as Q
-    rng = np.random.default_rng(12)
-    for wtype in ("q4_k", "q5_k", "q6_k"):
-        t = Q.NAME_TO_TYPE[wtype]
-        raw = Q.quantize(t, (0.05 * rng.standard_normal((160, 2048))).astype(np.float32))
-        x = rng.standard_normal((70, 2048)).astype(np.float32)
-        a = gpu_lib.amd_test_mmq2(t, raw, 1, 2048, 160, x, ks=1, generation=2)
-        b = gpu_lib.amd_test_mmq2(t, raw, 1, 2048, 160, x, ks=1, generation=3)
-        assert np.array_equal(a, b), wtype
+    a = gpu_lib.amd_test_mmq2(t, raw, 1, 5120, 256, x, ks=5)
+    b = gpu_lib.amd_test_mmq2(t, raw, 1, 5120, 256, x, ks=5)
+    assert np.array_equal(a, b)

@@ -68,3 +68,67 @@ def test_chatbot_uploads_a_file_through_the_native_image_path(gpu_lib, tmpdir_mo
         assert a == b == c and len(a) == 6
     finally:
         bot.free()
+
+
+def test_receive_mode_load_equals_file_load(gpu_lib, tiny_files):
+    """The multi-GPU load path on one GPU: a context loaded with MINIGPT4_LOAD=recv reads only the headers, lays its arenas out like the file-loading context (same plan),
+    receives the arena bytes (device-to-device copy standing in for the RCCL broadcast) and then produces the same image embedding and the same greedy tokens."""
+    import os
+    from minigpt4_cpp_amd import minigpt4_library as ML, modelgen as G
+    vp, llm = tiny_files
+    lp = llm("q5_k", "q5_k_m")
+    a = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=128, n_batch=32)
+    os.environ["MINIGPT4_LOAD"] = "recv"
+    try:
+        b = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=128, n_batch=32)
+    finally:
+        os.environ.pop("MINIGPT4_LOAD", None)
+    try:
+        assert gpu_lib.library.minigpt4_amd_load_mode(a.ptr) == 0 and gpu_lib.library.minigpt4_amd_load_mode(b.ptr) == 1
+        assert gpu_lib.amd_arena_plan(a) == gpu_lib.amd_arena_plan(b) == gpu_lib.amd_plan_arenas(vp, lp)
+        assert gpu_lib.library.minigpt4_amd_copy_arenas(b.ptr, a.ptr) == 0
+        assert gpu_lib.library.minigpt4_amd_weights_received(b.ptr) == 0 and gpu_lib.library.minigpt4_amd_load_mode(b.ptr) == 0
+        assert [gpu_lib.amd_arena_checksum(a, w) for w in (0, 1)] == [gpu_lib.amd_arena_checksum(b, w) for w in (0, 1)]
+        img = ML.array_to_image_struct(G.synth_image(5))
+        outs = []
+        for ctx in (a, b):
+            emb = gpu_lib.minigpt4_encode_image(ctx, img)
+            e = np.ctypeslib.as_array(emb.data, shape=(emb.n_embeddings,)).copy()
+            gpu_lib.amd_eval_tokens(ctx, [1, 5, 9, 11])
+            lg = gpu_lib.amd_logits(ctx).copy()
+            outs.append((e, lg))
+            gpu_lib.minigpt4_free_embedding(emb)
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    finally:
+        gpu_lib.minigpt4_free(a)
+        gpu_lib.minigpt4_free(b)
+
+
+def test_arena_tensor_view_and_single_rank_rccl_broadcast(gpu_lib, tiny_files):
+    """The zero-copy torch view of a weight arena (what dist.load_replica broadcasts) sees the arena's bytes: its word sum equals the engine's device checksum; a
+    world-size-1 RCCL process group runs the chunked broadcast over it (the N > 1 orchestration needs more GPUs than this box has; the gloo test covers its logic)."""
+    import torch
+    import torch.distributed as dist
+    from minigpt4_cpp_amd import dist as D
+    vp, llm = tiny_files
+    ctx = gpu_lib.minigpt4_model_load(vp, llm("q5_k", "q5_k_m"), verbosity=1, n_ctx=64, n_batch=16)
+    made = False
+    try:
+        dev = torch.device("cuda", 0)
+        for which in (0, 1):
+            t = D.arena_tensor(gpu_lib, ctx, which, dev)
+            assert t.dtype == torch.uint8 and t.is_cuda and t.numel() == gpu_lib.amd_arena_plan(ctx)["llm_bytes" if which == 0 else "vision_bytes"]
+            words = t[: t.numel() // 4 * 4].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+            assert int(words.sum().item()) % (1 << 64) == gpu_lib.amd_arena_checksum(ctx, which)
+        if not dist.is_initialized():
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            made = True
+        before = gpu_lib.amd_arena_checksum(ctx, 0)
+        D.broadcast_arena(D.arena_tensor(gpu_lib, ctx, 0, dev), src=0, chunk_bytes=1 << 20)
+        torch.cuda.synchronize()
+        assert gpu_lib.amd_arena_checksum(ctx, 0) == before
+    finally:
+        if made:
+            dist.destroy_process_group()
+        gpu_lib.minigpt4_free(ctx)
