@@ -118,7 +118,6 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     attn_prefill_ = !(getenv("MINIGPT4_ATTN_PREFILL") && !atoi(getenv("MINIGPT4_ATTN_PREFILL")));   // 0: the per-token attention kernel also for prompt rows (A/B, tests)
     // Opt-in experiment (unmeasured at the time of writing): the w1|w3 launch also prepares w2's activation row (last-arriver per 256-row block),
     // one launch less per layer.
-    tailq_ = getenv("MINIGPT4_TAILQ") ? atoi(getenv("MINIGPT4_TAILQ")) : 0;   // 1: tail-fused preparation; 2: only its contiguous row order (the standalone preparation still runs)
     if (getenv("MINIGPT4_BATCH_ROWS_MAX")) batch_rows_max_ = atoi(getenv("MINIGPT4_BATCH_ROWS_MAX"));
     if (const char *sk = getenv("MINIGPT4_SPLITK")) { sscanf(sk, "%d,%d", &splitk_proj_, &splitk_fc2_); splitk_proj_ = std::max(1, std::min(SPLITK_MAX, splitk_proj_)); splitk_fc2_ = std::max(1, std::min(SPLITK_MAX, splitk_fc2_)); }
     set_matvec_tuning(getenv("MINIGPT4_MV_WAVES") ? atoi(getenv("MINIGPT4_MV_WAVES")) : 0, getenv("MINIGPT4_FAT_LB") ? atoi(getenv("MINIGPT4_FAT_LB")) : 0, prop.multiProcessorCount);
@@ -465,8 +464,6 @@ void Engine::alloc_buffers() {
         act_.ws = reinterpret_cast<float *>(buf_arena_.take(slab_floats * 4)); act_.ws_floats = slab_floats;
         set_mmq2_cus(prop.multiProcessorCount);
     }
-    d_tq_cnt_ = reinterpret_cast<unsigned *>(reinterpret_cast<uint8_t *>(d_scratch_) + 4096);   // arrival counters of the tail-fused quantisation (MINIGPT4_TAILQ)
-    HIP_CHECK(hipMemset(d_tq_cnt_, 0, 4096));
     HIP_CHECK(hipMemset(d_npast_, 0, 256)); HIP_CHECK(hipMemset(d_argmax_, 0, 256)); HIP_CHECK(hipMemset(d_feed_, 0, 256)); HIP_CHECK(hipMemset(d_btok_, 0, 768));
     HIP_CHECK(hipMemset(d_tokens_, 0, B * 4));
     HIP_CHECK(hipHostMalloc((void **)&h_argmax_, 256, hipHostMallocDefault));
@@ -597,22 +594,13 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
         delete att_sc;
         mul_mat(L.wo, N, x_, E, x_, s, &p_att, fz(1), "wo");
         bool paired = false;   // h1_ already holds silu(w1 x) * (w3 x)
-        bool h_ready = false;  // act_ already holds the quantised silu(w1 x) * (w3 x) (tail-fused preparation)
-        if (dec && tailq_ && fz(2) && L.w1.type == L.w3.type) {
-            const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_};
-            SiteScope sc(this, "w1w3", (double)(L.w1.bytes + L.w3.bytes), s);
-            h_ready = launch_matvec_tailq(W2, Y2, act_, s, x_, L.ffn_norm, tabs_, tailq_ == 1 ? d_tq_cnt_ : nullptr, 1024, act_, act_mask_for(L.w2.type));
-        }
-        const bool w13_done = h_ready;
-        if (tailq_ != 1) h_ready = false;
-        if (w13_done) {}
-        else if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5), "w1w3"); }
+        if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5), "w1w3"); }
         else if (act_mask_for(L.w1.type) == act_mask_for(L.w3.type) && !fz(2)) {
             launch_rms_quant(x_, L.ffn_norm, N, E, act_, act_mask_for(L.w1.type), s);
             mul_mat(L.w1, N, h1_, F, nullptr, s, nullptr, false, "w1"); mul_mat(L.w3, N, h3_, F, nullptr, s, nullptr, false, "w3");
         } else { mul_mat(L.w1, N, h1_, F, nullptr, s, &p_ffn, fz(2), "w1"); mul_mat(L.w3, N, h3_, F, nullptr, s, &p_ffn, fz(2), "w3"); }
         const Prep p_h{2, h1_, nullptr};
-        mul_mat(L.w2, N, x_, E, x_, s, h_ready ? nullptr : (paired ? &p_h : &p_silu), fz(3), "w2");
+        mul_mat(L.w2, N, x_, E, x_, s, paired ? &p_h : &p_silu, fz(3), "w2");
     }
     // only the last token's logits are kept (llama.cpp logits_all = false)
     const Prep p_out{1, x_ + (size_t)(N - 1) * E, norm_};
@@ -803,17 +791,21 @@ int Engine::profile_sites(int steps, std::string &json) {
     if (steps <= 0 || cv.n_past + steps > n_ctx_) return 1;
     HIP_CHECK(hipStreamSynchronize(stream_));
     prof_on_ = true; kernel_name_tracing(true);
+    // Every step starts behind a gate kernel that holds the stream for ~8 ms: the host queues the step's ~250 launches and ~500 event records (6-7 us of host time
+    // each, more than most of the kernels run) while the gate spins, and the GPU then drains them back to back -- the event pairs time kernels, not the host.
     hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-    HIP_CHECK(hipEventRecord(a, stream_));
     int tok = h_argmax_[cur_];
+    float tot = 0;
     for (int i = 0; i < steps; i++) {
+        launch_delay(8000, stream_);
+        HIP_CHECK(hipEventRecord(a, stream_));
         if (eval_chunk(&tok, 1, nullptr)) { prof_on_ = false; kernel_name_tracing(false); return 1; }
         cv.n_past += 1;
+        HIP_CHECK(hipEventRecord(b, stream_));
         HIP_CHECK(hipStreamSynchronize(stream_));
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b)); tot += ms;
         tok = h_argmax_[cur_];
     }
-    HIP_CHECK(hipEventRecord(b, stream_));
-    HIP_CHECK(hipStreamSynchronize(stream_));
     prof_on_ = false; kernel_name_tracing(false);
     struct Agg { std::string site, kernel; double us = 0, bytes = 0; long calls = 0; };
     std::vector<Agg> agg;                                                    // first-seen order = launch order within the step
@@ -826,7 +818,6 @@ int Engine::profile_sites(int steps, std::string &json) {
         (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
     }
     site_events_.clear();
-    float tot = 0; HIP_CHECK(hipEventElapsedTime(&tot, a, b));
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     char buf[768];
     json = "{\"steps\": " + std::to_string(steps) + ", \"eager_ms_per_step\": " + std::to_string(tot / steps) + ", \"sites\": [";

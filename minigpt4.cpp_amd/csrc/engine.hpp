@@ -143,7 +143,7 @@ private:
     ActQ act_;
     // per conversation (indexed by slot): position, greedy token of the last evaluation, next input token; logits_ is [slots][n_vocab]
     int *d_npast_ = nullptr, *d_argmax_ = nullptr, *d_feed_ = nullptr;
-    int *d_tokens_ = nullptr; void *d_scratch_ = nullptr; unsigned *d_tq_cnt_ = nullptr; int tailq_ = 0;
+    int *d_tokens_ = nullptr; void *d_scratch_ = nullptr;
     int *d_btok_ = nullptr, *d_bslot_ = nullptr, *d_bpos_ = nullptr; float *blogits_ = nullptr;   // batched decode: row tokens / conversations / positions (one 768-byte slab), [rows][n_vocab] logits
     std::vector<hipGraphExec_t> batch_graph_;                             // [B]: the batched step for B rows (rows are described in device memory, so one graph serves any slot set)
     int *h_argmax_ = nullptr, *h_bstage_ = nullptr; float *h_logits_ = nullptr; int logits_host_slot_ = -1;

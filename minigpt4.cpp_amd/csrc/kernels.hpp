@@ -41,10 +41,6 @@ void set_mmq2_cus(int cus);   // CU count the K-split heuristic aims at (the K-s
 bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s, int pro = 0, const float *px = nullptr,
                        const float *pw = nullptr, const Tables *tb = nullptr, int epi = 0);   // epi 1: y[0][g] = silu(W0[g].x) * (W1[g].x) (n == 2)
 bool matvec_silu_pair_supported(int type, int cols);
-// opt-in: w1|w3 (ffn-norm prologue) + tail-fused preparation of the next mat-vec's row: out planes receive quant(silu(W0 x) * (W1 x)) in `out_mask` form; cnt = zeroed
-// arrival counters (>= rows / 256, left zeroed).  false -> nothing launched.
-bool launch_matvec_tailq(const QWeight *const *W, float *const *y, const ActQ &A, hipStream_t s, const float *px, const float *pw, const Tables &tb, unsigned *cnt, int cnt_capacity,
-                         const ActQ &out, int out_mask);
 // batched decode: N = 1..4 activation rows (prepared in `A`) against 1..3 same-type, same-shape, equally spaced matrices, weights streamed once;
 // y[m][t * ldy + r] (+ residual[m][t * ldy + r]).  false -> outside the kernel's range, use launch_mul_mat.
 bool launch_matvec_rows(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s);
@@ -90,6 +86,7 @@ void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s);
 uint64_t device_checksum(const void *p, size_t bytes, hipStream_t s);   // sum of the 32-bit words (bytes rounded down to 4), mod 2^64; synchronises the stream
 void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s);
 void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s);
+void launch_delay(int us, hipStream_t s);   // profiling gate: keeps the stream busy for `us` microseconds (see Engine::profile_sites)
 
 // ---- vision tower -----------------------------------------------------------------------------------------------------
 // C[M][N] = A[M][K](f16) . W[N][K](f16)^T + bias ; optional fp16-table GELU ; optional residual add (C = residual + C).

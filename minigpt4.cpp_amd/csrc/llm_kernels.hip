@@ -459,21 +459,11 @@ __device__ unsigned long long g_tl[1024 * 8];
 #else
 #define MG4_TL(i) do {} while (0)
 #endif
-// Tail-fused quantisation (TQ, opt-in: MINIGPT4_TAILQ=1; w1|w3 launch only).  The launch that produces h1 = w1 x and h3 = w3 x also prepares the NEXT mat-vec's
-// activation row, so the standalone k_silu_mul_quant launch between w1|w3 and w2 disappears: every wave owns a CONTIGUOUS range of rows, publishes its
-// results write-through (agent-scope stores), drains them and adds its row count to the arrival counter of each 256-row block it touched; the wave whose
-// add completes a block (256 rows of w1 + 256 of w3 = 512 arrivals) reads the block back with agent-scope loads and writes silu(h1) * h3 in ggml's
-// Q8_K / Q8_0 form into the activation planes -- the same quant_emit4 the standalone kernel runs, on the same values, hence bit-identical.  No wave ever
-// waits for another (last-arriver, no spinning), the last arriver zeroes the counter again (graph replay needs no memset node).
-struct TqArgs { unsigned *cnt; ActQ out; int mask; };
-template <int T, int NU, int R, int PRO, int EPI, bool TQ = false>
-__device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, const ProArgs &pa, const int n_groups, const int n_waves, const int wave, const TqArgs *tq = nullptr) {
+template <int T, int NU, int R, int PRO, int EPI>
+__device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, const ProArgs &pa, const int n_groups, const int n_waves, const int wave) {
     static_assert(EPI == EPI_STORE || R == 2, "the SiLU pair epilogue works on row pairs");
-    static_assert(!TQ || (EPI == EPI_STORE && PRO == PRO_RMS), "tail-fused quantisation: plain stores, input row prepared in LDS (the global planes are the OUTPUT)");
     // groups of this wave: g = g_first, g_first + g_step, ... < g_last
-    const int g_first = TQ ? (int)((unsigned)wave * (unsigned)n_groups / (unsigned)n_waves) : wave;
-    const int g_last = TQ ? (int)((unsigned)(wave + 1) * (unsigned)n_groups / (unsigned)n_waves) : n_groups;
-    const int g_step = TQ ? 1 : n_waves;
+    const int g_first = wave, g_last = n_groups, g_step = n_waves;
     MG4_TL(0);
     using X = Tr<T>;
     const int lane = threadIdx.x & 63;
@@ -507,14 +497,8 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
     };
     Grp cur, nxt;
     typename X::AU a[NU];
-    // MG4_PRIME2 (alternate build for A/B, see profiles/r01p_matvec_timeline.log): BOTH pipeline stages are requested before the activation row is prepared / loaded.
-    // The default requests the second stage only at the top of the loop, i.e. after the 2.6 us prologue of a fat-workgroup launch, during which only one stage
-    // (7 MB chip-wide) keeps the memory system busy.  Same loads, same arithmetic, same order of results.
     if (PRO == PRO_NONE) {
         fetch(g_first, cur);
-#ifdef MG4_PRIME2
-        fetch(g_first + g_step, nxt);
-#endif
         MG4_TL(1);
 #pragma unroll
         for (int i = 0; i < NU; i++) X::loada(A, 0, K, uc[i], a[i]);
@@ -553,9 +537,6 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
             for (int r = 0; r < RND; r++) { xv[r].x = tab(pa.tb.silu, xv[r].x); xv[r].y = tab(pa.tb.silu, xv[r].y); xv[r].z = tab(pa.tb.silu, xv[r].z); xv[r].w = tab(pa.tb.silu, xv[r].w); }
         }
         fetch(g_first, cur);
-#ifdef MG4_PRIME2
-        fetch(g_first + g_step, nxt);
-#endif
         MG4_TL(1);
         float scale = 1.0f;
         if (PRO == PRO_RMS) {
@@ -611,8 +592,7 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
                 if (lane == 0 && row < total_rows) {
                     const int m = row >= 2 * rows_each ? 2 : (row >= rows_each ? 1 : 0), lr = row - m * rows_each;
                     const float val = has_res ? out[r] + G.res[r] : out[r];
-                    if (TQ && tq->cnt) __hip_atomic_store(ms.y0 + ((long long)m * ms.dy + lr), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through: read by the block's last arriver
-                    else ms.y0[(long long)m * ms.dy + lr] = val;
+                    ms.y0[(long long)m * ms.dy + lr] = val;
                 }
             }
         }
@@ -620,25 +600,6 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
     // two statically named stages (a `cur = nxt` copy would have to wait for the loads in flight; the requested unroll is refused by the compiler)
     // The sched_barriers keep the next group's loads ahead of the current group's dot products (the scheduler otherwise hoists the arithmetic, and
     // with it the wait for the current tiles, above the loads: one tile in flight instead of two).
-#ifdef MG4_PRIME2
-    for (int g = g_first; g < g_last;) {                      // cur = group g, nxt = group g + step: both already requested
-        consume(g, cur);
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef MG4_TIMELINE
-        if (g == g_first) MG4_TL(3);
-#endif
-        g += g_step;
-        if (g >= g_last) break;
-        fetch(g + g_step, cur);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(g, nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        g += g_step;
-        if (g >= g_last) break;
-        fetch(g + g_step, nxt);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#else
     for (int g = g_first; g < g_last;) {
         fetch(g + g_step, nxt);
         __builtin_amdgcn_sched_barrier(0);
@@ -655,52 +616,17 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
         __builtin_amdgcn_sched_barrier(0);
         g += g_step;
     }
-#endif
     MG4_TL(4);
     if (EPI == EPI_SILU_PAIR) flush_pending();
 #ifdef MG4_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MG4_TL(5);
 #endif
-    if constexpr (TQ) {
-        // Arrival.  Lane 0 issued every result store of this wave; drain them (write-through stores are acknowledged by memory) before the counter moves.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int r = g_first * R;
-        const int r_end = tq->cnt ? min(g_last * R, total_rows) : 0;      // cnt == nullptr: only the contiguous row order is exercised (A/B of the mapping alone)
-        while (r < r_end) {                                               // wave-uniform: one pass per 256-row block the range touches (usually 1, at most 2-3)
-            const int lr = r >= rows_each ? r - rows_each : r;            // ms.n == 2, rows_each % 256 == 0 (checked by the host)
-            const int blk = lr >> 8;
-            const int seg_end = min(r_end, r - (lr & 255) + 256);
-            const unsigned n = (unsigned)(seg_end - r);
-            unsigned old = 0;
-            if (lane == 0) old = __hip_atomic_fetch_add(tq->cnt + blk, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-            if (old + n == 512u) {                                        // 256 rows of w1 and 256 rows of w3 are in memory: this wave prepares the block
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const int i = blk * 256 + lane * 4;
-                // agent-scope (sc1) 16-byte loads: both in flight together, then the four table gathers
-                const __amdgpu_buffer_rsrc_t hb = mkbuf(reinterpret_cast<const uint8_t *>(ms.y0 + blk * 256));       // one descriptor: h3 sits dy floats (< 2 GB) behind h1
-                const v4u_t ua = __builtin_amdgcn_raw_buffer_load_b128(hb, lane * 16, 0, 16);
-                const v4u_t ub = __builtin_amdgcn_raw_buffer_load_b128(hb, lane * 16, (int)ms.dy * 4, 16);
-                float v[4];
-                v[0] = tab(pa.tb.silu, __uint_as_float(ua.x)) * __uint_as_float(ub.x); v[1] = tab(pa.tb.silu, __uint_as_float(ua.y)) * __uint_as_float(ub.y);
-                v[2] = tab(pa.tb.silu, __uint_as_float(ua.z)) * __uint_as_float(ub.z); v[3] = tab(pa.tb.silu, __uint_as_float(ua.w)) * __uint_as_float(ub.w);
-                quant_emit4(v, true, i, 0, rows_each, tq->out, tq->mask);
-                if (lane == 0) __hip_atomic_store(tq->cnt + blk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            r = seg_end;
-        }
-    }
 }
 template <int T, int NU, int R, int PRO, int EPI>
 __global__ __launch_bounds__(PRO == PRO_NONE ? 256 : mv_fat_max_threads<NU>()) void k_matvec_v2(const MatSet ms, const ActQ A, const ProArgs pa, const int n_groups, const int n_waves) {
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));   // wave-uniform: scalar loop control
     matvec_run<T, NU, R, PRO, EPI>(ms, A, pa, n_groups, n_waves, wave);
-}
-template <int T, int NU, int R>
-__global__ __launch_bounds__(mv_fat_max_threads<NU>()) void k_matvec_tq(const MatSet ms, const ActQ A, const ProArgs pa, const TqArgs tq, const int n_groups, const int n_waves) {
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    matvec_run<T, NU, R, PRO_RMS, EPI_STORE, true>(ms, A, pa, n_groups, n_waves, wave, &tq);
 }
 // Two weight types in one launch (llama.cpp's k-quant mixes give wv more bits than wq|wk): waves [0, n_waves1) stream set 1, the rest set 2.  Both
 // sets share K and the prepared activation row (both types read the Q8_K image); every wave passes the same number of workgroup barriers.
@@ -876,42 +802,6 @@ bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *co
     }
 }
 
-// w1|w3 with the ffn-norm prologue AND the tail-fused preparation of w2's activation row (see TqArgs).  cnt: >= rows / 256 zeroed arrival counters (left zeroed).
-// Returns false (nothing launched) when the shape / type is outside the variant's range; the caller then takes the ordinary path.
-template <int T, int NU, int R>
-static void launch_tq_t(const MatSet &ms, const ActQ &A, const ProArgs &pa, const TqArgs &tq, hipStream_t s) {
-    const int n_groups = (ms.n * ms.rows_each + R - 1) / R;
-    const int LB = pick_fat_threads(n_groups, mv_fat_max_threads<NU>()), WPB = LB / 64;
-    const int n_blocks = std::min((n_groups + WPB - 1) / WPB, g_mv_cus);
-    hipLaunchKernelGGL((k_matvec_tq<T, NU, R>), dim3((unsigned)n_blocks), dim3((unsigned)LB), mv_prologue_lds(ms.w0.cols), s, ms, A, pa, tq, n_groups, n_blocks * WPB);
-}
-template <int T>
-static bool launch_tq_type(const MatSet &ms, const ActQ &A, const ProArgs &pa, const TqArgs &tq, hipStream_t s) {
-    const int nu = (ms.w0.cols / Tr<T>::EPU + 63) / 64;
-    switch (nu) {
-    case 1: launch_tq_t<T, 1, 2>(ms, A, pa, tq, s); return true;
-    case 2: launch_tq_t<T, 2, MG4_R_NU2>(ms, A, pa, tq, s); return true;
-    case 3: launch_tq_t<T, 3, MG4_R_NU3>(ms, A, pa, tq, s); return true;
-    case 4: launch_tq_t<T, 4, 1>(ms, A, pa, tq, s); return true;
-    default: return false;
-    }
-}
-bool launch_matvec_tailq(const QWeight *const *W, float *const *y, const ActQ &A, hipStream_t s, const float *px, const float *pw, const Tables &tb, unsigned *cnt, int cnt_capacity,
-                         const ActQ &out, int out_mask) {
-    if (!matvec_prologue_supported(W[0]->type, W[0]->cols) || W[0]->rows % 256 || (cnt && W[0]->rows / 256 > cnt_capacity)) return false;
-    if (out_mask != ACT_Q8K && out_mask != ACT_Q80) return false;
-    MatSet ms;
-    if (!fill_matset(ms, W, y, nullptr, 2)) return false;
-    ProArgs pa{}; pa.x = px; pa.w = pw; pa.tb = tb;
-    TqArgs tq{cnt, out, out_mask};
-    switch (W[0]->type) {
-    case GT_Q4_0: return launch_tq_type<GT_Q4_0>(ms, A, pa, tq, s);
-    case GT_Q4_K: return launch_tq_type<GT_Q4_K>(ms, A, pa, tq, s);
-    case GT_Q5_K: return launch_tq_type<GT_Q5_K>(ms, A, pa, tq, s);
-    case GT_Q6_K: return launch_tq_type<GT_Q6_K>(ms, A, pa, tq, s);
-    default: return false;
-    }
-}
 
 // =====================================================================================================================
 // Batched decode mat-vec (B conversations, one row each): the same persistent-wave two-stage weight pipeline as k_matvec_v2, for up to TN
@@ -959,9 +849,6 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
     Grp cur, nxt;
     MG4_TL(0);
     fetch(wave, cur);
-#ifdef MG4_PRIME2
-    fetch(wave + n_waves, nxt);
-#endif
     MG4_TL(1);
     // LDS image of the N activation rows, laid out like the global ActQ planes (so Tr<T>::loada indexes it unchanged)
     ActQ L;
@@ -1010,25 +897,6 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
             for (int t = 0; t < TN; t++) if (t < N) yo[(size_t)t * ldy] = has_res ? out[t] + G.res[t] : out[t];
         }
     };
-#ifdef MG4_PRIME2
-    for (int g = wave; g < n_groups;) {                       // see matvec_run: both stages were requested before the LDS copy
-        consume(g, cur);
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef MG4_TIMELINE
-        if (g == wave) MG4_TL(3);
-#endif
-        g += n_waves;
-        if (g >= n_groups) break;
-        fetch(g + n_waves, cur);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(g, nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        g += n_waves;
-        if (g >= n_groups) break;
-        fetch(g + n_waves, nxt);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#else
     for (int g = wave; g < n_groups;) {
         fetch(g + n_waves, nxt);
         __builtin_amdgcn_sched_barrier(0);
@@ -1045,7 +913,6 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
         __builtin_amdgcn_sched_barrier(0);
         g += n_waves;
     }
-#endif
     MG4_TL(4);
 #ifdef MG4_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1329,23 +1196,6 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
     __shared__ double s_dred[AT_THREADS / 64];
     const float scale = 1.0f / sqrtf((float)HD);
     const size_t qo = (size_t)t * E + (size_t)h * HD;
-#ifdef MG4_ATTN_EARLY
-    // Alternate build for A/B (same arithmetic, same order): the cached key row and the first cached value rows of this thread do not depend on this step's q / k / v, so
-    // they are requested BEFORE the RoPE prologue (whose q / k / v loads wait for the previous launch's results) instead of after it and after the scores.
-    constexpr int CH_E = HD / 8, P_E = AT_THREADS / CH_E, NPRE_E = 12;
-    int4 kk0[HD / 8];
-    {
-        const __half *kr0 = kc + (size_t)min(tid, max(Tg - 1, 0)) * E + (size_t)h * HD;
-#pragma unroll
-        for (int i = 0; i < HD / 8; i++) kk0[i] = ld16(kr0 + 8 * i);
-    }
-    int4 vpre[NPRE_E];
-    {
-        const __half *vb0 = vc + (size_t)h * HD + 8 * (tid % CH_E);
-#pragma unroll
-        for (int i = 0; i < NPRE_E; i++) vpre[i] = ld16(vb0 + (size_t)min(tid / CH_E + i * P_E, max(Tg - 1, 0)) * E);
-    }
-#endif
     if (FUSED) {
         if (tid < HD / 2) {
             const int i = tid;
@@ -1364,18 +1214,6 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
     unsigned qreg[HD / 2];
 #pragma unroll
     for (int i = 0; i < HD / 8; i++) { const int4 v4 = *reinterpret_cast<const int4 *>(qh + 8 * i); qreg[4 * i] = (unsigned)v4.x; qreg[4 * i + 1] = (unsigned)v4.y; qreg[4 * i + 2] = (unsigned)v4.z; qreg[4 * i + 3] = (unsigned)v4.w; }
-#ifdef MG4_ATTN_EARLY
-    auto dot_kk = [&](const int4 (&kk)[HD / 8]) {
-        float s = 0.0f;
-#pragma unroll
-        for (int i = 0; i < HD / 8; i++) {
-            const unsigned w[4] = {(unsigned)kk[i].x, (unsigned)kk[i].y, (unsigned)kk[i].z, (unsigned)kk[i].w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) { s = fmaf(h2f_bits(w[e] & 0xFFFF), h2f_bits(qreg[4 * i + e] & 0xFFFF), s); s = fmaf(h2f_bits(w[e] >> 16), h2f_bits(qreg[4 * i + e] >> 16), s); }
-        }
-        return s * scale;
-    };
-#endif
     auto dot_row = [&](const __half *kr) {
         int4 kk[HD / 8];
 #pragma unroll
@@ -1390,22 +1228,15 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
         return s * scale;
     };
     float mx = -INFINITY;
-#ifdef MG4_ATTN_EARLY
-    if (tid < Tg) { const float s = dot_kk(kk0); sc[tid] = s; mx = fmaxf(mx, s); }
-    for (int j = tid + AT_THREADS; j < Tg; j += AT_THREADS) { const float s = dot_row(kc + (size_t)j * E + (size_t)h * HD); sc[j] = s; mx = fmaxf(mx, s); }
-#else
     for (int j = tid; j < Tg; j += AT_THREADS) { const float s = dot_row(kc + (size_t)j * E + (size_t)h * HD); sc[j] = s; mx = fmaxf(mx, s); }
-#endif
     if (FUSED && tid == AT_THREADS - 1) { const float s = dot_row(knew); sc[pos] = s; mx = fmaxf(mx, s); }
     // The value rows do not depend on the scores: request the first NPRE of this thread's rows now, so that they arrive during the softmax.
     const int c = tid % CH, p = tid / CH;
     const __half *vb = vc + (size_t)h * HD + 8 * c;
     constexpr int NPRE = 12;
-#ifndef MG4_ATTN_EARLY
     int4 vpre[NPRE];
 #pragma unroll
     for (int i = 0; i < NPRE; i++) vpre[i] = ld16(vb + (size_t)min(p + i * P, max(Tg - 1, 0)) * E);   // clamped: never branches, never out of the cache
-#endif
     mx = wave_max(mx);
     if ((tid & 63) == 0) s_red[tid >> 6] = mx;
     __syncthreads();
@@ -1764,5 +1595,12 @@ void launch_batch_begin(int *n_past, const int *row_slot, const int *row_pos, in
 // end of a decode step: the KV position advances and the greedy token becomes the next input (the host may overwrite it)
 __global__ void k_advance(int *n_past, int n, int *tok0, const int *argmax) { *n_past += n; if (tok0) *tok0 = *argmax; }
 void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s) { note_kernel("k_advance"); hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, n_past, n, tok0, argmax); }
+// Profiling gate (Engine::profile_sites): one wave that keeps the stream busy for `us` microseconds (s_memrealtime: the constant 100 MHz clock) while the host
+// queues the step's launches behind it, so the per-site event pairs time the GPU and not the host's launch rate.  Bounded: at most 2^20 polls even if the clock stood still.
+__global__ void k_delay(int us) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), ticks = (unsigned long long)us * 100ull;
+    for (int i = 0; i < (1 << 20) && __builtin_amdgcn_s_memrealtime() - t0 < ticks; i++) __builtin_amdgcn_s_sleep(32);
+}
+void launch_delay(int us, hipStream_t s) { hipLaunchKernelGGL(k_delay, dim3(1), dim3(1), 0, s, us); }
 
 }  // namespace mg4

@@ -22,11 +22,8 @@ __device__ __forceinline__ v16i zero16() { v16i z; for (int i = 0; i < 16; i++) 
 __device__ __forceinline__ v4i bcast_byte(int b) { const int w = b * 0x01010101; v4i r = {w, w, w, w}; return r; }
 __device__ __forceinline__ int tok_of(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
-#ifndef MG4_MMQ_TT
-#define MG4_MMQ_TT 2        // -DMG4_MMQ_TT=1 (alternate build libminigpt4_tt1.so): half the accumulators / activation fragments per wave -> more waves per SIMD, weights re-read per 32 tokens
-#endif
-constexpr int MMQ_TT = MG4_MMQ_TT;   // token tiles (of 32) per wave
-#define MMQ_BOUNDS __launch_bounds__(256)      // (256, 2) makes hipcc spill the Q4_K / Q5_K kernel to scratch in the TT = 1 builds: not used
+constexpr int MMQ_TT = 2;           // token tiles (of 32) per wave
+#define MMQ_BOUNDS __launch_bounds__(256)
 
 // Combine the 4 K-slices of a workgroup (fixed order: deterministic) and store.  Wave w finalises accumulator registers 4w..4w+3.
 __device__ __forceinline__ void mmq_reduce_store(float (&acc)[MMQ_TT][16], int wv, int lane, int r0, int t0, int rows, int N, float *y, int ldy, const float *residual) {
@@ -81,32 +78,14 @@ __global__ MMQ_BOUNDS void k_mmq_q45k(const QWeight W, const ActQ A, const int N
     __syncthreads();
     Wsb cur, nxt;
     fetch(wv, cur);
-#ifdef MG4_MMQ_APF
-    // alternate build: the activation fragments of the NEXT super-block are requested together with its weights (one L2 round trip per iteration leaves the critical path)
-    v4i alo[MMQ_TT][4], ahi[MMQ_TT][4], alo_n[MMQ_TT][4], ahi_n[MMQ_TT][4];
-#pragma unroll
-    for (int tt = 0; tt < MMQ_TT; tt++)
-#pragma unroll
-        for (int jp = 0; jp < 4; jp++) { const int8_t *p = A.q8k + (size_t)tokc[tt] * K + (size_t)wv * 256 + 64 * jp + 16 * hh; alo[tt][jp] = ldv4(p); ahi[tt][jp] = ldv4(p + 32); }
-#endif
     for (int sb = wv; sb < NSB; sb += 4) {
         fetch(sb + 4, nxt);
-#ifdef MG4_MMQ_APF
-        {
-            const int sbn = min(sb + 4, NSB - 1);
-#pragma unroll
-            for (int tt = 0; tt < MMQ_TT; tt++)
-#pragma unroll
-                for (int jp = 0; jp < 4; jp++) { const int8_t *p = A.q8k + (size_t)tokc[tt] * K + (size_t)sbn * 256 + 64 * jp + 16 * hh; alo_n[tt][jp] = ldv4(p); ahi_n[tt][jp] = ldv4(p + 32); }
-        }
-#else
         // activation fragments of this super-block (L2-resident): per token tile 4 x {lo, hi}
         v4i alo[MMQ_TT][4], ahi[MMQ_TT][4];
 #pragma unroll
         for (int tt = 0; tt < MMQ_TT; tt++)
 #pragma unroll
             for (int jp = 0; jp < 4; jp++) { const int8_t *p = A.q8k + (size_t)tokc[tt] * K + (size_t)sb * 256 + 64 * jp + 16 * hh; alo[tt][jp] = ldv4(p); ahi[tt][jp] = ldv4(p + 32); }
-#endif
         // 6-bit scales / mins of this lane's weight row
         const unsigned s0 = (unsigned)cur.h[1], s1 = (unsigned)cur.h[2], s2 = (unsigned)cur.h[3];
         const unsigned scw[2] = {s0 & 0x3f3f3f3fu, (s2 & 0x0f0f0f0fu) | (((s0 >> 6) & 0x03030303u) << 4)};
@@ -145,12 +124,6 @@ __global__ MMQ_BOUNDS void k_mmq_q45k(const QWeight W, const ActQ A, const int N
                 acc[tt][r] = fmaf(-(dmin * da), (float)msum[tt][r], acc[tt][r]);
             }
         cur = nxt;
-#ifdef MG4_MMQ_APF
-#pragma unroll
-        for (int tt = 0; tt < MMQ_TT; tt++)
-#pragma unroll
-            for (int jp = 0; jp < 4; jp++) { alo[tt][jp] = alo_n[tt][jp]; ahi[tt][jp] = ahi_n[tt][jp]; }
-#endif
     }
     mmq_reduce_store(acc, wv, lane, r0, t0, W.rows, N, y, ldy, residual);
 }
@@ -197,30 +170,13 @@ __global__ MMQ_BOUNDS void k_mmq_q6k(const QWeight W, const ActQ A, const int N,
     Wsb cur, nxt;
     fetch(wv, cur);
     const v4i z4 = {0, 0, 0, 0};
-#ifdef MG4_MMQ_APF
-    v4i alo[MMQ_TT][4], ahi[MMQ_TT][4], alo_n[MMQ_TT][4], ahi_n[MMQ_TT][4];
-#pragma unroll
-    for (int tt = 0; tt < MMQ_TT; tt++)
-#pragma unroll
-        for (int p = 0; p < 4; p++) { const int n = p >> 1, c = p & 1; const int8_t *ap = A.q8k + (size_t)tokc[tt] * K + (size_t)wv * 256 + 128 * n + 32 * c + 16 * hh; alo[tt][p] = ldv4(ap); ahi[tt][p] = ldv4(ap + 64); }
-#endif
     for (int sb = wv; sb < NSB; sb += 4) {
         fetch(sb + 4, nxt);
-#ifdef MG4_MMQ_APF
-        {
-            const int sbn = min(sb + 4, NSB - 1);
-#pragma unroll
-            for (int tt = 0; tt < MMQ_TT; tt++)
-#pragma unroll
-                for (int p = 0; p < 4; p++) { const int n = p >> 1, c = p & 1; const int8_t *ap = A.q8k + (size_t)tokc[tt] * K + (size_t)sbn * 256 + 128 * n + 32 * c + 16 * hh; alo_n[tt][p] = ldv4(ap); ahi_n[tt][p] = ldv4(ap + 64); }
-        }
-#else
         v4i alo[MMQ_TT][4], ahi[MMQ_TT][4];
 #pragma unroll
         for (int tt = 0; tt < MMQ_TT; tt++)
 #pragma unroll
             for (int p = 0; p < 4; p++) { const int n = p >> 1, c = p & 1; const int8_t *ap = A.q8k + (size_t)tokc[tt] * K + (size_t)sb * 256 + 128 * n + 32 * c + 16 * hh; alo[tt][p] = ldv4(ap); ahi[tt][p] = ldv4(ap + 64); }
-#endif
         v16i isum[MMQ_TT];
 #pragma unroll
         for (int tt = 0; tt < MMQ_TT; tt++) isum[tt] = zero16();
@@ -254,12 +210,6 @@ __global__ MMQ_BOUNDS void k_mmq_q6k(const QWeight W, const ActQ A, const int N,
                 acc[tt][r] = fmaf(d * dkl[(tt * 32 + tok_of(r, hh)) * NSB + sb], (float)isum[tt][r], acc[tt][r]);
             }
         cur = nxt;
-#ifdef MG4_MMQ_APF
-#pragma unroll
-        for (int tt = 0; tt < MMQ_TT; tt++)
-#pragma unroll
-            for (int p = 0; p < 4; p++) { alo[tt][p] = alo_n[tt][p]; ahi[tt][p] = ahi_n[tt][p]; }
-#endif
     }
     mmq_reduce_store(acc, wv, lane, r0, t0, W.rows, N, y, ldy, residual);
 }

@@ -9,6 +9,9 @@ never exchange anything per token.  The only collective is the load-time broadca
   all           : the layout plans (sizes + take()-sequence hashes) must agree; both arenas are broadcast in <= 1 GiB pieces;
                   receivers call minigpt4_amd_weights_received; the arena checksums must agree
 so the 11.4 GB of the 13B pair cross the file system once per node instead of once per GPU.
+
+Process set-up order: a process that uses this module on GPUs must initialise torch's device side (`torch.cuda.set_device(local_rank)`) BEFORE it loads
+libminigpt4.so -- torch ships its own HIP runtime, and it only finds the GPUs when that runtime is the first one mapped (bench.py and tests/conftest.py do this).
 """
 from __future__ import annotations
 

@@ -29,6 +29,14 @@ def tmpdir_models(tmp_path_factory):
 
 @pytest.fixture(scope="session")
 def lib():
+    # A process that uses torch's GPU side (tests of dist.arena_tensor / RCCL) next to libminigpt4.so must let torch bring up ITS bundled HIP runtime first: with
+    # the library's /opt/rocm runtime mapped first, torch.cuda later fails with "No HIP GPUs are available" (seen on the GPU box, round 2).  bench.py has that order.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     from minigpt4_cpp_amd import minigpt4_library as ML
     so = ML.default_library_path()
     if not os.path.exists(so):
