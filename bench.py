@@ -285,14 +285,19 @@ def main():
     prof = lib.amd_profile_sites(ctx, 8)
     by_kernel = {}
     for r in prof["sites"]:
-        k = by_kernel.setdefault(r["kernel"], {"kernel": r["kernel"], "sites": [], "calls_per_token": 0.0, "us_per_token": 0.0, "bytes_per_token": 0.0})
+        k = by_kernel.setdefault(r["kernel"], {"kernel": r["kernel"], "sites": [], "calls_per_token": 0.0, "us_per_token": 0.0, "marker_us_per_token": 0.0, "bytes_per_token": 0.0,
+                                               "timing": r.get("timing", "markers")})
         k["sites"].append(r["site"])
         k["calls_per_token"] += r["calls_per_step"]
         k["us_per_token"] += r["calls_per_step"] * r["avg_us"]
+        k["marker_us_per_token"] += r["calls_per_step"] * r.get("avg_us_markers", r["avg_us"])
+        if r.get("timing", "markers") != "dispatch":
+            k["timing"] = "markers"
         k["bytes_per_token"] += r["calls_per_step"] * r["bytes_per_call"]
     table = []
     for k in by_kernel.values():
         k["avg_us"] = k["us_per_token"] / k["calls_per_token"]
+        k["avg_us_markers"] = k["marker_us_per_token"] / k["calls_per_token"]
         k["bytes_per_call"] = k["bytes_per_token"] / k["calls_per_token"]
         k["GBps"] = k["bytes_per_call"] / (k["avg_us"] * 1e-6) / 1e9 if k["avg_us"] > 0 else 0.0
         k["sites"] = sorted(set(k["sites"]))
@@ -304,12 +309,16 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom["kernel"], "sites": dom["sites"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBPS,
                 "frac_of_measured_copy_peak": dom["GBps"] / 6290.0, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": dom["avg_us"], "bytes_per_launch": dom["bytes_per_call"], "calls_per_token": dom["calls_per_token"],
-                "method": "hipEvent pairs around every launch site of 8 eager decode steps issuing the captured graph's launch set (same kernels, same geometry); algorithmic bytes = the "
-                          "weight planes (or cached K/V rows) the launch reads; per-symbol aggregation like rocprofv3 --stats",
+                "avg_launch_us_markers": dom["avg_us_markers"], "timing": dom["timing"],
+                "method": "8 eager decode steps issuing the captured graph's launch set (same kernels, same geometry) on the engine's stream; every launch carries its own start/stop "
+                          "hipEvent pair through hipExtLaunchKernel, which the runtime stamps with the dispatch's begin/end (timing = dispatch: the interval rocprofv3 --kernel-trace "
+                          "reports); avg_launch_us_markers = hipEventRecord pairs around the same launch sites (adds packet processing); algorithmic bytes = the weight planes (or "
+                          "cached K/V rows) the launch reads; per-symbol aggregation like rocprofv3 --stats; sum(kernel_table us_per_token) should equal ms_per_step",
+                "kernel_sum_ms_per_token": sum(k["us_per_token"] for k in table) / 1e3,
                 "whole_step": {"bytes": wbytes + kv_bytes_mid, "ms": dt * 1e3 / K, "GBps": (wbytes + kv_bytes_mid) / (dt / K) / 1e9, "frac": (wbytes + kv_bytes_mid) / (dt / K) / 1e9 / HBM_PEAK_GBPS},
                 "eager_ms_per_token_with_events": prof["eager_ms_per_step"],
                 "kernel_table": [{"kernel": k["kernel"], "sites": k["sites"], "calls_per_token": round(k["calls_per_token"], 3), "avg_us": round(k["avg_us"], 3),
-                                  "bytes_per_call": round(k["bytes_per_call"], 1), "GBps": round(k["GBps"], 1), "us_per_token": round(k["us_per_token"], 2)} for k in table]}
+                                  "avg_us_markers": round(k["avg_us_markers"], 3), "timing": k["timing"], "bytes_per_call": round(k["bytes_per_call"], 1), "GBps": round(k["GBps"], 1), "us_per_token": round(k["us_per_token"], 2)} for k in table]}
 
     out = {
         "metric": "decode tokens/sec", "value": K * world / dt, "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,

@@ -119,6 +119,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     // Opt-in experiment (unmeasured at the time of writing): the w1|w3 launch also prepares w2's activation row (last-arriver per 256-row block),
     // one launch less per layer.
     if (getenv("MINIGPT4_BATCH_ROWS_MAX")) batch_rows_max_ = atoi(getenv("MINIGPT4_BATCH_ROWS_MAX"));
+    batch_fuse_ = !(getenv("MINIGPT4_BATCH_FUSE") && !atoi(getenv("MINIGPT4_BATCH_FUSE")));   // 0: standalone row preparation in front of wq|wk|wv and w1|w3 (A/B, tests)
     if (const char *sk = getenv("MINIGPT4_SPLITK")) { sscanf(sk, "%d,%d", &splitk_proj_, &splitk_fc2_); splitk_proj_ = std::max(1, std::min(SPLITK_MAX, splitk_proj_)); splitk_fc2_ = std::max(1, std::min(SPLITK_MAX, splitk_fc2_)); }
     set_matvec_tuning(getenv("MINIGPT4_MV_WAVES") ? atoi(getenv("MINIGPT4_MV_WAVES")) : 0, getenv("MINIGPT4_FAT_LB") ? atoi(getenv("MINIGPT4_FAT_LB")) : 0, prop.multiProcessorCount);
     if (const char *ns = getenv("MINIGPT4_CONVERSATIONS")) conv_.assign((size_t)std::max(1, std::min(MAX_CONVERSATIONS, atoi(ns))), Conversation{});
@@ -443,6 +444,9 @@ void Engine::alloc_buffers() {
         __half *dg = takeh(65536), *ds = takeh(65536), *de = takeh(65536);
         HIP_CHECK(hipMemcpy(dg, g.data(), 131072, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(ds, si.data(), 131072, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(de, ex.data(), 131072, hipMemcpyHostToDevice));
         tabs_.gelu = dg; tabs_.silu = ds; tabs_.exp = de;
+        int last = 0;
+        for (int i = 0; i < 0x7C00; i++) if (__half2float(ex[(size_t)(0x8000 + i)]) != 0.0f) last = i;
+        tabs_.exp_neg_n = (last + 1 + 2047) / 2048 * 2048;
     }
     x_ = takef(B * E); q_ = takef(B * E); k_ = takef(B * E); v_ = takef(B * E); att_ = takef(B * E);
     h1_ = takef(B * F); h3_ = takef(B * F); logits_ = takef(S * V); blogits_ = takef(S * V);
@@ -494,6 +498,7 @@ void Engine::site_begin(const char *site, double bytes, hipStream_t s) {
     SiteEv ev{}; ev.site = site; ev.bytes = bytes;
     HIP_CHECK(hipEventCreate(&ev.a)); HIP_CHECK(hipEventCreate(&ev.b));
     reset_kernel_name();
+    ev.p0 = ev.p1 = launch_probe_count();
     HIP_CHECK(hipEventRecord(ev.a, s));
     site_events_.push_back(ev);
 }
@@ -502,6 +507,7 @@ void Engine::site_end(hipStream_t s) {
     SiteEv &ev = site_events_.back();
     HIP_CHECK(hipEventRecord(ev.b, s));
     ev.kernel = last_kernel_name();
+    ev.p1 = launch_probe_count();
 }
 bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair, const char *site) {
     bool same = true;
@@ -618,7 +624,8 @@ void Engine::forward_batch(int B, hipStream_t s) {
     const size_t C = (size_t)n_ctx_, seq_stride = layers_.size() * C * (size_t)E;
     // y_m[t][r] = W_m[r] . act[t] (+ res_m[t][r]) for n matrices that share the prepared rows.  Up to batch_rows_max_ rows go through the pipelined multi-row
     // mat-vec in passes of 4 rows (weights streamed once per pass); larger batches / other types through launch_mul_mat (int8-MFMA tiles from 5 rows).
-    auto mm = [&](std::initializer_list<const QWeight *> Ws, std::initializer_list<float *> ys, const float *res0, int ld) {
+    // px != null: the launch prepares its rows itself (rms_norm(px_t) * pw, quantised) -- only called when rows_pro() said the shape / type is in range
+    auto mm = [&](std::initializer_list<const QWeight *> Ws, std::initializer_list<float *> ys, const float *res0, int ld, const float *px = nullptr, const float *pw = nullptr) {
         const int n = (int)Ws.size();
         const QWeight *W[3]; float *y[3]; const float *r[3];
         int i = 0; for (const QWeight *w : Ws) W[i++] = w;
@@ -633,27 +640,42 @@ void Engine::forward_batch(int B, hipStream_t s) {
                 A.d0 += (size_t)t0 * (K / 32); A.d1 += (size_t)t0 * (K / 32); A.s1 += (size_t)t0 * (K / 32); A.sum0 += (size_t)t0 * (K / 32);
                 float *yo[3]; const float *ro[3];
                 for (int k = 0; k < n; k++) { yo[k] = y[k] + (size_t)t0 * ld; ro[k] = r[k] ? r[k] + (size_t)t0 * ld : nullptr; }
-                ok = launch_matvec_rows(W, yo, res0 ? ro : nullptr, n, A, std::min(4, B - t0), ld, s);
-                if (!ok && t0) throw HipError{hipErrorInvalidValue, "multi-row mat-vec refused a later pass", __FILE__, __LINE__};
+                ok = launch_matvec_rows(W, yo, res0 ? ro : nullptr, n, A, std::min(4, B - t0), ld, s, px ? px + (size_t)t0 * K : nullptr, pw, K);
+                if (!ok && (t0 || px)) throw HipError{hipErrorInvalidValue, "multi-row mat-vec refused a pass it had accepted", __FILE__, __LINE__};
             }
             if (ok) return;
         }
+        if (px) throw HipError{hipErrorInvalidValue, "multi-row mat-vec: prologue requested outside its range", __FILE__, __LINE__};
         for (int k = 0; k < n; k++) launch_mul_mat(*W[k], act_, B, y[k], ld, r[k], s);
+    };
+    // may the rows of this set be prepared inside its launch?  (same conditions mm() takes the multi-row kernel under)
+    auto rows_pro = [&](std::initializer_list<const QWeight *> Ws) {
+        if (!batch_fuse_ || B > batch_rows_max_) return false;
+        const QWeight *w0 = *Ws.begin();
+        for (const QWeight *w : Ws) if (w->type != w0->type || w->rows != w0->rows || w->cols != w0->cols) return false;
+        return matvec_rows_prologue_ok(w0->type, w0->cols);
     };
     launch_get_rows(tok_type_, tok_raw_, E, d_btok_, B, x_, s);
     for (size_t il = 0; il < layers_.size(); il++) {
         const LayerW &L = layers_[il];
         __half *kc = kc_ + il * C * E, *vc = vc_ + il * C * E;            // conversation 0's layer; the kernel adds slot * seq_stride
-        launch_rms_quant(x_, L.attn_norm, B, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s);
-        if (L.wv.type == L.wq.type && L.wk.type == L.wq.type) mm({&L.wq, &L.wk, &L.wv}, {q_, k_, v_}, nullptr, E);
-        else if (L.wk.type == L.wq.type) { mm({&L.wq, &L.wk}, {q_, k_}, nullptr, E); mm({&L.wv}, {v_}, nullptr, E); }
-        else { mm({&L.wq}, {q_}, nullptr, E); mm({&L.wk}, {k_}, nullptr, E); mm({&L.wv}, {v_}, nullptr, E); }
+        if (L.wv.type == L.wq.type && L.wk.type == L.wq.type && rows_pro({&L.wq, &L.wk, &L.wv})) mm({&L.wq, &L.wk, &L.wv}, {q_, k_, v_}, nullptr, E, x_, L.attn_norm);
+        else if (L.wk.type == L.wq.type && rows_pro({&L.wq, &L.wk}) && rows_pro({&L.wv})) { mm({&L.wq, &L.wk}, {q_, k_}, nullptr, E, x_, L.attn_norm); mm({&L.wv}, {v_}, nullptr, E, x_, L.attn_norm); }
+        else {
+            launch_rms_quant(x_, L.attn_norm, B, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s);
+            if (L.wv.type == L.wq.type && L.wk.type == L.wq.type) mm({&L.wq, &L.wk, &L.wv}, {q_, k_, v_}, nullptr, E);
+            else if (L.wk.type == L.wq.type) { mm({&L.wq, &L.wk}, {q_, k_}, nullptr, E); mm({&L.wv}, {v_}, nullptr, E); }
+            else { mm({&L.wq}, {q_}, nullptr, E); mm({&L.wk}, {k_}, nullptr, E); mm({&L.wv}, {v_}, nullptr, E); }
+        }
         launch_attn_llm_batched(q_, k_, v_, kc, vc, B, H, hd, d_npast_, d_bslot_, seq_stride, n_ctx_, cos_, sin_, tabs_, att_, s);
         launch_silu_mul_quant(att_, nullptr, B, E, act_, act_mask_for(L.wo.type), tabs_, s);
         mm({&L.wo}, {x_}, x_, E);
-        launch_rms_quant(x_, L.ffn_norm, B, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s);
-        if (L.w1.type == L.w3.type) mm({&L.w1, &L.w3}, {h1_, h3_}, nullptr, F);
-        else { mm({&L.w1}, {h1_}, nullptr, F); mm({&L.w3}, {h3_}, nullptr, F); }
+        if (L.w1.type == L.w3.type && rows_pro({&L.w1, &L.w3})) mm({&L.w1, &L.w3}, {h1_, h3_}, nullptr, F, x_, L.ffn_norm);
+        else {
+            launch_rms_quant(x_, L.ffn_norm, B, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s);
+            if (L.w1.type == L.w3.type) mm({&L.w1, &L.w3}, {h1_, h3_}, nullptr, F);
+            else { mm({&L.w1}, {h1_}, nullptr, F); mm({&L.w3}, {h3_}, nullptr, F); }
+        }
         launch_silu_mul_quant(h1_, h3_, B, F, act_, act_mask_for(L.w2.type), tabs_, s);
         mm({&L.w2}, {x_}, x_, E);
     }
@@ -807,14 +829,16 @@ int Engine::profile_sites(int steps, std::string &json) {
         tok = h_argmax_[cur_];
     }
     prof_on_ = false; kernel_name_tracing(false);
-    struct Agg { std::string site, kernel; double us = 0, bytes = 0; long calls = 0; };
+    struct Agg { std::string site, kernel; double us = 0, mus = 0, bytes = 0; long calls = 0; bool probed = true; };   // us: dispatch begin..end (launch probes); mus: marker pairs
     std::vector<Agg> agg;                                                    // first-seen order = launch order within the step
     for (auto &e : site_events_) {
         float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, e.a, e.b));
         size_t k = 0;
         while (k < agg.size() && !(agg[k].site == e.site && agg[k].kernel == e.kernel)) k++;
         if (k == agg.size()) { agg.push_back(Agg{}); agg[k].site = e.site; agg[k].kernel = e.kernel; }
-        agg[k].us += ms * 1e3; agg[k].bytes += e.bytes; agg[k].calls++;
+        const float pus = e.p1 > e.p0 ? launch_probe_us(e.p0, e.p1) : -1.0f;
+        if (pus < 0.0f) agg[k].probed = false;
+        agg[k].us += pus; agg[k].mus += ms * 1e3; agg[k].bytes += e.bytes; agg[k].calls++;
         (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
     }
     site_events_.clear();
@@ -822,8 +846,10 @@ int Engine::profile_sites(int steps, std::string &json) {
     char buf[768];
     json = "{\"steps\": " + std::to_string(steps) + ", \"eager_ms_per_step\": " + std::to_string(tot / steps) + ", \"sites\": [";
     for (size_t k = 0; k < agg.size(); k++) {
-        snprintf(buf, sizeof(buf), "%s{\"site\": \"%s\", \"kernel\": \"%s\", \"calls_per_step\": %.3f, \"avg_us\": %.3f, \"bytes_per_call\": %.1f}", k ? ", " : "", agg[k].site.c_str(),
-                 agg[k].kernel.c_str(), (double)agg[k].calls / steps, agg[k].us / (double)agg[k].calls, agg[k].bytes / (double)agg[k].calls);
+        // avg_us: the dispatches' own begin..end timestamps (what rocprofv3 reports); avg_us_markers: hipEventRecord pairs around the launch site (adds packet processing)
+        snprintf(buf, sizeof(buf), "%s{\"site\": \"%s\", \"kernel\": \"%s\", \"calls_per_step\": %.3f, \"avg_us\": %.3f, \"avg_us_markers\": %.3f, \"timing\": \"%s\", \"bytes_per_call\": %.1f}",
+                 k ? ", " : "", agg[k].site.c_str(), agg[k].kernel.c_str(), (double)agg[k].calls / steps, (agg[k].probed ? agg[k].us : agg[k].mus) / (double)agg[k].calls,
+                 agg[k].mus / (double)agg[k].calls, agg[k].probed ? "dispatch" : "markers", agg[k].bytes / (double)agg[k].calls);
         json += buf;
     }
     json += "]}";

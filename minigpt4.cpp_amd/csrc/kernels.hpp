@@ -6,6 +6,8 @@ namespace mg4 {
 
 struct Tables {               // fp16 lookup tables, 65536 entries each, indexed by the fp16 bit pattern of the argument
     const __half *gelu = nullptr, *silu = nullptr, *exp = nullptr;
+    int exp_neg_n = 0;         // entries of exp[0x8000 ...] (arguments -0, -2^-24, ...) up to and including the last nonzero finite one, rounded up to a multiple of 2048:
+                               // the part of the table k_attn_vit keeps in LDS (softmax arguments are <= 0)
 };
 
 // ---- load-time repack: raw ggml blocks (device copy of the file bytes) -> planes of a QWeight -------------------
@@ -43,7 +45,9 @@ bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *co
 bool matvec_silu_pair_supported(int type, int cols);
 // batched decode: N = 1..4 activation rows (prepared in `A`) against 1..3 same-type, same-shape, equally spaced matrices, weights streamed once;
 // y[m][t * ldy + r] (+ residual[m][t * ldy + r]).  false -> outside the kernel's range, use launch_mul_mat.
-bool launch_matvec_rows(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s);
+bool launch_matvec_rows(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s, const float *px = nullptr,
+                        const float *pw = nullptr, int ldx = 0);   // px != null: rows t of x (stride ldx) are rms-normed with pw and quantised inside the launch (A unused)
+bool matvec_rows_prologue_ok(int type, int K);
 // two k-quant types (Q4_K|Q5_K + Q6_K) with the same K in one launch; pro: 0 or 1 (rms_norm prologue)
 bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, hipStream_t s, int pro = 0,
                          const float *px = nullptr, const float *pw = nullptr);
@@ -52,6 +56,8 @@ void set_matvec_tuning(int waves_per_cu, int fat_threads, int cus);   // 0 = cho
 void kernel_name_tracing(bool on);
 const char *last_kernel_name();          // "" when nothing was launched since the last reset
 void reset_kernel_name();
+size_t launch_probe_count();                       // launches noted (and probed with their own start / stop events) since tracing was switched on
+float launch_probe_us(size_t first, size_t last);  // sum of the dispatch durations of probes [first, last) in microseconds (stream synchronised); < 0: not available
 int read_matvec_timeline(unsigned long long *out, int max_workgroups);   // diagnostic builds (MG4_TIMELINE): stamps of the last decode mat-vec launch; 0 otherwise
 
 // ---- token embedding gather (raw ggml rows, dequantised to f32) -----------------------------------------------------

@@ -10,18 +10,36 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstring>
+#include <tuple>
+#include <vector>
+#include <hip/hip_ext.h>
 
 namespace mg4 {
 
 // =====================================================================================================================
 // helpers
 // =====================================================================================================================
-// ---- measurement: kernel symbols of the launches (Engine::profile_sites) -----------------------------------------------------------------------------------------
+// ---- measurement: kernel symbols and per-dispatch timestamps of the launches (Engine::profile_sites) ----------------------------------------------------------------
+// While tracing is on, every launcher of this file notes the symbol it is about to launch, and the launch itself goes through hipExtLaunchKernel with a start / stop
+// event pair: the runtime stamps those with the dispatch's own begin / end times -- the interval rocprofv3 --kernel-trace reports -- instead of bracketing the launch
+// with marker events (measured +2.0...2.9 us of packet processing per pair, profiles/r02_bench_n1.json vs r02_decode_kernel_stats.csv).
 static bool g_kname_on = false;
 static char g_kname[192] = "";
-void kernel_name_tracing(bool on) { g_kname_on = on; g_kname[0] = 0; }
+struct LaunchProbe { hipEvent_t start, stop; };
+static std::vector<LaunchProbe> g_probes;      // one per noted launch since tracing was switched on
+static size_t g_probe_next = 0;                // first probe not yet attached to a launch
+void kernel_name_tracing(bool on) {
+    g_kname_on = on; g_kname[0] = 0;
+    if (on) { for (auto &p : g_probes) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); } g_probes.clear(); g_probe_next = 0; }
+}
 void reset_kernel_name() { g_kname[0] = 0; }
 const char *last_kernel_name() { return g_kname; }
+size_t launch_probe_count() { return g_probes.size(); }
+float launch_probe_us(size_t first, size_t last) {   // sum of the dispatch durations of probes [first, last); call after the stream has been synchronised
+    float us = 0.0f;
+    for (size_t i = first; i < last && i < g_probes.size(); i++) { float ms = 0.0f; if (hipEventElapsedTime(&ms, g_probes[i].start, g_probes[i].stop) != hipSuccess) return -1.0f; us += ms * 1e3f; }
+    return us;
+}
 static void note_kernel(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 static void note_kernel(const char *fmt, ...) {
     if (!g_kname_on) return;
@@ -29,7 +47,23 @@ static void note_kernel(const char *fmt, ...) {
     const size_t have = strlen(g_kname);
     if (have && have + 3 < sizeof(g_kname)) strcat(g_kname, " + ");
     strncat(g_kname, one, sizeof(g_kname) - strlen(g_kname) - 1);
+    LaunchProbe p{};
+    if (hipEventCreate(&p.start) == hipSuccess && hipEventCreate(&p.stop) == hipSuccess) g_probes.push_back(p);
 }
+// every kernel launch of this file: plain <<< >>> unless a noted launch is waiting for its probe
+template <typename... KA, typename... Args>
+static inline void launch_k(void (*k)(KA...), dim3 g, dim3 b, size_t lds, hipStream_t s, Args... args) {
+    static_assert(sizeof...(KA) == sizeof...(Args), "kernel argument count");
+    if (g_kname_on && g_probe_next < g_probes.size()) {
+        LaunchProbe &p = g_probes[g_probe_next++];
+        std::tuple<KA...> tup{static_cast<KA>(args)...};
+        std::apply([&](auto &...e) { void *ptrs[] = {static_cast<void *>(&e)...}; (void)hipExtLaunchKernel(reinterpret_cast<const void *>(k), g, b, ptrs, lds, s, p.start, p.stop, 0); }, tup);
+        return;
+    }
+    k<<<g, b, lds, s>>>(args...);
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(k, g, b, l, s, ...) launch_k(k, g, b, l, s, __VA_ARGS__)
 
 __device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 __device__ __forceinline__ float h2f_bits(unsigned short h) { return __half2float(__ushort_as_half(h)); }
@@ -817,8 +851,13 @@ static size_t mv_tn_lds(int type, int K, int TN) {
     return (size_t)TN * per_row + 64;
 }
 template <int NU> constexpr int mv_tn_threads() { return NU >= 7 ? 256 : 512; }   // widest K: one wave per SIMD (up to 512 VGPRs) -- two would spill Q5_K's weight stages; 4 waves x 7 units keep as many bytes in flight as 8 x 3
-template <int T, int NU, int TN>
-__global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet ms, const ActQ A, const int N, const int ldy, const int n_groups, const int n_waves) {
+// PRO = 1 (K <= 3 x 64 units only): the rows are prepared inside the launch -- rms_norm(x_t) * w and the quantisation of k_rms_quant, row by row with the single-row
+// prologue's arithmetic (matvec_run), into one LDS image per row -- so a batched decode step needs no standalone preparation launch in front of wq|wk|wv and w1|w3.
+static size_t mv_tn_image_bytes(int K) { return ((size_t)2 * K + (size_t)(K / 256 + 1) * 4 + (size_t)4 * (K / 32) * 4 + (size_t)(K / 16) * 2 + 64 + 15) & ~(size_t)15; }
+template <int T, int NU, int TN, int PRO = 0>
+__global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet ms, const ActQ A, const int N, const int ldy, const int n_groups, const int n_waves, const ProArgs pa,
+                                                                   const int ldx, const int image_bytes) {
+    static_assert(PRO == 0 || NU <= 3, "the prologue variant keeps the prepared rows in registers");
     using X = Tr<T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tn[];
     const int lane = threadIdx.x & 63;
@@ -848,16 +887,98 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
     };
     Grp cur, nxt;
     MG4_TL(0);
+    constexpr int PRND = PRO ? NU : 1;                                   // 512 threads x 4 elements per round: K <= NU * 2048
+    float4 pxv[PRO ? TN : 1][PRND], pyv[PRND];
+    bool pin[PRND];
+    if (PRO) {   // the rows are requested before the first weight tiles (vector-memory results return in issue order)
+#pragma unroll
+        for (int r = 0; r < PRND; r++) {
+            const int i = (r * 512 + (int)threadIdx.x) * 4;
+            pin[r] = i < K;
+            const int ic = pin[r] ? i : 0;
+            pyv[r] = *reinterpret_cast<const float4 *>(pa.w + ic);
+#pragma unroll
+            for (int t = 0; t < (PRO ? TN : 1); t++) pxv[t][r] = *reinterpret_cast<const float4 *>(pa.x + (size_t)min(t, N - 1) * ldx + ic);
+        }
+    }
     fetch(wave, cur);
     MG4_TL(1);
-    // LDS image of the N activation rows, laid out like the global ActQ planes (so Tr<T>::loada indexes it unchanged)
+    // K <= 3 x 64 units: every lane works on the SAME units of every weight row, so the TN activation fragments live in registers for the whole launch (no LDS
+    // image, no barrier, no LDS re-read per weight row -- the LDS variant below re-reads TN x 5 KB per 3.5 KB weight row and is LDS-bandwidth bound).
+    constexpr bool REG = NU <= 3;
+    typename X::AU ar[REG ? TN : 1][REG ? NU : 1];
+    if (REG && PRO) {
+        constexpr int mask = (T == GT_Q4_K || T == GT_Q5_K || T == GT_Q6_K) ? ACT_Q8K : ACT_Q80;
+        double *red = reinterpret_cast<double *>(smem_tn);               // [TN][8 waves]
+#pragma unroll
+        for (int t = 0; t < (PRO ? TN : 1); t++) {
+            double sum = 0.0;
+#pragma unroll
+            for (int r = 0; r < PRND; r++) {
+                const float4 v = pxv[t][r];
+                double q = 0.0;
+                q += (double)(v.x * v.x); q += (double)(v.y * v.y); q += (double)(v.z * v.z); q += (double)(v.w * v.w);
+                sum += pin[r] ? q : 0.0;
+            }
+            sum = wave_sum_d(sum);
+            if (lane == 0) red[t * 8 + (threadIdx.x >> 6)] = sum;
+        }
+        __syncthreads();
+        ActQ Li[PRO ? TN : 1];
+#pragma unroll
+        for (int t = 0; t < (PRO ? TN : 1); t++) {
+            double tot = 0.0;
+            for (int w = 0; w < 8; w++) tot += red[t * 8 + w];
+            const float mean = (float)(tot / (double)K);
+            const float scale = 1.0f / sqrtf(mean + 1e-6f);
+            unsigned char *p = smem_tn + 512 + (size_t)t * image_bytes;
+            ActQ L{};
+            L.q8k = reinterpret_cast<int8_t *>(p); p += (size_t)K;
+            L.q80 = reinterpret_cast<int8_t *>(p); p += (size_t)K;
+            L.dk = reinterpret_cast<float *>(p); p += (size_t)(K / 256 + 1) * 4;
+            L.d0 = reinterpret_cast<float *>(p); p += (size_t)(K / 32) * 4;
+            L.d1 = reinterpret_cast<float *>(p); p += (size_t)(K / 32) * 4;
+            L.s1 = reinterpret_cast<float *>(p); p += (size_t)(K / 32) * 4;
+            L.sum0 = reinterpret_cast<int *>(p); p += (size_t)(K / 32) * 4;
+            L.bsk = reinterpret_cast<int16_t *>(p);
+            L.bsq = nullptr; L.xh = nullptr; L.xf = nullptr;
+#pragma unroll
+            for (int r = 0; r < PRND; r++) {
+                const int i = (r * 512 + (int)threadIdx.x) * 4;
+                float v[4] = {(pxv[t][r].x * scale) * pyv[r].x, (pxv[t][r].y * scale) * pyv[r].y, (pxv[t][r].z * scale) * pyv[r].z, (pxv[t][r].w * scale) * pyv[r].w};
+                if (!pin[r]) { v[0] = 0.0f; v[1] = 0.0f; v[2] = 0.0f; v[3] = 0.0f; }
+                quant_emit4(v, pin[r], i, 0, K, L, mask);
+            }
+            Li[t] = L;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < (PRO ? TN : 1); t++)
+#pragma unroll
+            for (int i = 0; i < NU; i++) X::loada(Li[t], 0, K, uc[i], ar[REG ? t : 0][REG ? i : 0]);
+    } else if (REG) {
+#pragma unroll
+        for (int t = 0; t < TN; t++)
+#pragma unroll
+            for (int i = 0; i < NU; i++) X::loada(A, min(t, N - 1), K, uc[i], ar[REG ? t : 0][REG ? i : 0]);
+    }
+    // otherwise: LDS image of the N activation rows, laid out like the global ActQ planes (so Tr<T>::loada indexes it unchanged)
     ActQ L;
-    {
+    if (!REG) {
         unsigned char *p = smem_tn;
         const int nthr = (int)blockDim.x, tid = (int)threadIdx.x;
+        // LDS-DMA copy (global_load_lds, 16 bytes per lane, destination lane-linear = a plain contiguous copy): all pieces of all planes are in flight together; the
+        // round-1 form (a load -> ds_write loop, one dependent round trip per 4-8 KB) cost 14 serial round trips for a K = 13824 image -- most of the kernel's time.
+        const int nwv = nthr >> 6, wv = tid >> 6;
         auto copy16 = [&](void *dst, const void *src, size_t bytes) {      // bytes is a multiple of 16 for every plane x row count used here, except the tails handled below
+            const size_t n1k = (bytes + 1023) / 1024;
+            for (size_t c = (size_t)wv; c < n1k; c += (size_t)nwv) {
+                const size_t off = c * 1024 + (size_t)lane * 16;
+                if (off + 16 <= bytes)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(src) + off),
+                                                     (__attribute__((address_space(3))) void *)(reinterpret_cast<unsigned char *>(dst) + c * 1024), 16, 0, 0);
+            }
             const size_t n16 = bytes / 16;
-            for (size_t i = (size_t)tid; i < n16; i += (size_t)nthr) reinterpret_cast<int4 *>(dst)[i] = reinterpret_cast<const int4 *>(src)[i];
             for (size_t i = n16 * 16 + (size_t)tid; i < bytes; i += (size_t)nthr) reinterpret_cast<unsigned char *>(dst)[i] = reinterpret_cast<const unsigned char *>(src)[i];
         };
         if (tr_is_kquant<T>()) {
@@ -875,7 +996,7 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
             copy16(L.s1, A.s1, (size_t)N * (K / 32) * 4); copy16(L.sum0, A.sum0, (size_t)N * (K / 32) * 4);
         }
     }
-    __syncthreads();
+    if (!REG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
     MG4_TL(2);
     auto consume = [&](int g, const Grp &G) {
         float out[TN];
@@ -886,7 +1007,12 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
 #pragma unroll
         for (int i = 0; i < NU; i++) {
 #pragma unroll
-            for (int t = 0; t < TN; t++) { typename X::AU a; X::loada(L, min(t, N - 1), K, uc[i], a); float c = out[t]; X::dot(G.w[i], a, c); out[t] = ok[i] ? c : out[t]; }
+            for (int t = 0; t < TN; t++) {
+                float c = out[t];
+                if (REG) X::dot(G.w[i], ar[REG ? t : 0][REG ? i : 0], c);
+                else { typename X::AU a; X::loada(L, min(t, N - 1), K, uc[i], a); X::dot(G.w[i], a, c); }
+                out[t] = ok[i] ? c : out[t];
+            }
         }
 #pragma unroll
         for (int t = 0; t < TN; t++) out[t] = wave_sum(out[t]);
@@ -919,47 +1045,68 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
     MG4_TL(5);
 #endif
 }
-template <int T, int NU>
-static void launch_tn_t(const MatSet &ms, const ActQ &A, int N, int ldy, hipStream_t s) {
-    constexpr int TN = 4;
-    note_kernel("k_matvec_tn<%d, %d, 4>", T, NU);
+template <int T, int NU, int TN>
+static void launch_tn_n(const MatSet &ms, const ActQ &A, int N, int ldy, hipStream_t s, const float *px, const float *pw, int ldx) {
     const int n_groups = ms.n * ms.rows_each;
     constexpr int WPB = mv_tn_threads<NU>() / 64;
     const int n_blocks = std::min((n_groups + WPB - 1) / WPB, g_mv_cus), n_waves = n_blocks * WPB;
-    const size_t lds = mv_tn_lds(T, ms.w0.cols, TN);
+    ProArgs pa{}; pa.x = px; pa.w = pw;
+    constexpr bool PRO_OK = NU <= 3 && (T == GT_Q4_0 || T == GT_Q4_K || T == GT_Q5_K || T == GT_Q6_K);
+    if constexpr (PRO_OK) {
+        if (px) {
+            note_kernel("k_matvec_tn<%d, %d, %d, 1>", T, NU, TN);
+            const int img = (int)mv_tn_image_bytes(ms.w0.cols);
+            static bool attr1 = false;
+            if (!attr1) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+            hipLaunchKernelGGL((k_matvec_tn<T, NU, TN, 1>), dim3((unsigned)n_blocks), dim3((unsigned)mv_tn_threads<NU>()), (size_t)512 + (size_t)TN * img, s, ms, A, N, ldy, n_groups, n_waves, pa, ldx, img);
+            return;
+        }
+    }
+    note_kernel("k_matvec_tn<%d, %d, %d, 0>", T, NU, TN);
+    const size_t lds = NU <= 3 ? 0 : mv_tn_lds(T, ms.w0.cols, TN);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL((k_matvec_tn<T, NU, TN>), dim3((unsigned)n_blocks), dim3((unsigned)mv_tn_threads<NU>()), lds, s, ms, A, N, ldy, n_groups, n_waves);
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((k_matvec_tn<T, NU, TN, 0>), dim3((unsigned)n_blocks), dim3((unsigned)mv_tn_threads<NU>()), lds, s, ms, A, N, ldy, n_groups, n_waves, pa, 0, 0);
+}
+template <int T, int NU>
+static void launch_tn_t(const MatSet &ms, const ActQ &A, int N, int ldy, hipStream_t s, const float *px, const float *pw, int ldx) {   // 2-row instantiation: half the dot products (and LDS reads) of the 4-row one
+    if (N <= 2) launch_tn_n<T, NU, 2>(ms, A, N, ldy, s, px, pw, ldx); else launch_tn_n<T, NU, 4>(ms, A, N, ldy, s, px, pw, ldx);
 }
 template <int T>
-static bool launch_tn_type(const MatSet &ms, const ActQ &A, int N, int ldy, hipStream_t s) {
+static bool launch_tn_type(const MatSet &ms, const ActQ &A, int N, int ldy, hipStream_t s, const float *px, const float *pw, int ldx) {
     const int nu = (ms.w0.cols / Tr<T>::EPU + 63) / 64;
     switch (nu) {
-    case 1: launch_tn_t<T, 1>(ms, A, N, ldy, s); return true;
-    case 2: launch_tn_t<T, 2>(ms, A, N, ldy, s); return true;
-    case 3: launch_tn_t<T, 3>(ms, A, N, ldy, s); return true;
-    case 4: launch_tn_t<T, 4>(ms, A, N, ldy, s); return true;
-    case 5: launch_tn_t<T, 5>(ms, A, N, ldy, s); return true;
-    case 6: launch_tn_t<T, 6>(ms, A, N, ldy, s); return true;
-    case 7: launch_tn_t<T, 7>(ms, A, N, ldy, s); return true;
+    case 1: launch_tn_t<T, 1>(ms, A, N, ldy, s, px, pw, ldx); return true;
+    case 2: launch_tn_t<T, 2>(ms, A, N, ldy, s, px, pw, ldx); return true;
+    case 3: launch_tn_t<T, 3>(ms, A, N, ldy, s, px, pw, ldx); return true;
+    case 4: launch_tn_t<T, 4>(ms, A, N, ldy, s, px, pw, ldx); return true;
+    case 5: launch_tn_t<T, 5>(ms, A, N, ldy, s, px, pw, ldx); return true;
+    case 6: launch_tn_t<T, 6>(ms, A, N, ldy, s, px, pw, ldx); return true;
+    case 7: launch_tn_t<T, 7>(ms, A, N, ldy, s, px, pw, ldx); return true;
     default: return false;
     }
 }
 // 2..4 activation rows against 1..3 same-type, same-shape, equally spaced matrices in ONE weight pass: y[m][t * ldy + r] = W_m[r] . act[t] (+ residual[m][t * ldy + r]).
 // false -> shape / type outside the kernel's range (the caller falls back to launch_mul_mat per matrix).
-bool launch_matvec_rows(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s) {
+bool matvec_rows_prologue_ok(int type, int K) {
+    if (type != GT_Q4_0 && type != GT_Q4_K && type != GT_Q5_K && type != GT_Q6_K) return false;
+    const int epu = type == GT_Q4_0 ? Tr<GT_Q4_0>::EPU : 32;
+    return matvec_prologue_supported(type, K) && K / epu <= 192 && K % 4 == 0;
+}
+bool launch_matvec_rows(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s, const float *px, const float *pw, int ldx) {
+    if (px && !matvec_rows_prologue_ok(W[0]->type, W[0]->cols)) return false;
     if (N < 1 || N > 4 || !matvec_prologue_supported(W[0]->type, W[0]->cols)) return false;
     if (mv_tn_lds(W[0]->type, W[0]->cols, 4) > 150 * 1024) return false;
     MatSet ms;
     if (!fill_matset(ms, W, y, residual, n)) return false;
     switch (W[0]->type) {
-    case GT_Q4_0: return launch_tn_type<GT_Q4_0>(ms, A, N, ldy, s);
-    case GT_Q4_1: return launch_tn_type<GT_Q4_1>(ms, A, N, ldy, s);
-    case GT_Q5_0: return launch_tn_type<GT_Q5_0>(ms, A, N, ldy, s);
-    case GT_Q5_1: return launch_tn_type<GT_Q5_1>(ms, A, N, ldy, s);
-    case GT_Q4_K: return launch_tn_type<GT_Q4_K>(ms, A, N, ldy, s);
-    case GT_Q5_K: return launch_tn_type<GT_Q5_K>(ms, A, N, ldy, s);
-    case GT_Q6_K: return launch_tn_type<GT_Q6_K>(ms, A, N, ldy, s);
+    case GT_Q4_0: return launch_tn_type<GT_Q4_0>(ms, A, N, ldy, s, px, pw, ldx);
+    case GT_Q4_1: return launch_tn_type<GT_Q4_1>(ms, A, N, ldy, s, px, pw, ldx);
+    case GT_Q5_0: return launch_tn_type<GT_Q5_0>(ms, A, N, ldy, s, px, pw, ldx);
+    case GT_Q5_1: return launch_tn_type<GT_Q5_1>(ms, A, N, ldy, s, px, pw, ldx);
+    case GT_Q4_K: return launch_tn_type<GT_Q4_K>(ms, A, N, ldy, s, px, pw, ldx);
+    case GT_Q5_K: return launch_tn_type<GT_Q5_K>(ms, A, N, ldy, s, px, pw, ldx);
+    case GT_Q6_K: return launch_tn_type<GT_Q6_K>(ms, A, N, ldy, s, px, pw, ldx);
     default: return false;
     }
 }
@@ -1288,8 +1435,8 @@ static void launch_attn_hd(float *q, const float *k, const float *v, __half *kc,
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     note_kernel("k_attn_llm<%d, %s, false>", HD, fused ? "true" : "false");
-    if (fused) hipLaunchKernelGGL((k_attn_llm<HD, true>), dim3((unsigned)n_head, 1), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out);
-    else hipLaunchKernelGGL((k_attn_llm<HD, false>), dim3((unsigned)n_head, (unsigned)N), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out);
+    if (fused) hipLaunchKernelGGL((k_attn_llm<HD, true>), dim3((unsigned)n_head, 1), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out, (const int *)nullptr, (size_t)0);
+    else hipLaunchKernelGGL((k_attn_llm<HD, false>), dim3((unsigned)n_head, (unsigned)N), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out, (const int *)nullptr, (size_t)0);
 }
 template <int HD>
 static void launch_attn_batched_hd(float *q, const float *k, const float *v, __half *kc, __half *vc, int B, int n_head, const int *n_past, const int *row_slot, size_t seq_stride,

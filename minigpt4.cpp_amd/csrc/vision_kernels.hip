@@ -624,7 +624,135 @@ __global__ __launch_bounds__(256) void k_attn_mfma2(const float *__restrict__ q,
     }
 }
 
-static int g_attn_mfma = 1;
+// ---------------------------------------------------------------------------------------------------------------------
+// k_attn_vit -- fp32 attention without K / V staging (round 2; replaces the LDS-staged k_attn_mfma for nk <= 64 * TPW keys).
+//   * workgroup = (head, 16 queries, image); its 4 waves split the KEYS (wave w owns key tiles w, w + 4, ...), so a ViT layer is 16 x 17 = 272 workgroups
+//     (one per CU) whose critical path is a quarter of a head instead of the whole head;
+//   * scores are computed TRANSPOSED, S^T = K . Q^T (v_mfma_f32_16x16x4_f32; A = 16 keys, B = 16 queries): the MFMA reduction index may be labelled freely as
+//     long as A and B agree, so lane (row, g) takes the CONTIGUOUS dims [g * HD/4, (g + 1) * HD/4) of its row -- Q and K fragments come straight from global
+//     memory as 8-byte loads of whole 88 B / 64 B row quarters, no LDS, no transposition;
+//   * the C layout of S^T (lane (query, g), register r <-> key 16 kt + 4 g + r) IS the B-operand layout of O^T = V^T . P^T, so the probabilities never leave
+//     their registers; V enters as the A operand (lane (dim, g) <- V[key 16 kt + 4 g + r][dim]), again straight from global memory (64-byte segments);
+//   * softmax exactly as before (fp32 max, the fp16 exp table, fp64 sum -- exact in any order: <= 2^9 terms of 11-bit values --, p = e * (float)(1 / sum)),
+//     but the table's live part (arguments in [-17.4, -0]: tb.exp_neg_n entries from code 0x8000) sits in LDS (LDS-DMA at kernel entry, hidden behind the
+//     Q / K loads); anything outside (NaN) falls back to the global table, so the values are the same ones;
+//   * the 4 waves' partial O^T tiles are added in wave order through LDS (deterministic) and stored 4 dims at a time.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int HD, int TPW>
+__global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, int ldq, const float *__restrict__ k, const float *__restrict__ v, int ldk, int nq, int nk,
+                                                  float q_prescale, float score_div, const Tables tb, float *__restrict__ out, __half *__restrict__ out_h, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KS = HD / 4, DT = (HD + 15) / 16;
+    static_assert(KS % 2 == 0, "row quarters are loaded as float2");
+    { const size_t z = blockIdx.z; q += z * nq * ldq; k += z * nk * ldk; v += z * nk * ldk; if (out) out += z * nq * ldo; if (out_h) out_h += z * nq * ldo; }
+    const int h = blockIdx.x, q0 = blockIdx.y * 16, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+    float *red_m = reinterpret_cast<float *>(smem);                         // [4][16]
+    double *red_s = reinterpret_cast<double *>(smem + 256);                 // [4][16]
+    float *part = reinterpret_cast<float *>(smem + 768);                    // [4][DT * 4][64]
+    __half *etab = reinterpret_cast<__half *>(smem + 768 + 4 * DT * 4 * 64 * 4);
+    const unsigned NT = (unsigned)tb.exp_neg_n;                             // multiple of 2048
+    for (unsigned c0 = 0; c0 < NT; c0 += 2048)
+        __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(tb.exp + 0x8000 + c0 + tid * 8), (g_lds_ptr_t)(reinterpret_cast<unsigned char *>(etab) + (c0 + wave * 512) * 2), 16, 0, 0);
+    float qf[KS];
+    {
+        const float *qp = q + (size_t)min(q0 + j, nq - 1) * ldq + h * HD + g * KS;
+#pragma unroll
+        for (int u = 0; u < KS / 2; u++) { const float2 t = *reinterpret_cast<const float2 *>(qp + 2 * u); qf[2 * u] = t.x; qf[2 * u + 1] = t.y; }
+    }
+    float kf[TPW][KS];
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+        const float *kp = k + (size_t)min((wave + 4 * t) * 16 + j, nk - 1) * ldk + h * HD + g * KS;
+#pragma unroll
+        for (int u = 0; u < KS / 2; u++) { const float2 x = *reinterpret_cast<const float2 *>(kp + 2 * u); kf[t][2 * u] = x.x; kf[t][2 * u + 1] = x.y; }
+    }
+    if (q_prescale != 0.0f) {
+#pragma unroll
+        for (int u = 0; u < KS; u++) qf[u] *= q_prescale;
+    }
+    float sc[TPW][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+        float4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t][ks], qf[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float sv = acc[r];
+            if (score_div != 0.0f) sv = sv / score_div;
+            sv = (wave + 4 * t) * 16 + 4 * g + r < nk ? sv : -INFINITY;
+            sc[t][r] = sv; mx = fmaxf(mx, sv);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the table DMA (issued first, returned first) has landed
+    // V fragments of this wave's keys: requested now, consumed after the softmax
+    float vf[TPW][4][DT];
+#pragma unroll
+    for (int t = 0; t < TPW; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float *vp = v + (size_t)min((wave + 4 * t) * 16 + 4 * g + r, nk - 1) * ldk + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++) vf[t][r][dt] = vp[min(dt * 16 + j, HD - 1)];
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (g == 0) red_m[wave * 16 + j] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_m[j], red_m[16 + j]), fmaxf(red_m[32 + j], red_m[48 + j]));
+    double sum = 0.0;
+#pragma unroll
+    for (int t = 0; t < TPW; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float x = sc[t][r] - mx;
+            const unsigned code = f2h_bits_v(x), idx = code ^ 0x8000u;
+            float e;
+            if (idx < NT) e = __half2float(etab[idx]);
+            else if (code == 0u) e = 1.0f;                                  // the row maximum itself: table[+0] = fp16(expf(0))
+            else if (code == 0xFC00u) e = 0.0f;                             // -inf (keys past nk, underflowed differences): table[-inf] = 0
+            else e = __half2float(tb.exp[code]);
+            e = sc[t][r] == -INFINITY ? 0.0f : e;
+            sc[t][r] = e; sum += (double)e;
+        }
+    sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+    if (g == 0) red_s[wave * 16 + j] = sum;
+    __syncthreads();
+    sum = ((red_s[j] + red_s[16 + j]) + red_s[32 + j]) + red_s[48 + j];
+    const float inv = (float)(1.0 / sum);
+    float4_t o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) { o[dt][0] = 0.0f; o[dt][1] = 0.0f; o[dt][2] = 0.0f; o[dt][3] = 0.0f; }
+#pragma unroll
+    for (int t = 0; t < TPW; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float p = sc[t][r] * inv;
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[t][r][dt], p, o[dt], 0, 0, 0);
+        }
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) part[(wave * DT * 4 + dt * 4 + r) * 64 + lane] = o[dt][r];
+    __syncthreads();
+    for (int e = tid; e < DT * 64; e += 256) {
+        const int dt = e >> 6, ln = e & 63, dim0 = dt * 16 + 4 * (ln >> 4), qrow = q0 + (ln & 15);
+        float s4[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int o1 = (dt * 4 + r) * 64 + ln;
+            s4[r] = ((part[o1] + part[DT * 4 * 64 + o1]) + part[2 * DT * 4 * 64 + o1]) + part[3 * DT * 4 * 64 + o1];
+        }
+        if (qrow < nq && dim0 < HD) {
+            const size_t oo = (size_t)qrow * ldo + h * HD + dim0;
+            if (out) *reinterpret_cast<float4 *>(out + oo) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+            if (out_h) { __half2 a = __floats2half2_rn(s4[0], s4[1]), b = __floats2half2_rn(s4[2], s4[3]); uint2 w; w.x = *reinterpret_cast<unsigned *>(&a); w.y = *reinterpret_cast<unsigned *>(&b); *reinterpret_cast<uint2 *>(out_h + oo) = w; }
+        }
+    }
+}
+
+static int g_attn_mfma = 3;      // MINIGPT4_ATTN_MFMA: 0 v_fma kernel, 1 LDS-staged MFMA kernel (round 1), 2 its re-scheduled variant, 3 (default) k_attn_vit
 void set_attn_mfma(int v) { g_attn_mfma = v; }
 void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale, float score_div,
                      const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s, int batch) {
@@ -637,6 +765,21 @@ void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, in
         attr_set = true;
     }
     if (hd != 88 && hd != 64) throw HipError{hipErrorInvalidValue, "attn_f32: head size must be 88 or 64", __FILE__, __LINE__};
+    if (g_attn_mfma >= 3 && nk <= 320 && tb.exp_neg_n > 0 && tb.exp_neg_n % 2048 == 0) {
+        static bool attr3 = false;
+        if (!attr3) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<88, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<64, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr3 = true;
+        }
+        const size_t lds_v = 768 + (size_t)4 * ((hd + 15) / 16) * 4 * 64 * 4 + (size_t)tb.exp_neg_n * 2;
+        dim3 grid((unsigned)heads, (unsigned)((nq + 15) / 16), (unsigned)batch);
+        if (hd == 88) { hipLaunchKernelGGL((k_attn_vit<88, 5>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo); }
+        else if (nk <= 64) hipLaunchKernelGGL((k_attn_vit<64, 1>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
+        else hipLaunchKernelGGL((k_attn_vit<64, 5>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
+        return;
+    }
     const int nkp = (nk + 15) & ~15;
     const size_t lds_m = ((size_t)nkp * (hd + 1) + 32 * (size_t)(nkp + 1)) * 4;
     if (g_attn_mfma && lds_m <= 160 * 1024) {
