@@ -25,7 +25,12 @@ constexpr size_t kEmb7B = 32 * 4096, kEmb13B = 32 * 5120;
 inline Engine *E_(MiniGPT4Context *c) { return reinterpret_cast<Engine *>(c); }
 bool file_exists(const char *p) { struct stat st; return p && stat(p, &st) == 0; }
 
+// The HIP runtime keeps the last failed call of the thread as a sticky "last error" that the NEXT user of hipGetLastError sees -- e.g. the host application's own
+// launch checks (PyTorch raised "HIP error: invalid argument" on its first kernel after this library had ignored a refused hipFuncSetAttribute).  Every entry point
+// leaves that slot clean.
+struct ClearStickyHipError { ~ClearStickyHipError() { (void)hipGetLastError(); } };
 template <typename F> int guarded(int on_hip_error, F &&f) {
+    ClearStickyHipError clear_on_exit;
     try { return f(); }
     catch (const HipError &e) {
         char buf[512]; snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d: %s", (int)e.code, hipGetErrorString(e.code), e.file, e.line, e.what);
@@ -274,6 +279,7 @@ int minigpt4_amd_end_chat_batch(struct MiniGPT4Context *ctx, const int32_t *slot
 }
 int minigpt4_amd_weight_arena(struct MiniGPT4Context *ctx, int which, void **device_ptr, size_t *bytes) {
     if (!ctx || !device_ptr || !bytes) return 1;
+    ClearStickyHipError clear_on_exit;   // the caller is about to hand this pointer to another HIP user (torch / RCCL): no stale error of ours may meet its launch checks
     Engine *e = E_(ctx);
     *device_ptr = which == 0 ? (void *)e->llm_arena_ptr() : (void *)e->vision_arena_ptr();
     *bytes = which == 0 ? e->llm_arena_bytes() : e->vision_arena_bytes();

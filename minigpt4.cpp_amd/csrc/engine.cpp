@@ -119,7 +119,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     // Opt-in experiment (unmeasured at the time of writing): the w1|w3 launch also prepares w2's activation row (last-arriver per 256-row block),
     // one launch less per layer.
     if (getenv("MINIGPT4_BATCH_ROWS_MAX")) batch_rows_max_ = atoi(getenv("MINIGPT4_BATCH_ROWS_MAX"));
-    batch_fuse_ = !(getenv("MINIGPT4_BATCH_FUSE") && !atoi(getenv("MINIGPT4_BATCH_FUSE")));   // 0: standalone row preparation in front of wq|wk|wv and w1|w3 (A/B, tests)
+    batch_fuse_ = getenv("MINIGPT4_BATCH_FUSE") ? (atoi(getenv("MINIGPT4_BATCH_FUSE")) != 0) : -1;   // -1: by batch size (see forward_batch)
     if (const char *sk = getenv("MINIGPT4_SPLITK")) { sscanf(sk, "%d,%d", &splitk_proj_, &splitk_fc2_); splitk_proj_ = std::max(1, std::min(SPLITK_MAX, splitk_proj_)); splitk_fc2_ = std::max(1, std::min(SPLITK_MAX, splitk_fc2_)); }
     set_matvec_tuning(getenv("MINIGPT4_MV_WAVES") ? atoi(getenv("MINIGPT4_MV_WAVES")) : 0, getenv("MINIGPT4_FAT_LB") ? atoi(getenv("MINIGPT4_FAT_LB")) : 0, prop.multiProcessorCount);
     if (const char *ns = getenv("MINIGPT4_CONVERSATIONS")) conv_.assign((size_t)std::max(1, std::min(MAX_CONVERSATIONS, atoi(ns))), Conversation{});
@@ -650,7 +650,9 @@ void Engine::forward_batch(int B, hipStream_t s) {
     };
     // may the rows of this set be prepared inside its launch?  (same conditions mm() takes the multi-row kernel under)
     auto rows_pro = [&](std::initializer_list<const QWeight *> Ws) {
-        if (!batch_fuse_ || B > batch_rows_max_) return false;
+        // measured (profiles/r02j_batched_decode_ab.log): inside the launch the preparation pays at 2 rows (560 vs 540 tok/s) and loses at 4 (808 vs 829: every fat
+        // workgroup repeats four rows' norm + quantisation); MINIGPT4_BATCH_FUSE=1 forces it for every B <= 4, =0 switches it off
+        if (batch_fuse_ == 0 || B > batch_rows_max_ || B > 4 || (batch_fuse_ < 0 && B > 2)) return false;
         const QWeight *w0 = *Ws.begin();
         for (const QWeight *w : Ws) if (w->type != w0->type || w->rows != w0->rows || w->cols != w0->cols) return false;
         return matvec_rows_prologue_ok(w0->type, w0->cols);

@@ -1374,16 +1374,46 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
         }
         return s * scale;
     };
-    float mx = -INFINITY;
-    for (int j = tid; j < Tg; j += AT_THREADS) { const float s = dot_row(kc + (size_t)j * E + (size_t)h * HD); sc[j] = s; mx = fmaxf(mx, s); }
-    if (FUSED && tid == AT_THREADS - 1) { const float s = dot_row(knew); sc[pos] = s; mx = fmaxf(mx, s); }
-    // The value rows do not depend on the scores: request the first NPRE of this thread's rows now, so that they arrive during the softmax.
+    // Scores of the cached keys: 16 consecutive lanes share one key row (lane c holds its dims 8 c .. 8 c + 7 -- one 256-byte row per 16 lanes, four whole rows per
+    // wave instruction; the round-1 form, a whole row per lane, asked the address path for 64 different cache lines per instruction and grew by ~0.025 us per key), the
+    // 8-dim partial dots are added across the 16 lanes with DPP.  Key and value rows of the same (lane, round) sit at the same offset of the two caches, and neither
+    // depends on this step's scores: both are requested here, NPRE rounds deep, so they arrive during the dot products / the softmax.
     const int c = tid % CH, p = tid / CH;
-    const __half *vb = vc + (size_t)h * HD + 8 * c;
-    constexpr int NPRE = 12;
-    int4 vpre[NPRE];
+    const __half *kb = kc + (size_t)h * HD + 8 * c, *vb = vc + (size_t)h * HD + 8 * c;
+    constexpr int NPRE = 16;                        // x P = 32 key partitions: contexts up to 512 need no second round trip
+    int4 kpre[NPRE], vpre[NPRE];
 #pragma unroll
-    for (int i = 0; i < NPRE; i++) vpre[i] = ld16(vb + (size_t)min(p + i * P, max(Tg - 1, 0)) * E);   // clamped: never branches, never out of the cache
+    for (int i = 0; i < NPRE; i++) kpre[i] = ld16(kb + (size_t)min(p + i * P, max(Tg - 1, 0)) * E);   // clamped: never branches, never out of the cache
+#pragma unroll
+    for (int i = 0; i < NPRE; i++) vpre[i] = ld16(vb + (size_t)min(p + i * P, max(Tg - 1, 0)) * E);
+    float qd[8];
+    {
+        const int4 q4 = *reinterpret_cast<const int4 *>(qh + 8 * c);
+        const unsigned w[4] = {(unsigned)q4.x, (unsigned)q4.y, (unsigned)q4.z, (unsigned)q4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) { qd[2 * e] = h2f_bits(w[e] & 0xFFFF); qd[2 * e + 1] = h2f_bits(w[e] >> 16); }
+    }
+    auto dot16 = [&](const int4 &kk) {              // all 16 lanes of the row return the key's score
+        const unsigned w[4] = {(unsigned)kk.x, (unsigned)kk.y, (unsigned)kk.z, (unsigned)kk.w};
+        float s = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { s = fmaf(h2f_bits(w[e] & 0xFFFF), qd[2 * e], s); s = fmaf(h2f_bits(w[e] >> 16), qd[2 * e + 1], s); }
+        s += dpp_f<0xB1>(s); s += dpp_f<0x4E>(s);                 // the CH = HD / 8 lanes of the key: 4 (HD 32), 8 (HD 64: half a DPP row) or 16 (HD 128: a DPP row)
+        if (CH >= 8) s += dpp_f<0x141>(s);
+        if (CH >= 16) s += dpp_f<0x140>(s);
+        return s * scale;
+    };
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NPRE; i++) { const int j = p + i * P; const float s = dot16(kpre[i]); if (j < Tg) { if (c == 0) sc[j] = s; mx = fmaxf(mx, s); } }
+    for (int j0 = p + NPRE * P; j0 < Tg; j0 += 8 * P) {      // beyond the prefetch: 8 rows per round trip
+        int4 kk[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) kk[i] = ld16(kb + (size_t)min(j0 + i * P, Tg - 1) * E);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const int j = j0 + i * P; const float s = dot16(kk[i]); if (j < Tg) { if (c == 0) sc[j] = s; mx = fmaxf(mx, s); } }
+    }
+    if (FUSED && tid == AT_THREADS - 1) { const float s = dot_row(knew); sc[pos] = s; mx = fmaxf(mx, s); }
     mx = wave_max(mx);
     if ((tid & 63) == 0) s_red[tid >> 6] = mx;
     __syncthreads();
@@ -1410,8 +1440,13 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
     };
 #pragma unroll
     for (int i = 0; i < NPRE; i++) { const int j = p + i * P; if (j < Tg) pv_acc(vpre[i], j); }
-#pragma unroll 4
-    for (int j = p + NPRE * P; j < Tg; j += P) pv_acc(ld16(vb + (size_t)j * E), j);
+    for (int j0 = p + NPRE * P; j0 < Tg; j0 += 8 * P) {
+        int4 vv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) vv[i] = ld16(vb + (size_t)min(j0 + i * P, Tg - 1) * E);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const int j = j0 + i * P; if (j < Tg) pv_acc(vv[i], j); }
+    }
     if (FUSED && p == P - 1) {
         const float pj = __half2float(ph[pos]);
 #pragma unroll

@@ -414,216 +414,7 @@ __global__ __launch_bounds__(256) void k_attn_f32(const float *__restrict__ q, i
         }
     }
 }
-// ---------------------------------------------------------------------------------------------------------------------
-// fp32 attention on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, a k-ordered fma chain -> the same summation order
-// as the sequential CPU dot products).  Workgroup = (head, 32 queries), 4 waves.
-//   A: S = Q K^T   16x16 tiles: wave w owns q-tile (w & 1) and key tiles (w >> 1) + 2i; Q fragments live in registers, K in LDS
-//   B: softmax over LDS rows (8 lanes per query row; max, fp16-table exp, exact double sum)
-//   C: O = P V     16x16 tiles (2 q-tiles x ceil(HD/16) dim tiles over the 4 waves); each tile runs over all keys in order
-// ---------------------------------------------------------------------------------------------------------------------
 typedef float float4_t __attribute__((ext_vector_type(4)));
-// copy rows [0, nk) of one head (HD floats each, 16-byte aligned in global memory) into LDS rows of HD+1 floats; rows [nk, nkp) are zeroed.
-// 8 float4 loads are kept in flight per thread.
-template <int HD>
-__device__ __forceinline__ void stage_head(float *kv, const float *__restrict__ src, int ld, int h, int nk, int nkp, int tid) {
-    constexpr int C4 = HD / 4, LDV = HD + 1, B = 8;
-    const int total = nk * C4;
-    for (int e0 = 0; e0 < total; e0 += 256 * B) {
-        float4 x[B];
-#pragma unroll
-        for (int u = 0; u < B; u++) { const int e = min(e0 + tid + 256 * u, total - 1), j = e / C4, c = e - j * C4; x[u] = *reinterpret_cast<const float4 *>(src + (size_t)j * ld + h * HD + 4 * c); }
-#pragma unroll
-        for (int u = 0; u < B; u++) { const int e = e0 + tid + 256 * u; if (e < total) { const int j = e / C4, c = e - j * C4; float *d = kv + j * LDV + 4 * c; d[0] = x[u].x; d[1] = x[u].y; d[2] = x[u].z; d[3] = x[u].w; } }
-    }
-    for (int e = nk * LDV + tid; e < nkp * LDV; e += 256) kv[e] = 0.0f;
-}
-template <int HD>
-__global__ __launch_bounds__(256) void k_attn_mfma(const float *__restrict__ q, int ldq, const float *__restrict__ k, const float *__restrict__ v, int ldk, int nq, int nk,
-                                                   float q_prescale, float score_div, const Tables tb, float *__restrict__ out, __half *__restrict__ out_h, int ldo) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int LDV = HD + 1, DT = (HD + 15) / 16, KS = HD / 4;
-    { const size_t z = blockIdx.z; q += z * nq * ldq; k += z * nk * ldk; v += z * nk * ldk; if (out) out += z * nq * ldo; if (out_h) out_h += z * nq * ldo; }   // image z of a batch
-    const int nkp = (nk + 15) & ~15, LS = nkp + 1;
-    float *kv = reinterpret_cast<float *>(smem);               // [nkp][LDV]
-    float *S = kv + (size_t)nkp * LDV;                           // [32][LS]
-    const int h = blockIdx.x, q0 = blockIdx.y * 32, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // stage K_h (zero rows past nk)
-    stage_head<HD>(kv, k, ldk, h, nk, nkp, tid);
-    // Q fragments of this wave's q-tile: A[i = lane & 15][kk = lane >> 4] per k-step
-    const int qt = wave & 1;
-    float qf[KS];
-    {
-        const int qrow = min(q0 + qt * 16 + (lane & 15), nq - 1);
-        const float *qp = q + (size_t)qrow * ldq + h * HD + (lane >> 4);
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) { float t = qp[4 * ks]; if (q_prescale != 0.0f) t *= q_prescale; qf[ks] = t; }
-    }
-    __syncthreads();
-    const int KT = nkp / 16;
-    for (int kt = wave >> 1; kt < KT; kt += 2) {
-        float4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float *kb = kv + (size_t)(kt * 16 + (lane & 15)) * LDV + (lane >> 4);
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[ks], kb[4 * ks], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; r++) { float sv = acc[r]; if (score_div != 0.0f) sv = sv / score_div; S[(qt * 16 + (lane >> 4) * 4 + r) * LS + kt * 16 + (lane & 15)] = sv; }
-    }
-    __syncthreads();
-    // softmax: 8 lanes per query row
-    {
-        const int row = tid >> 3, sub = tid & 7;
-        float *sr = S + (size_t)row * LS;
-        float mx = -INFINITY;
-        for (int j = sub; j < nk; j += 8) mx = fmaxf(mx, sr[j]);
-        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
-        double sum = 0.0;
-        // the fp16-table gathers are L2 round trips: issue them in batches of 8 instead of one dependent gather per iteration
-        for (int j0 = sub; j0 < nk; j0 += 64) {
-            float e[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { const int j = j0 + 8 * u; e[u] = tab_v(tb.exp, sr[min(j, nk - 1)] - mx); }
-#pragma unroll
-            for (int u = 0; u < 8; u++) { const int j = j0 + 8 * u; if (j < nk) { sr[j] = e[u]; sum += (double)e[u]; } }
-        }
-        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
-        const float inv = (float)(1.0 / sum);
-        for (int j = sub; j < nkp; j += 8) sr[j] = j < nk ? sr[j] * inv : 0.0f;
-    }
-    __syncthreads();
-    // stage V_h over K_h
-    stage_head<HD>(kv, v, ldk, h, nk, nkp, tid);
-    __syncthreads();
-    const int nks = (nk + 3) / 4;
-    for (int tile = wave; tile < 2 * DT; tile += 4) {
-        const int pqt = tile & 1, dt = tile >> 1;
-        float4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float *pa = S + (size_t)(pqt * 16 + (lane & 15)) * LS + (lane >> 4);
-        const int dim = min(dt * 16 + (lane & 15), HD);                     // column HD of kv is the (finite) pad column; its results are discarded
-        const float *vb = kv + (size_t)(lane >> 4) * LDV + dim;
-#pragma unroll 8
-        for (int ks = 0; ks < nks; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * ks], vb[(size_t)4 * ks * LDV], acc, 0, 0, 0);
-        const int d = dt * 16 + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int qrow = q0 + pqt * 16 + (lane >> 4) * 4 + r;
-            if (qrow < nq && d < HD) { const size_t oo = (size_t)qrow * ldo + h * HD + d; if (out) out[oo] = acc[r]; if (out_h) out_h[oo] = __float2half_rn(acc[r]); }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// k_attn_mfma2 -- opt-in re-scheduling of k_attn_mfma (MINIGPT4_ATTN_MFMA=2; written after the GPU budget of round 1 was spent: UNMEASURED).  Same workgroup shape, LDS
-// layout and per-element arithmetic (every accumulator sees the same operands in the same order, so results are bit-identical to k_attn_mfma); what changes is where the
-// memory latencies sit (a dependent global round trip costs ~2 us at kernel start, profiles/r01p_matvec_timeline.log):
-//   (i)   the head's K AND V rows are requested at kernel entry and held in registers (one wave per SIMD here: 512 VGPRs each); V goes to LDS as soon as the scores
-//         are done -- before the softmax -- so the second staging latency and one barrier disappear;
-//   (ii)  a staging pass is ONE batch of loads per thread instead of three;
-//   (iii) the fp16-table gathers of a softmax row are one batch per lane;
-//   (iv)  a wave interleaves its independent MFMA chains (two key tiles in S = Q K^T; its dim tiles in O = P V, which share the P fragment): the 40-cycle
-//         dependent-accumulator latency of v_mfma_f32_16x16x4_f32 is hidden behind the 32-cycle issue of the other chain.
-// NB = float4 loads per thread and operand: needs nk * HD / 4 <= 256 * NB (the launcher checks; otherwise k_attn_mfma runs).
-// ---------------------------------------------------------------------------------------------------------------------
-template <int HD, int NB>
-__global__ __launch_bounds__(256) void k_attn_mfma2(const float *__restrict__ q, int ldq, const float *__restrict__ k, const float *__restrict__ v, int ldk, int nq, int nk,
-                                                    float q_prescale, float score_div, const Tables tb, float *__restrict__ out, __half *__restrict__ out_h, int ldo) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int LDV = HD + 1, DT = (HD + 15) / 16, KS = HD / 4, C4 = HD / 4, NT = DT / 2, NE = (NB * 256 / C4 + 7) / 8 + 1;
-    static_assert(DT % 2 == 0, "dim tiles are split over wave pairs");
-    { const size_t z = blockIdx.z; q += z * nq * ldq; k += z * nk * ldk; v += z * nk * ldk; if (out) out += z * nq * ldo; if (out_h) out_h += z * nq * ldo; }
-    const int nkp = (nk + 15) & ~15, LS = nkp + 1;
-    float *kv = reinterpret_cast<float *>(smem);               // [nkp][LDV]
-    float *S = kv + (size_t)nkp * LDV;                           // [32][LS]
-    const int h = blockIdx.x, q0 = blockIdx.y * 32, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int total = nk * C4;
-    // (i) + (ii): all K and V loads of this thread, K first (results return in issue order)
-    float4 kx[NB], vx[NB];
-#pragma unroll
-    for (int u = 0; u < NB; u++) { const int e = min(tid + 256 * u, total - 1), j = e / C4, c = e - j * C4; kx[u] = *reinterpret_cast<const float4 *>(k + (size_t)j * ldk + h * HD + 4 * c); }
-#pragma unroll
-    for (int u = 0; u < NB; u++) { const int e = min(tid + 256 * u, total - 1), j = e / C4, c = e - j * C4; vx[u] = *reinterpret_cast<const float4 *>(v + (size_t)j * ldk + h * HD + 4 * c); }
-    const int qt = wave & 1;
-    float qf[KS];
-    {
-        const int qrow = min(q0 + qt * 16 + (lane & 15), nq - 1);
-        const float *qp = q + (size_t)qrow * ldq + h * HD + (lane >> 4);
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) { float t = qp[4 * ks]; if (q_prescale != 0.0f) t *= q_prescale; qf[ks] = t; }
-    }
-#pragma unroll
-    for (int u = 0; u < NB; u++) { const int e = tid + 256 * u; if (e < total) { const int j = e / C4, c = e - j * C4; float *d = kv + j * LDV + 4 * c; d[0] = kx[u].x; d[1] = kx[u].y; d[2] = kx[u].z; d[3] = kx[u].w; } }
-    for (int e = nk * LDV + tid; e < nkp * LDV; e += 256) kv[e] = 0.0f;          // rows [nk, nkp) stay zero for V as well
-    __syncthreads();
-    // S = Q K^T: key tiles (wave >> 1) + 2 i of q-tile (wave & 1), two tiles at a time
-    const int KT = nkp / 16;
-    for (int kt = wave >> 1; kt < KT; kt += 4) {
-        const bool two = kt + 2 < KT;                             // wave-uniform
-        const int kt2 = two ? kt + 2 : kt;
-        float4_t acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float *kb0 = kv + (size_t)(kt * 16 + (lane & 15)) * LDV + (lane >> 4);
-        const float *kb1 = kv + (size_t)(kt2 * 16 + (lane & 15)) * LDV + (lane >> 4);
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[ks], kb0[4 * ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[ks], kb1[4 * ks], acc1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float s0 = acc0[r], s1 = acc1[r];
-            if (score_div != 0.0f) { s0 = s0 / score_div; s1 = s1 / score_div; }
-            float *srow = S + (size_t)(qt * 16 + (lane >> 4) * 4 + r) * LS + (lane & 15);
-            srow[kt * 16] = s0;
-            if (two) srow[kt2 * 16] = s1;
-        }
-    }
-    __syncthreads();                                              // every wave is done with K: V takes its place while the softmax runs on S
-#pragma unroll
-    for (int u = 0; u < NB; u++) { const int e = tid + 256 * u; if (e < total) { const int j = e / C4, c = e - j * C4; float *d = kv + j * LDV + 4 * c; d[0] = vx[u].x; d[1] = vx[u].y; d[2] = vx[u].z; d[3] = vx[u].w; } }
-    // softmax: 8 lanes per query row; (iii) one batch of table gathers per lane, summed in the same (ascending j) order as k_attn_mfma
-    {
-        const int row = tid >> 3, sub = tid & 7;
-        float *sr = S + (size_t)row * LS;
-        float mx = -INFINITY;
-        for (int j = sub; j < nk; j += 8) mx = fmaxf(mx, sr[j]);
-        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
-        float e[NE];
-#pragma unroll
-        for (int u = 0; u < NE; u++) { const int j = sub + 8 * u; e[u] = tab_v(tb.exp, sr[min(j, nk - 1)] - mx); }
-        double sum = 0.0;
-#pragma unroll
-        for (int u = 0; u < NE; u++) { const int j = sub + 8 * u; if (j < nk) { sr[j] = e[u]; sum += (double)e[u]; } }
-        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
-        const float inv = (float)(1.0 / sum);
-        for (int j = sub; j < nkp; j += 8) sr[j] = j < nk ? sr[j] * inv : 0.0f;
-    }
-    __syncthreads();
-    // O = P V: this wave's q-tile (wave & 1) and dim tiles (wave >> 1) + 2 j, all chains interleaved over the shared P fragment
-    const int nks = (nk + 3) / 4, pqt = wave & 1;
-    float4_t acc[NT];
-    const float *vb[NT];
-#pragma unroll
-    for (int j = 0; j < NT; j++) {
-        acc[j] = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
-        const int dim = min(((wave >> 1) + 2 * j) * 16 + (lane & 15), HD);              // column HD of kv is the (finite) pad column; its results are discarded
-        vb[j] = kv + (size_t)(lane >> 4) * LDV + dim;
-    }
-    const float *pa = S + (size_t)(pqt * 16 + (lane & 15)) * LS + (lane >> 4);
-#pragma unroll 4
-    for (int ks = 0; ks < nks; ks++) {
-        const float pv = pa[4 * ks];
-#pragma unroll
-        for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vb[j][(size_t)4 * ks * LDV], acc[j], 0, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < NT; j++) {
-        const int d = ((wave >> 1) + 2 * j) * 16 + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int qrow = q0 + pqt * 16 + (lane >> 4) * 4 + r;
-            if (qrow < nq && d < HD) { const size_t oo = (size_t)qrow * ldo + h * HD + d; if (out) out[oo] = acc[j][r]; if (out_h) out_h[oo] = __float2half_rn(acc[j][r]); }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // k_attn_vit -- fp32 attention without K / V staging (round 2; replaces the LDS-staged k_attn_mfma for nk <= 64 * TPW keys).
 //   * workgroup = (head, 16 queries, image); its 4 waves split the KEYS (wave w owns key tiles w, w + 4, ...), so a ViT layer is 16 x 17 = 272 workgroups
@@ -752,7 +543,7 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
     }
 }
 
-static int g_attn_mfma = 3;      // MINIGPT4_ATTN_MFMA: 0 v_fma kernel, 1 LDS-staged MFMA kernel (round 1), 2 its re-scheduled variant, 3 (default) k_attn_vit
+static int g_attn_mfma = 1;      // MINIGPT4_ATTN_MFMA=0: the v_fma / LDS kernel k_attn_f32 for every shape (tests, A/B)
 void set_attn_mfma(int v) { g_attn_mfma = v; }
 void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale, float score_div,
                      const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s, int batch) {
@@ -760,43 +551,18 @@ void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, in
     if (!attr_set) {   // > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_f32<88>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_f32<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_mfma<88>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_mfma<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<88, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<64, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (hd != 88 && hd != 64) throw HipError{hipErrorInvalidValue, "attn_f32: head size must be 88 or 64", __FILE__, __LINE__};
-    if (g_attn_mfma >= 3 && nk <= 320 && tb.exp_neg_n > 0 && tb.exp_neg_n % 2048 == 0) {
-        static bool attr3 = false;
-        if (!attr3) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<88, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<64, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr3 = true;
-        }
+    if (g_attn_mfma && nk <= 320 && tb.exp_neg_n > 0 && tb.exp_neg_n % 2048 == 0) {   // k_attn_vit (measured: ViT-g encode 5.29 vs 5.90 ms with the LDS-staged round-1 kernel)
         const size_t lds_v = 768 + (size_t)4 * ((hd + 15) / 16) * 4 * 64 * 4 + (size_t)tb.exp_neg_n * 2;
         dim3 grid((unsigned)heads, (unsigned)((nq + 15) / 16), (unsigned)batch);
-        if (hd == 88) { hipLaunchKernelGGL((k_attn_vit<88, 5>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo); }
+        if (hd == 88) hipLaunchKernelGGL((k_attn_vit<88, 5>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
         else if (nk <= 64) hipLaunchKernelGGL((k_attn_vit<64, 1>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
         else hipLaunchKernelGGL((k_attn_vit<64, 5>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
-        return;
-    }
-    const int nkp = (nk + 15) & ~15;
-    const size_t lds_m = ((size_t)nkp * (hd + 1) + 32 * (size_t)(nkp + 1)) * 4;
-    if (g_attn_mfma && lds_m <= 160 * 1024) {
-        dim3 grid((unsigned)heads, (unsigned)((nq + 31) / 32), (unsigned)batch);
-        if (g_attn_mfma == 2 && nk * (hd / 4) <= 256 * (hd == 88 ? 24 : 17)) {       // opt-in re-scheduled variant (bit-identical by construction, unmeasured)
-            static bool attr2 = false;
-            if (!attr2) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_mfma2<88, 24>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_mfma2<64, 17>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr2 = true;
-            }
-            if (hd == 88) hipLaunchKernelGGL((k_attn_mfma2<88, 24>), grid, dim3(256), lds_m, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
-            else hipLaunchKernelGGL((k_attn_mfma2<64, 17>), grid, dim3(256), lds_m, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
-            return;
-        }
-        if (hd == 88) hipLaunchKernelGGL((k_attn_mfma<88>), grid, dim3(256), lds_m, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
-        else hipLaunchKernelGGL((k_attn_mfma<64>), grid, dim3(256), lds_m, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
         return;
     }
     dim3 grid((unsigned)heads, (unsigned)((nq + 15) / 16), (unsigned)batch);

@@ -88,10 +88,19 @@ def load_replica(lib, vision_path: str, llm_path: str, rank: int, world: int, de
             torch.cuda.synchronize(device)
         dist.barrier()
         t0 = time.time()
-        for which in (0, 1):
-            broadcast_arena(arena_tensor(lib, ctx, which, device), src=0)
-        if device is not None:
-            torch.cuda.synchronize(device)
+        try:
+            for which in (0, 1):
+                broadcast_arena(arena_tensor(lib, ctx, which, device), src=0)
+            if device is not None:
+                torch.cuda.synchronize(device)
+        except Exception as e:   # a launch-time refusal is raised by every rank at the same call: all of them take this branch and fall back to reading the files
+            stats["bcast_error"] = f"{type(e).__name__}: {e}"[:300]
+            if recv:
+                lib.minigpt4_free(ctx)
+                t1 = time.time()
+                ctx = lib.minigpt4_model_load(vision_path, llm_path, **load_kw)
+                stats["mode"], stats["load_s"] = "full (broadcast refused)", time.time() - t1
+                recv = False
         stats["bcast_ms"] = (time.time() - t0) * 1e3
         if recv:
             assert lib.library.minigpt4_amd_weights_received(ctx.ptr) == 0
