@@ -35,7 +35,9 @@ int mmq_enabled();
 // chunk of <= 128 tokens, activations staged through LDS, optional K split (partial sums in A.ws) combined in fixed order.  false -> outside the kernels' range, nothing launched.
 bool mmq2_supported(int type, int rows, int cols);
 bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s);
-void set_mmq2_cus(int cus);   // CU count the K-split heuristic aims at (the K-split partial sums live in ActQ::ws, owned by whoever owns the activation planes)
+void set_mmq2_cus(int cus);
+void set_mmq_generation(int g);   // Q4_K / Q5_K prefill kernel: 2 = k_mmq2_q45k, 3 (default) = k_mmq3_q45k (scales folded into the int8 operands); results are bit-identical
+int mmq_generation();   // CU count the K-split heuristic aims at (the K-split partial sums live in ActQ::ws, owned by whoever owns the activation planes)
 
 // decode (N = 1) persistent-wave mat-vec over 1..3 same-type, same-shape matrices (wq|wk|wv, w1|w3); false -> caller falls back to launch_mul_mat
 // pro: 0 = activations come from `A` (prepared by launch_rms_quant / launch_silu_mul_quant); 1 = rms_norm(px) * pw, 2 = px, 3 = silu(px) * pw are

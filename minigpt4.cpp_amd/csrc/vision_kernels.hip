@@ -291,18 +291,34 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_ln(const float *__restric
                                                           __half *__restrict__ ln_out_h) {
     __shared__ double red[4];
     const size_t row = blockIdx.x;
-    constexpr int MAXE = 8;
+    constexpr int MAXE = 8, MAXZ = 12;            // n <= 2048, slabs <= Engine::SPLITK_MAX
     float xv[MAXE];
     double s = 0.0;
+    // every slab value of the row is requested before the first one is used (clamped indices, no load under a branch: the round-1 form walked the slabs with one
+    // dependent round trip each -- 13 us for a 4-slab row of 1408; same additions in the same order)
+    float part[MAXZ][MAXE], rv[MAXE], bv[MAXE];
+#pragma unroll
+    for (int z = 0; z < MAXZ; z++) {
+        const size_t zo = (size_t)min(z, n_slabs - 1) * slab_stride + row * n;
+#pragma unroll
+        for (int e = 0; e < MAXE; e++) part[z][e] = slabs[zo + min((int)threadIdx.x + 256 * e, n - 1)];
+    }
+#pragma unroll
+    for (int e = 0; e < MAXE; e++) {
+        const int ic = min((int)threadIdx.x + 256 * e, n - 1);
+        rv[e] = residual ? residual[row * n + ic] : 0.0f;
+        bv[e] = bias ? bias[ic] : 0.0f;
+    }
 #pragma unroll
     for (int e = 0; e < MAXE; e++) {
         const int i = threadIdx.x + 256 * e;
         float v = 0.0f;
         if (i < n) {
-            float a = slabs[row * n + i];
-            for (int z = 1; z < n_slabs; z++) a += slabs[(size_t)z * slab_stride + row * n + i];
-            v = bias ? bias[i] + a : a;
-            if (residual) v = residual[row * n + i] + v;
+            float a = part[0][e];
+#pragma unroll
+            for (int z = 1; z < MAXZ; z++) a = z < n_slabs ? a + part[z][e] : a;
+            v = bias ? bv[e] + a : a;
+            if (residual) v = rv[e] + v;
             if (x_out) x_out[row * n + i] = v;
         }
         xv[e] = v; s += (double)v;
@@ -420,8 +436,8 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 //   * workgroup = (head, 16 queries, image); its 4 waves split the KEYS (wave w owns key tiles w, w + 4, ...), so a ViT layer is 16 x 17 = 272 workgroups
 //     (one per CU) whose critical path is a quarter of a head instead of the whole head;
 //   * scores are computed TRANSPOSED, S^T = K . Q^T (v_mfma_f32_16x16x4_f32; A = 16 keys, B = 16 queries): the MFMA reduction index may be labelled freely as
-//     long as A and B agree, so lane (row, g) takes the CONTIGUOUS dims [g * HD/4, (g + 1) * HD/4) of its row -- Q and K fragments come straight from global
-//     memory as 8-byte loads of whole 88 B / 64 B row quarters, no LDS, no transposition;
+//     long as A and B agree, so Q and K fragments come straight from global memory as 16-byte loads (per instruction 64 contiguous bytes of each of the tile's 16
+//     rows), no LDS, no transposition;
 //   * the C layout of S^T (lane (query, g), register r <-> key 16 kt + 4 g + r) IS the B-operand layout of O^T = V^T . P^T, so the probabilities never leave
 //     their registers; V enters as the A operand (lane (dim, g) <- V[key 16 kt + 4 g + r][dim]), again straight from global memory (64-byte segments);
 //   * softmax exactly as before (fp32 max, the fp16 exp table, fp64 sum -- exact in any order: <= 2^9 terms of 11-bit values --, p = e * (float)(1 / sum)),
@@ -433,8 +449,8 @@ template <int HD, int TPW>
 __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, int ldq, const float *__restrict__ k, const float *__restrict__ v, int ldk, int nq, int nk,
                                                   float q_prescale, float score_div, const Tables tb, float *__restrict__ out, __half *__restrict__ out_h, int ldo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int KS = HD / 4, DT = (HD + 15) / 16;
-    static_assert(KS % 2 == 0, "row quarters are loaded as float2");
+    constexpr int DT = (HD + 15) / 16, KS4 = 4 * DT;
+    static_assert(HD % 4 == 0, "16-byte row pieces");
     { const size_t z = blockIdx.z; q += z * nq * ldq; k += z * nk * ldk; v += z * nk * ldk; if (out) out += z * nq * ldo; if (out_h) out_h += z * nq * ldo; }
     const int h = blockIdx.x, q0 = blockIdx.y * 16, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
     float *red_m = reinterpret_cast<float *>(smem);                         // [4][16]
@@ -444,22 +460,34 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
     const unsigned NT = (unsigned)tb.exp_neg_n;                             // multiple of 2048
     for (unsigned c0 = 0; c0 < NT; c0 += 2048)
         __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(tb.exp + 0x8000 + c0 + tid * 8), (g_lds_ptr_t)(reinterpret_cast<unsigned char *>(etab) + (c0 + wave * 512) * 2), 16, 0, 0);
-    float qf[KS];
+    // Q / K fragments: instruction u of a 16-row tile reads, per row, the 64 contiguous bytes of dims 16 u .. 16 u + 15 (lane (row, g): 16 bytes = dims 16 u + 4 g + e),
+    // i.e. 16 whole sectors per wave instruction.  (First version: lane (row, g) read its own 88-byte quarter row 8 bytes at a time -- 64 different sectors per
+    // instruction, and the address path, not the 90 KB of K, set the kernel's time.)  MFMA step (u, e) therefore reduces over dims {16 u + 4 g + e : g}; dims past HD
+    // (HD = 88: u = 5, g >= 2) contribute zeros.
+    float qf[KS4];
     {
-        const float *qp = q + (size_t)min(q0 + j, nq - 1) * ldq + h * HD + g * KS;
+        const float *qp = q + (size_t)min(q0 + j, nq - 1) * ldq + h * HD;
 #pragma unroll
-        for (int u = 0; u < KS / 2; u++) { const float2 t = *reinterpret_cast<const float2 *>(qp + 2 * u); qf[2 * u] = t.x; qf[2 * u + 1] = t.y; }
+        for (int u = 0; u < DT; u++) {
+            const int d0 = 16 * u + 4 * g;
+            const float4 t = *reinterpret_cast<const float4 *>(qp + min(d0, HD - 4));
+            const bool ok = d0 < HD;
+            qf[4 * u] = ok ? t.x : 0.0f; qf[4 * u + 1] = ok ? t.y : 0.0f; qf[4 * u + 2] = ok ? t.z : 0.0f; qf[4 * u + 3] = ok ? t.w : 0.0f;
+        }
     }
-    float kf[TPW][KS];
+    float kf[TPW][KS4];
 #pragma unroll
     for (int t = 0; t < TPW; t++) {
-        const float *kp = k + (size_t)min((wave + 4 * t) * 16 + j, nk - 1) * ldk + h * HD + g * KS;
+        const float *kp = k + (size_t)min((wave + 4 * t) * 16 + j, nk - 1) * ldk + h * HD;
 #pragma unroll
-        for (int u = 0; u < KS / 2; u++) { const float2 x = *reinterpret_cast<const float2 *>(kp + 2 * u); kf[t][2 * u] = x.x; kf[t][2 * u + 1] = x.y; }
+        for (int u = 0; u < DT; u++) {
+            const float4 x = *reinterpret_cast<const float4 *>(kp + min(16 * u + 4 * g, HD - 4));
+            kf[t][4 * u] = x.x; kf[t][4 * u + 1] = x.y; kf[t][4 * u + 2] = x.z; kf[t][4 * u + 3] = x.w;     // past HD: finite duplicates, multiplied by the zeros in qf
+        }
     }
     if (q_prescale != 0.0f) {
 #pragma unroll
-        for (int u = 0; u < KS; u++) qf[u] *= q_prescale;
+        for (int u = 0; u < KS4; u++) qf[u] *= q_prescale;
     }
     float sc[TPW][4];
     float mx = -INFINITY;
@@ -467,7 +495,7 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
     for (int t = 0; t < TPW; t++) {
         float4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t][ks], qf[ks], acc, 0, 0, 0);
+        for (int ks = 0; ks < KS4; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t][ks], qf[ks], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             float sv = acc[r];
