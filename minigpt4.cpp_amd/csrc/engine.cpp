@@ -108,7 +108,6 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     max_chunk_ = max_rows_;
     if (getenv("MINIGPT4_NO_MMQ")) set_mmq_enabled(atoi(getenv("MINIGPT4_NO_MMQ")) ? 0 : 2);
     if (getenv("MINIGPT4_MMQ")) set_mmq_enabled(atoi(getenv("MINIGPT4_MMQ")));   // 0: v_dot4 tiles, 1: round-1 int8-MFMA prefill kernels, 2 (default): LDS-staged second generation
-    if (getenv("MINIGPT4_MMQ_GEN")) set_mmq_generation(atoi(getenv("MINIGPT4_MMQ_GEN")));   // Q4_K / Q5_K: 2 = integer scale multiply-adds after the MFMAs, 3 (default) = scales folded into the operands
     if (getenv("MINIGPT4_ATTN_MFMA")) set_attn_mfma(atoi(getenv("MINIGPT4_ATTN_MFMA")));
     // Decode: which activation preparations run inside the consuming mat-vec's prologue (one fat workgroup per CU repeats the row preparation while
     // its first weight tiles are in flight) instead of as their own launch.  bit 0: attn_norm -> wq|wk|wv, 1: attention output -> wo,

@@ -17,6 +17,13 @@
 // Per (row tile, super-block, token tile): 8 + 2 MFMAs (Q4_K / Q5_K) or 16 (Q6_K) and ~300 VALU instructions per wave -- the kernel is VALU-bound by the integer
 // sub-block scale multiply-adds ggml's format requires (one per output element per 32 weights: 1 VALU operation per 32 MFMA multiply-accumulates on a chip whose matrix
 // pipe is 64 x wider than its vector pipe), not by the matrix cores (PMC, profiles/r02e_pmc_mmq2.txt: two waves per SIMD issue 84 % of the time, MFMA 9 % busy).
+// Measured and removed, second attempt at the same bound (profiles/r02l_prefill_gen3_scales_in_operands_microbench.log): the 6-bit sub-block scales multiplied into
+// the int8 OPERANDS at unpack time as two 3-bit digits (sc = 8 hi + lo; digit x quant <= 217 fits a byte, one v_pk_mul_lo_u16 scales four weights; Q5_K bytes stored
+// minus 128 and corrected through the staged per-32 sums), so that a token tile is two K = 256 accumulation chains and the per-(row, token, sub-block) integer
+// multiply-adds disappear.  Bit-identical to this kernel on every test shape, but 64 operand registers + 5-tile chunks meant one wave per SIMD, and the launches
+// were 1.4-1.8x SLOWER (13B layer at 142 rows: qkv 118 vs 64 us, w1|w3 169 vs 101, w2 93 vs 61; whole prefill 18.3 vs 13.2 ms).  The kernel is latency-bound at
+// one wave per SIMD long before the VALU work it saved matters; a pair-outer / tile-inner variant that keeps two waves per SIMD would cut the VALU work by only
+// ~1.36x at two tiles per chunk and was not built.
 // Measured and removed (profiles/r02g_prefill_generations_microbench.log): pre-scaled "prefill planes" -- sub-block scale x quant stored as two int8 digits,
 // 2 bytes per weight, so that the scales ride inside the MFMA accumulation (exact, bit-identical results, 41 % fewer VALU instructions) -- lost on Q4_K / Q5_K
 // (w1|w3 at 142 rows: 155 vs 100 us): 2.8 x the weight bytes per chunk of <= 96 tokens turned the kernel into a latency-bound HBM stream; it won only on Q6_K.
@@ -260,157 +267,6 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
     mmq2_store<TT>(acc, a, m, r0 + l31, W.rows, t0, my_tiles, hh);
 }
 
-// four bytes (each <= 31) times a 3-bit digit replicated into both halves of d2: one packed 16-bit multiply, no carries between the bytes (digit * byte <= 217)
-typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int pkmul16(int x, unsigned d2) { const us2_t a = __builtin_bit_cast(us2_t, x), b = __builtin_bit_cast(us2_t, d2); return __builtin_bit_cast(int, (us2_t)(a * b)); }
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Q4_K / Q5_K, generation 3: the sub-block scales are multiplied into the int8 weight operands (two 3-bit digits), see the comment at W1 / W2 below.  Up to 5
-// token tiles per chunk (a 142-row image turn is one chunk: the weights are unpacked once); one wave per SIMD.
-// ---------------------------------------------------------------------------------------------------------------------
-template <bool Q5, int TT>
-__global__ __launch_bounds__(256) void k_mmq3_q45k(const Mmq2Args a, const ActQ A) {
-    using S = Mmq2Stage<TT>;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_mmq2[];   // [2 activation stages][4 waves x 4 KiB weight transpose scratch]
-    const int lane = threadIdx.x & 63, hh = lane >> 5, l31 = lane & 31;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m = blockIdx.x / a.groups_each, g = blockIdx.x - m * a.groups_each;
-    const QWeight W = a.w[m];
-    const int K = W.cols, U = K / 32, NSB = K / 256, N = a.N;
-    const int r0 = (g * 4 + wv) * 32;
-    const int row = min(r0 + l31, W.rows - 1);
-    const int tile0 = blockIdx.y * a.tiles_per_chunk, my_tiles = min(TT, a.n_tiles - tile0), t0 = tile0 * 32;
-    const int sb0 = blockIdx.z * a.sb_per_split, sb1 = min(NSB, sb0 + a.sb_per_split);
-    unsigned char *scratch = smem_mmq2 + 2 * S::BYTES + wv * 4096;
-
-    float acc[TT][16];
-#pragma unroll
-    for (int tt = 0; tt < TT; tt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[tt][r] = 0.0f;
-
-    // Weight requests of one super-block, COALESCED (a lane-per-row gather costs 32 cache-line requests per instruction and the address path, not HBM, becomes the
-    // bound -- measured: the staging loop alone took 58 % of the round-2a kernel): main plane: instruction n reads rows 8 n .. 8 n + 7 x the super-block's 8 units
-    // (128 contiguous bytes per row); high-bit plane: lane (row, hh) reads the 16 bytes of units 4 hh .. 4 hh + 3; header: 16 bytes per row.
-    struct Raw { v4i q[4]; v4i p; v4i h; };
-    const unsigned char *wq[4];
-#pragma unroll
-    for (int n = 0; n < 4; n++) wq[n] = W.qs + ((size_t)min(r0 + 8 * n + (lane >> 3), W.rows - 1) * U + (lane & 7)) * 16;
-    const unsigned char *wp = W.qh + (size_t)row * U * 4 + hh * 16, *wh = W.sc + (size_t)row * NSB * 16;
-    auto fetch = [&](int sb, Raw &w) {
-#pragma unroll
-        for (int n = 0; n < 4; n++) w.q[n] = ldg16(wq[n] + (size_t)sb * 128);
-        if (Q5) w.p = ldg16(wp + (size_t)sb * 32);
-        w.h = ldg16(wh + (size_t)sb * 16);
-    };
-    // transpose scratch: [32 rows][8 units x 16 B], unit u of row r at slot u ^ ((r >> 1) & 7) (conflict-free for the row-per-lane fragment reads)
-    unsigned sw_addr[4], sr_addr[4];
-#pragma unroll
-    for (int n = 0; n < 4; n++) sw_addr[n] = (unsigned)((8 * n + (lane >> 3)) * 128 + (((lane & 7) ^ ((4 * n + (lane >> 4)) & 7)) << 4));
-#pragma unroll
-    for (int jp = 0; jp < 4; jp++) sr_addr[jp] = (unsigned)(l31 * 128 + (((2 * jp + hh) ^ ((l31 >> 1) & 7)) << 4));
-    // per-lane LDS read addresses (stage 0): A fragment of chunk C = 4 jp + 2 x (x = 0: low-nibble sub-block, 1: high) for token l31 of tile 0
-    const int v = hh ^ (lane & 15);
-    unsigned a_addr[8];
-#pragma unroll
-    for (int c8 = 0; c8 < 8; c8++) a_addr[c8] = (unsigned)(l31 * 256 + (((2 * c8) ^ v) << 4));
-    const unsigned bs_addr = (unsigned)(S::Q8 + l31 * 16), dk_addr = (unsigned)(S::Q8 + S::BS + 16 * hh);
-
-    Raw raw;
-    fetch(sb0, raw);
-    mmq2_stage_load<TT>(A, K, NSB, N, t0, sb0, smem_mmq2, wv, lane);
-    for (int sb = sb0; sb < sb1; sb++) {
-        const int buf = (sb - sb0) & 1;
-        unsigned char *st = smem_mmq2 + buf * S::BYTES;
-        __syncthreads();                                           // own DMA + weight loads done (vmcnt(0) is part of the barrier's fence), then everybody's
-        // ---- this super-block's weights: transpose through LDS (same wave writes and reads: LDS operations of a wave execute in order), unpack into MFMA B operands
-#pragma unroll
-        for (int n = 0; n < 4; n++) *reinterpret_cast<v4i *>(scratch + sw_addr[n]) = raw.q[n];
-        unsigned P[4] = {0u, 0u, 0u, 0u};
-        if (Q5) {   // lanes hh = 0 hold the high bits of units 0..3, hh = 1 of units 4..7: lane (row, hh) needs units 2 jp + hh
-            const auto s01 = __builtin_amdgcn_permlane32_swap((unsigned)raw.p[0], (unsigned)raw.p[1], false, false);
-            const auto s23 = __builtin_amdgcn_permlane32_swap((unsigned)raw.p[2], (unsigned)raw.p[3], false, false);
-            P[0] = s01[0]; P[2] = s01[1]; P[1] = s23[0]; P[3] = s23[1];
-        }
-        v4i wlo[4], whi[4];
-#pragma unroll
-        for (int jp = 0; jp < 4; jp++) {
-            const v4i q = *reinterpret_cast<const v4i *>(scratch + sr_addr[jp]); const unsigned Pj = P[jp];
-            wlo[jp][0] = (q[0] & 0x0F0F0F0F) | (int)((Pj << 4) & 0x10101010u); wlo[jp][1] = (q[1] & 0x0F0F0F0F) | (int)((Pj << 3) & 0x10101010u);
-            wlo[jp][2] = (q[2] & 0x0F0F0F0F) | (int)((Pj << 2) & 0x10101010u); wlo[jp][3] = (q[3] & 0x0F0F0F0F) | (int)((Pj << 1) & 0x10101010u);
-            whi[jp][0] = ((q[0] >> 4) & 0x0F0F0F0F) | (int)(Pj & 0x10101010u); whi[jp][1] = ((q[1] >> 4) & 0x0F0F0F0F) | (int)((Pj >> 1) & 0x10101010u);
-            whi[jp][2] = ((q[2] >> 4) & 0x0F0F0F0F) | (int)((Pj >> 2) & 0x10101010u); whi[jp][3] = ((q[3] >> 4) & 0x0F0F0F0F) | (int)((Pj >> 3) & 0x10101010u);
-        }
-        const unsigned s0 = (unsigned)raw.h[1], s1 = (unsigned)raw.h[2], s2 = (unsigned)raw.h[3];
-        const unsigned scw0 = s0 & 0x3f3f3f3fu, scw1 = (s2 & 0x0f0f0f0fu) | (((s0 >> 6) & 0x03030303u) << 4);          // scales of sub-blocks 0..3 / 4..7, one byte each
-        const unsigned mw0 = s1 & 0x3f3f3f3fu, mw1 = ((s2 >> 4) & 0x0f0f0f0fu) | (((s1 >> 6) & 0x03030303u) << 4);     // mins
-        const float dw = h2f_b((unsigned)raw.h[0] & 0xFFFF), ndmin = -h2f_b((unsigned)raw.h[0] >> 16);
-        const v4i bm_lo = {hh ? 0 : (int)mw0, hh ? 0 : (int)mw1, 0, 0}, bm_hi = {0, 0, hh ? 0 : (int)mw0, hh ? 0 : (int)mw1};
-        const v4i one_lo = {hh ? 0 : 0x01010101, hh ? 0 : 0x01010101, 0, 0}, one_hi = {0, 0, hh ? 0 : 0x01010101, hh ? 0 : 0x01010101};
-        // Scaled operands: the 6-bit sub-block scale is split into two 3-bit digits, sc = 8 hi + lo, and each digit is multiplied into the weights BEFORE the matrix
-        // cores see them: digit * q <= 7 * 31 = 217 fits a byte, so one packed 16-bit multiply scales four weights (no carries between the bytes), and
-        //     sum_j sc_j * (q_j . a_j)  =  8 * (sum over the whole super-block of (hi q) . a)  +  (sum of (lo q) . a)
-        // is two K = 256 accumulation chains of 8 MFMAs each -- the per-(row, token, sub-block) integer multiply-adds of generation 2 (8 x 16 registers x 2 per token
-        // tile, the kernel's bound: VALU issue 84 %, MFMA busy 9 %) disappear; what is left per token tile is one shift-add per accumulator.  Q5_K products exceed the
-        // signed byte range, so the bytes are stored minus 128 (x ^ 0x80) and 128 * sum(a) is added back per digit: 8 * 128 + 128 = 1152 times the token's
-        // super-block sum, which two more MFMAs take from the digit-split per-32 sums already staged for the min term.  All integer, all exact: the results equal
-        // generation 2's bit for bit.
-        v4i W1[8], W2[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const unsigned sj = (((j & 4) ? scw1 : scw0) >> (8 * (j & 3))) & 0xFFu;
-            const unsigned hi2 = (sj >> 3) * 0x00010001u, lo2 = (sj & 7u) * 0x00010001u;
-            const v4i &wq_ = (j & 1) ? whi[j >> 1] : wlo[j >> 1];
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                W1[j][w] = pkmul16(wq_[w], hi2) ^ (Q5 ? (int)0x80808080u : 0);
-                W2[j][w] = pkmul16(wq_[w], lo2) ^ (Q5 ? (int)0x80808080u : 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);                         // the raw registers are dead from here: the next super-block's loads reuse them (no second register stage)
-        {
-            const int sbn = min(sb + 1, sb1 - 1);
-            fetch(sbn, raw);
-            mmq2_stage_load<TT>(A, K, NSB, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int tt = 0; tt < TT; tt++) {
-            if (tt < my_tiles) {
-                const unsigned char *sq = st + tt * 8192;
-                v16i SH = zero16(), SL = zero16();
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const v4i af = *reinterpret_cast<const v4i *>(sq + a_addr[j]);
-                    SH = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, W1[j], SH, 0, 0, 0);
-                    SL = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, W2[j], SL, 0, 0, 0);
-                }
-                const v4i abs_ = *reinterpret_cast<const v4i *>(st + bs_addr + tt * 512);
-                const v16i D0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, bm_lo, zero16(), 0, 0, 0);
-                const v16i D1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, bm_hi, zero16(), 0, 0, 0);
-                v16i T0 = zero16(), T1 = zero16();
-                if (Q5) {
-                    T0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, one_lo, zero16(), 0, 0, 0);
-                    T1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, one_hi, zero16(), 0, 0, 0);
-                }
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    const v4f da = *reinterpret_cast<const v4f *>(st + dk_addr + tt * 128 + q4 * 32);   // tokens 8 q4 + 4 hh + 0..3 = accumulator registers 4 q4 .. 4 q4 + 3
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int r = 4 * q4 + e;
-                        int isum = (SH[r] << 3) + SL[r];
-                        if (Q5) isum += 1152 * (T1[r] * 128 + T0[r]);
-                        acc[tt][r] = fmaf(dw * da[e], (float)isum, acc[tt][r]);
-                        acc[tt][r] = fmaf(ndmin * da[e], (float)(D1[r] * 128 + D0[r]), acc[tt][r]);
-                    }
-                }
-            }
-        }
-    }
-    mmq2_store<TT>(acc, a, m, r0 + l31, W.rows, t0, my_tiles, hh);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // Q6_K.  Unit u = 4 n + 2 c + h: low nibbles (+ 2 high bits) = elements 128 n + 32 c + 16 h + i, high nibbles = the same + 64; int8 scale per 16 elements.
 // Pair p = 2 n + c: lanes hh = 0 / 1 load units (.., h = 0) / (.., h = 1).  A scale group is 16 weights, so the products run on v_mfma_i32_32x32x16_i8 (K = 16: one group per
@@ -586,19 +442,12 @@ void set_mmq2_cus(int cus) { if (cus > 0) g_mmq2_cus = cus; }
 
 template <typename KernelT>
 static void mmq2_launch_kernel(KernelT kernel, bool &attr_done, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_done = true; }
+    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_done = true; }
     hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a, A);
 }
-static int g_mmq_generation = 3;     // 2: per-sub-block integer scale multiply-adds after the MFMAs (k_mmq2_q45k); 3 (default): scales folded into the int8 operands (k_mmq3_q45k)
-void set_mmq_generation(int g) { g_mmq_generation = g; }
-int mmq_generation() { return g_mmq_generation; }
 template <int TT>
 static void mmq2_launch_tt(int type, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
-    static bool attr[5] = {false, false, false, false, false};
-    if (g_mmq_generation >= 3 && (type == GT_Q4_K || type == GT_Q5_K)) {
-        if (type == GT_Q4_K) mmq2_launch_kernel(&k_mmq3_q45k<false, TT>, attr[3], grid, lds, s, a, A); else mmq2_launch_kernel(&k_mmq3_q45k<true, TT>, attr[4], grid, lds, s, a, A);
-        return;
-    }
+    static bool attr[3] = {false, false, false};
     if constexpr (TT <= 3) {
         if (type == GT_Q4_K) { mmq2_launch_kernel(&k_mmq2_q45k<false, TT>, attr[0], grid, lds, s, a, A); return; }
         if (type == GT_Q5_K) { mmq2_launch_kernel(&k_mmq2_q45k<true, TT>, attr[1], grid, lds, s, a, A); return; }
@@ -618,9 +467,7 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     for (int i = 0; i < n; i++) { a.w[i] = *W[i]; a.y[i] = y[i]; a.res[i] = residual ? residual[i] : nullptr; }
     a.n_mat = n; a.groups_each = (W[0]->rows + 127) / 128; a.N = N; a.ldy = ldy;
     a.n_tiles = (N + 31) / 32;
-    // token tiles per chunk: generation 2 within the 256-register budget of two waves per SIMD (Q6_K keeps four half-masked operand sets per pair); generation 3 (one wave
-    // per SIMD) takes a whole 142-row image turn as one chunk
-    int max_tt = W[0]->type == GT_Q6_K ? 2 : (g_mmq_generation >= 3 ? 5 : 3);
+    int max_tt = W[0]->type == GT_Q6_K ? 2 : 3;          // token tiles per chunk the 256-register budget (two waves per SIMD) admits: Q6_K keeps four half-masked operand sets per pair
     { static int tt_env = -1; if (tt_env < 0) { const char *e = getenv("MINIGPT4_MMQ2_TT"); tt_env = e ? atoi(e) : 0; } if (tt_env > 0) max_tt = std::min(max_tt, tt_env); }   // experiments
     const int n_chunks = (a.n_tiles + max_tt - 1) / max_tt;
     a.tiles_per_chunk = (a.n_tiles + n_chunks - 1) / n_chunks;
@@ -644,8 +491,6 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     case 1: mmq2_launch_tt<1>(type, grid, 2 * Mmq2Stage<1>::BYTES + 16384, s, a, A); break;
     case 2: mmq2_launch_tt<2>(type, grid, 2 * Mmq2Stage<2>::BYTES + 16384, s, a, A); break;
     case 3: mmq2_launch_tt<3>(type, grid, 2 * Mmq2Stage<3>::BYTES + 16384, s, a, A); break;
-    case 4: mmq2_launch_tt<4>(type, grid, 2 * Mmq2Stage<4>::BYTES + 16384, s, a, A); break;
-    case 5: mmq2_launch_tt<5>(type, grid, 2 * Mmq2Stage<5>::BYTES + 16384, s, a, A); break;
     default: throw HipError{hipErrorInvalidValue, "mmq2: bad chunking", __FILE__, __LINE__};
     }
     if (ks > 1) {

@@ -34,12 +34,7 @@ def test_mmq2_matches_oracle(gpu_lib, wtype, case):
     x = rng.standard_normal((N, n_in)).astype(np.float32)
     x[N // 2, : min(256, n_in)] = 0.0                                   # an all-zero Q8_K block (d = 0)
     res = rng.standard_normal((n_mat, N, n_out)).astype(np.float32) if with_res else None
-    got = gpu_lib.amd_test_mmq2(t, raw, n_mat, n_in, n_out, x, residual=res, ks=ks, generation=3)   # the default: scales folded into the int8 operands (Q4_K / Q5_K)
-    if wtype != "q6_k":
-        # generation 2 (integer scale multiply-adds after the MFMAs) computes the same integers and the same fp32 operations on them.  Its chunking differs (<= 3
-        # token tiles per chunk instead of <= 5), which changes nothing per (row, token) -- bit-identical
-        got2 = gpu_lib.amd_test_mmq2(t, raw, n_mat, n_in, n_out, x, residual=res, ks=ks, generation=2)
-        assert np.array_equal(got, got2), (wtype, case, float(np.abs(got - got2).max()))
+    got = gpu_lib.amd_test_mmq2(t, raw, n_mat, n_in, n_out, x, residual=res, ks=ks)
     want = R.mul_mat(t, raw, n_in, n_mat * n_out, x).reshape(N, n_mat, n_out).transpose(1, 0, 2)
     scale = np.abs(want).max()
     if with_res:
@@ -56,15 +51,15 @@ def test_mmq2_is_deterministic_with_k_split(gpu_lib):
     t = Q.NAME_TO_TYPE["q5_k"]
     raw = Q.quantize(t, (0.05 * rng.standard_normal((256, 5120))).astype(np.float32))
     x = rng.standard_normal((142, 5120)).astype(np.float32)
-    a = gpu_lib.amd_test_mmq2(t, raw, 1, 5120, 256, x, ks=5, generation=3)
-    b = gpu_lib.amd_test_mmq2(t, raw, 1, 5120, 256, x, ks=5, generation=3)
+    a = gpu_lib.amd_test_mmq2(t, raw, 1, 5120, 256, x, ks=5)
+    b = gpu_lib.amd_test_mmq2(t, raw, 1, 5120, 256, x, ks=5)
     assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("wtype", ["q4_k", "q5_k"])
-def test_mmq3_extreme_values_stay_exact(gpu_lib, wtype):
-    """The folded operands are bytes: 3-bit digit x quant <= 7 x 31 (Q5_K stored minus 128 and corrected through the per-32 sums).  Weights that drive every quant and
-    every 6-bit scale to its maximum, against activation rows of +-127 everywhere (block sums at their extremes), must still equal the oracle's integers."""
+def test_mmq2_extreme_values_stay_exact(gpu_lib, wtype):
+    """Weights that drive every quant and every 6-bit scale to its maximum against activation rows of +-127 everywhere (block sums at their extremes: the min term's
+    digit split 128 hi + lo sees its largest values) must still equal the oracle's integers."""
     import refcpu as R
     from minigpt4_cpp_amd import quants as Q
     t = Q.NAME_TO_TYPE[wtype]
@@ -76,8 +71,6 @@ def test_mmq3_extreme_values_stay_exact(gpu_lib, wtype):
     raw = Q.quantize(t, w)
     x = np.where(rng.random((N, n_in)) < 0.5, 1.0, -1.0).astype(np.float32)
     x[0, :] = 1.0; x[1, :] = -1.0                                        # every int8 at +127 / -127... (Q8_K maps the max to -128 -> iscale sign)
-    got = gpu_lib.amd_test_mmq2(t, raw, 1, n_in, n_out, x, generation=3)
-    got2 = gpu_lib.amd_test_mmq2(t, raw, 1, n_in, n_out, x, generation=2)
-    assert np.array_equal(got, got2)
+    got = gpu_lib.amd_test_mmq2(t, raw, 1, n_in, n_out, x)
     want = R.mul_mat(t, raw, n_in, n_out, x).reshape(N, 1, n_out).transpose(1, 0, 2)
     assert float(np.abs(got - want).max() / np.abs(want).max()) < 2e-5
