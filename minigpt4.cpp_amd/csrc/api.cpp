@@ -25,13 +25,26 @@ constexpr size_t kEmb7B = 32 * 4096, kEmb13B = 32 * 5120;
 inline Engine *E_(MiniGPT4Context *c) { return reinterpret_cast<Engine *>(c); }
 bool file_exists(const char *p) { struct stat st; return p && stat(p, &st) == 0; }
 
-// The HIP runtime keeps the last failed call of the thread as a sticky "last error" that the NEXT user of hipGetLastError sees -- e.g. the host application's own
-// launch checks (PyTorch raised "HIP error: invalid argument" on its first kernel after this library had ignored a refused hipFuncSetAttribute).  Every entry point
-// leaves that slot clean.
+// The HIP runtime keeps the last failed call of the thread as a sticky "last error" that the NEXT user of hipGetLastError sees.  Entry: whatever another HIP user of the
+// process (PyTorch next to this library) left there is not ours.  Exit: kernel launches have no return value -- a refused launch (bad configuration, too much LDS) only
+// shows up in that slot -- so a leftover error fails the call loudly instead of letting generation continue on stale activations, and the slot is left clean for the
+// host application's own launch checks (PyTorch once raised "HIP error: invalid argument" on its first kernel after this library had ignored a refused attribute hint;
+// ignorable calls now go through HIP_IGNORE, which clears the slot itself).
 struct ClearStickyHipError { ~ClearStickyHipError() { (void)hipGetLastError(); } };
 template <typename F> int guarded(int on_hip_error, F &&f) {
+    (void)hipGetLastError();
     ClearStickyHipError clear_on_exit;
-    try { return f(); }
+    try {
+        const int rc = f();
+        const hipError_t left = hipGetLastError();
+        // host-only entry points also run where there is no device: the runtime then answers every query with "no device" -- nothing was launched, nothing to report
+        if (left != hipSuccess && left != hipErrorNoDevice && left != hipErrorInsufficientDriver && left != hipErrorNotInitialized) {
+            char buf[256]; snprintf(buf, sizeof(buf), "HIP error %d (%s) left behind by a kernel launch", (int)left, hipGetErrorString(left));
+            set_last_error(buf); MG4_ERR("%s", buf);
+            return rc ? rc : on_hip_error;
+        }
+        return rc;
+    }
     catch (const HipError &e) {
         char buf[512]; snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d: %s", (int)e.code, hipGetErrorString(e.code), e.file, e.line, e.what);
         set_last_error(buf); MG4_ERR("%s", buf); return on_hip_error;
@@ -46,7 +59,7 @@ const char *kErrNames[] = {"None", "LoadModelFileHeader", "LoadModelFileVersion"
 }  // namespace
 
 namespace {
-struct DevBuf { void *p = nullptr; DevBuf(size_t n) { HIP_CHECK(hipMalloc(&p, n ? n : 1)); } ~DevBuf() { if (p) (void)hipFree(p); } template <typename T> T *as() { return static_cast<T *>(p); } };
+struct DevBuf { void *p = nullptr; DevBuf(size_t n) { HIP_CHECK(hipMalloc(&p, n ? n : 1)); } ~DevBuf() { if (p) HIP_IGNORE(hipFree(p)); } template <typename T> T *as() { return static_cast<T *>(p); } };
 void alloc_act(ActQ &A, std::vector<std::unique_ptr<DevBuf>> &keep, size_t N, size_t K) {
     auto mk = [&](size_t bytes) { keep.emplace_back(new DevBuf(bytes + 256)); return keep.back()->p; };
     A.q8k = (int8_t *)mk(N * K); A.q80 = (int8_t *)mk(N * K); A.dk = (float *)mk(N * (K / 256 + 1) * 4); A.bsk = (int16_t *)mk(N * (K / 16 + 1) * 2); A.bsq = (int8_t *)mk(N * (K / 16 + 16));
@@ -566,7 +579,7 @@ int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int 
         HIP_CHECK(hipEventRecord(b, nullptr));
         HIP_CHECK(hipDeviceSynchronize());
         float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b));
         if (us_per_launch) *us_per_launch = ms * 1e3f / (float)iters;
         if (bytes_per_launch) *bytes_per_launch = (double)gt_nbytes(ggml_type, (size_t)rows * cols) * n_mat;
         return 0;
@@ -616,7 +629,7 @@ int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, 
         HIP_CHECK(hipEventRecord(eb, nullptr));
         HIP_CHECK(hipDeviceSynchronize());
         float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ea, eb));
-        (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+        HIP_IGNORE(hipEventDestroy(ea)); HIP_IGNORE(hipEventDestroy(eb));
         unsetenv("MINIGPT4_MMQ2_KS");
         set_mmq_enabled(keep_gen);
         if (us_per_launch) *us_per_launch = ms * 1e3f / (float)iters;

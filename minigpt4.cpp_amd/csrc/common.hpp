@@ -40,6 +40,9 @@ void log_msg(int level, const char *tag, const char *fmt, ...) __attribute__((fo
 
 struct HipError { hipError_t code; const char *what; const char *file; int line; };
 #define HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) throw ::mg4::HipError{_e, #expr, __FILE__, __LINE__}; } while (0)
+// A call whose failure is acceptable (attribute hints, teardown): the runtime's sticky per-thread "last error" is cleared right away, so that whatever IS left in that
+// slot when an entry point returns comes from a kernel launch (which has no return value) and is reported (api.cpp: guarded()).
+#define HIP_IGNORE(expr) do { (void)(expr); (void)hipGetLastError(); } while (0)
 
 // ------------------------------------------------------------------------------------------------------------
 // Device-side views

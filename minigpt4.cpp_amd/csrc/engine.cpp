@@ -23,7 +23,7 @@ void DeviceArena::alloc(size_t bytes) {
     else HIP_CHECK(hipMalloc((void **)&base, bytes));
     cap = bytes; used = 0; layout_hash = 1469598103934665603ull;
 }
-void DeviceArena::release() { if (base && !virt) (void)hipFree(base); base = nullptr; cap = used = 0; }
+void DeviceArena::release() { if (base && !virt) HIP_IGNORE(hipFree(base)); base = nullptr; cap = used = 0; }
 uint8_t *DeviceArena::take(size_t bytes, size_t align) {
     const size_t off = (used + align - 1) / align * align;
     if (off + bytes > cap) throw HipError{hipErrorOutOfMemory, "arena overflow", __FILE__, __LINE__};
@@ -51,7 +51,7 @@ void preprocess_image_device(hipStream_t s, const uint8_t *rgb, int w, int h, fl
     };
     ResampleCoeffs ch, cv;
     table(w, ch); table(h, cv);
-    struct Dev { void *p = nullptr; ~Dev() { if (p) (void)hipFree(p); } };
+    struct Dev { void *p = nullptr; ~Dev() { if (p) HIP_IGNORE(hipFree(p)); } };
     Dev d_src, d_tmp, d_out, d_tab;
     const size_t src_bytes = (size_t)w * h * 3, tmp_bytes = (size_t)h * OUT * 3, out_bytes = (size_t)3 * OUT * OUT * 4;
     std::vector<int> tab;                                                      // [first_h | count_h | kk_h | first_v | count_v | kk_v]
@@ -69,20 +69,20 @@ void preprocess_image_device(hipStream_t s, const uint8_t *rgb, int w, int h, fl
 }
 
 void Engine::release_buffers() {
-    for (Conversation &c : conv_) { if (c.graph) (void)hipGraphExecDestroy(c.graph); c.graph = nullptr; }
-    for (hipGraphExec_t &g : batch_graph_) { if (g) (void)hipGraphExecDestroy(g); g = nullptr; }
-    if (h_argmax_) (void)hipHostFree(h_argmax_);
-    if (h_bstage_) (void)hipHostFree(h_bstage_);
-    if (h_logits_) (void)hipHostFree(h_logits_);
+    for (Conversation &c : conv_) { if (c.graph) HIP_IGNORE(hipGraphExecDestroy(c.graph)); c.graph = nullptr; }
+    for (hipGraphExec_t &g : batch_graph_) { if (g) HIP_IGNORE(hipGraphExecDestroy(g)); g = nullptr; }
+    if (h_argmax_) HIP_IGNORE(hipHostFree(h_argmax_));
+    if (h_bstage_) HIP_IGNORE(hipHostFree(h_bstage_));
+    if (h_logits_) HIP_IGNORE(hipHostFree(h_logits_));
     h_argmax_ = nullptr; h_bstage_ = nullptr; h_logits_ = nullptr; logits_host_slot_ = -1;
     buf_arena_.release();
 }
 Engine::~Engine() {
-    if (stream_) (void)hipStreamSynchronize(stream_);
-    for (auto &e : site_events_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    if (stage_) (void)hipFree(stage_);
+    if (stream_) HIP_IGNORE(hipStreamSynchronize(stream_));
+    for (auto &e : site_events_) { HIP_IGNORE(hipEventDestroy(e.a)); HIP_IGNORE(hipEventDestroy(e.b)); }
+    if (stage_) HIP_IGNORE(hipFree(stage_));
     release_buffers();
-    if (stream_) (void)hipStreamDestroy(stream_);
+    if (stream_) HIP_IGNORE(hipStreamDestroy(stream_));
 }
 void Engine::sync() { (void)flush(); HIP_CHECK(hipStreamSynchronize(stream_)); }
 
@@ -133,7 +133,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     auto t2 = std::chrono::steady_clock::now();
     MG4_INFO("Loading minigpt4 model took %lld ms to complete", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count());
     alloc_buffers();
-    if (stage_) { (void)hipFree(stage_); stage_ = nullptr; stage_cap_ = 0; }
+    if (stage_) { HIP_IGNORE(hipFree(stage_)); stage_ = nullptr; stage_cap_ = 0; }
     return E_None;
 }
 
@@ -803,7 +803,7 @@ int Engine::decode_loop(int steps, int *tokens_out, float *ms_total) {
     HIP_CHECK(hipStreamSynchronize(stream_));
     float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
     if (ms_total) *ms_total = ms;
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b));
     cv.n_past += steps - 1; cv.n_committed += steps - 1;
     if (logits_host_slot_ == cur_) logits_host_slot_ = -1;
     return 0;
@@ -841,10 +841,10 @@ int Engine::profile_sites(int steps, std::string &json) {
         const float pus = e.p1 > e.p0 ? launch_probe_us(e.p0, e.p1) : -1.0f;
         if (pus < 0.0f) agg[k].probed = false;
         agg[k].us += pus; agg[k].mus += ms * 1e3; agg[k].bytes += e.bytes; agg[k].calls++;
-        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+        HIP_IGNORE(hipEventDestroy(e.a)); HIP_IGNORE(hipEventDestroy(e.b));
     }
     site_events_.clear();
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b));
     char buf[768];
     json = "{\"steps\": " + std::to_string(steps) + ", \"eager_ms_per_step\": " + std::to_string(tot / steps) + ", \"sites\": [";
     for (size_t k = 0; k < agg.size(); k++) {
@@ -993,7 +993,7 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
     for (int b = 0; b < B; b++) HIP_CHECK(hipMemcpyAsync(out[b], vi_out_ + (size_t)b * NQ * v_out_, (size_t)NQ * v_out_ * 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     HIP_CHECK(hipEventElapsedTime(&last_encode_ms_, ea, eb));
-    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    HIP_IGNORE(hipEventDestroy(ea)); HIP_IGNORE(hipEventDestroy(eb));
     return E_None;
 }
 int Engine::encode_image(const float *chw, float *out) { return encode_images(&chw, 1, &out); }

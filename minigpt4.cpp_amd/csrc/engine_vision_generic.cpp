@@ -17,7 +17,7 @@ int Engine::load_vision_generic() {
     const uint8_t *fb = vis_.mf.data;
     size_t max_raw = 0;
     for (auto &m : vis_.models) for (auto &t : m.second) if (t.second.type != GT_F16 && t.second.type != GT_F32) max_raw = std::max(max_raw, t.second.nbytes);
-    struct Stage { void *p = nullptr; ~Stage() { if (p) (void)hipFree(p); } } stage;
+    struct Stage { void *p = nullptr; ~Stage() { if (p) HIP_IGNORE(hipFree(p)); } } stage;
     if (max_raw) HIP_CHECK(hipMalloc(&stage.p, max_raw));
     std::string bad; int bad_code = 0;
     auto lin = [&](const std::string &model, const std::string &name, int64_t n_in, int64_t n_out, GLin &L) {
@@ -151,7 +151,7 @@ int Engine::encode_images_generic(const float *const *chw, int B, float *const *
     for (int b = 0; b < B; b++) HIP_CHECK(hipMemcpyAsync(out[b], vi_out_ + (size_t)b * NQ * v_out_, (size_t)NQ * v_out_ * 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     HIP_CHECK(hipEventElapsedTime(&last_encode_ms_, ea, eb));
-    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    HIP_IGNORE(hipEventDestroy(ea)); HIP_IGNORE(hipEventDestroy(eb));
     return E_None;
 }
 

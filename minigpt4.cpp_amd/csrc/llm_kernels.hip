@@ -30,7 +30,7 @@ static std::vector<LaunchProbe> g_probes;      // one per noted launch since tra
 static size_t g_probe_next = 0;                // first probe not yet attached to a launch
 void kernel_name_tracing(bool on) {
     g_kname_on = on; g_kname[0] = 0;
-    if (on) { for (auto &p : g_probes) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); } g_probes.clear(); g_probe_next = 0; }
+    if (on) { for (auto &p : g_probes) { HIP_IGNORE(hipEventDestroy(p.start)); HIP_IGNORE(hipEventDestroy(p.stop)); } g_probes.clear(); g_probe_next = 0; }
 }
 void reset_kernel_name() { g_kname[0] = 0; }
 const char *last_kernel_name() { return g_kname; }
@@ -57,7 +57,7 @@ static inline void launch_k(void (*k)(KA...), dim3 g, dim3 b, size_t lds, hipStr
     if (g_kname_on && g_probe_next < g_probes.size()) {
         LaunchProbe &p = g_probes[g_probe_next++];
         std::tuple<KA...> tup{static_cast<KA>(args)...};
-        std::apply([&](auto &...e) { void *ptrs[] = {static_cast<void *>(&e)...}; (void)hipExtLaunchKernel(reinterpret_cast<const void *>(k), g, b, ptrs, lds, s, p.start, p.stop, 0); }, tup);
+        std::apply([&](auto &...e) { void *ptrs[] = {static_cast<void *>(&e)...}; HIP_IGNORE(hipExtLaunchKernel(reinterpret_cast<const void *>(k), g, b, ptrs, lds, s, p.start, p.stop, 0)); }, tup);
         return;
     }
     k<<<g, b, lds, s>>>(args...);
@@ -1057,7 +1057,7 @@ static void launch_tn_n(const MatSet &ms, const ActQ &A, int N, int ldy, hipStre
             note_kernel("k_matvec_tn<%d, %d, %d, 1>", T, NU, TN);
             const int img = (int)mv_tn_image_bytes(ms.w0.cols);
             static bool attr1 = false;
-            if (!attr1) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+            if (!attr1) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr1 = true; }
             hipLaunchKernelGGL((k_matvec_tn<T, NU, TN, 1>), dim3((unsigned)n_blocks), dim3((unsigned)mv_tn_threads<NU>()), (size_t)512 + (size_t)TN * img, s, ms, A, N, ldy, n_groups, n_waves, pa, ldx, img);
             return;
         }
@@ -1065,7 +1065,7 @@ static void launch_tn_n(const MatSet &ms, const ActQ &A, int N, int ldy, hipStre
     note_kernel("k_matvec_tn<%d, %d, %d, 0>", T, NU, TN);
     const size_t lds = NU <= 3 ? 0 : mv_tn_lds(T, ms.w0.cols, TN);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     hipLaunchKernelGGL((k_matvec_tn<T, NU, TN, 0>), dim3((unsigned)n_blocks), dim3((unsigned)mv_tn_threads<NU>()), lds, s, ms, A, N, ldy, n_groups, n_waves, pa, 0, 0);
 }
 template <int T, int NU>
@@ -1467,8 +1467,8 @@ static void launch_attn_hd(float *q, const float *k, const float *v, __half *kc,
     const int Tpad = (n_ctx + 7) & ~7;
     const size_t lds = (size_t)Tpad * 6 + (size_t)HD * 6 + (size_t)(AT_THREADS / (HD / 8)) * HD * 4 + 64;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                 HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     note_kernel("k_attn_llm<%d, %s, false>", HD, fused ? "true" : "false");
     if (fused) hipLaunchKernelGGL((k_attn_llm<HD, true>), dim3((unsigned)n_head, 1), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out, (const int *)nullptr, (size_t)0);
     else hipLaunchKernelGGL((k_attn_llm<HD, false>), dim3((unsigned)n_head, (unsigned)N), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out, (const int *)nullptr, (size_t)0);
@@ -1479,7 +1479,7 @@ static void launch_attn_batched_hd(float *q, const float *k, const float *v, __h
     const int Tpad = (n_ctx + 7) & ~7;
     const size_t lds = (size_t)Tpad * 6 + (size_t)HD * 6 + (size_t)(AT_THREADS / (HD / 8)) * HD * 4 + 64;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     hipLaunchKernelGGL((k_attn_llm<HD, true, true>), dim3((unsigned)n_head, (unsigned)B), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out, row_slot,
                        seq_stride);
 }
@@ -1612,7 +1612,7 @@ static bool launch_attn_prefill_hd(const float *q, const __half *kc, const __hal
     const size_t lds = ((size_t)AP_QT * LS + (size_t)AP_KT * (HD + 1)) * 4;
     if (lds > 160 * 1024 - 512) return false;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     hipLaunchKernelGGL((k_attn_prefill<HD>), dim3((unsigned)n_head, (unsigned)((N + AP_QT - 1) / AP_QT)), dim3(256), lds, s, q, kc, vc, n_head * HD, N, n_past, tb, out, LS);
     return true;
 }
@@ -1695,7 +1695,7 @@ uint64_t device_checksum(const void *p, size_t bytes, hipStream_t s) {
     hipLaunchKernelGGL(k_checksum, dim3(2048), dim3(256), 0, s, static_cast<const unsigned *>(p), bytes / 4, d);
     HIP_CHECK(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
-    (void)hipFree(d);
+    HIP_IGNORE(hipFree(d));
     return (uint64_t)h;
 }
 __global__ void k_fill_u16(unsigned short *p, size_t n, unsigned short v) {
@@ -1741,7 +1741,7 @@ float probe_grid_barrier_us(int n_blocks, int iters, unsigned *errors_out) {
     float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
     unsigned err = 0; HIP_CHECK(hipMemcpy(&err, d + 1, 4, hipMemcpyDeviceToHost));
     if (errors_out) *errors_out = err;
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipFree(d);
+    HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b)); HIP_IGNORE(hipFree(d));
     return ms * 1e3f / (float)(2 * iters);
 }
 __global__ void k_set_int(int *p, int v) { *p = v; }

@@ -442,7 +442,7 @@ void set_mmq2_cus(int cus) { if (cus > 0) g_mmq2_cus = cus; }
 
 template <typename KernelT>
 static void mmq2_launch_kernel(KernelT kernel, bool &attr_done, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_done = true; }
+    if (!attr_done) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr_done = true; }
     hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a, A);
 }
 template <int TT>

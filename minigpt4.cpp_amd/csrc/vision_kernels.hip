@@ -128,10 +128,10 @@ static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, in
     dim3 grid((unsigned)((ntx + 7) / 8 * 8 * rt), 1, (unsigned)slices), block(BM / 32 * BN / 32 * 64);
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 8) * 2;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
     else if (gelu) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
     else if (residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
@@ -240,10 +240,10 @@ static bool launch_gemm_big(const __half *A, int lda, const __half *W, int ldw, 
                             float *out, __half *out_h, int ldo, hipStream_t s) {
     static bool init = false;
     if (!init) { if (const char *e = getenv("MINIGPT4_GEMM_BIG_M")) g_gemm_big_min_m = atoi(e); init = true;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); }
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); }
     if (g_gemm_big_min_m <= 0 || M < g_gemm_big_min_m || K % 64 || K < 64 || lda % 8 || ldw % 8 || (reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) % 16) return false;
     const int ntx = (N + 127) / 128, rt = (M + 127) / 128;
     const dim3 grid((unsigned)((ntx + 7) / 8 * 8 * rt)), block(256);
@@ -577,11 +577,11 @@ void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, in
                      const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s, int batch) {
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_f32<88>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_f32<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<88, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<64, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_f32<88>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_f32<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<88, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<64, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     if (hd != 88 && hd != 64) throw HipError{hipErrorInvalidValue, "attn_f32: head size must be 88 or 64", __FILE__, __LINE__};
