@@ -403,9 +403,17 @@ int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t 
         const QWeight *Wp[3]; float *Yp[3]; const float *Rp[3];
         for (int i = 0; i < n_mat; i++) { Wp[i] = &W[i]; Yp[i] = d_y.as<float>() + (size_t)i * out_each; Rp[i] = d_res.as<float>() + (size_t)i * out_each; }
         A.ws = d_ws.as<float>(); A.ws_floats = out_each * n_mat * 16;
-        if (ks > 0) setenv("MINIGPT4_MMQ2_KS", std::to_string(ks).c_str(), 1);
-        const bool ok = launch_mmq2_set(Wp, Yp, residual ? Rp : nullptr, n_mat, A, (int)N, (int)n_out, nullptr);
-        unsetenv("MINIGPT4_MMQ2_KS");
+        bool ok;
+        if (ggml_type == GT_F16) {   // the F16 language-model set path (big MFMA GEMM, several matrices per launch / split K)
+            const __half *Wh[3]; for (int i = 0; i < n_mat; i++) Wh[i] = reinterpret_cast<const __half *>(W[i].qs);
+            if (ks > 0) setenv("MINIGPT4_F16_KS", std::to_string(ks).c_str(), 1);
+            ok = launch_gemm_f16_set(A.xh, (int)n_in, Wh, n_mat, (int)N, (int)n_out, (int)n_in, Yp, residual ? Rp : nullptr, (int)n_out, A.ws, A.ws_floats, 256, nullptr);
+            unsetenv("MINIGPT4_F16_KS");
+        } else {
+            if (ks > 0) setenv("MINIGPT4_MMQ2_KS", std::to_string(ks).c_str(), 1);
+            ok = launch_mmq2_set(Wp, Yp, residual ? Rp : nullptr, n_mat, A, (int)N, (int)n_out, nullptr);
+            unsetenv("MINIGPT4_MMQ2_KS");
+        }
         HIP_CHECK(hipDeviceSynchronize());
         if (!ok) return 4;
         HIP_CHECK(hipMemcpy(y, d_y.p, out_each * n_mat * 4, hipMemcpyDeviceToHost));

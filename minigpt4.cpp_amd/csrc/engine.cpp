@@ -121,6 +121,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (getenv("MINIGPT4_BATCH_ROWS_MAX")) batch_rows_max_ = atoi(getenv("MINIGPT4_BATCH_ROWS_MAX"));
     batch_fuse_ = getenv("MINIGPT4_BATCH_FUSE") ? (atoi(getenv("MINIGPT4_BATCH_FUSE")) != 0) : -1;   // -1: by batch size (see forward_batch)
     if (const char *sk = getenv("MINIGPT4_SPLITK")) { sscanf(sk, "%d,%d", &splitk_proj_, &splitk_fc2_); splitk_proj_ = std::max(1, std::min(SPLITK_MAX, splitk_proj_)); splitk_fc2_ = std::max(1, std::min(SPLITK_MAX, splitk_fc2_)); }
+    n_cus_ = prop.multiProcessorCount;
     set_matvec_tuning(getenv("MINIGPT4_MV_WAVES") ? atoi(getenv("MINIGPT4_MV_WAVES")) : 0, getenv("MINIGPT4_FAT_LB") ? atoi(getenv("MINIGPT4_FAT_LB")) : 0, prop.multiProcessorCount);
     if (const char *ns = getenv("MINIGPT4_CONVERSATIONS")) conv_.assign((size_t)std::max(1, std::min(MAX_CONVERSATIONS, atoi(ns))), Conversation{});
     sampler_.seed(seed);
@@ -526,6 +527,10 @@ bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
     SiteScope sc(this, site, wbytes, s);
     bool done = false;
     if (N >= 5 && same && mmq_enabled() >= 2) done = launch_mmq2_set(W, y, res, n, act_, N, ldy, s);   // prefill: one launch for the set, weights streamed once per <= 128 rows
+    if (!done && same && W[0]->type == GT_F16 && N >= 512 && act_.xh) {   // unquantised weights at prompt sizes: the set in one launch of the big MFMA GEMM, split K for wo / w2
+        const __half *Wh[3]; for (int i = 0; i < n; i++) Wh[i] = reinterpret_cast<const __half *>(W[i]->qs);
+        done = launch_gemm_f16_set(act_.xh, W[0]->cols, Wh, n, N, W[0]->rows, W[0]->cols, y, res, ldy, act_.ws, act_.ws_floats, n_cus_, s);
+    }
     if (!done && silu_pair) {   // the pair epilogue needs the two matrices equally spaced; launch_matvec_set refuses otherwise and the plain launch below runs
         done = fuse ? launch_matvec_set(W, y, res, n, act_, s, prep->kind, prep->x, prep->w, &tabs_, 1) : launch_matvec_set(W, y, res, n, act_, s, 0, nullptr, nullptr, &tabs_, 1);
         silu_pair = done;

@@ -36,6 +36,11 @@ int mmq_enabled();
 bool mmq2_supported(int type, int rows, int cols);
 bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s);
 void set_mmq2_cus(int cus);
+void launch_slab_reduce(const float *slabs, int n_slabs, long long slab_stride, const float *residual, float *y, size_t n, hipStream_t s);   // y = (residual +) sum_z slab_z, fixed order
+// F16 weights at prompt sizes: 1..3 equally spaced [N][K] matrices x M fp16 rows in one launch of the 128x128 LDS-DMA GEMM (split K when the tiles do not fill the chip);
+// false -> outside this path, nothing launched
+bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n, int M, int N, int K, float *const *y, const float *const *residual, int ldo, float *ws,
+                         size_t ws_floats, int cus, hipStream_t s);
 void set_mmq_generation(int g);   // Q4_K / Q5_K prefill kernel: 2 = k_mmq2_q45k, 3 (default) = k_mmq3_q45k (scales folded into the int8 operands); results are bit-identical
 int mmq_generation();   // CU count the K-split heuristic aims at (the K-split partial sums live in ActQ::ws, owned by whoever owns the activation planes)
 

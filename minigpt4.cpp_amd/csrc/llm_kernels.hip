@@ -1318,7 +1318,6 @@ void launch_rope_kv(float *q, const float *k, const float *v, int N, int n_head,
 //   PV     : thread = (key partition, 8-dim chunk): 16-byte V loads, 4 in flight; partitions reduced through LDS
 // =====================================================================================================================
 constexpr int AT_THREADS = 512;
-constexpr int ATTN_ETAB_N = 20480;    // fp16 entries of the exp table k_attn_llm keeps in LDS (codes 0x8000 ..: arguments -0 ... -17.5; Tables::exp_neg_n with this image's libm); the rest is read from the global table
 //   BATCHED (decode of several conversations in one pass; implies FUSED): row t belongs to conversation row_slot[t], whose position is
 //            n_past[row_slot[t]] and whose caches start seq_stride * row_slot[t] elements behind kc / vc.
 template <int HD, bool FUSED, bool BATCHED = false>
@@ -1339,45 +1338,21 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
     __half *ph = reinterpret_cast<__half *>(sc + Tpad);           // [Tpad]
     __half *qh = ph + Tpad;                                       // [HD]
     __half *knew = qh + HD, *vnew = knew + HD;                    // [HD] each
+    float *part = reinterpret_cast<float *>(vnew + HD);           // [P][HD]
     __shared__ float s_red[AT_THREADS / 64];
     __shared__ double s_dred[AT_THREADS / 64];
     const float scale = 1.0f / sqrtf((float)HD);
     const size_t qo = (size_t)t * E + (size_t)h * HD;
-    // Request order = return order: (1) the live part of the fp16 exp table into LDS (LDS-DMA: softmax arguments are <= 0, tb.exp_neg_n entries from code 0x8000 --
-    // the round-1 form gathered from the global table after the max reduction, one more dependent round trip), (2) this step's q / k / v / cos / sin (unconditional,
-    // clamped lane index: a load under an exec mask would turn the counted waits into vmcnt(0)), (3) the cached K and V rows of the first NPRE * P positions --
-    // they depend only on the position, so they travel while the RoPE prologue runs instead of after its barrier.
-    float *part = reinterpret_cast<float *>(vnew + HD);           // [P][HD]
-    __half *etab = reinterpret_cast<__half *>(part + P * HD);     // [tb.exp_neg_n]
-    static_assert(ATTN_ETAB_N % (AT_THREADS * 8) == 0, "whole DMA rounds");
-    const unsigned NT = tb.exp_neg_n >= ATTN_ETAB_N ? (unsigned)ATTN_ETAB_N : 0u;   // a shorter live part (another libm) would leave stale LDS behind the table: then every lookup goes to the global table
-    for (unsigned c0 = 0; c0 < NT; c0 += AT_THREADS * 8)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tb.exp + 0x8000 + c0 + tid * 8),
-                                             (__attribute__((address_space(3))) void *)(reinterpret_cast<unsigned char *>(etab) + (c0 + (tid >> 6) * 512) * 2), 16, 0, 0);
-    float r_c = 0.0f, r_s = 0.0f, r_q0 = 0.0f, r_q1 = 0.0f, r_k0 = 0.0f, r_k1 = 0.0f, r_v0 = 0.0f, r_v1 = 0.0f;
-    if (FUSED) {
-        const int i = min(tid, HD / 2 - 1);
-        r_c = cos_tab[(size_t)pos * (HD / 2) + i]; r_s = sin_tab[(size_t)pos * (HD / 2) + i];
-        const float2 q2 = *reinterpret_cast<const float2 *>(q + qo + 2 * i), k2 = *reinterpret_cast<const float2 *>(kin + qo + 2 * i), v2 = *reinterpret_cast<const float2 *>(vin + qo + 2 * i);
-        r_q0 = q2.x; r_q1 = q2.y; r_k0 = k2.x; r_k1 = k2.y; r_v0 = v2.x; r_v1 = v2.y;
-    }
-    const int c = tid % CH, p = tid / CH;
-    const __half *kb = kc + (size_t)h * HD + 8 * c, *vb = vc + (size_t)h * HD + 8 * c;
-    constexpr int NPRE = 16;                        // x P = 32 key partitions: contexts up to 512 need no second round trip
-    int4 kpre[NPRE], vpre[NPRE];
-#pragma unroll
-    for (int i = 0; i < NPRE; i++) kpre[i] = ld16(kb + (size_t)min(p + i * P, max(Tg - 1, 0)) * E);   // clamped: never branches, never out of the cache
-#pragma unroll
-    for (int i = 0; i < NPRE; i++) vpre[i] = ld16(vb + (size_t)min(p + i * P, max(Tg - 1, 0)) * E);
-    __half2 kr_keep = __floats2half2_rn(0.0f, 0.0f), vr_keep = kr_keep;
     if (FUSED) {
         if (tid < HD / 2) {
             const int i = tid;
-            const __half2 qr = __floats2half2_rn(r_q0 * r_c - r_q1 * r_s, r_q0 * r_s + r_q1 * r_c), kr = __floats2half2_rn(r_k0 * r_c - r_k1 * r_s, r_k0 * r_s + r_k1 * r_c);
-            const __half2 vr = __floats2half2_rn(r_v0, r_v1);
+            const float c = cos_tab[(size_t)pos * (HD / 2) + i], s = sin_tab[(size_t)pos * (HD / 2) + i];
+            const float q0 = q[qo + 2 * i], q1 = q[qo + 2 * i + 1], k0 = kin[qo + 2 * i], k1 = kin[qo + 2 * i + 1];
+            const __half2 qr = __floats2half2_rn(q0 * c - q1 * s, q0 * s + q1 * c), kr = __floats2half2_rn(k0 * c - k1 * s, k0 * s + k1 * c);
+            const __half2 vr = __floats2half2_rn(vin[qo + 2 * i], vin[qo + 2 * i + 1]);
             *reinterpret_cast<__half2 *>(qh + 2 * i) = qr; *reinterpret_cast<__half2 *>(knew + 2 * i) = kr; *reinterpret_cast<__half2 *>(vnew + 2 * i) = vr;
-            kr_keep = kr; vr_keep = vr;          // appended to the caches at the END of the kernel: a global store before a workgroup barrier makes the barrier's fence
-                                                 // wait for every load in flight (the prefetch above)
+            const size_t co = (size_t)pos * E + (size_t)h * HD + 2 * i;
+            *reinterpret_cast<__half2 *>(kc + co) = kr; *reinterpret_cast<__half2 *>(vc + co) = vr;
         }
     } else {
         for (int i = tid; i < HD; i += AT_THREADS) qh[i] = __float2half_rn(q[qo + i]);
@@ -1399,9 +1374,21 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
         }
         return s * scale;
     };
+    // (Measured and not adopted, profiles/r02m_bench_n1.json vs r02k: requesting these K / V rows at kernel entry, before the RoPE prologue and its barrier, with the exp
+    // table's live part in LDS and the KV append moved behind the last barrier -- 11.7 us per launch at a context of 430 against 10.9 us for this form; beside LDS-DMA
+    // hipcc waits vmcnt(0) for every ordinary load, so the prologue sat out the whole prefetch.)
     // Scores of the cached keys: 16 consecutive lanes share one key row (lane c holds its dims 8 c .. 8 c + 7 -- one 256-byte row per 16 lanes, four whole rows per
     // wave instruction; the round-1 form, a whole row per lane, asked the address path for 64 different cache lines per instruction and grew by ~0.025 us per key), the
-    // 8-dim partial dots are added across the 16 lanes with DPP.
+    // 8-dim partial dots are added across the 16 lanes with DPP.  Key and value rows of the same (lane, round) sit at the same offset of the two caches, and neither
+    // depends on this step's scores: both are requested here, NPRE rounds deep, so they arrive during the dot products / the softmax.
+    const int c = tid % CH, p = tid / CH;
+    const __half *kb = kc + (size_t)h * HD + 8 * c, *vb = vc + (size_t)h * HD + 8 * c;
+    constexpr int NPRE = 16;                        // x P = 32 key partitions: contexts up to 512 need no second round trip
+    int4 kpre[NPRE], vpre[NPRE];
+#pragma unroll
+    for (int i = 0; i < NPRE; i++) kpre[i] = ld16(kb + (size_t)min(p + i * P, max(Tg - 1, 0)) * E);   // clamped: never branches, never out of the cache
+#pragma unroll
+    for (int i = 0; i < NPRE; i++) vpre[i] = ld16(vb + (size_t)min(p + i * P, max(Tg - 1, 0)) * E);
     float qd[8];
     {
         const int4 q4 = *reinterpret_cast<const int4 *>(qh + 8 * c);
@@ -1432,20 +1419,12 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
     if (FUSED && tid == AT_THREADS - 1) { const float s = dot_row(knew); sc[pos] = s; mx = fmaxf(mx, s); }
     mx = wave_max(mx);
     if ((tid & 63) == 0) s_red[tid >> 6] = mx;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's share of the exp-table DMA (requested first, returned first) has landed
     __syncthreads();
     mx = s_red[0];
 #pragma unroll
     for (int i = 1; i < AT_THREADS / 64; i++) mx = fmaxf(mx, s_red[i]);
     double sum = 0.0;
-    for (int j = tid; j < T; j += AT_THREADS) {
-        const unsigned code = f2h_bits(sc[j] - mx), idx = code ^ 0x8000u;
-        float v;
-        if (idx < NT) v = __half2float(etab[idx]);
-        else if (code == 0u) v = 1.0f;                                      // the maximum itself: table[+0] = fp16(expf(0))
-        else v = __half2float(tb.exp[code]);                                // outside the LDS part (underflowed to 0 there, or NaN): the global table's own entry
-        sc[j] = v; sum += (double)v;
-    }
+    for (int j = tid; j < T; j += AT_THREADS) { const float v = tab(tb.exp, sc[j] - mx); sc[j] = v; sum += (double)v; }
     sum = wave_sum_d(sum);
     if ((tid & 63) == 0) s_dred[tid >> 6] = sum;
     __syncthreads();
@@ -1483,17 +1462,13 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
 #pragma unroll 8
         for (int pp = 0; pp < P; pp++) s += part[pp * HD + i];
         out[qo + i] = s; }
-    if (FUSED && tid < HD / 2) {                                             // KV append (see the prologue)
-        const size_t co = (size_t)pos * E + (size_t)h * HD + 2 * tid;
-        *reinterpret_cast<__half2 *>(kc + co) = kr_keep; *reinterpret_cast<__half2 *>(vc + co) = vr_keep;
-    }
 }
 
 template <int HD>
 static void launch_attn_hd(float *q, const float *k, const float *v, __half *kc, __half *vc, int N, int n_head, const int *n_past, int n_ctx, const float *cos_tab,
                            const float *sin_tab, const Tables &tb, float *out, bool fused, hipStream_t s) {
     const int Tpad = (n_ctx + 7) & ~7;
-    const size_t lds = (size_t)Tpad * 6 + (size_t)HD * 6 + (size_t)(AT_THREADS / (HD / 8)) * HD * 4 + 64 + (size_t)ATTN_ETAB_N * 2;
+    const size_t lds = (size_t)Tpad * 6 + (size_t)HD * 6 + (size_t)(AT_THREADS / (HD / 8)) * HD * 4 + 64;
     static bool attr = false;
     if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                  HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
@@ -1505,7 +1480,7 @@ template <int HD>
 static void launch_attn_batched_hd(float *q, const float *k, const float *v, __half *kc, __half *vc, int B, int n_head, const int *n_past, const int *row_slot, size_t seq_stride,
                                    int n_ctx, const float *cos_tab, const float *sin_tab, const Tables &tb, float *out, hipStream_t s) {
     const int Tpad = (n_ctx + 7) & ~7;
-    const size_t lds = (size_t)Tpad * 6 + (size_t)HD * 6 + (size_t)(AT_THREADS / (HD / 8)) * HD * 4 + 64 + (size_t)ATTN_ETAB_N * 2;
+    const size_t lds = (size_t)Tpad * 6 + (size_t)HD * 6 + (size_t)(AT_THREADS / (HD / 8)) * HD * 4 + 64;
     static bool attr = false;
     if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     hipLaunchKernelGGL((k_attn_llm<HD, true, true>), dim3((unsigned)n_head, (unsigned)B), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out, row_slot,
@@ -1655,7 +1630,7 @@ bool launch_attn_prefill(const float *q, const __half *kcache, const __half *vca
     }
 }
 bool attn_head_size_supported(int hd) { return hd == 32 || hd == 64 || hd == 128; }
-static size_t attn_lds_bytes(int n_ctx, int hd) { const int Tpad = (n_ctx + 7) & ~7; return (size_t)Tpad * 6 + (size_t)hd * 6 + (size_t)(AT_THREADS / (hd / 8)) * hd * 4 + 64 + (size_t)ATTN_ETAB_N * 2; }
+static size_t attn_lds_bytes(int n_ctx, int hd) { const int Tpad = (n_ctx + 7) & ~7; return (size_t)Tpad * 6 + (size_t)hd * 6 + (size_t)(AT_THREADS / (hd / 8)) * hd * 4 + 64; }
 int attn_max_ctx(int hd) { int n = 0; while (attn_lds_bytes(n + 8, hd) + 256 /* static reduction arrays */ <= 160 * 1024) n += 8; return n; }
 // fused = true (N must be 1): q,k,v are the raw projections; RoPE + KV append happen inside.  fused = false: launch_rope_kv must have run.
 void launch_attn_llm(float *q, const float *k, const float *v, __half *kcache, __half *vcache, int N, int n_head, int hd, const int *n_past, int n_ctx,

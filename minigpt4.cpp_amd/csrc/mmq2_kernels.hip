@@ -435,6 +435,12 @@ __global__ __launch_bounds__(256) void k_mmq2_reduce(const float *__restrict__ s
     reinterpret_cast<float4 *>(y)[i] = s;
 }
 
+// y = (residual +) sum_z slab_z in fixed order, n floats (a multiple of 4) per slab: also the combine step of the split-K F16 GEMM (vision_kernels.hip)
+void launch_slab_reduce(const float *slabs, int n_slabs, long long slab_stride, const float *residual, float *y, size_t n, hipStream_t s) {
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(k_mmq2_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, slabs, n_slabs, slab_stride, residual, y, n4);
+}
+
 bool mmq2_supported(int type, int rows, int cols) { return (type == GT_Q4_K || type == GT_Q5_K || type == GT_Q6_K) && cols % 256 == 0 && rows >= 32; }
 
 static int g_mmq2_cus = 256;

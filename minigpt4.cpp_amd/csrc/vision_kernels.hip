@@ -147,9 +147,10 @@ static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, in
 // =====================================================================================================================
 typedef __attribute__((address_space(3))) void *g_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *g_glb_ptr_t;
+struct GemmSet { int n_per_mat; long long w_mat_stride, out_mat_stride; int k_per_slice; long long slab_stride; };   // all zero: one matrix, whole K
 template <bool GELU, bool RES>
 __global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K, const float *__restrict__ bias,
-                                                         const float *residual, const Tables tb, float *out, __half *__restrict__ out_h, int ldo) {
+                                                         const float *residual, const Tables tb, float *out, __half *__restrict__ out_h, int ldo, const GemmSet gs) {
     constexpr int BM = 128, BN = 128, BK = 64, TILE = BM * BK * 2;       // 16 KiB per operand tile
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_gb[];   // [2 buffers][A tile | W tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,7 +158,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restric
     const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
     const int bslot = blockIdx.x >> 3, bx = (bslot / rt) * 8 + (blockIdx.x & 7), by = bslot % rt;
     if (bx >= ntx) return;
-    const int m0 = by * BM, n0 = bx * BN;
+    const int m0 = by * BM;
+    int n0 = bx * BN;
+    // several equally spaced, equally shaped weight matrices in one launch (the F16 language model's wq|wk|wv and w1|w3: one launch with 3x / 2x the workgroups instead
+    // of launches that fill 160 of 256 CUs): column tile -> (matrix, local column); N becomes the matrix's own column count
+    if (gs.n_per_mat > 0) {
+        const int mat = n0 / gs.n_per_mat;
+        n0 -= mat * gs.n_per_mat; N = gs.n_per_mat;
+        W += (size_t)mat * gs.w_mat_stride;
+        if (out) out += (size_t)mat * gs.out_mat_stride;
+        if (RES) residual += (size_t)mat * gs.out_mat_stride;
+    }
+    // split K (grid.y slices, each writes raw partial sums into its own slab; combined in fixed order by launch_slab_reduce): wo / w2 have 160 column x row tiles
+    int k_begin = 0, k_end = K;
+    if (gs.k_per_slice > 0) { k_begin = blockIdx.y * gs.k_per_slice; k_end = min(K, k_begin + gs.k_per_slice); if (out) out += (size_t)blockIdx.y * gs.slab_stride; }
     const int wm = wave >> 1, wn = wave & 1;
     // DMA sources: instruction j (0..15) of a tile covers rows 8 j .. 8 j + 7; wave w issues j = 4 w .. 4 w + 3 for each operand.  lane -> (row = 8 j + lane / 8, slot = lane % 8),
     // source chunk = slot ^ ((row >> 1) & 7)
@@ -165,8 +179,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restric
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int row = 8 * (4 * wave + u) + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
-        asrc[u] = A + (size_t)min(m0 + row, M - 1) * lda + 8 * c;
-        wsrc[u] = W + (size_t)min(n0 + row, N - 1) * ldw + 8 * c;
+        asrc[u] = A + (size_t)min(m0 + row, M - 1) * lda + 8 * c + k_begin;
+        wsrc[u] = W + (size_t)min(n0 + row, N - 1) * ldw + 8 * c + k_begin;
     }
     auto stage = [&](int kt, int buf) {
         unsigned char *base = smem_gb + buf * 2 * TILE;
@@ -188,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restric
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-    const int nk = K / BK;
+    const int nk = (k_end - k_begin) / BK;
     stage(0, 0);
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restric
 }
 static int g_gemm_big_min_m = 512;   // MINIGPT4_GEMM_BIG_M: smallest M that takes the 128x128 kernel (0 = never)
 static bool launch_gemm_big(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
-                            float *out, __half *out_h, int ldo, hipStream_t s) {
+                            float *out, __half *out_h, int ldo, hipStream_t s, const GemmSet gs = GemmSet{0, 0, 0, 0, 0}, int slices = 1) {
     static bool init = false;
     if (!init) { if (const char *e = getenv("MINIGPT4_GEMM_BIG_M")) g_gemm_big_min_m = atoi(e); init = true;
         HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -246,13 +260,42 @@ static bool launch_gemm_big(const __half *A, int lda, const __half *W, int ldw, 
         HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); }
     if (g_gemm_big_min_m <= 0 || M < g_gemm_big_min_m || K % 64 || K < 64 || lda % 8 || ldw % 8 || (reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) % 16) return false;
     const int ntx = (N + 127) / 128, rt = (M + 127) / 128;
-    const dim3 grid((unsigned)((ntx + 7) / 8 * 8 * rt)), block(256);
+    const dim3 grid((unsigned)((ntx + 7) / 8 * 8 * rt), (unsigned)slices), block(256);
     const size_t lds = 64 * 1024;
-    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16_big<true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
-    else if (gelu) hipLaunchKernelGGL((k_gemm_f16_big<true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
-    else if (residual) hipLaunchKernelGGL((k_gemm_f16_big<false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
-    else hipLaunchKernelGGL((k_gemm_f16_big<false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16_big<true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
+    else if (gelu) hipLaunchKernelGGL((k_gemm_f16_big<true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
+    else if (residual) hipLaunchKernelGGL((k_gemm_f16_big<false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
+    else hipLaunchKernelGGL((k_gemm_f16_big<false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
     return true;
+}
+
+// F16 language-model weights at prompt sizes (M >= the big kernel's threshold): n = 1..3 equally spaced, equally shaped matrices [N][K] against the M fp16 rows of A in
+// ONE launch; y[m] are [M][ldo] fp32 (+ residual[m]).  With fewer column x row tiles than 2 per CU the K range is split (partial slabs in `ws`, combined in fixed
+// order by launch_slab_reduce).  false: shape outside this path (nothing launched) -- the caller multiplies matrix by matrix.
+bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n, int M, int N, int K, float *const *y, const float *const *residual, int ldo, float *ws,
+                         size_t ws_floats, int cus, hipStream_t s) {
+    if (n < 1 || n > 3 || N % 128 || K % 64) return false;
+    const long long wstride = n > 1 ? W[1] - W[0] : 0, ystride = n > 1 ? y[1] - y[0] : 0;
+    for (int i = 2; i < n; i++) if (W[i] - W[i - 1] != wstride || y[i] - y[i - 1] != ystride) return false;
+    if (n > 1 && (wstride <= 0 || ystride <= 0)) return false;
+    if (residual) for (int i = 0; i < n; i++) if (!residual[i] || residual[i] - residual[0] != (long long)i * ystride) return false;
+    Tables tb{};
+    const int tiles = ((M + 127) / 128) * (n * N / 128);
+    int ks = 1;
+    const size_t out_floats = (size_t)M * ldo;
+    while (tiles * ks < 2 * cus && (K / 64) / (ks + 1) >= 16 && ws && (size_t)(ks + 1) * out_floats * n <= ws_floats && ks < 4) ks++;
+    if (const char *e = getenv("MINIGPT4_F16_KS")) ks = std::max(1, std::min(atoi(e), 8));
+    if (ks > 1 && (!ws || (size_t)ks * out_floats * n > ws_floats || n > 1 || out_floats % 4)) ks = 1;   // split launches are single-matrix (wo, w2): the sets have tiles enough
+    GemmSet gs{n > 1 ? N : 0, wstride, ystride, 0, 0};
+    if (ks > 1) {
+        const int kt = K / 64, per = (kt + ks - 1) / ks;
+        gs.k_per_slice = per * 64; gs.slab_stride = (long long)out_floats;
+        ks = (kt + per - 1) / per;
+        if (!launch_gemm_big(A, lda, W[0], K, M, N, K, nullptr, nullptr, false, tb, ws, nullptr, ldo, s, gs, ks)) return false;
+        launch_slab_reduce(ws, ks, (long long)out_floats, residual ? residual[0] : nullptr, y[0], out_floats, s);
+        return true;
+    }
+    return launch_gemm_big(A, lda, W[0], K, M, n * N, K, nullptr, residual ? residual[0] : nullptr, false, tb, y[0], nullptr, ldo, s, gs, 1);
 }
 
 // Tile shape experiments at M = 257 (profiles/r01i_ab_encode.log): 128x64 (8 waves) and 128x128 (16 waves) tiles halve the bytes moved per flop but are

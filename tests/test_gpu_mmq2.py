@@ -74,3 +74,32 @@ def test_mmq2_extreme_values_stay_exact(gpu_lib, wtype):
     got = gpu_lib.amd_test_mmq2(t, raw, 1, n_in, n_out, x)
     want = R.mul_mat(t, raw, n_in, n_out, x).reshape(N, 1, n_out).transpose(1, 0, 2)
     assert float(np.abs(got - want).max() / np.abs(want).max()) < 2e-5
+
+
+F16_CASES = [
+    # N, n_in, n_out, n_mat, ks, residual -- the F16 language-model set path needs >= 512 rows, n_out % 128 == 0, n_in % 64 == 0
+    (512, 512, 256, 3, 0, False),        # wq|wk|wv in one launch
+    (512, 1024, 384, 2, 0, False),       # w1|w3
+    (640, 2048, 128, 1, 2, True),        # split K with residual (wo / w2), ragged last row tile
+    (512, 4096, 256, 1, 3, True),
+    (515, 512, 128, 1, 0, True),         # no split, residual in the epilogue, ragged rows
+]
+
+
+@pytest.mark.parametrize("case", F16_CASES, ids=lambda c: "N%d_K%d_R%d_m%d_ks%d_res%d" % c)
+def test_f16_set_gemm_matches_fp32_reference(gpu_lib, case):
+    """Unquantised weights at prompt sizes (BASELINE configs[4]): ggml rounds the activation rows to fp16 and accumulates exact fp16 x fp16 products in fp32 -- which is
+    what v_mfma_f32_32x32x16_f16 does; only the accumulation order differs -> 2e-5 of the row maximum against a float64 product of the same fp16-rounded operands."""
+    from minigpt4_cpp_amd import quants as Q
+    N, n_in, n_out, n_mat, ks, with_res = case
+    rng = np.random.default_rng(sum(case))
+    w = (0.05 * rng.standard_normal((n_mat * n_out, n_in))).astype(np.float16)
+    x = rng.standard_normal((N, n_in)).astype(np.float32)
+    res = rng.standard_normal((n_mat, N, n_out)).astype(np.float32) if with_res else None
+    got = gpu_lib.amd_test_mmq2(Q.NAME_TO_TYPE["f16"], w.view(np.uint8).reshape(-1), n_mat, n_in, n_out, x, residual=res, ks=ks)
+    want = (x.astype(np.float16).astype(np.float64) @ w.astype(np.float64).T).reshape(N, n_mat, n_out).transpose(1, 0, 2)
+    scale = np.abs(want).max()
+    if with_res:
+        want = want + res
+    assert got.shape == want.shape and np.isfinite(got).all()
+    assert float(np.abs(got - want).max() / scale) < 2e-5
