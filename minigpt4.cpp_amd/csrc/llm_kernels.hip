@@ -1119,7 +1119,7 @@ int mmq_enabled() { return g_mmq_enabled; }
 // (13B f16, 512-token prefill) is MFMA-bound instead of re-streaming 25 GB of weights once per 4 tokens.  MINIGPT4_F16_GEMM=0 keeps the v_dot path.
 static int g_f16_gemm = -1;
 void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
-    if (g_mmq_enabled >= 2 && N >= 5 && A.bsq && mmq2_supported(W.type, W.rows, W.cols)) {
+    if (g_mmq_enabled >= 2 && N >= 5 && (A.bsq || W.type == GT_Q4_0) && mmq2_supported(W.type, W.rows, W.cols)) {
         const QWeight *Wp[1] = {&W}; float *Yp[1] = {y}; const float *Rp[1] = {residual};
         if (launch_mmq2_set(Wp, Yp, residual ? Rp : nullptr, 1, A, N, ldy, s)) return;
     }

@@ -425,6 +425,154 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
     mmq2_store<TT>(acc, a, m, r0 + l31, W.rows, t0, my_tiles, hh);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Q4_0 (the 7B file of BASELINE configs[1..2]; round 1's k_mmq_q40 took 24.6 ms for the 142-row image turn).  Block = 32 weights = one 16-byte unit (low nibbles =
+// elements 0..15, high nibbles = 16..31) + one fp16 scale; activations are Q8_0 (int8 + one fp32 scale per 32).  Same skeleton as the k-quant kernels: 8 blocks
+// ("super-chunk" of 256 weights, 128 contiguous bytes per row) per stage, weights read coalesced and transposed through the per-wave LDS scratch, activations and
+// their scales by LDS-DMA; one K = 32 MFMA per block, nibbles sign-extended to q - 8 at unpack time (no per-32 sum correction), and per block
+// acc = fma(d_w * d_a, (float)isum, acc) exactly as the decode kernel (Tr<GT_Q4_0>::dot) and ggml's AVX2 path do it.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TT> struct Mmq2Stage80 {
+    static constexpr int TTP = (TT + 1) & ~1;
+    static constexpr int Q8 = TT * 32 * 256, DS = 8 * TTP * 32 * 4;      // q8 as Mmq2Stage; scales [8 blocks][TTP * 32 tokens] fp32 (token-contiguous: 4 accumulator registers = 16 bytes)
+    static constexpr int BYTES = Q8 + DS;
+};
+template <int TT>
+__device__ __forceinline__ void mmq2_stage_load80(const ActQ &A, int K, int N, int t0, int sb, unsigned char *st, int wv, int lane, const unsigned (&tokoff)[Mmq2Stage80<TT>::TTP / 2]) {
+    using S = Mmq2Stage80<TT>;
+#pragma unroll
+    for (int k = 0; k < 2 * TT; k++) {
+        const int ii = wv * 2 * TT + k;
+        const int tl = 4 * ii + (lane >> 4);
+        const int c = (lane & 15) ^ (tl & 15);
+        const int tok = min(t0 + tl, N - 1);
+        dma16(A.q80 + (size_t)tok * K + (size_t)sb * 256 + c * 16, st + ii * 1024);
+    }
+    // scales: instruction (b, j) = block b of the super-chunk, tokens 64 j + lane; wave wv takes blocks wv and wv + 4.  tokoff[j] (this lane's row offset into d0) is
+    // computed once by the caller: rebuilding 64-bit addresses per instruction is cheaper than the 16 hoisted pointer pairs hipcc otherwise keeps (and spills)
+    constexpr int HJ = S::TTP / 2;
+#pragma unroll
+    for (int j = 0; j < HJ; j++) {
+        const float *pj = A.d0 + (size_t)tokoff[j] + (size_t)sb * 8 + wv;
+        dma4(pj, st + S::Q8 + (wv * S::TTP * 32 + 64 * j) * 4);
+        dma4(pj + 4, st + S::Q8 + ((wv + 4) * S::TTP * 32 + 64 * j) * 4);
+    }
+}
+template <int TT>
+__global__ __launch_bounds__(256, 2) void k_mmq2_q40(const Mmq2Args a, const ActQ A) {
+    using S = Mmq2Stage80<TT>;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_mmq2[];   // [2 activation stages][4 waves x 4 KiB weight transpose scratch]
+    const int lane = threadIdx.x & 63, hh = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = blockIdx.x / a.groups_each, g = blockIdx.x - m * a.groups_each;
+    const QWeight W = a.w[m];
+    const int K = W.cols, U = K / 32, NSB = K / 256, N = a.N;
+    const int r0 = (g * 4 + wv) * 32;
+    const int row = min(r0 + l31, W.rows - 1);
+    const int tile0 = blockIdx.y * a.tiles_per_chunk, my_tiles = min(TT, a.n_tiles - tile0), t0 = tile0 * 32;
+    const int sb0 = blockIdx.z * a.sb_per_split, sb1 = min(NSB, sb0 + a.sb_per_split);
+    unsigned char *scratch = smem_mmq2 + 2 * S::BYTES + wv * 4096;
+
+    typedef float v16f_t __attribute__((ext_vector_type(16)));
+    v16f_t acc[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; tt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[tt][r] = 0.0f;
+
+    struct Raw { v4i q[4]; v4i h; };
+    const unsigned char *wq[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) wq[n] = W.qs + ((size_t)min(r0 + 8 * n + (lane >> 3), W.rows - 1) * U + (lane & 7)) * 16;
+    const unsigned char *wh = W.sc + (size_t)row * U * 2;
+    auto fetch = [&](int sb, Raw &w) {
+#pragma unroll
+        for (int n = 0; n < 4; n++) w.q[n] = ldg16(wq[n] + (size_t)sb * 128);
+        w.h = ldg16(wh + (size_t)sb * 16);
+    };
+    unsigned sw_addr[4], sr_addr[8], a_addr[8];
+#pragma unroll
+    for (int n = 0; n < 4; n++) sw_addr[n] = (unsigned)((8 * n + (lane >> 3)) * 128 + (((lane & 7) ^ ((4 * n + (lane >> 4)) & 7)) << 4));
+#pragma unroll
+    for (int b = 0; b < 8; b++) sr_addr[b] = (unsigned)(l31 * 128 + ((b ^ ((l31 >> 1) & 7)) << 4));     // both lane halves read unit b of their row (hh selects the nibble)
+    const int v = hh ^ (lane & 15);
+#pragma unroll
+    for (int b = 0; b < 8; b++) a_addr[b] = (unsigned)(l31 * 256 + (((2 * b) ^ v) << 4));                // elements 32 b + 16 hh .. + 15 of token l31
+    const unsigned ds_addr = (unsigned)(S::Q8 + 16 * hh);
+
+    unsigned tokoff[S::TTP / 2];
+#pragma unroll
+    for (int j = 0; j < S::TTP / 2; j++) tokoff[j] = (unsigned)min(t0 + 64 * j + lane, N - 1) * (unsigned)(K / 32);
+    Raw raw;
+    fetch(sb0, raw);
+    mmq2_stage_load80<TT>(A, K, N, t0, sb0, smem_mmq2, wv, lane, tokoff);
+    for (int sb = sb0; sb < sb1; sb++) {
+        const int buf = (sb - sb0) & 1;
+        unsigned char *st = smem_mmq2 + buf * S::BYTES;
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 4; n++) *reinterpret_cast<v4i *>(scratch + sw_addr[n]) = raw.q[n];
+        float dw[8];
+#pragma unroll
+        for (int b = 0; b < 8; b++) dw[b] = h2f_b(((unsigned)raw.h[b >> 1] >> (16 * (b & 1))) & 0xFFFF);
+        v4i wb[8];
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const v4i q = *reinterpret_cast<const v4i *>(scratch + sr_addr[b]);
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const unsigned x = hh ? ((unsigned)q[w] >> 4) & 0x0F0F0F0Fu : (unsigned)q[w] & 0x0F0F0F0Fu;
+                wb[b][w] = (int)(((x ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u);   // per byte x - 8 as int8: bit 7 set keeps the subtraction from borrowing across bytes
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int sbn = min(sb + 1, sb1 - 1);
+            fetch(sbn, raw);
+            mmq2_stage_load80<TT>(A, K, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane, tokoff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tt = 0; tt < TT; tt++) {
+            if (tt < my_tiles) {
+                const unsigned char *sq = st + tt * 8192;
+                v16i D[2];
+#define MMQ2_ISSUE40(b, k) { const v4i af_ = *reinterpret_cast<const v4i *>(sq + a_addr[b]); D[k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_, wb[b], zero16(), 0, 0, 0); }
+#define MMQ2_SCALE40(b, k) { _Pragma("unroll") for (int q4 = 0; q4 < 4; q4++) {                                                                                   \
+                               const v4f da = *reinterpret_cast<const v4f *>(st + ds_addr + ((b) * S::TTP * 32 + tt * 32 + 8 * q4) * 4);                            \
+                               _Pragma("unroll") for (int e = 0; e < 4; e++) { const int r = 4 * q4 + e; acc[tt][r] = fmaf(dw[b] * da[e], (float)D[k][r], acc[tt][r]); } }      \
+                             asm volatile("" : "+v"(acc[tt])); }   /* pins the block's scale arithmetic here: without it LLVM sinks all 8 blocks' conversions and fmas behind the 8 MFMAs (8 result sets + 128 scales live -> scratch) */
+                MMQ2_ISSUE40(0, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE40(1, 1) MMQ2_SCALE40(0, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE40(2, 0) MMQ2_SCALE40(1, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE40(3, 1) MMQ2_SCALE40(2, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE40(4, 0) MMQ2_SCALE40(3, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE40(5, 1) MMQ2_SCALE40(4, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE40(6, 0) MMQ2_SCALE40(5, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_ISSUE40(7, 1) MMQ2_SCALE40(6, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                MMQ2_SCALE40(7, 1)
+                __builtin_amdgcn_sched_barrier(0);
+#undef MMQ2_ISSUE40
+#undef MMQ2_SCALE40
+            }
+        }
+    }
+    float accf[TT][16];
+#pragma unroll
+    for (int tt = 0; tt < TT; tt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) accf[tt][r] = acc[tt][r];
+    mmq2_store<TT>(accf, a, m, r0 + l31, W.rows, t0, my_tiles, hh);
+}
+
 // y[t][r] = (residual[t][r] +) sum_z slab_z[t][r], z in fixed order (deterministic); rows x cols floats per slab
 __global__ __launch_bounds__(256) void k_mmq2_reduce(const float *__restrict__ slabs, int n_slabs, long long slab_stride, const float *__restrict__ residual, float *__restrict__ y, size_t n4) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -441,7 +589,7 @@ void launch_slab_reduce(const float *slabs, int n_slabs, long long slab_stride, 
     hipLaunchKernelGGL(k_mmq2_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, slabs, n_slabs, slab_stride, residual, y, n4);
 }
 
-bool mmq2_supported(int type, int rows, int cols) { return (type == GT_Q4_K || type == GT_Q5_K || type == GT_Q6_K) && cols % 256 == 0 && rows >= 32; }
+bool mmq2_supported(int type, int rows, int cols) { return (type == GT_Q4_K || type == GT_Q5_K || type == GT_Q6_K || type == GT_Q4_0) && cols % 256 == 0 && rows >= 32; }
 
 static int g_mmq2_cus = 256;
 void set_mmq2_cus(int cus) { if (cus > 0) g_mmq2_cus = cus; }
@@ -453,8 +601,9 @@ static void mmq2_launch_kernel(KernelT kernel, bool &attr_done, dim3 grid, size_
 }
 template <int TT>
 static void mmq2_launch_tt(int type, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
-    static bool attr[3] = {false, false, false};
+    static bool attr[4] = {false, false, false, false};
     if constexpr (TT <= 3) {
+        if (type == GT_Q4_0) { mmq2_launch_kernel(&k_mmq2_q40<TT>, attr[3], grid, lds, s, a, A); return; }
         if (type == GT_Q4_K) { mmq2_launch_kernel(&k_mmq2_q45k<false, TT>, attr[0], grid, lds, s, a, A); return; }
         if (type == GT_Q5_K) { mmq2_launch_kernel(&k_mmq2_q45k<true, TT>, attr[1], grid, lds, s, a, A); return; }
     }
@@ -467,7 +616,7 @@ static void mmq2_launch_tt(int type, dim3 grid, size_t lds, hipStream_t s, const
 // 1..3 same-type, same-shape matrices against the N prepared activation rows in one launch.  y[m][t * ldy + r] (+ residual[m][..]).  false -> shape outside the
 // kernel's range (nothing launched).
 bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s) {
-    if (n < 1 || n > 3 || !A.bsq || N < 1) return false;
+    if (n < 1 || n > 3 || N < 1 || (W[0]->type == GT_Q4_0 ? !(A.q80 && A.d0) : !A.bsq)) return false;
     for (int i = 0; i < n; i++) if (!mmq2_supported(W[i]->type, W[i]->rows, W[i]->cols) || W[i]->type != W[0]->type || W[i]->rows != W[0]->rows || W[i]->cols != W[0]->cols) return false;
     Mmq2Args a{};
     for (int i = 0; i < n; i++) { a.w[i] = *W[i]; a.y[i] = y[i]; a.res[i] = residual ? residual[i] : nullptr; }
@@ -493,10 +642,11 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     }
     const dim3 grid((unsigned)(n * a.groups_each), (unsigned)n_chunks, (unsigned)ks);
     const int type = W[0]->type;
+    const bool q40 = type == GT_Q4_0;
     switch (a.tiles_per_chunk) {
-    case 1: mmq2_launch_tt<1>(type, grid, 2 * Mmq2Stage<1>::BYTES + 16384, s, a, A); break;
-    case 2: mmq2_launch_tt<2>(type, grid, 2 * Mmq2Stage<2>::BYTES + 16384, s, a, A); break;
-    case 3: mmq2_launch_tt<3>(type, grid, 2 * Mmq2Stage<3>::BYTES + 16384, s, a, A); break;
+    case 1: mmq2_launch_tt<1>(type, grid, 2 * (q40 ? Mmq2Stage80<1>::BYTES : Mmq2Stage<1>::BYTES) + 16384, s, a, A); break;
+    case 2: mmq2_launch_tt<2>(type, grid, 2 * (q40 ? Mmq2Stage80<2>::BYTES : Mmq2Stage<2>::BYTES) + 16384, s, a, A); break;
+    case 3: mmq2_launch_tt<3>(type, grid, 2 * (q40 ? Mmq2Stage80<3>::BYTES : Mmq2Stage<3>::BYTES) + 16384, s, a, A); break;
     default: throw HipError{hipErrorInvalidValue, "mmq2: bad chunking", __FILE__, __LINE__};
     }
     if (ks > 1) {

@@ -21,7 +21,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("wtype", ["q4_k", "q5_k", "q6_k"])
+@pytest.mark.parametrize("wtype", ["q4_k", "q5_k", "q6_k", "q4_0"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "N%d_K%d_R%d_m%d_ks%d_res%d" % c)
 def test_mmq2_matches_oracle(gpu_lib, wtype, case):
     import refcpu as R
