@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q40(const Mmq2Args a, const Act
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 const unsigned x = hh ? ((unsigned)q[w] >> 4) & 0x0F0F0F0Fu : (unsigned)q[w] & 0x0F0F0F0Fu;
-                wb[b][w] = (int)(((x ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u);   // per byte x - 8 as int8: bit 7 set keeps the subtraction from borrowing across bytes
+                wb[b][w] = (int)(((x | 0x80808080u) - 0x08080808u) ^ 0x80808080u);   // per byte x - 8 as int8: bit 7 set keeps the subtraction from borrowing across bytes
             }
         }
         __builtin_amdgcn_sched_barrier(0);
