@@ -122,6 +122,7 @@ size_t plan_qweight(int type, int rows, int cols, QWeight &w, uint8_t *base) {
     case GT_Q5_0: w.qs = take(n / 32 * 16); w.qh = take(n / 32 * 4); w.sc = take(n / 32 * 2); break;
     case GT_Q5_1: w.qs = take(n / 32 * 16); w.qh = take(n / 32 * 4); w.sc = take(n / 32 * 4); break;
     case GT_Q8_0: w.qs = take(n / 32 * 32); w.sc = take(n / 32 * 2); break;
+    case GT_Q2_K: w.qs = take(n / 32 * 8); w.sc = take(n / 32 * 2); w.d = take(n / 256 * 4); break;   // unit = 32 consecutive weights = two 16-weight sub-blocks: 2-bit planes, {scale | min << 4} x 2, {d, dmin} per super-block
     case GT_Q4_K: w.qs = take(n / 256 * 128); w.sc = take(n / 256 * 16); break;
     case GT_Q5_K: w.qs = take(n / 256 * 128); w.qh = take(n / 256 * 32); w.sc = take(n / 256 * 16); break;
     case GT_Q6_K: w.qs = take(n / 256 * 128); w.qh = take(n / 256 * 64); w.sc = take(n / 256 * 16); w.d = take(n / 256 * 2); break;
@@ -131,7 +132,7 @@ size_t plan_qweight(int type, int rows, int cols, QWeight &w, uint8_t *base) {
     return off;
 }
 bool qweight_supported(int type) {
-    switch (type) { case GT_F32: case GT_F16: case GT_Q4_0: case GT_Q4_1: case GT_Q5_0: case GT_Q5_1: case GT_Q8_0: case GT_Q4_K: case GT_Q5_K: case GT_Q6_K: return true; default: return false; }
+    switch (type) { case GT_F32: case GT_F16: case GT_Q4_0: case GT_Q4_1: case GT_Q5_0: case GT_Q5_1: case GT_Q8_0: case GT_Q2_K: case GT_Q4_K: case GT_Q5_K: case GT_Q6_K: return true; default: return false; }
 }
 
 // high-bit transposition for 5-bit types: element e of 32 (lo: e<16 -> dword k=e/4, byte i=e%4, slot w=k; hi: e>=16 -> w=4+k)
@@ -161,6 +162,15 @@ __global__ void k_repack(const uint8_t *__restrict__ raw, QWeight w, size_t n_un
     case GT_Q8_0: { const size_t blk = g >> 1; const int half = (int)(g & 1); const uint8_t *b = raw + blk * 34;
         if (!half) { sc[blk * 2] = b[0]; sc[blk * 2 + 1] = b[1]; }
         for (int i = 0; i < 16; i++) qs[g * 16 + i] = b[2 + half * 16 + i];
+        break; }
+    case GT_Q2_K: {   // block_q2_K = scales[16] | qs[64] | d | dmin; element 128 n + 32 j + l = (qs[32 n + l] >> 2 j) & 3; unit i of a super-block = elements 32 i .. 32 i + 31
+        const size_t sb = g >> 3; const int i = (int)(g & 7), n = i >> 2, j = i & 3; const uint8_t *b = raw + sb * 84;
+        if (i == 0) for (int k = 0; k < 4; k++) dd[sb * 4 + k] = b[80 + k];
+        unsigned P0 = 0, P1 = 0;   // weight e (0..15) of a half at bits 8 (e & 3) + 2 (e >> 2): (P >> 2 k) & 0x03030303 = the four weights of dword k
+        for (int e = 0; e < 16; e++) { const int k = e >> 2, c = e & 3;
+            P0 |= (((unsigned)b[16 + 32 * n + e] >> (2 * j)) & 3u) << (8 * c + 2 * k); P1 |= (((unsigned)b[16 + 32 * n + 16 + e] >> (2 * j)) & 3u) << (8 * c + 2 * k); }
+        reinterpret_cast<unsigned *>(qs + g * 8)[0] = P0; reinterpret_cast<unsigned *>(qs + g * 8)[1] = P1;
+        sc[g * 2] = b[2 * i]; sc[g * 2 + 1] = b[2 * i + 1];
         break; }
     case GT_Q4_K: { const size_t sb = g >> 3; const int u = (int)(g & 7); const uint8_t *b = raw + sb * 144;
         if (u == 0) for (int i = 0; i < 16; i++) sc[sb * 16 + i] = b[i];
@@ -298,6 +308,27 @@ __device__ __forceinline__ void scale_min_pair(const int4 &h, int j, int &sc0, i
     const int sh = (j & 1) * 16;
     sc0 = (scw >> sh) & 0xFF; sc1 = (scw >> (sh + 8)) & 0xFF; m0 = (mw >> sh) & 0xFF; m1 = (mw >> (sh + 8)) & 0xFF;
 }
+template <> struct Tr<GT_Q2_K> {   // supported, not tuned: only the generic tile kernel k_mul_mat streams this type (no persistent-wave / MFMA path)
+    static constexpr int EPU = 32;
+    struct WU { uint2 p; unsigned short sc; unsigned dm; };
+    using AU = AK;
+    static __device__ __forceinline__ void loadw(const QWeight &W, size_t g0, int u, WU &w) {
+        w.p = ldw<uint2>(W.qs + g0 * 8 + (unsigned)(u * 8)); w.sc = ldw<unsigned short>(W.sc + g0 * 2 + (unsigned)(u * 2)); w.dm = ldw<unsigned>(W.d + (g0 >> 3) * 4 + (unsigned)((u >> 3) * 4)); }
+    static __device__ __forceinline__ void mkb(const QWeight &W, size_t g0, WBuf &B) { B.qs = mkbuf(W.qs + g0 * 8); B.sc = mkbuf(W.sc + g0 * 2); B.d = mkbuf(W.d + (g0 >> 3) * 4); }
+    static __device__ __forceinline__ void loadb(const WBuf &B, int u, WU &w) { w.p = bld8(B.qs, u * 8); w.sc = bld2(B.sc, u * 2); w.dm = bld4(B.d, (u >> 3) * 4); }
+    static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) {
+        const int8_t *p = A.q8k + (size_t)t * K + (size_t)u * 32; a.lo = ld16(p); a.hi = ld16(p + 16);
+        a.d = A.dk[(size_t)t * (K / 256) + (u >> 3)]; const int16_t *bs = A.bsk + (size_t)t * (K / 16) + 2 * u; a.bs_lo = bs[0]; a.bs_hi = bs[1]; }
+    static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
+        int s0 = 0, s1 = 0; const unsigned L = w.p.x, H = w.p.y;
+        s0 = dot4(L & 0x03030303, a.lo.x, s0); s0 = dot4((L >> 2) & 0x03030303, a.lo.y, s0); s0 = dot4((L >> 4) & 0x03030303, a.lo.z, s0); s0 = dot4((L >> 6) & 0x03030303, a.lo.w, s0);
+        s1 = dot4(H & 0x03030303, a.hi.x, s1); s1 = dot4((H >> 2) & 0x03030303, a.hi.y, s1); s1 = dot4((H >> 4) & 0x03030303, a.hi.z, s1); s1 = dot4((H >> 6) & 0x03030303, a.hi.w, s1);
+        const int sc0 = w.sc & 0xF, m0 = (w.sc >> 4) & 0xF, sc1 = (w.sc >> 8) & 0xF, m1 = w.sc >> 12;
+        const float d = h2f_bits(w.dm & 0xFFFF), dmin = h2f_bits(w.dm >> 16);
+        acc = fmaf(d * a.d, (float)(sc0 * s0 + sc1 * s1), acc);
+        acc = fmaf(-(dmin * a.d), (float)(m0 * a.bs_lo + m1 * a.bs_hi), acc);
+    }
+};
 template <> struct Tr<GT_Q4_K> {
     static constexpr int EPU = 32;
     struct WU { int4 q; int4 h; };
@@ -1134,6 +1165,7 @@ void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, c
     case GT_Q5_0: launch_mul_mat_t<GT_Q5_0>(W, A, N, y, ldy, residual, s); break;
     case GT_Q5_1: launch_mul_mat_t<GT_Q5_1>(W, A, N, y, ldy, residual, s); break;
     case GT_Q8_0: launch_mul_mat_t<GT_Q8_0>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q2_K: launch_mul_mat_t<GT_Q2_K>(W, A, N, y, ldy, residual, s); break;
     case GT_Q4_K: launch_mul_mat_t<GT_Q4_K>(W, A, N, y, ldy, residual, s); break;
     case GT_Q5_K: launch_mul_mat_t<GT_Q5_K>(W, A, N, y, ldy, residual, s); break;
     case GT_Q6_K: launch_mul_mat_t<GT_Q6_K>(W, A, N, y, ldy, residual, s); break;
@@ -1266,6 +1298,9 @@ __device__ float dequant_elem(int type, const uint8_t *row, int e) {
     case GT_Q5_1: { const uint8_t *b = row + (e >> 5) * 24; const int j = e & 31; const float d = h2f_bits(b[0] | (b[1] << 8)), m = h2f_bits(b[2] | (b[3] << 8)); const unsigned qh = b[4] | (b[5] << 8) | (b[6] << 16) | ((unsigned)b[7] << 24);
         const int q = (j < 16 ? (b[8 + j] & 15) : (b[8 + j - 16] >> 4)) | (((qh >> j) & 1) << 4); return (float)q * d + m; }
     case GT_Q8_0: { const uint8_t *b = row + (e >> 5) * 34; const float d = h2f_bits(b[0] | (b[1] << 8)); return (float)(signed char)b[2 + (e & 31)] * d; }
+    case GT_Q2_K: { const uint8_t *b = row + (e >> 8) * 84; const int i = e & 255, n = i >> 7, j = (i >> 5) & 3, l = i & 31; const uint8_t sc = b[i >> 4];
+        const float d = h2f_bits(b[80] | (b[81] << 8)), dm = h2f_bits(b[82] | (b[83] << 8)); const float dl = d * (float)(sc & 0xF), ml = dm * (float)(sc >> 4);
+        return dl * (float)((b[16 + 32 * n + l] >> (2 * j)) & 3) - ml; }
     case GT_Q4_K: { const uint8_t *b = row + (e >> 8) * 144; const int i = e & 255, s = i >> 5, l = i & 31; const float d = h2f_bits(b[0] | (b[1] << 8)), dm = h2f_bits(b[2] | (b[3] << 8)); int sc, m; sm_k4(s, b + 4, sc, m);
         const uint8_t qb = b[16 + (s >> 1) * 32 + l]; const int q = (s & 1) ? (qb >> 4) : (qb & 15); return (d * sc) * (float)q - dm * m; }
     case GT_Q5_K: { const uint8_t *b = row + (e >> 8) * 176; const int i = e & 255, s = i >> 5, l = i & 31; const float d = h2f_bits(b[0] | (b[1] << 8)), dm = h2f_bits(b[2] | (b[3] << 8)); int sc, m; sm_k4(s, b + 4, sc, m);

@@ -345,6 +345,54 @@ def dequantize_q6_k(buf: np.ndarray, n: int) -> np.ndarray:
     return y.reshape(-1)
 
 
+# --------------------------------------------------------------------------- Q2_K (84 bytes: scales[16] (4-bit scale | 4-bit min << 4), qs[64], d fp16, dmin fp16)
+def _q2k_values(b: np.ndarray) -> np.ndarray:
+    """[nb, 84] -> 2-bit values [nb, 256] in element order: y[128 n + 32 j + l] = (qs[32 n + l] >> 2 j) & 3."""
+    qs = b[:, 16:80].astype(np.int32)
+    v = np.zeros((b.shape[0], 256), np.int32)
+    for n_ in range(2):
+        for j in range(4):
+            v[:, 128 * n_ + 32 * j:128 * n_ + 32 * j + 32] = (qs[:, 32 * n_:32 * n_ + 32] >> (2 * j)) & 3
+    return v
+
+
+def dequantize_q2_k(buf: np.ndarray, n: int) -> np.ndarray:
+    b = np.frombuffer(buf, np.uint8, n // 256 * 84).reshape(-1, 84)
+    sc = (b[:, 0:16] & 15).astype(np.float64)
+    mn = (b[:, 0:16] >> 4).astype(np.float64)
+    d = b[:, 80:82].copy().view(np.float16).astype(np.float64)
+    dmin = b[:, 82:84].copy().view(np.float16).astype(np.float64)
+    y = _q2k_values(b).reshape(-1, 16, 16).astype(np.float64) * (d * sc)[:, :, None] - (dmin * mn)[:, :, None]
+    return y.reshape(-1)
+
+
+def quantize_q2_k(x: np.ndarray) -> np.ndarray:
+    """Valid Q2_K blocks (per sub-block min / range mapped onto 4-bit scale and min against the largest of the super-block); not ggml's make_qkx1_quants search."""
+    x = np.asarray(x, np.float32).reshape(-1, 16, 16)
+    nb = x.shape[0]
+    lo = np.minimum(x.min(axis=2), 0.0)                   # min <= 0 as in ggml (the offset is subtracted)
+    hi = x.max(axis=2)
+    scale = (hi - lo) / 3.0                               # per sub-block step
+    mn = -lo
+    d = _f16(scale.max(axis=1) / 15.0)
+    dmin = _f16(mn.max(axis=1) / 15.0)
+    df, mf = d.astype(np.float32), dmin.astype(np.float32)
+    ls = np.where(df[:, None] != 0, np.rint(scale / np.where(df != 0, df, 1)[:, None]), 0).clip(0, 15).astype(np.int32)
+    lm = np.where(mf[:, None] != 0, np.rint(mn / np.where(mf != 0, mf, 1)[:, None]), 0).clip(0, 15).astype(np.int32)
+    eff, off = df[:, None] * ls, mf[:, None] * lm
+    q = np.where(eff[:, :, None] != 0, np.rint((x + off[:, :, None]) / np.where(eff != 0, eff, 1)[:, :, None]), 0).clip(0, 3).astype(np.int32).reshape(nb, 256)
+    out = np.zeros((nb, 84), np.uint8)
+    qs = np.zeros((nb, 64), np.int32)
+    for n_ in range(2):
+        for j in range(4):
+            qs[:, 32 * n_:32 * n_ + 32] |= q[:, 128 * n_ + 32 * j:128 * n_ + 32 * j + 32] << (2 * j)
+    out[:, 0:16] = (ls | (lm << 4)).astype(np.uint8)
+    out[:, 16:80] = qs.astype(np.uint8)
+    out[:, 80:82] = d.view(np.uint8).reshape(-1, 2)
+    out[:, 82:84] = dmin.view(np.uint8).reshape(-1, 2)
+    return out.reshape(-1)
+
+
 # --------------------------------------------------------------------------- Q3_K (110 bytes: hmask[32], qs[64], scales[12] (16 x 6 bit), d fp16)
 def _q3k_unpack_scales(sb: np.ndarray) -> np.ndarray:
     """[nb, 12] uint8 -> [nb, 16] int (0..63), ggml's kmask1/kmask2 shuffle (k_quants.c dequantize_row_q3_K)."""
@@ -451,7 +499,7 @@ def quantize(gtype: int, x: np.ndarray) -> np.ndarray:
     fn = {
         GGML_Q4_0: quantize_q4_0, GGML_Q4_1: quantize_q4_1, GGML_Q5_0: quantize_q5_0,
         GGML_Q5_1: quantize_q5_1, GGML_Q8_0: quantize_q8_0, GGML_Q4_K: quantize_q4_k,
-        GGML_Q5_K: quantize_q5_k, GGML_Q6_K: quantize_q6_k, GGML_Q3_K: quantize_q3_k,
+        GGML_Q5_K: quantize_q5_k, GGML_Q6_K: quantize_q6_k, GGML_Q3_K: quantize_q3_k, GGML_Q2_K: quantize_q2_k,
     }[gtype]
     return fn(x)
 
@@ -465,6 +513,6 @@ def dequantize(gtype: int, buf, n: int) -> np.ndarray:
     fn = {
         GGML_Q4_0: dequantize_q4_0, GGML_Q4_1: dequantize_q4_1, GGML_Q5_0: dequantize_q5_0,
         GGML_Q5_1: dequantize_q5_1, GGML_Q8_0: dequantize_q8_0, GGML_Q4_K: dequantize_q4_k,
-        GGML_Q5_K: dequantize_q5_k, GGML_Q6_K: dequantize_q6_k, GGML_Q3_K: dequantize_q3_k,
+        GGML_Q5_K: dequantize_q5_k, GGML_Q6_K: dequantize_q6_k, GGML_Q3_K: dequantize_q3_k, GGML_Q2_K: dequantize_q2_k,
     }[gtype]
     return fn(np.frombuffer(buf, np.uint8), n)

@@ -94,6 +94,7 @@ typedef struct { f16_t d, dmin; uint8_t scales[12]; uint8_t qs[128]; } blk_q4_K;
 typedef struct { f16_t d, dmin; uint8_t scales[12]; uint8_t qh[32]; uint8_t qs[128]; } blk_q5_K;
 typedef struct { uint8_t ql[128]; uint8_t qh[64]; int8_t scales[16]; f16_t d; } blk_q6_K;
 typedef struct { uint8_t hmask[32]; uint8_t qs[64]; uint8_t scales[12]; f16_t d; } blk_q3_K;   /* k_quants.h block_q3_K, QK_K = 256 */
+typedef struct { uint8_t scales[16]; uint8_t qs[64]; f16_t d, dmin; } blk_q2_K;                  /* k_quants.h block_q2_K: scale (low nibble) and min (high nibble) per 16 weights */
 typedef struct { float d; int8_t qs[256]; int16_t bsums[16]; } blk_q8_K;
 #pragma pack(pop)
 
@@ -101,7 +102,7 @@ ORC_API int64_t orc_type_block(int type) { switch (type) { case T_F32: case T_F1
 ORC_API int64_t orc_type_bytes(int type) {
     switch (type) {
         case T_F32: return 4; case T_F16: return 2; case T_Q4_0: return 18; case T_Q4_1: return 20; case T_Q5_0: return 22;
-        case T_Q5_1: return 24; case T_Q8_0: return 34; case T_Q8_1: return 40; case T_Q3_K: return 110; case T_Q4_K: return 144; case T_Q5_K: return 176;
+        case T_Q5_1: return 24; case T_Q8_0: return 34; case T_Q8_1: return 40; case T_Q2_K: return 84; case T_Q3_K: return 110; case T_Q4_K: return 144; case T_Q5_K: return 176;
         case T_Q6_K: return 210; case T_Q8_K: return 292; default: return 0; }
 }
 static int64_t row_bytes(int type, int64_t n) { return n / orc_type_block(type) * orc_type_bytes(type); }
@@ -152,6 +153,11 @@ ORC_API int orc_dequantize_row(int type, const void *src, float *y, int64_t n) {
                 const int8_t q3 = (int8_t)((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32, q4 = (int8_t)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
                 y[l] = d * sc[is] * q1; y[l + 32] = d * sc[is + 2] * q2; y[l + 64] = d * sc[is + 4] * q3; y[l + 96] = d * sc[is + 6] * q4; }
             y += 128; ql += 64; qh += 32; sc += 8; } } return 0; }
+    case T_Q2_K: {   /* dequantize_row_q2_K: y[128 n + 32 j + l] = d * (sc & 0xF) * ((qs[32 n + l] >> 2 j) & 3) - dmin * (sc >> 4), sc = scales[8 n + 2 j + l / 16] */
+        const blk_q2_K *x = src; for (int64_t i = 0; i < n / QK_K; i++) { const float d = h2f(x[i].d), mn = h2f(x[i].dmin);
+            for (int e = 0; e < QK_K; e++) { const int nn = e >> 7, j = (e >> 5) & 3, l = e & 31; const uint8_t sc = x[i].scales[e >> 4];
+                const float dl = d * (sc & 0xF), ml = mn * (sc >> 4); y[e] = dl * (float)((x[i].qs[32 * nn + l] >> (2 * j)) & 3) - ml; }
+            y += QK_K; } return 0; }
     case T_Q3_K: { const blk_q3_K *x = src; for (int64_t i = 0; i < n / QK_K; i++) { const float d_all = h2f(x[i].d); int8_t sc[16], v[256]; q3k_scales(x[i].scales, sc); q3k_values(&x[i], v);
         for (int is = 0; is < 16; is++) { const float dl = d_all * (sc[is] - 32); for (int l = 0; l < 16; l++) y[is * 16 + l] = dl * v[is * 16 + l]; } y += QK_K; } return 0; }
     default: return -1;
@@ -161,7 +167,7 @@ ORC_API int orc_dequantize_row(int type, const void *src, float *y, int64_t n) {
 /* ---- activation quantisation: the vec_dot_type of each weight type ---- */
 ORC_API int orc_vec_dot_type(int wtype) {
     switch (wtype) { case T_Q4_0: case T_Q5_0: case T_Q8_0: return T_Q8_0; case T_Q4_1: case T_Q5_1: return T_Q8_1;
-        case T_Q3_K: case T_Q4_K: case T_Q5_K: case T_Q6_K: return T_Q8_K; case T_F16: return T_F16; case T_F32: return T_F32; default: return -1; }
+        case T_Q2_K: case T_Q3_K: case T_Q4_K: case T_Q5_K: case T_Q6_K: return T_Q8_K; case T_F16: return T_F16; case T_F32: return T_F32; default: return -1; }
 }
 
 static void quantize_row_q8_0(const float *x, blk_q8_0 *y, int64_t n) {
@@ -241,6 +247,14 @@ static float vec_dot_q3_K_q8_K(int64_t n, const blk_q3_K *x, const blk_q8_K *y) 
     for (int64_t i = 0; i < n / QK_K; i++) { int8_t sc[16], v[256]; q3k_scales(x[i].scales, sc); q3k_values(&x[i], v); int isum = 0;
         for (int is = 0; is < 16; is++) { int s = 0; for (int l = 0; l < 16; l++) s += v[is * 16 + l] * y[i].qs[is * 16 + l]; isum += (sc[is] - 32) * s; }
         sumf = fmaf(h2f(x[i].d) * y[i].d, (float)isum, sumf); } return sumf; }
+/* ggml_vec_dot_q2_K_q8_K: per 16-wide sub-block the 4-bit scale weights the integer dot, the 4-bit min weights the activation sum; two fp32 scales per super-block */
+static float vec_dot_q2_K_q8_K(int64_t n, const blk_q2_K *x, const blk_q8_K *y) { float sumf = 0;
+    for (int64_t i = 0; i < n / QK_K; i++) { int isum = 0, summs = 0;
+        for (int is = 0; is < 16; is++) { const int nn = is >> 3, j = (is >> 1) & 3, l0 = 16 * (is & 1); int s = 0;
+            for (int l = 0; l < 16; l++) s += (int)((x[i].qs[32 * nn + l0 + l] >> (2 * j)) & 3) * y[i].qs[16 * is + l];
+            isum += (x[i].scales[is] & 0xF) * s; summs += (x[i].scales[is] >> 4) * y[i].bsums[is]; }
+        sumf = fmaf(h2f(x[i].d) * y[i].d, (float)isum, sumf);
+        sumf = fmaf(-(h2f(x[i].dmin) * y[i].d), (float)summs, sumf); } return sumf; }
 static float vec_dot_f16(int64_t n, const f16_t *x, const f16_t *y) { float s = 0; for (int64_t i = 0; i < n; i++) s = fmaf(h2f(x[i]), h2f(y[i]), s); return s; }
 static float vec_dot_f32(int64_t n, const float *x, const float *y) { float s = 0; for (int64_t i = 0; i < n; i++) s = fmaf(x[i], y[i], s); return s; }
 
@@ -313,7 +327,7 @@ ORC_API float orc_vec_dot(int wtype, int64_t n, const void *w, const void *a) {
     case T_Q4_0: return vec_dot_q4_0_q8_0(n, w, a); case T_Q4_1: return vec_dot_q4_1_q8_1(n, w, a);
     case T_Q5_0: return vec_dot_q5_0_q8_0(n, w, a); case T_Q5_1: return vec_dot_q5_1_q8_1(n, w, a);
     case T_Q8_0: return vec_dot_q8_0_q8_0(n, w, a); case T_Q4_K: return vec_dot_q4_K_q8_K(n, w, a);
-    case T_Q5_K: return vec_dot_q5_K_q8_K(n, w, a); case T_Q6_K: return vec_dot_q6_K_q8_K(n, w, a); case T_Q3_K: return vec_dot_q3_K_q8_K(n, w, a);
+    case T_Q5_K: return vec_dot_q5_K_q8_K(n, w, a); case T_Q6_K: return vec_dot_q6_K_q8_K(n, w, a); case T_Q3_K: return vec_dot_q3_K_q8_K(n, w, a); case T_Q2_K: return vec_dot_q2_K_q8_K(n, w, a);
     case T_F16: return vec_dot_f16(n, w, a); case T_F32: return vec_dot_f32(n, w, a);
     default: return NAN; }
 }

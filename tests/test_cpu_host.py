@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ALL_QTYPES = ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q4_k", "q5_k", "q6_k", "f16"]
+ALL_QTYPES = ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q2_k", "q4_k", "q5_k", "q6_k", "f16"]
 
 
 def _rel(a, b):
@@ -70,7 +70,7 @@ def test_quantisers_roundtrip_and_agree_with_oracle(wtype):
     assert raw.nbytes == Q.nbytes(t, x.size) == R.lib().orc_type_bytes(t) * x.size // R.lib().orc_type_block(t)
     d_np, d_c = Q.dequantize(t, raw, x.size), R.dequantize_row(t, raw, x.size)
     assert np.abs(d_np - d_c).max() <= 1e-7 * np.abs(d_np).max()
-    bound = {"q4_0": 0.12, "q4_1": 0.08, "q5_0": 0.06, "q5_1": 0.04, "q8_0": 0.01, "q4_k": 0.08, "q5_k": 0.04, "q6_k": 0.03, "f16": 1e-3}[wtype]
+    bound = {"q4_0": 0.12, "q4_1": 0.08, "q5_0": 0.06, "q5_1": 0.04, "q8_0": 0.01, "q2_k": 0.4, "q4_k": 0.08, "q5_k": 0.04, "q6_k": 0.03, "f16": 1e-3}[wtype]
     assert _rel(d_np, x) < bound
 
 

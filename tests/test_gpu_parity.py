@@ -16,7 +16,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-QTYPES = ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q4_k", "q5_k", "q6_k", "f16", "f32"]
+QTYPES = ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q2_k", "q4_k", "q5_k", "q6_k", "f16", "f32"]
 
 
 def _rel(a, b):
@@ -228,7 +228,7 @@ LOGIT_TOL = 5e-2
 
 
 @pytest.mark.parametrize("wtype,mix", [("q4_0", "none"), ("q5_k", "q5_k_m"), ("q4_1", "none"), ("q8_0", "none"), ("q6_k", "none"), ("q5_0", "none"),
-                                       ("q5_1", "none"), ("q4_k", "none"), ("f16", "none")])
+                                       ("q5_1", "none"), ("q4_k", "none"), ("f16", "none"), ("q2_k", "none")])
 def test_llm_logits_and_greedy_tokens(gpu_lib, tiny_files, wtype, mix):
     import refcpu as R
     from minigpt4_cpp_amd import modelgen as G
