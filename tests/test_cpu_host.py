@@ -379,3 +379,27 @@ def test_request_sharding_is_disjoint_and_complete():
             seen += dist.shard_requests(32, r, world)
         assert sorted(seen) == list(range(32))
     assert dist.shard_requests(32, 3, 8) == [3, 11, 19, 27]
+
+
+def test_bench_line_is_reproducible_from_committed_profiles():
+    """Round-1 verdict item 5: the roofline fraction of the bench line must be recomputable from profiles/.  The committed rocprofv3 --kernel-trace --stats summary of
+    the eager decode run and the bench line's own kernel table (per-dispatch event pairs) must agree on the dominant kernel's average duration, the traffic record
+    must name its source, and the per-kernel table must add up to the step time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = json.loads([l for l in open(os.path.join(root, "profiles", "r02_bench_n1.json")) if l.lstrip().startswith("{")][-1])
+    roof = bench["roofline"]
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "roofline_from_profile.py"), "stats", os.path.join(root, "profiles", "r02_decode_kernel_stats.csv"),
+                          os.path.join(root, "profiles", "r02_bench_n1.json")], capture_output=True, text=True, check=True).stdout
+    row = [l for l in out.splitlines() if l.startswith(roof["kernel"])][0].split("|")[0].split()
+    frac_rocprof = float(row[-1])
+    assert abs(frac_rocprof - roof["frac"]) < 0.05 * roof["frac"], (frac_rocprof, roof["frac"])
+    assert roof["timing"] == "dispatch" and roof["bound"] == "hbm" and abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-9
+    traffic = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    # (the bench line read the record of the previous FETCH_SIZE pass; passes agree to 0.01 %)
+    assert "FETCH_SIZE" in traffic["command"] and abs(traffic["kernels"][roof["kernel"]]["bytes_per_launch"] / roof["traffic"] - 1.0) < 1e-3
+    assert 0.98 < roof["traffic"] / roof["bytes_per_launch"] < 1.05                       # measured HBM bytes vs algorithmic bytes: no re-reads
+    assert abs(roof["kernel_sum_ms_per_token"] - bench["ms_per_step"]) < 0.06 * bench["ms_per_step"]
+    assert bench["parity"]["oracle_self_noise"]["mean_logit_rel_range"] * 1.5 >= bench["parity"]["mean_logit_rel_range"]
