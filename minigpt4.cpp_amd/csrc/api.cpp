@@ -389,7 +389,7 @@ int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t 
         QWeight W[3], plan;
         const size_t need = plan_qweight(ggml_type, (int)n_out, (int)n_in, plan, nullptr);
         DevBuf d_raw(raw_each), d_planes(need * (size_t)n_mat + 1024), d_x((size_t)(N * n_in) * 4), d_y(out_each * n_mat * 4), d_res(out_each * n_mat * 4), d_ws(out_each * n_mat * 16 * 4);
-        struct Gen { int keep; Gen(int g) : keep(mmq_scaled_operands()) { set_mmq_scaled_operands(g >= 3 ? 1 : 0); } ~Gen() { set_mmq_scaled_operands(keep); } } gen_scope(generation);
+        (void)generation;
         for (int i = 0; i < n_mat; i++) {
             plan_qweight(ggml_type, (int)n_out, (int)n_in, W[i], d_planes.as<uint8_t>() + (size_t)i * need);
             HIP_CHECK(hipMemcpy(d_raw.p, static_cast<const uint8_t *>(raw_w) + (size_t)i * raw_each, raw_each, hipMemcpyHostToDevice));
@@ -623,7 +623,6 @@ int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, 
         if (ks > 0) setenv("MINIGPT4_MMQ2_KS", std::to_string(ks).c_str(), 1);
         const int keep_gen = mmq_enabled();
         set_mmq_enabled(std::min(generation, 2));
-        struct Gen { int keep; Gen(int g) : keep(mmq_scaled_operands()) { set_mmq_scaled_operands(g >= 3 ? 1 : 0); } ~Gen() { set_mmq_scaled_operands(keep); } } gen_scope(generation);
         const QWeight *Wp[3]; float *Yp[3];
         for (int m = 0; m < n_mat; m++) { Wp[m] = &W[m]; Yp[m] = dy.as<float>() + (size_t)m * out_each; }
         auto run = [&]() {

@@ -107,7 +107,6 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     defer_ = !(getenv("MINIGPT4_NO_DEFER") && atoi(getenv("MINIGPT4_NO_DEFER")));
     max_chunk_ = max_rows_;
     if (getenv("MINIGPT4_NO_MMQ")) set_mmq_enabled(atoi(getenv("MINIGPT4_NO_MMQ")) ? 0 : 2);
-    if (getenv("MINIGPT4_MMQ_SCALED")) set_mmq_scaled_operands(atoi(getenv("MINIGPT4_MMQ_SCALED")));   // Q4_K / Q5_K prefill: 0 = integer scale multiply-adds after the MFMAs (A/B)
     if (getenv("MINIGPT4_MMQ")) set_mmq_enabled(atoi(getenv("MINIGPT4_MMQ")));   // 0: v_dot4 tiles, 1: round-1 int8-MFMA prefill kernels, 2 (default): LDS-staged second generation
     if (getenv("MINIGPT4_ATTN_MFMA")) set_attn_mfma(atoi(getenv("MINIGPT4_ATTN_MFMA")));
     // Decode: which activation preparations run inside the consuming mat-vec's prologue (one fat workgroup per CU repeats the row preparation while

@@ -36,8 +36,6 @@ int mmq_enabled();
 bool mmq2_supported(int type, int rows, int cols);
 bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s);
 void set_mmq2_cus(int cus);
-void set_mmq_scaled_operands(int v);   // Q4_K / Q5_K prefill: 1 (default) = scales folded into the int8 MFMA operands, 0 = integer scale multiply-adds after the MFMAs; bit-identical results
-int mmq_scaled_operands();
 void launch_slab_reduce(const float *slabs, int n_slabs, long long slab_stride, const float *residual, float *y, size_t n, hipStream_t s);   // y = (residual +) sum_z slab_z, fixed order
 // F16 weights at prompt sizes: 1..3 equally spaced [N][K] matrices x M fp16 rows in one launch of the 128x128 LDS-DMA GEMM (split K when the tiles do not fill the chip);
 // false -> outside this path, nothing launched

@@ -22,8 +22,11 @@
 // minus 128 and corrected through the staged per-32 sums), so that a token tile is two K = 256 accumulation chains and the per-(row, token, sub-block) integer
 // multiply-adds disappear.  Bit-identical to this kernel on every test shape, but 64 operand registers + 5-tile chunks meant one wave per SIMD, and the launches
 // were 1.4-1.8x SLOWER (13B layer at 142 rows: qkv 118 vs 64 us, w1|w3 169 vs 101, w2 93 vs 61; whole prefill 18.3 vs 13.2 ms).  The kernel is latency-bound at
-// one wave per SIMD long before the VALU work it saved matters; a pair-outer / tile-inner variant that keeps two waves per SIMD would cut the VALU work by only
-// ~1.36x at two tiles per chunk and was not built.
+// one wave per SIMD long before the VALU work it saved matters.  Third attempt (profiles/r02p_prefill_scaled_operands_pair_outer_microbench.log): the same arithmetic
+// with the sub-block PAIRS as the outer loop and the token tiles inside, so that one pair's four scaled operands (16 registers) are live at a time and two waves per
+// SIMD fit (256 VGPRs, <= 236 B of scratch at 3 tiles): bit-identical again, and 2.4x SLOWER than this kernel (qkv 154 vs 64 us, w1|w3 247 vs 99 at 142 rows; 123 / 199
+// with two tiles per chunk).  Folding the scales into the operands doubles the MFMAs per token tile (two digit chains + the offset correction: 20 vs 10) and makes them
+// dependent accumulation chains; the multiply-adds it removes were overlapping with the MFMAs of the other resident waves anyway.  The scale multiply-adds stay.
 // Measured and removed (profiles/r02g_prefill_generations_microbench.log): pre-scaled "prefill planes" -- sub-block scale x quant stored as two int8 digits,
 // 2 bytes per weight, so that the scales ride inside the MFMA accumulation (exact, bit-identical results, 41 % fewer VALU instructions) -- lost on Q4_K / Q5_K
 // (w1|w3 at 142 rows: 155 vs 100 us): 2.8 x the weight bytes per chunk of <= 96 tokens turned the kernel into a latency-bound HBM stream; it won only on Q6_K.
@@ -258,156 +261,6 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
                         const int r = 4 * q4 + e;
                         acc[tt][r] = fmaf(dw * da[e], (float)isum[r], acc[tt][r]);
                         acc[tt][r] = fmaf(ndmin * da[e], (float)(D[0][1][r] * 128 + D[0][0][r]), acc[tt][r]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-    mmq2_store<TT>(acc, a, m, r0 + l31, W.rows, t0, my_tiles, hh);
-}
-
-// four bytes (each <= 31) times a 3-bit digit replicated into both halves of d2: one packed 16-bit multiply, no carries between the bytes (digit * byte <= 217)
-typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int pkmul16(int x, unsigned d2) { const us2_t a = __builtin_bit_cast(us2_t, x), b = __builtin_bit_cast(us2_t, d2); return __builtin_bit_cast(int, (us2_t)(a * b)); }
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Q4_K / Q5_K with the sub-block scales folded into the int8 operands (third form; the first attempt -- all 8 sub-blocks' operands resident, 5-tile chunks, one wave
-// per SIMD -- lost, see the file header).  sc = 8 hi + lo (3-bit digits); digit x quant <= 7 x 31 fits a byte, one v_pk_mul_lo_u16 scales four weights; Q5_K bytes are
-// stored minus 128 (x ^ 0x80) and 128 x sum(a) is added back per digit through the staged per-32 sums (1152 x the token's super-block sum).  The sub-block PAIRS are
-// the outer loop and the token tiles the inner one, so only one pair's operands (16 registers) are live and the kernel keeps two waves per SIMD.  All integer, all
-// exact: bit-identical to k_mmq2_q45k.
-// ---------------------------------------------------------------------------------------------------------------------
-template <bool Q5, int TT>
-__global__ __launch_bounds__(256, 2) void k_mmq2s_q45k(const Mmq2Args a, const ActQ A) {
-    using S = Mmq2Stage<TT>;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_mmq2[];   // [2 activation stages][4 waves x 4 KiB weight transpose scratch]
-    const int lane = threadIdx.x & 63, hh = lane >> 5, l31 = lane & 31;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m = blockIdx.x / a.groups_each, g = blockIdx.x - m * a.groups_each;
-    const QWeight W = a.w[m];
-    const int K = W.cols, U = K / 32, NSB = K / 256, N = a.N;
-    const int r0 = (g * 4 + wv) * 32;
-    const int row = min(r0 + l31, W.rows - 1);
-    const int tile0 = blockIdx.y * a.tiles_per_chunk, my_tiles = min(TT, a.n_tiles - tile0), t0 = tile0 * 32;
-    const int sb0 = blockIdx.z * a.sb_per_split, sb1 = min(NSB, sb0 + a.sb_per_split);
-    unsigned char *scratch = smem_mmq2 + 2 * S::BYTES + wv * 4096;
-
-    float acc[TT][16];
-#pragma unroll
-    for (int tt = 0; tt < TT; tt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[tt][r] = 0.0f;
-
-    // Weight requests of one super-block, COALESCED (a lane-per-row gather costs 32 cache-line requests per instruction and the address path, not HBM, becomes the
-    // bound -- measured: the staging loop alone took 58 % of the round-2a kernel): main plane: instruction n reads rows 8 n .. 8 n + 7 x the super-block's 8 units
-    // (128 contiguous bytes per row); high-bit plane: lane (row, hh) reads the 16 bytes of units 4 hh .. 4 hh + 3; header: 16 bytes per row.
-    struct Raw { v4i q[4]; v4i p; v4i h; };
-    const unsigned char *wq[4];
-#pragma unroll
-    for (int n = 0; n < 4; n++) wq[n] = W.qs + ((size_t)min(r0 + 8 * n + (lane >> 3), W.rows - 1) * U + (lane & 7)) * 16;
-    const unsigned char *wp = W.qh + (size_t)row * U * 4 + hh * 16, *wh = W.sc + (size_t)row * NSB * 16;
-    auto fetch = [&](int sb, Raw &w) {
-#pragma unroll
-        for (int n = 0; n < 4; n++) w.q[n] = ldg16(wq[n] + (size_t)sb * 128);
-        if (Q5) w.p = ldg16(wp + (size_t)sb * 32);
-        w.h = ldg16(wh + (size_t)sb * 16);
-    };
-    // transpose scratch: [32 rows][8 units x 16 B], unit u of row r at slot u ^ ((r >> 1) & 7) (conflict-free for the row-per-lane fragment reads)
-    unsigned sw_addr[4], sr_addr[4];
-#pragma unroll
-    for (int n = 0; n < 4; n++) sw_addr[n] = (unsigned)((8 * n + (lane >> 3)) * 128 + (((lane & 7) ^ ((4 * n + (lane >> 4)) & 7)) << 4));
-#pragma unroll
-    for (int jp = 0; jp < 4; jp++) sr_addr[jp] = (unsigned)(l31 * 128 + (((2 * jp + hh) ^ ((l31 >> 1) & 7)) << 4));
-    // per-lane LDS read addresses (stage 0): A fragment of chunk C = 4 jp + 2 x (x = 0: low-nibble sub-block, 1: high) for token l31 of tile 0
-    const int v = hh ^ (lane & 15);
-    unsigned a_addr[8];
-#pragma unroll
-    for (int c8 = 0; c8 < 8; c8++) a_addr[c8] = (unsigned)(l31 * 256 + (((2 * c8) ^ v) << 4));
-    const unsigned bs_addr = (unsigned)(S::Q8 + l31 * 16), dk_addr = (unsigned)(S::Q8 + S::BS + 16 * hh);
-
-    Raw raw;
-    fetch(sb0, raw);
-    mmq2_stage_load<TT>(A, K, NSB, N, t0, sb0, smem_mmq2, wv, lane);
-    for (int sb = sb0; sb < sb1; sb++) {
-        const int buf = (sb - sb0) & 1;
-        unsigned char *st = smem_mmq2 + buf * S::BYTES;
-        __syncthreads();                                           // own DMA + weight loads done (vmcnt(0) is part of the barrier's fence), then everybody's
-        // ---- this super-block's weights: transpose through LDS (same wave writes and reads: LDS operations of a wave execute in order), unpack into MFMA B operands
-#pragma unroll
-        for (int n = 0; n < 4; n++) *reinterpret_cast<v4i *>(scratch + sw_addr[n]) = raw.q[n];
-        unsigned P[4] = {0u, 0u, 0u, 0u};
-        if (Q5) {   // lanes hh = 0 hold the high bits of units 0..3, hh = 1 of units 4..7: lane (row, hh) needs units 2 jp + hh
-            const auto s01 = __builtin_amdgcn_permlane32_swap((unsigned)raw.p[0], (unsigned)raw.p[1], false, false);
-            const auto s23 = __builtin_amdgcn_permlane32_swap((unsigned)raw.p[2], (unsigned)raw.p[3], false, false);
-            P[0] = s01[0]; P[2] = s01[1]; P[1] = s23[0]; P[3] = s23[1];
-        }
-        const unsigned s0 = (unsigned)raw.h[1], s1 = (unsigned)raw.h[2], s2 = (unsigned)raw.h[3];
-        const unsigned scw0 = s0 & 0x3f3f3f3fu, scw1 = (s2 & 0x0f0f0f0fu) | (((s0 >> 6) & 0x03030303u) << 4);          // scales of sub-blocks 0..3 / 4..7, one byte each
-        const unsigned mw0 = s1 & 0x3f3f3f3fu, mw1 = ((s2 >> 4) & 0x0f0f0f0fu) | (((s1 >> 6) & 0x03030303u) << 4);     // mins
-        const float dw = h2f_b((unsigned)raw.h[0] & 0xFFFF), ndmin = -h2f_b((unsigned)raw.h[0] >> 16);
-        const v4i bm_lo = {hh ? 0 : (int)mw0, hh ? 0 : (int)mw1, 0, 0}, bm_hi = {0, 0, hh ? 0 : (int)mw0, hh ? 0 : (int)mw1};
-        const v4i one_lo = {hh ? 0 : 0x01010101, hh ? 0 : 0x01010101, 0, 0}, one_hi = {0, 0, hh ? 0 : 0x01010101, hh ? 0 : 0x01010101};
-        __builtin_amdgcn_sched_barrier(0);                         // the raw registers are dead from here: the next super-block's loads reuse them (no second register stage)
-        {
-            const int sbn = min(sb + 1, sb1 - 1);
-            fetch(sbn, raw);
-            mmq2_stage_load<TT>(A, K, NSB, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- sub-block pairs outermost: a pair's four scaled operands (16 registers) exist only while the TT token tiles consume them; the two accumulation chains
-        // of every tile (8 x the 3-bit high digit of the scale, the low digit) run over the whole super-block
-        v16i SH[TT], SL[TT];
-#pragma unroll
-        for (int tt = 0; tt < TT; tt++) { SH[tt] = zero16(); SL[tt] = zero16(); }
-#pragma unroll
-        for (int jp = 0; jp < 4; jp++) {
-            v4i q = *reinterpret_cast<const v4i *>(scratch + sr_addr[jp]); const unsigned Pj = P[jp];
-            asm volatile("" : "+v"(q));      // pins this pair's unpack arithmetic here: hoisted above the previous pairs' MFMAs it would keep all four pairs' operands (64 registers) live
-            const unsigned sa = (((jp & 2) ? scw1 : scw0) >> (16 * (jp & 1))) & 0xFFu, sb_ = (((jp & 2) ? scw1 : scw0) >> (16 * (jp & 1) + 8)) & 0xFFu;   // scales of sub-blocks 2 jp, 2 jp + 1
-            const unsigned ha = (sa >> 3) * 0x00010001u, la = (sa & 7u) * 0x00010001u, hb = (sb_ >> 3) * 0x00010001u, lb = (sb_ & 7u) * 0x00010001u;
-            v4i W1a, W2a, W1b, W2b;
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const int lo = (q[w] & 0x0F0F0F0F) | (Q5 ? (int)((w == 0 ? Pj << 4 : w == 1 ? Pj << 3 : w == 2 ? Pj << 2 : Pj << 1) & 0x10101010u) : 0);
-                const int hi = ((q[w] >> 4) & 0x0F0F0F0F) | (Q5 ? (int)((w == 0 ? Pj : w == 1 ? Pj >> 1 : w == 2 ? Pj >> 2 : Pj >> 3) & 0x10101010u) : 0);
-                W1a[w] = pkmul16(lo, ha) ^ (Q5 ? (int)0x80808080u : 0); W2a[w] = pkmul16(lo, la) ^ (Q5 ? (int)0x80808080u : 0);
-                W1b[w] = pkmul16(hi, hb) ^ (Q5 ? (int)0x80808080u : 0); W2b[w] = pkmul16(hi, lb) ^ (Q5 ? (int)0x80808080u : 0);
-            }
-#pragma unroll
-            for (int tt = 0; tt < TT; tt++) {
-                if (tt < my_tiles) {
-                    const unsigned char *sq = st + tt * 8192;
-                    const v4i a0 = *reinterpret_cast<const v4i *>(sq + a_addr[2 * jp]), a1 = *reinterpret_cast<const v4i *>(sq + a_addr[2 * jp + 1]);
-                    SH[tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, W1a, SH[tt], 0, 0, 0);
-                    SL[tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, W2a, SL[tt], 0, 0, 0);
-                    SH[tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, W1b, SH[tt], 0, 0, 0);
-                    SL[tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, W2b, SL[tt], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int tt = 0; tt < TT; tt++) {
-            if (tt < my_tiles) {
-                const v4i abs_ = *reinterpret_cast<const v4i *>(st + bs_addr + tt * 512);
-                const v16i D0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, bm_lo, zero16(), 0, 0, 0);
-                const v16i D1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, bm_hi, zero16(), 0, 0, 0);
-                v16i T0 = zero16(), T1 = zero16();
-                if (Q5) {
-                    T0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, one_lo, zero16(), 0, 0, 0);
-                    T1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(abs_, one_hi, zero16(), 0, 0, 0);
-                }
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    const v4f da = *reinterpret_cast<const v4f *>(st + dk_addr + tt * 128 + q4 * 32);   // tokens 8 q4 + 4 hh + 0..3 = accumulator registers 4 q4 .. 4 q4 + 3
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int r = 4 * q4 + e;
-                        int isum = (SH[tt][r] << 3) + SL[tt][r];
-                        if (Q5) isum += 1152 * (T1[r] * 128 + T0[r]);
-                        acc[tt][r] = fmaf(dw * da[e], (float)isum, acc[tt][r]);
-                        acc[tt][r] = fmaf(ndmin * da[e], (float)(D1[r] * 128 + D0[r]), acc[tt][r]);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -749,15 +602,10 @@ static void mmq2_launch_kernel(KernelT kernel, bool &attr_done, dim3 grid, size_
     if (!attr_done) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr_done = true; }
     hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a, A);
 }
-static int g_mmq_scaled_operands = 1;     // Q4_K / Q5_K: 1 = k_mmq2s_q45k (scales folded into the int8 operands), 0 = k_mmq2_q45k (integer scale multiply-adds after the MFMAs)
-void set_mmq_scaled_operands(int v) { g_mmq_scaled_operands = v; }
-int mmq_scaled_operands() { return g_mmq_scaled_operands; }
 template <int TT>
 static void mmq2_launch_tt(int type, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
-    static bool attr[6] = {false, false, false, false, false, false};
+    static bool attr[4] = {false, false, false, false};
     if constexpr (TT <= 3) {
-        if (g_mmq_scaled_operands && type == GT_Q4_K) { mmq2_launch_kernel(&k_mmq2s_q45k<false, TT>, attr[4], grid, lds, s, a, A); return; }
-        if (g_mmq_scaled_operands && type == GT_Q5_K) { mmq2_launch_kernel(&k_mmq2s_q45k<true, TT>, attr[5], grid, lds, s, a, A); return; }
         if (type == GT_Q4_0) { mmq2_launch_kernel(&k_mmq2_q40<TT>, attr[3], grid, lds, s, a, A); return; }
         if (type == GT_Q4_K) { mmq2_launch_kernel(&k_mmq2_q45k<false, TT>, attr[0], grid, lds, s, a, A); return; }
         if (type == GT_Q5_K) { mmq2_launch_kernel(&k_mmq2_q45k<true, TT>, attr[1], grid, lds, s, a, A); return; }
