@@ -210,6 +210,29 @@ void q45_K_levels(const float *x, int nmax, uint8_t *y_d, uint8_t *y_scales, uin
         for (int ii = 0; ii < 32; ii++) { int l = nearest_int((x[32 * j + ii] + dm) / d); l = std::max(0, std::min(nmax, l)); L[32 * j + ii] = (uint8_t)l; }
     }
 }
+// quantize_row_q2_K_reference [UPSTREAM-RECALL]: per 16 weights make_qkx1_quants(16, 3, ..., 5 tries) -> (scale, min); both against the largest of the super-block on
+// 4 bits; levels re-derived against the packed (fp16-rounded) scales; four 2-bit planes per 128 weights.  block_q2_K = {scales[16], qs[64], d, dmin}
+void q2_K_block(const float *x, uint8_t *y) {
+    uint8_t L[256]; float mins[16], scales[16];
+    float max_scale = 0, max_min = 0;
+    for (int j = 0; j < 16; j++) {
+        scales[j] = make_qkx1_quants(16, 3, x + 16 * j, L + 16 * j, &mins[j], 5);
+        if (scales[j] > max_scale) max_scale = scales[j];
+        if (mins[j] > max_min) max_min = mins[j];
+    }
+    uint8_t *ysc = y, *qs = y + 16, *yd = y + 80, *ydm = y + 82;
+    if (max_scale > 0) { const float iscale = 15.f / max_scale; for (int j = 0; j < 16; j++) ysc[j] = (uint8_t)nearest_int(iscale * scales[j]); put16(yd, f2h(max_scale / 15.f)); }
+    else { memset(ysc, 0, 16); put16(yd, f2h(0.f)); }
+    if (max_min > 0) { const float iscale = 15.f / max_min; for (int j = 0; j < 16; j++) ysc[j] |= (uint8_t)(nearest_int(iscale * mins[j]) << 4); put16(ydm, f2h(max_min / 15.f)); }
+    else put16(ydm, f2h(0.f));
+    const float dd = h2f((uint16_t)(yd[0] | (yd[1] << 8))), dmin = h2f((uint16_t)(ydm[0] | (ydm[1] << 8)));
+    for (int j = 0; j < 16; j++) {
+        const float d = dd * (ysc[j] & 0xF); if (!d) continue;
+        const float dm = dmin * (ysc[j] >> 4);
+        for (int ii = 0; ii < 16; ii++) { int l = nearest_int((x[16 * j + ii] + dm) / d); l = std::max(0, std::min(3, l)); L[16 * j + ii] = (uint8_t)l; }
+    }
+    for (int j = 0; j < 256; j += 128) for (int l = 0; l < 32; l++) qs[j / 4 + l] = (uint8_t)(L[j + l] | (L[j + l + 32] << 2) | (L[j + l + 64] << 4) | (L[j + l + 96] << 6));
+}
 void q4_K_block(const float *x, uint8_t *y) {   // {d, dmin, scales[12], qs[128]}
     uint8_t L[256];
     q45_K_levels(x, 15, y, y + 4, L);
@@ -262,7 +285,7 @@ void q6_K_block(const float *x, uint8_t *y) {   // {ql[128], qh[64], scales[16] 
 }  // namespace
 
 bool quantize_supported(int ggml_type) {
-    switch (ggml_type) { case GT_Q4_0: case GT_Q4_1: case GT_Q5_0: case GT_Q5_1: case GT_Q8_0: case GT_Q4_K: case GT_Q5_K: case GT_Q6_K: return true; default: return false; }
+    switch (ggml_type) { case GT_Q4_0: case GT_Q4_1: case GT_Q5_0: case GT_Q5_1: case GT_Q8_0: case GT_Q2_K: case GT_Q4_K: case GT_Q5_K: case GT_Q6_K: return true; default: return false; }
 }
 size_t quantize_chunk(int ggml_type, const float *x, uint8_t *dst, size_t n) {
     const size_t blk = (size_t)gt_block(ggml_type), bytes = (size_t)gt_bytes(ggml_type);
@@ -270,7 +293,7 @@ size_t quantize_chunk(int ggml_type, const float *x, uint8_t *dst, size_t n) {
     void (*fn)(const float *, uint8_t *) = nullptr;
     switch (ggml_type) {
     case GT_Q4_0: fn = q4_0_block; break; case GT_Q4_1: fn = q4_1_block; break; case GT_Q5_0: fn = q5_0_block; break; case GT_Q5_1: fn = q5_1_block; break;
-    case GT_Q8_0: fn = q8_0_block; break; case GT_Q4_K: fn = q4_K_block; break; case GT_Q5_K: fn = q5_K_block; break; default: fn = q6_K_block; break;
+    case GT_Q8_0: fn = q8_0_block; break; case GT_Q2_K: fn = q2_K_block; break; case GT_Q4_K: fn = q4_K_block; break; case GT_Q5_K: fn = q5_K_block; break; default: fn = q6_K_block; break;
     }
     const size_t nb = n / blk;
     // blocks are independent: plain std::thread fan-out (an offline tool; the 13B vision file has ~4 M super-blocks)

@@ -178,6 +178,48 @@ def _q45_levels(x, nmax):
     return d16 + m16 + bytes(sc), L
 
 
+def q2_k(x):
+    """quantize_row_q2_K_reference: {scales[16] (scale | min << 4), qs[64], d, dmin}."""
+    scales, mins, L = [], [], []
+    for j in range(16):
+        s, l, m = make_qkx1_quants(16, 3, x[16 * j:16 * j + 16], 5)
+        scales.append(s); mins.append(m); L += l
+    max_scale, max_min = F(0), F(0)
+    for j in range(16):
+        if scales[j] > max_scale:
+            max_scale = scales[j]
+        if mins[j] > max_min:
+            max_min = mins[j]
+    ysc = [0] * 16
+    if max_scale > 0:
+        iscale = F(F(15) / max_scale)
+        for j in range(16):
+            ysc[j] = nearest_int(F(iscale * scales[j])) & 0xFF
+        d_b = _hbytes(F(max_scale / F(15)))
+    else:
+        d_b = _hbytes(F(0))
+    if max_min > 0:
+        iscale = F(F(15) / max_min)
+        for j in range(16):
+            ysc[j] = (ysc[j] | (nearest_int(F(iscale * mins[j])) << 4)) & 0xFF
+        m_b = _hbytes(F(max_min / F(15)))
+    else:
+        m_b = _hbytes(F(0))
+    dd, dmin = _h(F(max_scale / F(15))) if max_scale > 0 else F(0), _h(F(max_min / F(15))) if max_min > 0 else F(0)
+    for j in range(16):
+        d = F(dd * F(ysc[j] & 0xF))
+        if d == 0:
+            continue
+        dm = F(dmin * F(ysc[j] >> 4))
+        for ii in range(16):
+            L[16 * j + ii] = max(0, min(3, nearest_int(F(F(x[16 * j + ii] + dm) / d))))
+    qs = [0] * 64
+    for j in range(0, 256, 128):
+        for l in range(32):
+            qs[j // 4 + l] = L[j + l] | (L[j + l + 32] << 2) | (L[j + l + 64] << 4) | (L[j + l + 96] << 6)
+    return bytes(ysc) + bytes(qs) + d_b + m_b
+
+
 def q4_k(x):
     head, L = _q45_levels(x, 15)
     qs = bytearray()
@@ -295,7 +337,7 @@ def q6_k(x):
     return bytes(ql) + bytes(qh) + bytes((s & 0xFF) for s in sc) + d16
 
 
-BLOCK_FN = {2: (32, q4_0), 3: (32, q4_1), 6: (32, q5_0), 7: (32, q5_1), 8: (32, q8_0), 12: (256, q4_k), 13: (256, q5_k), 14: (256, q6_k)}
+BLOCK_FN = {2: (32, q4_0), 3: (32, q4_1), 6: (32, q5_0), 7: (32, q5_1), 8: (32, q8_0), 10: (256, q2_k), 12: (256, q4_k), 13: (256, q5_k), 14: (256, q6_k)}
 
 
 def quantize_chunk(ggml_type: int, x: np.ndarray) -> np.ndarray:
