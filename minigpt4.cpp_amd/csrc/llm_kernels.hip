@@ -881,6 +881,9 @@ static size_t mv_tn_lds(int type, int K, int TN) {
     const size_t per_row = kq ? (size_t)K + (size_t)(K / 256) * 4 + (size_t)(K / 16) * 2 : (size_t)K + (size_t)(K / 32) * 16;
     return (size_t)TN * per_row + 64;
 }
+// Are the TN rows' activation fragments register-resident?  512-thread workgroups (two waves per SIMD): 256 registers -> K <= 3 x 64 units at 4 rows, <= 5 x 64 at
+// 2 rows; the widest K (NU = 7, K = 13824: w2) runs 256-thread workgroups, one wave per SIMD, 512 registers -> resident at 2 and at 4 rows (4 x 7 x 10 = 280 registers).
+template <int NU, int TN> constexpr bool mv_tn_reg() { return NU <= 3 || (TN == 2 && NU <= 5) || NU >= 7; }
 template <int NU> constexpr int mv_tn_threads() { return NU >= 7 ? 256 : 512; }   // widest K: one wave per SIMD (up to 512 VGPRs) -- two would spill Q5_K's weight stages; 4 waves x 7 units keep as many bytes in flight as 8 x 3
 // PRO = 1 (K <= 3 x 64 units only): the rows are prepared inside the launch -- rms_norm(x_t) * w and the quantisation of k_rms_quant, row by row with the single-row
 // prologue's arithmetic (matvec_run), into one LDS image per row -- so a batched decode step needs no standalone preparation launch in front of wq|wk|wv and w1|w3.
@@ -888,7 +891,7 @@ static size_t mv_tn_image_bytes(int K) { return ((size_t)2 * K + (size_t)(K / 25
 template <int T, int NU, int TN, int PRO = 0>
 __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet ms, const ActQ A, const int N, const int ldy, const int n_groups, const int n_waves, const ProArgs pa,
                                                                    const int ldx, const int image_bytes) {
-    static_assert(PRO == 0 || NU <= 3, "the prologue variant keeps the prepared rows in registers");
+    static_assert(PRO == 0 || NU <= 3, "the prologue variant: 512-thread workgroups, K <= 3 x 64 units");
     using X = Tr<T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_tn[];
     const int lane = threadIdx.x & 63;
@@ -936,7 +939,7 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
     MG4_TL(1);
     // K <= 3 x 64 units: every lane works on the SAME units of every weight row, so the TN activation fragments live in registers for the whole launch (no LDS
     // image, no barrier, no LDS re-read per weight row -- the LDS variant below re-reads TN x 5 KB per 3.5 KB weight row and is LDS-bandwidth bound).
-    constexpr bool REG = NU <= 3;
+    constexpr bool REG = mv_tn_reg<NU, TN>();
     typename X::AU ar[REG ? TN : 1][REG ? NU : 1];
     if (REG && PRO) {
         constexpr int mask = (T == GT_Q4_K || T == GT_Q5_K || T == GT_Q6_K) ? ACT_Q8K : ACT_Q80;
@@ -1094,7 +1097,7 @@ static void launch_tn_n(const MatSet &ms, const ActQ &A, int N, int ldy, hipStre
         }
     }
     note_kernel("k_matvec_tn<%d, %d, %d, 0>", T, NU, TN);
-    const size_t lds = NU <= 3 ? 0 : mv_tn_lds(T, ms.w0.cols, TN);
+    const size_t lds = mv_tn_reg<NU, TN>() ? 0 : mv_tn_lds(T, ms.w0.cols, TN);
     static bool attr = false;
     if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     hipLaunchKernelGGL((k_matvec_tn<T, NU, TN, 0>), dim3((unsigned)n_blocks), dim3((unsigned)mv_tn_threads<NU>()), lds, s, ms, A, N, ldy, n_groups, n_waves, pa, 0, 0);
