@@ -675,8 +675,8 @@ void Engine::forward_batch(int B, hipStream_t s) {
             else { mm({&L.wq}, {q_}, nullptr, E); mm({&L.wk}, {k_}, nullptr, E); mm({&L.wv}, {v_}, nullptr, E); }
         }
         launch_attn_llm_batched(q_, k_, v_, kc, vc, B, H, hd, d_npast_, d_bslot_, seq_stride, n_ctx_, cos_, sin_, tabs_, att_, s);
-        launch_silu_mul_quant(att_, nullptr, B, E, act_, act_mask_for(L.wo.type), tabs_, s);
-        mm({&L.wo}, {x_}, x_, E);
+        if (rows_pro({&L.wo})) mm({&L.wo}, {x_}, x_, E, att_, nullptr);     // the attention output rows are quantised inside the wo launch
+        else { launch_silu_mul_quant(att_, nullptr, B, E, act_, act_mask_for(L.wo.type), tabs_, s); mm({&L.wo}, {x_}, x_, E); }
         if (L.w1.type == L.w3.type && rows_pro({&L.w1, &L.w3})) mm({&L.w1, &L.w3}, {h1_, h3_}, nullptr, F, x_, L.ffn_norm);
         else {
             launch_rms_quant(x_, L.ffn_norm, B, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s);

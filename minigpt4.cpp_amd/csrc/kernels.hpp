@@ -53,7 +53,7 @@ bool matvec_silu_pair_supported(int type, int cols);
 // batched decode: N = 1..4 activation rows (prepared in `A`) against 1..3 same-type, same-shape, equally spaced matrices, weights streamed once;
 // y[m][t * ldy + r] (+ residual[m][t * ldy + r]).  false -> outside the kernel's range, use launch_mul_mat.
 bool launch_matvec_rows(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s, const float *px = nullptr,
-                        const float *pw = nullptr, int ldx = 0);   // px != null: rows t of x (stride ldx) are rms-normed with pw and quantised inside the launch (A unused)
+                        const float *pw = nullptr, int ldx = 0);   // px != null: rows t of x (stride ldx) are prepared inside the launch (A unused): pw != null rms-normed with pw, pw == null taken as they are; then quantised
 bool matvec_rows_prologue_ok(int type, int K);
 // two k-quant types (Q4_K|Q5_K + Q6_K) with the same K in one launch; pro: 0 or 1 (rms_norm prologue)
 bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, hipStream_t s, int pro = 0,

@@ -930,7 +930,7 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
             const int i = (r * 512 + (int)threadIdx.x) * 4;
             pin[r] = i < K;
             const int ic = pin[r] ? i : 0;
-            pyv[r] = *reinterpret_cast<const float4 *>(pa.w + ic);
+            pyv[r] = PRO == 1 ? *reinterpret_cast<const float4 *>(pa.w + ic) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
 #pragma unroll
             for (int t = 0; t < (PRO ? TN : 1); t++) pxv[t][r] = *reinterpret_cast<const float4 *>(pa.x + (size_t)min(t, N - 1) * ldx + ic);
         }
@@ -944,27 +944,32 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
     if (REG && PRO) {
         constexpr int mask = (T == GT_Q4_K || T == GT_Q5_K || T == GT_Q6_K) ? ACT_Q8K : ACT_Q80;
         double *red = reinterpret_cast<double *>(smem_tn);               // [TN][8 waves]
+        if (PRO == 1) {
 #pragma unroll
-        for (int t = 0; t < (PRO ? TN : 1); t++) {
-            double sum = 0.0;
+            for (int t = 0; t < (PRO ? TN : 1); t++) {
+                double sum = 0.0;
 #pragma unroll
-            for (int r = 0; r < PRND; r++) {
-                const float4 v = pxv[t][r];
-                double q = 0.0;
-                q += (double)(v.x * v.x); q += (double)(v.y * v.y); q += (double)(v.z * v.z); q += (double)(v.w * v.w);
-                sum += pin[r] ? q : 0.0;
+                for (int r = 0; r < PRND; r++) {
+                    const float4 v = pxv[t][r];
+                    double q = 0.0;
+                    q += (double)(v.x * v.x); q += (double)(v.y * v.y); q += (double)(v.z * v.z); q += (double)(v.w * v.w);
+                    sum += pin[r] ? q : 0.0;
+                }
+                sum = wave_sum_d(sum);
+                if (lane == 0) red[t * 8 + (threadIdx.x >> 6)] = sum;
             }
-            sum = wave_sum_d(sum);
-            if (lane == 0) red[t * 8 + (threadIdx.x >> 6)] = sum;
+            __syncthreads();
         }
-        __syncthreads();
         ActQ Li[PRO ? TN : 1];
 #pragma unroll
         for (int t = 0; t < (PRO ? TN : 1); t++) {
-            double tot = 0.0;
-            for (int w = 0; w < 8; w++) tot += red[t * 8 + w];
-            const float mean = (float)(tot / (double)K);
-            const float scale = 1.0f / sqrtf(mean + 1e-6f);
+            float scale = 1.0f;
+            if (PRO == 1) {
+                double tot = 0.0;
+                for (int w = 0; w < 8; w++) tot += red[t * 8 + w];
+                const float mean = (float)(tot / (double)K);
+                scale = 1.0f / sqrtf(mean + 1e-6f);
+            }
             unsigned char *p = smem_tn + 512 + (size_t)t * image_bytes;
             ActQ L{};
             L.q8k = reinterpret_cast<int8_t *>(p); p += (size_t)K;
@@ -979,7 +984,8 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
 #pragma unroll
             for (int r = 0; r < PRND; r++) {
                 const int i = (r * 512 + (int)threadIdx.x) * 4;
-                float v[4] = {(pxv[t][r].x * scale) * pyv[r].x, (pxv[t][r].y * scale) * pyv[r].y, (pxv[t][r].z * scale) * pyv[r].z, (pxv[t][r].w * scale) * pyv[r].w};
+                float v[4] = {pxv[t][r].x, pxv[t][r].y, pxv[t][r].z, pxv[t][r].w};                                     // PRO == 2: the rows as they are (attention output -> wo)
+                if (PRO == 1) { v[0] = (v[0] * scale) * pyv[r].x; v[1] = (v[1] * scale) * pyv[r].y; v[2] = (v[2] * scale) * pyv[r].z; v[3] = (v[3] * scale) * pyv[r].w; }
                 if (!pin[r]) { v[0] = 0.0f; v[1] = 0.0f; v[2] = 0.0f; v[3] = 0.0f; }
                 quant_emit4(v, pin[r], i, 0, K, L, mask);
             }
@@ -1088,11 +1094,13 @@ static void launch_tn_n(const MatSet &ms, const ActQ &A, int N, int ldy, hipStre
     constexpr bool PRO_OK = NU <= 3 && (T == GT_Q4_0 || T == GT_Q4_K || T == GT_Q5_K || T == GT_Q6_K);
     if constexpr (PRO_OK) {
         if (px) {
-            note_kernel("k_matvec_tn<%d, %d, %d, 1>", T, NU, TN);
             const int img = (int)mv_tn_image_bytes(ms.w0.cols);
             static bool attr1 = false;
-            if (!attr1) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr1 = true; }
-            hipLaunchKernelGGL((k_matvec_tn<T, NU, TN, 1>), dim3((unsigned)n_blocks), dim3((unsigned)mv_tn_threads<NU>()), (size_t)512 + (size_t)TN * img, s, ms, A, N, ldy, n_groups, n_waves, pa, ldx, img);
+            if (!attr1) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                          HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr1 = true; }
+            note_kernel("k_matvec_tn<%d, %d, %d, %d>", T, NU, TN, pw ? 1 : 2);
+            if (pw) hipLaunchKernelGGL((k_matvec_tn<T, NU, TN, 1>), dim3((unsigned)n_blocks), dim3((unsigned)mv_tn_threads<NU>()), (size_t)512 + (size_t)TN * img, s, ms, A, N, ldy, n_groups, n_waves, pa, ldx, img);
+            else hipLaunchKernelGGL((k_matvec_tn<T, NU, TN, 2>), dim3((unsigned)n_blocks), dim3((unsigned)mv_tn_threads<NU>()), (size_t)512 + (size_t)TN * img, s, ms, A, N, ldy, n_groups, n_waves, pa, ldx, img);
             return;
         }
     }
