@@ -585,6 +585,21 @@ __global__ __launch_bounds__(256) void k_mmq2_reduce(const float *__restrict__ s
     if (residual) { const float4 t = reinterpret_cast<const float4 *>(residual)[i]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
     reinterpret_cast<float4 *>(y)[i] = s;
 }
+// the same for the 1..3 matrices of a set in ONE launch (blockIdx.y = matrix; its slabs start m * n_slabs * slab_stride floats into the workspace): a prompt pass has
+// three sets per layer, and a 5 us launch per matrix was 11 % of the 142-row image turn
+struct ReduceSet { float *y[3]; const float *res[3]; };
+__global__ __launch_bounds__(256) void k_mmq2_reduce_set(const float *__restrict__ slabs, int n_slabs, long long slab_stride, const ReduceSet rs, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int m = blockIdx.y;
+    const float *sl = slabs + (size_t)m * n_slabs * slab_stride;
+    const float *residual = m == 0 ? rs.res[0] : (m == 1 ? rs.res[1] : rs.res[2]);
+    float *y = m == 0 ? rs.y[0] : (m == 1 ? rs.y[1] : rs.y[2]);
+    float4 s = reinterpret_cast<const float4 *>(sl)[i];
+    for (int z = 1; z < n_slabs; z++) { const float4 t = reinterpret_cast<const float4 *>(sl + (size_t)z * slab_stride)[i]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    if (residual) { const float4 t = reinterpret_cast<const float4 *>(residual)[i]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    reinterpret_cast<float4 *>(y)[i] = s;
+}
 
 // y = (residual +) sum_z slab_z in fixed order, n floats (a multiple of 4) per slab: also the combine step of the split-K F16 GEMM (vision_kernels.hip)
 void launch_slab_reduce(const float *slabs, int n_slabs, long long slab_stride, const float *residual, float *y, size_t n, hipStream_t s) {
@@ -634,7 +649,9 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     const int wgs = n * a.groups_each * n_chunks;
     int ks = 1;
     const size_t out_floats = (size_t)N * ldy;
-    while (wgs * ks < 2 * g_mmq2_cus && NSB / (ks + 1) >= 4 && A.ws && (size_t)(ks + 1) * out_floats * n <= A.ws_floats) ks++;
+    static int fill_pct = -1;     // workgroups per CU (x 100) below which another K slice is added (MINIGPT4_MMQ2_FILL; measured: profiles/r02r_*)
+    if (fill_pct < 0) { const char *e = getenv("MINIGPT4_MMQ2_FILL"); fill_pct = e ? std::max(50, atoi(e)) : 200; }
+    while (wgs * ks * 100 < fill_pct * g_mmq2_cus && NSB / (ks + 1) >= 4 && A.ws && (size_t)(ks + 1) * out_floats * n <= A.ws_floats) ks++;
     if (getenv("MINIGPT4_MMQ2_KS")) ks = std::max(1, std::min(atoi(getenv("MINIGPT4_MMQ2_KS")), std::min(NSB, A.ws ? (int)(A.ws_floats / std::max<size_t>(1, out_floats * n)) : 1)));
     a.sb_per_split = (NSB + ks - 1) / ks;
     ks = (NSB + a.sb_per_split - 1) / a.sb_per_split;
@@ -653,10 +670,10 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     default: throw HipError{hipErrorInvalidValue, "mmq2: bad chunking", __FILE__, __LINE__};
     }
     if (ks > 1) {
-        for (int i = 0; i < n; i++) {
-            const size_t n4 = out_floats / 4;
-            hipLaunchKernelGGL(k_mmq2_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, A.ws + (size_t)i * ks * out_floats, ks, (long long)out_floats, residual ? residual[i] : nullptr, y[i], n4);
-        }
+        const size_t n4 = out_floats / 4;
+        ReduceSet rs{};
+        for (int i = 0; i < n; i++) { rs.y[i] = y[i]; rs.res[i] = residual ? residual[i] : nullptr; }
+        hipLaunchKernelGGL(k_mmq2_reduce_set, dim3((unsigned)((n4 + 255) / 256), (unsigned)n), dim3(256), 0, s, A.ws, ks, (long long)out_floats, rs, n4);
     }
     return true;
 }
