@@ -645,12 +645,12 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     const int n_chunks = (a.n_tiles + max_tt - 1) / max_tt;
     a.tiles_per_chunk = (a.n_tiles + n_chunks - 1) / n_chunks;
     const int NSB = W[0]->cols / 256;
-    // K split: enough workgroups for two per CU, at least 4 super-blocks per slice, slabs must fit the workspace; the slices are combined in fixed order by k_mmq2_reduce
+    // K split: enough workgroups for 1.5 per CU, at least 4 super-blocks per slice, slabs must fit the workspace; the slices are combined in fixed order by k_mmq2_reduce
     const int wgs = n * a.groups_each * n_chunks;
     int ks = 1;
     const size_t out_floats = (size_t)N * ldy;
     static int fill_pct = -1;     // workgroups per CU (x 100) below which another K slice is added (MINIGPT4_MMQ2_FILL; measured: profiles/r02r_*)
-    if (fill_pct < 0) { const char *e = getenv("MINIGPT4_MMQ2_FILL"); fill_pct = e ? std::max(50, atoi(e)) : 200; }
+    if (fill_pct < 0) { const char *e = getenv("MINIGPT4_MMQ2_FILL"); fill_pct = e ? std::max(50, atoi(e)) : 150; }   // 13B image turn: 13.1 ms at 200, 11.7 at 150, 12.6 at 125 / 100 (w1|w3's 432 workgroups are better left unsplit)
     while (wgs * ks * 100 < fill_pct * g_mmq2_cus && NSB / (ks + 1) >= 4 && A.ws && (size_t)(ks + 1) * out_floats * n <= A.ws_floats) ks++;
     if (getenv("MINIGPT4_MMQ2_KS")) ks = std::max(1, std::min(atoi(getenv("MINIGPT4_MMQ2_KS")), std::min(NSB, A.ws ? (int)(A.ws_floats / std::max<size_t>(1, out_floats * n)) : 1)));
     a.sb_per_split = (NSB + ks - 1) / ks;
