@@ -1569,25 +1569,28 @@ __device__ __forceinline__ void ap_stage(float *kv, const __half *__restrict__ c
         for (int i = 0; i < 4; i++) { d[2 * i] = live ? h2f_bits(w[i] & 0xFFFF) : 0.0f; d[2 * i + 1] = live ? h2f_bits(w[i] >> 16) : 0.0f; }
     }
 }
-template <int HD>
+// QS = query sub-tiles of 16 per workgroup: 2 from 256 prompt rows on -- the staged key / value tile (the fp16 -> fp32 conversion and its LDS writes are most of the
+// kernel's time) then serves 32 queries instead of 16.
+template <int HD, int QS>
 __global__ __launch_bounds__(256) void k_attn_prefill(const float *__restrict__ q, const __half *__restrict__ kc, const __half *__restrict__ vc, int E, int N, const int *__restrict__ n_past,
                                                       const Tables tb, float *__restrict__ out, int LS) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ap[];
-    constexpr int LDV = HD + 1, KS = HD / 4, DT = HD / 16;
+    constexpr int LDV = HD + 1, KS = HD / 4, DT = HD / 16, QT = AP_QT * QS;
     static_assert(DT % 4 == 0 || DT == 2, "dim tiles are dealt to the 4 waves");
-    float *S = reinterpret_cast<float *>(smem_ap);                // [16][LS]
-    float *kv = S + (size_t)AP_QT * LS;                           // [64][LDV]
-    const int h = blockIdx.x, q0 = blockIdx.y * AP_QT, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *S = reinterpret_cast<float *>(smem_ap);                // [QT][LS]
+    float *kv = S + (size_t)QT * LS;                              // [64][LDV]
+    const int h = blockIdx.x, q0 = blockIdx.y * QT, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int np = *n_past;
-    const int T = np + min(q0 + AP_QT - 1, N - 1) + 1;            // keys the last query of this tile sees
+    const int T = np + min(q0 + QT - 1, N - 1) + 1;               // keys the last query of this tile sees
     const int nkt = (T + AP_KT - 1) / AP_KT;
     const float scale = 1.0f / sqrtf((float)HD);
     // Q fragments: A[i = lane & 15 (query)][kk = lane >> 4] per k-step, rounded to fp16 like ggml's f16 x f32 mul_mat
-    float qf[KS];
-    {
-        const float *qp = q + (size_t)min(q0 + (lane & 15), N - 1) * E + (size_t)h * HD + (lane >> 4);
+    float qf[QS][KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) qf[ks] = f16r(qp[4 * ks]);
+    for (int qs = 0; qs < QS; qs++) {
+        const float *qp = q + (size_t)min(q0 + 16 * qs + (lane & 15), N - 1) * E + (size_t)h * HD + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) qf[qs][ks] = f16r(qp[4 * ks]);
     }
     for (int kt = 0; kt < nkt; kt++) {
         __syncthreads();
@@ -1595,17 +1598,26 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float *__restrict__ 
         __syncthreads();
         const int key0 = kt * AP_KT + 16 * wave;
         if (key0 < T) {
-            pf4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
             const float *kb = kv + (size_t)(16 * wave + (lane & 15)) * LDV + (lane >> 4);
+            pf4_t acc[QS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[ks], kb[4 * ks], acc, 0, 0, 0);
+            for (int qs = 0; qs < QS; qs++) acc[qs] = pf4_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int r = 0; r < 4; r++) S[(size_t)((lane >> 4) * 4 + r) * LS + key0 + (lane & 15)] = acc[r] * scale;
+            for (int ks = 0; ks < KS; ks++) {
+                const float kval = kb[4 * ks];
+#pragma unroll
+                for (int qs = 0; qs < QS; qs++) acc[qs] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[qs][ks], kval, acc[qs], 0, 0, 0);
+            }
+#pragma unroll
+            for (int qs = 0; qs < QS; qs++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) S[(size_t)(16 * qs + (lane >> 4) * 4 + r) * LS + key0 + (lane & 15)] = acc[qs][r] * scale;
         }
     }
     __syncthreads();
-    {   // softmax: 16 lanes per query row; row r sees keys 0 .. np + q0 + r
-        const int row = tid >> 4, sub = tid & 15;
+#pragma unroll
+    for (int qs = 0; qs < QS; qs++) {   // softmax: 16 lanes per query row; row r sees keys 0 .. np + q0 + r
+        const int row = 16 * qs + (tid >> 4), sub = tid & 15;
         const int Tq = min(np + q0 + row + 1, T);
         float *sr = S + (size_t)row * LS;
         float mx = -INFINITY;
@@ -1625,44 +1637,60 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float *__restrict__ 
     }
     // O = P V: wave w owns dim tiles w, w + 4, ..; accumulators persist across the key tiles
     constexpr int DPW = (DT + 3) / 4;
-    pf4_t oacc[DPW];
+    pf4_t oacc[QS][DPW];
 #pragma unroll
-    for (int i = 0; i < DPW; i++) oacc[i] = pf4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int qs = 0; qs < QS; qs++)
+#pragma unroll
+        for (int i = 0; i < DPW; i++) oacc[qs][i] = pf4_t{0.0f, 0.0f, 0.0f, 0.0f};
     for (int kt = 0; kt < nkt; kt++) {
         __syncthreads();
         ap_stage<HD>(kv, vc, E, h, kt * AP_KT, T, tid);
         __syncthreads();
-        const float *pa = S + (size_t)(lane & 15) * LS + kt * AP_KT + (lane >> 4);
 #pragma unroll
         for (int i = 0; i < DPW; i++) {
             const int dt = wave + 4 * i;
             if (dt < DT) {
                 const float *vb = kv + (size_t)(lane >> 4) * LDV + dt * 16 + (lane & 15);
 #pragma unroll
-                for (int ks = 0; ks < AP_KT / 4; ks++) oacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * ks], vb[(size_t)4 * ks * LDV], oacc[i], 0, 0, 0);
+                for (int ks = 0; ks < AP_KT / 4; ks++) {
+                    const float vval = vb[(size_t)4 * ks * LDV];
+#pragma unroll
+                    for (int qs = 0; qs < QS; qs++)
+                        oacc[qs][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(S[(size_t)(16 * qs + (lane & 15)) * LS + kt * AP_KT + (lane >> 4) + 4 * ks], vval, oacc[qs][i], 0, 0, 0);
+                }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < DPW; i++) {
-        const int dt = wave + 4 * i;
-        if (dt < DT) {
+    for (int qs = 0; qs < QS; qs++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int qrow = q0 + (lane >> 4) * 4 + r;
-                if (qrow < N) out[(size_t)qrow * E + (size_t)h * HD + dt * 16 + (lane & 15)] = oacc[i][r];
+        for (int i = 0; i < DPW; i++) {
+            const int dt = wave + 4 * i;
+            if (dt < DT) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int qrow = q0 + 16 * qs + (lane >> 4) * 4 + r;
+                    if (qrow < N) out[(size_t)qrow * E + (size_t)h * HD + dt * 16 + (lane & 15)] = oacc[qs][i][r];
+                }
             }
         }
-    }
 }
 template <int HD>
 static bool launch_attn_prefill_hd(const float *q, const __half *kc, const __half *vc, int N, int n_head, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
     const int LS = ((t_max + AP_KT - 1) / AP_KT) * AP_KT + 1;
+    static bool attr = false;
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill<HD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                 HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill<HD, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    const char *qe = getenv("MINIGPT4_ATTN_QS2");                       // prompt rows from which a workgroup takes 32 queries (0 = never); read per call: tests toggle it
+    const int qs2_from = qe ? atoi(qe) : 256;
+    const size_t lds2 = ((size_t)2 * AP_QT * LS + (size_t)AP_KT * (HD + 1)) * 4;
+    if (qs2_from > 0 && N >= qs2_from && lds2 <= 160 * 1024 - 512) {
+        hipLaunchKernelGGL((k_attn_prefill<HD, 2>), dim3((unsigned)n_head, (unsigned)((N + 2 * AP_QT - 1) / (2 * AP_QT))), dim3(256), lds2, s, q, kc, vc, n_head * HD, N, n_past, tb, out, LS);
+        return true;
+    }
     const size_t lds = ((size_t)AP_QT * LS + (size_t)AP_KT * (HD + 1)) * 4;
     if (lds > 160 * 1024 - 512) return false;
-    static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL((k_attn_prefill<HD>), dim3((unsigned)n_head, (unsigned)((N + AP_QT - 1) / AP_QT)), dim3(256), lds, s, q, kc, vc, n_head * HD, N, n_past, tb, out, LS);
+    hipLaunchKernelGGL((k_attn_prefill<HD, 1>), dim3((unsigned)n_head, (unsigned)((N + AP_QT - 1) / AP_QT)), dim3(256), lds, s, q, kc, vc, n_head * HD, N, n_past, tb, out, LS);
     return true;
 }
 // N > 1 query rows at positions *n_past .. *n_past + N - 1 (launch_rope_kv has run); t_max >= *n_past + N (the host's view, sizes the LDS score rows).
