@@ -1679,15 +1679,9 @@ template <int HD>
 static bool launch_attn_prefill_hd(const float *q, const __half *kc, const __half *vc, int N, int n_head, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
     const int LS = ((t_max + AP_KT - 1) / AP_KT) * AP_KT + 1;
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill<HD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                 HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill<HD, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    const char *qe = getenv("MINIGPT4_ATTN_QS2");                       // prompt rows from which a workgroup takes 32 queries (0 = never); read per call: tests toggle it
-    const int qs2_from = qe ? atoi(qe) : 256;
-    const size_t lds2 = ((size_t)2 * AP_QT * LS + (size_t)AP_KT * (HD + 1)) * 4;
-    if (qs2_from > 0 && N >= qs2_from && lds2 <= 160 * 1024 - 512) {
-        hipLaunchKernelGGL((k_attn_prefill<HD, 2>), dim3((unsigned)n_head, (unsigned)((N + 2 * AP_QT - 1) / (2 * AP_QT))), dim3(256), lds2, s, q, kc, vc, n_head * HD, N, n_past, tb, out, LS);
-        return true;
-    }
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill<HD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    // (QS = 2 -- 32 queries per staged key / value tile from 256 prompt rows on -- is bit-identical and was measured 2 % SLOWER at 512 rows: 13B Q5_K_M 31.7 vs 31.0 ms,
+    // 13B f16 27.9 vs 27.2 ms, profiles/r02r_prefill_ksplit_fill_sweep.log; half the workgroups, each twice as long: not instantiated.)
     const size_t lds = ((size_t)AP_QT * LS + (size_t)AP_KT * (HD + 1)) * 4;
     if (lds > 160 * 1024 - 512) return false;
     hipLaunchKernelGGL((k_attn_prefill<HD, 1>), dim3((unsigned)n_head, (unsigned)((N + AP_QT - 1) / AP_QT)), dim3(256), lds, s, q, kc, vc, n_head * HD, N, n_past, tb, out, LS);
