@@ -403,3 +403,22 @@ def test_bench_line_is_reproducible_from_committed_profiles():
     assert 0.98 < roof["traffic"] / roof["bytes_per_launch"] < 1.05                       # measured HBM bytes vs algorithmic bytes: no re-reads
     assert abs(roof["kernel_sum_ms_per_token"] - bench["ms_per_step"]) < 0.06 * bench["ms_per_step"]
     assert bench["parity"]["oracle_self_noise"]["mean_logit_rel_range"] * 1.5 >= bench["parity"]["mean_logit_rel_range"]
+
+
+def test_pmc_summary_mfma_busy_is_per_xcd(tmp_path):
+    """tools/pmc_summary.py: SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs (round 1 forgot the / 8 and printed utilisations
+    8 x too small); FETCH_SIZE is in KB and counts half of the streamed bytes on gfx950."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src, dst = tmp_path / "cc.csv", tmp_path / "out.csv"
+    rows = ["Kernel_Name,Counter_Name,Counter_Value"]
+    for _ in range(3):
+        rows += ['"void mg4::k(int)",GRBM_GUI_ACTIVE,80000', '"void mg4::k(int)",SQ_VALU_MFMA_BUSY_CYCLES,2560000', '"void mg4::k(int)",FETCH_SIZE,1000']
+    src.write_text("\n".join(rows) + "\n")
+    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), str(src), str(dst), "test"], check=True, capture_output=True)
+    line = [l for l in dst.read_text().splitlines() if l.startswith('"void')][0].split(",")
+    head = [l for l in dst.read_text().splitlines() if l.startswith("kernel,")][0].split(",")
+    rec = dict(zip(head, line))
+    assert abs(float(rec["mfma_busy_frac"]) - 2560000 / (80000 / 8 * 1024)) < 1e-4          # = 0.25
+    assert abs(float(rec["avg_hbm_read_MB_corrected"]) - 1000 * 1024 * 2 / 1e6) < 1e-2
