@@ -651,10 +651,11 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     const size_t out_floats = (size_t)N * ldy;
     // workgroups per CU (x 100) below which another K slice is added.  Measured on the 142-row image turn (profiles/r02r_prefill_ksplit_fill_sweep.log): 13B (5120-wide
     // matrices) 13.1 ms at 200, 11.7 at 150, 12.6 at 125 / 100 -- w1|w3's 432 workgroups are better left unsplit; 7B (4096 x 4096 wq / wo ...) 7.7 at 200, 8.2 at 150,
-    // 8.0 at 125: small matrices want the deeper split.  MINIGPT4_MMQ2_FILL overrides.
+    // 8.0 at 125: the narrower model wants the deeper split.  MINIGPT4_MMQ2_FILL overrides.
     static int fill_env = -1;
     if (fill_env < 0) { const char *e = getenv("MINIGPT4_MMQ2_FILL"); fill_env = e ? std::max(50, atoi(e)) : 0; }
-    const int fill_pct = fill_env ? fill_env : ((size_t)W[0]->rows * W[0]->cols >= (size_t)24 << 20 ? 150 : 200);
+    // by the model's width (the smaller matrix dimension): rule = 0 / 1 lines of the sweep log are two other rules that lost (by weights per matrix; by workgroup count)
+    const int fill_pct = fill_env ? fill_env : (std::min(W[0]->rows, W[0]->cols) >= 5120 ? 150 : 200);
     while (wgs * ks * 100 < fill_pct * g_mmq2_cus && NSB / (ks + 1) >= 4 && A.ws && (size_t)(ks + 1) * out_floats * n <= A.ws_floats) ks++;
     if (getenv("MINIGPT4_MMQ2_KS")) ks = std::max(1, std::min(atoi(getenv("MINIGPT4_MMQ2_KS")), std::min(NSB, A.ws ? (int)(A.ws_floats / std::max<size_t>(1, out_floats * n)) : 1)));
     a.sb_per_split = (NSB + ks - 1) / ks;
