@@ -78,23 +78,26 @@ struct Mmq2Args {
     long long slab_stride;        // floats between K-split slabs
 };
 
-// Requests stage `sb` of this chunk into LDS buffer `st` (all 4 waves take part; every request is unconditional, indices clamped).
-template <int TT>
-__device__ __forceinline__ void mmq2_stage_load(const ActQ &A, int K, int NSB, int N, int t0, int sb, unsigned char *st, int wv, int lane) {
+// Requests stage `sb` of this chunk into LDS buffer `st` (all WPB waves of the workgroup take part; every request is unconditional, indices clamped).  n_q8: q8 wave-instructions
+// (4 tokens each) that carry live tokens -- the single-wave form (batched decode: a few rows) skips the rest; their LDS rows keep stale bytes that only ever reach
+// accumulator registers of tokens >= N, which are never stored.
+template <int TT, int WPB>
+__device__ __forceinline__ void mmq2_stage_load(const ActQ &A, int K, int NSB, int N, int t0, int sb, unsigned char *st, int wv, int lane, int n_q8) {
     using S = Mmq2Stage<TT>;
-    // q8: TT * 8 wave-instructions of 4 tokens x 16 chunks; wave wv issues instructions wv * 2 TT .. + 2 TT - 1
+    // q8: TT * 8 wave-instructions of 4 tokens x 16 chunks; wave wv issues instructions wv * (8 TT / WPB) .. + 8 TT / WPB - 1
 #pragma unroll
-    for (int k = 0; k < 2 * TT; k++) {
-        const int ii = wv * 2 * TT + k;
+    for (int k = 0; k < 8 * TT / WPB; k++) {
+        const int ii = wv * (8 * TT / WPB) + k;
         const int tl = 4 * ii + (lane >> 4);                 // token within the chunk
         const int c = (lane & 15) ^ (tl & 15);               // logical chunk that lands in slot (lane & 15)
         const int tok = min(t0 + tl, N - 1);
-        dma16(A.q8k + (size_t)tok * K + (size_t)sb * 256 + c * 16, st + ii * 1024);
+        if (WPB == 4 || ii < n_q8) dma16(A.q8k + (size_t)tok * K + (size_t)sb * 256 + c * 16, st + ii * 1024);
     }
-    if (wv == 0) {
+    if (WPB == 1 || wv == 0) {
 #pragma unroll
         for (int j = 0; j < S::TTP / 2; j++) { const int tok = min(t0 + 64 * j + lane, N - 1); dma16(A.bsq + ((size_t)tok * NSB + sb) * 16, st + S::Q8 + j * 1024); }
-    } else if (wv == 1) {
+    }
+    if (WPB == 1 || wv == 1) {
 #pragma unroll
         for (int j = 0; j < S::TTP / 2; j++) { const int tok = min(t0 + 64 * j + lane, N - 1); dma4(A.dk + (size_t)tok * NSB + sb, st + S::Q8 + S::BS + j * 256); }
     }
@@ -127,8 +130,8 @@ __device__ __forceinline__ void mmq2_store(const float (&acc)[TT][16], const Mmq
 // Q4_K / Q5_K.  Unit u of a super-block (16 bytes of the repacked main plane): low nibbles = elements 64 (u >> 1) + 16 (u & 1) + i of sub-block 2 (u >> 1),
 // high nibbles = the same elements of sub-block 2 (u >> 1) + 1.  Pair jp: lanes hh = 0 / 1 hold units 2 jp / 2 jp + 1 -> one K = 32 MFMA per sub-block.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool Q5, int TT>
-__global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const ActQ A) {
+template <bool Q5, int TT, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB, 2) void k_mmq2_q45k(const Mmq2Args a, const ActQ A) {
     using S = Mmq2Stage<TT>;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_mmq2[];   // [2 activation stages][4 waves x 4 KiB weight transpose scratch]
     const int lane = threadIdx.x & 63, hh = lane >> 5, l31 = lane & 31;
@@ -136,11 +139,12 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
     const int m = blockIdx.x / a.groups_each, g = blockIdx.x - m * a.groups_each;
     const QWeight W = a.w[m];
     const int K = W.cols, U = K / 32, NSB = K / 256, N = a.N;
-    const int r0 = (g * 4 + wv) * 32;
+    const int r0 = (g * WPB + wv) * 32;
     const int row = min(r0 + l31, W.rows - 1);
     const int tile0 = blockIdx.y * a.tiles_per_chunk, my_tiles = min(TT, a.n_tiles - tile0), t0 = tile0 * 32;
     const int sb0 = blockIdx.z * a.sb_per_split, sb1 = min(NSB, sb0 + a.sb_per_split);
     unsigned char *scratch = smem_mmq2 + 2 * S::BYTES + wv * 4096;
+    const int n_q8 = (min(N - t0, 32 * TT) + 3) / 4;             // q8 staging instructions that carry live tokens (single-wave form)
 
     float acc[TT][16];
 #pragma unroll
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
 
     Raw raw;
     fetch(sb0, raw);
-    mmq2_stage_load<TT>(A, K, NSB, N, t0, sb0, smem_mmq2, wv, lane);
+    mmq2_stage_load<TT, WPB>(A, K, NSB, N, t0, sb0, smem_mmq2, wv, lane, n_q8);
     for (int sb = sb0; sb < sb1; sb++) {
         const int buf = (sb - sb0) & 1;
         unsigned char *st = smem_mmq2 + buf * S::BYTES;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
         {
             const int sbn = min(sb + 1, sb1 - 1);
             fetch(sbn, raw);
-            mmq2_stage_load<TT>(A, K, NSB, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane);
+            mmq2_stage_load<TT, WPB>(A, K, NSB, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane, n_q8);
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- token tiles.  Within a tile the five MFMA pairs (4 sub-block pairs + the min term) run one step ahead of the integer scale multiply-adds that
@@ -276,8 +280,8 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q45k(const Mmq2Args a, const Ac
 // instruction, 8 bytes per lane; round 1 multiplied K = 32 operands twice with one lane half zeroed, which costs two 4-register operand copies per pair and token tile
 // budget).  Weights are q - 32 in int8; no min term.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TT>
-__global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const ActQ A) {
+template <int TT, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB, 2) void k_mmq2_q6k(const Mmq2Args a, const ActQ A) {
     using S = Mmq2Stage<TT>;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_mmq2[];   // [2 activation stages][4 waves x 4 KiB weight transpose scratch]
     const int lane = threadIdx.x & 63, hh = lane >> 5, l31 = lane & 31;
@@ -285,11 +289,12 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
     const int m = blockIdx.x / a.groups_each, g = blockIdx.x - m * a.groups_each;
     const QWeight W = a.w[m];
     const int K = W.cols, U = K / 32, NSB = K / 256, N = a.N;
-    const int r0 = (g * 4 + wv) * 32;
+    const int r0 = (g * WPB + wv) * 32;
     const int row = min(r0 + l31, W.rows - 1);
     const int tile0 = blockIdx.y * a.tiles_per_chunk, my_tiles = min(TT, a.n_tiles - tile0), t0 = tile0 * 32;
     const int sb0 = blockIdx.z * a.sb_per_split, sb1 = min(NSB, sb0 + a.sb_per_split);
     unsigned char *scratch = smem_mmq2 + 2 * S::BYTES + wv * 4096;
+    const int n_q8 = (min(N - t0, 32 * TT) + 3) / 4;             // q8 staging instructions that carry live tokens (single-wave form)
 
     float acc[TT][16];
 #pragma unroll
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
 
     Raw raw;
     fetch(sb0, raw);
-    mmq2_stage_load<TT>(A, K, NSB, N, t0, sb0, smem_mmq2, wv, lane);
+    mmq2_stage_load<TT, WPB>(A, K, NSB, N, t0, sb0, smem_mmq2, wv, lane, n_q8);
     for (int sb = sb0; sb < sb1; sb++) {
         const int buf = (sb - sb0) & 1;
         unsigned char *st = smem_mmq2 + buf * S::BYTES;
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q6k(const Mmq2Args a, const Act
         {
             const int sbn = min(sb + 1, sb1 - 1);
             fetch(sbn, raw);
-            mmq2_stage_load<TT>(A, K, NSB, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane);
+            mmq2_stage_load<TT, WPB>(A, K, NSB, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane, n_q8);
         }
         __builtin_amdgcn_sched_barrier(0);
         // eight half-pair steps per tile (low / high nibble part of pair p), MFMAs one step ahead of the scale multiply-adds
@@ -440,29 +445,35 @@ template <int TT> struct Mmq2Stage80 {
     static constexpr int Q8 = TT * 32 * 256, DS = 8 * TTP * 32 * 4;      // q8 as Mmq2Stage; scales [8 blocks][TTP * 32 tokens] fp32 (token-contiguous: 4 accumulator registers = 16 bytes)
     static constexpr int BYTES = Q8 + DS;
 };
-template <int TT>
-__device__ __forceinline__ void mmq2_stage_load80(const ActQ &A, int K, int N, int t0, int sb, unsigned char *st, int wv, int lane, const unsigned (&tokoff)[Mmq2Stage80<TT>::TTP / 2]) {
+template <int TT, int WPB>
+__device__ __forceinline__ void mmq2_stage_load80(const ActQ &A, int K, int N, int t0, int sb, unsigned char *st, int wv, int lane, const unsigned (&tokoff)[Mmq2Stage80<TT>::TTP / 2], int n_q8) {
     using S = Mmq2Stage80<TT>;
 #pragma unroll
-    for (int k = 0; k < 2 * TT; k++) {
-        const int ii = wv * 2 * TT + k;
+    for (int k = 0; k < 8 * TT / WPB; k++) {
+        const int ii = wv * (8 * TT / WPB) + k;
         const int tl = 4 * ii + (lane >> 4);
         const int c = (lane & 15) ^ (tl & 15);
         const int tok = min(t0 + tl, N - 1);
-        dma16(A.q80 + (size_t)tok * K + (size_t)sb * 256 + c * 16, st + ii * 1024);
+        if (WPB == 4 || ii < n_q8) dma16(A.q80 + (size_t)tok * K + (size_t)sb * 256 + c * 16, st + ii * 1024);
     }
-    // scales: instruction (b, j) = block b of the super-chunk, tokens 64 j + lane; wave wv takes blocks wv and wv + 4.  tokoff[j] (this lane's row offset into d0) is
-    // computed once by the caller: rebuilding 64-bit addresses per instruction is cheaper than the 16 hoisted pointer pairs hipcc otherwise keeps (and spills)
+    // scales: instruction (b, j) = block b of the super-chunk, tokens 64 j + lane; wave wv takes blocks wv and wv + 4 (the single wave: all 8).  tokoff[j] (this lane's row
+    // offset into d0) is computed once by the caller: rebuilding 64-bit addresses per instruction is cheaper than the 16 hoisted pointer pairs hipcc otherwise keeps (and spills)
     constexpr int HJ = S::TTP / 2;
 #pragma unroll
     for (int j = 0; j < HJ; j++) {
-        const float *pj = A.d0 + (size_t)tokoff[j] + (size_t)sb * 8 + wv;
-        dma4(pj, st + S::Q8 + (wv * S::TTP * 32 + 64 * j) * 4);
-        dma4(pj + 4, st + S::Q8 + ((wv + 4) * S::TTP * 32 + 64 * j) * 4);
+        if (WPB == 4) {
+            const float *pj = A.d0 + (size_t)tokoff[j] + (size_t)sb * 8 + wv;
+            dma4(pj, st + S::Q8 + (wv * S::TTP * 32 + 64 * j) * 4);
+            dma4(pj + 4, st + S::Q8 + ((wv + 4) * S::TTP * 32 + 64 * j) * 4);
+        } else {
+            const float *pj = A.d0 + (size_t)tokoff[j] + (size_t)sb * 8;
+#pragma unroll
+            for (int b = 0; b < 8; b++) dma4(pj + b, st + S::Q8 + (b * S::TTP * 32 + 64 * j) * 4);
+        }
     }
 }
-template <int TT>
-__global__ __launch_bounds__(256, 2) void k_mmq2_q40(const Mmq2Args a, const ActQ A) {
+template <int TT, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB, 2) void k_mmq2_q40(const Mmq2Args a, const ActQ A) {
     using S = Mmq2Stage80<TT>;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_mmq2[];   // [2 activation stages][4 waves x 4 KiB weight transpose scratch]
     const int lane = threadIdx.x & 63, hh = lane >> 5, l31 = lane & 31;
@@ -470,11 +481,12 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q40(const Mmq2Args a, const Act
     const int m = blockIdx.x / a.groups_each, g = blockIdx.x - m * a.groups_each;
     const QWeight W = a.w[m];
     const int K = W.cols, U = K / 32, NSB = K / 256, N = a.N;
-    const int r0 = (g * 4 + wv) * 32;
+    const int r0 = (g * WPB + wv) * 32;
     const int row = min(r0 + l31, W.rows - 1);
     const int tile0 = blockIdx.y * a.tiles_per_chunk, my_tiles = min(TT, a.n_tiles - tile0), t0 = tile0 * 32;
     const int sb0 = blockIdx.z * a.sb_per_split, sb1 = min(NSB, sb0 + a.sb_per_split);
     unsigned char *scratch = smem_mmq2 + 2 * S::BYTES + wv * 4096;
+    const int n_q8 = (min(N - t0, 32 * TT) + 3) / 4;             // q8 staging instructions that carry live tokens (single-wave form)
 
     typedef float v16f_t __attribute__((ext_vector_type(16)));
     v16f_t acc[TT];
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q40(const Mmq2Args a, const Act
     for (int j = 0; j < S::TTP / 2; j++) tokoff[j] = (unsigned)min(t0 + 64 * j + lane, N - 1) * (unsigned)(K / 32);
     Raw raw;
     fetch(sb0, raw);
-    mmq2_stage_load80<TT>(A, K, N, t0, sb0, smem_mmq2, wv, lane, tokoff);
+    mmq2_stage_load80<TT, WPB>(A, K, N, t0, sb0, smem_mmq2, wv, lane, tokoff, n_q8);
     for (int sb = sb0; sb < sb1; sb++) {
         const int buf = (sb - sb0) & 1;
         unsigned char *st = smem_mmq2 + buf * S::BYTES;
@@ -532,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void k_mmq2_q40(const Mmq2Args a, const Act
         {
             const int sbn = min(sb + 1, sb1 - 1);
             fetch(sbn, raw);
-            mmq2_stage_load80<TT>(A, K, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane, tokoff);
+            mmq2_stage_load80<TT, WPB>(A, K, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane, tokoff, n_q8);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -613,22 +625,34 @@ static int g_mmq2_cus = 256;
 void set_mmq2_cus(int cus) { if (cus > 0) g_mmq2_cus = cus; }
 
 template <typename KernelT>
-static void mmq2_launch_kernel(KernelT kernel, bool &attr_done, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
+static void mmq2_launch_kernel(KernelT kernel, bool &attr_done, dim3 grid, int threads, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
     if (!attr_done) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr_done = true; }
-    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a, A);
+    hipLaunchKernelGGL(kernel, grid, dim3((unsigned)threads), lds, s, a, A);
 }
 template <int TT>
 static void mmq2_launch_tt(int type, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
     static bool attr[4] = {false, false, false, false};
     if constexpr (TT <= 3) {
-        if (type == GT_Q4_0) { mmq2_launch_kernel(&k_mmq2_q40<TT>, attr[3], grid, lds, s, a, A); return; }
-        if (type == GT_Q4_K) { mmq2_launch_kernel(&k_mmq2_q45k<false, TT>, attr[0], grid, lds, s, a, A); return; }
-        if (type == GT_Q5_K) { mmq2_launch_kernel(&k_mmq2_q45k<true, TT>, attr[1], grid, lds, s, a, A); return; }
+        if (type == GT_Q4_0) { mmq2_launch_kernel(&k_mmq2_q40<TT>, attr[3], grid, 256, lds, s, a, A); return; }
+        if (type == GT_Q4_K) { mmq2_launch_kernel(&k_mmq2_q45k<false, TT>, attr[0], grid, 256, lds, s, a, A); return; }
+        if (type == GT_Q5_K) { mmq2_launch_kernel(&k_mmq2_q45k<true, TT>, attr[1], grid, 256, lds, s, a, A); return; }
     }
     if constexpr (TT <= 2) {
-        if (type == GT_Q6_K) { mmq2_launch_kernel(&k_mmq2_q6k<TT>, attr[2], grid, lds, s, a, A); return; }
+        if (type == GT_Q6_K) { mmq2_launch_kernel(&k_mmq2_q6k<TT>, attr[2], grid, 256, lds, s, a, A); return; }
     }
     throw HipError{hipErrorInvalidValue, "mmq2: token tiles per chunk outside the kernel's register budget", __FILE__, __LINE__};
+}
+// single-wave workgroups (one token tile, N <= 32: batched decode of 5..32 conversations): a workgroup = 32 weight rows x the whole K range it is given, so a layer's
+// launches have 160 .. 864 workgroups without a K split
+static void mmq2_launch_w1(int type, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
+    static bool attr[4] = {false, false, false, false};
+    switch (type) {
+    case GT_Q4_0: mmq2_launch_kernel(&k_mmq2_q40<1, 1>, attr[3], grid, 64, lds, s, a, A); return;
+    case GT_Q4_K: mmq2_launch_kernel(&k_mmq2_q45k<false, 1, 1>, attr[0], grid, 64, lds, s, a, A); return;
+    case GT_Q5_K: mmq2_launch_kernel(&k_mmq2_q45k<true, 1, 1>, attr[1], grid, 64, lds, s, a, A); return;
+    case GT_Q6_K: mmq2_launch_kernel(&k_mmq2_q6k<1, 1>, attr[2], grid, 64, lds, s, a, A); return;
+    default: throw HipError{hipErrorInvalidValue, "mmq2: type", __FILE__, __LINE__};
+    }
 }
 
 // 1..3 same-type, same-shape matrices against the N prepared activation rows in one launch.  y[m][t * ldy + r] (+ residual[m][..]).  false -> shape outside the
@@ -638,8 +662,11 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     for (int i = 0; i < n; i++) if (!mmq2_supported(W[i]->type, W[i]->rows, W[i]->cols) || W[i]->type != W[0]->type || W[i]->rows != W[0]->rows || W[i]->cols != W[0]->cols) return false;
     Mmq2Args a{};
     for (int i = 0; i < n; i++) { a.w[i] = *W[i]; a.y[i] = y[i]; a.res[i] = residual ? residual[i] : nullptr; }
-    a.n_mat = n; a.groups_each = (W[0]->rows + 127) / 128; a.N = N; a.ldy = ldy;
     a.n_tiles = (N + 31) / 32;
+    static int w1_env = -1;
+    if (w1_env < 0) { const char *e = getenv("MINIGPT4_MMQ2_W1"); w1_env = e ? atoi(e) : 1; }
+    const bool w1 = w1_env && a.n_tiles == 1;            // one token tile: single-wave workgroups of 32 rows
+    a.n_mat = n; a.groups_each = w1 ? (W[0]->rows + 31) / 32 : (W[0]->rows + 127) / 128; a.N = N; a.ldy = ldy;
     int max_tt = W[0]->type == GT_Q6_K ? 2 : 3;          // token tiles per chunk the 256-register budget (two waves per SIMD) admits: Q6_K keeps four half-masked operand sets per pair
     { static int tt_env = -1; if (tt_env < 0) { const char *e = getenv("MINIGPT4_MMQ2_TT"); tt_env = e ? atoi(e) : 0; } if (tt_env > 0) max_tt = std::min(max_tt, tt_env); }   // experiments
     const int n_chunks = (a.n_tiles + max_tt - 1) / max_tt;
@@ -668,7 +695,8 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     const dim3 grid((unsigned)(n * a.groups_each), (unsigned)n_chunks, (unsigned)ks);
     const int type = W[0]->type;
     const bool q40 = type == GT_Q4_0;
-    switch (a.tiles_per_chunk) {
+    if (w1) mmq2_launch_w1(type, grid, 2 * (q40 ? Mmq2Stage80<1>::BYTES : Mmq2Stage<1>::BYTES) + 4096, s, a, A);
+    else switch (a.tiles_per_chunk) {
     case 1: mmq2_launch_tt<1>(type, grid, 2 * (q40 ? Mmq2Stage80<1>::BYTES : Mmq2Stage<1>::BYTES) + 16384, s, a, A); break;
     case 2: mmq2_launch_tt<2>(type, grid, 2 * (q40 ? Mmq2Stage80<2>::BYTES : Mmq2Stage<2>::BYTES) + 16384, s, a, A); break;
     case 3: mmq2_launch_tt<3>(type, grid, 2 * (q40 ? Mmq2Stage80<3>::BYTES : Mmq2Stage<3>::BYTES) + 16384, s, a, A); break;
