@@ -642,18 +642,9 @@ static void mmq2_launch_tt(int type, dim3 grid, size_t lds, hipStream_t s, const
     }
     throw HipError{hipErrorInvalidValue, "mmq2: token tiles per chunk outside the kernel's register budget", __FILE__, __LINE__};
 }
-// single-wave workgroups (one token tile, N <= 32: batched decode of 5..32 conversations): a workgroup = 32 weight rows x the whole K range it is given, so a layer's
-// launches have 160 .. 864 workgroups without a K split
-static void mmq2_launch_w1(int type, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
-    static bool attr[4] = {false, false, false, false};
-    switch (type) {
-    case GT_Q4_0: mmq2_launch_kernel(&k_mmq2_q40<1, 1>, attr[3], grid, 64, lds, s, a, A); return;
-    case GT_Q4_K: mmq2_launch_kernel(&k_mmq2_q45k<false, 1, 1>, attr[0], grid, 64, lds, s, a, A); return;
-    case GT_Q5_K: mmq2_launch_kernel(&k_mmq2_q45k<true, 1, 1>, attr[1], grid, 64, lds, s, a, A); return;
-    case GT_Q6_K: mmq2_launch_kernel(&k_mmq2_q6k<1, 1>, attr[2], grid, 64, lds, s, a, A); return;
-    default: throw HipError{hipErrorInvalidValue, "mmq2: type", __FILE__, __LINE__};
-    }
-}
+// (Single-wave workgroups -- 32 weight rows x the whole K range, 160 .. 864 workgroups per launch without a K split -- were built for one-tile launches (batched decode of
+// 5..32 conversations), bit-identical, and measured SLOWER than the 4-wave form with its K split: 13B layer at 8 rows qkv 25.3 vs 18.9 us, w2 25.9 vs 21.0, w2 Q6_K 38.2 vs
+// 28.3 (profiles/r02x_prefill_single_wave_workgroups_microbench.log).  The WPB template parameter stays at 4.)
 
 // 1..3 same-type, same-shape matrices against the N prepared activation rows in one launch.  y[m][t * ldy + r] (+ residual[m][..]).  false -> shape outside the
 // kernel's range (nothing launched).
@@ -663,10 +654,7 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     Mmq2Args a{};
     for (int i = 0; i < n; i++) { a.w[i] = *W[i]; a.y[i] = y[i]; a.res[i] = residual ? residual[i] : nullptr; }
     a.n_tiles = (N + 31) / 32;
-    static int w1_env = -1;
-    if (w1_env < 0) { const char *e = getenv("MINIGPT4_MMQ2_W1"); w1_env = e ? atoi(e) : 1; }
-    const bool w1 = w1_env && a.n_tiles == 1;            // one token tile: single-wave workgroups of 32 rows
-    a.n_mat = n; a.groups_each = w1 ? (W[0]->rows + 31) / 32 : (W[0]->rows + 127) / 128; a.N = N; a.ldy = ldy;
+    a.n_mat = n; a.groups_each = (W[0]->rows + 127) / 128; a.N = N; a.ldy = ldy;
     int max_tt = W[0]->type == GT_Q6_K ? 2 : 3;          // token tiles per chunk the 256-register budget (two waves per SIMD) admits: Q6_K keeps four half-masked operand sets per pair
     { static int tt_env = -1; if (tt_env < 0) { const char *e = getenv("MINIGPT4_MMQ2_TT"); tt_env = e ? atoi(e) : 0; } if (tt_env > 0) max_tt = std::min(max_tt, tt_env); }   // experiments
     const int n_chunks = (a.n_tiles + max_tt - 1) / max_tt;
@@ -695,8 +683,7 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     const dim3 grid((unsigned)(n * a.groups_each), (unsigned)n_chunks, (unsigned)ks);
     const int type = W[0]->type;
     const bool q40 = type == GT_Q4_0;
-    if (w1) mmq2_launch_w1(type, grid, 2 * (q40 ? Mmq2Stage80<1>::BYTES : Mmq2Stage<1>::BYTES) + 4096, s, a, A);
-    else switch (a.tiles_per_chunk) {
+    switch (a.tiles_per_chunk) {
     case 1: mmq2_launch_tt<1>(type, grid, 2 * (q40 ? Mmq2Stage80<1>::BYTES : Mmq2Stage<1>::BYTES) + 16384, s, a, A); break;
     case 2: mmq2_launch_tt<2>(type, grid, 2 * (q40 ? Mmq2Stage80<2>::BYTES : Mmq2Stage<2>::BYTES) + 16384, s, a, A); break;
     case 3: mmq2_launch_tt<3>(type, grid, 2 * (q40 ? Mmq2Stage80<3>::BYTES : Mmq2Stage<3>::BYTES) + 16384, s, a, A); break;
