@@ -303,7 +303,7 @@ int Engine::load_vision(const std::string &path) {
         if (is_lin && tm.type != GT_F16) v_generic_ = true;
     }
     size_t total = 0;
-    for (auto &m : vis_.models) for (auto &t : m.second) total += t.second.nbytes + 512 + (v_generic_ ? 2048 : 0);
+    for (auto &m : vis_.models) for (auto &t : m.second) total += effective_nbytes(t.second) + 512 + (v_generic_ ? 2048 : 0);
     total += (size_t)v_D_ * 592 * 2 + (size_t)v_depth_ * 3 * v_D_ * 4 + (1 << 20);
     vis_arena_.alloc(total);
     const uint8_t *fb = vis_.mf.data;

@@ -6,6 +6,7 @@
 // (int8-MFMA tiles for Q4_0 / k-quants from 5 rows, v_dot4 tiles otherwise, the MFMA f16 GEMM for F16) -> bias / GELU / residual epilogue.  Activations stay fp32
 // between kernels, like ggml's tensors.  LayerNorm, attention, the conv patch embedding and the batching over images are shared with the F16 path.
 #include "engine.hpp"
+#include "quantize.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -16,7 +17,9 @@ int Engine::load_vision_generic() {
     auto fail = [&](const std::string &msg, int code) { set_last_error("vision file: " + msg); MG4_ERR("%s", last_error().c_str()); return code; };
     const uint8_t *fb = vis_.mf.data;
     size_t max_raw = 0;
-    for (auto &m : vis_.models) for (auto &t : m.second) if (t.second.type != GT_F16 && t.second.type != GT_F32) max_raw = std::max(max_raw, t.second.nbytes);
+    for (auto &m : vis_.models) for (auto &t : m.second) if (t.second.type != GT_F16 && t.second.type != GT_F32)
+        max_raw = std::max(max_raw, t.second.type == GT_Q3_K ? t.second.nbytes / 110 * 210 : t.second.nbytes);
+    std::vector<uint8_t> conv;
     struct Stage { void *p = nullptr; ~Stage() { if (p) HIP_IGNORE(hipFree(p)); } } stage;
     if (max_raw) HIP_CHECK(hipMalloc(&stage.p, max_raw));
     std::string bad; int bad_code = 0;
@@ -24,14 +27,20 @@ int Engine::load_vision_generic() {
         if (bad_code) return;
         const TensorMeta *t = vis_.find(model, name);
         if (!t || t->ne.size() != 2 || t->ne[0] != n_in || t->ne[1] != n_out) { bad = model + "." + name; bad_code = E_LoadModelFileHeader; return; }
-        if (!qweight_supported(t->type) || n_in % gt_block(t->type)) {
+        const int wt = t->type == GT_Q3_K ? GT_Q6_K : t->type;                  // Q3_K: exact Q6_K image built on the host (quantize.hpp), like the LLM loader
+        if (!qweight_supported(wt) || n_in % gt_block(t->type)) {
             bad = model + "." + name + ": type " + gt_name(t->type) + " with " + std::to_string(n_in) + " columns is not supported by the gfx950 kernels"; bad_code = E_LoadModelMiniGPT4DataType; return; }
         QWeight plan;
-        const size_t need = plan_qweight(t->type, (int)n_out, (int)n_in, plan, nullptr);
+        const size_t need = plan_qweight(wt, (int)n_out, (int)n_in, plan, nullptr);
         uint8_t *base = vis_arena_.take(need);
-        plan_qweight(t->type, (int)n_out, (int)n_in, L.w, base);
+        plan_qweight(wt, (int)n_out, (int)n_in, L.w, base);
         if (t->type == GT_F16 || t->type == GT_F32) { HIP_CHECK(hipMemcpy(base, fb + t->offset, t->nbytes, hipMemcpyHostToDevice)); return; }
-        HIP_CHECK(hipMemcpy(stage.p, fb + t->offset, t->nbytes, hipMemcpyHostToDevice));
+        if (t->type == GT_Q3_K) {
+            conv.resize(t->nbytes / 110 * 210);
+            q3k_to_q6k(fb + t->offset, conv.data(), t->nbytes / 110);
+            HIP_CHECK(hipMemcpy(stage.p, conv.data(), conv.size(), hipMemcpyHostToDevice));
+        } else
+            HIP_CHECK(hipMemcpy(stage.p, fb + t->offset, t->nbytes, hipMemcpyHostToDevice));
         launch_repack(static_cast<const uint8_t *>(stage.p), L.w, stream_);
         HIP_CHECK(hipStreamSynchronize(stream_));
     };

@@ -233,6 +233,71 @@ void q2_K_block(const float *x, uint8_t *y) {
     }
     for (int j = 0; j < 256; j += 128) for (int l = 0; l < 32; l++) qs[j / 4 + l] = (uint8_t)(L[j + l] | (L[j + l + 32] << 2) | (L[j + l + 64] << 4) | (L[j + l + 96] << 6));
 }
+// make_q3_quants(n, nmax, x, L, do_rmse = true) [UPSTREAM-RECALL]: signed levels in [-nmax, nmax - 1] against the signed maximum, then up to five sweeps of single-level
+// moves that raise (sum w x l)^2 / (sum w l^2) with w = x^2; returns sum w x l / sum w l^2 and stores the levels offset by nmax
+float make_q3_quants(int n, int nmax, const float *x, int8_t *L) {
+    float max = 0, amax = 0;
+    for (int i = 0; i < n; i++) { const float ax = fabsf(x[i]); if (ax > amax) { amax = ax; max = x[i]; } }
+    if (!amax) { for (int i = 0; i < n; i++) L[i] = 0; return 0.f; }
+    const float iscale = -nmax / max;
+    float sumlx = 0, suml2 = 0;
+    for (int i = 0; i < n; i++) {
+        int l = nearest_int(iscale * x[i]); l = std::max(-nmax, std::min(nmax - 1, l));
+        L[i] = (int8_t)l;
+        const float w = x[i] * x[i];
+        sumlx += w * x[i] * l; suml2 += w * l * l;
+    }
+    for (int itry = 0; itry < 5; itry++) {
+        int n_changed = 0;
+        for (int i = 0; i < n; i++) {
+            const float w = x[i] * x[i];
+            float slx = sumlx - w * x[i] * L[i];
+            if (slx > 0) {
+                float sl2 = suml2 - w * L[i] * L[i];
+                int new_l = nearest_int(x[i] * sl2 / slx); new_l = std::max(-nmax, std::min(nmax - 1, new_l));
+                if (new_l != L[i]) {
+                    slx += w * x[i] * new_l; sl2 += w * new_l * new_l;
+                    if (sl2 > 0 && slx * slx * suml2 > sumlx * sumlx * sl2) { L[i] = (int8_t)new_l; sumlx = slx; suml2 = sl2; ++n_changed; }
+                }
+            }
+        }
+        if (!n_changed) break;
+    }
+    for (int i = 0; i < n; i++) L[i] = (int8_t)(L[i] + nmax);
+    return sumlx / suml2;
+}
+// quantize_row_q3_K_reference [UPSTREAM-RECALL]: per 16 weights make_q3_quants(16, 4) -> signed scale; the sixteen scales against the one of largest magnitude on 6 bits
+// (offset 32: low nibbles in scales[0..7], the two high bits in scales[8..11]); levels re-derived against the packed scales; bit 2 of every level in hmask (weight j -> byte
+// j % 32, bit j / 32), the low two bits as four 2-bit planes per 128 weights.  block_q3_K = {hmask[32], qs[64], scales[12], d}
+void q3_K_block(const float *x, uint8_t *y) {
+    int8_t L[256]; float scales[16];
+    float max_scale = 0, amax = 0;
+    for (int j = 0; j < 16; j++) {
+        scales[j] = make_q3_quants(16, 4, x + 16 * j, L + 16 * j);
+        const float a = fabsf(scales[j]); if (a > amax) { amax = a; max_scale = scales[j]; }
+    }
+    uint8_t *hmask = y, *qs = y + 32, *ysc = y + 96, *yd = y + 108;
+    memset(ysc, 0, 12);
+    if (max_scale) {
+        const float iscale = -32.f / max_scale;
+        for (int j = 0; j < 16; j++) {
+            int l = (int8_t)nearest_int(iscale * scales[j]); l = std::max(-32, std::min(31, l)) + 32;
+            if (j < 8) ysc[j] = (uint8_t)(l & 0xF); else ysc[j - 8] |= (uint8_t)((l & 0xF) << 4);
+            ysc[j % 4 + 8] |= (uint8_t)((l >> 4) << (2 * (j / 4)));
+        }
+        put16(yd, f2h(1 / iscale));
+    } else put16(yd, f2h(0.f));
+    const float dd = h2f((uint16_t)(yd[0] | (yd[1] << 8)));
+    for (int j = 0; j < 16; j++) {
+        int sc = j < 8 ? ysc[j] & 0xF : ysc[j - 8] >> 4;
+        sc = (sc | (((ysc[8 + j % 4] >> (2 * (j / 4))) & 3) << 4)) - 32;
+        const float d = dd * sc; if (!d) continue;
+        for (int ii = 0; ii < 16; ii++) { int l = nearest_int(x[16 * j + ii] / d); l = std::max(-4, std::min(3, l)); L[16 * j + ii] = (int8_t)(l + 4); }
+    }
+    memset(hmask, 0, 32);
+    for (int j = 0; j < 256; j++) if (L[j] > 3) { hmask[j % 32] |= (uint8_t)(1u << (j / 32)); L[j] = (int8_t)(L[j] - 4); }
+    for (int j = 0; j < 256; j += 128) for (int l = 0; l < 32; l++) qs[j / 4 + l] = (uint8_t)(L[j + l] | (L[j + l + 32] << 2) | (L[j + l + 64] << 4) | (L[j + l + 96] << 6));
+}
 void q4_K_block(const float *x, uint8_t *y) {   // {d, dmin, scales[12], qs[128]}
     uint8_t L[256];
     q45_K_levels(x, 15, y, y + 4, L);
@@ -285,7 +350,7 @@ void q6_K_block(const float *x, uint8_t *y) {   // {ql[128], qh[64], scales[16] 
 }  // namespace
 
 bool quantize_supported(int ggml_type) {
-    switch (ggml_type) { case GT_Q4_0: case GT_Q4_1: case GT_Q5_0: case GT_Q5_1: case GT_Q8_0: case GT_Q2_K: case GT_Q4_K: case GT_Q5_K: case GT_Q6_K: return true; default: return false; }
+    switch (ggml_type) { case GT_Q4_0: case GT_Q4_1: case GT_Q5_0: case GT_Q5_1: case GT_Q8_0: case GT_Q2_K: case GT_Q3_K: case GT_Q4_K: case GT_Q5_K: case GT_Q6_K: return true; default: return false; }
 }
 size_t quantize_chunk(int ggml_type, const float *x, uint8_t *dst, size_t n) {
     const size_t blk = (size_t)gt_block(ggml_type), bytes = (size_t)gt_bytes(ggml_type);
@@ -293,7 +358,7 @@ size_t quantize_chunk(int ggml_type, const float *x, uint8_t *dst, size_t n) {
     void (*fn)(const float *, uint8_t *) = nullptr;
     switch (ggml_type) {
     case GT_Q4_0: fn = q4_0_block; break; case GT_Q4_1: fn = q4_1_block; break; case GT_Q5_0: fn = q5_0_block; break; case GT_Q5_1: fn = q5_1_block; break;
-    case GT_Q8_0: fn = q8_0_block; break; case GT_Q2_K: fn = q2_K_block; break; case GT_Q4_K: fn = q4_K_block; break; case GT_Q5_K: fn = q5_K_block; break; default: fn = q6_K_block; break;
+    case GT_Q8_0: fn = q8_0_block; break; case GT_Q2_K: fn = q2_K_block; break; case GT_Q3_K: fn = q3_K_block; break; case GT_Q4_K: fn = q4_K_block; break; case GT_Q5_K: fn = q5_K_block; break; default: fn = q6_K_block; break;
     }
     const size_t nb = n / blk;
     // blocks are independent: plain std::thread fan-out (an offline tool; the 13B vision file has ~4 M super-blocks)
@@ -330,7 +395,7 @@ int quantize_vision_file(const char *in_path, const char *out_path, int mg4_data
     VisionFile vf;
     if (int e = vf.load(in_path)) return e;
     const int out_type = mg4_to_ggml_q(mg4_data_type);
-    if (!quantize_supported(out_type)) { set_last_error("minigpt4_quantize_model: target type must be one of Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q4_K Q5_K Q6_K"); return E_LoadModelMiniGPT4DataType; }
+    if (!quantize_supported(out_type)) { set_last_error("minigpt4_quantize_model: target type must be one of Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q2_K Q3_K Q4_K Q5_K Q6_K"); return E_LoadModelMiniGPT4DataType; }
     if (!out_path) return E_DumpModelFileOpen;
     {   // the input stays mmap'd while the output is written: truncating it through a second name (same path or a hard link) would SIGBUS the next tensor read
         struct stat so;

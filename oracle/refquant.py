@@ -220,6 +220,85 @@ def q2_k(x):
     return bytes(ysc) + bytes(qs) + d_b + m_b
 
 
+def make_q3_quants(n, nmax, x):
+    """make_q3_quants with do_rmse = true: returns (scale, levels offset by nmax)."""
+    mx, amax = F(0), F(0)
+    for v in x:
+        if abs(v) > amax:
+            amax, mx = abs(v), v
+    if amax == 0:
+        return F(0), [0] * n
+    iscale = F(F(-nmax) / mx)
+    clamp = lambda l: max(-nmax, min(nmax - 1, l))          # noqa: E731
+    L, sumlx, suml2 = [0] * n, F(0), F(0)
+    for i in range(n):
+        l = clamp(nearest_int(F(iscale * x[i])))
+        L[i] = l
+        w = F(x[i] * x[i])
+        sumlx = F(sumlx + F(F(w * x[i]) * F(l)))
+        suml2 = F(suml2 + F(F(w * F(l)) * F(l)))
+    for _ in range(5):
+        n_changed = 0
+        for i in range(n):
+            w = F(x[i] * x[i])
+            slx = F(sumlx - F(F(w * x[i]) * F(L[i])))
+            if slx > 0:
+                sl2 = F(suml2 - F(F(w * F(L[i])) * F(L[i])))
+                new_l = clamp(nearest_int(F(F(x[i] * sl2) / slx)))
+                if new_l != L[i]:
+                    slx = F(slx + F(F(w * x[i]) * F(new_l)))
+                    sl2 = F(sl2 + F(F(w * F(new_l)) * F(new_l)))
+                    if sl2 > 0 and F(F(slx * slx) * suml2) > F(F(sumlx * sumlx) * sl2):
+                        L[i] = new_l
+                        sumlx, suml2 = slx, sl2
+                        n_changed += 1
+        if not n_changed:
+            break
+    return F(sumlx / suml2), [l + nmax for l in L]
+
+
+def q3_k(x):
+    """quantize_row_q3_K_reference: {hmask[32], qs[64], scales[12] (sixteen 6-bit values, offset 32), d}."""
+    scales, L = [], []
+    max_scale, amax = F(0), F(0)
+    for j in range(16):
+        s, l = make_q3_quants(16, 4, x[16 * j:16 * j + 16])
+        scales.append(s); L += l
+        if abs(s) > amax:
+            amax, max_scale = abs(s), s
+    ysc = [0] * 12
+    if max_scale != 0:
+        iscale = F(F(-32) / max_scale)
+        for j in range(16):
+            l = max(-32, min(31, nearest_int(F(iscale * scales[j])))) + 32
+            if j < 8:
+                ysc[j] = l & 0xF
+            else:
+                ysc[j - 8] |= (l & 0xF) << 4
+            ysc[j % 4 + 8] |= (l >> 4) << (2 * (j // 4))
+        d_b, dd = _hbytes(F(F(1) / iscale)), _h(F(F(1) / iscale))
+    else:
+        d_b, dd = _hbytes(F(0)), F(0)
+    for j in range(16):
+        sc = (ysc[j] & 0xF) if j < 8 else (ysc[j - 8] >> 4)
+        sc = (sc | (((ysc[8 + j % 4] >> (2 * (j // 4))) & 3) << 4)) - 32
+        d = F(dd * F(sc))
+        if d == 0:
+            continue
+        for ii in range(16):
+            L[16 * j + ii] = max(-4, min(3, nearest_int(F(x[16 * j + ii] / d)))) + 4
+    hmask = [0] * 32
+    for j in range(256):
+        if L[j] > 3:
+            hmask[j % 32] |= 1 << (j // 32)
+            L[j] -= 4
+    qs = [0] * 64
+    for j in range(0, 256, 128):
+        for l in range(32):
+            qs[j // 4 + l] = L[j + l] | (L[j + l + 32] << 2) | (L[j + l + 64] << 4) | (L[j + l + 96] << 6)
+    return bytes(hmask) + bytes(qs) + bytes(ysc) + d_b
+
+
 def q4_k(x):
     head, L = _q45_levels(x, 15)
     qs = bytearray()
@@ -337,7 +416,7 @@ def q6_k(x):
     return bytes(ql) + bytes(qh) + bytes((s & 0xFF) for s in sc) + d16
 
 
-BLOCK_FN = {2: (32, q4_0), 3: (32, q4_1), 6: (32, q5_0), 7: (32, q5_1), 8: (32, q8_0), 10: (256, q2_k), 12: (256, q4_k), 13: (256, q5_k), 14: (256, q6_k)}
+BLOCK_FN = {2: (32, q4_0), 3: (32, q4_1), 6: (32, q5_0), 7: (32, q5_1), 8: (32, q8_0), 10: (256, q2_k), 11: (256, q3_k), 12: (256, q4_k), 13: (256, q5_k), 14: (256, q6_k)}
 
 
 def quantize_chunk(ggml_type: int, x: np.ndarray) -> np.ndarray:

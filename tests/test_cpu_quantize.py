@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-TYPES = {"q4_0": 2, "q4_1": 3, "q5_0": 6, "q5_1": 7, "q8_0": 8, "q2_k": 10, "q4_k": 12, "q5_k": 13, "q6_k": 14}
+TYPES = {"q4_0": 2, "q4_1": 3, "q5_0": 6, "q5_1": 7, "q8_0": 8, "q2_k": 10, "q3_k": 11, "q4_k": 12, "q5_k": 13, "q6_k": 14}
 MG4 = {"f16": 0, "f32": 1, "q4_0": 4, "q4_1": 5, "q5_0": 6, "q5_1": 7, "q8_0": 8, "q2_k": 10, "q3_k": 11, "q4_k": 12, "q5_k": 13, "q6_k": 14}
 
 
@@ -79,7 +79,7 @@ def test_hand_derived_blocks(lib):
     assert np.array_equal(got[4:], q[:16] | (q[16:] << 4))
 
 
-@pytest.mark.parametrize("name,bound", [("q4_0", 0.12), ("q4_1", 0.10), ("q5_0", 0.06), ("q5_1", 0.05), ("q8_0", 0.01), ("q4_k", 0.09), ("q5_k", 0.045), ("q6_k", 0.025), ("q2_k", 0.45)])
+@pytest.mark.parametrize("name,bound", [("q4_0", 0.12), ("q4_1", 0.10), ("q5_0", 0.06), ("q5_1", 0.05), ("q8_0", 0.01), ("q4_k", 0.09), ("q5_k", 0.045), ("q6_k", 0.025), ("q2_k", 0.45), ("q3_k", 0.22)])
 def test_reconstruction_error(lib, name, bound):
     from minigpt4_cpp_amd import quants as Q
     t = TYPES[name]
@@ -103,7 +103,7 @@ def _eligible(model, t):
 
 
 @pytest.mark.parametrize("ftype", ["f16", "f32"])
-@pytest.mark.parametrize("target", ["q4_0", "q5_1", "q8_0", "q4_k", "q6_k", "q2_k"])
+@pytest.mark.parametrize("target", ["q4_0", "q5_1", "q8_0", "q4_k", "q6_k", "q2_k", "q3_k"])
 def test_quantize_model_rewrites_the_vision_file(lib, tmp_path, ftype, target):
     import refquant as RQ
     from minigpt4_cpp_amd import modelgen as G, quants as Q
@@ -152,7 +152,7 @@ def test_quantize_model_error_codes(lib, tmp_path):
     L = lib.library
     assert L.minigpt4_quantize_model(b"/nonexistent/in.bin", b"/tmp/x", MG4["q4_0"]) == 17       # PathDoesNotExist (minigpt4.cpp:2823-2826)
     assert L.minigpt4_quantize_model(src.encode(), b"/nonexistent_dir/out.bin", MG4["q4_0"]) == 18   # DumpModelFileOpen (:1636-1640)
-    for bad in (MG4["f16"], MG4["f32"], MG4["q3_k"], 2, 99, -1):
+    for bad in (MG4["f16"], MG4["f32"], 2, 3, 9, 15, 99, -1):
         assert L.minigpt4_quantize_model(src.encode(), str(tmp_path / "o.bin").encode(), bad) == 3  # LoadModelMiniGPT4DataType
     # output == input (same path, or a hard link to it): refused before the mmap'd input could be truncated, and the input survives intact
     import hashlib, os

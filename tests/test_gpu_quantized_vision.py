@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-MG4 = {"q4_0": 4, "q4_1": 5, "q5_0": 6, "q5_1": 7, "q8_0": 8, "q2_k": 10, "q4_k": 12, "q5_k": 13, "q6_k": 14}
+MG4 = {"q4_0": 4, "q4_1": 5, "q5_0": 6, "q5_1": 7, "q8_0": 8, "q2_k": 10, "q3_k": 11, "q4_k": 12, "q5_k": 13, "q6_k": 14}
 
 
 @pytest.fixture(scope="module")
