@@ -120,6 +120,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     // one launch less per layer.
     if (getenv("MINIGPT4_BATCH_ROWS_MAX")) batch_rows_max_ = atoi(getenv("MINIGPT4_BATCH_ROWS_MAX"));
     batch_fuse_ = getenv("MINIGPT4_BATCH_FUSE") ? (atoi(getenv("MINIGPT4_BATCH_FUSE")) != 0) : -1;   // -1: by batch size (see forward_batch)
+    batch_mix_ = !(getenv("MINIGPT4_BATCH_MIX") && atoi(getenv("MINIGPT4_BATCH_MIX")) == 0);
     if (const char *sk = getenv("MINIGPT4_SPLITK")) { sscanf(sk, "%d,%d", &splitk_proj_, &splitk_fc2_); splitk_proj_ = std::max(1, std::min(SPLITK_MAX, splitk_proj_)); splitk_fc2_ = std::max(1, std::min(SPLITK_MAX, splitk_fc2_)); }
     n_cus_ = prop.multiProcessorCount;
     set_matvec_tuning(getenv("MINIGPT4_MV_WAVES") ? atoi(getenv("MINIGPT4_MV_WAVES")) : 0, getenv("MINIGPT4_FAT_LB") ? atoi(getenv("MINIGPT4_FAT_LB")) : 0, prop.multiProcessorCount);
@@ -666,11 +667,20 @@ void Engine::forward_batch(int B, hipStream_t s) {
     for (size_t il = 0; il < layers_.size(); il++) {
         const LayerW &L = layers_[il];
         __half *kc = kc_ + il * C * E, *vc = vc_ + il * C * E;            // conversation 0's layer; the kernel adds slot * seq_stride
+        // a "more bits" layer (wq|wk Q4_K / Q5_K + wv Q6_K): one launch over both sets, like the single-row step's k_matvec_mix
+        auto qkv_mixed = [&](bool pro) {
+            if (!batch_mix_ || B > batch_rows_max_ || B > 4 || L.wk.type != L.wq.type || L.wv.type == L.wq.type) return false;
+            const QWeight *W1[2] = {&L.wq, &L.wk}, *W2[1] = {&L.wv};
+            float *y1[2] = {q_, k_}, *y2[1] = {v_};
+            return launch_matvec_rows_mixed(W1, y1, 2, W2, y2, 1, act_, B, E, s, pro ? x_ : nullptr, pro ? L.attn_norm : nullptr, E);
+        };
         if (L.wv.type == L.wq.type && L.wk.type == L.wq.type && rows_pro({&L.wq, &L.wk, &L.wv})) mm({&L.wq, &L.wk, &L.wv}, {q_, k_, v_}, nullptr, E, x_, L.attn_norm);
-        else if (L.wk.type == L.wq.type && rows_pro({&L.wq, &L.wk}) && rows_pro({&L.wv})) { mm({&L.wq, &L.wk}, {q_, k_}, nullptr, E, x_, L.attn_norm); mm({&L.wv}, {v_}, nullptr, E, x_, L.attn_norm); }
-        else {
+        else if (L.wk.type == L.wq.type && rows_pro({&L.wq, &L.wk}) && rows_pro({&L.wv})) {
+            if (!qkv_mixed(true)) { mm({&L.wq, &L.wk}, {q_, k_}, nullptr, E, x_, L.attn_norm); mm({&L.wv}, {v_}, nullptr, E, x_, L.attn_norm); }
+        } else {
             launch_rms_quant(x_, L.attn_norm, B, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s);
             if (L.wv.type == L.wq.type && L.wk.type == L.wq.type) mm({&L.wq, &L.wk, &L.wv}, {q_, k_, v_}, nullptr, E);
+            else if (qkv_mixed(false)) {}
             else if (L.wk.type == L.wq.type) { mm({&L.wq, &L.wk}, {q_, k_}, nullptr, E); mm({&L.wv}, {v_}, nullptr, E); }
             else { mm({&L.wq}, {q_}, nullptr, E); mm({&L.wk}, {k_}, nullptr, E); mm({&L.wv}, {v_}, nullptr, E); }
         }

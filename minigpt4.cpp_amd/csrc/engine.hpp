@@ -148,7 +148,8 @@ private:
     std::vector<hipGraphExec_t> batch_graph_;                             // [B]: the batched step for B rows (rows are described in device memory, so one graph serves any slot set)
     int *h_argmax_ = nullptr, *h_bstage_ = nullptr; float *h_logits_ = nullptr; int logits_host_slot_ = -1;
     bool use_graph_ = true, use_v2_ = true, attn_prefill_ = true;
-    int batch_rows_max_ = 4; int batch_fuse_ = -1; int n_cus_ = 256;   // MINIGPT4_BATCH_ROWS_MAX: batches up to this size use the multi-row mat-vec; 0 = never.  Measured (profiles/r02x_*): from 5 rows on the int8-MFMA kernels (single-wave workgroups, one token tile) beat two passes of the 4-row mat-vec
+    int batch_rows_max_ = 4; int batch_fuse_ = -1; int n_cus_ = 256;
+    bool batch_mix_ = true;            // MINIGPT4_BATCH_MIX=0: wq|wk and wv of a mixed-type layer as two launches (the form before k_matvec_tn_mix)   // MINIGPT4_BATCH_ROWS_MAX: batches up to this size use the multi-row mat-vec; 0 = never.  Measured (profiles/r02x_*): from 5 rows on the int8-MFMA kernels (single-wave workgroups, one token tile) beat two passes of the 4-row mat-vec
     static constexpr int FUSE_DEFAULT = 87; int fuse_mask_ = FUSE_DEFAULT;
     // profiling (profile_sites)
     bool prof_on_ = false;

@@ -58,6 +58,9 @@ bool matvec_rows_prologue_ok(int type, int K);
 // two k-quant types (Q4_K|Q5_K + Q6_K) with the same K in one launch; pro: 0 or 1 (rms_norm prologue)
 bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, hipStream_t s, int pro = 0,
                          const float *px = nullptr, const float *pw = nullptr);
+// the same for N = 1..4 rows of the batched step (K <= 6144); px != null: rows rms-normed with pw and quantised inside the launch
+bool launch_matvec_rows_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, int N, int ldy, hipStream_t s,
+                              const float *px = nullptr, const float *pw = nullptr, int ldx = 0);
 void set_matvec_tuning(int waves_per_cu, int fat_threads, int cus);   // 0 = choose per launch
 // measurement: while tracing is on, every launcher of llm_kernels.hip notes the kernel symbol it launched (as rocprofv3 prints it, without the argument list)
 void kernel_name_tracing(bool on);

@@ -297,6 +297,9 @@ template <> struct Tr<GT_Q8_0> {   // unit = half a block (16 int8); the two hal
     }
 };
 // k-quants ---------------------------------------------------------------------------------------------------------------
+// sub-block scale x integer block sum: |scale| <= 127 and |sum| <= 32 x 63 x 127 + 32 x 16 x 127 < 2^19, so the 24-bit multiplier is exact -- and full rate, where
+// the 32-bit v_mul_lo_u32 / v_mad_u64_u32 the compiler emits for int * int issue at a quarter of it (two of them per 32 weights and activation row)
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 struct AK { int4 lo, hi; float d; int bs_lo, bs_hi; };
 __device__ __forceinline__ void scale_min_pair(const int4 &h, int j, int &sc0, int &sc1, int &m0, int &m1) {
     // h.y,h.z,h.w = the 12 packed 6-bit (scale,min) bytes of a Q4_K/Q5_K super-block; pair j -> sub-blocks 2j, 2j+1
@@ -325,7 +328,7 @@ template <> struct Tr<GT_Q2_K> {   // supported, not tuned: only the generic til
         s1 = dot4(H & 0x03030303, a.hi.x, s1); s1 = dot4((H >> 2) & 0x03030303, a.hi.y, s1); s1 = dot4((H >> 4) & 0x03030303, a.hi.z, s1); s1 = dot4((H >> 6) & 0x03030303, a.hi.w, s1);
         const int sc0 = w.sc & 0xF, m0 = (w.sc >> 4) & 0xF, sc1 = (w.sc >> 8) & 0xF, m1 = w.sc >> 12;
         const float d = h2f_bits(w.dm & 0xFFFF), dmin = h2f_bits(w.dm >> 16);
-        acc = fmaf(d * a.d, (float)(sc0 * s0 + sc1 * s1), acc);
+        acc = fmaf(d * a.d, (float)(mul24(sc0, s0) + mul24(sc1, s1)), acc);
         acc = fmaf(-(dmin * a.d), (float)(m0 * a.bs_lo + m1 * a.bs_hi), acc);
     }
 };
@@ -347,7 +350,7 @@ template <> struct Tr<GT_Q4_K> {
         s0 = dot4(w.q.x & 0x0F0F0F0F, a.lo.x, s0); s0 = dot4(w.q.y & 0x0F0F0F0F, a.lo.y, s0); s0 = dot4(w.q.z & 0x0F0F0F0F, a.lo.z, s0); s0 = dot4(w.q.w & 0x0F0F0F0F, a.lo.w, s0);
         s1 = dot4((w.q.x >> 4) & 0x0F0F0F0F, a.hi.x, s1); s1 = dot4((w.q.y >> 4) & 0x0F0F0F0F, a.hi.y, s1); s1 = dot4((w.q.z >> 4) & 0x0F0F0F0F, a.hi.z, s1); s1 = dot4((w.q.w >> 4) & 0x0F0F0F0F, a.hi.w, s1);
         const float d = h2f_bits((unsigned)w.h.x & 0xFFFF), dmin = h2f_bits((unsigned)w.h.x >> 16);
-        acc = fmaf(d * a.d, (float)(sc0 * s0 + sc1 * s1), acc);
+        acc = fmaf(d * a.d, (float)(mul24(sc0, s0) + mul24(sc1, s1)), acc);
         acc = fmaf(-(dmin * a.d), (float)(m0 * a.bs_lo + m1 * a.bs_hi), acc);
     }
 };
@@ -368,7 +371,7 @@ template <> struct Tr<GT_Q5_K> {
         s1 = dot4(((w.q.x >> 4) & 0x0F0F0F0F) | (P & 0x10101010), a.hi.x, s1); s1 = dot4(((w.q.y >> 4) & 0x0F0F0F0F) | ((P >> 1) & 0x10101010), a.hi.y, s1);
         s1 = dot4(((w.q.z >> 4) & 0x0F0F0F0F) | ((P >> 2) & 0x10101010), a.hi.z, s1); s1 = dot4(((w.q.w >> 4) & 0x0F0F0F0F) | ((P >> 3) & 0x10101010), a.hi.w, s1);
         const float d = h2f_bits((unsigned)w.h.x & 0xFFFF), dmin = h2f_bits((unsigned)w.h.x >> 16);
-        acc = fmaf(d * a.d, (float)(sc0 * s0 + sc1 * s1), acc);
+        acc = fmaf(d * a.d, (float)(mul24(sc0, s0) + mul24(sc1, s1)), acc);
         acc = fmaf(-(dmin * a.d), (float)(m0 * a.bs_lo + m1 * a.bs_hi), acc);
     }
 };
@@ -396,7 +399,7 @@ static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u,
         s1 = dot4(((w.q.x >> 4) & 0x0F0F0F0F) | ((H << 4) & 0x30303030), a.hi.x, s1); s1 = dot4(((w.q.y >> 4) & 0x0F0F0F0F) | ((H << 2) & 0x30303030), a.hi.y, s1);
         s1 = dot4(((w.q.z >> 4) & 0x0F0F0F0F) | (H & 0x30303030), a.hi.z, s1); s1 = dot4(((w.q.w >> 4) & 0x0F0F0F0F) | ((H >> 2) & 0x30303030), a.hi.w, s1);
         s0 -= 32 * a.bs_lo; s1 -= 32 * a.bs_hi;
-        acc = fmaf(h2f_bits(w.dh) * a.d, (float)((int)(signed char)(w.sc & 0xFF) * s0 + (int)(signed char)(w.sc >> 8) * s1), acc);
+        acc = fmaf(h2f_bits(w.dh) * a.d, (float)(mul24((int)(signed char)(w.sc & 0xFF), s0) + mul24((int)(signed char)(w.sc >> 8), s1)), acc);
     }
 };
 template <> struct Tr<GT_F16> {
@@ -888,14 +891,14 @@ template <int NU> constexpr int mv_tn_threads() { return NU >= 7 ? 256 : 512; } 
 // PRO = 1 (K <= 3 x 64 units only): the rows are prepared inside the launch -- rms_norm(x_t) * w and the quantisation of k_rms_quant, row by row with the single-row
 // prologue's arithmetic (matvec_run), into one LDS image per row -- so a batched decode step needs no standalone preparation launch in front of wq|wk|wv and w1|w3.
 static size_t mv_tn_image_bytes(int K) { return ((size_t)2 * K + (size_t)(K / 256 + 1) * 4 + (size_t)4 * (K / 32) * 4 + (size_t)(K / 16) * 2 + 64 + 15) & ~(size_t)15; }
-template <int T, int NU, int TN, int PRO = 0>
-__global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet ms, const ActQ A, const int N, const int ldy, const int n_groups, const int n_waves, const ProArgs pa,
-                                                                   const int ldx, const int image_bytes) {
+extern __shared__ __attribute__((aligned(16))) unsigned char smem_tn[];
+// `wave` = this wave's index among the n_waves that share the set's rows (k_matvec_tn: all waves of the launch; k_matvec_tn_mix: the waves of one of its two sets)
+template <int T, int NU, int TN, int PRO>
+__device__ __forceinline__ void matvec_tn_run(const MatSet &ms, const ActQ &A, const int N, const int ldy, const int n_groups, const int n_waves, const int wave, const ProArgs &pa,
+                                              const int ldx, const int image_bytes) {
     static_assert(PRO == 0 || NU <= 3, "the prologue variant: 512-thread workgroups, K <= 3 x 64 units");
     using X = Tr<T>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_tn[];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int K = ms.w0.cols, U = K / X::EPU, rows_each = ms.rows_each, total_rows = ms.n * rows_each;
     int uc[NU]; bool ok[NU];
 #pragma unroll
@@ -1085,6 +1088,22 @@ __global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet 
     MG4_TL(5);
 #endif
 }
+template <int T, int NU, int TN, int PRO = 0>
+__global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn(const MatSet ms, const ActQ A, const int N, const int ldy, const int n_groups, const int n_waves, const ProArgs pa,
+                                                                   const int ldx, const int image_bytes) {
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    matvec_tn_run<T, NU, TN, PRO>(ms, A, N, ldy, n_groups, n_waves, wave, pa, ldx, image_bytes);
+}
+// Two sets of different k-quant types with the same K (wq|wk + wv of a "more bits" layer) against the same TN rows in ONE launch: the workgroups are split between
+// the sets by bytes, like k_matvec_mix does for the single-row step.  Both types quantise their rows to Q8_K, so the in-launch preparation (PRO = 1) is the same code
+// with the same barriers on both sides of the split (a workgroup is never divided: the split is at workgroup granularity).
+template <int T1, int T2, int NU, int TN, int PRO>
+__global__ __launch_bounds__(mv_tn_threads<NU>()) void k_matvec_tn_mix(const MatSet ms1, const MatSet ms2, const ActQ A, const int N, const int ldy, const int n_groups1, const int n_waves1,
+                                                                       const int n_groups2, const int n_waves2, const ProArgs pa, const int ldx, const int image_bytes) {
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (wave < n_waves1) matvec_tn_run<T1, NU, TN, PRO>(ms1, A, N, ldy, n_groups1, n_waves1, wave, pa, ldx, image_bytes);
+    else matvec_tn_run<T2, NU, TN, PRO>(ms2, A, N, ldy, n_groups2, n_waves2, wave - n_waves1, pa, ldx, image_bytes);
+}
 template <int T, int NU, int TN>
 static void launch_tn_n(const MatSet &ms, const ActQ &A, int N, int ldy, hipStream_t s, const float *px, const float *pw, int ldx) {
     const int n_groups = ms.n * ms.rows_each;
@@ -1151,6 +1170,64 @@ bool launch_matvec_rows(const QWeight *const *W, float *const *y, const float *c
     case GT_Q6_K: return launch_tn_type<GT_Q6_K>(ms, A, N, ldy, s, px, pw, ldx);
     default: return false;
     }
+}
+
+template <int T1, int T2, int NU, int TN>
+static void launch_tn_mix_n(const MatSet &m1, const MatSet &m2, double bytes1, double bytes2, const ActQ &A, int N, int ldy, hipStream_t s, const float *px, const float *pw, int ldx) {
+    static_assert(NU <= 3, "register-resident rows, the prologue's range");
+    const int ng1 = m1.n * m1.rows_each, ng2 = m2.n * m2.rows_each;
+    constexpr int WPB = mv_tn_threads<NU>() / 64;
+    const int total = g_mv_cus;
+    // split the workgroups so that the busiest wave of either set finishes earliest: cost = rows per wave x bytes per row (launch_mix_t)
+    const double bpr1 = bytes1 / ng1, bpr2 = bytes2 / ng2;
+    int best_b1 = 1; double best_cost = 1e300;
+    for (int b1 = 1; b1 < total; b1++) {
+        const int w1 = b1 * WPB, w2 = (total - b1) * WPB;
+        const double c = std::max((double)((ng1 + w1 - 1) / w1) * bpr1, (double)((ng2 + w2 - 1) / w2) * bpr2);
+        if (c < best_cost) { best_cost = c; best_b1 = b1; }
+    }
+    const int nw1 = best_b1 * WPB, nw2 = (total - best_b1) * WPB;
+    ProArgs pa{}; pa.x = px; pa.w = pw;
+    const dim3 grid((unsigned)total), block((unsigned)mv_tn_threads<NU>());
+    if (px) {
+        const int img = (int)mv_tn_image_bytes(m1.w0.cols);
+        static bool attr1 = false;
+        if (!attr1) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn_mix<T1, T2, NU, TN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr1 = true; }
+        note_kernel("k_matvec_tn_mix<%d, %d, %d, %d, 1>", T1, T2, NU, TN);
+        hipLaunchKernelGGL((k_matvec_tn_mix<T1, T2, NU, TN, 1>), grid, block, (size_t)512 + (size_t)TN * img, s, m1, m2, A, N, ldy, ng1, nw1, ng2, nw2, pa, ldx, img);
+        return;
+    }
+    note_kernel("k_matvec_tn_mix<%d, %d, %d, %d, 0>", T1, T2, NU, TN);
+    hipLaunchKernelGGL((k_matvec_tn_mix<T1, T2, NU, TN, 0>), grid, block, 0, s, m1, m2, A, N, ldy, ng1, nw1, ng2, nw2, pa, 0, 0);
+}
+template <int T1, int T2>
+static bool launch_tn_mix_type(const MatSet &m1, const MatSet &m2, double b1, double b2, const ActQ &A, int N, int ldy, hipStream_t s, const float *px, const float *pw, int ldx) {
+    const int nu = (m1.w0.cols / 32 + 63) / 64;
+    switch (nu * 2 + (N <= 2 ? 0 : 1)) {
+    case 2: launch_tn_mix_n<T1, T2, 1, 2>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    case 3: launch_tn_mix_n<T1, T2, 1, 4>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    case 4: launch_tn_mix_n<T1, T2, 2, 2>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    case 5: launch_tn_mix_n<T1, T2, 2, 4>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    case 6: launch_tn_mix_n<T1, T2, 3, 2>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    case 7: launch_tn_mix_n<T1, T2, 3, 4>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    default: return false;
+    }
+}
+// Batched decode, N = 1..4 rows: two sets of different k-quant types with the same K (wq|wk + wv of a "more bits" layer) in ONE launch.  px != null: the rows are
+// prepared inside the launch (rms_norm(px_t) * pw, quantised), as in launch_matvec_rows.  false: outside the kernel's range, nothing was launched.
+bool launch_matvec_rows_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, int N, int ldy, hipStream_t s,
+                              const float *px, const float *pw, int ldx) {
+    if (N < 1 || N > 4 || W1[0]->cols != W2[0]->cols || W1[0]->cols % 256 || W1[0]->cols / 32 > 3 * 64) return false;
+    if (px && (!pw || !matvec_rows_prologue_ok(W1[0]->type, W1[0]->cols) || !matvec_rows_prologue_ok(W2[0]->type, W2[0]->cols))) return false;
+    MatSet m1, m2;
+    if (!fill_matset(m1, W1, y1, nullptr, n1) || !fill_matset(m2, W2, y2, nullptr, n2)) return false;
+    double b1 = 0, b2 = 0;
+    for (int i = 0; i < n1; i++) b1 += (double)W1[i]->bytes;
+    for (int i = 0; i < n2; i++) b2 += (double)W2[i]->bytes;
+    const int t1 = W1[0]->type, t2 = W2[0]->type;
+    if (t1 == GT_Q5_K && t2 == GT_Q6_K) return launch_tn_mix_type<GT_Q5_K, GT_Q6_K>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx);
+    if (t1 == GT_Q4_K && t2 == GT_Q6_K) return launch_tn_mix_type<GT_Q4_K, GT_Q6_K>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx);
+    return false;
 }
 
 static int g_mmq_enabled = 2;   // 0: v_dot4 tiles only, 1: round-1 int8-MFMA kernels (mmq_kernels.hip), 2: + the LDS-staged kernels of mmq2_kernels.hip
@@ -1819,25 +1896,32 @@ __global__ void k_set_int(int *p, int v) { *p = v; }
 void launch_set_int(int *p, int v, hipStream_t s) { hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, p, v); }
 // Batched decode epilogue, one workgroup per row: greedy argmax of the row's logits (first maximum wins), stored with the logits' owner slot; the
 // conversation's position advances by one and the greedy token becomes its next input.
-__global__ __launch_bounds__(256) void k_batch_finish(const float *__restrict__ logits, int n_vocab, const int *__restrict__ row_slot, int *__restrict__ n_past, int *__restrict__ argmax,
+__global__ __launch_bounds__(1024) void k_batch_finish(const float *__restrict__ logits, int n_vocab, const int *__restrict__ row_slot, int *__restrict__ n_past, int *__restrict__ argmax,
                                                       int *__restrict__ feed, float *__restrict__ slot_logits) {
     const int r = blockIdx.x, slot = row_slot[r];
     const float *x = logits + (size_t)r * n_vocab;
     float *keep = slot_logits + (size_t)slot * n_vocab;                   // the conversation's own copy (sampling with temp > 0, minigpt4_amd_get_logits)
     float best = -INFINITY; int bi = 0x7FFFFFFF;
-    for (int i = threadIdx.x; i < n_vocab; i += 256) { const float v = x[i]; keep[i] = v; if (v > best) { best = v; bi = i; } }
-    __shared__ float sv[4]; __shared__ int si[4];
+    // 16 waves, 16-byte loads (a 256-thread scalar loop took 35 us for 32 000 logits: 125 dependent trips); every thread visits its indices in ascending order and
+    // argmax_combine prefers the lower index, so ties resolve to the first maximum as before
+    const int n4 = (n_vocab & 3) == 0 ? n_vocab >> 2 : 0;
+    for (int i = threadIdx.x; i < n4; i += 1024) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i]; reinterpret_cast<float4 *>(keep)[i] = v;
+        if (v.x > best) { best = v.x; bi = 4 * i; } if (v.y > best) { best = v.y; bi = 4 * i + 1; } if (v.z > best) { best = v.z; bi = 4 * i + 2; } if (v.w > best) { best = v.w; bi = 4 * i + 3; }
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < n_vocab; i += 1024) { const float v = x[i]; keep[i] = v; if (v > best) { best = v; bi = i; } }
+    __shared__ float sv[16]; __shared__ int si[16];
     argmax_wave(best, bi);
     if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; w++) argmax_combine(best, bi, sv[w], si[w]);
+        for (int w = 1; w < 16; w++) argmax_combine(best, bi, sv[w], si[w]);
         const int id = bi == 0x7FFFFFFF ? 0 : bi;
         argmax[slot] = id; feed[slot] = id; n_past[slot] += 1;
     }
 }
 void launch_batch_finish(const float *logits, int n_vocab, int B, const int *row_slot, int *n_past, int *argmax, int *feed, float *slot_logits, hipStream_t s) {
-    hipLaunchKernelGGL(k_batch_finish, dim3((unsigned)B), dim3(256), 0, s, logits, n_vocab, row_slot, n_past, argmax, feed, slot_logits);
+    hipLaunchKernelGGL(k_batch_finish, dim3((unsigned)B), dim3(1024), 0, s, logits, n_vocab, row_slot, n_past, argmax, feed, slot_logits);
 }
 // batched decode prologue: the host's view of each row's position (a conversation may have been reset) -> n_past[slot]
 __global__ void k_batch_begin(int *__restrict__ n_past, const int *__restrict__ row_slot, const int *__restrict__ row_pos, int B) {

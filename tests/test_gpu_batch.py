@@ -99,6 +99,49 @@ def test_batch_logits_equal_single_conversation_path(gpu_lib, tiny_files):
         gpu_lib.minigpt4_free(ref)
 
 
+@pytest.mark.parametrize("B", [2, 4])
+def test_mixed_type_layer_in_one_launch_full_width(gpu_lib, B, monkeypatch):
+    """k_matvec_tn_mix (wq|wk Q5_K + wv Q6_K of a "more bits" layer in ONE launch) at the 13B width (K = 5120: the 3-units-per-lane register tiling; B = 2 prepares
+    the rows inside the launch, B = 4 uses the standalone preparation): every row's dot products are summed in the same order as in the two separate launches
+    (MINIGPT4_BATCH_MIX=0), so the logits must be bit-identical to that form -- and agree with the single-conversation path within this file's own re-rounding noise."""
+    import headline as H
+    vp, lp = H.headline_files("13b_l2")                        # layer 0 is a "more bits" layer, layer 1 a plain Q5_K one
+    prompts = PROMPTS[:B]
+
+    def run(mix):
+        monkeypatch.setenv("MINIGPT4_BATCH_MIX", mix)
+        ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=256, n_batch=64)
+        try:
+            start(gpu_lib, ctx, prompts)
+            for _ in range(3):
+                gpu_lib.amd_end_chat_batch(ctx, list(range(B)), temp=0.0)
+            out = []
+            for sl in range(B):
+                gpu_lib.amd_select_conversation(ctx, sl)
+                out.append(gpu_lib.amd_logits(ctx).copy())
+            return np.stack(out)
+        finally:
+            gpu_lib.minigpt4_free(ctx)
+
+    one, two = run("1"), run("0")
+    assert np.isfinite(one).all() and np.array_equal(one, two)
+    monkeypatch.delenv("MINIGPT4_BATCH_MIX")
+    ref = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=256, n_batch=64)
+    try:
+        for sl, p in enumerate(prompts):
+            gpu_lib.minigpt4_reset_chat(ref)
+            gpu_lib.minigpt4_system_prompt(ref)
+            gpu_lib.minigpt4_begin_chat(ref, p.decode())
+            for _ in range(3):
+                gpu_lib.minigpt4_end_chat(ref, temp=0.0)
+            want = gpu_lib.amd_logits(ref)
+            err = float(np.abs(one[sl] - want).max() / (want.max() - want.min()))
+            print(f"B={B} conversation {sl}: batched vs single-conversation logits {err:.2e} of the range")
+            assert err < 3e-2          # this file's own int8 re-rounding noise is 1.2-1.5 % of the range (oracle/headline.py::oracle_self_noise, test_gpu_headline.py)
+    finally:
+        gpu_lib.minigpt4_free(ref)
+
+
 def test_interleaving_single_and_batched_steps_reset_and_subsets(gpu_lib, tiny_files):
     """Batched steps, single-conversation steps (the reference entry points on the selected conversation), a subset batch in a different order and a
     reset of one conversation interleave freely; each conversation still equals its own oracle chat."""
