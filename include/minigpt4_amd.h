@@ -96,12 +96,16 @@ MINIGPT4_API int minigpt4_amd_test_quantize(const float *x, const float *rms_w, 
 /* C[M][N] = A[M][K] . W[N][K]^T on the MFMA f16 path (inputs given as fp32, rounded to fp16 on the device) + optional bias/GELU */
 MINIGPT4_API int minigpt4_amd_test_gemm_f16(const float *A, const float *W, const float *bias, int M, int N, int K, int gelu, float *C);
 
-/* Micro-benchmark of the decode mat-vec kernels on synthetic weight planes (see bench_kernels.py). variant 0: one launch per matrix, 1: fused persistent-wave launch */
+/* Micro-benchmark of the decode mat-vec kernels on synthetic weight planes (see bench_kernels.py). variant 0: one launch per matrix, 1: fused persistent-wave launch,
+   2: the same with the rms-norm prologue, 3 / 4: the batched step's multi-row launch with 4 / 2 prepared rows, 5 / 6: 2 / 4 rows prepared inside the launch */
 MINIGPT4_API int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int variant, int iters, int n_sets, int waves_per_cu, float *us_per_launch, double *bytes_per_launch);
 
 /* Average latency (microseconds) of a device-wide barrier across n_blocks co-resident 512-thread workgroups (atomic counter + agent-scope fences); *errors
  * counts visibility failures of a neighbour-word check.  Measurement for DESIGN.md's launch-gap-vs-barrier analysis. */
 MINIGPT4_API float minigpt4_amd_probe_grid_barrier(int n_blocks, int iters, unsigned *errors);
+/* vector-ALU issue probe: ns per instruction and wave for one instruction kind (0 v_and, 1 v_dot4c_i32_i8, 2 v_mul_lo_u32, 3 v_mad_i32_i24, 4 v_fma_f32, 5 v_and_or,
+   6 v_bfe_u32, 7 v_cvt_f32_i32, 8 v_dot4_i32_i8, 9 v_mad_u64_u32, 10 v_lshrrev) at 1..4 waves per SIMD; < 0 without a GPU */
+MINIGPT4_API float minigpt4_amd_probe_valu(int op, int waves_per_simd, int iters);
 
 /* ---- host-only logic (no GPU needed) -------------------------------------------------------------------------------- */
 struct MiniGPT4Vocab;

@@ -566,7 +566,9 @@ int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int 
             if (ggml_type == GT_F16) launch_fill_u16(base, n, 0x2E66, nullptr);
             if (ggml_type == GT_F32) { std::vector<float> h(n, 0.01f); HIP_CHECK(hipMemcpy(base, h.data(), n * 4, hipMemcpyHostToDevice)); }
         }
-        const int NR = variant == 3 ? 4 : 1;                               // variant 3: the batched decode's multi-row launch (4 activation rows, weights streamed once)
+        // variants 3..6: the batched decode's multi-row launch (weights streamed once): 3 = 4 prepared rows, 4 = 2 prepared rows, 5 = 2 rows prepared inside the launch, 6 = 4 rows inside
+        // 10 + N / 20 + N: the multi-row launch with N = 1..4 prepared rows / rows prepared inside the launch (N = 1 and 3 run the 2- and 4-row kernels with a row to spare)
+        const int NR = (variant > 10 && variant <= 14) ? variant - 10 : (variant > 20 && variant <= 24) ? variant - 20 : (variant == 3 || variant == 6) ? 4 : ((variant == 4 || variant == 5) ? 2 : 1);
         ActQ A; alloc_act(A, keep, (size_t)NR, (size_t)cols);
         DevBuf dx((size_t)NR * cols * 4), dy((size_t)rows * 4 * 3 * NR);
         { std::vector<float> hx((size_t)NR * cols); for (size_t i = 0; i < hx.size(); i++) hx[i] = (float)((int)(i * 37 % 201) - 100) / 64.0f; HIP_CHECK(hipMemcpy(dx.p, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); }
@@ -575,7 +577,8 @@ int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int 
             const QWeight *Wp[3]; float *Yp[3];
             for (int m = 0; m < n_mat; m++) { Wp[m] = &W[(size_t)set * n_mat + m]; Yp[m] = dy.as<float>() + (size_t)m * rows * NR; }
             if (variant == 1 && launch_matvec_set(Wp, Yp, nullptr, n_mat, A, nullptr)) return;
-            if (variant == 3 && launch_matvec_rows(Wp, Yp, nullptr, n_mat, A, NR, rows, nullptr)) return;
+            if ((variant == 3 || variant == 4 || (variant > 10 && variant <= 14)) && launch_matvec_rows(Wp, Yp, nullptr, n_mat, A, NR, rows, nullptr)) return;
+            if ((variant == 5 || variant == 6 || (variant > 20 && variant <= 24)) && launch_matvec_rows(Wp, Yp, nullptr, n_mat, A, NR, rows, nullptr, dx.as<float>(), dx.as<float>(), cols)) return;
             if (variant == 2 && launch_matvec_set(Wp, Yp, nullptr, n_mat, A, nullptr, 1, dx.as<float>(), dx.as<float>())) return;   // rms-norm prologue, as the decode's qkv / w1|w3 launches
             for (int m = 0; m < n_mat; m++) launch_mul_mat(*Wp[m], A, 1, Yp[m], rows, nullptr, nullptr);
         };
@@ -645,6 +648,12 @@ int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, 
     });
 }
 
+float minigpt4_amd_probe_valu(int op, int waves_per_simd, int iters) {
+    if (device_count_noexcept() <= 0 || iters < 1) return -1.0f;
+    float ns = -1.0f;
+    guarded(1, [&] { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0)); set_matvec_tuning(0, 0, prop.multiProcessorCount); ns = probe_valu_ns(op, waves_per_simd, iters); return 0; });
+    return ns;
+}
 float minigpt4_amd_probe_grid_barrier(int n_blocks, int iters, unsigned *errors) {
     if (n_blocks < 1 || n_blocks > 1024 || iters < 1 || device_count_noexcept() <= 0) return -1.0f;
     float us = -1.0f;

@@ -97,6 +97,7 @@ int attn_max_ctx(int hd);   // largest n_ctx whose score / probability rows fit 
 void launch_argmax(const float *logits, int n, int *out, void *scratch /*>= 512 bytes*/, hipStream_t s);
 void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);
 void launch_set_int(int *p, int v, hipStream_t s);
+float probe_valu_ns(int op, int waves_per_simd, int iters);   // vector-ALU issue probe (tools/probe_valu.py): ns per instruction and wave
 float probe_grid_barrier_us(int n_blocks, int iters, unsigned *errors_out);   // average latency of a device-wide barrier across n_blocks co-resident 512-thread workgroups
 void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s);
 uint64_t device_checksum(const void *p, size_t bytes, hipStream_t s);   // sum of the 32-bit words (bytes rounded down to 4), mod 2^64; synchronises the stream

@@ -524,15 +524,18 @@ enum EpiKind : int { EPI_STORE = 0, EPI_SILU_PAIR = 1 };
 #ifdef MG4_TIMELINE
 __device__ unsigned long long g_tl[1024 * 8];
 #define MG4_TL(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_tl[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// slots 6 / 7: the LATEST end / entry over all waves of the workgroup (the clock only grows, so atomicMax needs no reset between launches)
+#define MG4_TL_ALL(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) atomicMax(&g_tl[blockIdx.x * 8 + (i)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
 #else
 #define MG4_TL(i) do {} while (0)
+#define MG4_TL_ALL(i) do {} while (0)
 #endif
 template <int T, int NU, int R, int PRO, int EPI>
 __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, const ProArgs &pa, const int n_groups, const int n_waves, const int wave) {
     static_assert(EPI == EPI_STORE || R == 2, "the SiLU pair epilogue works on row pairs");
     // groups of this wave: g = g_first, g_first + g_step, ... < g_last
     const int g_first = wave, g_last = n_groups, g_step = n_waves;
-    MG4_TL(0);
+    MG4_TL(0); MG4_TL_ALL(7);
     using X = Tr<T>;
     const int lane = threadIdx.x & 63;
     const int K = ms.w0.cols, U = K / X::EPU, rows_each = ms.rows_each, total_rows = ms.n * rows_each;
@@ -688,7 +691,7 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
     if (EPI == EPI_SILU_PAIR) flush_pending();
 #ifdef MG4_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MG4_TL(5);
+    MG4_TL(5); MG4_TL_ALL(6);
 #endif
 }
 template <int T, int NU, int R, int PRO, int EPI>
@@ -923,7 +926,7 @@ __device__ __forceinline__ void matvec_tn_run(const MatSet &ms, const ActQ &A, c
         for (int t = 0; t < TN; t++) G.res[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mkbuf(reinterpret_cast<const uint8_t *>(rb + (size_t)min(t, N - 1) * ldy)), 0, 0, 0));
     };
     Grp cur, nxt;
-    MG4_TL(0);
+    MG4_TL(0); MG4_TL_ALL(7);
     constexpr int PRND = PRO ? NU : 1;                                   // 512 threads x 4 elements per round: K <= NU * 2048
     float4 pxv[PRO ? TN : 1][PRND], pyv[PRND];
     bool pin[PRND];
@@ -1085,7 +1088,7 @@ __device__ __forceinline__ void matvec_tn_run(const MatSet &ms, const ActQ &A, c
     MG4_TL(4);
 #ifdef MG4_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MG4_TL(5);
+    MG4_TL(5); MG4_TL_ALL(6);
 #endif
 }
 template <int T, int NU, int TN, int PRO = 0>
@@ -1891,6 +1894,60 @@ float probe_grid_barrier_us(int n_blocks, int iters, unsigned *errors_out) {
     if (errors_out) *errors_out = err;
     HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b)); HIP_IGNORE(hipFree(d));
     return ms * 1e3f / (float)(2 * iters);
+}
+// Vector-ALU issue-rate probe (tools/probe_valu.py): every wave issues `iters` x 64 instructions of ONE kind over 8 independent accumulators (no dependent-issue
+// stalls); with 1 / 2 / 3 waves per SIMD the wall time per instruction tells the issue cost of that instruction relative to v_and_b32.
+template <int OP> __device__ __forceinline__ void valu_probe_op(int &acc, int a, int b) {
+    if constexpr (OP == 0) asm volatile("v_and_b32 %0, %1, %0" : "+v"(acc) : "v"(a));
+    else if constexpr (OP == 1) asm volatile("v_dot4c_i32_i8 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+    else if constexpr (OP == 2) asm volatile("v_mul_lo_u32 %0, %1, %0" : "+v"(acc) : "v"(a));
+    else if constexpr (OP == 3) asm volatile("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    else if constexpr (OP == 4) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    else if constexpr (OP == 5) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+    else if constexpr (OP == 6) asm volatile("v_bfe_u32 %0, %0, 4, 6" : "+v"(acc));
+    else if constexpr (OP == 7) asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(acc));
+    else if constexpr (OP == 8) asm volatile("v_dot4_i32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    else if constexpr (OP == 9) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(*reinterpret_cast<long long *>(&acc)) : "v"(a), "v"(b) : "vcc");
+    else asm volatile("v_lshrrev_b32 %0, 4, %0" : "+v"(acc));
+}
+template <int OP> __global__ __launch_bounds__(1024) void k_valu_probe(int iters, int *sink) {
+    int acc[8];
+    long long wide[8];                                       // OP 9 works on register pairs
+#pragma unroll
+    for (int i = 0; i < 8; i++) { acc[i] = (int)threadIdx.x + i; wide[i] = acc[i]; }
+    const int a = (int)threadIdx.x * 0x01010101, b = 0x01020304 + (int)blockIdx.x;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) { if constexpr (OP == 9) valu_probe_op<OP>(*reinterpret_cast<int *>(&wide[i]), a, b); else valu_probe_op<OP>(acc[i], a, b); }
+    }
+    int x = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) x ^= acc[i] ^ (int)wide[i];
+    if (x == 0x7FFFFFFF) *sink = x;
+}
+template <int OP> static float valu_probe_run(int threads, int iters) {
+    int *d = nullptr; HIP_CHECK(hipMalloc((void **)&d, 4));
+    hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(k_valu_probe<OP>, dim3((unsigned)g_mv_cus), dim3((unsigned)threads), 0, nullptr, 16, d);
+    HIP_CHECK(hipEventRecord(a, nullptr));
+    hipLaunchKernelGGL(k_valu_probe<OP>, dim3((unsigned)g_mv_cus), dim3((unsigned)threads), 0, nullptr, iters, d);
+    HIP_CHECK(hipEventRecord(b, nullptr));
+    HIP_CHECK(hipDeviceSynchronize());
+    float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b)); HIP_IGNORE(hipFree(d));
+    return ms * 1e6f / ((float)iters * 64.0f);              // ns per instruction of one wave
+}
+// ns per issued instruction and wave; threads = 256 x waves per SIMD (one workgroup per CU)
+float probe_valu_ns(int op, int waves_per_simd, int iters) {
+    const int threads = 256 * std::max(1, std::min(4, waves_per_simd));
+    switch (op) {
+    case 0: return valu_probe_run<0>(threads, iters); case 1: return valu_probe_run<1>(threads, iters); case 2: return valu_probe_run<2>(threads, iters);
+    case 3: return valu_probe_run<3>(threads, iters); case 4: return valu_probe_run<4>(threads, iters); case 5: return valu_probe_run<5>(threads, iters);
+    case 6: return valu_probe_run<6>(threads, iters); case 7: return valu_probe_run<7>(threads, iters); case 8: return valu_probe_run<8>(threads, iters);
+    case 9: return valu_probe_run<9>(threads, iters); case 10: return valu_probe_run<10>(threads, iters); default: return -1.0f;
+    }
 }
 __global__ void k_set_int(int *p, int v) { *p = v; }
 void launch_set_int(int *p, int v, hipStream_t s) { hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, p, v); }

@@ -4,7 +4,7 @@
   MINIGPT4_LIBRARY=minigpt4.cpp_amd/libminigpt4_tl.so python tools/timeline.py [type rows cols n_mat variant]...
 
 variant 1 = activation row prepared by its own launch, 2 = rms-norm prologue inside the mat-vec (the decode's qkv / w1|w3 flavour), 3 = the batched decode's
-multi-row launch (4 activation rows in LDS, k_matvec_tn).  Thread 0 of every workgroup
+multi-row launch (k_matvec_tn, 4 prepared rows), 4 = the same with 2 rows, 5 / 6 = 2 / 4 rows prepared inside the launch (rms-norm prologue).  Thread 0 of every workgroup
 stamps the 100 MHz constant clock at entry / first weight request / row ready / first group done / last group done / results stored; printed per stage as the
 min / median / max over workgroups, in microseconds after the EARLIEST workgroup's entry, next to the hipEvent time of the launch (which additionally holds the
 dispatch + end-of-kernel cost).  GPU only."""
@@ -20,7 +20,7 @@ _pkg.load_package()
 import numpy as np  # noqa: E402
 from minigpt4_cpp_amd import minigpt4_library as ML, quants as Q  # noqa: E402
 
-STAGES = ["entry", "first weight request", "activation row ready", "first row group done", "last row group done", "results stored"]
+STAGES = ["entry", "first weight request", "activation row ready", "first row group done", "last row group done", "results stored", "LAST wave of the workgroup done", "LAST wave of the workgroup entered"]
 
 
 def main():
@@ -43,7 +43,7 @@ def main():
         if n <= 0:
             print("  (library built without MG4_TIMELINE)" if n == 0 else "  timeline read failed")
             continue
-        a = np.frombuffer(buf, np.uint64).reshape(1024, 8)[:, :6].astype(np.float64)
+        a = np.frombuffer(buf, np.uint64).reshape(1024, 8).astype(np.float64)
         a = a[a[:, 0] > 0]                                   # workgroups that ran in the last launch (all slots are rewritten by every launch of <= 1024 workgroups)
         a = a[a[:, 5] >= a[:, 0]]
         a = a[a[:, 0] > a[:, 0].max() - 1e4]                # drop stale slots of an earlier, wider launch (older than 100 us)
