@@ -1134,7 +1134,9 @@ static void launch_tn_n(const MatSet &ms, const ActQ &A, int N, int ldy, hipStre
 }
 template <int T, int NU>
 static void launch_tn_t(const MatSet &ms, const ActQ &A, int N, int ldy, hipStream_t s, const float *px, const float *pw, int ldx) {   // 2-row instantiation: half the dot products (and LDS reads) of the 4-row one
-    if (N <= 2) launch_tn_n<T, NU, 2>(ms, A, N, ldy, s, px, pw, ldx); else launch_tn_n<T, NU, 4>(ms, A, N, ldy, s, px, pw, ldx);
+    if (N <= 2) launch_tn_n<T, NU, 2>(ms, A, N, ldy, s, px, pw, ldx);
+    else if (N == 3) launch_tn_n<T, NU, 3>(ms, A, N, ldy, s, px, pw, ldx);      // the kernels are vector-issue bound: a 4th, unused row costs a quarter more
+    else launch_tn_n<T, NU, 4>(ms, A, N, ldy, s, px, pw, ldx);
 }
 template <int T>
 static bool launch_tn_type(const MatSet &ms, const ActQ &A, int N, int ldy, hipStream_t s, const float *px, const float *pw, int ldx) {
@@ -1206,13 +1208,16 @@ static void launch_tn_mix_n(const MatSet &m1, const MatSet &m2, double bytes1, d
 template <int T1, int T2>
 static bool launch_tn_mix_type(const MatSet &m1, const MatSet &m2, double b1, double b2, const ActQ &A, int N, int ldy, hipStream_t s, const float *px, const float *pw, int ldx) {
     const int nu = (m1.w0.cols / 32 + 63) / 64;
-    switch (nu * 2 + (N <= 2 ? 0 : 1)) {
-    case 2: launch_tn_mix_n<T1, T2, 1, 2>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
-    case 3: launch_tn_mix_n<T1, T2, 1, 4>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
-    case 4: launch_tn_mix_n<T1, T2, 2, 2>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
-    case 5: launch_tn_mix_n<T1, T2, 2, 4>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
-    case 6: launch_tn_mix_n<T1, T2, 3, 2>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
-    case 7: launch_tn_mix_n<T1, T2, 3, 4>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    switch (nu * 3 + (N <= 2 ? 0 : N == 3 ? 1 : 2)) {
+    case 3: launch_tn_mix_n<T1, T2, 1, 2>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    case 4: launch_tn_mix_n<T1, T2, 1, 3>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    case 5: launch_tn_mix_n<T1, T2, 1, 4>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    case 6: launch_tn_mix_n<T1, T2, 2, 2>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    case 7: launch_tn_mix_n<T1, T2, 2, 3>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    case 8: launch_tn_mix_n<T1, T2, 2, 4>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    case 9: launch_tn_mix_n<T1, T2, 3, 2>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    case 10: launch_tn_mix_n<T1, T2, 3, 3>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
+    case 11: launch_tn_mix_n<T1, T2, 3, 4>(m1, m2, b1, b2, A, N, ldy, s, px, pw, ldx); return true;
     default: return false;
     }
 }
