@@ -655,10 +655,11 @@ void Engine::forward_batch(int B, hipStream_t s) {
         for (int k = 0; k < n; k++) launch_mul_mat(*W[k], act_, B, y[k], ld, r[k], s);
     };
     // may the rows of this set be prepared inside its launch?  (same conditions mm() takes the multi-row kernel under)
-    auto rows_pro = [&](std::initializer_list<const QWeight *> Ws) {
+    auto rows_pro = [&](std::initializer_list<const QWeight *> Ws, bool plain = false) {
         // measured (profiles/r02j_batched_decode_ab.log): inside the launch the preparation pays at 2 rows (560 vs 540 tok/s) and loses at 4 (808 vs 829: every fat
         // workgroup repeats four rows' norm + quantisation); MINIGPT4_BATCH_FUSE=1 forces it for every B <= 4, =0 switches it off
-        if (batch_fuse_ == 0 || B > batch_rows_max_ || B > 4 || (batch_fuse_ < 0 && B > 2)) return false;
+        // plain = quantisation only (the attention output in front of wo: no norm, no double-precision sums): cheap enough to stay inside the launch at 3 and 4 rows too
+        if (batch_fuse_ == 0 || B > batch_rows_max_ || B > 4 || (batch_fuse_ < 0 && B > 2 && !plain)) return false;
         const QWeight *w0 = *Ws.begin();
         for (const QWeight *w : Ws) if (w->type != w0->type || w->rows != w0->rows || w->cols != w0->cols) return false;
         return matvec_rows_prologue_ok(w0->type, w0->cols);
@@ -685,7 +686,7 @@ void Engine::forward_batch(int B, hipStream_t s) {
             else { mm({&L.wq}, {q_}, nullptr, E); mm({&L.wk}, {k_}, nullptr, E); mm({&L.wv}, {v_}, nullptr, E); }
         }
         launch_attn_llm_batched(q_, k_, v_, kc, vc, B, H, hd, d_npast_, d_bslot_, seq_stride, n_ctx_, cos_, sin_, tabs_, att_, s);
-        if (rows_pro({&L.wo})) mm({&L.wo}, {x_}, x_, E, att_, nullptr);     // the attention output rows are quantised inside the wo launch
+        if (rows_pro({&L.wo}, true)) mm({&L.wo}, {x_}, x_, E, att_, nullptr);     // the attention output rows are quantised inside the wo launch
         else { launch_silu_mul_quant(att_, nullptr, B, E, act_, act_mask_for(L.wo.type), tabs_, s); mm({&L.wo}, {x_}, x_, E); }
         if (L.w1.type == L.w3.type && rows_pro({&L.w1, &L.w3})) mm({&L.w1, &L.w3}, {h1_, h3_}, nullptr, F, x_, L.ffn_norm);
         else {
