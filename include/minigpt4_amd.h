@@ -32,6 +32,11 @@ MINIGPT4_API int minigpt4_amd_tokenize(struct MiniGPT4Context *ctx, const char *
 MINIGPT4_API int minigpt4_amd_sample(struct MiniGPT4Context *ctx, int32_t *token_id, float temp, int32_t top_k, float top_p, float tfs_z, float typical_p,
                                      int mirostat, float mirostat_tau, float mirostat_eta);                 /* samples, does NOT eval */
 
+/* Parity mode (also MINIGPT4_PARITY=1 in the environment at load): every fp32 accumulation of the language path in the CPU oracle's order (oracle/refcpu.c) -- logits and
+ * greedy ids bit-identical to it; slow (one wavefront per output element).  Takes effect with the next evaluation; the KV cache and positions are kept.  0 / 1 */
+MINIGPT4_API int minigpt4_amd_set_parity(struct MiniGPT4Context *ctx, int on);
+MINIGPT4_API int minigpt4_amd_parity(struct MiniGPT4Context *ctx);                 /* 1 / 0; -1 without a context */
+
 /* ---- measurement ---------------------------------------------------------------------------------------------------- */
 /* `steps` greedy decode steps fed back on the device (no host round trip between steps); hipEvent time of steps 1..steps-1. */
 MINIGPT4_API int minigpt4_amd_decode_loop(struct MiniGPT4Context *ctx, int steps, int32_t *tokens_out, float *ms_total);
@@ -77,6 +82,8 @@ MINIGPT4_API int minigpt4_amd_arena_checksum(struct MiniGPT4Context *ctx, int wh
 /* ---- single-kernel hooks for parity tests (need a GPU; allocate + free their own device memory) ------------------ */
 /* y[N][n_out] = W . x with ggml's quantised-activation arithmetic.  raw_w: the tensor bytes exactly as stored in a model file. */
 MINIGPT4_API int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y);
+/* the same through the parity-mode kernel (k_mul_mat_ref): the per-block fp32 terms in the CPU oracle's order -- results bit-identical to oracle/refcpu.c */
+MINIGPT4_API int minigpt4_amd_test_mul_mat_ref(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y);
 /* prefill launch as the engine issues it for N > 4 rows: n_mat (1..3) equally shaped k-quant matrices (raw blocks back to back) against N rows in ONE launch of the LDS-staged
  * int8-MFMA kernels; residual ([n_mat][N][n_out]) optional; ks > 1 forces that K split (0 = the launcher's choice).  y: [n_mat][N][n_out].  4 = shape refused. */
 /* prefill mat-mul micro-benchmark: n_mat random matrices [rows][cols] against N random rows, average microseconds per (set) launch; generation 2 = mmq2_kernels.hip, 1 = round-1 kernels */

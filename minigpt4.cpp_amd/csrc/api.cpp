@@ -317,6 +317,11 @@ int minigpt4_amd_arena_plan(struct MiniGPT4Context *ctx, size_t *llm_bytes, size
     if (llm_hash) *llm_hash = p.llm_hash; if (vision_hash) *vision_hash = p.vision_hash;
     return 0;
 }
+int minigpt4_amd_set_parity(struct MiniGPT4Context *ctx, int on) {
+    if (!ctx) return 1;
+    return guarded(1, [&]() -> int { E_(ctx)->set_parity(on != 0); return 0; });
+}
+int minigpt4_amd_parity(struct MiniGPT4Context *ctx) { return ctx ? (int)E_(ctx)->parity() : -1; }
 int minigpt4_amd_load_mode(struct MiniGPT4Context *ctx) { return ctx ? (int)E_(ctx)->load_mode() : -1; }
 int minigpt4_amd_weights_received(struct MiniGPT4Context *ctx) {
     if (!ctx) return 1;
@@ -353,11 +358,14 @@ int minigpt4_amd_convert_q3k_q6k(const void *src, void *dst, int64_t n_blocks) {
     return 0;
 }
 
-int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y) {
+static int test_mul_mat_impl(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y, bool ref);
+int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y) { return test_mul_mat_impl(ggml_type, raw_w, n_in, n_out, x, N, y, false); }
+int minigpt4_amd_test_mul_mat_ref(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y) { return test_mul_mat_impl(ggml_type, raw_w, n_in, n_out, x, N, y, true); }
+static int test_mul_mat_impl(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y, bool ref) {
     if (ggml_type == GT_Q3_K && raw_w && n_in > 0 && n_out > 0 && n_in % 256 == 0) {   // the engine's load path: exact Q6_K image (quantize.hpp)
         std::vector<uint8_t> q6((size_t)(n_in / 256 * n_out) * 210);
         q3k_to_q6k(static_cast<const uint8_t *>(raw_w), q6.data(), (size_t)(n_in / 256 * n_out));
-        return minigpt4_amd_test_mul_mat(GT_Q6_K, q6.data(), n_in, n_out, x, N, y);
+        return test_mul_mat_impl(GT_Q6_K, q6.data(), n_in, n_out, x, N, y, ref);
     }
     if (!raw_w || !x || !y || n_in <= 0 || n_out <= 0 || N <= 0 || !qweight_supported(ggml_type) || n_in % gt_block(ggml_type)) return 1;
     if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
@@ -372,7 +380,8 @@ int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int64_t n_in, in
         HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)(N * n_in) * 4, hipMemcpyHostToDevice));
         ActQ A; std::vector<std::unique_ptr<DevBuf>> keep; alloc_act(A, keep, (size_t)N, (size_t)n_in);
         launch_rms_quant(d_x.as<float>(), nullptr, (int)N, (int)n_in, A, act_mask_for(ggml_type), nullptr);
-        launch_mul_mat(W, A, (int)N, d_y.as<float>(), (int)n_out, nullptr, nullptr);
+        if (ref) launch_mul_mat_ref(W, A, (int)N, d_y.as<float>(), (int)n_out, nullptr, nullptr);
+        else launch_mul_mat(W, A, (int)N, d_y.as<float>(), (int)n_out, nullptr, nullptr);
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemcpy(y, d_y.p, (size_t)(N * n_out) * 4, hipMemcpyDeviceToHost));
         return 0;

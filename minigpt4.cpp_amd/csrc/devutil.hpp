@@ -1,6 +1,7 @@
 // Device-side wave64 primitives on the DPP crossbar (no LDS round trips, no lgkmcnt waits) shared by the kernel files.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 
 namespace mg4 {
 
@@ -18,6 +19,10 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
 }
+// fp32 -> fp16, IEEE round-to-nearest-even of the fp32 VALUE (what ggml's F16C / software conversion does to a float that sits in memory).  The empty asm makes the value
+// opaque: otherwise hipcc folds the multiply that produced it into v_fma_mixlo_f16, which rounds the EXACT product once -- the CPU rounds twice (to fp32, then to fp16) and the
+// two differ for ~6e-5 of random operands (tools/probe_mixlo.hip: 1045 of 2^24).  Found by MINIGPT4_PARITY as a 1-ulp softmax-probability difference (round 3).
+__device__ __forceinline__ __half f2h_rn(float x) { asm("" : "+v"(x)); return __float2half_rn(x); }
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
     const long long b = __builtin_bit_cast(long long, v);

@@ -78,6 +78,7 @@ void Engine::release_buffers() {
     buf_arena_.release();
 }
 Engine::~Engine() {
+    if (trace_file_) { fclose(trace_file_); trace_file_ = nullptr; }
     if (stream_) HIP_IGNORE(hipStreamSynchronize(stream_));
     for (auto &e : site_events_) { HIP_IGNORE(hipEventDestroy(e.a)); HIP_IGNORE(hipEventDestroy(e.b)); }
     if (stage_) HIP_IGNORE(hipFree(stage_));
@@ -126,6 +127,8 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     set_matvec_tuning(getenv("MINIGPT4_MV_WAVES") ? atoi(getenv("MINIGPT4_MV_WAVES")) : 0, getenv("MINIGPT4_FAT_LB") ? atoi(getenv("MINIGPT4_FAT_LB")) : 0, prop.multiProcessorCount);
     if (const char *ns = getenv("MINIGPT4_CONVERSATIONS")) conv_.assign((size_t)std::max(1, std::min(MAX_CONVERSATIONS, atoi(ns))), Conversation{});
     sampler_.seed(seed);
+    if (const char *tf = getenv("MINIGPT4_PARITY_TRACE")) { if (*tf) trace_file_ = fopen(tf, "wb"); }
+    parity_ = trace_file_ || (getenv("MINIGPT4_PARITY") && atoi(getenv("MINIGPT4_PARITY")));   // oracle-order fp32 accumulation (forward_ref): bit-identical to the CPU oracle, slow
     if (const char *lm = getenv("MINIGPT4_LOAD")) load_mode_ = !strcmp(lm, "recv") ? LOAD_RECV : LOAD_FULL;
     auto t0 = std::chrono::steady_clock::now();
     if (int e = load_llm(llm_path)) return e;
@@ -571,8 +574,66 @@ bool Engine::mixed_qkv(const LayerW &L, hipStream_t s, bool fuse) {
     return true;
 }
 
+// MINIGPT4_PARITY=1 (or minigpt4_amd_set_parity): the same graph as forward() below with every fp32 accumulation in the CPU oracle's order -- standalone row
+// preparation (sum of squares in element order), k_mul_mat_ref (per-block terms added block after block), RoPE + cache append, k_attn_ref (sequential score / P.V
+// chains), no fused prologues, no MFMA tiles.  Everything else (integer block dots, activation quantisation, fp16 tables, RoPE table) is shared with the fast path
+// and exact there, so this pass is BIT-IDENTICAL to oracle/refcpu.c: logits and greedy ids (tests/test_gpu_paritymode.py).  Slow by design (one wave per output).
+void Engine::forward_ref(int N, bool from_tokens, hipStream_t s, bool feed) {
+    const int E = (int)llm_.n_embd, F = (int)llm_.n_ff(), H = (int)llm_.n_head, hd = E / H, V = (int)llm_.n_vocab;
+    const size_t C = (size_t)n_ctx_, sl = (size_t)cur_;
+    int *const d_npast = d_npast_ + sl, *const d_argmax = d_argmax_ + sl, *const d_feed = d_feed_ + sl;
+    float *const logits = logits_ + sl * (size_t)V;
+    if (from_tokens) launch_get_rows(tok_type_, tok_raw_, E, feed ? d_feed : d_tokens_, N, x_, s);
+    // MINIGPT4_PARITY_TRACE=<file>: every intermediate as a record {char name[32]; int64 n; float[n]} -- the oracle writes the same sequence (orc_set_trace), and
+    // tools/trace_diff.py reports the first record that differs.  Synchronises after every launch; never inside a graph capture.
+    auto tr = [&](const char *what, int il, const float *p, size_t n) {
+        if (!trace_file_) return;
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone; HIP_IGNORE(hipStreamIsCapturing(s, &st));
+        if (st != hipStreamCaptureStatusNone) return;
+        std::vector<float> h(n);
+        HIP_CHECK(hipMemcpyAsync(h.data(), p, n * 4, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s));
+        char name[32]; memset(name, 0, sizeof name); snprintf(name, sizeof name, "%s.%d", what, il);
+        const long long cnt = (long long)n;
+        fwrite(name, 1, 32, trace_file_); fwrite(&cnt, 8, 1, trace_file_); fwrite(h.data(), 4, n, trace_file_); fflush(trace_file_);
+    };
+    tr("embd", -1, x_, (size_t)N * E);
+    const int t_max = n_ctx_;                                              // sizes k_attn_ref's LDS rows; a captured decode step is replayed at later positions
+    for (size_t il = 0; il < layers_.size(); il++) {
+        const LayerW &L = layers_[il];
+        __half *kc = kc_ + (sl * layers_.size() + il) * C * E, *vc = vc_ + (sl * layers_.size() + il) * C * E;
+        launch_rms_quant(x_, L.attn_norm, N, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s, true);
+        launch_mul_mat_ref(L.wq, act_, N, q_, E, nullptr, s); launch_mul_mat_ref(L.wk, act_, N, k_, E, nullptr, s); launch_mul_mat_ref(L.wv, act_, N, v_, E, nullptr, s);
+        tr("q", (int)il, q_, (size_t)N * E); tr("k", (int)il, k_, (size_t)N * E); tr("v", (int)il, v_, (size_t)N * E);
+        launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s);
+        launch_attn_ref(q_, kc, vc, N, H, hd, d_npast, t_max, tabs_, att_, s);
+        tr("q_rope", (int)il, q_, (size_t)N * E); tr("att", (int)il, att_, (size_t)N * E);
+        launch_silu_mul_quant(att_, nullptr, N, E, act_, act_mask_for(L.wo.type), tabs_, s);
+        launch_mul_mat_ref(L.wo, act_, N, x_, E, x_, s);
+        tr("x_attn", (int)il, x_, (size_t)N * E);
+        launch_rms_quant(x_, L.ffn_norm, N, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s, true);
+        launch_mul_mat_ref(L.w1, act_, N, h1_, F, nullptr, s); launch_mul_mat_ref(L.w3, act_, N, h3_, F, nullptr, s);
+        tr("h1", (int)il, h1_, (size_t)N * F); tr("h3", (int)il, h3_, (size_t)N * F);
+        launch_silu_mul_quant(h1_, h3_, N, F, act_, act_mask_for(L.w2.type), tabs_, s);
+        launch_mul_mat_ref(L.w2, act_, N, x_, E, x_, s);
+        tr("x_ffn", (int)il, x_, (size_t)N * E);
+    }
+    launch_rms_quant(x_ + (size_t)(N - 1) * E, norm_, 1, E, act_, act_mask_for(output_.type), s, true);
+    launch_mul_mat_ref(output_, act_, 1, logits, V, nullptr, s);
+    launch_argmax(logits, V, d_argmax, d_scratch_, s);
+    launch_advance(d_npast, N, d_feed, d_argmax, s);
+    HIP_CHECK(hipMemcpyAsync(h_argmax_ + sl, d_argmax, 4, hipMemcpyDeviceToHost, s));
+}
+void Engine::set_parity(bool on) {
+    if (on == parity_) return;
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    for (Conversation &c : conv_) { if (c.graph) HIP_IGNORE(hipGraphExecDestroy(c.graph)); c.graph = nullptr; }   // captured with the other mode's launches
+    for (hipGraphExec_t &g : batch_graph_) { if (g) HIP_IGNORE(hipGraphExecDestroy(g)); g = nullptr; }
+    parity_ = on;
+}
+
 // Enqueue one forward pass for N rows already described by d_tokens_ (from_tokens) or x_ (embeddings), at position *d_npast_.
 void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
+    if (parity_) { forward_ref(N, from_tokens, s, feed); return; }
     const int E = (int)llm_.n_embd, F = (int)llm_.n_ff(), H = (int)llm_.n_head, hd = E / H, V = (int)llm_.n_vocab;
     const size_t C = (size_t)n_ctx_, sl = (size_t)cur_;                     // everything below addresses the selected conversation's cache / scalars
     int *const d_npast = d_npast_ + sl, *const d_argmax = d_argmax_ + sl, *const d_feed = d_feed_ + sl;
@@ -711,7 +772,7 @@ int Engine::eval_chunk(const int *row_tok, int N, const float *embd) {
     launch_set_int(d_npast_ + cur_, cv.n_committed, stream_);
     if (N == 1 && row_tok[0] >= 0) {
         launch_set_int(d_feed_ + cur_, row_tok[0], stream_);
-        if (use_graph_ && !prof_on_) {
+        if (use_graph_ && !prof_on_ && !trace_file_) {
             if (!cv.graph) {
                 hipGraph_t g = nullptr;
                 HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
@@ -908,6 +969,11 @@ int Engine::decode_batch(const int *slots, int n, const SampleParams &p, int *id
         h_bstage_[B] = ids_out[i]; h_bstage_[MAX_CONVERSATIONS + B] = slots[i]; h_bstage_[2 * MAX_CONVERSATIONS + B] = cv.n_committed; B++;
     }
     if (!B) return 0;
+    if (parity_) {   // oracle-order arithmetic exists for the single-conversation pass only: one pass per conversation (same results as the batched step is tested to give)
+        for (int r = 0; r < B; r++) { cur_ = h_bstage_[MAX_CONVERSATIONS + r]; const int id = h_bstage_[r]; if (eval_chunk(&id, 1, nullptr)) return 1; conv_[(size_t)cur_].n_past += 1; }
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        return 0;
+    }
     // rows (token, conversation, position) travel in one copy; the device positions are normally current (k_advance / k_batch_finish keep them), but a
     // reset may have moved the host's view, so k_batch_begin writes them like eval_chunk does
     HIP_CHECK(hipMemcpyAsync(d_btok_, h_bstage_, 768, hipMemcpyHostToDevice, stream_));

@@ -91,6 +91,8 @@ public:
     // of record is the graph replay's.
     int profile_sites(int steps, std::string &json);
     float last_encode_ms() const { return last_encode_ms_; }
+    void set_parity(bool on);                          // MINIGPT4_PARITY at run time (tests): drops the captured graphs, the next evaluation uses the other mode
+    bool parity() const { return parity_; }
 
 private:
     int load_llm(const std::string &path);
@@ -98,6 +100,7 @@ private:
     void alloc_buffers();
     int eval_chunk(const int *row_tok, int N, const float *embd);
     void forward(int N, bool from_tokens, hipStream_t s, bool feed = false);   // feed: N == 1 and the token comes from d_feed_ (decode)
+    void forward_ref(int N, bool from_tokens, hipStream_t s, bool feed);   // parity mode: the oracle's accumulation order
     void forward_batch(int B, hipStream_t s);          // B decode rows of B conversations: tokens d_btok_[r], conversations d_bslot_[r]
     struct Prep { int kind; const float *x; const float *w; };   // 1: rms_norm(x)*w, 2: x, 3: silu(x)*w -- then quantised for the consumer's type
     void mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse, const char *site = "matmul");
@@ -147,7 +150,8 @@ private:
     int *d_btok_ = nullptr, *d_bslot_ = nullptr, *d_bpos_ = nullptr; float *blogits_ = nullptr;   // batched decode: row tokens / conversations / positions (one 768-byte slab), [rows][n_vocab] logits
     std::vector<hipGraphExec_t> batch_graph_;                             // [B]: the batched step for B rows (rows are described in device memory, so one graph serves any slot set)
     int *h_argmax_ = nullptr, *h_bstage_ = nullptr; float *h_logits_ = nullptr; int logits_host_slot_ = -1;
-    bool use_graph_ = true, use_v2_ = true, attn_prefill_ = true;
+    bool use_graph_ = true, use_v2_ = true, attn_prefill_ = true, parity_ = false;
+    FILE *trace_file_ = nullptr;       // MINIGPT4_PARITY_TRACE
     int batch_rows_max_ = 4; int batch_fuse_ = -1; int n_cus_ = 256;
     bool batch_mix_ = true;            // MINIGPT4_BATCH_MIX=0: wq|wk and wv of a mixed-type layer as two launches (the form before k_matvec_tn_mix)   // MINIGPT4_BATCH_ROWS_MAX: batches up to this size use the multi-row mat-vec; 0 = never.  Measured (profiles/r02x_*): from 5 rows on the int8-MFMA kernels (single-wave workgroups, one token tile) beat two passes of the 4-row mat-vec
     static constexpr int FUSE_DEFAULT = 87; int fuse_mask_ = FUSE_DEFAULT;

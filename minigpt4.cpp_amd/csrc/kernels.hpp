@@ -18,13 +18,15 @@ bool qweight_supported(int type);
 
 // ---- activations -------------------------------------------------------------------------------------------------
 // y = rms_norm(x) * w  (w == nullptr: y = x), quantised into the formats in `mask`; N rows of width K.
-void launch_rms_quant(const float *x, const float *w, int N, int K, const ActQ &A, int mask, hipStream_t s);
+void launch_rms_quant(const float *x, const float *w, int N, int K, const ActQ &A, int mask, hipStream_t s, bool sequential_sum = false);   // sequential_sum: the sum of squares in element order by one thread (MINIGPT4_PARITY)
 // y = silu(a) * b (fp16-table silu), quantised; or y = a when b == nullptr.
 void launch_silu_mul_quant(const float *a, const float *b, int N, int K, const ActQ &A, int mask, const Tables &tb, hipStream_t s);
 
 // ---- quantised mat-mul: y[t][r] = W[r] . act[t]  (+ residual[t][r]) ------------------------------------------------
 void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s);
 
+// MINIGPT4_PARITY=1: the same unit traits, the per-block fp32 terms added in the CPU oracle's order (one sequential chain per output) -- bit-identical to oracle/refcpu.c, slow
+void launch_mul_mat_ref(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s);
 // prefill (N >= 16) on the int8 matrix cores for Q4_K / Q5_K / Q6_K / Q4_0; launch_mul_mat dispatches to it automatically
 bool mmq_supported(int type);
 bool matvec_prologue_supported(int type, int cols);   // the fused row-preparation variants of the decode mat-vec
@@ -92,6 +94,8 @@ void launch_batch_begin(int *n_past, const int *row_slot, const int *row_pos, in
 // prefill (N > 1 rows of one conversation, after launch_rope_kv): workgroup = (head, 16 queries), keys streamed through LDS in tiles, exact-f32 MFMA; t_max >= *n_past + N
 // sizes the LDS score rows; false -> does not fit (the caller uses launch_attn_llm)
 bool launch_attn_prefill(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s);
+// MINIGPT4_PARITY=1: scores / softmax / P.V with every fp32 chain in the oracle's order (after launch_rope_kv); t_max >= *n_past + N
+void launch_attn_ref(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s);
 bool attn_head_size_supported(int hd);
 int attn_max_ctx(int hd);   // largest n_ctx whose score / probability rows fit the attention kernel's LDS
 void launch_argmax(const float *logits, int n, int *out, void *scratch /*>= 512 bytes*/, hipStream_t s);

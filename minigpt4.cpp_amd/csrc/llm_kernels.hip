@@ -67,8 +67,8 @@ static inline void launch_k(void (*k)(KA...), dim3 g, dim3 b, size_t lds, hipStr
 
 __device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 __device__ __forceinline__ float h2f_bits(unsigned short h) { return __half2float(__ushort_as_half(h)); }
-__device__ __forceinline__ unsigned short f2h_bits(float f) { return __half_as_ushort(__float2half_rn(f)); }
-__device__ __forceinline__ float f16r(float f) { return __half2float(__float2half_rn(f)); }
+__device__ __forceinline__ unsigned short f2h_bits(float f) { return __half_as_ushort(f2h_rn(f)); }
+__device__ __forceinline__ float f16r(float f) { return __half2float(f2h_rn(f)); }
 __device__ __forceinline__ float tab(const __half *t, float x) { return __half2float(t[f2h_bits(x)]); }
 
 __device__ __forceinline__ int4 ld16(const void *p) { return *reinterpret_cast<const int4 *>(p); }
@@ -220,6 +220,14 @@ template <> struct Tr<GT_Q4_0> {
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) {
         const int8_t *p = A.q80 + (size_t)t * K + (size_t)u * 32; a.a0 = ld16(p); a.a1 = ld16(p + 16);
         const size_t b = (size_t)t * (K / 32) + u; a.d = A.d0[b]; a.sum = A.sum0[b]; }
+    static constexpr int GROUP = 1, TERMS = 1;   // units per ggml block, fp32 terms per block (k_mul_mat_ref)
+    static __device__ __forceinline__ void ints(const WU &w, const AU &a, int &i0, int &i1) {
+        int s = 0;
+        s = dot4(w.q.x & 0x0F0F0F0F, a.a0.x, s); s = dot4(w.q.y & 0x0F0F0F0F, a.a0.y, s); s = dot4(w.q.z & 0x0F0F0F0F, a.a0.z, s); s = dot4(w.q.w & 0x0F0F0F0F, a.a0.w, s);
+        s = dot4((w.q.x >> 4) & 0x0F0F0F0F, a.a1.x, s); s = dot4((w.q.y >> 4) & 0x0F0F0F0F, a.a1.y, s); s = dot4((w.q.z >> 4) & 0x0F0F0F0F, a.a1.z, s); s = dot4((w.q.w >> 4) & 0x0F0F0F0F, a.a1.w, s);
+        i0 = s - 8 * a.sum; i1 = 0;
+    }
+    static __device__ __forceinline__ void terms(const WU &w, const AU &a, int i0, int, float &f0, float &v0, float &f1, float &v1) { f0 = h2f_bits(w.dh) * a.d; v0 = (float)i0; f1 = v1 = 0.0f; }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
         int s = 0;
         s = dot4(w.q.x & 0x0F0F0F0F, a.a0.x, s); s = dot4(w.q.y & 0x0F0F0F0F, a.a0.y, s); s = dot4(w.q.z & 0x0F0F0F0F, a.a0.z, s); s = dot4(w.q.w & 0x0F0F0F0F, a.a0.w, s);
@@ -238,6 +246,14 @@ template <> struct Tr<GT_Q4_1> {
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) {
         const int8_t *p = A.q80 + (size_t)t * K + (size_t)u * 32; a.a0 = ld16(p); a.a1 = ld16(p + 16);
         const size_t b = (size_t)t * (K / 32) + u; a.d = A.d1[b]; a.s = A.s1[b]; }
+    static constexpr int GROUP = 1, TERMS = 2;
+    static __device__ __forceinline__ void ints(const WU &w, const AU &a, int &i0, int &i1) {
+        int s = 0;
+        s = dot4(w.q.x & 0x0F0F0F0F, a.a0.x, s); s = dot4(w.q.y & 0x0F0F0F0F, a.a0.y, s); s = dot4(w.q.z & 0x0F0F0F0F, a.a0.z, s); s = dot4(w.q.w & 0x0F0F0F0F, a.a0.w, s);
+        s = dot4((w.q.x >> 4) & 0x0F0F0F0F, a.a1.x, s); s = dot4((w.q.y >> 4) & 0x0F0F0F0F, a.a1.y, s); s = dot4((w.q.z >> 4) & 0x0F0F0F0F, a.a1.z, s); s = dot4((w.q.w >> 4) & 0x0F0F0F0F, a.a1.w, s);
+        i0 = s; i1 = 0;
+    }
+    static __device__ __forceinline__ void terms(const WU &w, const AU &a, int i0, int, float &f0, float &v0, float &f1, float &v1) { f0 = h2f_bits(w.dm & 0xFFFF) * a.d; v0 = (float)i0; f1 = h2f_bits(w.dm >> 16); v1 = a.s; }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
         int s = 0;
         s = dot4(w.q.x & 0x0F0F0F0F, a.a0.x, s); s = dot4(w.q.y & 0x0F0F0F0F, a.a0.y, s); s = dot4(w.q.z & 0x0F0F0F0F, a.a0.z, s); s = dot4(w.q.w & 0x0F0F0F0F, a.a0.w, s);
@@ -260,6 +276,13 @@ template <> struct Tr<GT_Q5_0> {
     static __device__ __forceinline__ void mkb(const QWeight &W, size_t g0, WBuf &B) { B.qs = mkbuf(W.qs + g0 * 16); B.qh = mkbuf(W.qh + g0 * 4); B.sc = mkbuf(W.sc + g0 * 2); }
     static __device__ __forceinline__ void loadb(const WBuf &B, int u, WU &w) { w.q = bld16(B.qs, u * 16); w.P = bld4(B.qh, u * 4); w.dh = bld2(B.sc, u * 2); }
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { Tr<GT_Q4_0>::loada(A, t, K, u, a); }
+    static constexpr int GROUP = 1, TERMS = 1;
+    static __device__ __forceinline__ void ints(const WU &w, const AU &a, int &i0, int &i1) {
+        int s = 0; const unsigned P = w.P;
+        MG4_Q5_DOT8(w.q, P, a.a0, a.a1, s)
+        i0 = s - 16 * a.sum; i1 = 0;
+    }
+    static __device__ __forceinline__ void terms(const WU &w, const AU &a, int i0, int, float &f0, float &v0, float &f1, float &v1) { f0 = h2f_bits(w.dh) * a.d; v0 = (float)i0; f1 = v1 = 0.0f; }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
         int s = 0; const unsigned P = w.P;
         MG4_Q5_DOT8(w.q, P, a.a0, a.a1, s)
@@ -276,6 +299,13 @@ template <> struct Tr<GT_Q5_1> {
     static __device__ __forceinline__ void mkb(const QWeight &W, size_t g0, WBuf &B) { B.qs = mkbuf(W.qs + g0 * 16); B.qh = mkbuf(W.qh + g0 * 4); B.sc = mkbuf(W.sc + g0 * 4); }
     static __device__ __forceinline__ void loadb(const WBuf &B, int u, WU &w) { w.q = bld16(B.qs, u * 16); w.P = bld4(B.qh, u * 4); w.dm = bld4(B.sc, u * 4); }
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { Tr<GT_Q4_1>::loada(A, t, K, u, a); }
+    static constexpr int GROUP = 1, TERMS = 2;
+    static __device__ __forceinline__ void ints(const WU &w, const AU &a, int &i0, int &i1) {
+        int s = 0; const unsigned P = w.P;
+        MG4_Q5_DOT8(w.q, P, a.a0, a.a1, s)
+        i0 = s; i1 = 0;
+    }
+    static __device__ __forceinline__ void terms(const WU &w, const AU &a, int i0, int, float &f0, float &v0, float &f1, float &v1) { f0 = h2f_bits(w.dm & 0xFFFF) * a.d; v0 = (float)i0; f1 = h2f_bits(w.dm >> 16); v1 = a.s; }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
         int s = 0; const unsigned P = w.P;
         MG4_Q5_DOT8(w.q, P, a.a0, a.a1, s)
@@ -289,6 +319,13 @@ template <> struct Tr<GT_Q8_0> {   // unit = half a block (16 int8); the two hal
     struct AU { int4 a; float d; };
     static __device__ __forceinline__ void loadw(const QWeight &W, size_t g0, int u, WU &w) { w.q = ldw<int4>(W.qs + g0 * 16 + (unsigned)(u * 16)); w.dh = ldw<unsigned short>(W.sc + (g0 >> 1) * 2 + (unsigned)((u >> 1) * 2)); }
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { a.a = ld16(A.q80 + (size_t)t * K + (size_t)u * 16); a.d = A.d0[(size_t)t * (K / 32) + (u >> 1)]; }
+    static constexpr int GROUP = 2, TERMS = 1;
+    static __device__ __forceinline__ void ints(const WU &w, const AU &a, int &i0, int &i1) {
+        int s = 0;
+        s = dot4(w.q.x, a.a.x, s); s = dot4(w.q.y, a.a.y, s); s = dot4(w.q.z, a.a.z, s); s = dot4(w.q.w, a.a.w, s);
+        i0 = s; i1 = 0;
+    }
+    static __device__ __forceinline__ void terms(const WU &w, const AU &a, int i0, int, float &f0, float &v0, float &f1, float &v1) { f0 = h2f_bits(w.dh) * a.d; v0 = (float)i0; f1 = v1 = 0.0f; }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
         int s = 0;
         s = dot4(w.q.x, a.a.x, s); s = dot4(w.q.y, a.a.y, s); s = dot4(w.q.z, a.a.z, s); s = dot4(w.q.w, a.a.w, s);
@@ -322,6 +359,16 @@ template <> struct Tr<GT_Q2_K> {   // supported, not tuned: only the generic til
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) {
         const int8_t *p = A.q8k + (size_t)t * K + (size_t)u * 32; a.lo = ld16(p); a.hi = ld16(p + 16);
         a.d = A.dk[(size_t)t * (K / 256) + (u >> 3)]; const int16_t *bs = A.bsk + (size_t)t * (K / 16) + 2 * u; a.bs_lo = bs[0]; a.bs_hi = bs[1]; }
+    static constexpr int GROUP = 8, TERMS = 2;
+    static __device__ __forceinline__ void ints(const WU &w, const AU &a, int &i0, int &i1) {
+        int s0 = 0, s1 = 0; const unsigned L = w.p.x, H = w.p.y;
+        s0 = dot4(L & 0x03030303, a.lo.x, s0); s0 = dot4((L >> 2) & 0x03030303, a.lo.y, s0); s0 = dot4((L >> 4) & 0x03030303, a.lo.z, s0); s0 = dot4((L >> 6) & 0x03030303, a.lo.w, s0);
+        s1 = dot4(H & 0x03030303, a.hi.x, s1); s1 = dot4((H >> 2) & 0x03030303, a.hi.y, s1); s1 = dot4((H >> 4) & 0x03030303, a.hi.z, s1); s1 = dot4((H >> 6) & 0x03030303, a.hi.w, s1);
+        const int sc0 = w.sc & 0xF, m0 = (w.sc >> 4) & 0xF, sc1 = (w.sc >> 8) & 0xF, m1 = w.sc >> 12;
+        i0 = mul24(sc0, s0) + mul24(sc1, s1); i1 = m0 * a.bs_lo + m1 * a.bs_hi;
+    }
+    static __device__ __forceinline__ void terms(const WU &w, const AU &a, int i0, int i1, float &f0, float &v0, float &f1, float &v1) {
+        const float d = h2f_bits(w.dm & 0xFFFF), dmin = h2f_bits(w.dm >> 16); f0 = d * a.d; v0 = (float)i0; f1 = -(dmin * a.d); v1 = (float)i1; }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
         int s0 = 0, s1 = 0; const unsigned L = w.p.x, H = w.p.y;
         s0 = dot4(L & 0x03030303, a.lo.x, s0); s0 = dot4((L >> 2) & 0x03030303, a.lo.y, s0); s0 = dot4((L >> 4) & 0x03030303, a.lo.z, s0); s0 = dot4((L >> 6) & 0x03030303, a.lo.w, s0);
@@ -343,6 +390,17 @@ template <> struct Tr<GT_Q4_K> {
         const int sb = u >> 3, i = u & 7, j = i >> 1, h = i & 1;
         const int8_t *p = A.q8k + (size_t)t * K + (size_t)sb * 256 + 64 * j + 16 * h; a.lo = ld16(p); a.hi = ld16(p + 32);
         a.d = A.dk[(size_t)t * (K / 256) + sb]; const int16_t *bs = A.bsk + (size_t)t * (K / 16) + sb * 16 + 4 * j + h; a.bs_lo = bs[0]; a.bs_hi = bs[2]; }
+    static constexpr int GROUP = 8, TERMS = 2;
+    static __device__ __forceinline__ void ints(const WU &w, const AU &a, int &i0, int &i1) {
+        const int j = (threadIdx.x & 7) >> 1;
+        int sc0, sc1, m0, m1; scale_min_pair(w.h, j, sc0, sc1, m0, m1);
+        int s0 = 0, s1 = 0;
+        s0 = dot4(w.q.x & 0x0F0F0F0F, a.lo.x, s0); s0 = dot4(w.q.y & 0x0F0F0F0F, a.lo.y, s0); s0 = dot4(w.q.z & 0x0F0F0F0F, a.lo.z, s0); s0 = dot4(w.q.w & 0x0F0F0F0F, a.lo.w, s0);
+        s1 = dot4((w.q.x >> 4) & 0x0F0F0F0F, a.hi.x, s1); s1 = dot4((w.q.y >> 4) & 0x0F0F0F0F, a.hi.y, s1); s1 = dot4((w.q.z >> 4) & 0x0F0F0F0F, a.hi.z, s1); s1 = dot4((w.q.w >> 4) & 0x0F0F0F0F, a.hi.w, s1);
+        i0 = mul24(sc0, s0) + mul24(sc1, s1); i1 = m0 * a.bs_lo + m1 * a.bs_hi;
+    }
+    static __device__ __forceinline__ void terms(const WU &w, const AU &a, int i0, int i1, float &f0, float &v0, float &f1, float &v1) {
+        const float d = h2f_bits((unsigned)w.h.x & 0xFFFF), dmin = h2f_bits((unsigned)w.h.x >> 16); f0 = d * a.d; v0 = (float)i0; f1 = -(dmin * a.d); v1 = (float)i1; }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
         const int j = (threadIdx.x & 7) >> 1;
         int sc0, sc1, m0, m1; scale_min_pair(w.h, j, sc0, sc1, m0, m1);
@@ -362,6 +420,19 @@ template <> struct Tr<GT_Q5_K> {
     static __device__ __forceinline__ void mkb(const QWeight &W, size_t g0, WBuf &B) { B.qs = mkbuf(W.qs + g0 * 16); B.sc = mkbuf(W.sc + (g0 >> 3) * 16); B.qh = mkbuf(W.qh + g0 * 4); }
     static __device__ __forceinline__ void loadb(const WBuf &B, int u, WU &w) { w.q = bld16(B.qs, u * 16); w.h = bld16(B.sc, (u >> 3) * 16); w.P = bld4(B.qh, u * 4); }
     static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u, AU &a) { Tr<GT_Q4_K>::loada(A, t, K, u, a); }
+    static constexpr int GROUP = 8, TERMS = 2;
+    static __device__ __forceinline__ void ints(const WU &w, const AU &a, int &i0, int &i1) {
+        const int j = (threadIdx.x & 7) >> 1;
+        int sc0, sc1, m0, m1; scale_min_pair(w.h, j, sc0, sc1, m0, m1);
+        const unsigned P = w.P; int s0 = 0, s1 = 0;
+        s0 = dot4((w.q.x & 0x0F0F0F0F) | ((P << 4) & 0x10101010), a.lo.x, s0); s0 = dot4((w.q.y & 0x0F0F0F0F) | ((P << 3) & 0x10101010), a.lo.y, s0);
+        s0 = dot4((w.q.z & 0x0F0F0F0F) | ((P << 2) & 0x10101010), a.lo.z, s0); s0 = dot4((w.q.w & 0x0F0F0F0F) | ((P << 1) & 0x10101010), a.lo.w, s0);
+        s1 = dot4(((w.q.x >> 4) & 0x0F0F0F0F) | (P & 0x10101010), a.hi.x, s1); s1 = dot4(((w.q.y >> 4) & 0x0F0F0F0F) | ((P >> 1) & 0x10101010), a.hi.y, s1);
+        s1 = dot4(((w.q.z >> 4) & 0x0F0F0F0F) | ((P >> 2) & 0x10101010), a.hi.z, s1); s1 = dot4(((w.q.w >> 4) & 0x0F0F0F0F) | ((P >> 3) & 0x10101010), a.hi.w, s1);
+        i0 = mul24(sc0, s0) + mul24(sc1, s1); i1 = m0 * a.bs_lo + m1 * a.bs_hi;
+    }
+    static __device__ __forceinline__ void terms(const WU &w, const AU &a, int i0, int i1, float &f0, float &v0, float &f1, float &v1) {
+        const float d = h2f_bits((unsigned)w.h.x & 0xFFFF), dmin = h2f_bits((unsigned)w.h.x >> 16); f0 = d * a.d; v0 = (float)i0; f1 = -(dmin * a.d); v1 = (float)i1; }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
         const int j = (threadIdx.x & 7) >> 1;
         int sc0, sc1, m0, m1; scale_min_pair(w.h, j, sc0, sc1, m0, m1);
@@ -392,6 +463,17 @@ static __device__ __forceinline__ void loada(const ActQ &A, int t, int K, int u,
         const int sb = u >> 3, i = u & 7, n = i >> 2, c = (i >> 1) & 1, h = i & 1;
         const int8_t *p = A.q8k + (size_t)t * K + (size_t)sb * 256 + 128 * n + 32 * c + 16 * h; a.lo = ld16(p); a.hi = ld16(p + 64);
         a.d = A.dk[(size_t)t * (K / 256) + sb]; const int16_t *bs = A.bsk + (size_t)t * (K / 16) + sb * 16 + 8 * n + 2 * c + h; a.bs_lo = bs[0]; a.bs_hi = bs[4]; }
+    static constexpr int GROUP = 8, TERMS = 1;
+    static __device__ __forceinline__ void ints(const WU &w, const AU &a, int &i0, int &i1) {
+        int s0 = 0, s1 = 0; const unsigned L = w.Plo, H = w.Phi;
+        s0 = dot4((w.q.x & 0x0F0F0F0F) | ((L << 4) & 0x30303030), a.lo.x, s0); s0 = dot4((w.q.y & 0x0F0F0F0F) | ((L << 2) & 0x30303030), a.lo.y, s0);
+        s0 = dot4((w.q.z & 0x0F0F0F0F) | (L & 0x30303030), a.lo.z, s0); s0 = dot4((w.q.w & 0x0F0F0F0F) | ((L >> 2) & 0x30303030), a.lo.w, s0);
+        s1 = dot4(((w.q.x >> 4) & 0x0F0F0F0F) | ((H << 4) & 0x30303030), a.hi.x, s1); s1 = dot4(((w.q.y >> 4) & 0x0F0F0F0F) | ((H << 2) & 0x30303030), a.hi.y, s1);
+        s1 = dot4(((w.q.z >> 4) & 0x0F0F0F0F) | (H & 0x30303030), a.hi.z, s1); s1 = dot4(((w.q.w >> 4) & 0x0F0F0F0F) | ((H >> 2) & 0x30303030), a.hi.w, s1);
+        s0 -= 32 * a.bs_lo; s1 -= 32 * a.bs_hi;
+        i0 = mul24((int)(signed char)(w.sc & 0xFF), s0) + mul24((int)(signed char)(w.sc >> 8), s1); i1 = 0;
+    }
+    static __device__ __forceinline__ void terms(const WU &w, const AU &a, int i0, int, float &f0, float &v0, float &f1, float &v1) { f0 = h2f_bits(w.dh) * a.d; v0 = (float)i0; f1 = v1 = 0.0f; }
     static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
         int s0 = 0, s1 = 0; const unsigned L = w.Plo, H = w.Phi;
         s0 = dot4((w.q.x & 0x0F0F0F0F) | ((L << 4) & 0x30303030), a.lo.x, s0); s0 = dot4((w.q.y & 0x0F0F0F0F) | ((L << 2) & 0x30303030), a.lo.y, s0);
@@ -484,6 +566,65 @@ static void launch_mul_mat_t(const QWeight &W, const ActQ &A, int N, float *y, i
         hipLaunchKernelGGL((k_mul_mat<T, R, TN>), grid, dim3(256), 0, s, W, A, N, y, ldy, residual);
     }
 }
+// =====================================================================================================================
+// MINIGPT4_PARITY=1 -- the oracle's fp32 ORDER (oracle/refcpu.c vec_dot_*: one sequential chain of fma's per output, block after block).  One wave per
+// (row, token): the lanes split the row's units exactly like k_mul_mat and use the same unit traits (same loads, same integer dot products), but the integer parts are
+// first combined per ggml block (8 units per k-quant super-block, 2 per Q8_0 block: exact), and the per-block fp32 terms are then added by every lane in block order.
+// The fast kernels differ from this one only in the order of those additions; this one is bit-identical to the CPU oracle.  F16 / F32: one fma per ELEMENT in
+// element order (ggml_vec_dot_f16 restated as a scalar loop), unit after unit.
+// =====================================================================================================================
+template <int T>
+__global__ __launch_bounds__(256) void k_mul_mat_ref(const QWeight W, const ActQ A, const int N, float *y, const int ldy, const float *residual) {
+    using X = Tr<T>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave, t = blockIdx.y;
+    if (row >= W.rows || t >= N) return;          // wave-uniform
+    const int K = W.cols, U = K / X::EPU;
+    float acc = 0.0f;
+    for (int u0 = 0; u0 < U; u0 += 64) {
+        const int u = u0 + lane;
+        const bool ok = u < U;
+        const int uc = ok ? u : 0;
+        const int n_here = min(64, U - u0);
+        typename X::AU a; X::loada(A, t, K, uc, a);
+        typename X::WU w; X::loadw(W, (size_t)row * U, uc, w);
+        if constexpr (T == GT_F16 || T == GT_F32) {
+            for (int g = 0; g < n_here; g++) { float c = acc; X::dot(w, a, c); acc = __shfl(c, g); }   // unit g continues the chain where unit g - 1 left it
+        } else {
+            int i0, i1; X::ints(w, a, i0, i1);
+            if (!ok) { i0 = 0; i1 = 0; }
+#pragma unroll
+            for (int m = 1; m < X::GROUP; m <<= 1) { i0 += __shfl_xor(i0, m); i1 += __shfl_xor(i1, m); }
+            float f0, v0, f1, v1; X::terms(w, a, i0, i1, f0, v0, f1, v1);
+            for (int g = 0; g < n_here; g += X::GROUP) {
+                acc = fmaf(__shfl(f0, g), __shfl(v0, g), acc);
+                if (X::TERMS == 2) acc = fmaf(__shfl(f1, g), __shfl(v1, g), acc);
+            }
+        }
+    }
+    if (lane == 0) { const size_t o = (size_t)t * ldy + row; y[o] = residual ? acc + residual[o] : acc; }
+}
+template <int T> static void launch_mul_mat_ref_t(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
+    note_kernel("k_mul_mat_ref<%d>", T);
+    hipLaunchKernelGGL((k_mul_mat_ref<T>), dim3((unsigned)((W.rows + 3) / 4), (unsigned)N), dim3(256), 0, s, W, A, N, y, ldy, residual);
+}
+void launch_mul_mat_ref(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
+    switch (W.type) {
+    case GT_Q4_0: launch_mul_mat_ref_t<GT_Q4_0>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q4_1: launch_mul_mat_ref_t<GT_Q4_1>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q5_0: launch_mul_mat_ref_t<GT_Q5_0>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q5_1: launch_mul_mat_ref_t<GT_Q5_1>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q8_0: launch_mul_mat_ref_t<GT_Q8_0>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q2_K: launch_mul_mat_ref_t<GT_Q2_K>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q4_K: launch_mul_mat_ref_t<GT_Q4_K>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q5_K: launch_mul_mat_ref_t<GT_Q5_K>(W, A, N, y, ldy, residual, s); break;
+    case GT_Q6_K: launch_mul_mat_ref_t<GT_Q6_K>(W, A, N, y, ldy, residual, s); break;
+    case GT_F16: launch_mul_mat_ref_t<GT_F16>(W, A, N, y, ldy, residual, s); break;
+    case GT_F32: launch_mul_mat_ref_t<GT_F32>(W, A, N, y, ldy, residual, s); break;
+    default: throw HipError{hipErrorInvalidValue, "unsupported weight type", __FILE__, __LINE__};
+    }
+}
+
 // =====================================================================================================================
 // Decode mat-vec, v2: persistent waves.  The launch covers up to 3 matrices of one type and one K (wq|wk|wv, w1|w3) as one
 // concatenated row space.  A wave walks row groups g = wave, wave + n_waves, ...; each lane owns NU fixed units of a row
@@ -1279,7 +1420,7 @@ __device__ __forceinline__ void quant_emit4(const float v[4], const bool in_rang
                                             const ActQ &A, const int mask) {
     const int lane = threadIdx.x & 63;
     if (mask & ACT_F32) { if (in_range) *reinterpret_cast<float4 *>(A.xf + row * K + idx) = make_float4(v[0], v[1], v[2], v[3]); }
-    if (mask & ACT_F16) { if (in_range) { __half2 h0 = __floats2half2_rn(v[0], v[1]), h1 = __floats2half2_rn(v[2], v[3]);
+    if (mask & ACT_F16) { if (in_range) { __half2 h0 = __halves2half2(f2h_rn(v[0]), f2h_rn(v[1])), h1 = __halves2half2(f2h_rn(v[2]), f2h_rn(v[3]));
             uint2 o; o.x = *reinterpret_cast<unsigned *>(&h0); o.y = *reinterpret_cast<unsigned *>(&h1); *reinterpret_cast<uint2 *>(A.xh + row * K + idx) = o; } }
     if (mask & ACT_Q8K) {
         // signed value of the FIRST element with the largest magnitude in the 256-block (ggml quantize_row_q8_K): the wave = one block,
@@ -1328,12 +1469,17 @@ __device__ __forceinline__ void quant_emit4(const float v[4], const bool in_rang
 }
 
 constexpr int RQ_THREADS = 1024;
-__global__ __launch_bounds__(RQ_THREADS) void k_rms_quant(const float *__restrict__ x, const float *__restrict__ w, const int K, const ActQ A, const int mask) {
+__global__ __launch_bounds__(RQ_THREADS) void k_rms_quant(const float *__restrict__ x, const float *__restrict__ w, const int K, const ActQ A, const int mask, const int seq) {
     const size_t row = blockIdx.x;
     const float *xr = x + row * K;
     __shared__ double red[RQ_THREADS / 64];
     float scale = 1.0f;
-    if (w) {
+    if (w && seq) {   // MINIGPT4_PARITY: ggml_compute_forward_rms_norm's loop literally -- one double accumulator, element order
+        if (threadIdx.x == 0) { double sum = 0.0; for (int i = 0; i < K; i++) sum += (double)(xr[i] * xr[i]); red[0] = sum; }
+        __syncthreads();
+        const float mean = (float)(red[0] / (double)K);
+        scale = 1.0f / sqrtf(mean + 1e-6f);
+    } else if (w) {
         double sum = 0.0;
         for (int i = threadIdx.x * 4; i < K; i += RQ_THREADS * 4) { const float4 v = *reinterpret_cast<const float4 *>(xr + i);
             sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w); }
@@ -1356,9 +1502,9 @@ __global__ __launch_bounds__(RQ_THREADS) void k_rms_quant(const float *__restric
         quant_emit4(v, in, i, row, K, A, mask);
     }
 }
-void launch_rms_quant(const float *x, const float *w, int N, int K, const ActQ &A, int mask, hipStream_t s) {
+void launch_rms_quant(const float *x, const float *w, int N, int K, const ActQ &A, int mask, hipStream_t s, bool sequential_sum) {
     note_kernel("k_rms_quant");
-    hipLaunchKernelGGL(k_rms_quant, dim3((unsigned)N), dim3(RQ_THREADS), 0, s, x, w, K, A, mask);
+    hipLaunchKernelGGL(k_rms_quant, dim3((unsigned)N), dim3(RQ_THREADS), 0, s, x, w, K, A, mask, sequential_sum ? 1 : 0);
 }
 
 __global__ __launch_bounds__(256) void k_silu_mul_quant(const float *__restrict__ a, const float *__restrict__ b, const int K, const ActQ A, const int mask, const Tables tb) {
@@ -1486,7 +1632,7 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
             *reinterpret_cast<__half2 *>(kc + co) = kr; *reinterpret_cast<__half2 *>(vc + co) = vr;
         }
     } else {
-        for (int i = tid; i < HD; i += AT_THREADS) qh[i] = __float2half_rn(q[qo + i]);
+        for (int i = tid; i < HD; i += AT_THREADS) qh[i] = f2h_rn(q[qo + i]);
     }
     __syncthreads();
     unsigned qreg[HD / 2];
@@ -1563,7 +1709,7 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
 #pragma unroll
     for (int i = 0; i < AT_THREADS / 64; i++) tot += s_dred[i];
     const float inv = (float)(1.0 / tot);
-    for (int j = tid; j < T; j += AT_THREADS) ph[j] = __float2half_rn(sc[j] * inv);
+    for (int j = tid; j < T; j += AT_THREADS) ph[j] = f2h_rn(sc[j] * inv);
     __syncthreads();
     float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto pv_acc = [&](const int4 &vv, const int j) {
@@ -1794,6 +1940,55 @@ void launch_attn_llm(float *q, const float *k, const float *v, __half *kcache, _
     case 128: launch_attn_hd<128>(q, k, v, kcache, vcache, N, n_head, n_past, n_ctx, cos_tab, sin_tab, tb, out, fused, s); break;
     default: throw HipError{hipErrorInvalidValue, "unsupported head size", __FILE__, __LINE__};
     }
+}
+
+// =====================================================================================================================
+// MINIGPT4_PARITY=1 attention: the oracle's loops (oracle/refcpu.c orc_llama_eval, = ggml's mul_mat(K, Q) / soft_max / mul_mat(V, P) on f16 operands) with every fp32
+// chain in ITS order: thread = one key for the scores (sequential fma over the head dimension), exact double sum for the softmax, thread = one output
+// dimension for P.V (sequential fma over the keys).  After launch_rope_kv (q rotated in place, caches appended).  One workgroup per (head, query row).
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void k_attn_ref(const float *__restrict__ q, const __half *__restrict__ kc, const __half *__restrict__ vc, int E, int hd, const int *__restrict__ n_past,
+                                                  const Tables tb, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ref[];
+    const int h = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    const int T = *n_past + t + 1;
+    float *sc = reinterpret_cast<float *>(smem_ref);              // [T]
+    __half *ph = reinterpret_cast<__half *>(sc + ((T + 3) & ~3)); // [T]
+    __half *qh = ph + ((T + 7) & ~7);                             // [hd]
+    __shared__ float red_f[4]; __shared__ double red_d[4];
+    for (int i = tid; i < hd; i += 256) qh[i] = __float2half_rn(q[(size_t)t * E + (size_t)h * hd + i]);
+    __syncthreads();
+    const float kq_scale = 1.0f / sqrtf((float)hd);
+    float mx = -INFINITY;
+    for (int j = tid; j < T; j += 256) {
+        const __half *kr = kc + (size_t)j * E + (size_t)h * hd;
+        float s = 0.0f;
+        for (int i = 0; i < hd; i++) s = fmaf(__half2float(kr[i]), __half2float(qh[i]), s);
+        s *= kq_scale; sc[j] = s; mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red_f[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    double sum = 0.0;
+    for (int j = tid; j < T; j += 256) { const float v = tab(tb.exp, sc[j] - mx); sc[j] = v; sum += (double)v; }   // <= 2048 fp16 values: the double sum is exact in any order
+    sum = wave_sum_d(sum);
+    if ((tid & 63) == 0) red_d[tid >> 6] = sum;
+    __syncthreads();
+    const float inv = (float)(1.0 / (((red_d[0] + red_d[1]) + red_d[2]) + red_d[3]));
+    for (int j = tid; j < T; j += 256) ph[j] = f2h_rn(sc[j] * inv);
+    __syncthreads();
+    for (int i = tid; i < hd; i += 256) {
+        const __half *vr = vc + (size_t)h * hd + i;
+        float s = 0.0f;
+        for (int j = 0; j < T; j++) s = fmaf(__half2float(vr[(size_t)j * E]), __half2float(ph[j]), s);
+        out[(size_t)t * E + (size_t)h * hd + i] = s;
+    }
+}
+void launch_attn_ref(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
+    note_kernel("k_attn_ref");
+    const size_t lds = (size_t)((t_max + 3) & ~3) * 4 + (size_t)((t_max + 7) & ~7) * 2 + (size_t)hd * 2 + 64;
+    hipLaunchKernelGGL(k_attn_ref, dim3((unsigned)n_head, (unsigned)N), dim3(256), lds, s, q, kcache, vcache, n_head * hd, hd, n_past, tb, out);
 }
 
 // =====================================================================================================================

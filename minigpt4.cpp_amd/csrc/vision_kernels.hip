@@ -13,7 +13,7 @@ namespace mg4 {
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ unsigned short f2h_bits_v(float f) { return __half_as_ushort(__float2half_rn(f)); }
+__device__ __forceinline__ unsigned short f2h_bits_v(float f) { return __half_as_ushort(f2h_rn(f)); }
 __device__ __forceinline__ float tab_v(const __half *t, float x) { return __half2float(t[f2h_bits_v(x)]); }
 
 // =====================================================================================================================
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(GB_M / 32 * BN / 32 * 64) void k_gemm_f16(const __h
         for (int r = 0; r < 16; r++) v[r] = rr[r] + v[r];
     }
 #pragma unroll
-    for (int r = 0; r < 16; r++) if (okr[r]) { if (out) out[o[r]] = v[r]; if (out_h) out_h[o[r]] = __float2half_rn(v[r]); }
+    for (int r = 0; r < 16; r++) if (okr[r]) { if (out) out[o[r]] = v[r]; if (out_h) out_h[o[r]] = f2h_rn(v[r]); }
 }
 template <int BK, int BM, int BN>
 static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restric
                 for (int r = 0; r < 16; r++) v[r] = rr[r] + v[r];
             }
 #pragma unroll
-            for (int r = 0; r < 16; r++) if (okr[r]) { if (out) out[o[r]] = v[r]; if (out_h) out_h[o[r]] = __float2half_rn(v[r]); }
+            for (int r = 0; r < 16; r++) if (okr[r]) { if (out) out[o[r]] = v[r]; if (out_h) out_h[o[r]] = f2h_rn(v[r]); }
         }
     }
 }
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_ln(const float *__restric
             v = ln_w[i] * v;
             if (ln_b) v = v + ln_b[i];
             if (ln_out) ln_out[row * n + i] = v;
-            if (ln_out_h) ln_out_h[row * n + i] = __float2half_rn(v);
+            if (ln_out_h) ln_out_h[row * n + i] = f2h_rn(v);
         }
     }
 }
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
             v = w[i] * v;
             if (b) v = v + b[i];
             if (out) out[row * n + i] = v;
-            if (out_h) out_h[row * n + i] = __float2half_rn(v);
+            if (out_h) out_h[row * n + i] = f2h_rn(v);
         }
     }
 }
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void k_attn_f32(const float *__restrict__ q, i
             for (int j = 0; j < nk; j++) o = fmaf(kv[j * LDK + d], sc[qi * nkp + j], o);
             const size_t oo = (size_t)(q0 + qi) * ldo + h * HD + d;
             if (out) out[oo] = o;
-            if (out_h) out_h[oo] = __float2half_rn(o);
+            if (out_h) out_h[oo] = f2h_rn(o);
         }
     }
 }
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
         if (qrow < nq && dim0 < HD) {
             const size_t oo = (size_t)qrow * ldo + h * HD + dim0;
             if (out) *reinterpret_cast<float4 *>(out + oo) = make_float4(s4[0], s4[1], s4[2], s4[3]);
-            if (out_h) { __half2 a = __floats2half2_rn(s4[0], s4[1]), b = __floats2half2_rn(s4[2], s4[3]); uint2 w; w.x = *reinterpret_cast<unsigned *>(&a); w.y = *reinterpret_cast<unsigned *>(&b); *reinterpret_cast<uint2 *>(out_h + oo) = w; }
+            if (out_h) { __half2 a = __halves2half2(f2h_rn(s4[0]), f2h_rn(s4[1])), b = __halves2half2(f2h_rn(s4[2]), f2h_rn(s4[3])); uint2 w; w.x = *reinterpret_cast<unsigned *>(&a); w.y = *reinterpret_cast<unsigned *>(&b); *reinterpret_cast<uint2 *>(out_h + oo) = w; }
         }
     }
 }
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256) void k_lin_epilogue(const float *__restrict__ 
     if (gelu) v = tab_v(tb.gelu, v);
     if (residual) v = residual[i] + v;
     if (out) out[i] = v;
-    if (out_h) out_h[i] = __float2half_rn(v);
+    if (out_h) out_h[i] = f2h_rn(v);
 }
 void launch_lin_epilogue(const float *y, const float *bias, const float *residual, bool gelu, const Tables &tb, int rows, int n, float *out, __half *out_h, hipStream_t s) {
     const size_t total = (size_t)rows * n;
@@ -671,7 +671,7 @@ __global__ void k_im2col(const float *__restrict__ img, __half *__restrict__ pat
     for (int kk = threadIdx.x; kk < ldp; kk += blockDim.x) {
         float v = 0.0f;
         if (kk < 588) { const int c = kk / 196, r = kk - c * 196, kh = r / 14, kw = r - kh * 14; v = img[(size_t)c * 224 * 224 + (size_t)(oh * 14 + kh) * 224 + ow * 14 + kw]; }
-        patches[(size_t)p * ldp + kk] = __float2half_rn(v);
+        patches[(size_t)p * ldp + kk] = f2h_rn(v);
     }
 }
 void launch_im2col(const float *image, __half *patches, int ldp, hipStream_t s, int batch) { hipLaunchKernelGGL(k_im2col, dim3(256, (unsigned)batch), dim3(256), 0, s, image, patches, ldp); }
@@ -689,7 +689,7 @@ void launch_assemble_embeddings(const float *cls, const float *pe, const float *
 }
 __global__ void k_f32_to_f16(const float *__restrict__ x, __half *__restrict__ y, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] = __float2half_rn(x[i]);
+    if (i < n) y[i] = f2h_rn(x[i]);
 }
 void launch_f32_to_f16(const float *x, __half *y, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_f32_to_f16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n); }
 

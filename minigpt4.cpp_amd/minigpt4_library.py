@@ -121,6 +121,7 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_weight_arena.argtypes = [VOID_PTR, I32, P(VOID_PTR), P(SIZE_T)]
         L.minigpt4_amd_convert_q3k_q6k.argtypes = [VOID_PTR, VOID_PTR, ctypes.c_int64]
         L.minigpt4_amd_test_mul_mat.argtypes = [I32, VOID_PTR, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, ctypes.c_int64, FLOAT_PTR]
+        L.minigpt4_amd_test_mul_mat_ref.argtypes = L.minigpt4_amd_test_mul_mat.argtypes
         L.minigpt4_amd_test_mmq2.argtypes = [I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, ctypes.c_int64, FLOAT_PTR, I32, I32, FLOAT_PTR]
         L.minigpt4_amd_test_matvec.argtypes = [I32, VOID_PTR, I32, I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, FLOAT_PTR, I32, I32, I32, FLOAT_PTR, FLOAT_PTR]
         L.minigpt4_amd_test_matvec_rows.argtypes = [I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, I32, FLOAT_PTR, FLOAT_PTR]
@@ -145,6 +146,8 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_weights_received.argtypes = [VOID_PTR]
         L.minigpt4_amd_copy_arenas.argtypes = [VOID_PTR, VOID_PTR]
         L.minigpt4_amd_arena_checksum.argtypes = [VOID_PTR, I32, U64P]
+        L.minigpt4_amd_set_parity.argtypes = [VOID_PTR, I32]
+        L.minigpt4_amd_parity.argtypes = [VOID_PTR]
         L.minigpt4_amd_set_conversations.argtypes = [VOID_PTR, I32]
         L.minigpt4_amd_select_conversation.argtypes = [VOID_PTR, I32]
         L.minigpt4_amd_n_conversations.argtypes = [VOID_PTR]
@@ -256,6 +259,11 @@ class MiniGPT4SharedLibrary:
         return int(v.value)
 
     # several conversations per context (include/minigpt4_amd.h): the reference calls act on the selected one
+    def amd_set_parity(self, ctx, on: bool):
+        """Parity mode (MINIGPT4_PARITY): the language path adds its fp32 terms in the CPU oracle's order -- bit-identical logits, slow."""
+        if self.library.minigpt4_amd_set_parity(ctx.ptr, 1 if on else 0):
+            raise RuntimeError("minigpt4_amd_set_parity failed")
+
     def amd_set_conversations(self, ctx, n: int):
         if self.library.minigpt4_amd_set_conversations(ctx.ptr, n):
             raise RuntimeError("set_conversations failed: " + self.library.minigpt4_amd_last_error().decode())
@@ -316,11 +324,13 @@ class MiniGPT4SharedLibrary:
             raise RuntimeError("profile_sites failed")
         return _json.loads(buf.value.decode())
 
-    def amd_test_mul_mat(self, ggml_type: int, raw_w: np.ndarray, n_in: int, n_out: int, x: np.ndarray) -> np.ndarray:
+    def amd_test_mul_mat(self, ggml_type: int, raw_w: np.ndarray, n_in: int, n_out: int, x: np.ndarray, ref: bool = False) -> np.ndarray:
+        """ref: the parity-mode kernel (oracle accumulation order) instead of the engine's fast dispatch."""
         x = np.ascontiguousarray(x, np.float32).reshape(-1, n_in)
         raw_w = np.ascontiguousarray(raw_w)
         y = np.empty((x.shape[0], n_out), np.float32)
-        rc = self.library.minigpt4_amd_test_mul_mat(ggml_type, raw_w.ctypes.data_as(VOID_PTR), n_in, n_out, x.ctypes.data_as(FLOAT_PTR), x.shape[0],
+        fn = self.library.minigpt4_amd_test_mul_mat_ref if ref else self.library.minigpt4_amd_test_mul_mat
+        rc = fn(ggml_type, raw_w.ctypes.data_as(VOID_PTR), n_in, n_out, x.ctypes.data_as(FLOAT_PTR), x.shape[0],
                                                     y.ctypes.data_as(FLOAT_PTR))
         if rc:
             raise RuntimeError(f"test_mul_mat rc={rc}: " + self.library.minigpt4_amd_last_error().decode())

@@ -412,6 +412,16 @@ static void soft_max_row(float *p, int n) { /* ggml_compute_forward_soft_max_f32
     const float inv = (float)(1.0 / sum); for (int i = 0; i < n; i++) p[i] *= inv;
 }
 
+/* Optional trace of every intermediate of orc_llama_eval (tools/trace_diff.py: the GPU's parity mode writes the same records; the first differing record localises a
+ * divergence).  Record = 32-byte name, int64 count, count floats. */
+static FILE *g_trace = NULL;
+ORC_API int orc_set_trace(const char *path) { if (g_trace) { fclose(g_trace); g_trace = NULL; } if (path && *path) { g_trace = fopen(path, "wb"); return g_trace ? 0 : 1; } return 0; }
+static void trace(const char *what, int il, const float *p, int64_t n) {
+    if (!g_trace) return;
+    char name[32]; memset(name, 0, sizeof name); snprintf(name, sizeof name, "%s.%d", what, il);
+    fwrite(name, 1, 32, g_trace); fwrite(&n, 8, 1, g_trace); fwrite(p, 4, (size_t)n, g_trace); fflush(g_trace);
+}
+
 /* tokens != NULL: ids; else embd [N][n_embd].  logits_out: n_vocab floats of the LAST token.
  * all_logits (optional): [N][n_vocab].  hidden_out (optional): final normed hidden of every token [N][n_embd]. */
 ORC_API int orc_llama_eval(orc_llama *m, const int *tokens, const float *embd, int N, int n_past, float *logits_out, float *all_logits) {
@@ -422,6 +432,7 @@ ORC_API int orc_llama_eval(orc_llama *m, const int *tokens, const float *embd, i
     float *h1 = malloc(sizeof(float) * (size_t)N * F), *h3 = malloc(sizeof(float) * (size_t)N * F), *tmp = malloc(sizeof(float) * (size_t)N * E);
     if (tokens) { const int64_t rb = row_bytes(m->tok.type, E); for (int t = 0; t < N; t++) orc_dequantize_row(m->tok.type, (const uint8_t *)m->tok.data + (int64_t)tokens[t] * rb, inpL + (size_t)t * E, E); }
     else memcpy(inpL, embd, sizeof(float) * (size_t)N * E);
+    trace("embd", -1, inpL, (int64_t)N * E);
     const float kq_scale = 1.0f / sqrtf((float)hd);
     const int T = n_past + N;
     for (int il = 0; il < m->n_layer; il++) {
@@ -431,6 +442,7 @@ ORC_API int orc_llama_eval(orc_llama *m, const int *tokens, const float *embd, i
         orc_mul_mat(L->wq.type, L->wq.data, E, E, cur, N, q);
         orc_mul_mat(L->wk.type, L->wk.data, E, E, cur, N, k);
         orc_mul_mat(L->wv.type, L->wv.data, E, E, cur, N, v);
+        trace("q", il, q, (int64_t)N * E); trace("k", il, k, (int64_t)N * E); trace("v", il, v, (int64_t)N * E);
         for (int t = 0; t < N; t++) { rope_row(q + (size_t)t * E, H, hd, n_past + t); rope_row(k + (size_t)t * E, H, hd, n_past + t);
             for (int i = 0; i < E; i++) { kc[(size_t)(n_past + t) * E + i] = f2h(k[(size_t)t * E + i]); vc[(size_t)i * C + n_past + t] = f2h(v[(size_t)t * E + i]); } }
 #pragma omp parallel for collapse(2) schedule(static)
@@ -444,14 +456,18 @@ ORC_API int orc_llama_eval(orc_llama *m, const int *tokens, const float *embd, i
             for (int i = 0; i < hd; i++) att[(size_t)t * E + h * hd + i] = vec_dot_f16(T, vc + (size_t)(h * hd + i) * C, ph);
             free(sc); free(ph);
         }
+        trace("q_rope", il, q, (int64_t)N * E); trace("att", il, att, (int64_t)N * E);
         orc_mul_mat(L->wo.type, L->wo.data, E, E, att, N, tmp);
         for (size_t i = 0; i < (size_t)N * E; i++) inpL[i] = tmp[i] + inpL[i]; /* inpFF */
+        trace("x_attn", il, inpL, (int64_t)N * E);
         for (int t = 0; t < N; t++) rms_norm_mul(inpL + (size_t)t * E, L->ffn_norm.data, cur + (size_t)t * E, E);
         orc_mul_mat(L->w1.type, L->w1.data, E, F, cur, N, h1);
         orc_mul_mat(L->w3.type, L->w3.data, E, F, cur, N, h3);
+        trace("h1", il, h1, (int64_t)N * F); trace("h3", il, h3, (int64_t)N * F);
         for (size_t i = 0; i < (size_t)N * F; i++) h1[i] = silu_t(h1[i]) * h3[i];
         orc_mul_mat(L->w2.type, L->w2.data, F, E, h1, N, tmp);
         for (size_t i = 0; i < (size_t)N * E; i++) inpL[i] = tmp[i] + inpL[i];
+        trace("x_ffn", il, inpL, (int64_t)N * E);
     }
     for (int t = 0; t < N; t++) rms_norm_mul(inpL + (size_t)t * E, m->norm.data, cur + (size_t)t * E, E);
     if (all_logits) orc_mul_mat(m->output.type, m->output.data, E, m->n_vocab, cur, N, all_logits);

@@ -54,6 +54,7 @@ def lib(native: bool = False):
     L.orc_vec_dot.argtypes = [i32, i64, vp, vp]
     L.orc_mul_mat.argtypes = [i32, vp, i64, i64, vp, i64, vp]
     L.orc_set_simd.argtypes = [i32]
+    L.orc_set_trace.argtypes = [C.c_char_p]
     L.orc_set_simd.restype = None
     L.orc_llama_new.restype = vp
     L.orc_llama_new.argtypes = [i32] * 6

@@ -1,0 +1,134 @@
+"""MINIGPT4_PARITY mode: the language path with every fp32 accumulation in the CPU oracle's order must equal the oracle BIT FOR BIT.
+
+north_star: "bit-exact token ids under greedy sampling with fp32 accumulation, logits within 1e-2 relative otherwise".  The fast kernels add the per-block fp32
+terms of a dot product in a parallel order (lanes, waves, K splits, MFMA tiles); everything else -- activation quantisation, integer block dots, fp16 tables, RoPE,
+softmax sum -- is exact and shared.  Parity mode (Engine::forward_ref: k_mul_mat_ref / k_attn_ref / sequential rms sum) uses the same unit traits and the same
+HBM planes, but adds in oracle/refcpu.c's order, so:
+  * parity-mode logits == oracle logits, `np.array_equal`, for every weight type, prompt chunks, embedding rows and decode steps;
+  * any residual difference would localise a real bug (layout, integer arithmetic, table, stride) rather than "summation noise";
+  * the fast path is then compared with parity mode ON THE GPU (same weights in HBM): that difference is summation order only.
+Reference call sites: /root/reference/minigpt4.cpp:2365-2382 (add_tokens -> llama_eval), :2399-2422 (llama_eval_embd), :2425-2456 (greedy).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+QTYPES = ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q2_k", "q3_k", "q4_k", "q5_k", "q6_k", "f16", "f32"]
+
+
+@pytest.mark.parametrize("wtype", QTYPES)
+@pytest.mark.parametrize("shape", [(1, 512, 96), (5, 768, 70), (2, 5120, 64), (3, 13824, 40), (33, 1024, 130), (7, 352, 100), (4, 1408, 64)])
+def test_mul_mat_ref_bit_identical(gpu_lib, wtype, shape):
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    N, n_in, n_out = shape
+    t = Q.NAME_TO_TYPE[wtype]
+    if n_in % Q.BLOCK[t][0]:
+        pytest.skip("row length is not a whole number of blocks of this type")
+    rng = np.random.default_rng(sum(map(ord, wtype)) * 999 + sum(shape))
+    w = (0.05 * rng.standard_normal((n_out, n_in))).astype(np.float32)
+    raw = Q.quantize(t, w)
+    x = rng.standard_normal((N, n_in)).astype(np.float32)
+    want = R.mul_mat(t, raw, n_in, n_out, x)
+    got = gpu_lib.amd_test_mul_mat(t, raw, n_in, n_out, x, ref=True)
+    assert np.array_equal(got, want), (wtype, shape, float(np.abs(got - want).max()))
+    fast = gpu_lib.amd_test_mul_mat(t, raw, n_in, n_out, x)            # the fast dispatch differs by summation order only
+    assert np.abs(fast - want).max() <= 2e-5 * np.abs(want).max()
+
+
+TOKS = [1, 5, 300, 44, 270, 99, 400, 17, 33, 260, 301, 302, 303, 304, 305, 306, 307, 308, 309, 310, 311]   # 21 tokens: 2 chunks of n_batch = 16
+
+
+@pytest.mark.parametrize("wtype,mix", [("q4_0", "none"), ("q5_k", "q5_k_m"), ("q4_k", "q5_k_m"), ("q4_1", "none"), ("q8_0", "none"), ("q6_k", "none"), ("q5_0", "none"),
+                                       ("q5_1", "none"), ("q4_k", "none"), ("f16", "none"), ("f32", "none"), ("q2_k", "none"), ("q3_k", "none")])
+def test_llm_parity_mode_is_bit_identical_to_the_oracle(gpu_lib, tiny_files, wtype, mix):
+    """Prompt chunks (16 + 5 rows), 9 embedding rows (llama_eval_embd), then 24 FREE-RUNNING greedy steps on both sides: every logits vector equal bit for bit,
+    every greedy id equal."""
+    import refcpu as R
+    from minigpt4_cpp_amd import modelgen as G
+    vp, llm = tiny_files
+    lp = llm(wtype, mix)
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=96, n_batch=16)
+    try:
+        gpu_lib.amd_set_parity(ctx, True)
+        o = R.OracleLLM(G.read_llm_file(lp), n_ctx=96)
+        gpu_lib.amd_eval_tokens(ctx, TOKS)
+        o.eval_tokens(TOKS[:16])
+        want = o.eval_tokens(TOKS[16:])
+        got = gpu_lib.amd_logits(ctx)
+        assert np.array_equal(got, want), float(np.abs(got - want).max())
+        emb = (0.05 * np.random.default_rng(3).standard_normal((9, 256))).astype(np.float32)
+        gpu_lib.amd_eval_embd(ctx, emb)
+        want = o.eval_embd(emb)
+        got = gpu_lib.amd_logits(ctx)
+        assert np.array_equal(got, want), float(np.abs(got - want).max())
+        for step in range(24):
+            gid, oid = int(got.argmax()), int(want.argmax())
+            assert gid == oid
+            gpu_lib.amd_eval_tokens(ctx, [gid])
+            want = o.eval_tokens([oid])
+            got = gpu_lib.amd_logits(ctx)
+            assert np.array_equal(got, want), (step, float(np.abs(got - want).max()))
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+
+
+def test_fast_path_differs_from_parity_mode_by_summation_order_only(gpu_lib, tiny_files):
+    """Same context, same HBM planes, same KV cache: switching the mode mid-conversation changes the logits by fp32 summation noise re-rounded through the int8
+    activation steps of two layers -- and switching back to parity mode for a fresh conversation reproduces the oracle exactly again."""
+    import refcpu as R
+    from minigpt4_cpp_amd import modelgen as G
+    vp, llm = tiny_files
+    lp = llm("q5_k", "q5_k_m")
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=96, n_batch=16)
+    try:
+        o = R.OracleLLM(G.read_llm_file(lp), n_ctx=96)
+        want = None
+        o.eval_tokens(TOKS[:16]); want = o.eval_tokens(TOKS[16:])
+        gpu_lib.amd_eval_tokens(ctx, TOKS)
+        fast = gpu_lib.amd_logits(ctx)
+        gpu_lib.minigpt4_reset_chat(ctx)
+        gpu_lib.amd_set_parity(ctx, True)
+        gpu_lib.amd_eval_tokens(ctx, TOKS)
+        par = gpu_lib.amd_logits(ctx)
+        assert np.array_equal(par, want)
+        assert np.abs(fast - par).max() <= 5e-2 * (par.max() - par.min())
+        gpu_lib.amd_set_parity(ctx, False)
+        gpu_lib.minigpt4_reset_chat(ctx)
+        gpu_lib.amd_eval_tokens(ctx, TOKS)
+        assert np.array_equal(gpu_lib.amd_logits(ctx), fast)          # the fast path itself is deterministic
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+
+
+def test_parity_mode_through_the_reference_chat_flow(gpu_lib, tmpdir_models):
+    """system_prompt -> begin_chat_image(oracle's embedding) -> 16 x end_chat_image(temp 0) (minigpt4.cpp:2671-2732) in parity mode: pieces identical to OracleChat and
+    the logits behind every sampled token bit-identical."""
+    import os
+    import refcpu as R
+    from minigpt4_cpp_amd import minigpt4_library as ML, modelgen as G
+    vp = os.path.join(tmpdir_models, "vision_pm.bin")
+    lp = os.path.join(tmpdir_models, "llm_pm.bin")
+    G.write_vision_file(vp, G.tiny_vision(n_embd_llm=4096), seed=11, std=0.05)
+    G.write_llm_file(lp, G.tiny_llm(wtype="q5_k", n_embd=4096, n_layer=2, n_head=32, n_vocab=512, mix="q5_k_m"), seed=2, std=0.02)
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=256, n_batch=64)
+    try:
+        gpu_lib.amd_set_parity(ctx, True)
+        emb_np = R.OracleVision(G.read_vision_file(vp)).encode(G.synth_image(42)).astype(np.float32)
+        emb = ML.MiniGPT4Embedding()
+        flat = np.ascontiguousarray(emb_np.reshape(-1))
+        emb.data = flat.ctypes.data_as(ML.FLOAT_PTR)
+        emb.n_embeddings = flat.size
+        chat = R.OracleChat(R.OracleLLM(G.read_llm_file(lp), n_ctx=256), n_batch=64)
+        chat.system_prompt()
+        chat.begin_chat_image(emb_np, b"what is the text in the picture?")
+        gpu_lib.minigpt4_system_prompt(ctx)
+        gpu_lib.minigpt4_begin_chat_image(ctx, emb, "what is the text in the picture?")
+        for _ in range(16):
+            assert np.array_equal(gpu_lib.amd_logits(ctx), chat.llm.logits)
+            want = chat.end_chat(temp=0.0)[1].decode("utf-8", errors="replace")
+            got = gpu_lib.minigpt4_end_chat_image(ctx, temp=0.0)
+            assert got == want
+    finally:
+        gpu_lib.minigpt4_free(ctx)
