@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- decode tokens/s (+ image-encode ms) of the MI355X MiniGPT-4 engine, measured through the drop-in C ABI.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 13b|7b|tiny]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 13b|7b|tiny]      (N > 1 without a launcher: bench.py starts the N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one decode step of the hot path (one `minigpt4_end_chat_image` call: sample + 1-token eval) on one conversation.
@@ -49,21 +49,22 @@ def model_dir():
 def make_models(config: str, rank: int, world: int, barrier):
     from minigpt4_cpp_amd import modelgen as G
     d = model_dir()
-    if config == "13b":
-        vcfg, lcfg, ul, ub = G.vision_13b(), G.llm_13b(), 1, 1
-    elif config == "7b":
-        vcfg, lcfg, ul, ub = G.vision_7b(), G.llm_7b("q4_0"), 1, 1
+    if config in ("13b", "7b"):
+        vcfg, ub = (G.vision_13b() if config == "13b" else G.vision_7b()), 1
+        lcfg, lkw = G.headline_llm(config)                 # the same files tests/test_gpu_headline.py checks against the oracle (oracle/headline.py::headline_files)
+        lname = f"llm_{config}_r3.bin"
     else:
-        vcfg = G.tiny_vision(n_embd_llm=4096)
-        lcfg, ul, ub = G.tiny_llm(wtype="q5_k", n_embd=4096, n_layer=2, n_head=32, n_vocab=2048, mix="q5_k_m"), None, None
-    vp, lp = os.path.join(d, f"vision_{config}.bin"), os.path.join(d, f"llm_{config}.bin")
+        vcfg, ub = G.tiny_vision(n_embd_llm=4096), None
+        lcfg, lkw = G.tiny_llm(wtype="q5_k", n_embd=4096, n_layer=2, n_head=32, n_vocab=2048, mix="q5_k_m"), dict(seed=1234, std=0.02, fast=True)
+        lname = "llm_tiny.bin"
+    vp, lp = os.path.join(d, f"vision_{config}.bin"), os.path.join(d, lname)
     if rank == 0:
         t0 = time.time()
         if not os.path.exists(vp + ".ok"):
             G.write_vision_file(vp, vcfg, seed=4321, std=0.02, unique_blocks=ub, fast=True)
             open(vp + ".ok", "w").write("ok")
         if not os.path.exists(lp + ".ok"):
-            G.write_llm_file(lp, lcfg, seed=1234, std=0.02, unique_layers=ul, fast=True)
+            G.write_llm_file(lp, lcfg, **lkw)
             open(lp + ".ok", "w").write("ok")
         log(f"[bench] synthetic model files ready in {time.time() - t0:.1f}s: {vp} ({os.path.getsize(vp) / 1e9:.2f} GB), {lp} ({os.path.getsize(lp) / 1e9:.2f} GB)")
     barrier()
@@ -162,6 +163,24 @@ def pmc_traffic(kernel_symbol: str):
     return ent["bytes_per_launch"], f"profiles/pmc_traffic.json <- {rec.get('source_csv')} ({rec.get('command')}); FETCH_SIZE x 1024 x 2 (gfx950), avg over {ent['launches']} launches"
 
 
+def self_launch(n_gpus: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: fan out to N ranks (one per GPU) under torch.distributed.run -- the same command line the driver uses when it
+    launches the ranks itself -- and return the launcher's exit code.  Rank 0's JSON line passes through on stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env["MG4_BENCH_LAUNCHER"] = "self"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    log(f"[bench] --gpus {n_gpus} without WORLD_SIZE: launching {n_gpus} ranks: {' '.join(cmd)}")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,19 +188,28 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default=os.environ.get("MG4_BENCH_CONFIG", "13b"), choices=["13b", "7b", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parity-steps", type=int, default=16, help="greedy steps compared with the CPU oracle on the measured file (part of the cpu_baseline leg)")
+    ap.add_argument("--parity-steps", type=int, default=32, help="greedy steps compared with the CPU oracle on the measured file (part of the cpu_baseline leg)")
     ap.add_argument("--n-ctx", type=int, default=0, help="context size; default: 2048 or whatever --steps needs")
     ap.add_argument("--conversations", type=int, default=4, help="extra leg: batched decode of this many conversations per GPU in one weight pass (BASELINE.json configs[3] "
                     "has 4 requests per replica); reported as `batched_decode`, never as `value`.  0/1 = skip")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dist = None
     if world > 1:
+        log(f"[bench r{rank}] rank {rank} of {world} started (launcher: {os.environ.get('MG4_BENCH_LAUNCHER', 'external')}), local GPU {local_rank}")
         import torch
         import torch.distributed as dist_
+        if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"bench.py rank {rank}: no HIP device {local_rank} visible ({torch.cuda.device_count() if torch.cuda.is_available() else 0} GPUs); one GPU per rank is required")
         torch.cuda.set_device(local_rank)
         dist_.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_
@@ -332,6 +360,10 @@ def main():
         "device_ms_per_token_graph_loop": dev_ms_per_tok, "device_tokens_per_s_graph_loop": 1e3 / dev_ms_per_tok,
         "weight_bytes_per_token": wbytes, "decode_weight_GBps_end_to_end": wbytes * K / dt / 1e9,
         "model_load_s": load_s, "recv_load_s": recv_load_s, "weight_bcast_ms": bcast_ms,
+        "rccl_ranks": dist.get_world_size() if dist is not None else 1, "launcher": os.environ.get("MG4_BENCH_LAUNCHER", "external") if world > 1 else "none",
+        "weight_bcast": None if not bcast_ms else {"bytes": lstats["plan"]["llm_bytes"] + lstats["plan"]["vision_bytes"], "ms": bcast_ms,
+                                                   "GBps": (lstats["plan"]["llm_bytes"] + lstats["plan"]["vision_bytes"]) / bcast_ms / 1e6, "xgmi_link_GBps": 153.0,
+                                                   "note": "both weight arenas, rank 0 -> all, ncclBroadcast in <= 1 GiB pieces; a ring broadcast is bound by one xGMI link"},
         "roofline": roofline,
     }
     # ---- extra leg (not the headline): B conversations per replica decoded in ONE weight pass per step (include/minigpt4_amd.h)
@@ -370,11 +402,14 @@ def main():
             gp = H.gpu_free_run(lib, ctx, emb, args.parity_steps)
             gl = H.gpu_teacher_forced(lib, ctx, emb, orc["ids"])
             out["parity"] = H.compare(orc, gp, gl)
+            out["parity"]["parity_mode"] = H.gpu_parity_mode_run(lib, ctx, emb, orc)   # MINIGPT4_PARITY: oracle-order accumulation -> logits bit-identical, free-running
             out["parity"]["oracle_prefill_s"] = orc["prefill_s"]
             out["parity"]["oracle_self_noise"] = H.oracle_self_noise(lp, emb_np, orc, eps=1e-6, n_ctx=320, threads=max(1, min(usable, 32)))
-            out["parity"]["note"] = ("GPU vs CPU oracle on THIS run's files: system_prompt + begin_chat_image + greedy steps; `identical` counts free-running pieces, `decided` = steps whose "
-                                     "oracle top-2 margin exceeds 2x the largest observed logit difference; max_logit_rel_range = max |delta| / (max - min) of the oracle's logits; oracle_self_noise = the same "
-                                     "quantity for the oracle against ITSELF with the image embedding perturbed by 1e-6 relative (int8 activation re-rounding: the floor any other summation order hits)")
+            out["parity"]["note"] = ("GPU vs CPU oracle on THIS run's files: system_prompt + begin_chat_image + greedy steps; free_running_identical counts the measured (fast) path's greedy pieces, "
+                                     "`decided` = steps whose oracle top-2 margin exceeds 2x the largest observed logit difference; max_logit_rel = max |delta| / max |logit| per step (north_star: "
+                                     "<= 1e-2), max_logit_rel_range = the same over (max - min); parity_mode = the engine with MINIGPT4_PARITY (per-block fp32 terms added in the oracle's order): "
+                                     "free-running, logits bit-identical and ids identical at every step; oracle_self_noise = the oracle against ITSELF with the image embedding perturbed by 1e-6 "
+                                     "relative (int8 activation re-rounding: the floor any other summation order hits)")
             del orc
         except Exception as e:
             out["parity"] = {"error": repr(e)}

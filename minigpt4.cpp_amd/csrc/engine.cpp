@@ -20,7 +20,7 @@ int device_count_noexcept() {
 void DeviceArena::alloc(size_t bytes) {
     release();
     if (virt) base = reinterpret_cast<uint8_t *>((uintptr_t)1 << 40);      // never dereferenced
-    else HIP_CHECK(hipMalloc((void **)&base, bytes));
+    else { HIP_CHECK(hipMalloc((void **)&base, bytes)); HIP_CHECK(hipMemset(base, 0, bytes)); HIP_CHECK(hipDeviceSynchronize()); }   // alignment gaps / plane padding are part of what arena checksums cover: make them deterministic
     cap = bytes; used = 0; layout_hash = 1469598103934665603ull;
 }
 void DeviceArena::release() { if (base && !virt) HIP_IGNORE(hipFree(base)); base = nullptr; cap = used = 0; }
@@ -764,8 +764,17 @@ void Engine::forward_batch(int B, hipStream_t s) {
 }
 
 // Evaluate one chunk of N rows of the selected conversation at its position n_committed.  row_tok[i] >= 0: token id; -1: the next packed embedding row of `embd`.
+// LOAD_RECV: the arenas are allocated but hold nothing until the broadcast has landed and weights_received() ran -- every compute entry point refuses until then
+// (a caller that skipped the hand-over, or an inherited MINIGPT4_LOAD=recv, must get an error, not text generated from uninitialised weights).
+bool Engine::weights_missing() const {
+    if (load_mode_ != LOAD_RECV) return false;
+    set_last_error("the context was loaded in receive mode (MINIGPT4_LOAD=recv) and its weight arenas have not been filled: broadcast them, then call minigpt4_amd_weights_received");
+    MG4_ERR("%s", last_error().c_str());
+    return true;
+}
 int Engine::eval_chunk(const int *row_tok, int N, const float *embd) {
     if (N <= 0) return 0;
+    if (weights_missing()) return 1;
     const int E = (int)llm_.n_embd;
     Conversation &cv = conv_[(size_t)cur_];
     if (logits_host_slot_ == cur_) logits_host_slot_ = -1;
@@ -954,6 +963,7 @@ int Engine::select_conversation(int slot) {
 }
 int Engine::decode_batch(const int *slots, int n, const SampleParams &p, int *ids_out) {
     if (!slots || !ids_out || n < 1 || n > (int)conv_.size()) { set_last_error("decode_batch: bad slot list"); return 1; }
+    if (weights_missing()) return 1;
     bool seen[MAX_CONVERSATIONS] = {false};
     for (int i = 0; i < n; i++) { if (slots[i] < 0 || slots[i] >= (int)conv_.size() || seen[slots[i]]) { set_last_error("decode_batch: conversations must be distinct and in range"); return 1; } seen[slots[i]] = true; }
     const int keep = cur_;
@@ -1008,6 +1018,7 @@ int Engine::decode_batch(const int *slots, int n, const SampleParams &p, int *id
 // batch equals the same image encoded alone bit for bit (tests/test_gpu_parity.py::test_batched_image_encode_is_bit_identical).
 int Engine::encode_images(const float *const *chw, int B, float *const *out) {
     if (B < 1 || B > VISION_BATCH_MAX) { set_last_error("encode_images: batch size out of range"); return E_ImageSize; }
+    if (weights_missing()) return E_LoadModelFileHeader;
     if (v_generic_) return encode_images_generic(chw, B, out);
     hipStream_t s = stream_;
     const int D = v_D_, M = v_M_, NQ = v_nq_, H = 768;

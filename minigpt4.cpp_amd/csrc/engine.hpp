@@ -111,6 +111,7 @@ private:
 
     LoadMode load_mode_ = LOAD_FULL;
     bool moves_data() const { return load_mode_ == LOAD_FULL; }
+    bool weights_missing() const;      // LOAD_RECV before weights_received(): sets the error text, true
     int device_ = 0;
     hipStream_t stream_ = nullptr;
     int n_ctx_ = 2048, n_batch_ = 512, max_rows_ = 512;

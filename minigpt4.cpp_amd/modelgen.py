@@ -96,6 +96,26 @@ def llm_13b(wtype="q5_k") -> LLMConfig:
     return LLMConfig(n_vocab=32000, n_embd=5120, n_head=40, n_layer=40, wtype=wtype, mix="q5_k_m", ftype=17)
 
 
+def headline_llm(config: str):
+    """(LLMConfig, write_llm_file keyword arguments) of the synthetic BASELINE.json files bench.py measures and tests/test_gpu_headline.py checks -- one definition for both.
+    Round 3: the files are CONDITIONED like a trained network rather than an i.i.d. Gaussian stack -- wo / w2 scaled by 1 / sqrt(2 n_layer) (GPT-2 / Megatron scaled init),
+    token embeddings at a scale that keeps the residual stream tied to the current token, an output matrix whose logits make decisive greedy choices (`output_tie`), and
+    every layer different (`rotate_layers`; the 2-layer file has genuinely independent layers).  Same shapes, types and byte volume as before."""
+    if config == "13b":
+        cfg = llm_13b()
+    elif config == "7b":
+        cfg = llm_7b("q4_0")
+    elif config == "13b_l2":
+        # the 13B graph at full width, two layers deep: layer 0 a "more bits" layer (wv / w2 in Q6_K: the mixed-type qkv launch, the Q6_K NU = 7 tiling), layer 1 a plain
+        # Q5_K layer, output Q6_K -- every kernel instantiation / tiling / launch geometry of the 40-layer headline model
+        cfg = LLMConfig(n_vocab=32000, n_embd=5120, n_head=40, n_layer=2, wtype="q5_k", mix="q5_k_m", ftype=17, more_bits_layers=(0,))
+    else:
+        raise ValueError(config)
+    kw = dict(seed=1234, std=0.02, unique_layers=(None if cfg.n_layer <= 2 else 1), fast=True, resid_scale=float(1.0 / np.sqrt(2.0 * cfg.n_layer)), rotate_layers=True,
+              tok_std=6.0, output_tie=0.15)
+    return cfg, kw
+
+
 def use_more_bits(i: int, n: int) -> bool:
     return i < n // 8 or i >= 7 * n // 8 or (i - n // 8) % 3 == 2
 
@@ -228,13 +248,20 @@ class _Pool:
 
 def write_llm_file(path: str, cfg: LLMConfig, seed: int = 1234, std: float = 0.02,
                    unique_layers: Optional[int] = None, vocab: Optional[List[Tuple[bytes, float]]] = None,
-                   fast: bool = False, resid_scale: float = 1.0) -> None:
+                   fast: bool = False, resid_scale: float = 1.0, rotate_layers: bool = False, tok_std: Optional[float] = None,
+                   output_tie: float = 0.0) -> None:
     """Write a GGJT-v3 file with Gaussian weights.  `unique_layers` < n_layer re-uses the quantised bytes
     of layer (i % unique_layers) for layer i (bench-size files: same byte volume, generation in seconds).
     `resid_scale` multiplies the two matrices that write into the residual stream (attention.wo, feed_forward.w2) -- the
     GPT-2 / Megatron "scaled init" 1 / sqrt(2 n_layer): without it a deep random-weight stack amplifies a 1e-6 input
     perturbation to percents of the logit range (the int8 activation roundings of the two runs decorrelate), which drowns
-    any GPU-vs-oracle comparison in the arithmetic's own noise."""
+    any GPU-vs-oracle comparison in the arithmetic's own noise.
+    `rotate_layers`: a layer that re-uses another layer's quantised bytes gets them with the ROWS of every matrix rotated by a layer- and tensor-dependent amount
+    (norm vectors: their elements) -- whole quantised rows move, so the blocks stay valid and all n_layer layers differ (a wrong layer stride / weight pointer shows).
+    `tok_std`: standard deviation of tok_embeddings (default `std`); ~1 keeps the residual stream correlated with the current token through a deep stack.
+    `output_tie` = beta in (0, 1]: output row u = std * (beta * e[p[u]] + sqrt(1 - beta^2) * r_u), e = the unit-variance token embeddings, p a fixed random permutation,
+    r Gaussian -- the logit of the token u with p[u] == current token stands out of the Gaussian rest by a margin beta controls: DECISIVE greedy decisions (top-2 margin
+    far above the comparison tolerance) on a walk through the permutation instead of near-ties between 32000 i.i.d. logits."""
     rng = np.random.default_rng(seed)
     types, shapes = llm_tensor_types(cfg), llm_tensor_shapes(cfg)
     vocab = vocab if vocab is not None else synth_vocab(cfg.n_vocab)
@@ -242,6 +269,8 @@ def write_llm_file(path: str, cfg: LLMConfig, seed: int = 1234, std: float = 0.0
     uniq = unique_layers if unique_layers else cfg.n_layer
     cache: Dict[Tuple[str, int], np.ndarray] = {}
     pool = _Pool(rng) if fast else None
+
+    tok_unit: Dict[str, np.ndarray] = {}
 
     def gen(name: str) -> np.ndarray:
         ne, t = shapes[name], types[name]
@@ -251,14 +280,25 @@ def write_llm_file(path: str, cfg: LLMConfig, seed: int = 1234, std: float = 0.0
             _, idx, rest = name.split(".", 2)
             key = (rest, int(idx) % uniq, t)
             if key in cache:
-                return cache[key]
+                raw = cache[key]
+                if rotate_layers and int(idx) >= uniq:
+                    rows = ne[1] if len(ne) == 2 else ne[0]
+                    shift = (int(idx) * 977 + sum(map(ord, rest)) * 131) % rows or 1
+                    raw = np.roll(raw.reshape(rows, -1), shift, axis=0).reshape(-1)
+                return raw
         if name.endswith("norm.weight"):
             x = (1.0 + 0.02 * rng.standard_normal(n)).astype(np.float32)
         elif pool is not None:
             x = pool.take(n)
-            x *= np.float32(std)
         else:
-            x = (std * rng.standard_normal(n, dtype=np.float32)).astype(np.float32)
+            x = rng.standard_normal(n, dtype=np.float32)
+        if not name.endswith("norm.weight"):
+            if name == "tok_embeddings.weight" and output_tie:
+                tok_unit["e"] = x.reshape(cfg.n_vocab, cfg.n_embd).copy()
+            if name == "output.weight" and output_tie:
+                perm = np.random.default_rng(seed + 77).permutation(cfg.n_vocab)
+                x = (np.float32(output_tie) * tok_unit["e"][perm] + np.float32(np.sqrt(1.0 - output_tie * output_tie)) * x.reshape(cfg.n_vocab, cfg.n_embd)).reshape(-1)
+            x = x * np.float32(tok_std if (name == "tok_embeddings.weight" and tok_std is not None) else std)
         if resid_scale != 1.0 and (name.endswith("attention.wo.weight") or name.endswith("feed_forward.w2.weight")):
             x = x * np.float32(resid_scale)
         raw = Q.quantize(t, x)

@@ -4,7 +4,8 @@ Used by tests/test_gpu_headline.py and by bench.py's `cpu_baseline` leg (the `pa
 `minigpt4_system_prompt -> minigpt4_begin_chat_image -> K x minigpt4_end_chat_image(temp 0)` (reference minigpt4.cpp:2671-2718, 2720-2732;
 examples/main.cpp:207-293); the oracle side is OracleChat over OracleLLM (oracle/refcpu.py, oracle/refcpu.c).
 
-Two comparisons on the same file, the same image embedding and the same prompt:
+Three comparisons on the same file, the same image embedding and the same prompt:
+  * parity mode (MINIGPT4_PARITY, oracle-order fp32 accumulation): free-running, logits BIT-IDENTICAL and greedy ids identical at every step (gpu_parity_mode_run);
   * free-running: both sides decode greedily on their own; the piece sequences are compared (north_star: "bit-exact token ids under greedy sampling");
   * teacher-forced: the GPU is fed the ORACLE's token at every step, so every step's logits are comparable even after a near-tie would have made the
     free-running sequences part ways; reported as max |delta| / (max - min of the oracle's logits) per step, plus whether the argmax agrees and whether the
@@ -35,30 +36,18 @@ def model_dir() -> str:
 
 
 def headline_files(config: str):
-    """The synthetic files bench.py measures (same generator arguments, same cache directory): returns (vision_path, llm_path)."""
+    """The synthetic files bench.py measures (same generator arguments -- modelgen.headline_llm -- same cache directory): returns (vision_path, llm_path)."""
     from minigpt4_cpp_amd import modelgen as G
     d = model_dir()
-    ul = 1
-    if config == "13b":
-        vcfg, lcfg = G.vision_13b(), G.llm_13b()
-    elif config == "7b":
-        vcfg, lcfg = G.vision_7b(), G.llm_7b("q4_0")
-    elif config == "13b_l2":
-        # the 13B graph at full width, two layers deep: layer 0 a "more bits" layer (wv / w2 in Q6_K: the mixed-type qkv launch, the Q6_K NU = 7 tiling), layer 1 a
-        # plain Q5_K layer, output Q6_K -- every kernel instantiation / tiling / launch geometry of the 40-layer headline model, without the depth that turns the
-        # reference arithmetic's int8 re-roundings into percent-level logit noise (see compare())
-        vcfg = G.vision_13b()
-        lcfg = G.LLMConfig(n_vocab=32000, n_embd=5120, n_head=40, n_layer=2, wtype="q5_k", mix="q5_k_m", ftype=17, more_bits_layers=(0,))
-        ul = None
-    else:
-        raise ValueError(config)
+    lcfg, kw = G.headline_llm(config)
+    vcfg = G.vision_7b() if config == "7b" else G.vision_13b()
     vname = "13b" if config == "13b_l2" else config
-    vp, lp = os.path.join(d, f"vision_{vname}.bin"), os.path.join(d, f"llm_{config}.bin")
+    vp, lp = os.path.join(d, f"vision_{vname}.bin"), os.path.join(d, f"llm_{config}_r3.bin")
     if not os.path.exists(vp + ".ok"):
         G.write_vision_file(vp, vcfg, seed=4321, std=0.02, unique_blocks=1, fast=True)
         open(vp + ".ok", "w").write("ok")
     if not os.path.exists(lp + ".ok"):
-        G.write_llm_file(lp, lcfg, seed=1234, std=0.02, unique_layers=ul, fast=True)
+        G.write_llm_file(lp, lcfg, **kw)
         open(lp + ".ok", "w").write("ok")
     return vp, lp
 
@@ -125,6 +114,35 @@ def gpu_teacher_forced(lib, ctx, emb_struct, ids: List[int], prompt: str = PROMP
         out.append(lib.amd_logits(ctx).copy())
         lib.amd_eval_tokens(ctx, [int(tid)])
     return np.stack(out)
+
+
+def gpu_parity_mode_run(lib, ctx, emb_struct, oracle: Dict, prompt: str = PROMPT) -> Dict:
+    """The same chat flow with the engine in parity mode (MINIGPT4_PARITY: every fp32 accumulation in the oracle's order), FREE-RUNNING: the logits behind every sampled
+    token must equal the oracle's bit for bit and every greedy piece must be the oracle's.  Returns counts (and the first mismatching step, -1 when none)."""
+    lib.amd_set_parity(ctx, True)
+    try:
+        lib.minigpt4_reset_chat(ctx)
+        lib.minigpt4_system_prompt(ctx)
+        lib.minigpt4_begin_chat_image(ctx, emb_struct, prompt)
+        n = len(oracle["ids"])
+        bit, ids, first, worst = 0, 0, -1, 0.0
+        for i in range(n):
+            lg = lib.amd_logits(ctx)
+            same = bool(np.array_equal(lg, oracle["logits"][i]))
+            bit += same
+            if not same:
+                worst = max(worst, float(np.abs(lg.astype(np.float64) - oracle["logits"][i]).max()))
+            piece = lib.minigpt4_end_chat_image(ctx, temp=0.0)
+            ok = piece == oracle["pieces"][i]
+            ids += ok
+            if first < 0 and not (same and ok):
+                first = i
+            if not ok:                       # the two sequences have parted: later steps are not comparable
+                break
+        return {"steps": n, "logits_bit_identical": bit, "greedy_ids_identical": ids, "first_mismatch": first, "max_abs_logit_delta": worst}
+    finally:
+        lib.amd_set_parity(ctx, False)
+        lib.minigpt4_reset_chat(ctx)
 
 
 def compare(oracle: Dict, gpu_pieces: List[str], gpu_logits: np.ndarray) -> Dict:

@@ -64,3 +64,25 @@ def test_two_rank_gloo(tmp_path):
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver runs `--gpus 1`): bench.py itself must fan out to 2 ranks under torch.distributed.run.  There is
+    no GPU here, so every rank stops at its device check -- after announcing itself; the launcher's failure is propagated as a non-zero exit code."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""          # also on a GPU box: no device for the ranks
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "tiny", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    err = r.stderr
+    assert "launching 2 ranks" in err and "--nproc-per-node=2" in err, err[-2000:]
+    assert "rank 0 of 2 started (launcher: self)" in err and "rank 1 of 2 started (launcher: self)" in err, err[-2000:]
+    assert r.returncode != 0 and "no HIP device" in err, (r.returncode, err[-2000:])
+    assert r.stdout.strip() == ""            # no JSON line from a run that measured nothing
+
+
+def test_bench_world_size_must_match_gpus_flag():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--config", "tiny"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

@@ -1,11 +1,17 @@
-"""GPU parity at the BASELINE.json headline shapes (round-1 verdict, "What's missing" #1): the 13B Q5_K_M graph (mixed Q5_K / Q6_K launches, the NU = 3 / 7
-register tilings, split-K vision GEMMs, XCD tile order) and the 7B Q4_0 graph, compared with the CPU oracle through the reference's call sequence
-`system_prompt -> begin_chat_image -> 32 x end_chat_image(temp 0)` (reference minigpt4.cpp:2671-2732), and one full-size ViT-g/14 (1408 x 39 blocks) +
-Q-Former encode against OracleVision.
+"""GPU parity at the BASELINE.json headline shapes: the 13B Q5_K_M graph (40 layers, all different; mixed Q5_K / Q6_K launches, the NU = 3 / 7 register tilings), the same
+graph two layers deep, and the 7B Q4_0 graph -- against the CPU oracle through the reference's call sequence `system_prompt -> begin_chat_image -> K x end_chat_image(temp 0)`
+(reference minigpt4.cpp:2671-2732, :2365-2382 add_tokens, :2425-2456 greedy sampling), plus one full-size ViT-g/14 (1408 x 39 blocks) + Q-Former encode against OracleVision.
 
-Observed errors are written to gpurun_out/parity_observed_<config>.json on every run; the committed copy (tests/golden/parity_observed.json) records what a
-GPU box measured: a run must also stay within 2x the recorded maximum, so a numerics regression at the real shapes fails here even when the tiny-model tests
-stay green.
+north_star: "bit-exact token ids under greedy sampling with fp32 accumulation, logits within 1e-2 relative otherwise".  Both halves are asserted:
+  * PARITY MODE (MINIGPT4_PARITY: the per-block fp32 terms added in the oracle's order): free-running, the logits behind EVERY sampled token equal the oracle's bit for bit and
+    every greedy id is identical -- 256 steps on the 40-layer 13B file;
+  * FAST MODE (the kernels bench.py measures): identical free-running greedy ids for all 32 steps, teacher-forced logits within 1e-2 of the largest |logit| at every step,
+    at least 24 of 32 steps "decided" (oracle top-2 margin > 2 x the largest observed difference) with identical argmax on all of them.
+The files (modelgen.headline_llm) are conditioned like a trained network -- scaled residual writers, every layer different, decisive output logits -- so that the criterion
+is a statement about the kernels rather than about near-ties between 32000 i.i.d. logits.  The oracle's own sensitivity (1e-6 input perturbation: int8 activation
+re-rounding, ~5e-3 of the logit range on the 13B file) is measured in the same run and recorded next to the GPU's numbers.
+
+Observed numbers are written to gpurun_out/parity_observed_<config>.json on every run; tests/golden/parity_observed.json is the committed record of a GPU box.
 """
 import json
 import os
@@ -17,6 +23,8 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS = 32
+PARITY_STEPS = {"13b": 256, "13b_l2": 64, "7b": 64}   # free-running steps in parity mode (bit-identical logits at every one of them)
+LOGIT_REL_TOL = 1e-2        # north_star: fast-mode logits within 1e-2 relative (max |delta| / max |logit| per step)
 ABS_BAR_VISION = 3e-3       # fp16-weight tower: no int8 rounding in the path; observed 5.6e-4 at the full ViT-g/14 + Q-Former (tests/golden/parity_observed.json)
 
 
@@ -40,16 +48,10 @@ def omp_threads():
 
 @pytest.mark.parametrize("config", ["13b_l2", "13b", "7b"])
 def test_headline_chat_flow_matches_oracle(gpu_lib, config, omp_threads):
-    """What can and cannot be asserted end to end (measured, oracle/headline.py::oracle_self_noise): ggml rounds every activation row to int8 before every mat-mul, so the
-    oracle ITSELF moves by 1.2-1.5 % of its logit range on the 2-layer full-width model and by ~5 % on the 40-layer one when its input is perturbed by 1e-6..1e-7
-    relative -- the size of fp32 summation-order differences.  No implementation that adds the per-block fp32 terms in another order can be closer to it than that, so
-    the end-to-end criterion is statistical: the GPU-vs-oracle difference must not exceed the oracle-vs-perturbed-oracle difference of the same run (x 1.5 on the mean,
-    x 2 on the maximum), greedy ids must be identical wherever the oracle's top-2 margin exceeds twice the observed difference, and the teacher-forced argmax agreement
-    must match the oracle's agreement with itself.  Bit-level claims live in the component tests (activation quantisation bit-exact, integer block dots exact,
-    mat-mul 2e-5 at these row lengths: test_gpu_parity.py, test_gpu_mmq2.py)."""
     import headline as H
     from minigpt4_cpp_amd import minigpt4_library as ML, modelgen as G
     vp, lp = H.headline_files(config)
+    n_par = PARITY_STEPS[config]
     ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=512, n_batch=512)
     try:
         img = G.synth_image(42)
@@ -57,28 +59,30 @@ def test_headline_chat_flow_matches_oracle(gpu_lib, config, omp_threads):
         E = emb.n_embeddings // 32
         emb_np = np.ctypeslib.as_array(emb.data, shape=(emb.n_embeddings,)).copy().reshape(32, E)
         assert np.isfinite(emb_np).all()
-        orc = H.oracle_run(lp, emb_np, STEPS, threads=omp_threads)
-        noise = H.oracle_self_noise(lp, emb_np, orc, eps=1e-6, threads=omp_threads)
+        orc = H.oracle_run(lp, emb_np, n_par, threads=omp_threads)
+        # ---- parity mode: bit-identical logits, identical greedy ids, free-running, every step
+        par = H.gpu_parity_mode_run(gpu_lib, ctx, emb, orc)
+        # ---- fast mode on the first STEPS steps
+        head = {"logits": orc["logits"][:STEPS], "ids": orc["ids"][:STEPS], "pieces": orc["pieces"][:STEPS], "n_prompt": orc["n_prompt"]}
+        noise = H.oracle_self_noise(lp, emb_np, head, eps=1e-6, threads=omp_threads)
         pieces = H.gpu_free_run(gpu_lib, ctx, emb, STEPS)
-        logits = H.gpu_teacher_forced(gpu_lib, ctx, emb, orc["ids"])
-        res = H.compare(orc, pieces, logits)
+        logits = H.gpu_teacher_forced(gpu_lib, ctx, emb, head["ids"])
+        res = H.compare(head, pieces, logits)
+        res["parity_mode"] = par
         res["oracle_self_noise"] = noise
         res["oracle_prefill_s"], res["oracle_decode_s"] = orc["prefill_s"], orc["decode_s"]
+        res["distinct_greedy_ids"] = len(set(orc["ids"]))
         _dump(config, res)
         print(config, json.dumps(res))
-        assert res["mean_logit_rel_range"] <= 1.5 * noise["mean_logit_rel_range"] + 1e-4, res
-        assert res["max_logit_rel_range"] <= 2.0 * noise["max_logit_rel_range"] + 1e-4, res
+        assert par["logits_bit_identical"] == n_par and par["greedy_ids_identical"] == n_par and par["first_mismatch"] == -1, par
+        assert res["distinct_greedy_ids"] >= n_par // 2, res            # the greedy walk is not a fixed point: identical ids are not a vacuous statement
+        assert res["max_logit_rel"] <= LOGIT_REL_TOL, res
+        assert res["free_running_identical"] == STEPS and res["free_running_first_divergence"] == STEPS, res
+        assert res["teacher_forced_argmax_identical"] == STEPS, res
+        assert res["decided"] >= 24 and res["decided_argmax_identical"] == res["decided"], res
         rec = _recorded().get(config, {})
-        if "max_logit_rel_range" in rec:                       # and never more than twice what the committed record of this config shows
-            assert res["max_logit_rel_range"] <= 2.0 * rec["max_logit_rel_range"], (res, rec)
-        # bit-exact greedy ids wherever the oracle's own decision is outside the arithmetic's noise band
-        assert res["decided_argmax_identical"] == res["decided"], res
-        assert res["teacher_forced_argmax_identical"] >= noise["argmax_identical"] - 4, res
-        # free-running text: identical up to the first undecided step at least
-        ol = orc["logits"].astype(np.float64)
-        srt = np.sort(ol, axis=1)
-        undecided = [i for i in range(STEPS) if (srt[i, -1] - srt[i, -2]) <= 2.0 * np.abs(logits - ol).max()]
-        assert res["free_running_first_divergence"] >= (undecided[0] if undecided else STEPS), res
+        if "max_logit_rel" in rec:                              # and never more than twice what the committed record of this config shows
+            assert res["max_logit_rel"] <= 2.0 * rec["max_logit_rel"], (res, rec)
         gpu_lib.minigpt4_free_embedding(emb)
     finally:
         gpu_lib.minigpt4_free(ctx)

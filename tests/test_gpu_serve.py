@@ -86,6 +86,16 @@ def test_receive_mode_load_equals_file_load(gpu_lib, tiny_files):
     try:
         assert gpu_lib.library.minigpt4_amd_load_mode(a.ptr) == 0 and gpu_lib.library.minigpt4_amd_load_mode(b.ptr) == 1
         assert gpu_lib.amd_arena_plan(a) == gpu_lib.amd_arena_plan(b) == gpu_lib.amd_plan_arenas(vp, lp)
+        # before the hand-over the receive-mode context must REFUSE to compute (round-2 advisor: it used to run on uninitialised weights): encode -> error code, token eval -> 8
+        img0 = ML.array_to_image_struct(G.synth_image(5))
+        assert gpu_lib.library.minigpt4_encode_image(b.ptr, img0, ML.MiniGPT4Embedding(), 0) != 0
+        assert b"receive mode" in gpu_lib.library.minigpt4_amd_last_error()
+        import ctypes
+        toks = (ctypes.c_int32 * 2)(1, 5)
+        gpu_lib.library.minigpt4_amd_eval_tokens(b.ptr, toks, 2)
+        lg0 = np.empty(gpu_lib.library.minigpt4_amd_n_vocab(b.ptr), np.float32)
+        assert gpu_lib.library.minigpt4_amd_get_logits(b.ptr, lg0.ctypes.data_as(ML.FLOAT_PTR), lg0.size) != 0
+        gpu_lib.minigpt4_reset_chat(b)
         assert gpu_lib.library.minigpt4_amd_copy_arenas(b.ptr, a.ptr) == 0
         assert gpu_lib.library.minigpt4_amd_weights_received(b.ptr) == 0 and gpu_lib.library.minigpt4_amd_load_mode(b.ptr) == 0
         assert [gpu_lib.amd_arena_checksum(a, w) for w in (0, 1)] == [gpu_lib.amd_arena_checksum(b, w) for w in (0, 1)]
