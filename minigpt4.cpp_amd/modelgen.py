@@ -673,5 +673,10 @@ def tiny_llm(wtype: str = "q4_0", n_embd: int = 4096, n_layer: int = 2, n_head: 
                      wtype=wtype, mix=mix, output_type=output_type, tok_type=tok_type)
 
 
+# write_llm_file keyword arguments that condition a TINY test model like modelgen.headline_llm conditions the headline files (scaled residual writers, token-scale
+# embeddings, decisive output logits): whole-model comparisons on such a file can be held to north_star's 1e-2 and its greedy decisions are far outside the noise.
+TINY_CONDITIONED = dict(resid_scale=0.5, tok_std=4.0, output_tie=0.4)
+
+
 def synth_image(seed: int = 42) -> np.ndarray:
     return np.random.default_rng(seed).standard_normal((3, 224, 224)).astype(np.float32)

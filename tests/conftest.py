@@ -60,12 +60,41 @@ def tiny_files(tmpdir_models):
     G.write_vision_file(vp, G.tiny_vision(n_embd_llm=4096), seed=3, std=0.05)
     made = {}
 
-    def llm(wtype, mix="none", n_vocab=512, output_type=None, tok_type=None):
-        key = (wtype, mix, n_vocab, output_type, tok_type)
+    def llm(wtype, mix="none", n_vocab=512, output_type=None, tok_type=None, conditioned=False):
+        """conditioned: modelgen.TINY_CONDITIONED (scaled residual writers, decisive logits) -- the whole-model tolerance tests; False: plain i.i.d. Gaussian weights."""
+        key = (wtype, mix, n_vocab, output_type, tok_type, conditioned)
         if key not in made:
-            p = os.path.join(tmpdir_models, f"llm_{wtype}_{mix}_{n_vocab}_{output_type}_{tok_type}.bin")
+            p = os.path.join(tmpdir_models, f"llm_{wtype}_{mix}_{n_vocab}_{output_type}_{tok_type}_{int(conditioned)}.bin")
             G.write_llm_file(p, G.tiny_llm(wtype=wtype, n_embd=256, n_layer=2, n_head=4, n_vocab=n_vocab, mix=mix, output_type=output_type,
-                                           tok_type=tok_type), seed=1, std=0.05)
+                                           tok_type=tok_type), seed=1, std=0.05, **(G.TINY_CONDITIONED if conditioned else {}))
             made[key] = p
         return made[key]
     return vp, llm
+
+
+# ---- observed whole-model errors: every run writes what it measured to gpurun_out/parity_observed_tiny.json; tests/golden/parity_observed_tiny.json is the committed record
+# of a GPU box, and a bar is min(north_star's 1e-2, 2 x the recorded value) -- so a numerics regression fails even when it stays inside the absolute tolerance.
+_OBS = {}
+
+
+def record_observed(name: str, value: float) -> None:
+    import json
+    _OBS[name] = max(float(value), _OBS.get(name, 0.0))
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    p = os.path.join(d, "parity_observed_tiny.json")
+    cur = {}
+    if os.path.exists(p):
+        try:
+            cur = json.load(open(p))
+        except ValueError:
+            cur = {}
+    cur.update(_OBS)
+    json.dump(cur, open(p, "w"), indent=1, sort_keys=True)
+
+
+def observed_bar(name: str, absolute: float = 1e-2) -> float:
+    import json
+    p = os.path.join(ROOT, "tests", "golden", "parity_observed_tiny.json")
+    rec = json.load(open(p)) if os.path.exists(p) else {}
+    return min(absolute, 2.0 * rec[name]) if name in rec and rec[name] > 0 else absolute

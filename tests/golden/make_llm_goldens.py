@@ -21,7 +21,7 @@ import _pkg  # noqa: E402
 
 _pkg.load_package()
 
-CASES = [("q4_0", "none"), ("q5_k", "q5_k_m"), ("q8_0", "none"), ("q4_1", "none"), ("f16", "none")]
+CASES = [("q4_0", "none"), ("q5_k", "q5_k_m"), ("q8_0", "none"), ("q4_1", "none"), ("q6_k", "none"), ("f16", "none")]
 PROMPT = [1, 5, 300, 44, 270, 99, 400, 17, 33, 260, 301, 302, 303, 304, 305, 306, 307, 308, 309, 310, 311]
 N_GREEDY = 16
 
@@ -30,7 +30,7 @@ def llm_case(wtype, mix, d):
     import refcpu as R
     from minigpt4_cpp_amd import modelgen as G
     p = os.path.join(d, f"llm_{wtype}.bin")
-    G.write_llm_file(p, G.tiny_llm(wtype=wtype, n_embd=256, n_layer=2, n_head=4, n_vocab=512, mix=mix), seed=1, std=0.05)
+    G.write_llm_file(p, G.tiny_llm(wtype=wtype, n_embd=256, n_layer=2, n_head=4, n_vocab=512, mix=mix), seed=1, std=0.05, **G.TINY_CONDITIONED)   # = conftest tiny_files llm(..., conditioned=True)
     o = R.OracleLLM(G.read_llm_file(p), n_ctx=96)
     o.eval_tokens(PROMPT[:16])
     logits = o.eval_tokens(PROMPT[16:]).copy()

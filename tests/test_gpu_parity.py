@@ -4,10 +4,9 @@ Tolerances (north_star: greedy token ids identical; logits within 1e-2 relative)
   * activation quantisation (Q8_K / Q8_0): bit-exact int8 / scales;
   * quantised mat-mul: integer block dots are exact, only the fp32 summation order differs -> 2e-5 relative to the row maximum;
   * f16 MFMA GEMM: exact products, fp32 accumulation order differs -> 2e-5 relative;
-  * whole-model logits of the TINY models here: LOGIT_TOL = 5e-2 of the logit range for quantised weights (every activation row is re-rounded to int8 before every
-    mat-mul, so the oracle's own logits move ~1e-2 of their range under a 1e-6 input perturbation: test_oracle_sensitivity), 3e-3 for f16 weights (no int8 step);
-    greedy ids identical wherever the oracle's top-2 margin exceeds that noise.  The headline-size models are compared against the oracle's self-noise measured in
-    the same run (tests/test_gpu_headline.py; observed errors in tests/golden/parity_observed.json).
+  * whole-model logits of the tiny (conditioned) models here: LOGIT_TOL = 1e-2 of the largest |logit| (north_star) and 2 x the recorded observation, 3e-3 for f16 weights
+    (no int8 step); free-running greedy ids identical at every step.  Bit-identical logits in parity mode: tests/test_gpu_paritymode.py.  Headline sizes:
+    tests/test_gpu_headline.py (observed errors in tests/golden/parity_observed.json).
 """
 import os
 
@@ -220,20 +219,21 @@ def test_encode_image_matches_oracle(gpu_lib, tiny_files):
         gpu_lib.minigpt4_free(ctx)
 
 
-# Whole-model tolerance.  ggml's arithmetic quantises every activation row to int8 before each mat-mul, which makes the *reference
-# arithmetic itself* discontinuous: a 1e-6 relative perturbation of the inputs (i.e. fp32 summation-order noise) flips a few int8
-# roundings and moves the oracle's own logits by ~1e-2 of their range (measured: tests/test_cpu_host.py::test_oracle_sensitivity).
-# Hence: logits within 5e-2 of the range, and identical greedy ids wherever the oracle's top-2 margin exceeds that noise.
-LOGIT_TOL = 5e-2
+# Whole-model tolerance (north_star: "logits within 1e-2 relative", greedy ids identical).  The models of these tests are conditioned like the headline files
+# (modelgen.TINY_CONDITIONED): on an i.i.d. Gaussian stack the reference arithmetic's own int8 re-roundings move the logits by percents of their range (measured:
+# tests/test_cpu_host.py::test_oracle_sensitivity), which says nothing about a kernel.  Bit-level equality with the oracle is asserted in tests/test_gpu_paritymode.py;
+# here the FAST kernels are held to 1e-2 of the largest |logit| AND to twice the error a GPU box recorded (tests/golden/parity_observed_tiny.json).
+LOGIT_TOL = 1e-2
 
 
 @pytest.mark.parametrize("wtype,mix", [("q4_0", "none"), ("q5_k", "q5_k_m"), ("q4_1", "none"), ("q8_0", "none"), ("q6_k", "none"), ("q5_0", "none"),
                                        ("q5_1", "none"), ("q4_k", "none"), ("f16", "none"), ("q2_k", "none")])
 def test_llm_logits_and_greedy_tokens(gpu_lib, tiny_files, wtype, mix):
     import refcpu as R
+    from conftest import observed_bar, record_observed
     from minigpt4_cpp_amd import modelgen as G
     vp, llm = tiny_files
-    lp = llm(wtype, mix)
+    lp = llm(wtype, mix, conditioned=True)
     ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=96, n_batch=16)
     try:
         o = R.OracleLLM(G.read_llm_file(lp), n_ctx=96)
@@ -243,23 +243,22 @@ def test_llm_logits_and_greedy_tokens(gpu_lib, tiny_files, wtype, mix):
         want = o.eval_tokens(toks[16:])
         got = gpu_lib.amd_logits(ctx)
         errs = [_rel(got, want)]
-        # 24 teacher-forced decode steps (graph-replayed on the GPU): both sides consume the oracle's greedy token
-        decided = agree = 0
+        # 24 FREE-RUNNING greedy steps (graph-replayed on the GPU): each side consumes its own greedy token, which must be the same one
+        decided, ids = 0, []
         for _ in range(24):
             srt = np.sort(want)
-            margin = (srt[-1] - srt[-2]) / (np.abs(want).max() + 1e-30)
-            if margin > LOGIT_TOL:
-                decided += 1
-                agree += int(got.argmax() == want.argmax())
-            tid = int(want.argmax())
-            gpu_lib.amd_eval_tokens(ctx, [tid])
-            want = o.eval_tokens([tid])
+            decided += int((srt[-1] - srt[-2]) / (np.abs(want).max() + 1e-30) > 2 * LOGIT_TOL)
+            gid, oid = int(got.argmax()), int(want.argmax())
+            assert gid == oid, (len(ids), gid, oid)
+            ids.append(oid)
+            gpu_lib.amd_eval_tokens(ctx, [gid])
+            want = o.eval_tokens([oid])
             got = gpu_lib.amd_logits(ctx)
             errs.append(_rel(got, want))
-        assert max(errs) < LOGIT_TOL, errs
-        assert agree == decided, (agree, decided)
-        if wtype == "f16":   # no int8 activation quantisation on this path: the whole model agrees tightly
-            assert max(errs) < 3e-3, errs
+        name = f"llm_logits/{wtype}_{mix}"
+        record_observed(name, max(errs))
+        assert max(errs) <= observed_bar(name, 3e-3 if wtype == "f16" else LOGIT_TOL), (max(errs), errs)
+        assert decided >= 20 and len(set(ids)) >= 12, (decided, ids)   # the identical-ids statement above is about decisive, varied choices
     finally:
         gpu_lib.minigpt4_free(ctx)
 
@@ -413,7 +412,7 @@ def test_long_context_decode_matches_oracle(gpu_lib, tiny_files):
     import refcpu as R
     from minigpt4_cpp_amd import modelgen as G
     vp, llm = tiny_files
-    lp = llm("q4_0")
+    lp = llm("q4_0", conditioned=True)
     ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=1100, n_batch=512)
     try:
         o = R.OracleLLM(G.read_llm_file(lp), n_ctx=1100)

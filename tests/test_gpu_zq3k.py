@@ -27,8 +27,8 @@ def test_q3k_model_logits_and_greedy_tokens(gpu_lib, tiny_files):
     import refcpu as R
     from minigpt4_cpp_amd import modelgen as G
     vp, llm = tiny_files
-    lp = llm("q3_k")
-    tol = 5e-2                                           # whole-model tolerance of tests/test_gpu_parity.py (int8 activation rounding)
+    lp = llm("q3_k", conditioned=True)
+    tol = 1e-2                                           # north_star's whole-model tolerance on the conditioned tiny model (tests/test_gpu_parity.py)
     ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=96, n_batch=16)
     try:
         o = R.OracleLLM(G.read_llm_file(lp), n_ctx=96)
@@ -50,6 +50,6 @@ def test_q3k_model_logits_and_greedy_tokens(gpu_lib, tiny_files):
             got = gpu_lib.amd_logits(ctx)
             errs.append(_rel(got, want))
         assert max(errs) < tol, errs
-        assert agree == decided, (agree, decided)
+        assert agree == decided and decided >= 12, (agree, decided)
     finally:
         gpu_lib.minigpt4_free(ctx)
