@@ -97,4 +97,5 @@ def observed_bar(name: str, absolute: float = 1e-2) -> float:
     import json
     p = os.path.join(ROOT, "tests", "golden", "parity_observed_tiny.json")
     rec = json.load(open(p)) if os.path.exists(p) else {}
-    return min(absolute, 2.0 * rec[name]) if name in rec and rec[name] > 0 else absolute
+    # 5e-3 floor: a run in which no int8 rounding happened to flip records ~1e-7; one flipped rounding (a benign change of summation order) costs ~2e-3 on these models
+    return min(absolute, max(2.0 * rec[name], 5e-3)) if name in rec and rec[name] > 0 else absolute
