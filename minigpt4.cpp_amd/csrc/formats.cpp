@@ -1,4 +1,5 @@
 #include "formats.hpp"
+#include <functional>
 #include "common.hpp"
 
 #include <fcntl.h>
@@ -219,8 +220,20 @@ int LLMFile::load_gguf(bool vocab_only) {
                 token_type.resize((size_t)cnt);
                 if (!r.need((size_t)cnt * 4)) return fail("truncated token types");
                 memcpy(token_type.data(), r.p + r.pos, (size_t)cnt * 4); r.pos += (size_t)cnt * 4;
-            } else if (et == 8) { for (uint64_t k = 0; k < cnt && r.ok; k++) gstr(); }
-            else { if (et > 12 || !scalar_size[et] || !r.need((size_t)cnt * scalar_size[et])) return fail("bad array"); r.pos += (size_t)cnt * scalar_size[et]; }
+            } else {   // an array this loader has no use for: skip it (strings one by one; arrays may nest, bounded depth; fixed-size elements in one step)
+                std::function<bool(uint32_t, uint64_t, int)> skip = [&](uint32_t t, uint64_t n, int depth) -> bool {
+                    if (t == 8) { for (uint64_t k = 0; k < n && r.ok; k++) gstr(); return r.ok; }
+                    if (t == 9) {
+                        if (depth >= 4) return false;
+                        for (uint64_t k = 0; k < n && r.ok; k++) { const uint32_t it = r.u4(); const uint64_t ic = u8(); if (!r.ok || ic > (r.size - r.pos) || !skip(it, ic, depth + 1)) return false; }
+                        return r.ok;
+                    }
+                    if (t > 12 || !scalar_size[t] || !r.need((size_t)n * scalar_size[t])) return false;
+                    r.pos += (size_t)n * scalar_size[t];
+                    return true;
+                };
+                if (!skip(et, cnt, 0)) return fail("bad array");
+            }
             continue;
         }
         if (vt == 6 || vt == 12) {                                // f32 / f64

@@ -76,3 +76,74 @@ def test_gguf_variants_outside_the_reference_graph_are_refused(lib, tiny_files, 
     assert rc_of(b) == 4
     b = bytearray(good); struct.pack_into("<Q", b, 16, 1 << 60)                               # absurd kv count
     assert rc_of(b) == 4
+
+
+# ---- files from an INDEPENDENT writer (tests/gguf_independent.py: written from the GGUF specification, no code shared with modelgen.ggjt_to_gguf) -------------------------
+def _fixture_paths(tmp_path):
+    import os
+    import gguf_independent as GI
+    src = str(tmp_path / "fixture_src.bin")
+    GI.write_fixture_source(src)
+    return src, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_independent_v3.gguf")
+
+
+def test_committed_independent_gguf_fixture_matches_its_ggjt_source(lib, tmp_path):
+    """tests/golden/tiny_independent_v3.gguf is a COMMITTED file (128-byte alignment as a u64, tokenizer keys first, mixed integer widths, f64 rope base, a nested array,
+    tensors in reverse order, 0xAB padding, trailing bytes): the loader's view of it -- hyper-parameters, vocabulary, every tensor's type / shape / bytes -- must equal
+    its view of the GGJT v3 model regenerated from the seed."""
+    src, fx = _fixture_paths(tmp_path)
+    a, b = digest(lib, src), digest(lib, fx)
+    assert a[0] == 0 and b[0] == 0, (a, b, lib.library.minigpt4_amd_last_error())
+    assert a[1] == b[1]
+    L = lib.library
+    va, vb = L.minigpt4_amd_vocab_load(src.encode()), L.minigpt4_amd_vocab_load(fx.encode())
+    try:
+        assert va and vb and L.minigpt4_amd_vocab_size(va) == L.minigpt4_amd_vocab_size(vb) == 300
+        for text in (b"Human: <Img>", b"### Assistant: what  is this?", "▁ é \xff".encode("utf-8", "surrogatepass")):
+            oa, ob = (ctypes.c_int32 * 128)(), (ctypes.c_int32 * 128)()
+            na, nb = L.minigpt4_amd_vocab_tokenize(va, text, 1, oa, 128), L.minigpt4_amd_vocab_tokenize(vb, text, 1, ob, 128)
+            assert na == nb and list(oa[:na]) == list(ob[:nb])
+    finally:
+        L.minigpt4_amd_vocab_free(va)
+        L.minigpt4_amd_vocab_free(vb)
+
+
+@pytest.mark.parametrize("wtype,mix", [("q5_k", "q5_k_m"), ("f16", "none"), ("q3_k", "none"), ("q8_0", "none")])
+@pytest.mark.parametrize("version,alignment", [(3, 64), (2, 256)])
+def test_independent_writer_other_types_and_versions(lib, tiny_files, tmp_path, wtype, mix, version, alignment):
+    import gguf_independent as GI
+    from minigpt4_cpp_amd import modelgen as G
+    _, llm = tiny_files
+    src = llm(wtype, mix)
+    dst = str(tmp_path / "ind.gguf")
+    open(dst, "wb").write(GI.convert(G.read_llm_file(src), version=version, alignment=alignment))
+    a, b = digest(lib, src), digest(lib, dst)
+    assert a[0] == 0 and b[0] == 0, (a, b, lib.library.minigpt4_amd_last_error())
+    assert a[1] == b[1]
+    # and the repo's own converter agrees with the independent one
+    own = str(tmp_path / "own.gguf")
+    G.ggjt_to_gguf(src, own, version=version, alignment=32)
+    assert digest(lib, own)[1] == b[1]
+
+
+def test_independent_writer_unknown_value_type_and_deep_nesting_are_refused(lib, tmp_path):
+    import gguf_independent as GI
+    from minigpt4_cpp_amd import modelgen as G
+    src, _ = _fixture_paths(tmp_path)
+    f = G.read_llm_file(src)
+    good = GI.convert(f)
+    bad = str(tmp_path / "bad.gguf")
+    # a value type the specification does not define (13): its size is unknowable, the file cannot be parsed past it
+    i = good.find(b"writer.i8")
+    b = bytearray(good); struct.pack_into("<I", b, i + len(b"writer.i8"), 13)
+    open(bad, "wb").write(bytes(b))
+    assert digest(lib, bad)[0] == 4
+    # arrays nested deeper than the loader's bound
+    g = GI.IndependentGGUF()
+    deep = GI.Value(GI.ARRAY, [1], GI.I16)
+    for _ in range(6):
+        deep = GI.Value(GI.ARRAY, [deep], GI.ARRAY)
+    g.kv.append(("writer.deep", deep))
+    g.put("general.architecture", GI.STRING, "llama")
+    open(bad, "wb").write(g.serialise())
+    assert digest(lib, bad)[0] == 4
