@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-steps", type=int, default=32, help="greedy steps compared with the CPU oracle on the measured file (part of the cpu_baseline leg)")
     ap.add_argument("--n-ctx", type=int, default=0, help="context size; default: 2048 or whatever --steps needs")
+    ap.add_argument("--no-long-context", dest="long_context", action="store_false", help="skip the long-context leg (decode rate at 1024 / 2040 cached keys)")
     ap.add_argument("--conversations", type=int, default=4, help="extra leg: batched decode of this many conversations per GPU in one weight pass (BASELINE.json configs[3] "
                     "has 4 requests per replica); reported as `batched_decode`, never as `value`.  0/1 = skip")
     args = ap.parse_args()
@@ -366,6 +367,29 @@ def main():
                                                    "note": "both weight arenas, rank 0 -> all, ncclBroadcast in <= 1 GiB pieces; a ring broadcast is bound by one xGMI link"},
         "roofline": roofline,
     }
+    # ---- extra leg (not the headline): decode rate at long contexts (the reference's default n_ctx is 2048, examples/main.cpp:128-131): random prompt rows up to the
+    # context, then a device-resident greedy loop.  From 768 cached keys on the step uses the key-split attention launches (k_attn_split_*).
+    if args.n_ctx >= 2048 and args.long_context:
+        try:
+            rng = np.random.default_rng(3)
+            lib.minigpt4_reset_chat(ctx)
+            have, lc = 0, []
+            for C in (1024, 2040):
+                steps = 24
+                need = C - steps - have
+                toks = ([1] if have == 0 else []) + [int(t) for t in rng.integers(3, lcfg.n_vocab - 1, need - (1 if have == 0 else 0))]
+                for i in range(0, len(toks), 512):
+                    lib.amd_eval_tokens(ctx, toks[i:i + 512])
+                lib.amd_logits(ctx)
+                _, ms = lib.amd_decode_loop(ctx, steps + 1)
+                have = C + 1
+                kv = 4.0 * lcfg.n_embd * lcfg.n_layer * C
+                lc.append({"context": C, "ms_per_step": ms / steps, "tokens_per_s": 1e3 * steps / ms, "GBps": (wbytes + kv) / (ms / steps * 1e-3) / 1e9,
+                           "frac_of_8TBps": (wbytes + kv) / (ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+            out["long_context"] = lc
+            lib.minigpt4_reset_chat(ctx)
+        except Exception as e:
+            out["long_context"] = {"error": str(e)}
     # ---- extra leg (not the headline): B conversations per replica decoded in ONE weight pass per step (include/minigpt4_amd.h)
     if args.conversations > 1:
         try:

@@ -128,6 +128,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (const char *ns = getenv("MINIGPT4_CONVERSATIONS")) conv_.assign((size_t)std::max(1, std::min(MAX_CONVERSATIONS, atoi(ns))), Conversation{});
     sampler_.seed(seed);
     if (const char *tf = getenv("MINIGPT4_PARITY_TRACE")) { if (*tf) trace_file_ = fopen(tf, "wb"); }
+    if (const char *e = getenv("MINIGPT4_ATTN_SPLIT_T")) attn_split_t_ = atoi(e);   // cached keys from which the decode step uses the key-split attention (0 = never)
     parity_ = trace_file_ || (getenv("MINIGPT4_PARITY") && atoi(getenv("MINIGPT4_PARITY")));   // oracle-order fp32 accumulation (forward_ref): bit-identical to the CPU oracle, slow
     if (const char *lm = getenv("MINIGPT4_LOAD")) load_mode_ = !strcmp(lm, "recv") ? LOAD_RECV : LOAD_FULL;
     auto t0 = std::chrono::steady_clock::now();
@@ -419,7 +420,7 @@ void Engine::alloc_buffers() {
     sz(S * L * C * E * 2); sz(S * L * C * E * 2); sz(2 * C * (hd / 2) * 4 * 2); sz(3 * 65536 * 2);
     sz(5 * B * E * 4); sz(2 * B * F * 4); sz(S * V * 4); sz(S * V * 4); sz(8 * 256 + 2 * B * 4);
     sz(2 * B * Kmax); sz(B * Kmax / 256 * 4 + 64); sz(B * Kmax / 16 * 2 + 64); sz(B * Kmax / 16 + 64); sz(4 * (B * Kmax / 32 * 4 + 64)); sz(B * Kmax * 2); sz(B * Kmax * 4);
-    sz(8192); sz((size_t)64 << 20);
+    sz(8192); sz((size_t)64 << 20); sz(attn_split_workspace_bytes((int)llm_.n_head, (int)hd, n_ctx_, attn_split_count((int)llm_.n_head, n_cus_)));
     const size_t VB = (size_t)VISION_BATCH_MAX;                            // images encoded in one pass (minigpt4_encode_images)
     sz(VB * 3 * 224 * 224 * 4); sz(VB * 256 * 592 * 2); sz(VB * 256 * D * 4); sz(VB * 257 * D * 4); sz(VB * 257 * 3 * D * 4); sz(VB * 3 * 257 * D * 2); sz(VB * 257 * M * 2);
     sz(VB * (size_t)SPLITK_MAX * 257 * D * 4);
@@ -467,6 +468,9 @@ void Engine::alloc_buffers() {
     batch_graph_.assign((size_t)MAX_CONVERSATIONS + 1, nullptr);
     d_tokens_ = reinterpret_cast<int *>(buf_arena_.take(B * 4));
     d_scratch_ = buf_arena_.take(8192);
+    attn_splits_ = attn_split_count((int)llm_.n_head, n_cus_);
+    attn_ws_ = buf_arena_.take(attn_split_workspace_bytes((int)llm_.n_head, (int)hd, n_ctx_, attn_splits_));
+    HIP_CHECK(hipMemset(attn_ws_, 0, attn_split_workspace_bytes((int)llm_.n_head, (int)hd, n_ctx_, attn_splits_)));   // the arrival counters start (and are left) at zero
     {   // K-split partial sums of the prefill mat-mul (only prompts short enough to need the extra parallelism use them)
         const size_t slab_floats = (size_t)16 << 20;
         hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, device_));
@@ -658,7 +662,8 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
         }
         // algorithmic bytes of the attention site: the cached fp16 K and V rows of every head up to the current position
         SiteScope *att_sc = prof_on_ ? new SiteScope(this, "attention", 4.0 * (double)E * (double)(conv_[sl].n_committed + N), s) : nullptr;
-        if (dec) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, true, s);
+        if (dec && attn_split_now_) launch_attn_llm_split(q_, k_, v_, kc, vc, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, attn_ws_, attn_splits_, s);
+        else if (dec) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, true, s);
         else {
             launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s);
             if (!(attn_prefill_ && launch_attn_prefill(q_, kc, vc, N, H, hd, d_npast, conv_[sl].n_committed + N, tabs_, att_, s)))
@@ -781,7 +786,13 @@ int Engine::eval_chunk(const int *row_tok, int N, const float *embd) {
     launch_set_int(d_npast_ + cur_, cv.n_committed, stream_);
     if (N == 1 && row_tok[0] >= 0) {
         launch_set_int(d_feed_ + cur_, row_tok[0], stream_);
+        // long contexts: the decode step's attention shares every head's keys between workgroups (two launches instead of one: pays from a few hundred keys on).  The choice
+        // is part of the captured graph, so a conversation that crosses the threshold gets its step re-captured (once).
+        const bool split = attn_split_t_ > 0 && cv.n_committed + 1 > attn_split_t_;
+        attn_split_now_ = split;
         if (use_graph_ && !prof_on_ && !trace_file_) {
+            if (cv.graph && cv.graph_split != split) { HIP_IGNORE(hipGraphExecDestroy(cv.graph)); cv.graph = nullptr; }
+            cv.graph_split = split;
             if (!cv.graph) {
                 hipGraph_t g = nullptr;
                 HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));

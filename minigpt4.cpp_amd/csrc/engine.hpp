@@ -120,6 +120,7 @@ private:
         int n_committed = 0;   // rows already evaluated on the device
         std::vector<int> pend_tok; std::vector<float> pend_embd;
         hipGraphExec_t graph = nullptr;   // decode step captured with this conversation's cache / position / token addresses
+        bool graph_split = false;         // ... with the key-split attention launches (long context) or the one-workgroup-per-head kernel
     };
     std::vector<Conversation> conv_ = std::vector<Conversation>(1);
     int cur_ = 0;
@@ -153,6 +154,7 @@ private:
     int *h_argmax_ = nullptr, *h_bstage_ = nullptr; float *h_logits_ = nullptr; int logits_host_slot_ = -1;
     bool use_graph_ = true, use_v2_ = true, attn_prefill_ = true, parity_ = false;
     FILE *trace_file_ = nullptr;       // MINIGPT4_PARITY_TRACE
+    void *attn_ws_ = nullptr; int attn_splits_ = 6; int attn_split_t_ = 768; bool attn_split_now_ = false;   // key-split decode attention (llm_kernels.hip: k_attn_split_*)
     int batch_rows_max_ = 4; int batch_fuse_ = -1; int n_cus_ = 256;
     bool batch_mix_ = true;            // MINIGPT4_BATCH_MIX=0: wq|wk and wv of a mixed-type layer as two launches (the form before k_matvec_tn_mix)   // MINIGPT4_BATCH_ROWS_MAX: batches up to this size use the multi-row mat-vec; 0 = never.  Measured (profiles/r02x_*): from 5 rows on the int8-MFMA kernels (single-wave workgroups, one token tile) beat two passes of the 4-row mat-vec
     static constexpr int FUSE_DEFAULT = 87; int fuse_mask_ = FUSE_DEFAULT;

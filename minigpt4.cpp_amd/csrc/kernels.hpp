@@ -84,6 +84,13 @@ void launch_rope_kv(float *q, const float *k, const float *v, int N, int n_head,
 // !fused: launch_rope_kv must have run (q rotated in place, caches appended).
 void launch_attn_llm(float *q, const float *k, const float *v, __half *kcache, __half *vcache, int N, int n_head, int hd, const int *n_past, int n_ctx,
                      const float *cos_tab, const float *sin_tab, const Tables &tb, float *out, bool fused, hipStream_t s);
+// key-split decode attention for long contexts (one row; RoPE + KV append fused): every head's keys are shared by `splits` workgroups in two launches (scores; softmax + P.V
+// + deterministic combine by the last-arriving workgroup of the head).  ws: attn_split_workspace_bytes() bytes of device memory whose LAST 1 KiB + n_head words (the arrival
+// counters) were zeroed once; the kernels leave them zero.
+size_t attn_split_workspace_bytes(int n_head, int hd, int n_ctx, int splits);
+int attn_split_count(int n_head, int cus);
+void launch_attn_llm_split(float *q, const float *k, const float *v, __half *kcache, __half *vcache, int n_head, int hd, const int *n_past, int n_ctx, const float *cos_tab,
+                           const float *sin_tab, const Tables &tb, float *out, void *ws, int splits, hipStream_t s);
 // decode of B different conversations in one pass (RoPE + KV append fused): row t -> conversation row_slot[t] at position n_past[row_slot[t]], caches at
 // kcache / vcache + row_slot[t] * seq_stride elements.
 void launch_attn_llm_batched(float *q, const float *k, const float *v, __half *kcache, __half *vcache, int B, int n_head, int hd, const int *n_past, const int *row_slot,

@@ -1774,6 +1774,202 @@ void launch_attn_llm_batched(float *q, const float *k, const float *v, __half *k
     }
 }
 // =====================================================================================================================
+// Key-split decode attention (long contexts): k_attn_llm above puts ONE workgroup on a head -- 40 workgroups on a 256-CU chip, 0.015 us per cached key, 35 us per layer
+// at 2048 keys.  Here S workgroups share a head's keys (n_head x S >= 240 workgroups) in two launches; nothing spins, so nothing can hang:
+//   k_attn_split_scores : (head, split) -> RoPE of q / k (every workgroup; split 0 appends k, v to the cache), scores of its key range into a per-head fp32 row in HBM
+//                         (16 lanes per 256-byte key row, DPP reduction -- the arithmetic of k_attn_llm), the new key's score by the last split;
+//   k_attn_split_pv     : (head, split) -> every workgroup reads the head's whole score row (T x 4 bytes), max, fp16-table exp, exact sum, 1 / sum (identical in all S
+//                         workgroups: the same values in, order-independent exact arithmetic); probabilities rounded to fp16 and P.V over ITS key range; the partial
+//                         output goes out as device-scope (sc1) stores, an arrival counter per head names the last workgroup, and that one adds the S partials in
+//                         split order (deterministic) and resets the counter for the next launch.
+// Softmax semantics are those of k_attn_llm (global max BEFORE the table lookups: the fp16 exp table does not allow the flash-decoding rescale).
+// =====================================================================================================================
+constexpr int AS_THREADS = 256;
+template <int HD>
+__global__ __launch_bounds__(AS_THREADS) void k_attn_split_scores(const float *__restrict__ q, const float *__restrict__ kin, const float *__restrict__ vin, __half *__restrict__ kc,
+                                                                   __half *__restrict__ vc, int E, const int *__restrict__ n_past, const float *__restrict__ cos_tab,
+                                                                   const float *__restrict__ sin_tab, float *__restrict__ scores, int ld_scores, __half *__restrict__ qrot) {
+    constexpr int CH = HD / 8, P = AS_THREADS / CH;
+    constexpr int NR = 16;                                        // key rows per lane group in flight (16 x P x 256 B = 64 KiB per workgroup at HD 128)
+    const int h = blockIdx.x, sp = blockIdx.y, S = gridDim.y, tid = threadIdx.x;
+    const int pos = *n_past, Tg = pos;                            // keys 0 .. pos - 1 come from the cache, key pos is this step's
+    __shared__ __attribute__((aligned(16))) __half qh[HD];
+    __shared__ __attribute__((aligned(16))) __half knew[HD];
+    const float scale = 1.0f / sqrtf((float)HD);
+    const size_t qo = (size_t)h * HD;
+    const int c = tid % CH, p = tid / CH;
+    const int per = ((Tg + S - 1) / S + P - 1) / P * P;           // keys per split, a whole number of passes
+    const int j_lo = sp * per, j_hi = min(Tg, j_lo + per), j_cl = max(j_hi - 1, 0);
+    const __half *kb = kc + (size_t)h * HD + 8 * c;
+    // the first NR key rows of this lane group do not depend on q: requested before the RoPE prologue and its barrier
+    int4 kk[NR];
+#pragma unroll
+    for (int i = 0; i < NR; i++) kk[i] = ld16(kb + (size_t)min(j_lo + p + i * P, j_cl) * E);
+    if (tid < HD / 2) {
+        const int i = tid;
+        const float cs = cos_tab[(size_t)pos * (HD / 2) + i], sn = sin_tab[(size_t)pos * (HD / 2) + i];
+        const float q0 = q[qo + 2 * i], q1 = q[qo + 2 * i + 1], k0 = kin[qo + 2 * i], k1 = kin[qo + 2 * i + 1];
+        const __half2 qr = __halves2half2(f2h_rn(q0 * cs - q1 * sn), f2h_rn(q0 * sn + q1 * cs)), kr = __halves2half2(f2h_rn(k0 * cs - k1 * sn), f2h_rn(k0 * sn + k1 * cs));
+        *reinterpret_cast<__half2 *>(qh + 2 * i) = qr; *reinterpret_cast<__half2 *>(knew + 2 * i) = kr;
+        if (sp == 0) {
+            const __half2 vr = __halves2half2(f2h_rn(vin[qo + 2 * i]), f2h_rn(vin[qo + 2 * i + 1]));
+            const size_t co = (size_t)pos * E + (size_t)h * HD + 2 * i;
+            *reinterpret_cast<__half2 *>(kc + co) = kr; *reinterpret_cast<__half2 *>(vc + co) = vr;
+            *reinterpret_cast<__half2 *>(qrot + qo + 2 * i) = qr;   // (diagnostics / tests)
+        }
+    }
+    __syncthreads();
+    float qd[8];
+    {
+        const int4 q4 = *reinterpret_cast<const int4 *>(qh + 8 * c);
+        const unsigned w[4] = {(unsigned)q4.x, (unsigned)q4.y, (unsigned)q4.z, (unsigned)q4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) { qd[2 * e] = h2f_bits(w[e] & 0xFFFF); qd[2 * e + 1] = h2f_bits(w[e] >> 16); }
+    }
+    auto dot16 = [&](const int4 &kv) {
+        const unsigned w[4] = {(unsigned)kv.x, (unsigned)kv.y, (unsigned)kv.z, (unsigned)kv.w};
+        float s = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { s = fmaf(h2f_bits(w[e] & 0xFFFF), qd[2 * e], s); s = fmaf(h2f_bits(w[e] >> 16), qd[2 * e + 1], s); }
+        s += dpp_f<0xB1>(s); s += dpp_f<0x4E>(s);
+        if (CH >= 8) s += dpp_f<0x141>(s);
+        if (CH >= 16) s += dpp_f<0x140>(s);
+        return s * scale;
+    };
+    float *srow = scores + (size_t)h * ld_scores;
+    for (int j0 = j_lo + p; j0 < j_hi; j0 += NR * P) {
+        int4 nx[NR];
+        const bool more = j0 + NR * P < j_hi;                     // wave-uniform up to the lane group; clamped loads keep it branch-free
+#pragma unroll
+        for (int i = 0; i < NR; i++) nx[i] = ld16(kb + (size_t)min(j0 + (NR + i) * P, j_cl) * E);
+#pragma unroll
+        for (int i = 0; i < NR; i++) { const int j = j0 + i * P; const float s = dot16(kk[i]); if (j < j_hi && c == 0) srow[j] = s; }
+        (void)more;
+#pragma unroll
+        for (int i = 0; i < NR; i++) kk[i] = nx[i];
+    }
+    if (sp == S - 1 && tid == 0) {                                // this step's key: one lane, the whole row in element order (k_attn_llm's dot_row)
+        float s = 0.0f;
+        for (int i = 0; i < HD; i++) s = fmaf(__half2float(knew[i]), __half2float(qh[i]), s);
+        srow[pos] = s * scale;
+    }
+}
+template <int HD>
+__global__ __launch_bounds__(AS_THREADS) void k_attn_split_pv(const float *__restrict__ scores, int ld_scores, const __half *__restrict__ vc, int E, const int *__restrict__ n_past,
+                                                               const Tables tb, float *__restrict__ partial, unsigned *__restrict__ arrive, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sp[];
+    constexpr int CH = HD / 8, P = AS_THREADS / CH;
+    const int h = blockIdx.x, sp = blockIdx.y, S = gridDim.y, tid = threadIdx.x;
+    const int pos = *n_past, T = pos + 1;
+    float *sc = reinterpret_cast<float *>(smem_sp);               // [T] scores, then exp values
+    float *part = sc + ((T + 3) & ~3);                            // [P][HD]
+    __shared__ float s_red[AS_THREADS / 64];
+    __shared__ double s_dred[AS_THREADS / 64];
+    __shared__ int s_last;
+    constexpr int NR = 16;
+    // this split's key range of the T keys (key pos included: it was appended by the score launch); its first NR value rows do not depend on the softmax: requested first
+    const int per = ((T + S - 1) / S + P - 1) / P * P;
+    const int j_lo = sp * per, j_hi = min(T, j_lo + per), j_cl = max(j_hi - 1, 0);
+    const int c = tid % CH, p = tid / CH;
+    const __half *vb = vc + (size_t)h * HD + 8 * c;
+    int4 vv[NR];
+#pragma unroll
+    for (int i = 0; i < NR; i++) vv[i] = ld16(vb + (size_t)min(j_lo + p + i * P, j_cl) * E);
+    const float *srow = scores + (size_t)h * ld_scores;
+    float mx = -INFINITY;
+    for (int j = tid; j < T; j += AS_THREADS) { const float s = srow[j]; sc[j] = s; mx = fmaxf(mx, s); }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    double sum = 0.0;
+    for (int j0 = tid; j0 < T; j0 += 4 * AS_THREADS) {            // four independent table gathers in flight per thread
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int j = j0 + u * AS_THREADS; v[u] = j < T ? tab(tb.exp, sc[j] - mx) : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int j = j0 + u * AS_THREADS; if (j < T) { sc[j] = v[u]; sum += (double)v[u]; } }   // fp16 values: the double sum is exact in any order
+    }
+    sum = wave_sum_d(sum);
+    if ((tid & 63) == 0) s_dred[tid >> 6] = sum;
+    __syncthreads();
+    const float inv = (float)(1.0 / (((s_dred[0] + s_dred[1]) + s_dred[2]) + s_dred[3]));
+    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j0 = j_lo + p; j0 < j_hi; j0 += NR * P) {
+        int4 nx[NR];
+#pragma unroll
+        for (int i = 0; i < NR; i++) nx[i] = ld16(vb + (size_t)min(j0 + (NR + i) * P, j_cl) * E);
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            const int j = j0 + i * P;
+            if (j < j_hi) {
+                const float pj = __half2float(f2h_rn(sc[j] * inv));
+                const unsigned w[4] = {(unsigned)vv[i].x, (unsigned)vv[i].y, (unsigned)vv[i].z, (unsigned)vv[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) { o[2 * e] = fmaf(h2f_bits(w[e] & 0xFFFF), pj, o[2 * e]); o[2 * e + 1] = fmaf(h2f_bits(w[e] >> 16), pj, o[2 * e + 1]); }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NR; i++) vv[i] = nx[i];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) part[p * HD + 8 * c + e] = o[e];
+    __syncthreads();
+    float *mine = partial + ((size_t)h * S + sp) * HD;
+    for (int i = tid; i < HD; i += AS_THREADS) {
+        float s = 0.0f;
+#pragma unroll 8
+        for (int pp = 0; pp < P; pp++) s += part[pp * HD + i];
+        __hip_atomic_store(mine + i, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // device-scope (sc1) store: visible to a reader on another XCD without a cache flush
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this thread's partial stores have completed ...
+    __syncthreads();                                              // ... and so have everybody's, before the arrival is counted
+    if (tid == 0) s_last = __hip_atomic_fetch_add(arrive + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(S - 1);
+    __syncthreads();
+    if (!s_last) return;
+    for (int i = tid; i < HD; i += AS_THREADS) {                  // the last workgroup of the head: the S partials in split order
+        float s = 0.0f;
+        for (int k = 0; k < S; k++) s += __hip_atomic_load(partial + ((size_t)h * S + k) * HD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out[(size_t)h * HD + i] = s;
+    }
+    if (tid == 0) __hip_atomic_store(arrive + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every other workgroup of this head has arrived: ready for the next launch
+}
+size_t attn_split_workspace_bytes(int n_head, int hd, int n_ctx, int splits) {
+    return (size_t)n_head * (size_t)((n_ctx + 3) & ~3) * 4 + (size_t)n_head * splits * hd * 4 + (size_t)n_head * hd * 2 + (size_t)n_head * 4 + 1024;
+}
+int attn_split_count(int n_head, int cus) {   // ~240 of 256 CUs per "wave" of workgroups: 6 splits for 40 heads, 7 for 32; MINIGPT4_ATTN_SPLITS overrides (experiments)
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("MINIGPT4_ATTN_SPLITS"); forced = e ? std::max(0, std::min(32, atoi(e))) : 0; }
+    return forced ? forced : std::max(2, std::min(16, (cus - cus / 16) / std::max(1, n_head)));
+}
+template <int HD>
+static void launch_attn_split_hd(float *q, const float *k, const float *v, __half *kc, __half *vc, int n_head, const int *n_past, int n_ctx, const float *cos_tab, const float *sin_tab,
+                                 const Tables &tb, float *out, void *ws, int splits, hipStream_t s) {
+    const int ld = (n_ctx + 3) & ~3;
+    float *scores = reinterpret_cast<float *>(ws);
+    float *partial = scores + (size_t)n_head * ld;
+    __half *qrot = reinterpret_cast<__half *>(partial + (size_t)n_head * splits * HD);
+    unsigned *arrive = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(qrot) + (((size_t)n_head * HD * 2 + 255) & ~(size_t)255));
+    note_kernel("k_attn_split_scores<%d>", HD);
+    hipLaunchKernelGGL((k_attn_split_scores<HD>), dim3((unsigned)n_head, (unsigned)splits), dim3(AS_THREADS), 0, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, scores, ld, qrot);
+    const size_t lds = (size_t)ld * 4 + (size_t)(AS_THREADS / (HD / 8)) * HD * 4 + 64;
+    static bool attr = false;
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_split_pv<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    note_kernel("k_attn_split_pv<%d>", HD);
+    hipLaunchKernelGGL((k_attn_split_pv<HD>), dim3((unsigned)n_head, (unsigned)splits), dim3(AS_THREADS), lds, s, scores, ld, vc, n_head * HD, n_past, tb, partial, arrive, out);
+}
+// decode (one row): RoPE + KV append + attention with the keys of every head shared by `splits` workgroups; `ws` >= attn_split_workspace_bytes(...), its last 1 KiB zeroed once
+void launch_attn_llm_split(float *q, const float *k, const float *v, __half *kcache, __half *vcache, int n_head, int hd, const int *n_past, int n_ctx, const float *cos_tab,
+                           const float *sin_tab, const Tables &tb, float *out, void *ws, int splits, hipStream_t s) {
+    switch (hd) {
+    case 32: launch_attn_split_hd<32>(q, k, v, kcache, vcache, n_head, n_past, n_ctx, cos_tab, sin_tab, tb, out, ws, splits, s); break;
+    case 64: launch_attn_split_hd<64>(q, k, v, kcache, vcache, n_head, n_past, n_ctx, cos_tab, sin_tab, tb, out, ws, splits, s); break;
+    case 128: launch_attn_split_hd<128>(q, k, v, kcache, vcache, n_head, n_past, n_ctx, cos_tab, sin_tab, tb, out, ws, splits, s); break;
+    default: throw HipError{hipErrorInvalidValue, "unsupported head size", __FILE__, __LINE__};
+    }
+}
+
+// =====================================================================================================================
 // Prefill attention (N > 1 query rows of one conversation) on the exact-f32 matrix cores.  The per-token kernel above re-reads a head's whole K and V once per
 // query (142 x 40 workgroups per layer for the image-turn prompt: 82 us per layer); here a workgroup owns (head, 16 consecutive queries) and streams the keys the
 // LAST of its queries may see through LDS in tiles of 64 -- K once for the scores, V once for the output.

@@ -471,3 +471,49 @@ def test_temperature_sampling_path_runs_and_is_seeded(gpu_lib, tiny_files):
         finally:
             gpu_lib.minigpt4_free(ctx)
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("n_embd,n_head", [(256, 4), (512, 4), (128, 4)])      # head sizes 64, 128, 32
+def test_key_split_decode_attention_matches_the_single_workgroup_kernel_and_the_oracle(gpu_lib, tmpdir_models, n_embd, n_head):
+    """Long contexts: the decode step shares every head's keys between workgroups (k_attn_split_scores / k_attn_split_pv, two launches, last-arriver combine).  Same
+    conversation evaluated with the split attention from 48 cached keys on (MINIGPT4_ATTN_SPLIT_T=48: the captured step is re-captured when the context crosses it) and with
+    the one-workgroup-per-head kernel only (=0): logits equal up to the fp32 order of the P.V partial sums, greedy ids identical, and both within 1e-2 of the CPU oracle."""
+    import refcpu as R
+    from minigpt4_cpp_amd import modelgen as G
+    vp = os.path.join(tmpdir_models, "vision_tiny_split.bin")
+    if not os.path.exists(vp):
+        G.write_vision_file(vp, G.tiny_vision(n_embd_llm=4096), seed=3, std=0.05)
+    lp = os.path.join(tmpdir_models, f"llm_split_{n_embd}.bin")
+    G.write_llm_file(lp, G.tiny_llm(wtype="q4_0", n_embd=n_embd, n_layer=2, n_head=n_head, n_vocab=512), seed=5, std=0.05, **G.TINY_CONDITIONED)
+    rng = np.random.default_rng(11)
+    toks = [1] + [int(t) for t in rng.integers(3, 512, 39)]       # 40 prompt rows, then 700 decode steps: the context crosses 48 and grows to 740
+    o = R.OracleLLM(G.read_llm_file(lp), n_ctx=768)
+    want = o.eval_tokens(toks)
+    runs = {}
+    for thr in ("48", "0"):
+        os.environ["MINIGPT4_ATTN_SPLIT_T"] = thr
+        try:
+            ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=768, n_batch=64)
+        finally:
+            os.environ.pop("MINIGPT4_ATTN_SPLIT_T", None)
+        try:
+            gpu_lib.amd_eval_tokens(ctx, toks)
+            got = gpu_lib.amd_logits(ctx)
+            ids, lg = [], [got.copy()]
+            for step in range(700):
+                tid = int(got.argmax())
+                ids.append(tid)
+                gpu_lib.amd_eval_tokens(ctx, [tid])
+                got = gpu_lib.amd_logits(ctx)
+                if step % 50 == 49 or step < 12:
+                    lg.append(got.copy())
+            runs[thr] = (ids, lg)
+        finally:
+            gpu_lib.minigpt4_free(ctx)
+    assert runs["48"][0] == runs["0"][0]
+    for a, b in zip(runs["48"][1], runs["0"][1]):
+        assert _rel(a, b) < 1e-2
+    ow = want
+    for step, tid in enumerate(runs["48"][0][:60]):               # the oracle along the same greedy path
+        assert int(ow.argmax()) == tid, step
+        ow = o.eval_tokens([tid])
