@@ -2,11 +2,12 @@
  * minigpt4_amd.h -- ADDITIVE entry points of the MI355X build of libminigpt4.so.
  *
  * Nothing here changes the reference ABI (include/minigpt4.h).  These symbols exist for
- *   (1) measurement: device-resident decode loops timed with hipEvents, per-kernel-class timing, image-encode time;
- *   (2) parity tests through the C-ABI: token-level eval / logits, single kernels (mat-mul, activation quantisation);
- *   (3) host logic that needs no GPU: file parsing, tokenizer, sampler (run by the CPU-only test tier);
- *   (4) batched / multi-GPU use: the already-declared-but-unused MiniGPT4Images / MiniGPT4Embeddings carriers
- *       (reference minigpt4.h:80-90) and access to the weight arenas for a load-time RCCL broadcast.
+ *   (1) measurement: device-resident decode loops timed with hipEvents, the per-launch-site table of the decode step, image-encode time;
+ *   (2) token-level use of the language path (eval / logits / tokenize / sample) and the parity-mode switch;
+ *   (3) batched / multi-GPU serving: the already-declared-but-unused MiniGPT4Images / MiniGPT4Embeddings carriers (reference minigpt4.h:80-90), several
+ *       conversations per context, access to the weight arenas for a load-time RCCL broadcast.
+ * Kernel-level test hooks, micro-benchmarks, hardware probes and host-only test helpers are NOT part of libminigpt4.so: they are declared in
+ * minigpt4_amd_test.h and exported by libminigpt4_test.so (the same objects + csrc/test_hooks.cpp), which only tests/ and tools/ load.
  * Plain C types only (pointers + sizes); no torch / HIP types cross this boundary.
  */
 #pragma once
@@ -76,73 +77,7 @@ MINIGPT4_API int minigpt4_amd_plan_arenas(const char *vision_path, const char *l
 MINIGPT4_API int minigpt4_amd_arena_plan(struct MiniGPT4Context *ctx, size_t *llm_bytes, size_t *vision_bytes, uint64_t *llm_hash, uint64_t *vision_hash);
 MINIGPT4_API int minigpt4_amd_load_mode(struct MiniGPT4Context *ctx);              /* 0 full, 1 waiting for the arenas */
 MINIGPT4_API int minigpt4_amd_weights_received(struct MiniGPT4Context *ctx);
-MINIGPT4_API int minigpt4_amd_copy_arenas(struct MiniGPT4Context *dst, struct MiniGPT4Context *src);   /* tests: device-to-device stand-in for the broadcast on one GPU */
 MINIGPT4_API int minigpt4_amd_arena_checksum(struct MiniGPT4Context *ctx, int which, uint64_t *sum);   /* 64-bit sum of the arena's 32-bit words (device reduction) */
-
-/* ---- single-kernel hooks for parity tests (need a GPU; allocate + free their own device memory) ------------------ */
-/* y[N][n_out] = W . x with ggml's quantised-activation arithmetic.  raw_w: the tensor bytes exactly as stored in a model file. */
-MINIGPT4_API int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y);
-/* the same through the parity-mode kernel (k_mul_mat_ref): the per-block fp32 terms in the CPU oracle's order -- results bit-identical to oracle/refcpu.c */
-MINIGPT4_API int minigpt4_amd_test_mul_mat_ref(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y);
-/* prefill launch as the engine issues it for N > 4 rows: n_mat (1..3) equally shaped k-quant matrices (raw blocks back to back) against N rows in ONE launch of the LDS-staged
- * int8-MFMA kernels; residual ([n_mat][N][n_out]) optional; ks > 1 forces that K split (0 = the launcher's choice).  y: [n_mat][N][n_out].  4 = shape refused. */
-/* prefill mat-mul micro-benchmark: n_mat random matrices [rows][cols] against N random rows, average microseconds per (set) launch; generation 2 = mmq2_kernels.hip, 1 = round-1 kernels */
-MINIGPT4_API int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, int iters, int ks, int generation, float *us_per_launch);
-MINIGPT4_API int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int64_t N, const float *residual, int ks, int generation, float *y);
-/* The decode (N = 1) mat-vec launches as the engine issues them: n1 equally spaced matrices of type1 (raw1 = their file bytes back to back), optionally one more of
- * type2 in the same mixed-type launch; prep 1 = rms_norm(x) * x2, 2 = x, 3 = silu(x) * x2, run standalone (fuse = 0) or in the kernel prologue (fuse = 1);
- * epi = 1: y[g] = silu(W0[g] . a) * (W1[g] . a) (n1 == 2).  residual / y: (n1 + n2) * n_out floats.  Returns 4 when the shape is outside the kernel's range. */
-MINIGPT4_API int minigpt4_amd_test_matvec(int type1, const void *raw1, int n1, int type2, const void *raw2, int n2, int64_t n_in, int64_t n_out, const float *x, const float *x2,
-                                          int prep, int fuse, int epi, const float *residual, float *y);
-/* The batched-decode mat-vec: N = 1..4 activation rows x[N][n_in] against n_mat (1..3) equally spaced matrices in one weight pass; y / residual: [n_mat][N][n_out].
- * Returns 4 when the shape / type is outside the kernel's range. */
-MINIGPT4_API int minigpt4_amd_test_matvec_rows(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int N, const float *residual, float *y);
-/* Activation quantisation (optionally after rms_norm with weight w): returns Q8_K and Q8_0 images of x[N][K].
- * q8k: int8[N*K], dk: float[N*K/256], bsums: int16[N*K/16], q80: int8[N*K], d0: float[N*K/32] (fp16-rounded). Any may be NULL. */
-MINIGPT4_API int minigpt4_amd_test_quantize(const float *x, const float *rms_w, int64_t N, int64_t K, int8_t *q8k, float *dk, int16_t *bsums, int8_t *q80, float *d0);
-/* C[M][N] = A[M][K] . W[N][K]^T on the MFMA f16 path (inputs given as fp32, rounded to fp16 on the device) + optional bias/GELU */
-MINIGPT4_API int minigpt4_amd_test_gemm_f16(const float *A, const float *W, const float *bias, int M, int N, int K, int gelu, float *C);
-
-/* Micro-benchmark of the decode mat-vec kernels on synthetic weight planes (see bench_kernels.py). variant 0: one launch per matrix, 1: fused persistent-wave launch,
-   2: the same with the rms-norm prologue, 3 / 4: the batched step's multi-row launch with 4 / 2 prepared rows, 5 / 6: 2 / 4 rows prepared inside the launch */
-MINIGPT4_API int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int variant, int iters, int n_sets, int waves_per_cu, float *us_per_launch, double *bytes_per_launch);
-
-/* Average latency (microseconds) of a device-wide barrier across n_blocks co-resident 512-thread workgroups (atomic counter + agent-scope fences); *errors
- * counts visibility failures of a neighbour-word check.  Measurement for DESIGN.md's launch-gap-vs-barrier analysis. */
-MINIGPT4_API float minigpt4_amd_probe_grid_barrier(int n_blocks, int iters, unsigned *errors);
-/* vector-ALU issue probe: ns per instruction and wave for one instruction kind (0 v_and, 1 v_dot4c_i32_i8, 2 v_mul_lo_u32, 3 v_mad_i32_i24, 4 v_fma_f32, 5 v_and_or,
-   6 v_bfe_u32, 7 v_cvt_f32_i32, 8 v_dot4_i32_i8, 9 v_mad_u64_u32, 10 v_lshrrev) at 1..4 waves per SIMD; < 0 without a GPU */
-MINIGPT4_API float minigpt4_amd_probe_valu(int op, int waves_per_simd, int iters);
-
-/* ---- host-only logic (no GPU needed) -------------------------------------------------------------------------------- */
-struct MiniGPT4Vocab;
-MINIGPT4_API struct MiniGPT4Vocab *minigpt4_amd_vocab_load(const char *llm_path);            /* parses hparams + vocab of a GGJT v3 file */
-MINIGPT4_API void minigpt4_amd_vocab_free(struct MiniGPT4Vocab *v);
-MINIGPT4_API int minigpt4_amd_vocab_size(struct MiniGPT4Vocab *v);
-MINIGPT4_API const char *minigpt4_amd_vocab_piece(struct MiniGPT4Vocab *v, int id, int *len);
-MINIGPT4_API int minigpt4_amd_vocab_tokenize(struct MiniGPT4Vocab *v, const char *text, int add_bos, int32_t *out, int cap);
-/* Parses both files without touching a GPU.  Returns a MiniGPT4Error; fills counts when non-NULL. */
-MINIGPT4_API int minigpt4_amd_inspect_files(const char *vision_path, const char *llm_path, int *n_vision_tensors, int *n_llm_tensors, int64_t *llm_weight_bytes_per_token);
-/* Image file decoding from memory (the host half of minigpt4_image_load_from_file): PNG / JPEG / BMP / binary PNM bytes -> U8 HWC RGB with
- * cv::imread(IMREAD_COLOR)+BGR2RGB semantics.  The library allocates image->data; release with minigpt4_free_image.  0 or 5 (OpenImage). */
-MINIGPT4_API int minigpt4_amd_decode_image(const void *bytes, size_t n, OUT struct MiniGPT4Image *image);
-/* Pillow's 8-bit bicubic resample tables for in_size -> out_size (what the preprocess kernels consume): first/count: int[out_size],
- * kk: int[out_size * ksize] (22-bit fixed point).  Call with kk = NULL to learn ksize.  0, -1 (bad sizes) or -2 (kk_cap too small). */
-MINIGPT4_API int minigpt4_amd_resample_coeffs(int in_size, int out_size, int *ksize, int *first, int *count, int *kk, size_t kk_cap);
-/* Digest (FNV-1a 64) of what the engine takes from an LLM file -- hyper-parameters, vocabulary, every tensor's name / type / shape (and bytes when
- * with_data != 0).  GGJT v3 and GGUF v2 / v3 files of the same model digest equally.  Returns a MiniGPT4Error. */
-MINIGPT4_API int minigpt4_amd_llm_file_digest(const char *llm_path, uint64_t *digest, int with_data);
-/* ggml's reference block quantisers as minigpt4_quantize_model applies them (ggml_quantize_chunk): n floats (a whole number of blocks) -> dst; returns the
- * bytes written, 0 for an unsupported type (supported: Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q4_K Q5_K Q6_K, ggml type ids) or a ragged n. */
-MINIGPT4_API int64_t minigpt4_amd_quantize_chunk(int ggml_type, const float *x, void *dst, int64_t n);
-/* Diagnostic builds only (-DMG4_TIMELINE): 8 x uint64 constant-clock (100 MHz) stamps per workgroup of the LAST decode mat-vec launch -- entry, first weight
- * request, activation row ready, first row group done, last row group done, results stored.  Returns the workgroups copied, 0 for a normal build, -1 on error. */
-MINIGPT4_API int minigpt4_amd_timeline(unsigned long long *out, int max_workgroups);
-/* load-time re-encoding of Q3_K super-blocks (110 B) as value-identical Q6_K super-blocks (210 B); host only.  0 / 1 */
-MINIGPT4_API int minigpt4_amd_convert_q3k_q6k(const void *src, void *dst, int64_t n_blocks);
-/* Host sampler with an explicit seed (fresh std::mt19937 per call). */
-MINIGPT4_API int minigpt4_amd_sample_logits(const float *logits, int n_vocab, int seed, float temp, int32_t top_k, float top_p, float tfs_z, float typical_p,
-                                            int mirostat, float mirostat_tau, float mirostat_eta);
 
 #ifdef __cplusplus
 }

@@ -108,8 +108,12 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     defer_ = !(getenv("MINIGPT4_NO_DEFER") && atoi(getenv("MINIGPT4_NO_DEFER")));
     max_chunk_ = max_rows_;
     if (getenv("MINIGPT4_NO_MMQ")) set_mmq_enabled(atoi(getenv("MINIGPT4_NO_MMQ")) ? 0 : 2);
-    if (getenv("MINIGPT4_MMQ")) set_mmq_enabled(atoi(getenv("MINIGPT4_MMQ")));   // 0: v_dot4 tiles, 1: round-1 int8-MFMA prefill kernels, 2 (default): LDS-staged second generation
-    if (getenv("MINIGPT4_ATTN_MFMA")) set_attn_mfma(atoi(getenv("MINIGPT4_ATTN_MFMA")));
+    if (getenv("MINIGPT4_MMQ")) set_mmq_enabled(atoi(getenv("MINIGPT4_MMQ")) ? 2 : 0);   // 0: v_dot4 tiles only, otherwise (default) the LDS-staged int8-MFMA prefill kernels
+    // experiment knobs of the launchers: read here, once -- no launcher calls getenv
+    set_mmq2_tuning(getenv("MINIGPT4_MMQ2_TT") ? atoi(getenv("MINIGPT4_MMQ2_TT")) : 0, getenv("MINIGPT4_MMQ2_FILL") ? atoi(getenv("MINIGPT4_MMQ2_FILL")) : 0,
+                    getenv("MINIGPT4_MMQ2_KS") ? atoi(getenv("MINIGPT4_MMQ2_KS")) : 0);
+    set_gemm_tuning(getenv("MINIGPT4_GEMM_BIG_M") ? atoi(getenv("MINIGPT4_GEMM_BIG_M")) : -1, getenv("MINIGPT4_F16_KS") ? atoi(getenv("MINIGPT4_F16_KS")) : 0);
+    if (getenv("MINIGPT4_F16_GEMM")) set_f16_gemm(atoi(getenv("MINIGPT4_F16_GEMM")));
     // Decode: which activation preparations run inside the consuming mat-vec's prologue (one fat workgroup per CU repeats the row preparation while
     // its first weight tiles are in flight) instead of as their own launch.  bit 0: attn_norm -> wq|wk|wv, 1: attention output -> wo,
     // 2: ffn_norm -> w1|w3, 3: silu(w1 x) * (w3 x) -> w2, 4: final norm -> output; bit 5: w1|w3 launch writes silu(w1 x) * (w3 x) itself
@@ -128,6 +132,8 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (const char *ns = getenv("MINIGPT4_CONVERSATIONS")) conv_.assign((size_t)std::max(1, std::min(MAX_CONVERSATIONS, atoi(ns))), Conversation{});
     sampler_.seed(seed);
     if (const char *tf = getenv("MINIGPT4_PARITY_TRACE")) { if (*tf) trace_file_ = fopen(tf, "wb"); }
+    if (const char *e = getenv("MINIGPT4_ATTN_SPLITS")) attn_splits_forced_ = std::max(0, std::min(32, atoi(e)));   // workgroups per head of the key-split attention (0 = by CU count)
+    if (const char *e = getenv("MINIGPT4_QF_SKINNY")) qf_skinny_ = atoi(e) != 0;
     if (const char *e = getenv("MINIGPT4_ATTN_SPLIT_T")) attn_split_t_ = atoi(e);   // cached keys from which the decode step uses the key-split attention (0 = never)
     parity_ = trace_file_ || (getenv("MINIGPT4_PARITY") && atoi(getenv("MINIGPT4_PARITY")));   // oracle-order fp32 accumulation (forward_ref): bit-identical to the CPU oracle, slow
     if (const char *lm = getenv("MINIGPT4_LOAD")) load_mode_ = !strcmp(lm, "recv") ? LOAD_RECV : LOAD_FULL;
@@ -420,7 +426,7 @@ void Engine::alloc_buffers() {
     sz(S * L * C * E * 2); sz(S * L * C * E * 2); sz(2 * C * (hd / 2) * 4 * 2); sz(3 * 65536 * 2);
     sz(5 * B * E * 4); sz(2 * B * F * 4); sz(S * V * 4); sz(S * V * 4); sz(8 * 256 + 2 * B * 4);
     sz(2 * B * Kmax); sz(B * Kmax / 256 * 4 + 64); sz(B * Kmax / 16 * 2 + 64); sz(B * Kmax / 16 + 64); sz(4 * (B * Kmax / 32 * 4 + 64)); sz(B * Kmax * 2); sz(B * Kmax * 4);
-    sz(8192); sz((size_t)64 << 20); sz(attn_split_workspace_bytes((int)llm_.n_head, (int)hd, n_ctx_, attn_split_count((int)llm_.n_head, n_cus_)));
+    sz(8192); sz((size_t)64 << 20); sz(attn_split_workspace_bytes((int)llm_.n_head, (int)hd, n_ctx_, std::max(attn_splits_forced_, attn_split_count((int)llm_.n_head, n_cus_))));
     const size_t VB = (size_t)VISION_BATCH_MAX;                            // images encoded in one pass (minigpt4_encode_images)
     sz(VB * 3 * 224 * 224 * 4); sz(VB * 256 * 592 * 2); sz(VB * 256 * D * 4); sz(VB * 257 * D * 4); sz(VB * 257 * 3 * D * 4); sz(VB * 3 * 257 * D * 2); sz(VB * 257 * M * 2);
     sz(VB * (size_t)SPLITK_MAX * 257 * D * 4);
@@ -468,7 +474,7 @@ void Engine::alloc_buffers() {
     batch_graph_.assign((size_t)MAX_CONVERSATIONS + 1, nullptr);
     d_tokens_ = reinterpret_cast<int *>(buf_arena_.take(B * 4));
     d_scratch_ = buf_arena_.take(8192);
-    attn_splits_ = attn_split_count((int)llm_.n_head, n_cus_);
+    attn_splits_ = attn_splits_forced_ > 0 ? attn_splits_forced_ : attn_split_count((int)llm_.n_head, n_cus_);
     attn_ws_ = buf_arena_.take(attn_split_workspace_bytes((int)llm_.n_head, (int)hd, n_ctx_, attn_splits_));
     HIP_CHECK(hipMemset(attn_ws_, 0, attn_split_workspace_bytes((int)llm_.n_head, (int)hd, n_ctx_, attn_splits_)));   // the arrival counters start (and are left) at zero
     {   // K-split partial sums of the prefill mat-mul (only prompts short enough to need the extra parallelism use them)
@@ -1072,27 +1078,30 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
         }
     }
     if (vblocks_.empty()) launch_layernorm(vi_x_, v_lnv_w_, v_lnv_b_, R, D, nullptr, vi_img_h_, s);
-    // Q-Former (masks are all-zero)
+    // Q-Former (masks are all-zero).  Its GEMMs have 32 rows per image: the skinny-M kernel (MINIGPT4_QF_SKINNY=0: the 64x64-tile kernel, A/B)
+    auto qgemm = [&](const __half *A, int lda, const __half *W, int ldw, int Mr, int N, int K, const float *bias, const float *residual, bool gelu, float *o, __half *oh, int ldo) {
+        if (!(qf_skinny_ && launch_gemm_f16_skinny(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_, o, oh, ldo, s))) launch_gemm_f16(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_, o, oh, ldo, s);
+    };
     launch_layernorm(vi_qtok_rep_, v_qeln_w_, v_qeln_b_, RQ, H, vi_hs_, vi_hs_h_, s);
     for (const QLayer &L : qlayers_) {
-        launch_gemm_f16(vi_hs_h_, H, L.self.q_w, H, RQ, 3 * H, H, L.self.q_b, nullptr, false, tabs_, vi_qq_, nullptr, 3 * H, s);
+        qgemm(vi_hs_h_, H, L.self.q_w, H, RQ, 3 * H, H, L.self.q_b, nullptr, false, vi_qq_, nullptr, 3 * H);
         launch_attn_f32(vi_qq_, 3 * H, vi_qq_ + H, vi_qq_ + 2 * H, 3 * H, NQ, NQ, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s, B);
-        launch_gemm_f16(vi_ctx_h_, H, L.self.dense_w, H, RQ, H, H, L.self.dense_b, vi_hs_, false, tabs_, vi_d_, nullptr, H, s);
+        qgemm(vi_ctx_h_, H, L.self.dense_w, H, RQ, H, H, L.self.dense_b, vi_hs_, false, vi_d_, nullptr, H);
         launch_layernorm(vi_d_, L.self.ln_w, L.self.ln_b, RQ, H, vi_a1_, vi_a1_h_, s);
         const float *ao = vi_a1_; const __half *ao_h = vi_a1_h_;
         if (L.has_cross) {
-            launch_gemm_f16(vi_a1_h_, H, L.cross.q_w, H, RQ, H, H, L.cross.q_b, nullptr, false, tabs_, vi_qq_, nullptr, H, s);
+            qgemm(vi_a1_h_, H, L.cross.q_w, H, RQ, H, H, L.cross.q_b, nullptr, false, vi_qq_, nullptr, H);
             launch_gemm_f16(vi_img_h_, D, L.cross.kv_w, D, R, 2 * H, D, L.cross.kv_b, nullptr, false, tabs_, vi_kv_, nullptr, 2 * H, s);
             launch_attn_f32(vi_qq_, H, vi_kv_, vi_kv_ + H, 2 * H, NQ, 257, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s, B);
-            launch_gemm_f16(vi_ctx_h_, H, L.cross.dense_w, H, RQ, H, H, L.cross.dense_b, vi_a1_, false, tabs_, vi_d_, nullptr, H, s);
+            qgemm(vi_ctx_h_, H, L.cross.dense_w, H, RQ, H, H, L.cross.dense_b, vi_a1_, false, vi_d_, nullptr, H);
             launch_layernorm(vi_d_, L.cross.ln_w, L.cross.ln_b, RQ, H, vi_a2_, vi_a2_h_, s);
             ao = vi_a2_; ao_h = vi_a2_h_;
         }
-        launch_gemm_f16(ao_h, H, L.inter_w, H, RQ, v_qi_, H, L.inter_b, nullptr, true, tabs_, nullptr, vi_im_h_, v_qi_, s);
-        launch_gemm_f16(vi_im_h_, v_qi_, L.out_w, v_qi_, RQ, H, v_qi_, L.out_b, ao, false, tabs_, vi_d_, nullptr, H, s);
+        qgemm(ao_h, H, L.inter_w, H, RQ, v_qi_, H, L.inter_b, nullptr, true, nullptr, vi_im_h_, v_qi_);
+        qgemm(vi_im_h_, v_qi_, L.out_w, v_qi_, RQ, H, v_qi_, L.out_b, ao, false, vi_d_, nullptr, H);
         launch_layernorm(vi_d_, L.oln_w, L.oln_b, RQ, H, vi_hs_, vi_hs_h_, s);
     }
-    launch_gemm_f16(vi_hs_h_, H, v_proj_w_, H, RQ, v_out_, H, v_proj_b_, nullptr, false, tabs_, vi_out_, nullptr, v_out_, s);
+    qgemm(vi_hs_h_, H, v_proj_w_, H, RQ, v_out_, H, v_proj_b_, nullptr, false, vi_out_, nullptr, v_out_);
     HIP_CHECK(hipEventRecord(eb, s));
     for (int b = 0; b < B; b++) HIP_CHECK(hipMemcpyAsync(out[b], vi_out_ + (size_t)b * NQ * v_out_, (size_t)NQ * v_out_ * 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));

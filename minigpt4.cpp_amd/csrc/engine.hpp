@@ -154,7 +154,7 @@ private:
     int *h_argmax_ = nullptr, *h_bstage_ = nullptr; float *h_logits_ = nullptr; int logits_host_slot_ = -1;
     bool use_graph_ = true, use_v2_ = true, attn_prefill_ = true, parity_ = false;
     FILE *trace_file_ = nullptr;       // MINIGPT4_PARITY_TRACE
-    void *attn_ws_ = nullptr; int attn_splits_ = 6; int attn_split_t_ = 768; bool attn_split_now_ = false;   // key-split decode attention (llm_kernels.hip: k_attn_split_*)
+    void *attn_ws_ = nullptr; int attn_splits_ = 6; int attn_split_t_ = 768; bool attn_split_now_ = false; int attn_splits_forced_ = 0;   // key-split decode attention (llm_kernels.hip: k_attn_split_*)
     int batch_rows_max_ = 4; int batch_fuse_ = -1; int n_cus_ = 256;
     bool batch_mix_ = true;            // MINIGPT4_BATCH_MIX=0: wq|wk and wv of a mixed-type layer as two launches (the form before k_matvec_tn_mix)   // MINIGPT4_BATCH_ROWS_MAX: batches up to this size use the multi-row mat-vec; 0 = never.  Measured (profiles/r02x_*): from 5 rows on the int8-MFMA kernels (single-wave workgroups, one token tile) beat two passes of the 4-row mat-vec
     static constexpr int FUSE_DEFAULT = 87; int fuse_mask_ = FUSE_DEFAULT;
@@ -182,6 +182,7 @@ private:
     float *vi_img_ = nullptr, *vi_pe_ = nullptr, *vi_x_ = nullptr, *vi_qkv_ = nullptr, *vi_hs_ = nullptr, *vi_a1_ = nullptr, *vi_a2_ = nullptr, *vi_d_ = nullptr, *vi_qq_ = nullptr, *vi_kv_ = nullptr, *vi_out_ = nullptr;
     __half *vi_patches_ = nullptr, *vi_ln_h_ = nullptr, *vi_att_h_ = nullptr, *vi_mlp_h_ = nullptr, *vi_img_h_ = nullptr, *vi_hs_h_ = nullptr, *vi_a1_h_ = nullptr, *vi_a2_h_ = nullptr, *vi_ctx_h_ = nullptr, *vi_im_h_ = nullptr;
     float last_encode_ms_ = 0;
+    bool qf_skinny_ = true;            // Q-Former GEMMs on k_gemm_f16_skinny
 
     // ---- vision files whose Linear weights are not all F16 (an `--ftype f32` conversion, or a file written by minigpt4_quantize_model): every Linear is a
     // QWeight served by the LLM mat-mul kernels (activations quantised to the weight type's vec_dot_type, exactly ggml's mul_mat), activations stay fp32.

@@ -27,10 +27,7 @@ void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, c
 
 // MINIGPT4_PARITY=1: the same unit traits, the per-block fp32 terms added in the CPU oracle's order (one sequential chain per output) -- bit-identical to oracle/refcpu.c, slow
 void launch_mul_mat_ref(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s);
-// prefill (N >= 16) on the int8 matrix cores for Q4_K / Q5_K / Q6_K / Q4_0; launch_mul_mat dispatches to it automatically
-bool mmq_supported(int type);
 bool matvec_prologue_supported(int type, int cols);   // the fused row-preparation variants of the decode mat-vec
-void launch_mmq(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s);
 void set_mmq_enabled(int v);
 int mmq_enabled();
 // second-generation prefill kernels (mmq2_kernels.hip): 1..3 same-type, same-shape k-quant matrices against N >= 1 prepared rows (A.bsq required), weights streamed once per
@@ -38,13 +35,14 @@ int mmq_enabled();
 bool mmq2_supported(int type, int rows, int cols);
 bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s);
 void set_mmq2_cus(int cus);
+void set_mmq2_tuning(int tt, int fill_pct, int ks);   // experiment knobs, 0 = the launcher's choice, < 0 = leave as it is (read from the environment once, by Engine::init)
+void set_gemm_tuning(int big_min_m, int f16_ks);      // smallest M of the 128x128 GEMM (< 0: leave), forced K split of the F16 set launches (0 = choose)
+void set_f16_gemm(int v);                             // F16 language-model weights at >= 16 rows on the MFMA GEMM (default 1)
 void launch_slab_reduce(const float *slabs, int n_slabs, long long slab_stride, const float *residual, float *y, size_t n, hipStream_t s);   // y = (residual +) sum_z slab_z, fixed order
 // F16 weights at prompt sizes: 1..3 equally spaced [N][K] matrices x M fp16 rows in one launch of the 128x128 LDS-DMA GEMM (split K when the tiles do not fill the chip);
 // false -> outside this path, nothing launched
 bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n, int M, int N, int K, float *const *y, const float *const *residual, int ldo, float *ws,
                          size_t ws_floats, int cus, hipStream_t s);
-void set_mmq_generation(int g);   // Q4_K / Q5_K prefill kernel: 2 = k_mmq2_q45k, 3 (default) = k_mmq3_q45k (scales folded into the int8 operands); results are bit-identical
-int mmq_generation();   // CU count the K-split heuristic aims at (the K-split partial sums live in ActQ::ws, owned by whoever owns the activation planes)
 
 // decode (N = 1) persistent-wave mat-vec over 1..3 same-type, same-shape matrices (wq|wk|wv, w1|w3); false -> caller falls back to launch_mul_mat
 // pro: 0 = activations come from `A` (prepared by launch_rms_quant / launch_silu_mul_quant); 1 = rms_norm(px) * pw, 2 = px, 3 = silu(px) * pw are
@@ -108,9 +106,6 @@ int attn_max_ctx(int hd);   // largest n_ctx whose score / probability rows fit 
 void launch_argmax(const float *logits, int n, int *out, void *scratch /*>= 512 bytes*/, hipStream_t s);
 void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);
 void launch_set_int(int *p, int v, hipStream_t s);
-float probe_valu_ns(int op, int waves_per_simd, int iters);   // vector-ALU issue probe (tools/probe_valu.py): ns per instruction and wave
-float probe_grid_barrier_us(int n_blocks, int iters, unsigned *errors_out);   // average latency of a device-wide barrier across n_blocks co-resident 512-thread workgroups
-void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s);
 uint64_t device_checksum(const void *p, size_t bytes, hipStream_t s);   // sum of the 32-bit words (bytes rounded down to 4), mod 2^64; synchronises the stream
 void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s);
 void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s);
@@ -122,8 +117,11 @@ void launch_delay(int us, hipStream_t s);   // profiling gate: keeps the stream 
 void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual,
                      bool gelu, const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s);
 // out = [residual +] gelu?(bias + y) over [rows][n] contiguous fp32 (y may alias out); writes fp32 (nullable) and / or fp16 (nullable)
+// the same product for FEW rows (the Q-Former's 32 queries per image): N / 16 workgroups, K split across the waves of a workgroup, no LDS staging.  false -> shape outside
+// the kernel's range (N % 16, K % 32), nothing launched
+bool launch_gemm_f16_skinny(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
+                            float *out, __half *out_h, int ldo, hipStream_t s);
 void launch_lin_epilogue(const float *y, const float *bias, const float *residual, bool gelu, const Tables &tb, int rows, int n, float *out, __half *out_h, hipStream_t s);
-void set_attn_mfma(int v);   // 1: f32-MFMA attention kernel (default), 0: VALU/LDS kernel
 // LayerNorm (ggml_norm eps 1e-5, then w*x+b); rows x n; writes fp32 (nullable) and fp16 (nullable).
 void launch_layernorm(const float *x, const float *w, const float *b, int rows, int n, float *out, __half *out_h, hipStream_t s);
 // split-K GEMM (raw fp32 partial sums into `slices` slabs) + the deterministic reduce fused with bias / residual / the following LayerNorm

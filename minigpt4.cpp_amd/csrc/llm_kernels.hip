@@ -1379,21 +1379,20 @@ bool launch_matvec_rows_mixed(const QWeight *const *W1, float *const *y1, int n1
     return false;
 }
 
-static int g_mmq_enabled = 2;   // 0: v_dot4 tiles only, 1: round-1 int8-MFMA kernels (mmq_kernels.hip), 2: + the LDS-staged kernels of mmq2_kernels.hip
+static int g_mmq_enabled = 2;   // 0: v_dot4 tiles only (tests / A-B), 2: the LDS-staged int8-MFMA kernels of mmq2_kernels.hip for N >= 5 rows
 void set_mmq_enabled(int v) { g_mmq_enabled = v; }
 int mmq_enabled() { return g_mmq_enabled; }
 // Unquantised (F16) weights, prefill: ggml converts the activation rows to fp16 and accumulates exact fp16 products in fp32 (ggml_vec_dot_f16) -- which is
 // precisely the vision tower's MFMA GEMM (v_mfma_f32_32x32x16_f16, fp32 accumulators), so rows >= 16 go there: BASELINE.json configs[4]
 // (13B f16, 512-token prefill) is MFMA-bound instead of re-streaming 25 GB of weights once per 4 tokens.  MINIGPT4_F16_GEMM=0 keeps the v_dot path.
-static int g_f16_gemm = -1;
+static int g_f16_gemm = 1;
+void set_f16_gemm(int v) { g_f16_gemm = v != 0; }
 void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
     if (g_mmq_enabled >= 2 && N >= 5 && (A.bsq || W.type == GT_Q4_0) && mmq2_supported(W.type, W.rows, W.cols)) {
         const QWeight *Wp[1] = {&W}; float *Yp[1] = {y}; const float *Rp[1] = {residual};
         if (launch_mmq2_set(Wp, Yp, residual ? Rp : nullptr, 1, A, N, ldy, s)) return;
     }
-    if (g_mmq_enabled && N >= 5 && mmq_supported(W.type)) { launch_mmq(W, A, N, y, ldy, residual, s); return; }
     if (W.type == GT_F16 && N >= 16 && W.cols % 8 == 0) {
-        if (g_f16_gemm < 0) { const char *e = getenv("MINIGPT4_F16_GEMM"); g_f16_gemm = e ? atoi(e) != 0 : 1; }
         if (g_f16_gemm) { launch_gemm_f16(A.xh, W.cols, reinterpret_cast<const __half *>(W.qs), W.cols, N, W.rows, W.cols, nullptr, residual, false, Tables{}, y, nullptr, ldy, s); return; }
     }
     switch (W.type) {
@@ -1937,11 +1936,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_split_pv(const float *__res
 size_t attn_split_workspace_bytes(int n_head, int hd, int n_ctx, int splits) {
     return (size_t)n_head * (size_t)((n_ctx + 3) & ~3) * 4 + (size_t)n_head * splits * hd * 4 + (size_t)n_head * hd * 2 + (size_t)n_head * 4 + 1024;
 }
-int attn_split_count(int n_head, int cus) {   // ~240 of 256 CUs per "wave" of workgroups: 6 splits for 40 heads, 7 for 32; MINIGPT4_ATTN_SPLITS overrides (experiments)
-    static int forced = -1;
-    if (forced < 0) { const char *e = getenv("MINIGPT4_ATTN_SPLITS"); forced = e ? std::max(0, std::min(32, atoi(e))) : 0; }
-    return forced ? forced : std::max(2, std::min(16, (cus - cus / 16) / std::max(1, n_head)));
-}
+int attn_split_count(int n_head, int cus) { return std::max(2, std::min(16, (cus - cus / 16) / std::max(1, n_head))); }   // ~240 of 256 CUs: 6 splits for 40 heads, 7 for 32
 template <int HD>
 static void launch_attn_split_hd(float *q, const float *k, const float *v, __half *kc, __half *vc, int n_head, const int *n_past, int n_ctx, const float *cos_tab, const float *sin_tab,
                                  const Tables &tb, float *out, void *ws, int splits, hipStream_t s) {
@@ -2224,11 +2219,6 @@ __global__ void k_add_inplace(float *__restrict__ x, const float *__restrict__ y
 }
 void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n); }
 
-__global__ void k_fill_random(unsigned *p, size_t n_words, unsigned seed) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) {
-        unsigned x = (unsigned)i * 2654435761u ^ seed; x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; p[i] = x; }
-}
-void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s) { hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, s, (unsigned *)p, bytes / 4, seed); }
 __global__ __launch_bounds__(256) void k_checksum(const unsigned *__restrict__ p, size_t n_words, unsigned long long *out) {
     unsigned long long s = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) s += p[i];
@@ -2249,102 +2239,6 @@ __global__ void k_fill_u16(unsigned short *p, size_t n, unsigned short v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s) { hipLaunchKernelGGL(k_fill_u16, dim3(1024), dim3(256), 0, s, (unsigned short *)p, n, v); }
-// Device-wide barrier latency probe (is a persistent multi-phase decode kernel worth building?): `n_blocks` co-resident workgroups pass `iters` barriers.
-// Between barriers every workgroup writes one word and reads its neighbour's (so the fences have something to make visible).
-__device__ __forceinline__ void grid_sync(unsigned *bar, unsigned &target, unsigned n_blocks) {
-    target += n_blocks;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        atomicAdd(bar, 1u);
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-        __threadfence();
-    }
-    __syncthreads();
-}
-__global__ __launch_bounds__(512) void k_barrier_probe(unsigned *bar, unsigned *words, int iters, unsigned *errors) {
-    unsigned target = 0;
-    const unsigned nb = gridDim.x, me = blockIdx.x, nxt = (me + 1) % nb;
-    unsigned bad = 0;
-    for (int i = 0; i < iters; i++) {
-        if (threadIdx.x == 0) words[me] = (unsigned)i * 2654435761u + me;
-        grid_sync(bar, target, nb);
-        if (threadIdx.x == 0) bad += words[nxt] != (unsigned)i * 2654435761u + nxt;
-        grid_sync(bar, target, nb);
-    }
-    if (threadIdx.x == 0 && bad) atomicAdd(errors, bad);
-}
-float probe_grid_barrier_us(int n_blocks, int iters, unsigned *errors_out) {
-    unsigned *d = nullptr;
-    HIP_CHECK(hipMalloc((void **)&d, (size_t)(n_blocks + 2) * 4));
-    HIP_CHECK(hipMemset(d, 0, (size_t)(n_blocks + 2) * 4));
-    hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-    hipLaunchKernelGGL(k_barrier_probe, dim3((unsigned)n_blocks), dim3(512), 0, nullptr, d, d + 2, 4, d + 1);       // warm-up
-    HIP_CHECK(hipMemset(d, 0, 8));
-    HIP_CHECK(hipEventRecord(a, nullptr));
-    hipLaunchKernelGGL(k_barrier_probe, dim3((unsigned)n_blocks), dim3(512), 0, nullptr, d, d + 2, iters, d + 1);
-    HIP_CHECK(hipEventRecord(b, nullptr));
-    HIP_CHECK(hipDeviceSynchronize());
-    float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-    unsigned err = 0; HIP_CHECK(hipMemcpy(&err, d + 1, 4, hipMemcpyDeviceToHost));
-    if (errors_out) *errors_out = err;
-    HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b)); HIP_IGNORE(hipFree(d));
-    return ms * 1e3f / (float)(2 * iters);
-}
-// Vector-ALU issue-rate probe (tools/probe_valu.py): every wave issues `iters` x 64 instructions of ONE kind over 8 independent accumulators (no dependent-issue
-// stalls); with 1 / 2 / 3 waves per SIMD the wall time per instruction tells the issue cost of that instruction relative to v_and_b32.
-template <int OP> __device__ __forceinline__ void valu_probe_op(int &acc, int a, int b) {
-    if constexpr (OP == 0) asm volatile("v_and_b32 %0, %1, %0" : "+v"(acc) : "v"(a));
-    else if constexpr (OP == 1) asm volatile("v_dot4c_i32_i8 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
-    else if constexpr (OP == 2) asm volatile("v_mul_lo_u32 %0, %1, %0" : "+v"(acc) : "v"(a));
-    else if constexpr (OP == 3) asm volatile("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-    else if constexpr (OP == 4) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-    else if constexpr (OP == 5) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
-    else if constexpr (OP == 6) asm volatile("v_bfe_u32 %0, %0, 4, 6" : "+v"(acc));
-    else if constexpr (OP == 7) asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(acc));
-    else if constexpr (OP == 8) asm volatile("v_dot4_i32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-    else if constexpr (OP == 9) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(*reinterpret_cast<long long *>(&acc)) : "v"(a), "v"(b) : "vcc");
-    else asm volatile("v_lshrrev_b32 %0, 4, %0" : "+v"(acc));
-}
-template <int OP> __global__ __launch_bounds__(1024) void k_valu_probe(int iters, int *sink) {
-    int acc[8];
-    long long wide[8];                                       // OP 9 works on register pairs
-#pragma unroll
-    for (int i = 0; i < 8; i++) { acc[i] = (int)threadIdx.x + i; wide[i] = acc[i]; }
-    const int a = (int)threadIdx.x * 0x01010101, b = 0x01020304 + (int)blockIdx.x;
-    for (int it = 0; it < iters; it++) {
-#pragma unroll
-        for (int r = 0; r < 8; r++)
-#pragma unroll
-            for (int i = 0; i < 8; i++) { if constexpr (OP == 9) valu_probe_op<OP>(*reinterpret_cast<int *>(&wide[i]), a, b); else valu_probe_op<OP>(acc[i], a, b); }
-    }
-    int x = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) x ^= acc[i] ^ (int)wide[i];
-    if (x == 0x7FFFFFFF) *sink = x;
-}
-template <int OP> static float valu_probe_run(int threads, int iters) {
-    int *d = nullptr; HIP_CHECK(hipMalloc((void **)&d, 4));
-    hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-    hipLaunchKernelGGL(k_valu_probe<OP>, dim3((unsigned)g_mv_cus), dim3((unsigned)threads), 0, nullptr, 16, d);
-    HIP_CHECK(hipEventRecord(a, nullptr));
-    hipLaunchKernelGGL(k_valu_probe<OP>, dim3((unsigned)g_mv_cus), dim3((unsigned)threads), 0, nullptr, iters, d);
-    HIP_CHECK(hipEventRecord(b, nullptr));
-    HIP_CHECK(hipDeviceSynchronize());
-    float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-    HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b)); HIP_IGNORE(hipFree(d));
-    return ms * 1e6f / ((float)iters * 64.0f);              // ns per instruction of one wave
-}
-// ns per issued instruction and wave; threads = 256 x waves per SIMD (one workgroup per CU)
-float probe_valu_ns(int op, int waves_per_simd, int iters) {
-    const int threads = 256 * std::max(1, std::min(4, waves_per_simd));
-    switch (op) {
-    case 0: return valu_probe_run<0>(threads, iters); case 1: return valu_probe_run<1>(threads, iters); case 2: return valu_probe_run<2>(threads, iters);
-    case 3: return valu_probe_run<3>(threads, iters); case 4: return valu_probe_run<4>(threads, iters); case 5: return valu_probe_run<5>(threads, iters);
-    case 6: return valu_probe_run<6>(threads, iters); case 7: return valu_probe_run<7>(threads, iters); case 8: return valu_probe_run<8>(threads, iters);
-    case 9: return valu_probe_run<9>(threads, iters); case 10: return valu_probe_run<10>(threads, iters); default: return -1.0f;
-    }
-}
 __global__ void k_set_int(int *p, int v) { *p = v; }
 void launch_set_int(int *p, int v, hipStream_t s) { hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, p, v); }
 // Batched decode epilogue, one workgroup per row: greedy argmax of the row's logits (first maximum wins), stored with the logits' owner slot; the

@@ -623,6 +623,9 @@ bool mmq2_supported(int type, int rows, int cols) { return (type == GT_Q4_K || t
 
 static int g_mmq2_cus = 256;
 void set_mmq2_cus(int cus) { if (cus > 0) g_mmq2_cus = cus; }
+// experiment knobs (MINIGPT4_MMQ2_TT / _FILL / _KS, read ONCE by Engine::init; the test hooks set the K split directly): 0 = the launcher's own choice
+static int g_mmq2_tt = 0, g_mmq2_fill = 0, g_mmq2_ks = 0;
+void set_mmq2_tuning(int tt, int fill_pct, int ks) { if (tt >= 0) g_mmq2_tt = tt; if (fill_pct >= 0) g_mmq2_fill = fill_pct ? std::max(50, fill_pct) : 0; if (ks >= 0) g_mmq2_ks = ks; }
 
 template <typename KernelT>
 static void mmq2_launch_kernel(KernelT kernel, bool &attr_done, dim3 grid, int threads, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
@@ -656,7 +659,7 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     a.n_tiles = (N + 31) / 32;
     a.n_mat = n; a.groups_each = (W[0]->rows + 127) / 128; a.N = N; a.ldy = ldy;
     int max_tt = W[0]->type == GT_Q6_K ? 2 : 3;          // token tiles per chunk the 256-register budget (two waves per SIMD) admits: Q6_K keeps four half-masked operand sets per pair
-    { static int tt_env = -1; if (tt_env < 0) { const char *e = getenv("MINIGPT4_MMQ2_TT"); tt_env = e ? atoi(e) : 0; } if (tt_env > 0) max_tt = std::min(max_tt, tt_env); }   // experiments
+    if (g_mmq2_tt > 0) max_tt = std::min(max_tt, g_mmq2_tt);   // experiments
     const int n_chunks = (a.n_tiles + max_tt - 1) / max_tt;
     a.tiles_per_chunk = (a.n_tiles + n_chunks - 1) / n_chunks;
     const int NSB = W[0]->cols / 256;
@@ -667,12 +670,11 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     // workgroups per CU (x 100) below which another K slice is added.  Measured on the 142-row image turn (profiles/r02r_prefill_ksplit_fill_sweep.log): 13B (5120-wide
     // matrices) 13.1 ms at 200, 11.7 at 150, 12.6 at 125 / 100 -- w1|w3's 432 workgroups are better left unsplit; 7B (4096 x 4096 wq / wo ...) 7.7 at 200, 8.2 at 150,
     // 8.0 at 125: the narrower model wants the deeper split.  MINIGPT4_MMQ2_FILL overrides.
-    static int fill_env = -1;
-    if (fill_env < 0) { const char *e = getenv("MINIGPT4_MMQ2_FILL"); fill_env = e ? std::max(50, atoi(e)) : 0; }
+    const int fill_env = g_mmq2_fill;
     // by the model's width (the smaller matrix dimension): rule = 0 / 1 lines of the sweep log are two other rules that lost (by weights per matrix; by workgroup count)
     const int fill_pct = fill_env ? fill_env : (std::min(W[0]->rows, W[0]->cols) >= 5120 ? 150 : 200);
     while (wgs * ks * 100 < fill_pct * g_mmq2_cus && NSB / (ks + 1) >= 4 && A.ws && (size_t)(ks + 1) * out_floats * n <= A.ws_floats) ks++;
-    if (getenv("MINIGPT4_MMQ2_KS")) ks = std::max(1, std::min(atoi(getenv("MINIGPT4_MMQ2_KS")), std::min(NSB, A.ws ? (int)(A.ws_floats / std::max<size_t>(1, out_floats * n)) : 1)));
+    if (g_mmq2_ks > 0) ks = std::max(1, std::min(g_mmq2_ks, std::min(NSB, A.ws ? (int)(A.ws_floats / std::max<size_t>(1, out_floats * n)) : 1)));
     a.sb_per_split = (NSB + ks - 1) / ks;
     ks = (NSB + a.sb_per_split - 1) / a.sb_per_split;
     if (ks > 1) {

@@ -1,0 +1,448 @@
+// extern "C" hooks of libminigpt4_test.so ONLY (include/minigpt4_amd_test.h): single-kernel parity hooks, micro-benchmarks, hardware probes and host-only helpers for
+// the CPU test tier.  The product library (libminigpt4.so) is linked without this file: none of these symbols ship.
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstring>
+
+#include "api_internal.hpp"
+#include "imageio.hpp"
+#include "quantize.hpp"
+#include "minigpt4_amd.h"
+#include "minigpt4_amd_test.h"
+
+using namespace mg4;
+using namespace mg4::apiutil;
+
+namespace mg4 {   // probe_kernels.hip
+float probe_valu_ns(int op, int waves_per_simd, int iters, int cus);
+float probe_grid_barrier_us(int n_blocks, int iters, unsigned *errors_out);
+void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s);
+}
+
+extern "C" {
+
+int minigpt4_amd_copy_arenas(struct MiniGPT4Context *dst, struct MiniGPT4Context *src) {   // single-GPU stand-in for the broadcast (tests): both weight arenas, device to device
+    if (!dst || !src) return 1;
+    return guarded(3, [&]() -> int {
+        Engine *d = E_(dst), *s = E_(src);
+        if (d->llm_arena_bytes() != s->llm_arena_bytes() || d->vision_arena_bytes() != s->vision_arena_bytes()) { set_last_error("arena sizes differ"); return 2; }
+        HIP_CHECK(hipMemcpy(d->llm_arena_ptr(), s->llm_arena_ptr(), s->llm_arena_bytes(), hipMemcpyDeviceToDevice));
+        HIP_CHECK(hipMemcpy(d->vision_arena_ptr(), s->vision_arena_ptr(), s->vision_arena_bytes(), hipMemcpyDeviceToDevice));
+        return 0;
+    });
+}
+
+// ---- single-kernel hooks ---------------------------------------------------------------------------------------------------
+
+int minigpt4_amd_timeline(unsigned long long *out, int max_workgroups) { return (out && max_workgroups > 0) ? read_matvec_timeline(out, max_workgroups) : -1; }
+
+int minigpt4_amd_convert_q3k_q6k(const void *src, void *dst, int64_t n_blocks) {
+    if (!src || !dst || n_blocks < 0) return 1;
+    q3k_to_q6k(static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), (size_t)n_blocks);
+    return 0;
+}
+
+static int test_mul_mat_impl(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y, bool ref);
+int minigpt4_amd_test_mul_mat(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y) { return test_mul_mat_impl(ggml_type, raw_w, n_in, n_out, x, N, y, false); }
+int minigpt4_amd_test_mul_mat_ref(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y) { return test_mul_mat_impl(ggml_type, raw_w, n_in, n_out, x, N, y, true); }
+static int test_mul_mat_impl(int ggml_type, const void *raw_w, int64_t n_in, int64_t n_out, const float *x, int64_t N, float *y, bool ref) {
+    if (ggml_type == GT_Q3_K && raw_w && n_in > 0 && n_out > 0 && n_in % 256 == 0) {   // the engine's load path: exact Q6_K image (quantize.hpp)
+        std::vector<uint8_t> q6((size_t)(n_in / 256 * n_out) * 210);
+        q3k_to_q6k(static_cast<const uint8_t *>(raw_w), q6.data(), (size_t)(n_in / 256 * n_out));
+        return test_mul_mat_impl(GT_Q6_K, q6.data(), n_in, n_out, x, N, y, ref);
+    }
+    if (!raw_w || !x || !y || n_in <= 0 || n_out <= 0 || N <= 0 || !qweight_supported(ggml_type) || n_in % gt_block(ggml_type)) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const size_t raw_bytes = gt_nbytes(ggml_type, (size_t)(n_in * n_out));
+        QWeight W, plan;
+        const size_t need = plan_qweight(ggml_type, (int)n_out, (int)n_in, plan, nullptr);
+        DevBuf d_raw(raw_bytes), d_planes(need), d_x((size_t)(N * n_in) * 4), d_y((size_t)(N * n_out) * 4);
+        plan_qweight(ggml_type, (int)n_out, (int)n_in, W, d_planes.as<uint8_t>());
+        HIP_CHECK(hipMemcpy(d_raw.p, raw_w, raw_bytes, hipMemcpyHostToDevice));
+        if (ggml_type == GT_F16 || ggml_type == GT_F32) HIP_CHECK(hipMemcpy(d_planes.p, raw_w, raw_bytes, hipMemcpyHostToDevice)); else launch_repack(d_raw.as<uint8_t>(), W, nullptr);
+        HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)(N * n_in) * 4, hipMemcpyHostToDevice));
+        ActQ A; std::vector<std::unique_ptr<DevBuf>> keep; alloc_act(A, keep, (size_t)N, (size_t)n_in);
+        launch_rms_quant(d_x.as<float>(), nullptr, (int)N, (int)n_in, A, act_mask_for(ggml_type), nullptr);
+        if (ref) launch_mul_mat_ref(W, A, (int)N, d_y.as<float>(), (int)n_out, nullptr, nullptr);
+        else launch_mul_mat(W, A, (int)N, d_y.as<float>(), (int)n_out, nullptr, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(y, d_y.p, (size_t)(N * n_out) * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+
+// The prefill launch of Engine::forward for N > 4 rows (mmq2_kernels.hip): n_mat equally shaped matrices (rows of `raw_w` back to back) against N rows in ONE launch, optional
+// residual ([n_mat][N][n_out]), optional forced K split (ks > 1: partial sums combined in fixed order).  y: [n_mat][N][n_out].  Returns 4 when the kernels refuse the shape.
+int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int64_t N, const float *residual, int ks, int generation, float *y) {
+    if (!raw_w || !x || !y || n_in <= 0 || n_out <= 0 || N <= 0 || n_mat < 1 || n_mat > 3 || !qweight_supported(ggml_type) || n_in % gt_block(ggml_type)) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const size_t raw_each = gt_nbytes(ggml_type, (size_t)(n_in * n_out)), out_each = (size_t)(N * n_out);
+        QWeight W[3], plan;
+        const size_t need = plan_qweight(ggml_type, (int)n_out, (int)n_in, plan, nullptr);
+        DevBuf d_raw(raw_each), d_planes(need * (size_t)n_mat + 1024), d_x((size_t)(N * n_in) * 4), d_y(out_each * n_mat * 4), d_res(out_each * n_mat * 4), d_ws(out_each * n_mat * 16 * 4);
+        (void)generation;
+        for (int i = 0; i < n_mat; i++) {
+            plan_qweight(ggml_type, (int)n_out, (int)n_in, W[i], d_planes.as<uint8_t>() + (size_t)i * need);
+            HIP_CHECK(hipMemcpy(d_raw.p, static_cast<const uint8_t *>(raw_w) + (size_t)i * raw_each, raw_each, hipMemcpyHostToDevice));
+            launch_repack(d_raw.as<uint8_t>(), W[i], nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+        }
+        HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)(N * n_in) * 4, hipMemcpyHostToDevice));
+        if (residual) HIP_CHECK(hipMemcpy(d_res.p, residual, out_each * n_mat * 4, hipMemcpyHostToDevice));
+        ActQ A; std::vector<std::unique_ptr<DevBuf>> keep; alloc_act(A, keep, (size_t)N, (size_t)n_in);
+        launch_rms_quant(d_x.as<float>(), nullptr, (int)N, (int)n_in, A, act_mask_for(ggml_type), nullptr);
+        const QWeight *Wp[3]; float *Yp[3]; const float *Rp[3];
+        for (int i = 0; i < n_mat; i++) { Wp[i] = &W[i]; Yp[i] = d_y.as<float>() + (size_t)i * out_each; Rp[i] = d_res.as<float>() + (size_t)i * out_each; }
+        A.ws = d_ws.as<float>(); A.ws_floats = out_each * n_mat * 16;
+        bool ok;
+        if (ggml_type == GT_F16) {   // the F16 language-model set path (big MFMA GEMM, several matrices per launch / split K)
+            const __half *Wh[3]; for (int i = 0; i < n_mat; i++) Wh[i] = reinterpret_cast<const __half *>(W[i].qs);
+            struct KsScope { KsScope(int k) { set_gemm_tuning(-1, k); } ~KsScope() { set_gemm_tuning(-1, 0); } } scope(std::max(0, ks));   // restored on every exit path
+            ok = launch_gemm_f16_set(A.xh, (int)n_in, Wh, n_mat, (int)N, (int)n_out, (int)n_in, Yp, residual ? Rp : nullptr, (int)n_out, A.ws, A.ws_floats, 256, nullptr);
+        } else {
+            struct KsScope { KsScope(int k) { set_mmq2_tuning(-1, -1, k); } ~KsScope() { set_mmq2_tuning(-1, -1, 0); } } scope(std::max(0, ks));
+            ok = launch_mmq2_set(Wp, Yp, residual ? Rp : nullptr, n_mat, A, (int)N, (int)n_out, nullptr);
+        }
+        HIP_CHECK(hipDeviceSynchronize());
+        if (!ok) return 4;
+        HIP_CHECK(hipMemcpy(y, d_y.p, out_each * n_mat * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+
+// The decode mat-vec launches exactly as Engine::forward issues them: n1 equally spaced matrices of type1 (+ optionally n2 of type2 in the same,
+// mixed-type launch), activation preparation either standalone (fuse = 0) or in the kernel prologue, optional residual, optional SiLU row-pair
+// epilogue.  prep: 1 = rms_norm(x) * x2, 2 = x, 3 = silu(x) * x2.  y: (n1 + n2) * n_out floats (epi = 1: n_out floats).
+int minigpt4_amd_test_matvec(int type1, const void *raw1, int n1, int type2, const void *raw2, int n2, int64_t n_in, int64_t n_out, const float *x, const float *x2, int prep,
+                             int fuse, int epi, const float *residual, float *y) {
+    if (!raw1 || !x || !y || n_in <= 0 || n_out <= 0 || n1 < 1 || n1 > 3 || n2 < 0 || n2 > 1 || prep < 1 || prep > 3 || (prep != 2 && !x2)) return 1;
+    if (!qweight_supported(type1) || n_in % gt_block(type1) || (n2 && (!raw2 || !qweight_supported(type2) || n_in % gt_block(type2)))) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const int K = (int)n_in, R = (int)n_out, nt = n1 + n2;
+        std::vector<std::unique_ptr<DevBuf>> keep;
+        std::vector<QWeight> W((size_t)nt);
+        auto upload = [&](int type, const void *raw, int n, QWeight *dst) {
+            QWeight plan; const size_t need = plan_qweight(type, R, K, plan, nullptr), raw_bytes = gt_nbytes(type, (size_t)R * K);
+            keep.emplace_back(new DevBuf(need * (size_t)n)); uint8_t *base = (uint8_t *)keep.back()->p;   // one allocation: equal spacing
+            DevBuf d_raw(raw_bytes);
+            for (int m = 0; m < n; m++) {
+                plan_qweight(type, R, K, dst[m], base + (size_t)m * need);
+                HIP_CHECK(hipMemcpy(d_raw.p, (const uint8_t *)raw + (size_t)m * raw_bytes, raw_bytes, hipMemcpyHostToDevice));
+                if (type == GT_F16 || type == GT_F32) HIP_CHECK(hipMemcpy(base + (size_t)m * need, d_raw.p, raw_bytes, hipMemcpyDeviceToDevice)); else launch_repack(d_raw.as<uint8_t>(), dst[m], nullptr);
+                HIP_CHECK(hipDeviceSynchronize());
+            }
+        };
+        upload(type1, raw1, n1, W.data());
+        if (n2) upload(type2, raw2, n2, W.data() + n1);
+        DevBuf d_x((size_t)K * 4), d_x2((size_t)K * 4), d_y((size_t)nt * R * 4), d_res((size_t)nt * R * 4), d_tab(65536 * 2);
+        HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)K * 4, hipMemcpyHostToDevice));
+        if (x2) HIP_CHECK(hipMemcpy(d_x2.p, x2, (size_t)K * 4, hipMemcpyHostToDevice));
+        if (residual) HIP_CHECK(hipMemcpy(d_res.p, residual, (size_t)nt * R * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(d_y.p, 0xFF, (size_t)nt * R * 4));
+        Tables tb;
+        { std::vector<__half> si(65536);
+          for (int i = 0; i < 65536; i++) { const float v = __half2float(__ushort_as_half((unsigned short)i)); si[(size_t)i] = __float2half_rn(v / (1.0f + expf(-v))); }
+          HIP_CHECK(hipMemcpy(d_tab.p, si.data(), 131072, hipMemcpyHostToDevice)); tb.silu = d_tab.as<__half>(); }
+        ActQ A; alloc_act(A, keep, 1, (size_t)K);
+        int mask = 0; for (int m = 0; m < nt; m++) mask |= act_mask_for(W[(size_t)m].type);
+        if (!fuse) {
+            if (prep == 1) launch_rms_quant(d_x.as<float>(), d_x2.as<float>(), 1, K, A, mask, nullptr);
+            else launch_silu_mul_quant(d_x.as<float>(), prep == 3 ? d_x2.as<float>() : nullptr, 1, K, A, mask, tb, nullptr);
+        }
+        const QWeight *Wp[4]; float *Yp[4]; const float *Rp[4];
+        for (int m = 0; m < nt; m++) { Wp[m] = &W[(size_t)m]; Yp[m] = d_y.as<float>() + (size_t)m * R; Rp[m] = d_res.as<float>() + (size_t)m * R; }
+        bool ok;
+        if (n2) ok = launch_matvec_mixed(Wp, Yp, n1, Wp + n1, Yp + n1, n2, A, nullptr, fuse ? prep : 0, d_x.as<float>(), d_x2.as<float>());
+        else ok = launch_matvec_set(Wp, Yp, residual ? Rp : nullptr, n1, A, nullptr, fuse ? prep : 0, d_x.as<float>(), d_x2.as<float>(), &tb, epi);
+        if (!ok) { set_last_error("shape / type outside the decode mat-vec kernel's range"); return 4; }
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(y, d_y.p, (size_t)(epi ? 1 : nt) * R * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+
+// The batched-decode mat-vec (k_matvec_tn) as Engine::forward_batch issues it: N = 1..4 rows against n_mat equally spaced matrices (raw_w = their file bytes
+// back to back), optional residual.  x: [N][n_in]; y / residual: [n_mat][N][n_out].  Returns 4 when the shape is outside the kernel's range.
+int minigpt4_amd_test_matvec_rows(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int N, const float *residual, float *y) {
+    if (!raw_w || !x || !y || n_in <= 0 || n_out <= 0 || n_mat < 1 || n_mat > 3 || N < 1 || N > 4 || !qweight_supported(ggml_type) || n_in % gt_block(ggml_type)) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const int K = (int)n_in, R = (int)n_out;
+        QWeight plan; const size_t need = plan_qweight(ggml_type, R, K, plan, nullptr), raw_bytes = gt_nbytes(ggml_type, (size_t)R * K);
+        DevBuf planes(need * (size_t)n_mat), d_raw(raw_bytes), d_x((size_t)N * K * 4), d_y((size_t)n_mat * N * R * 4), d_res((size_t)n_mat * N * R * 4);
+        std::vector<QWeight> W((size_t)n_mat);
+        for (int m = 0; m < n_mat; m++) {
+            plan_qweight(ggml_type, R, K, W[(size_t)m], planes.as<uint8_t>() + (size_t)m * need);
+            HIP_CHECK(hipMemcpy(d_raw.p, (const uint8_t *)raw_w + (size_t)m * raw_bytes, raw_bytes, hipMemcpyHostToDevice));
+            if (ggml_type == GT_F16 || ggml_type == GT_F32) HIP_CHECK(hipMemcpy(planes.as<uint8_t>() + (size_t)m * need, d_raw.p, raw_bytes, hipMemcpyDeviceToDevice)); else launch_repack(d_raw.as<uint8_t>(), W[(size_t)m], nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+        }
+        HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)N * K * 4, hipMemcpyHostToDevice));
+        if (residual) HIP_CHECK(hipMemcpy(d_res.p, residual, (size_t)n_mat * N * R * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(d_y.p, 0xFF, (size_t)n_mat * N * R * 4));
+        ActQ A; std::vector<std::unique_ptr<DevBuf>> keep; alloc_act(A, keep, (size_t)N, (size_t)K);
+        launch_rms_quant(d_x.as<float>(), nullptr, N, K, A, act_mask_for(ggml_type), nullptr);
+        const QWeight *Wp[3]; float *Yp[3]; const float *Rp[3];
+        for (int m = 0; m < n_mat; m++) { Wp[m] = &W[(size_t)m]; Yp[m] = d_y.as<float>() + (size_t)m * N * R; Rp[m] = d_res.as<float>() + (size_t)m * N * R; }
+        if (!launch_matvec_rows(Wp, Yp, residual ? Rp : nullptr, n_mat, A, N, R, nullptr)) { set_last_error("shape / type outside the multi-row mat-vec kernel's range"); return 4; }
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(y, d_y.p, (size_t)n_mat * N * R * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+
+int minigpt4_amd_test_quantize(const float *x, const float *rms_w, int64_t N, int64_t K, int8_t *q8k, float *dk, int16_t *bsums, int8_t *q80, float *d0) {
+    if (!x || N <= 0 || K <= 0 || K % 256) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        DevBuf d_x((size_t)(N * K) * 4), d_w((size_t)K * 4);
+        HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)(N * K) * 4, hipMemcpyHostToDevice));
+        if (rms_w) HIP_CHECK(hipMemcpy(d_w.p, rms_w, (size_t)K * 4, hipMemcpyHostToDevice));
+        ActQ A; std::vector<std::unique_ptr<DevBuf>> keep; alloc_act(A, keep, (size_t)N, (size_t)K);
+        launch_rms_quant(d_x.as<float>(), rms_w ? d_w.as<float>() : nullptr, (int)N, (int)K, A, ACT_Q8K | ACT_Q80, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        if (q8k) HIP_CHECK(hipMemcpy(q8k, A.q8k, (size_t)(N * K), hipMemcpyDeviceToHost));
+        if (dk) HIP_CHECK(hipMemcpy(dk, A.dk, (size_t)(N * K / 256) * 4, hipMemcpyDeviceToHost));
+        if (bsums) HIP_CHECK(hipMemcpy(bsums, A.bsk, (size_t)(N * K / 16) * 2, hipMemcpyDeviceToHost));
+        if (q80) HIP_CHECK(hipMemcpy(q80, A.q80, (size_t)(N * K), hipMemcpyDeviceToHost));
+        if (d0) HIP_CHECK(hipMemcpy(d0, A.d0, (size_t)(N * K / 32) * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+
+static int test_gemm_impl(const float *A, const float *W, const float *bias, int M, int N, int K, int gelu, float *C, bool skinny);
+int minigpt4_amd_test_gemm_f16(const float *A, const float *W, const float *bias, int M, int N, int K, int gelu, float *C) { return test_gemm_impl(A, W, bias, M, N, K, gelu, C, false); }
+int minigpt4_amd_test_gemm_f16_skinny(const float *A, const float *W, const float *bias, int M, int N, int K, int gelu, float *C) { return test_gemm_impl(A, W, bias, M, N, K, gelu, C, true); }
+static int test_gemm_impl(const float *A, const float *W, const float *bias, int M, int N, int K, int gelu, float *C, bool skinny) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || K % 16) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        DevBuf dA((size_t)M * K * 4), dW((size_t)N * K * 4), dAh((size_t)M * K * 2), dWh((size_t)N * K * 2), dC((size_t)M * N * 4), db((size_t)N * 4), dtab(65536 * 2);
+        HIP_CHECK(hipMemcpy(dA.p, A, (size_t)M * K * 4, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(dW.p, W, (size_t)N * K * 4, hipMemcpyHostToDevice));
+        if (bias) HIP_CHECK(hipMemcpy(db.p, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+        Tables tb;
+        if (gelu) { std::vector<__half> g(65536);
+            for (int i = 0; i < 65536; i++) { const float x = __half2float(__ushort_as_half((unsigned short)i)); g[(size_t)i] = __float2half_rn(0.5f * x * (1.0f + tanhf(0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x)))); }
+            HIP_CHECK(hipMemcpy(dtab.p, g.data(), 131072, hipMemcpyHostToDevice)); tb.gelu = dtab.as<__half>(); }
+        launch_f32_to_f16(dA.as<float>(), dAh.as<__half>(), (size_t)M * K, nullptr); launch_f32_to_f16(dW.as<float>(), dWh.as<__half>(), (size_t)N * K, nullptr);
+        if (skinny) { if (!launch_gemm_f16_skinny(dAh.as<__half>(), K, dWh.as<__half>(), K, M, N, K, bias ? db.as<float>() : nullptr, nullptr, gelu != 0, tb, dC.as<float>(), nullptr, N, nullptr)) return 4; }
+        else launch_gemm_f16(dAh.as<__half>(), K, dWh.as<__half>(), K, M, N, K, bias ? db.as<float>() : nullptr, nullptr, gelu != 0, tb, dC.as<float>(), nullptr, N, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(C, dC.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+
+// Micro-benchmark of the decode mat-vec kernels on synthetic planes (random quant bytes, sane fp16 scales).  `n_sets` distinct weight sets
+// are cycled so the 256 MiB Infinity Cache cannot serve repeats.  variant 0 = k_mul_mat per matrix, 1 = persistent-wave v2 (fused set).
+int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int variant, int iters, int n_sets, int waves_per_cu, float *us_per_launch, double *bytes_per_launch) {
+    if (!qweight_supported(ggml_type) || rows <= 0 || cols <= 0 || cols % gt_block(ggml_type) || n_mat < 1 || n_mat > 3 || iters < 1 || n_sets < 1) return 1;
+    if (device_count_noexcept() <= 0) return 2;
+    return guarded(3, [&]() -> int {
+        hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0));
+        set_matvec_tuning(waves_per_cu, 0, prop.multiProcessorCount);
+        QWeight plan; const size_t need = plan_qweight(ggml_type, rows, cols, plan, nullptr);
+        std::vector<std::unique_ptr<DevBuf>> keep;
+        std::vector<QWeight> W((size_t)n_sets * n_mat);
+        for (size_t i = 0; i < W.size(); i++) {
+            keep.emplace_back(new DevBuf(need));
+            uint8_t *base = (uint8_t *)keep.back()->p;
+            plan_qweight(ggml_type, rows, cols, W[i], base);
+            launch_fill_random(base, need, (unsigned)(i * 7919 + 13), nullptr);
+            const size_t n = (size_t)rows * cols;
+            if (W[i].sc) { const size_t sc_bytes = (size_t)((W[i].d ? W[i].d : base + need) - W[i].sc);
+                if (ggml_type == GT_Q4_K || ggml_type == GT_Q5_K) { /* header: d, dmin fp16 then 12 scale bytes: make d/dmin sane, keep scales random */
+                    launch_fill_u16((void *)W[i].sc, std::min(sc_bytes, n / 256 * 16) / 2, 0x1C00, nullptr); }
+                else if (ggml_type != GT_Q6_K) launch_fill_u16((void *)W[i].sc, std::min(sc_bytes, n / 32 * 4) / 2, 0x1C00, nullptr); }
+            if (W[i].d) launch_fill_u16((void *)W[i].d, n / 256, 0x1C00, nullptr);
+            if (ggml_type == GT_F16) launch_fill_u16(base, n, 0x2E66, nullptr);
+            if (ggml_type == GT_F32) { std::vector<float> h(n, 0.01f); HIP_CHECK(hipMemcpy(base, h.data(), n * 4, hipMemcpyHostToDevice)); }
+        }
+        // variants 3..6: the batched decode's multi-row launch (weights streamed once): 3 = 4 prepared rows, 4 = 2 prepared rows, 5 = 2 rows prepared inside the launch, 6 = 4 rows inside
+        // 10 + N / 20 + N: the multi-row launch with N = 1..4 prepared rows / rows prepared inside the launch (N = 1 and 3 run the 2- and 4-row kernels with a row to spare)
+        const int NR = (variant > 10 && variant <= 14) ? variant - 10 : (variant > 20 && variant <= 24) ? variant - 20 : (variant == 3 || variant == 6) ? 4 : ((variant == 4 || variant == 5) ? 2 : 1);
+        ActQ A; alloc_act(A, keep, (size_t)NR, (size_t)cols);
+        DevBuf dx((size_t)NR * cols * 4), dy((size_t)rows * 4 * 3 * NR);
+        { std::vector<float> hx((size_t)NR * cols); for (size_t i = 0; i < hx.size(); i++) hx[i] = (float)((int)(i * 37 % 201) - 100) / 64.0f; HIP_CHECK(hipMemcpy(dx.p, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); }
+        launch_rms_quant(dx.as<float>(), nullptr, NR, cols, A, act_mask_for(ggml_type), nullptr);
+        auto run = [&](int set) {
+            const QWeight *Wp[3]; float *Yp[3];
+            for (int m = 0; m < n_mat; m++) { Wp[m] = &W[(size_t)set * n_mat + m]; Yp[m] = dy.as<float>() + (size_t)m * rows * NR; }
+            if (variant == 1 && launch_matvec_set(Wp, Yp, nullptr, n_mat, A, nullptr)) return;
+            if ((variant == 3 || variant == 4 || (variant > 10 && variant <= 14)) && launch_matvec_rows(Wp, Yp, nullptr, n_mat, A, NR, rows, nullptr)) return;
+            if ((variant == 5 || variant == 6 || (variant > 20 && variant <= 24)) && launch_matvec_rows(Wp, Yp, nullptr, n_mat, A, NR, rows, nullptr, dx.as<float>(), dx.as<float>(), cols)) return;
+            if (variant == 2 && launch_matvec_set(Wp, Yp, nullptr, n_mat, A, nullptr, 1, dx.as<float>(), dx.as<float>())) return;   // rms-norm prologue, as the decode's qkv / w1|w3 launches
+            for (int m = 0; m < n_mat; m++) launch_mul_mat(*Wp[m], A, 1, Yp[m], rows, nullptr, nullptr);
+        };
+        for (int i = 0; i < std::min(n_sets, 4); i++) run(i);
+        HIP_CHECK(hipDeviceSynchronize());
+        hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+        HIP_CHECK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; i++) run(i % n_sets);
+        HIP_CHECK(hipEventRecord(b, nullptr));
+        HIP_CHECK(hipDeviceSynchronize());
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b));
+        if (us_per_launch) *us_per_launch = ms * 1e3f / (float)iters;
+        if (bytes_per_launch) *bytes_per_launch = (double)gt_nbytes(ggml_type, (size_t)rows * cols) * n_mat;
+        return 0;
+    });
+}
+
+// Prefill mat-mul micro-benchmark (tools/mmq2_bench.py): n_mat matrices of random blocks against N random rows, `iters` launches of the engine's prefill launch
+// (generation 2: mmq2_kernels.hip; generation 1: the round-1 kernels, one launch per matrix); ks: forced K split (0 = the launcher's choice).
+int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, int iters, int ks, int generation, float *us_per_launch) {
+    if (!qweight_supported(ggml_type) || rows <= 0 || cols <= 0 || cols % gt_block(ggml_type) || n_mat < 1 || n_mat > 3 || iters < 1 || N < 1) return 1;
+    if (device_count_noexcept() <= 0) return 2;
+    return guarded(3, [&]() -> int {
+        hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0));
+        QWeight plan; const size_t need = plan_qweight(ggml_type, rows, cols, plan, nullptr);
+        std::vector<std::unique_ptr<DevBuf>> keep;
+        QWeight W[3];
+        for (int i = 0; i < n_mat; i++) {
+            keep.emplace_back(new DevBuf(need));
+            uint8_t *base = (uint8_t *)keep.back()->p;
+            plan_qweight(ggml_type, rows, cols, W[i], base);
+            launch_fill_random(base, need, (unsigned)(i * 7919 + 13), nullptr);
+            const size_t n = (size_t)rows * cols;
+            if (ggml_type == GT_Q4_K || ggml_type == GT_Q5_K) launch_fill_u16((void *)W[i].sc, n / 256 * 16 / 2, 0x1C00, nullptr);
+            if (W[i].d) launch_fill_u16((void *)W[i].d, n / 256, 0x1C00, nullptr);
+        }
+        ActQ A; alloc_act(A, keep, (size_t)N, (size_t)cols);
+        const size_t out_each = (size_t)N * rows;
+        DevBuf dx((size_t)N * cols * 4), dy(out_each * n_mat * 4), dws(out_each * n_mat * 16 * 4);
+        { std::vector<float> hx((size_t)N * cols); for (size_t i = 0; i < hx.size(); i++) hx[i] = (float)((int)(i * 37 % 201) - 100) / 64.0f; HIP_CHECK(hipMemcpy(dx.p, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); }
+        launch_rms_quant(dx.as<float>(), nullptr, N, cols, A, act_mask_for(ggml_type), nullptr);
+        A.ws = dws.as<float>(); A.ws_floats = out_each * n_mat * 16;
+        set_mmq2_cus(prop.multiProcessorCount);
+        struct KsScope { KsScope(int k) { set_mmq2_tuning(-1, -1, k); } ~KsScope() { set_mmq2_tuning(-1, -1, 0); } } ks_scope(std::max(0, ks));
+        const int keep_gen = mmq_enabled();
+        set_mmq_enabled(std::min(generation, 2));
+        const QWeight *Wp[3]; float *Yp[3];
+        for (int m = 0; m < n_mat; m++) { Wp[m] = &W[m]; Yp[m] = dy.as<float>() + (size_t)m * out_each; }
+        auto run = [&]() {
+            if (generation >= 2 && launch_mmq2_set(Wp, Yp, nullptr, n_mat, A, N, rows, nullptr)) return;
+            for (int m = 0; m < n_mat; m++) launch_mul_mat(*Wp[m], A, N, Yp[m], rows, nullptr, nullptr);
+        };
+        run(); run();
+        HIP_CHECK(hipDeviceSynchronize());
+        hipEvent_t ea, eb; HIP_CHECK(hipEventCreate(&ea)); HIP_CHECK(hipEventCreate(&eb));
+        HIP_CHECK(hipEventRecord(ea, nullptr));
+        for (int i = 0; i < iters; i++) run();
+        HIP_CHECK(hipEventRecord(eb, nullptr));
+        HIP_CHECK(hipDeviceSynchronize());
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ea, eb));
+        HIP_IGNORE(hipEventDestroy(ea)); HIP_IGNORE(hipEventDestroy(eb));
+        set_mmq_enabled(keep_gen);
+        if (us_per_launch) *us_per_launch = ms * 1e3f / (float)iters;
+        return 0;
+    });
+}
+
+float minigpt4_amd_probe_valu(int op, int waves_per_simd, int iters) {
+    if (device_count_noexcept() <= 0 || iters < 1) return -1.0f;
+    float ns = -1.0f;
+    guarded(1, [&] { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0)); set_matvec_tuning(0, 0, prop.multiProcessorCount); ns = probe_valu_ns(op, waves_per_simd, iters, prop.multiProcessorCount); return 0; });
+    return ns;
+}
+float minigpt4_amd_probe_grid_barrier(int n_blocks, int iters, unsigned *errors) {
+    if (n_blocks < 1 || n_blocks > 1024 || iters < 1 || device_count_noexcept() <= 0) return -1.0f;
+    float us = -1.0f;
+    guarded(1, [&] { us = probe_grid_barrier_us(n_blocks, iters, errors); return 0; });
+    return us;
+}
+
+// ---- host-only logic -----------------------------------------------------------------------------------------------------------
+struct MiniGPT4Vocab { LLMFile f; Tokenizer t; };
+struct MiniGPT4Vocab *minigpt4_amd_vocab_load(const char *llm_path) {
+    if (!file_exists(llm_path)) return nullptr;
+    MiniGPT4Vocab *v = new (std::nothrow) MiniGPT4Vocab();
+    if (!v) return nullptr;
+    if (v->f.load(llm_path, true)) { delete v; return nullptr; }
+    v->t.init(v->f);
+    return v;
+}
+void minigpt4_amd_vocab_free(struct MiniGPT4Vocab *v) { delete v; }
+int minigpt4_amd_vocab_size(struct MiniGPT4Vocab *v) { return v ? (int)v->f.n_vocab : 0; }
+const char *minigpt4_amd_vocab_piece(struct MiniGPT4Vocab *v, int id, int *len) {
+    if (!v || id < 0 || id >= (int)v->f.pieces.size()) return nullptr;
+    if (len) *len = (int)v->f.pieces[(size_t)id].size();
+    return v->f.pieces[(size_t)id].c_str();
+}
+int minigpt4_amd_vocab_tokenize(struct MiniGPT4Vocab *v, const char *text, int add_bos, int32_t *out, int cap) {
+    if (!v || !text) return -1;
+    const std::vector<int> t = v->t.tokenize(text, add_bos != 0);
+    for (int i = 0; i < (int)t.size() && i < cap; i++) out[i] = t[(size_t)i];
+    return (int)t.size();
+}
+int minigpt4_amd_inspect_files(const char *vision_path, const char *llm_path, int *n_vision_tensors, int *n_llm_tensors, int64_t *llm_weight_bytes_per_token) {
+    if (vision_path) {
+        if (!file_exists(vision_path)) return E_PathDoesNotExist;
+        VisionFile vf; if (int e = vf.load(vision_path)) return e;
+        int n = 0; for (auto &m : vf.models) n += (int)m.second.size();
+        if (n_vision_tensors) *n_vision_tensors = n;
+    }
+    if (llm_path) {
+        if (!file_exists(llm_path)) return E_PathDoesNotExist;
+        LLMFile lf; if (int e = lf.load(llm_path)) return e;
+        if (n_llm_tensors) *n_llm_tensors = (int)lf.tensors.size();
+        if (llm_weight_bytes_per_token) { int64_t b = 0; for (auto &t : lf.tensors) b += t.first == "tok_embeddings.weight" ? (int64_t)gt_nbytes(t.second.type, (size_t)t.second.ne[0]) : (int64_t)t.second.nbytes; *llm_weight_bytes_per_token = b; }
+    }
+    return E_None;
+}
+int minigpt4_amd_decode_image(const void *bytes, size_t n, struct MiniGPT4Image *image) {
+    if (!bytes || !image) return E_OpenImage;
+    ImageRGB8 im; std::string err;
+    if (!decode_image(static_cast<const uint8_t *>(bytes), n, im, err)) { set_last_error(err); return E_OpenImage; }
+    uint8_t *data = new (std::nothrow) uint8_t[im.px.size()];
+    if (!data) return E_OpenImage;
+    memcpy(data, im.px.data(), im.px.size());
+    image->data = data; image->width = im.w; image->height = im.h; image->channels = 3; image->format = MINIGPT4_IMAGE_FORMAT_U8;
+    return E_None;
+}
+int minigpt4_amd_resample_coeffs(int in_size, int out_size, int *ksize, int *first, int *count, int *kk, size_t kk_cap) {
+    if (in_size <= 0 || out_size <= 0 || in_size > (1 << 24) || out_size > (1 << 16)) return -1;
+    ResampleCoeffs c; precompute_bicubic_8bpc(in_size, out_size, c);
+    if (ksize) *ksize = c.ksize;
+    if (first) memcpy(first, c.first.data(), (size_t)out_size * 4);
+    if (count) memcpy(count, c.count.data(), (size_t)out_size * 4);
+    if (kk) { if (kk_cap < c.kk.size()) return -2; memcpy(kk, c.kk.data(), c.kk.size() * 4); }
+    return 0;
+}
+// FNV-1a digest of everything the engine takes from an LLM file: hyper-parameters, vocabulary (pieces + scores) and every tensor (name, type, shape, bytes),
+// tensors in name order.  A GGUF file and the GGJT v3 file of the same model must give the same digest.
+int minigpt4_amd_llm_file_digest(const char *llm_path, uint64_t *digest, int with_data) {
+    if (!llm_path || !digest) return E_LoadLanguageModel;
+    if (!file_exists(llm_path)) return E_PathDoesNotExist;
+    LLMFile f;
+    if (int e = f.load(llm_path)) return e;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) { const uint8_t *b = static_cast<const uint8_t *>(p); for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+    const uint32_t hp[5] = {f.n_vocab, f.n_embd, f.n_head, f.n_layer, f.n_ff()};
+    mix(hp, sizeof(hp));
+    for (size_t i = 0; i < f.pieces.size(); i++) { const uint32_t n = (uint32_t)f.pieces[i].size(); mix(&n, 4); mix(f.pieces[i].data(), n); mix(&f.scores[i], 4); }
+    for (auto &kv : f.tensors) {
+        const TensorMeta &t = kv.second;
+        mix(kv.first.data(), kv.first.size()); mix(&t.type, 4);
+        for (int64_t d : t.ne) mix(&d, 8);
+        if (with_data) mix(f.mf.data + t.offset, t.nbytes);
+    }
+    *digest = h;
+    return E_None;
+}
+int64_t minigpt4_amd_quantize_chunk(int ggml_type, const float *x, void *dst, int64_t n) {
+    if (!x || !dst || n <= 0) return 0;
+    return (int64_t)quantize_chunk(ggml_type, x, static_cast<uint8_t *>(dst), (size_t)n);
+}
+int minigpt4_amd_sample_logits(const float *logits, int n_vocab, int seed, float temp, int32_t top_k, float top_p, float tfs_z, float typical_p, int mirostat, float mirostat_tau, float mirostat_eta) {
+    if (!logits || n_vocab <= 0) return -1;
+    Sampler s; s.seed(seed);
+    SampleParams p; p.temp = temp; p.top_k = top_k; p.top_p = top_p; p.tfs_z = tfs_z; p.typical_p = typical_p; p.mirostat = mirostat; p.mirostat_tau = mirostat_tau; p.mirostat_eta = mirostat_eta;
+    return s.sample(logits, n_vocab, p);
+}
+
+}  // extern "C"

@@ -249,11 +249,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restric
         }
     }
 }
-static int g_gemm_big_min_m = 512;   // MINIGPT4_GEMM_BIG_M: smallest M that takes the 128x128 kernel (0 = never)
+static int g_gemm_big_min_m = 512;   // smallest M that takes the 128x128 kernel (0 = never); MINIGPT4_GEMM_BIG_M, read once by Engine::init
+static int g_f16_ks = 0;             // forced K split of the F16 set launches (0 = choose); MINIGPT4_F16_KS, read once by Engine::init
+void set_gemm_tuning(int big_min_m, int f16_ks) { if (big_min_m >= 0) g_gemm_big_min_m = big_min_m; g_f16_ks = std::max(0, std::min(f16_ks, 8)); }
 static bool launch_gemm_big(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
                             float *out, __half *out_h, int ldo, hipStream_t s, const GemmSet gs = GemmSet{0, 0, 0, 0, 0}, int slices = 1) {
     static bool init = false;
-    if (!init) { if (const char *e = getenv("MINIGPT4_GEMM_BIG_M")) g_gemm_big_min_m = atoi(e); init = true;
+    if (!init) { init = true;
         HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -284,7 +286,7 @@ bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n
     int ks = 1;
     const size_t out_floats = (size_t)M * ldo;
     while (tiles * ks < 2 * cus && (K / 64) / (ks + 1) >= 16 && ws && (size_t)(ks + 1) * out_floats * n <= ws_floats && ks < 4) ks++;
-    if (const char *e = getenv("MINIGPT4_F16_KS")) ks = std::max(1, std::min(atoi(e), 8));
+    if (g_f16_ks > 0) ks = g_f16_ks;
     if (ks > 1 && (!ws || (size_t)ks * out_floats * n > ws_floats || n > 1 || out_floats % 4)) ks = 1;   // split launches are single-matrix (wo, w2): the sets have tiles enough
     GemmSet gs{n > 1 ? N : 0, wstride, ystride, 0, 0};
     if (ks > 1) {
@@ -303,6 +305,93 @@ bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n
 // HBM (PMC FETCH_SIZE) without changing the time; 64x128 tiles with two accumulators per wave (fewer LDS reads per MFMA) are 26 % slower.  Every
 // variant with fewer workgroups loses: the launches are bound by the serial per-k-tile chain of each workgroup (global -> register -> LDS ->
 // MFMA, two barriers per tile), not by traffic, LDS bandwidth or the matrix cores -- the next step is an LDS-DMA ring per workgroup.
+// =====================================================================================================================
+// Skinny-M form (the Q-Former: 32 query rows per image against 768- / 3072-wide layers).  With 64x64 tiles a [32 x 768] x [768 x 768] product is 12 workgroups on a
+// 256-CU chip, each walking its K alone: 8-12 us per GEMM for 1.2 MB of weights (round 2: the Q-Former ran at ~40x its HBM floor).  Here a workgroup owns 16 output
+// COLUMNS (N / 16 workgroups: 48 ... 320) and 32 or 64 rows; its eight waves split K (k-steps of 32, interleaved), every lane fetches its MFMA fragments straight from
+// global memory (16-byte loads, up to 12 k-steps in flight = ONE round trip for K <= 3072 -- no LDS staging: nothing is reused inside a workgroup),
+// v_mfma_f32_16x16x32_f16, and the eight partial tiles are added in wave order through LDS (deterministic).  Same arithmetic as k_gemm_f16 (exact fp16 products, fp32 accumulation); per output element the order of additions
+// does not depend on M, so a batched encode still equals the single-image encode bit for bit.
+// =====================================================================================================================
+typedef float float4v_t __attribute__((ext_vector_type(4)));
+constexpr int SK_WAVES = 8;                                       // waves per workgroup = K slices (fixed: the order of additions per output element must not depend on M)
+template <int MT, bool GELU, bool RES>
+__global__ __launch_bounds__(64 * SK_WAVES) void k_gemm_f16_skinny(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K,
+                                                                   const float *__restrict__ bias, const float *residual, const Tables tb, float *out, __half *__restrict__ out_h, int ldo) {
+    constexpr int U = MT <= 2 ? 12 : 8;                           // k-steps in flight per wave: U x (1 + MT) 16-byte loads per lane (36 / 40)
+    __shared__ float red[SK_WAVES][MT][64][4];                    // [wave][m tile][lane][acc register]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * MT);
+    const int r16 = lane & 15, kc = lane >> 4;
+    const half8_t *wp = reinterpret_cast<const half8_t *>(W + (size_t)min(n0 + r16, N - 1) * ldw + 8 * kc);
+    const half8_t *ap[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) ap[mt] = reinterpret_cast<const half8_t *>(A + (size_t)min(m0 + 16 * mt + r16, M - 1) * lda + 8 * kc);
+    const int mt_n = min(MT, (M - m0 + 15) / 16);                 // live M tiles (workgroup-uniform)
+    float4v_t acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt] = float4v_t{0.0f, 0.0f, 0.0f, 0.0f};
+    const int nks = K / 32;                                       // k-steps; wave w takes w, w + 8, ... (K = 768: 3 each, 3072: 12 each -- one round trip)
+    for (int ks0 = wave; ks0 < nks; ks0 += SK_WAVES * U) {
+        half8_t wf[U], af[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int ks = min(ks0 + SK_WAVES * u, nks - 1);      // clamped: the loads never branch; a step past the end is not multiplied
+            wf[u] = wp[ks * 4];                                   // 32 halfs = 4 chunks of 8 per k-step
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) af[u][mt] = ap[mt][ks * 4];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (ks0 + SK_WAVES * u < nks) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) if (mt < mt_n) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u][mt], wf[u], acc[mt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave][mt][lane][r] = acc[mt][r];
+    __syncthreads();
+    // wave w finishes M tile w: the eight K partials in wave order, then the epilogue of k_gemm_f16 (bias, fp16-table GELU, residual)
+    const int mt = wave;
+    if (mt >= mt_n) return;
+    const int col = n0 + r16;
+    const float bv = bias ? bias[min(col, N - 1)] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = m0 + 16 * mt + 4 * kc + r;
+        float v = red[0][mt][lane][r];
+#pragma unroll
+        for (int w = 1; w < SK_WAVES; w++) v += red[w][mt][lane][r];
+        if (bias) v = bv + v;
+        if (GELU) v = tab_v(tb.gelu, v);
+        if (row < M && col < N) {
+            const size_t o = (size_t)row * ldo + col;
+            if (RES) v = residual[o] + v;
+            if (out) out[o] = v;
+            if (out_h) out_h[o] = f2h_rn(v);
+        }
+    }
+}
+template <int MT>
+static void launch_skinny_mt(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
+                             float *out, __half *out_h, int ldo, hipStream_t s) {
+    const dim3 grid((unsigned)(N / 16), (unsigned)((M + 16 * MT - 1) / (16 * MT))), block(64 * SK_WAVES);
+    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16_skinny<MT, true, true>), grid, block, 0, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+    else if (gelu) hipLaunchKernelGGL((k_gemm_f16_skinny<MT, true, false>), grid, block, 0, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+    else if (residual) hipLaunchKernelGGL((k_gemm_f16_skinny<MT, false, true>), grid, block, 0, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+    else hipLaunchKernelGGL((k_gemm_f16_skinny<MT, false, false>), grid, block, 0, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+}
+bool launch_gemm_f16_skinny(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
+                            float *out, __half *out_h, int ldo, hipStream_t s) {
+    if (N % 16 || K % 32 || M < 1 || (lda % 8) || (ldw % 8)) return false;
+    // 32 rows per workgroup for one image (no register or bandwidth spent on clamped rows), 64 for a batch; the result of a row does not depend on the choice
+    if (M <= 32) launch_skinny_mt<2>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);
+    else launch_skinny_mt<4>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);
+    return true;
+}
 void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
                      float *out, __half *out_h, int ldo, hipStream_t s) {
     if (launch_gemm_big(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;
@@ -424,55 +513,6 @@ void launch_layernorm(const float *x, const float *w, const float *b, int rows, 
     hipLaunchKernelGGL(k_layernorm, dim3((unsigned)rows), dim3(256), 0, s, x, w, b, n, out, out_h);
 }
 
-// =====================================================================================================================
-// fp32 attention.  Workgroup = (head, tile of 16 queries); thread = (query, 1 of 16 key/dim lanes).
-// =====================================================================================================================
-template <int HD>
-__global__ __launch_bounds__(256) void k_attn_f32(const float *__restrict__ q, int ldq, const float *__restrict__ k, const float *__restrict__ v, int ldk, int nq, int nk,
-                                                  float q_prescale, float score_div, const Tables tb, float *__restrict__ out, __half *__restrict__ out_h, int ldo) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int LDK = HD + 1;
-    { const size_t z = blockIdx.z; q += z * nq * ldq; k += z * nk * ldk; v += z * nk * ldk; if (out) out += z * nq * ldo; if (out_h) out_h += z * nq * ldo; }   // image z of a batch
-    float *kv = reinterpret_cast<float *>(smem);            // [nk][HD+1]
-    const int nkp = (nk + 3) & ~3;
-    float *sc = kv + (size_t)nk * LDK;                        // [16][nkp]
-    const int h = blockIdx.x, q0 = blockIdx.y * 16, tid = threadIdx.x;
-    const int qi = tid >> 4, kl = tid & 15;
-    const int qrow = min(q0 + qi, nq - 1);
-    for (int e = tid; e < nk * HD; e += 256) { const int j = e / HD, i = e - j * HD; kv[j * LDK + i] = k[(size_t)j * ldk + h * HD + i]; }
-    float qv[HD];
-#pragma unroll
-    for (int i = 0; i < HD; i++) { float t = q[(size_t)qrow * ldq + h * HD + i]; if (q_prescale != 0.0f) t *= q_prescale; qv[i] = t; }
-    __syncthreads();
-    float mx = -INFINITY;
-    for (int j = kl; j < nk; j += 16) {
-        float s = 0.0f;
-#pragma unroll
-        for (int i = 0; i < HD; i++) s = fmaf(kv[j * LDK + i], qv[i], s);
-        if (score_div != 0.0f) s = s / score_div;
-        sc[qi * nkp + j] = s; mx = fmaxf(mx, s);
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    double sum = 0.0;
-    for (int j = kl; j < nk; j += 16) { const float e = tab_v(tb.exp, sc[qi * nkp + j] - mx); sc[qi * nkp + j] = e; sum += (double)e; }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    const float inv = (float)(1.0 / sum);
-    for (int j = kl; j < nk; j += 16) sc[qi * nkp + j] *= inv;
-    __syncthreads();
-    for (int e = tid; e < nk * HD; e += 256) { const int j = e / HD, i = e - j * HD; kv[j * LDK + i] = v[(size_t)j * ldk + h * HD + i]; }
-    __syncthreads();
-    if (q0 + qi < nq) {
-        for (int d = kl; d < HD; d += 16) {
-            float o = 0.0f;
-            for (int j = 0; j < nk; j++) o = fmaf(kv[j * LDK + d], sc[qi * nkp + j], o);
-            const size_t oo = (size_t)(q0 + qi) * ldo + h * HD + d;
-            if (out) out[oo] = o;
-            if (out_h) out_h[oo] = f2h_rn(o);
-        }
-    }
-}
 typedef float float4_t __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------------------------------
 // k_attn_vit -- fp32 attention without K / V staging (round 2; replaces the LDS-staged k_attn_mfma for nk <= 64 * TPW keys).
@@ -614,32 +654,23 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
     }
 }
 
-static int g_attn_mfma = 1;      // MINIGPT4_ATTN_MFMA=0: the v_fma / LDS kernel k_attn_f32 for every shape (tests, A/B)
-void set_attn_mfma(int v) { g_attn_mfma = v; }
+// ViT / BERT attention (fp32 scores and outputs on the exact-f32 matrix cores, k_attn_vit).  nk <= 320 keys (the reference's graphs have 257 or 32).
 void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale, float score_div,
                      const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s, int batch) {
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
-        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_f32<88>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_f32<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<88, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<64, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     if (hd != 88 && hd != 64) throw HipError{hipErrorInvalidValue, "attn_f32: head size must be 88 or 64", __FILE__, __LINE__};
-    if (g_attn_mfma && nk <= 320 && tb.exp_neg_n > 0 && tb.exp_neg_n % 2048 == 0) {   // k_attn_vit (measured: ViT-g encode 5.29 vs 5.90 ms with the LDS-staged round-1 kernel)
-        const size_t lds_v = 768 + (size_t)4 * ((hd + 15) / 16) * 4 * 64 * 4 + (size_t)tb.exp_neg_n * 2;
-        dim3 grid((unsigned)heads, (unsigned)((nq + 15) / 16), (unsigned)batch);
-        if (hd == 88) hipLaunchKernelGGL((k_attn_vit<88, 5>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
-        else if (nk <= 64) hipLaunchKernelGGL((k_attn_vit<64, 1>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
-        else hipLaunchKernelGGL((k_attn_vit<64, 5>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
-        return;
-    }
+    if (nk > 320 || tb.exp_neg_n <= 0 || tb.exp_neg_n % 2048) throw HipError{hipErrorInvalidValue, "attn_f32: more than 320 keys, or the exp table's LDS part is not set up", __FILE__, __LINE__};
+    const size_t lds_v = 768 + (size_t)4 * ((hd + 15) / 16) * 4 * 64 * 4 + (size_t)tb.exp_neg_n * 2;
     dim3 grid((unsigned)heads, (unsigned)((nq + 15) / 16), (unsigned)batch);
-    const size_t lds = ((size_t)nk * (hd + 1) + 16 * (size_t)((nk + 3) & ~3)) * 4;
-    if (hd == 88) hipLaunchKernelGGL((k_attn_f32<88>), grid, dim3(256), lds, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
-    else hipLaunchKernelGGL((k_attn_f32<64>), grid, dim3(256), lds, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
+    if (hd == 88) hipLaunchKernelGGL((k_attn_vit<88, 5>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
+    else if (nk <= 64) hipLaunchKernelGGL((k_attn_vit<64, 1>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
+    else hipLaunchKernelGGL((k_attn_vit<64, 5>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
 }
 
 // =====================================================================================================================

@@ -67,12 +67,45 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
+class _Symbols:
+    """Attribute access to the product library's symbols; a symbol the product does not export (kernel-level test hooks, micro-benchmarks, probes, host-only test helpers:
+    include/minigpt4_amd_test.h) is looked up in libminigpt4_test.so, which is loaded -- and has its prototypes declared -- on first use.  Only tests/ and tools/ ever get there."""
+
+    def __init__(self, product, test_path: str, declare_test):
+        self.__dict__.update(_product=product, _test_path=test_path, _declare_test=declare_test, _test=None)
+
+    def _hooks(self):
+        if self._test is None:
+            if not os.path.exists(self._test_path):
+                raise AttributeError(f"{self._test_path} not found (the test-hook build of the library: `make -C minigpt4.cpp_amd/csrc`)")
+            self.__dict__["_test"] = ctypes.cdll.LoadLibrary(self._test_path)
+            self._declare_test(self._test)
+        return self._test
+
+    def _last_error(self):
+        """thread-local error text of the product library and, once it is loaded, of the test-hook library (each has its own copy of the engine's state)."""
+        a = self._product.minigpt4_amd_last_error() or b""
+        b = (self._test.minigpt4_amd_last_error() or b"") if self._test is not None else b""
+        return a + (b" | " if a and b else b"") + b
+
+    def __getattr__(self, name):
+        if name == "minigpt4_amd_last_error":
+            return self._last_error
+        try:
+            return getattr(self._product, name)
+        except AttributeError:
+            return getattr(self._hooks(), name)
+
+
 class MiniGPT4SharedLibrary:
     """ctypes wrapper around libminigpt4.so (reference class of the same name)."""
 
-    def __init__(self, shared_library_path: str):
-        self.library = ctypes.cdll.LoadLibrary(shared_library_path)
-        L = self.library
+    def __init__(self, shared_library_path: str, test_library_path: Optional[str] = None):
+        product = ctypes.cdll.LoadLibrary(shared_library_path)
+        if test_library_path is None:
+            test_library_path = os.environ.get("MINIGPT4_TEST_LIBRARY", shared_library_path[:-3] + "_test.so" if shared_library_path.endswith(".so") else shared_library_path + "_test")
+        self.library = _Symbols(product, test_library_path, self._declare_test_hooks)
+        L = product
         P = ctypes.POINTER
         L.minigpt4_model_load.argtypes = [CHAR_PTR, CHAR_PTR, I32, I32, I32, I32, ctypes.c_bool]
         L.minigpt4_model_load.restype = VOID_PTR
@@ -119,6 +152,24 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_encode_images.argtypes = [VOID_PTR, P(MiniGPT4Images), P(MiniGPT4Embeddings), SIZE_T]
         L.minigpt4_free_embeddings.argtypes = [P(MiniGPT4Embeddings)]
         L.minigpt4_amd_weight_arena.argtypes = [VOID_PTR, I32, P(VOID_PTR), P(SIZE_T)]
+        U64P, SZP = P(ctypes.c_uint64), P(ctypes.c_size_t)
+        L.minigpt4_amd_plan_arenas.argtypes = [CHAR_PTR, CHAR_PTR, SZP, SZP, U64P, U64P]
+        L.minigpt4_amd_arena_plan.argtypes = [VOID_PTR, SZP, SZP, U64P, U64P]
+        L.minigpt4_amd_load_mode.argtypes = [VOID_PTR]
+        L.minigpt4_amd_weights_received.argtypes = [VOID_PTR]
+        L.minigpt4_amd_arena_checksum.argtypes = [VOID_PTR, I32, U64P]
+        L.minigpt4_amd_set_parity.argtypes = [VOID_PTR, I32]
+        L.minigpt4_amd_parity.argtypes = [VOID_PTR]
+        L.minigpt4_amd_set_conversations.argtypes = [VOID_PTR, I32]
+        L.minigpt4_amd_select_conversation.argtypes = [VOID_PTR, I32]
+        L.minigpt4_amd_n_conversations.argtypes = [VOID_PTR]
+        L.minigpt4_amd_end_chat_batch.argtypes = [VOID_PTR, INT_PTR, I32, P(ctypes.c_char_p), F32, I32, F32, F32, F32, I32, F32, F32]
+
+    @staticmethod
+    def _declare_test_hooks(L):
+        """Prototypes of libminigpt4_test.so's extra symbols (include/minigpt4_amd_test.h)."""
+        P = ctypes.POINTER
+        U64P = P(ctypes.c_uint64)
         L.minigpt4_amd_convert_q3k_q6k.argtypes = [VOID_PTR, VOID_PTR, ctypes.c_int64]
         L.minigpt4_amd_test_mul_mat.argtypes = [I32, VOID_PTR, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, ctypes.c_int64, FLOAT_PTR]
         L.minigpt4_amd_test_mul_mat_ref.argtypes = L.minigpt4_amd_test_mul_mat.argtypes
@@ -127,6 +178,8 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_test_matvec_rows.argtypes = [I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, I32, FLOAT_PTR, FLOAT_PTR]
         L.minigpt4_amd_test_quantize.argtypes = [FLOAT_PTR, FLOAT_PTR, ctypes.c_int64, ctypes.c_int64, VOID_PTR, VOID_PTR, VOID_PTR, VOID_PTR, VOID_PTR]
         L.minigpt4_amd_test_gemm_f16.argtypes = [FLOAT_PTR, FLOAT_PTR, FLOAT_PTR, I32, I32, I32, I32, FLOAT_PTR]
+        L.minigpt4_amd_test_gemm_f16_skinny.argtypes = L.minigpt4_amd_test_gemm_f16.argtypes
+        L.minigpt4_amd_last_error.restype = CHAR_PTR
         L.minigpt4_amd_vocab_load.argtypes = [CHAR_PTR]
         L.minigpt4_amd_vocab_load.restype = VOID_PTR
         L.minigpt4_amd_vocab_free.argtypes = [VOID_PTR]
@@ -139,19 +192,12 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_sample_logits.argtypes = [FLOAT_PTR, I32, I32, F32, I32, F32, F32, F32, I32, F32, F32]
         L.minigpt4_amd_decode_image.argtypes = [CHAR_PTR, SIZE_T, P(MiniGPT4Image)]
         L.minigpt4_amd_resample_coeffs.argtypes = [I32, I32, INT_PTR, INT_PTR, INT_PTR, INT_PTR, SIZE_T]
-        U64P, SZP = P(ctypes.c_uint64), P(ctypes.c_size_t)
-        L.minigpt4_amd_plan_arenas.argtypes = [CHAR_PTR, CHAR_PTR, SZP, SZP, U64P, U64P]
-        L.minigpt4_amd_arena_plan.argtypes = [VOID_PTR, SZP, SZP, U64P, U64P]
-        L.minigpt4_amd_load_mode.argtypes = [VOID_PTR]
-        L.minigpt4_amd_weights_received.argtypes = [VOID_PTR]
         L.minigpt4_amd_copy_arenas.argtypes = [VOID_PTR, VOID_PTR]
-        L.minigpt4_amd_arena_checksum.argtypes = [VOID_PTR, I32, U64P]
-        L.minigpt4_amd_set_parity.argtypes = [VOID_PTR, I32]
-        L.minigpt4_amd_parity.argtypes = [VOID_PTR]
-        L.minigpt4_amd_set_conversations.argtypes = [VOID_PTR, I32]
-        L.minigpt4_amd_select_conversation.argtypes = [VOID_PTR, I32]
-        L.minigpt4_amd_n_conversations.argtypes = [VOID_PTR]
-        L.minigpt4_amd_end_chat_batch.argtypes = [VOID_PTR, INT_PTR, I32, P(ctypes.c_char_p), F32, I32, F32, F32, F32, I32, F32, F32]
+        L.minigpt4_amd_llm_file_digest.argtypes = [CHAR_PTR, U64P, I32]
+        L.minigpt4_amd_quantize_chunk.argtypes = [I32, FLOAT_PTR, VOID_PTR, ctypes.c_int64]
+        L.minigpt4_amd_quantize_chunk.restype = ctypes.c_int64
+        L.minigpt4_amd_probe_valu.restype = F32
+        L.minigpt4_amd_probe_grid_barrier.restype = F32
 
     # ---------------------------------------------------------------- reference surface
     def panic_if_error(self, error_code: int) -> None:
@@ -391,15 +437,15 @@ class MiniGPT4SharedLibrary:
             raise RuntimeError(f"test_quantize rc={rc}")
         return q8k, dk, bs, q80, d0
 
-    def amd_test_gemm_f16(self, A: np.ndarray, W: np.ndarray, bias: Optional[np.ndarray] = None, gelu: bool = False) -> np.ndarray:
+    def amd_test_gemm_f16(self, A: np.ndarray, W: np.ndarray, bias: Optional[np.ndarray] = None, gelu: bool = False, skinny: bool = False) -> np.ndarray:
         A = np.ascontiguousarray(A, np.float32)
         W = np.ascontiguousarray(W, np.float32)
         M, K = A.shape
         N = W.shape[0]
         C = np.empty((M, N), np.float32)
         b = None if bias is None else np.ascontiguousarray(bias, np.float32)
-        rc = self.library.minigpt4_amd_test_gemm_f16(A.ctypes.data_as(FLOAT_PTR), W.ctypes.data_as(FLOAT_PTR), None if b is None else b.ctypes.data_as(FLOAT_PTR),
-                                                     M, N, K, int(gelu), C.ctypes.data_as(FLOAT_PTR))
+        fn = self.library.minigpt4_amd_test_gemm_f16_skinny if skinny else self.library.minigpt4_amd_test_gemm_f16
+        rc = fn(A.ctypes.data_as(FLOAT_PTR), W.ctypes.data_as(FLOAT_PTR), None if b is None else b.ctypes.data_as(FLOAT_PTR), M, N, K, int(gelu), C.ctypes.data_as(FLOAT_PTR))
         if rc:
             raise RuntimeError(f"test_gemm_f16 rc={rc}")
         return C

@@ -517,3 +517,27 @@ def test_key_split_decode_attention_matches_the_single_workgroup_kernel_and_the_
     for step, tid in enumerate(runs["48"][0][:60]):               # the oracle along the same greedy path
         assert int(ow.argmax()) == tid, step
         ow = o.eval_tokens([tid])
+
+
+@pytest.mark.parametrize("shape", [(32, 768, 768), (32, 768, 2304), (32, 3072, 768), (32, 768, 3072), (32, 768, 5120), (64, 768, 768), (96, 768, 2304), (256, 3072, 768), (1, 64, 16),
+                                   (33, 96, 48), (17, 768, 4096)])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_gemm_f16_skinny_kernel(gpu_lib, shape, gelu):
+    """k_gemm_f16_skinny (the Q-Former's GEMMs: few rows, N / 16 workgroups, K split across the four waves) against a float64 product of the fp16-rounded operands, and
+    against the 64x64-tile kernel (same exact products, another fp32 order)."""
+    import refcpu as R
+    M, K, N = shape
+    rng = np.random.default_rng(M * 11 + K + N)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (0.1 * rng.standard_normal((N, K))).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    got = gpu_lib.amd_test_gemm_f16(A, W, b, gelu, skinny=True)
+    ref = A.astype(np.float16).astype(np.float64) @ W.astype(np.float16).astype(np.float64).T + b
+    if gelu:
+        tab = R.table(0).view(np.float16)
+        ref32 = (A.astype(np.float16).astype(np.float64) @ W.astype(np.float16).astype(np.float64).T).astype(np.float32) + b
+        want = tab[ref32.astype(np.float16).view(np.uint16)].astype(np.float32)
+        assert (np.abs(got - want) > 2e-3 * (1 + np.abs(want))).mean() < 2e-3
+    else:
+        assert _rel(got, ref) < 2e-5
+        assert _rel(got, gpu_lib.amd_test_gemm_f16(A, W, b, gelu)) < 2e-5
