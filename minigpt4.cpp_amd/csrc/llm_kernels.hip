@@ -2097,8 +2097,166 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float *__restrict__ 
             }
         }
 }
+// The same on the fp16 matrix cores (round 3): every operand of both products IS an fp16 value in the reference (K / V cache rows, q rounded to fp16 by ggml's f16 x f32
+// mul_mat, probabilities rounded to fp16 before P.V), so v_mfma_f32_16x16x32_f16 multiplies them exactly and accumulates in fp32 -- 16x the rate of the f32 MFMA above and
+// no fp16 -> fp32 staging pass.  K tiles go to LDS as they are (16-byte chunks XOR-swizzled by the key index: conflict-free fragment reads); V tiles are written
+// TRANSPOSED ([dim][key], 70-half rows) so that a lane's 8 consecutive keys of one dim are contiguous.  Softmax as above.  fp32 accumulation order inside the MFMA differs
+// from the sequential chain of k_attn_llm / the oracle (fp32 rounding only; MINIGPT4_PARITY uses k_attn_ref).
+typedef _Float16 aph8_t __attribute__((ext_vector_type(8)));
+constexpr int APH_LDT = 70;
+template <int HD, int QS>
+__global__ __launch_bounds__(256) void k_attn_prefill_h(const float *__restrict__ q, const __half *__restrict__ kc, const __half *__restrict__ vc, int E, int N, const int *__restrict__ n_past,
+                                                        const Tables tb, float *__restrict__ out, int LS) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_aph[];
+    constexpr int C8 = HD / 8, QT = AP_QT * QS, KSQ = HD / 32, DT = HD / 16, PER = AP_KT * C8 / 256;
+    static_assert(PER >= 1 && (DT % 4 == 0 || DT == 2), "tile geometry");
+    float *S = reinterpret_cast<float *>(smem_aph);               // [QT][LS], LS = 4 mod 64
+    __half *Kt = reinterpret_cast<__half *>(S + (size_t)QT * LS); // [64][HD], chunk c of row j at slot c ^ (j & (C8 - 1))
+    __half *Vt = Kt + AP_KT * HD;                                 // [HD][APH_LDT]
+    const int h = blockIdx.x, q0 = blockIdx.y * QT, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int np = *n_past;
+    const int T = np + min(q0 + QT - 1, N - 1) + 1;               // keys the last query of this tile sees
+    const int nkt = (T + AP_KT - 1) / AP_KT;
+    const float scale = 1.0f / sqrtf((float)HD);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    aph8_t qf[QS][KSQ];                                           // A fragments: query l15, dims 32 ks + 8 l4 .. + 7, rounded to fp16
+#pragma unroll
+    for (int qs = 0; qs < QS; qs++) {
+        const float *qp = q + (size_t)min(q0 + 16 * qs + l15, N - 1) * E + (size_t)h * HD + 8 * l4;
+#pragma unroll
+        for (int ks = 0; ks < KSQ; ks++) {
+            const float4 a = *reinterpret_cast<const float4 *>(qp + 32 * ks), b = *reinterpret_cast<const float4 *>(qp + 32 * ks + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int e = 0; e < 8; e++) qf[qs][ks][e] = (_Float16)__half2float(f2h_rn(v[e]));
+        }
+    }
+    for (int kt = 0; kt < nkt; kt++) {
+        __syncthreads();
+        {
+            int4 x[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) { const int e = tid + 256 * u, j = e / C8, c = e - j * C8; x[u] = ld16(kc + (size_t)min(kt * AP_KT + j, T - 1) * E + (size_t)h * HD + 8 * c); }
+#pragma unroll
+            for (int u = 0; u < PER; u++) { const int e = tid + 256 * u, j = e / C8, c = e - j * C8; *reinterpret_cast<int4 *>(Kt + j * HD + ((c ^ (j & (C8 - 1))) << 3)) = x[u]; }
+        }
+        __syncthreads();
+        const int key0 = kt * AP_KT + 16 * wave;
+        if (key0 < T) {
+            const int row = 16 * wave + l15;
+            pf4_t acc[QS];
+#pragma unroll
+            for (int qs = 0; qs < QS; qs++) acc[qs] = pf4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ks = 0; ks < KSQ; ks++) {
+                const aph8_t kf = *reinterpret_cast<const aph8_t *>(Kt + row * HD + (((4 * ks + l4) ^ (row & (C8 - 1))) << 3));
+#pragma unroll
+                for (int qs = 0; qs < QS; qs++) acc[qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[qs][ks], kf, acc[qs], 0, 0, 0);
+            }
+#pragma unroll
+            for (int qs = 0; qs < QS; qs++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) S[(size_t)(16 * qs + l4 * 4 + r) * LS + key0 + l15] = acc[qs][r] * scale;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qs = 0; qs < QS; qs++) {   // softmax: 16 lanes per query row; row r sees keys 0 .. np + q0 + r  (k_attn_prefill's code)
+        const int row = 16 * qs + (tid >> 4), sub = tid & 15;
+        const int Tq = min(np + q0 + row + 1, T);
+        float *sr = S + (size_t)row * LS;
+        float mx = -INFINITY;
+        for (int j = sub; j < Tq; j += 16) mx = fmaxf(mx, sr[j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 8));
+        double sum = 0.0;
+        for (int j0 = sub; j0 < Tq; j0 += 64) {
+            float e[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = tab(tb.exp, sr[min(j0 + 16 * u, Tq - 1)] - mx);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int j = j0 + 16 * u; if (j < Tq) { sr[j] = e[u]; sum += (double)e[u]; } }
+        }
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+        const float inv = (float)(1.0 / sum);
+        for (int j = sub; j < nkt * AP_KT; j += 16) sr[j] = j < Tq ? f16r(sr[j] * inv) : 0.0f;
+    }
+    constexpr int DPW = (DT + 3) / 4;
+    pf4_t oacc[QS][DPW];
+#pragma unroll
+    for (int qs = 0; qs < QS; qs++)
+#pragma unroll
+        for (int i = 0; i < DPW; i++) oacc[qs][i] = pf4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int kt = 0; kt < nkt; kt++) {
+        __syncthreads();
+        {
+            int4 x[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) { const int e = tid + 256 * u, j = e / C8, c = e - j * C8; x[u] = ld16(vc + (size_t)min(kt * AP_KT + j, T - 1) * E + (size_t)h * HD + 8 * c); }
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int e = tid + 256 * u, j = e / C8, c = e - j * C8;
+                const bool live = kt * AP_KT + j < T;
+                const unsigned w[4] = {(unsigned)x[u].x, (unsigned)x[u].y, (unsigned)x[u].z, (unsigned)x[u].w};
+                unsigned short *d = reinterpret_cast<unsigned short *>(Vt) + (8 * c) * APH_LDT + j;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { d[(2 * i) * APH_LDT] = live ? (unsigned short)(w[i] & 0xFFFF) : (unsigned short)0; d[(2 * i + 1) * APH_LDT] = live ? (unsigned short)(w[i] >> 16) : (unsigned short)0; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < DPW; i++) {
+            const int dt = wave + 4 * i;
+            if (dt < DT) {
+#pragma unroll
+                for (int k2 = 0; k2 < AP_KT / 32; k2++) {
+                    const unsigned *vp = reinterpret_cast<const unsigned *>(Vt + (16 * dt + l15) * APH_LDT + 32 * k2 + 8 * l4);   // 4-byte aligned: 140-byte rows
+                    union { unsigned u[4]; aph8_t v; } vb;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) vb.u[e] = vp[e];
+#pragma unroll
+                    for (int qs = 0; qs < QS; qs++) {
+                        const float *pp = S + (size_t)(16 * qs + l15) * LS + kt * AP_KT + 32 * k2 + 8 * l4;
+                        const float4 a = *reinterpret_cast<const float4 *>(pp), b = *reinterpret_cast<const float4 *>(pp + 4);
+                        aph8_t pf;
+                        pf[0] = (_Float16)a.x; pf[1] = (_Float16)a.y; pf[2] = (_Float16)a.z; pf[3] = (_Float16)a.w; pf[4] = (_Float16)b.x; pf[5] = (_Float16)b.y; pf[6] = (_Float16)b.z; pf[7] = (_Float16)b.w;
+                        oacc[qs][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vb.v, oacc[qs][i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int qs = 0; qs < QS; qs++)
+#pragma unroll
+        for (int i = 0; i < DPW; i++) {
+            const int dt = wave + 4 * i;
+            if (dt < DT) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int qrow = q0 + 16 * qs + l4 * 4 + r;
+                    if (qrow < N) out[(size_t)qrow * E + (size_t)h * HD + dt * 16 + l15] = oacc[qs][i][r];
+                }
+            }
+        }
+}
+static int g_attn_prefill_f16 = 1;   // 1: prompt attention on the fp16 matrix cores (k_attn_prefill_h), 0: the exact-f32 MFMA kernel (k_attn_prefill); MINIGPT4_ATTN_PREFILL_F16, read by Engine::init
+void set_attn_prefill_f16(int v) { g_attn_prefill_f16 = v != 0; }
+template <int HD, int QS>
+static bool launch_attn_prefill_h_qs(const float *q, const __half *kc, const __half *vc, int N, int n_head, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
+    const int LS = ((t_max + AP_KT - 1) / AP_KT) * AP_KT + 4;
+    static bool attr = false;
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill_h<HD, QS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    const size_t lds = (size_t)AP_QT * QS * LS * 4 + (size_t)AP_KT * HD * 2 + (size_t)HD * APH_LDT * 2;
+    if (lds > 160 * 1024 - 512) return false;
+    hipLaunchKernelGGL((k_attn_prefill_h<HD, QS>), dim3((unsigned)n_head, (unsigned)((N + AP_QT * QS - 1) / (AP_QT * QS))), dim3(256), lds, s, q, kc, vc, n_head * HD, N, n_past, tb, out, LS);
+    return true;
+}
 template <int HD>
 static bool launch_attn_prefill_hd(const float *q, const __half *kc, const __half *vc, int N, int n_head, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
+    if (g_attn_prefill_f16) {   // 32 queries per staged K / V tile once that still gives every CU a workgroup
+        if (n_head * ((N + 31) / 32) >= 256 && launch_attn_prefill_h_qs<HD, 2>(q, kc, vc, N, n_head, n_past, t_max, tb, out, s)) return true;
+        if (launch_attn_prefill_h_qs<HD, 1>(q, kc, vc, N, n_head, n_past, t_max, tb, out, s)) return true;
+    }
     const int LS = ((t_max + AP_KT - 1) / AP_KT) * AP_KT + 1;
     static bool attr = false;
     if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill<HD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }

@@ -314,7 +314,7 @@ bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n
 // does not depend on M, so a batched encode still equals the single-image encode bit for bit.
 // =====================================================================================================================
 typedef float float4v_t __attribute__((ext_vector_type(4)));
-constexpr int SK_WAVES = 8;                                       // waves per workgroup = K slices (fixed: the order of additions per output element must not depend on M)
+constexpr int SK_WAVES = 4;                                       // waves per workgroup = K slices (fixed: the order of additions per output element must not depend on M)
 template <int MT, bool GELU, bool RES>
 __global__ __launch_bounds__(64 * SK_WAVES) void k_gemm_f16_skinny(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K,
                                                                    const float *__restrict__ bias, const float *residual, const Tables tb, float *out, __half *__restrict__ out_h, int ldo) {
