@@ -3,6 +3,7 @@
 #include "imageio.hpp"
 
 #include <algorithm>
+#include <optional>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -518,10 +519,10 @@ void Engine::site_begin(const char *site, double bytes, hipStream_t s) {
     HIP_CHECK(hipEventRecord(ev.a, s));
     site_events_.push_back(ev);
 }
-void Engine::site_end(hipStream_t s) {
+void Engine::site_end(hipStream_t s) noexcept {   // called from SiteScope's destructor: must not throw (a failed record marks the site invalid instead)
     if (!prof_on_ || site_events_.empty()) return;
     SiteEv &ev = site_events_.back();
-    HIP_CHECK(hipEventRecord(ev.b, s));
+    if (hipEventRecord(ev.b, s) != hipSuccess) { (void)hipGetLastError(); ev.bytes = -1.0; }
     ev.kernel = last_kernel_name();
     ev.p1 = launch_probe_count();
 }
@@ -572,9 +573,9 @@ void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *re
 bool Engine::mixed_qkv(const LayerW &L, hipStream_t s, bool fuse) {
     if (!use_v2_) return false;
     const int E = (int)llm_.n_embd;
-    SiteScope sc(this, "qkv", (double)(L.wq.bytes + L.wk.bytes + L.wv.bytes), s);
     const QWeight *W1[2] = {&L.wq, &L.wk}, *W2[1] = {&L.wv}; float *Y1[2] = {q_, k_}, *Y2[1] = {v_};
     if (act_mask_for(L.wq.type) != ACT_Q8K || act_mask_for(L.wv.type) != ACT_Q8K) return false;
+    SiteScope sc(this, "qkv", (double)(L.wq.bytes + L.wk.bytes + L.wv.bytes), s);   // only once the launch is certain: a refused shape must not record an empty site
     if (fuse && matvec_prologue_supported(L.wq.type, E)) { if (launch_matvec_mixed(W1, Y1, 2, W2, Y2, 1, act_, s, 1, x_, L.attn_norm)) return true; }
     // standalone preparation, then the mixed launch; if that is refused the caller's per-type launches find the row already prepared
     launch_rms_quant(x_, L.attn_norm, 1, E, act_, ACT_Q8K, s);
@@ -668,7 +669,8 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
             } else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s, &p_attn, fz(0), false, "qk"); mul_mat(L.wv, N, v_, E, nullptr, s, &p_attn, fz(0), "v"); }
         }
         // algorithmic bytes of the attention site: the cached fp16 K and V rows of every head up to the current position
-        SiteScope *att_sc = prof_on_ ? new SiteScope(this, "attention", 4.0 * (double)E * (double)(conv_[sl].n_committed + N), s) : nullptr;
+        std::optional<SiteScope> att_sc;
+        if (prof_on_) att_sc.emplace(this, "attention", 4.0 * (double)E * (double)(conv_[sl].n_committed + N), s);
         if (dec && attn_split_now_) launch_attn_llm_split(q_, k_, v_, kc, vc, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, attn_ws_, attn_splits_, s);
         else if (dec) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, true, s);
         else {
@@ -676,7 +678,7 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
             if (!(attn_prefill_ && launch_attn_prefill(q_, kc, vc, N, H, hd, d_npast, conv_[sl].n_committed + N, tabs_, att_, s)))
                 launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, false, s);
         }
-        delete att_sc;
+        att_sc.reset();
         mul_mat(L.wo, N, x_, E, x_, s, &p_att, fz(1), "wo");
         bool paired = false;   // h1_ already holds silu(w1 x) * (w3 x)
         if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5), "w1w3"); }
@@ -720,11 +722,15 @@ void Engine::forward_batch(int B, hipStream_t s) {
                 float *yo[3]; const float *ro[3];
                 for (int k = 0; k < n; k++) { yo[k] = y[k] + (size_t)t0 * ld; ro[k] = r[k] ? r[k] + (size_t)t0 * ld : nullptr; }
                 ok = launch_matvec_rows(W, yo, res0 ? ro : nullptr, n, A, std::min(4, B - t0), ld, s, px ? px + (size_t)t0 * K : nullptr, pw, K);
-                if (!ok && (t0 || px)) throw HipError{hipErrorInvalidValue, "multi-row mat-vec refused a pass it had accepted", __FILE__, __LINE__};
+                if (!ok && t0) throw HipError{hipErrorInvalidValue, "multi-row mat-vec refused a pass it had accepted", __FILE__, __LINE__};
             }
             if (ok) return;
         }
-        if (px) throw HipError{hipErrorInvalidValue, "multi-row mat-vec: prologue requested outside its range", __FILE__, __LINE__};
+        if (px) {   // the launch that was to prepare its rows itself was refused (plane spacing, LDS): a performance choice must not fail the step -- prepare them standalone
+            const int K = W[0]->cols; int mask = 0;
+            for (int k = 0; k < n; k++) mask |= act_mask_for(W[k]->type);
+            if (pw) launch_rms_quant(px, pw, B, K, act_, mask, s); else launch_silu_mul_quant(px, nullptr, B, K, act_, mask, tabs_, s);
+        }
         for (int k = 0; k < n; k++) launch_mul_mat(*W[k], act_, B, y[k], ld, r[k], s);
     };
     // may the rows of this set be prepared inside its launch?  (same conditions mm() takes the multi-row kernel under)

@@ -163,7 +163,7 @@ private:
     struct SiteEv { hipEvent_t a, b; const char *site; std::string kernel; double bytes; size_t p0 = 0, p1 = 0; };   // [p0, p1): the launch probes of the site
     std::vector<SiteEv> site_events_;
     void site_begin(const char *site, double bytes, hipStream_t s);
-    void site_end(hipStream_t s);
+    void site_end(hipStream_t s) noexcept;
     struct SiteScope { Engine *e; hipStream_t s; SiteScope(Engine *e_, const char *site, double bytes, hipStream_t s_) : e(e_), s(s_) { e->site_begin(site, bytes, s); } ~SiteScope() { e->site_end(s); } };
 
     // vision

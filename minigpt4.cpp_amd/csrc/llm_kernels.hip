@@ -2384,13 +2384,13 @@ __global__ __launch_bounds__(256) void k_checksum(const unsigned *__restrict__ p
     if ((threadIdx.x & 63) == 0) atomicAdd(out, s);                      // integer sum: order does not matter
 }
 uint64_t device_checksum(const void *p, size_t bytes, hipStream_t s) {
-    unsigned long long *d = nullptr, h = 0;
-    HIP_CHECK(hipMalloc((void **)&d, 8));
-    HIP_CHECK(hipMemsetAsync(d, 0, 8, s));
-    hipLaunchKernelGGL(k_checksum, dim3(2048), dim3(256), 0, s, static_cast<const unsigned *>(p), bytes / 4, d);
-    HIP_CHECK(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, s));
+    struct Word { unsigned long long *d = nullptr; ~Word() { if (d) HIP_IGNORE(hipFree(d)); } } w;   // freed on every path, also when a check below throws
+    unsigned long long h = 0;
+    HIP_CHECK(hipMalloc((void **)&w.d, 8));
+    HIP_CHECK(hipMemsetAsync(w.d, 0, 8, s));
+    hipLaunchKernelGGL(k_checksum, dim3(2048), dim3(256), 0, s, static_cast<const unsigned *>(p), bytes / 4, w.d);
+    HIP_CHECK(hipMemcpyAsync(&h, w.d, 8, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
-    HIP_IGNORE(hipFree(d));
     return (uint64_t)h;
 }
 __global__ void k_fill_u16(unsigned short *p, size_t n, unsigned short v) {
