@@ -1043,6 +1043,7 @@ int Engine::decode_batch(const int *slots, int n, const SampleParams &p, int *id
 int Engine::encode_images(const float *const *chw, int B, float *const *out) {
     if (B < 1 || B > VISION_BATCH_MAX) { set_last_error("encode_images: batch size out of range"); return E_ImageSize; }
     if (weights_missing()) return E_LoadModelFileHeader;
+    if (parity_) return encode_images_ref(chw, B, out);                    // MINIGPT4_PARITY: the oracle's accumulation order, image embedding bit-identical to oracle/refcpu.c
     if (v_generic_) return encode_images_generic(chw, B, out);
     hipStream_t s = stream_;
     const int D = v_D_, M = v_M_, NQ = v_nq_, H = 768;

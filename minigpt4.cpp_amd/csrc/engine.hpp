@@ -198,6 +198,8 @@ private:
     int load_vision_generic();
     void alloc_vision_generic();
     int encode_images_generic(const float *const *chw, int B, float *const *out);
+    int encode_images_ref(const float *const *chw, int B, float *const *out);   // parity mode (engine_vision_generic.cpp)
+    void build_vision_views();
     void glinear(const GLin &L, const float *x, int rows, const float *bias, bool gelu, const float *residual, float *out, hipStream_t s);
 };
 

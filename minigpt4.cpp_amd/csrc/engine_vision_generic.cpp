@@ -164,4 +164,108 @@ int Engine::encode_images_generic(const float *const *chw, int B, float *const *
     return E_None;
 }
 
+// ====================================================================================================================
+// MINIGPT4_PARITY image path: the generic graph above with every fp32 accumulation in the CPU oracle's order (oracle/refcpu.c orc_vision_encode) -- Linear = activation
+// conversion + k_mul_mat_ref (one sequential chain per output: ggml_vec_dot_f16 / the block dots of a quantised file) + the bias / GELU / residual epilogue, LayerNorm with
+// its two sums added in element order, attention through k_attn_vref.  Works for F16 files (the Linears are viewed as F16 QWeights in place: nothing is copied) and for
+// the quantised / F32 files of the generic path.  The image embedding equals the oracle's bit for bit (tests/test_gpu_paritymode.py); slow by design.
+// ====================================================================================================================
+void Engine::build_vision_views() {
+    if (v_generic_ || !gblocks_.empty()) return;                           // generic files already carry QWeights
+    auto view = [](const __half *p, int n_in, int n_out) { GLin L; L.w.type = GT_F16; L.w.rows = n_out; L.w.cols = n_in; L.w.qs = reinterpret_cast<const uint8_t *>(p); L.w.bytes = (size_t)n_in * n_out * 2; return L; };
+    const int D = v_D_, M = v_M_, H = 768;
+    gblocks_.assign(vblocks_.size(), GBlock{});
+    for (size_t i = 0; i < vblocks_.size(); i++) {
+        const VBlock &b = vblocks_[i];
+        gblocks_[i].qkv = view(b.qkv_w, D, 3 * D); gblocks_[i].proj = view(b.proj_w, D, D); gblocks_[i].fc1 = view(b.fc1_w, D, M); gblocks_[i].fc2 = view(b.fc2_w, M, D);
+    }
+    gql_.assign(qlayers_.size(), GQLayer{});
+    for (size_t i = 0; i < qlayers_.size(); i++) {
+        const QLayer &L = qlayers_[i]; GQLayer &G = gql_[i];
+        G.self.q = view(L.self.q_w, H, H); G.self.k = view(L.self.q_w + (size_t)H * H, H, H); G.self.v = view(L.self.q_w + (size_t)2 * H * H, H, H);   // stored as one [2304][768] matrix
+        G.self.dense = view(L.self.dense_w, H, H);
+        if (L.has_cross) {
+            G.cross.q = view(L.cross.q_w, H, H); G.cross.k = view(L.cross.kv_w, D, H); G.cross.v = view(L.cross.kv_w + (size_t)H * D, D, H);            // [1536][D]
+            G.cross.dense = view(L.cross.dense_w, H, H);
+        }
+        G.inter = view(L.inter_w, H, v_qi_); G.out = view(L.out_w, v_qi_, H);
+    }
+    gproj_ = view(v_proj_w_, H, v_out_);
+}
+
+int Engine::encode_images_ref(const float *const *chw, int B, float *const *out) {
+    hipStream_t s = stream_;
+    build_vision_views();
+    if (!vg_ln_) alloc_vision_generic();                                   // fp32 activation buffers + the activation planes of the generic path
+    const int D = v_D_, NQ = v_nq_, H = 768;
+    const int R = B * 257, RQ = B * NQ;
+    auto rlinear = [&](const GLin &L, const float *x, int rows, const float *bias, bool gelu, const float *residual, float *o) {
+        launch_rms_quant(x, nullptr, rows, L.w.cols, vact_, act_mask_for(L.w.type), s);
+        launch_mul_mat_ref(L.w, vact_, rows, vg_tmp_, L.w.rows, nullptr, s);
+        launch_lin_epilogue(vg_tmp_, bias, residual, gelu, tabs_, rows, L.w.rows, o, nullptr, s);
+    };
+    hipEvent_t ea, eb; HIP_CHECK(hipEventCreate(&ea)); HIP_CHECK(hipEventCreate(&eb));
+    for (int b = 0; b < B; b++) HIP_CHECK(hipMemcpyAsync(vi_img_ + (size_t)b * 3 * 224 * 224, chw[b], 3 * 224 * 224 * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipEventRecord(ea, s));
+    // patch embedding: fp16 im2col rows x the F16 conv kernel ([D][592], columns 588.. are zero on both sides), one sequential chain per output, + bias
+    launch_im2col(vi_img_, vi_patches_, 592, s, B);
+    {
+        QWeight Wp; Wp.type = GT_F16; Wp.rows = D; Wp.cols = 592; Wp.qs = reinterpret_cast<const uint8_t *>(v_patch_w_); Wp.bytes = (size_t)D * 592 * 2;
+        ActQ Ap{}; Ap.xh = vi_patches_;
+        launch_mul_mat_ref(Wp, Ap, B * 256, vi_pe_, D, nullptr, s);
+        launch_lin_epilogue(vi_pe_, v_patch_b_, nullptr, false, tabs_, B * 256, D, vi_pe_, nullptr, s);
+    }
+    launch_assemble_embeddings(v_cls_, vi_pe_, v_pos_, D, vi_x_, s, B);
+    const float scale = 1.0f / sqrtf(88.0f);
+    for (size_t ib = 0; ib < vblocks_.size(); ib++) {
+        const VBlock &b = vblocks_[ib]; const GBlock &g = gblocks_[ib];
+        launch_layernorm(vi_x_, b.n1w, b.n1b, R, D, vg_ln_, nullptr, s, true);
+        rlinear(g.qkv, vg_ln_, R, b.qkv_b, false, nullptr, vi_qkv_);
+        launch_attn_vref(vi_qkv_, 3 * D, vi_qkv_ + D, vi_qkv_ + 2 * D, 3 * D, 257, 257, v_heads_, 88, scale, 0.0f, tabs_, vg_att_, D, s, B);
+        rlinear(g.proj, vg_att_, R, b.proj_b, false, vi_x_, vi_x_);
+        launch_layernorm(vi_x_, b.n2w, b.n2b, R, D, vg_ln_, nullptr, s, true);
+        rlinear(g.fc1, vg_ln_, R, b.fc1_b, true, nullptr, vg_mlp_);
+        rlinear(g.fc2, vg_mlp_, R, b.fc2_b, false, vi_x_, vi_x_);
+    }
+    launch_layernorm(vi_x_, v_lnv_w_, v_lnv_b_, R, D, vg_img_, nullptr, s, true);
+    launch_layernorm(vi_qtok_rep_, v_qeln_w_, v_qeln_b_, RQ, H, vi_hs_, nullptr, s, true);
+    for (size_t il = 0; il < qlayers_.size(); il++) {
+        const QLayer &L = qlayers_[il]; const GQLayer &G = gql_[il];
+        {   // self attention: q | k | v side by side ([RQ][3H]), each its own Linear as in the reference graph
+            const GLin *qkv[3] = {&G.self.q, &G.self.k, &G.self.v};
+            for (int j = 0; j < 3; j++) {
+                rlinear(*qkv[j], vi_hs_, RQ, L.self.q_b + (size_t)j * H, false, nullptr, vg_tmp_);
+                HIP_CHECK(hipMemcpy2DAsync(vi_qq_ + (size_t)j * H, (size_t)3 * H * 4, vg_tmp_, (size_t)H * 4, (size_t)H * 4, (size_t)RQ, hipMemcpyDeviceToDevice, s));
+            }
+        }
+        launch_attn_vref(vi_qq_, 3 * H, vi_qq_ + H, vi_qq_ + 2 * H, 3 * H, NQ, NQ, 12, 64, 0.0f, 8.0f, tabs_, vg_ctx_, H, s, B);
+        rlinear(G.self.dense, vg_ctx_, RQ, L.self.dense_b, false, vi_hs_, vi_d_);
+        launch_layernorm(vi_d_, L.self.ln_w, L.self.ln_b, RQ, H, vi_a1_, nullptr, s, true);
+        const float *ao = vi_a1_;
+        if (L.has_cross) {
+            rlinear(G.cross.q, vi_a1_, RQ, L.cross.q_b, false, nullptr, vi_qq_);
+            const GLin *kv[2] = {&G.cross.k, &G.cross.v};
+            for (int j = 0; j < 2; j++) {
+                rlinear(*kv[j], vg_img_, R, L.cross.kv_b + (size_t)j * H, false, nullptr, vg_tmp_);
+                HIP_CHECK(hipMemcpy2DAsync(vi_kv_ + (size_t)j * H, (size_t)2 * H * 4, vg_tmp_, (size_t)H * 4, (size_t)H * 4, (size_t)R, hipMemcpyDeviceToDevice, s));
+            }
+            launch_attn_vref(vi_qq_, H, vi_kv_, vi_kv_ + H, 2 * H, NQ, 257, 12, 64, 0.0f, 8.0f, tabs_, vg_ctx_, H, s, B);
+            rlinear(G.cross.dense, vg_ctx_, RQ, L.cross.dense_b, false, vi_a1_, vi_d_);
+            launch_layernorm(vi_d_, L.cross.ln_w, L.cross.ln_b, RQ, H, vi_a2_, nullptr, s, true);
+            ao = vi_a2_;
+        }
+        rlinear(G.inter, ao, RQ, L.inter_b, true, nullptr, vg_im_);
+        rlinear(G.out, vg_im_, RQ, L.out_b, false, ao, vi_d_);
+        launch_layernorm(vi_d_, L.oln_w, L.oln_b, RQ, H, vi_hs_, nullptr, s, true);
+    }
+    rlinear(gproj_, vi_hs_, RQ, v_proj_b_, false, nullptr, vi_out_);
+    HIP_CHECK(hipEventRecord(eb, s));
+    for (int b = 0; b < B; b++) HIP_CHECK(hipMemcpyAsync(out[b], vi_out_ + (size_t)b * NQ * v_out_, (size_t)NQ * v_out_ * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipEventElapsedTime(&last_encode_ms_, ea, eb));
+    HIP_IGNORE(hipEventDestroy(ea)); HIP_IGNORE(hipEventDestroy(eb));
+    return E_None;
+}
+
 }  // namespace mg4

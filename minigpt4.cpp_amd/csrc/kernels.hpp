@@ -124,7 +124,10 @@ bool launch_gemm_f16_skinny(const __half *A, int lda, const __half *W, int ldw, 
                             float *out, __half *out_h, int ldo, hipStream_t s);
 void launch_lin_epilogue(const float *y, const float *bias, const float *residual, bool gelu, const Tables &tb, int rows, int n, float *out, __half *out_h, hipStream_t s);
 // LayerNorm (ggml_norm eps 1e-5, then w*x+b); rows x n; writes fp32 (nullable) and fp16 (nullable).
-void launch_layernorm(const float *x, const float *w, const float *b, int rows, int n, float *out, __half *out_h, hipStream_t s);
+void launch_layernorm(const float *x, const float *w, const float *b, int rows, int n, float *out, __half *out_h, hipStream_t s, bool sequential_sums = false);   // sequential_sums: MINIGPT4_PARITY
+// MINIGPT4_PARITY: ViT / BERT attention with every fp32 chain in the oracle's order (fp32 output); same argument meaning as launch_attn_f32
+void launch_attn_vref(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale, float score_div, const Tables &tb,
+                      float *out, int ldo, hipStream_t s, int batch = 1);
 // split-K GEMM (raw fp32 partial sums into `slices` slabs) + the deterministic reduce fused with bias / residual / the following LayerNorm
 int gemm_split_slices(int K, int want);   // slices actually used for a K (whole 128-wide k tiles per slice)
 void launch_gemm_f16_splitk(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, int slices, float *slabs, size_t slab_stride, int ldo, hipStream_t s);

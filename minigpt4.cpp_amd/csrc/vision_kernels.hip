@@ -481,7 +481,7 @@ void launch_splitk_reduce_ln(const float *slabs, int n_slabs, size_t slab_stride
 }
 
 __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b, int n, float *__restrict__ out,
-                                                   __half *__restrict__ out_h) {
+                                                   __half *__restrict__ out_h, int seq) {
     __shared__ double red[4];
     const size_t row = blockIdx.x;
     const float *xr = x + row * n;
@@ -490,11 +490,23 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
     double s = 0.0;
 #pragma unroll
     for (int e = 0; e < MAXE; e++) { const int i = threadIdx.x + 256 * e; xv[e] = i < n ? xr[i] : 0.0f; s += (double)xv[e]; }
-    const float mean = (float)(block_sum_d(s, red) / (double)n);
+    float mean, variance;
+    if (seq) {   // MINIGPT4_PARITY: ggml_norm's two loops literally -- one double accumulator each, element order (oracle/refcpu.c layer_norm)
+        if (threadIdx.x == 0) {
+            double a = 0.0; for (int i = 0; i < n; i++) a += (double)xr[i];
+            const float m = (float)(a / (double)n);
+            double a2 = 0.0; for (int i = 0; i < n; i++) { const float v = xr[i] - m; a2 += (double)(v * v); }
+            red[0] = (double)m; red[1] = a2;
+        }
+        __syncthreads();
+        mean = (float)red[0]; variance = (float)(red[1] / (double)n);
+    } else {
+    mean = (float)(block_sum_d(s, red) / (double)n);
     double s2 = 0.0;
 #pragma unroll
     for (int e = 0; e < MAXE; e++) { const int i = threadIdx.x + 256 * e; if (i < n) { const float v = xv[e] - mean; s2 += (double)(v * v); } }
-    const float variance = (float)(block_sum_d(s2, red) / (double)n);
+    variance = (float)(block_sum_d(s2, red) / (double)n);
+    }
     const float scale = 1.0f / sqrtf(variance + 1e-5f);
 #pragma unroll
     for (int e = 0; e < MAXE; e++) {
@@ -508,9 +520,54 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
         }
     }
 }
-void launch_layernorm(const float *x, const float *w, const float *b, int rows, int n, float *out, __half *out_h, hipStream_t s) {
+void launch_layernorm(const float *x, const float *w, const float *b, int rows, int n, float *out, __half *out_h, hipStream_t s, bool sequential_sums) {
     if (n > 2048) throw HipError{hipErrorInvalidValue, "layernorm: row longer than 2048", __FILE__, __LINE__};
-    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)rows), dim3(256), 0, s, x, w, b, n, out, out_h);
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)rows), dim3(256), 0, s, x, w, b, n, out, out_h, sequential_sums ? 1 : 0);
+}
+// MINIGPT4_PARITY attention of the vision tower / Q-Former: oracle/refcpu.c attention_f32 with every fp32 chain in its order -- thread = one key for the scores
+// (q * prescale, sequential fma over the head dimension, / score_div), max, fp16-table exp, exact double sum, p = e * (1 / sum) in fp32 (no fp16 rounding here: ggml's
+// f32 x f32 mul_mat), thread = one output dimension for P.V (sequential over the keys).  One workgroup per (head, query, image).
+__global__ __launch_bounds__(256) void k_attn_vref(const float *__restrict__ q, int ldq, const float *__restrict__ k, const float *__restrict__ v, int ldk, int nq, int nk, int hd,
+                                                   float q_prescale, float score_div, const Tables tb, float *__restrict__ out, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_vr[];
+    float *sc = reinterpret_cast<float *>(smem_vr);               // [nk]
+    float *qv = sc + ((nk + 3) & ~3);                             // [hd]
+    __shared__ float red_f[4]; __shared__ double red_d[4];
+    const int h = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    { const size_t z = blockIdx.z; q += z * nq * ldq; k += z * nk * ldk; v += z * nk * ldk; out += z * nq * ldo; }
+    for (int i = tid; i < hd; i += 256) { float x = q[(size_t)t * ldq + (size_t)h * hd + i]; if (q_prescale != 0.0f) x *= q_prescale; qv[i] = x; }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = tid; j < nk; j += 256) {
+        const float *kr = k + (size_t)j * ldk + (size_t)h * hd;
+        float s = 0.0f;
+        for (int i = 0; i < hd; i++) s = fmaf(kr[i], qv[i], s);
+        if (score_div != 0.0f) s = s / score_div;
+        sc[j] = s; mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red_f[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    double sum = 0.0;
+    for (int j = tid; j < nk; j += 256) { const float e = tab_v(tb.exp, sc[j] - mx); sc[j] = e; sum += (double)e; }   // fp16 values: exact in any order
+    sum = wave_sum_d(sum);
+    if ((tid & 63) == 0) red_d[tid >> 6] = sum;
+    __syncthreads();
+    const float inv = (float)(1.0 / (((red_d[0] + red_d[1]) + red_d[2]) + red_d[3]));
+    for (int j = tid; j < nk; j += 256) sc[j] = sc[j] * inv;
+    __syncthreads();
+    for (int i = tid; i < hd; i += 256) {
+        const float *vr = v + (size_t)h * hd + i;
+        float s = 0.0f;
+        for (int j = 0; j < nk; j++) s = fmaf(vr[(size_t)j * ldk], sc[j], s);
+        out[(size_t)t * ldo + (size_t)h * hd + i] = s;
+    }
+}
+void launch_attn_vref(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale, float score_div, const Tables &tb,
+                      float *out, int ldo, hipStream_t s, int batch) {
+    const size_t lds = (size_t)((nk + 3) & ~3) * 4 + (size_t)hd * 4 + 64;
+    hipLaunchKernelGGL(k_attn_vref, dim3((unsigned)heads, (unsigned)nq, (unsigned)batch), dim3(256), lds, s, q, ldq, k, v, ldk, nq, nk, hd, q_prescale, score_div, tb, out, ldo);
 }
 
 typedef float float4_t __attribute__((ext_vector_type(4)));

@@ -109,8 +109,16 @@ def test_full_size_vit_g_encode_matches_oracle(gpu_lib, omp_threads):
         got = np.ctypeslib.as_array(emb.data, shape=(emb.n_embeddings,)).copy().reshape(32, -1)
         want = R.OracleVision(G.read_vision_file(vp)).encode(img)
         err = float(np.abs(got - want).max() / np.abs(want).max())
-        _dump("vision_13b", {"max_rel": err, "shape": list(got.shape)})
-        print("vision_13b", err)
+        # parity mode at full size: every one of the 39 different blocks, the 12 Q-Former layers and the projection in the oracle's accumulation order -> bit-identical
+        gpu_lib.amd_set_parity(ctx, True)
+        emb_p = gpu_lib.minigpt4_encode_image(ctx, ML.array_to_image_struct(img))
+        par = np.ctypeslib.as_array(emb_p.data, shape=(emb_p.n_embeddings,)).copy().reshape(32, -1)
+        gpu_lib.minigpt4_free_embedding(emb_p)
+        gpu_lib.amd_set_parity(ctx, False)
+        bit = bool(np.array_equal(par, want))
+        _dump("vision_13b", {"max_rel": err, "shape": list(got.shape), "parity_mode_bit_identical": bit, "parity_mode_max_abs_delta": float(np.abs(par - want).max())})
+        print("vision_13b", err, "parity mode bit-identical:", bit)
+        assert bit, float(np.abs(par - want).max())
         rec = _recorded().get("vision_13b", {})
         bar = min(ABS_BAR_VISION, 2.0 * rec["max_rel"]) if "max_rel" in rec else ABS_BAR_VISION
         assert got.shape == want.shape and err <= bar, err

@@ -132,3 +132,87 @@ def test_parity_mode_through_the_reference_chat_flow(gpu_lib, tmpdir_models):
             assert got == want
     finally:
         gpu_lib.minigpt4_free(ctx)
+
+
+def _encode(lib, ctx, img):
+    from minigpt4_cpp_amd import minigpt4_library as ML
+    emb = lib.minigpt4_encode_image(ctx, ML.array_to_image_struct(img))
+    got = np.ctypeslib.as_array(emb.data, shape=(emb.n_embeddings,)).copy().reshape(32, -1)
+    lib.minigpt4_free_embedding(emb)
+    return got
+
+
+def test_image_encode_parity_mode_is_bit_identical_to_the_oracle(gpu_lib, tiny_files):
+    """MINIGPT4_PARITY covers the image path too (Engine::encode_images_ref): patch embedding, ViT blocks, ln_vision, Q-Former and llama_proj with every fp32 chain in the
+    oracle's order -- the embedding of minigpt4_encode_image equals OracleVision's bit for bit; the fast path stays within fp16-GEMM summation noise of it."""
+    import refcpu as R
+    from minigpt4_cpp_amd import modelgen as G
+    vp, llm = tiny_files
+    ctx = gpu_lib.minigpt4_model_load(vp, llm("q4_0"), verbosity=1, n_ctx=64, n_batch=32)
+    try:
+        o = R.OracleVision(G.read_vision_file(vp))
+        for seed in (42, 7):
+            img = G.synth_image(seed)
+            want = o.encode(img)
+            fast = _encode(gpu_lib, ctx, img)
+            gpu_lib.amd_set_parity(ctx, True)
+            par = _encode(gpu_lib, ctx, img)
+            gpu_lib.amd_set_parity(ctx, False)
+            assert np.array_equal(par, want), float(np.abs(par - want).max())
+            assert np.abs(fast - want).max() <= 2e-3 * np.abs(want).max()
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+
+
+@pytest.mark.parametrize("qtype", ["q4_0", "q5_k", "q8_0"])
+def test_quantised_vision_file_parity_mode_is_bit_identical(gpu_lib, tiny_files, tmp_path, qtype):
+    """A vision file re-quantised by minigpt4_quantize_model (the generic image path; dims that hold whole k-quant super-blocks): parity mode equals the oracle's
+    evaluation of the same file bit for bit."""
+    import refcpu as R
+    import test_gpu_quantized_vision as TQ
+    from minigpt4_cpp_amd import modelgen as G
+    _, llm = tiny_files
+    src = str(tmp_path / "vision_f16.bin")
+    G.write_vision_file(src, G.tiny_vision(n_embd_llm=4096, embed_dim=352, mlp_dim=512, q_inter=256), seed=21, std=0.05)
+    qp = str(tmp_path / f"vision_{qtype}.bin")
+    assert gpu_lib.library.minigpt4_quantize_model(src.encode(), qp.encode(), TQ.MG4[qtype]) == 0
+    ctx = gpu_lib.minigpt4_model_load(qp, llm("q4_0"), verbosity=1, n_ctx=64, n_batch=32)
+    try:
+        gpu_lib.amd_set_parity(ctx, True)
+        img = G.synth_image(11)
+        want = R.OracleVision(G.read_vision_file(qp)).encode(img)
+        par = _encode(gpu_lib, ctx, img)
+        assert np.array_equal(par, want), float(np.abs(par - want).max())
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+
+
+def test_parity_mode_chat_from_the_raw_image_is_bit_identical(gpu_lib, tmpdir_models):
+    """The whole reference flow in parity mode -- encode_image (GPU, parity) -> system_prompt -> begin_chat_image -> 12 x end_chat_image -- against OracleVision + OracleChat:
+    nothing is handed from one side to the other; image embedding, every logits vector and every greedy piece are identical."""
+    import os
+    import refcpu as R
+    from minigpt4_cpp_amd import minigpt4_library as ML, modelgen as G
+    vp = os.path.join(tmpdir_models, "vision_pm2.bin")
+    lp = os.path.join(tmpdir_models, "llm_pm2.bin")
+    G.write_vision_file(vp, G.tiny_vision(n_embd_llm=4096), seed=12, std=0.05)
+    G.write_llm_file(lp, G.tiny_llm(wtype="q5_k", n_embd=4096, n_layer=2, n_head=32, n_vocab=512, mix="q5_k_m"), seed=4, std=0.02, **G.TINY_CONDITIONED)
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=256, n_batch=64)
+    try:
+        gpu_lib.amd_set_parity(ctx, True)
+        img = G.synth_image(5)
+        emb = gpu_lib.minigpt4_encode_image(ctx, ML.array_to_image_struct(img))
+        got = np.ctypeslib.as_array(emb.data, shape=(emb.n_embeddings,)).copy().reshape(32, -1)
+        want = R.OracleVision(G.read_vision_file(vp)).encode(img)
+        assert np.array_equal(got, want)
+        chat = R.OracleChat(R.OracleLLM(G.read_llm_file(lp), n_ctx=256), n_batch=64)
+        chat.system_prompt()
+        chat.begin_chat_image(want, b"what is the text in the picture?")
+        gpu_lib.minigpt4_system_prompt(ctx)
+        gpu_lib.minigpt4_begin_chat_image(ctx, emb, "what is the text in the picture?")
+        for _ in range(12):
+            assert np.array_equal(gpu_lib.amd_logits(ctx), chat.llm.logits)
+            assert gpu_lib.minigpt4_end_chat_image(ctx, temp=0.0) == chat.end_chat(temp=0.0)[1].decode("utf-8", errors="replace")
+        gpu_lib.minigpt4_free_embedding(emb)
+    finally:
+        gpu_lib.minigpt4_free(ctx)
