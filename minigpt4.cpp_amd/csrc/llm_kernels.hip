@@ -2113,7 +2113,8 @@ __global__ __launch_bounds__(256) void k_attn_prefill_h(const float *__restrict_
     float *S = reinterpret_cast<float *>(smem_aph);               // [QT][LS], LS = 4 mod 64
     __half *Kt = reinterpret_cast<__half *>(S + (size_t)QT * LS); // [64][HD], chunk c of row j at slot c ^ (j & (C8 - 1))
     __half *Vt = Kt + AP_KT * HD;                                 // [HD][APH_LDT]
-    const int h = blockIdx.x, q0 = blockIdx.y * QT, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // causal: the LAST query tile sees the most keys -- it is dispatched first (longest-first), so the short tiles fill the tail of the launch
+    const int h = blockIdx.x, q0 = (int)(gridDim.y - 1 - blockIdx.y) * QT, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int np = *n_past;
     const int T = np + min(q0 + QT - 1, N - 1) + 1;               // keys the last query of this tile sees
     const int nkt = (T + AP_KT - 1) / AP_KT;
@@ -2131,15 +2132,16 @@ __global__ __launch_bounds__(256) void k_attn_prefill_h(const float *__restrict_
             for (int e = 0; e < 8; e++) qf[qs][ks][e] = (_Float16)__half2float(f2h_rn(v[e]));
         }
     }
+    // the global loads of tile kt + 1 are issued before the MFMAs of tile kt (register double buffer): one exposed memory round trip per phase instead of one per tile
+    int4 xk[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) { const int e = tid + 256 * u, j = e / C8, c = e - j * C8; xk[u] = ld16(kc + (size_t)min(j, T - 1) * E + (size_t)h * HD + 8 * c); }
     for (int kt = 0; kt < nkt; kt++) {
         __syncthreads();
-        {
-            int4 x[PER];
 #pragma unroll
-            for (int u = 0; u < PER; u++) { const int e = tid + 256 * u, j = e / C8, c = e - j * C8; x[u] = ld16(kc + (size_t)min(kt * AP_KT + j, T - 1) * E + (size_t)h * HD + 8 * c); }
+        for (int u = 0; u < PER; u++) { const int e = tid + 256 * u, j = e / C8, c = e - j * C8; *reinterpret_cast<int4 *>(Kt + j * HD + ((c ^ (j & (C8 - 1))) << 3)) = xk[u]; }
 #pragma unroll
-            for (int u = 0; u < PER; u++) { const int e = tid + 256 * u, j = e / C8, c = e - j * C8; *reinterpret_cast<int4 *>(Kt + j * HD + ((c ^ (j & (C8 - 1))) << 3)) = x[u]; }
-        }
+        for (int u = 0; u < PER; u++) { const int e = tid + 256 * u, j = e / C8, c = e - j * C8; xk[u] = ld16(kc + (size_t)min((kt + 1) * AP_KT + j, T - 1) * E + (size_t)h * HD + 8 * c); }
         __syncthreads();
         const int key0 = kt * AP_KT + 16 * wave;
         if (key0 < T) {
@@ -2186,22 +2188,22 @@ __global__ __launch_bounds__(256) void k_attn_prefill_h(const float *__restrict_
     for (int qs = 0; qs < QS; qs++)
 #pragma unroll
         for (int i = 0; i < DPW; i++) oacc[qs][i] = pf4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    int4 xv[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) { const int e = tid + 256 * u, j = e / C8, c = e - j * C8; xv[u] = ld16(vc + (size_t)min(j, T - 1) * E + (size_t)h * HD + 8 * c); }
     for (int kt = 0; kt < nkt; kt++) {
         __syncthreads();
-        {
-            int4 x[PER];
 #pragma unroll
-            for (int u = 0; u < PER; u++) { const int e = tid + 256 * u, j = e / C8, c = e - j * C8; x[u] = ld16(vc + (size_t)min(kt * AP_KT + j, T - 1) * E + (size_t)h * HD + 8 * c); }
+        for (int u = 0; u < PER; u++) {
+            const int e = tid + 256 * u, j = e / C8, c = e - j * C8;
+            const bool live = kt * AP_KT + j < T;
+            const unsigned w[4] = {(unsigned)xv[u].x, (unsigned)xv[u].y, (unsigned)xv[u].z, (unsigned)xv[u].w};
+            unsigned short *d = reinterpret_cast<unsigned short *>(Vt) + (8 * c) * APH_LDT + j;
 #pragma unroll
-            for (int u = 0; u < PER; u++) {
-                const int e = tid + 256 * u, j = e / C8, c = e - j * C8;
-                const bool live = kt * AP_KT + j < T;
-                const unsigned w[4] = {(unsigned)x[u].x, (unsigned)x[u].y, (unsigned)x[u].z, (unsigned)x[u].w};
-                unsigned short *d = reinterpret_cast<unsigned short *>(Vt) + (8 * c) * APH_LDT + j;
-#pragma unroll
-                for (int i = 0; i < 4; i++) { d[(2 * i) * APH_LDT] = live ? (unsigned short)(w[i] & 0xFFFF) : (unsigned short)0; d[(2 * i + 1) * APH_LDT] = live ? (unsigned short)(w[i] >> 16) : (unsigned short)0; }
-            }
+            for (int i = 0; i < 4; i++) { d[(2 * i) * APH_LDT] = live ? (unsigned short)(w[i] & 0xFFFF) : (unsigned short)0; d[(2 * i + 1) * APH_LDT] = live ? (unsigned short)(w[i] >> 16) : (unsigned short)0; }
         }
+#pragma unroll
+        for (int u = 0; u < PER; u++) { const int e = tid + 256 * u, j = e / C8, c = e - j * C8; xv[u] = ld16(vc + (size_t)min((kt + 1) * AP_KT + j, T - 1) * E + (size_t)h * HD + 8 * c); }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < DPW; i++) {
