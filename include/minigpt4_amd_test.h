@@ -39,6 +39,15 @@ MINIGPT4_API int minigpt4_amd_test_gemm_f16(const float *A, const float *W, cons
 /* the same through the skinny-M kernel of the Q-Former (k_gemm_f16_skinny: N % 16 == 0, K % 32 == 0; 4 otherwise) */
 MINIGPT4_API int minigpt4_amd_test_gemm_f16_skinny(const float *A, const float *W, const float *bias, int M, int N, int K, int gelu, float *C);
 
+/* Micro-benchmark of the image path's fp16 GEMM on synthetic operands (tools/timeline_gemm.py). flags: 1 GELU, 2 residual, 4 fp16 output too; variant 0 = the dispatcher
+ * (launch_gemm_f16), 1 = the skinny-M kernel, 2 + (slices << 8) = split K + k_splitk_reduce_ln; n_sets weight matrices are cycled (no Infinity-Cache repeats) */
+MINIGPT4_API int minigpt4_amd_bench_gemm_f16(int M, int N, int K, int flags, int variant, int iters, int n_sets, float *us_per_launch);
+/* Micro-benchmark of the ViT / Q-Former attention kernel on synthetic rows (tools/timeline_attn.py) */
+MINIGPT4_API int minigpt4_amd_bench_attn_f32(int heads, int hd, int nq, int nk, int iters, float *us_per_launch);
+/* force one tile shape (an "arm" of launch_gemm_f16_arm in vision_kernels.hip; 0 = the launcher's own choice) for every small-M GEMM / split-K GEMM of this process */
+MINIGPT4_API void minigpt4_amd_test_set_gemm_arm(int arm, int sk_arm);
+/* diagnostic builds (-DMG4_TIMELINE): the 32 clock stamps per workgroup of the last image-path GEMM launch; 0 = built without */
+MINIGPT4_API int minigpt4_amd_timeline_vision(unsigned long long *out, int max_workgroups);
 /* Micro-benchmark of the decode mat-vec kernels on synthetic weight planes (see bench_kernels.py). variant 0: one launch per matrix, 1: fused persistent-wave launch,
    2: the same with the rms-norm prologue, 3 / 4: the batched step's multi-row launch with 4 / 2 prepared rows, 5 / 6: 2 / 4 rows prepared inside the launch */
 MINIGPT4_API int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int variant, int iters, int n_sets, int waves_per_cu, float *us_per_launch, double *bytes_per_launch);

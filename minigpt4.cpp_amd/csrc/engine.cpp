@@ -113,7 +113,8 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     // experiment knobs of the launchers: read here, once -- no launcher calls getenv
     set_mmq2_tuning(getenv("MINIGPT4_MMQ2_TT") ? atoi(getenv("MINIGPT4_MMQ2_TT")) : 0, getenv("MINIGPT4_MMQ2_FILL") ? atoi(getenv("MINIGPT4_MMQ2_FILL")) : 0,
                     getenv("MINIGPT4_MMQ2_KS") ? atoi(getenv("MINIGPT4_MMQ2_KS")) : 0);
-    set_gemm_tuning(getenv("MINIGPT4_GEMM_BIG_M") ? atoi(getenv("MINIGPT4_GEMM_BIG_M")) : -1, getenv("MINIGPT4_F16_KS") ? atoi(getenv("MINIGPT4_F16_KS")) : 0);
+    set_gemm_tuning(getenv("MINIGPT4_GEMM_BIG_M") ? atoi(getenv("MINIGPT4_GEMM_BIG_M")) : -1, getenv("MINIGPT4_F16_KS") ? atoi(getenv("MINIGPT4_F16_KS")) : 0,
+                    getenv("MINIGPT4_GEMM_ARM") ? atoi(getenv("MINIGPT4_GEMM_ARM")) : -1, getenv("MINIGPT4_GEMM_SK_ARM") ? atoi(getenv("MINIGPT4_GEMM_SK_ARM")) : -1);
     if (getenv("MINIGPT4_F16_GEMM")) set_f16_gemm(atoi(getenv("MINIGPT4_F16_GEMM")));
     if (getenv("MINIGPT4_ATTN_PREFILL_F16")) set_attn_prefill_f16(atoi(getenv("MINIGPT4_ATTN_PREFILL_F16")));
     // Decode: which activation preparations run inside the consuming mat-vec's prologue (one fat workgroup per CU repeats the row preparation while

@@ -36,7 +36,7 @@ bool mmq2_supported(int type, int rows, int cols);
 bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s);
 void set_mmq2_cus(int cus);
 void set_mmq2_tuning(int tt, int fill_pct, int ks);   // experiment knobs, 0 = the launcher's choice, < 0 = leave as it is (read from the environment once, by Engine::init)
-void set_gemm_tuning(int big_min_m, int f16_ks);      // smallest M of the 128x128 GEMM (< 0: leave), forced K split of the F16 set launches (0 = choose)
+void set_gemm_tuning(int big_min_m, int f16_ks, int arm = -1, int sk_arm = -1);      // smallest M of the 128x128 GEMM (< 0: leave), forced K split of the F16 set launches (0 = choose)
 void set_f16_gemm(int v);                             // F16 language-model weights at >= 16 rows on the MFMA GEMM (default 1)
 void launch_slab_reduce(const float *slabs, int n_slabs, long long slab_stride, const float *residual, float *y, size_t n, hipStream_t s);   // y = (residual +) sum_z slab_z, fixed order
 // F16 weights at prompt sizes: 1..3 equally spaced [N][K] matrices x M fp16 rows in one launch of the 128x128 LDS-DMA GEMM (split K when the tiles do not fill the chip);
@@ -69,6 +69,7 @@ void reset_kernel_name();
 size_t launch_probe_count();                       // launches noted (and probed with their own start / stop events) since tracing was switched on
 float launch_probe_us(size_t first, size_t last);  // sum of the dispatch durations of probes [first, last) in microseconds (stream synchronised); < 0: not available
 int read_matvec_timeline(unsigned long long *out, int max_workgroups);   // diagnostic builds (MG4_TIMELINE): stamps of the last decode mat-vec launch; 0 otherwise
+int read_vision_timeline(unsigned long long *out, int max_workgroups);   // the same for the image path's kernels (32 x u64 per workgroup)
 
 // ---- token embedding gather (raw ggml rows, dequantised to f32) -----------------------------------------------------
 void launch_get_rows(int type, const uint8_t *raw_table, int K, const int *tokens, int N, float *out, hipStream_t s);
@@ -129,6 +130,9 @@ void launch_layernorm(const float *x, const float *w, const float *b, int rows, 
 void launch_attn_vref(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale, float score_div, const Tables &tb,
                       float *out, int ldo, hipStream_t s, int batch = 1);
 // split-K GEMM (raw fp32 partial sums into `slices` slabs) + the deterministic reduce fused with bias / residual / the following LayerNorm
+bool launch_gemm_f16_arm(int arm, const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
+                         float *out, __half *out_h, int ldo, hipStream_t s);   // micro-benchmark arms (other tile shapes of k_gemm_f16)
+bool launch_gemm_f16_splitk_arm(int arm, const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, int slices, float *slabs, size_t slab_stride, int ldo, hipStream_t s);
 int gemm_split_slices(int K, int want);   // slices actually used for a K (whole 128-wide k tiles per slice)
 void launch_gemm_f16_splitk(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, int slices, float *slabs, size_t slab_stride, int ldo, hipStream_t s);
 void launch_splitk_reduce_ln(const float *slabs, int n_slabs, size_t slab_stride, const float *bias, const float *residual, int rows, int n, float *x_out, const float *ln_w,

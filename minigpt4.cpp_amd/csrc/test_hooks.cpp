@@ -237,6 +237,85 @@ static int test_gemm_impl(const float *A, const float *W, const float *bias, int
     });
 }
 
+// Micro-benchmark of the fp16 GEMM of the image path on synthetic operands (tools/timeline_gemm.py): `iters` launches of C[M][N] = A[M][K] . W[N][K]^T, cycling through
+// `n_sets` weight matrices so that the Infinity Cache cannot serve repeats (as in the encoder, where every block has its own weights).  flags: 1 = GELU epilogue,
+// 2 = residual epilogue, 4 = fp16 output as well.  variant 0 = launch_gemm_f16 (the dispatcher: 128x128 tiles from M = 512, 64x64 below), 1 = the skinny-M kernel,
+// 2 = split K in `slices` + k_splitk_reduce_ln (the ViT's fc2 form; `slices` in bits 8.. of `variant`).
+int minigpt4_amd_bench_gemm_f16(int M, int N, int K, int flags, int variant, int iters, int n_sets, float *us_per_launch) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 16 || iters < 1 || n_sets < 1) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const int slices = std::max(1, (variant >> 8) & 255), sk_arm = variant >> 16; variant &= 255;
+        DevBuf dA((size_t)M * K * 2), dC((size_t)M * N * 4), dCh((size_t)M * N * 2), dR((size_t)M * N * 4), db((size_t)N * 4), dtab(65536 * 2), dslab((size_t)std::max(slices, 8) * M * N * 4), dln((size_t)N * 4);
+        std::vector<std::unique_ptr<DevBuf>> W;
+        for (int i = 0; i < n_sets; i++) { W.emplace_back(new DevBuf((size_t)N * K * 2)); launch_fill_u16(W.back()->p, (size_t)N * K, (unsigned short)(0x2E66 + i), nullptr); }
+        launch_fill_u16(dA.p, (size_t)M * K, 0x3266, nullptr); launch_fill_u16(dtab.p, 65536, 0x3800, nullptr);
+        HIP_CHECK(hipMemset(dR.p, 0, (size_t)M * N * 4)); HIP_CHECK(hipMemset(db.p, 0, (size_t)N * 4)); HIP_CHECK(hipMemset(dln.p, 0, (size_t)N * 4));
+        Tables tb; tb.gelu = dtab.as<__half>();
+        const bool gelu = flags & 1, res = flags & 2;
+        auto run = [&](int set) -> bool {
+            const __half *Wh = W[(size_t)set]->as<__half>();
+            if (variant == 1) return launch_gemm_f16_skinny(dA.as<__half>(), K, Wh, K, M, N, K, db.as<float>(), res ? dR.as<float>() : nullptr, gelu, tb, dC.as<float>(), (flags & 4) ? dCh.as<__half>() : nullptr, N, nullptr);
+            if (variant == 2) {
+                int sl = gemm_split_slices(K, slices);
+                if (sk_arm) { sl = slices; if (!launch_gemm_f16_splitk_arm(sk_arm, dA.as<__half>(), K, Wh, K, M, N, K, sl, dslab.as<float>(), (size_t)M * N, N, nullptr)) return false; }
+                else launch_gemm_f16_splitk(dA.as<__half>(), K, Wh, K, M, N, K, sl, dslab.as<float>(), (size_t)M * N, N, nullptr);
+                if (N > 2048) launch_slab_reduce(dslab.as<float>(), sl, (long long)M * N, dR.as<float>(), dC.as<float>(), (size_t)M * N, nullptr);   // the language model's combine
+                else launch_splitk_reduce_ln(dslab.as<float>(), sl, (size_t)M * N, db.as<float>(), dR.as<float>(), M, N, dC.as<float>(), dln.as<float>(), dln.as<float>(), nullptr, dCh.as<__half>(), nullptr);
+                return true;
+            }
+            if (variant >= 101 && variant <= 103) {   // the F16 language model's set launch (n = variant - 100 equally spaced matrices of N columns each; wo / w2: n = 1 with a residual)
+                const int n = variant - 100;
+                const __half *Wp[3]; float *Yp[3]; const float *Rp[3];
+                for (int m = 0; m < n; m++) { Wp[m] = Wh + (size_t)m * (N / n) * K; Yp[m] = dC.as<float>() + (size_t)m * M * (N / n); Rp[m] = dR.as<float>() + (size_t)m * M * (N / n); }
+                return launch_gemm_f16_set(dA.as<__half>(), K, Wp, n, M, N / n, K, Yp, res ? Rp : nullptr, N / n, dslab.as<float>(), (size_t)8 * M * N, 256, nullptr);
+            }
+            if (variant >= 3 && variant < 100) return launch_gemm_f16_arm(variant, dA.as<__half>(), K, Wh, K, M, N, K, db.as<float>(), res ? dR.as<float>() : nullptr, gelu, tb, dC.as<float>(), (flags & 4) ? dCh.as<__half>() : nullptr, N, nullptr);
+            launch_gemm_f16(dA.as<__half>(), K, Wh, K, M, N, K, db.as<float>(), res ? dR.as<float>() : nullptr, gelu, tb, dC.as<float>(), (flags & 4) ? dCh.as<__half>() : nullptr, N, nullptr);
+            return true;
+        };
+        for (int i = 0; i < std::min(n_sets, 4); i++) if (!run(i)) return 4;
+        HIP_CHECK(hipDeviceSynchronize());
+        hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+        HIP_CHECK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; i++) run(i % n_sets);
+        HIP_CHECK(hipEventRecord(b, nullptr));
+        HIP_CHECK(hipDeviceSynchronize());
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b));
+        if (us_per_launch) *us_per_launch = ms * 1e3f / (float)iters;
+        return 0;
+    });
+}
+// Micro-benchmark of the ViT / Q-Former attention (launch_attn_f32) on synthetic q|k|v rows: heads x hd wide, nq queries against nk keys, `iters` launches.
+int minigpt4_amd_bench_attn_f32(int heads, int hd, int nq, int nk, int iters, float *us_per_launch) {
+    if (heads < 1 || (hd != 88 && hd != 64) || nq < 1 || nk < 1 || nk > 320 || iters < 1) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const int D = heads * hd, n = std::max(nq, nk);
+        DevBuf dq((size_t)n * 3 * D * 4), dout((size_t)nq * D * 4), douth((size_t)nq * D * 2), dtab(65536 * 2);
+        { std::vector<float> h((size_t)n * 3 * D); for (size_t i = 0; i < h.size(); i++) h[i] = (float)((int)(i * 2654435761u % 2001u) - 1000) / 1000.0f; HIP_CHECK(hipMemcpy(dq.p, h.data(), h.size() * 4, hipMemcpyHostToDevice)); }
+        { std::vector<__half> e(65536); for (int i = 0; i < 65536; i++) e[(size_t)i] = __float2half_rn(expf(__half2float(__ushort_as_half((unsigned short)i)))); HIP_CHECK(hipMemcpy(dtab.p, e.data(), 131072, hipMemcpyHostToDevice)); }
+        Tables tb; tb.exp = dtab.as<__half>();
+        { int nneg = 0; for (int c = 0x8000; c < 0xFC00; c++) { if (__half2float(__float2half_rn(expf(__half2float(__ushort_as_half((unsigned short)c))))) == 0.0f) break; nneg++; } tb.exp_neg_n = (nneg + 2047) / 2048 * 2048; }
+        const float scale = 1.0f / sqrtf((float)hd);
+        auto run = [&]() { launch_attn_f32(dq.as<float>(), 3 * D, dq.as<float>() + D, dq.as<float>() + 2 * D, 3 * D, nq, nk, heads, hd, scale, 0.0f, tb, nullptr, douth.as<__half>(), D, nullptr, 1); };
+        for (int i = 0; i < 3; i++) run();
+        HIP_CHECK(hipDeviceSynchronize());
+        hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+        HIP_CHECK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; i++) run();
+        HIP_CHECK(hipEventRecord(b, nullptr));
+        HIP_CHECK(hipDeviceSynchronize());
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b));
+        if (us_per_launch) *us_per_launch = ms * 1e3f / (float)iters;
+        return 0;
+    });
+}
+void minigpt4_amd_test_set_gemm_arm(int arm, int sk_arm) { set_gemm_tuning(-1, 0, arm, sk_arm); }
+int minigpt4_amd_timeline_vision(unsigned long long *out, int max_workgroups) { return (out && max_workgroups > 0) ? read_vision_timeline(out, max_workgroups) : -1; }
+
 // Micro-benchmark of the decode mat-vec kernels on synthetic planes (random quant bytes, sane fp16 scales).  `n_sets` distinct weight sets
 // are cycled so the 256 MiB Infinity Cache cannot serve repeats.  variant 0 = k_mul_mat per matrix, 1 = persistent-wave v2 (fused set).
 int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, int n_mat, int variant, int iters, int n_sets, int waves_per_cu, float *us_per_launch, double *bytes_per_launch) {

@@ -12,25 +12,52 @@ namespace mg4 {
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef unsigned v4u_g __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned short f2h_bits_v(float f) { return __half_as_ushort(f2h_rn(f)); }
 __device__ __forceinline__ float tab_v(const __half *t, float x) { return __half2float(t[f2h_bits_v(x)]); }
+
+// In-kernel timeline of the image path's kernels (diagnostic builds only, as the mat-vec's: make EXTRA=-DMG4_TIMELINE OUT=../libminigpt4_tl.so OBJ=build_tl).  Thread 0 of
+// every workgroup stamps the 100 MHz constant clock into 32 slots; the last launch wins; read with minigpt4_amd_timeline_vision (tools/timeline_gemm.py).
+#ifdef MG4_TIMELINE
+__device__ unsigned long long g_tlv[1024 * 32];
+#define MG4_TLV(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.z == 0) g_tlv[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MG4_TLA(i) do { const unsigned lb_ = blockIdx.x + gridDim.x * blockIdx.y; if (threadIdx.x == 0 && lb_ < 1024 && blockIdx.z == 0) g_tlv[lb_ * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MG4_TLV(i) do {} while (0)
+#define MG4_TLA(i) do {} while (0)
+#endif
+int read_vision_timeline(unsigned long long *out, int max_workgroups) {
+#ifdef MG4_TIMELINE
+    const int n = std::min(max_workgroups, 1024);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tlv), (size_t)n * 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return n;
+#else
+    (void)out; (void)max_workgroups; return 0;
+#endif
+}
 
 // =====================================================================================================================
 // C[M][N] = A[M][K] . W[N][K]^T  (+bias, GELU, +residual).  64x64 tile per 256-thread workgroup, 4 waves of 32x32,
 // BK = 32 staged through LDS (80-byte padded rows: conflict-free ds_read_b128), register prefetch of the next tile.
 // =====================================================================================================================
-// Deep K tiles (BK = 128/256): with M = 257 a launch has only ~1-2 workgroups per CU, so the exposed global-load latency per k-iteration
-// dominates; fewer, fatter iterations (8-16 MFMAs per wave each) amortise it.  One LDS buffer, next tile prefetched into registers.
-// (A 3-stage register ring + LDS double buffer was measured 3x SLOWER: hipcc's counted waits degenerate around the ring, see DESIGN.md.)
-template <int BK, int GB_M, int BN, bool GELU, bool RES>
-__global__ __launch_bounds__(GB_M / 32 * BN / 32 * 64) void k_gemm_f16(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K,
+// Deep K tiles (BK = 64/128): with M = 257 a launch has ~1 workgroup per CU, so the exposed global-load latency per k-iteration dominates; fewer, fatter
+// iterations amortise it.  A wave owns TM x TN MFMA tiles (32x32 each): with 1 x 1 every MFMA costs two 1 KB fragment reads and the kernel is bound by the LDS
+// (round-3 timeline: 0.5 us per 64x64x128 step against 0.21 us of MFMA); 2 x 1 / 1 x 2 share a fragment between two MFMAs.
+// Round-3 findings that shaped this form (tools/timeline_gemm.py, tools/isa_waits.py):
+//   * operands by raw buffer loads whose out-of-range chunks come back as zeros -- zeroing the loaded registers made hipcc drain the pipeline (vmcnt(0)) every sextuple;
+//   * scheduling barriers keep the prologue's three stages in issue order (one s_waitcnt serves the prologue and the back edge);
+//   * the epilogue stores through buffer descriptors too (rows / columns past the edge and absent outputs are dropped by the bounds check): the branchy form
+//     waited for vmcnt(0) in front of every store, i.e. 16 serial store round trips = 2 us per workgroup.
+template <int BK, int GB_M, int BN, int TM, int TN, bool GELU, bool RES>
+__global__ __launch_bounds__(GB_M / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm_f16(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K,
                                                   const float *__restrict__ bias, const float *residual, const Tables tb,
                                                   float *out, __half *__restrict__ out_h, int ldo, int k_per_slice, size_t slab_stride) {
     constexpr int LD = BK + 8;                 // +16 bytes per row: conflict-free ds_read_b128 for BK = 32/64/128/256
     constexpr int CPR = BK / 8;                // 16-byte chunks per row
-    constexpr int WN = BN / 32, NT = GB_M / 32 * WN * 64;   // one 32x32 MFMA tile per wave: 4 waves for 64x64, 8 for 128x64, 16 for 128x128
+    constexpr int WNN = BN / (32 * TN), NT = GB_M / (32 * TM) * WNN * 64;
     constexpr int NCA = GB_M * CPR / NT, NCW = BN * CPR / NT;   // 16-byte chunks per thread: A tile, W tile
+    static_assert(NCA * NT == GB_M * CPR && NCW * NT == BN * CPR, "tile chunks must divide over the threads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
     __half *As = reinterpret_cast<__half *>(smem_g), *Ws = As + GB_M * LD, *As1 = Ws + BN * LD, *Ws1 = As1 + GB_M * LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -38,56 +65,79 @@ __global__ __launch_bounds__(GB_M / 32 * BN / 32 * 64) void k_gemm_f16(const __h
     // consecutive slots of ONE XCD, so the weight tile is fetched from HBM once instead of once per XCD (measured 4x re-fetch without this).
     const int ntx = (N + BN - 1) / BN, rt = (M + GB_M - 1) / GB_M;
     const int bslot = blockIdx.x >> 3, bx = (bslot / rt) * 8 + (blockIdx.x & 7), by = bslot % rt;
+    MG4_TLV(0);
     if (bx >= ntx) return;
     const int m0 = by * GB_M, n0 = bx * BN;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = wave / WNN, wn = wave % WNN;
     if (k_per_slice > 0) {   // split-K: slice z multiplies columns [z * k_per_slice, ...) and writes its raw fp32 partial sums into slab z
         const int k0 = blockIdx.z * k_per_slice;
         A += k0; W += k0; K = min(K - k0, k_per_slice);
         out += (size_t)blockIdx.z * slab_stride;
     }
     const int nk = (K + BK - 1) / BK;
-    // per-thread source pointers (row clamped) and LDS offsets of its chunks
-    const __half *asrc[NCA], *wsrc[NCW]; int lofa[NCA], kofa[NCA], lofw[NCW], kofw[NCW];
+    const __amdgpu_buffer_rsrc_t ab = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(A), 0, (int)(((size_t)(M - 1) * lda + K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wb = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(W), 0, (int)(((size_t)(N - 1) * ldw + K) * 2), 0x00020000);
+    int aoff[NCA], woff[NCW]; int lofa[NCA], kofa[NCA], lofw[NCW], kofw[NCW];
 #pragma unroll
-    for (int i = 0; i < NCA; i++) { const int c = tid + NT * i, row = c / CPR; kofa[i] = (c % CPR) * 8; lofa[i] = row * LD + kofa[i]; asrc[i] = A + (size_t)min(m0 + row, M - 1) * lda + kofa[i]; }
+    for (int i = 0; i < NCA; i++) { const int c = tid + NT * i, row = c / CPR; kofa[i] = (c % CPR) * 8; lofa[i] = row * LD + kofa[i]; aoff[i] = (min(m0 + row, M - 1) * lda + kofa[i]) * 2; }
 #pragma unroll
-    for (int i = 0; i < NCW; i++) { const int c = tid + NT * i, row = c / CPR; kofw[i] = (c % CPR) * 8; lofw[i] = row * LD + kofw[i]; wsrc[i] = W + (size_t)min(n0 + row, N - 1) * ldw + kofw[i]; }
-    float16_t acc;
+    for (int i = 0; i < NCW; i++) { const int c = tid + NT * i, row = c / CPR; kofw[i] = (c % CPR) * 8; lofw[i] = row * LD + kofw[i]; woff[i] = (min(n0 + row, N - 1) * ldw + kofw[i]) * 2; }
+    float16_t acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int b = 0; b < TN; b++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[a][b][i] = 0.0f;
     // Three statically named register stages: while tile k is multiplied out of LDS, the loads of tiles k+1 and k+2 are in flight and tile
     // k+3 is issued.  No lambdas / structs / register copies around the stages (each of those made hipcc spill to scratch or wait on the
-    // in-flight loads); all loads unconditional (clamped + zeroed).  K is a multiple of 8, so a 16-byte chunk is entirely in or out.
-    int4 ra0[NCA], rw0[NCW], ra1[NCA], rw1[NCW], ra2[NCA], rw2[NCW];
+    // in-flight loads); all loads unconditional.  K is a multiple of 8, so a 16-byte chunk is entirely in or out.
+    v4u_g ra0[NCA], rw0[NCW], ra1[NCA], rw1[NCW], ra2[NCA], rw2[NCW];
 #define MG4_GLOAD(kt, RA, RW)                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < NCA; i++) {                                                           \
-        const bool valid = (kt) * BK + kofa[i] < K; const int ko = valid ? (kt) * BK : -kofa[i];                \
-        int4 va = *reinterpret_cast<const int4 *>(asrc[i] + ko);                                                \
-        if (!valid) { va.x = va.y = va.z = va.w = 0; }                                                          \
-        RA[i] = va; }                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < NCW; i++) {                                                           \
-        const bool valid = (kt) * BK + kofw[i] < K; const int ko = valid ? (kt) * BK : -kofw[i];                \
-        int4 vw = *reinterpret_cast<const int4 *>(wsrc[i] + ko);                                                \
-        if (!valid) { vw.x = vw.y = vw.z = vw.w = 0; }                                                          \
-        RW[i] = vw; }
+    _Pragma("unroll") for (int i = 0; i < NCA; i++)                                                             \
+        RA[i] = __builtin_amdgcn_raw_buffer_load_b128(ab, (kt) * BK + kofa[i] < K ? aoff[i] + (kt) * (BK * 2) : (int)0x80000000, 0, 0); \
+    _Pragma("unroll") for (int i = 0; i < NCW; i++)                                                             \
+        RW[i] = __builtin_amdgcn_raw_buffer_load_b128(wb, (kt) * BK + kofw[i] < K ? woff[i] + (kt) * (BK * 2) : (int)0x80000000, 0, 0);
 #define MG4_STEP(kt, RA, RW, AS, WS)                                                                            \
-    {   _Pragma("unroll") for (int i = 0; i < NCA; i++) *reinterpret_cast<int4 *>(&AS[lofa[i]]) = RA[i];        \
-        _Pragma("unroll") for (int i = 0; i < NCW; i++) *reinterpret_cast<int4 *>(&WS[lofw[i]]) = RW[i];        \
+    {   _Pragma("unroll") for (int i = 0; i < NCA; i++) *reinterpret_cast<v4u_g *>(&AS[lofa[i]]) = RA[i];       \
+        _Pragma("unroll") for (int i = 0; i < NCW; i++) *reinterpret_cast<v4u_g *>(&WS[lofw[i]]) = RW[i];       \
         __syncthreads();                                                                                        \
-        MG4_GLOAD((kt) + 3, RA, RW)      /* past the end: zeroed */                                             \
+        if ((kt) < 26) MG4_TLV(2 + (kt));                                                                       \
+        MG4_GLOAD((kt) + 3, RA, RW)      /* past the end: zeros */                                              \
         _Pragma("unroll") for (int ks = 0; ks < BK / 16; ks++) {                                                \
-            const half8_t af = *reinterpret_cast<const half8_t *>(&AS[(wm * 32 + (lane & 31)) * LD + ks * 16 + (lane >> 5) * 8]); \
-            const half8_t bf = *reinterpret_cast<const half8_t *>(&WS[(wn * 32 + (lane & 31)) * LD + ks * 16 + (lane >> 5) * 8]); \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0); } }
+            half8_t af[TM], bf[TN];                                                                             \
+            _Pragma("unroll") for (int a = 0; a < TM; a++) af[a] = *reinterpret_cast<const half8_t *>(&AS[((wm * TM + a) * 32 + (lane & 31)) * LD + ks * 16 + (lane >> 5) * 8]); \
+            _Pragma("unroll") for (int b = 0; b < TN; b++) bf[b] = *reinterpret_cast<const half8_t *>(&WS[((wn * TN + b) * 32 + (lane & 31)) * LD + ks * 16 + (lane >> 5) * 8]); \
+            _Pragma("unroll") for (int a = 0; a < TM; a++)                                                      \
+                _Pragma("unroll") for (int b = 0; b < TN; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0); } }
     // Two LDS buffers, ONE barrier per k tile: tile k+1 is written into the other buffer while slower waves still multiply tile k; a wave can only
     // reach the barrier of step k+1 after its own reads of step k, so the buffer written in step k+2 is free.  (3 register stages x 2 LDS buffers
     // -> the loop body is unrolled 6 times with statically named stages and buffers.)
     MG4_GLOAD(0, ra0, rw0)
+    __builtin_amdgcn_sched_barrier(0);
     MG4_GLOAD(1, ra1, rw1)
+    __builtin_amdgcn_sched_barrier(0);
     MG4_GLOAD(2, ra2, rw2)
-    for (int kt = 0; kt < nk; kt += 6) {      // whole sextuples: steps past nk multiply zero tiles (accumulators unchanged)
-        MG4_STEP(kt, ra0, rw0, As, Ws)
+    __builtin_amdgcn_sched_barrier(0);
+    MG4_TLV(1);
+    // epilogue operands requested now, behind the three stages: bias (and, for one tile per wave, the residual) would otherwise be a memory round trip after the loop
+    const int lcol = lane & 31, hh = lane >> 5;
+    float bv[TN];
+#pragma unroll
+    for (int b = 0; b < TN; b++) bv[b] = bias ? bias[min(n0 + (wn * TN + b) * 32 + lcol, N - 1)] : 0.0f;
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(RES ? residual : bias), 0, RES ? (int)(((size_t)(M - 1) * ldo + N) * 4) : 0, 0x00020000);
+    constexpr bool RES_EARLY = RES && TM * TN == 1;
+    float rr0[16];
+    if (RES_EARLY) {
+        const int col = n0 + wn * 32 + lcol;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            rr0[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, row < M && col < N ? (row * ldo + col) * 4 : (int)0x80000000, 0, 0));
+        }
+    }
+    for (int kt = 0; kt < nk; kt += 6) {      // whole sextuples: steps past nk multiply zero tiles (accumulators unchanged).  (Uniform exits between the steps were tried: the
+        MG4_STEP(kt, ra0, rw0, As, Ws)        //  merged control flow brought vmcnt(0) waits back into the body.)
         MG4_STEP(kt + 1, ra1, rw1, As1, Ws1)
         MG4_STEP(kt + 2, ra2, rw2, As, Ws)
         MG4_STEP(kt + 3, ra0, rw0, As1, Ws1)
@@ -96,46 +146,231 @@ __global__ __launch_bounds__(GB_M / 32 * BN / 32 * 64) void k_gemm_f16(const __h
     }
 #undef MG4_STEP
 #undef MG4_GLOAD
-    // epilogue: all gathers of one kind are issued together (no per-element branches around loads)
-    const int col = n0 + wn * 32 + (lane & 31), colc = min(col, N - 1);
-    const float bv = bias ? bias[colc] : 0.0f;
-    float v[16]; size_t o[16]; bool okr[16];
+    MG4_TLV(29);
+    // epilogue, branch-free: every store goes through a buffer descriptor (an absent output has zero records), rows >= M / columns >= N get an out-of-range offset
+    const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc(out, 0, out ? (int)(((size_t)(M - 1) * ldo + N) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hb = __builtin_amdgcn_make_buffer_rsrc(out_h, 0, out_h ? (int)(((size_t)(M - 1) * ldo + N) * 2) : 0, 0x00020000);
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        okr[r] = row < M && col < N; o[r] = (size_t)min(row, M - 1) * ldo + colc;
-        v[r] = bias ? bv + acc[r] : acc[r];
+    for (int b = 0; b < TN; b++) {
+        const int col = n0 + (wn * TN + b) * 32 + lcol;
+#pragma unroll
+        for (int a = 0; a < TM; a++) {
+            float v[16]; unsigned o[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                o[r] = row < M && col < N ? (unsigned)(row * ldo + col) : 0x20000000u;   // x 4 = 0x80000000, x 2 = 0x40000000: both past any tensor of this path
+                v[r] = bias ? bv[b] + acc[a][b][r] : acc[a][b][r];
+            }
+            if (GELU) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = tab_v(tb.gelu, v[r]);
+            }
+            if (RES) {
+                float rr[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) rr[r] = RES_EARLY ? rr0[r] : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, (int)(o[r] * 4u), 0, 0));
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = rr[r] + v[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ob, (int)(o[r] * 4u), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(__half_as_ushort(f2h_rn(v[r])), hb, (int)(o[r] * 2u), 0, 0);
+            }
+        }
     }
-    if (GELU) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = tab_v(tb.gelu, v[r]);
-    }
-    if (RES) {
-        float rr[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) rr[r] = residual[o[r]];
-#pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = rr[r] + v[r];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r++) if (okr[r]) { if (out) out[o[r]] = v[r]; if (out_h) out_h[o[r]] = f2h_rn(v[r]); }
+#ifdef MG4_TIMELINE
+    MG4_TLV(30);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MG4_TLV(31);
+#endif
 }
-template <int BK, int BM, int BN>
+template <int BK, int BM, int BN, int TM = 1, int TN = 1>
 static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
                           float *out, __half *out_h, int ldo, hipStream_t s, int slices = 1, size_t slab_stride = 0) {
     const int k_per_slice = slices > 1 ? ((K + BK - 1) / BK + slices - 1) / slices * BK : 0;
     const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
-    dim3 grid((unsigned)((ntx + 7) / 8 * 8 * rt), 1, (unsigned)slices), block(BM / 32 * BN / 32 * 64);
+    dim3 grid((unsigned)((ntx + 7) / 8 * 8 * rt), 1, (unsigned)slices), block(BM / (32 * TM) * (BN / (32 * TN)) * 64);
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 8) * 2;
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
-    else if (gelu) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
-    else if (residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
-    else hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, TM, TN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, TM, TN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, TM, TN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, TM, TN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
+    else if (gelu) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
+    else if (residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
+    else hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
+}
+// =====================================================================================================================
+// LDS-DMA ring form of the small-M GEMM (round 3).  The timeline of k_gemm_f16 put the k loop at 0.5 us per 64x64x128 step against 0.21 us of MFMA: the
+// register-staged tile costs 32 ds_write_b128 per step (13 cycles each through the VGPR -> LDS path, MI355X_MICROARCH.md LDS table) on the same waves that issue
+// the MFMAs.  Here the tiles travel global -> LDS by global_load_lds (no staging registers, no ds_write), S buffers deep, with counted waits:
+//     [s_waitcnt vmcnt((S - 2) * PW): own pieces of tile k landed]  [raw s_barrier: everybody's pieces landed, everybody left buffer k - 1]
+//     [request tile k + S - 1 into buffer k - 1]  [fragment reads + MFMAs on tile k]
+// (raw barrier + explicit counts: __syncthreads() would drain the DMA queue -- cdna_hip_programming.md "Pipelining across barriers").  A stage holds KT
+// sub-tiles of 64 k each: rows of 128 bytes, the 16-byte chunks XOR-swizzled by ((row >> 1) & 7) on the SOURCE side (the DMA destination is lane-linear), as in
+// k_gemm_f16_big.  Same arithmetic as k_gemm_f16 (exact fp16 products, fp32 accumulation in k order per 16-wide MFMA step), same epilogue.
+// =====================================================================================================================
+typedef __attribute__((address_space(3))) void *g_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *g_glb_ptr_t;
+// several equally spaced, equally shaped weight matrices in one launch (column tile -> matrix), and / or a K range split over grid.z with one fp32 slab per slice
+struct GemmSet { int n_per_mat; long long w_mat_stride, out_mat_stride; int k_per_slice; long long slab_stride; };   // all zero: one matrix, whole K
+template <int BM, int BN, int TM, int TN, int KT, int S, bool GELU, bool RES>
+__global__ __launch_bounds__(BM / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm_dma(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K,
+                                                  const float *__restrict__ bias, const float *residual, const Tables tb,
+                                                  float *out, __half *__restrict__ out_h, int ldo, const GemmSet gs) {
+    constexpr int WNN = BN / (32 * TN), NW = BM / (32 * TM) * WNN;
+    constexpr int SUB = (BM + BN) * 128, STAGE = KT * SUB;          // bytes: one 64-wide pair of tiles [A rows | W rows]; one stage
+    constexpr int RI = (BM + BN) / 8, PW = RI * KT / NW;            // DMA instructions (8 rows x 128 bytes each) per sub-tile pair; per wave per stage
+    static_assert(PW * NW == RI * KT && (S - 2) * PW <= 63 && S >= 2, "stage pieces must divide over the waves; vmcnt is 6 bits");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_d[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
+    const int bslot = blockIdx.x >> 3, bx = (bslot / rt) * 8 + (blockIdx.x & 7), by = bslot % rt;   // XCD-aware order (k_gemm_f16)
+    MG4_TLV(0);
+    if (bx >= ntx) return;
+    const int m0 = by * BM;
+    int n0 = bx * BN;
+    const int wm = wave / WNN, wn = wave % WNN;
+    if (gs.n_per_mat > 0) {   // the F16 language model's wq|wk|wv and w1|w3 in one launch: column tile -> (matrix, local column); n_per_mat is a multiple of BN
+        const int mat = n0 / gs.n_per_mat;
+        n0 -= mat * gs.n_per_mat; N = gs.n_per_mat;
+        W += (size_t)mat * gs.w_mat_stride;
+        if (out) out += (size_t)mat * gs.out_mat_stride;
+        if (RES) residual += (size_t)mat * gs.out_mat_stride;
+    }
+    if (gs.k_per_slice > 0) {
+        const int k0 = blockIdx.z * gs.k_per_slice;
+        A += k0; W += k0; K = min(K - k0, gs.k_per_slice);
+        out += (size_t)blockIdx.z * gs.slab_stride;
+    }
+    const int nk = K > 0 ? K / (64 * KT) : 0;                       // the launcher guarantees K % (64 * KT) == 0
+    // epilogue operands first: an ordinary load whose result is used while DMAs are in flight would make hipcc wait for vmcnt(0)
+    const int lcol = lane & 31, hh = lane >> 5;
+    float bv[TN];
+#pragma unroll
+    for (int b = 0; b < TN; b++) bv[b] = bias ? bias[min(n0 + (wn * TN + b) * 32 + lcol, N - 1)] : 0.0f;
+    // DMA sources of this lane: piece q = wave * PW + u -> (sub-tile q / RI, rows 8 j .. 8 j + 7 of [A rows | W rows], j = q % RI); lane -> (row = 8 j + lane / 8,
+    // slot = lane % 8), source chunk = slot ^ ((row >> 1) & 7)
+    const __half *src[PW]; unsigned dst[PW];
+#pragma unroll
+    for (int u = 0; u < PW; u++) {
+        const int q = wave * PW + u, sub = q / RI, j = q % RI;
+        const bool isA = j < BM / 8;
+        const int row = 8 * (isA ? j : j - BM / 8) + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+        src[u] = (isA ? A + (size_t)min(m0 + row, M - 1) * lda : W + (size_t)min(n0 + row, N - 1) * ldw) + 8 * c + 64 * sub;
+        dst[u] = (unsigned)(sub * SUB + j * 1024);
+    }
+    auto stage = [&](int kt, int buf) {
+        unsigned char *base = smem_d + buf * STAGE;
+#pragma unroll
+        for (int u = 0; u < PW; u++) {
+            const __half *g = kt < nk ? src[u] + (size_t)kt * (64 * KT) : A;     // past the end: one harmless line into a free buffer (the wait counts stay uniform)
+            __builtin_amdgcn_global_load_lds((g_glb_ptr_t)g, (g_lds_ptr_t)(base + dst[u]), 16, 0, 0);
+        }
+    };
+    const int l31 = lane & 31, key = (l31 >> 1) & 7;
+    unsigned fa[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) fa[ks] = (unsigned)(l31 * 128 + (((2 * ks + hh) ^ key) << 4));
+    float16_t acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int b = 0; b < TN; b++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[a][b][i] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < S - 1; t++) stage(t, t);
+    MG4_TLV(1);
+    int buf = 0;
+    for (int kt = 0; kt < nk; kt++) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * PW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt < 26) MG4_TLV(2 + kt);
+        stage(kt + S - 1, buf == 0 ? S - 1 : buf - 1);
+        const unsigned char *st = smem_d + buf * STAGE;
+#pragma unroll
+        for (int sub = 0; sub < KT; sub++)
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                half8_t af[TM], bf[TN];
+#pragma unroll
+                for (int a = 0; a < TM; a++) af[a] = *reinterpret_cast<const half8_t *>(st + sub * SUB + (wm * TM + a) * 32 * 128 + fa[ks]);
+#pragma unroll
+                for (int b = 0; b < TN; b++) bf[b] = *reinterpret_cast<const half8_t *>(st + sub * SUB + BM * 128 + (wn * TN + b) * 32 * 128 + fa[ks]);
+#pragma unroll
+                for (int a = 0; a < TM; a++)
+#pragma unroll
+                    for (int b = 0; b < TN; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        buf = buf + 1 == S ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the trailing dummy pieces
+    MG4_TLV(29);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(RES ? residual : bias), 0, RES ? (int)(((size_t)(M - 1) * ldo + N) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc(out, 0, out ? (int)(((size_t)(M - 1) * ldo + N) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hb = __builtin_amdgcn_make_buffer_rsrc(out_h, 0, out_h ? (int)(((size_t)(M - 1) * ldo + N) * 2) : 0, 0x00020000);
+#pragma unroll
+    for (int b = 0; b < TN; b++) {
+        const int col = n0 + (wn * TN + b) * 32 + lcol;
+#pragma unroll
+        for (int a = 0; a < TM; a++) {
+            float v[16]; unsigned o[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                o[r] = row < M && col < N ? (unsigned)(row * ldo + col) : 0x20000000u;
+                v[r] = bias ? bv[b] + acc[a][b][r] : acc[a][b][r];
+            }
+            if (GELU) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = tab_v(tb.gelu, v[r]);
+            }
+            if (RES) {
+                float rr[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, (int)(o[r] * 4u), 0, 0));
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = rr[r] + v[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ob, (int)(o[r] * 4u), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(__half_as_ushort(f2h_rn(v[r])), hb, (int)(o[r] * 2u), 0, 0);
+            }
+        }
+    }
+#ifdef MG4_TIMELINE
+    MG4_TLV(30);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MG4_TLV(31);
+#endif
+}
+template <int BM, int BN, int TM, int TN, int KT, int S>
+static bool launch_gemm_dma_t(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
+                              float *out, __half *out_h, int ldo, hipStream_t s, int slices = 1, size_t slab_stride = 0, GemmSet gs = GemmSet{0, 0, 0, 0, 0}) {
+    constexpr int BKS = 64 * KT;
+    if (K % BKS || lda % 8 || ldw % 8 || (reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) % 16 || (gs.n_per_mat > 0 && gs.n_per_mat % BN)) return false;
+    gs.k_per_slice = slices > 1 ? (K / BKS + slices - 1) / slices * BKS : 0;
+    gs.slab_stride = (long long)slab_stride;
+    const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
+    dim3 grid((unsigned)((ntx + 7) / 8 * 8 * rt), 1, (unsigned)slices), block(BM / (32 * TM) * (BN / (32 * TN)) * 64);
+    const size_t lds = (size_t)S * KT * (BM + BN) * 128;
+    static bool attr = false;
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_dma<BM, BN, TM, TN, KT, S, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_dma<BM, BN, TM, TN, KT, S, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_dma<BM, BN, TM, TN, KT, S, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_dma<BM, BN, TM, TN, KT, S, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    if (gelu && residual) hipLaunchKernelGGL((k_gemm_dma<BM, BN, TM, TN, KT, S, true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
+    else if (gelu) hipLaunchKernelGGL((k_gemm_dma<BM, BN, TM, TN, KT, S, true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
+    else if (residual) hipLaunchKernelGGL((k_gemm_dma<BM, BN, TM, TN, KT, S, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
+    else hipLaunchKernelGGL((k_gemm_dma<BM, BN, TM, TN, KT, S, false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
+    return true;
 }
 // =====================================================================================================================
 // Large-M form (M >= 512: the unquantised LLM's prompt rows -- BASELINE.json configs[4] -- and batched image encodes): 128x128 tile per 256-thread workgroup,
@@ -145,9 +380,6 @@ static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, in
 // One barrier per k tile: [own DMA landed] barrier [request tile k + 1 into the other buffer] [16 MFMAs on tile k].
 // Same arithmetic as k_gemm_f16: exact fp16 products, fp32 accumulation over k in index order per 16-wide MFMA step.
 // =====================================================================================================================
-typedef __attribute__((address_space(3))) void *g_lds_ptr_t;
-typedef const __attribute__((address_space(1))) void *g_glb_ptr_t;
-struct GemmSet { int n_per_mat; long long w_mat_stride, out_mat_stride; int k_per_slice; long long slab_stride; };   // all zero: one matrix, whole K
 template <bool GELU, bool RES>
 __global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K, const float *__restrict__ bias,
                                                          const float *residual, const Tables tb, float *out, __half *__restrict__ out_h, int ldo, const GemmSet gs) {
@@ -219,18 +451,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restric
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
-    // epilogue (as k_gemm_f16): all gathers of one kind issued together
+    // epilogue (as k_gemm_f16): branch-free, every store through a buffer descriptor (rows >= M / columns >= N get an out-of-range offset, an absent output has
+    // zero records) -- the branchy form put s_waitcnt vmcnt(0) in front of each of the 64 stores of a wave
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(RES ? residual : bias), 0, RES ? (int)(((size_t)(M - 1) * ldo + N) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc(out, 0, out ? (int)(((size_t)(M - 1) * ldo + N) * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hb = __builtin_amdgcn_make_buffer_rsrc(out_h, 0, out_h ? (int)(((size_t)(M - 1) * ldo + N) * 2) : 0, 0x00020000);
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int col = n0 + wn * 64 + j * 32 + l31, colc = min(col, N - 1);
         const float bv = bias ? bias[colc] : 0.0f;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            float v[16]; size_t o[16]; bool okr[16];
+            float v[16]; unsigned o[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                okr[r] = row < M && col < N; o[r] = (size_t)min(row, M - 1) * ldo + colc;
+                o[r] = row < M && col < N ? (unsigned)(row * ldo + col) : 0x20000000u;
                 v[r] = bias ? bv + acc[i][j][r] : acc[i][j][r];
             }
             if (GELU) {
@@ -240,18 +476,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restric
             if (RES) {
                 float rr[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) rr[r] = residual[o[r]];
+                for (int r = 0; r < 16; r++) rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, (int)(o[r] * 4u), 0, 0));
 #pragma unroll
                 for (int r = 0; r < 16; r++) v[r] = rr[r] + v[r];
             }
 #pragma unroll
-            for (int r = 0; r < 16; r++) if (okr[r]) { if (out) out[o[r]] = v[r]; if (out_h) out_h[o[r]] = f2h_rn(v[r]); }
+            for (int r = 0; r < 16; r++) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), ob, (int)(o[r] * 4u), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(__half_as_ushort(f2h_rn(v[r])), hb, (int)(o[r] * 2u), 0, 0);
+            }
         }
     }
 }
 static int g_gemm_big_min_m = 512;   // smallest M that takes the 128x128 kernel (0 = never); MINIGPT4_GEMM_BIG_M, read once by Engine::init
 static int g_f16_ks = 0;             // forced K split of the F16 set launches (0 = choose); MINIGPT4_F16_KS, read once by Engine::init
-void set_gemm_tuning(int big_min_m, int f16_ks) { if (big_min_m >= 0) g_gemm_big_min_m = big_min_m; g_f16_ks = std::max(0, std::min(f16_ks, 8)); }
+static int g_gemm_arm = 0, g_gemm_sk_arm = 0;   // experiments: force one tile shape for every small-M GEMM / split-K GEMM (MINIGPT4_GEMM_ARM / _SK_ARM, read once by Engine::init); 0 = choose, -2 = the 64x64 launch always, -3 = round 2's kernels everywhere (64x64 tiles, 128x128 large-M kernel)
+void set_gemm_tuning(int big_min_m, int f16_ks, int arm, int sk_arm) {
+    if (big_min_m >= 0) g_gemm_big_min_m = big_min_m;
+    g_f16_ks = std::max(0, std::min(f16_ks, 8));
+    if (arm >= 0 || arm == -2 || arm == -3) g_gemm_arm = arm;
+    if (sk_arm >= 0) g_gemm_sk_arm = sk_arm;
+}
 static bool launch_gemm_big(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
                             float *out, __half *out_h, int ldo, hipStream_t s, const GemmSet gs = GemmSet{0, 0, 0, 0, 0}, int slices = 1) {
     static bool init = false;
@@ -282,9 +527,30 @@ bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n
     if (n > 1 && (wstride <= 0 || ystride <= 0)) return false;
     if (residual) for (int i = 0; i < n; i++) if (!residual[i] || residual[i] - residual[0] != (long long)i * ystride) return false;
     Tables tb{};
+    const size_t out_floats = (size_t)M * ldo;
+    // Round 3: 256x128 tiles of the LDS-DMA ring kernel (8 waves of 64x64, three stages, counted waits), with the K range split until the launch has about one
+    // workgroup per CU -- 13B at 512 rows: wq|wk|wv 240 workgroups 104 -> 83 us, w1|w3 432 workgroups 199 -> 161 us, wo 80 x 3 slices 63 -> 45 us, w2 139 -> 85 us
+    // (profiles/r03b_gemm_f16_set_512rows.log).  MINIGPT4_GEMM_ARM=-3: the 128x128 kernel below (A/B).
+    if (g_gemm_arm != -3 && M >= 256) {
+        const int wgs = ((M + 255) / 256) * (n * N / 128);
+        int ks = 1;
+        if (n == 1 && out_floats % 4 == 0)
+            while (wgs * (ks + 1) <= cus && (K / 64) / (ks + 1) >= 16 && ws && (size_t)(ks + 1) * out_floats <= ws_floats && ks < 4) ks++;
+        const GemmSet gs{n > 1 ? N : 0, wstride, ystride, 0, 0};
+        if (ks > 1) {
+            if (launch_gemm_dma_t<256, 128, 2, 2, 1, 3>(A, lda, W[0], K, M, N, K, nullptr, nullptr, false, tb, ws, nullptr, ldo, s, ks, out_floats, gs)) {
+                launch_slab_reduce(ws, ks, (long long)out_floats, residual ? residual[0] : nullptr, y[0], out_floats, s);
+                return true;
+            }
+        } else {
+            // far more 256x128 tiles than CUs (w1|w3: 432): 256x256 tiles, 8 waves of 128x64, two stages (216 workgroups: 159 -> 146 us)
+            if (wgs * 2 > cus * 3 && N % 256 == 0 &&
+                launch_gemm_dma_t<256, 256, 4, 2, 1, 2>(A, lda, W[0], K, M, n * N, K, nullptr, residual ? residual[0] : nullptr, false, tb, y[0], nullptr, ldo, s, 1, 0, gs)) return true;
+            if (launch_gemm_dma_t<256, 128, 2, 2, 1, 3>(A, lda, W[0], K, M, n * N, K, nullptr, residual ? residual[0] : nullptr, false, tb, y[0], nullptr, ldo, s, 1, 0, gs)) return true;
+        }
+    }
     const int tiles = ((M + 127) / 128) * (n * N / 128);
     int ks = 1;
-    const size_t out_floats = (size_t)M * ldo;
     while (tiles * ks < 2 * cus && (K / 64) / (ks + 1) >= 16 && ws && (size_t)(ks + 1) * out_floats * n <= ws_floats && ks < 4) ks++;
     if (g_f16_ks > 0) ks = g_f16_ks;
     if (ks > 1 && (!ws || (size_t)ks * out_floats * n > ws_floats || n > 1 || out_floats % 4)) ks = 1;   // split launches are single-matrix (wo, w2): the sets have tiles enough
@@ -394,8 +660,68 @@ bool launch_gemm_f16_skinny(const __half *A, int lda, const __half *W, int ldw, 
 }
 void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
                      float *out, __half *out_h, int ldo, hipStream_t s) {
+    static int cus = 0;
+    if (!cus) { hipDeviceProp_t prop; cus = hipGetDeviceProperties(&prop, 0) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+    // large M with no more 128x128 tiles than CUs (the batched encoder's attn.proj: 9 x 11): the three-stage ring kernel, one workgroup per CU (19.8 vs 23.9 us)
+    if (g_gemm_arm != -3 && g_gemm_big_min_m > 0 && M >= g_gemm_big_min_m && ((M + 127) / 128) * ((N + 127) / 128) <= cus &&
+        launch_gemm_dma_t<128, 128, 2, 2, 1, 3>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;
     if (launch_gemm_big(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;
+    if (g_gemm_arm > 0 && launch_gemm_f16_arm(g_gemm_arm, A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;
+    // Tile shape by workgroup count (round 3, tools/timeline_gemm.py): a small-M launch lasts as long as ONE workgroup's chain (1.5 us to the first request, ~0.5 us per
+    // 128 k, the epilogue) as long as every workgroup has a CU to itself -- a CU pulls only 50-75 GB/s through its load path whatever the kernel does, so the second
+    // workgroup of a CU roughly doubles that CU's time (330 tiles of 64x64 on 256 CUs: 16 us; 198 tiles of 128x64: 12.8 us).  Hence: the shape with the MOST
+    // workgroups that still fit one per CU.  Every shape accumulates an output element in the same order (tests: ..._tile_shapes_are_bit_identical).
+    struct Shape { int bm, bn, arm; };
+    static const Shape shapes[4] = {{64, 32, 11}, {64, 64, 0}, {128, 64, 31}, {64, 128, 5}};      // arms of launch_gemm_f16_arm; 0 = the 64x64 launch below
+    int pick = -1, pick_n = 0;
+    for (int i = 0; i < 4 && g_gemm_arm == 0; i++) {
+        const int n = ((M + shapes[i].bm - 1) / shapes[i].bm) * ((N + shapes[i].bn - 1) / shapes[i].bn);
+        if (pick < 0 || (n <= cus ? (pick_n > cus || n > pick_n) : (pick_n > cus && n < pick_n))) { pick = i; pick_n = n; }
+    }
+    if (pick >= 0 && shapes[pick].arm) {
+        if (launch_gemm_f16_arm(shapes[pick].arm, A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;
+        if (shapes[pick].arm == 31 && launch_gemm_f16_arm(4, A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;   // K % 64: the register-staged 128x64
+    }
     launch_gemm_t<128, 64, 64>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);
+}
+
+// tile-shape arms of k_gemm_f16 for the micro-benchmark (test library only calls this): 3 = BK 64, 4 = 128x64 tiles, 5 = 64x128 tiles, 6 = BK 256
+bool launch_gemm_f16_arm(int arm, const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
+                         float *out, __half *out_h, int ldo, hipStream_t s) {
+    switch (arm) {
+    case 3: launch_gemm_t<64, 64, 64>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); return true;
+    case 4: launch_gemm_t<128, 128, 64>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); return true;          // 8 waves, one tile each
+    case 5: launch_gemm_t<128, 64, 128>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); return true;
+    case 7: launch_gemm_t<128, 128, 64, 2, 1>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); return true;    // 4 waves of 64x32
+    case 8: launch_gemm_t<64, 128, 64, 2, 1>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); return true;
+    case 9: launch_gemm_t<128, 64, 128, 1, 2>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); return true;    // 4 waves of 32x64
+    case 10: launch_gemm_t<64, 64, 128, 1, 2>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); return true;
+    case 11: launch_gemm_t<128, 64, 32>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); return true;          // 2 waves
+    case 12: launch_gemm_t<64, 64, 32>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); return true;
+    case 13: launch_gemm_t<64, 128, 128, 2, 2>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); return true;   // 4 waves of 64x64
+    case 14: launch_gemm_t<128, 32, 64>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); return true;          // 2 waves, 32 rows
+    case 20: return launch_gemm_dma_t<64, 64, 1, 1, 1, 4>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);     // 64 KB: two workgroups per CU
+    case 21: return launch_gemm_dma_t<64, 64, 1, 1, 2, 3>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);     // 96 KB
+    case 22: return launch_gemm_dma_t<64, 64, 1, 1, 2, 4>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);     // 128 KB
+    case 23: return launch_gemm_dma_t<128, 64, 2, 1, 1, 4>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);    // 96 KB, 4 waves of 64x32
+    case 24: return launch_gemm_dma_t<128, 64, 2, 1, 2, 3>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);    // 144 KB
+    case 25: return launch_gemm_dma_t<64, 128, 1, 2, 1, 4>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);    // 4 waves of 32x64
+    case 26: return launch_gemm_dma_t<64, 128, 1, 2, 2, 3>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);
+    case 27: return launch_gemm_dma_t<64, 32, 1, 1, 1, 4>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);     // 2 waves, 48 KB
+    case 28: return launch_gemm_dma_t<64, 32, 1, 1, 2, 4>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);     // 2 waves, 96 KB
+    case 29: return launch_gemm_dma_t<32, 64, 1, 1, 2, 4>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);     // 2 waves, 32 rows
+    case 30: return launch_gemm_dma_t<128, 128, 2, 2, 1, 4>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);   // 4 waves of 64x64, 128 KB
+    case 31: return launch_gemm_dma_t<128, 64, 1, 1, 1, 4>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);    // 8 waves of 32x32
+    case 32: return launch_gemm_dma_t<128, 128, 2, 2, 1, 3>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);   // the large-M tile with 3 / 2 stages
+    case 33: return launch_gemm_dma_t<128, 128, 2, 2, 1, 2>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);
+    case 34: return launch_gemm_dma_t<256, 128, 2, 2, 1, 3>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);   // 8 waves of 64x64, 144 KB
+    case 35: return launch_gemm_dma_t<128, 256, 2, 2, 1, 3>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);
+    case 36: return launch_gemm_dma_t<256, 128, 2, 2, 1, 2>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);   // 96 KB
+    case 38: return launch_gemm_dma_t<256, 256, 2, 2, 1, 2>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);   // 16 waves of 64x64, 128 KB
+    case 39: return launch_gemm_dma_t<256, 256, 4, 2, 1, 2>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);   // 8 waves of 128x64
+    case 37: launch_gemm_t<128, 64, 64>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s); return true;          // the 64x64 launch
+    default: return false;
+    }
 }
 
 // =====================================================================================================================
@@ -414,7 +740,28 @@ __device__ __forceinline__ double block_sum_d(double v, double *red) {
 int gemm_split_slices(int K, int want) { const int nk = (K + 127) / 128; int s = std::max(1, std::min(want, nk)); const int per = (nk + s - 1) / s; return (nk + per - 1) / per; }
 void launch_gemm_f16_splitk(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, int slices, float *slabs, size_t slab_stride, int ldo, hipStream_t s) {
     Tables tb{};
+    if (g_gemm_sk_arm && launch_gemm_f16_splitk_arm(g_gemm_sk_arm, A, lda, W, ldw, M, N, K, slices, slabs, slab_stride, ldo, s)) return;
     launch_gemm_t<128, 64, 64>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride);
+}
+bool launch_gemm_f16_splitk_arm(int arm, const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, int slices, float *slabs, size_t slab_stride, int ldo, hipStream_t s) {
+    Tables tb{};
+    switch (arm) {   // micro-benchmark arms (slices counted in whole k tiles of the arm's BK by launch_gemm_t)
+    case 0: launch_gemm_t<128, 64, 64>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride); return true;
+    case 3: launch_gemm_t<64, 64, 64>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride); return true;
+    case 7: launch_gemm_t<128, 128, 64, 2, 1>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride); return true;
+    case 8: launch_gemm_t<64, 128, 64, 2, 1>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride); return true;
+    case 11: launch_gemm_t<128, 64, 32>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride); return true;
+    case 12: launch_gemm_t<64, 64, 32>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride); return true;
+    case 13: launch_gemm_t<64, 128, 128, 2, 2>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride); return true;
+    case 20: return launch_gemm_dma_t<64, 64, 1, 1, 1, 4>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride);
+    case 21: return launch_gemm_dma_t<64, 64, 1, 1, 2, 3>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride);
+    case 23: return launch_gemm_dma_t<128, 64, 2, 1, 1, 4>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride);
+    case 27: return launch_gemm_dma_t<64, 32, 1, 1, 1, 4>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride);
+    case 28: return launch_gemm_dma_t<64, 32, 1, 1, 2, 4>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride);
+    case 32: return launch_gemm_dma_t<128, 128, 2, 2, 1, 3>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride);
+    case 34: return launch_gemm_dma_t<256, 128, 2, 2, 1, 3>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride);
+    default: return false;
+    }
 }
 // x = residual + (bias + sum_z slab_z)   [x_out, fp32];   then, when ln_w is given, ggml_norm(x) * ln_w + ln_b -> ln_out (fp32) / ln_out_h (fp16).
 // One workgroup per row, n <= 2048.
@@ -428,7 +775,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_ln(const float *__restric
     double s = 0.0;
     // every slab value of the row is requested before the first one is used (clamped indices, no load under a branch: the round-1 form walked the slabs with one
     // dependent round trip each -- 13 us for a 4-slab row of 1408; same additions in the same order)
-    float part[MAXZ][MAXE], rv[MAXE], bv[MAXE];
+    float part[MAXZ][MAXE], rv[MAXE], bv[MAXE], lw[MAXE], lb[MAXE];
 #pragma unroll
     for (int z = 0; z < MAXZ; z++) {
         const size_t zo = (size_t)min(z, n_slabs - 1) * slab_stride + row * n;
@@ -440,6 +787,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_ln(const float *__restric
         const int ic = min((int)threadIdx.x + 256 * e, n - 1);
         rv[e] = residual ? residual[row * n + ic] : 0.0f;
         bv[e] = bias ? bias[ic] : 0.0f;
+        lw[e] = ln_w ? ln_w[ic] : 0.0f; lb[e] = ln_b ? ln_b[ic] : 0.0f;     // requested with the first loads: not a second round trip after the reductions
     }
 #pragma unroll
     for (int e = 0; e < MAXE; e++) {
@@ -467,8 +815,8 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_ln(const float *__restric
         const int i = threadIdx.x + 256 * e;
         if (i < n) {
             float v = (xv[e] - mean) * scale;
-            v = ln_w[i] * v;
-            if (ln_b) v = v + ln_b[i];
+            v = lw[e] * v;
+            if (ln_b) v = v + lb[e];
             if (ln_out) ln_out[row * n + i] = v;
             if (ln_out_h) ln_out_h[row * n + i] = f2h_rn(v);
         }
@@ -490,6 +838,10 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
     double s = 0.0;
 #pragma unroll
     for (int e = 0; e < MAXE; e++) { const int i = threadIdx.x + 256 * e; xv[e] = i < n ? xr[i] : 0.0f; s += (double)xv[e]; }
+    // weight and bias requested together with the row (the barriers of the two reductions would otherwise put this memory round trip at the END of the kernel)
+    float wv[MAXE], bb[MAXE];
+#pragma unroll
+    for (int e = 0; e < MAXE; e++) { const int ic = min((int)threadIdx.x + 256 * e, n - 1); wv[e] = w[ic]; bb[e] = b ? b[ic] : 0.0f; }
     float mean, variance;
     if (seq) {   // MINIGPT4_PARITY: ggml_norm's two loops literally -- one double accumulator each, element order (oracle/refcpu.c layer_norm)
         if (threadIdx.x == 0) {
@@ -513,8 +865,8 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
         const int i = threadIdx.x + 256 * e;
         if (i < n) {
             float v = (xv[e] - mean) * scale;
-            v = w[i] * v;
-            if (b) v = v + b[i];
+            v = wv[e] * v;
+            if (b) v = v + bb[e];
             if (out) out[row * n + i] = v;
             if (out_h) out_h[row * n + i] = f2h_rn(v);
         }
@@ -592,14 +944,19 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
     constexpr int DT = (HD + 15) / 16, KS4 = 4 * DT;
     static_assert(HD % 4 == 0, "16-byte row pieces");
     { const size_t z = blockIdx.z; q += z * nq * ldq; k += z * nk * ldk; v += z * nk * ldk; if (out) out += z * nq * ldo; if (out_h) out_h += z * nq * ldo; }
-    const int h = blockIdx.x, q0 = blockIdx.y * 16, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
     float *red_m = reinterpret_cast<float *>(smem);                         // [4][16]
     double *red_s = reinterpret_cast<double *>(smem + 256);                 // [4][16]
     float *part = reinterpret_cast<float *>(smem + 768);                    // [4][DT * 4][64]
     __half *etab = reinterpret_cast<__half *>(smem + 768 + 4 * DT * 4 * 64 * 4);
     const unsigned NT = (unsigned)tb.exp_neg_n;                             // multiple of 2048
+    MG4_TLA(0);
     for (unsigned c0 = 0; c0 < NT; c0 += 2048)
         __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(tb.exp + 0x8000 + c0 + tid * 8), (g_lds_ptr_t)(reinterpret_cast<unsigned char *>(etab) + (c0 + wave * 512) * 2), 16, 0, 0);
+    // (Round 3 tried 16 x 16 = 256 workgroups for the ViT's 257 queries -- the last tile's workgroup serving the left-over query in a second softmax + P.V pass over the
+    // K / V fragments it holds: 23.9 -> 20.9 us back to back, but 18.8 -> 19.9 us inside the encoder, where the 16 extra workgroups of the 272 overlap the next launch's
+    // ramp.  Not kept; profiles/r03_experiments_not_adopted.log.)
+    const int q0 = blockIdx.y * 16;
     // Q / K fragments: instruction u of a 16-row tile reads, per row, the 64 contiguous bytes of dims 16 u .. 16 u + 15 (lane (row, g): 16 bytes = dims 16 u + 4 g + e),
     // i.e. 16 whole sectors per wave instruction.  (First version: lane (row, g) read its own 88-byte quarter row 8 bytes at a time -- 64 different sectors per
     // instruction, and the address path, not the 90 KB of K, set the kernel's time.)  MFMA step (u, e) therefore reduces over dims {16 u + 4 g + e : g}; dims past HD
@@ -625,6 +982,7 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
             kf[t][4 * u] = x.x; kf[t][4 * u + 1] = x.y; kf[t][4 * u + 2] = x.z; kf[t][4 * u + 3] = x.w;     // past HD: finite duplicates, multiplied by the zeros in qf
         }
     }
+    MG4_TLA(1);
     if (q_prescale != 0.0f) {
 #pragma unroll
         for (int u = 0; u < KS4; u++) qf[u] *= q_prescale;
@@ -644,7 +1002,9 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
             sc[t][r] = sv; mx = fmaxf(mx, sv);
         }
     }
+    MG4_TLA(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the table DMA (issued first, returned first) has landed
+    MG4_TLA(3);
     // V fragments of this wave's keys: requested now, consumed after the softmax
     float vf[TPW][4][DT];
 #pragma unroll
@@ -655,60 +1015,92 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
 #pragma unroll
             for (int dt = 0; dt < DT; dt++) vf[t][r][dt] = vp[min(dt * 16 + j, HD - 1)];
         }
-    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (g == 0) red_m[wave * 16 + j] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red_m[j], red_m[16 + j]), fmaxf(red_m[32 + j], red_m[48 + j]));
-    double sum = 0.0;
+    MG4_TLA(4);
+    {
+        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (g == 0) red_m[wave * 16 + j] = mx;
+        __syncthreads();
+        MG4_TLA(5);
+        mx = fmaxf(fmaxf(red_m[j], red_m[16 + j]), fmaxf(red_m[32 + j], red_m[48 + j]));
+        double sum = 0.0;
+        // all LDS gathers first (clamped index, no branch: the branchy form made 20 serial LDS round trips), then the three special cases by selects; a code outside
+        // all of them (NaN, or a positive difference -- cannot happen for finite scores) takes the global table in a wave-uniform slow path
+        unsigned code[TPW][4]; float el[TPW][4];
+        bool odd = false;
 #pragma unroll
-    for (int t = 0; t < TPW; t++)
+        for (int t = 0; t < TPW; t++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float x = sc[t][r] - mx;
-            const unsigned code = f2h_bits_v(x), idx = code ^ 0x8000u;
-            float e;
-            if (idx < NT) e = __half2float(etab[idx]);
-            else if (code == 0u) e = 1.0f;                                  // the row maximum itself: table[+0] = fp16(expf(0))
-            else if (code == 0xFC00u) e = 0.0f;                             // -inf (keys past nk, underflowed differences): table[-inf] = 0
-            else e = __half2float(tb.exp[code]);
-            e = sc[t][r] == -INFINITY ? 0.0f : e;
-            sc[t][r] = e; sum += (double)e;
+            for (int r = 0; r < 4; r++) {
+                code[t][r] = f2h_bits_v(sc[t][r] - mx);
+                el[t][r] = __half2float(etab[min(code[t][r] ^ 0x8000u, NT - 1u)]);
+            }
+#pragma unroll
+        for (int t = 0; t < TPW; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const unsigned c = code[t][r], idx = c ^ 0x8000u;
+                float e = idx < NT ? el[t][r] : (c == 0u ? 1.0f : 0.0f);    // +0: the row maximum itself, table[+0] = fp16(expf(0)) = 1; 0xFC00 = -inf: table[-inf] = 0
+                odd = odd || (idx >= NT && c != 0u && c != 0xFC00u);
+                el[t][r] = e;
+            }
+        if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {
+#pragma unroll
+            for (int t = 0; t < TPW; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const unsigned c = code[t][r], idx = c ^ 0x8000u;
+                    if (idx >= NT && c != 0u && c != 0xFC00u) el[t][r] = __half2float(tb.exp[c]);
+                }
         }
-    sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
-    if (g == 0) red_s[wave * 16 + j] = sum;
-    __syncthreads();
-    sum = ((red_s[j] + red_s[16 + j]) + red_s[32 + j]) + red_s[48 + j];
-    const float inv = (float)(1.0 / sum);
-    float4_t o[DT];
 #pragma unroll
-    for (int dt = 0; dt < DT; dt++) { o[dt][0] = 0.0f; o[dt][1] = 0.0f; o[dt][2] = 0.0f; o[dt][3] = 0.0f; }
+        for (int t = 0; t < TPW; t++)
 #pragma unroll
-    for (int t = 0; t < TPW; t++)
+            for (int r = 0; r < 4; r++) { sc[t][r] = el[t][r]; sum += (double)el[t][r]; }   // (a masked key's score is -inf: code 0xFC00 above, e = 0; the maximum is finite)
+        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        if (g == 0) red_s[wave * 16 + j] = sum;
+        MG4_TLA(6);
+        __syncthreads();
+        MG4_TLA(7);
+        sum = ((red_s[j] + red_s[16 + j]) + red_s[32 + j]) + red_s[48 + j];
+        const float inv = (float)(1.0 / sum);
+        float4_t o[DT];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float p = sc[t][r] * inv;
+        for (int dt = 0; dt < DT; dt++) { o[dt][0] = 0.0f; o[dt][1] = 0.0f; o[dt][2] = 0.0f; o[dt][3] = 0.0f; }
 #pragma unroll
-            for (int dt = 0; dt < DT; dt++) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[t][r][dt], p, o[dt], 0, 0, 0);
-        }
+        for (int t = 0; t < TPW; t++)
 #pragma unroll
-    for (int dt = 0; dt < DT; dt++)
+            for (int r = 0; r < 4; r++) {
+                const float p = sc[t][r] * inv;
 #pragma unroll
-        for (int r = 0; r < 4; r++) part[(wave * DT * 4 + dt * 4 + r) * 64 + lane] = o[dt][r];
-    __syncthreads();
-    for (int e = tid; e < DT * 64; e += 256) {
-        const int dt = e >> 6, ln = e & 63, dim0 = dt * 16 + 4 * (ln >> 4), qrow = q0 + (ln & 15);
-        float s4[4];
+                for (int dt = 0; dt < DT; dt++) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[t][r][dt], p, o[dt], 0, 0, 0);
+            }
+        MG4_TLA(8);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int o1 = (dt * 4 + r) * 64 + ln;
-            s4[r] = ((part[o1] + part[DT * 4 * 64 + o1]) + part[2 * DT * 4 * 64 + o1]) + part[3 * DT * 4 * 64 + o1];
-        }
-        if (qrow < nq && dim0 < HD) {
-            const size_t oo = (size_t)qrow * ldo + h * HD + dim0;
-            if (out) *reinterpret_cast<float4 *>(out + oo) = make_float4(s4[0], s4[1], s4[2], s4[3]);
-            if (out_h) { __half2 a = __halves2half2(f2h_rn(s4[0]), f2h_rn(s4[1])), b = __halves2half2(f2h_rn(s4[2]), f2h_rn(s4[3])); uint2 w; w.x = *reinterpret_cast<unsigned *>(&a); w.y = *reinterpret_cast<unsigned *>(&b); *reinterpret_cast<uint2 *>(out_h + oo) = w; }
+        for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[(wave * DT * 4 + dt * 4 + r) * 64 + lane] = o[dt][r];
+        __syncthreads();
+        MG4_TLA(9);
+        for (int e = tid; e < DT * 64; e += 256) {
+            const int dt = e >> 6, ln = e & 63, dim0 = dt * 16 + 4 * (ln >> 4), qrow = q0 + (ln & 15);
+            float s4[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o1 = (dt * 4 + r) * 64 + ln;
+                s4[r] = ((part[o1] + part[DT * 4 * 64 + o1]) + part[2 * DT * 4 * 64 + o1]) + part[3 * DT * 4 * 64 + o1];
+            }
+            if (qrow < nq && dim0 < HD) {
+                const size_t oo = (size_t)qrow * ldo + h * HD + dim0;
+                if (out) *reinterpret_cast<float4 *>(out + oo) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+                if (out_h) { __half2 a = __halves2half2(f2h_rn(s4[0]), f2h_rn(s4[1])), b = __halves2half2(f2h_rn(s4[2]), f2h_rn(s4[3])); uint2 w; w.x = *reinterpret_cast<unsigned *>(&a); w.y = *reinterpret_cast<unsigned *>(&b); *reinterpret_cast<uint2 *>(out_h + oo) = w; }
+            }
         }
     }
+#ifdef MG4_TIMELINE
+    MG4_TLA(10);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MG4_TLA(11);
+#endif
 }
 
 // ViT / BERT attention (fp32 scores and outputs on the exact-f32 matrix cores, k_attn_vit).  nk <= 320 keys (the reference's graphs have 257 or 32).

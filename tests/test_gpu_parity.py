@@ -193,6 +193,35 @@ def test_gemm_f16_mfma(gpu_lib, shape, gelu):
         assert _rel(got, ref) < 2e-5
 
 
+GEMM_ARMS = [3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31]
+
+
+@pytest.mark.parametrize("arm", GEMM_ARMS)
+def test_gemm_f16_tile_shapes_are_bit_identical(gpu_lib, arm):
+    """Every tile shape of the small-M fp16 GEMM (register-staged k_gemm_f16 arms 3..14, LDS-DMA ring k_gemm_dma arms 20..31; vision_kernels.hip launch_gemm_f16_arm)
+    accumulates an output element over k in the same order, so on ragged shapes (M = 257, N not a tile multiple, one and several k tiles) each arm must reproduce the default
+    launch bit for bit, GELU epilogue included; a shape outside an arm's range (K % 64) falls back to the default and is trivially equal."""
+    import ctypes
+    L = gpu_lib.library
+    L.minigpt4_amd_test_set_gemm_arm.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.minigpt4_amd_test_set_gemm_arm.restype = None
+    rng = np.random.default_rng(arm)
+    try:
+        for (M, K, N, gelu) in [(257, 256, 352, False), (257, 1408, 224, True), (70, 128, 96, False), (33, 592, 64, False), (300, 640, 1056, True)]:
+            A = rng.standard_normal((M, K)).astype(np.float32)
+            W = (0.1 * rng.standard_normal((N, K))).astype(np.float32)
+            b = rng.standard_normal(N).astype(np.float32)
+            L.minigpt4_amd_test_set_gemm_arm(-2, 0)                  # the 64x64 launch, whatever the shape
+            want = gpu_lib.amd_test_gemm_f16(A, W, b, gelu)
+            L.minigpt4_amd_test_set_gemm_arm(0, 0)                   # the launcher's own choice of tile shape
+            assert np.array_equal(gpu_lib.amd_test_gemm_f16(A, W, b, gelu).view(np.uint32), want.view(np.uint32))
+            L.minigpt4_amd_test_set_gemm_arm(arm, 0)
+            got = gpu_lib.amd_test_gemm_f16(A, W, b, gelu)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (arm, M, K, N, float(np.abs(got - want).max()))
+    finally:
+        L.minigpt4_amd_test_set_gemm_arm(0, 0)
+
+
 def test_encode_image_matches_oracle(gpu_lib, tiny_files):
     import refcpu as R
     from minigpt4_cpp_amd import minigpt4_library as ML, modelgen as G
