@@ -61,12 +61,15 @@ __global__ __launch_bounds__(GB_M / (32 * TM) * (BN / (32 * TN)) * 64) void k_ge
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
     __half *As = reinterpret_cast<__half *>(smem_g), *Ws = As + GB_M * LD, *As1 = Ws + BN * LD, *Ws1 = As1 + GB_M * LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware tile order (blocks are dealt round-robin to the 8 XCDs, each with its own L2): the row tiles that share a weight tile get
-    // consecutive slots of ONE XCD, so the weight tile is fetched from HBM once instead of once per XCD (measured 4x re-fetch without this).
+    // XCD-aware tile order (blocks are dealt round-robin to the 8 XCDs, each with its own L2): XCD x owns the tiles [x * chunk, (x + 1) * chunk) of the column-major
+    // tile list, so the row tiles that share a weight tile sit on ONE XCD (the weight tile is fetched from HBM once instead of once per XCD: 4x re-fetch measured
+    // without) AND every XCD gets the same number of tiles +- 1.  (Until round 3 XCD x owned the column tiles x, x + 8, ...: 33 column tiles x 7 row tiles put 35
+    // workgroups on XCD 0's 32 CUs and 28 on the others -- 35 us instead of ~20 for the 3-image qkv launch.)
     const int ntx = (N + BN - 1) / BN, rt = (M + GB_M - 1) / GB_M;
-    const int bslot = blockIdx.x >> 3, bx = (bslot / rt) * 8 + (blockIdx.x & 7), by = bslot % rt;
+    const int tile_n = ntx * rt, tile_chunk = (tile_n + 7) >> 3, tile_slot = blockIdx.x >> 3, tile_id = (int)(blockIdx.x & 7) * tile_chunk + tile_slot;   // XCD-aware, balanced (below)
+    const int bx = tile_id / rt, by = tile_id - bx * rt;
     MG4_TLV(0);
-    if (bx >= ntx) return;
+    if (tile_slot >= tile_chunk || tile_id >= tile_n) return;
     const int m0 = by * GB_M, n0 = bx * BN;
     const int wm = wave / WNN, wn = wave % WNN;
     if (k_per_slice > 0) {   // split-K: slice z multiplies columns [z * k_per_slice, ...) and writes its raw fp32 partial sums into slab z
@@ -191,7 +194,7 @@ static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, in
                           float *out, __half *out_h, int ldo, hipStream_t s, int slices = 1, size_t slab_stride = 0) {
     const int k_per_slice = slices > 1 ? ((K + BK - 1) / BK + slices - 1) / slices * BK : 0;
     const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
-    dim3 grid((unsigned)((ntx + 7) / 8 * 8 * rt), 1, (unsigned)slices), block(BM / (32 * TM) * (BN / (32 * TN)) * 64);
+    dim3 grid((unsigned)((ntx * rt + 7) / 8 * 8), 1, (unsigned)slices), block(BM / (32 * TM) * (BN / (32 * TN)) * 64);
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 8) * 2;
     static bool attr = false;
     if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, TM, TN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -228,9 +231,10 @@ __global__ __launch_bounds__(BM / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_d[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
-    const int bslot = blockIdx.x >> 3, bx = (bslot / rt) * 8 + (blockIdx.x & 7), by = bslot % rt;   // XCD-aware order (k_gemm_f16)
+    const int tile_n = ntx * rt, tile_chunk = (tile_n + 7) >> 3, tile_slot = blockIdx.x >> 3, tile_id = (int)(blockIdx.x & 7) * tile_chunk + tile_slot;   // XCD-aware, balanced (below)
+    const int bx = tile_id / rt, by = tile_id - bx * rt;
     MG4_TLV(0);
-    if (bx >= ntx) return;
+    if (tile_slot >= tile_chunk || tile_id >= tile_n) return;
     const int m0 = by * BM;
     int n0 = bx * BN;
     const int wm = wave / WNN, wn = wave % WNN;
@@ -359,7 +363,7 @@ static bool launch_gemm_dma_t(const __half *A, int lda, const __half *W, int ldw
     gs.k_per_slice = slices > 1 ? (K / BKS + slices - 1) / slices * BKS : 0;
     gs.slab_stride = (long long)slab_stride;
     const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
-    dim3 grid((unsigned)((ntx + 7) / 8 * 8 * rt), 1, (unsigned)slices), block(BM / (32 * TM) * (BN / (32 * TN)) * 64);
+    dim3 grid((unsigned)((ntx * rt + 7) / 8 * 8), 1, (unsigned)slices), block(BM / (32 * TM) * (BN / (32 * TN)) * 64);
     const size_t lds = (size_t)S * KT * (BM + BN) * 128;
     static bool attr = false;
     if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_dma<BM, BN, TM, TN, KT, S, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -388,8 +392,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware order: the row tiles that share a weight tile run on ONE XCD (blocks are dealt round-robin to the 8 XCDs, each with its own L2)
     const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
-    const int bslot = blockIdx.x >> 3, bx = (bslot / rt) * 8 + (blockIdx.x & 7), by = bslot % rt;
-    if (bx >= ntx) return;
+    const int tile_n = ntx * rt, tile_chunk = (tile_n + 7) >> 3, tile_slot = blockIdx.x >> 3, tile_id = (int)(blockIdx.x & 7) * tile_chunk + tile_slot;   // XCD-aware, balanced (below)
+    const int bx = tile_id / rt, by = tile_id - bx * rt;
+    if (tile_slot >= tile_chunk || tile_id >= tile_n) return;
     const int m0 = by * BM;
     int n0 = bx * BN;
     // several equally spaced, equally shaped weight matrices in one launch (the F16 language model's wq|wk|wv and w1|w3: one launch with 3x / 2x the workgroups instead
@@ -507,7 +512,7 @@ static bool launch_gemm_big(const __half *A, int lda, const __half *W, int ldw, 
         HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); }
     if (g_gemm_big_min_m <= 0 || M < g_gemm_big_min_m || K % 64 || K < 64 || lda % 8 || ldw % 8 || (reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) % 16) return false;
     const int ntx = (N + 127) / 128, rt = (M + 127) / 128;
-    const dim3 grid((unsigned)((ntx + 7) / 8 * 8 * rt), (unsigned)slices), block(256);
+    const dim3 grid((unsigned)((ntx * rt + 7) / 8 * 8), (unsigned)slices), block(256);
     const size_t lds = 64 * 1024;
     if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16_big<true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
     else if (gelu) hipLaunchKernelGGL((k_gemm_f16_big<true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
@@ -532,7 +537,7 @@ bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n
     // workgroup per CU -- 13B at 512 rows: wq|wk|wv 240 workgroups 104 -> 83 us, w1|w3 432 workgroups 199 -> 161 us, wo 80 x 3 slices 63 -> 45 us, w2 139 -> 85 us
     // (profiles/r03b_gemm_f16_set_512rows.log).  MINIGPT4_GEMM_ARM=-3: the 128x128 kernel below (A/B).
     if (g_gemm_arm != -3 && M >= 256) {
-        const int wgs = ((M + 255) / 256) * (n * N / 128);
+        const int wgs = (((M + 255) / 256) * (n * N / 128) + 7) / 8 * 8;   // the tiles are dealt to the 8 XCDs in equal shares
         int ks = 1;
         if (n == 1 && out_floats % 4 == 0)
             while (wgs * (ks + 1) <= cus && (K / 64) / (ks + 1) >= 16 && ws && (size_t)(ks + 1) * out_floats <= ws_floats && ks < 4) ks++;
@@ -662,25 +667,25 @@ void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, 
                      float *out, __half *out_h, int ldo, hipStream_t s) {
     static int cus = 0;
     if (!cus) { hipDeviceProp_t prop; cus = hipGetDeviceProperties(&prop, 0) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
-    // large M with no more 128x128 tiles than CUs (the batched encoder's attn.proj: 9 x 11): the three-stage ring kernel, one workgroup per CU (19.8 vs 23.9 us)
-    if (g_gemm_arm != -3 && g_gemm_big_min_m > 0 && M >= g_gemm_big_min_m && ((M + 127) / 128) * ((N + 127) / 128) <= cus &&
-        launch_gemm_dma_t<128, 128, 2, 2, 1, 3>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;
-    if (launch_gemm_big(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;
     if (g_gemm_arm > 0 && launch_gemm_f16_arm(g_gemm_arm, A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;
-    // Tile shape by workgroup count (round 3, tools/timeline_gemm.py): a small-M launch lasts as long as ONE workgroup's chain (1.5 us to the first request, ~0.5 us per
+    // Tile shape by workgroup count (round 3, tools/timeline_gemm.py): a launch lasts as long as ONE workgroup's chain (1.5 us to the first request, ~0.5 us per
     // 128 k, the epilogue) as long as every workgroup has a CU to itself -- a CU pulls only 50-75 GB/s through its load path whatever the kernel does, so the second
     // workgroup of a CU roughly doubles that CU's time (330 tiles of 64x64 on 256 CUs: 16 us; 198 tiles of 128x64: 12.8 us).  Hence: the shape with the MOST
-    // workgroups that still fit one per CU.  Every shape accumulates an output element in the same order (tests: ..._tile_shapes_are_bit_identical).
+    // workgroups that still fit one per CU (counted per XCD: the tiles are dealt to the 8 XCDs in equal shares); nothing fits -> from 512 rows on the 128x128 kernel
+    // with two workgroups per CU (k_gemm_f16_big), below that the shape with the fewest workgroups.  Every shape accumulates an output element in the same order
+    // (tests: ..._tile_shapes_are_bit_identical), so the choice never changes a result.
     struct Shape { int bm, bn, arm; };
-    static const Shape shapes[4] = {{64, 32, 11}, {64, 64, 0}, {128, 64, 31}, {64, 128, 5}};      // arms of launch_gemm_f16_arm; 0 = the 64x64 launch below
+    static const Shape shapes[5] = {{64, 32, 11}, {64, 64, 0}, {128, 64, 31}, {64, 128, 5}, {128, 128, 32}};   // arms of launch_gemm_f16_arm; 0 = the 64x64 launch below
     int pick = -1, pick_n = 0;
-    for (int i = 0; i < 4 && g_gemm_arm == 0; i++) {
-        const int n = ((M + shapes[i].bm - 1) / shapes[i].bm) * ((N + shapes[i].bn - 1) / shapes[i].bn);
+    for (int i = 0; i < 5 && g_gemm_arm == 0; i++) {
+        const int n = (((M + shapes[i].bm - 1) / shapes[i].bm) * ((N + shapes[i].bn - 1) / shapes[i].bn) + 7) / 8 * 8;
         if (pick < 0 || (n <= cus ? (pick_n > cus || n > pick_n) : (pick_n > cus && n < pick_n))) { pick = i; pick_n = n; }
     }
+    if ((pick < 0 || pick_n > cus) && launch_gemm_big(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;   // M >= 512 (MINIGPT4_GEMM_BIG_M)
     if (pick >= 0 && shapes[pick].arm) {
         if (launch_gemm_f16_arm(shapes[pick].arm, A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;
         if (shapes[pick].arm == 31 && launch_gemm_f16_arm(4, A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;   // K % 64: the register-staged 128x64
+        if (shapes[pick].arm == 32 && launch_gemm_big(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;
     }
     launch_gemm_t<128, 64, 64>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);
 }
@@ -737,6 +742,8 @@ __device__ __forceinline__ double block_sum_d(double v, double *red) {
 // Split-K form for the GEMMs whose N gives fewer 64x64 tiles than CUs (ViT attn.proj / mlp.fc2, the Q-Former's 768-wide layers): `slices` workgroups
 // share an output tile, each multiplies a contiguous K range and writes raw fp32 partial sums into its own slab [M][ldo]; k_splitk_reduce_ln adds
 // the slabs in a fixed order (deterministic) together with bias / residual and the LayerNorm that follows in the graph.
+// (The slice count must not depend on the number of rows: image b of a batch has to equal the same image encoded alone bit for bit, and the slices fix the order in
+// which an output element's k ranges are added.  4 images' fc2 would prefer 3 slices of 256x128 tiles -- 61 -> 48 us, profiles/r03b_gemm_batched_encode.log -- not taken.)
 int gemm_split_slices(int K, int want) { const int nk = (K + 127) / 128; int s = std::max(1, std::min(want, nk)); const int per = (nk + s - 1) / s; return (nk + per - 1) / per; }
 void launch_gemm_f16_splitk(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, int slices, float *slabs, size_t slab_stride, int ldo, hipStream_t s) {
     Tables tb{};
