@@ -122,6 +122,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     // 2: ffn_norm -> w1|w3, 3: silu(w1 x) * (w3 x) -> w2, 4: final norm -> output; bit 5: w1|w3 launch writes silu(w1 x) * (w3 x) itself
     // (row-pair epilogue); bit 6: wq|wk and a differently typed wv in one launch.  See DESIGN.md "mat-vec prologue".
     fuse_mask_ = getenv("MINIGPT4_FUSE") ? atoi(getenv("MINIGPT4_FUSE")) : FUSE_DEFAULT;
+    if (const char *dc = getenv("MINIGPT4_DEFER_COMBINE")) defer_combine_ = atoi(dc) != 0;
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
     attn_prefill_ = !(getenv("MINIGPT4_ATTN_PREFILL") && !atoi(getenv("MINIGPT4_ATTN_PREFILL")));   // 0: the per-token attention kernel also for prompt rows (A/B, tests)
     // Opt-in experiment (unmeasured at the time of writing): the w1|w3 launch also prepares w2's activation row (last-arriver per 256-row block),
@@ -527,23 +528,37 @@ void Engine::site_end(hipStream_t s) noexcept {   // called from SiteScope's des
     ev.kernel = last_kernel_name();
     ev.p1 = launch_probe_count();
 }
-bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair, const char *site) {
+// rms norm * w + quantisation of N rows of x; when x is the pending result of a deferred K-split combine (x = residual + slabs), x is formed by the same launch
+void Engine::prep_rms(const float *x, const float *w, int N, int K, int mask, hipStream_t s) {
+    if (pend_.ks > 1 && pend_.n == 1 && pend_.y[0] == x && pend_.stride == (long long)N * K) { launch_rms_quant_slabs(pend_, w, N, K, act_, mask, s); pend_ = SlabSrc{}; return; }
+    flush_pending(s);
+    launch_rms_quant(x, w, N, K, act_, mask, s);
+}
+void Engine::flush_pending(hipStream_t s) { if (pend_.ks > 1) { launch_slab_flush(pend_, s); } pend_ = SlabSrc{}; }
+bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair, const char *site, bool defer_ok) {
     bool same = true;
     int mask = 0;
     for (int i = 0; i < n; i++) { mask |= act_mask_for(W[i]->type); if (i) same = same && W[i]->type == W[0]->type && W[i]->rows == W[0]->rows && W[i]->cols == W[0]->cols; }
     const bool v2 = N == 1 && use_v2_ && same;
     fuse = fuse && v2 && prep && matvec_prologue_supported(W[0]->type, W[0]->cols);
     silu_pair = silu_pair && v2 && n == 2 && !res && matvec_silu_pair_supported(W[0]->type, W[0]->cols) && (!fuse || prep->kind == 1);
-    if (prep && !fuse) {   // standalone preparation
+    if (prep && !fuse) {   // standalone preparation -- also the consumer of a deferred split-K combine (pend_): x = residual + slabs / silu(h1) * h3 straight from the slabs
         SiteScope sc(this, "prepare", 0.0, s);
-        if (prep->kind == 1) launch_rms_quant(prep->x, prep->w, N, W[0]->cols, act_, mask, s);
-        else launch_silu_mul_quant(prep->x, prep->kind == 3 ? prep->w : nullptr, N, W[0]->cols, act_, mask, tabs_, s);
+        const int K = W[0]->cols;
+        if (prep->kind == 1) prep_rms(prep->x, prep->w, N, K, mask, s);
+        else if (pend_.ks > 1 && prep->kind == 3 && pend_.n == 2 && pend_.y[0] == prep->x && pend_.y[1] == prep->w && !pend_.res[0] && !pend_.res[1] && pend_.stride == (long long)N * K) {
+            launch_silu_mul_quant_slabs(pend_, N, K, act_, mask, tabs_, s); pend_ = SlabSrc{};
+        } else {
+            flush_pending(s);
+            launch_silu_mul_quant(prep->x, prep->kind == 3 ? prep->w : nullptr, N, K, act_, mask, tabs_, s);
+        }
     }
+    flush_pending(s);      // (nothing left unless the preparation above was fused into a mat-vec prologue or absent)
     double wbytes = 0;
     for (int i = 0; i < n; i++) wbytes += (double)W[i]->bytes;
     SiteScope sc(this, site, wbytes, s);
     bool done = false;
-    if (N >= 5 && same && mmq_enabled() >= 2) done = launch_mmq2_set(W, y, res, n, act_, N, ldy, s);   // prefill: one launch for the set, weights streamed once per <= 128 rows
+    if (N >= 5 && same && mmq_enabled() >= 2) done = launch_mmq2_set(W, y, res, n, act_, N, ldy, s, defer_ok && defer_combine_ ? &pend_ : nullptr);   // prefill: one launch for the set, weights streamed once per <= 128 rows
     if (!done && same && W[0]->type == GT_F16 && N >= 512 && act_.xh) {   // unquantised weights at prompt sizes: the set in one launch of the big MFMA GEMM, split K for wo / w2
         const __half *Wh[3]; for (int i = 0; i < n; i++) Wh[i] = reinterpret_cast<const __half *>(W[i]->qs);
         done = launch_gemm_f16_set(act_.xh, W[0]->cols, Wh, n, N, W[0]->rows, W[0]->cols, y, res, ldy, act_.ws, act_.ws_floats, n_cus_, s);
@@ -565,9 +580,9 @@ bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
     }
     return silu_pair;
 }
-void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse, const char *site) {
+void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse, const char *site, bool defer_ok) {
     const QWeight *Wp[1] = {&W}; float *Yp[1] = {y}; const float *Rp[1] = {residual};
-    mul_mat_set(Wp, Yp, Rp, 1, N, ldy, s, prep, fuse, false, site);
+    mul_mat_set(Wp, Yp, Rp, 1, N, ldy, s, prep, fuse, false, site, defer_ok);
 }
 
 // wq|wk and a differently typed wv (k-quant "more bits" layers) in one launch; returns false when the shapes / types are outside the mixed kernel's range.
@@ -662,10 +677,10 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
         const Prep p_attn{1, x_, L.attn_norm}, p_att{2, att_, nullptr}, p_ffn{1, x_, L.ffn_norm}, p_silu{3, h1_, h3_};
         {
             const QWeight *W3[3] = {&L.wq, &L.wk, &L.wv}; float *Y3[3] = {q_, k_, v_};
-            if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s, &p_attn, fz(0), false, "qkv");
+            if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s, &p_attn, fz(0), false, "qkv", !dec);   // a K-split combine is left to launch_rope_kv_slabs
             else if (fz(6) && L.wk.type == L.wq.type && mixed_qkv(L, s, fz(0))) {}
             else if (act_mask_for(L.wv.type) == act_mask_for(L.wq.type) && !fz(0)) {   // one standalone preparation serves both launches
-                launch_rms_quant(x_, L.attn_norm, N, E, act_, act_mask_for(L.wq.type), s);
+                prep_rms(x_, L.attn_norm, N, E, act_mask_for(L.wq.type), s);
                 mul_mat_set(W3, Y3, nullptr, 2, N, E, s, nullptr, false, false, "qk"); mul_mat(L.wv, N, v_, E, nullptr, s, nullptr, false, "v");
             } else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s, &p_attn, fz(0), false, "qk"); mul_mat(L.wv, N, v_, E, nullptr, s, &p_attn, fz(0), "v"); }
         }
@@ -675,21 +690,24 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
         if (dec && attn_split_now_) launch_attn_llm_split(q_, k_, v_, kc, vc, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, attn_ws_, attn_splits_, s);
         else if (dec) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, true, s);
         else {
-            launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s);
+            if (pend_.ks > 1 && pend_.n == 3 && pend_.y[0] == q_ && pend_.y[1] == k_ && pend_.y[2] == v_ && !pend_.res[0] && pend_.stride == (long long)N * E) {
+                launch_rope_kv_slabs(pend_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); pend_ = SlabSrc{};
+            } else { flush_pending(s); launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); }
             if (!(attn_prefill_ && launch_attn_prefill(q_, kc, vc, N, H, hd, d_npast, conv_[sl].n_committed + N, tabs_, att_, s)))
                 launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, false, s);
         }
         att_sc.reset();
-        mul_mat(L.wo, N, x_, E, x_, s, &p_att, fz(1), "wo");
+        mul_mat(L.wo, N, x_, E, x_, s, &p_att, fz(1), "wo", !dec);             // combine left to the ffn norm's preparation
         bool paired = false;   // h1_ already holds silu(w1 x) * (w3 x)
-        if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5), "w1w3"); }
+        if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5), "w1w3", !dec); }   // combine left to silu * mul
         else if (act_mask_for(L.w1.type) == act_mask_for(L.w3.type) && !fz(2)) {
-            launch_rms_quant(x_, L.ffn_norm, N, E, act_, act_mask_for(L.w1.type), s);
+            prep_rms(x_, L.ffn_norm, N, E, act_mask_for(L.w1.type), s);
             mul_mat(L.w1, N, h1_, F, nullptr, s, nullptr, false, "w1"); mul_mat(L.w3, N, h3_, F, nullptr, s, nullptr, false, "w3");
         } else { mul_mat(L.w1, N, h1_, F, nullptr, s, &p_ffn, fz(2), "w1"); mul_mat(L.w3, N, h3_, F, nullptr, s, &p_ffn, fz(2), "w3"); }
         const Prep p_h{2, h1_, nullptr};
-        mul_mat(L.w2, N, x_, E, x_, s, paired ? &p_h : &p_silu, fz(3), "w2");
+        mul_mat(L.w2, N, x_, E, x_, s, paired ? &p_h : &p_silu, fz(3), "w2", !dec);   // combine left to the next layer's attention norm (or flushed in front of the output matrix)
     }
+    flush_pending(s);
     // only the last token's logits are kept (llama.cpp logits_all = false)
     const Prep p_out{1, x_ + (size_t)(N - 1) * E, norm_};
     mul_mat(output_, 1, logits, V, nullptr, s, &p_out, fz(4), "output");

@@ -33,7 +33,15 @@ int mmq_enabled();
 // second-generation prefill kernels (mmq2_kernels.hip): 1..3 same-type, same-shape k-quant matrices against N >= 1 prepared rows (A.bsq required), weights streamed once per
 // chunk of <= 128 tokens, activations staged through LDS, optional K split (partial sums in A.ws) combined in fixed order.  false -> outside the kernels' range, nothing launched.
 bool mmq2_supported(int type, int rows, int cols);
-bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s);
+// A split-K mat-mul whose combine step is left to its consumer (round 3): matrix m's ks slabs of `stride` floats start m * ks * stride floats into ws; the value of an
+// element is (slab_0 + ... + slab_{ks-1}) (+ res[m]) and belongs at y[m].  ks <= 1: nothing pending.
+struct SlabSrc { const float *ws = nullptr; int ks = 0; long long stride = 0; int n = 0; float *y[3] = {nullptr, nullptr, nullptr}; const float *res[3] = {nullptr, nullptr, nullptr}; };
+void launch_slab_flush(const SlabSrc &src, hipStream_t s);                                      // the combine as its own launch (k_mmq2_reduce_set)
+void launch_rms_quant_slabs(const SlabSrc &src, const float *w, int N, int K, const ActQ &A, int mask, hipStream_t s);       // n == 1: y[0] = res[0] + slabs, then rms norm * w, quantised
+void launch_silu_mul_quant_slabs(const SlabSrc &src, int N, int K, const ActQ &A, int mask, const Tables &tb, hipStream_t s);   // n == 2: silu(a) * b, quantised
+void launch_rope_kv_slabs(const SlabSrc &src, int N, int n_head, int hd, const int *n_past, const float *cos_tab, const float *sin_tab, __half *kcache, __half *vcache, hipStream_t s);   // n == 3
+// defer != nullptr: with a K split the combine launch is skipped and *defer describes the slabs (ks > 1); otherwise *defer is cleared
+bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s, SlabSrc *defer = nullptr);
 void set_mmq2_cus(int cus);
 void set_mmq2_tuning(int tt, int fill_pct, int ks);   // experiment knobs, 0 = the launcher's choice, < 0 = leave as it is (read from the environment once, by Engine::init)
 void set_gemm_tuning(int big_min_m, int f16_ks, int arm = -1, int sk_arm = -1);      // smallest M of the 128x128 GEMM (< 0: leave), forced K split of the F16 set launches (0 = choose)

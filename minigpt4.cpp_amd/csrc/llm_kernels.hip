@@ -1501,6 +1501,48 @@ __global__ __launch_bounds__(RQ_THREADS) void k_rms_quant(const float *__restric
         quant_emit4(v, in, i, row, K, A, mask);
     }
 }
+// Consumers of a split-K mat-mul whose combine step was deferred (round 3; SlabSrc in kernels.hpp): the value of element i of matrix m is
+//     (slab_0[i] + slab_1[i] + ... + slab_{ks-1}[i]) (+ residual[i])          -- exactly k_mmq2_reduce_set's additions, in its order --
+// formed where it is consumed instead of by a launch of its own (a prompt pass had 3.5 such launches per layer: 0.73 of the 142-row pass's 11.3 ms).
+__device__ __forceinline__ float4 slab_sum4(const float *__restrict__ base, int ks, long long stride, const float *__restrict__ res, size_t i) {
+    float4 s = *reinterpret_cast<const float4 *>(base + i);
+    for (int z = 1; z < ks; z++) { const float4 t = *reinterpret_cast<const float4 *>(base + (size_t)z * stride + i); s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    if (res) { const float4 t = *reinterpret_cast<const float4 *>(res + i); s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    return s;
+}
+// x_out = residual + sum of slabs (the residual stream, materialised here), then k_rms_quant's norm + quantisation of the row
+__global__ __launch_bounds__(RQ_THREADS) void k_rms_quant_slabs(const float *__restrict__ slabs, const int ks, const long long stride, const float *res, float *x_out,
+                                                                const float *__restrict__ w, const int K, const ActQ A, const int mask) {
+    const size_t row = blockIdx.x;
+    float *xr = x_out + row * K;
+    __shared__ double red[RQ_THREADS / 64];
+    double sum = 0.0;
+    for (int i = threadIdx.x * 4; i < K; i += RQ_THREADS * 4) {
+        const float4 v = slab_sum4(slabs, ks, stride, res, row * K + i);
+        *reinterpret_cast<float4 *>(xr + i) = v;                   // re-read below by the same thread
+        sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w);
+    }
+    sum = wave_sum_d(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < RQ_THREADS / 64; i++) tot += red[i];
+    const float mean = (float)(tot / (double)K);
+    const float scale = 1.0f / sqrtf(mean + 1e-6f);
+    for (int i0 = 0; i0 < K; i0 += RQ_THREADS * 4) {
+        const int i = i0 + threadIdx.x * 4;
+        const bool in = i < K;
+        float v[4] = {0, 0, 0, 0};
+        if (in) { const float4 xv = *reinterpret_cast<const float4 *>(xr + i); const float4 wv = *reinterpret_cast<const float4 *>(w + i);
+            v[0] = (xv.x * scale) * wv.x; v[1] = (xv.y * scale) * wv.y; v[2] = (xv.z * scale) * wv.z; v[3] = (xv.w * scale) * wv.w; }
+        quant_emit4(v, in, i, row, K, A, mask);
+    }
+}
+void launch_rms_quant_slabs(const SlabSrc &src, const float *w, int N, int K, const ActQ &A, int mask, hipStream_t s) {
+    note_kernel("k_rms_quant_slabs");
+    hipLaunchKernelGGL(k_rms_quant_slabs, dim3((unsigned)N), dim3(RQ_THREADS), 0, s, src.ws, src.ks, src.stride, src.res[0], src.y[0], w, K, A, mask);
+}
 void launch_rms_quant(const float *x, const float *w, int N, int K, const ActQ &A, int mask, hipStream_t s, bool sequential_sum) {
     note_kernel("k_rms_quant");
     hipLaunchKernelGGL(k_rms_quant, dim3((unsigned)N), dim3(RQ_THREADS), 0, s, x, w, K, A, mask, sequential_sum ? 1 : 0);
@@ -1516,6 +1558,22 @@ __global__ __launch_bounds__(256) void k_silu_mul_quant(const float *__restrict_
             v[0] = tab(tb.silu, av.x) * bv.x; v[1] = tab(tb.silu, av.y) * bv.y; v[2] = tab(tb.silu, av.z) * bv.z; v[3] = tab(tb.silu, av.w) * bv.w; }
         else { v[0] = av.x; v[1] = av.y; v[2] = av.z; v[3] = av.w; } }
     quant_emit4(v, in, i, row, K, A, mask);
+}
+// a = sum of matrix 0's slabs, b = sum of matrix 1's (w1 | w3 of a prompt pass): neither product is written out
+__global__ __launch_bounds__(256) void k_silu_mul_quant_slabs(const float *__restrict__ slabs, const int ks, const long long stride, const int K, const ActQ A, const int mask, const Tables tb) {
+    const size_t row = blockIdx.y;
+    const int i = blockIdx.x * 1024 + threadIdx.x * 4;
+    const bool in = i < K;
+    float v[4] = {0, 0, 0, 0};
+    if (in) {
+        const float4 av = slab_sum4(slabs, ks, stride, nullptr, row * K + i), bv = slab_sum4(slabs + (size_t)ks * stride, ks, stride, nullptr, row * K + i);
+        v[0] = tab(tb.silu, av.x) * bv.x; v[1] = tab(tb.silu, av.y) * bv.y; v[2] = tab(tb.silu, av.z) * bv.z; v[3] = tab(tb.silu, av.w) * bv.w;
+    }
+    quant_emit4(v, in, i, row, K, A, mask);
+}
+void launch_silu_mul_quant_slabs(const SlabSrc &src, int N, int K, const ActQ &A, int mask, const Tables &tb, hipStream_t s) {
+    note_kernel("k_silu_mul_quant_slabs");
+    hipLaunchKernelGGL(k_silu_mul_quant_slabs, dim3((unsigned)((K + 1023) / 1024), (unsigned)N), dim3(256), 0, s, src.ws, src.ks, src.stride, K, A, mask, tb);
 }
 void launch_silu_mul_quant(const float *a, const float *b, int N, int K, const ActQ &A, int mask, const Tables &tb, hipStream_t s) {
     note_kernel("k_silu_mul_quant");
@@ -1579,6 +1637,29 @@ __global__ void k_rope_kv(float *__restrict__ q, const float *__restrict__ k, co
     const size_t co = (size_t)pos * E + (size_t)h * hd + 2 * i;
     *reinterpret_cast<__half2 *>(kc + co) = __floats2half2_rn(k0 * c - k1 * s, k0 * s + k1 * c);
     *reinterpret_cast<__half2 *>(vc + co) = __floats2half2_rn(v[o], v[o + 1]);
+}
+// q | k | v = the sums of the three matrices' slabs (wq | wk | wv of a prompt pass); the rotated q is written to `q` as before, k and v only to the caches
+__global__ void k_rope_kv_slabs(const float *__restrict__ slabs, const int ks, const long long stride, float *__restrict__ q, int E, int hd, const int *__restrict__ n_past,
+                                const float *__restrict__ cos_tab, const float *__restrict__ sin_tab, __half *__restrict__ kc, __half *__restrict__ vc) {
+    const int t = blockIdx.x, h = blockIdx.y, i = threadIdx.x;   // i < hd/2
+    const int pos = *n_past + t;
+    const float c = cos_tab[(size_t)pos * (hd / 2) + i], s = sin_tab[(size_t)pos * (hd / 2) + i];
+    const size_t o = (size_t)t * E + (size_t)h * hd + 2 * i;
+    float2 m[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float *b = slabs + (size_t)a * ks * stride + o;
+        float2 acc = *reinterpret_cast<const float2 *>(b);
+        for (int z = 1; z < ks; z++) { const float2 u = *reinterpret_cast<const float2 *>(b + (size_t)z * stride); acc.x += u.x; acc.y += u.y; }
+        m[a] = acc;
+    }
+    q[o] = m[0].x * c - m[0].y * s; q[o + 1] = m[0].x * s + m[0].y * c;
+    const size_t co = (size_t)pos * E + (size_t)h * hd + 2 * i;
+    *reinterpret_cast<__half2 *>(kc + co) = __floats2half2_rn(m[1].x * c - m[1].y * s, m[1].x * s + m[1].y * c);
+    *reinterpret_cast<__half2 *>(vc + co) = __floats2half2_rn(m[2].x, m[2].y);
+}
+void launch_rope_kv_slabs(const SlabSrc &src, int N, int n_head, int hd, const int *n_past, const float *cos_tab, const float *sin_tab, __half *kcache, __half *vcache, hipStream_t s) {
+    hipLaunchKernelGGL(k_rope_kv_slabs, dim3((unsigned)N, (unsigned)n_head), dim3((unsigned)(hd / 2)), 0, s, src.ws, src.ks, src.stride, src.y[0], n_head * hd, hd, n_past, cos_tab, sin_tab, kcache, vcache);
 }
 void launch_rope_kv(float *q, const float *k, const float *v, int N, int n_head, int hd, const int *n_past, const float *cos_tab, const float *sin_tab,
                     __half *kcache, __half *vcache, hipStream_t s) {

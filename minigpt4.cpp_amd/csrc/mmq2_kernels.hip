@@ -651,7 +651,15 @@ static void mmq2_launch_tt(int type, dim3 grid, size_t lds, hipStream_t s, const
 
 // 1..3 same-type, same-shape matrices against the N prepared activation rows in one launch.  y[m][t * ldy + r] (+ residual[m][..]).  false -> shape outside the
 // kernel's range (nothing launched).
-bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s) {
+void launch_slab_flush(const SlabSrc &src, hipStream_t s) {
+    if (src.ks <= 1) return;
+    const size_t n4 = (size_t)src.stride / 4;
+    ReduceSet rs{};
+    for (int i = 0; i < src.n; i++) { rs.y[i] = src.y[i]; rs.res[i] = src.res[i]; }
+    hipLaunchKernelGGL(k_mmq2_reduce_set, dim3((unsigned)((n4 + 255) / 256), (unsigned)src.n), dim3(256), 0, s, src.ws, src.ks, src.stride, rs, n4);
+}
+bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s, SlabSrc *defer) {
+    if (defer) *defer = SlabSrc{};
     if (n < 1 || n > 3 || N < 1 || (W[0]->type == GT_Q4_0 ? !(A.q80 && A.d0) : !A.bsq)) return false;
     for (int i = 0; i < n; i++) if (!mmq2_supported(W[i]->type, W[i]->rows, W[i]->cols) || W[i]->type != W[0]->type || W[i]->rows != W[0]->rows || W[i]->cols != W[0]->cols) return false;
     Mmq2Args a{};
@@ -692,10 +700,9 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     default: throw HipError{hipErrorInvalidValue, "mmq2: bad chunking", __FILE__, __LINE__};
     }
     if (ks > 1) {
-        const size_t n4 = out_floats / 4;
-        ReduceSet rs{};
-        for (int i = 0; i < n; i++) { rs.y[i] = y[i]; rs.res[i] = residual ? residual[i] : nullptr; }
-        hipLaunchKernelGGL(k_mmq2_reduce_set, dim3((unsigned)((n4 + 255) / 256), (unsigned)n), dim3(256), 0, s, A.ws, ks, (long long)out_floats, rs, n4);
+        SlabSrc src; src.ws = A.ws; src.ks = ks; src.stride = (long long)out_floats; src.n = n;
+        for (int i = 0; i < n; i++) { src.y[i] = y[i]; src.res[i] = residual ? residual[i] : nullptr; }
+        if (defer) *defer = src; else launch_slab_flush(src, s);
     }
     return true;
 }
