@@ -44,6 +44,9 @@ MINIGPT4_API int minigpt4_amd_test_gemm_f16_skinny(const float *A, const float *
 MINIGPT4_API int minigpt4_amd_bench_gemm_f16(int M, int N, int K, int flags, int variant, int iters, int n_sets, float *us_per_launch);
 /* Micro-benchmark of the ViT / Q-Former attention kernel on synthetic rows (tools/timeline_attn.py) */
 MINIGPT4_API int minigpt4_amd_bench_attn_f32(int heads, int hd, int nq, int nk, int iters, float *us_per_launch);
+/* Micro-benchmark of the prompt-row attention on a synthetic fp16 K / V cache (tools/timeline_attn_prefill.py); _timeline_attn: its stamps in a -DMG4_TIMELINE build */
+MINIGPT4_API int minigpt4_amd_bench_attn_prefill(int n_head, int hd, int N, int n_past, int iters, float *us_per_launch);
+MINIGPT4_API int minigpt4_amd_timeline_attn(unsigned long long *out, int max_workgroups);
 /* force one tile shape (an "arm" of launch_gemm_f16_arm in vision_kernels.hip; 0 = the launcher's own choice) for every small-M GEMM / split-K GEMM of this process */
 MINIGPT4_API void minigpt4_amd_test_set_gemm_arm(int arm, int sk_arm);
 /* diagnostic builds (-DMG4_TIMELINE): the 32 clock stamps per workgroup of the last image-path GEMM launch; 0 = built without */

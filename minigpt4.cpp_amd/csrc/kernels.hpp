@@ -50,7 +50,7 @@ void launch_slab_reduce(const float *slabs, int n_slabs, long long slab_stride, 
 // F16 weights at prompt sizes: 1..3 equally spaced [N][K] matrices x M fp16 rows in one launch of the 128x128 LDS-DMA GEMM (split K when the tiles do not fill the chip);
 // false -> outside this path, nothing launched
 bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n, int M, int N, int K, float *const *y, const float *const *residual, int ldo, float *ws,
-                         size_t ws_floats, int cus, hipStream_t s);
+                         size_t ws_floats, int cus, hipStream_t s, SlabSrc *defer = nullptr);
 
 // decode (N = 1) persistent-wave mat-vec over 1..3 same-type, same-shape matrices (wq|wk|wv, w1|w3); false -> caller falls back to launch_mul_mat
 // pro: 0 = activations come from `A` (prepared by launch_rms_quant / launch_silu_mul_quant); 1 = rms_norm(px) * pw, 2 = px, 3 = silu(px) * pw are
@@ -77,6 +77,7 @@ void reset_kernel_name();
 size_t launch_probe_count();                       // launches noted (and probed with their own start / stop events) since tracing was switched on
 float launch_probe_us(size_t first, size_t last);  // sum of the dispatch durations of probes [first, last) in microseconds (stream synchronised); < 0: not available
 int read_matvec_timeline(unsigned long long *out, int max_workgroups);   // diagnostic builds (MG4_TIMELINE): stamps of the last decode mat-vec launch; 0 otherwise
+int read_attn_timeline(unsigned long long *out, int max_workgroups);     // prompt attention (8 x u64 per workgroup, up to 2048 workgroups)
 int read_vision_timeline(unsigned long long *out, int max_workgroups);   // the same for the image path's kernels (32 x u64 per workgroup)
 
 // ---- token embedding gather (raw ggml rows, dequantised to f32) -----------------------------------------------------

@@ -667,7 +667,11 @@ __device__ unsigned long long g_tl[1024 * 8];
 #define MG4_TL(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_tl[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // slots 6 / 7: the LATEST end / entry over all waves of the workgroup (the clock only grows, so atomicMax needs no reset between launches)
 #define MG4_TL_ALL(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) atomicMax(&g_tl[blockIdx.x * 8 + (i)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+// the prompt attention's own slots (workgroup = blockIdx.x + gridDim.x * blockIdx.y): 0 entry, 1 scores done, 2 softmax done, 3 P.V done, 4 stored
+__device__ unsigned long long g_tla[2048 * 8];
+#define MG4_TLP(i) do { const unsigned lb_ = blockIdx.x + gridDim.x * blockIdx.y; if (threadIdx.x == 0 && lb_ < 2048) g_tla[lb_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
+#define MG4_TLP(i) do {} while (0)
 #define MG4_TL(i) do {} while (0)
 #define MG4_TL_ALL(i) do {} while (0)
 #endif
@@ -916,6 +920,15 @@ static bool launch_v2_type(const MatSet &ms, const ActQ &A, int pro, const ProAr
     return ok;
 }
 // copies the timeline stamps of the last decode mat-vec launch (8 x u64 per workgroup); 0 when the library was built without MG4_TIMELINE
+int read_attn_timeline(unsigned long long *out, int max_workgroups) {
+#ifdef MG4_TIMELINE
+    const int n = std::min(max_workgroups, 2048);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tla), (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return n;
+#else
+    (void)out; (void)max_workgroups; return 0;
+#endif
+}
 int read_matvec_timeline(unsigned long long *out, int max_workgroups) {
 #ifdef MG4_TIMELINE
     const int n = std::min(max_workgroups, 1024);
@@ -2196,6 +2209,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill_h(const float *__restrict_
     __half *Vt = Kt + AP_KT * HD;                                 // [HD][APH_LDT]
     // causal: the LAST query tile sees the most keys -- it is dispatched first (longest-first), so the short tiles fill the tail of the launch
     const int h = blockIdx.x, q0 = (int)(gridDim.y - 1 - blockIdx.y) * QT, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    MG4_TLP(0);
     const int np = *n_past;
     const int T = np + min(q0 + QT - 1, N - 1) + 1;               // keys the last query of this tile sees
     const int nkt = (T + AP_KT - 1) / AP_KT;
@@ -2243,26 +2257,57 @@ __global__ __launch_bounds__(256) void k_attn_prefill_h(const float *__restrict_
         }
     }
     __syncthreads();
+    MG4_TLP(1);
 #pragma unroll
-    for (int qs = 0; qs < QS; qs++) {   // softmax: 16 lanes per query row; row r sees keys 0 .. np + q0 + r  (k_attn_prefill's code)
+    for (int qs = 0; qs < QS; qs++) {
+        // softmax: 16 lanes per query row, lane `sub` owns the keys 64 s + 4 sub .. + 3 (16-byte LDS accesses); row r sees keys 0 .. np + q0 + r.  Same values as
+        // k_attn_prefill's loop (max, fp16-table exp, exact double sum -- order-free --, p = fp16(e * (1 / sum))); what changed in round 3 is the shape: the timeline
+        // had this phase at 15 of a workgroup's 35 us -- 16 dependent rounds of 4 table gathers per row pass -- now 16 gathers are in flight per round.
         const int row = 16 * qs + (tid >> 4), sub = tid & 15;
-        const int Tq = min(np + q0 + row + 1, T);
+        const int Tq = min(np + q0 + row + 1, T), nb = nkt * AP_KT;
         float *sr = S + (size_t)row * LS;
         float mx = -INFINITY;
-        for (int j = sub; j < Tq; j += 16) mx = fmaxf(mx, sr[j]);
+        for (int j = 4 * sub; j < nb; j += 64) {
+            const float4 v = *reinterpret_cast<const float4 *>(sr + j);
+            mx = fmaxf(mx, j < Tq ? v.x : -INFINITY); mx = fmaxf(mx, j + 1 < Tq ? v.y : -INFINITY); mx = fmaxf(mx, j + 2 < Tq ? v.z : -INFINITY); mx = fmaxf(mx, j + 3 < Tq ? v.w : -INFINITY);
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 8));
         double sum = 0.0;
-        for (int j0 = sub; j0 < Tq; j0 += 64) {
-            float e[4];
+        for (int j0 = 0; j0 < nb; j0 += 256) {
+            float x[16]; unsigned short t[16];
 #pragma unroll
-            for (int u = 0; u < 4; u++) e[u] = tab(tb.exp, sr[min(j0 + 16 * u, Tq - 1)] - mx);
+            for (int u = 0; u < 4; u++) {
+                const int jj = min(j0 + 64 * u, nb - 64) + 4 * sub;          // a block past the end repeats the last one (its values are dropped below)
+                const float4 v = *reinterpret_cast<const float4 *>(sr + jj);
+                x[4 * u] = v.x; x[4 * u + 1] = v.y; x[4 * u + 2] = v.z; x[4 * u + 3] = v.w;
+            }
+            // (the table stays in global memory: an LDS copy -- 39 KB by LDS-DMA per workgroup -- left this phase at 8.0 us against 7.7 and cost the 142-row launch its
+            //  co-resident workgroups, 11.3 -> 15.1 us: the phase is bound by its ~30 vector instructions per element, not by the gathers)
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int j = j0 + 16 * u; if (j < Tq) { sr[j] = e[u]; sum += (double)e[u]; } }
+            for (int e = 0; e < 16; e++) {
+                const int jj = j0 + 64 * (e >> 2) + 4 * sub + (e & 3);
+                t[e] = reinterpret_cast<const unsigned short *>(tb.exp)[f2h_bits(jj < Tq ? x[e] - mx : 0.0f)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int jj = j0 + 64 * u + 4 * sub;
+                if (j0 + 64 * u < nb) {                                       // uniform over the 16 lanes of a row
+                    float4 ev;
+                    ev.x = jj < Tq ? h2f_bits(t[4 * u]) : 0.0f; ev.y = jj + 1 < Tq ? h2f_bits(t[4 * u + 1]) : 0.0f; ev.z = jj + 2 < Tq ? h2f_bits(t[4 * u + 2]) : 0.0f; ev.w = jj + 3 < Tq ? h2f_bits(t[4 * u + 3]) : 0.0f;
+                    sum += (double)ev.x; sum += (double)ev.y; sum += (double)ev.z; sum += (double)ev.w;
+                    *reinterpret_cast<float4 *>(sr + jj) = ev;
+                }
+            }
         }
         sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
         const float inv = (float)(1.0 / sum);
-        for (int j = sub; j < nkt * AP_KT; j += 16) sr[j] = j < Tq ? f16r(sr[j] * inv) : 0.0f;
+        for (int j = 4 * sub; j < nb; j += 64) {                             // keys past the row's limit already hold 0
+            float4 v = *reinterpret_cast<const float4 *>(sr + j);
+            v.x = f16r(v.x * inv); v.y = f16r(v.y * inv); v.z = f16r(v.z * inv); v.w = f16r(v.w * inv);
+            *reinterpret_cast<float4 *>(sr + j) = v;
+        }
     }
+    MG4_TLP(2);
     constexpr int DPW = (DT + 3) / 4;
     pf4_t oacc[QS][DPW];
 #pragma unroll
@@ -2308,6 +2353,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill_h(const float *__restrict_
             }
         }
     }
+    MG4_TLP(3);
 #pragma unroll
     for (int qs = 0; qs < QS; qs++)
 #pragma unroll
@@ -2321,6 +2367,10 @@ __global__ __launch_bounds__(256) void k_attn_prefill_h(const float *__restrict_
                 }
             }
         }
+#ifdef MG4_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MG4_TLP(4);
+#endif
 }
 static int g_attn_prefill_f16 = 1;   // 1: prompt attention on the fp16 matrix cores (k_attn_prefill_h), 0: the exact-f32 MFMA kernel (k_attn_prefill); MINIGPT4_ATTN_PREFILL_F16, read by Engine::init
 void set_attn_prefill_f16(int v) { g_attn_prefill_f16 = v != 0; }

@@ -313,6 +313,35 @@ int minigpt4_amd_bench_attn_f32(int heads, int hd, int nq, int nk, int iters, fl
         return 0;
     });
 }
+// Micro-benchmark of the prompt-row attention (launch_attn_prefill): N query rows at positions n_past .. n_past + N - 1 of an fp16 K / V cache filled with synthetic rows
+int minigpt4_amd_bench_attn_prefill(int n_head, int hd, int N, int n_past, int iters, float *us_per_launch) {
+    if (n_head < 1 || !attn_head_size_supported(hd) || N < 2 || n_past < 0 || iters < 1) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const int E = n_head * hd, T = n_past + N;
+        DevBuf dq((size_t)N * E * 4), dk((size_t)T * E * 2), dv((size_t)T * E * 2), dout((size_t)N * E * 4), dtab(65536 * 2), dnp(4);
+        { std::vector<float> h((size_t)N * E); for (size_t i = 0; i < h.size(); i++) h[i] = (float)((int)(i * 2654435761u % 2001u) - 1000) / 4000.0f; HIP_CHECK(hipMemcpy(dq.p, h.data(), h.size() * 4, hipMemcpyHostToDevice)); }
+        { std::vector<__half> h((size_t)T * E); for (size_t i = 0; i < h.size(); i++) h[i] = __float2half_rn((float)((int)(i * 40503u % 1001u) - 500) / 500.0f);
+          HIP_CHECK(hipMemcpy(dk.p, h.data(), h.size() * 2, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(dv.p, h.data(), h.size() * 2, hipMemcpyHostToDevice)); }
+        { std::vector<__half> e(65536); for (int i = 0; i < 65536; i++) e[(size_t)i] = __float2half_rn(expf(__half2float(__ushort_as_half((unsigned short)i)))); HIP_CHECK(hipMemcpy(dtab.p, e.data(), 131072, hipMemcpyHostToDevice)); }
+        HIP_CHECK(hipMemcpy(dnp.p, &n_past, 4, hipMemcpyHostToDevice));
+        Tables tb; tb.exp = dtab.as<__half>();
+        { int nneg = 0; for (int c = 0x8000; c < 0xFC00; c++) { if (__half2float(__float2half_rn(expf(__half2float(__ushort_as_half((unsigned short)c))))) == 0.0f) break; nneg++; } tb.exp_neg_n = (nneg + 2047) / 2048 * 2048; }
+        auto run = [&]() { return launch_attn_prefill(dq.as<float>(), dk.as<__half>(), dv.as<__half>(), N, n_head, hd, dnp.as<int>(), T, tb, dout.as<float>(), nullptr); };
+        for (int i = 0; i < 3; i++) if (!run()) return 4;
+        HIP_CHECK(hipDeviceSynchronize());
+        hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+        HIP_CHECK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; i++) run();
+        HIP_CHECK(hipEventRecord(b, nullptr));
+        HIP_CHECK(hipDeviceSynchronize());
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b));
+        if (us_per_launch) *us_per_launch = ms * 1e3f / (float)iters;
+        return 0;
+    });
+}
+int minigpt4_amd_timeline_attn(unsigned long long *out, int max_workgroups) { return (out && max_workgroups > 0) ? read_attn_timeline(out, max_workgroups) : -1; }
 void minigpt4_amd_test_set_gemm_arm(int arm, int sk_arm) { set_gemm_tuning(-1, 0, arm, sk_arm); }
 int minigpt4_amd_timeline_vision(unsigned long long *out, int max_workgroups) { return (out && max_workgroups > 0) ? read_vision_timeline(out, max_workgroups) : -1; }
 

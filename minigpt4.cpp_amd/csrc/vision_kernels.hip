@@ -525,7 +525,8 @@ static bool launch_gemm_big(const __half *A, int lda, const __half *W, int ldw, 
 // ONE launch; y[m] are [M][ldo] fp32 (+ residual[m]).  With fewer column x row tiles than 2 per CU the K range is split (partial slabs in `ws`, combined in fixed
 // order by launch_slab_reduce).  false: shape outside this path (nothing launched) -- the caller multiplies matrix by matrix.
 bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n, int M, int N, int K, float *const *y, const float *const *residual, int ldo, float *ws,
-                         size_t ws_floats, int cus, hipStream_t s) {
+                         size_t ws_floats, int cus, hipStream_t s, SlabSrc *defer) {
+    if (defer) *defer = SlabSrc{};
     if (n < 1 || n > 3 || N % 128 || K % 64) return false;
     const long long wstride = n > 1 ? W[1] - W[0] : 0, ystride = n > 1 ? y[1] - y[0] : 0;
     for (int i = 2; i < n; i++) if (W[i] - W[i - 1] != wstride || y[i] - y[i - 1] != ystride) return false;
@@ -544,7 +545,8 @@ bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n
         const GemmSet gs{n > 1 ? N : 0, wstride, ystride, 0, 0};
         if (ks > 1) {
             if (launch_gemm_dma_t<256, 128, 2, 2, 1, 3>(A, lda, W[0], K, M, N, K, nullptr, nullptr, false, tb, ws, nullptr, ldo, s, ks, out_floats, gs)) {
-                launch_slab_reduce(ws, ks, (long long)out_floats, residual ? residual[0] : nullptr, y[0], out_floats, s);
+                if (defer) { defer->ws = ws; defer->ks = ks; defer->stride = (long long)out_floats; defer->n = 1; defer->y[0] = y[0]; defer->res[0] = residual ? residual[0] : nullptr; }   // combined by the consumer
+                else launch_slab_reduce(ws, ks, (long long)out_floats, residual ? residual[0] : nullptr, y[0], out_floats, s);
                 return true;
             }
         } else {
