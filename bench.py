@@ -278,11 +278,19 @@ def main():
         enc_batch = {"error": str(e)}
 
     # ---- prefill: system prompt + image turn (reference call sequence, examples/main.cpp:207-293)
-    t0 = time.perf_counter()
-    lib.minigpt4_system_prompt(ctx)
-    lib.minigpt4_begin_chat_image(ctx, emb, PROMPT)
-    lib.library.minigpt4_amd_sync(ctx.ptr)
-    prefill_ms = (time.perf_counter() - t0) * 1e3
+    # twice: the first pass of a process also loads the prompt kernels' code objects and sets their attributes (reported as prefill_first_ms); the chat is reset in between
+    prefill_first_ms = None
+    for _pass in range(2):
+        if _pass:
+            lib.minigpt4_reset_chat(ctx)
+        lib.library.minigpt4_amd_sync(ctx.ptr)
+        t0 = time.perf_counter()
+        lib.minigpt4_system_prompt(ctx)
+        lib.minigpt4_begin_chat_image(ctx, emb, PROMPT)
+        lib.library.minigpt4_amd_sync(ctx.ptr)
+        prefill_ms = (time.perf_counter() - t0) * 1e3
+        if not _pass:
+            prefill_first_ms = prefill_ms
     n_prompt = lib.library.minigpt4_amd_n_past(ctx.ptr)
 
     # ---- decode: W untimed + K timed greedy steps through the C ABI (EOS ignored so exactly K tokens are produced)
@@ -357,7 +365,7 @@ def main():
         "config": {"workload": {"13b": "MiniGPT4-13B f16 vision + Vicuna-13B Q5_K_M (wv/w2 Q6_K in 'more-bits' layers, output Q6_K), batch 1 per GPU, greedy decode through the C ABI",
                                 "7b": "MiniGPT4-7B f16 vision + Vicuna-7B Q4_0 (output Q6_K), batch 1 per GPU", "tiny": "tiny smoke-test model"}[args.config],
                    "n_ctx": args.n_ctx, "prompt_tokens": n_prompt, "context_at_mid_run": ctx_mid, "parallelism": f"dp{world} (independent replicas)"},
-        "image_encode_ms": image_encode_ms, "image_encode_device_ms": image_encode_dev_ms, "image_encode_batched": enc_batch, "prefill_ms": prefill_ms, "prefill_tokens": n_prompt,
+        "image_encode_ms": image_encode_ms, "image_encode_device_ms": image_encode_dev_ms, "image_encode_batched": enc_batch, "prefill_ms": prefill_ms, "prefill_first_ms": prefill_first_ms, "prefill_tokens": n_prompt,
         "device_ms_per_token_graph_loop": dev_ms_per_tok, "device_tokens_per_s_graph_loop": 1e3 / dev_ms_per_tok,
         "weight_bytes_per_token": wbytes, "decode_weight_GBps_end_to_end": wbytes * K / dt / 1e9,
         "model_load_s": load_s, "recv_load_s": recv_load_s, "weight_bcast_ms": bcast_ms,

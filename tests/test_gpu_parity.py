@@ -193,13 +193,13 @@ def test_gemm_f16_mfma(gpu_lib, shape, gelu):
         assert _rel(got, ref) < 2e-5
 
 
-GEMM_ARMS = [3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31]
+GEMM_ARMS = [3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 38, 39]
 
 
 @pytest.mark.parametrize("arm", GEMM_ARMS)
 def test_gemm_f16_tile_shapes_are_bit_identical(gpu_lib, arm):
     """Every tile shape of the small-M fp16 GEMM (register-staged k_gemm_f16 arms 3..14, LDS-DMA ring k_gemm_dma arms 20..31; vision_kernels.hip launch_gemm_f16_arm)
-    accumulates an output element over k in the same order, so on ragged shapes (M = 257, N not a tile multiple, one and several k tiles) each arm must reproduce the default
+    (arms 32..39: the 128x128 / 256x128 / 256x256 tiles of the large-M and F16 set launches) accumulates an output element over k in the same order, so on ragged shapes (M = 257, N not a tile multiple, one and several k tiles) each arm must reproduce the default
     launch bit for bit, GELU epilogue included; a shape outside an arm's range (K % 64) falls back to the default and is trivially equal."""
     import ctypes
     L = gpu_lib.library
