@@ -123,6 +123,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     // (row-pair epilogue); bit 6: wq|wk and a differently typed wv in one launch.  See DESIGN.md "mat-vec prologue".
     fuse_mask_ = getenv("MINIGPT4_FUSE") ? atoi(getenv("MINIGPT4_FUSE")) : FUSE_DEFAULT;
     if (const char *dc = getenv("MINIGPT4_DEFER_COMBINE")) defer_combine_ = atoi(dc) != 0;
+    if (const char *bs = getenv("MINIGPT4_BATCH_SETS")) batch_sets_ = atoi(bs) != 0;
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
     attn_prefill_ = !(getenv("MINIGPT4_ATTN_PREFILL") && !atoi(getenv("MINIGPT4_ATTN_PREFILL")));   // 0: the per-token attention kernel also for prompt rows (A/B, tests)
     // Opt-in experiment (unmeasured at the time of writing): the w1|w3 launch also prepares w2's activation row (last-arriver per 256-row block),
@@ -773,6 +774,25 @@ void Engine::forward_batch(int B, hipStream_t s) {
             float *y1[2] = {q_, k_}, *y2[1] = {v_};
             return launch_matvec_rows_mixed(W1, y1, 2, W2, y2, 1, act_, B, E, s, pro ? x_ : nullptr, pro ? L.attn_norm : nullptr, E);
         };
+        if (B > batch_rows_max_ && batch_sets_) {
+            // More conversations than the multi-row mat-vec takes (5 ... 32): the prompt pass's launches -- one int8-MFMA launch per matrix SET, row preparations that also
+            // combine a K-split predecessor (pend_), i.e. 11 launches per layer instead of the 19 of one launch + one combine per matrix (round 3).
+            const Prep p_attn{1, x_, L.attn_norm}, p_att{2, att_, nullptr}, p_ffn{1, x_, L.ffn_norm}, p_silu{3, h1_, h3_};
+            const QWeight *W3[3] = {&L.wq, &L.wk, &L.wv}; float *Y3[3] = {q_, k_, v_};
+            if (L.wv.type == L.wq.type && L.wk.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, B, E, s, &p_attn, false, false, "qkv");
+            else {
+                prep_rms(x_, L.attn_norm, B, E, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s);
+                if (L.wk.type == L.wq.type) { mul_mat_set(W3, Y3, nullptr, 2, B, E, s, nullptr, false, false, "qk"); mul_mat(L.wv, B, v_, E, nullptr, s, nullptr, false, "v"); }
+                else { mul_mat(L.wq, B, q_, E, nullptr, s, nullptr, false, "q"); mul_mat(L.wk, B, k_, E, nullptr, s, nullptr, false, "k"); mul_mat(L.wv, B, v_, E, nullptr, s, nullptr, false, "v"); }
+            }
+            flush_pending(s);
+            launch_attn_llm_batched(q_, k_, v_, kc, vc, B, H, hd, d_npast_, d_bslot_, seq_stride, n_ctx_, cos_, sin_, tabs_, att_, s);
+            mul_mat(L.wo, B, x_, E, x_, s, &p_att, false, "wo", true);
+            if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; mul_mat_set(W2, Y2, nullptr, 2, B, F, s, &p_ffn, false, false, "w1w3", true); }
+            else { prep_rms(x_, L.ffn_norm, B, E, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s); mul_mat(L.w1, B, h1_, F, nullptr, s, nullptr, false, "w1"); mul_mat(L.w3, B, h3_, F, nullptr, s, nullptr, false, "w3"); }
+            mul_mat(L.w2, B, x_, E, x_, s, &p_silu, false, "w2", true);
+            continue;
+        }
         if (L.wv.type == L.wq.type && L.wk.type == L.wq.type && rows_pro({&L.wq, &L.wk, &L.wv})) mm({&L.wq, &L.wk, &L.wv}, {q_, k_, v_}, nullptr, E, x_, L.attn_norm);
         else if (L.wk.type == L.wq.type && rows_pro({&L.wq, &L.wk}) && rows_pro({&L.wv})) {
             if (!qkv_mixed(true)) { mm({&L.wq, &L.wk}, {q_, k_}, nullptr, E, x_, L.attn_norm); mm({&L.wv}, {v_}, nullptr, E, x_, L.attn_norm); }
@@ -795,7 +815,7 @@ void Engine::forward_batch(int B, hipStream_t s) {
         launch_silu_mul_quant(h1_, h3_, B, F, act_, act_mask_for(L.w2.type), tabs_, s);
         mm({&L.w2}, {x_}, x_, E);
     }
-    launch_rms_quant(x_, norm_, B, E, act_, act_mask_for(output_.type), s);
+    prep_rms(x_, norm_, B, E, act_mask_for(output_.type), s);                 // (also combines the last layer's w2 slabs when its combine was deferred)
     mm({&output_}, {blogits_}, nullptr, V);
     launch_batch_finish(blogits_, V, B, d_bslot_, d_npast_, d_argmax_, d_feed_, logits_, s);
 }
