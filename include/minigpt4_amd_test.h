@@ -44,6 +44,8 @@ MINIGPT4_API int minigpt4_amd_test_gemm_f16_skinny(const float *A, const float *
 MINIGPT4_API int minigpt4_amd_bench_gemm_f16(int M, int N, int K, int flags, int variant, int iters, int n_sets, float *us_per_launch);
 /* Micro-benchmark of the ViT / Q-Former attention kernel on synthetic rows (tools/timeline_attn.py) */
 MINIGPT4_API int minigpt4_amd_bench_attn_f32(int heads, int hd, int nq, int nk, int iters, float *us_per_launch);
+/* the F16 feed-forward pair launch: out_h[N][n_out] = fp16(silu_table(w1 x) * (w3 x)) (uint16 bit patterns), w = w1 then w3 as fp16 [n_out][n_in]; 4 = shape outside the path */
+MINIGPT4_API int minigpt4_amd_test_f16_silu_pair(const float *x, const void *w_f16, int64_t N, int64_t n_in, int64_t n_out, unsigned short *out_h, float *out_f);
 /* Micro-benchmark of the prompt-row attention on a synthetic fp16 K / V cache (tools/timeline_attn_prefill.py); _timeline_attn: its stamps in a -DMG4_TIMELINE build */
 MINIGPT4_API int minigpt4_amd_bench_attn_prefill(int n_head, int hd, int N, int n_past, int iters, float *us_per_launch);
 MINIGPT4_API int minigpt4_amd_timeline_attn(unsigned long long *out, int max_workgroups);

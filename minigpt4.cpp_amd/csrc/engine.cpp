@@ -124,6 +124,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     fuse_mask_ = getenv("MINIGPT4_FUSE") ? atoi(getenv("MINIGPT4_FUSE")) : FUSE_DEFAULT;
     if (const char *dc = getenv("MINIGPT4_DEFER_COMBINE")) defer_combine_ = atoi(dc) != 0;
     if (const char *bs = getenv("MINIGPT4_BATCH_SETS")) batch_sets_ = atoi(bs) != 0;
+    if (const char *fp = getenv("MINIGPT4_F16_PAIR")) f16_pair_ = atoi(fp) != 0;
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
     attn_prefill_ = !(getenv("MINIGPT4_ATTN_PREFILL") && !atoi(getenv("MINIGPT4_ATTN_PREFILL")));   // 0: the per-token attention kernel also for prompt rows (A/B, tests)
     // Opt-in experiment (unmeasured at the time of writing): the w1|w3 launch also prepares w2's activation row (last-arriver per 256-row block),
@@ -537,6 +538,7 @@ void Engine::prep_rms(const float *x, const float *w, int N, int K, int mask, hi
 }
 void Engine::flush_pending(hipStream_t s) { if (pend_.ks > 1) { launch_slab_flush(pend_, s); } pend_ = SlabSrc{}; }
 bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair, const char *site, bool defer_ok) {
+    struct ClearOverride { const __half *&p; ~ClearOverride() { p = nullptr; } } clear_override{xh_override_};   // valid for exactly one call
     bool same = true;
     int mask = 0;
     for (int i = 0; i < n; i++) { mask |= act_mask_for(W[i]->type); if (i) same = same && W[i]->type == W[0]->type && W[i]->rows == W[0]->rows && W[i]->cols == W[0]->cols; }
@@ -562,7 +564,8 @@ bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
     if (N >= 5 && same && mmq_enabled() >= 2) done = launch_mmq2_set(W, y, res, n, act_, N, ldy, s, defer_ok && defer_combine_ ? &pend_ : nullptr);   // prefill: one launch for the set, weights streamed once per <= 128 rows
     if (!done && same && W[0]->type == GT_F16 && N >= 512 && act_.xh) {   // unquantised weights at prompt sizes: the set in one launch of the big MFMA GEMM, split K for wo / w2
         const __half *Wh[3]; for (int i = 0; i < n; i++) Wh[i] = reinterpret_cast<const __half *>(W[i]->qs);
-        done = launch_gemm_f16_set(act_.xh, W[0]->cols, Wh, n, N, W[0]->rows, W[0]->cols, y, res, ldy, act_.ws, act_.ws_floats, n_cus_, s, defer_ok && defer_combine_ ? &pend_ : nullptr);
+        const __half *Ain = !prep && xh_override_ ? xh_override_ : act_.xh;     // rows some launch left in fp16 elsewhere (the feed-forward pair's epilogue)
+        done = launch_gemm_f16_set(Ain, W[0]->cols, Wh, n, N, W[0]->rows, W[0]->cols, y, res, ldy, act_.ws, act_.ws_floats, n_cus_, s, defer_ok && defer_combine_ ? &pend_ : nullptr);
     }
     if (!done && silu_pair) {   // the pair epilogue needs the two matrices equally spaced; launch_matvec_set refuses otherwise and the plain launch below runs
         done = fuse ? launch_matvec_set(W, y, res, n, act_, s, prep->kind, prep->x, prep->w, &tabs_, 1) : launch_matvec_set(W, y, res, n, act_, s, 0, nullptr, nullptr, &tabs_, 1);
@@ -700,6 +703,20 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
         att_sc.reset();
         mul_mat(L.wo, N, x_, E, x_, s, &p_att, fz(1), "wo", !dec);             // combine left to the ffn norm's preparation
         bool paired = false;   // h1_ already holds silu(w1 x) * (w3 x)
+        // F16 weights at prompt sizes: w1 | w3 in one launch whose epilogue stores fp16(silu(w1 x) * (w3 x)) -- the rows w2 multiplies -- into h1_'s memory (round 3)
+        bool pair16 = false;
+        if (!dec && f16_pair_ && N >= 512 && L.w1.type == GT_F16 && L.w3.type == GT_F16 && L.w1.rows == L.w3.rows && L.w1.cols == L.w3.cols && act_.xh &&
+            L.w2.type == GT_F16 && E % 128 == 0 && F % 64 == 0) {   // (w2's set launch must take the fp16 rows: its own shape conditions)
+            prep_rms(x_, L.ffn_norm, N, E, act_mask_for(GT_F16), s);
+            SiteScope sc(this, "w1w3", (double)(L.w1.bytes + L.w3.bytes), s);
+            pair16 = launch_gemm_f16_silu_pair(act_.xh, E, reinterpret_cast<const __half *>(L.w1.qs), reinterpret_cast<const __half *>(L.w3.qs), N, F, E, tabs_, nullptr,
+                                               reinterpret_cast<__half *>(h1_), F, n_cus_, s);
+        }
+        if (pair16) {
+            xh_override_ = reinterpret_cast<const __half *>(h1_);
+            mul_mat(L.w2, N, x_, E, x_, s, nullptr, false, "w2", true);
+            continue;
+        }
         if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5), "w1w3", !dec); }   // combine left to silu * mul
         else if (act_mask_for(L.w1.type) == act_mask_for(L.w3.type) && !fz(2)) {
             prep_rms(x_, L.ffn_norm, N, E, act_mask_for(L.w1.type), s);

@@ -49,6 +49,7 @@ void set_f16_gemm(int v);                             // F16 language-model weig
 void launch_slab_reduce(const float *slabs, int n_slabs, long long slab_stride, const float *residual, float *y, size_t n, hipStream_t s);   // y = (residual +) sum_z slab_z, fixed order
 // F16 weights at prompt sizes: 1..3 equally spaced [N][K] matrices x M fp16 rows in one launch of the 128x128 LDS-DMA GEMM (split K when the tiles do not fill the chip);
 // false -> outside this path, nothing launched
+bool launch_gemm_f16_silu_pair(const __half *A, int lda, const __half *W1, const __half *W3, int M, int N, int K, const Tables &tb, float *out, __half *out_h, int ldo, int cus, hipStream_t s);   // fp16(silu(A.W1^T) * (A.W3^T)) in one launch (F16 w1|w3 at prompt sizes)
 bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n, int M, int N, int K, float *const *y, const float *const *residual, int ldo, float *ws,
                          size_t ws_floats, int cus, hipStream_t s, SlabSrc *defer = nullptr);
 

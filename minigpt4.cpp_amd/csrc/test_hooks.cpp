@@ -313,6 +313,28 @@ int minigpt4_amd_bench_attn_f32(int heads, int hd, int nq, int nk, int iters, fl
         return 0;
     });
 }
+// The F16 feed-forward pair launch (launch_gemm_f16_silu_pair): x [N][n_in] fp32 (rounded to fp16 as the engine's row preparation does), w = w1 then w3, each [n_out][n_in]
+// fp16; out_h [N][n_out] = fp16(silu_table(w1 x) * (w3 x)) as uint16 bit patterns, out_f (optional) the fp32 product before the rounding
+int minigpt4_amd_test_f16_silu_pair(const float *x, const void *w_f16, int64_t N, int64_t n_in, int64_t n_out, unsigned short *out_h, float *out_f) {
+    if (!x || !w_f16 || !out_h || N <= 0 || n_in <= 0 || n_out <= 0) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const size_t nx = (size_t)(N * n_in), nw = (size_t)(n_in * n_out), no = (size_t)(N * n_out);
+        DevBuf dx(nx * 4), dxh(nx * 2), dw(nw * 2 * 2), dh(no * 2), df(no * 4), dtab(65536 * 2);
+        HIP_CHECK(hipMemcpy(dx.p, x, nx * 4, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(dw.p, w_f16, nw * 4, hipMemcpyHostToDevice));
+        { std::vector<__half> si(65536); for (int i = 0; i < 65536; i++) { const float v = __half2float(__ushort_as_half((unsigned short)i)); si[(size_t)i] = __float2half_rn(v / (1.0f + expf(-v))); }
+          HIP_CHECK(hipMemcpy(dtab.p, si.data(), 131072, hipMemcpyHostToDevice)); }
+        launch_f32_to_f16(dx.as<float>(), dxh.as<__half>(), nx, nullptr);
+        Tables tb; tb.silu = dtab.as<__half>();
+        hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0));
+        if (!launch_gemm_f16_silu_pair(dxh.as<__half>(), (int)n_in, dw.as<__half>(), dw.as<__half>() + nw, (int)N, (int)n_out, (int)n_in, tb, df.as<float>(), dh.as<__half>(), (int)n_out,
+                                       prop.multiProcessorCount, nullptr)) return 4;
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(out_h, dh.p, no * 2, hipMemcpyDeviceToHost));
+        if (out_f) HIP_CHECK(hipMemcpy(out_f, df.p, no * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
 // Micro-benchmark of the prompt-row attention (launch_attn_prefill): N query rows at positions n_past .. n_past + N - 1 of an fp16 K / V cache filled with synthetic rows
 int minigpt4_amd_bench_attn_prefill(int n_head, int hd, int N, int n_past, int iters, float *us_per_launch) {
     if (n_head < 1 || !attn_head_size_supported(hd) || N < 2 || n_past < 0 || iters < 1) return 1;

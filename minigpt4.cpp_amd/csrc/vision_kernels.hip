@@ -10,6 +10,7 @@
 
 namespace mg4 {
 
+static int g_gemm_arm = 0, g_gemm_sk_arm = 0;   // experiments: force one tile shape for every small-M GEMM / split-K GEMM (MINIGPT4_GEMM_ARM / _SK_ARM, read once by Engine::init); 0 = choose, -2 = the 64x64 launch always, -3 = round 2's kernels everywhere (64x64 tiles, 128x128 large-M kernel)
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 typedef unsigned v4u_g __attribute__((ext_vector_type(4)));
@@ -220,7 +221,10 @@ typedef __attribute__((address_space(3))) void *g_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *g_glb_ptr_t;
 // several equally spaced, equally shaped weight matrices in one launch (column tile -> matrix), and / or a K range split over grid.z with one fp32 slab per slice
 struct GemmSet { int n_per_mat; long long w_mat_stride, out_mat_stride; int k_per_slice; long long slab_stride; };   // all zero: one matrix, whole K
-template <int BM, int BN, int TM, int TN, int KT, int S, bool GELU, bool RES>
+// PAIR (TN = 2, no GELU / residual): the feed-forward pair of an F16 language model in one tile -- the BN tile columns are 32-column blocks taken alternately from W
+// (w1) and W + gs.w_mat_stride (w3), rows n0 .. of both, so a wave's two column tiles hold (w1 x)[r][c] and (w3 x)[r][c] for the SAME (r, c) and the epilogue stores
+// fp16(silu_table(w1 x) * (w3 x)) -- the row w2 multiplies -- instead of the two fp32 products (56 MB written and read back per 512-row layer, and a launch).
+template <int BM, int BN, int TM, int TN, int KT, int S, bool GELU, bool RES, bool PAIR = false>
 __global__ __launch_bounds__(BM / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm_dma(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K,
                                                   const float *__restrict__ bias, const float *residual, const Tables tb,
                                                   float *out, __half *__restrict__ out_h, int ldo, const GemmSet gs) {
@@ -230,15 +234,17 @@ __global__ __launch_bounds__(BM / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm
     static_assert(PW * NW == RI * KT && (S - 2) * PW <= 63 && S >= 2, "stage pieces must divide over the waves; vmcnt is 6 bits");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_d[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
+    static_assert(!PAIR || (TN == 2 && !GELU && !RES), "pair epilogue: two column tiles per wave");
+    constexpr int BNO = PAIR ? BN / 2 : BN;                         // output columns per tile
+    const int ntx = (N + BNO - 1) / BNO, rt = (M + BM - 1) / BM;
     const int tile_n = ntx * rt, tile_chunk = (tile_n + 7) >> 3, tile_slot = blockIdx.x >> 3, tile_id = (int)(blockIdx.x & 7) * tile_chunk + tile_slot;   // XCD-aware, balanced (below)
     const int bx = tile_id / rt, by = tile_id - bx * rt;
     MG4_TLV(0);
     if (tile_slot >= tile_chunk || tile_id >= tile_n) return;
     const int m0 = by * BM;
-    int n0 = bx * BN;
+    int n0 = bx * BNO;
     const int wm = wave / WNN, wn = wave % WNN;
-    if (gs.n_per_mat > 0) {   // the F16 language model's wq|wk|wv and w1|w3 in one launch: column tile -> (matrix, local column); n_per_mat is a multiple of BN
+    if (!PAIR && gs.n_per_mat > 0) {   // the F16 language model's wq|wk|wv and w1|w3 in one launch: column tile -> (matrix, local column); n_per_mat is a multiple of BN
         const int mat = n0 / gs.n_per_mat;
         n0 -= mat * gs.n_per_mat; N = gs.n_per_mat;
         W += (size_t)mat * gs.w_mat_stride;
@@ -264,7 +270,9 @@ __global__ __launch_bounds__(BM / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm
         const int q = wave * PW + u, sub = q / RI, j = q % RI;
         const bool isA = j < BM / 8;
         const int row = 8 * (isA ? j : j - BM / 8) + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
-        src[u] = (isA ? A + (size_t)min(m0 + row, M - 1) * lda : W + (size_t)min(n0 + row, N - 1) * ldw) + 8 * c + 64 * sub;
+        // W tile row -> weight row: as it is, or (PAIR) 32-row blocks alternately from the two matrices
+        const size_t wrow = PAIR ? (size_t)((row >> 5) & 1) * (size_t)gs.w_mat_stride + (size_t)min(n0 + ((row >> 6) << 5) + (row & 31), N - 1) * ldw : (size_t)min(n0 + row, N - 1) * ldw;
+        src[u] = (isA ? A + (size_t)min(m0 + row, M - 1) * lda : W + wrow) + 8 * c + 64 * sub;
         dst[u] = (unsigned)(sub * SUB + j * 1024);
     }
     auto stage = [&](int kt, int buf) {
@@ -319,6 +327,20 @@ __global__ __launch_bounds__(BM / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(RES ? residual : bias), 0, RES ? (int)(((size_t)(M - 1) * ldo + N) * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc(out, 0, out ? (int)(((size_t)(M - 1) * ldo + N) * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t hb = __builtin_amdgcn_make_buffer_rsrc(out_h, 0, out_h ? (int)(((size_t)(M - 1) * ldo + N) * 2) : 0, 0x00020000);
+    if constexpr (PAIR) {
+        const int col = n0 + wn * 32 + lcol;
+#pragma unroll
+        for (int a = 0; a < TM; a++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const unsigned o = row < M && col < N ? (unsigned)(row * ldo + col) : 0x20000000u;
+                const float v = tab_v(tb.silu, acc[a][0][r]) * acc[a][1][r];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ob, (int)(o * 4u), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(__half_as_ushort(f2h_rn(v)), hb, (int)(o * 2u), 0, 0);
+            }
+        }
+    } else
 #pragma unroll
     for (int b = 0; b < TN; b++) {
         const int col = n0 + (wn * TN + b) * 32 + lcol;
@@ -375,6 +397,27 @@ static bool launch_gemm_dma_t(const __half *A, int lda, const __half *W, int ldw
     else if (residual) hipLaunchKernelGGL((k_gemm_dma<BM, BN, TM, TN, KT, S, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
     else hipLaunchKernelGGL((k_gemm_dma<BM, BN, TM, TN, KT, S, false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
     return true;
+}
+template <int BM, int BN, int TM, int KT, int S>
+static bool launch_gemm_dma_pair_t(const __half *A, int lda, const __half *W1, long long w3_minus_w1, int ldw, int M, int N, int K, const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s) {
+    if (K % (64 * KT) || lda % 8 || ldw % 8 || N % 32 || (reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W1)) % 16 || w3_minus_w1 % 8) return false;
+    GemmSet gs{0, w3_minus_w1, 0, 0, 0};
+    const int ntx = (N + BN / 2 - 1) / (BN / 2), rt = (M + BM - 1) / BM;
+    dim3 grid((unsigned)((ntx * rt + 7) / 8 * 8), 1, 1), block(BM / (32 * TM) * (BN / 64) * 64);
+    const size_t lds = (size_t)S * KT * (BM + BN) * 128;
+    static bool attr = false;
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_dma<BM, BN, TM, 2, KT, S, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL((k_gemm_dma<BM, BN, TM, 2, KT, S, false, false, true>), grid, block, lds, s, A, lda, W1, ldw, M, N, K, nullptr, nullptr, tb, out, out_h, ldo, gs);
+    return true;
+}
+// The feed-forward pair of an F16 language model at prompt sizes: out_h[M][ldo] = fp16(silu_table(A . W1^T) * (A . W3^T)), N columns (rows of W1 / W3), one launch; `out`
+// (optional) receives the fp32 product before the rounding.  false: shape outside this path.
+bool launch_gemm_f16_silu_pair(const __half *A, int lda, const __half *W1, const __half *W3, int M, int N, int K, const Tables &tb, float *out, __half *out_h, int ldo, int cus, hipStream_t s) {
+    if (M < 256 || g_gemm_arm == -3 || !tb.silu || W3 <= W1) return false;
+    const long long d = W3 - W1;
+    const int wgs128 = (((M + 255) / 256) * ((N + 63) / 64) + 7) / 8 * 8;          // 256x128 tiles carry 64 pair columns
+    if ((wgs128 * 2 > cus * 3 || N % 64) && launch_gemm_dma_pair_t<256, 256, 4, 1, 2>(A, lda, W1, d, K, M, N, K, tb, out, out_h, ldo, s)) return true;
+    return launch_gemm_dma_pair_t<256, 128, 2, 1, 3>(A, lda, W1, d, K, M, N, K, tb, out, out_h, ldo, s);
 }
 // =====================================================================================================================
 // Large-M form (M >= 512: the unquantised LLM's prompt rows -- BASELINE.json configs[4] -- and batched image encodes): 128x128 tile per 256-thread workgroup,
@@ -495,7 +538,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restric
 }
 static int g_gemm_big_min_m = 512;   // smallest M that takes the 128x128 kernel (0 = never); MINIGPT4_GEMM_BIG_M, read once by Engine::init
 static int g_f16_ks = 0;             // forced K split of the F16 set launches (0 = choose); MINIGPT4_F16_KS, read once by Engine::init
-static int g_gemm_arm = 0, g_gemm_sk_arm = 0;   // experiments: force one tile shape for every small-M GEMM / split-K GEMM (MINIGPT4_GEMM_ARM / _SK_ARM, read once by Engine::init); 0 = choose, -2 = the 64x64 launch always, -3 = round 2's kernels everywhere (64x64 tiles, 128x128 large-M kernel)
 void set_gemm_tuning(int big_min_m, int f16_ks, int arm, int sk_arm) {
     if (big_min_m >= 0) g_gemm_big_min_m = big_min_m;
     g_f16_ks = std::max(0, std::min(f16_ks, 8));

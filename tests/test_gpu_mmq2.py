@@ -103,3 +103,28 @@ def test_f16_set_gemm_matches_fp32_reference(gpu_lib, case):
         want = want + res
     assert got.shape == want.shape and np.isfinite(got).all()
     assert float(np.abs(got - want).max() / scale) < 2e-5
+
+
+@pytest.mark.parametrize("case", [(512, 512, 256), (640, 1024, 768), (515, 256, 128), (512, 2048, 1408), (512, 256, 12416)], ids=lambda c: "N%d_K%d_F%d" % c)
+def test_f16_silu_pair_launch_is_bit_identical_to_the_two_products(gpu_lib, case):
+    """F16 weights at prompt sizes: w1 | w3 in ONE launch whose epilogue stores fp16(silu_table(w1 x) * (w3 x)) (k_gemm_dma PAIR, round 3).  Each product is accumulated in
+    the order of every other tile shape, so the stored row must equal -- bit for bit -- what the two-product set launch followed by k_silu_mul_quant's fp16 leg produces:
+    silu through ggml's fp16 table on the fp16-rounded w1 product, times the fp32 w3 product, rounded to fp16.  (The last case has enough column tiles for the 256x256
+    form; the reference launch needs n_out % 128 == 0.)"""
+    import ctypes
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    N, n_in, n_out = case
+    rng = np.random.default_rng(sum(case))
+    w = (0.05 * rng.standard_normal((2 * n_out, n_in))).astype(np.float16)
+    x = rng.standard_normal((N, n_in)).astype(np.float32)
+    h = gpu_lib.amd_test_mmq2(Q.NAME_TO_TYPE["f16"], w.view(np.uint8).reshape(-1), 2, n_in, n_out, x)          # [2][N][n_out] fp32, the set launch
+    tab = R.table(1).view(np.float16)                                                                           # ggml's table_silu_f16
+    want = (tab[h[0].astype(np.float16).view(np.uint16)].astype(np.float32) * h[1]).astype(np.float16)
+    L = gpu_lib.library
+    L.minigpt4_amd_test_f16_silu_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    got = np.zeros((N, n_out), np.uint16)
+    xs = np.ascontiguousarray(x); ws = np.ascontiguousarray(w)
+    rc = L.minigpt4_amd_test_f16_silu_pair(xs.ctypes.data, ws.ctypes.data, N, n_in, n_out, got.ctypes.data, None)
+    assert rc == 0, rc
+    assert np.array_equal(got, want.view(np.uint16)), int((got != want.view(np.uint16)).sum())
