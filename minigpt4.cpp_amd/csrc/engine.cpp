@@ -117,6 +117,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
                     getenv("MINIGPT4_GEMM_ARM") ? atoi(getenv("MINIGPT4_GEMM_ARM")) : -1, getenv("MINIGPT4_GEMM_SK_ARM") ? atoi(getenv("MINIGPT4_GEMM_SK_ARM")) : -1);
     if (getenv("MINIGPT4_F16_GEMM")) set_f16_gemm(atoi(getenv("MINIGPT4_F16_GEMM")));
     if (getenv("MINIGPT4_ATTN_PREFILL_F16")) set_attn_prefill_f16(atoi(getenv("MINIGPT4_ATTN_PREFILL_F16")));
+    if (getenv("MINIGPT4_ATTN_PREFILL_W8")) set_attn_prefill_w8(atoi(getenv("MINIGPT4_ATTN_PREFILL_W8")));
     // Decode: which activation preparations run inside the consuming mat-vec's prologue (one fat workgroup per CU repeats the row preparation while
     // its first weight tiles are in flight) instead of as their own launch.  bit 0: attn_norm -> wq|wk|wv, 1: attention output -> wo,
     // 2: ffn_norm -> w1|w3, 3: silu(w1 x) * (w3 x) -> w2, 4: final norm -> output; bit 5: w1|w3 launch writes silu(w1 x) * (w3 x) itself

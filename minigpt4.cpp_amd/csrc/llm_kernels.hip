@@ -2372,6 +2372,221 @@ __global__ __launch_bounds__(256) void k_attn_prefill_h(const float *__restrict_
     MG4_TLP(4);
 #endif
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// k_attn_prefill_h8 (round 3): the same arithmetic as k_attn_prefill_h in a 512-thread workgroup whose waves have ROLES.  The timeline of the 4-wave form had a 512-key
+// workgroup at 6.2 us of scores + 7.7 us of softmax + 12.7 us of P.V, each key tile paying [barrier, LDS write of the staged tile, barrier, MFMAs] in sequence on the same
+// four waves.  Here waves 4..7 are LOADERS (global -> registers two tiles ahead -> LDS tile kt, transposing V) while waves 0..3 multiply tile kt - 1 out of the OTHER LDS
+// buffer: one barrier per tile and the staging runs beside the MFMAs; the softmax uses all 512 threads (32 rows x 16 lanes at once).  QS = 2 only (32 queries).
+// Every value is formed by the same operations in the same order as in k_attn_prefill_h (scores: one MFMA chain per (query group, key tile) over ks; softmax: order-free
+// max / exact sum; P.V: tiles in key order), so the two kernels are bit-identical (MINIGPT4_ATTN_PREFILL_W8=0 selects the 4-wave form, A/B).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(512) void k_attn_prefill_h8(const float *__restrict__ q, const __half *__restrict__ kc, const __half *__restrict__ vc, int E, int N, const int *__restrict__ n_past,
+                                                         const Tables tb, float *__restrict__ out, int LS) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_aph8[];
+    constexpr int QS = 2, C8 = HD / 8, QT = AP_QT * QS, KSQ = HD / 32, DT = HD / 16, PER = AP_KT * C8 / 256;
+    constexpr int KVB = (AP_KT * HD * 2 > HD * APH_LDT * 2 ? AP_KT * HD * 2 : HD * APH_LDT * 2);        // bytes of one K (or transposed V) tile buffer
+    static_assert(PER >= 1 && (DT % 4 == 0 || DT == 2), "tile geometry");
+    float *S = reinterpret_cast<float *>(smem_aph8);                                                 // [QT][LS]
+    unsigned char *kvb = smem_aph8 + (size_t)QT * LS * 4;                                             // two tile buffers (K tiles, later V tiles)
+    const int h = blockIdx.x, q0 = (int)(gridDim.y - 1 - blockIdx.y) * QT, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int lt = tid & 255, mw = wave & 3;                                                           // loader thread / MFMA wave index
+    MG4_TLP(0);
+    const int np = *n_past;
+    const int T = np + min(q0 + QT - 1, N - 1) + 1;
+    const int nkt = (T + AP_KT - 1) / AP_KT;
+    const float scale = 1.0f / sqrtf((float)HD);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    aph8_t qf[QS][KSQ];
+    if (!loader) {
+#pragma unroll
+        for (int qs = 0; qs < QS; qs++) {
+            const float *qp = q + (size_t)min(q0 + 16 * qs + l15, N - 1) * E + (size_t)h * HD + 8 * l4;
+#pragma unroll
+            for (int ks = 0; ks < KSQ; ks++) {
+                const float4 a = *reinterpret_cast<const float4 *>(qp + 32 * ks), b = *reinterpret_cast<const float4 *>(qp + 32 * ks + 4);
+                const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int e = 0; e < 8; e++) qf[qs][ks][e] = (_Float16)__half2float(f2h_rn(v[e]));
+            }
+        }
+    }
+    // ---- scores: iteration kt stages tile kt (loaders) and multiplies tile kt - 1 (MFMA waves)
+    int4 xa[PER], xb[PER];                                                                            // loaders: tiles kt and kt + 1 in flight
+#define MG4_KV_LOAD(X, base, tile)                                                                          \
+    _Pragma("unroll") for (int u = 0; u < PER; u++) { const int e = lt + 256 * u, j = e / C8, c = e - j * C8;   \
+        X[u] = ld16(base + (size_t)min((tile) * AP_KT + j, T - 1) * E + (size_t)h * HD + 8 * c); }
+    if (loader) { MG4_KV_LOAD(xa, kc, 0) MG4_KV_LOAD(xb, kc, 1) }
+    auto k_write = [&](const int4 (&X)[PER], int buf) {
+        __half *Kt = reinterpret_cast<__half *>(kvb + (size_t)buf * KVB);
+#pragma unroll
+        for (int u = 0; u < PER; u++) { const int e = lt + 256 * u, j = e / C8, c = e - j * C8; *reinterpret_cast<int4 *>(Kt + j * HD + ((c ^ (j & (C8 - 1))) << 3)) = X[u]; }
+    };
+    auto k_mul = [&](int kt, int buf) {
+        const __half *Kt = reinterpret_cast<const __half *>(kvb + (size_t)buf * KVB);
+        const int key0 = kt * AP_KT + 16 * mw;
+        if (key0 < T) {
+            const int row = 16 * mw + l15;
+            pf4_t acc[QS];
+#pragma unroll
+            for (int qs = 0; qs < QS; qs++) acc[qs] = pf4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ks = 0; ks < KSQ; ks++) {
+                const aph8_t kf = *reinterpret_cast<const aph8_t *>(Kt + row * HD + (((4 * ks + l4) ^ (row & (C8 - 1))) << 3));
+#pragma unroll
+                for (int qs = 0; qs < QS; qs++) acc[qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[qs][ks], kf, acc[qs], 0, 0, 0);
+            }
+#pragma unroll
+            for (int qs = 0; qs < QS; qs++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) S[(size_t)(16 * qs + l4 * 4 + r) * LS + key0 + l15] = acc[qs][r] * scale;
+        }
+    };
+    for (int kt = 0; kt <= nkt; kt += 2) {
+        if (loader) { if (kt < nkt) { k_write(xa, 0); MG4_KV_LOAD(xa, kc, kt + 2) } }
+        else if (kt >= 1) k_mul(kt - 1, 1);
+        __syncthreads();
+        if (kt + 1 > nkt) break;
+        if (loader) { if (kt + 1 < nkt) { k_write(xb, 1); MG4_KV_LOAD(xb, kc, kt + 3) } }
+        else k_mul(kt, 0);
+        __syncthreads();
+    }
+    MG4_TLP(1);
+    // the first two V tiles are requested now: they arrive while the softmax runs
+    if (loader) { MG4_KV_LOAD(xa, vc, 0) MG4_KV_LOAD(xb, vc, 1) }
+    {   // softmax: 32 rows x 16 lanes at once (k_attn_prefill_h's code with qs = tid >> 8)
+        const int row = tid >> 4, sub = tid & 15;
+        const int Tq = min(np + q0 + row + 1, T), nb = nkt * AP_KT;
+        float *sr = S + (size_t)row * LS;
+        float mx = -INFINITY;
+        for (int j = 4 * sub; j < nb; j += 64) {
+            const float4 v = *reinterpret_cast<const float4 *>(sr + j);
+            mx = fmaxf(mx, j < Tq ? v.x : -INFINITY); mx = fmaxf(mx, j + 1 < Tq ? v.y : -INFINITY); mx = fmaxf(mx, j + 2 < Tq ? v.z : -INFINITY); mx = fmaxf(mx, j + 3 < Tq ? v.w : -INFINITY);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 8));
+        double sum = 0.0;
+        for (int j0 = 0; j0 < nb; j0 += 256) {
+            float x[16]; unsigned short t[16];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int jj = min(j0 + 64 * u, nb - 64) + 4 * sub;
+                const float4 v = *reinterpret_cast<const float4 *>(sr + jj);
+                x[4 * u] = v.x; x[4 * u + 1] = v.y; x[4 * u + 2] = v.z; x[4 * u + 3] = v.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int jj = j0 + 64 * (e >> 2) + 4 * sub + (e & 3);
+                t[e] = reinterpret_cast<const unsigned short *>(tb.exp)[f2h_bits(jj < Tq ? x[e] - mx : 0.0f)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int jj = j0 + 64 * u + 4 * sub;
+                if (j0 + 64 * u < nb) {
+                    float4 ev;
+                    ev.x = jj < Tq ? h2f_bits(t[4 * u]) : 0.0f; ev.y = jj + 1 < Tq ? h2f_bits(t[4 * u + 1]) : 0.0f; ev.z = jj + 2 < Tq ? h2f_bits(t[4 * u + 2]) : 0.0f; ev.w = jj + 3 < Tq ? h2f_bits(t[4 * u + 3]) : 0.0f;
+                    sum += (double)ev.x; sum += (double)ev.y; sum += (double)ev.z; sum += (double)ev.w;
+                    *reinterpret_cast<float4 *>(sr + jj) = ev;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+        const float inv = (float)(1.0 / sum);
+        for (int j = 4 * sub; j < nb; j += 64) {
+            float4 v = *reinterpret_cast<const float4 *>(sr + j);
+            v.x = f16r(v.x * inv); v.y = f16r(v.y * inv); v.z = f16r(v.z * inv); v.w = f16r(v.w * inv);
+            *reinterpret_cast<float4 *>(sr + j) = v;
+        }
+    }
+    MG4_TLP(2);
+    // ---- P.V: the same two-role loop over the V tiles (written transposed: [dim][key])
+    constexpr int DPW = (DT + 3) / 4;
+    pf4_t oacc[QS][DPW];
+#pragma unroll
+    for (int qs = 0; qs < QS; qs++)
+#pragma unroll
+        for (int i = 0; i < DPW; i++) oacc[qs][i] = pf4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    auto v_write = [&](const int4 (&X)[PER], int kt, int buf) {
+        __half *Vt = reinterpret_cast<__half *>(kvb + (size_t)buf * KVB);
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int e = lt + 256 * u, j = e / C8, c = e - j * C8;
+            const bool live = kt * AP_KT + j < T;
+            const unsigned w[4] = {(unsigned)X[u].x, (unsigned)X[u].y, (unsigned)X[u].z, (unsigned)X[u].w};
+            unsigned short *d = reinterpret_cast<unsigned short *>(Vt) + (8 * c) * APH_LDT + j;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { d[(2 * i) * APH_LDT] = live ? (unsigned short)(w[i] & 0xFFFF) : (unsigned short)0; d[(2 * i + 1) * APH_LDT] = live ? (unsigned short)(w[i] >> 16) : (unsigned short)0; }
+        }
+    };
+    auto v_mul = [&](int kt, int buf) {
+        const __half *Vt = reinterpret_cast<const __half *>(kvb + (size_t)buf * KVB);
+#pragma unroll
+        for (int i = 0; i < DPW; i++) {
+            const int dt = mw + 4 * i;
+            if (dt < DT) {
+#pragma unroll
+                for (int k2 = 0; k2 < AP_KT / 32; k2++) {
+                    const unsigned *vp = reinterpret_cast<const unsigned *>(Vt + (16 * dt + l15) * APH_LDT + 32 * k2 + 8 * l4);
+                    union { unsigned u[4]; aph8_t v; } vb;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) vb.u[e] = vp[e];
+#pragma unroll
+                    for (int qs = 0; qs < QS; qs++) {
+                        const float *pp = S + (size_t)(16 * qs + l15) * LS + kt * AP_KT + 32 * k2 + 8 * l4;
+                        const float4 a = *reinterpret_cast<const float4 *>(pp), b = *reinterpret_cast<const float4 *>(pp + 4);
+                        aph8_t pf;
+                        pf[0] = (_Float16)a.x; pf[1] = (_Float16)a.y; pf[2] = (_Float16)a.z; pf[3] = (_Float16)a.w; pf[4] = (_Float16)b.x; pf[5] = (_Float16)b.y; pf[6] = (_Float16)b.z; pf[7] = (_Float16)b.w;
+                        oacc[qs][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vb.v, oacc[qs][i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    __syncthreads();                                                     // normalised probabilities visible; the K buffers are free
+    for (int kt = 0; kt <= nkt; kt += 2) {
+        if (loader) { if (kt < nkt) { v_write(xa, kt, 0); MG4_KV_LOAD(xa, vc, kt + 2) } }
+        else if (kt >= 1) v_mul(kt - 1, 1);
+        __syncthreads();
+        if (kt + 1 > nkt) break;
+        if (loader) { if (kt + 1 < nkt) { v_write(xb, kt + 1, 1); MG4_KV_LOAD(xb, vc, kt + 3) } }
+        else v_mul(kt, 0);
+        __syncthreads();
+    }
+#undef MG4_KV_LOAD
+    MG4_TLP(3);
+    if (!loader) {
+#pragma unroll
+        for (int qs = 0; qs < QS; qs++)
+#pragma unroll
+            for (int i = 0; i < DPW; i++) {
+                const int dt = mw + 4 * i;
+                if (dt < DT) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int qrow = q0 + 16 * qs + l4 * 4 + r;
+                        if (qrow < N) out[(size_t)qrow * E + (size_t)h * HD + dt * 16 + l15] = oacc[qs][i][r];
+                    }
+                }
+            }
+    }
+#ifdef MG4_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MG4_TLP(4);
+#endif
+}
+static int g_attn_prefill_w8 = 1;    // 1: the 8-wave loader / MFMA form for 32-query tiles; MINIGPT4_ATTN_PREFILL_W8, read by Engine::init
+void set_attn_prefill_w8(int v) { g_attn_prefill_w8 = v != 0; }
+template <int HD>
+static bool launch_attn_prefill_h8(const float *q, const __half *kc, const __half *vc, int N, int n_head, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
+    const int LS = ((t_max + AP_KT - 1) / AP_KT) * AP_KT + 4;
+    static bool attr = false;
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill_h8<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    const size_t kvbytes = std::max((size_t)AP_KT * HD * 2, (size_t)HD * APH_LDT * 2);
+    const size_t lds = (size_t)AP_QT * 2 * LS * 4 + 2 * kvbytes;
+    if (lds > 160 * 1024 - 512) return false;
+    hipLaunchKernelGGL((k_attn_prefill_h8<HD>), dim3((unsigned)n_head, (unsigned)((N + AP_QT * 2 - 1) / (AP_QT * 2))), dim3(512), lds, s, q, kc, vc, n_head * HD, N, n_past, tb, out, LS);
+    return true;
+}
 static int g_attn_prefill_f16 = 1;   // 1: prompt attention on the fp16 matrix cores (k_attn_prefill_h), 0: the exact-f32 MFMA kernel (k_attn_prefill); MINIGPT4_ATTN_PREFILL_F16, read by Engine::init
 void set_attn_prefill_f16(int v) { g_attn_prefill_f16 = v != 0; }
 template <int HD, int QS>
@@ -2387,6 +2602,7 @@ static bool launch_attn_prefill_h_qs(const float *q, const __half *kc, const __h
 template <int HD>
 static bool launch_attn_prefill_hd(const float *q, const __half *kc, const __half *vc, int N, int n_head, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
     if (g_attn_prefill_f16) {   // 32 queries per staged K / V tile once that still gives every CU a workgroup
+        if (g_attn_prefill_w8 && n_head * ((N + 31) / 32) >= 256 && launch_attn_prefill_h8<HD>(q, kc, vc, N, n_head, n_past, t_max, tb, out, s)) return true;
         if (n_head * ((N + 31) / 32) >= 256 && launch_attn_prefill_h_qs<HD, 2>(q, kc, vc, N, n_head, n_past, t_max, tb, out, s)) return true;
         if (launch_attn_prefill_h_qs<HD, 1>(q, kc, vc, N, n_head, n_past, t_max, tb, out, s)) return true;
     }

@@ -337,6 +337,7 @@ int minigpt4_amd_test_f16_silu_pair(const float *x, const void *w_f16, int64_t N
 }
 // Micro-benchmark of the prompt-row attention (launch_attn_prefill): N query rows at positions n_past .. n_past + N - 1 of an fp16 K / V cache filled with synthetic rows
 int minigpt4_amd_bench_attn_prefill(int n_head, int hd, int N, int n_past, int iters, float *us_per_launch) {
+    if (const char *w8 = getenv("MINIGPT4_ATTN_PREFILL_W8")) set_attn_prefill_w8(atoi(w8));        // micro-benchmark only (no engine in this process)
     if (n_head < 1 || !attn_head_size_supported(hd) || N < 2 || n_past < 0 || iters < 1) return 1;
     if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
     return guarded(3, [&]() -> int {
