@@ -125,7 +125,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     fuse_mask_ = getenv("MINIGPT4_FUSE") ? atoi(getenv("MINIGPT4_FUSE")) : FUSE_DEFAULT;
     if (const char *dc = getenv("MINIGPT4_DEFER_COMBINE")) defer_combine_ = atoi(dc) != 0;
     if (const char *bs = getenv("MINIGPT4_BATCH_SETS")) batch_sets_ = atoi(bs) != 0;
-    if (const char *fp = getenv("MINIGPT4_F16_PAIR")) f16_pair_ = atoi(fp) != 0;
+    if (const char *fp = getenv("MINIGPT4_F16_PAIR")) f16_pair_ = atoi(fp);        // bit mask (A/B): 1 w1|w3 + silu*mul in one launch, 4 the attention kernel stores fp16 rows for wo
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
     attn_prefill_ = !(getenv("MINIGPT4_ATTN_PREFILL") && !atoi(getenv("MINIGPT4_ATTN_PREFILL")));   // 0: the per-token attention kernel also for prompt rows (A/B, tests)
     // Opt-in experiment (unmeasured at the time of writing): the w1|w3 launch also prepares w2's activation row (last-arriver per 256-row block),
@@ -690,6 +690,7 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
             } else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s, &p_attn, fz(0), false, "qk"); mul_mat(L.wv, N, v_, E, nullptr, s, &p_attn, fz(0), "v"); }
         }
         // algorithmic bytes of the attention site: the cached fp16 K and V rows of every head up to the current position
+        bool att_in_xh = false;                                             // the attention kernel left fp16 rows in act_.xh
         std::optional<SiteScope> att_sc;
         if (prof_on_) att_sc.emplace(this, "attention", 4.0 * (double)E * (double)(conv_[sl].n_committed + N), s);
         if (dec && attn_split_now_) launch_attn_llm_split(q_, k_, v_, kc, vc, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, attn_ws_, attn_splits_, s);
@@ -698,15 +699,17 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
             if (pend_.ks > 1 && pend_.n == 3 && pend_.y[0] == q_ && pend_.y[1] == k_ && pend_.y[2] == v_ && !pend_.res[0] && pend_.stride == (long long)N * E) {
                 launch_rope_kv_slabs(pend_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); pend_ = SlabSrc{};
             } else { flush_pending(s); launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); }
-            if (!(attn_prefill_ && launch_attn_prefill(q_, kc, vc, N, H, hd, d_npast, conv_[sl].n_committed + N, tabs_, att_, s)))
+            // an F16 wo at prompt sizes multiplies fp16(attention output): let the attention kernel store those rows itself (act_.xh), no conversion launch
+            const bool want_h = (f16_pair_ & 4) && L.wo.type == GT_F16 && N >= 512 && act_.xh && E % 128 == 0;
+            if (!(attn_prefill_ && launch_attn_prefill(q_, kc, vc, N, H, hd, d_npast, conv_[sl].n_committed + N, tabs_, att_, s, want_h ? act_.xh : nullptr, &att_in_xh)))
                 launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, false, s);
         }
         att_sc.reset();
-        mul_mat(L.wo, N, x_, E, x_, s, &p_att, fz(1), "wo", !dec);             // combine left to the ffn norm's preparation
+        mul_mat(L.wo, N, x_, E, x_, s, att_in_xh ? nullptr : &p_att, fz(1), "wo", !dec);             // combine left to the ffn norm's preparation
         bool paired = false;   // h1_ already holds silu(w1 x) * (w3 x)
         // F16 weights at prompt sizes: w1 | w3 in one launch whose epilogue stores fp16(silu(w1 x) * (w3 x)) -- the rows w2 multiplies -- into h1_'s memory (round 3)
         bool pair16 = false;
-        if (!dec && f16_pair_ && N >= 512 && L.w1.type == GT_F16 && L.w3.type == GT_F16 && L.w1.rows == L.w3.rows && L.w1.cols == L.w3.cols && act_.xh &&
+        if (!dec && (f16_pair_ & 1) && N >= 512 && L.w1.type == GT_F16 && L.w3.type == GT_F16 && L.w1.rows == L.w3.rows && L.w1.cols == L.w3.cols && act_.xh &&
             L.w2.type == GT_F16 && E % 128 == 0 && F % 64 == 0) {   // (w2's set launch must take the fp16 rows: its own shape conditions)
             prep_rms(x_, L.ffn_norm, N, E, act_mask_for(GT_F16), s);
             SiteScope sc(this, "w1w3", (double)(L.w1.bytes + L.w3.bytes), s);

@@ -108,7 +108,7 @@ private:
     // prompt passes: the combine of a K-split mat-mul is left to the kernel that consumes the result (rope + cache append, the next norm + quantisation, silu * mul); pend_
     // describes the slabs until then, flush_pending runs the combine as its own launch when the next consumer is not one of those.  MINIGPT4_DEFER_COMBINE=0: always flush (A/B)
     SlabSrc pend_; bool defer_combine_ = true;
-    const __half *xh_override_ = nullptr; bool f16_pair_ = true;   // F16 prompt pass: w1 | w3 + silu * mul in one launch, its fp16 rows feed w2 (MINIGPT4_F16_PAIR=0: A/B)
+    const __half *xh_override_ = nullptr; int f16_pair_ = 7;   // F16 prompt pass: w1 | w3 + silu * mul in one launch, its fp16 rows feed w2 (MINIGPT4_F16_PAIR=0: A/B)
     bool batch_sets_ = true;   // batched decode of > batch_rows_max_ conversations through the prompt pass's set launches (MINIGPT4_BATCH_SETS=0: one launch per matrix, A/B)
     void flush_pending(hipStream_t s);
     void prep_rms(const float *x, const float *w, int N, int K, int mask, hipStream_t s);

@@ -109,7 +109,8 @@ void launch_batch_finish(const float *logits, int n_vocab, int B, const int *row
 void launch_batch_begin(int *n_past, const int *row_slot, const int *row_pos, int B, hipStream_t s);   // n_past[row_slot[r]] = row_pos[r]
 // prefill (N > 1 rows of one conversation, after launch_rope_kv): workgroup = (head, 16 queries), keys streamed through LDS in tiles, exact-f32 MFMA; t_max >= *n_past + N
 // sizes the LDS score rows; false -> does not fit (the caller uses launch_attn_llm)
-bool launch_attn_prefill(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s);
+// out_h (optional): a kernel that can do so stores the fp16-rounded rows THERE instead of fp32 rows in `out` and sets *wrote_h (the F16 wo's input rows)
+bool launch_attn_prefill(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s, __half *out_h = nullptr, bool *wrote_h = nullptr);
 // MINIGPT4_PARITY=1: scores / softmax / P.V with every fp32 chain in the oracle's order (after launch_rope_kv); t_max >= *n_past + N
 void launch_attn_ref(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s);
 void set_attn_prefill_f16(int v);

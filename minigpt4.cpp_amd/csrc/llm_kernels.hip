@@ -2382,7 +2382,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill_h(const float *__restrict_
 // ---------------------------------------------------------------------------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(512) void k_attn_prefill_h8(const float *__restrict__ q, const __half *__restrict__ kc, const __half *__restrict__ vc, int E, int N, const int *__restrict__ n_past,
-                                                         const Tables tb, float *__restrict__ out, int LS) {
+                                                         const Tables tb, float *__restrict__ out, int LS, __half *__restrict__ out_h) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_aph8[];
     constexpr int QS = 2, C8 = HD / 8, QT = AP_QT * QS, KSQ = HD / 32, DT = HD / 16, PER = AP_KT * C8 / 256;
     constexpr int KVB = (AP_KT * HD * 2 > HD * APH_LDT * 2 ? AP_KT * HD * 2 : HD * APH_LDT * 2);        // bytes of one K (or transposed V) tile buffer
@@ -2564,7 +2564,11 @@ __global__ __launch_bounds__(512) void k_attn_prefill_h8(const float *__restrict
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int qrow = q0 + 16 * qs + l4 * 4 + r;
-                        if (qrow < N) out[(size_t)qrow * E + (size_t)h * HD + dt * 16 + l15] = oacc[qs][i][r];
+                        // out_h: the rows as the consumer wants them (an F16 wo multiplies the fp16-rounded attention output: the conversion launch is saved)
+                        if (out_h) {   // pairs of dims from neighbouring lanes: 4-byte stores
+                            const float o0 = oacc[qs][i][r], o1 = __shfl_xor(o0, 1);
+                            if (qrow < N && !(l15 & 1)) *reinterpret_cast<__half2 *>(out_h + (size_t)qrow * E + (size_t)h * HD + dt * 16 + l15) = __halves2half2(f2h_rn(o0), f2h_rn(o1));
+                        } else if (qrow < N) out[(size_t)qrow * E + (size_t)h * HD + dt * 16 + l15] = oacc[qs][i][r];
                     }
                 }
             }
@@ -2577,14 +2581,14 @@ __global__ __launch_bounds__(512) void k_attn_prefill_h8(const float *__restrict
 static int g_attn_prefill_w8 = 1;    // 1: the 8-wave loader / MFMA form for 32-query tiles; MINIGPT4_ATTN_PREFILL_W8, read by Engine::init
 void set_attn_prefill_w8(int v) { g_attn_prefill_w8 = v != 0; }
 template <int HD>
-static bool launch_attn_prefill_h8(const float *q, const __half *kc, const __half *vc, int N, int n_head, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
+static bool launch_attn_prefill_h8(const float *q, const __half *kc, const __half *vc, int N, int n_head, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s, __half *out_h) {
     const int LS = ((t_max + AP_KT - 1) / AP_KT) * AP_KT + 4;
     static bool attr = false;
     if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill_h8<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     const size_t kvbytes = std::max((size_t)AP_KT * HD * 2, (size_t)HD * APH_LDT * 2);
     const size_t lds = (size_t)AP_QT * 2 * LS * 4 + 2 * kvbytes;
     if (lds > 160 * 1024 - 512) return false;
-    hipLaunchKernelGGL((k_attn_prefill_h8<HD>), dim3((unsigned)n_head, (unsigned)((N + AP_QT * 2 - 1) / (AP_QT * 2))), dim3(512), lds, s, q, kc, vc, n_head * HD, N, n_past, tb, out, LS);
+    hipLaunchKernelGGL((k_attn_prefill_h8<HD>), dim3((unsigned)n_head, (unsigned)((N + AP_QT * 2 - 1) / (AP_QT * 2))), dim3(512), lds, s, q, kc, vc, n_head * HD, N, n_past, tb, out, LS, out_h);
     return true;
 }
 static int g_attn_prefill_f16 = 1;   // 1: prompt attention on the fp16 matrix cores (k_attn_prefill_h), 0: the exact-f32 MFMA kernel (k_attn_prefill); MINIGPT4_ATTN_PREFILL_F16, read by Engine::init
@@ -2600,9 +2604,9 @@ static bool launch_attn_prefill_h_qs(const float *q, const __half *kc, const __h
     return true;
 }
 template <int HD>
-static bool launch_attn_prefill_hd(const float *q, const __half *kc, const __half *vc, int N, int n_head, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
+static bool launch_attn_prefill_hd(const float *q, const __half *kc, const __half *vc, int N, int n_head, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s, __half *out_h, bool *wrote_h) {
     if (g_attn_prefill_f16) {   // 32 queries per staged K / V tile once that still gives every CU a workgroup
-        if (g_attn_prefill_w8 && n_head * ((N + 31) / 32) >= 256 && launch_attn_prefill_h8<HD>(q, kc, vc, N, n_head, n_past, t_max, tb, out, s)) return true;
+        if (g_attn_prefill_w8 && n_head * ((N + 31) / 32) >= 256 && launch_attn_prefill_h8<HD>(q, kc, vc, N, n_head, n_past, t_max, tb, out, s, out_h)) { if (wrote_h) *wrote_h = out_h != nullptr; return true; }
         if (n_head * ((N + 31) / 32) >= 256 && launch_attn_prefill_h_qs<HD, 2>(q, kc, vc, N, n_head, n_past, t_max, tb, out, s)) return true;
         if (launch_attn_prefill_h_qs<HD, 1>(q, kc, vc, N, n_head, n_past, t_max, tb, out, s)) return true;
     }
@@ -2618,11 +2622,13 @@ static bool launch_attn_prefill_hd(const float *q, const __half *kc, const __hal
 }
 // N > 1 query rows at positions *n_past .. *n_past + N - 1 (launch_rope_kv has run); t_max >= *n_past + N (the host's view, sizes the LDS score rows).
 // false -> the score rows do not fit LDS (very long contexts): the caller runs launch_attn_llm instead.
-bool launch_attn_prefill(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
+bool launch_attn_prefill(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s,
+                         __half *out_h, bool *wrote_h) {
+    if (wrote_h) *wrote_h = false;
     switch (hd) {
-    case 32: return launch_attn_prefill_hd<32>(q, kcache, vcache, N, n_head, n_past, t_max, tb, out, s);
-    case 64: return launch_attn_prefill_hd<64>(q, kcache, vcache, N, n_head, n_past, t_max, tb, out, s);
-    case 128: return launch_attn_prefill_hd<128>(q, kcache, vcache, N, n_head, n_past, t_max, tb, out, s);
+    case 32: return launch_attn_prefill_hd<32>(q, kcache, vcache, N, n_head, n_past, t_max, tb, out, s, out_h, wrote_h);
+    case 64: return launch_attn_prefill_hd<64>(q, kcache, vcache, N, n_head, n_past, t_max, tb, out, s, out_h, wrote_h);
+    case 128: return launch_attn_prefill_hd<128>(q, kcache, vcache, N, n_head, n_past, t_max, tb, out, s, out_h, wrote_h);
     default: return false;
     }
 }

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(BM / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_d[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     static_assert(!PAIR || (TN == 2 && !GELU && !RES), "pair epilogue: two column tiles per wave");
+
     constexpr int BNO = PAIR ? BN / 2 : BN;                         // output columns per tile
     const int ntx = (N + BNO - 1) / BNO, rt = (M + BM - 1) / BM;
     const int tile_n = ntx * rt, tile_chunk = (tile_n + 7) >> 3, tile_slot = blockIdx.x >> 3, tile_id = (int)(blockIdx.x & 7) * tile_chunk + tile_slot;   // XCD-aware, balanced (below)

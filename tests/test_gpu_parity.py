@@ -292,6 +292,41 @@ def test_llm_logits_and_greedy_tokens(gpu_lib, tiny_files, wtype, mix):
         gpu_lib.minigpt4_free(ctx)
 
 
+def test_f16_prompt_pass_of_600_rows_fused_launches(gpu_lib, tiny_files, tmpdir_models, monkeypatch):
+    """Unquantised weights at prompt sizes (>= 512 rows: BASELINE configs[4]'s path) on a one-layer 2048-wide model with 16 heads of 128: the round-3 launches -- the 8-wave
+    prompt attention storing fp16 rows for wo, w1|w3 with silu * mul in the epilogue, split-K combines
+    folded into the next norm -- against (a) the same pass with MINIGPT4_F16_PAIR=0 / ATTN_PREFILL_W8=0 / DEFER_COMBINE=0 (separate launches): logits bit-identical, also after
+    three more single-token steps that read the K / V rows the epilogue wrote; (b) the CPU oracle within the f16 tolerance."""
+    import refcpu as R
+    from minigpt4_cpp_amd import modelgen as G
+    vp, _ = tiny_files
+    lp = os.path.join(tmpdir_models, "llm_f16_2048x1.bin")
+    if not os.path.exists(lp):
+        G.write_llm_file(lp, G.tiny_llm(wtype="f16", n_embd=2048, n_layer=1, n_head=16, n_vocab=512), seed=3, std=0.02, **G.TINY_CONDITIONED)
+    toks = [1] + [int(x) for x in np.random.default_rng(5).integers(3, 512, 599)]
+    res = {}
+    for mode in ("fused", "separate"):
+        for k in ("MINIGPT4_F16_PAIR", "MINIGPT4_ATTN_PREFILL_W8", "MINIGPT4_DEFER_COMBINE"):
+            monkeypatch.setenv(k, ("7" if k == "MINIGPT4_F16_PAIR" else "1") if mode == "fused" else "0")
+        ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=1024, n_batch=1024)
+        try:
+            gpu_lib.amd_eval_tokens(ctx, toks)
+            a = gpu_lib.amd_logits(ctx)
+            for t in (7, 300, 41):
+                gpu_lib.amd_eval_tokens(ctx, [t])
+            res[mode] = (a, gpu_lib.amd_logits(ctx))
+        finally:
+            gpu_lib.minigpt4_free(ctx)
+    for i in range(2):
+        assert np.array_equal(res["fused"][i].view(np.uint32), res["separate"][i].view(np.uint32)), (i, float(np.abs(res["fused"][i] - res["separate"][i]).max()))
+    o = R.OracleLLM(G.read_llm_file(lp), n_ctx=1024)
+    want = o.eval_tokens(toks)
+    assert _rel(res["fused"][0], want) < 3e-3, _rel(res["fused"][0], want)
+    for t in (7, 300, 41):
+        want = o.eval_tokens([t])
+    assert _rel(res["fused"][1], want) < 3e-3, _rel(res["fused"][1], want)
+
+
 def test_eval_embd_matches_oracle(gpu_lib, tiny_files):
     import refcpu as R
     from minigpt4_cpp_amd import modelgen as G
