@@ -329,16 +329,25 @@ __global__ __launch_bounds__(BM / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm
     const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc(out, 0, out ? (int)(((size_t)(M - 1) * ldo + N) * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t hb = __builtin_amdgcn_make_buffer_rsrc(out_h, 0, out_h ? (int)(((size_t)(M - 1) * ldo + N) * 2) : 0, 0x00020000);
     if constexpr (PAIR) {
+        // all 16 table gathers of a tile are requested together; neighbouring lanes hold neighbouring columns, so the even lane stores the fp16 PAIR (4 bytes: a store
+        // instruction covers 128 contiguous bytes per token row instead of 64)
         const int col = n0 + wn * 32 + lcol;
+        const bool even = !(lcol & 1);
 #pragma unroll
         for (int a = 0; a < TM; a++) {
+            float sv[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) sv[r] = tab_v(tb.silu, acc[a][0][r]);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const unsigned o = row < M && col < N ? (unsigned)(row * ldo + col) : 0x20000000u;
-                const float v = tab_v(tb.silu, acc[a][0][r]) * acc[a][1][r];
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ob, (int)(o * 4u), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b16(__half_as_ushort(f2h_rn(v)), hb, (int)(o * 2u), 0, 0);
+                const float v = sv[r] * acc[a][1][r], v1 = __shfl_xor(v, 1);
+                const bool ok = row < M && col < N;
+                if (out && ok) out[(size_t)row * ldo + col] = v;
+                if (out_h && ok) {
+                    if (col + 1 < N || !even) { if (even) *reinterpret_cast<__half2 *>(out_h + (size_t)row * ldo + col) = __halves2half2(f2h_rn(v), f2h_rn(v1)); }
+                    else out_h[(size_t)row * ldo + col] = f2h_rn(v);           // odd N: the last column alone
+                }
             }
         }
     } else
