@@ -538,7 +538,7 @@ void Engine::prep_rms(const float *x, const float *w, int N, int K, int mask, hi
     launch_rms_quant(x, w, N, K, act_, mask, s);
 }
 void Engine::flush_pending(hipStream_t s) { if (pend_.ks > 1) { launch_slab_flush(pend_, s); } pend_ = SlabSrc{}; }
-bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair, const char *site, bool defer_ok) {
+bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair, const char *site, bool defer_ok, bool keep_pending) {
     struct ClearOverride { const __half *&p; ~ClearOverride() { p = nullptr; } } clear_override{xh_override_};   // valid for exactly one call
     bool same = true;
     int mask = 0;
@@ -557,12 +557,20 @@ bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
             launch_silu_mul_quant(prep->x, prep->kind == 3 ? prep->w : nullptr, N, K, act_, mask, tabs_, s);
         }
     }
+    // keep_pending (wv after a deferred wq|wk): the earlier launch's slabs stay where they are, this launch's go behind them, and both are handed to the consumer together
+    SlabSrc kept;
+    ActQ act_here = act_;
+    if (keep_pending && !prep && pend_.ks > 1 && !pend_.mixed && pend_.n == 2 && n == 1 && (size_t)pend_.n * pend_.ks * (size_t)pend_.stride < act_.ws_floats) {
+        kept = pend_; pend_ = SlabSrc{};
+        const size_t used = (size_t)kept.n * kept.ks * (size_t)kept.stride;
+        act_here.ws += used; act_here.ws_floats -= used;
+    }
     flush_pending(s);      // (nothing left unless the preparation above was fused into a mat-vec prologue or absent)
     double wbytes = 0;
     for (int i = 0; i < n; i++) wbytes += (double)W[i]->bytes;
     SiteScope sc(this, site, wbytes, s);
     bool done = false;
-    if (N >= 5 && same && mmq_enabled() >= 2) done = launch_mmq2_set(W, y, res, n, act_, N, ldy, s, defer_ok && defer_combine_ ? &pend_ : nullptr);   // prefill: one launch for the set, weights streamed once per <= 128 rows
+    if (N >= 5 && same && mmq_enabled() >= 2) done = launch_mmq2_set(W, y, res, n, act_here, N, ldy, s, defer_ok && defer_combine_ ? &pend_ : nullptr);   // prefill: one launch for the set, weights streamed once per <= 128 rows
     if (!done && same && W[0]->type == GT_F16 && N >= 512 && act_.xh) {   // unquantised weights at prompt sizes: the set in one launch of the big MFMA GEMM, split K for wo / w2
         const __half *Wh[3]; for (int i = 0; i < n; i++) Wh[i] = reinterpret_cast<const __half *>(W[i]->qs);
         const __half *Ain = !prep && xh_override_ ? xh_override_ : act_.xh;     // rows some launch left in fp16 elsewhere (the feed-forward pair's epilogue)
@@ -583,11 +591,17 @@ bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
             if (!(N == 1 && use_v2_ && launch_matvec_set(Wp, Yp, Rp, 1, act_, s))) launch_mul_mat(*W[i], act_, N, y[i], ldy, res ? res[i] : nullptr, s);
         }
     }
+    if (kept.ks > 1) {   // q | k pending from the earlier launch + this launch's v (pending or already in place): one SlabSrc for launch_rope_kv_slabs / the flush
+        SlabSrc m = kept; m.mixed = true; m.n = 3;
+        m.y[2] = y[0]; m.res[2] = res ? res[0] : nullptr;
+        if (pend_.ks > 1) { m.mbase[2] = pend_.mbase[0]; m.mks[2] = pend_.mks[0]; } else { m.mbase[2] = y[0]; m.mks[2] = 1; }
+        pend_ = m;
+    }
     return silu_pair;
 }
-void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse, const char *site, bool defer_ok) {
+void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse, const char *site, bool defer_ok, bool keep_pending) {
     const QWeight *Wp[1] = {&W}; float *Yp[1] = {y}; const float *Rp[1] = {residual};
-    mul_mat_set(Wp, Yp, Rp, 1, N, ldy, s, prep, fuse, false, site, defer_ok);
+    mul_mat_set(Wp, Yp, Rp, 1, N, ldy, s, prep, fuse, false, site, defer_ok, keep_pending);
 }
 
 // wq|wk and a differently typed wv (k-quant "more bits" layers) in one launch; returns false when the shapes / types are outside the mixed kernel's range.
@@ -686,7 +700,7 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
             else if (fz(6) && L.wk.type == L.wq.type && mixed_qkv(L, s, fz(0))) {}
             else if (act_mask_for(L.wv.type) == act_mask_for(L.wq.type) && !fz(0)) {   // one standalone preparation serves both launches
                 prep_rms(x_, L.attn_norm, N, E, act_mask_for(L.wq.type), s);
-                mul_mat_set(W3, Y3, nullptr, 2, N, E, s, nullptr, false, false, "qk"); mul_mat(L.wv, N, v_, E, nullptr, s, nullptr, false, "v");
+                mul_mat_set(W3, Y3, nullptr, 2, N, E, s, nullptr, false, false, "qk", !dec); mul_mat(L.wv, N, v_, E, nullptr, s, nullptr, false, "v", !dec, !dec);   // both combines left to the rope launch
             } else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s, &p_attn, fz(0), false, "qk"); mul_mat(L.wv, N, v_, E, nullptr, s, &p_attn, fz(0), "v"); }
         }
         // algorithmic bytes of the attention site: the cached fp16 K and V rows of every head up to the current position
@@ -696,7 +710,7 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
         if (dec && attn_split_now_) launch_attn_llm_split(q_, k_, v_, kc, vc, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, attn_ws_, attn_splits_, s);
         else if (dec) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, true, s);
         else {
-            if (pend_.ks > 1 && pend_.n == 3 && pend_.y[0] == q_ && pend_.y[1] == k_ && pend_.y[2] == v_ && !pend_.res[0] && pend_.stride == (long long)N * E) {
+            if (pend_.ks > 1 && pend_.n == 3 && pend_.y[0] == q_ && pend_.y[1] == k_ && pend_.y[2] == v_ && !pend_.res[0] && !pend_.res[1] && !pend_.res[2] && pend_.stride == (long long)N * E) {
                 launch_rope_kv_slabs(pend_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); pend_ = SlabSrc{};
             } else { flush_pending(s); launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); }
             // an F16 wo at prompt sizes multiplies fp16(attention output): let the attention kernel store those rows itself (act_.xh), no conversion launch

@@ -103,8 +103,8 @@ private:
     void forward_ref(int N, bool from_tokens, hipStream_t s, bool feed);   // parity mode: the oracle's accumulation order
     void forward_batch(int B, hipStream_t s);          // B decode rows of B conversations: tokens d_btok_[r], conversations d_bslot_[r]
     struct Prep { int kind; const float *x; const float *w; };   // 1: rms_norm(x)*w, 2: x, 3: silu(x)*w -- then quantised for the consumer's type
-    void mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse, const char *site = "matmul", bool defer_ok = false);
-    bool mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair = false, const char *site = "matmul", bool defer_ok = false);
+    void mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse, const char *site = "matmul", bool defer_ok = false, bool keep_pending = false);
+    bool mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair = false, const char *site = "matmul", bool defer_ok = false, bool keep_pending = false);
     // prompt passes: the combine of a K-split mat-mul is left to the kernel that consumes the result (rope + cache append, the next norm + quantisation, silu * mul); pend_
     // describes the slabs until then, flush_pending runs the combine as its own launch when the next consumer is not one of those.  MINIGPT4_DEFER_COMBINE=0: always flush (A/B)
     SlabSrc pend_; bool defer_combine_ = true;

@@ -35,7 +35,10 @@ int mmq_enabled();
 bool mmq2_supported(int type, int rows, int cols);
 // A split-K mat-mul whose combine step is left to its consumer (round 3): matrix m's ks slabs of `stride` floats start m * ks * stride floats into ws; the value of an
 // element is (slab_0 + ... + slab_{ks-1}) (+ res[m]) and belongs at y[m].  ks <= 1: nothing pending.
-struct SlabSrc { const float *ws = nullptr; int ks = 0; long long stride = 0; int n = 0; float *y[3] = {nullptr, nullptr, nullptr}; const float *res[3] = {nullptr, nullptr, nullptr}; };
+struct SlabSrc { const float *ws = nullptr; int ks = 0; long long stride = 0; int n = 0; float *y[3] = {nullptr, nullptr, nullptr}; const float *res[3] = {nullptr, nullptr, nullptr};
+                 // general form (results of TWO launches pending together, e.g. wq|wk and a differently typed wv): matrix m = sum of mks[m] slabs from mbase[m]; mks[m] == 1 with
+                 // mbase[m] == y[m] is a matrix that is already in place.  Set by the deferring launches as mbase[m] = ws + m * ks * stride, mks[m] = ks.
+                 const float *mbase[3] = {nullptr, nullptr, nullptr}; int mks[3] = {0, 0, 0}; bool mixed = false; };
 void launch_slab_flush(const SlabSrc &src, hipStream_t s);                                      // the combine as its own launch (k_mmq2_reduce_set)
 void launch_rms_quant_slabs(const SlabSrc &src, const float *w, int N, int K, const ActQ &A, int mask, hipStream_t s);       // n == 1: y[0] = res[0] + slabs, then rms norm * w, quantised
 void launch_silu_mul_quant_slabs(const SlabSrc &src, int N, int K, const ActQ &A, int mask, const Tables &tb, hipStream_t s);   // n == 2: silu(a) * b, quantised

@@ -1652,7 +1652,8 @@ __global__ void k_rope_kv(float *__restrict__ q, const float *__restrict__ k, co
     *reinterpret_cast<__half2 *>(vc + co) = __floats2half2_rn(v[o], v[o + 1]);
 }
 // q | k | v = the sums of the three matrices' slabs (wq | wk | wv of a prompt pass); the rotated q is written to `q` as before, k and v only to the caches
-__global__ void k_rope_kv_slabs(const float *__restrict__ slabs, const int ks, const long long stride, float *__restrict__ q, int E, int hd, const int *__restrict__ n_past,
+struct RopeSlabs { const float *base[3]; int ks[3]; };
+__global__ void k_rope_kv_slabs(const RopeSlabs rs, const long long stride, float *__restrict__ q, int E, int hd, const int *__restrict__ n_past,
                                 const float *__restrict__ cos_tab, const float *__restrict__ sin_tab, __half *__restrict__ kc, __half *__restrict__ vc) {
     const int t = blockIdx.x, h = blockIdx.y, i = threadIdx.x;   // i < hd/2
     const int pos = *n_past + t;
@@ -1661,9 +1662,9 @@ __global__ void k_rope_kv_slabs(const float *__restrict__ slabs, const int ks, c
     float2 m[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const float *b = slabs + (size_t)a * ks * stride + o;
+        const float *b = rs.base[a] + o;
         float2 acc = *reinterpret_cast<const float2 *>(b);
-        for (int z = 1; z < ks; z++) { const float2 u = *reinterpret_cast<const float2 *>(b + (size_t)z * stride); acc.x += u.x; acc.y += u.y; }
+        for (int z = 1; z < rs.ks[a]; z++) { const float2 u = *reinterpret_cast<const float2 *>(b + (size_t)z * stride); acc.x += u.x; acc.y += u.y; }
         m[a] = acc;
     }
     q[o] = m[0].x * c - m[0].y * s; q[o + 1] = m[0].x * s + m[0].y * c;
@@ -1672,7 +1673,9 @@ __global__ void k_rope_kv_slabs(const float *__restrict__ slabs, const int ks, c
     *reinterpret_cast<__half2 *>(vc + co) = __floats2half2_rn(m[2].x, m[2].y);
 }
 void launch_rope_kv_slabs(const SlabSrc &src, int N, int n_head, int hd, const int *n_past, const float *cos_tab, const float *sin_tab, __half *kcache, __half *vcache, hipStream_t s) {
-    hipLaunchKernelGGL(k_rope_kv_slabs, dim3((unsigned)N, (unsigned)n_head), dim3((unsigned)(hd / 2)), 0, s, src.ws, src.ks, src.stride, src.y[0], n_head * hd, hd, n_past, cos_tab, sin_tab, kcache, vcache);
+    RopeSlabs rs;
+    for (int a = 0; a < 3; a++) { rs.base[a] = src.mbase[a]; rs.ks[a] = src.mks[a]; }
+    hipLaunchKernelGGL(k_rope_kv_slabs, dim3((unsigned)N, (unsigned)n_head), dim3((unsigned)(hd / 2)), 0, s, rs, src.stride, src.y[0], n_head * hd, hd, n_past, cos_tab, sin_tab, kcache, vcache);
 }
 void launch_rope_kv(float *q, const float *k, const float *v, int N, int n_head, int hd, const int *n_past, const float *cos_tab, const float *sin_tab,
                     __half *kcache, __half *vcache, hipStream_t s) {

@@ -653,6 +653,10 @@ static void mmq2_launch_tt(int type, dim3 grid, size_t lds, hipStream_t s, const
 // kernel's range (nothing launched).
 void launch_slab_flush(const SlabSrc &src, hipStream_t s) {
     if (src.ks <= 1) return;
+    if (src.mixed) {   // matrices of two launches: one combine per matrix that was split
+        for (int i = 0; i < src.n; i++) if (src.mks[i] > 1) launch_slab_reduce(src.mbase[i], src.mks[i], src.stride, src.res[i], src.y[i], (size_t)src.stride, s);
+        return;
+    }
     const size_t n4 = (size_t)src.stride / 4;
     ReduceSet rs{};
     for (int i = 0; i < src.n; i++) { rs.y[i] = src.y[i]; rs.res[i] = src.res[i]; }
@@ -701,7 +705,7 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     }
     if (ks > 1) {
         SlabSrc src; src.ws = A.ws; src.ks = ks; src.stride = (long long)out_floats; src.n = n;
-        for (int i = 0; i < n; i++) { src.y[i] = y[i]; src.res[i] = residual ? residual[i] : nullptr; }
+        for (int i = 0; i < n; i++) { src.y[i] = y[i]; src.res[i] = residual ? residual[i] : nullptr; src.mbase[i] = A.ws + (size_t)i * ks * out_floats; src.mks[i] = ks; }
         if (defer) *defer = src; else launch_slab_flush(src, s);
     }
     return true;
