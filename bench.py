@@ -370,9 +370,7 @@ def main():
         "weight_bytes_per_token": wbytes, "decode_weight_GBps_end_to_end": wbytes * K / dt / 1e9,
         "model_load_s": load_s, "recv_load_s": recv_load_s, "weight_bcast_ms": bcast_ms,
         "rccl_ranks": dist.get_world_size() if dist is not None else 1, "launcher": os.environ.get("MG4_BENCH_LAUNCHER", "external") if world > 1 else "none",
-        "weight_bcast": None if not bcast_ms else {"bytes": lstats["plan"]["llm_bytes"] + lstats["plan"]["vision_bytes"], "ms": bcast_ms,
-                                                   "GBps": (lstats["plan"]["llm_bytes"] + lstats["plan"]["vision_bytes"]) / bcast_ms / 1e6, "xgmi_link_GBps": 153.0,
-                                                   "note": "both weight arenas, rank 0 -> all, ncclBroadcast in <= 1 GiB pieces; a ring broadcast is bound by one xGMI link"},
+        "weight_bcast": D.bcast_report(lstats), "load_mode": lstats["mode"],
         "roofline": roofline,
     }
     # ---- extra leg (not the headline): decode rate at long contexts (the reference's default n_ctx is 2048, examples/main.cpp:128-131): random prompt rows up to the
@@ -420,7 +418,16 @@ def main():
                                      "weight_GBps": wbytes * KB / dtb / 1e9, "note": "one hipGraph per step; every conversation has its own KV cache and position; weights streamed once per 4 conversations"}
         except Exception as e:   # never lose the headline line to the extra leg
             out["batched_decode"] = {"error": str(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if dist is not None:   # whole-job figure: every rank's leg (a collective -- every rank reaches it, error or not); the slowest rank's step bounds the job
+            legs = D.gather_objects(out["batched_decode"], world)
+            good = [x for x in legs if "error" not in x]
+            out["batched_decode"] = dict(legs[0], ranks_reporting=len(good), tokens_per_s_all_gpus=sum(x["tokens_per_s_per_gpu"] for x in good),
+                                         tokens_per_s_per_gpu_min=min((x["tokens_per_s_per_gpu"] for x in good), default=None),
+                                         ms_per_step_max_over_ranks=max((x["ms_per_step"] for x in good), default=None),
+                                         errors=[x["error"] for x in legs if "error" in x] or None) if legs else {"error": "no rank reported"}
+    # the CPU legs run on rank 0 at every world size (the other ranks wait at the closing barrier; their host threads sleep in it), so an N > 1 line carries
+    # `cpu_baseline` and `parity` like the N = 1 line
+    if rank == 0 and not args.no_cpu_baseline:
         # ---- parity on the measured file (checker use of the oracle, inside the cpu_baseline leg): the reference call sequence on both engines, same image
         # embedding, same prompt -- free-running greedy pieces + teacher-forced logits of every step (oracle/headline.py)
         try:

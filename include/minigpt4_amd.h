@@ -79,6 +79,10 @@ MINIGPT4_API int minigpt4_amd_load_mode(struct MiniGPT4Context *ctx);           
 MINIGPT4_API int minigpt4_amd_weights_received(struct MiniGPT4Context *ctx);
 MINIGPT4_API int minigpt4_amd_arena_checksum(struct MiniGPT4Context *ctx, int which, uint64_t *sum);   /* 64-bit sum of the arena's 32-bit words (device reduction) */
 
+/* Image file decoding from memory (the host half of minigpt4_image_load_from_file; the request server takes images as bytes): PNG / JPEG / BMP / binary PNM bytes -> U8 HWC RGB
+ * with cv::imread(IMREAD_COLOR)+BGR2RGB semantics.  The library allocates image->data; release with minigpt4_free_image.  0 or 5 (OpenImage). */
+MINIGPT4_API int minigpt4_amd_decode_image(const void *bytes, size_t n, OUT struct MiniGPT4Image *image);
+
 #ifdef __cplusplus
 }
 #endif

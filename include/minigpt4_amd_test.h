@@ -73,9 +73,6 @@ MINIGPT4_API const char *minigpt4_amd_vocab_piece(struct MiniGPT4Vocab *v, int i
 MINIGPT4_API int minigpt4_amd_vocab_tokenize(struct MiniGPT4Vocab *v, const char *text, int add_bos, int32_t *out, int cap);
 /* Parses both files without touching a GPU.  Returns a MiniGPT4Error; fills counts when non-NULL. */
 MINIGPT4_API int minigpt4_amd_inspect_files(const char *vision_path, const char *llm_path, int *n_vision_tensors, int *n_llm_tensors, int64_t *llm_weight_bytes_per_token);
-/* Image file decoding from memory (the host half of minigpt4_image_load_from_file): PNG / JPEG / BMP / binary PNM bytes -> U8 HWC RGB with
- * cv::imread(IMREAD_COLOR)+BGR2RGB semantics.  The library allocates image->data; release with minigpt4_free_image.  0 or 5 (OpenImage). */
-MINIGPT4_API int minigpt4_amd_decode_image(const void *bytes, size_t n, OUT struct MiniGPT4Image *image);
 /* Pillow's 8-bit bicubic resample tables for in_size -> out_size (what the preprocess kernels consume): first/count: int[out_size],
  * kk: int[out_size * ksize] (22-bit fixed point).  Call with kk = NULL to learn ksize.  0, -1 (bad sizes) or -2 (kk_cap too small). */
 MINIGPT4_API int minigpt4_amd_resample_coeffs(int in_size, int out_size, int *ksize, int *first, int *count, int *kk, size_t kk_cap);

@@ -161,7 +161,7 @@ void minigpt4_set_verbosity(int verbosity) { g_verbosity = verbosity & 0xFF; }
 // ======================================================================================================== additive API
 int minigpt4_amd_device_count(void) { return device_count_noexcept(); }
 const char *minigpt4_amd_last_error(void) { return last_error().c_str(); }
-const char *minigpt4_amd_build_info(void) { return "minigpt4.cpp_amd: gfx950 (CDNA4) HIP kernels; v_dot4_i32_i8 fused-dequant mat-vec, MFMA f16 GEMM"; }
+const char *minigpt4_amd_build_info(void) { return "minigpt4.cpp_amd: gfx950 (CDNA4) HIP kernels; v_dot4_i32_i8 fused-dequant mat-vec, MFMA f16 GEMM; api.o built " __DATE__ " " __TIME__; }
 int minigpt4_amd_n_vocab(struct MiniGPT4Context *ctx) { return ctx ? E_(ctx)->n_vocab() : 0; }
 int minigpt4_amd_n_embd(struct MiniGPT4Context *ctx) { return ctx ? E_(ctx)->n_embd() : 0; }
 int minigpt4_amd_n_past(struct MiniGPT4Context *ctx) { return ctx ? E_(ctx)->n_past() : 0; }
@@ -302,4 +302,16 @@ int minigpt4_amd_arena_checksum(struct MiniGPT4Context *ctx, int which, uint64_t
     });
 }
 
+int minigpt4_amd_decode_image(const void *bytes, size_t n, struct MiniGPT4Image *image) {
+    if (!bytes || !image) return E_OpenImage;
+    return guarded((int)E_OpenImage, [&]() -> int {
+        ImageRGB8 im; std::string err;
+        if (!decode_image(static_cast<const uint8_t *>(bytes), n, im, err)) { set_last_error(err); return E_OpenImage; }
+        uint8_t *data = new (std::nothrow) uint8_t[im.px.size()];
+        if (!data) return E_OpenImage;
+        memcpy(data, im.px.data(), im.px.size());
+        image->data = data; image->width = im.w; image->height = im.h; image->channels = 3; image->format = MINIGPT4_IMAGE_FORMAT_U8;
+        return E_None;
+    });
+}
 }  // extern "C"

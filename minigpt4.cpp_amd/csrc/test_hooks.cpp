@@ -525,16 +525,6 @@ int minigpt4_amd_inspect_files(const char *vision_path, const char *llm_path, in
     }
     return E_None;
 }
-int minigpt4_amd_decode_image(const void *bytes, size_t n, struct MiniGPT4Image *image) {
-    if (!bytes || !image) return E_OpenImage;
-    ImageRGB8 im; std::string err;
-    if (!decode_image(static_cast<const uint8_t *>(bytes), n, im, err)) { set_last_error(err); return E_OpenImage; }
-    uint8_t *data = new (std::nothrow) uint8_t[im.px.size()];
-    if (!data) return E_OpenImage;
-    memcpy(data, im.px.data(), im.px.size());
-    image->data = data; image->width = im.w; image->height = im.h; image->channels = 3; image->format = MINIGPT4_IMAGE_FORMAT_U8;
-    return E_None;
-}
 int minigpt4_amd_resample_coeffs(int in_size, int out_size, int *ksize, int *first, int *count, int *kk, size_t kk_cap) {
     if (in_size <= 0 || out_size <= 0 || in_size > (1 << 24) || out_size > (1 << 16)) return -1;
     ResampleCoeffs c; precompute_bicubic_8bpc(in_size, out_size, c);

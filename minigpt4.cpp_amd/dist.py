@@ -93,19 +93,36 @@ def load_replica(lib, vision_path: str, llm_path: str, rank: int, world: int, de
                 broadcast_arena(arena_tensor(lib, ctx, which, device), src=0)
             if device is not None:
                 torch.cuda.synchronize(device)
+            stats["bcast_ms"] = (time.time() - t0) * 1e3       # only a broadcast that COMPLETED is a measurement
         except Exception as e:   # a launch-time refusal is raised by every rank at the same call: all of them take this branch and fall back to reading the files
             stats["bcast_error"] = f"{type(e).__name__}: {e}"[:300]
+            stats["bcast_failed_after_ms"] = (time.time() - t0) * 1e3
             if recv:
                 lib.minigpt4_free(ctx)
                 t1 = time.time()
                 ctx = lib.minigpt4_model_load(vision_path, llm_path, **load_kw)
                 stats["mode"], stats["load_s"] = "full (broadcast refused)", time.time() - t1
                 recv = False
-        stats["bcast_ms"] = (time.time() - t0) * 1e3
         if recv:
             assert lib.library.minigpt4_amd_weights_received(ctx.ptr) == 0
         sums = gather_objects([lib.amd_arena_checksum(ctx, 0), lib.amd_arena_checksum(ctx, 1)], world)
         if any(c != sums[0] for c in sums):
             raise RuntimeError(f"rank {rank}: arena contents differ after the broadcast: {sums}")
         stats["checksums"] = sums[0]
+        errs = gather_objects(stats.get("bcast_error"), world)
+        if any(errs) and not stats.get("bcast_error"):          # some OTHER rank fell back to the files: this rank's timing is not a broadcast measurement either
+            stats["bcast_error"], stats["bcast_ms"] = "another rank: " + next(e for e in errs if e), None
     return ctx, stats
+
+
+def bcast_report(stats: dict):
+    """The `weight_bcast` object of the bench line, from load_replica's stats: a measured broadcast, an explicit error record when the broadcast was refused
+    (the replicas then came from the files -- never a GB/s figure), or None for a single-rank run."""
+    if stats.get("bcast_error"):
+        return {"error": stats["bcast_error"], "mode": stats.get("mode"), "failed_after_ms": stats.get("bcast_failed_after_ms"),
+                "note": "the arena broadcast was refused; every rank loaded from the files instead -- no broadcast rate was measured"}
+    if not stats.get("bcast_ms"):
+        return None
+    nbytes = stats["plan"]["llm_bytes"] + stats["plan"]["vision_bytes"]
+    return {"bytes": nbytes, "ms": stats["bcast_ms"], "GBps": nbytes / stats["bcast_ms"] / 1e6, "xgmi_link_GBps": 153.0,
+            "note": "both weight arenas, rank 0 -> all, ncclBroadcast in <= 1 GiB pieces; a ring broadcast is bound by one xGMI link"}

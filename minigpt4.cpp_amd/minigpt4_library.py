@@ -67,20 +67,44 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
+def _test_hook_names() -> frozenset:
+    """The names include/minigpt4_amd_test.h declares: the ONLY symbols that may be served by libminigpt4_test.so."""
+    import re
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "minigpt4_amd_test.h")
+    try:
+        with open(hdr) as f:
+            return frozenset(re.findall(r"\b(minigpt4_amd_[a-z0-9_]+)\s*\(", f.read()))
+    except OSError:
+        return frozenset()
+
+
 class _Symbols:
-    """Attribute access to the product library's symbols; a symbol the product does not export (kernel-level test hooks, micro-benchmarks, probes, host-only test helpers:
-    include/minigpt4_amd_test.h) is looked up in libminigpt4_test.so, which is loaded -- and has its prototypes declared -- on first use.  Only tests/ and tools/ ever get there."""
+    """Attribute access to the product library's symbols.  A name that include/minigpt4_amd_test.h declares (kernel-level test hooks, micro-benchmarks, probes, host-only test
+    helpers) is served by libminigpt4_test.so, which is loaded -- and has its prototypes declared -- on first use; only tests/ and tools/ ever get there.  Any other
+    name the product does not export is an AttributeError (a typo must not load a second copy of the engine).  The two libraries are separate copies of the engine's
+    state (tuning knobs, last error): contexts are never passed from one to the other except by `minigpt4_amd_copy_arenas`, and both must report the same build."""
 
     def __init__(self, product, test_path: str, declare_test):
-        self.__dict__.update(_product=product, _test_path=test_path, _declare_test=declare_test, _test=None)
+        self.__dict__.update(_product=product, _test_path=test_path, _declare_test=declare_test, _test=None, _hook_names=_test_hook_names())
 
     def _hooks(self):
         if self._test is None:
             if not os.path.exists(self._test_path):
                 raise AttributeError(f"{self._test_path} not found (the test-hook build of the library: `make -C minigpt4.cpp_amd/csrc`)")
-            self.__dict__["_test"] = ctypes.cdll.LoadLibrary(self._test_path)
-            self._declare_test(self._test)
+            test = ctypes.cdll.LoadLibrary(self._test_path)
+            for lib_ in (test, self._product):
+                lib_.minigpt4_amd_build_info.restype = CHAR_PTR
+            a, b = self._product.minigpt4_amd_build_info(), test.minigpt4_amd_build_info()
+            if a != b:
+                raise RuntimeError(f"libminigpt4.so and {os.path.basename(self._test_path)} come from different builds ({a!r} vs {b!r}): rebuild both (`make -C minigpt4.cpp_amd/csrc`)")
+            self.__dict__["_test"] = test
+            self._declare_test(test)
         return self._test
+
+    @property
+    def test_hooks(self):
+        """libminigpt4_test.so itself (explicit handle)."""
+        return self._hooks()
 
     def _last_error(self):
         """thread-local error text of the product library and, once it is loaded, of the test-hook library (each has its own copy of the engine's state)."""
@@ -91,10 +115,9 @@ class _Symbols:
     def __getattr__(self, name):
         if name == "minigpt4_amd_last_error":
             return self._last_error
-        try:
-            return getattr(self._product, name)
-        except AttributeError:
+        if name in self._hook_names:
             return getattr(self._hooks(), name)
+        return getattr(self._product, name)
 
 
 class MiniGPT4SharedLibrary:
@@ -135,6 +158,8 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_device_count.restype = I32
         L.minigpt4_amd_last_error.restype = CHAR_PTR
         L.minigpt4_amd_build_info.restype = CHAR_PTR
+        L.minigpt4_amd_decode_image.argtypes = [CHAR_PTR, SIZE_T, P(MiniGPT4Image)]
+        L.minigpt4_amd_decode_image.restype = I32
         for name in ("n_vocab", "n_embd", "n_past", "sync"):
             getattr(L, "minigpt4_amd_" + name).argtypes = [VOID_PTR]
             getattr(L, "minigpt4_amd_" + name).restype = I32
@@ -190,7 +215,6 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_vocab_tokenize.argtypes = [VOID_PTR, CHAR_PTR, I32, INT_PTR, I32]
         L.minigpt4_amd_inspect_files.argtypes = [CHAR_PTR, CHAR_PTR, INT_PTR, INT_PTR, P(ctypes.c_int64)]
         L.minigpt4_amd_sample_logits.argtypes = [FLOAT_PTR, I32, I32, F32, I32, F32, F32, F32, I32, F32, F32]
-        L.minigpt4_amd_decode_image.argtypes = [CHAR_PTR, SIZE_T, P(MiniGPT4Image)]
         L.minigpt4_amd_resample_coeffs.argtypes = [I32, I32, INT_PTR, INT_PTR, INT_PTR, INT_PTR, SIZE_T]
         L.minigpt4_amd_copy_arenas.argtypes = [VOID_PTR, VOID_PTR]
         L.minigpt4_amd_llm_file_digest.argtypes = [CHAR_PTR, U64P, I32]

@@ -37,9 +37,15 @@ def plan_waves(n_requests: int, conversations: int) -> List[List[int]]:
 
 class ReplicaServer:
     def __init__(self, vision_path: str, llm_path: str, conversations: int = 4, n_ctx: int = 2048, n_batch: int = 512, seed: int = 1337,
-                 library: Optional[ML.MiniGPT4SharedLibrary] = None, verbosity: int = 0):
+                 library: Optional[ML.MiniGPT4SharedLibrary] = None, verbosity: int = 0, rank: int = 0, world: int = 1, device=None):
+        """world > 1 (inside an initialised `torch.distributed` job): the replica is loaded through `dist.load_replica` -- rank 0 reads the files, every other
+        rank loads headers only and receives both weight arenas by broadcast, so the weights cross the file system once per node."""
         self.lib = library or ML.load_library()
-        self.ctx = self.lib.minigpt4_model_load(vision_path, llm_path, verbosity=verbosity, seed=seed, n_ctx=n_ctx, n_batch=n_batch)
+        self.load_stats = None
+        if world > 1:
+            self.ctx, self.load_stats = D.load_replica(self.lib, vision_path, llm_path, rank, world, device=device, verbosity=verbosity, seed=seed, n_ctx=n_ctx, n_batch=n_batch)
+        else:
+            self.ctx = self.lib.minigpt4_model_load(vision_path, llm_path, verbosity=verbosity, seed=seed, n_ctx=n_ctx, n_batch=n_batch)
         self.conversations = conversations
         self.lib.amd_set_conversations(self.ctx, conversations)
 
@@ -110,10 +116,12 @@ class ReplicaServer:
 
 def serve(requests: Sequence[Request], vision_path: str, llm_path: str, conversations: int = 4, **kw) -> Optional[List[str]]:
     """Data-parallel entry point: call it on every rank of a `torch.distributed` job (or alone).  Rank r serves requests r, r + world, ...;
-    rank 0 returns all answers in request order, the other ranks return None."""
+    rank 0 returns all answers in request order, the other ranks return None.  With world > 1 the replicas are loaded through `dist.load_replica`
+    (file load on rank 0, arena broadcast to the others); pass `device=torch.device("cuda", local_rank)` on GPUs."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     mine = D.shard_requests(len(requests), rank, world)
-    server = ReplicaServer(vision_path, llm_path, conversations=conversations, **{k: v for k, v in kw.items() if k in ("n_ctx", "n_batch", "seed", "library", "verbosity")})
+    server = ReplicaServer(vision_path, llm_path, conversations=conversations, rank=rank, world=world, device=kw.get("device"),
+                           **{k: v for k, v in kw.items() if k in ("n_ctx", "n_batch", "seed", "library", "verbosity")})
     try:
         out = server.run([requests[i] for i in mine], **{k: v for k, v in kw.items() if k in ("temp", "top_k", "top_p", "ignore_eos")})
     finally:

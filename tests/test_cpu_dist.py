@@ -86,3 +86,98 @@ def test_bench_world_size_must_match_gpus_flag():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--config", "tiny"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+# ---- load_replica on two gloo ranks with a stand-in library (no GPU): the good path, and a REFUSED broadcast -- the JSON must say so, never a GB/s figure
+class _FakeCtx:
+    def __init__(self, mode, torch, np):
+        self.mode, self.ptr, self.received = mode, id(self), False
+        rng = np.random.default_rng(5)
+        self.arenas = [torch.from_numpy(rng.integers(0, 256, n, dtype=np.uint8)) if mode == "full" else torch.zeros(n, dtype=torch.uint8) for n in (70001, 3001)]
+
+
+class _FakeLib:
+    """What dist.load_replica / serve.ReplicaServer use of MiniGPT4SharedLibrary."""
+    def __init__(self, torch, np):
+        self.torch, self.np, self.loads, self.freed, self.conversations = torch, np, [], 0, None
+        outer = self
+
+        class _Raw:
+            @staticmethod
+            def minigpt4_amd_weights_received(ptr):
+                outer.received = True
+                return 0
+        self.library, self.received = _Raw, False
+
+    def minigpt4_model_load(self, vp, lp, **kw):
+        mode = "recv" if os.environ.get("MINIGPT4_LOAD") == "recv" else "full"
+        self.loads.append(mode)
+        return _FakeCtx(mode, self.torch, self.np)
+
+    def amd_arena_plan(self, ctx):
+        return {"llm_bytes": 70001, "vision_bytes": 3001, "llm_hash": 11, "vision_hash": 12}
+
+    def amd_arena_checksum(self, ctx, which):
+        return int(ctx.arenas[which].to(self.torch.int64).sum())
+
+    def minigpt4_free(self, ctx):
+        self.freed += 1
+
+    def amd_set_conversations(self, ctx, n):
+        self.conversations = n
+
+
+def _replica_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import _pkg
+    _pkg.load_package()
+    import json
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from minigpt4_cpp_amd import dist as D, serve as S
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D.arena_tensor = lambda lib, ctx, which, device: ctx.arenas[which]
+        # 1) the broadcast works: rank 1 loaded headers only, received the arenas, finished the load; the report carries a rate
+        lib = _FakeLib(torch, np)
+        ctx, st = D.load_replica(lib, "v.bin", "l.bin", rank, world)
+        assert lib.loads == (["full"] if rank == 0 else ["recv"]) and lib.received == (rank != 0) and lib.freed == 0
+        assert st["bcast_ms"] is not None and "bcast_error" not in st and st["mode"] == ("full" if rank == 0 else "recv")
+        rep = D.bcast_report(st)
+        assert rep["bytes"] == 73002 and rep["GBps"] > 0 and "error" not in rep
+        # 2) the broadcast is refused at its first call on every rank (what a launch-time RCCL refusal looks like)
+        real_bcast = D.broadcast_arena
+
+        def refuse(*a, **k):
+            raise RuntimeError("ncclInternalError: injected")
+        D.broadcast_arena = refuse
+        lib = _FakeLib(torch, np)
+        ctx, st = D.load_replica(lib, "v.bin", "l.bin", rank, world)
+        assert lib.loads == (["full"] if rank == 0 else ["recv", "full"]) and lib.freed == (0 if rank == 0 else 1) and not lib.received
+        assert st["bcast_ms"] is None and "injected" in st["bcast_error"] and (rank == 0 or st["mode"] == "full (broadcast refused)")
+        rep = D.bcast_report(st)
+        assert "injected" in rep["error"] and "GBps" not in rep and "ms" not in rep
+        json.dumps(rep)
+        # 3) the request-level entry point loads its replicas the same way (serve.ReplicaServer -> dist.load_replica)
+        D.broadcast_arena = real_bcast
+        lib = _FakeLib(torch, np)
+        srv = S.ReplicaServer("v.bin", "l.bin", conversations=3, library=lib, rank=rank, world=world)
+        assert lib.loads == (["full"] if rank == 0 else ["recv"]) and lib.conversations == 3 and srv.load_stats["bcast_ms"] is not None
+        with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_load_replica_reports_a_refused_broadcast_as_an_error_not_as_a_rate(tmp_path):
+    import torch.multiprocessing as mp
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_replica_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_bcast_report_single_rank_is_none():
+    from minigpt4_cpp_amd import dist as D
+    assert D.bcast_report({"mode": "full", "load_s": 1.0, "bcast_ms": None, "plan": {"llm_bytes": 1, "vision_bytes": 1}}) is None
