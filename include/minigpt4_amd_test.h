@@ -49,6 +49,8 @@ MINIGPT4_API int minigpt4_amd_test_f16_silu_pair(const float *x, const void *w_f
 /* Micro-benchmark of the prompt-row attention on a synthetic fp16 K / V cache (tools/timeline_attn_prefill.py); _timeline_attn: its stamps in a -DMG4_TIMELINE build */
 MINIGPT4_API int minigpt4_amd_bench_attn_prefill(int n_head, int hd, int N, int n_past, int iters, float *us_per_launch);
 MINIGPT4_API int minigpt4_amd_timeline_attn(unsigned long long *out, int max_workgroups);
+/* the persistent decode engine's stamps (64 x u64 per workgroup, csrc/decode_engine.hip) of the last launch of the selected layer; layer >= 0 selects the layer (out may be NULL) */
+MINIGPT4_API int minigpt4_amd_timeline_engine(unsigned long long *out, int max_workgroups, int layer);
 /* force one tile shape (an "arm" of launch_gemm_f16_arm in vision_kernels.hip; 0 = the launcher's own choice) for every small-M GEMM / split-K GEMM of this process */
 MINIGPT4_API void minigpt4_amd_test_set_gemm_arm(int arm, int sk_arm);
 /* diagnostic builds (-DMG4_TIMELINE): the 32 clock stamps per workgroup of the last image-path GEMM launch; 0 = built without */
@@ -60,6 +62,9 @@ MINIGPT4_API int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, in
 /* Average latency (microseconds) of a device-wide barrier across n_blocks co-resident 512-thread workgroups (atomic counter + agent-scope fences); *errors
  * counts visibility failures of a neighbour-word check.  Measurement for DESIGN.md's launch-gap-vs-barrier analysis. */
 MINIGPT4_API float minigpt4_amd_probe_grid_barrier(int n_blocks, int iters, unsigned *errors);
+/* LDS-DMA stream probe (csrc/probe_kernels.hip, tools/probe_dma.py): chip-wide GB/s of `waves` loader waves per CU keeping `depth` fills of `fill` bytes in flight into an LDS
+ * ring; form 0 scalar base + instruction offsets, 1 per-lane addresses, 2 register loads, 3 register loads + ds_write; policy 0 nt, 1 default; deal 0 blocked, 1 round-robin */
+MINIGPT4_API float minigpt4_amd_probe_dma(int form, int policy, int waves, int fill, int depth, int deal, double total_gb);
 /* vector-ALU issue probe: ns per instruction and wave for one instruction kind (0 v_and, 1 v_dot4c_i32_i8, 2 v_mul_lo_u32, 3 v_mad_i32_i24, 4 v_fma_f32, 5 v_and_or,
    6 v_bfe_u32, 7 v_cvt_f32_i32, 8 v_dot4_i32_i8, 9 v_mad_u64_u32, 10 v_lshrrev) at 1..4 waves per SIMD; < 0 without a GPU */
 MINIGPT4_API float minigpt4_amd_probe_valu(int op, int waves_per_simd, int iters);

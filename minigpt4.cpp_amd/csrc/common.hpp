@@ -80,7 +80,7 @@ struct ActQ {
     float *ws = nullptr; size_t ws_floats = 0;   // (optional) workspace that travels with the planes: K-split partial sums of the prefill mat-mul (mmq2_kernels.hip)
 };
 enum ActMask : int { ACT_Q8K = 1, ACT_Q80 = 2, ACT_F16 = 4, ACT_F32 = 8 };
-inline int act_mask_for(int wtype) {
+__host__ __device__ inline int act_mask_for(int wtype) {
     switch (wtype) { case GT_Q4_0: case GT_Q5_0: case GT_Q8_0: case GT_Q4_1: case GT_Q5_1: return ACT_Q80; case GT_Q2_K: case GT_Q4_K: case GT_Q5_K: case GT_Q6_K: return ACT_Q8K;
         case GT_F16: return ACT_F16; case GT_F32: return ACT_F32; default: return 0; }
 }

@@ -8,6 +8,7 @@
 namespace mg4 {
 
 static int g_probe_cus = 256;
+typedef unsigned v4u_pr __attribute__((ext_vector_type(4)));
 __global__ void k_fill_random(unsigned *p, size_t n_words, unsigned seed) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) {
         unsigned x = (unsigned)i * 2654435761u ^ seed; x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; p[i] = x; }
@@ -109,6 +110,99 @@ float probe_valu_ns(int op, int waves_per_simd, int iters, int cus) {
     case 6: return valu_probe_run<6>(threads, iters); case 7: return valu_probe_run<7>(threads, iters); case 8: return valu_probe_run<8>(threads, iters);
     case 9: return valu_probe_run<9>(threads, iters); case 10: return valu_probe_run<10>(threads, iters); default: return -1.0f;
     }
+}
+
+// LDS-DMA stream probe (tools/probe_dma.py): how fast can loader waves alone pull a large buffer into an LDS ring?  One workgroup per CU, `waves` loader waves, each
+// keeping `depth` fills of `fill` bytes (whole KiB) in flight into its own slots of the ring; nobody reads the data.  form 0: scalar base + lane offset + instruction
+// offsets, four pieces per M0 write (the decode engine's statement); form 1: per-lane 64-bit address, one piece per M0 write.  policy 0: nt, 1: default.  deal 0: every
+// workgroup streams its own contiguous region, 1: fills dealt round-robin over the workgroups.  Compared with form 2: the same bytes through ordinary register loads
+// (8 x dwordx4 per lane in flight per wave, what k_matvec_v2's pipeline does), and form 3: register loads + ds_write into the ring.
+typedef __attribute__((address_space(3))) void *pr_lds_t;
+template <int FORM, int POLICY>
+__global__ __launch_bounds__(512) void k_probe_dma(const unsigned char *__restrict__ src, size_t bytes_per_wg, int fill, int depth, int deal, unsigned *sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
+    const int n_fills = (int)(bytes_per_wg / (size_t)fill);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)ring);
+    const int pieces = fill >> 10;
+    unsigned acc = 0;
+    int issued = 0;                                     // fills this wave has issued
+    for (int f = wave; f < n_fills; f += n_waves, issued++) {
+        const size_t gfill = deal ? (size_t)f * gridDim.x + blockIdx.x : (size_t)blockIdx.x * n_fills + f;
+        const unsigned char *p = src + gfill * (size_t)fill;
+        const unsigned slot = (unsigned)((wave * depth + issued % depth) * fill);
+        if (FORM <= 1) {
+            if (issued >= depth) {                      // the fill that used this slot must have landed: at most (depth - 1) fills' pieces may remain in flight
+                const int left = (depth - 1) * pieces;
+                switch (left) { case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break; case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break; case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+                    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break; case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+                    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break; case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+                    case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break; case 42: asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); break;
+                    case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break; case 56: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break; }
+            }
+            if (FORM == 0) {
+                const unsigned long long a = (unsigned long long)(size_t)p;
+                unsigned long long sb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
+                unsigned ld = lds0 + slot; const unsigned voff = (unsigned)lane * 16u;
+                for (int k = 0; k + 4 <= pieces; k += 4, sb += 4096, ld += 4096) {
+                    unsigned keep;
+                    if (POLICY == 0) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:0 nt\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024 nt\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048 nt\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072 nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sb), "s"(ld) : "memory");
+                    else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:0\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sb), "s"(ld) : "memory");
+                }
+            } else {
+                for (int k = 0; k < pieces; k++) {
+                    const unsigned char *g = p + (size_t)k * 1024 + lane * 16;
+                    const unsigned ld = lds0 + slot + (unsigned)k * 1024u;
+                    unsigned keep;
+                    if (POLICY == 0) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(ld) : "memory");
+                    else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(ld) : "memory");
+                }
+            }
+        } else {                                        // register loads: `pieces` x dwordx4 per lane, consumed (xor) one fill later so that two fills are in flight
+            for (int k = 0; k < pieces; k += 8) {
+                v4u_pr v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = POLICY == 0 ? __builtin_nontemporal_load(reinterpret_cast<const v4u_pr *>(p + (size_t)(k + j) * 1024 + lane * 16)) : *reinterpret_cast<const v4u_pr *>(p + (size_t)(k + j) * 1024 + lane * 16);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (FORM == 3) *reinterpret_cast<v4u_pr *>(ring + slot + (size_t)(k + j) * 1024 + lane * 16) = v[j];
+                    else acc ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (acc == 0x12345678u) *sink = acc;
+}
+// GB/s over the whole chip; < 0 on a bad argument
+float probe_dma_GBps(int form, int policy, int waves, int fill, int depth, int deal, size_t total_bytes) {
+    if (fill % 1024 || fill <= 0 || (form <= 1 && (fill >> 10) % 4) || waves < 1 || waves > 8 || depth < 1 || (size_t)waves * depth * fill > 150 * 1024) return -1.0f;
+    hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const size_t per_wg = total_bytes / cus / fill * fill, total = per_wg * cus;
+    unsigned char *buf = nullptr; unsigned *sink = nullptr;
+    HIP_CHECK(hipMalloc((void **)&buf, total + 4096)); HIP_CHECK(hipMalloc((void **)&sink, 4));
+    launch_fill_random(buf, total, 7u, nullptr);
+    const size_t lds = (size_t)waves * depth * fill;
+    auto launch = [&](size_t bytes_per_wg) {
+        const dim3 g((unsigned)cus), b((unsigned)waves * 64);
+#define PR_GO(F, P) do { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_probe_dma<F, P>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                         hipLaunchKernelGGL((k_probe_dma<F, P>), g, b, lds, nullptr, buf, bytes_per_wg, fill, depth, deal, sink); } while (0)
+        switch (form * 2 + policy) { case 0: PR_GO(0, 0); break; case 1: PR_GO(0, 1); break; case 2: PR_GO(1, 0); break; case 3: PR_GO(1, 1); break;
+                                     case 4: PR_GO(2, 0); break; case 5: PR_GO(2, 1); break; case 6: PR_GO(3, 0); break; default: PR_GO(3, 1); break; }
+#undef PR_GO
+    };
+    hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+    launch((size_t)fill * waves * 4);                   // warm-up (code object, attributes)
+    HIP_CHECK(hipEventRecord(a, nullptr));
+    launch(per_wg);
+    HIP_CHECK(hipEventRecord(b, nullptr));
+    HIP_CHECK(hipDeviceSynchronize());
+    float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b)); HIP_IGNORE(hipFree(buf)); HIP_IGNORE(hipFree(sink));
+    return (float)((double)total / (ms * 1e-3) / 1e9);
 }
 
 }  // namespace mg4

@@ -17,6 +17,7 @@ using namespace mg4::apiutil;
 namespace mg4 {   // probe_kernels.hip
 float probe_valu_ns(int op, int waves_per_simd, int iters, int cus);
 float probe_grid_barrier_us(int n_blocks, int iters, unsigned *errors_out);
+float probe_dma_GBps(int form, int policy, int waves, int fill, int depth, int deal, size_t total_bytes);
 void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s);
 }
 
@@ -364,6 +365,7 @@ int minigpt4_amd_bench_attn_prefill(int n_head, int hd, int N, int n_past, int i
         return 0;
     });
 }
+int minigpt4_amd_timeline_engine(unsigned long long *out, int max_workgroups, int layer) { return read_engine_timeline(out, max_workgroups, layer); }
 int minigpt4_amd_timeline_attn(unsigned long long *out, int max_workgroups) { return (out && max_workgroups > 0) ? read_attn_timeline(out, max_workgroups) : -1; }
 void minigpt4_amd_test_set_gemm_arm(int arm, int sk_arm) { set_gemm_tuning(-1, 0, arm, sk_arm); }
 int minigpt4_amd_timeline_vision(unsigned long long *out, int max_workgroups) { return (out && max_workgroups > 0) ? read_vision_timeline(out, max_workgroups) : -1; }
@@ -479,6 +481,11 @@ float minigpt4_amd_probe_valu(int op, int waves_per_simd, int iters) {
     float ns = -1.0f;
     guarded(1, [&] { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0)); set_matvec_tuning(0, 0, prop.multiProcessorCount); ns = probe_valu_ns(op, waves_per_simd, iters, prop.multiProcessorCount); return 0; });
     return ns;
+}
+float minigpt4_amd_probe_dma(int form, int policy, int waves, int fill, int depth, int deal, double total_gb) {
+    float r = -1.0f;
+    guarded(1, [&] { r = probe_dma_GBps(form, policy, waves, fill, depth, deal, (size_t)(total_gb * 1e9)); return 0; });
+    return r;
 }
 float minigpt4_amd_probe_grid_barrier(int n_blocks, int iters, unsigned *errors) {
     if (n_blocks < 1 || n_blocks > 1024 || iters < 1 || device_count_noexcept() <= 0) return -1.0f;
