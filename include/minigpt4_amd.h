@@ -36,10 +36,6 @@ MINIGPT4_API int minigpt4_amd_sample(struct MiniGPT4Context *ctx, int32_t *token
 /* Parity mode (also MINIGPT4_PARITY=1 in the environment at load): every fp32 accumulation of the language path in the CPU oracle's order (oracle/refcpu.c) -- logits and
  * greedy ids bit-identical to it; slow (one wavefront per output element).  Takes effect with the next evaluation; the KV cache and positions are kept.  0 / 1 */
 MINIGPT4_API int minigpt4_amd_set_parity(struct MiniGPT4Context *ctx, int on);
-/* The persistent decode engine (one launch per layer runs wo -> w1|w3 -> w2 -> the next layer's q|k|v with in-launch hand-offs; MINIGPT4_ENGINE=0 in the environment switches
- * it off at load): on / off at run time -- both steps produce bit-identical logits -- and whether the selected path is the engine (0 when the model is outside its range). */
-MINIGPT4_API int minigpt4_amd_set_engine(struct MiniGPT4Context *ctx, int on);
-MINIGPT4_API int minigpt4_amd_engine_active(struct MiniGPT4Context *ctx);
 MINIGPT4_API int minigpt4_amd_parity(struct MiniGPT4Context *ctx);                 /* 1 / 0; -1 without a context */
 
 /* ---- measurement ---------------------------------------------------------------------------------------------------- */

@@ -49,8 +49,6 @@ MINIGPT4_API int minigpt4_amd_test_f16_silu_pair(const float *x, const void *w_f
 /* Micro-benchmark of the prompt-row attention on a synthetic fp16 K / V cache (tools/timeline_attn_prefill.py); _timeline_attn: its stamps in a -DMG4_TIMELINE build */
 MINIGPT4_API int minigpt4_amd_bench_attn_prefill(int n_head, int hd, int N, int n_past, int iters, float *us_per_launch);
 MINIGPT4_API int minigpt4_amd_timeline_attn(unsigned long long *out, int max_workgroups);
-/* the persistent decode engine's stamps (64 x u64 per workgroup, csrc/decode_engine.hip) of the last launch of the selected layer; layer >= 0 selects the layer (out may be NULL) */
-MINIGPT4_API int minigpt4_amd_timeline_engine(unsigned long long *out, int max_workgroups, int layer);
 /* force one tile shape (an "arm" of launch_gemm_f16_arm in vision_kernels.hip; 0 = the launcher's own choice) for every small-M GEMM / split-K GEMM of this process */
 MINIGPT4_API void minigpt4_amd_test_set_gemm_arm(int arm, int sk_arm);
 /* diagnostic builds (-DMG4_TIMELINE): the 32 clock stamps per workgroup of the last image-path GEMM launch; 0 = built without */

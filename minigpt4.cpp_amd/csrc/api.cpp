@@ -285,11 +285,6 @@ int minigpt4_amd_set_parity(struct MiniGPT4Context *ctx, int on) {
     if (!ctx) return 1;
     return guarded(1, [&]() -> int { E_(ctx)->set_parity(on != 0); return 0; });
 }
-int minigpt4_amd_set_engine(struct MiniGPT4Context *ctx, int on) {
-    if (!ctx) return 1;
-    return guarded(1, [&]() -> int { E_(ctx)->set_engine(on != 0); return 0; });
-}
-int minigpt4_amd_engine_active(struct MiniGPT4Context *ctx) { return ctx && E_(ctx)->engine_active() ? 1 : 0; }
 int minigpt4_amd_parity(struct MiniGPT4Context *ctx) { return ctx ? (int)E_(ctx)->parity() : -1; }
 int minigpt4_amd_load_mode(struct MiniGPT4Context *ctx) { return ctx ? (int)E_(ctx)->load_mode() : -1; }
 int minigpt4_amd_weights_received(struct MiniGPT4Context *ctx) {

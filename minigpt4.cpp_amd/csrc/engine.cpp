@@ -86,7 +86,7 @@ Engine::~Engine() {
     release_buffers();
     if (stream_) HIP_IGNORE(hipStreamDestroy(stream_));
 }
-void Engine::sync() { (void)flush(); HIP_CHECK(hipStreamSynchronize(stream_)); check_engine_status(); }
+void Engine::sync() { (void)flush(); HIP_CHECK(hipStreamSynchronize(stream_)); }
 
 // ====================================================================================================================
 // init / load
@@ -127,7 +127,6 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (const char *bs = getenv("MINIGPT4_BATCH_SETS")) batch_sets_ = atoi(bs) != 0;
     if (const char *fp = getenv("MINIGPT4_F16_PAIR")) f16_pair_ = atoi(fp);        // bit mask (A/B): 1 w1|w3 + silu*mul in one launch, 4 the attention kernel stores fp16 rows for wo
     use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
-    if (const char *e = getenv("MINIGPT4_ENGINE")) use_engine_ = atoi(e) != 0;   // 0: the launch-per-op decode step (A/B, and what every engine result must equal bit for bit)
     attn_prefill_ = !(getenv("MINIGPT4_ATTN_PREFILL") && !atoi(getenv("MINIGPT4_ATTN_PREFILL")));   // 0: the per-token attention kernel also for prompt rows (A/B, tests)
     // Opt-in experiment (unmeasured at the time of writing): the w1|w3 launch also prepares w2's activation row (last-arriver per 256-row block),
     // one launch less per layer.
@@ -163,7 +162,6 @@ int Engine::weights_received() {
     load_mode_ = LOAD_FULL;
     const size_t NQ = (size_t)v_nq_;
     for (size_t b = 0; b < (size_t)VISION_BATCH_MAX; b++) HIP_CHECK(hipMemcpy(vi_qtok_rep_ + b * NQ * 768, v_qtok_, NQ * 768 * 4, hipMemcpyDeviceToDevice));
-    build_engine_ops();                                                             // the decode engine's fill-major images, from the planes that have just arrived
     return 0;
 }
 // Host only: the arena layout (sizes + layout hashes) the two files produce, without a device: what a receiving rank must reproduce (tests/test_cpu_dist.py).
@@ -435,7 +433,6 @@ void Engine::alloc_buffers() {
     sz(S * L * C * E * 2); sz(S * L * C * E * 2); sz(2 * C * (hd / 2) * 4 * 2); sz(3 * 65536 * 2);
     sz(5 * B * E * 4); sz(2 * B * F * 4); sz(S * V * 4); sz(S * V * 4); sz(8 * 256 + 2 * B * 4);
     sz(2 * B * Kmax); sz(B * Kmax / 256 * 4 + 64); sz(B * Kmax / 16 * 2 + 64); sz(B * Kmax / 16 + 64); sz(4 * (B * Kmax / 32 * 4 + 64)); sz(B * Kmax * 2); sz(B * Kmax * 4);
-    sz((L + S) * ENG_OPS_MAX * sizeof(EngOp)); sz(3 * (Kmax + 1024) * 8); sz(256);   // decode engine: op tables, granule buffers, step counter + error word
     sz(8192); sz((size_t)64 << 20); sz(attn_split_workspace_bytes((int)llm_.n_head, (int)hd, n_ctx_, std::max(attn_splits_forced_, attn_split_count((int)llm_.n_head, n_cus_))));
     const size_t VB = (size_t)VISION_BATCH_MAX;                            // images encoded in one pass (minigpt4_encode_images)
     sz(VB * 3 * 224 * 224 * 4); sz(VB * 256 * 592 * 2); sz(VB * 256 * D * 4); sz(VB * 257 * D * 4); sz(VB * 257 * 3 * D * 4); sz(VB * 3 * 257 * D * 2); sz(VB * 257 * M * 2);
@@ -493,10 +490,6 @@ void Engine::alloc_buffers() {
         act_.ws = reinterpret_cast<float *>(buf_arena_.take(slab_floats * 4)); act_.ws_floats = slab_floats;
         set_mmq2_cus(prop.multiProcessorCount);
     }
-    d_eng_ops_ = reinterpret_cast<EngOp *>(buf_arena_.take((L + S) * ENG_OPS_MAX * sizeof(EngOp)));
-    eng_gstride_ = (int)Kmax + 1024; d_eng_gbuf_ = reinterpret_cast<unsigned long long *>(buf_arena_.take(3 * (Kmax + 1024) * 8));   // per buffer: the row's granules + one sentinel per workgroup
-    d_epoch_ = reinterpret_cast<int *>(buf_arena_.take(256)); d_eng_err_ = reinterpret_cast<unsigned *>(d_epoch_ + 16);
-    HIP_CHECK(hipMemset(d_eng_gbuf_, 0, 3 * (Kmax + 1024) * 8)); HIP_CHECK(hipMemset(d_epoch_, 0, 256));
     HIP_CHECK(hipMemset(d_npast_, 0, 256)); HIP_CHECK(hipMemset(d_argmax_, 0, 256)); HIP_CHECK(hipMemset(d_feed_, 0, 256)); HIP_CHECK(hipMemset(d_btok_, 0, 768));
     HIP_CHECK(hipMemset(d_tokens_, 0, B * 4));
     HIP_CHECK(hipHostMalloc((void **)&h_argmax_, 256, hipHostMallocDefault));
@@ -513,94 +506,7 @@ void Engine::alloc_buffers() {
     vi_qtok_rep_ = takef(VB * NQ * 768);                                  // the query tokens once per image of a batch (every image starts from the same rows)
     if (load_mode_ == LOAD_FULL) for (size_t b = 0; b < VB; b++) HIP_CHECK(hipMemcpy(vi_qtok_rep_ + b * NQ * 768, v_qtok_, NQ * 768 * 4, hipMemcpyDeviceToDevice));   // LOAD_RECV: weights_received()
     if (v_generic_) alloc_vision_generic();
-    build_engine_ops();
     MG4_INFO("KV cache %.1f MB (fp16, n_ctx %d, %zu conversation%s), activation arena %.1f MB", 2.0 * S * L * C * E * 2 / 1048576.0, n_ctx_, S, S == 1 ? "" : "s", buf_arena_.used / 1048576.0);
-}
-
-// Decode-engine op tables (decode_engine.hip).  Chain of layer il: wo (row = attention output, + residual x) -> w1 | w3 (ffn norm of the gathered row) -> w2 (+ residual)
-// -> layer il + 1's wq, wk, wv (attention norm) or, for the last layer, the final norm -> output matrix.  Any shape / type outside the engine's range switches the
-// engine off for this model: the launch-per-op kernels serve it as before.
-// The fill-major image of an op's matrix (pair), built on first use.
-const uint8_t *Engine::engine_image(EngOp &op) {
-    for (auto &kv : eng_images_) if (kv.first == op.pl[0].base) return kv.second.bytes == eng_image_bytes(op) ? kv.second.ptr : nullptr;
-    if (!eng_arena_.base) {   // ONE allocation for every image (large fragments for the address translation; the images together are the layer weights' bytes + 16-byte paddings)
-        const size_t cap = llm_arena_.used + llm_arena_.used / 50 + ((size_t)64 << 20);
-        if (hipMalloc((void **)&eng_arena_.base, cap) != hipSuccess) { (void)hipGetLastError(); eng_arena_.base = nullptr; return nullptr; }
-        eng_arena_.cap = cap; eng_arena_.used = 0;
-    }
-    EngImage im{nullptr, eng_image_bytes(op)};
-    const size_t need = (im.bytes + 4096 + 255) & ~(size_t)255;
-    if (eng_arena_.used + need > eng_arena_.cap) return nullptr;
-    im.ptr = eng_arena_.base + eng_arena_.used; eng_arena_.used += need;
-    HIP_CHECK(hipMemsetAsync(im.ptr, 0, need, stream_));
-    launch_eng_repack(op, im.ptr, stream_);
-    eng_images_.emplace_back(op.pl[0].base, im);
-    eng_image_total_ += im.bytes;
-    return im.ptr;
-}
-void Engine::build_engine_ops() {
-    engine_ok_ = false;
-    const size_t L = layers_.size(), S = conv_.size();
-    if (!L || L > 64 || n_cus_ > 1024 || !use_engine_ || !use_v2_) return;                           // (granule tags carry 6 bits of layer index)
-    if (load_mode_ == LOAD_RECV) return;                                            // the planes are not there yet: weights_received() builds the images
-    const int E = (int)llm_.n_embd, V = (int)llm_.n_vocab;
-    std::vector<EngOp> host((L + S) * ENG_OPS_MAX);
-    eng_n_ops_.assign(L + S, 0); eng_bytes_.assign(L + S, 0.0);
-    if ((E / 4 + n_cus_ - 1) / n_cus_ * 4 > 256 || E > 3 * 2048) return;          // own rows kept in LDS for the second residual; normed rows of at most three prologue rounds
-    auto chain = [&](size_t il, size_t table, size_t slot) -> bool {
-        const LayerW &W = layers_[il];
-        EngOp *o = host.data() + table * ENG_OPS_MAX;
-        int n = 0; double bytes = 0;
-        auto add = [&](const QWeight &w0, const QWeight *w1, bool matched) -> EngOp * {
-            if (n >= ENG_OPS_MAX || !eng_make_op(o[n], w0, w1, matched)) return nullptr;
-            if (!(o[n].image = engine_image(o[n]))) return nullptr;
-            bytes += (double)w0.bytes + (w1 ? (double)w1->bytes : 0.0);
-            return &o[n++];
-        };
-        EngOp *p;
-        if (!(p = add(W.wo, nullptr, true))) return false;                       // x1 = wo . quant(att) + x
-        p->in_kind = ENG_IN_PLAIN; p->in_x = att_; p->out_kind = ENG_OUT_GRANULE; p->out_g = 0; p->res_kind = ENG_RES_GLOBAL; p->res = x_; p->save_res = 1;
-        if (W.w1.cols != E || W.wo.rows != E || W.wo.cols != E) return false;
-        if (!(p = add(W.w1, &W.w3, false))) return false;                        // h = silu(w1 . n) * (w3 . n), n = quant(rms(x1) * ffn_norm)
-        p->in_kind = ENG_IN_GATHER_RMS; p->in_g = 0; p->in_w = W.ffn_norm; p->out_kind = ENG_OUT_GRANULE; p->out_g = 1;
-        if (!(p = add(W.w2, nullptr, true))) return false;                       // x2 = w2 . quant(h) + x1
-        if (W.w2.rows != E || W.w2.cols != W.w1.rows) return false;
-        p->in_kind = ENG_IN_GATHER; p->in_g = 1; p->out_kind = ENG_OUT_GRANULE | ENG_OUT_PLAIN; p->out_g = 2; p->y = x_; p->res_kind = ENG_RES_SAVED;
-        if (il + 1 < L) {
-            const LayerW &N = layers_[il + 1];
-            const QWeight *w3[3] = {&N.wq, &N.wk, &N.wv}; float *y3[3] = {q_, k_, v_};
-            for (int m = 0; m < 3; m++) {
-                if (w3[m]->cols != E || w3[m]->rows != E || act_mask_for(w3[m]->type) != act_mask_for(N.wq.type)) return false;
-                if (!(p = add(*w3[m], nullptr, false))) return false;
-                p->in_kind = m ? ENG_IN_KEEP : ENG_IN_GATHER_RMS; p->in_g = 2; p->in_w = N.attn_norm; p->out_kind = ENG_OUT_PLAIN; p->y = y3[m];
-            }
-        } else {
-            if (output_.cols != E || output_.rows != V) return false;
-            if (!(p = add(output_, nullptr, false))) return false;
-            p->in_kind = ENG_IN_GATHER_RMS; p->in_g = 2; p->in_w = norm_; p->out_kind = ENG_OUT_PLAIN; p->y = logits_ + slot * (size_t)V;
-        }
-        eng_n_ops_[table] = n; eng_bytes_[table] = bytes;
-        return true;
-    };
-    for (size_t il = 0; il + 1 < L; il++) if (!chain(il, il, 0)) return;
-    for (size_t sl = 0; sl < S; sl++) if (!chain(L - 1, L - 1 + sl, sl)) return;
-    HIP_CHECK(hipStreamSynchronize(stream_));                                       // the repack launches
-    HIP_CHECK(hipMemcpy(d_eng_ops_, host.data(), host.size() * sizeof(EngOp), hipMemcpyHostToDevice));
-    engine_ok_ = true;
-    MG4_INFO("decode engine: %zu chains of %d mat-vecs, %.1f MB of weights per layer launch, fill-major weight images %.2f GB, %zu KiB of LDS per workgroup", L, eng_n_ops_[0],
-             eng_bytes_[0] / 1e6, eng_image_total_ / 1e9, decode_engine_lds_bytes() / 1024);
-}
-void Engine::check_engine_status() {
-    if (!engine_ok_ || !d_eng_err_) return;
-    unsigned code = 0;
-    HIP_CHECK(hipMemcpy(&code, d_eng_err_, 4, hipMemcpyDeviceToHost));
-    if (!code) return;
-    HIP_CHECK(hipMemset(d_eng_err_, 0, 4));
-    engine_ok_ = false;                                                         // the launch-per-op path from now on
-    for (Conversation &c : conv_) { if (c.graph) HIP_IGNORE(hipGraphExecDestroy(c.graph)); c.graph = nullptr; }
-    char msg[160]; snprintf(msg, sizeof msg, "decode engine gave up (code 0x%x: a bounded wait timed out); the decode steps since the last check are invalid", code);
-    set_last_error(msg); MG4_ERR("%s", msg);
-    throw HipError{hipErrorLaunchFailure, "decode engine timeout", __FILE__, __LINE__};
 }
 
 // ====================================================================================================================
@@ -764,13 +670,6 @@ void Engine::forward_ref(int N, bool from_tokens, hipStream_t s, bool feed) {
     launch_advance(d_npast, N, d_feed, d_argmax, s);
     HIP_CHECK(hipMemcpyAsync(h_argmax_ + sl, d_argmax, 4, hipMemcpyDeviceToHost, s));
 }
-void Engine::set_engine(bool on) {
-    if (on == use_engine_) return;
-    HIP_CHECK(hipStreamSynchronize(stream_));
-    for (Conversation &c : conv_) { if (c.graph) HIP_IGNORE(hipGraphExecDestroy(c.graph)); c.graph = nullptr; }   // captured with the other launch set
-    use_engine_ = on;
-    if (on && !engine_ok_) build_engine_ops();
-}
 void Engine::set_parity(bool on) {
     if (on == parity_) return;
     HIP_CHECK(hipStreamSynchronize(stream_));
@@ -791,14 +690,11 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
     // embedding row already sitting in x_) -- a chunk of exactly ONE embedding row must not pick up the stale decode token
     if (from_tokens) { SiteScope sc(this, "embed", (double)gt_nbytes(tok_type_, (size_t)E) * N, s); launch_get_rows(tok_type_, tok_raw_, E, feed ? d_feed : d_tokens_, N, x_, s); }
     auto fz = [&](int bit) { return dec && (fuse_mask_ >> bit & 1); };
-    // decode through the persistent engine: layer 0's q | k | v by the launch-per-op kernels, then per layer attention + ONE engine launch (wo ... the next layer's q | k | v,
-    // the last layer's launch ends with the logits)
-    const bool eng = dec && engine_ok_ && use_engine_;
     for (size_t il = 0; il < layers_.size(); il++) {
         const LayerW &L = layers_[il];
         __half *kc = kc_ + (sl * layers_.size() + il) * C * E, *vc = vc_ + (sl * layers_.size() + il) * C * E;
         const Prep p_attn{1, x_, L.attn_norm}, p_att{2, att_, nullptr}, p_ffn{1, x_, L.ffn_norm}, p_silu{3, h1_, h3_};
-        if (!(eng && il > 0)) {
+        {
             const QWeight *W3[3] = {&L.wq, &L.wk, &L.wv}; float *Y3[3] = {q_, k_, v_};
             if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s, &p_attn, fz(0), false, "qkv", !dec);   // a K-split combine is left to launch_rope_kv_slabs
             else if (fz(6) && L.wk.type == L.wq.type && mixed_qkv(L, s, fz(0))) {}
@@ -823,13 +719,6 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
                 launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, false, s);
         }
         att_sc.reset();
-        if (eng) {
-            const size_t table = il + 1 < layers_.size() ? il : layers_.size() - 1 + sl;
-            SiteScope sc(this, il + 1 < layers_.size() ? "engine" : "engine_last", eng_bytes_[table], s);
-            if (!launch_decode_engine(d_eng_ops_ + table * ENG_OPS_MAX, eng_n_ops_[table], d_eng_gbuf_, eng_gstride_, d_epoch_, (int)il, tabs_, d_eng_err_, n_cus_, s))
-                throw HipError{hipErrorInvalidValue, "decode engine launch refused", __FILE__, __LINE__};
-            continue;
-        }
         mul_mat(L.wo, N, x_, E, x_, s, att_in_xh ? nullptr : &p_att, fz(1), "wo", !dec);             // combine left to the ffn norm's preparation
         bool paired = false;   // h1_ already holds silu(w1 x) * (w3 x)
         // F16 weights at prompt sizes: w1 | w3 in one launch whose epilogue stores fp16(silu(w1 x) * (w3 x)) -- the rows w2 multiplies -- into h1_'s memory (round 3)
@@ -856,12 +745,10 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
     }
     flush_pending(s);
     // only the last token's logits are kept (llama.cpp logits_all = false)
-    if (!eng) {
-        const Prep p_out{1, x_ + (size_t)(N - 1) * E, norm_};
-        mul_mat(output_, 1, logits, V, nullptr, s, &p_out, fz(4), "output");
-    }
+    const Prep p_out{1, x_ + (size_t)(N - 1) * E, norm_};
+    mul_mat(output_, 1, logits, V, nullptr, s, &p_out, fz(4), "output");
     { SiteScope sc(this, "argmax", (double)V * 4, s); launch_argmax(logits, V, d_argmax, d_scratch_, s); }
-    { SiteScope sc(this, "advance", 0.0, s); launch_advance(d_npast, N, d_feed, d_argmax, s, d_epoch_); }
+    { SiteScope sc(this, "advance", 0.0, s); launch_advance(d_npast, N, d_feed, d_argmax, s); }
     HIP_CHECK(hipMemcpyAsync(h_argmax_ + sl, d_argmax, 4, hipMemcpyDeviceToHost, s));
 }
 
@@ -1065,7 +952,6 @@ const float *Engine::logits_host() {
     if (logits_host_slot_ != cur_) {
         HIP_CHECK(hipMemcpyAsync(h_logits_, logits_ + (size_t)cur_ * llm_.n_vocab, (size_t)llm_.n_vocab * 4, hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipStreamSynchronize(stream_));
-        check_engine_status();
         logits_host_slot_ = cur_;
     }
     return h_logits_;

@@ -93,8 +93,6 @@ public:
     float last_encode_ms() const { return last_encode_ms_; }
     void set_parity(bool on);                          // MINIGPT4_PARITY at run time (tests): drops the captured graphs, the next evaluation uses the other mode
     bool parity() const { return parity_; }
-    void set_engine(bool on);                          // MINIGPT4_ENGINE at run time (tests / A-B): the persistent decode engine or the launch-per-op step
-    bool engine_active() const { return use_engine_ && engine_ok_ && !parity_; }
 
 private:
     int load_llm(const std::string &path);
@@ -167,22 +165,6 @@ private:
     int batch_rows_max_ = 4; int batch_fuse_ = -1; int n_cus_ = 256;
     bool batch_mix_ = true;            // MINIGPT4_BATCH_MIX=0: wq|wk and wv of a mixed-type layer as two launches (the form before k_matvec_tn_mix)   // MINIGPT4_BATCH_ROWS_MAX: batches up to this size use the multi-row mat-vec; 0 = never.  Measured (profiles/r02x_*): from 5 rows on the int8-MFMA kernels (single-wave workgroups, one token tile) beat two passes of the 4-row mat-vec
     static constexpr int FUSE_DEFAULT = 87; int fuse_mask_ = FUSE_DEFAULT;
-    // persistent decode engine (decode_engine.hip): per layer ONE launch runs wo -> w1|w3 -> w2 -> the next layer's wq, wk, wv (the last layer: final norm -> output matrix);
-    // attention stays its own launch.  Op tables live in device memory: table il for layers 0 .. L-2, table L-1 + slot for the last layer of conversation `slot` (its logits row)
-    static constexpr int ENG_OPS_MAX = 8;
-    bool use_engine_ = true, engine_ok_ = false;
-    EngOp *d_eng_ops_ = nullptr; std::vector<int> eng_n_ops_; std::vector<double> eng_bytes_;
-    unsigned long long *d_eng_gbuf_ = nullptr; int eng_gstride_ = 0;
-    int *d_epoch_ = nullptr; unsigned *d_eng_err_ = nullptr;
-    // fill-major copies of the chain matrices (one per matrix / w1|w3 pair, keyed by the first plane's address; built once from the weight arena, kept across buffer
-    // reallocations): a second copy of the language model's layer weights -- 9.2 GB for 13B Q5_K_M out of 288 GB of HBM
-    struct EngImage { uint8_t *ptr; size_t bytes; };
-    std::vector<std::pair<const uint8_t *, EngImage>> eng_images_;
-    size_t eng_image_total_ = 0;
-    DeviceArena eng_arena_;
-    const uint8_t *engine_image(EngOp &op);
-    void build_engine_ops();
-    void check_engine_status();         // throws when an engine launch gave up (a bounded spin timed out): results since the last check are invalid
     // profiling (profile_sites)
     bool prof_on_ = false;
     struct SiteEv { hipEvent_t a, b; const char *site; std::string kernel; double bytes; size_t p0 = 0, p1 = 0; };   // [p0, p1): the launch probes of the site

@@ -76,7 +76,6 @@ bool launch_matvec_rows_mixed(const QWeight *const *W1, float *const *y1, int n1
 void set_matvec_tuning(int waves_per_cu, int fat_threads, int cus);   // 0 = choose per launch
 // measurement: while tracing is on, every launcher of llm_kernels.hip notes the kernel symbol it launched (as rocprofv3 prints it, without the argument list)
 void kernel_name_tracing(bool on);
-bool kernel_probe_begin(const char *name, hipEvent_t *start, hipEvent_t *stop);   // for launchers outside llm_kernels.hip: true -> launch through hipExtLaunchKernel with these events
 const char *last_kernel_name();          // "" when nothing was launched since the last reset
 void reset_kernel_name();
 size_t launch_probe_count();                       // launches noted (and probed with their own start / stop events) since tracing was switched on
@@ -84,32 +83,6 @@ float launch_probe_us(size_t first, size_t last);  // sum of the dispatch durati
 int read_matvec_timeline(unsigned long long *out, int max_workgroups);   // diagnostic builds (MG4_TIMELINE): stamps of the last decode mat-vec launch; 0 otherwise
 int read_attn_timeline(unsigned long long *out, int max_workgroups);     // prompt attention (8 x u64 per workgroup, up to 2048 workgroups)
 int read_vision_timeline(unsigned long long *out, int max_workgroups);   // the same for the image path's kernels (32 x u64 per workgroup)
-
-// ---- persistent decode engine (decode_engine.hip): one launch runs a chain of dependent decode mat-vecs with in-launch hand-offs ---------------------------------
-constexpr int ENG_SLOT_BYTES = 17408;                      // one LDS ring slot = the planes of one fill (G rows, or G row pairs of w1 | w3)
-enum EngIn : int { ENG_IN_KEEP = 0,                         // the previous op's activation image (same row, same quantised form)
-                   ENG_IN_PLAIN_RMS = 1, ENG_IN_PLAIN = 2,  // in_x is complete in global memory when the launch starts: rms_norm(in_x) * in_w | in_x, then quantised
-                   ENG_IN_GATHER_RMS = 3, ENG_IN_GATHER = 4 };   // the row is an earlier op's output of THIS launch: granule buffer in_g
-enum EngOut : int { ENG_OUT_PLAIN = 1, ENG_OUT_GRANULE = 2 };
-enum EngRes : int { ENG_RES_NONE = 0, ENG_RES_GLOBAL = 1 /* res[] complete at launch */, ENG_RES_SAVED = 2 /* this workgroup's own rows of an earlier op with save_res (same partition) */ };
-struct EngPlane { const uint8_t *base /*the plane in the weight arena (source of the fill-major copy)*/; int rb /*bytes per row*/, loff /*byte offset inside a fill*/, pad_[2]; };
-// One mat-vec of a chain.  The engine streams a FILL-MAJOR copy of the matrix ("image", built once at load by launch_eng_repack): fill g = rows [g G, (g + 1) G) of every
-// plane (for the w1 | w3 pair: of both matrices) back to back, each plane's piece 16-byte aligned -- one contiguous fill_bytes region per fill, so the loader wave issues a
-// fill with a handful of scalar instructions (the plane layout the other kernels use needs one address stream per plane: 2.5 us of scalar code per fill, first timelines).
-struct EngOp {
-    int type, K, rows, G /*rows per fill (per matrix)*/, unit /*rows per partition unit*/, pair /*w1 | w3: h = silu(w1 x) * (w3 x)*/, nu /*units per lane*/, n_planes, ipf /*DMA instructions per fill*/, fill_bytes;
-    EngPlane pl[8]; int pidx[8] /*matrix m, plane p of the type -> index into pl: pidx[m * 4 + p]*/;
-    const uint8_t *image;
-    int in_kind, in_g; const float *in_x, *in_w;
-    int out_kind, out_g; float *y;
-    int res_kind, save_res; const float *res;
-};
-inline size_t eng_image_bytes(const EngOp &op) { return (size_t)(op.rows / op.G) * (size_t)op.fill_bytes; }
-void launch_eng_repack(const EngOp &op, uint8_t *image, hipStream_t s);   // planes -> the fill-major image (image zeroed by the caller)
-bool eng_make_op(EngOp &op, const QWeight &W0, const QWeight *W1, bool matched_partition);   // geometry + planes of one mat-vec; false: outside the engine's range
-size_t decode_engine_lds_bytes();
-bool launch_decode_engine(const EngOp *d_ops, int n_ops, unsigned long long *gbuf, int gstride, const int *d_epoch, int layer, const Tables &tb, unsigned *d_err, int n_cus, hipStream_t s);
-int read_engine_timeline(unsigned long long *out, int max_workgroups, int layer = -1);   // layer >= 0: from now on keep the stamps of that layer's launches   // diagnostic builds (MG4_TIMELINE): 64 x u64 stamps per workgroup of the last engine launch
 
 // ---- token embedding gather (raw ggml rows, dequantised to f32) -----------------------------------------------------
 void launch_get_rows(int type, const uint8_t *raw_table, int K, const int *tokens, int N, float *out, hipStream_t s);
@@ -152,7 +125,7 @@ void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);
 void launch_set_int(int *p, int v, hipStream_t s);
 uint64_t device_checksum(const void *p, size_t bytes, hipStream_t s);   // sum of the 32-bit words (bytes rounded down to 4), mod 2^64; synchronises the stream
 void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s);
-void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s, int *epoch = nullptr);   // epoch: the decode engine's step counter (granule tags), bumped with the position
+void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s);
 void launch_delay(int us, hipStream_t s);   // profiling gate: keeps the stream busy for `us` microseconds (see Engine::profile_sites)
 
 // ---- vision tower -----------------------------------------------------------------------------------------------------

@@ -50,15 +50,6 @@ static void note_kernel(const char *fmt, ...) {
     LaunchProbe p{};
     if (hipEventCreate(&p.start) == hipSuccess && hipEventCreate(&p.stop) == hipSuccess) g_probes.push_back(p);
 }
-// a launch issued by another kernel file (decode_engine.hip): notes the symbol and hands out the event pair its hipExtLaunchKernel should carry; false = tracing is off
-bool kernel_probe_begin(const char *name, hipEvent_t *start, hipEvent_t *stop) {
-    if (!g_kname_on) return false;
-    note_kernel("%s", name);
-    if (g_probe_next >= g_probes.size()) return false;
-    LaunchProbe &p = g_probes[g_probe_next++];
-    *start = p.start; *stop = p.stop;
-    return true;
-}
 // every kernel launch of this file: plain <<< >>> unless a noted launch is waiting for its probe
 template <typename... KA, typename... Args>
 static inline void launch_k(void (*k)(KA...), dim3 g, dim3 b, size_t lds, hipStream_t s, Args... args) {
@@ -2412,8 +2403,8 @@ __global__ void k_batch_begin(int *__restrict__ n_past, const int *__restrict__ 
 }
 void launch_batch_begin(int *n_past, const int *row_slot, const int *row_pos, int B, hipStream_t s) { hipLaunchKernelGGL(k_batch_begin, dim3(1), dim3(64), 0, s, n_past, row_slot, row_pos, B); }
 // end of a decode step: the KV position advances and the greedy token becomes the next input (the host may overwrite it)
-__global__ void k_advance(int *n_past, int n, int *tok0, const int *argmax, int *epoch) { *n_past += n; if (tok0) *tok0 = *argmax; if (epoch) *epoch += 1; }
-void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s, int *epoch) { note_kernel("k_advance"); hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, n_past, n, tok0, argmax, epoch); }
+__global__ void k_advance(int *n_past, int n, int *tok0, const int *argmax) { *n_past += n; if (tok0) *tok0 = *argmax; }
+void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s) { note_kernel("k_advance"); hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, n_past, n, tok0, argmax); }
 // Profiling gate (Engine::profile_sites): one wave that keeps the stream busy for `us` microseconds (s_memrealtime: the constant 100 MHz clock) while the host
 // queues the step's launches behind it, so the per-site event pairs time the GPU and not the host's launch rate.  Bounded: at most 2^20 polls even if the clock stood still.
 __global__ void k_delay(int us) {

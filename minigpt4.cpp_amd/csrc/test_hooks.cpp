@@ -365,7 +365,6 @@ int minigpt4_amd_bench_attn_prefill(int n_head, int hd, int N, int n_past, int i
         return 0;
     });
 }
-int minigpt4_amd_timeline_engine(unsigned long long *out, int max_workgroups, int layer) { return read_engine_timeline(out, max_workgroups, layer); }
 int minigpt4_amd_timeline_attn(unsigned long long *out, int max_workgroups) { return (out && max_workgroups > 0) ? read_attn_timeline(out, max_workgroups) : -1; }
 void minigpt4_amd_test_set_gemm_arm(int arm, int sk_arm) { set_gemm_tuning(-1, 0, arm, sk_arm); }
 int minigpt4_amd_timeline_vision(unsigned long long *out, int max_workgroups) { return (out && max_workgroups > 0) ? read_vision_timeline(out, max_workgroups) : -1; }

@@ -188,10 +188,6 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_weights_received.argtypes = [VOID_PTR]
         L.minigpt4_amd_arena_checksum.argtypes = [VOID_PTR, I32, U64P]
         L.minigpt4_amd_set_parity.argtypes = [VOID_PTR, I32]
-        L.minigpt4_amd_set_engine.argtypes = [VOID_PTR, I32]
-        L.minigpt4_amd_set_engine.restype = I32
-        L.minigpt4_amd_engine_active.argtypes = [VOID_PTR]
-        L.minigpt4_amd_engine_active.restype = I32
         L.minigpt4_amd_parity.argtypes = [VOID_PTR]
         L.minigpt4_amd_set_conversations.argtypes = [VOID_PTR, I32]
         L.minigpt4_amd_select_conversation.argtypes = [VOID_PTR, I32]
@@ -337,14 +333,6 @@ class MiniGPT4SharedLibrary:
         return int(v.value)
 
     # several conversations per context (include/minigpt4_amd.h): the reference calls act on the selected one
-    def amd_set_engine(self, ctx, on: bool):
-        """persistent decode engine on / off (bit-identical results either way)"""
-        if self.library.minigpt4_amd_set_engine(ctx.ptr, 1 if on else 0):
-            raise RuntimeError("minigpt4_amd_set_engine failed: " + (self.library.minigpt4_amd_last_error() or b"").decode(errors="replace"))
-
-    def amd_engine_active(self, ctx) -> bool:
-        return bool(self.library.minigpt4_amd_engine_active(ctx.ptr))
-
     def amd_set_parity(self, ctx, on: bool):
         """Parity mode (MINIGPT4_PARITY): the language path adds its fp32 terms in the CPU oracle's order -- bit-identical logits, slow."""
         if self.library.minigpt4_amd_set_parity(ctx.ptr, 1 if on else 0):
