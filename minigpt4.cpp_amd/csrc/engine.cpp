@@ -105,43 +105,21 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     n_ctx_ = n_ctx > 0 ? n_ctx : 2048;
     n_batch_ = n_batch > 0 ? n_batch : 512;
     max_rows_ = std::max(n_batch_, 32);
+    // Run-time switches read here, once (no launcher calls getenv).  What is left after round 4's pruning: device / conversation count / load mode / parity mode, the graph
+    // switch the profiling tools use, and the five arms the bit-identity tests compare against (tests/test_gpu_parity.py, tests/test_gpu_batch.py).  Tile shapes, K splits and
+    // the other experiment parameters are reachable only through the test library's setters (include/minigpt4_amd_test.h).
     use_graph_ = !(getenv("MINIGPT4_NO_GRAPH") && atoi(getenv("MINIGPT4_NO_GRAPH")));
-    defer_ = !(getenv("MINIGPT4_NO_DEFER") && atoi(getenv("MINIGPT4_NO_DEFER")));
     max_chunk_ = max_rows_;
-    if (getenv("MINIGPT4_NO_MMQ")) set_mmq_enabled(atoi(getenv("MINIGPT4_NO_MMQ")) ? 0 : 2);
-    if (getenv("MINIGPT4_MMQ")) set_mmq_enabled(atoi(getenv("MINIGPT4_MMQ")) ? 2 : 0);   // 0: v_dot4 tiles only, otherwise (default) the LDS-staged int8-MFMA prefill kernels
-    // experiment knobs of the launchers: read here, once -- no launcher calls getenv
-    set_mmq2_tuning(getenv("MINIGPT4_MMQ2_TT") ? atoi(getenv("MINIGPT4_MMQ2_TT")) : 0, getenv("MINIGPT4_MMQ2_FILL") ? atoi(getenv("MINIGPT4_MMQ2_FILL")) : 0,
-                    getenv("MINIGPT4_MMQ2_KS") ? atoi(getenv("MINIGPT4_MMQ2_KS")) : 0);
-    set_gemm_tuning(getenv("MINIGPT4_GEMM_BIG_M") ? atoi(getenv("MINIGPT4_GEMM_BIG_M")) : -1, getenv("MINIGPT4_F16_KS") ? atoi(getenv("MINIGPT4_F16_KS")) : 0,
-                    getenv("MINIGPT4_GEMM_ARM") ? atoi(getenv("MINIGPT4_GEMM_ARM")) : -1, getenv("MINIGPT4_GEMM_SK_ARM") ? atoi(getenv("MINIGPT4_GEMM_SK_ARM")) : -1);
-    if (getenv("MINIGPT4_F16_GEMM")) set_f16_gemm(atoi(getenv("MINIGPT4_F16_GEMM")));
-    if (getenv("MINIGPT4_ATTN_PREFILL_F16")) set_attn_prefill_f16(atoi(getenv("MINIGPT4_ATTN_PREFILL_F16")));
-    if (getenv("MINIGPT4_ATTN_PREFILL_W8")) set_attn_prefill_w8(atoi(getenv("MINIGPT4_ATTN_PREFILL_W8")));
-    // Decode: which activation preparations run inside the consuming mat-vec's prologue (one fat workgroup per CU repeats the row preparation while
-    // its first weight tiles are in flight) instead of as their own launch.  bit 0: attn_norm -> wq|wk|wv, 1: attention output -> wo,
-    // 2: ffn_norm -> w1|w3, 3: silu(w1 x) * (w3 x) -> w2, 4: final norm -> output; bit 5: w1|w3 launch writes silu(w1 x) * (w3 x) itself
-    // (row-pair epilogue); bit 6: wq|wk and a differently typed wv in one launch.  See DESIGN.md "mat-vec prologue".
-    fuse_mask_ = getenv("MINIGPT4_FUSE") ? atoi(getenv("MINIGPT4_FUSE")) : FUSE_DEFAULT;
-    if (const char *dc = getenv("MINIGPT4_DEFER_COMBINE")) defer_combine_ = atoi(dc) != 0;
-    if (const char *bs = getenv("MINIGPT4_BATCH_SETS")) batch_sets_ = atoi(bs) != 0;
-    if (const char *fp = getenv("MINIGPT4_F16_PAIR")) f16_pair_ = atoi(fp);        // bit mask (A/B): 1 w1|w3 + silu*mul in one launch, 4 the attention kernel stores fp16 rows for wo
-    use_v2_ = !(getenv("MINIGPT4_MATVEC_V1") && atoi(getenv("MINIGPT4_MATVEC_V1")));
-    attn_prefill_ = !(getenv("MINIGPT4_ATTN_PREFILL") && !atoi(getenv("MINIGPT4_ATTN_PREFILL")));   // 0: the per-token attention kernel also for prompt rows (A/B, tests)
-    // Opt-in experiment (unmeasured at the time of writing): the w1|w3 launch also prepares w2's activation row (last-arriver per 256-row block),
-    // one launch less per layer.
-    if (getenv("MINIGPT4_BATCH_ROWS_MAX")) batch_rows_max_ = atoi(getenv("MINIGPT4_BATCH_ROWS_MAX"));
-    batch_fuse_ = getenv("MINIGPT4_BATCH_FUSE") ? (atoi(getenv("MINIGPT4_BATCH_FUSE")) != 0) : -1;   // -1: by batch size (see forward_batch)
-    batch_mix_ = !(getenv("MINIGPT4_BATCH_MIX") && atoi(getenv("MINIGPT4_BATCH_MIX")) == 0);
-    if (const char *sk = getenv("MINIGPT4_SPLITK")) { sscanf(sk, "%d,%d", &splitk_proj_, &splitk_fc2_); splitk_proj_ = std::max(1, std::min(SPLITK_MAX, splitk_proj_)); splitk_fc2_ = std::max(1, std::min(SPLITK_MAX, splitk_fc2_)); }
+    if (getenv("MINIGPT4_ATTN_PREFILL_W8")) set_attn_prefill_w8(atoi(getenv("MINIGPT4_ATTN_PREFILL_W8")));   // 0: prompt attention without the 8-wave loader / MFMA form
+    if (const char *dc = getenv("MINIGPT4_DEFER_COMBINE")) defer_combine_ = atoi(dc) != 0;                    // 0: every K-split combine as its own launch
+    if (const char *fp = getenv("MINIGPT4_F16_PAIR")) f16_pair_ = atoi(fp);        // bit mask: 1 w1|w3 + silu*mul in one launch, 4 the attention kernel stores fp16 rows for wo
+    batch_mix_ = !(getenv("MINIGPT4_BATCH_MIX") && atoi(getenv("MINIGPT4_BATCH_MIX")) == 0);                 // 0: wq|wk and wv of a mixed-type layer as two launches (batched step)
+    if (const char *e = getenv("MINIGPT4_ATTN_SPLIT_T")) attn_split_t_ = atoi(e);   // cached keys from which the decode step uses the key-split attention (0 = never)
     n_cus_ = prop.multiProcessorCount;
-    set_matvec_tuning(getenv("MINIGPT4_MV_WAVES") ? atoi(getenv("MINIGPT4_MV_WAVES")) : 0, getenv("MINIGPT4_FAT_LB") ? atoi(getenv("MINIGPT4_FAT_LB")) : 0, prop.multiProcessorCount);
+    set_matvec_tuning(0, 0, prop.multiProcessorCount);
     if (const char *ns = getenv("MINIGPT4_CONVERSATIONS")) conv_.assign((size_t)std::max(1, std::min(MAX_CONVERSATIONS, atoi(ns))), Conversation{});
     sampler_.seed(seed);
     if (const char *tf = getenv("MINIGPT4_PARITY_TRACE")) { if (*tf) trace_file_ = fopen(tf, "wb"); }
-    if (const char *e = getenv("MINIGPT4_ATTN_SPLITS")) attn_splits_forced_ = std::max(0, std::min(32, atoi(e)));   // workgroups per head of the key-split attention (0 = by CU count)
-    if (const char *e = getenv("MINIGPT4_QF_SKINNY")) qf_skinny_ = atoi(e) != 0;
-    if (const char *e = getenv("MINIGPT4_ATTN_SPLIT_T")) attn_split_t_ = atoi(e);   // cached keys from which the decode step uses the key-split attention (0 = never)
     parity_ = trace_file_ || (getenv("MINIGPT4_PARITY") && atoi(getenv("MINIGPT4_PARITY")));   // oracle-order fp32 accumulation (forward_ref): bit-identical to the CPU oracle, slow
     if (const char *lm = getenv("MINIGPT4_LOAD")) load_mode_ = !strcmp(lm, "recv") ? LOAD_RECV : LOAD_FULL;
     auto t0 = std::chrono::steady_clock::now();
@@ -571,11 +549,13 @@ bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
     SiteScope sc(this, site, wbytes, s);
     bool done = false;
     if (N >= 5 && same && mmq_enabled() >= 2) done = launch_mmq2_set(W, y, res, n, act_here, N, ldy, s, defer_ok && defer_combine_ ? &pend_ : nullptr);   // prefill: one launch for the set, weights streamed once per <= 128 rows
+    const bool staged_elsewhere = !prep && (xh_override_ != nullptr || (same && W[0]->type == GT_F16 && N >= 512));   // the rows were left in fp16 by an earlier launch, act_ holds OTHER rows
     if (!done && same && W[0]->type == GT_F16 && N >= 512 && act_.xh) {   // unquantised weights at prompt sizes: the set in one launch of the big MFMA GEMM, split K for wo / w2
         const __half *Wh[3]; for (int i = 0; i < n; i++) Wh[i] = reinterpret_cast<const __half *>(W[i]->qs);
         const __half *Ain = !prep && xh_override_ ? xh_override_ : act_.xh;     // rows some launch left in fp16 elsewhere (the feed-forward pair's epilogue)
         done = launch_gemm_f16_set(Ain, W[0]->cols, Wh, n, N, W[0]->rows, W[0]->cols, y, res, ldy, act_.ws, act_.ws_floats, n_cus_, s, defer_ok && defer_combine_ ? &pend_ : nullptr);
     }
+    if (!done && staged_elsewhere && xh_override_) throw HipError{hipErrorInvalidValue, "F16 set launch refused rows that only exist in fp16 (no generic path may read act_ here)", __FILE__, __LINE__};
     if (!done && silu_pair) {   // the pair epilogue needs the two matrices equally spaced; launch_matvec_set refuses otherwise and the plain launch below runs
         done = fuse ? launch_matvec_set(W, y, res, n, act_, s, prep->kind, prep->x, prep->w, &tabs_, 1) : launch_matvec_set(W, y, res, n, act_, s, 0, nullptr, nullptr, &tabs_, 1);
         silu_pair = done;
@@ -680,6 +660,7 @@ void Engine::set_parity(bool on) {
 
 // Enqueue one forward pass for N rows already described by d_tokens_ (from_tokens) or x_ (embeddings), at position *d_npast_.
 void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
+    pend_ = SlabSrc{}; xh_override_ = nullptr;          // host-side state of a pass that threw half-way must not reach this one
     if (parity_) { forward_ref(N, from_tokens, s, feed); return; }
     const int E = (int)llm_.n_embd, F = (int)llm_.n_ff(), H = (int)llm_.n_head, hd = E / H, V = (int)llm_.n_vocab;
     const size_t C = (size_t)n_ctx_, sl = (size_t)cur_;                     // everything below addresses the selected conversation's cache / scalars
@@ -756,6 +737,7 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
 // (k_mul_mat's 4-token tiles up to B = 4, the int8-MFMA kernels from B = 5); attention runs per row against its conversation's cache.  Same arithmetic per
 // row as forward(1): per-row activation quantisation, exact integer block dots, the same attention kernel body.
 void Engine::forward_batch(int B, hipStream_t s) {
+    pend_ = SlabSrc{}; xh_override_ = nullptr;
     const int E = (int)llm_.n_embd, F = (int)llm_.n_ff(), H = (int)llm_.n_head, hd = E / H, V = (int)llm_.n_vocab;
     const size_t C = (size_t)n_ctx_, seq_stride = layers_.size() * C * (size_t)E;
     // y_m[t][r] = W_m[r] . act[t] (+ res_m[t][r]) for n matrices that share the prepared rows.  Up to batch_rows_max_ rows go through the pipelined multi-row

@@ -1096,10 +1096,28 @@ __global__ __launch_bounds__(RQ_THREADS) void k_rms_quant(const float *__restric
     const float *xr = x + row * K;
     __shared__ double red[RQ_THREADS / 64];
     float scale = 1.0f;
-    if (w && seq) {   // MINIGPT4_PARITY: ggml_compute_forward_rms_norm's loop literally -- one double accumulator, element order
-        if (threadIdx.x == 0) { double sum = 0.0; for (int i = 0; i < K; i++) sum += (double)(xr[i] * xr[i]); red[0] = sum; }
+    if (w && seq) {   // MINIGPT4_PARITY: the value of ggml_compute_forward_rms_norm's loop -- ONE double accumulator, element order -- without running 5120 dependent double
+        // additions on one lane (20 us per norm, 1.6 ms of a 13B token).  Every addend is >= 0, so the sequential sum S and the parallel sum T below both lie within
+        // K * 2^-53 (relative) of the exact sum; mean = (float)(S / K) is monotone in S, so if the two ends of T (1 +- 4e-16 K) convert to the SAME float, that float is
+        // the oracle's mean, whatever S is.  Otherwise (a sum that close to a float rounding boundary: ~1e-4 of the rows) thread 0 runs the literal loop.
+        double sum = 0.0;
+        for (int i = threadIdx.x * 4; i < K; i += RQ_THREADS * 4) { const float4 v = *reinterpret_cast<const float4 *>(xr + i);
+            sum += (double)(v.x * v.x); sum += (double)(v.y * v.y); sum += (double)(v.z * v.z); sum += (double)(v.w * v.w); }
+        sum = wave_sum_d(sum);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
         __syncthreads();
-        const float mean = (float)(red[0] / (double)K);
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < RQ_THREADS / 64; i++) tot += red[i];
+        const double delta = (double)K * 4e-16;          // two sums of K non-negative terms, each within K * 2^-53 of the exact one, and margin for the multiplications below
+        const float lo = (float)(tot * (1.0 - delta) / (double)K), hi = (float)(tot * (1.0 + delta) / (double)K);
+        float mean = lo;
+        if (lo != hi) {                                  // block-uniform: every thread computed the same tot
+            __syncthreads();
+            if (threadIdx.x == 0) { double sq = 0.0; for (int i = 0; i < K; i++) sq += (double)(xr[i] * xr[i]); red[0] = sq; }
+            __syncthreads();
+            mean = (float)(red[0] / (double)K);
+        }
         scale = 1.0f / sqrtf(mean + 1e-6f);
     } else if (w) {
         double sum = 0.0;
@@ -1628,6 +1646,10 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_split_pv(const float *__res
         for (int pp = 0; pp < P; pp++) s += part[pp * HD + i];
         __hip_atomic_store(mine + i, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // device-scope (sc1) store: visible to a reader on another XCD without a cache flush
     }
+    // Hand-off form (cdna_hip_programming.md Guideline 16, R1; MI355X_MICROARCH.md "Valid forms"): payload by write-through (sc1) stores, EVERY storing thread drains
+    // vmcnt(0), workgroup barrier, ONE lane's agent-scope arrival; the reader (below) takes the payload with sc1 loads, which the guide lists as replacing the acquire when
+    // the producer stored sc1.  A release on the arrival would add buffer_wbl2 (~1.7 us) to every one of the n_head x S workgroups of every layer.  Exercised across XCDs
+    // at the real head count by tests/test_gpu_parity.py::test_key_split_attention_at_the_13b_head_count_is_bit_identical.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this thread's partial stores have completed ...
     __syncthreads();                                              // ... and so have everybody's, before the arrival is counted
     if (tid == 0) s_last = __hip_atomic_fetch_add(arrive + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(S - 1);
