@@ -625,27 +625,43 @@ void Engine::forward_ref(int N, bool from_tokens, hipStream_t s, bool feed) {
     };
     tr("embd", -1, x_, (size_t)N * E);
     const int t_max = n_ctx_;                                              // sizes k_attn_ref's LDS rows; a captured decode step is replayed at later positions
+    // one row (decode): same-type matrices of a set in one launch of the prefetching row kernel; otherwise (prompt rows, other types) one generic launch per matrix
+    auto ref_set = [&](std::initializer_list<const QWeight *> Ws, std::initializer_list<float *> Ys, const float *res) {
+        const QWeight *W[3]; float *Y[3]; const float *R[3]; int n = 0;
+        for (const QWeight *w : Ws) W[n++] = w;
+        n = 0; for (float *yv : Ys) { Y[n] = yv; R[n] = res; n++; }
+        int done = 0;
+        if (N == 1) {                                // split into runs of equal type / shape (wq | wk + a differently typed wv)
+            while (done < n) {
+                int run = 1; while (done + run < n && W[done + run]->type == W[done]->type && W[done + run]->rows == W[done]->rows && W[done + run]->cols == W[done]->cols) run++;
+                if (!launch_mul_mat_ref_set(W + done, Y + done, res ? R + done : nullptr, run, act_, s))
+                    for (int i = 0; i < run; i++) launch_mul_mat_ref(*W[done + i], act_, N, Y[done + i], W[done + i]->rows, res, s);
+                done += run;
+            }
+        } else for (int i = 0; i < n; i++) launch_mul_mat_ref(*W[i], act_, N, Y[i], W[i]->rows, res, s);
+    };
     for (size_t il = 0; il < layers_.size(); il++) {
         const LayerW &L = layers_[il];
         __half *kc = kc_ + (sl * layers_.size() + il) * C * E, *vc = vc_ + (sl * layers_.size() + il) * C * E;
         launch_rms_quant(x_, L.attn_norm, N, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s, true);
-        launch_mul_mat_ref(L.wq, act_, N, q_, E, nullptr, s); launch_mul_mat_ref(L.wk, act_, N, k_, E, nullptr, s); launch_mul_mat_ref(L.wv, act_, N, v_, E, nullptr, s);
+        ref_set({&L.wq, &L.wk, &L.wv}, {q_, k_, v_}, nullptr);
         tr("q", (int)il, q_, (size_t)N * E); tr("k", (int)il, k_, (size_t)N * E); tr("v", (int)il, v_, (size_t)N * E);
         launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s);
         launch_attn_ref(q_, kc, vc, N, H, hd, d_npast, t_max, tabs_, att_, s);
         tr("q_rope", (int)il, q_, (size_t)N * E); tr("att", (int)il, att_, (size_t)N * E);
         launch_silu_mul_quant(att_, nullptr, N, E, act_, act_mask_for(L.wo.type), tabs_, s);
-        launch_mul_mat_ref(L.wo, act_, N, x_, E, x_, s);
+        ref_set({&L.wo}, {x_}, x_);
         tr("x_attn", (int)il, x_, (size_t)N * E);
         launch_rms_quant(x_, L.ffn_norm, N, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s, true);
-        launch_mul_mat_ref(L.w1, act_, N, h1_, F, nullptr, s); launch_mul_mat_ref(L.w3, act_, N, h3_, F, nullptr, s);
+        ref_set({&L.w1, &L.w3}, {h1_, h3_}, nullptr);
         tr("h1", (int)il, h1_, (size_t)N * F); tr("h3", (int)il, h3_, (size_t)N * F);
         launch_silu_mul_quant(h1_, h3_, N, F, act_, act_mask_for(L.w2.type), tabs_, s);
-        launch_mul_mat_ref(L.w2, act_, N, x_, E, x_, s);
+        ref_set({&L.w2}, {x_}, x_);
         tr("x_ffn", (int)il, x_, (size_t)N * E);
     }
     launch_rms_quant(x_ + (size_t)(N - 1) * E, norm_, 1, E, act_, act_mask_for(output_.type), s, true);
-    launch_mul_mat_ref(output_, act_, 1, logits, V, nullptr, s);
+    { const int keepN = N; (void)keepN; const QWeight *Wo[1] = {&output_}; float *Yo[1] = {logits};
+      if (!launch_mul_mat_ref_set(Wo, Yo, nullptr, 1, act_, s)) launch_mul_mat_ref(output_, act_, 1, logits, V, nullptr, s); }
     launch_argmax(logits, V, d_argmax, d_scratch_, s);
     launch_advance(d_npast, N, d_feed, d_argmax, s);
     HIP_CHECK(hipMemcpyAsync(h_argmax_ + sl, d_argmax, 4, hipMemcpyDeviceToHost, s));

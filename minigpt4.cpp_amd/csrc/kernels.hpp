@@ -27,6 +27,7 @@ void launch_mul_mat(const QWeight &W, const ActQ &A, int N, float *y, int ldy, c
 
 // MINIGPT4_PARITY=1: the same unit traits, the per-block fp32 terms added in the CPU oracle's order (one sequential chain per output) -- bit-identical to oracle/refcpu.c, slow
 void launch_mul_mat_ref(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s);
+bool launch_mul_mat_ref_set(const QWeight *const *W, float *const *y, const float *const *res, int n, const ActQ &A, hipStream_t s);   // one row (decode) x 1..3 same-shape matrices: every unit of a row requested up front; false -> use launch_mul_mat_ref
 bool matvec_prologue_supported(int type, int cols);   // the fused row-preparation variants of the decode mat-vec
 void set_mmq_enabled(int v);
 int mmq_enabled();

@@ -269,6 +269,98 @@ __global__ __launch_bounds__(256) void k_mul_mat_ref(const QWeight W, const ActQ
     }
     if (lane == 0) { const size_t o = (size_t)t * ldy + row; y[o] = residual ? acc + residual[o] : acc; }
 }
+// The same chain for ONE activation row (decode) over up to three matrices of one type and K in one launch: every lane's NU units (u = lane + 64 i, as in k_matvec_v2) are
+// requested before the first block is added, so a wave pays one memory round trip instead of one per 64 units (the generic kernel above: 3 ... 7 dependent round trips per
+// row, 5.5 ms per 13B token in parity mode).  The per-block terms are added in the same order: chunk after chunk, block after block -- bit-identical to k_mul_mat_ref.
+struct RefSet { QWeight w[3]; float *y[3]; const float *res[3]; int n; };
+template <int T, int NU>
+__global__ __launch_bounds__(256) void k_mul_mat_ref_row(const RefSet S, const ActQ A) {
+    using X = Tr<T>;
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.y;
+    const QWeight &W = S.w[m];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), n_waves = (int)gridDim.x * 4;
+    const int K = W.cols, U = K / X::EPU, rows = W.rows;
+    if (wave >= rows) return;                     // wave-uniform
+    typename X::AU a[NU]; bool ok[NU]; int uc[NU];
+#pragma unroll
+    for (int i = 0; i < NU; i++) { const int u = lane + 64 * i; ok[i] = u < U; uc[i] = ok[i] ? u : 0; X::loada(A, 0, K, uc[i], a[i]); }
+    struct Row { typename X::WU w[NU]; };
+    auto fetch = [&](int row, Row &Rw) {           // clamped instead of branching: every load of the pipeline is unconditional (counted waits)
+        const int r = min(row, rows - 1);
+#pragma unroll
+        for (int i = 0; i < NU; i++) X::loadw(W, (size_t)r * U, uc[i], Rw.w[i]);
+    };
+    auto chain = [&](int row, const Row &Rw) {     // the oracle's order: chunk after chunk, block after block
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NU; i++) {
+            const int n_here = min(64, U - 64 * i);
+            if (n_here <= 0) break;
+            int i0, i1; X::ints(Rw.w[i], a[i], i0, i1);
+            if (!ok[i]) { i0 = 0; i1 = 0; }
+            // the block's integer parts over its GROUP lanes on the DPP crossbar (exact integer sums: any combining order gives the same value; __shfl_xor is an LDS permute)
+            if (X::GROUP >= 2) { i0 += dpp_i<0xB1>(i0); i1 += dpp_i<0xB1>(i1); }
+            if (X::GROUP >= 4) { i0 += dpp_i<0x4E>(i0); i1 += dpp_i<0x4E>(i1); }
+            if (X::GROUP >= 8) { i0 += dpp_i<0x141>(i0); i1 += dpp_i<0x141>(i1); }
+            static_assert(X::GROUP <= 8, "one DPP row half per ggml block");
+            float f0, v0, f1, v1; X::terms(Rw.w[i], a[i], i0, i1, f0, v0, f1, v1);
+            for (int g = 0; g < n_here; g += X::GROUP) {   // g is wave-uniform: v_readlane (the generic __shfl is an LDS permute, ~100 dependent cycles per block term)
+                acc = fmaf(readlane_f(f0, g), readlane_f(v0, g), acc);
+                if (X::TERMS == 2) acc = fmaf(readlane_f(f1, g), readlane_f(v1, g), acc);
+            }
+        }
+        if (lane == 0) { const float *r = S.res[m]; S.y[m][row] = r ? acc + r[row] : acc; }
+    };
+    Row cur, nxt;                                  // two statically named stages, as in matvec_run: the next row is in flight while this one is chained
+    fetch(wave, cur);
+    for (int row = wave; row < rows;) {
+        fetch(row + n_waves, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        chain(row, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        row += n_waves;
+        if (row >= rows) break;
+        fetch(row + n_waves, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        chain(row, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        row += n_waves;
+    }
+}
+static int g_ref_cus = 256;
+template <int T> static bool launch_mul_mat_ref_row_t(const RefSet &S, const ActQ &A, hipStream_t s) {
+    const int U = S.w[0].cols / Tr<T>::EPU, nu = (U + 63) / 64;
+    // persistent waves: ~16 per CU over the whole set, each walking rows wave, wave + n_waves, ...
+    const int blocks = std::max(1, std::min((S.w[0].rows + 3) / 4, g_ref_cus * 4 / S.n));
+    const dim3 grid((unsigned)blocks, (unsigned)S.n);
+    note_kernel("k_mul_mat_ref_row<%d, %d>", T, nu);
+    switch (nu) {
+    case 1: hipLaunchKernelGGL((k_mul_mat_ref_row<T, 1>), grid, dim3(256), 0, s, S, A); return true;
+    case 2: hipLaunchKernelGGL((k_mul_mat_ref_row<T, 2>), grid, dim3(256), 0, s, S, A); return true;
+    case 3: hipLaunchKernelGGL((k_mul_mat_ref_row<T, 3>), grid, dim3(256), 0, s, S, A); return true;
+    case 4: hipLaunchKernelGGL((k_mul_mat_ref_row<T, 4>), grid, dim3(256), 0, s, S, A); return true;
+    case 6: hipLaunchKernelGGL((k_mul_mat_ref_row<T, 6>), grid, dim3(256), 0, s, S, A); return true;
+    case 7: hipLaunchKernelGGL((k_mul_mat_ref_row<T, 7>), grid, dim3(256), 0, s, S, A); return true;
+    default: return false;
+    }
+}
+// One activation row against 1..3 equally shaped matrices of one type (parity mode's decode step); false -> shape outside this kernel, use launch_mul_mat_ref per matrix
+bool launch_mul_mat_ref_set(const QWeight *const *W, float *const *y, const float *const *res, int n, const ActQ &A, hipStream_t s) {
+    if (n < 1 || n > 3) return false;
+    RefSet S{}; S.n = n;
+    for (int i = 0; i < n; i++) { if (W[i]->type != W[0]->type || W[i]->rows != W[0]->rows || W[i]->cols != W[0]->cols) return false; S.w[i] = *W[i]; S.y[i] = y[i]; S.res[i] = res ? res[i] : nullptr; }
+    switch (W[0]->type) {
+    case GT_Q4_0: return launch_mul_mat_ref_row_t<GT_Q4_0>(S, A, s);
+    case GT_Q4_1: return launch_mul_mat_ref_row_t<GT_Q4_1>(S, A, s);
+    case GT_Q5_0: return launch_mul_mat_ref_row_t<GT_Q5_0>(S, A, s);
+    case GT_Q5_1: return launch_mul_mat_ref_row_t<GT_Q5_1>(S, A, s);
+    case GT_Q4_K: return launch_mul_mat_ref_row_t<GT_Q4_K>(S, A, s);
+    case GT_Q5_K: return launch_mul_mat_ref_row_t<GT_Q5_K>(S, A, s);
+    case GT_Q6_K: return launch_mul_mat_ref_row_t<GT_Q6_K>(S, A, s);
+    default: return false;                       // (Q8_0 / Q2_K / F16 / F32 rows have other unit widths: the generic kernel serves them)
+    }
+}
 template <int T> static void launch_mul_mat_ref_t(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
     note_kernel("k_mul_mat_ref<%d>", T);
     hipLaunchKernelGGL((k_mul_mat_ref<T>), dim3((unsigned)((W.rows + 3) / 4), (unsigned)N), dim3(256), 0, s, W, A, N, y, ldy, residual);
@@ -673,7 +765,7 @@ bool matvec_prologue_supported(int type, int cols) {
     switch (type) { case GT_Q4_0: case GT_Q4_1: case GT_Q5_0: case GT_Q5_1: case GT_Q4_K: case GT_Q5_K: case GT_Q6_K: break; default: return false; }
     return cols % 32 == 0 && cols / 32 <= 7 * 64 && ((type != GT_Q4_K && type != GT_Q5_K && type != GT_Q6_K) || cols % 256 == 0);
 }
-void set_matvec_tuning(int waves_per_cu, int fat_threads, int cus) { g_mv_force_waves = std::max(0, waves_per_cu); g_mv_force_fat = std::max(0, fat_threads); if (cus > 0) g_mv_cus = cus; }
+void set_matvec_tuning(int waves_per_cu, int fat_threads, int cus) { g_mv_force_waves = std::max(0, waves_per_cu); g_mv_force_fat = std::max(0, fat_threads); if (cus > 0) { g_mv_cus = cus; g_ref_cus = cus; } }
 // Decode (N = 1) mat-vec over 1..3 same-type, same-shape, equally spaced matrices.  Returns false when the set is outside the v2 kernel's range.
 bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s, int pro, const float *px, const float *pw,
                        const Tables *tb, int epi) {
@@ -2299,10 +2391,21 @@ __global__ __launch_bounds__(256) void k_attn_ref(const float *__restrict__ q, c
     __syncthreads();
     const float kq_scale = 1.0f / sqrtf((float)hd);
     float mx = -INFINITY;
-    for (int j = tid; j < T; j += 256) {
+    for (int j = tid; j < T; j += 256) {                          // the row in 16-byte pieces (hd % 8 == 0), the fma chain in element order as before
         const __half *kr = kc + (size_t)j * E + (size_t)h * hd;
         float s = 0.0f;
-        for (int i = 0; i < hd; i++) s = fmaf(__half2float(kr[i]), __half2float(qh[i]), s);
+        for (int i0 = 0; i0 < hd; i0 += 32) {
+            int4 kk[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) kk[c] = i0 + 8 * c < hd ? ld16(kr + i0 + 8 * c) : make_int4(0, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (i0 + 8 * c >= hd) break;
+                const unsigned wds[4] = {(unsigned)kk[c].x, (unsigned)kk[c].y, (unsigned)kk[c].z, (unsigned)kk[c].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const int i = i0 + 8 * c + 2 * e; s = fmaf(h2f_bits(wds[e] & 0xFFFF), __half2float(qh[i]), s); s = fmaf(h2f_bits(wds[e] >> 16), __half2float(qh[i + 1]), s); }
+            }
+        }
         s *= kq_scale; sc[j] = s; mx = fmaxf(mx, s);
     }
     mx = wave_max(mx);
@@ -2320,7 +2423,15 @@ __global__ __launch_bounds__(256) void k_attn_ref(const float *__restrict__ q, c
     for (int i = tid; i < hd; i += 256) {
         const __half *vr = vc + (size_t)h * hd + i;
         float s = 0.0f;
-        for (int j = 0; j < T; j++) s = fmaf(__half2float(vr[(size_t)j * E]), __half2float(ph[j]), s);
+        int j = 0;
+        for (; j + 8 <= T; j += 8) {                              // eight keys' values requested together, added in key order
+            __half vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) vv[u] = vr[(size_t)(j + u) * E];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s = fmaf(__half2float(vv[u]), __half2float(ph[j + u]), s);
+        }
+        for (; j < T; j++) s = fmaf(__half2float(vr[(size_t)j * E]), __half2float(ph[j]), s);
         out[(size_t)t * E + (size_t)h * hd + i] = s;
     }
 }
