@@ -88,6 +88,48 @@ def test_headline_chat_flow_matches_oracle(gpu_lib, config, omp_threads):
         gpu_lib.minigpt4_free(ctx)
 
 
+def test_f16_13b_width_512_token_prefill_matches_oracle(gpu_lib, omp_threads):
+    """BASELINE.json configs[4] at its REAL shapes: Vicuna-13B f16 (unquantised) width -- n_embd 5120, 40 heads of 128, n_ff 13824, n_vocab 32000 -- and one 512-token
+    `llama_eval`, i.e. the launches the 18 ms / 720 TFLOP/s figure is quoted on (`k_gemm_dma` 256x128 / 256x256 set launches with K split, the w1|w3 PAIR launch whose epilogue
+    stores fp16(silu * mul), `k_attn_prefill_h8` storing fp16 rows for wo, split-K combines folded into the norms).  The file is the 40-layer graph cut to TWO layers (every launch
+    shape of the full file occurs; the oracle's 512-row f16 pass over 40 layers would take minutes).  Last-token logits within 3e-3 of the CPU oracle (reference path:
+    llama_eval behind minigpt4.cpp:2373, ggml f16 mat-mul with fp16-rounded activations), also after four decode steps on the cache the prompt launches filled."""
+    import refcpu as R
+    import headline as H
+    from minigpt4_cpp_amd import modelgen as G
+    d = H.model_dir()
+    lp = os.path.join(d, "llm_13b_f16_l2.bin")
+    if not os.path.exists(lp + ".ok"):
+        lcfg = G.LLMConfig(n_vocab=32000, n_embd=5120, n_mult=256, n_head=40, n_layer=2, ftype=1, wtype="f16", mix="none")
+        G.write_llm_file(lp, lcfg, seed=77, std=0.02, fast=True, **{k: v for k, v in G.TINY_CONDITIONED.items()})
+        open(lp + ".ok", "w").write("ok")
+    vp = os.path.join(d, "vision_tiny_5120.bin")
+    if not os.path.exists(vp):
+        G.write_vision_file(vp, G.tiny_vision(n_embd_llm=5120), seed=3, std=0.05)
+    toks = [1] + [int(x) for x in np.random.default_rng(8).integers(259, 32000, 511)]
+    R.lib().orc_set_threads(int(omp_threads))
+    o = R.OracleLLM(G.read_llm_file(lp, in_memory=True), n_ctx=640)
+    want = o.eval_tokens(toks)
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=640, n_batch=512)
+    try:
+        gpu_lib.amd_eval_tokens(ctx, toks)
+        fast = gpu_lib.amd_logits(ctx).copy()
+        ids = []
+        for _ in range(4):                                      # and four decode steps that read the K / V rows the prompt launches wrote
+            ids.append(int(gpu_lib.amd_logits(ctx).argmax()))
+            gpu_lib.amd_eval_tokens(ctx, [ids[-1]])
+        after = gpu_lib.amd_logits(ctx).copy()
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+    for t in ids:
+        want2 = o.eval_tokens([t])
+    rel = float(np.abs(fast - want).max() / np.abs(want).max())
+    rel2 = float(np.abs(after - want2).max() / np.abs(want2).max())
+    _dump("13b_f16_l2_prefill512", {"max_logit_rel": rel, "max_logit_rel_after_4_decode_steps": rel2})
+    assert np.isfinite(fast).all() and rel <= 3e-3, rel
+    assert rel2 <= 3e-3, rel2
+
+
 def test_full_size_vit_g_encode_matches_oracle(gpu_lib, omp_threads):
     """EVA ViT-g/14 at its real size (dim 1408, 16 heads x 88, MLP 6144, 39 blocks) + the 12-layer Q-Former + llama_proj (5120): every block has its own
     weights here (unique_blocks = None), so a wrong stride / tile order / split-K slab shows up."""
