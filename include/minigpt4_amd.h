@@ -73,6 +73,12 @@ MINIGPT4_API int minigpt4_amd_weight_arena(struct MiniGPT4Context *ctx, int whic
  * set MINIGPT4_LOAD=recv before minigpt4_model_load: headers are parsed, both arenas are laid out and allocated exactly as rank 0's (compare minigpt4_amd_arena_plan), no
  * tensor data is read, uploaded or repacked; after the arenas have been received (minigpt4_amd_weight_arena gives the device ranges) minigpt4_amd_weights_received builds
  * what is derived from them on the device.  minigpt4_amd_plan_arenas computes the same layout from the files alone, without a GPU. */
+/* The same exchange INSIDE minigpt4_model_load, for clients without Python / torch (csrc/dist.cpp): with MINIGPT4_WORLD_SIZE = N, MINIGPT4_RANK = r and
+ * MINIGPT4_NCCL_ID_FILE = <a path every rank of the job can read, unique to the job> in the environment, rank 0 loads the files, writes the ncclUniqueId to that file and
+ * broadcasts both arenas (librccl.so by dlopen, <= 1 GiB pieces); ranks 1..N-1 load headers only, wait for the id (MINIGPT4_DIST_TIMEOUT_S, default 120), receive, finish
+ * the load; layout hashes before and arena checksums after must agree.  Any failure fails the load (NULL; text in minigpt4_amd_last_error) -- no fallback to the files.
+ * One process per GPU: MINIGPT4_DEVICE (or LOCAL_RANK) selects it.  minigpt4_amd_dist_info: what this context's load did (bcast_ms = 0 for an ordinary load). */
+MINIGPT4_API int minigpt4_amd_dist_info(struct MiniGPT4Context *ctx, int *world, int *rank, float *bcast_ms);
 MINIGPT4_API int minigpt4_amd_plan_arenas(const char *vision_path, const char *llm_path, size_t *llm_bytes, size_t *vision_bytes, uint64_t *llm_hash, uint64_t *vision_hash);
 MINIGPT4_API int minigpt4_amd_arena_plan(struct MiniGPT4Context *ctx, size_t *llm_bytes, size_t *vision_bytes, uint64_t *llm_hash, uint64_t *vision_hash);
 MINIGPT4_API int minigpt4_amd_load_mode(struct MiniGPT4Context *ctx);              /* 0 full, 1 waiting for the arenas */

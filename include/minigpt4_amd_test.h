@@ -60,6 +60,8 @@ MINIGPT4_API int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, in
 /* Average latency (microseconds) of a device-wide barrier across n_blocks co-resident 512-thread workgroups (atomic counter + agent-scope fences); *errors
  * counts visibility failures of a neighbour-word check.  Measurement for DESIGN.md's launch-gap-vs-barrier analysis. */
 MINIGPT4_API float minigpt4_amd_probe_grid_barrier(int n_blocks, int iters, unsigned *errors);
+/* what csrc/dist.cpp reads from MINIGPT4_WORLD_SIZE / MINIGPT4_RANK / MINIGPT4_NCCL_ID_FILE / MINIGPT4_DIST_TIMEOUT_S (host only): 0, or 1 with the reason in err */
+MINIGPT4_API int minigpt4_amd_dist_env(int *world, int *rank, char *id_file, size_t cap, char *err, size_t err_cap);
 /* LDS-DMA stream probe (csrc/probe_kernels.hip, tools/probe_dma.py): chip-wide GB/s of `waves` loader waves per CU keeping `depth` fills of `fill` bytes in flight into an LDS
  * ring; form 0 scalar base + instruction offsets, 1 per-lane addresses, 2 register loads, 3 register loads + ds_write; policy 0 nt, 1 default; deal 0 blocked, 1 round-robin */
 MINIGPT4_API float minigpt4_amd_probe_dma(int form, int policy, int waves, int fill, int depth, int deal, double total_gb);

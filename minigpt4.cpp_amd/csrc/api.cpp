@@ -281,6 +281,13 @@ int minigpt4_amd_arena_plan(struct MiniGPT4Context *ctx, size_t *llm_bytes, size
     if (llm_hash) *llm_hash = p.llm_hash; if (vision_hash) *vision_hash = p.vision_hash;
     return 0;
 }
+int minigpt4_amd_dist_info(struct MiniGPT4Context *ctx, int *world, int *rank, float *bcast_ms) {
+    if (!ctx) return 1;
+    if (world) *world = E_(ctx)->dist_world();
+    if (rank) *rank = E_(ctx)->dist_rank();
+    if (bcast_ms) *bcast_ms = E_(ctx)->dist_bcast_ms();
+    return 0;
+}
 int minigpt4_amd_set_parity(struct MiniGPT4Context *ctx, int on) {
     if (!ctx) return 1;
     return guarded(1, [&]() -> int { E_(ctx)->set_parity(on != 0); return 0; });

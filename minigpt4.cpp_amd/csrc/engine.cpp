@@ -1,9 +1,11 @@
 #include "engine.hpp"
+#include "dist.hpp"
 #include "quantize.hpp"
 #include "imageio.hpp"
 
 #include <algorithm>
 #include <optional>
+#include <unistd.h>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -122,6 +124,10 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (const char *tf = getenv("MINIGPT4_PARITY_TRACE")) { if (*tf) trace_file_ = fopen(tf, "wb"); }
     parity_ = trace_file_ || (getenv("MINIGPT4_PARITY") && atoi(getenv("MINIGPT4_PARITY")));   // oracle-order fp32 accumulation (forward_ref): bit-identical to the CPU oracle, slow
     if (const char *lm = getenv("MINIGPT4_LOAD")) load_mode_ = !strcmp(lm, "recv") ? LOAD_RECV : LOAD_FULL;
+    // native multi-GPU load (dist.hpp): MINIGPT4_WORLD_SIZE / MINIGPT4_RANK / MINIGPT4_NCCL_ID_FILE -> rank 0 reads the files, every other rank loads headers only and
+    // receives both weight arenas by ncclBroadcast inside this call
+    DistEnv dist; { std::string derr; if (parse_dist_env(dist, derr)) { set_last_error(derr); MG4_ERR("%s", derr.c_str()); return E_LoadLanguageModel; } }
+    if (dist.active() && dist.rank != 0) load_mode_ = LOAD_RECV;
     auto t0 = std::chrono::steady_clock::now();
     if (int e = load_llm(llm_path)) return e;
     auto t1 = std::chrono::steady_clock::now();
@@ -131,6 +137,46 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     MG4_INFO("Loading minigpt4 model took %lld ms to complete", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count());
     alloc_buffers();
     if (stage_) { HIP_IGNORE(hipFree(stage_)); stage_ = nullptr; stage_cap_ = 0; }
+    if (dist.active()) { if (int e = native_broadcast(dist.world, dist.rank, dist.id_file, dist.timeout_s)) return e; }
+    return E_None;
+}
+
+// The load-time exchange of a node's replicas, inside the C library: unique id through a file, communicator, layout agreement, both arenas from rank 0 in <= 1 GiB pieces,
+// checksum agreement.  Any failure is an error of minigpt4_model_load (message in minigpt4_amd_last_error); there is no fallback to reading the files.
+int Engine::native_broadcast(int world, int rank, const std::string &id_file, int timeout_s) {
+    std::string err;
+    auto fail = [&](const std::string &what) { set_last_error("weight broadcast (rank " + std::to_string(rank) + " of " + std::to_string(world) + "): " + what); MG4_ERR("%s", last_error().c_str()); return (int)E_LoadLanguageModel; };
+    Rccl rccl;
+    if (rccl.open(err)) return fail(err);
+    uint8_t id[128];
+    if (rank == 0) { if (rccl.unique_id(id, err) || publish_unique_id(id_file, id, err)) return fail(err); }
+    else if (await_unique_id(id_file, id, timeout_s, err)) return fail(err);
+    if (rccl.init(world, rank, id, err)) return fail(err);
+    if (rank == 0) unlink(id_file.c_str());            // every rank has joined: a later job must not pick this id up
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long *d_words = nullptr;
+    HIP_CHECK(hipMalloc((void **)&d_words, 64));
+    struct Free { unsigned long long *p; ~Free() { HIP_IGNORE(hipFree(p)); } } free_words{d_words};
+    auto agree = [&](const unsigned long long mine[4], const char *what) -> bool {     // rank 0's four words against this rank's
+        unsigned long long theirs[4];
+        HIP_CHECK(hipMemcpyAsync(d_words, mine, 32, hipMemcpyHostToDevice, stream_));
+        if (rccl.broadcast(d_words, 32, 0, stream_, err)) return false;
+        HIP_CHECK(hipMemcpyAsync(theirs, d_words, 32, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        if (memcmp(mine, theirs, 32)) { char b[200]; snprintf(b, sizeof b, "%s differ from rank 0's (%llx %llx %llx %llx vs %llx %llx %llx %llx)", what, mine[0], mine[1], mine[2], mine[3], theirs[0], theirs[1], theirs[2], theirs[3]); err = b; return false; }
+        return true;
+    };
+    const ArenaPlan pl = arena_plan();
+    const unsigned long long plan_words[4] = {(unsigned long long)pl.llm_bytes, (unsigned long long)pl.vision_bytes, (unsigned long long)pl.llm_hash, (unsigned long long)pl.vision_hash};
+    if (!agree(plan_words, "arena layouts (sizes / layout hashes)")) return fail(err);
+    if (rccl.broadcast(llm_arena_.base, llm_arena_.used, 0, stream_, err) || rccl.broadcast(vis_arena_.base, vis_arena_.used, 0, stream_, err)) return fail(err);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    dist_bcast_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (load_mode_ == LOAD_RECV) weights_received();
+    const unsigned long long sums[4] = {device_checksum(llm_arena_.base, llm_arena_.used, stream_), device_checksum(vis_arena_.base, vis_arena_.used, stream_), 0ull, 0ull};
+    if (!agree(sums, "arena contents (checksums) after the broadcast")) return fail(err);
+    dist_world_ = world; dist_rank_ = rank;
+    MG4_INFO("rank %d of %d: weight arenas %s in %.1f ms (%.2f GB, RCCL)", rank, world, rank ? "received" : "broadcast", dist_bcast_ms_, (llm_arena_.used + vis_arena_.used) / 1e9);
     return E_None;
 }
 

@@ -39,6 +39,10 @@ public:
     static int plan_arenas(const std::string &vision_path, const std::string &llm_path, ArenaPlan &out);   // host only
     ArenaPlan arena_plan() const { ArenaPlan p; p.llm_bytes = llm_arena_.used; p.vision_bytes = vis_arena_.used; p.llm_hash = llm_arena_.layout_hash; p.vision_hash = vis_arena_.layout_hash; return p; }
     LoadMode load_mode() const { return load_mode_; }
+    // native broadcast (dist.hpp): what this context's load did -- world size, rank, milliseconds of the exchange (0 when the load was an ordinary one)
+    int dist_world() const { return dist_world_; }
+    int dist_rank() const { return dist_rank_; }
+    float dist_bcast_ms() const { return dist_bcast_ms_; }
 
     // ---- image path (reference encode_image, minigpt4.cpp:2094-2363)
     int encode_image(const float *chw, float *out);   // out: [32][proj_out()]
@@ -116,6 +120,8 @@ private:
     template <typename T> T *upload_raw(DeviceArena &a, const void *src, size_t bytes);
 
 
+    int native_broadcast(int world, int rank, const std::string &id_file, int timeout_s);
+    int dist_world_ = 1, dist_rank_ = 0; float dist_bcast_ms_ = 0.0f;
     LoadMode load_mode_ = LOAD_FULL;
     bool moves_data() const { return load_mode_ == LOAD_FULL; }
     bool weights_missing() const;      // LOAD_RECV before weights_received(): sets the error text, true

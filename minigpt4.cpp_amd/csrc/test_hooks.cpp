@@ -17,6 +17,7 @@ using namespace mg4::apiutil;
 namespace mg4 {   // probe_kernels.hip
 float probe_valu_ns(int op, int waves_per_simd, int iters, int cus);
 float probe_grid_barrier_us(int n_blocks, int iters, unsigned *errors_out);
+int parse_dist_env_for_test(int *world, int *rank, char *id_file, size_t cap, char *err, size_t err_cap);
 float probe_dma_GBps(int form, int policy, int waves, int fill, int depth, int deal, size_t total_bytes);
 void launch_fill_random(void *p, size_t bytes, unsigned seed, hipStream_t s);
 }
@@ -481,6 +482,7 @@ float minigpt4_amd_probe_valu(int op, int waves_per_simd, int iters) {
     guarded(1, [&] { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0)); set_matvec_tuning(0, 0, prop.multiProcessorCount); ns = probe_valu_ns(op, waves_per_simd, iters, prop.multiProcessorCount); return 0; });
     return ns;
 }
+int minigpt4_amd_dist_env(int *world, int *rank, char *id_file, size_t cap, char *err, size_t err_cap) { return parse_dist_env_for_test(world, rank, id_file, cap, err, err_cap); }
 float minigpt4_amd_probe_dma(int form, int policy, int waves, int fill, int depth, int deal, double total_gb) {
     float r = -1.0f;
     guarded(1, [&] { r = probe_dma_GBps(form, policy, waves, fill, depth, deal, (size_t)(total_gb * 1e9)); return 0; });

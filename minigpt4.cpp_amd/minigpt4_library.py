@@ -188,6 +188,8 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_weights_received.argtypes = [VOID_PTR]
         L.minigpt4_amd_arena_checksum.argtypes = [VOID_PTR, I32, U64P]
         L.minigpt4_amd_set_parity.argtypes = [VOID_PTR, I32]
+        L.minigpt4_amd_dist_info.argtypes = [VOID_PTR, P(I32), P(I32), P(F32)]
+        L.minigpt4_amd_dist_info.restype = I32
         L.minigpt4_amd_parity.argtypes = [VOID_PTR]
         L.minigpt4_amd_set_conversations.argtypes = [VOID_PTR, I32]
         L.minigpt4_amd_select_conversation.argtypes = [VOID_PTR, I32]
@@ -333,6 +335,12 @@ class MiniGPT4SharedLibrary:
         return int(v.value)
 
     # several conversations per context (include/minigpt4_amd.h): the reference calls act on the selected one
+    def amd_dist_info(self, ctx) -> dict:
+        """what the native (in-library RCCL) weight broadcast of this context's load did: world size, rank, milliseconds (0.0 for an ordinary load)"""
+        w, r, ms = I32(), I32(), F32()
+        assert self.library.minigpt4_amd_dist_info(ctx.ptr, ctypes.byref(w), ctypes.byref(r), ctypes.byref(ms)) == 0
+        return {"world": w.value, "rank": r.value, "bcast_ms": ms.value}
+
     def amd_set_parity(self, ctx, on: bool):
         """Parity mode (MINIGPT4_PARITY): the language path adds its fp32 terms in the CPU oracle's order -- bit-identical logits, slow."""
         if self.library.minigpt4_amd_set_parity(ctx.ptr, 1 if on else 0):

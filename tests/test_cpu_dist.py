@@ -181,3 +181,34 @@ def test_load_replica_reports_a_refused_broadcast_as_an_error_not_as_a_rate(tmp_
 def test_bcast_report_single_rank_is_none():
     from minigpt4_cpp_amd import dist as D
     assert D.bcast_report({"mode": "full", "load_s": 1.0, "bcast_ms": None, "plan": {"llm_bytes": 1, "vision_bytes": 1}}) is None
+
+
+# ---- the native (in-library) broadcast's environment contract (csrc/dist.cpp), host only
+def _dist_env(lib, env):
+    import ctypes
+    keys = ("MINIGPT4_WORLD_SIZE", "MINIGPT4_RANK", "MINIGPT4_NCCL_ID_FILE", "MINIGPT4_DIST_TIMEOUT_S")
+    old = {k: os.environ.pop(k, None) for k in keys}
+    os.environ.update(env)
+    try:
+        f = lib.library.minigpt4_amd_dist_env
+        f.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+        w, r, idf, err = ctypes.c_int(), ctypes.c_int(), ctypes.create_string_buffer(512), ctypes.create_string_buffer(512)
+        rc = f(ctypes.byref(w), ctypes.byref(r), idf, 512, err, 512)
+        return rc, w.value, r.value, idf.value.decode(), err.value.decode()
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
+            if old[k] is not None:
+                os.environ[k] = old[k]
+
+
+def test_native_broadcast_environment_contract(lib):
+    assert _dist_env(lib, {}) == (0, 1, 0, "", "")                                            # nothing set: an ordinary single-GPU load
+    assert _dist_env(lib, {"MINIGPT4_WORLD_SIZE": "8", "MINIGPT4_RANK": "3", "MINIGPT4_NCCL_ID_FILE": "/tmp/job17.id"})[:4] == (0, 8, 3, "/tmp/job17.id")
+    assert _dist_env(lib, {"MINIGPT4_WORLD_SIZE": "1", "MINIGPT4_NCCL_ID_FILE": "/tmp/x.id"})[:4] == (0, 1, 0, "/tmp/x.id")   # a communicator of one rank (the single-GPU test)
+    for env, needle in (({"MINIGPT4_WORLD_SIZE": "2", "MINIGPT4_RANK": "1"}, "MINIGPT4_NCCL_ID_FILE"),
+                        ({"MINIGPT4_WORLD_SIZE": "2", "MINIGPT4_RANK": "2", "MINIGPT4_NCCL_ID_FILE": "/tmp/a"}, "MINIGPT4_RANK"),
+                        ({"MINIGPT4_WORLD_SIZE": "0"}, "MINIGPT4_WORLD_SIZE"), ({"MINIGPT4_WORLD_SIZE": "eight"}, "not an integer"),
+                        ({"MINIGPT4_RANK": "-1"}, "MINIGPT4_RANK"), ({"MINIGPT4_DIST_TIMEOUT_S": "0", "MINIGPT4_NCCL_ID_FILE": "/tmp/a"}, "TIMEOUT")):
+        rc, _, _, _, err = _dist_env(lib, env)
+        assert rc == 1 and needle in err, (env, err)

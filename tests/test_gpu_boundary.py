@@ -104,3 +104,9 @@ def test_c_client_replays_examples_main(gpu_lib, e2e_files, tmp_path):
     body = out.split("BEGIN\n", 1)[1].rsplit("END\n", 1)[0]
     want = _product_pieces(gpu_lib, vp, lp, img, n)
     assert body == "".join(p + "\n" for p in want)
+    # the same C client as a RANK of the native broadcast (csrc/dist.cpp): nothing but three environment variables changes for it
+    idf = str(tmp_path / "c_client.id")
+    run2 = subprocess.run([exe, vp, lp, raw, str(n), PROMPT], capture_output=True, timeout=300,
+                          env=dict(os.environ, MINIGPT4_WORLD_SIZE="1", MINIGPT4_RANK="0", MINIGPT4_NCCL_ID_FILE=idf))
+    assert run2.returncode == 0, run2.stderr.decode(errors="replace")[-500:]
+    assert run2.stdout.decode("utf-8", errors="replace").split("BEGIN\n", 1)[1].rsplit("END\n", 1)[0] == body and not os.path.exists(idf)

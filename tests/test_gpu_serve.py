@@ -142,3 +142,42 @@ def test_arena_tensor_view_and_single_rank_rccl_broadcast(gpu_lib, tiny_files):
         if made:
             dist.destroy_process_group()
         gpu_lib.minigpt4_free(ctx)
+
+
+def test_native_broadcast_inside_model_load_single_rank(gpu_lib, tiny_files, tmp_path, monkeypatch):
+    """csrc/dist.cpp: with MINIGPT4_WORLD_SIZE / MINIGPT4_RANK / MINIGPT4_NCCL_ID_FILE set, minigpt4_model_load itself opens librccl.so, exchanges the ncclUniqueId through
+    the file, builds the communicator, checks the arena layouts, broadcasts both arenas and compares checksums -- no Python / torch in the path (rank 0 reads the
+    files, the others receive).  One GPU here, so the communicator has ONE rank: every call of the sequence runs, the collectives have nobody to talk to.  The context must
+    behave exactly like an ordinary load; a bad environment must fail the load with the reason, not fall back."""
+    vp, llm = tiny_files
+    lp = llm("q5_k", "q5_k_m")
+    toks = [1, 5, 300, 44, 270, 99]
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=64, n_batch=16)
+    try:
+        assert gpu_lib.amd_dist_info(ctx) == {"world": 1, "rank": 0, "bcast_ms": 0.0}
+        gpu_lib.amd_eval_tokens(ctx, toks); want = gpu_lib.amd_logits(ctx).copy()
+        sums = [gpu_lib.amd_arena_checksum(ctx, 0), gpu_lib.amd_arena_checksum(ctx, 1)]
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+    idf = str(tmp_path / "job.id")
+    for k, v in (("MINIGPT4_WORLD_SIZE", "1"), ("MINIGPT4_RANK", "0"), ("MINIGPT4_NCCL_ID_FILE", idf)):
+        monkeypatch.setenv(k, v)
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=64, n_batch=16)
+    try:
+        info = gpu_lib.amd_dist_info(ctx)
+        assert info["world"] == 1 and info["rank"] == 0 and info["bcast_ms"] > 0.0, info
+        assert not os.path.exists(idf), "rank 0 removes the id file once every rank has joined"
+        assert [gpu_lib.amd_arena_checksum(ctx, 0), gpu_lib.amd_arena_checksum(ctx, 1)] == sums
+        gpu_lib.amd_eval_tokens(ctx, toks)
+        assert np.array_equal(gpu_lib.amd_logits(ctx), want)
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+    # a rank that never gets an id: the load fails after the timeout, with the reason -- it does not read the files instead
+    monkeypatch.setenv("MINIGPT4_WORLD_SIZE", "2"); monkeypatch.setenv("MINIGPT4_RANK", "1"); monkeypatch.setenv("MINIGPT4_DIST_TIMEOUT_S", "1")
+    with pytest.raises(RuntimeError) as ei:
+        gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=64, n_batch=16)
+    assert "ncclUniqueId" in str(ei.value) or "rank 1 of 2" in str(ei.value), str(ei.value)
+    monkeypatch.setenv("MINIGPT4_RANK", "5")
+    with pytest.raises(RuntimeError) as ei:
+        gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=64, n_batch=16)
+    assert "MINIGPT4_RANK" in str(ei.value), str(ei.value)
