@@ -85,7 +85,6 @@ int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t 
         QWeight W[3], plan;
         const size_t need = plan_qweight(ggml_type, (int)n_out, (int)n_in, plan, nullptr);
         DevBuf d_raw(raw_each), d_planes(need * (size_t)n_mat + 1024), d_x((size_t)(N * n_in) * 4), d_y(out_each * n_mat * 4), d_res(out_each * n_mat * 4), d_ws(out_each * n_mat * 16 * 4);
-        (void)generation;
         for (int i = 0; i < n_mat; i++) {
             plan_qweight(ggml_type, (int)n_out, (int)n_in, W[i], d_planes.as<uint8_t>() + (size_t)i * need);
             HIP_CHECK(hipMemcpy(d_raw.p, static_cast<const uint8_t *>(raw_w) + (size_t)i * raw_each, raw_each, hipMemcpyHostToDevice));
@@ -105,8 +104,16 @@ int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t 
             struct KsScope { KsScope(int k) { set_gemm_tuning(-1, k); } ~KsScope() { set_gemm_tuning(-1, 0); } } scope(std::max(0, ks));   // restored on every exit path
             ok = launch_gemm_f16_set(A.xh, (int)n_in, Wh, n_mat, (int)N, (int)n_out, (int)n_in, Yp, residual ? Rp : nullptr, (int)n_out, A.ws, A.ws_floats, 256, nullptr);
         } else {
-            struct KsScope { KsScope(int k) { set_mmq2_tuning(-1, -1, k); } ~KsScope() { set_mmq2_tuning(-1, -1, 0); } } scope(std::max(0, ks));
-            ok = launch_mmq2_set(Wp, Yp, residual ? Rp : nullptr, n_mat, A, (int)N, (int)n_out, nullptr);
+            struct KsScope { KsScope(int k) { set_mmq2_tuning(-1, -1, k); set_mmq3_tuning(-1, k); } ~KsScope() { set_mmq2_tuning(-1, -1, 0); set_mmq3_tuning(-1, 0); } } scope(std::max(0, ks));
+            if (generation == 3) {   // load-time digit planes (mmq3_kernels.hip)
+                if (!mmq3_supported(ggml_type, (int)n_out, (int)n_in)) return 4;
+                const size_t pb = mmq3_plane_bytes((int)n_out, (int)n_in);
+                DevBuf d_pl(pb * (size_t)n_mat);
+                const uint8_t *Pp[3];
+                for (int i = 0; i < n_mat; i++) { Pp[i] = d_pl.as<uint8_t>() + (size_t)i * pb; launch_mmq3_build(W[i], d_pl.as<uint8_t>() + (size_t)i * pb, nullptr); }
+                ok = launch_mmq3_set(Wp, Pp, Yp, residual ? Rp : nullptr, n_mat, A, (int)N, (int)n_out, nullptr);
+                HIP_CHECK(hipDeviceSynchronize());
+            } else ok = launch_mmq2_set(Wp, Yp, residual ? Rp : nullptr, n_mat, A, (int)N, (int)n_out, nullptr);
         }
         HIP_CHECK(hipDeviceSynchronize());
         if (!ok) return 4;
@@ -452,12 +459,21 @@ int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, 
         launch_rms_quant(dx.as<float>(), nullptr, N, cols, A, act_mask_for(ggml_type), nullptr);
         A.ws = dws.as<float>(); A.ws_floats = out_each * n_mat * 16;
         set_mmq2_cus(prop.multiProcessorCount);
-        struct KsScope { KsScope(int k) { set_mmq2_tuning(-1, -1, k); } ~KsScope() { set_mmq2_tuning(-1, -1, 0); } } ks_scope(std::max(0, ks));
+        struct KsScope { KsScope(int k) { set_mmq2_tuning(-1, -1, k); set_mmq3_tuning(-1, k); } ~KsScope() { set_mmq2_tuning(-1, -1, 0); set_mmq3_tuning(-1, 0); } } ks_scope(std::max(0, ks));
+        set_mmq3_tuning(prop.multiProcessorCount, -1);
+        { const char *e = getenv("MMQ3_EXP"); set_mmq3_exp(e ? atoi(e) : 0); }
+        const uint8_t *Pp[3] = {nullptr, nullptr, nullptr};
+        if (generation == 3) {
+            if (!mmq3_supported(ggml_type, rows, cols)) return 4;
+            const size_t pb = mmq3_plane_bytes(rows, cols);
+            for (int i = 0; i < n_mat; i++) { keep.emplace_back(new DevBuf(pb)); Pp[i] = (const uint8_t *)keep.back()->p; launch_mmq3_build(W[i], (uint8_t *)keep.back()->p, nullptr); }
+        }
         const int keep_gen = mmq_enabled();
         set_mmq_enabled(std::min(generation, 2));
         const QWeight *Wp[3]; float *Yp[3];
         for (int m = 0; m < n_mat; m++) { Wp[m] = &W[m]; Yp[m] = dy.as<float>() + (size_t)m * out_each; }
         auto run = [&]() {
+            if (generation == 3) { if (!launch_mmq3_set(Wp, Pp, Yp, nullptr, n_mat, A, N, rows, nullptr)) throw HipError{hipErrorInvalidValue, "mmq3 refused the shape", __FILE__, __LINE__}; return; }
             if (generation >= 2 && launch_mmq2_set(Wp, Yp, nullptr, n_mat, A, N, rows, nullptr)) return;
             for (int m = 0; m < n_mat; m++) launch_mul_mat(*Wp[m], A, N, Yp[m], rows, nullptr, nullptr);
         };
