@@ -29,14 +29,21 @@ __device__ __forceinline__ float h2f_u(unsigned h) { return __half2float(__ushor
 __device__ __forceinline__ long pk64(int lo, int hi) { return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo); }
 __device__ __forceinline__ v4i z4() { return v4i{0, 0, 0, 0}; }
 
-// LDS image.  Stage (K = 128 = two k steps): W_LO [8 row tiles][2 k steps][1 KiB fragment], W_HI [8 row tiles][2 k steps][512 B], ACT [NT token tiles][2 k steps][1 KiB].
-// Side data of one super-block (three copies: a super-block is closed one stage late): HDR [128 rows][16 B] {d, dmin, scales12}, BSQ [192 tokens][16 B] digit-split per-32 sums, DK [192 tokens] fp32.
-template <int NT> struct L3 {
-    static constexpr int W_LO = 0, W_HI = 16384, ACT = 24576, STAGE = ACT + NT * 2048, S = 3;
+// LDS image of a workgroup of NW waves (= NW row tiles of 16 weight rows).  Stage (K = 128 = two k steps): W_LO [NW row tiles][2 k steps][1 KiB fragment], W_HI [NW][2][512 B],
+// ACT [NT token tiles][2 k steps][1 KiB]; S stages.  Side data of one super-block (S copies): HDR [16 NW rows][16 B] {d, dmin, scales12}, BSQ [192 tokens][16 B] digit-split
+// per-32 sums, DK [192 tokens] fp32.
+//   NW = 8, S = 3: one workgroup per CU (145 KiB), two stages in flight.
+//   NW = 4, S = 2: TWO workgroups per CU (73 KiB each): the two waves of a SIMD belong to different workgroups and are not phase-locked by each other's barriers, so one's
+//                  super-block epilogue (vector pipe) overlaps the other's MFMAs; one stage in flight per workgroup.
+template <int NT, int NW> struct L3 {
+    static constexpr int S = NW == 8 ? 3 : 2;
+    static constexpr int W_LO = 0, W_HI = NW * 2048, ACT = NW * 3072, STAGE = ACT + NT * 2048;
     static constexpr int SIDE0 = S * STAGE, HDR = 0, BSQ = 2048, DK = 5120, SIDE = 6144;
-    static constexpr int DUMP = SIDE0 + 3 * SIDE, TOTAL = DUMP + 1024;
-    static constexpr int APW = (2 * NT + 7) / 8;                       // activation pieces per wave and stage (the last ones may be dummies: the wait counts stay uniform)
-    static constexpr int N_ODD = 3 + APW, N_EVEN = N_ODD + 1;          // DMA instructions per wave: odd stage; even stage (+ 1 side piece)
+    static constexpr int DUMP = SIDE0 + S * SIDE, TOTAL = DUMP + 1024;
+    static constexpr int APW = (2 * NT + NW - 1) / NW;                 // activation pieces per wave and stage (the last ones may be dummies: the wait counts stay uniform)
+    static constexpr int SPW = 8 / NW;                                 // side pieces per wave and super-block (8 slots: HDR x NW / 4, BSQ x 3, DK x 3, the rest dummies)
+    static constexpr int N_ODD = 3 + APW, N_EVEN = N_ODD + SPW;        // DMA instructions per wave: odd stage; even stage
+    static_assert((size_t)16 * NT * 16 * NW * 4 <= (size_t)S * STAGE, "the result tile is staged through the ring");
 };
 }  // namespace
 
@@ -49,22 +56,22 @@ struct Mmq3Args {
     long long slab_stride;
 };
 
-// Workgroup = 8 waves (two per SIMD: one wave's fp32 / integer bookkeeping overlaps the other's MFMAs, and each hides the other's LDS latency); wave = one row tile of 16
-// weight rows x NT token tiles.
-template <int NT, int EXP = 0>   // EXP: experiment bits (test library): 1 = no super-block epilogue, 2 = no main MFMAs, 4 = no token fragment reloads, 8 = no DMA inside the loop
-__global__ __launch_bounds__(512, 1) void k_mmq3_q45k(const Mmq3Args a, const ActQ A) {
-    using L = L3<NT>;
+// wave = one row tile of 16 weight rows x NT token tiles
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_mmq3_q45k(const Mmq3Args a, const ActQ A) {
+    using L = L3<NT, NW>;
+    constexpr int S = L::S, RW = 16 * NW;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];
     const int lane = threadIdx.x & 63, l15 = lane & 15, kg = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = blockIdx.x / a.groups_each, g = blockIdx.x - m * a.groups_each;
     const QWeight W = a.w[m];
     const int K = W.cols, KS = K / 64, NSB = K / 256, N = a.N;
-    const int r0 = g * 128, t0 = blockIdx.y * a.tiles_per_chunk * 16;
+    const int r0 = g * RW, t0 = blockIdx.y * a.tiles_per_chunk * 16;
     const int sb0 = blockIdx.z * a.sb_per_split, nsb = min(NSB, sb0 + a.sb_per_split) - sb0;
 
     // ---- DMA sources of this lane (stage 2 i + h relative to sb0; everything advances linearly with the stage / super-block index)
-    const size_t rt = (size_t)(g * 8 + wv);
+    const size_t rt = (size_t)(g * NW + wv);
     const uint8_t *s_lo = a.plo[m] + (rt * KS + (size_t)sb0 * 4) * 1024 + lane * 16;
     const uint8_t *s_hi = a.phi[m] + (rt * KS + (size_t)sb0 * 4) * 512 + lane * 16;
     const int8_t *s_act[L::APW]; unsigned d_act[L::APW];
@@ -75,15 +82,22 @@ __global__ __launch_bounds__(512, 1) void k_mmq3_q45k(const Mmq3Args a, const Ac
         s_act[u] = A.q8k + (size_t)tok * K + (size_t)sb0 * 256 + (pp & 1) * 64 + kg * 16;
         d_act[u] = live ? (unsigned)(L::ACT + p * 1024) : 0xFFFFFFFFu;
     }
-    // side piece of this wave: 0, 1: HDR (rows 64 q ..); 2..4: BSQ (tokens 64 (q - 2) ..); 5..7: DK
-    const uint8_t *s_side; unsigned d_side;
-    if (wv < 2) { s_side = W.sc + ((size_t)min(r0 + 64 * wv + lane, W.rows - 1) * NSB + sb0) * 16; d_side = (unsigned)(L::HDR + wv * 1024); }
-    else if (wv < 5) { s_side = reinterpret_cast<const uint8_t *>(A.bsq) + ((size_t)min(t0 + 64 * (wv - 2) + lane, N - 1) * NSB + sb0) * 16; d_side = (unsigned)(L::BSQ + (wv - 2) * 1024); }
-    else { s_side = reinterpret_cast<const uint8_t *>(A.dk) + ((size_t)min(t0 + 64 * (wv - 5) + lane, N - 1) * NSB + sb0) * 4; d_side = (unsigned)(L::DK + (wv - 5) * 256); }
+    // side pieces: slot q = wv * SPW + j of 8.  NW = 8: q 0, 1 HDR (rows 64 q ..), 2..4 BSQ (tokens 64 (q - 2) ..), 5..7 DK.  NW = 4: q 0 HDR, 1..3 BSQ, 4..6 DK, 7 dummy.
+    const uint8_t *s_side[L::SPW]; unsigned d_side[L::SPW]; bool side16[L::SPW];
+#pragma unroll
+    for (int j = 0; j < L::SPW; j++) {
+        const int q = wv * L::SPW + j;
+        constexpr int NH = NW / 4;                                     // HDR pieces
+        if (q < NH) { s_side[j] = W.sc + ((size_t)min(r0 + 64 * q + lane, W.rows - 1) * NSB + sb0) * 16; d_side[j] = (unsigned)(L::HDR + q * 1024); side16[j] = true; }
+        else if (q < NH + 3) { s_side[j] = reinterpret_cast<const uint8_t *>(A.bsq) + ((size_t)min(t0 + 64 * (q - NH) + lane, N - 1) * NSB + sb0) * 16; d_side[j] = (unsigned)(L::BSQ + (q - NH) * 1024); side16[j] = true; }
+        else { const int c = min(q - NH - 3, 2); s_side[j] = reinterpret_cast<const uint8_t *>(A.dk) + ((size_t)min(t0 + 64 * c + lane, N - 1) * NSB + sb0) * 4; d_side[j] = q - NH - 3 < 3 ? (unsigned)(L::DK + c * 256) : 0xFFFFFFFFu; side16[j] = false; }
+    }
 
     auto issue = [&](int i, int h, int slot, int copy) {   // stage 2 i + h of this K range into ring slot `slot`; h == 0 also brings super-block i's side data into side copy `copy`
         unsigned char *st = smem3 + slot * L::STAGE;
-        const size_t so = (size_t)(2 * i + h);
+        int so_ = 2 * i + h;
+        asm volatile("" : "+s"(so_));                    // opaque: otherwise every piece of every call site becomes its own 64-bit induction pointer (20 register pairs, scratch)
+        const size_t so = (size_t)so_;
         unsigned char *dl = st + L::W_LO + wv * 2048;
         __builtin_amdgcn_global_load_lds((glb1_t)(s_lo + so * 2048), (lds3_t)dl, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb1_t)(s_lo + so * 2048), (lds3_t)dl, 16, 1024, 0);
@@ -94,9 +108,12 @@ __global__ __launch_bounds__(512, 1) void k_mmq3_q45k(const Mmq3Args a, const Ac
             __builtin_amdgcn_global_load_lds((glb1_t)(s_act[u] + so * 128), (lds3_t)d, 16, 0, 0);
         }
         if (h == 0) {
-            unsigned char *sd = smem3 + L::SIDE0 + copy * L::SIDE + d_side;
-            if (wv < 5) __builtin_amdgcn_global_load_lds((glb1_t)(s_side + (size_t)i * 16), (lds3_t)sd, 16, 0, 0);
-            else __builtin_amdgcn_global_load_lds((glb1_t)(s_side + (size_t)i * 4), (lds3_t)sd, 4, 0, 0);
+#pragma unroll
+            for (int j = 0; j < L::SPW; j++) {
+                unsigned char *sd = d_side[j] == 0xFFFFFFFFu ? smem3 + L::DUMP : smem3 + L::SIDE0 + copy * L::SIDE + d_side[j];
+                if (side16[j]) __builtin_amdgcn_global_load_lds((glb1_t)(s_side[j] + (size_t)i * 16), (lds3_t)sd, 16, 0, 0);
+                else __builtin_amdgcn_global_load_lds((glb1_t)(s_side[j] + (size_t)i * 4), (lds3_t)sd, 4, 0, 0);
+            }
         }
     };
 
@@ -105,10 +122,10 @@ __global__ __launch_bounds__(512, 1) void k_mmq3_q45k(const Mmq3Args a, const Ac
 #pragma unroll
     for (int tt = 0; tt < NT; tt++) { acc[tt] = v4f{0.f, 0.f, 0.f, 0.f}; alo[tt] = z4(); ahi[tt] = z4(); }
 
-    // One k step (K = 64) of a stage = one batch: the weight tile's lo / packed hi fragment + NT token fragments.  The two waves of a SIMD are phase-locked by the stage
-    // barriers and cannot cover each other's LDS latency, so the loop is software-pipelined by one batch INSIDE a wave: while batch b's MFMAs issue, the token fragment a tile
-    // has just consumed is reloaded (same registers) from batch b + 1, and batch b + 1's weight fragments are requested at the top of batch b -- also across a stage barrier
-    // (a wave arrives at the barrier that publishes stage s + 1 with batch (s, 1) in registers, and reloads from stage s + 1 while it multiplies that batch).
+    // One k step (K = 64) of a stage = one batch: the weight tile's lo / packed hi fragment + NT token fragments.  The loop is software-pipelined by one batch inside a wave:
+    // while batch b's MFMAs issue, the token fragment a tile has just consumed is reloaded (same registers) from batch b + 1, and batch b + 1's weight fragments are requested
+    // at the top of batch b -- also across a stage barrier (a wave arrives at the barrier that publishes stage s + 1 with batch (s, 1) in registers, and reloads from stage
+    // s + 1 while it multiplies that batch).
     struct WB { v4i blo; v2i hp; };
     v4i X[NT];
     auto rdw = [&](const unsigned char *st, int ks, WB &w) {
@@ -120,12 +137,9 @@ __global__ __launch_bounds__(512, 1) void k_mmq3_q45k(const Mmq3Args a, const Ac
         const v4i bhi = v4i{w.hp[0] & 0x0F0F0F0F, w.hp[1] & 0x0F0F0F0F, (w.hp[0] >> 4) & 0x0F0F0F0F, (w.hp[1] >> 4) & 0x0F0F0F0F};
 #pragma unroll
         for (int tt = 0; tt < NT; tt++) {
-            if (!(EXP & 2)) {
-                alo[tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X[tt], w.blo, zero ? z4() : alo[tt], 0, 0, 0);
-                ahi[tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X[tt], bhi, zero ? z4() : ahi[tt], 0, 0, 0);
-                if (EXP & 1) asm volatile("" : "+v"(alo[tt]), "+v"(ahi[tt]));
-            } else asm volatile("" :: "v"(X[tt]), "v"(w.blo), "v"(bhi));
-            if (reload && !(EXP & 4)) X[tt] = *reinterpret_cast<const v4i *>(nst + L::ACT + (tt * 2 + nks) * 1024 + lane * 16);
+            alo[tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X[tt], w.blo, zero ? z4() : alo[tt], 0, 0, 0);
+            ahi[tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X[tt], bhi, zero ? z4() : ahi[tt], 0, 0, 0);
+            if (reload) X[tt] = *reinterpret_cast<const v4i *>(nst + L::ACT + (tt * 2 + nks) * 1024 + lane * 16);
         }
     };
     // end of a super-block: min term on the matrix cores (K = 8 sub-blocks, digit split of the per-32 sums), then the two fp32 updates of mmq2 in mmq2's order
@@ -151,63 +165,71 @@ __global__ __launch_bounds__(512, 1) void k_mmq3_q45k(const Mmq3Args a, const Ac
         }
     };
 
+    // Ring: stage s lives in slot s % S; the barrier that publishes stage s (everybody's pieces landed, everybody's LDS reads of stage s - 1 done) is followed by the request
+    // for stage s + S - 1 into the slot stage s - 1 has just left.  Super-block i's side data travels with stage 2 i into side copy i % S and is used one stage late.
     WB w0, w1;
-    if (!(EXP & 32)) { issue(0, 0, 0, 0); issue(0, 1, 1, 0); }
-    int slot = 0, copy = 0;                                 // ring slot of stage 2 i; side copy of super-block i (i % 3)
+    issue(0, 0, 0, 0);
+    if (S == 3) issue(0, 1, 1, 0);
+    int slot = 0, copy = 0;                                 // ring slot of stage 2 i; side copy of super-block i
+#pragma clang loop unroll(disable)
     for (int i = 0; i < nsb; i++) {
-        const int s1 = slot == 2 ? 0 : slot + 1, s2 = s1 == 2 ? 0 : s1 + 1, inext = min(i + 1, nsb - 1);
-        const int c1 = copy == 2 ? 0 : copy + 1, cprev = copy == 0 ? 2 : copy - 1;
+        asm volatile("" : "+s"(slot));                  // S == 2: keeps the slot a run-time scalar -- as constants hipcc hoists every fragment address into its own register (492 B of scratch)
+        const int s1 = slot + 1 == S ? 0 : slot + 1, s2 = s1 + 1 == S ? 0 : s1 + 1, inext = min(i + 1, nsb - 1);
+        const int c1 = copy + 1 == S ? 0 : copy + 1, cprev = copy == 0 ? S - 1 : copy - 1;
         const unsigned char *se = smem3 + slot * L::STAGE, *so = smem3 + s1 * L::STAGE;
         // ---- stage 2 i published
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(L::N_ODD) : "memory");   // own pieces of stage 2 i (+ super-block i's side data) landed; own LDS reads of stage 2 i - 1 done
-        __builtin_amdgcn_s_barrier();                                                   // everybody's; slot s2 (stage 2 i - 1) and side copy c1 (super-block i - 2) are free
+        if (S == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(L::N_ODD) : "memory");   // own pieces of stage 2 i (+ side data) landed (stage 2 i + 1 may be in flight); own LDS reads of stage 2 i - 1 done
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (!(EXP & 8)) issue(inext, 0, s2, c1);                                                        // stage 2 i + 2 (past the end: the last even stage again, into the free slot / copy)
+        if (S == 3) issue(inext, 0, s2, c1);                                            // stage 2 i + 2 (past the end: the last even stage again, into the free slot / copy)
+        else issue(i, 1, s1, 0);                                                        // stage 2 i + 1
         if (i > 0) {
-            mm(w1, false, true, se, 0, w0);                                                  // batch (2 i - 1, 1) closes super-block i - 1
-            if (!(EXP & 1)) finish(smem3 + L::SIDE0 + cprev * L::SIDE);
+            mm(w1, false, true, se, 0, w0);                                             // batch (2 i - 1, 1) closes super-block i - 1
+            finish(smem3 + L::SIDE0 + cprev * L::SIDE);
         } else {
             rdw(se, 0, w0);
 #pragma unroll
             for (int tt = 0; tt < NT; tt++) X[tt] = *reinterpret_cast<const v4i *>(se + L::ACT + (tt * 2) * 1024 + lane * 16);
         }
         __builtin_amdgcn_sched_barrier(0);
-        mm(w0, true, true, se, 1, w1);                                                       // batch (2 i, 0)
+        mm(w0, true, true, se, 1, w1);                                                  // batch (2 i, 0)
         __builtin_amdgcn_sched_barrier(0);
         // ---- stage 2 i + 1 published
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(L::N_EVEN) : "memory");
+        if (S == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(L::N_EVEN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (!(EXP & 8)) issue(inext, 1, slot, 0);                                                       // stage 2 i + 3 -> the slot stage 2 i just left
-        mm(w1, false, true, so, 0, w0);                                                      // batch (2 i, 1)
+        if (S == 3) issue(inext, 1, slot, 0);                                           // stage 2 i + 3 -> the slot stage 2 i just left
+        else issue(inext, 0, slot, c1);                                                 // stage 2 i + 2 (+ the next super-block's side data)
+        mm(w1, false, true, so, 0, w0);                                                 // batch (2 i, 1)
         __builtin_amdgcn_sched_barrier(0);
-        mm(w0, false, true, so, 1, w1);                                                      // batch (2 i + 1, 0)
+        mm(w0, false, true, so, 1, w1);                                                 // batch (2 i + 1, 0)
         __builtin_amdgcn_sched_barrier(0);
-        slot = s2; copy = c1;
+        slot = S == 3 ? s2 : slot; copy = c1;
     }
-    mm(w1, false, false, smem3, 0, w0);                                                // batch (2 nsb - 1, 1)
-    if (!(EXP & 1)) finish(smem3 + L::SIDE0 + (copy == 0 ? 2 : copy - 1) * L::SIDE);
+    mm(w1, false, false, smem3, 0, w0);                                                 // batch (2 nsb - 1, 1)
+    finish(smem3 + L::SIDE0 + (copy == 0 ? S - 1 : copy - 1) * L::SIDE);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    // the trailing dummy pieces
 
-    // ---- results: through LDS (the ring is free now), so that a token's 128 outputs leave as one 512-byte run instead of eight 64-byte pieces from eight waves
-    // (the direct store took 4.5 - 8.7 us of a 142-row launch: ~2 TB/s)
+    // ---- results: through LDS (the ring is free now), so that a token's RW outputs leave as one run instead of 64-byte pieces from NW waves
     __builtin_amdgcn_s_barrier();
-    float *T = reinterpret_cast<float *>(smem3);                                        // [16 NT tokens][128 rows]
+    float *T = reinterpret_cast<float *>(smem3);                                        // [16 NT tokens][RW rows]
 #pragma unroll
     for (int tt = 0; tt < NT; tt++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) T[(tt * 16 + 4 * kg + e) * 128 + wv * 16 + l15] = acc[tt][e];
+        for (int e = 0; e < 4; e++) T[(tt * 16 + 4 * kg + e) * RW + wv * 16 + l15] = acc[tt][e];
     __syncthreads();
     float *y = a.y[m] + (size_t)blockIdx.z * a.slab_stride;
     const float *res = (gridDim.z == 1) ? a.res[m] : nullptr;
-    const int c4 = threadIdx.x & 31, tr = threadIdx.x >> 5, row = r0 + 4 * c4;
+    constexpr int C4 = RW / 4, TR = 64 * NW / C4;                                       // float4 columns of a token's run; tokens per sweep of the workgroup (16)
+    const int c4 = threadIdx.x % C4, tr = threadIdx.x / C4, row = r0 + 4 * c4;
     const bool vec = (a.ldy & 3) == 0 && (W.rows & 3) == 0;
-    if (!(EXP & 16))
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-        const int tl = j * 16 + tr, tok = t0 + tl;
-        if (j < a.tiles_per_chunk && tok < N && row < W.rows) {
-            v4f v = *reinterpret_cast<const v4f *>(T + tl * 128 + 4 * c4);
+    for (int j = 0; j < 16 * NT / TR; j++) {
+        const int tl = j * TR + tr, tok = t0 + tl;
+        if (tl < 16 * a.tiles_per_chunk && tok < N && row < W.rows) {
+            v4f v = *reinterpret_cast<const v4f *>(T + tl * RW + 4 * c4);
             const size_t o = (size_t)tok * a.ldy + row;
             if (vec) {
                 if (res) { const v4f r = *reinterpret_cast<const v4f *>(res + o); v += r; }
@@ -273,15 +295,25 @@ void launch_mmq3_build(const QWeight &W, uint8_t *planes, hipStream_t s) {
     else hipLaunchKernelGGL(k_mmq3_build<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, planes, planes + hi_off);
 }
 
-static int g_mmq3_cus = 256, g_mmq3_ks = 0, g_mmq3_exp = 0;
-void set_mmq3_exp(int e) { g_mmq3_exp = e; }
+static int g_mmq3_cus = 256, g_mmq3_ks = 0, g_mmq3_nw = 4;
 void set_mmq3_tuning(int cus, int ks) { if (cus > 0) g_mmq3_cus = cus; if (ks >= 0) g_mmq3_ks = ks; }
+void set_mmq3_waves(int nw) { g_mmq3_nw = nw == 8 ? 8 : 4; }
 
-template <int NT, int EXP = 0>
+template <int NT, int NW>
 static void mmq3_launch_nt(dim3 grid, hipStream_t s, const Mmq3Args &a, const ActQ &A) {
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mmq3_q45k<NT, EXP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL((k_mmq3_q45k<NT, EXP>), grid, dim3(512), (size_t)L3<NT>::TOTAL, s, a, A);
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mmq3_q45k<NT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL((k_mmq3_q45k<NT, NW>), grid, dim3(64 * NW), (size_t)(L3<NT, NW>::TOTAL), s, a, A);
+}
+template <int NW>
+static void mmq3_launch(int tiles, dim3 grid, hipStream_t s, const Mmq3Args &a, const ActQ &A) {
+    switch (tiles) {
+    case 1: case 2: mmq3_launch_nt<2, NW>(grid, s, a, A); break;
+    case 3: case 4: mmq3_launch_nt<4, NW>(grid, s, a, A); break;
+    case 5: case 6: mmq3_launch_nt<6, NW>(grid, s, a, A); break;
+    case 7: case 8: mmq3_launch_nt<8, NW>(grid, s, a, A); break;
+    default: mmq3_launch_nt<9, NW>(grid, s, a, A); break;
+    }
 }
 
 // 1..3 same-type, same-shape Q4_K / Q5_K matrices with planes (planes[i]: launch_mmq3_build's output) against the N prepared rows in one launch.  Same contract as
@@ -295,11 +327,12 @@ bool launch_mmq3_set(const QWeight *const *W, const uint8_t *const *planes, floa
     for (int i = 0; i < n; i++) { a.w[i] = *W[i]; a.plo[i] = planes[i]; a.phi[i] = planes[i] + hi_off; a.y[i] = y[i]; a.res[i] = residual ? residual[i] : nullptr; }
     const int tiles = (N + 15) / 16, n_chunks = (tiles + 8) / 9;
     a.tiles_per_chunk = (tiles + n_chunks - 1) / n_chunks;
-    a.n_mat = n; a.groups_each = (W[0]->rows + 127) / 128; a.N = N; a.ldy = ldy;
+    const int nw = g_mmq3_nw, rw = 16 * nw, slots = g_mmq3_cus * (nw == 8 ? 1 : 2);   // workgroups the chip holds at once
+    a.n_mat = n; a.groups_each = (W[0]->rows + rw - 1) / rw; a.N = N; a.ldy = ldy;
     const int NSB = W[0]->cols / 256, wgs = n * a.groups_each * n_chunks;
     const size_t out_floats = (size_t)N * ldy;
-    // K split: one workgroup per CU is all the LDS admits, so split until the launch just fills the chip; at least 4 super-blocks (8 stages) per slice
-    int ks = std::max(1, g_mmq3_cus / wgs);
+    // K split: split until the launch just fills the chip; at least 4 super-blocks (8 stages) per slice
+    int ks = std::max(1, slots / wgs);
     while (ks > 1 && (NSB / ks < 4 || !A.ws || (size_t)ks * out_floats * n > A.ws_floats)) ks--;
     if (g_mmq3_ks > 0) ks = std::max(1, std::min(g_mmq3_ks, std::min(NSB, A.ws ? (int)(A.ws_floats / std::max<size_t>(1, out_floats * n)) : 1)));
     a.sb_per_split = (NSB + ks - 1) / ks;
@@ -310,26 +343,7 @@ bool launch_mmq3_set(const QWeight *const *W, const uint8_t *const *planes, floa
         for (int i = 0; i < n; i++) { a.y[i] = A.ws + (size_t)i * ks * out_floats; a.res[i] = nullptr; }
     }
     const dim3 grid((unsigned)(n * a.groups_each), (unsigned)n_chunks, (unsigned)ks);
-    switch (a.tiles_per_chunk) {
-    case 1: case 2: mmq3_launch_nt<2>(grid, s, a, A); break;
-    case 3: case 4: mmq3_launch_nt<4>(grid, s, a, A); break;
-    case 5: case 6: mmq3_launch_nt<6>(grid, s, a, A); break;
-    case 7: case 8: mmq3_launch_nt<8>(grid, s, a, A); break;
-    default:
-        switch (g_mmq3_exp) {
-        case 1: mmq3_launch_nt<9, 1>(grid, s, a, A); break;
-        case 2: mmq3_launch_nt<9, 2>(grid, s, a, A); break;
-        case 3: mmq3_launch_nt<9, 3>(grid, s, a, A); break;
-        case 6: mmq3_launch_nt<9, 6>(grid, s, a, A); break;
-        case 7: mmq3_launch_nt<9, 7>(grid, s, a, A); break;
-        case 8: mmq3_launch_nt<9, 8>(grid, s, a, A); break;
-        case 15: mmq3_launch_nt<9, 15>(grid, s, a, A); break;
-        case 31: mmq3_launch_nt<9, 31>(grid, s, a, A); break;
-        case 63: mmq3_launch_nt<9, 63>(grid, s, a, A); break;
-        default: mmq3_launch_nt<9>(grid, s, a, A); break;
-        }
-        break;
-    }
+    if (nw == 8) mmq3_launch<8>(a.tiles_per_chunk, grid, s, a, A); else mmq3_launch<4>(a.tiles_per_chunk, grid, s, a, A);
     if (ks > 1) {
         SlabSrc src; src.ws = A.ws; src.ks = ks; src.stride = (long long)out_floats; src.n = n;
         for (int i = 0; i < n; i++) { src.y[i] = y[i]; src.res[i] = residual ? residual[i] : nullptr; src.mbase[i] = A.ws + (size_t)i * ks * out_floats; src.mks[i] = ks; }
