@@ -61,7 +61,6 @@ struct QWeight {
     const uint8_t *sc = nullptr;     // scale plane: Q4_0/Q5_0/Q8_0: f16 d per block; Q4_1/Q5_1: {d,m}; Q4_K/Q5_K: 16 B {d,dmin,scales12} per
                                      //   super-block; Q6_K: 2 int8 per unit
     const uint8_t *d = nullptr;      // Q6_K: f16 d per super-block
-    const uint8_t *pp = nullptr;     // (optional, Q4_K / Q5_K) prompt planes: scale x quant as 128 hi + lo in MFMA-fragment order (mmq3_kernels.hip); derived data, not part of `bytes`
     size_t bytes = 0;                // HBM bytes of all planes (== file bytes of the tensor)
 };
 

@@ -85,7 +85,6 @@ Engine::~Engine() {
     if (stream_) HIP_IGNORE(hipStreamSynchronize(stream_));
     for (auto &e : site_events_) { HIP_IGNORE(hipEventDestroy(e.a)); HIP_IGNORE(hipEventDestroy(e.b)); }
     if (stage_) HIP_IGNORE(hipFree(stage_));
-    if (pp_arena_) HIP_IGNORE(hipFree(pp_arena_));
     release_buffers();
     if (stream_) HIP_IGNORE(hipStreamDestroy(stream_));
 }
@@ -124,7 +123,6 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     sampler_.seed(seed);
     if (const char *tf = getenv("MINIGPT4_PARITY_TRACE")) { if (*tf) trace_file_ = fopen(tf, "wb"); }
     parity_ = trace_file_ || (getenv("MINIGPT4_PARITY") && atoi(getenv("MINIGPT4_PARITY")));   // oracle-order fp32 accumulation (forward_ref): bit-identical to the CPU oracle, slow
-    if (const char *e = getenv("MINIGPT4_PROMPT_PLANES")) prompt_planes_ = atoi(e) != 0;   // 0: no load-time digit planes (prompt passes of <= 144 rows stay on the unpacking kernels; saves 1.5 B per k-quant weight of HBM)
     if (const char *lm = getenv("MINIGPT4_LOAD")) load_mode_ = !strcmp(lm, "recv") ? LOAD_RECV : LOAD_FULL;
     // native multi-GPU load (dist.hpp): MINIGPT4_WORLD_SIZE / MINIGPT4_RANK / MINIGPT4_NCCL_ID_FILE -> rank 0 reads the files, every other rank loads headers only and
     // receives both weight arenas by ncclBroadcast inside this call
@@ -140,7 +138,6 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     alloc_buffers();
     if (stage_) { HIP_IGNORE(hipFree(stage_)); stage_ = nullptr; stage_cap_ = 0; }
     if (dist.active()) { if (int e = native_broadcast(dist.world, dist.rank, dist.id_file, dist.timeout_s)) return e; }
-    if (load_mode_ == LOAD_FULL) build_prompt_planes();      // LOAD_RECV without the native broadcast: weights_received() builds them
     return E_None;
 }
 
@@ -189,26 +186,7 @@ int Engine::weights_received() {
     load_mode_ = LOAD_FULL;
     const size_t NQ = (size_t)v_nq_;
     for (size_t b = 0; b < (size_t)VISION_BATCH_MAX; b++) HIP_CHECK(hipMemcpy(vi_qtok_rep_ + b * NQ * 768, v_qtok_, NQ * 768 * 4, hipMemcpyDeviceToDevice));
-    build_prompt_planes();
     return 0;
-}
-// Prompt planes (mmq3_kernels.hip) of every Q4_K / Q5_K layer matrix: derived from the repacked weights on the device, once per load, in their own allocation (they
-// are not part of the arenas: a receiving rank rebuilds them from what was broadcast).  Skipped -- prompt passes then stay on the unpacking kernels -- when HBM is short.
-void Engine::build_prompt_planes() {
-    if (!prompt_planes_ || pp_arena_ || layers_.empty()) return;
-    std::vector<QWeight *> ws;
-    size_t total = 0;
-    for (auto &L : layers_) for (QWeight *w : {&L.wq, &L.wk, &L.wv, &L.wo, &L.w1, &L.w2, &L.w3}) if (mmq3_supported(w->type, w->rows, w->cols)) { ws.push_back(w); total += (mmq3_plane_bytes(w->rows, w->cols) + 1023) & ~(size_t)1023; }
-    if (ws.empty()) return;
-    size_t free_b = 0, total_b = 0;
-    HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    if (free_b < total + ((size_t)8 << 30)) { MG4_INFO("prompt planes skipped: %.1f GB needed, %.1f GB of HBM free", total / 1e9, free_b / 1e9); return; }
-    HIP_CHECK(hipMalloc((void **)&pp_arena_, total));
-    pp_bytes_ = total;
-    size_t off = 0;
-    for (QWeight *w : ws) { launch_mmq3_build(*w, pp_arena_ + off, stream_); w->pp = pp_arena_ + off; off += (mmq3_plane_bytes(w->rows, w->cols) + 1023) & ~(size_t)1023; }
-    HIP_CHECK(hipStreamSynchronize(stream_));
-    MG4_INFO("prompt planes: %zu matrices, %.2f GB", ws.size(), total / 1e9);
 }
 // Host only: the arena layout (sizes + layout hashes) the two files produce, without a device: what a receiving rank must reproduce (tests/test_cpu_dist.py).
 int Engine::plan_arenas(const std::string &vision_path, const std::string &llm_path, ArenaPlan &out) {
@@ -535,7 +513,6 @@ void Engine::alloc_buffers() {
         hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, device_));
         act_.ws = reinterpret_cast<float *>(buf_arena_.take(slab_floats * 4)); act_.ws_floats = slab_floats;
         set_mmq2_cus(prop.multiProcessorCount);
-        set_mmq3_tuning(prop.multiProcessorCount, -1);
     }
     HIP_CHECK(hipMemset(d_npast_, 0, 256)); HIP_CHECK(hipMemset(d_argmax_, 0, 256)); HIP_CHECK(hipMemset(d_feed_, 0, 256)); HIP_CHECK(hipMemset(d_btok_, 0, 768));
     HIP_CHECK(hipMemset(d_tokens_, 0, B * 4));
@@ -617,12 +594,7 @@ bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
     for (int i = 0; i < n; i++) wbytes += (double)W[i]->bytes;
     SiteScope sc(this, site, wbytes, s);
     bool done = false;
-    if (N >= 17 && N <= 144 && same && W[0]->pp && mmq_enabled() >= 2) {   // a prompt of <= 144 rows: every row in one pass over the load-time digit planes (mmq3: -17 % per launch at 64 / 142 rows)
-        const uint8_t *P[3] = {nullptr, nullptr, nullptr}; bool all = true;
-        for (int i = 0; i < n; i++) { P[i] = W[i]->pp; all = all && P[i]; }
-        if (all) done = launch_mmq3_set(W, P, y, res, n, act_here, N, ldy, s, defer_ok && defer_combine_ ? &pend_ : nullptr);
-    }
-    if (!done && N >= 5 && same && mmq_enabled() >= 2) done = launch_mmq2_set(W, y, res, n, act_here, N, ldy, s, defer_ok && defer_combine_ ? &pend_ : nullptr);   // prefill: one launch for the set, weights streamed once per <= 128 rows
+    if (N >= 5 && same && mmq_enabled() >= 2) done = launch_mmq2_set(W, y, res, n, act_here, N, ldy, s, defer_ok && defer_combine_ ? &pend_ : nullptr);   // prefill: one launch for the set, weights streamed once per <= 128 rows
     const bool staged_elsewhere = !prep && (xh_override_ != nullptr || (same && W[0]->type == GT_F16 && N >= 512));   // the rows were left in fp16 by an earlier launch, act_ holds OTHER rows
     if (!done && same && W[0]->type == GT_F16 && N >= 512 && act_.xh) {   // unquantised weights at prompt sizes: the set in one launch of the big MFMA GEMM, split K for wo / w2
         const __half *Wh[3]; for (int i = 0; i < n; i++) Wh[i] = reinterpret_cast<const __half *>(W[i]->qs);

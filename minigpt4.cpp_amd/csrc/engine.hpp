@@ -152,8 +152,6 @@ private:
     uint8_t *tok_raw_ = nullptr; int tok_type_ = -1;
     DeviceArena llm_arena_, vis_arena_, buf_arena_;
     uint8_t *stage_ = nullptr; size_t stage_cap_ = 0;
-    uint8_t *pp_arena_ = nullptr; size_t pp_bytes_ = 0; bool prompt_planes_ = true;   // derived prompt planes of the Q4_K / Q5_K layer matrices (build_prompt_planes)
-    void build_prompt_planes();
     size_t wbytes_token_ = 0;
     __half *kc_ = nullptr, *vc_ = nullptr;
     float *cos_ = nullptr, *sin_ = nullptr;

@@ -47,12 +47,12 @@ void launch_rope_kv_slabs(const SlabSrc &src, int N, int n_head, int hd, const i
 // defer != nullptr: with a K split the combine launch is skipped and *defer describes the slabs (ks > 1); otherwise *defer is cleared
 bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s, SlabSrc *defer = nullptr);
 void set_mmq2_cus(int cus);
-// prompt mat-mul on load-time digit planes (mmq3_kernels.hip): Q4_K / Q5_K, sub-block scale x quant stored as 128 hi + lo (1.5 B per weight) in MFMA-fragment order
+// (test library only: measured in round 4, not adopted) prompt mat-mul on load-time digit planes (mmq3_kernels.hip): Q4_K / Q5_K, sub-block scale x quant stored as 128 hi + lo (1.5 B per weight) in MFMA-fragment order
 bool mmq3_supported(int type, int rows, int cols);
 size_t mmq3_plane_bytes(int rows, int cols, size_t *hi_off = nullptr);
 void launch_mmq3_build(const QWeight &W, uint8_t *planes, hipStream_t s);
 bool launch_mmq3_set(const QWeight *const *W, const uint8_t *const *planes, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s, SlabSrc *defer = nullptr);
-void set_mmq3_waves(int nw);                          // 4 (default): 64-row workgroups, two per CU; 8: 128-row workgroups, one per CU
+void set_mmq3_waves(int nw);                          // 8 (default): 128-row workgroups, one per CU; 4: 64-row workgroups, two per CU (slower)
 void set_mmq3_tuning(int cus, int ks);                // CU count (<= 0: leave), forced K split (0 = the launcher's choice, < 0: leave)
 void set_mmq2_tuning(int tt, int fill_pct, int ks);   // experiment knobs, 0 = the launcher's choice, < 0 = leave as it is (read from the environment once, by Engine::init)
 void set_gemm_tuning(int big_min_m, int f16_ks, int arm = -1, int sk_arm = -1);      // smallest M of the 128x128 GEMM (< 0: leave), forced K split of the F16 set launches (0 = choose)

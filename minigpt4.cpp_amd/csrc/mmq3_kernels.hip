@@ -1,3 +1,5 @@
+// TEST LIBRARY ONLY -- measured in round 4 and NOT adopted: in the engine it is at parity with k_mmq2_q45k (142-row image turn 10.94 -> 10.82 ms) for 1.5 bytes of HBM per weight
+// (profiles/r04_prefill_digit_planes.log has every version, the leave-one-out timings and what bounds it: instruction issue, ~620 per wave and super-block).
 // Prompt mat-mul on pre-scaled digit planes (round 4): y[t][r] = W[r] . act[t] for Q4_K / Q5_K weights at prompt sizes, the arithmetic of mmq2_kernels.hip
 // (reference minigpt4.cpp:2373 / 2412 -> llama_eval -> ggml_mul_mat: Q8_K activations, exact int32 sums, fp32 super-block scales accumulated super-block by super-block),
 // bit-identical to k_mmq2_q45k for the same K split.
@@ -295,9 +297,9 @@ void launch_mmq3_build(const QWeight &W, uint8_t *planes, hipStream_t s) {
     else hipLaunchKernelGGL(k_mmq3_build<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, planes, planes + hi_off);
 }
 
-static int g_mmq3_cus = 256, g_mmq3_ks = 0, g_mmq3_nw = 4;
+static int g_mmq3_cus = 256, g_mmq3_ks = 0, g_mmq3_nw = 8;
 void set_mmq3_tuning(int cus, int ks) { if (cus > 0) g_mmq3_cus = cus; if (ks >= 0) g_mmq3_ks = ks; }
-void set_mmq3_waves(int nw) { g_mmq3_nw = nw == 8 ? 8 : 4; }
+void set_mmq3_waves(int nw) { g_mmq3_nw = nw == 4 ? 4 : 8; }
 
 template <int NT, int NW>
 static void mmq3_launch_nt(dim3 grid, hipStream_t s, const Mmq3Args &a, const ActQ &A) {

@@ -461,7 +461,7 @@ int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, 
         set_mmq2_cus(prop.multiProcessorCount);
         struct KsScope { KsScope(int k) { set_mmq2_tuning(-1, -1, k); set_mmq3_tuning(-1, k); } ~KsScope() { set_mmq2_tuning(-1, -1, 0); set_mmq3_tuning(-1, 0); } } ks_scope(std::max(0, ks));
         set_mmq3_tuning(prop.multiProcessorCount, -1);
-        { const char *e = getenv("MMQ3_NW"); set_mmq3_waves(e ? atoi(e) : 4); }
+        { const char *e = getenv("MMQ3_NW"); set_mmq3_waves(e ? atoi(e) : 8); }
         const uint8_t *Pp[3] = {nullptr, nullptr, nullptr};
         if (generation == 3) {
             if (!mmq3_supported(ggml_type, rows, cols)) return 4;
