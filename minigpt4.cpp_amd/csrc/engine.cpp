@@ -692,8 +692,8 @@ void Engine::forward_ref(int N, bool from_tokens, hipStream_t s, bool feed) {
         launch_rms_quant(x_, L.attn_norm, N, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s, true);
         ref_set({&L.wq, &L.wk, &L.wv}, {q_, k_, v_}, nullptr);
         tr("q", (int)il, q_, (size_t)N * E); tr("k", (int)il, k_, (size_t)N * E); tr("v", (int)il, v_, (size_t)N * E);
-        launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s);
-        launch_attn_ref(q_, kc, vc, N, H, hd, d_npast, t_max, tabs_, att_, s);
+        if (N == 1 && !trace_file_) launch_attn_ref_fused(q_, k_, v_, kc, vc, H, hd, d_npast, t_max, cos_, sin_, tabs_, att_, s);   // decode: RoPE + cache append inside the attention launch
+        else { launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); launch_attn_ref(q_, kc, vc, N, H, hd, d_npast, t_max, tabs_, att_, s); }
         tr("q_rope", (int)il, q_, (size_t)N * E); tr("att", (int)il, att_, (size_t)N * E);
         launch_silu_mul_quant(att_, nullptr, N, E, act_, act_mask_for(L.wo.type), tabs_, s);
         ref_set({&L.wo}, {x_}, x_);

@@ -124,6 +124,8 @@ void launch_batch_begin(int *n_past, const int *row_slot, const int *row_pos, in
 bool launch_attn_prefill(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s, __half *out_h = nullptr, bool *wrote_h = nullptr);
 // MINIGPT4_PARITY=1: scores / softmax / P.V with every fp32 chain in the oracle's order (after launch_rope_kv); t_max >= *n_past + N
 void launch_attn_ref(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s);
+void launch_attn_ref_fused(const float *q, const float *k, const float *v, __half *kcache, __half *vcache, int n_head, int hd, const int *n_past, int t_max, const float *cos_tab, const float *sin_tab,
+                           const Tables &tb, float *out, hipStream_t s);   // one query row: RoPE + cache append inside
 void set_attn_prefill_f16(int v);
 void set_attn_prefill_w8(int v);    // 8-wave loader / MFMA form of the fp16 prompt attention (MINIGPT4_ATTN_PREFILL_W8)   // 1 (default): prompt attention on the fp16 matrix cores, 0: the exact-f32 MFMA kernel
 bool attn_head_size_supported(int hd);

@@ -305,9 +305,27 @@ __global__ __launch_bounds__(256) void k_mul_mat_ref_row(const RefSet S, const A
             if (X::GROUP >= 8) { i0 += dpp_i<0x141>(i0); i1 += dpp_i<0x141>(i1); }
             static_assert(X::GROUP <= 8, "one DPP row half per ggml block");
             float f0, v0, f1, v1; X::terms(Rw.w[i], a[i], i0, i1, f0, v0, f1, v1);
-            for (int g = 0; g < n_here; g += X::GROUP) {   // g is wave-uniform: v_readlane (the generic __shfl is an LDS permute, ~100 dependent cycles per block term)
-                acc = fmaf(readlane_f(f0, g), readlane_f(v0, g), acc);
-                if (X::TERMS == 2) acc = fmaf(readlane_f(f1, g), readlane_f(v1, g), acc);
+            if constexpr (X::GROUP == 8) {
+                // k-quants: the chain walks the 8-lane groups of this register in place.  At step g every lane takes the running value of the lane 8 below it (row_shr:8:
+                // the lower half of its 16-lane row) or, where a row begins, of the previous row's last lane (row_bcast:15), and adds ITS block's terms: after step g the
+                // lanes of group g hold the oracle's running sum, the other lanes hold values nobody reads.  3 instructions per block instead of 4 v_readlane + 2 fma.
+                const int ng = n_here / 8;
+                float run = acc;                   // wave-uniform value carried in from the previous register
+#pragma unroll
+                for (int g = 0; g < 8; g++) {
+                    if (g < ng) {
+                        float t = g == 0 ? acc : ((g & 1) ? dpp_f<0x118>(run) : dpp_f<0x142>(run));
+                        t = fmaf(f0, v0, t);
+                        if (X::TERMS == 2) t = fmaf(f1, v1, t);
+                        run = t;
+                    }
+                }
+                acc = readlane_f(run, 8 * (ng - 1));
+            } else {
+                for (int g = 0; g < n_here; g += X::GROUP) {   // g is wave-uniform: v_readlane (the generic __shfl is an LDS permute, ~100 dependent cycles per block term)
+                    acc = fmaf(readlane_f(f0, g), readlane_f(v0, g), acc);
+                    if (X::TERMS == 2) acc = fmaf(readlane_f(f1, g), readlane_f(v1, g), acc);
+                }
             }
         }
         if (lane == 0) { const float *r = S.res[m]; S.y[m][row] = r ? acc + r[row] : acc; }
@@ -2378,21 +2396,44 @@ void launch_attn_llm(float *q, const float *k, const float *v, __half *kcache, _
 // chain in ITS order: thread = one key for the scores (sequential fma over the head dimension), exact double sum for the softmax, thread = one output
 // dimension for P.V (sequential fma over the keys).  After launch_rope_kv (q rotated in place, caches appended).  One workgroup per (head, query row).
 // =====================================================================================================================
-__global__ __launch_bounds__(256) void k_attn_ref(const float *__restrict__ q, const __half *__restrict__ kc, const __half *__restrict__ vc, int E, int hd, const int *__restrict__ n_past,
-                                                  const Tables tb, float *__restrict__ out) {
+// FUSED (one query row, decode): q | k | v are the raw projections; RoPE and the cache append (k_rope_kv's arithmetic) happen here, the new key / value row is also kept in LDS
+// (the cache line written by this workgroup is not read back).  P.V: the value rows travel through LDS in chunks of 128 keys (16-byte coalesced loads, the next chunk in
+// registers while this one is chained) -- a thread's chain over the keys is unchanged, it no longer waits for a strided 2-byte load per key.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_attn_ref(const float *__restrict__ q, const float *__restrict__ kraw, const float *__restrict__ vraw, __half *__restrict__ kc, __half *__restrict__ vc,
+                                                  int E, int hd, const int *__restrict__ n_past, const float *__restrict__ cos_tab, const float *__restrict__ sin_tab, const Tables tb, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ref[];
     const int h = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
     const int T = *n_past + t + 1;
-    float *sc = reinterpret_cast<float *>(smem_ref);              // [T]
+    constexpr int CH = 128;                                       // keys per value chunk
+    __half *vbuf = reinterpret_cast<__half *>(smem_ref);          // [2][CH][hd]
+    float *sc = reinterpret_cast<float *>(vbuf + 2 * CH * hd);    // [T]
     __half *ph = reinterpret_cast<__half *>(sc + ((T + 3) & ~3)); // [T]
     __half *qh = ph + ((T + 7) & ~7);                             // [hd]
+    __half *knew = qh + hd, *vnew = knew + hd;                    // [hd] each (FUSED)
     __shared__ float red_f[4]; __shared__ double red_d[4];
-    for (int i = tid; i < hd; i += 256) qh[i] = __float2half_rn(q[(size_t)t * E + (size_t)h * hd + i]);
+    if (FUSED) {
+        if (tid < hd / 2) {
+            const int i = tid, pos = T - 1;
+            const float c = cos_tab[(size_t)pos * (hd / 2) + i], s = sin_tab[(size_t)pos * (hd / 2) + i];
+            const size_t o = (size_t)h * hd + 2 * i;
+            const float q0 = q[o], q1 = q[o + 1];
+            const float r0 = q0 * c - q1 * s, r1 = q0 * s + q1 * c;
+            qh[2 * i] = f2h_rn(r0); qh[2 * i + 1] = f2h_rn(r1);
+            const float k0 = kraw[o], k1 = kraw[o + 1];
+            const size_t co = (size_t)pos * E + (size_t)h * hd + 2 * i;
+            const __half2 kk = __floats2half2_rn(k0 * c - k1 * s, k0 * s + k1 * c), vv = __floats2half2_rn(vraw[o], vraw[o + 1]);
+            *reinterpret_cast<__half2 *>(kc + co) = kk; *reinterpret_cast<__half2 *>(vc + co) = vv;
+            *reinterpret_cast<__half2 *>(knew + 2 * i) = kk; *reinterpret_cast<__half2 *>(vnew + 2 * i) = vv;
+        }
+    } else {
+        for (int i = tid; i < hd; i += 256) qh[i] = __float2half_rn(q[(size_t)t * E + (size_t)h * hd + i]);
+    }
     __syncthreads();
     const float kq_scale = 1.0f / sqrtf((float)hd);
     float mx = -INFINITY;
     for (int j = tid; j < T; j += 256) {                          // the row in 16-byte pieces (hd % 8 == 0), the fma chain in element order as before
-        const __half *kr = kc + (size_t)j * E + (size_t)h * hd;
+        const __half *kr = (FUSED && j == T - 1) ? knew : kc + (size_t)j * E + (size_t)h * hd;
         float s = 0.0f;
         for (int i0 = 0; i0 < hd; i0 += 32) {
             int4 kk[4];
@@ -2419,26 +2460,54 @@ __global__ __launch_bounds__(256) void k_attn_ref(const float *__restrict__ q, c
     __syncthreads();
     const float inv = (float)(1.0 / (((red_d[0] + red_d[1]) + red_d[2]) + red_d[3]));
     for (int j = tid; j < T; j += 256) ph[j] = f2h_rn(sc[j] * inv);
-    __syncthreads();
-    for (int i = tid; i < hd; i += 256) {
-        const __half *vr = vc + (size_t)h * hd + i;
-        float s = 0.0f;
-        int j = 0;
-        for (; j + 8 <= T; j += 8) {                              // eight keys' values requested together, added in key order
-            __half vv[8];
+    // ---- P.V: chunk c = keys c CH .. of this head's value rows -> LDS; 16 threads x 16 bytes cover a row's hd (= 128) halves, 16 keys per pass of the workgroup
+    const int per_row = hd / 8, keys_per_pass = 256 / per_row, passes = CH / keys_per_pass;   // hd = 128: 16, 16, 8; hd = 64: 8, 32, 4; hd = 32: 4, 64, 2
+    const int kr_ = tid / per_row, part = tid - kr_ * per_row;
+    const int n_chunks = (T + CH - 1) / CH;
+    int4 stage[8];
+    auto request = [&](int c) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) vv[u] = vr[(size_t)(j + u) * E];
-#pragma unroll
-            for (int u = 0; u < 8; u++) s = fmaf(__half2float(vv[u]), __half2float(ph[j + u]), s);
+        for (int p = 0; p < 8; p++) if (p < passes) {
+            const int j = min(c * CH + p * keys_per_pass + kr_, T - 1);                     // clamped: rows past T are never chained
+            const __half *src = (FUSED && j == T - 1) ? vnew + part * 8 : vc + (size_t)j * E + (size_t)h * hd + part * 8;
+            stage[p] = ld16(src);
         }
-        for (; j < T; j++) s = fmaf(__half2float(vr[(size_t)j * E]), __half2float(ph[j]), s);
-        out[(size_t)t * E + (size_t)h * hd + i] = s;
+    };
+    auto deposit = [&](int b) {
+#pragma unroll
+        for (int p = 0; p < 8; p++) if (p < passes) *reinterpret_cast<int4 *>(vbuf + ((size_t)b * CH + p * keys_per_pass + kr_) * hd + part * 8) = stage[p];
+    };
+    request(0);
+    __syncthreads();                                              // ph complete (and knew / vnew visible)
+    deposit(0);
+    float s = 0.0f;
+    for (int c = 0; c < n_chunks; c++) {
+        __syncthreads();                                          // chunk c deposited; everybody has left the buffer chunk c + 1 goes to
+        if (c + 1 < n_chunks) request(c + 1);
+        if (tid < hd) {
+            const __half *vb = vbuf + (size_t)(c & 1) * CH * hd + tid;
+            const int j0 = c * CH, n = min(CH, T - j0);
+            for (int u = 0; u < n; u++) s = fmaf(__half2float(vb[(size_t)u * hd]), __half2float(ph[j0 + u]), s);   // key order
+        }
+        if (c + 1 < n_chunks) deposit((c + 1) & 1);
     }
+    if (tid < hd) out[(size_t)t * E + (size_t)h * hd + tid] = s;
 }
+static size_t attn_ref_lds(int t_max, int hd) { return (size_t)2 * 128 * hd * 2 + (size_t)((t_max + 3) & ~3) * 4 + (size_t)((t_max + 7) & ~7) * 2 + (size_t)hd * 2 * 3 + 64; }
 void launch_attn_ref(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
     note_kernel("k_attn_ref");
-    const size_t lds = (size_t)((t_max + 3) & ~3) * 4 + (size_t)((t_max + 7) & ~7) * 2 + (size_t)hd * 2 + 64;
-    hipLaunchKernelGGL(k_attn_ref, dim3((unsigned)n_head, (unsigned)N), dim3(256), lds, s, q, kcache, vcache, n_head * hd, hd, n_past, tb, out);
+    static bool attr = false;
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_ref<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(k_attn_ref<false>, dim3((unsigned)n_head, (unsigned)N), dim3(256), attn_ref_lds(t_max, hd), s, q, nullptr, nullptr, const_cast<__half *>(kcache), const_cast<__half *>(vcache),
+                       n_head * hd, hd, n_past, nullptr, nullptr, tb, out);
+}
+// one query row: RoPE + cache append + attention in one launch (q, k, v: the raw projections; q is left unrotated)
+void launch_attn_ref_fused(const float *q, const float *k, const float *v, __half *kcache, __half *vcache, int n_head, int hd, const int *n_past, int t_max, const float *cos_tab, const float *sin_tab,
+                           const Tables &tb, float *out, hipStream_t s) {
+    note_kernel("k_attn_ref");
+    static bool attr = false;
+    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_ref<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(k_attn_ref<true>, dim3((unsigned)n_head, 1), dim3(256), attn_ref_lds(t_max, hd), s, q, k, v, kcache, vcache, n_head * hd, hd, n_past, cos_tab, sin_tab, tb, out);
 }
 
 // =====================================================================================================================
