@@ -686,28 +686,52 @@ void Engine::forward_ref(int N, bool from_tokens, hipStream_t s, bool feed) {
             }
         } else for (int i = 0; i < n; i++) launch_mul_mat_ref(*W[i], act_, N, Y[i], W[i]->rows, res, s);
     };
+    // One row without a trace (the decode step): the fast step's launch structure -- row preparation in the mat-vec prologues, wq | wk (| wv) and w1 | w3 as set launches --
+    // on the oracle-order variants of the same kernels (MATVEC_EPI_REF); a set those kernels refuse (non-k-quant types) takes the standalone preparation + row kernels below.
+    const bool fused_row = N == 1 && !trace_file_;
+    auto fused_set = [&](std::initializer_list<const QWeight *> Ws, std::initializer_list<float *> Ys, const float *res, int pro, const float *px, const float *pw) -> bool {
+        if (!fused_row) return false;
+        const QWeight *W[3]; float *Y[3]; const float *R[3]; int n = 0;
+        for (const QWeight *w : Ws) W[n++] = w;
+        n = 0; for (float *yv : Ys) { Y[n] = yv; R[n] = res; n++; }
+        if (pro != 0 && !matvec_prologue_supported(W[0]->type, W[0]->cols)) return false;
+        bool same = true;
+        for (int i = 1; i < n; i++) same = same && W[i]->type == W[0]->type && W[i]->rows == W[0]->rows && W[i]->cols == W[0]->cols;
+        if (same) return launch_matvec_set(W, Y, res ? R : nullptr, n, act_, s, pro, px, pw, &tabs_, MATVEC_EPI_REF);
+        if (n == 3 && !res && W[1]->type == W[0]->type && W[1]->rows == W[0]->rows && W[1]->cols == W[0]->cols && W[2]->cols == W[0]->cols && (pro == 0 || pro == 1))
+            return launch_matvec_mixed(W, Y, 2, W + 2, Y + 2, 1, act_, s, pro, px, pw, MATVEC_EPI_REF);     // wq | wk + a differently typed wv
+        return false;
+    };
     for (size_t il = 0; il < layers_.size(); il++) {
         const LayerW &L = layers_[il];
         __half *kc = kc_ + (sl * layers_.size() + il) * C * E, *vc = vc_ + (sl * layers_.size() + il) * C * E;
-        launch_rms_quant(x_, L.attn_norm, N, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s, true);
-        ref_set({&L.wq, &L.wk, &L.wv}, {q_, k_, v_}, nullptr);
+        if (!fused_set({&L.wq, &L.wk, &L.wv}, {q_, k_, v_}, nullptr, 1, x_, L.attn_norm)) {
+            launch_rms_quant(x_, L.attn_norm, N, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s, true);
+            ref_set({&L.wq, &L.wk, &L.wv}, {q_, k_, v_}, nullptr);
+        }
         tr("q", (int)il, q_, (size_t)N * E); tr("k", (int)il, k_, (size_t)N * E); tr("v", (int)il, v_, (size_t)N * E);
         if (N == 1 && !trace_file_) launch_attn_ref_fused(q_, k_, v_, kc, vc, H, hd, d_npast, t_max, cos_, sin_, tabs_, att_, s);   // decode: RoPE + cache append inside the attention launch
         else { launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); launch_attn_ref(q_, kc, vc, N, H, hd, d_npast, t_max, tabs_, att_, s); }
         tr("q_rope", (int)il, q_, (size_t)N * E); tr("att", (int)il, att_, (size_t)N * E);
-        launch_silu_mul_quant(att_, nullptr, N, E, act_, act_mask_for(L.wo.type), tabs_, s);
-        ref_set({&L.wo}, {x_}, x_);
+        if (!fused_set({&L.wo}, {x_}, x_, 2, att_, nullptr)) {
+            launch_silu_mul_quant(att_, nullptr, N, E, act_, act_mask_for(L.wo.type), tabs_, s);
+            ref_set({&L.wo}, {x_}, x_);
+        }
         tr("x_attn", (int)il, x_, (size_t)N * E);
-        launch_rms_quant(x_, L.ffn_norm, N, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s, true);
-        ref_set({&L.w1, &L.w3}, {h1_, h3_}, nullptr);
+        if (!fused_set({&L.w1, &L.w3}, {h1_, h3_}, nullptr, 1, x_, L.ffn_norm)) {
+            launch_rms_quant(x_, L.ffn_norm, N, E, act_, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s, true);
+            ref_set({&L.w1, &L.w3}, {h1_, h3_}, nullptr);
+        }
         tr("h1", (int)il, h1_, (size_t)N * F); tr("h3", (int)il, h3_, (size_t)N * F);
         launch_silu_mul_quant(h1_, h3_, N, F, act_, act_mask_for(L.w2.type), tabs_, s);
-        ref_set({&L.w2}, {x_}, x_);
+        if (!fused_set({&L.w2}, {x_}, x_, 0, nullptr, nullptr)) ref_set({&L.w2}, {x_}, x_);
         tr("x_ffn", (int)il, x_, (size_t)N * E);
     }
-    launch_rms_quant(x_ + (size_t)(N - 1) * E, norm_, 1, E, act_, act_mask_for(output_.type), s, true);
-    { const int keepN = N; (void)keepN; const QWeight *Wo[1] = {&output_}; float *Yo[1] = {logits};
-      if (!launch_mul_mat_ref_set(Wo, Yo, nullptr, 1, act_, s)) launch_mul_mat_ref(output_, act_, 1, logits, V, nullptr, s); }
+    if (!(N == 1 && fused_set({&output_}, {logits}, nullptr, 1, x_, norm_))) {
+        launch_rms_quant(x_ + (size_t)(N - 1) * E, norm_, 1, E, act_, act_mask_for(output_.type), s, true);
+        const QWeight *Wo[1] = {&output_}; float *Yo[1] = {logits};
+        if (!launch_mul_mat_ref_set(Wo, Yo, nullptr, 1, act_, s)) launch_mul_mat_ref(output_, act_, 1, logits, V, nullptr, s);
+    }
     launch_argmax(logits, V, d_argmax, d_scratch_, s);
     launch_advance(d_npast, N, d_feed, d_argmax, s);
     HIP_CHECK(hipMemcpyAsync(h_argmax_ + sl, d_argmax, 4, hipMemcpyDeviceToHost, s));

@@ -68,7 +68,8 @@ bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n
 // pro: 0 = activations come from `A` (prepared by launch_rms_quant / launch_silu_mul_quant); 1 = rms_norm(px) * pw, 2 = px, 3 = silu(px) * pw are
 // prepared and quantised inside the kernel prologue (one launch less per use).
 bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, hipStream_t s, int pro = 0, const float *px = nullptr,
-                       const float *pw = nullptr, const Tables *tb = nullptr, int epi = 0);   // epi 1: y[0][g] = silu(W0[g].x) * (W1[g].x) (n == 2)
+                       const float *pw = nullptr, const Tables *tb = nullptr, int epi = 0);   // epi 1: y[0][g] = silu(W0[g].x) * (W1[g].x) (n == 2); MATVEC_EPI_REF: the CPU oracle's fp32 order (k-quants; pro 0..2)
+constexpr int MATVEC_EPI_REF = 2;
 bool matvec_silu_pair_supported(int type, int cols);
 // batched decode: N = 1..4 activation rows (prepared in `A`) against 1..3 same-type, same-shape, equally spaced matrices, weights streamed once;
 // y[m][t * ldy + r] (+ residual[m][t * ldy + r]).  false -> outside the kernel's range, use launch_mul_mat.
@@ -77,7 +78,7 @@ bool launch_matvec_rows(const QWeight *const *W, float *const *y, const float *c
 bool matvec_rows_prologue_ok(int type, int K);
 // two k-quant types (Q4_K|Q5_K + Q6_K) with the same K in one launch; pro: 0 or 1 (rms_norm prologue)
 bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, hipStream_t s, int pro = 0,
-                         const float *px = nullptr, const float *pw = nullptr);
+                         const float *px = nullptr, const float *pw = nullptr, int epi = 0);
 // the same for N = 1..4 rows of the batched step (K <= 6144); px != null: rows rms-normed with pw and quantised inside the launch
 bool launch_matvec_rows_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, int N, int ldy, hipStream_t s,
                               const float *px = nullptr, const float *pw = nullptr, int ldx = 0);

@@ -269,6 +269,48 @@ __global__ __launch_bounds__(256) void k_mul_mat_ref(const QWeight W, const ActQ
     }
     if (lane == 0) { const size_t o = (size_t)t * ldy + row; y[o] = residual ? acc + residual[o] : acc; }
 }
+// One output in the oracle's order from the lanes' units (u = lane + 64 i): chunk after chunk, block after block.  Returns the wave-uniform result.
+template <int T, int NU>
+__device__ __forceinline__ float ref_chain(const typename Tr<T>::WU (&w)[NU], const typename Tr<T>::AU (&a)[NU], const bool (&ok)[NU], const int U) {
+    using X = Tr<T>;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NU; i++) {
+        const int n_here = min(64, U - 64 * i);
+        if (n_here <= 0) break;
+        int i0, i1; X::ints(w[i], a[i], i0, i1);
+        if (!ok[i]) { i0 = 0; i1 = 0; }
+        // the block's integer parts over its GROUP lanes on the DPP crossbar (exact integer sums: any combining order gives the same value; __shfl_xor is an LDS permute)
+        if (X::GROUP >= 2) { i0 += dpp_i<0xB1>(i0); i1 += dpp_i<0xB1>(i1); }
+        if (X::GROUP >= 4) { i0 += dpp_i<0x4E>(i0); i1 += dpp_i<0x4E>(i1); }
+        if (X::GROUP >= 8) { i0 += dpp_i<0x141>(i0); i1 += dpp_i<0x141>(i1); }
+        static_assert(X::GROUP <= 8, "one DPP row half per ggml block");
+        float f0, v0, f1, v1; X::terms(w[i], a[i], i0, i1, f0, v0, f1, v1);
+        if constexpr (X::GROUP == 8) {
+            // k-quants: the chain walks the 8-lane groups of this register in place.  At step g every lane takes the running value of the lane 8 below it (row_shr:8:
+            // the lower half of its 16-lane row) or, where a row begins, of the previous row's last lane (row_bcast:15), and adds ITS block's terms: after step g the
+            // lanes of group g hold the oracle's running sum, the other lanes hold values nobody reads.  3 instructions per block instead of 4 v_readlane + 2 fma.
+            const int ng = n_here / 8;
+            float run = acc;                   // wave-uniform value carried in from the previous register
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                if (g < ng) {
+                    float t = g == 0 ? acc : ((g & 1) ? dpp_f<0x118>(run) : dpp_f<0x142>(run));
+                    t = fmaf(f0, v0, t);
+                    if (X::TERMS == 2) t = fmaf(f1, v1, t);
+                    run = t;
+                }
+            }
+            acc = readlane_f(run, 8 * (ng - 1));
+        } else {
+            for (int g = 0; g < n_here; g += X::GROUP) {   // g is wave-uniform: v_readlane (the generic __shfl is an LDS permute, ~100 dependent cycles per block term)
+                acc = fmaf(readlane_f(f0, g), readlane_f(v0, g), acc);
+                if (X::TERMS == 2) acc = fmaf(readlane_f(f1, g), readlane_f(v1, g), acc);
+            }
+        }
+    }
+    return acc;
+}
 // The same chain for ONE activation row (decode) over up to three matrices of one type and K in one launch: every lane's NU units (u = lane + 64 i, as in k_matvec_v2) are
 // requested before the first block is added, so a wave pays one memory round trip instead of one per 64 units (the generic kernel above: 3 ... 7 dependent round trips per
 // row, 5.5 ms per 13B token in parity mode).  The per-block terms are added in the same order: chunk after chunk, block after block -- bit-identical to k_mul_mat_ref.
@@ -292,42 +334,7 @@ __global__ __launch_bounds__(256) void k_mul_mat_ref_row(const RefSet S, const A
         for (int i = 0; i < NU; i++) X::loadw(W, (size_t)r * U, uc[i], Rw.w[i]);
     };
     auto chain = [&](int row, const Row &Rw) {     // the oracle's order: chunk after chunk, block after block
-        float acc = 0.0f;
-#pragma unroll
-        for (int i = 0; i < NU; i++) {
-            const int n_here = min(64, U - 64 * i);
-            if (n_here <= 0) break;
-            int i0, i1; X::ints(Rw.w[i], a[i], i0, i1);
-            if (!ok[i]) { i0 = 0; i1 = 0; }
-            // the block's integer parts over its GROUP lanes on the DPP crossbar (exact integer sums: any combining order gives the same value; __shfl_xor is an LDS permute)
-            if (X::GROUP >= 2) { i0 += dpp_i<0xB1>(i0); i1 += dpp_i<0xB1>(i1); }
-            if (X::GROUP >= 4) { i0 += dpp_i<0x4E>(i0); i1 += dpp_i<0x4E>(i1); }
-            if (X::GROUP >= 8) { i0 += dpp_i<0x141>(i0); i1 += dpp_i<0x141>(i1); }
-            static_assert(X::GROUP <= 8, "one DPP row half per ggml block");
-            float f0, v0, f1, v1; X::terms(Rw.w[i], a[i], i0, i1, f0, v0, f1, v1);
-            if constexpr (X::GROUP == 8) {
-                // k-quants: the chain walks the 8-lane groups of this register in place.  At step g every lane takes the running value of the lane 8 below it (row_shr:8:
-                // the lower half of its 16-lane row) or, where a row begins, of the previous row's last lane (row_bcast:15), and adds ITS block's terms: after step g the
-                // lanes of group g hold the oracle's running sum, the other lanes hold values nobody reads.  3 instructions per block instead of 4 v_readlane + 2 fma.
-                const int ng = n_here / 8;
-                float run = acc;                   // wave-uniform value carried in from the previous register
-#pragma unroll
-                for (int g = 0; g < 8; g++) {
-                    if (g < ng) {
-                        float t = g == 0 ? acc : ((g & 1) ? dpp_f<0x118>(run) : dpp_f<0x142>(run));
-                        t = fmaf(f0, v0, t);
-                        if (X::TERMS == 2) t = fmaf(f1, v1, t);
-                        run = t;
-                    }
-                }
-                acc = readlane_f(run, 8 * (ng - 1));
-            } else {
-                for (int g = 0; g < n_here; g += X::GROUP) {   // g is wave-uniform: v_readlane (the generic __shfl is an LDS permute, ~100 dependent cycles per block term)
-                    acc = fmaf(readlane_f(f0, g), readlane_f(v0, g), acc);
-                    if (X::TERMS == 2) acc = fmaf(readlane_f(f1, g), readlane_f(v1, g), acc);
-                }
-            }
-        }
+        const float acc = ref_chain<T, NU>(Rw.w, a, ok, U);
         if (lane == 0) { const float *r = S.res[m]; S.y[m][row] = r ? acc + r[row] : acc; }
     };
     Row cur, nxt;                                  // two statically named stages, as in matvec_run: the next row is in flight while this one is chained
@@ -433,7 +440,7 @@ template <int NU> constexpr int mv_fat_max_threads() { return NU <= 4 ? 768 : 51
 // EPI_SILU_PAIR (w1|w3 of the feed-forward block; ms.n == 2, R == 2): group g = the row pair (w1[g], w3[g]); the wave writes
 // h[g] = silu_table(w1[g] . x) * (w3[g] . x) instead of the two dot products.  The table lookup of a group is consumed one group later, so
 // that it never stalls the weight stream.
-enum EpiKind : int { EPI_STORE = 0, EPI_SILU_PAIR = 1 };
+enum EpiKind : int { EPI_STORE = 0, EPI_SILU_PAIR = 1, EPI_REF = 2 };   // EPI_REF (MINIGPT4_PARITY): store, every fp32 accumulation in the CPU oracle's order (ref_chain; the rms sum = the oracle's value)
 // In-kernel timeline (diagnostic builds only: make EXTRA=-DMG4_TIMELINE OUT=../libminigpt4_tl.so OBJ=build_tl).  Thread 0 of every workgroup of a decode mat-vec
 // stamps the 100 MHz constant clock at: 0 entry, 1 first weight tiles requested, 2 activation row ready (prologue done), 3 first row group finished, 4 last row
 // group finished, 5 results stored.  The last launch wins; read with minigpt4_amd_timeline after a single-launch micro-benchmark (tools/timeline.py).
@@ -452,7 +459,7 @@ __device__ unsigned long long g_tla[2048 * 8];
 #endif
 template <int T, int NU, int R, int PRO, int EPI>
 __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, const ProArgs &pa, const int n_groups, const int n_waves, const int wave) {
-    static_assert(EPI == EPI_STORE || R == 2, "the SiLU pair epilogue works on row pairs");
+    static_assert(EPI != EPI_SILU_PAIR || R == 2, "the SiLU pair epilogue works on row pairs");
     // groups of this wave: g = g_first, g_first + g_step, ... < g_last
     const int g_first = wave, g_last = n_groups, g_step = n_waves;
     MG4_TL(0); MG4_TL_ALL(7);
@@ -544,7 +551,18 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
             __syncthreads();
             double tot = 0.0;
             for (int w = 0; w < nthr / 64; w++) tot += red[w];
-            const float mean = (float)(tot / (double)K);
+            float mean;
+            if (EPI == EPI_REF) {   // the oracle's mean (one double accumulator in element order) from a parallel sum: k_rms_quant's interval argument
+                const double delta = (double)K * 4e-16;
+                const float lo = (float)(tot * (1.0 - delta) / (double)K), hi = (float)(tot * (1.0 + delta) / (double)K);
+                mean = lo;
+                if (lo != hi) {     // workgroup-uniform (~1e-4 of the rows): the literal loop
+                    __syncthreads();
+                    if (threadIdx.x == 0) { double sq = 0.0; for (int i = 0; i < K; i++) sq += (double)(pa.x[i] * pa.x[i]); red[0] = sq; }
+                    __syncthreads();
+                    mean = (float)(red[0] / (double)K);
+                }
+            } else mean = (float)(tot / (double)K);
             scale = 1.0f / sqrtf(mean + 1e-6f);
         }
 #pragma unroll
@@ -568,10 +586,13 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
         float out[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            float acc = 0.0f;
+            if constexpr (EPI == EPI_REF) out[r] = ref_chain<T, NU>(G.w[r], a, ok, U);
+            else {
+                float acc = 0.0f;
 #pragma unroll
-            for (int i = 0; i < NU; i++) { float c = acc; X::dot(G.w[r][i], a[i], c); acc = ok[i] ? c : acc; }
-            out[r] = wave_sum(acc);
+                for (int i = 0; i < NU; i++) { float c = acc; X::dot(G.w[r][i], a[i], c); acc = ok[i] ? c : acc; }
+                out[r] = wave_sum(acc);
+            }
         }
         if (EPI == EPI_SILU_PAIR) {
             flush_pending();
@@ -621,12 +642,12 @@ __global__ __launch_bounds__(PRO == PRO_NONE ? 256 : mv_fat_max_threads<NU>()) v
 }
 // Two weight types in one launch (llama.cpp's k-quant mixes give wv more bits than wq|wk): waves [0, n_waves1) stream set 1, the rest set 2.  Both
 // sets share K and the prepared activation row (both types read the Q8_K image); every wave passes the same number of workgroup barriers.
-template <int T1, int T2, int NU, int PRO>
+template <int T1, int T2, int NU, int PRO, int EPI = EPI_STORE>
 __global__ __launch_bounds__(PRO == PRO_NONE ? 256 : mv_fat_max_threads<NU>()) void k_matvec_mix(const MatSet ms1, const MatSet ms2, const ActQ A, const ProArgs pa, const int n_groups1,
                                                                                                  const int n_waves1, const int n_groups2, const int n_waves2) {
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    if (wave < n_waves1) matvec_run<T1, NU, 1, PRO, EPI_STORE>(ms1, A, pa, n_groups1, n_waves1, wave);
-    else matvec_run<T2, NU, 1, PRO, EPI_STORE>(ms2, A, pa, n_groups2, n_waves2, wave - n_waves1);
+    if (wave < n_waves1) matvec_run<T1, NU, 1, PRO, EPI>(ms1, A, pa, n_groups1, n_waves1, wave);
+    else matvec_run<T2, NU, 1, PRO, EPI>(ms2, A, pa, n_groups2, n_waves2, wave - n_waves1);
 }
 static int g_mv_cus = 256;
 static int g_mv_force_waves = 0;    // MINIGPT4_MV_WAVES: waves per CU of the prologue-free launches (0 = choose)
@@ -658,9 +679,9 @@ static void launch_v2_t(const MatSet &ms, const ActQ &A, int pro, const ProArgs 
     if constexpr (EPI == EPI_SILU_PAIR) {   // w1|w3 follow the ffn norm: only that prologue is instantiated for the pair epilogue
         hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_RMS, EPI>), grid, block, lds, s, ms, A, pa, n_groups, n_waves);
     } else switch (pro) {
-    case PRO_RMS: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_RMS, EPI_STORE>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
-    case PRO_PLAIN: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_PLAIN, EPI_STORE>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
-    default: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_SILU, EPI_STORE>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
+    case PRO_RMS: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_RMS, EPI>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
+    case PRO_PLAIN: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_PLAIN, EPI>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
+    default: if constexpr (EPI == EPI_STORE) hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_SILU, EPI>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
     }
 }
 #ifndef MG4_R_NU3
@@ -682,6 +703,20 @@ static bool launch_v2_type(const MatSet &ms, const ActQ &A, int pro, const ProAr
         case 3: launch_v2_t<T, 3, 2, EPI_SILU_PAIR>(ms, A, pro, pa, s); break;
         default: ok = false;
         }
+    } else if (epi == EPI_REF) {   // parity mode: the k-quants of the headline files (other types: k_mul_mat_ref_row); no SiLU prologue (the row comes from k_silu_mul_quant)
+        if constexpr (T == GT_Q4_K || T == GT_Q5_K || T == GT_Q6_K) {
+            if (pro == PRO_SILU) return false;
+            switch (nu) {
+            case 1: launch_v2_t<T, 1, 1, EPI_REF>(ms, A, pro, pa, s); break;
+            case 2: launch_v2_t<T, 2, 1, EPI_REF>(ms, A, pro, pa, s); break;
+            case 3: launch_v2_t<T, 3, 1, EPI_REF>(ms, A, pro, pa, s); break;
+            case 4: launch_v2_t<T, 4, 1, EPI_REF>(ms, A, pro, pa, s); break;
+            case 5: launch_v2_t<T, 5, 1, EPI_REF>(ms, A, pro, pa, s); break;
+            case 6: launch_v2_t<T, 6, 1, EPI_REF>(ms, A, pro, pa, s); break;
+            case 7: launch_v2_t<T, 7, 1, EPI_REF>(ms, A, pro, pa, s); break;
+            default: ok = false;
+            }
+        } else ok = false;
     } else switch (nu) {
     case 1: launch_v2_t<T, 1, 2, EPI_STORE>(ms, A, pro, pa, s); break;
     case 2: launch_v2_t<T, 2, MG4_R_NU2, EPI_STORE>(ms, A, pro, pa, s); break;
@@ -730,7 +765,7 @@ static bool fill_matset(MatSet &ms, const QWeight *const *W, float *const *y, co
     }
     return true;
 }
-template <int T1, int T2, int NU>
+template <int T1, int T2, int NU, int EPI = EPI_STORE>
 static void launch_mix_t(const MatSet &m1, const MatSet &m2, double bytes1, double bytes2, const ActQ &A, int pro, const ProArgs &pa, hipStream_t s) {
     const int ng1 = m1.n * m1.rows_each, ng2 = m2.n * m2.rows_each;
     // split the workgroups so that the busiest wave of either set finishes earliest: cost = rows per wave x bytes per row
@@ -746,26 +781,26 @@ static void launch_mix_t(const MatSet &m1, const MatSet &m2, double bytes1, doub
             if (c < best_cost) { best_cost = c; best_t = t; best_b1 = b1; best_total = total; }
         }
     }
-    note_kernel("k_matvec_mix<%d, %d, %d, %d>", T1, T2, NU, pro == PRO_NONE ? 0 : 1);
+    note_kernel(EPI == EPI_REF ? "k_matvec_mix<%d, %d, %d, %d, 2>" : "k_matvec_mix<%d, %d, %d, %d>", T1, T2, NU, pro == PRO_NONE ? 0 : 1);
     const int wpb = best_t / 64, nw1 = best_b1 * wpb, nw2 = (best_total - best_b1) * wpb;
     const dim3 grid((unsigned)best_total), block((unsigned)best_t);
-    if (pro == PRO_NONE) hipLaunchKernelGGL((k_matvec_mix<T1, T2, NU, PRO_NONE>), grid, block, 0, s, m1, m2, A, pa, ng1, nw1, ng2, nw2);
-    else hipLaunchKernelGGL((k_matvec_mix<T1, T2, NU, PRO_RMS>), grid, block, mv_prologue_lds(m1.w0.cols), s, m1, m2, A, pa, ng1, nw1, ng2, nw2);
+    if (pro == PRO_NONE) hipLaunchKernelGGL((k_matvec_mix<T1, T2, NU, PRO_NONE, EPI>), grid, block, 0, s, m1, m2, A, pa, ng1, nw1, ng2, nw2);
+    else hipLaunchKernelGGL((k_matvec_mix<T1, T2, NU, PRO_RMS, EPI>), grid, block, mv_prologue_lds(m1.w0.cols), s, m1, m2, A, pa, ng1, nw1, ng2, nw2);
 }
-template <int T1, int T2>
+template <int T1, int T2, int EPI = EPI_STORE>
 static bool launch_mix_nu(const MatSet &m1, const MatSet &m2, double b1, double b2, const ActQ &A, int pro, const ProArgs &pa, hipStream_t s) {
     const int nu = (m1.w0.cols / 32 + 63) / 64;
     switch (nu) {
-    case 1: launch_mix_t<T1, T2, 1>(m1, m2, b1, b2, A, pro, pa, s); return true;
-    case 2: launch_mix_t<T1, T2, 2>(m1, m2, b1, b2, A, pro, pa, s); return true;
-    case 3: launch_mix_t<T1, T2, 3>(m1, m2, b1, b2, A, pro, pa, s); return true;
-    case 4: launch_mix_t<T1, T2, 4>(m1, m2, b1, b2, A, pro, pa, s); return true;
+    case 1: launch_mix_t<T1, T2, 1, EPI>(m1, m2, b1, b2, A, pro, pa, s); return true;
+    case 2: launch_mix_t<T1, T2, 2, EPI>(m1, m2, b1, b2, A, pro, pa, s); return true;
+    case 3: launch_mix_t<T1, T2, 3, EPI>(m1, m2, b1, b2, A, pro, pa, s); return true;
+    case 4: launch_mix_t<T1, T2, 4, EPI>(m1, m2, b1, b2, A, pro, pa, s); return true;
     default: return false;
     }
 }
 // Decode mat-vec over two sets of different k-quant types with the same K (wq|wk + wv of a "more bits" layer) in ONE launch.  pro: PRO_NONE or PRO_RMS.
 bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, hipStream_t s, int pro,
-                         const float *px, const float *pw) {
+                         const float *px, const float *pw, int epi) {
     if (pro != PRO_NONE && pro != PRO_RMS) return false;
     if (W1[0]->cols != W2[0]->cols || W1[0]->cols % 256) return false;
     MatSet m1, m2;
@@ -775,6 +810,11 @@ bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, con
     for (int i = 0; i < n1; i++) b1 += (double)W1[i]->bytes;
     for (int i = 0; i < n2; i++) b2 += (double)W2[i]->bytes;
     const int t1 = W1[0]->type, t2 = W2[0]->type;
+    if (epi == EPI_REF) {
+        if (t1 == GT_Q5_K && t2 == GT_Q6_K) return launch_mix_nu<GT_Q5_K, GT_Q6_K, EPI_REF>(m1, m2, b1, b2, A, pro, pa, s);
+        if (t1 == GT_Q4_K && t2 == GT_Q6_K) return launch_mix_nu<GT_Q4_K, GT_Q6_K, EPI_REF>(m1, m2, b1, b2, A, pro, pa, s);
+        return false;
+    }
     if (t1 == GT_Q5_K && t2 == GT_Q6_K) return launch_mix_nu<GT_Q5_K, GT_Q6_K>(m1, m2, b1, b2, A, pro, pa, s);
     if (t1 == GT_Q4_K && t2 == GT_Q6_K) return launch_mix_nu<GT_Q4_K, GT_Q6_K>(m1, m2, b1, b2, A, pro, pa, s);
     return false;
