@@ -665,12 +665,13 @@ static void launch_v2_t(const MatSet &ms, const ActQ &A, int pro, const ProArgs 
     const int n_groups = EPI == EPI_SILU_PAIR ? ms.rows_each : (total_rows + R - 1) / R;
     note_kernel("k_matvec_v2<%d, %d, %d, %d, %d>", T, NU, R, EPI == EPI_SILU_PAIR && pro != PRO_NONE ? (int)PRO_RMS : pro, (int)EPI);
     if (pro == PRO_NONE) {
-        int n_waves = std::min(n_groups, g_mv_cus * pick_waves_per_cu(n_groups, mv_max_wpc<NU>()));
+        // EPI_REF: the block chain is a dependent sequence per wave (DPP move + fma per block): as many waves per SIMD as the registers admit, not the stream-optimal 8 per CU
+        int n_waves = std::min(n_groups, g_mv_cus * (EPI == EPI_REF ? mv_max_wpc<NU>() : pick_waves_per_cu(n_groups, mv_max_wpc<NU>())));
         n_waves = (n_waves + 3) & ~3;
         hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_NONE, EPI>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, s, ms, A, pa, n_groups, n_waves);
         return;
     }
-    const int LB = pick_fat_threads(n_groups, mv_fat_max_threads<NU>()), WPB = LB / 64;
+    const int LB = EPI == EPI_REF ? mv_fat_max_threads<NU>() : pick_fat_threads(n_groups, mv_fat_max_threads<NU>()), WPB = LB / 64;
     const int n_blocks = std::min((n_groups + WPB - 1) / WPB, g_mv_cus);
     const int n_waves = n_blocks * WPB;
     const dim3 grid((unsigned)n_blocks), block((unsigned)LB);
@@ -771,10 +772,10 @@ static void launch_mix_t(const MatSet &m1, const MatSet &m2, double bytes1, doub
     // split the workgroups so that the busiest wave of either set finishes earliest: cost = rows per wave x bytes per row
     const double bpr1 = bytes1 / ng1, bpr2 = bytes2 / ng2;
     int best_t = 0, best_b1 = 0, best_total = 0; double best_cost = 1e300;
-    const int t_fix = pro == PRO_NONE ? 256 : pick_fat_threads(ng1, mv_fat_max_threads<NU>());
+    const int t_fix = pro == PRO_NONE ? 256 : (EPI == EPI_REF ? mv_fat_max_threads<NU>() : pick_fat_threads(ng1, mv_fat_max_threads<NU>()));
     for (int t = t_fix; t <= t_fix; t += 64) {
         const int wpb = t / 64;
-        const int total = pro == PRO_NONE ? g_mv_cus * pick_waves_per_cu(ng1 + ng2, mv_max_wpc<NU>()) / 4 : g_mv_cus;
+        const int total = pro == PRO_NONE ? g_mv_cus * (EPI == EPI_REF ? mv_max_wpc<NU>() : pick_waves_per_cu(ng1 + ng2, mv_max_wpc<NU>())) / 4 : g_mv_cus;
         for (int b1 = 1; b1 < total; b1++) {
             const int w1 = b1 * wpb, w2 = (total - b1) * wpb;
             const double c = std::max((double)((ng1 + w1 - 1) / w1) * bpr1, (double)((ng2 + w2 - 1) / w2) * bpr2);
