@@ -238,6 +238,7 @@ static void launch_mul_mat_t(const QWeight &W, const ActQ &A, int N, float *y, i
 // The fast kernels differ from this one only in the order of those additions; this one is bit-identical to the CPU oracle.  F16 / F32: one fma per ELEMENT in
 // element order (ggml_vec_dot_f16 restated as a scalar loop), unit after unit.
 // =====================================================================================================================
+template <int T> __device__ __forceinline__ float ref_chunk(const typename Tr<T>::WU &w, const typename Tr<T>::AU &a, const bool ok, const int n_here, float acc);   // below
 template <int T>
 __global__ __launch_bounds__(256) void k_mul_mat_ref(const QWeight W, const ActQ A, const int N, float *y, const int ldy, const float *residual) {
     using X = Tr<T>;
@@ -256,58 +257,57 @@ __global__ __launch_bounds__(256) void k_mul_mat_ref(const QWeight W, const ActQ
         if constexpr (T == GT_F16 || T == GT_F32) {
             for (int g = 0; g < n_here; g++) { float c = acc; X::dot(w, a, c); acc = __shfl(c, g); }   // unit g continues the chain where unit g - 1 left it
         } else {
-            int i0, i1; X::ints(w, a, i0, i1);
-            if (!ok) { i0 = 0; i1 = 0; }
-#pragma unroll
-            for (int m = 1; m < X::GROUP; m <<= 1) { i0 += __shfl_xor(i0, m); i1 += __shfl_xor(i1, m); }
-            float f0, v0, f1, v1; X::terms(w, a, i0, i1, f0, v0, f1, v1);
-            for (int g = 0; g < n_here; g += X::GROUP) {
-                acc = fmaf(__shfl(f0, g), __shfl(v0, g), acc);
-                if (X::TERMS == 2) acc = fmaf(__shfl(f1, g), __shfl(v1, g), acc);
-            }
+            acc = ref_chunk<T>(w, a, ok, n_here, acc);
         }
     }
     if (lane == 0) { const size_t o = (size_t)t * ldy + row; y[o] = residual ? acc + residual[o] : acc; }
 }
-// One output in the oracle's order from the lanes' units (u = lane + 64 i): chunk after chunk, block after block.  Returns the wave-uniform result.
+// One chunk of <= 64 units (n_here of them; lane = unit) of one output in the oracle's order: the running value `acc` (wave-uniform) comes in, the value after the chunk's
+// last block goes out.
+template <int T>
+__device__ __forceinline__ float ref_chunk(const typename Tr<T>::WU &w, const typename Tr<T>::AU &a, const bool ok, const int n_here, float acc) {
+    using X = Tr<T>;
+    int i0, i1; X::ints(w, a, i0, i1);
+    if (!ok) { i0 = 0; i1 = 0; }
+    // the block's integer parts over its GROUP lanes on the DPP crossbar (exact integer sums: any combining order gives the same value; __shfl_xor is an LDS permute)
+    if (X::GROUP >= 2) { i0 += dpp_i<0xB1>(i0); i1 += dpp_i<0xB1>(i1); }
+    if (X::GROUP >= 4) { i0 += dpp_i<0x4E>(i0); i1 += dpp_i<0x4E>(i1); }
+    if (X::GROUP >= 8) { i0 += dpp_i<0x141>(i0); i1 += dpp_i<0x141>(i1); }
+    static_assert(X::GROUP <= 8, "one DPP row half per ggml block");
+    float f0, v0, f1, v1; X::terms(w, a, i0, i1, f0, v0, f1, v1);
+    if constexpr (X::GROUP == 8) {
+        // k-quants: the chain walks the 8-lane groups of this register in place.  At step g every lane takes the running value of the lane 8 below it (row_shr:8:
+        // the lower half of its 16-lane row) or, where a row begins, of the previous row's last lane (row_bcast:15), and adds ITS block's terms: after step g the
+        // lanes of group g hold the oracle's running sum, the other lanes hold values nobody reads.  3 instructions per block instead of 4 v_readlane + 2 fma.
+        const int ng = n_here / 8;
+        float run = acc;
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            if (g < ng) {
+                float t = g == 0 ? acc : ((g & 1) ? dpp_f<0x118>(run) : dpp_f<0x142>(run));
+                t = fmaf(f0, v0, t);
+                if (X::TERMS == 2) t = fmaf(f1, v1, t);
+                run = t;
+            }
+        }
+        acc = readlane_f(run, 8 * (ng - 1));
+    } else {
+        for (int g = 0; g < n_here; g += X::GROUP) {   // g is wave-uniform: v_readlane (the generic __shfl is an LDS permute, ~100 dependent cycles per block term)
+            acc = fmaf(readlane_f(f0, g), readlane_f(v0, g), acc);
+            if (X::TERMS == 2) acc = fmaf(readlane_f(f1, g), readlane_f(v1, g), acc);
+        }
+    }
+    return acc;
+}
+// One output from the lanes' NU registers of units (u = lane + 64 i): chunk after chunk.  Returns the wave-uniform result.
 template <int T, int NU>
 __device__ __forceinline__ float ref_chain(const typename Tr<T>::WU (&w)[NU], const typename Tr<T>::AU (&a)[NU], const bool (&ok)[NU], const int U) {
-    using X = Tr<T>;
     float acc = 0.0f;
 #pragma unroll
     for (int i = 0; i < NU; i++) {
         const int n_here = min(64, U - 64 * i);
         if (n_here <= 0) break;
-        int i0, i1; X::ints(w[i], a[i], i0, i1);
-        if (!ok[i]) { i0 = 0; i1 = 0; }
-        // the block's integer parts over its GROUP lanes on the DPP crossbar (exact integer sums: any combining order gives the same value; __shfl_xor is an LDS permute)
-        if (X::GROUP >= 2) { i0 += dpp_i<0xB1>(i0); i1 += dpp_i<0xB1>(i1); }
-        if (X::GROUP >= 4) { i0 += dpp_i<0x4E>(i0); i1 += dpp_i<0x4E>(i1); }
-        if (X::GROUP >= 8) { i0 += dpp_i<0x141>(i0); i1 += dpp_i<0x141>(i1); }
-        static_assert(X::GROUP <= 8, "one DPP row half per ggml block");
-        float f0, v0, f1, v1; X::terms(w[i], a[i], i0, i1, f0, v0, f1, v1);
-        if constexpr (X::GROUP == 8) {
-            // k-quants: the chain walks the 8-lane groups of this register in place.  At step g every lane takes the running value of the lane 8 below it (row_shr:8:
-            // the lower half of its 16-lane row) or, where a row begins, of the previous row's last lane (row_bcast:15), and adds ITS block's terms: after step g the
-            // lanes of group g hold the oracle's running sum, the other lanes hold values nobody reads.  3 instructions per block instead of 4 v_readlane + 2 fma.
-            const int ng = n_here / 8;
-            float run = acc;                   // wave-uniform value carried in from the previous register
-#pragma unroll
-            for (int g = 0; g < 8; g++) {
-                if (g < ng) {
-                    float t = g == 0 ? acc : ((g & 1) ? dpp_f<0x118>(run) : dpp_f<0x142>(run));
-                    t = fmaf(f0, v0, t);
-                    if (X::TERMS == 2) t = fmaf(f1, v1, t);
-                    run = t;
-                }
-            }
-            acc = readlane_f(run, 8 * (ng - 1));
-        } else {
-            for (int g = 0; g < n_here; g += X::GROUP) {   // g is wave-uniform: v_readlane (the generic __shfl is an LDS permute, ~100 dependent cycles per block term)
-                acc = fmaf(readlane_f(f0, g), readlane_f(v0, g), acc);
-                if (X::TERMS == 2) acc = fmaf(readlane_f(f1, g), readlane_f(v1, g), acc);
-            }
-        }
+        acc = ref_chunk<T>(w[i], a[i], ok[i], n_here, acc);
     }
     return acc;
 }
