@@ -782,7 +782,7 @@ static void launch_mix_t(const MatSet &m1, const MatSet &m2, double bytes1, doub
             if (c < best_cost) { best_cost = c; best_t = t; best_b1 = b1; best_total = total; }
         }
     }
-    note_kernel(EPI == EPI_REF ? "k_matvec_mix<%d, %d, %d, %d, 2>" : "k_matvec_mix<%d, %d, %d, %d>", T1, T2, NU, pro == PRO_NONE ? 0 : 1);
+    note_kernel("k_matvec_mix<%d, %d, %d, %d, %d>", T1, T2, NU, pro == PRO_NONE ? 0 : 1, (int)EPI);
     const int wpb = best_t / 64, nw1 = best_b1 * wpb, nw2 = (best_total - best_b1) * wpb;
     const dim3 grid((unsigned)best_total), block((unsigned)best_t);
     if (pro == PRO_NONE) hipLaunchKernelGGL((k_matvec_mix<T1, T2, NU, PRO_NONE, EPI>), grid, block, 0, s, m1, m2, A, pa, ng1, nw1, ng2, nw2);
