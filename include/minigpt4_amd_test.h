@@ -25,7 +25,7 @@ MINIGPT4_API int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n
 MINIGPT4_API int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int64_t N, const float *residual, int ks, int generation, float *y);
 /* The decode (N = 1) mat-vec launches as the engine issues them: n1 equally spaced matrices of type1 (raw1 = their file bytes back to back), optionally one more of
  * type2 in the same mixed-type launch; prep 1 = rms_norm(x) * x2, 2 = x, 3 = silu(x) * x2, run standalone (fuse = 0) or in the kernel prologue (fuse = 1);
- * epi = 1: y[g] = silu(W0[g] . a) * (W1[g] . a) (n1 == 2).  residual / y: (n1 + n2) * n_out floats.  Returns 4 when the shape is outside the kernel's range. */
+ * epi = 1: y[g] = silu(W0[g] . a) * (W1[g] . a) (n1 == 2); epi = 2: every fp32 accumulation in the CPU oracle's order (k-quants; bit-identical to oracle/refcpu.c).  residual / y: (n1 + n2) * n_out floats.  Returns 4 when the shape is outside the kernel's range. */
 MINIGPT4_API int minigpt4_amd_test_matvec(int type1, const void *raw1, int n1, int type2, const void *raw2, int n2, int64_t n_in, int64_t n_out, const float *x, const float *x2,
                                           int prep, int fuse, int epi, const float *residual, float *y);
 /* The batched-decode mat-vec: N = 1..4 activation rows x[N][n_in] against n_mat (1..3) equally spaced matrices in one weight pass; y / residual: [n_mat][N][n_out].

@@ -159,17 +159,17 @@ int minigpt4_amd_test_matvec(int type1, const void *raw1, int n1, int type2, con
         ActQ A; alloc_act(A, keep, 1, (size_t)K);
         int mask = 0; for (int m = 0; m < nt; m++) mask |= act_mask_for(W[(size_t)m].type);
         if (!fuse) {
-            if (prep == 1) launch_rms_quant(d_x.as<float>(), d_x2.as<float>(), 1, K, A, mask, nullptr);
+            if (prep == 1) launch_rms_quant(d_x.as<float>(), d_x2.as<float>(), 1, K, A, mask, nullptr, epi == MATVEC_EPI_REF);   // oracle-order launch: the oracle's rms mean
             else launch_silu_mul_quant(d_x.as<float>(), prep == 3 ? d_x2.as<float>() : nullptr, 1, K, A, mask, tb, nullptr);
         }
         const QWeight *Wp[4]; float *Yp[4]; const float *Rp[4];
         for (int m = 0; m < nt; m++) { Wp[m] = &W[(size_t)m]; Yp[m] = d_y.as<float>() + (size_t)m * R; Rp[m] = d_res.as<float>() + (size_t)m * R; }
         bool ok;
-        if (n2) ok = launch_matvec_mixed(Wp, Yp, n1, Wp + n1, Yp + n1, n2, A, nullptr, fuse ? prep : 0, d_x.as<float>(), d_x2.as<float>());
+        if (n2) ok = launch_matvec_mixed(Wp, Yp, n1, Wp + n1, Yp + n1, n2, A, nullptr, fuse ? prep : 0, d_x.as<float>(), d_x2.as<float>(), epi);
         else ok = launch_matvec_set(Wp, Yp, residual ? Rp : nullptr, n1, A, nullptr, fuse ? prep : 0, d_x.as<float>(), d_x2.as<float>(), &tb, epi);
         if (!ok) { set_last_error("shape / type outside the decode mat-vec kernel's range"); return 4; }
         HIP_CHECK(hipDeviceSynchronize());
-        HIP_CHECK(hipMemcpy(y, d_y.p, (size_t)(epi ? 1 : nt) * R * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(y, d_y.p, (size_t)(epi == 1 ? 1 : nt) * R * 4, hipMemcpyDeviceToHost));
         return 0;
     });
 }

@@ -440,7 +440,7 @@ class MiniGPT4SharedLibrary:
         n2 = 0 if raw2 is None else 1
         raw2c = None if raw2 is None else np.ascontiguousarray(raw2)
         res = None if residual is None else np.ascontiguousarray(residual, np.float32).reshape(-1)
-        y = np.empty(((1 if epi else n1 + n2), n_out), np.float32)
+        y = np.empty(((1 if epi == 1 else n1 + n2), n_out), np.float32)      # epi 1: the SiLU pair epilogue writes one row; 2: the CPU oracle's fp32 order (k-quants)
         rc = self.library.minigpt4_amd_test_matvec(type1, raw1.ctypes.data_as(VOID_PTR), n1, type2, None if raw2c is None else raw2c.ctypes.data_as(VOID_PTR), n2,
                                                    n_in, n_out, x.ctypes.data_as(FLOAT_PTR), None if x2c is None else x2c.ctypes.data_as(FLOAT_PTR), prep, int(fuse), epi,
                                                    None if res is None else res.ctypes.data_as(FLOAT_PTR), y.ctypes.data_as(FLOAT_PTR))

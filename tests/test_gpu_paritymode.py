@@ -216,3 +216,77 @@ def test_parity_mode_chat_from_the_raw_image_is_bit_identical(gpu_lib, tmpdir_mo
         gpu_lib.minigpt4_free_embedding(emb)
     finally:
         gpu_lib.minigpt4_free(ctx)
+
+
+def _rms_boundary_row(K, rng):
+    """A row whose sum of squares sits on a float rounding boundary of the mean: any parallel sum T has (float)(T(1-d)/K) != (float)(T(1+d)/K), so the kernels must take
+    the literal element-order loop (k_rms_quant's / the EPI_REF prologue's fallback, ~1e-4 of real rows) to land on the oracle's side of the boundary."""
+    x = rng.standard_normal(K).astype(np.float32)
+    sq = (x * x).astype(np.float32).astype(np.float64)
+    rest = 0.0
+    for v in sq[:-1]:
+        rest += v
+    m0 = np.float32(rest / K)
+    up = np.nextafter(m0, np.float32(np.inf))
+    mid = (np.float64(m0) + np.float64(up)) / 2.0
+    if mid * K <= rest:                                                  # the midpoint above rest / K
+        mid = (np.float64(up) + np.float64(np.nextafter(up, np.float32(np.inf)))) / 2.0
+    need = mid * K - rest                                                # what the last element's fl(x^2) has to add
+    c0 = np.float32(np.sqrt(need))
+    best, best_err = c0, np.inf
+    c = c0
+    for _ in range(4000):
+        c = np.nextafter(c, np.float32(0))
+    for _ in range(8000):
+        err = abs(rest + np.float64(np.float32(c * c)) - mid * K)
+        if err < best_err:
+            best, best_err = c, err
+        c = np.nextafter(c, np.float32(np.inf))
+    x[-1] = best
+    T = rest + np.float64(np.float32(best * best))
+    d = K * 4e-16
+    assert np.float32(T * (1 - d) / K) != np.float32(T * (1 + d) / K), "the crafted row does not straddle a boundary"
+    return x
+
+
+@pytest.mark.parametrize("wtype,K", [("q4_k", 512), ("q5_k", 5120), ("q6_k", 5120), ("q5_k", 13824), ("q6_k", 13824), ("q4_k", 4096)])
+@pytest.mark.parametrize("prep,fuse", [(1, True), (1, False), (2, True), (2, False)])
+def test_oracle_order_matvec_is_bit_identical(gpu_lib, wtype, K, prep, fuse):
+    """The decode mat-vec in its oracle-order form (MATVEC_EPI_REF: block chain on the DPP crossbar, the oracle's rms mean in the prologue) against oracle/refcpu.c's
+    quantise + mul_mat on the identically prepared row: every bit, 1 and 3 matrices per launch, with and without residual -- including a row that forces the rms
+    interval check's fallback."""
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    from test_gpu_parity import _prepared_row
+    t = Q.NAME_TO_TYPE[wtype]
+    rng = np.random.default_rng(K * 11 + prep * 5 + int(fuse) + sum(map(ord, wtype)))
+    n_mat = 3 if prep == 1 else 1
+    rows = 2300 if K <= 5120 else 1100
+    raw = Q.quantize(t, (0.03 * rng.standard_normal((n_mat * rows, K))).astype(np.float32))
+    x2 = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float32) if prep == 1 else None
+    res = rng.standard_normal(n_mat * rows).astype(np.float32) if prep == 2 else None
+    for x in ((rng.standard_normal(K)).astype(np.float32),) + ((_rms_boundary_row(K, rng),) if prep == 1 else ()):
+        got = gpu_lib.amd_test_matvec(t, raw, n_mat, K, rows, x, x2, prep=prep, fuse=fuse, epi=2, residual=res).reshape(-1)
+        want = R.mul_mat(t, raw, K, n_mat * rows, _prepared_row(prep, x, x2, None)[None, :])[0]
+        if res is not None:
+            want = want + res
+        assert np.array_equal(got, want), (wtype, K, prep, fuse, float(np.abs(got - want).max()))
+
+
+@pytest.mark.parametrize("t1,K", [("q5_k", 5120), ("q4_k", 4096)])
+@pytest.mark.parametrize("fuse", [False, True])
+def test_oracle_order_mixed_type_launch_is_bit_identical(gpu_lib, t1, K, fuse):
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    from test_gpu_parity import _prepared_row
+    ta, tb = Q.NAME_TO_TYPE[t1], Q.NAME_TO_TYPE["q6_k"]
+    rng = np.random.default_rng(K * 3 + int(fuse) + 17)
+    rows = 1500
+    ra = Q.quantize(ta, (0.03 * rng.standard_normal((2 * rows, K))).astype(np.float32))
+    rb = Q.quantize(tb, (0.03 * rng.standard_normal((rows, K))).astype(np.float32))
+    x = rng.standard_normal(K).astype(np.float32)
+    nw = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float32)
+    got = gpu_lib.amd_test_matvec(ta, ra, 2, K, rows, x, nw, prep=1, fuse=fuse, epi=2, type2=tb, raw2=rb).reshape(-1)
+    row = _prepared_row(1, x, nw, None)[None, :]
+    want = np.concatenate([R.mul_mat(ta, ra, K, 2 * rows, row)[0], R.mul_mat(tb, rb, K, rows, row)[0]])
+    assert np.array_equal(got, want)
