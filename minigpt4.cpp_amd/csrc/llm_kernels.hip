@@ -386,11 +386,69 @@ bool launch_mul_mat_ref_set(const QWeight *const *W, float *const *y, const floa
     default: return false;                       // (Q8_0 / Q2_K / F16 / F32 rows have other unit widths: the generic kernel serves them)
     }
 }
+// Prompt rows in parity mode: one wave per WEIGHT row (persistent over rows wave, wave + n_waves, ...), the row's units in registers for all N activation rows -- the
+// generic kernel above re-reads the weights once per (output, activation row).  The chain per (row, activation row) is ref_chain's: bit-identical to k_mul_mat_ref.
+template <int T, int NU>
+__global__ __launch_bounds__(256) void k_mul_mat_ref_rows(const QWeight W, const ActQ A, const int N, float *y, const int ldy, const float *residual) {
+    using X = Tr<T>;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), n_waves = (int)gridDim.x * 4;
+    const int K = W.cols, U = K / X::EPU, rows = W.rows;
+    bool ok[NU]; int uc[NU];
+#pragma unroll
+    for (int i = 0; i < NU; i++) { const int u = lane + 64 * i; ok[i] = u < U; uc[i] = ok[i] ? u : 0; }
+    for (int row = wave; row < rows; row += n_waves) {
+        typename X::WU w[NU];
+#pragma unroll
+        for (int i = 0; i < NU; i++) X::loadw(W, (size_t)row * U, uc[i], w[i]);
+        typename X::AU a0[NU], a1[NU];              // two statically named stages: the next activation row is in flight while this one is chained
+#pragma unroll
+        for (int i = 0; i < NU; i++) X::loada(A, 0, K, uc[i], a0[i]);
+        for (int t = 0; t < N;) {
+#pragma unroll
+            for (int i = 0; i < NU; i++) X::loada(A, min(t + 1, N - 1), K, uc[i], a1[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            { const float acc = ref_chain<T, NU>(w, a0, ok, U); if (lane == 0) { const size_t o = (size_t)t * ldy + row; y[o] = residual ? acc + residual[o] : acc; } }
+            __builtin_amdgcn_sched_barrier(0);
+            if (++t >= N) break;
+#pragma unroll
+            for (int i = 0; i < NU; i++) X::loada(A, min(t + 1, N - 1), K, uc[i], a0[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            { const float acc = ref_chain<T, NU>(w, a1, ok, U); if (lane == 0) { const size_t o = (size_t)t * ldy + row; y[o] = residual ? acc + residual[o] : acc; } }
+            __builtin_amdgcn_sched_barrier(0);
+            ++t;
+        }
+    }
+}
+template <int T> static bool launch_mul_mat_ref_rows_t(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
+    const int U = W.cols / Tr<T>::EPU, nu = (U + 63) / 64;
+    const dim3 grid((unsigned)std::max(1, std::min((W.rows + 3) / 4, g_ref_cus * 4)));
+    note_kernel("k_mul_mat_ref_rows<%d, %d>", T, nu);
+    switch (nu) {
+    case 1: hipLaunchKernelGGL((k_mul_mat_ref_rows<T, 1>), grid, dim3(256), 0, s, W, A, N, y, ldy, residual); return true;
+    case 2: hipLaunchKernelGGL((k_mul_mat_ref_rows<T, 2>), grid, dim3(256), 0, s, W, A, N, y, ldy, residual); return true;
+    case 3: hipLaunchKernelGGL((k_mul_mat_ref_rows<T, 3>), grid, dim3(256), 0, s, W, A, N, y, ldy, residual); return true;
+    case 4: hipLaunchKernelGGL((k_mul_mat_ref_rows<T, 4>), grid, dim3(256), 0, s, W, A, N, y, ldy, residual); return true;
+    case 6: hipLaunchKernelGGL((k_mul_mat_ref_rows<T, 6>), grid, dim3(256), 0, s, W, A, N, y, ldy, residual); return true;
+    case 7: hipLaunchKernelGGL((k_mul_mat_ref_rows<T, 7>), grid, dim3(256), 0, s, W, A, N, y, ldy, residual); return true;
+    default: return false;
+    }
+}
 template <int T> static void launch_mul_mat_ref_t(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
     note_kernel("k_mul_mat_ref<%d>", T);
     hipLaunchKernelGGL((k_mul_mat_ref<T>), dim3((unsigned)((W.rows + 3) / 4), (unsigned)N), dim3(256), 0, s, W, A, N, y, ldy, residual);
 }
 void launch_mul_mat_ref(const QWeight &W, const ActQ &A, int N, float *y, int ldy, const float *residual, hipStream_t s) {
+    if (N > 1) {   // prompt rows: the weight row stays in registers for all N activation rows (k-quants; the other types and unit counts take the generic kernel)
+        bool done = false;
+        switch (W.type) {
+        case GT_Q4_K: done = launch_mul_mat_ref_rows_t<GT_Q4_K>(W, A, N, y, ldy, residual, s); break;
+        case GT_Q5_K: done = launch_mul_mat_ref_rows_t<GT_Q5_K>(W, A, N, y, ldy, residual, s); break;
+        case GT_Q6_K: done = launch_mul_mat_ref_rows_t<GT_Q6_K>(W, A, N, y, ldy, residual, s); break;
+        default: break;
+        }
+        if (done) return;
+    }
     switch (W.type) {
     case GT_Q4_0: launch_mul_mat_ref_t<GT_Q4_0>(W, A, N, y, ldy, residual, s); break;
     case GT_Q4_1: launch_mul_mat_ref_t<GT_Q4_1>(W, A, N, y, ldy, residual, s); break;
