@@ -684,7 +684,16 @@ void Engine::forward_ref(int N, bool from_tokens, hipStream_t s, bool feed) {
                     for (int i = 0; i < run; i++) launch_mul_mat_ref(*W[done + i], act_, N, Y[done + i], W[done + i]->rows, res, s);
                 done += run;
             }
-        } else for (int i = 0; i < n; i++) launch_mul_mat_ref(*W[i], act_, N, Y[i], W[i]->rows, res, s);
+        } else {
+            // prompt rows: the int8-MFMA kernels WITHOUT a K split add every output's per-block terms block after block -- the oracle's order (bit-identical: test_gpu_paritymode);
+            // runs of equal type / shape in one launch each, anything they refuse on the oracle-order row kernels
+            while (done < n) {
+                int run = 1; while (done + run < n && W[done + run]->type == W[done]->type && W[done + run]->rows == W[done]->rows && W[done + run]->cols == W[done]->cols) run++;
+                if (!(N >= 5 && launch_mmq2_set(W + done, Y + done, res ? R + done : nullptr, run, act_, N, W[done]->rows, s, nullptr, 1)))
+                    for (int i = 0; i < run; i++) launch_mul_mat_ref(*W[done + i], act_, N, Y[done + i], W[done + i]->rows, res, s);
+                done += run;
+            }
+        }
     };
     // One row without a trace (the decode step): the fast step's launch structure -- row preparation in the mat-vec prologues, wq | wk (| wv) and w1 | w3 as set launches --
     // on the oracle-order variants of the same kernels (MATVEC_EPI_REF); a set those kernels refuse (non-k-quant types) takes the standalone preparation + row kernels below.

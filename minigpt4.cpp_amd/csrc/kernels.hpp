@@ -45,7 +45,8 @@ void launch_rms_quant_slabs(const SlabSrc &src, const float *w, int N, int K, co
 void launch_silu_mul_quant_slabs(const SlabSrc &src, int N, int K, const ActQ &A, int mask, const Tables &tb, hipStream_t s);   // n == 2: silu(a) * b, quantised
 void launch_rope_kv_slabs(const SlabSrc &src, int N, int n_head, int hd, const int *n_past, const float *cos_tab, const float *sin_tab, __half *kcache, __half *vcache, hipStream_t s);   // n == 3
 // defer != nullptr: with a K split the combine launch is skipped and *defer describes the slabs (ks > 1); otherwise *defer is cleared
-bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s, SlabSrc *defer = nullptr);
+bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s, SlabSrc *defer = nullptr,
+                     int force_ks = 0);   // force_ks == 1: no K split = the CPU oracle's fp32 order (parity mode's prompt rows)
 void set_mmq2_cus(int cus);
 // (test library only: measured in round 4, not adopted) prompt mat-mul on load-time digit planes (mmq3_kernels.hip): Q4_K / Q5_K, sub-block scale x quant stored as 128 hi + lo (1.5 B per weight) in MFMA-fragment order
 bool mmq3_supported(int type, int rows, int cols);

@@ -650,7 +650,8 @@ static void mmq2_launch_tt(int type, dim3 grid, size_t lds, hipStream_t s, const
 // 28.3 (profiles/r02x_prefill_single_wave_workgroups_microbench.log).  The WPB template parameter stays at 4.)
 
 // 1..3 same-type, same-shape matrices against the N prepared activation rows in one launch.  y[m][t * ldy + r] (+ residual[m][..]).  false -> shape outside the
-// kernel's range (nothing launched).
+// kernel's range (nothing launched).  force_ks == 1: no K split -- every output is then the CPU oracle's value bit for bit (exact integer block sums, the per-block fp32 updates
+// in block order: tests/test_gpu_paritymode.py), which is how parity mode runs its prompt rows.
 void launch_slab_flush(const SlabSrc &src, hipStream_t s) {
     if (src.ks <= 1) return;
     if (src.mixed) {   // matrices of two launches: one combine per matrix that was split
@@ -662,7 +663,7 @@ void launch_slab_flush(const SlabSrc &src, hipStream_t s) {
     for (int i = 0; i < src.n; i++) { rs.y[i] = src.y[i]; rs.res[i] = src.res[i]; }
     hipLaunchKernelGGL(k_mmq2_reduce_set, dim3((unsigned)((n4 + 255) / 256), (unsigned)src.n), dim3(256), 0, s, src.ws, src.ks, src.stride, rs, n4);
 }
-bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s, SlabSrc *defer) {
+bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s, SlabSrc *defer, int force_ks) {
     if (defer) *defer = SlabSrc{};
     if (n < 1 || n > 3 || N < 1 || (W[0]->type == GT_Q4_0 ? !(A.q80 && A.d0) : !A.bsq)) return false;
     for (int i = 0; i < n; i++) if (!mmq2_supported(W[i]->type, W[i]->rows, W[i]->cols) || W[i]->type != W[0]->type || W[i]->rows != W[0]->rows || W[i]->cols != W[0]->cols) return false;
@@ -687,6 +688,7 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     const int fill_pct = fill_env ? fill_env : (std::min(W[0]->rows, W[0]->cols) >= 5120 ? 150 : 200);
     while (wgs * ks * 100 < fill_pct * g_mmq2_cus && NSB / (ks + 1) >= 4 && A.ws && (size_t)(ks + 1) * out_floats * n <= A.ws_floats) ks++;
     if (g_mmq2_ks > 0) ks = std::max(1, std::min(g_mmq2_ks, std::min(NSB, A.ws ? (int)(A.ws_floats / std::max<size_t>(1, out_floats * n)) : 1)));
+    if (force_ks == 1) ks = 1;   // parity mode: without a K split the kernels add a row's per-block terms block after block -- the CPU oracle's order, bit for bit
     a.sb_per_split = (NSB + ks - 1) / ks;
     ks = (NSB + a.sb_per_split - 1) / a.sb_per_split;
     if (ks > 1) {

@@ -290,3 +290,25 @@ def test_oracle_order_mixed_type_launch_is_bit_identical(gpu_lib, t1, K, fuse):
     row = _prepared_row(1, x, nw, None)[None, :]
     want = np.concatenate([R.mul_mat(ta, ra, K, 2 * rows, row)[0], R.mul_mat(tb, rb, K, rows, row)[0]])
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("wtype", ["q4_k", "q5_k", "q6_k", "q4_0"])
+@pytest.mark.parametrize("case", [(142, 5120, 384, 1, True), (70, 13824, 256, 1, False), (33, 2048, 130, 3, False), (512, 2560, 128, 1, True), (5, 768, 70, 2, False)],
+                         ids=lambda c: "N%d_K%d_R%d_m%d_res%d" % c)
+def test_prompt_matmul_without_k_split_is_the_oracle_bit_for_bit(gpu_lib, wtype, case):
+    """The int8-MFMA prompt kernels (mmq2) add an output's per-block fp32 terms block after block; with the K split forced to 1 that IS oracle/refcpu.c's order, so the
+    result must equal the oracle's in every bit (integer block sums are exact in any order) -- this is how parity mode runs its prompt rows."""
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    N, K, rows, nm, with_res = case
+    t = Q.NAME_TO_TYPE[wtype]
+    rng = np.random.default_rng(sum(map(ord, wtype)) * 31 + sum(case))
+    raw = Q.quantize(t, (0.05 * rng.standard_normal((nm * rows, K))).astype(np.float32))
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    x[N // 2, : min(256, K)] = 0.0
+    res = rng.standard_normal((nm, N, rows)).astype(np.float32) if with_res else None
+    got = gpu_lib.amd_test_mmq2(t, raw, nm, K, rows, x, residual=res, ks=1)
+    want = R.mul_mat(t, raw, K, nm * rows, x).reshape(N, nm, rows).transpose(1, 0, 2)
+    if with_res:
+        want = want + res
+    assert np.array_equal(got, want), (wtype, case, float(np.abs(got - want).max()))
