@@ -490,7 +490,12 @@ def main():
             lib.amd_set_conversations(ctx, 1)
         lib.amd_set_parity(ctx, True)
         lib.minigpt4_reset_chat(ctx); lib.minigpt4_system_prompt(ctx); lib.minigpt4_begin_chat_image(ctx, emb, PROMPT)
-        for _ in range(4):
+        lib.minigpt4_end_chat_image(ctx, temp=0.0); lib.library.minigpt4_amd_sync(ctx.ptr)
+        lib.minigpt4_reset_chat(ctx); lib.library.minigpt4_amd_sync(ctx.ptr)     # second pass, timed like prefill_ms: system prompt + image turn (one deferred pass) + the first token
+        t0 = time.perf_counter()
+        lib.minigpt4_system_prompt(ctx); lib.minigpt4_begin_chat_image(ctx, emb, PROMPT); lib.minigpt4_end_chat_image(ctx, temp=0.0); lib.library.minigpt4_amd_sync(ctx.ptr)
+        out["parity_mode_prefill_plus_first_token_ms"] = (time.perf_counter() - t0) * 1e3
+        for _ in range(3):
             lib.minigpt4_end_chat_image(ctx, temp=0.0)
         lib.library.minigpt4_amd_sync(ctx.ptr)
         t0 = time.perf_counter()
