@@ -50,15 +50,17 @@ def model_dir():
 def make_models(config: str, rank: int, world: int, barrier):
     from minigpt4_cpp_amd import modelgen as G
     d = model_dir()
-    if config in ("13b", "7b"):
-        vcfg, ub = (G.vision_13b() if config == "13b" else G.vision_7b()), 1
+    vname = config
+    if config != "tiny":
+        vname = "7b" if config.startswith("7b") else "13b"  # the vision file depends on the LLM width only
+        vcfg, ub = (G.vision_13b() if vname == "13b" else G.vision_7b()), 1
         lcfg, lkw = G.headline_llm(config)                 # the same files tests/test_gpu_headline.py checks against the oracle (oracle/headline.py::headline_files)
         lname = f"llm_{config}_r3.bin"
     else:
         vcfg, ub = G.tiny_vision(n_embd_llm=4096), None
         lcfg, lkw = G.tiny_llm(wtype="q5_k", n_embd=4096, n_layer=2, n_head=32, n_vocab=2048, mix="q5_k_m"), dict(seed=1234, std=0.02, fast=True)
         lname = "llm_tiny.bin"
-    vp, lp = os.path.join(d, f"vision_{config}.bin"), os.path.join(d, lname)
+    vp, lp = os.path.join(d, f"vision_{vname}.bin"), os.path.join(d, lname)
     if rank == 0:
         t0 = time.time()
         if not os.path.exists(vp + ".ok"):
@@ -173,12 +175,13 @@ def extra_config_legs(lib, budget_s: float) -> dict:
 
     def young():
         return time.time() - T_PROCESS_START < budget_s
-    # configs[1]: MiniGPT4-7B f16 vision + Vicuna-7B Q4_0, batch 1, 128 greedy tokens through the C ABI
-    try:
-        if not young():
-            res["7b_q4_0_decode128"] = {"skipped": f"run older than {budget_s:.0f} s"}
-        else:
-            vp, lp, vcfg, lcfg = make_models("7b", 0, 1, lambda: None)
+    def decode_leg(key, config, workload, keep_file=True):
+        """128 greedy tokens through the C ABI (reference call sequence) on the synthetic file `config` names; own context, freed afterwards."""
+        try:
+            if not young():
+                res[key] = {"skipped": f"run older than {budget_s:.0f} s"}
+                return
+            vp, lp, vcfg, lcfg = make_models(config, 0, 1, lambda: None)
             ctx = lib.minigpt4_model_load(vp, lp, verbosity=0, seed=1337, n_ctx=2048, n_batch=512)
             try:
                 emb = lib.minigpt4_encode_image(ctx, ML.array_to_image_struct(G.synth_image(42)))
@@ -188,19 +191,31 @@ def extra_config_legs(lib, budget_s: float) -> dict:
                     lib.minigpt4_end_chat_image(ctx, temp=0.0)
                 lib.library.minigpt4_amd_sync(ctx.ptr)
                 t0 = time.perf_counter()
-                for _ in range(128):
-                    lib.minigpt4_end_chat_image(ctx, temp=0.0)
+                ids = [lib.minigpt4_end_chat_image(ctx, temp=0.0) for _ in range(128)]
                 lib.library.minigpt4_amd_sync(ctx.ptr)
                 dt = time.perf_counter() - t0
                 wb = lib.library.minigpt4_amd_weight_bytes_per_token(ctx.ptr)
                 kv = 4.0 * lcfg.n_embd * lcfg.n_layer * (n_prompt + 8 + 64)
-                res["7b_q4_0_decode128"] = {"tokens_per_s": 128 / dt, "ms_per_step": dt * 1e3 / 128, "weight_bytes_per_token": wb, "GBps": (wb + kv) / (dt / 128) / 1e9,
-                                            "frac_of_8TBps": (wb + kv) / (dt / 128) / 1e9 / HBM_PEAK_GBPS, "prompt_tokens": n_prompt,
-                                            "workload": "MiniGPT4-7B f16 vision + Vicuna-7B Q4_0 (output Q6_K), batch 1, 128 greedy tokens through the C ABI (BASELINE.json configs[1])"}
+                res[key] = {"tokens_per_s": 128 / dt, "ms_per_step": dt * 1e3 / 128, "weight_bytes_per_token": wb, "GBps": (wb + kv) / (dt / 128) / 1e9,
+                            "frac_of_8TBps": (wb + kv) / (dt / 128) / 1e9 / HBM_PEAK_GBPS, "prompt_tokens": n_prompt, "distinct_pieces": len(set(ids)), "workload": workload}
             finally:
                 lib.minigpt4_free(ctx)
-    except Exception as e:
-        res["7b_q4_0_decode128"] = {"error": str(e)[:300]}
+            if not keep_file:                       # the file serves this leg only: give the space back (the 26 GB f16 file of the last leg needs it)
+                for suffix in ("", ".ok"):
+                    try:
+                        os.remove(lp + suffix)
+                    except OSError:
+                        pass
+        except Exception as e:
+            res[key] = {"error": str(e)[:300]}
+    # configs[1]: MiniGPT4-7B f16 vision + Vicuna-7B Q4_0, batch 1, 128 greedy tokens through the C ABI
+    decode_leg("7b_q4_0_decode128", "7b", "MiniGPT4-7B f16 vision + Vicuna-7B Q4_0 (output Q6_K), batch 1, 128 greedy tokens through the C ABI (BASELINE.json configs[1])")
+    # round 5: the type mix of the file a user of the reference really loads (n_vocab 32001 -> output.weight F16, tok_embeddings Q4_0: 9.310 GB per token), and the two other
+    # block types north_star names (Q8_0, Q4_1) as whole-model decode rates
+    decode_leg("13b_q5k_vocab32001_decode128", "13b_v32001", "MiniGPT4-13B f16 vision + Vicuna-13B Q5_K_M with Vicuna-v0's real n_vocab = 32001 (llama.cpp's k-quant fallback: output.weight F16, "
+               "tok_embeddings Q4_0), batch 1, 128 greedy tokens through the C ABI", keep_file=False)
+    decode_leg("7b_q8_0_decode128", "7b_q8_0", "MiniGPT4-7B f16 vision + Vicuna-7B Q8_0 (every matrix), batch 1, 128 greedy tokens through the C ABI", keep_file=False)
+    decode_leg("7b_q4_1_decode128", "7b_q4_1", "MiniGPT4-7B f16 vision + Vicuna-7B Q4_1 (every matrix), batch 1, 128 greedy tokens through the C ABI", keep_file=False)
     # configs[4]: Vicuna-13B f16 (unquantised), one 512-token llama_eval on the MFMA GEMMs
     try:
         if not young():

@@ -521,7 +521,7 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
     // groups of this wave: g = g_first, g_first + g_step, ... < g_last
     const int g_first = wave, g_last = n_groups, g_step = n_waves;
     MG4_TL(0); MG4_TL_ALL(7);
-    using X = Tr<T>;
+    using X = TrMV<T>;
     const int lane = threadIdx.x & 63;
     const int K = ms.w0.cols, U = K / X::EPU, rows_each = ms.rows_each, total_rows = ms.n * rows_each;
     int uc[NU]; bool ok[NU];
@@ -574,10 +574,11 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
         L.s1 = reinterpret_cast<float *>(p); p += (size_t)(K / 32) * 4;
         L.sum0 = reinterpret_cast<int *>(p); p += (size_t)(K / 32) * 4;
         L.bsk = reinterpret_cast<int16_t *>(p); p += (size_t)(K / 16) * 2;
-        L.xh = nullptr; L.xf = nullptr;
-        constexpr int RND = (NU * 512 + MV_FAT_MIN - 1) / MV_FAT_MIN;    // K <= NU * 2048 elements, 4 per thread per round, >= MV_FAT_MIN threads
+        L.xh = reinterpret_cast<__half *>(smem_mv + 128);                // F16 weights: the fp16 row takes the place of the two int8 images (2 K bytes)
+        L.xf = nullptr;
+        constexpr int RND = (NU * 64 * X::EPU / 4 + MV_FAT_MIN - 1) / MV_FAT_MIN;    // K <= NU * 64 * EPU elements, 4 per thread per round, >= MV_FAT_MIN threads
         const int nthr = (int)blockDim.x;
-        constexpr int mask = (T == GT_Q4_K || T == GT_Q5_K || T == GT_Q6_K) ? ACT_Q8K : ACT_Q80;
+        constexpr int mask = T == GT_F16 ? ACT_F16 : (T == GT_Q4_K || T == GT_Q5_K || T == GT_Q6_K) ? ACT_Q8K : ACT_Q80;
         float4 xv[RND], yv[RND];
         bool in[RND];
 #pragma unroll
@@ -749,6 +750,27 @@ static void launch_v2_t(const MatSet &ms, const ActQ &A, int pro, const ProArgs 
 #ifndef MG4_R_NU2
 #define MG4_R_NU2 1
 #endif
+// Q8_0 / F16 (16-byte units of 16 / 8 weights): a row needs more units per lane than the 32-weight types, and only a few unit counts are instantiated -- a row takes the
+// smallest one that covers it (the surplus units are masked like any ragged tail).  Q8_0: K <= 1024 | 4096 | 5120 | 11264; F16: K <= 512 | 1024 | 4096 | 5120.
+template <int T>
+static bool launch_v2_narrow(const MatSet &ms, const ActQ &A, int pro, const ProArgs &pa, int epi, hipStream_t s) {
+    if (epi != EPI_STORE) return false;
+    const int nu = (ms.w0.cols / TrMV<T>::EPU + 63) / 64;
+    if constexpr (T == GT_Q8_0) {
+        if (nu <= 1) launch_v2_t<T, 1, 2, EPI_STORE>(ms, A, pro, pa, s);
+        else if (nu <= 4) launch_v2_t<T, 4, 1, EPI_STORE>(ms, A, pro, pa, s);
+        else if (nu <= 5) launch_v2_t<T, 5, 1, EPI_STORE>(ms, A, pro, pa, s);
+        else if (nu <= 11) launch_v2_t<T, 11, 1, EPI_STORE>(ms, A, pro, pa, s);
+        else return false;
+    } else {
+        if (nu <= 1) launch_v2_t<T, 1, 2, EPI_STORE>(ms, A, pro, pa, s);
+        else if (nu <= 2) launch_v2_t<T, 2, 1, EPI_STORE>(ms, A, pro, pa, s);
+        else if (nu <= 8) launch_v2_t<T, 8, 1, EPI_STORE>(ms, A, pro, pa, s);
+        else if (nu <= 10) launch_v2_t<T, 10, 1, EPI_STORE>(ms, A, pro, pa, s);
+        else return false;
+    }
+    return true;
+}
 template <int T>
 static bool launch_v2_type(const MatSet &ms, const ActQ &A, int pro, const ProArgs &pa, int epi, hipStream_t s) {
     const int U = ms.w0.cols / Tr<T>::EPU;
@@ -807,7 +829,7 @@ int read_matvec_timeline(unsigned long long *out, int max_workgroups) {
     (void)out; (void)max_workgroups; return 0;
 #endif
 }
-bool matvec_silu_pair_supported(int type, int cols) { return matvec_prologue_supported(type, cols) && cols / 32 <= 3 * 64; }
+bool matvec_silu_pair_supported(int type, int cols) { return type != GT_Q8_0 && type != GT_F16 && matvec_prologue_supported(type, cols) && cols / 32 <= 3 * 64; }
 
 static bool fill_matset(MatSet &ms, const QWeight *const *W, float *const *y, const float *const *residual, int n) {
     ms = MatSet{};
@@ -879,6 +901,8 @@ bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, con
     return false;
 }
 bool matvec_prologue_supported(int type, int cols) {
+    if (type == GT_Q8_0) return cols % 32 == 0 && cols <= 11 * 64 * 16;      // launch_v2_narrow's instantiations
+    if (type == GT_F16) return cols % 8 == 0 && cols <= 10 * 64 * 8;
     switch (type) { case GT_Q4_0: case GT_Q4_1: case GT_Q5_0: case GT_Q5_1: case GT_Q4_K: case GT_Q5_K: case GT_Q6_K: break; default: return false; }
     return cols % 32 == 0 && cols / 32 <= 7 * 64 && ((type != GT_Q4_K && type != GT_Q5_K && type != GT_Q6_K) || cols % 256 == 0);
 }
@@ -897,7 +921,9 @@ bool launch_matvec_set(const QWeight *const *W, float *const *y, const float *co
     case GT_Q4_K: return launch_v2_type<GT_Q4_K>(ms, A, pro, pa, epi, s);
     case GT_Q5_K: return launch_v2_type<GT_Q5_K>(ms, A, pro, pa, epi, s);
     case GT_Q6_K: return launch_v2_type<GT_Q6_K>(ms, A, pro, pa, epi, s);
-    default: return false;   // Q8_0 / F16 / F32 rows have more units per row: served by k_mul_mat
+    case GT_Q8_0: return launch_v2_narrow<GT_Q8_0>(ms, A, pro, pa, epi, s);
+    case GT_F16: return launch_v2_narrow<GT_F16>(ms, A, pro, pa, epi, s);
+    default: return false;   // F32 rows, and Q8_0 / F16 rows wider than launch_v2_narrow's instantiations: served by k_mul_mat
     }
 }
 

@@ -347,6 +347,35 @@ template <> struct Tr<GT_F32> {
 };
 
 // =====================================================================================================================
+// Decode mat-vec traits (k_matvec_v2): the unit traits above, plus buffer-descriptor loads for the two types whose 16-byte unit covers fewer than 32 weights -- Q8_0
+// (16 weights: half a block) and F16 (8 weights).  A lane's units stay lane-contiguous 16-byte pieces (u = lane + 64 i: every wave load instruction reads 1 KiB of whole
+// cache lines), so a row needs more units per lane than the 32-weight types (K = 5120: F16 10, Q8_0 5; K = 11008: Q8_0 11).  Q8_0: each HALF block is scaled by the
+// block's d on its own lane (d * (s_lo + s_hi) = d * s_lo + d * s_hi up to fp32 rounding; the oracle-order kernels keep the lane-pair sum of Tr<GT_Q8_0>).
+// The real Vicuna-v0 file has n_vocab = 32001, for which llama.cpp's k-quant mixes fall back to an F16 output matrix (327.7 MB streamed per token).
+// =====================================================================================================================
+template <int T> struct TrMV : Tr<T> {};
+template <> struct TrMV<GT_Q8_0> : Tr<GT_Q8_0> {
+    static __device__ __forceinline__ void mkb(const QWeight &W, size_t g0, WBuf &B) { B.qs = mkbuf(W.qs + g0 * 16); B.sc = mkbuf(W.sc + (g0 >> 1) * 2); }
+    static __device__ __forceinline__ void loadb(const WBuf &B, int u, WU &w) { w.q = bld16(B.qs, u * 16); w.dh = bld2(B.sc, (u >> 1) * 2); }
+    static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {
+        int s = 0;
+        s = dot4(w.q.x, a.a.x, s); s = dot4(w.q.y, a.a.y, s); s = dot4(w.q.z, a.a.z, s); s = dot4(w.q.w, a.a.w, s);
+        acc = fmaf(h2f_bits(w.dh) * a.d, (float)s, acc);
+    }
+};
+typedef _Float16 v2h_t __attribute__((ext_vector_type(2)));
+template <> struct TrMV<GT_F16> : Tr<GT_F16> {
+    static __device__ __forceinline__ void mkb(const QWeight &W, size_t g0, WBuf &B) { B.qs = mkbuf(W.qs + g0 * 16); }
+    static __device__ __forceinline__ void loadb(const WBuf &B, int u, WU &w) { w.q = bld16(B.qs, u * 16); }
+    static __device__ __forceinline__ void dot(const WU &w, const AU &a, float &acc) {   // v_dot2_f32_f16: exact fp16 products, fp32 accumulate
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h_t, w.q.x), __builtin_bit_cast(v2h_t, a.a.x), acc, false);
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h_t, w.q.y), __builtin_bit_cast(v2h_t, a.a.y), acc, false);
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h_t, w.q.z), __builtin_bit_cast(v2h_t, a.a.z), acc, false);
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h_t, w.q.w), __builtin_bit_cast(v2h_t, a.a.w), acc, false);
+    }
+};
+
+// =====================================================================================================================
 // activation preparation: (rms_norm * w | silu(a)*b | identity) -> {Q8_K, Q8_0/Q8_1, f16, f32}
 // thread t of a 256-thread group owns 4 consecutive values; a wave = one 256-wide Q8_K block, 8 lanes = one 32-wide block.
 // =====================================================================================================================

@@ -105,6 +105,15 @@ def headline_llm(config: str):
         cfg = llm_13b()
     elif config == "7b":
         cfg = llm_7b("q4_0")
+    elif config in ("7b_q8_0", "7b_q4_1"):
+        # the other two block types north_star names next to Q4_0 / Q5_K ("Q4_0/Q4_1/Q5_K/Q8_0 block dequant fused into the matvec"): every 2-D tensor of the 7B graph in that type
+        cfg = LLMConfig(n_vocab=32000, n_embd=4096, n_head=32, n_layer=32, wtype=config[3:], mix="none", ftype=7 if config == "7b_q8_0" else 3)
+    elif config == "13b_v32001":
+        # the type mix of the file a user of the reference really loads: Vicuna-v0 has n_vocab 32001 -> llama.cpp's k-quant fallback (llm_tensor_types): output.weight F16
+        # (327.7 MB streamed per token), tok_embeddings Q4_0; 9.310 GB per token
+        cfg = LLMConfig(n_vocab=32001, n_embd=5120, n_head=40, n_layer=40, wtype="q5_k", mix="q5_k_m", ftype=17)
+    elif config == "13b_v32001_l2":
+        cfg = LLMConfig(n_vocab=32001, n_embd=5120, n_head=40, n_layer=2, wtype="q5_k", mix="q5_k_m", ftype=17, more_bits_layers=(0,))
     elif config == "13b_l2":
         # the 13B graph at full width, two layers deep: layer 0 a "more bits" layer (wv / w2 in Q6_K: the mixed-type qkv launch, the Q6_K NU = 7 tiling), layer 1 a plain
         # Q5_K layer, output Q6_K -- every kernel instantiation / tiling / launch geometry of the 40-layer headline model
@@ -126,6 +135,14 @@ def llm_tensor_types(cfg: LLMConfig) -> Dict[str, int]:
     out: Dict[str, int] = {}
     otype = Q.NAME_TO_TYPE[cfg.output_type] if cfg.output_type else (Q.GGML_Q6_K if cfg.mix == "q5_k_m" else base)
     ttype = Q.NAME_TO_TYPE[cfg.tok_type] if cfg.tok_type else base
+    # llama.cpp's quantiser with k-quants on (the reference forces GGML_USE_K_QUANTS, /root/reference/CMakeLists.txt:317): a tensor whose ne[0] or ne[1] is not a multiple
+    # of QK_K = 256 cannot take a k-quant type and falls back -- output.weight to F16, tok_embeddings.weight to Q4_0.  Vicuna-v0 has n_vocab = 32001,
+    # so the file the reference's README names (ggml-vicuna-13B-v0-q5_k.bin, /root/reference/README.md:134) carries exactly that pair.
+    if cfg.n_vocab % 256 or cfg.n_embd % 256:
+        if not cfg.output_type and Q.BLOCK[otype][0] == 256:
+            otype = Q.GGML_F16
+        if not cfg.tok_type and Q.BLOCK[ttype][0] == 256:
+            ttype = Q.GGML_Q4_0
     for t in (otype, ttype, base):
         e, _ = Q.BLOCK[t]
         assert cfg.n_embd % e == 0 and cfg.n_ff % e == 0, "row length must be a multiple of the block size"

@@ -40,8 +40,8 @@ def headline_files(config: str):
     from minigpt4_cpp_amd import modelgen as G
     d = model_dir()
     lcfg, kw = G.headline_llm(config)
-    vcfg = G.vision_7b() if config == "7b" else G.vision_13b()
-    vname = "13b" if config == "13b_l2" else config
+    vcfg = G.vision_7b() if config.startswith("7b") else G.vision_13b()
+    vname = "7b" if config.startswith("7b") else "13b"          # the vision file depends on the LLM width only
     vp, lp = os.path.join(d, f"vision_{vname}.bin"), os.path.join(d, f"llm_{config}_r3.bin")
     if not os.path.exists(vp + ".ok"):
         G.write_vision_file(vp, vcfg, seed=4321, std=0.02, unique_blocks=1, fast=True)

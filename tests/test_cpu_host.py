@@ -184,6 +184,31 @@ def test_llm_file_layout_and_bytes_per_token(tiny_files):
     assert abs(G.llm_weight_bytes_per_token(G.llm_7b()) / 1e9 - 3.751) < 0.001
 
 
+def test_kquant_fallback_types_of_the_real_vicuna_v0_vocabulary(tmp_path):
+    """llama.cpp's k-quant quantiser cannot give a k-quant type to a tensor with a dimension that is not a multiple of 256: with Vicuna-v0's n_vocab = 32001 the file the
+    reference's README names (ggml-vicuna-13B-v0-q5_k.bin) has output.weight in F16 and tok_embeddings in Q4_0 -> 9.310 GB streamed per token.  The
+    generator applies that rule, the product's host-side loader and the oracle read such a file, and the oracle evaluates it."""
+    import refcpu as R
+    from minigpt4_cpp_amd import modelgen as G, quants as Q
+    cfg, _ = G.headline_llm("13b_v32001")
+    t = G.llm_tensor_types(cfg)
+    assert t["output.weight"] == Q.GGML_F16 and t["tok_embeddings.weight"] == Q.GGML_Q4_0
+    assert t["layers.0.attention.wv.weight"] == Q.GGML_Q6_K and t["layers.5.attention.wv.weight"] == Q.GGML_Q5_K and t["layers.5.feed_forward.w1.weight"] == Q.GGML_Q5_K
+    assert abs(G.llm_weight_bytes_per_token(cfg) / 1e9 - 9.310) < 0.001
+    for name, want in (("7b_q8_0", 7.021), ("7b_q4_1", 4.130)):
+        assert abs(G.llm_weight_bytes_per_token(G.headline_llm(name)[0]) / 1e9 - want) < 0.001
+    # an explicit type still wins; a vocabulary that IS a multiple of 256 keeps the k-quant types
+    assert G.llm_tensor_types(G.tiny_llm(wtype="q5_k", n_embd=256, n_vocab=513, mix="q5_k_m", output_type="q8_0"))["output.weight"] == Q.GGML_Q8_0
+    assert G.llm_tensor_types(G.tiny_llm(wtype="q5_k", n_embd=256, n_vocab=512, mix="q5_k_m"))["output.weight"] == Q.GGML_Q6_K
+    small = G.tiny_llm(wtype="q5_k", n_embd=256, n_layer=1, n_head=4, n_vocab=513, mix="q5_k_m")
+    lp = str(tmp_path / "oddv.bin")
+    G.write_llm_file(lp, small, seed=5, std=0.05)
+    f = G.read_llm_file(lp)
+    assert f.tensors["output.weight"].gtype == Q.GGML_F16 and f.tensors["output.weight"].ne == (256, 513) and f.tensors["tok_embeddings.weight"].gtype == Q.GGML_Q4_0
+    logits = R.OracleLLM(f, n_ctx=16).eval_tokens([1, 5, 512])          # 512: the last row of the odd vocabulary
+    assert logits.shape == (513,) and np.isfinite(logits).all()
+
+
 def test_product_loaders_parse_both_files_without_gpu(lib, tiny_files, tmp_path):
     from minigpt4_cpp_amd import modelgen as G
     vp, llm = tiny_files

@@ -100,7 +100,10 @@ def _silu_table():
 
 # (type, K): K / 32 / 64 = units per lane: 1, 2, 3, 6, 7 -> every register-tiling of the persistent-wave kernel; rows > 2048 waves -> several groups per wave
 MATVEC_CASES = [("q4_0", 512), ("q5_k", 512), ("q4_1", 4096), ("q4_k", 4096), ("q5_0", 5120), ("q5_k", 5120), ("q6_k", 5120), ("q5_1", 5120), ("q4_0", 11008),
-                ("q4_k", 11008), ("q5_k", 13824), ("q6_k", 13824)]
+                ("q4_k", 11008), ("q5_k", 13824), ("q6_k", 13824),
+                # round 5: Q8_0 / F16 rows on the same pipelined kernel (16-byte units of 16 / 8 weights: 1, 4, 5, 11 resp. 1, 2, 8, 10 units per lane; 2048 and 1024 take
+                # the next larger instantiation with masked surplus units) -- the real Vicuna-v0 file's F16 output matrix, the 7B Q8_0 file
+                ("q8_0", 512), ("q8_0", 2048), ("q8_0", 4096), ("q8_0", 5120), ("q8_0", 11008), ("f16", 256), ("f16", 1024), ("f16", 2040), ("f16", 4096), ("f16", 5120)]
 
 
 @pytest.mark.parametrize("wtype,K", MATVEC_CASES)
@@ -441,6 +444,52 @@ def test_chat_flow_with_image_end_to_end(gpu_lib, tmpdir_models):
         bot.free()
 
 
+def test_odd_vocabulary_kquant_fallback_chat_flow(gpu_lib, tmpdir_models):
+    """The type mix of the file a user of the reference really loads (ggml-vicuna-13B-v0-q5_k.bin, /root/reference/README.md:134): Vicuna-v0's n_vocab is 32001, not a
+    multiple of 256, so llama.cpp's k-quant mixes leave output.weight in F16 and tok_embeddings in Q4_0 (modelgen.llm_tensor_types).  Here at tiny size with an ODD vocabulary
+    (513: ragged last argmax partition, an F16 mat-vec with an odd row count, Q4_0 embedding rows) through the whole reference call sequence: greedy pieces identical and
+    logits within 1e-2 in fast mode, logits bit-identical in parity mode."""
+    import refcpu as R
+    from minigpt4_cpp_amd import minigpt4_library as ML, modelgen as G, quants as Q
+    vp = os.path.join(tmpdir_models, "vision_oddv.bin")
+    lp = os.path.join(tmpdir_models, "llm_oddv.bin")
+    G.write_vision_file(vp, G.tiny_vision(n_embd_llm=4096), seed=11, std=0.05)
+    cfg = G.tiny_llm(wtype="q5_k", n_embd=4096, n_layer=2, n_head=32, n_vocab=513, mix="q5_k_m")
+    types = G.llm_tensor_types(cfg)
+    assert types["output.weight"] == Q.GGML_F16 and types["tok_embeddings.weight"] == Q.GGML_Q4_0 and types["layers.0.attention.wq.weight"] == Q.GGML_Q5_K
+    G.write_llm_file(lp, cfg, seed=2, std=0.02, **G.TINY_CONDITIONED)
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=256, n_batch=64)
+    try:
+        img = G.synth_image(42)
+        emb = gpu_lib.minigpt4_encode_image(ctx, ML.array_to_image_struct(img))
+        emb_np = np.ctypeslib.as_array(emb.data, shape=(emb.n_embeddings,)).copy().reshape(32, -1)
+        for parity in (False, True):
+            gpu_lib.amd_set_parity(ctx, parity)
+            gpu_lib.minigpt4_reset_chat(ctx)
+            chat = R.OracleChat(R.OracleLLM(G.read_llm_file(lp), n_ctx=256), n_batch=64)
+            gpu_lib.minigpt4_system_prompt(ctx)
+            chat.system_prompt()
+            gpu_lib.minigpt4_begin_chat_image(ctx, emb, "what is the text in the picture?")
+            chat.begin_chat_image(emb_np, b"what is the text in the picture?")
+            ids = []
+            for step in range(16):
+                got, want = gpu_lib.amd_logits(ctx), chat.llm.logits
+                assert got.shape == (513,)
+                if parity:
+                    assert np.array_equal(got, want), (step, float(np.abs(got - want).max()))
+                else:
+                    assert _rel(got, want) <= LOGIT_TOL, (step, _rel(got, want))
+                piece = gpu_lib.minigpt4_end_chat_image(ctx, temp=0.0)
+                tid, opiece = chat.end_chat(temp=0.0)
+                assert piece == opiece.decode("utf-8", errors="replace"), (parity, step)
+                ids.append(int(tid))
+            assert len(set(ids)) >= 6, ids
+        gpu_lib.amd_set_parity(ctx, False)
+        gpu_lib.minigpt4_free_embedding(emb)
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+
+
 def test_decode_loop_device_feedback_equals_api_path(gpu_lib, tiny_files):
     vp, llm = tiny_files
     lp = llm("q5_k", "q5_k_m")
@@ -485,7 +534,7 @@ def test_context_overflow_is_reported_not_fatal(gpu_lib, tiny_files):
         gpu_lib.minigpt4_free(ctx)
 
 
-@pytest.mark.parametrize("wtype,rows,cols", [("q5_k", 5120, 13824), ("q6_k", 32000, 5120), ("q4_0", 4096, 11008)])
+@pytest.mark.parametrize("wtype,rows,cols", [("q5_k", 5120, 13824), ("q6_k", 32000, 5120), ("q4_0", 4096, 11008), ("f16", 32001, 5120), ("q8_0", 4096, 11008)])
 def test_full_size_matvec_properties(gpu_lib, wtype, rows, cols):
     """BASELINE-size mat-vecs (13B w2, 13B output matrix, 7B w2): sampled rows against the oracle, plus size-independent properties --
     exact linearity in a power-of-two scaling of the weights' block scales, and row-permutation consistency."""
@@ -511,6 +560,31 @@ def test_full_size_matvec_properties(gpu_lib, wtype, rows, cols):
     assert np.array_equal(got_p, got[perm])
     # a checksum of the output equals the dot of the column-summed dequantised weights with the dequantised activations (fp64), loosely
     assert abs(float(got.astype(np.float64).sum())) < 1e6
+
+
+@pytest.mark.parametrize("wtype,rows,cols", [("f16", 32001, 5120), ("q8_0", 4096, 11008)])
+def test_full_size_narrow_unit_matvec_on_the_pipelined_kernel(gpu_lib, wtype, rows, cols):
+    """The real Vicuna-v0 output matrix (F16, 32001 x 5120: an ODD row count over the persistent waves) and the 7B Q8_0 w2 (11 units per lane) through the decode path's own
+    launch (k_matvec_v2 with the rms-norm prologue): sampled rows against the oracle on the identically prepared row, every row finite, and the launch's result equal to
+    the generic tile kernel's (k_mul_mat: a different summation order) within fp32 noise on ALL rows."""
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    t = Q.NAME_TO_TYPE[wtype]
+    rng = np.random.default_rng(rows + cols)
+    pool = (0.02 * rng.standard_normal(1 << 22)).astype(np.float32)
+    raw = Q.quantize(t, np.resize(pool, rows * cols))
+    x = rng.standard_normal(cols).astype(np.float32)
+    nw = (1.0 + 0.2 * rng.standard_normal(cols)).astype(np.float32)
+    got = gpu_lib.amd_test_matvec(t, raw, 1, cols, rows, x, nw, prep=1, fuse=True).reshape(-1)
+    assert got.shape == (rows,) and np.isfinite(got).all()
+    row = _prepared_row(1, x, nw, None)
+    rb = Q.nbytes(t, cols)
+    pick = np.concatenate([rng.choice(rows, 94, replace=False), [0, rows - 1]])
+    sub = np.concatenate([raw[r * rb:(r + 1) * rb] for r in pick])
+    want = R.mul_mat(t, sub, cols, len(pick), row[None, :])[0]
+    assert np.abs(got[pick] - want).max() <= 2e-5 * np.abs(want).max()
+    generic = gpu_lib.amd_test_mul_mat(t, raw, cols, rows, row[None, :])[0]
+    assert np.abs(got - generic).max() <= 2e-5 * np.abs(generic).max()
 
 
 def test_long_context_decode_matches_oracle(gpu_lib, tiny_files):
