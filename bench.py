@@ -552,6 +552,7 @@ def main():
             out["parity"]["parity_mode"] = H.gpu_parity_mode_run(lib, ctx, emb, orc)   # MINIGPT4_PARITY: oracle-order accumulation -> logits bit-identical, free-running
             out["parity"]["oracle_prefill_s"] = orc["prefill_s"]
             out["parity"]["oracle_self_noise"] = H.oracle_self_noise(lp, emb_np, orc, eps=1e-6, n_ctx=320, threads=max(1, min(usable, 32)))
+            out["parity"]["oracle_order_spread"] = H.oracle_order_spread(lp, emb_np, orc, n_ctx=320, threads=max(1, min(usable, 32)))   # order 0 (one chain) vs order 1 (ggml's lane partials)
             out["parity"]["note"] = ("GPU vs CPU oracle on THIS run's files: system_prompt + begin_chat_image + greedy steps; free_running_identical counts the measured (fast) path's greedy pieces, "
                                      "`decided` = steps whose oracle top-2 margin exceeds 2x the largest observed logit difference; max_logit_rel = max |delta| / max |logit| per step (north_star: "
                                      "<= 1e-2), max_logit_rel_range = the same over (max - min); parity_mode = the engine with MINIGPT4_PARITY (per-block fp32 terms added in the oracle's order): "

@@ -96,6 +96,25 @@ def oracle_self_noise(lp: str, embedding: np.ndarray, base: Dict, eps: float = 1
     return {"eps": eps, "max_logit_rel_range": float(rel.max()), "mean_logit_rel_range": float(rel.mean()), "argmax_identical": int((pl.argmax(axis=1) == ol.argmax(axis=1)).sum())}
 
 
+def oracle_order_spread(lp: str, embedding: np.ndarray, base: Dict, native: bool = False, **kw) -> Dict:
+    """The oracle against ITSELF in its other fp32 accumulation order (refcpu.c `orc_set_order(1)`: ggml's own x86 structure as best recalled -- eight lane partials per
+    row, fmadd per block, hsum at the end -- where `base` was computed in order 0, one fma chain per output), same image embedding, teacher-forced on base's ids.  Neither
+    order is pinned to a ggml binary; the spread between them is what "bit-exact against the reference" can mean at best on this file, and it is the yardstick for the
+    GPU's fast mode (which differs from BOTH only by its own summation order).  The GPU's parity mode reproduces order 0."""
+    import refcpu as R
+    L = R.lib(native)
+    L.orc_set_order(1)
+    try:
+        alt = oracle_run(lp, embedding, len(base["ids"]), teacher_ids=base["ids"], native=native, **kw)
+    finally:
+        L.orc_set_order(0)
+    ol, al = base["logits"].astype(np.float64), alt["logits"].astype(np.float64)
+    rel = np.abs(al - ol).max(axis=1) / np.abs(ol).max(axis=1)
+    return {"steps": len(base["ids"]), "max_logit_rel": float(rel.max()), "mean_logit_rel": float(rel.mean()), "logits_bit_identical_steps": int((al == ol).all(axis=1).sum()),
+            "argmax_identical": int((al.argmax(axis=1) == ol.argmax(axis=1)).sum()),
+            "orders": "0: one fma chain per output (GPU parity mode = this, bit for bit); 1: ggml-style 8 lane partials + hsum (k-quant min term in its own 4-lane accumulator)"}
+
+
 def gpu_free_run(lib, ctx, emb_struct, steps: int, prompt: str = PROMPT) -> List[str]:
     """The reference API flow on the GPU: pieces of `steps` greedy tokens (EOS ignored)."""
     lib.minigpt4_reset_chat(ctx)

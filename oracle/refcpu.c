@@ -19,8 +19,17 @@
  *
  * Rounding choices where ggml's own code paths differ by ISA (the reference builds with AVX2/F16C
  * by default, CMakeLists.txt:27-30): activation quantisation rounds half-to-even (the AVX2 path),
- * fp32<->fp16 conversions are IEEE RNE (F16C), block results are accumulated block-by-block in fp32
- * with one fma per block.
+ * fp32<->fp16 conversions are IEEE RNE (F16C).
+ *
+ * FP32 ACCUMULATION ORDER -- what "bit-identical to the oracle" means.  The integer block dots are exact and order-free; the fp32 additions are not, and ggml's order
+ * depends on the ISA path.  This file carries TWO orders (orc_set_order):
+ *   order 0 (default): ONE fma chain per output, `sumf = fmaf(d_w * d_a, (float)isum, sumf)` block after block (F16 / F32 rows: element after element).  This is a
+ *       SELF-DEFINED idealisation -- no ggml code path adds in exactly this order.  The GPU's parity mode (MINIGPT4_PARITY) reproduces it bit for bit; that statement is
+ *       identity with THIS order, not with any binary the reference produces.
+ *   order 1: ggml's AVX2 structure as best recalled from k_quants.c / ggml.c at the pinned tag (eight fp32 lane partials per row, fmadd per block, hsum_float_8 at the end;
+ *       separate min-term accumulators; 4 x 8-lane accumulators for F16 / F32 rows) -- see the comment at `g_order`.  Unverifiable here as well (no ggml source or binary).
+ * bench.py reports the logit spread BETWEEN the two orders on the headline file (`parity.oracle_order_spread`): that spread is the best "bit-exact vs the reference" can
+ * mean while no real ggml pin exists; the GPU's fast mode is held to north_star's 1e-2 against order 0 and sits within the same noise of order 1.
  *
  * What pins it instead (tests/test_cpu_host.py, tests/test_cpu_thirdparty.py): hand-computed block vectors, an independent numpy implementation of every block
  * format, a float64 forward of both models, and -- as tolerance pins against real third-party code present in this image -- Hugging Face LlamaForCausalLM, Hugging
@@ -316,7 +325,196 @@ static float vec_dot_q6_K_q8_K_avx2(int64_t n, const blk_q6_K *x, const blk_q8_K
         sumf = fmaf(h2f(x[i].d) * y[i].d, (float)(hsum_i32_8(acc) - 32 * off), sumf); } return sumf; }
 #endif
 
+/* --------------------------------------------------------------------------------------------
+ * ORDER 1 (orc_set_order(1)): the fp32 accumulation order of ggml's own x86 kernels, as best recalled (ggml.c / k_quants.c @ master-31cfbb1, the AVX2 code paths the
+ * reference builds by default, /root/reference/CMakeLists.txt:27-30).  ggml does NOT run one fma chain per output (order 0 above): its AVX2 kernels keep EIGHT fp32
+ * lane partials -- int32 lane L of a 256-bit register collects the products of bytes 4L .. 4L+3 of every 32-byte chunk (maddubs pairs bytes, madd pairs words) --
+ * convert the eight lane sums of a block to float separately, `acc = fmadd(d, float(sumi), acc)` per block, and reduce with hsum_float_8
+ * ((x[i] + x[i+4]) -> (r0 + r2), (r1 + r3) -> sum) at the end of the row.  The Q4_K / Q5_K min term runs in its own four-lane accumulator
+ * (madd(mins, hadd(bsums)) -> 4 int32 -> fmadd(dmin, ..)), added after the reduction; Q4_1 / Q5_1 add m * s into a scalar.  F16 / F32 rows: four 8-lane accumulators
+ * over 32-element steps (GGML_F32x8: sum[j] = fmadd(x, y, sum[j])), pairwise vector adds, 128-bit halves, two hadds; a tail of n % 32 elements is added in double.
+ * Q2_K / Q3_K keep order 0 (their AVX2 forms are not restated).  The integer parts are identical in both orders; only the fp32 additions differ, so the two orders agree to
+ * ~1e-6 relative per dot product and differ in the last bits (tests/test_cpu_host.py::test_oracle_accumulation_orders).  NEITHER order is pinned to a ggml binary (none
+ * exists on this machine): order 1 is what "bit-exact vs the reference" could mean at best, the spread between the two is reported by bench.py (`parity.oracle_order_spread`).
+ * The GPU's parity mode (MINIGPT4_PARITY) reproduces ORDER 0.
+ * ------------------------------------------------------------------------------------------ */
+static int g_order = 0;
+ORC_API void orc_set_order(int order) { g_order = order ? 1 : 0; }
+ORC_API int orc_get_order(void) { return g_order; }
+static inline float hsum_float_8(const float *x) { const float r0 = x[4] + x[0], r1 = x[5] + x[1], r2 = x[6] + x[2], r3 = x[7] + x[3]; const float s0 = r0 + r2, s1 = r1 + r3; return s0 + s1; }
+/* eight int32 lane sums of one 32-byte chunk: lane L = sum over bytes 4L .. 4L+3 of w * a */
+static inline void lanes32(const int8_t *w, const int8_t *a, int *lane) { for (int L = 0; L < 8; L++) { int s = 0; for (int b = 0; b < 4; b++) s += (int)w[4 * L + b] * (int)a[4 * L + b]; lane[L] = s; } }
+static float vec_dot_32_lanes(int wtype, int64_t n, const void *xv, const void *yv) {   /* Q4_0 Q5_0 Q8_0 (x Q8_0), Q4_1 Q5_1 (x Q8_1): scalar restatement of the 8-lane forms */
+    float acc[8] = {0}, summs = 0.0f;
+    for (int64_t i = 0; i < n / QK; i++) { int8_t w[32]; const int8_t *a; float d, m = 0.0f, s = 0.0f;
+        switch (wtype) {
+        case T_Q4_0: { const blk_q4_0 *x = (const blk_q4_0 *)xv + i; const blk_q8_0 *y = (const blk_q8_0 *)yv + i; for (int j = 0; j < 16; j++) { w[j] = (int8_t)((x->qs[j] & 15) - 8); w[j + 16] = (int8_t)((x->qs[j] >> 4) - 8); }
+            a = y->qs; d = h2f(x->d) * h2f(y->d); break; }
+        case T_Q5_0: { const blk_q5_0 *x = (const blk_q5_0 *)xv + i; const blk_q8_0 *y = (const blk_q8_0 *)yv + i; uint32_t qh; memcpy(&qh, x->qh, 4);
+            for (int j = 0; j < 16; j++) { w[j] = (int8_t)(((x->qs[j] & 15) | (((qh >> j) << 4) & 0x10)) - 16); w[j + 16] = (int8_t)(((x->qs[j] >> 4) | ((qh >> (j + 12)) & 0x10)) - 16); }
+            a = y->qs; d = h2f(x->d) * h2f(y->d); break; }
+        case T_Q8_0: { const blk_q8_0 *x = (const blk_q8_0 *)xv + i; const blk_q8_0 *y = (const blk_q8_0 *)yv + i; memcpy(w, x->qs, 32); a = y->qs; d = h2f(x->d) * h2f(y->d); break; }
+        case T_Q4_1: { const blk_q4_1 *x = (const blk_q4_1 *)xv + i; const blk_q8_1 *y = (const blk_q8_1 *)yv + i; for (int j = 0; j < 16; j++) { w[j] = (int8_t)(x->qs[j] & 15); w[j + 16] = (int8_t)(x->qs[j] >> 4); }
+            a = y->qs; d = h2f(x->d) * y->d; m = h2f(x->m); s = y->s; break; }
+        default: { const blk_q5_1 *x = (const blk_q5_1 *)xv + i; const blk_q8_1 *y = (const blk_q8_1 *)yv + i; uint32_t qh; memcpy(&qh, x->qh, 4);
+            for (int j = 0; j < 16; j++) { w[j] = (int8_t)((x->qs[j] & 15) | (((qh >> j) << 4) & 0x10)); w[j + 16] = (int8_t)((x->qs[j] >> 4) | ((qh >> (j + 12)) & 0x10)); }
+            a = y->qs; d = h2f(x->d) * y->d; m = h2f(x->m); s = y->s; break; }
+        }
+        int lane[8]; lanes32(w, a, lane);
+        for (int L = 0; L < 8; L++) acc[L] = fmaf(d, (float)lane[L], acc[L]);
+        summs = fmaf(m, s, summs);                     /* `summs += m * s`, contracted to an fma by the compilers ggml is built with (-mfma, fp-contract on) */
+    }
+    return hsum_float_8(acc) + summs;
+}
+static float vec_dot_q45_K_lanes(int64_t n, const void *xv, const blk_q8_K *y, int q5) {
+    float acc[8] = {0}, acc_m[4] = {0};
+    for (int64_t i = 0; i < n / QK_K; i++) {
+        const uint8_t *scales, *qs, *qh = NULL; f16_t dh, dminh;
+        if (q5) { const blk_q5_K *x = (const blk_q5_K *)xv + i; scales = x->scales; qs = x->qs; qh = x->qh; dh = x->d; dminh = x->dmin; }
+        else { const blk_q4_K *x = (const blk_q4_K *)xv + i; scales = x->scales; qs = x->qs; dh = x->d; dminh = x->dmin; }
+        const float d = y[i].d * h2f(dh), dmin = -y[i].d * h2f(dminh);
+        uint8_t sc[8], mn[8]; for (int j = 0; j < 8; j++) get_scale_min_k4(j, scales, &sc[j], &mn[j]);
+        for (int t = 0; t < 4; t++) {                  /* q8s[k] = bsums[2k] + bsums[2k+1] (hadd_epi16); prod[t] = mins[2t] q8s[2t] + mins[2t+1] q8s[2t+1] (madd_epi16) */
+            const int prod = mn[2 * t] * (y[i].bsums[4 * t] + y[i].bsums[4 * t + 1]) + mn[2 * t + 1] * (y[i].bsums[4 * t + 2] + y[i].bsums[4 * t + 3]);
+            acc_m[t] = fmaf(dmin, (float)prod, acc_m[t]); }
+        int sumi[8] = {0};
+        for (int j = 0; j < 4; j++) { int8_t w0[32], w1[32]; int lane[8];
+            for (int l = 0; l < 32; l++) { w0[l] = (int8_t)((qs[32 * j + l] & 15) | (q5 ? ((qh[l] >> (2 * j)) & 1) << 4 : 0)); w1[l] = (int8_t)((qs[32 * j + l] >> 4) | (q5 ? ((qh[l] >> (2 * j + 1)) & 1) << 4 : 0)); }
+            lanes32(w0, y[i].qs + 64 * j, lane); for (int L = 0; L < 8; L++) sumi[L] += sc[2 * j] * lane[L];
+            lanes32(w1, y[i].qs + 64 * j + 32, lane); for (int L = 0; L < 8; L++) sumi[L] += sc[2 * j + 1] * lane[L]; }
+        for (int L = 0; L < 8; L++) acc[L] = fmaf(d, (float)sumi[L], acc[L]);
+    }
+    const float m0 = acc_m[0] + acc_m[2], m1 = acc_m[1] + acc_m[3];     /* add_ps(acc_m, movehl(acc_m, acc_m)); add_ss(acc_m, movehdup(acc_m)) */
+    return hsum_float_8(acc) + (m0 + m1);
+}
+static float vec_dot_q6_K_lanes(int64_t n, const blk_q6_K *x, const blk_q8_K *y) {
+    float acc[8] = {0};
+    for (int64_t i = 0; i < n / QK_K; i++) { const float d = y[i].d * h2f(x[i].d); const uint8_t *ql = x[i].ql, *qh = x[i].qh; const int8_t *sc = x[i].scales, *a = y[i].qs; int sumi[8] = {0};
+        for (int nn = 0; nn < 2; nn++) { int8_t w[4][32];
+            for (int l = 0; l < 32; l++) { w[0][l] = (int8_t)(((ql[l] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32); w[1][l] = (int8_t)(((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32);
+                w[2][l] = (int8_t)(((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32); w[3][l] = (int8_t)(((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32); }
+            for (int g = 0; g < 4; g++) { int lane[8]; lanes32(w[g], a + 32 * g, lane);   /* chunk g = elements 32 g ..: lanes 0-3 belong to sub-block 2 g, lanes 4-7 to 2 g + 1 */
+                for (int L = 0; L < 8; L++) sumi[L] += (int)sc[2 * g + (L >> 2)] * lane[L]; }
+            ql += 64; qh += 32; sc += 8; a += 128; }
+        for (int L = 0; L < 8; L++) acc[L] = fmaf(d, (float)sumi[L], acc[L]); }
+    return hsum_float_8(acc);
+}
+/* ggml_vec_dot_f16 / ggml_vec_dot_f32 with the 8-wide vector macros (GGML_F32x8 / GGML_F32Cx8: STEP 32, four accumulators); x, y given as float getters */
+#define LANES_DOT_BODY(GETX, GETY)                                                                                                   \
+    float sum[4][8]; memset(sum, 0, sizeof sum); const int64_t np = n & ~(int64_t)31;                                                \
+    for (int64_t i = 0; i < np; i += 32) for (int j = 0; j < 4; j++) for (int L = 0; L < 8; L++) sum[j][L] = fmaf(GETX(i + 8 * j + L), GETY(i + 8 * j + L), sum[j][L]); \
+    for (int L = 0; L < 8; L++) { sum[0][L] = sum[0][L] + sum[1][L]; sum[2][L] = sum[2][L] + sum[3][L]; }                             \
+    for (int L = 0; L < 8; L++) sum[0][L] = sum[0][L] + sum[2][L];                                                                    \
+    float t0[4]; for (int L = 0; L < 4; L++) t0[L] = sum[0][L] + sum[0][L + 4];                                                       \
+    const float t1a = t0[0] + t0[1], t1b = t0[2] + t0[3];                                                                             \
+    double sumf = (double)(t1a + t1b);                                                                                                \
+    for (int64_t i = np; i < n; i++) sumf += (double)(GETX(i) * GETY(i));                                                             \
+    return (float)sumf;
+static float vec_dot_f16_lanes(int64_t n, const f16_t *x, const f16_t *y) {
+#define GX(i) h2f(x[i])
+#define GY(i) h2f(y[i])
+    LANES_DOT_BODY(GX, GY)
+#undef GX
+#undef GY
+}
+static float vec_dot_f32_lanes(int64_t n, const float *x, const float *y) {
+#define GX(i) x[i]
+#define GY(i) y[i]
+    LANES_DOT_BODY(GX, GY)
+#undef GX
+#undef GY
+}
+#ifdef __AVX2__
+/* AVX2 forms of order 1 for the types of the headline files (bit-identical to the scalar restatements above: same lane assignment, same fma per lane) */
+static inline float hsum_float_8_avx(const __m256 x) { __m128 res = _mm256_extractf128_ps(x, 1); res = _mm_add_ps(res, _mm256_castps256_ps128(x)); res = _mm_add_ps(res, _mm_movehl_ps(res, res));
+    res = _mm_add_ss(res, _mm_movehdup_ps(res)); return _mm_cvtss_f32(res); }
+static float vec_dot_q45_K_lanes_avx2(int64_t n, const void *xv, const blk_q8_K *y, int q5) {
+    const __m256i m4 = _mm256_set1_epi8(0x0F), one8 = _mm256_set1_epi8(1);
+    __m256 acc = _mm256_setzero_ps(); float acc_m[4] = {0};
+    for (int64_t i = 0; i < n / QK_K; i++) {
+        const uint8_t *scales, *qs, *qh = NULL; f16_t dh, dminh;
+        if (q5) { const blk_q5_K *x = (const blk_q5_K *)xv + i; scales = x->scales; qs = x->qs; qh = x->qh; dh = x->d; dminh = x->dmin; }
+        else { const blk_q4_K *x = (const blk_q4_K *)xv + i; scales = x->scales; qs = x->qs; dh = x->d; dminh = x->dmin; }
+        const float d = y[i].d * h2f(dh), dmin = -y[i].d * h2f(dminh);
+        uint8_t sc[8], mn[8]; for (int j = 0; j < 8; j++) get_scale_min_k4(j, scales, &sc[j], &mn[j]);
+        for (int t = 0; t < 4; t++) { const int prod = mn[2 * t] * (y[i].bsums[4 * t] + y[i].bsums[4 * t + 1]) + mn[2 * t + 1] * (y[i].bsums[4 * t + 2] + y[i].bsums[4 * t + 3]);
+            acc_m[t] = fmaf(dmin, (float)prod, acc_m[t]); }
+        const __m256i hb = q5 ? _mm256_loadu_si256((const __m256i *)qh) : _mm256_setzero_si256();
+        __m256i sumi = _mm256_setzero_si256();
+        for (int j = 0; j < 4; j++) {
+            const __m256i q = _mm256_loadu_si256((const __m256i *)(qs + 32 * j));
+            __m256i w0 = _mm256_and_si256(q, m4), w1 = _mm256_and_si256(_mm256_srli_epi16(q, 4), m4);
+            if (q5) { w0 = _mm256_or_si256(w0, _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(hb, 2 * j), one8), 4));
+                      w1 = _mm256_or_si256(w1, _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(hb, 2 * j + 1), one8), 4)); }
+            const __m256i a0 = _mm256_loadu_si256((const __m256i *)(y[i].qs + 64 * j)), a1 = _mm256_loadu_si256((const __m256i *)(y[i].qs + 64 * j + 32));
+            sumi = _mm256_add_epi32(sumi, _mm256_madd_epi16(_mm256_set1_epi16(sc[2 * j]), _mm256_maddubs_epi16(w0, a0)));
+            sumi = _mm256_add_epi32(sumi, _mm256_madd_epi16(_mm256_set1_epi16(sc[2 * j + 1]), _mm256_maddubs_epi16(w1, a1))); }
+        acc = _mm256_fmadd_ps(_mm256_set1_ps(d), _mm256_cvtepi32_ps(sumi), acc);
+    }
+    const float m0 = acc_m[0] + acc_m[2], m1 = acc_m[1] + acc_m[3];
+    return hsum_float_8_avx(acc) + (m0 + m1);
+}
+static float vec_dot_q6_K_lanes_avx2(int64_t n, const blk_q6_K *x, const blk_q8_K *y) {
+    const __m256i m4 = _mm256_set1_epi8(0x0F), m2 = _mm256_set1_epi8(3), m32s = _mm256_set1_epi8(32);
+    __m256 acc = _mm256_setzero_ps();
+    for (int64_t i = 0; i < n / QK_K; i++) { const float d = y[i].d * h2f(x[i].d); const uint8_t *ql = x[i].ql, *qh = x[i].qh; const int8_t *sc = x[i].scales, *a = y[i].qs;
+        __m256i sumi = _mm256_setzero_si256();
+        for (int nn = 0; nn < 2; nn++) {
+            const __m256i l0 = _mm256_loadu_si256((const __m256i *)ql), l1 = _mm256_loadu_si256((const __m256i *)(ql + 32)), h = _mm256_loadu_si256((const __m256i *)qh);
+            const __m256i w[4] = { _mm256_or_si256(_mm256_and_si256(l0, m4), _mm256_slli_epi16(_mm256_and_si256(h, m2), 4)),
+                                   _mm256_or_si256(_mm256_and_si256(l1, m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(h, 2), m2), 4)),
+                                   _mm256_or_si256(_mm256_and_si256(_mm256_srli_epi16(l0, 4), m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(h, 4), m2), 4)),
+                                   _mm256_or_si256(_mm256_and_si256(_mm256_srli_epi16(l1, 4), m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(h, 6), m2), 4)) };
+            for (int g = 0; g < 4; g++) { const __m256i av = _mm256_loadu_si256((const __m256i *)(a + 32 * g));
+                __m256i p16 = _mm256_sub_epi16(_mm256_maddubs_epi16(w[g], av), _mm256_maddubs_epi16(m32s, av));          /* (q6 - 32) . a, pairwise: |.| <= 2 * 32 * 128 */
+                const __m256i scv = _mm256_set_m128i(_mm_set1_epi16(sc[2 * g + 1]), _mm_set1_epi16(sc[2 * g]));
+                sumi = _mm256_add_epi32(sumi, _mm256_madd_epi16(scv, p16)); }
+            ql += 64; qh += 32; sc += 8; a += 128; }
+        acc = _mm256_fmadd_ps(_mm256_set1_ps(d), _mm256_cvtepi32_ps(sumi), acc); }
+    return hsum_float_8_avx(acc);
+}
+static float vec_dot_q4_0_lanes_avx2(int64_t n, const blk_q4_0 *x, const blk_q8_0 *y) {
+    const __m128i m4 = _mm_set1_epi8(0x0F); const __m256i ones16 = _mm256_set1_epi16(1), off = _mm256_set1_epi8(8);
+    __m256 acc = _mm256_setzero_ps();
+    for (int64_t i = 0; i < n / QK; i++) { const __m128i q = _mm_loadu_si128((const __m128i *)x[i].qs);
+        const __m256i bx = _mm256_sub_epi8(_mm256_set_m128i(_mm_and_si128(_mm_srli_epi16(q, 4), m4), _mm_and_si128(q, m4)), off), by = _mm256_loadu_si256((const __m256i *)y[i].qs);
+        const __m256i dot = _mm256_maddubs_epi16(_mm256_sign_epi8(bx, bx), _mm256_sign_epi8(by, bx));                          /* mul_sum_i8_pairs_float */
+        acc = _mm256_fmadd_ps(_mm256_set1_ps(h2f(x[i].d) * h2f(y[i].d)), _mm256_cvtepi32_ps(_mm256_madd_epi16(ones16, dot)), acc); }
+    return hsum_float_8_avx(acc);
+}
+static float vec_dot_f16_lanes_avx2(int64_t n, const f16_t *x, const f16_t *y) {
+    __m256 sum[4] = { _mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps() }; const int64_t np = n & ~(int64_t)31;
+    for (int64_t i = 0; i < np; i += 32) for (int j = 0; j < 4; j++)
+        sum[j] = _mm256_fmadd_ps(_mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(x + i + 8 * j))), _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(y + i + 8 * j))), sum[j]);
+    sum[0] = _mm256_add_ps(sum[0], sum[1]); sum[2] = _mm256_add_ps(sum[2], sum[3]); sum[0] = _mm256_add_ps(sum[0], sum[2]);
+    const __m128 t0 = _mm_add_ps(_mm256_castps256_ps128(sum[0]), _mm256_extractf128_ps(sum[0], 1)); const __m128 t1 = _mm_hadd_ps(t0, t0);
+    double sumf = (double)_mm_cvtss_f32(_mm_hadd_ps(t1, t1));
+    for (int64_t i = np; i < n; i++) sumf += (double)(h2f(x[i]) * h2f(y[i]));
+    return (float)sumf;
+}
+#endif
+static float vec_dot_f16_any(int64_t n, const f16_t *x, const f16_t *y) {   /* the attention's K.q and V.p products follow the selected order too (ggml_mul_mat on f16 tensors) */
+    if (!g_order) return vec_dot_f16(n, x, y);
+#ifdef __AVX2__
+    if (g_simd) return vec_dot_f16_lanes_avx2(n, x, y);
+#endif
+    return vec_dot_f16_lanes(n, x, y);
+}
+static float vec_dot_order1(int wtype, int64_t n, const void *w, const void *a) {
+#ifdef __AVX2__
+    if (g_simd) switch (wtype) {
+        case T_Q4_0: return vec_dot_q4_0_lanes_avx2(n, w, a); case T_Q4_K: return vec_dot_q45_K_lanes_avx2(n, w, a, 0); case T_Q5_K: return vec_dot_q45_K_lanes_avx2(n, w, a, 1);
+        case T_Q6_K: return vec_dot_q6_K_lanes_avx2(n, w, a); case T_F16: return vec_dot_f16_lanes_avx2(n, w, a); default: break; }
+#endif
+    switch (wtype) {
+    case T_Q4_0: case T_Q4_1: case T_Q5_0: case T_Q5_1: case T_Q8_0: return vec_dot_32_lanes(wtype, n, w, a);
+    case T_Q4_K: return vec_dot_q45_K_lanes(n, w, a, 0); case T_Q5_K: return vec_dot_q45_K_lanes(n, w, a, 1); case T_Q6_K: return vec_dot_q6_K_lanes(n, w, a);
+    case T_F16: return vec_dot_f16_lanes(n, w, a); case T_F32: return vec_dot_f32_lanes(n, w, a);
+    default: return NAN; }
+}
+
 ORC_API float orc_vec_dot(int wtype, int64_t n, const void *w, const void *a) {
+    if (g_order && wtype != T_Q2_K && wtype != T_Q3_K) return vec_dot_order1(wtype, n, w, a);
 #ifdef __AVX2__
     if (g_simd) switch (wtype) {
         case T_Q4_0: return vec_dot_q4_0_q8_0_avx2(n, w, a); case T_Q4_K: return vec_dot_q45_K_q8_K_avx2(n, w, a, 0);
@@ -450,10 +648,10 @@ ORC_API int orc_llama_eval(orc_llama *m, const int *tokens, const float *embd, i
             float *sc = malloc(sizeof(float) * (size_t)T); f16_t qh[256]; f16_t *ph = malloc(sizeof(f16_t) * (size_t)T);
             for (int i = 0; i < hd; i++) qh[i] = f2h(q[(size_t)t * E + h * hd + i]);
             const int lim = n_past + t; /* causal: keys 0..n_past+t */
-            for (int j = 0; j < T; j++) { if (j > lim) { sc[j] = -INFINITY; continue; } sc[j] = vec_dot_f16(hd, kc + (size_t)j * E + h * hd, qh) * kq_scale; }
+            for (int j = 0; j < T; j++) { if (j > lim) { sc[j] = -INFINITY; continue; } sc[j] = vec_dot_f16_any(hd, kc + (size_t)j * E + h * hd, qh) * kq_scale; }
             soft_max_row(sc, T);
             for (int j = 0; j < T; j++) ph[j] = f2h(sc[j]);
-            for (int i = 0; i < hd; i++) att[(size_t)t * E + h * hd + i] = vec_dot_f16(T, vc + (size_t)(h * hd + i) * C, ph);
+            for (int i = 0; i < hd; i++) att[(size_t)t * E + h * hd + i] = vec_dot_f16_any(T, vc + (size_t)(h * hd + i) * C, ph);
             free(sc); free(ph);
         }
         trace("q_rope", il, q, (int64_t)N * E); trace("att", il, att, (int64_t)N * E);
@@ -550,8 +748,13 @@ static void attention_f32(const float *q, const float *k, const float *v, int nq
     for (int h = 0; h < heads; h++) for (int t = 0; t < nq; t++) {
         float *sc = malloc(sizeof(float) * (size_t)nk); float qv[256];
         for (int i = 0; i < hd; i++) { qv[i] = q[(size_t)t * qs + h * hd + i]; if (q_prescale != 0.0f) qv[i] *= q_prescale; }
-        for (int j = 0; j < nk; j++) { float s = vec_dot_f32(hd, k + (size_t)j * ks + h * hd, qv); if (score_div != 0.0f) s = s / score_div; sc[j] = s; }
+        for (int j = 0; j < nk; j++) { float s = g_order ? vec_dot_f32_lanes(hd, k + (size_t)j * ks + h * hd, qv) : vec_dot_f32(hd, k + (size_t)j * ks + h * hd, qv); if (score_div != 0.0f) s = s / score_div; sc[j] = s; }
         soft_max_row(sc, nk);
+        if (g_order) {   /* order 1: the P.V product is a ggml_vec_dot_f32 over the keys of the transposed (contiguous) V */
+            float *col = malloc(sizeof(float) * (size_t)nk);
+            for (int i = 0; i < hd; i++) { for (int j = 0; j < nk; j++) col[j] = v[(size_t)j * ks + h * hd + i]; out[(size_t)t * os + h * hd + i] = vec_dot_f32_lanes(nk, col, sc); }
+            free(col);
+        } else
         for (int i = 0; i < hd; i++) { float s = 0; for (int j = 0; j < nk; j++) s = fmaf(v[(size_t)j * ks + h * hd + i], sc[j], s); out[(size_t)t * os + h * hd + i] = s; }
         free(sc);
     }

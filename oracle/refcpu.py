@@ -56,6 +56,8 @@ def lib(native: bool = False):
     L.orc_set_simd.argtypes = [i32]
     L.orc_set_trace.argtypes = [C.c_char_p]
     L.orc_set_simd.restype = None
+    L.orc_set_order.argtypes = [i32]
+    L.orc_set_order.restype = None
     L.orc_llama_new.restype = vp
     L.orc_llama_new.argtypes = [i32] * 6
     L.orc_llama_free.argtypes = [vp]

@@ -284,6 +284,47 @@ def test_oracle_simd_dots_equal_scalar():
         L.orc_set_simd(1)
 
 
+def test_oracle_accumulation_orders(tiny_files):
+    """The oracle's two fp32 accumulation orders (oracle/refcpu.c): order 0 = ONE fma chain per output (what the GPU's parity mode reproduces bit for bit), order 1 = ggml's
+    own x86 structure as best recalled (eight lane partials per row, fmadd per block, hsum at the end; the k-quant min term in a separate four-lane accumulator).  Same
+    integers, different fp32 additions: every dot product of the two agrees to <= 1e-5 of the row's largest value and the results differ in their last bits; the AVX2 form of
+    order 1 is bit-identical to its scalar lane-by-lane restatement; a whole tiny model evaluates in both orders to logits within 1e-3 of each other."""
+    import refcpu as R
+    from minigpt4_cpp_amd import modelgen as G, quants as Q
+    L = R.lib()
+    rng = np.random.default_rng(23)
+    n_in, n_out = 2048 + 32, 64               # + 32: a 32-element tail for the F16 / F32 rows' vector loop; k-quants use 2048
+    try:
+        for name in ("q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q4_k", "q5_k", "q6_k", "f16", "f32"):
+            t = Q.NAME_TO_TYPE[name]
+            k = 2048 if Q.BLOCK[t][0] == 256 else (n_in + 7 if name in ("f16", "f32") else n_in)    # f16 / f32: 7 leftover elements go through the double tail
+            raw = Q.quantize(t, (0.05 * rng.standard_normal((n_out, k))).astype(np.float32))
+            x = (rng.standard_normal((3, k)) * np.array([1.0, 37.0, 1e-3])[:, None]).astype(np.float32)
+            L.orc_set_order(0)
+            a = R.mul_mat(t, raw, k, n_out, x)
+            L.orc_set_order(1)
+            b = R.mul_mat(t, raw, k, n_out, x)
+            L.orc_set_simd(0)
+            c = R.mul_mat(t, raw, k, n_out, x)
+            L.orc_set_simd(1)
+            assert np.array_equal(b, c), name                                   # AVX2 lanes == scalar lanes
+            scale = np.abs(a).max(axis=1, keepdims=True)
+            assert (np.abs(a - b) <= 1e-5 * scale).all(), (name, float((np.abs(a - b) / scale).max()))
+            assert not np.array_equal(a, b), name                               # ... and the orders are really different additions
+        _, llm = tiny_files
+        f = G.read_llm_file(llm("q5_k", "q5_k_m", conditioned=True))
+        toks = [1, 5, 300, 44, 270, 99, 400, 17]
+        L.orc_set_order(0)
+        l0 = R.OracleLLM(f, n_ctx=32).eval_tokens(toks)
+        L.orc_set_order(1)
+        l1 = R.OracleLLM(f, n_ctx=32).eval_tokens(toks)
+        spread = float(np.abs(l0 - l1).max() / np.abs(l0).max())
+        assert 0.0 < spread < 1e-3, spread
+    finally:
+        L.orc_set_order(0)
+        L.orc_set_simd(1)
+
+
 # ------------------------------------------------------------------------------------------------ tokenizer / sampler / templating
 def test_tokenizer_matches_oracle(lib, tiny_files):
     import refcpu as R

@@ -72,6 +72,7 @@ def test_headline_chat_flow_matches_oracle(gpu_lib, config, omp_threads):
         res = H.compare(head, pieces, logits)
         res["parity_mode"] = par
         res["oracle_self_noise"] = noise
+        res["oracle_order_spread"] = H.oracle_order_spread(lp, emb_np, head, threads=omp_threads)   # the oracle's OTHER fp32 order (ggml-style lane partials) against the one used here
         res["oracle_prefill_s"], res["oracle_decode_s"] = orc["prefill_s"], orc["decode_s"]
         res["distinct_greedy_ids"] = len(set(orc["ids"]))
         _dump(config, res)
