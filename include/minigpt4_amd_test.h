@@ -59,7 +59,12 @@ MINIGPT4_API int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, in
 
 /* Average latency (microseconds) of a device-wide barrier across n_blocks co-resident 512-thread workgroups (atomic counter + agent-scope fences); *errors
  * counts visibility failures of a neighbour-word check.  Measurement for DESIGN.md's launch-gap-vs-barrier analysis. */
+/* 1 when the test library was built by `make test-extras` (closed-direction kernels included: the generation-3 prompt mat-mul, the batched-decode MFMA probe), else 0 */
+MINIGPT4_API int minigpt4_amd_test_extras(void);
 MINIGPT4_API float minigpt4_amd_probe_grid_barrier(int n_blocks, int iters, unsigned *errors);
+/* round 5 (csrc/tn_mfma_probe.hip, tools/batched_mfma_probe.py): the batched decode mat-vec on v_mfma_i32_4x4x4_16B_i8 over row-interleaved SYNTHETIC Q5_K planes -- microseconds per
+ * launch for one rows x cols matrix set against TN = 1..4 prepared rows; check != 0 validates the launch against a scalar kernel over the same planes (relative difference out) */
+MINIGPT4_API int minigpt4_amd_probe_tn_mfma(int rows, int cols, int TN, int iters, int n_sets, int check, float *us_per_launch, float *rel_diff);
 /* what csrc/dist.cpp reads from MINIGPT4_WORLD_SIZE / MINIGPT4_RANK / MINIGPT4_NCCL_ID_FILE / MINIGPT4_DIST_TIMEOUT_S (host only): 0, or 1 with the reason in err */
 MINIGPT4_API int minigpt4_amd_dist_env(int *world, int *rank, char *id_file, size_t cap, char *err, size_t err_cap);
 /* LDS-DMA stream probe (csrc/probe_kernels.hip, tools/probe_dma.py): chip-wide GB/s of `waves` loader waves per CU keeping `depth` fills of `fill` bytes in flight into an LDS

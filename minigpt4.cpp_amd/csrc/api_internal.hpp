@@ -50,7 +50,7 @@ template <typename F> inline int guarded(int on_hip_error, F &&f) {
 struct DevBuf { void *p = nullptr; DevBuf(size_t n) { HIP_CHECK(hipMalloc(&p, n ? n : 1)); } ~DevBuf() { if (p) HIP_IGNORE(hipFree(p)); } template <typename T> T *as() { return static_cast<T *>(p); } };
 inline void alloc_act(ActQ &A, std::vector<std::unique_ptr<DevBuf>> &keep, size_t N, size_t K) {
     auto mk = [&](size_t bytes) { keep.emplace_back(new DevBuf(bytes + 256)); return keep.back()->p; };
-    A.q8k = (int8_t *)mk(N * K); A.q80 = (int8_t *)mk(N * K); A.dk = (float *)mk(N * (K / 256 + 1) * 4); A.bsk = (int16_t *)mk(N * (K / 16 + 1) * 2); A.bsq = (int8_t *)mk(N * (K / 16 + 16));
+    A.q8k = (int8_t *)mk(N * K); A.q80 = (int8_t *)mk(N * K); A.dk = (float *)mk(N * (K / 256 + 1) * 4); A.bsk = (int16_t *)mk(N * (K / 16 + 1) * 2); A.bsq = (int8_t *)mk(N * (K / 16 + 16)); A.q16 = (__half *)mk(N * K * 2); A.bs16 = (__half *)mk(N * (K / 16 + 16) * 2);
     A.d0 = (float *)mk(N * (K / 32 + 1) * 4); A.d1 = (float *)mk(N * (K / 32 + 1) * 4); A.s1 = (float *)mk(N * (K / 32 + 1) * 4); A.sum0 = (int *)mk(N * (K / 32 + 1) * 4);
     A.xh = (__half *)mk(N * K * 2); A.xf = (float *)mk(N * K * 4);
 }

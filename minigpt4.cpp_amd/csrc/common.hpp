@@ -70,6 +70,10 @@ struct ActQ {
     float *dk = nullptr;     // [N][K/256]
     int16_t *bsk = nullptr;  // [N][K/16]  Q8_K bsums
     int8_t *bsq = nullptr;   // [N][K/256][16] (optional) per-32 sums of the Q8_K values split for the int8 matrix cores: bytes 0..7 = s & 127, bytes 8..15 = s >> 7 (s = 128 hi + lo)
+    // (optional, round 5) fp16 images of the SAME Q8_K row for the fp16-MFMA prompt mat-mul (k_mmqh_q45k): the int8 values as fp16, in the kernel's fragment order --
+    // per super-block 32 chunks of 8 halfs, chunk c = 8 p + 4 uu + d holds elements 64 p + 16 uu + 4 d + {0, 2, 1, 3} and the same + 32 -- and the digit-split per-32 sums as fp16
+    __half *q16 = nullptr;   // [N][K]
+    __half *bs16 = nullptr;  // [N][K/256][16]: halfs 0..7 = s & 127, 8..15 = s >> 7
     int8_t *q80 = nullptr;   // [N][K]     Q8_0 / Q8_1 values (identical)
     float *d0 = nullptr;     // [N][K/32]  Q8_0 d, fp16-rounded
     float *d1 = nullptr;     // [N][K/32]  Q8_1 d (float)

@@ -23,16 +23,24 @@ public:
     ~Rccl();
     int open(std::string &err);
     int unique_id(uint8_t id[128], std::string &err);
-    int init(int world, int rank, const uint8_t id[128], std::string &err);
+    // ncclCommInitRank under a watchdog: a peer that died before it joined (header error, no librccl, its own time-out) must not leave this rank inside RCCL's bootstrap
+    // for ever.  After `timeout_s` the call gives up: the helper thread that is still inside ncclCommInitRank is abandoned and this object is deliberately never closed
+    // (poisoned()): the load fails, the process lives.
+    int init(int world, int rank, const uint8_t id[128], int timeout_s, std::string &err);
     int broadcast(void *device_ptr, size_t bytes, int root, void *stream, std::string &err);   // in place, <= 1 GiB pieces
+    int allreduce_max_u64(void *device_words, size_t count, void *stream, std::string &err);   // in place: every rank ends with the element-wise maximum
     void close();
+    bool poisoned() const { return poisoned_; }
 private:
     void *lib_ = nullptr, *comm_ = nullptr;
-    void *get_id_ = nullptr, *init_ = nullptr, *bcast_ = nullptr, *destroy_ = nullptr, *errstr_ = nullptr;
+    void *get_id_ = nullptr, *init_ = nullptr, *bcast_ = nullptr, *allreduce_ = nullptr, *destroy_ = nullptr, *errstr_ = nullptr;
+    bool poisoned_ = false;
     std::string why(int rc) const;
 };
-// rank 0: writes the id (tmp + rename); others: wait for a 128-byte file.  0 or error text.
+// rank 0: writes the id (tmp + rename); others: wait for a 128-byte file that is not older than `not_before` (seconds since the epoch; 0 = any): an id a crashed earlier
+// job left behind would bootstrap against a dead address.  0 or error text.
 int publish_unique_id(const std::string &path, const uint8_t id[128], std::string &err);
-int await_unique_id(const std::string &path, uint8_t id[128], int timeout_s, std::string &err);
+int await_unique_id(const std::string &path, uint8_t id[128], int timeout_s, std::string &err, long long not_before = 0);
+long long process_start_epoch_s();   // when this process started (from /proc/self/stat; falls back to "now - 1 s")
 
 }  // namespace mg4

@@ -7,6 +7,7 @@
 #include <optional>
 #include <unistd.h>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstring>
 
@@ -118,6 +119,10 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     batch_mix_ = !(getenv("MINIGPT4_BATCH_MIX") && atoi(getenv("MINIGPT4_BATCH_MIX")) == 0);                 // 0: wq|wk and wv of a mixed-type layer as two launches (batched step)
     if (const char *e = getenv("MINIGPT4_ATTN_SPLIT_T")) attn_split_t_ = atoi(e);   // cached keys from which the decode step uses the key-split attention (0 = never)
     n_cus_ = prop.multiProcessorCount;
+    if (const char *e = getenv("MINIGPT4_MMQH")) set_mmqh(atoi(e));              // 1: Q4_K / Q5_K prompt rows on the fp16-MFMA form with scaled operands (k_mmqh_q45k: measured SLOWER, profiles/r05_prefill_fp16_scaled_operands.md; A/B)
+    if (const char *e = getenv("MINIGPT4_MV_PACK")) set_matvec_pack(atoi(e));      // 0: decode mat-vec rows of K = 5120 one per lane-walk (round-4 form, A/B)
+    if (const char *e = getenv("MINIGPT4_QF_FOLD")) qf_fold_ = atoi(e) != 0;       // 0: the Q-Former's image-independent head is recomputed per encode (round-4 form, A/B)
+    if (const char *e = getenv("MINIGPT4_KV_HOIST")) kv_hoist_ = atoi(e) != 0;     // 0: one K | V projection GEMM per cross-attention layer (round-4 form, A/B)
     set_matvec_tuning(0, 0, prop.multiProcessorCount);
     if (const char *ns = getenv("MINIGPT4_CONVERSATIONS")) conv_.assign((size_t)std::max(1, std::min(MAX_CONVERSATIONS, atoi(ns))), Conversation{});
     sampler_.seed(seed);
@@ -127,54 +132,91 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     // native multi-GPU load (dist.hpp): MINIGPT4_WORLD_SIZE / MINIGPT4_RANK / MINIGPT4_NCCL_ID_FILE -> rank 0 reads the files, every other rank loads headers only and
     // receives both weight arenas by ncclBroadcast inside this call
     DistEnv dist; { std::string derr; if (parse_dist_env(dist, derr)) { set_last_error(derr); MG4_ERR("%s", derr.c_str()); return E_LoadLanguageModel; } }
-    if (dist.active() && dist.rank != 0) load_mode_ = LOAD_RECV;
+    if (dist.active()) {
+        load_mode_ = dist.rank != 0 ? LOAD_RECV : LOAD_FULL;               // the exchange decides who reads the files: MINIGPT4_LOAD=recv on rank 0 would broadcast empty arenas
+        if (!dv && dist.world > 1) { device_ = dist.rank % ndev; HIP_CHECK(hipSetDevice(device_)); MG4_INFO("no MINIGPT4_DEVICE / LOCAL_RANK: rank %d takes device %d", dist.rank, device_); }
+    }
+    // With the native exchange active a load error on THIS rank is not returned at once: the rank still joins the communicator and reports it there, so that its peers fail
+    // with it instead of waiting for it inside RCCL (native_broadcast).
+    int load_err = E_None;
     auto t0 = std::chrono::steady_clock::now();
-    if (int e = load_llm(llm_path)) return e;
-    auto t1 = std::chrono::steady_clock::now();
-    MG4_INFO("LLM model init took %lld ms to complete", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count());
-    if (int e = load_vision(vision_path)) return e;
-    auto t2 = std::chrono::steady_clock::now();
-    MG4_INFO("Loading minigpt4 model took %lld ms to complete", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count());
-    alloc_buffers();
+    try {
+        load_err = load_llm(llm_path);
+        auto t1 = std::chrono::steady_clock::now();
+        if (!load_err) MG4_INFO("LLM model init took %lld ms to complete", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count());
+        if (!load_err) load_err = load_vision(vision_path);
+        auto t2 = std::chrono::steady_clock::now();
+        if (!load_err) MG4_INFO("Loading minigpt4 model took %lld ms to complete", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count());
+        if (!load_err) { alloc_buffers(); if (load_mode_ == LOAD_FULL) fold_qformer_constants(); }   // LOAD_RECV: weights_received()
+    } catch (const HipError &e) {
+        if (!dist.active()) throw;
+        set_last_error(std::string("load failed: ") + e.what + " (" + hipGetErrorString(e.code) + ")"); load_err = E_LoadLanguageModel;
+    }
     if (stage_) { HIP_IGNORE(hipFree(stage_)); stage_ = nullptr; stage_cap_ = 0; }
-    if (dist.active()) { if (int e = native_broadcast(dist.world, dist.rank, dist.id_file, dist.timeout_s)) return e; }
-    return E_None;
+    if (dist.active()) { if (int e = native_broadcast(dist.world, dist.rank, dist.id_file, dist.timeout_s, load_err)) return load_err ? load_err : e; }
+    return load_err;
 }
 
 // The load-time exchange of a node's replicas, inside the C library: unique id through a file, communicator, layout agreement, both arenas from rank 0 in <= 1 GiB pieces,
 // checksum agreement.  Any failure is an error of minigpt4_model_load (message in minigpt4_amd_last_error); there is no fallback to reading the files.
-int Engine::native_broadcast(int world, int rank, const std::string &id_file, int timeout_s) {
+int Engine::native_broadcast(int world, int rank, const std::string &id_file, int timeout_s, int local_err) {
     std::string err;
-    auto fail = [&](const std::string &what) { set_last_error("weight broadcast (rank " + std::to_string(rank) + " of " + std::to_string(world) + "): " + what); MG4_ERR("%s", last_error().c_str()); return (int)E_LoadLanguageModel; };
-    Rccl rccl;
+    // round 5 (advisor): EVERY rank takes part in the same sequence of collectives and learns the same verdict, so a failure anywhere fails the load everywhere instead of
+    // leaving the healthy ranks inside a collective for ever: (1) a rank whose own load failed (header error, unsupported tensor) still joins and says so; (2) agreement is a
+    // symmetric all-reduce (element-wise max of {x, ~x} = max and min of every word, plus an "I am fine" flag), not a one-way broadcast only the receivers compare;
+    // (3) ncclCommInitRank runs under a watchdog (dist.cpp) and the stream waits below are bounded by MINIGPT4_DIST_TIMEOUT_S.
+    auto fail = [&](const std::string &what) {
+        if (rank == 0) unlink(id_file.c_str());        // never leave an id behind that a later job could pick up
+        set_last_error("weight broadcast (rank " + std::to_string(rank) + " of " + std::to_string(world) + "): " + what); MG4_ERR("%s", last_error().c_str()); return (int)E_LoadLanguageModel; };
+    // the Rccl object outlives a timed-out bootstrap on purpose (its helper thread is still inside the library): heap-allocated, leaked when poisoned
+    struct Holder { Rccl *r = new Rccl; ~Holder() { if (r && !r->poisoned()) delete r; } } holder;
+    Rccl &rccl = *holder.r;
     if (rccl.open(err)) return fail(err);
     uint8_t id[128];
-    if (rank == 0) { if (rccl.unique_id(id, err) || publish_unique_id(id_file, id, err)) return fail(err); }
-    else if (await_unique_id(id_file, id, timeout_s, err)) return fail(err);
-    if (rccl.init(world, rank, id, err)) return fail(err);
+    if (rank == 0) { unlink(id_file.c_str()); if (rccl.unique_id(id, err) || publish_unique_id(id_file, id, err)) return fail(err); }
+    else if (await_unique_id(id_file, id, timeout_s, err, process_start_epoch_s())) return fail(err);
+    if (rccl.init(world, rank, id, timeout_s, err)) return fail(err);
     if (rank == 0) unlink(id_file.c_str());            // every rank has joined: a later job must not pick this id up
     const auto t0 = std::chrono::steady_clock::now();
+    auto wait_stream = [&](const char *what) -> bool {   // bounded hipStreamSynchronize: a peer that died inside a collective must not hang this rank
+        const auto w0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(stream_);
+            if (q == hipSuccess) return true;
+            if (q != hipErrorNotReady) { (void)hipGetLastError(); err = std::string(what) + ": " + hipGetErrorString(q); return false; }
+            if (std::chrono::steady_clock::now() - w0 > std::chrono::seconds(timeout_s)) { err = std::string(what) + " did not complete within " + std::to_string(timeout_s) + " s (a peer left the exchange?)"; return false; }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    };
     unsigned long long *d_words = nullptr;
-    HIP_CHECK(hipMalloc((void **)&d_words, 64));
+    HIP_CHECK(hipMalloc((void **)&d_words, 128));
     struct Free { unsigned long long *p; ~Free() { HIP_IGNORE(hipFree(p)); } } free_words{d_words};
-    auto agree = [&](const unsigned long long mine[4], const char *what) -> bool {     // rank 0's four words against this rank's
-        unsigned long long theirs[4];
-        HIP_CHECK(hipMemcpyAsync(d_words, mine, 32, hipMemcpyHostToDevice, stream_));
-        if (rccl.broadcast(d_words, 32, 0, stream_, err)) return false;
-        HIP_CHECK(hipMemcpyAsync(theirs, d_words, 32, hipMemcpyDeviceToHost, stream_));
-        HIP_CHECK(hipStreamSynchronize(stream_));
-        if (memcmp(mine, theirs, 32)) { char b[200]; snprintf(b, sizeof b, "%s differ from rank 0's (%llx %llx %llx %llx vs %llx %llx %llx %llx)", what, mine[0], mine[1], mine[2], mine[3], theirs[0], theirs[1], theirs[2], theirs[3]); err = b; return false; }
+    // Symmetric agreement: true on EVERY rank iff every rank passed ok and all ranks hold the same four words; otherwise false on every rank, with a message naming the cause.
+    auto agree = [&](const unsigned long long mine[4], bool ok_here, const char *what) -> bool {
+        unsigned long long v[10], r[10];
+        for (int i = 0; i < 4; i++) { v[i] = mine[i]; v[4 + i] = ~mine[i]; }
+        v[8] = ok_here ? 0ull : 1ull;                    // max over ranks: 1 = somebody failed before this point
+        v[9] = ok_here ? 0ull : (unsigned long long)(rank + 1);   // ... and (one of) who
+        HIP_CHECK(hipMemcpyAsync(d_words, v, sizeof v, hipMemcpyHostToDevice, stream_));
+        if (rccl.allreduce_max_u64(d_words, 10, stream_, err)) return false;
+        HIP_CHECK(hipMemcpyAsync(r, d_words, sizeof r, hipMemcpyDeviceToHost, stream_));
+        if (!wait_stream(what)) return false;
+        if (r[8]) { err = std::string("rank ") + std::to_string((long long)r[9] - 1) + " failed before \"" + what + "\"" + (ok_here ? "" : " (this rank: " + last_error() + ")"); return false; }
+        for (int i = 0; i < 4; i++) if (r[i] != ~r[4 + i]) {   // max != min: the ranks disagree
+            char b[256]; snprintf(b, sizeof b, "%s differ between the ranks (word %d: max %llx, min %llx; this rank %llx)", what, i, r[i], ~r[4 + i], mine[i]); err = b; return false; }
         return true;
     };
     const ArenaPlan pl = arena_plan();
     const unsigned long long plan_words[4] = {(unsigned long long)pl.llm_bytes, (unsigned long long)pl.vision_bytes, (unsigned long long)pl.llm_hash, (unsigned long long)pl.vision_hash};
-    if (!agree(plan_words, "arena layouts (sizes / layout hashes)")) return fail(err);
+    if (!agree(plan_words, local_err == 0, "arena layouts (sizes / layout hashes)")) return fail(err);
     if (rccl.broadcast(llm_arena_.base, llm_arena_.used, 0, stream_, err) || rccl.broadcast(vis_arena_.base, vis_arena_.used, 0, stream_, err)) return fail(err);
-    HIP_CHECK(hipStreamSynchronize(stream_));
+    if (!wait_stream("the arena broadcast")) return fail(err);
     dist_bcast_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (load_mode_ == LOAD_RECV) weights_received();
-    const unsigned long long sums[4] = {device_checksum(llm_arena_.base, llm_arena_.used, stream_), device_checksum(vis_arena_.base, vis_arena_.used, stream_), 0ull, 0ull};
-    if (!agree(sums, "arena contents (checksums) after the broadcast")) return fail(err);
+    bool derived_ok = true;
+    try { if (load_mode_ == LOAD_RECV) weights_received(); } catch (const HipError &e) { derived_ok = false; set_last_error(std::string("weights_received: ") + e.what); }
+    unsigned long long sums[4] = {0ull, 0ull, 0ull, 0ull};
+    if (derived_ok) { sums[0] = device_checksum(llm_arena_.base, llm_arena_.used, stream_); sums[1] = device_checksum(vis_arena_.base, vis_arena_.used, stream_); }
+    if (!agree(sums, derived_ok, "arena contents (checksums) after the broadcast")) return fail(err);
     dist_world_ = world; dist_rank_ = rank;
     MG4_INFO("rank %d of %d: weight arenas %s in %.1f ms (%.2f GB, RCCL)", rank, world, rank ? "received" : "broadcast", dist_bcast_ms_, (llm_arena_.used + vis_arena_.used) / 1e9);
     return E_None;
@@ -186,6 +228,7 @@ int Engine::weights_received() {
     load_mode_ = LOAD_FULL;
     const size_t NQ = (size_t)v_nq_;
     for (size_t b = 0; b < (size_t)VISION_BATCH_MAX; b++) HIP_CHECK(hipMemcpy(vi_qtok_rep_ + b * NQ * 768, v_qtok_, NQ * 768 * 4, hipMemcpyDeviceToDevice));
+    fold_qformer_constants();
     return 0;
 }
 // Host only: the arena layout (sizes + layout hashes) the two files produce, without a device: what a receiving rank must reproduce (tests/test_cpu_dist.py).
@@ -234,6 +277,8 @@ int Engine::load_llm(const std::string &path) {
     const int hd = E / (int)llm_.n_head;
     if (!attn_head_size_supported(hd)) { set_last_error("unsupported head size (supported: 32, 64, 128)"); return E_LoadLanguageModel; }
     // k_attn_llm keeps one fp32 score + one fp16 probability per key of the context in LDS (6 bytes per key, 160 KiB per workgroup): refuse what cannot launch
+    if (parity_) attn_ref_prepare();
+    if (parity_ && n_ctx_ > attn_ref_max_ctx(hd)) { set_last_error("MINIGPT4_PARITY: n_ctx " + std::to_string(n_ctx_) + " exceeds what the oracle-order attention kernel's LDS rows hold (" + std::to_string(attn_ref_max_ctx(hd)) + ")"); MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
     if (n_ctx_ > attn_max_ctx(hd)) { set_last_error("n_ctx " + std::to_string(n_ctx_) + " exceeds what the attention kernel's LDS score buffer holds (" + std::to_string(attn_max_ctx(hd)) + ")"); MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
     MG4_INFO("llm: n_vocab %d n_embd %d n_head %u n_layer %d n_ff %d n_ctx %d", V, E, llm_.n_head, L, F, n_ctx_);
     auto need = [&](const std::string &name, int64_t ne0, int64_t ne1) -> const TensorMeta * {
@@ -363,14 +408,14 @@ int Engine::load_vision(const std::string &path) {
     };
     // generic mode: the Linear weights are uploaded as QWeights by load_vision_generic(); the fp16 pointers of this path stay null
     auto up16 = [&](const TensorMeta *t) -> __half * { return t && !v_generic_ ? upload_raw<__half>(vis_arena_, fb + t->offset, t->nbytes) : nullptr; };
-    auto concat16 = [&](std::initializer_list<const TensorMeta *> ts) -> __half * {
+    auto concat16 = [&](const std::vector<const TensorMeta *> &ts) -> __half * {
         if (v_generic_) return nullptr;
         size_t bytes = 0; for (auto t : ts) { if (!t) return nullptr; bytes += t->nbytes; }
         uint8_t *d = vis_arena_.take(bytes); size_t off = 0;
         for (auto t : ts) { if (moves_data()) HIP_CHECK(hipMemcpy(d + off, fb + t->offset, t->nbytes, hipMemcpyHostToDevice)); off += t->nbytes; }
         return reinterpret_cast<__half *>(d);
     };
-    auto concat32 = [&](std::initializer_list<std::pair<const char *, std::string>> names, int64_t each) -> float * {
+    auto concat32 = [&](const std::vector<std::pair<const char *, std::string>> &names, int64_t each) -> float * {
         uint8_t *d = vis_arena_.take((size_t)each * 4 * names.size()); size_t off = 0;
         for (auto &nm : names) { const TensorMeta *t = vis_.find(nm.first, nm.second);
             if (!t || t->type != GT_F32 || t->nelements() != each) { ok = false; bad = nm.second; return nullptr; }
@@ -413,6 +458,18 @@ int Engine::load_vision(const std::string &path) {
     const char *QF = "Qformer";
     v_qeln_w_ = f32v(QF, "bert.embeddings.LayerNorm.weight", 768); v_qeln_b_ = f32v(QF, "bert.embeddings.LayerNorm.bias", 768);
     qlayers_.resize((size_t)v_ql_);
+    {   // the K | V projections of every cross-attention layer as ONE contiguous block [n_cross * 1536][D] (+ biases): one GEMM per image batch instead of one per cross layer
+        std::vector<const TensorMeta *> kvw; std::vector<std::pair<const char *, std::string>> kvb;
+        v_ncross_ = 0;
+        for (int i = 0; i < v_ql_; i++) {
+            const std::string a = "bert.encoder.layer." + std::to_string(i) + ".crossattention.";
+            if (!vis_.find(QF, a + "self.query.weight")) continue;
+            kvw.push_back(f16m(QF, a + "self.key.weight", D, 768)); kvw.push_back(f16m(QF, a + "self.value.weight", D, 768));
+            kvb.push_back({QF, a + "self.key.bias"}); kvb.push_back({QF, a + "self.value.bias"});
+            qlayers_[(size_t)i].cross_idx = v_ncross_++;
+        }
+        if (v_ncross_ && ok) { v_kv_all_w_ = concat16(kvw); v_kv_all_b_ = concat32(kvb, 768); }
+    }
     for (int i = 0; i < v_ql_ && ok; i++) {
         const std::string p = "bert.encoder.layer." + std::to_string(i) + ".";
         QLayer &L = qlayers_[(size_t)i];
@@ -427,8 +484,8 @@ int Engine::load_vision(const std::string &path) {
         if (L.has_cross) {
             const std::string a = p + "crossattention.";
             L.cross.q_w = up16(f16m(QF, a + "self.query.weight", 768, 768)); L.cross.q_b = f32v(QF, a + "self.query.bias", 768);
-            L.cross.kv_w = concat16({f16m(QF, a + "self.key.weight", D, 768), f16m(QF, a + "self.value.weight", D, 768)});
-            L.cross.kv_b = concat32({{QF, a + "self.key.bias"}, {QF, a + "self.value.bias"}}, 768);
+            L.cross.kv_w = v_kv_all_w_ ? v_kv_all_w_ + (size_t)L.cross_idx * 1536 * D : nullptr;          // this layer's [1536][D] slice of the shared block
+            L.cross.kv_b = v_kv_all_b_ ? v_kv_all_b_ + (size_t)L.cross_idx * 1536 : nullptr;
             L.cross.dense_w = up16(f16m(QF, a + "output.dense.weight", 768, 768)); L.cross.dense_b = f32v(QF, a + "output.dense.bias", 768);
             L.cross.ln_w = f32v(QF, a + "output.LayerNorm.weight", 768); L.cross.ln_b = f32v(QF, a + "output.LayerNorm.bias", 768);
         }
@@ -456,12 +513,12 @@ void Engine::alloc_buffers() {
     auto sz = [&](size_t b) { total += (b + 255) / 256 * 256 + 256; };
     sz(S * L * C * E * 2); sz(S * L * C * E * 2); sz(2 * C * (hd / 2) * 4 * 2); sz(3 * 65536 * 2);
     sz(5 * B * E * 4); sz(2 * B * F * 4); sz(S * V * 4); sz(S * V * 4); sz(8 * 256 + 2 * B * 4);
-    sz(2 * B * Kmax); sz(B * Kmax / 256 * 4 + 64); sz(B * Kmax / 16 * 2 + 64); sz(B * Kmax / 16 + 64); sz(4 * (B * Kmax / 32 * 4 + 64)); sz(B * Kmax * 2); sz(B * Kmax * 4);
+    sz(2 * B * Kmax); sz(B * Kmax / 256 * 4 + 64); sz(B * Kmax / 16 * 2 + 64); sz(B * Kmax / 16 + 64); sz(B * Kmax * 2); sz(B * Kmax / 8 + 128); sz(4 * (B * Kmax / 32 * 4 + 64)); sz(B * Kmax * 2); sz(B * Kmax * 4);
     sz(8192); sz((size_t)64 << 20); sz(attn_split_workspace_bytes((int)llm_.n_head, (int)hd, n_ctx_, std::max(attn_splits_forced_, attn_split_count((int)llm_.n_head, n_cus_))));
     const size_t VB = (size_t)VISION_BATCH_MAX;                            // images encoded in one pass (minigpt4_encode_images)
     sz(VB * 3 * 224 * 224 * 4); sz(VB * 256 * 592 * 2); sz(VB * 256 * D * 4); sz(VB * 257 * D * 4); sz(VB * 257 * 3 * D * 4); sz(VB * 3 * 257 * D * 2); sz(VB * 257 * M * 2);
     sz(VB * (size_t)SPLITK_MAX * 257 * D * 4);
-    sz(VB * 9 * NQ * 2304 * 4); sz(VB * 257 * 1536 * 4); sz(VB * NQ * (size_t)std::max(v_qi_, 768) * 2 * 4); sz(VB * NQ * (size_t)v_out_ * 4); sz(1 << 20);
+    sz(VB * 9 * NQ * 2304 * 4); sz(VB * 257 * 1536 * 4 * (size_t)std::max(1, v_ncross_)); sz(VB * NQ * 768 * 4); sz(VB * NQ * 768 * 4); sz(VB * NQ * 768 * 2); sz(VB * NQ * (size_t)std::max(v_qi_, 768) * 2 * 4); sz(VB * NQ * (size_t)v_out_ * 4); sz(1 << 20);
     buf_arena_.alloc(total);
     auto takef = [&](size_t n) { return reinterpret_cast<float *>(buf_arena_.take(n * 4)); };
     auto takeh = [&](size_t n) { return reinterpret_cast<__half *>(buf_arena_.take(n * 2)); };
@@ -496,6 +553,7 @@ void Engine::alloc_buffers() {
     act_.q8k = reinterpret_cast<int8_t *>(buf_arena_.take(B * Kmax)); act_.q80 = reinterpret_cast<int8_t *>(buf_arena_.take(B * Kmax));
     act_.dk = takef(B * Kmax / 256 + 16); act_.bsk = reinterpret_cast<int16_t *>(buf_arena_.take(B * Kmax / 16 * 2 + 64));
     act_.bsq = reinterpret_cast<int8_t *>(buf_arena_.take(B * Kmax / 16 + 64));
+    if (mmqh_enabled()) { act_.q16 = takeh(B * Kmax); act_.bs16 = takeh(B * Kmax / 16 + 64); }   // MINIGPT4_MMQH=1 only: fp16 images of the Q8_K rows for the fp16-MFMA prompt mat-mul (k_mmqh_q45k, not adopted)
     act_.d0 = takef(B * Kmax / 32 + 16); act_.d1 = takef(B * Kmax / 32 + 16); act_.s1 = takef(B * Kmax / 32 + 16);
     act_.sum0 = reinterpret_cast<int *>(buf_arena_.take(B * Kmax / 32 * 4 + 64));
     act_.xh = takeh(B * Kmax); act_.xf = takef(B * Kmax);
@@ -524,11 +582,12 @@ void Engine::alloc_buffers() {
     vi_img_ = takef(VB * 3 * 224 * 224); vi_patches_ = takeh(VB * 256 * 592); vi_pe_ = takef(VB * 256 * D); vi_x_ = takef(VB * 257 * D); vi_qkv_ = takef(VB * 257 * 3 * D);
     vi_slab_ = takef(VB * (size_t)SPLITK_MAX * 257 * D);
     vi_ln_h_ = takeh(VB * 257 * D); vi_att_h_ = takeh(VB * 257 * D); vi_img_h_ = takeh(VB * 257 * D); vi_mlp_h_ = takeh(VB * 257 * M);
-    vi_hs_ = takef(VB * NQ * 768); vi_a1_ = takef(VB * NQ * 768); vi_a2_ = takef(VB * NQ * 768); vi_d_ = takef(VB * NQ * 768); vi_qq_ = takef(VB * NQ * 2304); vi_kv_ = takef(VB * 257 * 1536);
+    vi_hs_ = takef(VB * NQ * 768); vi_a1_ = takef(VB * NQ * 768); vi_a2_ = takef(VB * NQ * 768); vi_d_ = takef(VB * NQ * 768); vi_qq_ = takef(VB * NQ * 2304); vi_kv_ = takef(VB * 257 * 1536 * (size_t)std::max(1, v_ncross_));
     vi_hs_h_ = takeh(VB * NQ * 768); vi_a1_h_ = takeh(VB * NQ * 768); vi_a2_h_ = takeh(VB * NQ * 768); vi_ctx_h_ = takeh(VB * NQ * 768); vi_im_h_ = takeh(VB * NQ * (size_t)v_qi_);
     vi_out_ = takef(VB * NQ * (size_t)v_out_);
     vi_qtok_rep_ = takef(VB * NQ * 768);                                  // the query tokens once per image of a batch (every image starts from the same rows)
     if (load_mode_ == LOAD_FULL) for (size_t b = 0; b < VB; b++) HIP_CHECK(hipMemcpy(vi_qtok_rep_ + b * NQ * 768, v_qtok_, NQ * 768 * 4, hipMemcpyDeviceToDevice));   // LOAD_RECV: weights_received()
+    vi_c_a1_ = takef(VB * NQ * 768); vi_c_qq_ = takef(VB * NQ * 768); vi_c_a1_h_ = takeh(VB * NQ * 768);
     if (v_generic_) alloc_vision_generic();
     MG4_INFO("KV cache %.1f MB (fp16, n_ctx %d, %zu conversation%s), activation arena %.1f MB", 2.0 * S * L * C * E * 2 / 1048576.0, n_ctx_, S, S == 1 ? "" : "s", buf_arena_.used / 1048576.0);
 }
@@ -747,6 +806,11 @@ void Engine::forward_ref(int N, bool from_tokens, hipStream_t s, bool feed) {
 }
 void Engine::set_parity(bool on) {
     if (on == parity_) return;
+    if (on && llm_.n_head > 0) {   // (advisor, round 4) the oracle-order attention kernel holds fewer keys in LDS than the fast one: refuse here, not at the first launch
+        const int hd = (int)(llm_.n_embd / llm_.n_head), lim = attn_ref_max_ctx(hd);
+        if (n_ctx_ > lim) throw HipError{hipErrorInvalidValue, "parity mode: n_ctx exceeds what the oracle-order attention kernel's LDS rows hold (attn_ref_max_ctx)", __FILE__, __LINE__};
+        attn_ref_prepare();
+    }
     HIP_CHECK(hipStreamSynchronize(stream_));
     for (Conversation &c : conv_) { if (c.graph) HIP_IGNORE(hipGraphExecDestroy(c.graph)); c.graph = nullptr; }   // captured with the other mode's launches
     for (hipGraphExec_t &g : batch_graph_) { if (g) HIP_IGNORE(hipGraphExecDestroy(g)); g = nullptr; }
@@ -1241,18 +1305,31 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
     auto qgemm = [&](const __half *A, int lda, const __half *W, int ldw, int Mr, int N, int K, const float *bias, const float *residual, bool gelu, float *o, __half *oh, int ldo) {
         if (!(qf_skinny_ && launch_gemm_f16_skinny(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_, o, oh, ldo, s))) launch_gemm_f16(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_, o, oh, ldo, s);
     };
-    launch_layernorm(vi_qtok_rep_, v_qeln_w_, v_qeln_b_, RQ, H, vi_hs_, vi_hs_h_, s);
-    for (const QLayer &L : qlayers_) {
-        qgemm(vi_hs_h_, H, L.self.q_w, H, RQ, 3 * H, H, L.self.q_b, nullptr, false, vi_qq_, nullptr, 3 * H);
-        launch_attn_f32(vi_qq_, 3 * H, vi_qq_ + H, vi_qq_ + 2 * H, 3 * H, NQ, NQ, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s, B);
-        qgemm(vi_ctx_h_, H, L.self.dense_w, H, RQ, H, H, L.self.dense_b, vi_hs_, false, vi_d_, nullptr, H);
-        launch_layernorm(vi_d_, L.self.ln_w, L.self.ln_b, RQ, H, vi_a1_, vi_a1_h_, s);
-        const float *ao = vi_a1_; const __half *ao_h = vi_a1_h_;
+    // the cross-attention K | V projections of every cross layer depend on the image features only (minigpt4.cpp:1148-1155): ONE [R x D] . [D x n_cross * 1536] launch here instead
+    // of one per cross layer inside the loop; layer i reads its [R][1536] column slice (row stride n_cross * 1536)
+    const bool hoist = kv_hoist_ && v_ncross_ > 0 && v_kv_all_w_;
+    const int ldkv = hoist ? v_ncross_ * 2 * H : 2 * H;
+    if (hoist) launch_gemm_f16(vi_img_h_, D, v_kv_all_w_, D, R, v_ncross_ * 2 * H, D, v_kv_all_b_, nullptr, false, tabs_, vi_kv_, nullptr, ldkv, s);
+    const bool folded = qf_fold_ && qf_folded_;                            // layer 0's image-independent head was evaluated at load time (fold_qformer_constants)
+    if (!folded) launch_layernorm(vi_qtok_rep_, v_qeln_w_, v_qeln_b_, RQ, H, vi_hs_, vi_hs_h_, s);
+    for (size_t il = 0; il < qlayers_.size(); il++) {
+        const QLayer &L = qlayers_[il];
+        const bool pre = folded && il == 0;
+        const float *a1 = pre ? vi_c_a1_ : vi_a1_; const __half *a1_h = pre ? vi_c_a1_h_ : vi_a1_h_;
+        if (!pre) {
+            qgemm(vi_hs_h_, H, L.self.q_w, H, RQ, 3 * H, H, L.self.q_b, nullptr, false, vi_qq_, nullptr, 3 * H);
+            launch_attn_f32(vi_qq_, 3 * H, vi_qq_ + H, vi_qq_ + 2 * H, 3 * H, NQ, NQ, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s, B);
+            qgemm(vi_ctx_h_, H, L.self.dense_w, H, RQ, H, H, L.self.dense_b, vi_hs_, false, vi_d_, nullptr, H);
+            launch_layernorm(vi_d_, L.self.ln_w, L.self.ln_b, RQ, H, vi_a1_, vi_a1_h_, s);
+        }
+        const float *ao = a1; const __half *ao_h = a1_h;
         if (L.has_cross) {
-            qgemm(vi_a1_h_, H, L.cross.q_w, H, RQ, H, H, L.cross.q_b, nullptr, false, vi_qq_, nullptr, H);
-            launch_gemm_f16(vi_img_h_, D, L.cross.kv_w, D, R, 2 * H, D, L.cross.kv_b, nullptr, false, tabs_, vi_kv_, nullptr, 2 * H, s);
-            launch_attn_f32(vi_qq_, H, vi_kv_, vi_kv_ + H, 2 * H, NQ, 257, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s, B);
-            qgemm(vi_ctx_h_, H, L.cross.dense_w, H, RQ, H, H, L.cross.dense_b, vi_a1_, false, vi_d_, nullptr, H);
+            const float *cq = pre ? vi_c_qq_ : vi_qq_;
+            if (!pre) qgemm(vi_a1_h_, H, L.cross.q_w, H, RQ, H, H, L.cross.q_b, nullptr, false, vi_qq_, nullptr, H);
+            const float *kv = hoist ? vi_kv_ + (size_t)L.cross_idx * 2 * H : vi_kv_;
+            if (!hoist) launch_gemm_f16(vi_img_h_, D, L.cross.kv_w, D, R, 2 * H, D, L.cross.kv_b, nullptr, false, tabs_, vi_kv_, nullptr, 2 * H, s);
+            launch_attn_f32(cq, H, kv, kv + H, ldkv, NQ, 257, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s, B);
+            qgemm(vi_ctx_h_, H, L.cross.dense_w, H, RQ, H, H, L.cross.dense_b, a1, false, vi_d_, nullptr, H);
             launch_layernorm(vi_d_, L.cross.ln_w, L.cross.ln_b, RQ, H, vi_a2_, vi_a2_h_, s);
             ao = vi_a2_; ao_h = vi_a2_h_;
         }
@@ -1269,5 +1346,33 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
     return E_None;
 }
 int Engine::encode_image(const float *chw, float *out) { return encode_images(&chw, 1, &out); }
+
+// What the Q-Former computes before it first looks at the image: hs = LayerNorm(query tokens) (minigpt4.cpp:2236-2246), layer 0's self-attention block on hs
+// (NNSelfAttention + residual + LayerNorm, minigpt4.cpp:1365-1400) and, when layer 0 has cross-attention, its query projection.  None of it depends on the image, so it is
+// evaluated ONCE here -- by the very launches encode_images would issue for one image (32 rows) -- and replicated for the images of a batch: six launches less per encode,
+// bit-identical embeddings.  Fast f16 path only (parity mode and quantised / f32 vision files run their own chains).
+void Engine::fold_qformer_constants() {
+    qf_folded_ = false;
+    if (!qf_fold_ || v_generic_ || qlayers_.empty() || !vi_c_a1_) return;
+    hipStream_t s = stream_;
+    const int H = 768, NQ = v_nq_;
+    const QLayer &L = qlayers_[0];
+    auto qgemm = [&](const __half *A, int lda, const __half *W, int ldw, int Mr, int N, int K, const float *bias, const float *residual, bool gelu, float *o, __half *oh, int ldo) {
+        if (!(qf_skinny_ && launch_gemm_f16_skinny(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_, o, oh, ldo, s))) launch_gemm_f16(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_, o, oh, ldo, s);
+    };
+    launch_layernorm(vi_qtok_rep_, v_qeln_w_, v_qeln_b_, NQ, H, vi_hs_, vi_hs_h_, s);
+    qgemm(vi_hs_h_, H, L.self.q_w, H, NQ, 3 * H, H, L.self.q_b, nullptr, false, vi_qq_, nullptr, 3 * H);
+    launch_attn_f32(vi_qq_, 3 * H, vi_qq_ + H, vi_qq_ + 2 * H, 3 * H, NQ, NQ, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s, 1);
+    qgemm(vi_ctx_h_, H, L.self.dense_w, H, NQ, H, H, L.self.dense_b, vi_hs_, false, vi_d_, nullptr, H);
+    launch_layernorm(vi_d_, L.self.ln_w, L.self.ln_b, NQ, H, vi_c_a1_, vi_c_a1_h_, s);
+    if (L.has_cross) qgemm(vi_c_a1_h_, H, L.cross.q_w, H, NQ, H, H, L.cross.q_b, nullptr, false, vi_c_qq_, nullptr, H);
+    HIP_CHECK(hipStreamSynchronize(s));
+    const size_t n = (size_t)NQ * H;
+    for (size_t b = 1; b < (size_t)VISION_BATCH_MAX; b++) {
+        HIP_CHECK(hipMemcpy(vi_c_a1_ + b * n, vi_c_a1_, n * 4, hipMemcpyDeviceToDevice)); HIP_CHECK(hipMemcpy(vi_c_a1_h_ + b * n, vi_c_a1_h_, n * 2, hipMemcpyDeviceToDevice));
+        if (L.has_cross) HIP_CHECK(hipMemcpy(vi_c_qq_ + b * n, vi_c_qq_, n * 4, hipMemcpyDeviceToDevice));
+    }
+    qf_folded_ = true;
+}
 
 }  // namespace mg4

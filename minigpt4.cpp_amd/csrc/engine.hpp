@@ -120,7 +120,7 @@ private:
     template <typename T> T *upload_raw(DeviceArena &a, const void *src, size_t bytes);
 
 
-    int native_broadcast(int world, int rank, const std::string &id_file, int timeout_s);
+    int native_broadcast(int world, int rank, const std::string &id_file, int timeout_s, int local_err = 0);
     int dist_world_ = 1, dist_rank_ = 0; float dist_bcast_ms_ = 0.0f;
     LoadMode load_mode_ = LOAD_FULL;
     bool moves_data() const { return load_mode_ == LOAD_FULL; }
@@ -184,7 +184,7 @@ private:
     int v_D_ = 0, v_depth_ = 0, v_M_ = 0, v_heads_ = 0, v_ql_ = 0, v_qi_ = 0, v_nq_ = 32, v_out_ = 0;
     struct VBlock { float *n1w, *n1b, *n2w, *n2b, *qkv_b, *proj_b, *fc1_b, *fc2_b; __half *qkv_w, *proj_w, *fc1_w, *fc2_w; };
     struct QAtt { __half *q_w = nullptr, *kv_w = nullptr, *dense_w = nullptr; float *q_b = nullptr, *kv_b = nullptr, *dense_b = nullptr, *ln_w = nullptr, *ln_b = nullptr; };
-    struct QLayer { QAtt self, cross; bool has_cross = false; __half *inter_w, *out_w; float *inter_b, *out_b, *oln_w, *oln_b; };
+    struct QLayer { QAtt self, cross; bool has_cross = false; int cross_idx = -1; __half *inter_w, *out_w; float *inter_b, *out_b, *oln_w, *oln_b; };
     std::vector<VBlock> vblocks_;
     std::vector<QLayer> qlayers_;
     float *v_cls_ = nullptr, *v_pos_ = nullptr, *v_patch_b_ = nullptr, *v_lnv_w_ = nullptr, *v_lnv_b_ = nullptr, *v_qtok_ = nullptr, *v_qeln_w_ = nullptr, *v_qeln_b_ = nullptr, *v_proj_b_ = nullptr;
@@ -196,6 +196,14 @@ private:
     __half *vi_patches_ = nullptr, *vi_ln_h_ = nullptr, *vi_att_h_ = nullptr, *vi_mlp_h_ = nullptr, *vi_img_h_ = nullptr, *vi_hs_h_ = nullptr, *vi_a1_h_ = nullptr, *vi_a2_h_ = nullptr, *vi_ctx_h_ = nullptr, *vi_im_h_ = nullptr;
     float last_encode_ms_ = 0;
     bool qf_skinny_ = true;            // Q-Former GEMMs on k_gemm_f16_skinny
+    // round 5, launch count of the image path: (1) the cross-attention K | V projections of ALL cross layers are one weight block [n_cross * 1536][D] -- they depend on the
+    // image features only (minigpt4.cpp:1148-1155), so one GEMM right after ln_vision replaces one per cross layer; (2) what the Q-Former computes BEFORE it first looks at
+    // the image -- LayerNorm(query tokens), layer 0's self-attention block and its cross-attention query projection -- does not depend on the image at all: evaluated once
+    // at load time by the same launches (fold_qformer_constants), kept for every image of a batch.  MINIGPT4_QF_FOLD=0 / MINIGPT4_KV_HOIST=0: the round-4 form (A/B).
+    __half *v_kv_all_w_ = nullptr; float *v_kv_all_b_ = nullptr; int v_ncross_ = 0;
+    float *vi_c_a1_ = nullptr, *vi_c_qq_ = nullptr; __half *vi_c_a1_h_ = nullptr;
+    bool qf_fold_ = true, qf_folded_ = false, kv_hoist_ = true;
+    void fold_qformer_constants();
 
     // ---- vision files whose Linear weights are not all F16 (an `--ftype f32` conversion, or a file written by minigpt4_quantize_model): every Linear is a
     // QWeight served by the LLM mat-mul kernels (activations quantised to the weight type's vec_dot_type, exactly ggml's mul_mat), activations stay fp32.

@@ -48,11 +48,14 @@ void launch_rope_kv_slabs(const SlabSrc &src, int N, int n_head, int hd, const i
 bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s, SlabSrc *defer = nullptr,
                      int force_ks = 0);   // force_ks == 1: no K split = the CPU oracle's fp32 order (parity mode's prompt rows)
 void set_mmq2_cus(int cus);
+void set_mmqh(int v);   // 1: Q4_K / Q5_K prompt rows on the fp16 matrix cores with the sub-block scales folded into the weight operands (k_mmqh_q45k; measured slower, profiles/r05_prefill_fp16_scaled_operands.md); 0 (default): the int8 kernels
+int mmqh_enabled();
 // (test library only: measured in round 4, not adopted) prompt mat-mul on load-time digit planes (mmq3_kernels.hip): Q4_K / Q5_K, sub-block scale x quant stored as 128 hi + lo (1.5 B per weight) in MFMA-fragment order
 bool mmq3_supported(int type, int rows, int cols);
 size_t mmq3_plane_bytes(int rows, int cols, size_t *hi_off = nullptr);
 void launch_mmq3_build(const QWeight &W, uint8_t *planes, hipStream_t s);
 bool launch_mmq3_set(const QWeight *const *W, const uint8_t *const *planes, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s, SlabSrc *defer = nullptr);
+int probe_tn_mfma(int rows, int cols, int TN, int iters, int n_sets, int check, int cus, float *us_per_launch, float *rel_diff);   // (test library with `make test-extras` only) tn_mfma_probe.hip
 void set_mmq3_waves(int nw);                          // 8 (default): 128-row workgroups, one per CU; 4: 64-row workgroups, two per CU (slower)
 void set_mmq3_tuning(int cus, int ks);                // CU count (<= 0: leave), forced K split (0 = the launcher's choice, < 0: leave)
 void set_mmq2_tuning(int tt, int fill_pct, int ks);   // experiment knobs, 0 = the launcher's choice, < 0 = leave as it is (read from the environment once, by Engine::init)
@@ -84,6 +87,7 @@ bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, con
 bool launch_matvec_rows_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, int N, int ldy, hipStream_t s,
                               const float *px = nullptr, const float *pw = nullptr, int ldx = 0);
 void set_matvec_tuning(int waves_per_cu, int fat_threads, int cus);   // 0 = choose per launch
+void set_matvec_pack(int v);   // 1 (default): K = 5120 k-quant rows pair-packed (two rows per 5 lane-walks); 0: one row per 3
 // measurement: while tracing is on, every launcher of llm_kernels.hip notes the kernel symbol it launched (as rocprofv3 prints it, without the argument list)
 void kernel_name_tracing(bool on);
 const char *last_kernel_name();          // "" when nothing was launched since the last reset
@@ -131,6 +135,8 @@ void launch_attn_ref_fused(const float *q, const float *k, const float *v, __hal
 void set_attn_prefill_f16(int v);
 void set_attn_prefill_w8(int v);    // 8-wave loader / MFMA form of the fp16 prompt attention (MINIGPT4_ATTN_PREFILL_W8)   // 1 (default): prompt attention on the fp16 matrix cores, 0: the exact-f32 MFMA kernel
 bool attn_head_size_supported(int hd);
+void attn_ref_prepare();        // the oracle-order attention kernels' > 64 KiB LDS opt-in on the current device, checked (throws HipError); outside any stream capture
+int attn_ref_max_ctx(int hd);   // the same bound for the oracle-order kernel of parity mode (smaller: it also stages value rows in LDS)
 int attn_max_ctx(int hd);   // largest n_ctx whose score / probability rows fit the attention kernel's LDS
 void launch_argmax(const float *logits, int n, int *out, void *scratch /*>= 512 bytes*/, hipStream_t s);
 void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);

@@ -588,6 +588,212 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_mmq2_q40(const Mmq2Args a, cons
     mmq2_store<TT>(accf, a, m, r0 + l31, W.rows, t0, my_tiles, hh);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Q4_K / Q5_K prompt rows on the FP16 matrix cores, sub-block scales folded into the weight operands (round 5; north_star: "block dequant fused into the ... matmul, MFMA
+// bf16/fp16 tiles for ... Vicuna prefill").  The int8 kernels above are bound by vector issue: one integer multiply-add per output element per 32 weights for the 6-bit
+// sub-block scales (8 per 256 weights, ~300 VALU instructions per token tile and super-block beside 10 MFMAs).  Here the scale rides INSIDE the matrix product:
+//   * B operand = sc_j * q as fp16 -- an integer <= 63 * 31 = 1953 < 2048, EXACT in fp16 -- built once per super-block and row tile (mask + v_pk_fma_f16 per two weights:
+//     (1024 + q) * sc - 1024 * sc) and reused for every token tile;
+//   * A operand = the activation row's Q8_K values (ggml's quantisation, unchanged) as fp16, from the plane the activation quantiser writes next to the int8 one (ActQ::q16,
+//     already in fragment order): |q8| <= 127 exact;
+//   * v_mfma_f32_32x32x16_f16 accumulates the super-block's 256 products (<= 1953 * 127, exact in the fp32 accumulator up to 2^24, beyond that rounded at 6e-8 relative)
+//     -> ONE fma per output element per super-block with d_w * d_a;  the min term sum_j m_j * bsum_j is one more MFMA on the digit split bsum = 128 hi + lo (exact).
+// 17 MFMAs + 48 VALU operations per token tile and super-block instead of 10 + ~300; same ggml arithmetic (Q8_K activations, integer sub-block products, fp32 super-block
+// scales) up to the fp32 rounding of the in-block sum, i.e. it differs from k_mmq2_q45k like one summation order from another.  Parity mode keeps k_mmq2_q45k (force_ks == 1).
+// Stages are HALF super-blocks (128 weights = units 4 h .. 4 h + 3): the fp16 activation image is twice the int8 one, and half stages keep the LDS footprint of the int8
+// kernel (two workgroups per CU).  Lane (row, hh) owns pair p = 2 h + hh of the half: units 2 p, 2 p + 1 = low nibbles -> sub-block 2 p, high nibbles -> sub-block 2 p + 1;
+// MFMA (uu, d) of a half multiplies dword d of unit 2 p + uu: k order [lo e0, e2, e1, e3 | hi e0, e2, e1, e3] (what two masks of one dword give), the activation plane is
+// stored in that order.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+template <int TT> struct MmqhStage {
+    static constexpr int TTP = (TT + 1) & ~1;
+    static constexpr int Q = TT * 32 * 256;                  // half super-block of fp16 values: 16 chunks of 16 B per token, chunk c at slot c ^ (token & 15)
+    static constexpr int BS = 2 * TTP * 32 * 16, DK = TTP * 32 * 4;   // per SUPER-block: digit halves [lo | hi][token][16 B], fp32 scale
+    static constexpr int BYTES = 2 * Q + 2 * (BS + DK);      // two half stages + two super-block side buffers
+};
+__device__ __forceinline__ unsigned pkfma(unsigned x, unsigned s2, unsigned c2) {   // v_pk_fma_f16 on bit patterns
+    const h2_t r = __builtin_elementwise_fma(__builtin_bit_cast(h2_t, x), __builtin_bit_cast(h2_t, s2), __builtin_bit_cast(h2_t, c2));
+    return __builtin_bit_cast(unsigned, r);
+}
+template <bool Q5, int TT>
+__global__ __launch_bounds__(256, 2) void k_mmqh_q45k(const Mmq2Args a, const ActQ A) {
+    using S = MmqhStage<TT>;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_mmq2[];   // [2 half stages][2 x (digits, scales)][4 waves x 4 KiB weight transpose scratch]
+    const int lane = threadIdx.x & 63, hh = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = blockIdx.x / a.groups_each, g = blockIdx.x - m * a.groups_each;
+    const QWeight W = a.w[m];
+    const int K = W.cols, U = K / 32, NSB = K / 256, N = a.N;
+    const int r0 = (g * 4 + wv) * 32;
+    const int row = min(r0 + l31, W.rows - 1);
+    const int tile0 = blockIdx.y * a.tiles_per_chunk, my_tiles = min(TT, a.n_tiles - tile0), t0 = tile0 * 32;
+    const int sb0 = blockIdx.z * a.sb_per_split, sb1 = min(NSB, sb0 + a.sb_per_split);
+    unsigned char *const side0 = smem_mmq2 + 2 * S::Q;
+    unsigned char *scratch = smem_mmq2 + S::BYTES + wv * 4096;
+
+    v16f acc[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; tt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[tt][r] = 0.0f;
+
+    struct Raw { v4i q[4]; v4i p; v4i h; };
+    const unsigned char *wq[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) wq[n] = W.qs + ((size_t)min(r0 + 8 * n + (lane >> 3), W.rows - 1) * U + (lane & 7)) * 16;
+    const unsigned char *wp = W.qh + (size_t)row * U * 4 + hh * 16, *wh = W.sc + (size_t)row * NSB * 16;
+    auto fetch = [&](int sb, Raw &w) {
+#pragma unroll
+        for (int n = 0; n < 4; n++) w.q[n] = ldg16(wq[n] + (size_t)sb * 128);
+        if (Q5) w.p = ldg16(wp + (size_t)sb * 32);
+        w.h = ldg16(wh + (size_t)sb * 16);
+    };
+    // half-stage requests: TT * 8 wave-instructions of 4 tokens x 16 chunks (the half's 256 bytes per token); wave wv issues 2 TT of them
+    // (per-lane byte offsets once, 32 bits: the rows of a prompt pass span < 2^31 bytes; per step only a wave-uniform offset is added)
+    unsigned qoff[2 * TT], soff[S::TTP / 2];
+#pragma unroll
+    for (int k = 0; k < 2 * TT; k++) {
+        const int tl = 4 * (wv * (2 * TT) + k) + (lane >> 4);
+        qoff[k] = (unsigned)min(t0 + tl, N - 1) * (unsigned)K * 2u + (unsigned)(((lane & 15) ^ (tl & 15)) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < S::TTP / 2; j++) soff[j] = (unsigned)min(t0 + 64 * j + lane, N - 1) * (unsigned)NSB;
+    const unsigned char *const q16b = reinterpret_cast<const unsigned char *>(A.q16), *const bs16b = reinterpret_cast<const unsigned char *>(A.bs16);
+    auto stage_half = [&](int sb, int h, unsigned char *st) {
+        const unsigned step = (unsigned)sb * 512u + (unsigned)h * 256u;
+#pragma unroll
+        for (int k = 0; k < 2 * TT; k++) dma16(q16b + (size_t)(qoff[k] + step), st + (wv * (2 * TT) + k) * 1024);
+    };
+    auto stage_side = [&](int sb, unsigned char *sd) {      // the super-block's digit sums (wave 0: low digits, wave 1: high digits) and scales (wave 2)
+#pragma unroll
+        for (int j = 0; j < S::TTP / 2; j++) {
+            if (wv < 2) dma16(bs16b + (size_t)((soff[j] + (unsigned)sb) * 32u + (unsigned)wv * 16u), sd + wv * (S::TTP * 32 * 16) + j * 1024);
+            if (wv == 2) dma4(A.dk + (size_t)(soff[j] + (unsigned)sb), sd + S::BS + j * 256);
+        }
+    };
+    unsigned sw_addr[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) sw_addr[n] = (unsigned)((8 * n + (lane >> 3)) * 128 + (((lane & 7) ^ ((4 * n + (lane >> 4)) & 7)) << 4));
+    // A fragment of MFMA (uu, d): chunk 8 hh + 4 uu + d of the half's 16, token l31 of tile 0
+    unsigned a_addr[8];
+#pragma unroll
+    for (int c8 = 0; c8 < 8; c8++) a_addr[c8] = (unsigned)(l31 * 256 + (((8 * hh + c8) ^ (l31 & 15)) << 4));
+    const unsigned bs_addr = (unsigned)(hh * (S::TTP * 32 * 16) + l31 * 16), dk_addr = (unsigned)(S::BS + 16 * hh);
+
+    Raw raw;
+    fetch(sb0, raw);
+    stage_half(sb0, 0, smem_mmq2);
+    stage_side(sb0, side0);
+    unsigned Pn[2][2] = {{0u, 0u}, {0u, 0u}};
+    unsigned scw[2] = {0u, 0u};
+    float dw = 0.0f, ndmin = 0.0f;
+    v4i bmin = {0, 0, 0, 0};
+    for (int sb = sb0; sb < sb1; sb++) {
+        unsigned char *const sd = side0 + ((sb - sb0) & 1) * (S::BS + S::DK);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            unsigned char *const st = smem_mmq2 + h * S::Q;
+            __syncthreads();                                       // own DMA + weight loads landed (vmcnt(0) is part of the barrier's fence), then everybody's
+            if (h == 0) {
+                // this super-block's weights: transpose through LDS (a wave's LDS operations execute in order), scales / mins / high bits into registers
+#pragma unroll
+                for (int n = 0; n < 4; n++) *reinterpret_cast<v4i *>(scratch + sw_addr[n]) = raw.q[n];
+                if (Q5) {   // lanes hh = 0 hold the high-bit words of units 0..3, hh = 1 of units 4..7; lane (row, hh) needs units 4 h + 2 hh + uu
+                    const auto s02 = __builtin_amdgcn_permlane32_swap((unsigned)raw.p[0], (unsigned)raw.p[2], false, false);
+                    const auto s13 = __builtin_amdgcn_permlane32_swap((unsigned)raw.p[1], (unsigned)raw.p[3], false, false);
+                    Pn[0][0] = s02[0]; Pn[1][0] = s02[1]; Pn[0][1] = s13[0]; Pn[1][1] = s13[1];
+                }
+                const unsigned s0 = (unsigned)raw.h[1], s1 = (unsigned)raw.h[2], s2 = (unsigned)raw.h[3];
+                scw[0] = s0 & 0x3f3f3f3fu; scw[1] = (s2 & 0x0f0f0f0fu) | (((s0 >> 6) & 0x03030303u) << 4);                    // scales of sub-blocks 0..3 / 4..7, one byte each
+                const unsigned mw0 = s1 & 0x3f3f3f3fu, mw1 = ((s2 >> 4) & 0x0f0f0f0fu) | (((s1 >> 6) & 0x03030303u) << 4);   // mins
+                dw = h2f_b((unsigned)raw.h[0] & 0xFFFF); ndmin = -h2f_b((unsigned)raw.h[0] >> 16);
+                // min-term B operand: k = 8 hh + j -> lanes hh = 0 carry m_j (against the low digits), hh = 1 carry 128 m_j (against the high digits); fp16 integers, exact
+                const unsigned mult = hh ? 0x58005800u : 0x3C003C00u;                                                         // half2(128) : half2(1)
+                const unsigned mm[4] = {(mw0 & 0xFFu) | ((mw0 & 0xFF00u) << 8), ((mw0 >> 16) & 0xFFu) | ((mw0 >> 8) & 0xFF0000u), (mw1 & 0xFFu) | ((mw1 & 0xFF00u) << 8), ((mw1 >> 16) & 0xFFu) | ((mw1 >> 8) & 0xFF0000u)};
+#pragma unroll
+                for (int i = 0; i < 4; i++) bmin[i] = (int)pkfma(pkfma(mm[i] | 0x64006400u, 0x3C003C00u, 0xE400E400u), mult, 0u);   // ((1024 + m) - 1024) * mult: m, resp. 128 m <= 8064
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // request the next half stage (the other buffer: every wave has passed the barrier, nobody still reads it); at h = 1 also the next super-block's weights and side data
+            if (h == 0) stage_half(sb, 1, smem_mmq2 + S::Q);
+            else {
+                const int sbn = min(sb + 1, sb1 - 1);
+                fetch(sbn, raw);
+                stage_half(sbn, 0, smem_mmq2);
+                stage_side(sbn, side0 + ((sb + 1 - sb0) & 1) * (S::BS + S::DK));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // B operands of this half: units 2 p, 2 p + 1 of pair p = 2 h + hh, scaled by sc[2 p] (low nibbles) / sc[2 p + 1] (high nibbles)
+            const unsigned scb = scw[h] >> (16 * hh);
+            const unsigned short slo_h = __half_as_ushort(__int2half_rn((int)(scb & 0xFFu))), shi_h = __half_as_ushort(__int2half_rn((int)((scb >> 8) & 0xFFu)));
+            const unsigned slo2 = (unsigned)slo_h * 0x10001u, shi2 = (unsigned)shi_h * 0x10001u;
+            const unsigned clo2 = (unsigned)__half_as_ushort(__float2half_rn(-1024.0f * (float)(scb & 0xFFu))) * 0x10001u, chi2 = (unsigned)__half_as_ushort(__float2half_rn(-1024.0f * (float)((scb >> 8) & 0xFFu))) * 0x10001u;
+            v4i wb[8];
+#pragma unroll
+            for (int uu = 0; uu < 2; uu++) {
+                const v4i q = *reinterpret_cast<const v4i *>(scratch + (unsigned)(l31 * 128 + (((4 * h + 2 * hh + uu) ^ ((l31 >> 1) & 7)) << 4)));
+                const unsigned P = Pn[h][uu];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    unsigned lo = (unsigned)q[d], hi = (unsigned)q[d] >> 4;
+                    unsigned mask = 0x000F000Fu;
+                    if (Q5) {   // bit 4 of every byte <- the element's high bit (pack_hb1 layout); bits 5..7 keep garbage that the 0x001F001F masks drop
+                        lo = (lo & ~0x10101010u) | ((d == 0 ? P << 4 : d == 1 ? P << 3 : d == 2 ? P << 2 : P << 1) & 0x10101010u);
+                        hi = (hi & ~0x10101010u) | ((d == 0 ? P : d == 1 ? P >> 1 : d == 2 ? P >> 2 : P >> 3) & 0x10101010u);
+                        mask = 0x001F001Fu;
+                    }
+                    wb[4 * uu + d][0] = (int)pkfma((lo & mask) | 0x64006400u, slo2, clo2);
+                    wb[4 * uu + d][1] = (int)pkfma(((lo >> 8) & mask) | 0x64006400u, slo2, clo2);
+                    wb[4 * uu + d][2] = (int)pkfma((hi & mask) | 0x64006400u, shi2, chi2);
+                    wb[4 * uu + d][3] = (int)pkfma(((hi >> 8) & mask) | 0x64006400u, shi2, chi2);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tt = 0; tt < TT; tt++) {
+                if (tt < my_tiles) {
+                    const unsigned char *sq = st + tt * 8192;
+                    v16f c; for (int r = 0; r < 16; r++) c[r] = 0.0f;
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; s8++) {
+                        const h8_t af = *reinterpret_cast<const h8_t *>(sq + a_addr[s8]);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(h8_t, wb[s8]), c, 0, 0, 0);
+                    }
+                    // the half's 128 products, scaled and added at once (a super-block's two halves as two fmas: the half sums are exact integers < 2^24, so the only
+                    // difference from one fma on their sum is one fp32 rounding); h = 1 also adds the super-block's min term
+                    v16f cm;
+                    if (h == 1) {
+                        const h8_t ab = *reinterpret_cast<const h8_t *>(sd + bs_addr + tt * 512);
+                        v16f z; for (int r = 0; r < 16; r++) z[r] = 0.0f;
+                        cm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab, __builtin_bit_cast(h8_t, bmin), z, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const v4f da = *reinterpret_cast<const v4f *>(sd + dk_addr + tt * 128 + q4 * 32);   // tokens 8 q4 + 4 hh + 0..3 = accumulator registers 4 q4 .. 4 q4 + 3
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int r = 4 * q4 + e;
+                            acc[tt][r] = fmaf(dw * da[e], c[r], acc[tt][r]);
+                            if (h == 1) acc[tt][r] = fmaf(ndmin * da[e], cm[r], acc[tt][r]);
+                        }
+                    }
+                    asm volatile("" : "+v"(acc[tt]));   // keeps this tile's scale arithmetic here (see k_mmq2_q40: LLVM otherwise sinks every tile's fmas behind all the MFMAs and spills)
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float accf[TT][16];
+#pragma unroll
+    for (int tt = 0; tt < TT; tt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) accf[tt][r] = acc[tt][r];
+    mmq2_store<TT>(accf, a, m, r0 + l31, W.rows, t0, my_tiles, hh);
+}
+
 // y[t][r] = (residual[t][r] +) sum_z slab_z[t][r], z in fixed order (deterministic); rows x cols floats per slab
 __global__ __launch_bounds__(256) void k_mmq2_reduce(const float *__restrict__ slabs, int n_slabs, long long slab_stride, const float *__restrict__ residual, float *__restrict__ y, size_t n4) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -632,9 +838,16 @@ static void mmq2_launch_kernel(KernelT kernel, bool &attr_done, dim3 grid, int t
     if (!attr_done) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr_done = true; }
     hipLaunchKernelGGL(kernel, grid, dim3((unsigned)threads), lds, s, a, A);
 }
+static int g_mmqh = 0;   // measured in round 5 and NOT adopted (profiles/r05_prefill_fp16_scaled_operands.md): 10-17 % slower per launch than the int8 kernels -- both forms are bound by the CU's load path, and the fp16 activation image doubles the staged bytes
+void set_mmqh(int v) { g_mmqh = v != 0; }
+int mmqh_enabled() { return g_mmqh; }
 template <int TT>
-static void mmq2_launch_tt(int type, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A) {
-    static bool attr[4] = {false, false, false, false};
+static void mmq2_launch_tt(int type, dim3 grid, size_t lds, hipStream_t s, const Mmq2Args &a, const ActQ &A, bool fp16_form = false) {
+    static bool attr[6] = {false, false, false, false, false, false};
+    if constexpr (TT <= 3) {
+        if (fp16_form && type == GT_Q4_K) { mmq2_launch_kernel(&k_mmqh_q45k<false, TT>, attr[4], grid, 256, MmqhStage<TT>::BYTES + 16384, s, a, A); return; }
+        if (fp16_form && type == GT_Q5_K) { mmq2_launch_kernel(&k_mmqh_q45k<true, TT>, attr[5], grid, 256, MmqhStage<TT>::BYTES + 16384, s, a, A); return; }
+    }
     if constexpr (TT <= 3) {
         if (type == GT_Q4_0) { mmq2_launch_kernel(&k_mmq2_q40<TT>, attr[3], grid, 256, lds, s, a, A); return; }
         if (type == GT_Q4_K) { mmq2_launch_kernel(&k_mmq2_q45k<false, TT>, attr[0], grid, 256, lds, s, a, A); return; }
@@ -699,10 +912,12 @@ bool launch_mmq2_set(const QWeight *const *W, float *const *y, const float *cons
     const dim3 grid((unsigned)(n * a.groups_each), (unsigned)n_chunks, (unsigned)ks);
     const int type = W[0]->type;
     const bool q40 = type == GT_Q4_0;
+    // fast mode, Q4_K / Q5_K: the fp16-MFMA form (k_mmqh_q45k) whenever the activation rows carry their fp16 image; force_ks == 1 (parity mode: the oracle's fp32 order) keeps the int8 kernels
+    const bool h16 = g_mmqh && force_ks != 1 && (type == GT_Q4_K || type == GT_Q5_K) && A.q16 && A.bs16;
     switch (a.tiles_per_chunk) {
-    case 1: mmq2_launch_tt<1>(type, grid, 2 * (q40 ? Mmq2Stage80<1>::BYTES : Mmq2Stage<1>::BYTES) + 16384, s, a, A); break;
-    case 2: mmq2_launch_tt<2>(type, grid, 2 * (q40 ? Mmq2Stage80<2>::BYTES : Mmq2Stage<2>::BYTES) + 16384, s, a, A); break;
-    case 3: mmq2_launch_tt<3>(type, grid, 2 * (q40 ? Mmq2Stage80<3>::BYTES : Mmq2Stage<3>::BYTES) + 16384, s, a, A); break;
+    case 1: mmq2_launch_tt<1>(type, grid, 2 * (q40 ? Mmq2Stage80<1>::BYTES : Mmq2Stage<1>::BYTES) + 16384, s, a, A, h16); break;
+    case 2: mmq2_launch_tt<2>(type, grid, 2 * (q40 ? Mmq2Stage80<2>::BYTES : Mmq2Stage<2>::BYTES) + 16384, s, a, A, h16); break;
+    case 3: mmq2_launch_tt<3>(type, grid, 2 * (q40 ? Mmq2Stage80<3>::BYTES : Mmq2Stage<3>::BYTES) + 16384, s, a, A, h16); break;
     default: throw HipError{hipErrorInvalidValue, "mmq2: bad chunking", __FILE__, __LINE__};
     }
     if (ks > 1) {

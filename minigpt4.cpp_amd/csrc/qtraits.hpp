@@ -411,7 +411,14 @@ __device__ __forceinline__ void quant_emit4(const float v[4], const bool in_rang
         }
         if (A.bsq) {   // prefill (csrc/mmq2_kernels.hip): the per-32 sums as two int8 digits, so that sum_j m_j * bsum_j runs on the int8 matrix cores
             const int s32 = s + dpp_i<0x141>(s);                              // row_half_mirror: the other 16-group of this 32-block
-            if (in_range && (lane & 7) == 0) { int8_t *o = A.bsq + (row * (K / 256) + idx / 256) * 16 + ((idx & 255) >> 5); o[0] = (int8_t)(s32 & 127); o[8] = (int8_t)(s32 >> 7); }
+            if (in_range && (lane & 7) == 0) { int8_t *o = A.bsq + (row * (K / 256) + idx / 256) * 16 + ((idx & 255) >> 5); o[0] = (int8_t)(s32 & 127); o[8] = (int8_t)(s32 >> 7);
+                if (A.bs16) { __half *oh = A.bs16 + (row * (K / 256) + idx / 256) * 16 + ((idx & 255) >> 5); oh[0] = __int2half_rn(s32 & 127); oh[8] = __int2half_rn(s32 >> 7); } }
+        }
+        if (A.q16 && in_range) {   // the same int8 values as fp16 in k_mmqh_q45k's fragment order (common.hpp): this thread's 4 elements are one half of one 16-byte chunk
+            const int i = idx & 255, c = (i >> 6) * 8 + ((i >> 4) & 1) * 4 + ((i >> 2) & 3), x = (i >> 5) & 1;
+            const __half2 h0 = __halves2half2(__int2half_rn(q[0]), __int2half_rn(q[2])), h1 = __halves2half2(__int2half_rn(q[1]), __int2half_rn(q[3]));
+            uint2 o; o.x = *reinterpret_cast<const unsigned *>(&h0); o.y = *reinterpret_cast<const unsigned *>(&h1);
+            *reinterpret_cast<uint2 *>(A.q16 + row * K + (size_t)(idx & ~255) + c * 8 + x * 4) = o;
         }
     }
     if (mask & ACT_Q80) {

@@ -113,7 +113,10 @@ int minigpt4_amd_test_mmq2(int ggml_type, const void *raw_w, int n_mat, int64_t 
                 for (int i = 0; i < n_mat; i++) { Pp[i] = d_pl.as<uint8_t>() + (size_t)i * pb; launch_mmq3_build(W[i], d_pl.as<uint8_t>() + (size_t)i * pb, nullptr); }
                 ok = launch_mmq3_set(Wp, Pp, Yp, residual ? Rp : nullptr, n_mat, A, (int)N, (int)n_out, nullptr);
                 HIP_CHECK(hipDeviceSynchronize());
-            } else ok = launch_mmq2_set(Wp, Yp, residual ? Rp : nullptr, n_mat, A, (int)N, (int)n_out, nullptr);
+            } else {
+                struct HScope { int keep; HScope(int v) : keep(mmqh_enabled()) { set_mmqh(v); } ~HScope() { set_mmqh(keep); } } h_scope(generation == 4);   // 4: k_mmqh_q45k (fp16-MFMA form, not adopted)
+                ok = launch_mmq2_set(Wp, Yp, residual ? Rp : nullptr, n_mat, A, (int)N, (int)n_out, nullptr);
+            }
         }
         HIP_CHECK(hipDeviceSynchronize());
         if (!ok) return 4;
@@ -470,6 +473,7 @@ int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, 
         }
         const int keep_gen = mmq_enabled();
         set_mmq_enabled(std::min(generation, 2));
+        struct HScope { int keep; HScope(int v) : keep(mmqh_enabled()) { set_mmqh(v); } ~HScope() { set_mmqh(keep); } } h_scope(generation == 4);   // 4: the fp16-MFMA form of the Q4_K / Q5_K launches (k_mmqh_q45k), 2: the int8 kernels
         const QWeight *Wp[3]; float *Yp[3];
         for (int m = 0; m < n_mat; m++) { Wp[m] = &W[m]; Yp[m] = dy.as<float>() + (size_t)m * out_each; }
         auto run = [&]() {
@@ -492,6 +496,28 @@ int minigpt4_amd_bench_mmq(int ggml_type, int rows, int cols, int n_mat, int N, 
     });
 }
 
+// Kernels of directions that were measured and closed (mmq3_kernels.hip: the digit-plane prompt mat-mul of round 4; tn_mfma_probe.hip: the batched-decode MFMA probe of round 5)
+// are built into the test library only by `make test-extras` (-DMG4_TEST_EXTRAS); the default test library carries these refusing stubs, and minigpt4_amd_test_extras() says which.
+#ifndef MG4_TEST_EXTRAS
+extern "C++" {
+namespace mg4 {
+bool mmq3_supported(int, int, int) { return false; }
+size_t mmq3_plane_bytes(int, int, size_t *) { return 0; }
+void launch_mmq3_build(const QWeight &, uint8_t *, hipStream_t) {}
+bool launch_mmq3_set(const QWeight *const *, const uint8_t *const *, float *const *, const float *const *, int, const ActQ &, int, int, hipStream_t, SlabSrc *) { return false; }
+void set_mmq3_waves(int) {}
+void set_mmq3_tuning(int, int) {}
+int probe_tn_mfma(int, int, int, int, int, int, int, float *, float *) { return 5; }
+}
+}  // extern "C++"
+int minigpt4_amd_test_extras(void) { return 0; }
+#else
+int minigpt4_amd_test_extras(void) { return 1; }
+#endif
+int minigpt4_amd_probe_tn_mfma(int rows, int cols, int TN, int iters, int n_sets, int check, float *us_per_launch, float *rel_diff) {
+    if (device_count_noexcept() <= 0) return 2;
+    return guarded(3, [&]() -> int { hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0)); return probe_tn_mfma(rows, cols, TN, iters, n_sets, check, prop.multiProcessorCount, us_per_launch, rel_diff); });
+}
 float minigpt4_amd_probe_valu(int op, int waves_per_simd, int iters) {
     if (device_count_noexcept() <= 0 || iters < 1) return -1.0f;
     float ns = -1.0f;

@@ -44,6 +44,32 @@ def test_mmq2_matches_oracle(gpu_lib, wtype, case):
     assert err < 2e-5, (wtype, case, err)
 
 
+@pytest.mark.parametrize("wtype", ["q4_k", "q5_k"])
+@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[5], CASES[6], CASES[8], CASES[9]], ids=lambda c: "N%d_K%d_R%d_m%d_ks%d_res%d" % c)
+def test_fp16_mfma_form_with_scaled_operands_matches_oracle(gpu_lib, wtype, case):
+    """k_mmqh_q45k (round 5; measured 10-17 % slower than the int8 kernels and NOT the default -- profiles/r05_prefill_fp16_scaled_operands.md; kept as the record of the
+    direction): sub-block scale x quant as exact fp16 integers (<= 1953) in the B operand, the Q8_K activation values as fp16 in the A operand, one fp32 fma per output
+    element and half super-block.  Same ggml arithmetic up to the fp32 rounding of the in-block sums -> the same 2e-5 bar as the int8 kernels, and within 2e-6 of them."""
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    N, n_in, n_out, n_mat, ks, with_res = case
+    t = Q.NAME_TO_TYPE[wtype]
+    rng = np.random.default_rng(sum(map(ord, wtype)) * 977 + sum(case) + 4)
+    raw = Q.quantize(t, (0.05 * rng.standard_normal((n_mat * n_out, n_in))).astype(np.float32))
+    x = rng.standard_normal((N, n_in)).astype(np.float32)
+    x[N // 2, : min(256, n_in)] = 0.0
+    res = rng.standard_normal((n_mat, N, n_out)).astype(np.float32) if with_res else None
+    got = gpu_lib.amd_test_mmq2(t, raw, n_mat, n_in, n_out, x, residual=res, ks=ks, generation=4)
+    int8 = gpu_lib.amd_test_mmq2(t, raw, n_mat, n_in, n_out, x, residual=res, ks=ks, generation=2)
+    want = R.mul_mat(t, raw, n_in, n_mat * n_out, x).reshape(N, n_mat, n_out).transpose(1, 0, 2)
+    scale = np.abs(want).max()
+    if with_res:
+        want = want + res
+    assert np.isfinite(got).all()
+    assert float(np.abs(got - want).max() / scale) < 2e-5
+    assert float(np.abs(got - int8).max() / scale) < 2e-6
+
+
 def test_mmq2_is_deterministic_with_k_split(gpu_lib):
     """The K-split partial sums are combined in a fixed order: two runs give identical bits."""
     from minigpt4_cpp_amd import quants as Q

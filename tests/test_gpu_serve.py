@@ -181,3 +181,53 @@ def test_native_broadcast_inside_model_load_single_rank(gpu_lib, tiny_files, tmp
     with pytest.raises(RuntimeError) as ei:
         gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=64, n_batch=16)
     assert "MINIGPT4_RANK" in str(ei.value), str(ei.value)
+
+
+def test_native_broadcast_failures_fail_everywhere_and_never_hang(gpu_lib, tiny_files, tmp_path, monkeypatch):
+    """Round-4 advisor findings on csrc/dist.cpp / Engine::native_broadcast: (1) a rank whose OWN load fails must still join the exchange and say so (its peers would
+    otherwise wait for it inside RCCL) -- here with a one-rank communicator: the load error comes back through the symmetric agreement step; (2) a stale id file left by a
+    crashed job (older than this process) must not be taken for the new job's id; (3) rank 0 whose peer never joins must give up after MINIGPT4_DIST_TIMEOUT_S instead of
+    sitting in ncclCommInitRank for ever -- in a child process, because the abandoned bootstrap thread stays inside librccl."""
+    import subprocess
+    import sys
+    import time
+    vp, llm = tiny_files
+    lp = llm("q5_k", "q5_k_m")
+    idf = str(tmp_path / "job2.id")
+    # (1) truncated LLM file + the native exchange: the error is the load's own, and the id file is gone afterwards
+    bad = str(tmp_path / "truncated.bin")
+    open(bad, "wb").write(open(lp, "rb").read()[:20000])
+    for k, v in (("MINIGPT4_WORLD_SIZE", "1"), ("MINIGPT4_RANK", "0"), ("MINIGPT4_NCCL_ID_FILE", idf), ("MINIGPT4_DIST_TIMEOUT_S", "5")):
+        monkeypatch.setenv(k, v)
+    with pytest.raises(RuntimeError) as ei:
+        gpu_lib.minigpt4_model_load(vp, bad, verbosity=0, n_ctx=64, n_batch=16)
+    assert "failed before" in str(ei.value) or "rank 0" in str(ei.value), str(ei.value)
+    assert not os.path.exists(idf)
+    # (2) a 128-byte id file from "an hour ago": rank 1 keeps waiting for a fresh one and times out with the reason
+    open(idf, "wb").write(bytes(128))
+    old = time.time() - 3600
+    os.utime(idf, (old, old))
+    monkeypatch.setenv("MINIGPT4_WORLD_SIZE", "2"); monkeypatch.setenv("MINIGPT4_RANK", "1"); monkeypatch.setenv("MINIGPT4_DIST_TIMEOUT_S", "1")
+    t0 = time.time()
+    with pytest.raises(RuntimeError) as ei:
+        gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=64, n_batch=16)
+    assert "ncclUniqueId" in str(ei.value), str(ei.value)
+    assert time.time() - t0 < 30
+    os.remove(idf)
+    # (3) rank 0 of 2, nobody else: bounded wait, error text, process alive
+    code = ("import os, sys, time; sys.path.insert(0, %r); import _pkg; _pkg.load_package()\n"
+            "from minigpt4_cpp_amd import minigpt4_library as ML\n"
+            "lib = ML.load_library(); t0 = time.time()\n"
+            "try:\n"
+            "    lib.minigpt4_model_load(%r, %r, verbosity=0, n_ctx=64, n_batch=16); print('LOADED')\n"
+            "except RuntimeError as e:\n"
+            "    print('ERR %%.1f %%s' %% (time.time() - t0, e))\n"
+            "sys.stdout.flush(); os._exit(0)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), vp, lp)
+    env = dict(os.environ, MINIGPT4_WORLD_SIZE="2", MINIGPT4_RANK="0", MINIGPT4_NCCL_ID_FILE=str(tmp_path / "job3.id"), MINIGPT4_DIST_TIMEOUT_S="4")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180)
+    line = [l for l in r.stdout.splitlines() if l.startswith(("ERR", "LOADED"))]
+    assert line and line[-1].startswith("ERR"), (r.stdout[-500:], r.stderr[-500:])
+    assert "did not complete within" in line[-1] or "ncclCommInitRank" in line[-1], line[-1]
+    assert float(line[-1].split()[1]) < 60.0, line[-1]
+    assert not os.path.exists(str(tmp_path / "job3.id"))
+

@@ -18,13 +18,13 @@ def child(ns):
         row = []
         for name, t, rows, cols, n_mat in SHAPES:
             us = ctypes.c_float()
-            gens = tuple(int(g) for g in os.environ.get("GENS", "3,2").split(","))
+            gens = tuple(int(g) for g in os.environ.get("GENS", "4,2").split(","))
             vals = []
             for g in gens:
                 rc = L.minigpt4_amd_bench_mmq(Q.NAME_TO_TYPE[t], rows, cols, n_mat, N, 20, int(os.environ.get("KS", "0")), g, ctypes.byref(us))
                 vals.append(us.value if rc == 0 else float("nan"))
             row.append(f"{name} " + "/".join(f"{v:.1f}" for v in vals))
-        print(f"N={N} dbg={os.environ.get('MINIGPT4_MMQ2_DBG', '0')} ks={os.environ.get('KS', 'auto')}: " + "  ".join(row) + "   (us per launch: generations " + os.environ.get("GENS", "3,2") + "; 3 = digit planes mmq3, 2 = mmq2, 1 = round 1)", flush=True)
+        print(f"N={N} dbg={os.environ.get('MINIGPT4_MMQ2_DBG', '0')} ks={os.environ.get('KS', 'auto')}: " + "  ".join(row) + "   (us per launch: generations " + os.environ.get("GENS", "4,2") + "; 4 = fp16-MFMA k_mmqh (round 5), 3 = digit planes mmq3, 2 = int8 mmq2, 1 = round 1)", flush=True)
 
 
 if __name__ == "__main__":
