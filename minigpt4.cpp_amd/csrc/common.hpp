@@ -44,6 +44,16 @@ struct HipError { hipError_t code; const char *what; const char *file; int line;
 // slot when an entry point returns comes from a kernel launch (which has no return value) and is reported (api.cpp: guarded()).
 #define HIP_IGNORE(expr) do { (void)(expr); (void)hipGetLastError(); } while (0)
 
+// The > 64 KiB dynamic-LDS opt-in of a kernel.  The request must leave room for the kernel's STATIC shared arrays: asking for the CU's full 160 KiB is refused (invalid
+// argument) for any kernel that has some -- which rounds 1-4 did, behind HIP_IGNORE, so those opt-ins never took effect (found in round 5 when the call became checked).
+template <typename K> inline hipError_t lds_optin_max(K kernel) {
+    hipFuncAttributes fa;
+    const hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel));
+    if (e != hipSuccess) return e;
+    const int dyn = (160 * 1024 - (int)fa.sharedSizeBytes) & ~255;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Device-side views
 // ------------------------------------------------------------------------------------------------------------
@@ -63,6 +73,10 @@ struct QWeight {
     const uint8_t *d = nullptr;      // Q6_K: f16 d per super-block
     size_t bytes = 0;                // HBM bytes of all planes (== file bytes of the tensor)
 };
+
+// Row-interleaved second image of a k-quant matrix for the batched decode step on the int8 matrix cores (ri_kernels.hip): per group of 64 rows and per unit the 64 rows'
+// pieces back to back, so that a LANE owns a weight row and a wave load is still 1 KiB of whole cache lines.  Built on the device when a context gets > 1 conversation.
+struct RiPlanes { const uint8_t *qs = nullptr, *qh = nullptr, *sc = nullptr, *d = nullptr; };
 
 // Quantised activations ("vec_dot_type" of ggml) for N rows of width K.
 struct ActQ {

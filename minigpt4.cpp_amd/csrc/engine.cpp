@@ -120,7 +120,8 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (const char *e = getenv("MINIGPT4_ATTN_SPLIT_T")) attn_split_t_ = atoi(e);   // cached keys from which the decode step uses the key-split attention (0 = never)
     n_cus_ = prop.multiProcessorCount;
     if (const char *e = getenv("MINIGPT4_MMQH")) set_mmqh(atoi(e));              // 1: Q4_K / Q5_K prompt rows on the fp16-MFMA form with scaled operands (k_mmqh_q45k: measured SLOWER, profiles/r05_prefill_fp16_scaled_operands.md; A/B)
-    if (const char *e = getenv("MINIGPT4_MV_PACK")) set_matvec_pack(atoi(e));      // 0: decode mat-vec rows of K = 5120 one per lane-walk (round-4 form, A/B)
+    if (const char *e = getenv("MINIGPT4_RI")) use_ri_ = atoi(e) != 0;             // 0: batched decode on the v_dot4 multi-row mat-vec (rounds 2-4), no row-interleaved image
+    set_ri_cus(prop.multiProcessorCount);
     if (const char *e = getenv("MINIGPT4_QF_FOLD")) qf_fold_ = atoi(e) != 0;       // 0: the Q-Former's image-independent head is recomputed per encode (round-4 form, A/B)
     if (const char *e = getenv("MINIGPT4_KV_HOIST")) kv_hoist_ = atoi(e) != 0;     // 0: one K | V projection GEMM per cross-attention layer (round-4 form, A/B)
     set_matvec_tuning(0, 0, prop.multiProcessorCount);
@@ -902,12 +903,28 @@ void Engine::forward_batch(int B, hipStream_t s) {
     // y_m[t][r] = W_m[r] . act[t] (+ res_m[t][r]) for n matrices that share the prepared rows.  Up to batch_rows_max_ rows go through the pipelined multi-row
     // mat-vec in passes of 4 rows (weights streamed once per pass); larger batches / other types through launch_mul_mat (int8-MFMA tiles from 5 rows).
     // px != null: the launch prepares its rows itself (rms_norm(px_t) * pw, quantised) -- only called when rows_pro() said the shape / type is in range
+    // Does the row-interleaved MFMA launch serve this set?  Every matrix of one k-quant type and shape with its image built, AND where it was measured faster than the v_dot4
+    // multi-row mat-vec (profiles/r05_batched_shapes.log, us per launch, dot4 / mfma at B = 2 | 3 | 4): sets of >= 128 row groups -- qkv 17.2/15.2 | 19.8/15.2 | 23.2/15.6,
+    // wq|wk 12.4/12.9 | 14.7/12.9 | 17.1/13.2, w1|w3 25.7/22.2 | 29.6/22.1 | 34.4/22.1, output 27.3/27.0 | 33.1/27.2 | 37.3/27.5 -- but not the 80-group matrices (wo 12.1/11.6,
+    // w2 22.5/21.7, a lone wv 12.1/13.4 at B = 4: one workgroup per group leaves two thirds of the CUs idle), and from 3 rows on: at B = 2 the v_dot4 launches prepare their
+    // rows in their own prologue (two launches less per layer), which outweighs the 2-3.5 us the MFMA launch would save.
+    auto ri_serves = [&](std::initializer_list<const QWeight *> Ws) {
+        if (!ri_ready_ || B < 3 || B > 4) return false;
+        const QWeight *w0 = *Ws.begin();
+        int groups = 0;
+        for (const QWeight *w : Ws) { if (!ri_of(w) || w->type != w0->type || w->rows != w0->rows || w->cols != w0->cols) return false; groups += w->rows / 64; }
+        return groups >= 128;
+    };
     auto mm = [&](std::initializer_list<const QWeight *> Ws, std::initializer_list<float *> ys, const float *res0, int ld, const float *px = nullptr, const float *pw = nullptr) {
         const int n = (int)Ws.size();
         const QWeight *W[3]; float *y[3]; const float *r[3];
         int i = 0; for (const QWeight *w : Ws) W[i++] = w;
         i = 0; for (float *p : ys) { y[i] = p; r[i] = res0; i++; }
         bool same = true; for (int k = 1; k < n; k++) same = same && W[k]->type == W[0]->type && W[k]->rows == W[0]->rows && W[k]->cols == W[0]->cols;
+        if (!px && ri_serves(Ws)) {                         // (rows_pro() is false for such a set, so its rows were prepared by a standalone launch)
+            const RiPlanes *rp[3]; for (int k = 0; k < n; k++) rp[k] = ri_of(W[k]);
+            if (launch_matvec_ri(W, rp, y, res0 ? r : nullptr, n, act_, B, ld, s)) return;
+        }
         if (same && B <= batch_rows_max_) {
             bool ok = true;
             for (int t0 = 0; t0 < B && ok; t0 += 4) {
@@ -935,6 +952,7 @@ void Engine::forward_batch(int B, hipStream_t s) {
         // workgroup repeats four rows' norm + quantisation); MINIGPT4_BATCH_FUSE=1 forces it for every B <= 4, =0 switches it off
         // plain = quantisation only (the attention output in front of wo: no norm, no double-precision sums): cheap enough to stay inside the launch at 3 and 4 rows too
         if (batch_fuse_ == 0 || B > batch_rows_max_ || B > 4 || (batch_fuse_ < 0 && B > 2 && !plain)) return false;
+        if (ri_serves(Ws)) return false;                  // the MFMA launch takes PREPARED rows: standalone preparation, then mm()
         const QWeight *w0 = *Ws.begin();
         for (const QWeight *w : Ws) if (w->type != w0->type || w->rows != w0->rows || w->cols != w0->cols) return false;
         return matvec_rows_prologue_ok(w0->type, w0->cols);
@@ -1186,6 +1204,31 @@ int Engine::profile_sites(int steps, std::string &json) {
 // ====================================================================================================================
 // several conversations per replica
 // ====================================================================================================================
+// The row-interleaved image of every k-quant matrix the batched step multiplies (ri_kernels.hip), built once, on the device, from the ordinary planes.
+void Engine::build_ri_planes() {
+    if (ri_ready_ || !use_ri_ || weights_missing()) return;
+    std::vector<const QWeight *> ws;
+    // only the sets the batched step serves this way (forward_batch: ri_serves): wq | wk | wv of one type, w1 | w3, the output matrix -- not the 80-group wo / w2
+    for (const LayerW &L : layers_) {
+        if (L.wk.type == L.wq.type && L.wv.type == L.wq.type) for (const QWeight *w : {&L.wq, &L.wk, &L.wv}) ws.push_back(w);
+        if (L.w1.type == L.w3.type) for (const QWeight *w : {&L.w1, &L.w3}) ws.push_back(w);
+    }
+    ws.push_back(&output_);
+    size_t total = 0;
+    for (const QWeight *w : ws) { RiPlanes p; total += ri_plan(w->type, w->rows, w->cols, p, nullptr); }
+    if (!total) return;
+    ri_arena_.alloc(total + 4096);
+    for (const QWeight *w : ws) {
+        RiPlanes p; const size_t need = ri_plan(w->type, w->rows, w->cols, p, nullptr);
+        if (!need) continue;
+        ri_plan(w->type, w->rows, w->cols, p, ri_arena_.take(need));
+        launch_ri_build(*w, p, stream_);
+        ri_map_.emplace_back(w, p);
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    ri_ready_ = true;
+    MG4_INFO("batched decode: row-interleaved image of %zu k-quant matrices, %.2f GB", ri_map_.size(), ri_arena_.used / 1e9);
+}
 int Engine::set_conversations(int n) {
     if (n < 1 || n > MAX_CONVERSATIONS) { set_last_error("conversation count out of range"); return 1; }
     HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1193,6 +1236,7 @@ int Engine::set_conversations(int n) {
     conv_.assign((size_t)n, Conversation{});
     cur_ = 0;
     alloc_buffers();
+    if (n > 1) build_ri_planes();                          // batched decode on the matrix cores needs the row-interleaved image (once per context)
     return 0;
 }
 int Engine::select_conversation(int slot) {

@@ -169,6 +169,13 @@ private:
     FILE *trace_file_ = nullptr;       // MINIGPT4_PARITY_TRACE
     void *attn_ws_ = nullptr; int attn_splits_ = 6; int attn_split_t_ = 768; bool attn_split_now_ = false; int attn_splits_forced_ = 0;   // key-split decode attention (llm_kernels.hip: k_attn_split_*)
     int batch_rows_max_ = 4; int batch_fuse_ = -1; int n_cus_ = 256;
+    // round 5: B = 2..4 rows per weight pass on the int8 matrix cores over a row-interleaved second image of the k-quant matrices (ri_kernels.hip); built by
+    // set_conversations(n > 1) -- a context with one conversation never pays the memory.  MINIGPT4_RI=0: the v_dot4 multi-row mat-vec of rounds 2-4 (A/B)
+    bool use_ri_ = true, ri_ready_ = false;
+    DeviceArena ri_arena_;
+    std::vector<std::pair<const QWeight *, RiPlanes>> ri_map_;
+    const RiPlanes *ri_of(const QWeight *w) const { for (const auto &e : ri_map_) if (e.first == w) return &e.second; return nullptr; }
+    void build_ri_planes();
     bool batch_mix_ = true;            // MINIGPT4_BATCH_MIX=0: wq|wk and wv of a mixed-type layer as two launches (the form before k_matvec_tn_mix)   // MINIGPT4_BATCH_ROWS_MAX: batches up to this size use the multi-row mat-vec; 0 = never.  Measured (profiles/r02x_*): from 5 rows on the int8-MFMA kernels (single-wave workgroups, one token tile) beat two passes of the 4-row mat-vec
     static constexpr int FUSE_DEFAULT = 87; int fuse_mask_ = FUSE_DEFAULT;
     // profiling (profile_sites)

@@ -80,6 +80,13 @@ bool matvec_silu_pair_supported(int type, int cols);
 bool launch_matvec_rows(const QWeight *const *W, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s, const float *px = nullptr,
                         const float *pw = nullptr, int ldx = 0);   // px != null: rows t of x (stride ldx) are prepared inside the launch (A unused): pw != null rms-normed with pw, pw == null taken as they are; then quantised
 bool matvec_rows_prologue_ok(int type, int K);
+// batched decode on v_mfma_i32_4x4x4_16B_i8 over the row-interleaved image (ri_kernels.hip, round 5): N = 1..4 PREPARED rows (Q8_K image incl. bsk / bsq) against 1..3 same-type,
+// same-shape Q4_K / Q5_K / Q6_K matrices; false -> outside the kernel's range, nothing launched
+bool ri_supported(int type, int rows, int cols);
+size_t ri_plan(int type, int rows, int cols, RiPlanes &p, uint8_t *base);      // assigns the image's plane pointers from `base` (nullptr: sizes only), returns the bytes used
+void launch_ri_build(const QWeight &w, const RiPlanes &p, hipStream_t s);      // ordinary planes -> row-interleaved image
+bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s);
+void set_ri_cus(int cus);
 // two k-quant types (Q4_K|Q5_K + Q6_K) with the same K in one launch; pro: 0 or 1 (rms_norm prologue)
 bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, hipStream_t s, int pro = 0,
                          const float *px = nullptr, const float *pw = nullptr, int epi = 0);
@@ -87,7 +94,6 @@ bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, con
 bool launch_matvec_rows_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, int N, int ldy, hipStream_t s,
                               const float *px = nullptr, const float *pw = nullptr, int ldx = 0);
 void set_matvec_tuning(int waves_per_cu, int fat_threads, int cus);   // 0 = choose per launch
-void set_matvec_pack(int v);   // 1 (default): K = 5120 k-quant rows pair-packed (two rows per 5 lane-walks); 0: one row per 3
 // measurement: while tracing is on, every launcher of llm_kernels.hip notes the kernel symbol it launched (as rocprofv3 prints it, without the argument list)
 void kernel_name_tracing(bool on);
 const char *last_kernel_name();          // "" when nothing was launched since the last reset

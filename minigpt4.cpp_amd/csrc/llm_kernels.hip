@@ -515,14 +515,11 @@ __device__ unsigned long long g_tla[2048 * 8];
 #define MG4_TL(i) do {} while (0)
 #define MG4_TL_ALL(i) do {} while (0)
 #endif
-// PK (round 5, "pair packing"): a lane-walk covers TWO consecutive rows as one run of 2 U units -- consecutive rows are contiguous in every plane -- instead of one row
-// padded to a multiple of 64 units.  K = 5120 (every matrix of the 13B model but w2): a row is 160 units = 2.5 lane-walks, so the row-per-walk form issues 3 loads per
-// plane and lane with 17 % of them masked (they still cost an address slot and fetch unit 0 again); the pair takes 5 for two rows.  The units of the second row sit
-// (lane + 64 i - U) into that row: each lane keeps the activation unit matching ITS position, and the two rows' partial sums are kept apart per slot.
-template <int T, int NU, int R, int PRO, int EPI, bool PK = false>
+// (Round 5 measured "pair packing" -- two consecutive K = 5120 rows as ONE run of 320 units over 5 lane-walks instead of 2 x 3 with 17 % of the lanes masked -- and lost:
+// 356 vs 374 tok/s on the 13B file, profiles/r05_experiments_not_adopted.md; removed again.)
+template <int T, int NU, int R, int PRO, int EPI>
 __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, const ProArgs &pa, const int n_groups, const int n_waves, const int wave) {
     static_assert(EPI != EPI_SILU_PAIR || R == 2, "the SiLU pair epilogue works on row pairs");
-    static_assert(!PK || (R == 1 && EPI == EPI_STORE), "pair packing: one pair per group, plain store");
     // groups of this wave: g = g_first, g_first + g_step, ... < g_last
     const int g_first = wave, g_last = n_groups, g_step = n_waves;
     MG4_TL(0); MG4_TL_ALL(7);
@@ -530,12 +527,11 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
     const int lane = threadIdx.x & 63;
     const int K = ms.w0.cols, U = K / X::EPU, rows_each = ms.rows_each, total_rows = ms.n * rows_each;
     int uc[NU]; bool ok[NU];
-    int ua[NU]; bool hiw[NU];                   // PK: the activation unit of the slot (its position within ITS row) and whether the slot belongs to the pair's second row
 #pragma unroll
-    for (int i = 0; i < NU; i++) { const int u = lane + 64 * i; ok[i] = u < (PK ? 2 * U : U); uc[i] = ok[i] ? u : 0; hiw[i] = PK && uc[i] >= U; ua[i] = hiw[i] ? uc[i] - U : uc[i]; }
+    for (int i = 0; i < NU; i++) { const int u = lane + 64 * i; ok[i] = u < U; uc[i] = ok[i] ? u : 0; }
     // NOTE: every load of the pipeline is unconditional (indices are clamped instead of branching): a load inside an exec-masked branch
     // makes hipcc's counted s_waitcnt fall back to (near) vmcnt(0), which drains the prefetch -- see DESIGN.md "mat-vec pipeline".
-    struct Grp { typename X::WU w[R][NU]; float res[PK ? 2 : R]; };
+    struct Grp { typename X::WU w[R][NU]; float res[R]; };
     const bool has_res = ms.res0 != nullptr;
     const float *res_base = has_res ? ms.res0 : ms.y0;                     // always a valid address; the value is dropped when there is no residual
     const long long res_stride = has_res ? ms.dres : ms.dy;
@@ -544,7 +540,7 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
         for (int r = 0; r < R; r++) {
             // wave-uniform (scalar) row, clamped instead of branching; the matrix of the row is selected on the operands themselves (a
             // bool -> int conversion would be done on the vector ALU)
-            const int row = EPI == EPI_SILU_PAIR ? min(g, rows_each - 1) + r * rows_each : PK ? min(2 * g, total_rows - 2) : min(g * R + r, total_rows - 1);
+            const int row = EPI == EPI_SILU_PAIR ? min(g, rows_each - 1) + r * rows_each : min(g * R + r, total_rows - 1);
             const bool m1 = row >= rows_each, m2 = row >= 2 * rows_each;
             const int lr = row - (m2 ? 2 * rows_each : (m1 ? rows_each : 0));
             const long long d = m2 ? 2 * ms.dmat : (m1 ? ms.dmat : 0ll);
@@ -555,7 +551,6 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
 #pragma unroll
             for (int i = 0; i < NU; i++) X::loadb(B, uc[i], G.w[r][i]);
             G.res[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mkbuf(reinterpret_cast<const uint8_t *>(res_base + (m2 ? 2 * res_stride : (m1 ? res_stride : 0ll)) + lr)), 0, 0, 0));
-            if (PK) G.res[PK ? 1 : 0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mkbuf(reinterpret_cast<const uint8_t *>(res_base + (m2 ? 2 * res_stride : (m1 ? res_stride : 0ll)) + lr)), 4, 0, 0));
         }
     };
     Grp cur, nxt;
@@ -564,7 +559,7 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
         fetch(g_first, cur);
         MG4_TL(1);
 #pragma unroll
-        for (int i = 0; i < NU; i++) X::loada(A, 0, K, ua[i], a[i]);
+        for (int i = 0; i < NU; i++) X::loada(A, 0, K, uc[i], a[i]);
         MG4_TL(2);
     } else {
         // Row preparation in the prologue.  Order matters (vector-memory results return in issue order): the row (and, for SiLU, the table
@@ -643,29 +638,12 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NU; i++) X::loada(L, 0, K, ua[i], a[i]);
+        for (int i = 0; i < NU; i++) X::loada(L, 0, K, uc[i], a[i]);
         MG4_TL(2);
     }
     unsigned short pend_t = 0; float pend_b = 0.0f; int pend_row = -1;          // EPI_SILU_PAIR: the previous group's table lookup, not yet consumed
     auto flush_pending = [&]() { if (pend_row >= 0 && lane == 0) ms.y0[pend_row] = h2f_bits(pend_t) * pend_b; };
     auto consume = [&](int g, const Grp &G) {
-        if constexpr (PK) {
-            float s0 = 0.0f, s1 = 0.0f;             // the pair's two rows: a slot adds to the sum of the row ITS unit belongs to (lane-dependent in the slot that straddles the rows)
-#pragma unroll
-            for (int i = 0; i < NU; i++) {
-                float c = hiw[i] ? s1 : s0;
-                X::dot(G.w[0][i], a[i], c);
-                s0 = (ok[i] && !hiw[i]) ? c : s0; s1 = (ok[i] && hiw[i]) ? c : s1;
-            }
-            const float o0 = wave_sum(s0), o1 = wave_sum(s1);
-            const int row = 2 * g;
-            if (lane == 0 && row < total_rows) {
-                const int m = row >= 2 * rows_each ? 2 : (row >= rows_each ? 1 : 0), lr = row - m * rows_each;
-                float *yo = ms.y0 + (long long)m * ms.dy + lr;
-                yo[0] = has_res ? o0 + G.res[0] : o0; yo[1] = has_res ? o1 + G.res[PK ? 1 : 0] : o1;
-            }
-            return;
-        }
         float out[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -718,10 +696,10 @@ __device__ __forceinline__ void matvec_run(const MatSet &ms, const ActQ &A, cons
     MG4_TL(5); MG4_TL_ALL(6);
 #endif
 }
-template <int T, int NU, int R, int PRO, int EPI, bool PK = false>
+template <int T, int NU, int R, int PRO, int EPI>
 __global__ __launch_bounds__(PRO == PRO_NONE ? 256 : mv_fat_max_threads<NU>()) void k_matvec_v2(const MatSet ms, const ActQ A, const ProArgs pa, const int n_groups, const int n_waves) {
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));   // wave-uniform: scalar loop control
-    matvec_run<T, NU, R, PRO, EPI, PK>(ms, A, pa, n_groups, n_waves, wave);
+    matvec_run<T, NU, R, PRO, EPI>(ms, A, pa, n_groups, n_waves, wave);
 }
 // Two weight types in one launch (llama.cpp's k-quant mixes give wv more bits than wq|wk): waves [0, n_waves1) stream set 1, the rest set 2.  Both
 // sets share K and the prepared activation row (both types read the Q8_K image); every wave passes the same number of workgroup barriers.
@@ -733,8 +711,6 @@ __global__ __launch_bounds__(PRO == PRO_NONE ? 256 : mv_fat_max_threads<NU>()) v
     else matvec_run<T2, NU, 1, PRO, EPI>(ms2, A, pa, n_groups2, n_waves2, wave - n_waves1);
 }
 static int g_mv_cus = 256;
-static int g_mv_pack = 1;           // MINIGPT4_MV_PACK=0: K = 5120 rows one per lane-walk (the round-1..4 form, A/B)
-void set_matvec_pack(int v) { g_mv_pack = v != 0; }
 static int g_mv_force_waves = 0;    // MINIGPT4_MV_WAVES: waves per CU of the prologue-free launches (0 = choose)
 static int g_mv_force_fat = 0;      // MINIGPT4_FAT_LB: threads of the fat workgroups (0 = choose)
 // Launch geometry (measured on the 13B decode, profiles/r01g_ab_geometry.log): 8 waves per CU everywhere.  More waves lose even where they divide
@@ -744,17 +720,16 @@ static int pick_waves_per_cu(int /*groups*/, int max_wpc) { return std::min(g_mv
 static int pick_fat_threads(int /*groups*/, int max_threads) { return g_mv_force_fat ? std::max(MV_FAT_MIN, std::min(g_mv_force_fat / 64 * 64, max_threads)) : MV_FAT_MIN; }
 static size_t mv_prologue_lds(int K) { return 128 + (size_t)2 * K + (size_t)(K / 256 + 1) * 4 + (size_t)4 * (K / 32) * 4 + (size_t)(K / 16) * 2 + 64; }
 template <int NU> constexpr int mv_max_wpc() { return NU <= 3 ? 16 : NU == 4 ? 12 : 8; }      // register budget of the two-stage pipeline
-template <int T, int NU, int R, int EPI, bool PK = false>
+template <int T, int NU, int R, int EPI>
 static void launch_v2_t(const MatSet &ms, const ActQ &A, int pro, const ProArgs &pa, hipStream_t s) {
     const int total_rows = ms.n * ms.rows_each;
-    const int n_groups = EPI == EPI_SILU_PAIR ? ms.rows_each : PK ? total_rows / 2 : (total_rows + R - 1) / R;
-    if (PK) note_kernel("k_matvec_v2<%d, %d, %d, %d, %d, 1>", T, NU, R, pro, (int)EPI);
-    else note_kernel("k_matvec_v2<%d, %d, %d, %d, %d>", T, NU, R, EPI == EPI_SILU_PAIR && pro != PRO_NONE ? (int)PRO_RMS : pro, (int)EPI);
+    const int n_groups = EPI == EPI_SILU_PAIR ? ms.rows_each : (total_rows + R - 1) / R;
+    note_kernel("k_matvec_v2<%d, %d, %d, %d, %d>", T, NU, R, EPI == EPI_SILU_PAIR && pro != PRO_NONE ? (int)PRO_RMS : pro, (int)EPI);
     if (pro == PRO_NONE) {
         // EPI_REF: the block chain is a dependent sequence per wave (DPP move + fma per block): as many waves per SIMD as the registers admit, not the stream-optimal 8 per CU
         int n_waves = std::min(n_groups, g_mv_cus * (EPI == EPI_REF ? mv_max_wpc<NU>() : pick_waves_per_cu(n_groups, mv_max_wpc<NU>())));
         n_waves = (n_waves + 3) & ~3;
-        hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_NONE, EPI, PK>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, s, ms, A, pa, n_groups, n_waves);
+        hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_NONE, EPI>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, s, ms, A, pa, n_groups, n_waves);
         return;
     }
     const int LB = EPI == EPI_REF ? mv_fat_max_threads<NU>() : pick_fat_threads(n_groups, mv_fat_max_threads<NU>()), WPB = LB / 64;
@@ -766,9 +741,9 @@ static void launch_v2_t(const MatSet &ms, const ActQ &A, int pro, const ProArgs 
     if constexpr (EPI == EPI_SILU_PAIR) {   // w1|w3 follow the ffn norm: only that prologue is instantiated for the pair epilogue
         hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_RMS, EPI>), grid, block, lds, s, ms, A, pa, n_groups, n_waves);
     } else switch (pro) {
-    case PRO_RMS: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_RMS, EPI, PK>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
-    case PRO_PLAIN: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_PLAIN, EPI, PK>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
-    default: if constexpr (EPI == EPI_STORE) hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_SILU, EPI, PK>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
+    case PRO_RMS: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_RMS, EPI>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
+    case PRO_PLAIN: hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_PLAIN, EPI>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
+    default: if constexpr (EPI == EPI_STORE) hipLaunchKernelGGL((k_matvec_v2<T, NU, R, PRO_SILU, EPI>), grid, block, lds, s, ms, A, pa, n_groups, n_waves); break;
     }
 }
 #ifndef MG4_R_NU3
@@ -828,11 +803,7 @@ static bool launch_v2_type(const MatSet &ms, const ActQ &A, int pro, const ProAr
     } else switch (nu) {
     case 1: launch_v2_t<T, 1, 2, EPI_STORE>(ms, A, pro, pa, s); break;
     case 2: launch_v2_t<T, 2, MG4_R_NU2, EPI_STORE>(ms, A, pro, pa, s); break;
-    case 3:
-        if constexpr (T == GT_Q4_K || T == GT_Q5_K || T == GT_Q6_K) {   // pair packing (matvec_run, PK): 129..160 units per row (K = 5120) -> two rows in 5 lane-walks instead of 6
-            if (g_mv_pack && 2 * U <= 5 * 64 && ms.rows_each % 2 == 0) { launch_v2_t<T, 5, 1, EPI_STORE, true>(ms, A, pro, pa, s); break; }
-        }
-        launch_v2_t<T, 3, MG4_R_NU3, EPI_STORE>(ms, A, pro, pa, s); break;
+    case 3: launch_v2_t<T, 3, MG4_R_NU3, EPI_STORE>(ms, A, pro, pa, s); break;
     case 4: launch_v2_t<T, 4, 1, EPI_STORE>(ms, A, pro, pa, s); break;
     case 5: launch_v2_t<T, 5, 1, EPI_STORE>(ms, A, pro, pa, s); break;
     case 6: launch_v2_t<T, 6, 1, EPI_STORE>(ms, A, pro, pa, s); break;
@@ -1203,8 +1174,8 @@ static void launch_tn_n(const MatSet &ms, const ActQ &A, int N, int ldy, hipStre
         if (px) {
             const int img = (int)mv_tn_image_bytes(ms.w0.cols);
             static bool attr1 = false;
-            if (!attr1) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                          HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr1 = true; }
+            if (!attr1) { HIP_IGNORE(lds_optin_max(&k_matvec_tn<T, NU, TN, 1>));
+                          HIP_IGNORE(lds_optin_max(&k_matvec_tn<T, NU, TN, 2>)); attr1 = true; }
             note_kernel("k_matvec_tn<%d, %d, %d, %d>", T, NU, TN, pw ? 1 : 2);
             if (pw) hipLaunchKernelGGL((k_matvec_tn<T, NU, TN, 1>), dim3((unsigned)n_blocks), dim3((unsigned)mv_tn_threads<NU>()), (size_t)512 + (size_t)TN * img, s, ms, A, N, ldy, n_groups, n_waves, pa, ldx, img);
             else hipLaunchKernelGGL((k_matvec_tn<T, NU, TN, 2>), dim3((unsigned)n_blocks), dim3((unsigned)mv_tn_threads<NU>()), (size_t)512 + (size_t)TN * img, s, ms, A, N, ldy, n_groups, n_waves, pa, ldx, img);
@@ -1214,7 +1185,7 @@ static void launch_tn_n(const MatSet &ms, const ActQ &A, int N, int ldy, hipStre
     note_kernel("k_matvec_tn<%d, %d, %d, 0>", T, NU, TN);
     const size_t lds = mv_tn_reg<NU, TN>() ? 0 : mv_tn_lds(T, ms.w0.cols, TN);
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn<T, NU, TN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    if (!attr) { HIP_IGNORE(lds_optin_max(&k_matvec_tn<T, NU, TN, 0>)); attr = true; }
     hipLaunchKernelGGL((k_matvec_tn<T, NU, TN, 0>), dim3((unsigned)n_blocks), dim3((unsigned)mv_tn_threads<NU>()), lds, s, ms, A, N, ldy, n_groups, n_waves, pa, 0, 0);
 }
 template <int T, int NU>
@@ -1282,7 +1253,7 @@ static void launch_tn_mix_n(const MatSet &m1, const MatSet &m2, double bytes1, d
     if (px) {
         const int img = (int)mv_tn_image_bytes(m1.w0.cols);
         static bool attr1 = false;
-        if (!attr1) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_matvec_tn_mix<T1, T2, NU, TN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr1 = true; }
+        if (!attr1) { HIP_IGNORE(lds_optin_max(&k_matvec_tn_mix<T1, T2, NU, TN, 1>)); attr1 = true; }
         note_kernel("k_matvec_tn_mix<%d, %d, %d, %d, 1>", T1, T2, NU, TN);
         hipLaunchKernelGGL((k_matvec_tn_mix<T1, T2, NU, TN, 1>), grid, block, (size_t)512 + (size_t)TN * img, s, m1, m2, A, N, ldy, ng1, nw1, ng2, nw2, pa, ldx, img);
         return;
@@ -1737,8 +1708,8 @@ static void launch_attn_hd(float *q, const float *k, const float *v, __half *kc,
     const int Tpad = (n_ctx + 7) & ~7;
     const size_t lds = (size_t)Tpad * 6 + (size_t)HD * 6 + (size_t)(AT_THREADS / (HD / 8)) * HD * 4 + 64;
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                 HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    if (!attr) { HIP_IGNORE(lds_optin_max(&k_attn_llm<HD, true>));
+                 HIP_IGNORE(lds_optin_max(&k_attn_llm<HD, false>)); attr = true; }
     note_kernel("k_attn_llm<%d, %s, false>", HD, fused ? "true" : "false");
     if (fused) hipLaunchKernelGGL((k_attn_llm<HD, true>), dim3((unsigned)n_head, 1), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out, (const int *)nullptr, (size_t)0);
     else hipLaunchKernelGGL((k_attn_llm<HD, false>), dim3((unsigned)n_head, (unsigned)N), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out, (const int *)nullptr, (size_t)0);
@@ -1749,7 +1720,7 @@ static void launch_attn_batched_hd(float *q, const float *k, const float *v, __h
     const int Tpad = (n_ctx + 7) & ~7;
     const size_t lds = (size_t)Tpad * 6 + (size_t)HD * 6 + (size_t)(AT_THREADS / (HD / 8)) * HD * 4 + 64;
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_llm<HD, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    if (!attr) { HIP_IGNORE(lds_optin_max(&k_attn_llm<HD, true, true>)); attr = true; }
     hipLaunchKernelGGL((k_attn_llm<HD, true, true>), dim3((unsigned)n_head, (unsigned)B), dim3(AT_THREADS), lds, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, tb, out, row_slot,
                        seq_stride);
 }
@@ -1944,7 +1915,7 @@ static void launch_attn_split_hd(float *q, const float *k, const float *v, __hal
     hipLaunchKernelGGL((k_attn_split_scores<HD>), dim3((unsigned)n_head, (unsigned)splits), dim3(AS_THREADS), 0, s, q, k, v, kc, vc, n_head * HD, n_past, cos_tab, sin_tab, scores, ld, qrot);
     const size_t lds = (size_t)ld * 4 + (size_t)(AS_THREADS / (HD / 8)) * HD * 4 + 64;
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_split_pv<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    if (!attr) { HIP_IGNORE(lds_optin_max(&k_attn_split_pv<HD>)); attr = true; }
     note_kernel("k_attn_split_pv<%d>", HD);
     hipLaunchKernelGGL((k_attn_split_pv<HD>), dim3((unsigned)n_head, (unsigned)splits), dim3(AS_THREADS), lds, s, scores, ld, vc, n_head * HD, n_past, tb, partial, arrive, out);
 }
@@ -2485,7 +2456,7 @@ template <int HD>
 static bool launch_attn_prefill_h8(const float *q, const __half *kc, const __half *vc, int N, int n_head, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s, __half *out_h) {
     const int LS = ((t_max + AP_KT - 1) / AP_KT) * AP_KT + 4;
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill_h8<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    if (!attr) { HIP_IGNORE(lds_optin_max(&k_attn_prefill_h8<HD>)); attr = true; }
     const size_t kvbytes = std::max((size_t)AP_KT * HD * 2, (size_t)HD * APH_LDT * 2);
     const size_t lds = (size_t)AP_QT * 2 * LS * 4 + 2 * kvbytes;
     if (lds > 160 * 1024 - 512) return false;
@@ -2498,7 +2469,7 @@ template <int HD, int QS>
 static bool launch_attn_prefill_h_qs(const float *q, const __half *kc, const __half *vc, int N, int n_head, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
     const int LS = ((t_max + AP_KT - 1) / AP_KT) * AP_KT + 4;
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill_h<HD, QS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    if (!attr) { HIP_IGNORE(lds_optin_max(&k_attn_prefill_h<HD, QS>)); attr = true; }
     const size_t lds = (size_t)AP_QT * QS * LS * 4 + (size_t)AP_KT * HD * 2 + (size_t)HD * APH_LDT * 2;
     if (lds > 160 * 1024 - 512) return false;
     hipLaunchKernelGGL((k_attn_prefill_h<HD, QS>), dim3((unsigned)n_head, (unsigned)((N + AP_QT * QS - 1) / (AP_QT * QS))), dim3(256), lds, s, q, kc, vc, n_head * HD, N, n_past, tb, out, LS);
@@ -2513,7 +2484,7 @@ static bool launch_attn_prefill_hd(const float *q, const __half *kc, const __hal
     }
     const int LS = ((t_max + AP_KT - 1) / AP_KT) * AP_KT + 1;
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_prefill<HD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    if (!attr) { HIP_IGNORE(lds_optin_max(&k_attn_prefill<HD, 1>)); attr = true; }
     // (QS = 2 -- 32 queries per staged key / value tile from 256 prompt rows on -- is bit-identical and was measured 2 % SLOWER at 512 rows: 13B Q5_K_M 31.7 vs 31.0 ms,
     // 13B f16 27.9 vs 27.2 ms, profiles/r02r_prefill_ksplit_fill_sweep.log; half the workgroups, each twice as long: not instantiated.)
     const size_t lds = ((size_t)AP_QT * LS + (size_t)AP_KT * (HD + 1)) * 4;
@@ -2651,20 +2622,23 @@ __global__ __launch_bounds__(256) void k_attn_ref(const float *__restrict__ q, c
 }
 static size_t attn_ref_lds(int t_max, int hd) { return (size_t)2 * 128 * hd * 2 + (size_t)((t_max + 3) & ~3) * 4 + (size_t)((t_max + 7) & ~7) * 2 + (size_t)hd * 2 * 3 + 64; }
 // largest n_ctx whose score / probability rows fit k_attn_ref's LDS next to its value staging (parity mode): smaller than attn_max_ctx(hd), which is the fast kernel's
-int attn_ref_max_ctx(int hd) { int n = 0; while (attn_ref_lds(n + 8, hd) <= 160 * 1024) n += 8; return n; }
+constexpr size_t ATTN_REF_DYN_LDS = 160 * 1024 - 512;                     // the CU's 160 KiB minus the kernel's static reduction arrays (48 B), rounded
+int attn_ref_max_ctx(int hd) { int n = 0; while (attn_ref_lds(n + 8, hd) <= ATTN_REF_DYN_LDS) n += 8; return n; }
 // the > 64 KiB dynamic-LDS opt-in of a kernel: once per DEVICE (the attribute belongs to the device's code object), and a refusal is an error here, not a launch failure later
 static unsigned long long g_attn_ref_optin_mask = 0;                       // bit d: device d has the attribute for both instantiations (<= 64 devices per process)
 void attn_ref_prepare() {   // called by Engine::init / set_parity when parity mode is switched on -- never inside a stream capture (an attribute call there is refused)
     int dev = 0; HIP_CHECK(hipGetDevice(&dev));
     if (dev < 64 && (g_attn_ref_optin_mask >> dev & 1)) return;
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_ref<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_ref<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // (a request for the full 160 KiB is refused -- invalid argument -- because the kernels also have static LDS; rounds 3-4 asked for exactly that behind HIP_IGNORE, so the
+    // opt-in never took effect and parity mode silently depended on staying below the 64 KiB default)
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_ref<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATTN_REF_DYN_LDS));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_ref<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATTN_REF_DYN_LDS));
     if (dev < 64) g_attn_ref_optin_mask |= 1ull << dev;
 }
 template <typename K> static void attn_ref_lds_optin(K kernel) {       // launchers reached without attn_ref_prepare (test hooks): best effort, as before
     int dev = 0; if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
     if (dev < 64 && (g_attn_ref_optin_mask >> dev & 1)) return;
-    HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATTN_REF_DYN_LDS));
 }
 void launch_attn_ref(const float *q, const __half *kcache, const __half *vcache, int N, int n_head, int hd, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
     note_kernel("k_attn_ref");

@@ -304,7 +304,7 @@ void set_mmq3_waves(int nw) { g_mmq3_nw = nw == 4 ? 4 : 8; }
 template <int NT, int NW>
 static void mmq3_launch_nt(dim3 grid, hipStream_t s, const Mmq3Args &a, const ActQ &A) {
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mmq3_q45k<NT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    if (!attr) { HIP_IGNORE(lds_optin_max(&k_mmq3_q45k<NT, NW>)); attr = true; }
     hipLaunchKernelGGL((k_mmq3_q45k<NT, NW>), grid, dim3(64 * NW), (size_t)(L3<NT, NW>::TOTAL), s, a, A);
 }
 template <int NW>

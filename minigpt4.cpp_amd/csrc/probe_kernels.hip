@@ -188,7 +188,7 @@ float probe_dma_GBps(int form, int policy, int waves, int fill, int depth, int d
     const size_t lds = (size_t)waves * depth * fill;
     auto launch = [&](size_t bytes_per_wg) {
         const dim3 g((unsigned)cus), b((unsigned)waves * 64);
-#define PR_GO(F, P) do { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_probe_dma<F, P>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+#define PR_GO(F, P) do { HIP_IGNORE(lds_optin_max(&k_probe_dma<F, P>)); \
                          hipLaunchKernelGGL((k_probe_dma<F, P>), g, b, lds, nullptr, buf, bytes_per_wg, fill, depth, deal, sink); } while (0)
         switch (form * 2 + policy) { case 0: PR_GO(0, 0); break; case 1: PR_GO(0, 1); break; case 2: PR_GO(1, 0); break; case 3: PR_GO(1, 1); break;
                                      case 4: PR_GO(2, 0); break; case 5: PR_GO(2, 1); break; case 6: PR_GO(3, 0); break; default: PR_GO(3, 1); break; }

@@ -1,0 +1,264 @@
+// Batched decode (B = 2..4 conversations per weight pass, SURVEY.md 8f-1 / BASELINE.json configs[3]: 4 requests per replica) on the int8 matrix cores -- round 5.
+//
+// The multi-row mat-vec of rounds 2-4 (k_matvec_tn, llm_kernels.hip) keeps the single-row kernel's lane map -- 64 lanes share ONE weight row, a lane owns a 32-weight unit --
+// and multiplies every unit against each of the B activation rows with v_dot4_i32_i8: 8 dot instructions per row and unit, vector-issue bound at B = 4 (84 % VALU busy,
+// weights at 2 TB/s).  v_mfma_i32_4x4x4_16B_i8 computes 16 independent 4 x 4 x 4 products per instruction; with the TOKENS as the 4 rows of the A operand (the same in all 16
+// blocks) and 64 different WEIGHT ROWS as the columns of the B operand, one instruction multiplies 4 consecutive weights of 64 rows against up to 4 tokens -- the work of
+// four v_dot4 per lane -- and accumulates it in the lane's own four registers (register r = token r).  That needs lane = weight ROW, i.e. loads of 16 bytes per row at a
+// stride of one row; so the k-quant matrices get a second, ROW-INTERLEAVED image (built on the device from the ordinary planes when a context is given more than one
+// conversation: Engine::build_ri_planes): for every group of 64 rows and every unit the 64 rows' 16-byte pieces back to back (1 KiB per wave load), the same for the
+// high-bit words and the per-super-block headers.  Micro-benchmark on the 13B w1|w3 set (profiles/r05_batched_decode_mfma.log): 22 us per launch at B = 2, 3 and 4 against
+// 25.6 / 29.7 / 33.8 us for k_matvec_tn.
+//
+// Arithmetic: ggml's (reference minigpt4.cpp:2373 -> llama_eval -> ggml_mul_mat, k-quant x Q8_K): exact int32 sub-block dots (the MFMA's integer accumulation), integer
+// sub-block scales, one fp32 update per super-block with d_w * d_a.  Per output the super-blocks of a K quarter are added in order and the four quarters (the four waves
+// of a workgroup) in wave order: a fixed order, but not k_matvec_tn's -- results differ from it in the last bits like any two summation orders.
+//   Q4_K / Q5_K: min term sum_j m_j * bsum_j as four more MFMAs per super-block on the digit split bsum = 128 hi + lo (the quantiser's bsq plane).
+//   Q6_K: weights enter as their unsigned 6-bit codes; the -32 offset is sum_g sc_g * bsum16_g, eight MFMAs per super-block on the digit split of the 16-element sums.
+#include "kernels.hpp"
+#include "devutil.hpp"
+
+#include <algorithm>
+
+namespace mg4 {
+
+typedef int v4i_r __attribute__((ext_vector_type(4)));
+
+// ---- the row-interleaved image ---------------------------------------------------------------------------------------------------------------------
+// G = rows / 64 groups, U = K / 32 units, NSB = K / 256 super-blocks:
+//   qs [G][U][64][16]                       every type
+//   qh [G][U][64][4] (Q5_K: pack_hb1 word)  /  [G][U][64][8] (Q6_K: Plo, Phi)
+//   sc [G][NSB][64][16]                     Q4_K / Q5_K: {d, dmin, 12 packed scale / min bytes};  Q6_K: the super-block's 8 x {lo, hi} int8 scales
+//   d  [G][NSB][64][2]                      Q6_K: fp16 d
+bool ri_supported(int type, int rows, int cols) { return (type == GT_Q4_K || type == GT_Q5_K || type == GT_Q6_K) && rows % 64 == 0 && cols % 256 == 0 && cols <= 16384; }
+size_t ri_plan(int type, int rows, int cols, RiPlanes &p, uint8_t *base) {
+    p = RiPlanes{};
+    if (!ri_supported(type, rows, cols)) return 0;
+    const size_t G = (size_t)rows / 64, U = (size_t)cols / 32, NSB = (size_t)cols / 256;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const uint8_t *q = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return q; };
+    p.qs = take(G * U * 1024);
+    if (type == GT_Q5_K) p.qh = take(G * U * 256);
+    if (type == GT_Q6_K) p.qh = take(G * U * 512);
+    p.sc = take(G * NSB * 1024);
+    if (type == GT_Q6_K) p.d = take(G * NSB * 128);
+    return off;
+}
+__global__ __launch_bounds__(256) void k_ri_build(const QWeight w, const RiPlanes p, const size_t n_units) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;              // (row, unit) of the ordinary planes
+    if (i >= n_units) return;
+    const int U = w.cols / 32, NSB = w.cols / 256;
+    const size_t row = i / U; const int u = (int)(i - row * U);
+    const size_t g = row >> 6; const int l = (int)(row & 63);
+    uint8_t *qs = const_cast<uint8_t *>(p.qs), *qh = const_cast<uint8_t *>(p.qh), *sc = const_cast<uint8_t *>(p.sc), *dd = const_cast<uint8_t *>(p.d);
+    *reinterpret_cast<v4i_r *>(qs + ((g * U + u) * 64 + l) * 16) = *reinterpret_cast<const v4i_r *>(w.qs + i * 16);
+    if (w.type == GT_Q5_K) *reinterpret_cast<unsigned *>(qh + ((g * U + u) * 64 + l) * 4) = *reinterpret_cast<const unsigned *>(w.qh + i * 4);
+    if (w.type == GT_Q6_K) *reinterpret_cast<uint2 *>(qh + ((g * U + u) * 64 + l) * 8) = *reinterpret_cast<const uint2 *>(w.qh + i * 8);
+    if ((u & 7) == 0) {
+        const int sb = u >> 3;
+        if (w.type == GT_Q6_K) {
+            *reinterpret_cast<v4i_r *>(sc + ((g * NSB + sb) * 64 + l) * 16) = *reinterpret_cast<const v4i_r *>(w.sc + i * 2);      // 8 units x 2 int8, contiguous in the ordinary plane
+            *reinterpret_cast<unsigned short *>(dd + ((g * NSB + sb) * 64 + l) * 2) = *reinterpret_cast<const unsigned short *>(w.d + (i >> 3) * 2);
+        } else *reinterpret_cast<v4i_r *>(sc + ((g * NSB + sb) * 64 + l) * 16) = *reinterpret_cast<const v4i_r *>(w.sc + (i >> 3) * 16);
+    }
+}
+void launch_ri_build(const QWeight &w, const RiPlanes &p, hipStream_t s) {
+    const size_t n = (size_t)w.rows * (w.cols / 32);
+    hipLaunchKernelGGL(k_ri_build, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, p, n);
+}
+
+// ---- the kernel ----------------------------------------------------------------------------------------------------------------------------------------
+struct RiMat { RiPlanes p; float *y; const float *res; };
+struct RiArgs { RiMat m[3]; int n_mat, groups_each, rows_each, K, N, ldy; };
+
+__device__ __forceinline__ void ri_scale_min_words(const v4i_r &h, unsigned &scw0, unsigned &scw1, unsigned &mw0, unsigned &mw1) {
+    const unsigned s0 = (unsigned)h[1], s1 = (unsigned)h[2], s2 = (unsigned)h[3];
+    scw0 = s0 & 0x3f3f3f3fu; scw1 = (s2 & 0x0f0f0f0fu) | (((s0 >> 6) & 0x03030303u) << 4);
+    mw0 = s1 & 0x3f3f3f3fu; mw1 = ((s2 >> 4) & 0x0f0f0f0fu) | (((s1 >> 6) & 0x03030303u) << 4);
+}
+__device__ __forceinline__ float ri_h2f(unsigned short h) { return __half2float(__ushort_as_half(h)); }
+
+// LDS image of the <= 4 activation rows (rows >= N are zero):  q8 [4][K]  |  dg [4][NSB][DG]  |  dk [4][NSB]  |  red [WPB][4][64]
+//   DG = 16 (Q4_K / Q5_K): the quantiser's digit-split per-32 sums (bytes 0..7 low digits of sub-blocks 0..7, 8..15 high digits)
+//   DG = 32 (Q6_K): the 16-element sums of the super-block in the ORDER OF THE SCALE BYTES (unit i = (n, c, h): byte 2 i <-> group 8 n + 2 c + h, byte 2 i + 1 <-> that + 4),
+//                   bytes 0..15 low digits (s & 127), 16..31 high digits (s >> 7)
+template <int T, int WPB>
+__global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const ActQ A) {
+    constexpr bool Q6 = T == GT_Q6_K, Q5 = T == GT_Q5_K;
+    constexpr int DG = Q6 ? 32 : 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ri[];
+    const int K = a.K, U = K / 32, NSB = K / 256, N = a.N;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, t4 = lane & 3;
+    int8_t *q8 = reinterpret_cast<int8_t *>(smem_ri);
+    int8_t *dg = q8 + 4 * K;
+    float *dk = reinterpret_cast<float *>(dg + 4 * NSB * DG);
+    float *red = dk + 4 * NSB;
+    for (int i = threadIdx.x * 16; i < 4 * K; i += 64 * WPB * 16) {
+        const int t = i / K;
+        v4i_r v = {0, 0, 0, 0};
+        if (t < N) v = *reinterpret_cast<const v4i_r *>(A.q8k + (size_t)t * K + (i - t * K));
+        *reinterpret_cast<v4i_r *>(q8 + i) = v;
+    }
+    for (int i = threadIdx.x; i < 4 * NSB; i += 64 * WPB) {
+        const int t = i / NSB, sb = i - t * NSB;
+        float d = 0.0f;
+        if (!Q6) {
+            v4i_r v = {0, 0, 0, 0};
+            if (t < N) { v = *reinterpret_cast<const v4i_r *>(A.bsq + ((size_t)t * NSB + sb) * 16); d = A.dk[(size_t)t * NSB + sb]; }
+            *reinterpret_cast<v4i_r *>(dg + (size_t)i * 16) = v;
+        } else {
+            int8_t *o = dg + (size_t)i * 32;
+            if (t < N) d = A.dk[(size_t)t * NSB + sb];
+#pragma unroll
+            for (int ui = 0; ui < 8; ui++) {
+                const int n = ui >> 2, c = (ui >> 1) & 1, h = ui & 1, grp = 8 * n + 2 * c + h;
+                const int s_lo = t < N ? (int)A.bsk[(size_t)t * (K / 16) + sb * 16 + grp] : 0, s_hi = t < N ? (int)A.bsk[(size_t)t * (K / 16) + sb * 16 + grp + 4] : 0;
+                o[2 * ui] = (int8_t)(s_lo & 127); o[2 * ui + 1] = (int8_t)(s_hi & 127); o[16 + 2 * ui] = (int8_t)(s_lo >> 7); o[16 + 2 * ui + 1] = (int8_t)(s_hi >> 7);
+            }
+        }
+        dk[i] = d;
+    }
+    __syncthreads();
+    const int sb_per = (NSB + WPB - 1) / WPB, sb0 = wv * sb_per, sb1 = min(NSB, sb0 + sb_per);
+    const int8_t *qa = q8 + (size_t)t4 * K;
+    const int8_t *da = dg + (size_t)t4 * NSB * DG;
+    struct Raw { v4i_r q[8]; unsigned p[Q6 ? 16 : (Q5 ? 8 : 1)]; v4i_r h; unsigned short d; };
+    const int total_groups = a.n_mat * a.groups_each;
+    for (int g = blockIdx.x; g < total_groups; g += gridDim.x) {
+        const int m = g / a.groups_each, gl = g - m * a.groups_each;
+        const RiMat &M = a.m[m];
+        const uint8_t *pq = M.p.qs + (size_t)gl * U * 1024 + lane * 16, *pp = M.p.qh + (size_t)gl * U * (Q6 ? 512 : 256) + lane * (Q6 ? 8 : 4), *ph = M.p.sc + (size_t)gl * NSB * 1024 + lane * 16,
+                      *pd = M.p.d + (size_t)gl * NSB * 128 + lane * 2;
+        auto fetch = [&](int sb, Raw &r) {          // every load unconditional (clamped super-block): counted waits
+            const int sbc = min(sb, NSB - 1);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                r.q[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i_r *>(pq + (size_t)(sbc * 8 + u) * 1024));
+                if (Q5) r.p[u] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(pp + (size_t)(sbc * 8 + u) * 256));
+                if (Q6) { typedef unsigned v2u_r __attribute__((ext_vector_type(2))); const v2u_r w2 = __builtin_nontemporal_load(reinterpret_cast<const v2u_r *>(pp + (size_t)(sbc * 8 + u) * 512)); r.p[Q6 ? 2 * u : 0] = w2.x; r.p[Q6 ? 2 * u + 1 : 0] = w2.y; }
+            }
+            r.h = __builtin_nontemporal_load(reinterpret_cast<const v4i_r *>(ph + (size_t)sbc * 1024));
+            if (Q6) r.d = __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(pd + (size_t)sbc * 128));
+        };
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        auto consume = [&](int sb, const Raw &r) {
+            int isum[4] = {0, 0, 0, 0};
+            unsigned scw0 = 0, scw1 = 0, mw0 = 0, mw1 = 0;
+            if (!Q6) ri_scale_min_words(r.h, scw0, scw1, mw0, mw1);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                // activation bytes of the unit's low / high nibbles (Tr<T>::loada): Q4_K / Q5_K: 64 j + 16 h and + 32;  Q6_K: 128 n + 32 c + 16 h and + 64
+                const int off = Q6 ? 128 * (u >> 2) + 32 * ((u >> 1) & 1) + 16 * (u & 1) : 64 * (u >> 1) + 16 * (u & 1);
+                const v4i_r alo = *reinterpret_cast<const v4i_r *>(qa + sb * 256 + off), ahi = *reinterpret_cast<const v4i_r *>(qa + sb * 256 + off + (Q6 ? 64 : 32));
+                v4i_r D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const unsigned q = (unsigned)r.q[u][d];
+                    unsigned wlo = q & 0x0F0F0F0Fu, whi = (q >> 4) & 0x0F0F0F0Fu;
+                    if (Q5) { const unsigned P = r.p[Q5 ? u : 0];
+                        wlo |= (d == 0 ? P << 4 : d == 1 ? P << 3 : d == 2 ? P << 2 : P << 1) & 0x10101010u; whi |= (d == 0 ? P : d == 1 ? P >> 1 : d == 2 ? P >> 2 : P >> 3) & 0x10101010u; }
+                    if (Q6) { const unsigned L = r.p[Q6 ? 2 * u : 0], H = r.p[Q6 ? 2 * u + 1 : 0];
+                        wlo |= (d == 0 ? L << 4 : d == 1 ? L << 2 : d == 2 ? L : L >> 2) & 0x30303030u; whi |= (d == 0 ? H << 4 : d == 1 ? H << 2 : d == 2 ? H : H >> 2) & 0x30303030u; }
+                    D0 = __builtin_amdgcn_mfma_i32_4x4x4i8(alo[d], (int)wlo, D0, 0, 0, 0);
+                    D1 = __builtin_amdgcn_mfma_i32_4x4x4i8(ahi[d], (int)whi, D1, 0, 0, 0);
+                }
+                int sc0, sc1;
+                if (Q6) { const unsigned w16 = ((unsigned)r.h[u >> 1] >> (16 * (u & 1))) & 0xFFFFu; sc0 = (int)(signed char)(w16 & 0xFF); sc1 = (int)(signed char)(w16 >> 8); }
+                else { const int j = u >> 1; const unsigned scw = (j & 2) ? scw1 : scw0; sc0 = (int)(scw >> (16 * (j & 1))) & 0xFF; sc1 = (int)(scw >> (16 * (j & 1) + 8)) & 0xFF; }
+#pragma unroll
+                for (int t = 0; t < 4; t++) isum[t] += __mul24(sc0, D0[t]) + __mul24(sc1, D1[t]);
+            }
+            if (!Q6) {
+                // min term: sum_j m_j * bsum_j on the digit split of the per-32 sums
+                const v4i_r dgt = *reinterpret_cast<const v4i_r *>(da + sb * 16);
+                v4i_r Ml = {0, 0, 0, 0}, Mh = {0, 0, 0, 0};
+                Ml = __builtin_amdgcn_mfma_i32_4x4x4i8(dgt[0], (int)mw0, Ml, 0, 0, 0); Ml = __builtin_amdgcn_mfma_i32_4x4x4i8(dgt[1], (int)mw1, Ml, 0, 0, 0);
+                Mh = __builtin_amdgcn_mfma_i32_4x4x4i8(dgt[2], (int)mw0, Mh, 0, 0, 0); Mh = __builtin_amdgcn_mfma_i32_4x4x4i8(dgt[3], (int)mw1, Mh, 0, 0, 0);
+                const float d = ri_h2f((unsigned short)((unsigned)r.h[0] & 0xFFFF)), dmin = ri_h2f((unsigned short)((unsigned)r.h[0] >> 16));
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const float dkt = dk[t * NSB + sb];
+                    acc[t] = fmaf(d * dkt, (float)isum[t], acc[t]);
+                    acc[t] = fmaf(-(dmin * dkt), (float)(Mh[t] * 128 + Ml[t]), acc[t]);
+                }
+            } else {
+                // the -32 offset of the 6-bit codes: sum over the 16 scale groups of sc_g * bsum16_g, digit split (scale bytes and digit bytes are in the same order)
+                const v4i_r dl = *reinterpret_cast<const v4i_r *>(da + sb * 32), dh = *reinterpret_cast<const v4i_r *>(da + sb * 32 + 16);
+                v4i_r Cl = {0, 0, 0, 0}, Ch = {0, 0, 0, 0};
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) { Cl = __builtin_amdgcn_mfma_i32_4x4x4i8(dl[k4], r.h[k4], Cl, 0, 0, 0); Ch = __builtin_amdgcn_mfma_i32_4x4x4i8(dh[k4], r.h[k4], Ch, 0, 0, 0); }
+                const float d = ri_h2f(r.d);
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[t] = fmaf(d * dk[t * NSB + sb], (float)(isum[t] - 32 * (Ch[t] * 128 + Cl[t])), acc[t]);
+            }
+        };
+        Raw cur, nxt;
+        fetch(sb0, cur);
+        for (int sb = sb0; sb < sb1;) {
+            fetch(sb + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(sb, cur);
+            __builtin_amdgcn_sched_barrier(0);
+            if (++sb >= sb1) break;
+            fetch(sb + 1, cur);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(sb, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            ++sb;
+        }
+        // the K ranges of the WPB waves, combined in wave order
+#pragma unroll
+        for (int t = 0; t < 4; t++) red[(wv * 4 + t) * 64 + lane] = acc[t];
+        __syncthreads();
+        if (wv < N) {
+            const int t = wv;
+            float s = red[t * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < WPB; w++) s += red[(w * 4 + t) * 64 + lane];
+            const size_t o = (size_t)t * a.ldy + (size_t)gl * 64 + lane;
+            M.y[o] = M.res ? s + M.res[o] : s;
+        }
+        __syncthreads();
+    }
+}
+
+static int g_ri_cus = 256;
+void set_ri_cus(int cus) { if (cus > 0) g_ri_cus = cus; }
+static size_t ri_lds(int type, int K, int wpb) { const int NSB = K / 256; return (size_t)4 * K + (size_t)4 * NSB * (type == GT_Q6_K ? 32 : 16) + (size_t)4 * NSB * 4 + (size_t)wpb * 4 * 64 * 4; }
+template <int T>
+static bool launch_ri_t(const RiArgs &a, const ActQ &A, hipStream_t s) {
+    const int total = a.n_mat * a.groups_each;
+    // 4 waves per workgroup (each a K quarter), two workgroups per CU; matrices with fewer 64-row groups than CUs (wo, w2: 80 groups at the 13B width) split K over 8 waves
+    const bool wide = total < g_ri_cus;
+    const size_t lds = ri_lds(T, a.K, wide ? 8 : 4);
+    if (lds > (wide ? 150u : 78u) * 1024u) return false;
+    static bool attr[2] = {false, false};
+    if (wide) {
+        if (!attr[1]) { HIP_IGNORE(lds_optin_max(&k_matvec_ri<T, 8>)); attr[1] = true; }
+        hipLaunchKernelGGL((k_matvec_ri<T, 8>), dim3((unsigned)std::min(total, g_ri_cus)), dim3(512), lds, s, a, A);
+    } else {
+        if (!attr[0]) { HIP_IGNORE(lds_optin_max(&k_matvec_ri<T, 4>)); attr[0] = true; }
+        hipLaunchKernelGGL((k_matvec_ri<T, 4>), dim3((unsigned)std::min(total, 2 * g_ri_cus)), dim3(256), lds, s, a, A);
+    }
+    return true;
+}
+// y[m][t * ldy + r] = W_m[r] . act[t] (+ residual[m][t * ldy + r]) for N = 1..4 prepared rows (A: Q8_K image incl. bsq) against 1..3 same-type, same-shape k-quant matrices
+// that carry their row-interleaved image (ri[k]); false -> outside this kernel's range, nothing launched
+bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s) {
+    if (n < 1 || n > 3 || N < 1 || N > 4 || !A.q8k || !A.dk || !A.bsk || !A.bsq) return false;
+    RiArgs a{};
+    for (int i = 0; i < n; i++) {
+        if (!ri[i] || !ri[i]->qs || W[i]->type != W[0]->type || W[i]->rows != W[0]->rows || W[i]->cols != W[0]->cols) return false;
+        a.m[i].p = *ri[i]; a.m[i].y = y[i]; a.m[i].res = residual ? residual[i] : nullptr;
+    }
+    if (!ri_supported(W[0]->type, W[0]->rows, W[0]->cols)) return false;
+    a.n_mat = n; a.groups_each = W[0]->rows / 64; a.rows_each = W[0]->rows; a.K = W[0]->cols; a.N = N; a.ldy = ldy;
+    switch (W[0]->type) {
+    case GT_Q4_K: return launch_ri_t<GT_Q4_K>(a, A, s);
+    case GT_Q5_K: return launch_ri_t<GT_Q5_K>(a, A, s);
+    case GT_Q6_K: return launch_ri_t<GT_Q6_K>(a, A, s);
+    default: return false;
+    }
+}
+
+}  // namespace mg4

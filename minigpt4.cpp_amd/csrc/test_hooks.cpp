@@ -207,6 +207,86 @@ int minigpt4_amd_test_matvec_rows(int ggml_type, const void *raw_w, int n_mat, i
     });
 }
 
+// The batched decode's MFMA launch (ri_kernels.hip): n_mat equally shaped k-quant matrices (rows of raw_w back to back) as ordinary planes -> row-interleaved image -> N = 1..4
+// prepared rows; y [n_mat][N][n_out].  4: the kernel refuses the shape / type.
+int minigpt4_amd_test_matvec_ri(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int N, const float *residual, float *y) {
+    if (!raw_w || !x || !y || n_in <= 0 || n_out <= 0 || n_mat < 1 || n_mat > 3 || N < 1 || N > 4 || !qweight_supported(ggml_type) || n_in % gt_block(ggml_type)) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const int K = (int)n_in, R = (int)n_out;
+        if (!ri_supported(ggml_type, R, K)) { set_last_error("type / shape outside the row-interleaved kernel's range"); return 4; }
+        QWeight plan; const size_t need = plan_qweight(ggml_type, R, K, plan, nullptr), raw_bytes = gt_nbytes(ggml_type, (size_t)R * K);
+        RiPlanes rplan; const size_t rneed = ri_plan(ggml_type, R, K, rplan, nullptr);
+        DevBuf planes(need * (size_t)n_mat), rplanes(rneed * (size_t)n_mat), d_raw(raw_bytes), d_x((size_t)N * K * 4), d_y((size_t)n_mat * N * R * 4), d_res((size_t)n_mat * N * R * 4);
+        std::vector<QWeight> W((size_t)n_mat); std::vector<RiPlanes> P((size_t)n_mat);
+        for (int m = 0; m < n_mat; m++) {
+            plan_qweight(ggml_type, R, K, W[(size_t)m], planes.as<uint8_t>() + (size_t)m * need);
+            HIP_CHECK(hipMemcpy(d_raw.p, (const uint8_t *)raw_w + (size_t)m * raw_bytes, raw_bytes, hipMemcpyHostToDevice));
+            launch_repack(d_raw.as<uint8_t>(), W[(size_t)m], nullptr);
+            ri_plan(ggml_type, R, K, P[(size_t)m], rplanes.as<uint8_t>() + (size_t)m * rneed);
+            launch_ri_build(W[(size_t)m], P[(size_t)m], nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+        }
+        HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)N * K * 4, hipMemcpyHostToDevice));
+        if (residual) HIP_CHECK(hipMemcpy(d_res.p, residual, (size_t)n_mat * N * R * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(d_y.p, 0xFF, (size_t)n_mat * N * R * 4));
+        ActQ A; std::vector<std::unique_ptr<DevBuf>> keep; alloc_act(A, keep, (size_t)N, (size_t)K);
+        launch_rms_quant(d_x.as<float>(), nullptr, N, K, A, ACT_Q8K, nullptr);
+        const QWeight *Wp[3]; const RiPlanes *Pp[3]; float *Yp[3]; const float *Rp[3];
+        for (int m = 0; m < n_mat; m++) { Wp[m] = &W[(size_t)m]; Pp[m] = &P[(size_t)m]; Yp[m] = d_y.as<float>() + (size_t)m * N * R; Rp[m] = d_res.as<float>() + (size_t)m * N * R; }
+        hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0)); set_ri_cus(prop.multiProcessorCount);
+        if (!launch_matvec_ri(Wp, Pp, Yp, residual ? Rp : nullptr, n_mat, A, N, R, nullptr)) { set_last_error("launch_matvec_ri refused"); return 4; }
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(y, d_y.p, (size_t)n_mat * N * R * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+
+// microseconds per launch of the row-interleaved MFMA mat-vec for one set of n_mat rows x cols matrices against N prepared rows; n_sets weight sets are rotated
+int minigpt4_amd_bench_matvec_ri(int ggml_type, int rows, int cols, int n_mat, int N, int iters, int n_sets, float *us_per_launch) {
+    if (!ri_supported(ggml_type, rows, cols) || n_mat < 1 || n_mat > 3 || N < 1 || N > 4 || iters < 1 || n_sets < 1) return 1;
+    if (device_count_noexcept() <= 0) return 2;
+    return guarded(3, [&]() -> int {
+        hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0)); set_ri_cus(prop.multiProcessorCount);
+        QWeight plan; const size_t need = plan_qweight(ggml_type, rows, cols, plan, nullptr);
+        RiPlanes rplan; const size_t rneed = ri_plan(ggml_type, rows, cols, rplan, nullptr);
+        std::vector<std::unique_ptr<DevBuf>> keep;
+        std::vector<QWeight> W((size_t)n_sets * n_mat); std::vector<RiPlanes> P((size_t)n_sets * n_mat);
+        DevBuf tmp(need);
+        for (size_t i = 0; i < W.size(); i++) {
+            plan_qweight(ggml_type, rows, cols, W[i], tmp.as<uint8_t>());
+            launch_fill_random(tmp.p, need, (unsigned)(i * 7919 + 13), nullptr);
+            const size_t n = (size_t)rows * cols;
+            if (ggml_type == GT_Q4_K || ggml_type == GT_Q5_K) launch_fill_u16((void *)W[i].sc, n / 256 * 16 / 2, 0x1C00, nullptr);
+            if (W[i].d) launch_fill_u16((void *)W[i].d, n / 256, 0x1C00, nullptr);
+            keep.emplace_back(new DevBuf(rneed));
+            ri_plan(ggml_type, rows, cols, P[i], (uint8_t *)keep.back()->p);
+            launch_ri_build(W[i], P[i], nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+        }
+        ActQ A; alloc_act(A, keep, (size_t)N, (size_t)cols);
+        DevBuf dx((size_t)N * cols * 4), dy((size_t)rows * 4 * 3 * N);
+        { std::vector<float> hx((size_t)N * cols); for (size_t i = 0; i < hx.size(); i++) hx[i] = (float)((int)(i * 37 % 201) - 100) / 64.0f; HIP_CHECK(hipMemcpy(dx.p, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); }
+        launch_rms_quant(dx.as<float>(), nullptr, N, cols, A, ACT_Q8K, nullptr);
+        auto run = [&](int set) {
+            const QWeight *Wp[3]; const RiPlanes *Pp[3]; float *Yp[3];
+            for (int m = 0; m < n_mat; m++) { Wp[m] = &W[(size_t)set * n_mat + m]; Pp[m] = &P[(size_t)set * n_mat + m]; Yp[m] = dy.as<float>() + (size_t)m * rows * N; }
+            if (!launch_matvec_ri(Wp, Pp, Yp, nullptr, n_mat, A, N, rows, nullptr)) throw HipError{hipErrorInvalidValue, "launch_matvec_ri refused", __FILE__, __LINE__};
+        };
+        for (int i = 0; i < std::min(n_sets, 4); i++) run(i);
+        HIP_CHECK(hipDeviceSynchronize());
+        hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+        HIP_CHECK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; i++) run(i % n_sets);
+        HIP_CHECK(hipEventRecord(b, nullptr));
+        HIP_CHECK(hipDeviceSynchronize());
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        if (us_per_launch) *us_per_launch = ms * 1e3f / (float)iters;
+        HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b));
+        return 0;
+    });
+}
+
 int minigpt4_amd_test_quantize(const float *x, const float *rms_w, int64_t N, int64_t K, int8_t *q8k, float *dk, int16_t *bsums, int8_t *q80, float *d0) {
     if (!x || N <= 0 || K <= 0 || K % 256) return 1;
     if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }

@@ -198,10 +198,10 @@ static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, in
     dim3 grid((unsigned)((ntx * rt + 7) / 8 * 8), 1, (unsigned)slices), block(BM / (32 * TM) * (BN / (32 * TN)) * 64);
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 8) * 2;
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, TM, TN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, TM, TN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, TM, TN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<BK, BM, BN, TM, TN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    if (!attr) { HIP_IGNORE(lds_optin_max(&k_gemm_f16<BK, BM, BN, TM, TN, true, true>));
+        HIP_IGNORE(lds_optin_max(&k_gemm_f16<BK, BM, BN, TM, TN, true, false>));
+        HIP_IGNORE(lds_optin_max(&k_gemm_f16<BK, BM, BN, TM, TN, false, true>));
+        HIP_IGNORE(lds_optin_max(&k_gemm_f16<BK, BM, BN, TM, TN, false, false>)); attr = true; }
     if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
     else if (gelu) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
     else if (residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
@@ -398,10 +398,10 @@ static bool launch_gemm_dma_t(const __half *A, int lda, const __half *W, int ldw
     dim3 grid((unsigned)((ntx * rt + 7) / 8 * 8), 1, (unsigned)slices), block(BM / (32 * TM) * (BN / (32 * TN)) * 64);
     const size_t lds = (size_t)S * KT * (BM + BN) * 128;
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_dma<BM, BN, TM, TN, KT, S, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_dma<BM, BN, TM, TN, KT, S, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_dma<BM, BN, TM, TN, KT, S, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_dma<BM, BN, TM, TN, KT, S, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    if (!attr) { HIP_IGNORE(lds_optin_max(&k_gemm_dma<BM, BN, TM, TN, KT, S, true, true>));
+        HIP_IGNORE(lds_optin_max(&k_gemm_dma<BM, BN, TM, TN, KT, S, true, false>));
+        HIP_IGNORE(lds_optin_max(&k_gemm_dma<BM, BN, TM, TN, KT, S, false, true>));
+        HIP_IGNORE(lds_optin_max(&k_gemm_dma<BM, BN, TM, TN, KT, S, false, false>)); attr = true; }
     if (gelu && residual) hipLaunchKernelGGL((k_gemm_dma<BM, BN, TM, TN, KT, S, true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
     else if (gelu) hipLaunchKernelGGL((k_gemm_dma<BM, BN, TM, TN, KT, S, true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
     else if (residual) hipLaunchKernelGGL((k_gemm_dma<BM, BN, TM, TN, KT, S, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, gs);
@@ -416,7 +416,7 @@ static bool launch_gemm_dma_pair_t(const __half *A, int lda, const __half *W1, l
     dim3 grid((unsigned)((ntx * rt + 7) / 8 * 8), 1, 1), block(BM / (32 * TM) * (BN / 64) * 64);
     const size_t lds = (size_t)S * KT * (BM + BN) * 128;
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_dma<BM, BN, TM, 2, KT, S, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    if (!attr) { HIP_IGNORE(lds_optin_max(&k_gemm_dma<BM, BN, TM, 2, KT, S, false, false, true>)); attr = true; }
     hipLaunchKernelGGL((k_gemm_dma<BM, BN, TM, 2, KT, S, false, false, true>), grid, block, lds, s, A, lda, W1, ldw, M, N, K, nullptr, nullptr, tb, out, out_h, ldo, gs);
     return true;
 }
@@ -1177,9 +1177,9 @@ void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, in
                      const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s, int batch) {
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
-        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<88, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<64, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_attn_vit<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_IGNORE(lds_optin_max(&k_attn_vit<88, 5>));
+        HIP_IGNORE(lds_optin_max(&k_attn_vit<64, 5>));
+        HIP_IGNORE(lds_optin_max(&k_attn_vit<64, 1>));
         attr_set = true;
     }
     if (hd != 88 && hd != 64) throw HipError{hipErrorInvalidValue, "attn_f32: head size must be 88 or 64", __FILE__, __LINE__};

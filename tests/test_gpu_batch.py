@@ -259,3 +259,37 @@ def test_multi_row_matvec_matches_oracle(gpu_lib, wtype, K, N, n_mat, with_res):
         want = want + res
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), (wtype, K, N, n_mat)
+
+
+# rows: multiples of 64 (the row-interleaved groups); 2304 rows x 3 matrices = 108 groups (< CUs: the 8-wave form), 5120 x 2 = 160, 13824 x 2 = 432 (>= CUs: 4 waves, two
+# workgroups per CU); K = 256 (one super-block: three of the four waves idle), 5120 / 13824 (the 13B widths: 20 / 54 super-blocks over 4 or 8 waves, ragged)
+RI_CASES = [("q4_k", 256, 128, 1), ("q5_k", 512, 192, 2), ("q6_k", 768, 64, 3), ("q4_k", 4096, 2304, 3), ("q5_k", 5120, 2304, 3), ("q5_k", 5120, 5120, 2), ("q6_k", 5120, 2304, 1),
+            ("q5_k", 13824, 1152, 1), ("q6_k", 13824, 1152, 1), ("q5_k", 5120, 13824, 2)]
+
+
+@pytest.mark.parametrize("wtype,K,rows,n_mat", RI_CASES)
+@pytest.mark.parametrize("N,with_res", [(1, False), (2, True), (3, False), (4, True)])
+def test_row_interleaved_mfma_matvec_matches_oracle(gpu_lib, wtype, K, rows, n_mat, N, with_res):
+    """The batched decode's mat-vec of round 5 (csrc/ri_kernels.hip: v_mfma_i32_4x4x4_16B_i8, lane = weight row, row-interleaved image built from the ordinary planes)
+    against the oracle's quantise + mul_mat: exact integer sub-block dots, the fp32 super-block terms of a K range added in order and the ranges in wave order -> 2e-5 of
+    the row maximum, the bar of every other mat-vec kernel; and agreement with the v_dot4 multi-row kernel (k_matvec_tn) on the same planes to that bar."""
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    t = Q.NAME_TO_TYPE[wtype]
+    rng = np.random.default_rng(K * 13 + rows + N * 5 + n_mat + sum(map(ord, wtype)))
+    w = (0.03 * rng.standard_normal((n_mat * rows, K))).astype(np.float32)
+    w[3, :] = 0.11                                            # a constant row: scales 0, mins maximal
+    raw = Q.quantize(t, w)
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    x[0, :min(K, 256)] = 0.0                                  # an all-zero activation block
+    if N > 1:
+        x[1] *= 37.0                                          # rows of very different magnitude: per-row scales
+    res = rng.standard_normal((n_mat, N, rows)).astype(np.float32) if with_res else None
+    got = gpu_lib.amd_test_matvec_ri(t, raw, n_mat, K, rows, x, res)
+    want = R.mul_mat(t, raw, K, n_mat * rows, x).reshape(N, n_mat, rows).transpose(1, 0, 2)
+    if res is not None:
+        want = want + res
+    assert got.shape == want.shape and np.isfinite(got).all()
+    scale = np.abs(want).max(axis=2, keepdims=True)
+    assert (np.abs(got - want) <= 2e-5 * scale).all(), (wtype, K, rows, N, float((np.abs(got - want) / scale).max()))
+
