@@ -498,6 +498,29 @@ def main():
                                          tokens_per_s_per_gpu_min=min((x["tokens_per_s_per_gpu"] for x in good), default=None),
                                          ms_per_step_max_over_ranks=max((x["ms_per_step"] for x in good), default=None),
                                          errors=[x["error"] for x in legs if "error" in x] or None) if legs else {"error": "no rank reported"}
+    # ---- extra leg: BASELINE.json configs[3]'s per-GPU share END TO END through the request server (minigpt4.cpp_amd/serve.py): 4 requests = one pass of the vision
+    # tower over 4 images + 4 system-prompt / image-turn prefills + batched decode of 64 tokens each (EOS ignored), own context; requests/s and tokens/s per replica
+    if args.conversations > 1 and rank == 0 and args.config == "13b":
+        try:
+            from minigpt4_cpp_amd import serve as S
+            nreq, ntok = 4, 64
+            srv = S.ReplicaServer(vp, lp, conversations=nreq, n_ctx=2048, n_batch=512, library=lib)
+            try:
+                reqs = [S.Request(G.synth_image(200 + i), PROMPT, ntok) for i in range(nreq)]
+                srv.run([S.Request(G.synth_image(7), PROMPT, 4)] * nreq, temp=0.0, ignore_eos=True)       # warm-up wave: graphs, code objects
+                lib.library.minigpt4_amd_sync(srv.ctx.ptr)
+                t0 = time.perf_counter()
+                ans = srv.run(reqs, temp=0.0, ignore_eos=True)
+                lib.library.minigpt4_amd_sync(srv.ctx.ptr)
+                dts = time.perf_counter() - t0
+                out["configs3_share_per_gpu"] = {"requests": nreq, "tokens_per_request": ntok, "wall_s": dts, "requests_per_s": nreq / dts, "tokens_per_s": nreq * ntok / dts,
+                                                 "answers_nonempty": int(all(len(a) > 0 for a in ans)),
+                                                 "workload": "4 image+prompt requests on ONE GPU through serve.ReplicaServer: encode 4 images in one pass, 4 prefills (142 rows each), "
+                                                             "64 batched greedy decode steps (BASELINE.json configs[3] = 8 such replicas)"}
+            finally:
+                srv.close()
+        except Exception as e:
+            out["configs3_share_per_gpu"] = {"error": str(e)[:300]}
     # ---- the bit-exact mode as a measured mode (MINIGPT4_PARITY / minigpt4_amd_set_parity: every fp32 accumulation in the CPU oracle's order; logits and greedy ids equal
     # the oracle's bit for bit -- asserted by `parity.parity_mode` below and tests/test_gpu_headline.py): same file, same prompt, 32 greedy steps through the C ABI
     try:

@@ -120,6 +120,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (const char *e = getenv("MINIGPT4_ATTN_SPLIT_T")) attn_split_t_ = atoi(e);   // cached keys from which the decode step uses the key-split attention (0 = never)
     n_cus_ = prop.multiProcessorCount;
     if (const char *e = getenv("MINIGPT4_MMQH")) set_mmqh(atoi(e));              // 1: Q4_K / Q5_K prompt rows on the fp16-MFMA form with scaled operands (k_mmqh_q45k: measured SLOWER, profiles/r05_prefill_fp16_scaled_operands.md; A/B)
+    if (const char *e = getenv("MINIGPT4_RI_FUSE")) ri_fuse_ = atoi(e) != 0;       // 1: the MFMA batched launches norm + quantise their rows themselves (measured SLOWER: 864 vs 987 tok/s at B = 4; A/B)
     if (const char *e = getenv("MINIGPT4_RI")) use_ri_ = atoi(e) != 0;             // 0: batched decode on the v_dot4 multi-row mat-vec (rounds 2-4), no row-interleaved image
     set_ri_cus(prop.multiProcessorCount);
     if (const char *e = getenv("MINIGPT4_QF_FOLD")) qf_fold_ = atoi(e) != 0;       // 0: the Q-Former's image-independent head is recomputed per encode (round-4 form, A/B)
@@ -898,6 +899,7 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
 // row as forward(1): per-row activation quantisation, exact integer block dots, the same attention kernel body.
 void Engine::forward_batch(int B, hipStream_t s) {
     pend_ = SlabSrc{}; xh_override_ = nullptr;
+    set_ri_workspace(ri_slabs_, ri_slab_floats_, ri_tickets_, ri_ticket_n_);   // this context's K-split workspace (null until build_ri_planes ran)
     const int E = (int)llm_.n_embd, F = (int)llm_.n_ff(), H = (int)llm_.n_head, hd = E / H, V = (int)llm_.n_vocab;
     const size_t C = (size_t)n_ctx_, seq_stride = layers_.size() * C * (size_t)E;
     // y_m[t][r] = W_m[r] . act[t] (+ res_m[t][r]) for n matrices that share the prepared rows.  Up to batch_rows_max_ rows go through the pipelined multi-row
@@ -913,6 +915,8 @@ void Engine::forward_batch(int B, hipStream_t s) {
         const QWeight *w0 = *Ws.begin();
         int groups = 0;
         for (const QWeight *w : Ws) { if (!ri_of(w) || w->type != w0->type || w->rows != w0->rows || w->cols != w0->cols) return false; groups += w->rows / 64; }
+        // (the K-split form of k_matvec_ri -- three or four workgroups share a row group of a long-K matrix, last arriver adds the parts -- brings the 13B w2 from 22.5 to
+        // 19.8 us (Q5_K) / 21.7 us (Q6_K) per launch at B = 4, and the whole step nowhere: 978 vs 988 tok/s, profiles/r05_batched_decode_inengine.log.  Not used.)
         return groups >= 128;
     };
     auto mm = [&](std::initializer_list<const QWeight *> Ws, std::initializer_list<float *> ys, const float *res0, int ld, const float *px = nullptr, const float *pw = nullptr) {
@@ -921,9 +925,9 @@ void Engine::forward_batch(int B, hipStream_t s) {
         int i = 0; for (const QWeight *w : Ws) W[i++] = w;
         i = 0; for (float *p : ys) { y[i] = p; r[i] = res0; i++; }
         bool same = true; for (int k = 1; k < n; k++) same = same && W[k]->type == W[0]->type && W[k]->rows == W[0]->rows && W[k]->cols == W[0]->cols;
-        if (!px && ri_serves(Ws)) {                         // (rows_pro() is false for such a set, so its rows were prepared by a standalone launch)
+        if (ri_serves(Ws) && (!px || pw)) {                 // prepared rows, or rows this launch rms-norms and quantises itself (px, pw)
             const RiPlanes *rp[3]; for (int k = 0; k < n; k++) rp[k] = ri_of(W[k]);
-            if (launch_matvec_ri(W, rp, y, res0 ? r : nullptr, n, act_, B, ld, s)) return;
+            if (launch_matvec_ri(W, rp, y, res0 ? r : nullptr, n, act_, B, ld, s, px, pw, W[0]->cols)) return;
         }
         if (same && B <= batch_rows_max_) {
             bool ok = true;
@@ -951,8 +955,8 @@ void Engine::forward_batch(int B, hipStream_t s) {
         // measured (profiles/r02j_batched_decode_ab.log): inside the launch the preparation pays at 2 rows (560 vs 540 tok/s) and loses at 4 (808 vs 829: every fat
         // workgroup repeats four rows' norm + quantisation); MINIGPT4_BATCH_FUSE=1 forces it for every B <= 4, =0 switches it off
         // plain = quantisation only (the attention output in front of wo: no norm, no double-precision sums): cheap enough to stay inside the launch at 3 and 4 rows too
+        if (ri_serves(Ws)) return !plain && ri_fuse_;      // the MFMA launch norms + quantises its rows itself (not the plain quantisation in front of wo: wo is not served)
         if (batch_fuse_ == 0 || B > batch_rows_max_ || B > 4 || (batch_fuse_ < 0 && B > 2 && !plain)) return false;
-        if (ri_serves(Ws)) return false;                  // the MFMA launch takes PREPARED rows: standalone preparation, then mm()
         const QWeight *w0 = *Ws.begin();
         for (const QWeight *w : Ws) if (w->type != w0->type || w->rows != w0->rows || w->cols != w0->cols) return false;
         return matvec_rows_prologue_ok(w0->type, w0->cols);
@@ -1009,8 +1013,11 @@ void Engine::forward_batch(int B, hipStream_t s) {
         launch_silu_mul_quant(h1_, h3_, B, F, act_, act_mask_for(L.w2.type), tabs_, s);
         mm({&L.w2}, {x_}, x_, E);
     }
-    prep_rms(x_, norm_, B, E, act_mask_for(output_.type), s);                 // (also combines the last layer's w2 slabs when its combine was deferred)
-    mm({&output_}, {blogits_}, nullptr, V);
+    if (B <= batch_rows_max_ && ri_fuse_ && ri_serves({&output_})) mm({&output_}, {blogits_}, nullptr, V, x_, norm_);   // final norm inside the output matrix's MFMA launch
+    else {
+        prep_rms(x_, norm_, B, E, act_mask_for(output_.type), s);             // (also combines the last layer's w2 slabs when its combine was deferred)
+        mm({&output_}, {blogits_}, nullptr, V);
+    }
     launch_batch_finish(blogits_, V, B, d_bslot_, d_npast_, d_argmax_, d_feed_, logits_, s);
 }
 
@@ -1217,7 +1224,10 @@ void Engine::build_ri_planes() {
     size_t total = 0;
     for (const QWeight *w : ws) { RiPlanes p; total += ri_plan(w->type, w->rows, w->cols, p, nullptr); }
     if (!total) return;
-    ri_arena_.alloc(total + 4096);
+    ri_slab_floats_ = (size_t)1 << 18; ri_ticket_n_ = 1024;
+    ri_arena_.alloc(total + ri_slab_floats_ * 4 + (size_t)ri_ticket_n_ * 4 + 8192);
+    ri_slabs_ = reinterpret_cast<float *>(ri_arena_.take(ri_slab_floats_ * 4)); ri_tickets_ = reinterpret_cast<unsigned *>(ri_arena_.take((size_t)ri_ticket_n_ * 4));
+    HIP_CHECK(hipMemset(ri_tickets_, 0, (size_t)ri_ticket_n_ * 4));
     for (const QWeight *w : ws) {
         RiPlanes p; const size_t need = ri_plan(w->type, w->rows, w->cols, p, nullptr);
         if (!need) continue;

@@ -171,8 +171,9 @@ private:
     int batch_rows_max_ = 4; int batch_fuse_ = -1; int n_cus_ = 256;
     // round 5: B = 2..4 rows per weight pass on the int8 matrix cores over a row-interleaved second image of the k-quant matrices (ri_kernels.hip); built by
     // set_conversations(n > 1) -- a context with one conversation never pays the memory.  MINIGPT4_RI=0: the v_dot4 multi-row mat-vec of rounds 2-4 (A/B)
-    bool use_ri_ = true, ri_ready_ = false;
+    bool use_ri_ = true, ri_ready_ = false, ri_fuse_ = false;   // ri_fuse_: rows prepared inside the MFMA launches -- measured slower (profiles/r05_batched_decode_inengine.log), off
     DeviceArena ri_arena_;
+    float *ri_slabs_ = nullptr; size_t ri_slab_floats_ = 0; unsigned *ri_tickets_ = nullptr; int ri_ticket_n_ = 0;   // K-split workspace of k_matvec_ri (zeroed tickets)
     std::vector<std::pair<const QWeight *, RiPlanes>> ri_map_;
     const RiPlanes *ri_of(const QWeight *w) const { for (const auto &e : ri_map_) if (e.first == w) return &e.second; return nullptr; }
     void build_ri_planes();

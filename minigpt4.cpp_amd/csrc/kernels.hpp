@@ -85,8 +85,14 @@ bool matvec_rows_prologue_ok(int type, int K);
 bool ri_supported(int type, int rows, int cols);
 size_t ri_plan(int type, int rows, int cols, RiPlanes &p, uint8_t *base);      // assigns the image's plane pointers from `base` (nullptr: sizes only), returns the bytes used
 void launch_ri_build(const QWeight &w, const RiPlanes &p, hipStream_t s);      // ordinary planes -> row-interleaved image
-bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s);
+bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s,
+                      const float *px = nullptr, const float *pw = nullptr, int ldx = 0);   // px != null: rows t of px (stride ldx) are rms-normed with pw and quantised inside the launch (A unused)
 void set_ri_cus(int cus);
+// workspace of the K-split form (few row groups, long K: the 13B w2): slabs for the workgroups' partial sums and one arrival ticket per row group, ZEROED by the caller (the kernel
+// leaves them zero); without it such sets run one workgroup per group.  One workspace per process: contexts of one process share a stream order per context, launches of two
+// contexts on different streams must not run this form concurrently (the engine sets it per context before capturing / launching a batched step)
+void set_ri_workspace(float *slabs, size_t slab_floats, unsigned *tickets, int n_tickets);
+int ri_ksplit(int total_groups, int K);
 // two k-quant types (Q4_K|Q5_K + Q6_K) with the same K in one launch; pro: 0 or 1 (rms_norm prologue)
 bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, hipStream_t s, int pro = 0,
                          const float *px = nullptr, const float *pw = nullptr, int epi = 0);

@@ -2677,6 +2677,8 @@ __global__ __launch_bounds__(64) void k_argmax_final(const float *__restrict__ p
     argmax_wave(best, bi);
     if (threadIdx.x == 0) *out = bi == 0x7FFFFFFF ? 0 : bi;
 }
+// (Round 5 measured argmax + advance as ONE launch -- last-arriving workgroup reduces the partial maxima and advances the position: 374.1 vs 374.4 tok/s, no difference;
+// removed again, profiles/r05_experiments_not_adopted.md.)
 // first maximum wins, like llama_sample_token_greedy.  `scratch` holds AM_BLOCKS floats + AM_BLOCKS ints.
 void launch_argmax(const float *logits, int n, int *out, void *scratch, hipStream_t s) {
     note_kernel("k_argmax_part"); note_kernel("k_argmax_final");

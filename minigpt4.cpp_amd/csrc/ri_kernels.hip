@@ -17,6 +17,7 @@
 //   Q6_K: weights enter as their unsigned 6-bit codes; the -32 offset is sum_g sc_g * bsum16_g, eight MFMAs per super-block on the digit split of the 16-element sums.
 #include "kernels.hpp"
 #include "devutil.hpp"
+#include "qtraits.hpp"
 
 #include <algorithm>
 
@@ -69,7 +70,10 @@ void launch_ri_build(const QWeight &w, const RiPlanes &p, hipStream_t s) {
 
 // ---- the kernel ----------------------------------------------------------------------------------------------------------------------------------------
 struct RiMat { RiPlanes p; float *y; const float *res; };
-struct RiArgs { RiMat m[3]; int n_mat, groups_each, rows_each, K, N, ldy; };
+struct RiArgs { RiMat m[3]; int n_mat, groups_each, rows_each, K, N, ldy; const float *px, *pw; int ldx;
+                // ksplit > 1 (matrices with few row groups and a long K: the 13B w2 has 80 groups x 54 super-blocks): `ksplit` workgroups share a row group, each a contiguous
+                // K range; their partial sums go to `slabs` [group][part][4][64] and the LAST one to arrive (ticket per group, self-resetting) adds them in part order
+                int ksplit; float *slabs; unsigned *tickets; };   // px: rows prepared inside the launch (PRO): rms_norm(px_t) * pw, quantised
 
 __device__ __forceinline__ void ri_scale_min_words(const v4i_r &h, unsigned &scw0, unsigned &scw1, unsigned &mw0, unsigned &mw1) {
     const unsigned s0 = (unsigned)h[1], s1 = (unsigned)h[2], s2 = (unsigned)h[3];
@@ -82,7 +86,10 @@ __device__ __forceinline__ float ri_h2f(unsigned short h) { return __half2float(
 //   DG = 16 (Q4_K / Q5_K): the quantiser's digit-split per-32 sums (bytes 0..7 low digits of sub-blocks 0..7, 8..15 high digits)
 //   DG = 32 (Q6_K): the 16-element sums of the super-block in the ORDER OF THE SCALE BYTES (unit i = (n, c, h): byte 2 i <-> group 8 n + 2 c + h, byte 2 i + 1 <-> that + 4),
 //                   bytes 0..15 low digits (s & 127), 16..31 high digits (s >> 7)
-template <int T, int WPB>
+// PRO: the rows are prepared inside the launch -- rms_norm(x_t) * w (ggml_rms_norm: fp32 squares summed in double, eps 1e-6) and ggml's Q8_K quantisation, the arithmetic of
+// k_rms_quant -- by every workgroup into its own LDS image (the image is needed there anyway): one standalone preparation launch less in front of wq|wk|wv, w1|w3 and the
+// output matrix (~5 us each against ~1 us of redundant work per workgroup).
+template <int T, int WPB, bool PRO>
 __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const ActQ A) {
     constexpr bool Q6 = T == GT_Q6_K, Q5 = T == GT_Q5_K;
     constexpr int DG = Q6 ? 32 : 16;
@@ -93,14 +100,64 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
     int8_t *dg = q8 + 4 * K;
     float *dk = reinterpret_cast<float *>(dg + 4 * NSB * DG);
     float *red = dk + 4 * NSB;
-    for (int i = threadIdx.x * 16; i < 4 * K; i += 64 * WPB * 16) {
-        const int t = i / K;
+    int16_t *bsl = reinterpret_cast<int16_t *>(red + WPB * 4 * 64);       // PRO: the rows' 16-element sums [4][K / 16] (quantiser output; Q6_K's digit image is derived from them)
+    if constexpr (PRO) {
+        constexpr int NT = 64 * WPB;
+        ActQ L{}; L.q8k = q8; L.dk = dk; L.bsk = bsl; L.bsq = Q6 ? nullptr : dg;
+        double *redd = reinterpret_cast<double *>(red);
+        for (int t = 0; t < 4; t++) {
+            if (t < N) {                                                      // workgroup-uniform
+                const float *xr = a.px + (size_t)t * a.ldx;
+                double sum = 0.0;
+                for (int i = threadIdx.x * 4; i < K; i += NT * 4) { const float4 v = *reinterpret_cast<const float4 *>(xr + i);
+                    double q = 0.0; q += (double)(v.x * v.x); q += (double)(v.y * v.y); q += (double)(v.z * v.z); q += (double)(v.w * v.w); sum += q; }
+                sum = wave_sum_d(sum);
+                if (lane == 0) redd[wv] = sum;
+                __syncthreads();
+                double tot = 0.0;
+                for (int w = 0; w < WPB; w++) tot += redd[w];
+                __syncthreads();
+                const float scale = 1.0f / sqrtf((float)(tot / (double)K) + 1e-6f);
+                for (int i0 = 0; i0 < K; i0 += NT * 4) {                      // whole waves per 256-block (K is a multiple of 256): the Q8_K emission is a wave-level operation
+                    const int i = i0 + threadIdx.x * 4; const bool in = i < K; const int ic = in ? i : 0;
+                    const float4 xv = *reinterpret_cast<const float4 *>(xr + ic), wv4 = *reinterpret_cast<const float4 *>(a.pw + ic);
+                    float v[4] = {(xv.x * scale) * wv4.x, (xv.y * scale) * wv4.y, (xv.z * scale) * wv4.z, (xv.w * scale) * wv4.w};
+                    if (!in) { v[0] = 0.0f; v[1] = 0.0f; v[2] = 0.0f; v[3] = 0.0f; }
+                    if (i0 + (int)(threadIdx.x & ~63) * 4 < K) quant_emit4(v, in, i, (size_t)t, K, L, ACT_Q8K);   // (wave-uniform condition: a wave entirely past the row skips)
+                }
+            } else {
+                for (int i = threadIdx.x * 16; i < K; i += NT * 16) { const v4i_r z = {0, 0, 0, 0}; *reinterpret_cast<v4i_r *>(q8 + (size_t)t * K + i) = z; }
+                for (int i = threadIdx.x; i < NSB; i += NT) { dk[t * NSB + i] = 0.0f; if (!Q6) { const v4i_r z = {0, 0, 0, 0}; *reinterpret_cast<v4i_r *>(dg + (size_t)(t * NSB + i) * 16) = z; } }
+                for (int i = threadIdx.x; i < K / 16; i += NT) bsl[t * (K / 16) + i] = 0;
+            }
+        }
+        __syncthreads();
+        if (Q6) {
+            for (int i = threadIdx.x; i < 4 * NSB; i += NT) {
+                const int t = i / NSB, sb = i - t * NSB;
+                int8_t *o = dg + (size_t)i * 32;
+#pragma unroll
+                for (int ui = 0; ui < 8; ui++) {
+                    const int n = ui >> 2, c = (ui >> 1) & 1, h = ui & 1, grp = 8 * n + 2 * c + h;
+                    const int s_lo = (int)bsl[t * (K / 16) + sb * 16 + grp], s_hi = (int)bsl[t * (K / 16) + sb * 16 + grp + 4];
+                    o[2 * ui] = (int8_t)(s_lo & 127); o[2 * ui + 1] = (int8_t)(s_hi & 127); o[16 + 2 * ui] = (int8_t)(s_lo >> 7); o[16 + 2 * ui + 1] = (int8_t)(s_hi >> 7);
+                }
+            }
+        }
+    } else {
+    // a workgroup that serves exactly ONE task of the K-split form copies only that task's K range (320 workgroups each copying the 55 KB image of a K = 13824 row set
+    // would move more bytes than a third of the weights)
+    int c_sb0 = 0, c_sb1 = NSB;
+    if (a.ksplit > 1 && (int)gridDim.x >= a.n_mat * a.groups_each * a.ksplit) { const int part = (int)blockIdx.x % a.ksplit; c_sb0 = (int)((long long)NSB * part / a.ksplit); c_sb1 = (int)((long long)NSB * (part + 1) / a.ksplit); }
+    const int cK = (c_sb1 - c_sb0) * 256;
+    for (int i = threadIdx.x * 16; i < 4 * cK; i += 64 * WPB * 16) {
+        const int t = i / cK, e = c_sb0 * 256 + (i - t * cK);
         v4i_r v = {0, 0, 0, 0};
-        if (t < N) v = *reinterpret_cast<const v4i_r *>(A.q8k + (size_t)t * K + (i - t * K));
-        *reinterpret_cast<v4i_r *>(q8 + i) = v;
+        if (t < N) v = *reinterpret_cast<const v4i_r *>(A.q8k + (size_t)t * K + e);
+        *reinterpret_cast<v4i_r *>(q8 + (size_t)t * K + e) = v;
     }
-    for (int i = threadIdx.x; i < 4 * NSB; i += 64 * WPB) {
-        const int t = i / NSB, sb = i - t * NSB;
+    for (int i0 = threadIdx.x; i0 < 4 * (c_sb1 - c_sb0); i0 += 64 * WPB) {
+        const int t = i0 / (c_sb1 - c_sb0), sb = c_sb0 + (i0 - t * (c_sb1 - c_sb0)), i = t * NSB + sb;
         float d = 0.0f;
         if (!Q6) {
             v4i_r v = {0, 0, 0, 0};
@@ -118,13 +175,18 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
         }
         dk[i] = d;
     }
+    }
     __syncthreads();
-    const int sb_per = (NSB + WPB - 1) / WPB, sb0 = wv * sb_per, sb1 = min(NSB, sb0 + sb_per);
+    const int S = a.ksplit > 1 ? a.ksplit : 1;
+    __shared__ int s_last;
     const int8_t *qa = q8 + (size_t)t4 * K;
     const int8_t *da = dg + (size_t)t4 * NSB * DG;
     struct Raw { v4i_r q[8]; unsigned p[Q6 ? 16 : (Q5 ? 8 : 1)]; v4i_r h; unsigned short d; };
     const int total_groups = a.n_mat * a.groups_each;
-    for (int g = blockIdx.x; g < total_groups; g += gridDim.x) {
+    for (int task = blockIdx.x; task < total_groups * S; task += gridDim.x) {
+        const int g = task / S, part = task - g * S;
+        const int psb0 = (int)((long long)NSB * part / S), psb1 = (int)((long long)NSB * (part + 1) / S);       // this workgroup's K range
+        const int sb_per = (psb1 - psb0 + WPB - 1) / WPB, sb0 = psb0 + wv * sb_per, sb1 = min(psb1, sb0 + sb_per);
         const int m = g / a.groups_each, gl = g - m * a.groups_each;
         const RiMat &M = a.m[m];
         const uint8_t *pq = M.p.qs + (size_t)gl * U * 1024 + lane * 16, *pp = M.p.qh + (size_t)gl * U * (Q6 ? 512 : 256) + lane * (Q6 ? 8 : 4), *ph = M.p.sc + (size_t)gl * NSB * 1024 + lane * 16,
@@ -210,13 +272,32 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
 #pragma unroll
         for (int t = 0; t < 4; t++) red[(wv * 4 + t) * 64 + lane] = acc[t];
         __syncthreads();
+        float s = 0.0f;
         if (wv < N) {
-            const int t = wv;
-            float s = red[t * 64 + lane];
+            s = red[wv * 64 + lane];
 #pragma unroll
-            for (int w = 1; w < WPB; w++) s += red[(w * 4 + t) * 64 + lane];
-            const size_t o = (size_t)t * a.ldy + (size_t)gl * 64 + lane;
-            M.y[o] = M.res ? s + M.res[o] : s;
+            for (int w = 1; w < WPB; w++) s += red[(w * 4 + wv) * 64 + lane];
+        }
+        if (S == 1) {
+            if (wv < N) { const size_t o = (size_t)wv * a.ldy + (size_t)gl * 64 + lane; M.y[o] = M.res ? s + M.res[o] : s; }
+        } else {
+            // hand-off without cache maintenance (a release / acquire FENCE writes back and invalidates the whole L2 of the XCD -- measured: 78 us instead of 22 for the 13B w2,
+            // the weight stream of every other workgroup loses its lines): the partial sums are agent-scope (write-through, sc1) stores, drained with vmcnt(0) before the
+            // ticket; the last arriver reads them with agent-scope (cache-bypassing) loads
+            if (wv < N) __hip_atomic_store(a.slabs + ((size_t)task * 4 + wv) * 64 + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(a.tickets + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(S - 1);
+            __syncthreads();
+            if (s_last) {                                      // workgroup-uniform: the last of the group's S workgroups adds the parts in part order (deterministic)
+                if (wv < N) {
+                    float tot = 0.0f;
+                    for (int p = 0; p < S; p++) tot += __hip_atomic_load(a.slabs + (((size_t)g * S + p) * 4 + wv) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const size_t o = (size_t)wv * a.ldy + (size_t)gl * 64 + lane;
+                    M.y[o] = M.res ? tot + M.res[o] : tot;
+                }
+                if (threadIdx.x == 0) __hip_atomic_store(a.tickets + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
+            }
         }
         __syncthreads();
     }
@@ -224,35 +305,49 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
 
 static int g_ri_cus = 256;
 void set_ri_cus(int cus) { if (cus > 0) g_ri_cus = cus; }
-static size_t ri_lds(int type, int K, int wpb) { const int NSB = K / 256; return (size_t)4 * K + (size_t)4 * NSB * (type == GT_Q6_K ? 32 : 16) + (size_t)4 * NSB * 4 + (size_t)wpb * 4 * 64 * 4; }
+static size_t ri_lds(int type, int K, int wpb, bool pro) { const int NSB = K / 256; return (size_t)4 * K + (size_t)4 * NSB * (type == GT_Q6_K ? 32 : 16) + (size_t)4 * NSB * 4 + (size_t)wpb * 4 * 64 * 4 + (pro ? (size_t)4 * (K / 16) * 2 : 0); }
+template <int T, int WPB, bool PRO>
+static void launch_ri_k(const RiArgs &a, const ActQ &A, unsigned blocks, size_t lds, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { HIP_IGNORE(lds_optin_max(&k_matvec_ri<T, WPB, PRO>)); attr = true; }
+    hipLaunchKernelGGL((k_matvec_ri<T, WPB, PRO>), dim3(blocks), dim3(64 * WPB), lds, s, a, A);
+}
 template <int T>
 static bool launch_ri_t(const RiArgs &a, const ActQ &A, hipStream_t s) {
     const int total = a.n_mat * a.groups_each;
     // 4 waves per workgroup (each a K quarter), two workgroups per CU; matrices with fewer 64-row groups than CUs (wo, w2: 80 groups at the 13B width) split K over 8 waves
-    const bool wide = total < g_ri_cus;
-    const size_t lds = ri_lds(T, a.K, wide ? 8 : 4);
+    const bool wide = total < g_ri_cus && a.ksplit <= 1, pro = a.px != nullptr;
+    const size_t lds = ri_lds(T, a.K, wide ? 8 : 4, pro);
     if (lds > (wide ? 150u : 78u) * 1024u) return false;
-    static bool attr[2] = {false, false};
-    if (wide) {
-        if (!attr[1]) { HIP_IGNORE(lds_optin_max(&k_matvec_ri<T, 8>)); attr[1] = true; }
-        hipLaunchKernelGGL((k_matvec_ri<T, 8>), dim3((unsigned)std::min(total, g_ri_cus)), dim3(512), lds, s, a, A);
-    } else {
-        if (!attr[0]) { HIP_IGNORE(lds_optin_max(&k_matvec_ri<T, 4>)); attr[0] = true; }
-        hipLaunchKernelGGL((k_matvec_ri<T, 4>), dim3((unsigned)std::min(total, 2 * g_ri_cus)), dim3(256), lds, s, a, A);
-    }
+    if (wide) { const unsigned nb = (unsigned)std::min(total, g_ri_cus); if (pro) launch_ri_k<T, 8, true>(a, A, nb, lds, s); else launch_ri_k<T, 8, false>(a, A, nb, lds, s); }
+    else { const unsigned nb = (unsigned)std::min(total * std::max(1, a.ksplit), 2 * g_ri_cus); if (pro) launch_ri_k<T, 4, true>(a, A, nb, lds, s); else launch_ri_k<T, 4, false>(a, A, nb, lds, s); }
     return true;
 }
 // y[m][t * ldy + r] = W_m[r] . act[t] (+ residual[m][t * ldy + r]) for N = 1..4 prepared rows (A: Q8_K image incl. bsq) against 1..3 same-type, same-shape k-quant matrices
 // that carry their row-interleaved image (ri[k]); false -> outside this kernel's range, nothing launched
-bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s) {
-    if (n < 1 || n > 3 || N < 1 || N > 4 || !A.q8k || !A.dk || !A.bsk || !A.bsq) return false;
+static float *g_ri_slabs = nullptr; static unsigned *g_ri_tickets = nullptr; static size_t g_ri_slab_floats = 0; static int g_ri_ticket_n = 0;
+void set_ri_workspace(float *slabs, size_t slab_floats, unsigned *tickets, int n_tickets) { g_ri_slabs = slabs; g_ri_slab_floats = slab_floats; g_ri_tickets = tickets; g_ri_ticket_n = n_tickets; }
+// K split over workgroups for a set with few row groups and a long K (ri_kernels.hip header): parts of >= 8 super-blocks (two per wave), at most 4, only when the workspace is set
+int ri_ksplit(int total_groups, int K) {
+    const int NSB = K / 256;
+    if (!g_ri_slabs || total_groups >= g_ri_cus / 2 || total_groups > g_ri_ticket_n) return 1;
+    int S = std::min(4, std::min(NSB / 8, 2 * g_ri_cus / std::max(1, total_groups)));
+    while (S > 1 && (size_t)total_groups * S * 256 > g_ri_slab_floats) S--;
+    return std::max(1, S);
+}
+bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s,
+                      const float *px, const float *pw, int ldx) {
+    if (n < 1 || n > 3 || N < 1 || N > 4) return false;
+    if (px ? (!pw || ldx < W[0]->cols) : (!A.q8k || !A.dk || !A.bsk || !A.bsq)) return false;
     RiArgs a{};
+    a.px = px; a.pw = pw; a.ldx = ldx;
     for (int i = 0; i < n; i++) {
         if (!ri[i] || !ri[i]->qs || W[i]->type != W[0]->type || W[i]->rows != W[0]->rows || W[i]->cols != W[0]->cols) return false;
         a.m[i].p = *ri[i]; a.m[i].y = y[i]; a.m[i].res = residual ? residual[i] : nullptr;
     }
     if (!ri_supported(W[0]->type, W[0]->rows, W[0]->cols)) return false;
     a.n_mat = n; a.groups_each = W[0]->rows / 64; a.rows_each = W[0]->rows; a.K = W[0]->cols; a.N = N; a.ldy = ldy;
+    a.ksplit = ri_ksplit(n * a.groups_each, a.K); a.slabs = g_ri_slabs; a.tickets = g_ri_tickets;
     switch (W[0]->type) {
     case GT_Q4_K: return launch_ri_t<GT_Q4_K>(a, A, s);
     case GT_Q5_K: return launch_ri_t<GT_Q5_K>(a, A, s);

@@ -209,7 +209,7 @@ int minigpt4_amd_test_matvec_rows(int ggml_type, const void *raw_w, int n_mat, i
 
 // The batched decode's MFMA launch (ri_kernels.hip): n_mat equally shaped k-quant matrices (rows of raw_w back to back) as ordinary planes -> row-interleaved image -> N = 1..4
 // prepared rows; y [n_mat][N][n_out].  4: the kernel refuses the shape / type.
-int minigpt4_amd_test_matvec_ri(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int N, const float *residual, float *y) {
+int minigpt4_amd_test_matvec_ri(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int N, const float *residual, const float *rms_w, float *y) {
     if (!raw_w || !x || !y || n_in <= 0 || n_out <= 0 || n_mat < 1 || n_mat > 3 || N < 1 || N > 4 || !qweight_supported(ggml_type) || n_in % gt_block(ggml_type)) return 1;
     if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
     return guarded(3, [&]() -> int {
@@ -231,11 +231,18 @@ int minigpt4_amd_test_matvec_ri(int ggml_type, const void *raw_w, int n_mat, int
         if (residual) HIP_CHECK(hipMemcpy(d_res.p, residual, (size_t)n_mat * N * R * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemset(d_y.p, 0xFF, (size_t)n_mat * N * R * 4));
         ActQ A; std::vector<std::unique_ptr<DevBuf>> keep; alloc_act(A, keep, (size_t)N, (size_t)K);
-        launch_rms_quant(d_x.as<float>(), nullptr, N, K, A, ACT_Q8K, nullptr);
+        DevBuf d_w((size_t)K * 4);
+        if (rms_w) HIP_CHECK(hipMemcpy(d_w.p, rms_w, (size_t)K * 4, hipMemcpyHostToDevice));
+        else launch_rms_quant(d_x.as<float>(), nullptr, N, K, A, ACT_Q8K, nullptr);                   // rms_w given: the launch norms + quantises the rows itself
         const QWeight *Wp[3]; const RiPlanes *Pp[3]; float *Yp[3]; const float *Rp[3];
         for (int m = 0; m < n_mat; m++) { Wp[m] = &W[(size_t)m]; Pp[m] = &P[(size_t)m]; Yp[m] = d_y.as<float>() + (size_t)m * N * R; Rp[m] = d_res.as<float>() + (size_t)m * N * R; }
         hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0)); set_ri_cus(prop.multiProcessorCount);
-        if (!launch_matvec_ri(Wp, Pp, Yp, residual ? Rp : nullptr, n_mat, A, N, R, nullptr)) { set_last_error("launch_matvec_ri refused"); return 4; }
+        DevBuf d_ws(((size_t)1 << 18) * 4 + 4096);                           // K-split workspace (few groups, long K): slabs + zeroed tickets
+        HIP_CHECK(hipMemset(d_ws.p, 0, ((size_t)1 << 18) * 4 + 4096));
+        struct WsScope { WsScope(float *sl, unsigned *tk) { set_ri_workspace(sl, (size_t)1 << 18, tk, 1024); } ~WsScope() { set_ri_workspace(nullptr, 0, nullptr, 0); } } ws_scope(d_ws.as<float>(), reinterpret_cast<unsigned *>(d_ws.as<float>() + ((size_t)1 << 18)));
+        if (!launch_matvec_ri(Wp, Pp, Yp, residual ? Rp : nullptr, n_mat, A, N, R, nullptr, rms_w ? d_x.as<float>() : nullptr, rms_w ? d_w.as<float>() : nullptr, K)) { set_last_error("launch_matvec_ri refused"); return 4; }
+        HIP_CHECK(hipDeviceSynchronize());
+        if (!launch_matvec_ri(Wp, Pp, Yp, residual ? Rp : nullptr, n_mat, A, N, R, nullptr, rms_w ? d_x.as<float>() : nullptr, rms_w ? d_w.as<float>() : nullptr, K)) { set_last_error("launch_matvec_ri refused"); return 4; }   // twice: the tickets must be back at zero
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemcpy(y, d_y.p, (size_t)n_mat * N * R * 4, hipMemcpyDeviceToHost));
         return 0;
@@ -268,6 +275,10 @@ int minigpt4_amd_bench_matvec_ri(int ggml_type, int rows, int cols, int n_mat, i
         DevBuf dx((size_t)N * cols * 4), dy((size_t)rows * 4 * 3 * N);
         { std::vector<float> hx((size_t)N * cols); for (size_t i = 0; i < hx.size(); i++) hx[i] = (float)((int)(i * 37 % 201) - 100) / 64.0f; HIP_CHECK(hipMemcpy(dx.p, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); }
         launch_rms_quant(dx.as<float>(), nullptr, N, cols, A, ACT_Q8K, nullptr);
+        DevBuf d_ws(((size_t)1 << 18) * 4 + 4096);
+        HIP_CHECK(hipMemset(d_ws.p, 0, ((size_t)1 << 18) * 4 + 4096));
+        struct WsScope { WsScope(float *sl, unsigned *tk, bool on) { if (on) set_ri_workspace(sl, (size_t)1 << 18, tk, 1024); } ~WsScope() { set_ri_workspace(nullptr, 0, nullptr, 0); } }
+            ws_scope(d_ws.as<float>(), reinterpret_cast<unsigned *>(d_ws.as<float>() + ((size_t)1 << 18)), !getenv("MG4_RI_NOSPLIT"));
         auto run = [&](int set) {
             const QWeight *Wp[3]; const RiPlanes *Pp[3]; float *Yp[3];
             for (int m = 0; m < n_mat; m++) { Wp[m] = &W[(size_t)set * n_mat + m]; Pp[m] = &P[(size_t)set * n_mat + m]; Yp[m] = dy.as<float>() + (size_t)m * rows * N; }

@@ -460,15 +460,18 @@ class MiniGPT4SharedLibrary:
             raise RuntimeError(f"test_matvec_rows rc={rc}: " + self.library.minigpt4_amd_last_error().decode())
         return y
 
-    def amd_test_matvec_ri(self, ggml_type: int, raw_w: np.ndarray, n_mat: int, n_in: int, n_out: int, x: np.ndarray, residual: Optional[np.ndarray] = None) -> np.ndarray:
+    def amd_test_matvec_ri(self, ggml_type: int, raw_w: np.ndarray, n_mat: int, n_in: int, n_out: int, x: np.ndarray, residual: Optional[np.ndarray] = None,
+                           rms_w: Optional[np.ndarray] = None) -> np.ndarray:
         """The batched decode's MFMA launch over the row-interleaved image (csrc/ri_kernels.hip): x [N][n_in] (N <= 4) -> [n_mat][N][n_out]."""
         x = np.ascontiguousarray(x, np.float32).reshape(-1, n_in)
         raw_w = np.ascontiguousarray(raw_w)
         res = None if residual is None else np.ascontiguousarray(residual, np.float32)
         y = np.empty((n_mat, x.shape[0], n_out), np.float32)
         f = self.library.minigpt4_amd_test_matvec_ri
-        f.argtypes = [I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, I32, FLOAT_PTR, FLOAT_PTR]
-        rc = f(ggml_type, raw_w.ctypes.data_as(VOID_PTR), n_mat, n_in, n_out, x.ctypes.data_as(FLOAT_PTR), x.shape[0], None if res is None else res.ctypes.data_as(FLOAT_PTR), y.ctypes.data_as(FLOAT_PTR))
+        f.argtypes = [I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, I32, FLOAT_PTR, FLOAT_PTR, FLOAT_PTR]
+        w = None if rms_w is None else np.ascontiguousarray(rms_w, np.float32)
+        rc = f(ggml_type, raw_w.ctypes.data_as(VOID_PTR), n_mat, n_in, n_out, x.ctypes.data_as(FLOAT_PTR), x.shape[0], None if res is None else res.ctypes.data_as(FLOAT_PTR),
+               None if w is None else w.ctypes.data_as(FLOAT_PTR), y.ctypes.data_as(FLOAT_PTR))
         if rc:
             raise RuntimeError(f"test_matvec_ri rc={rc}: " + self.library.minigpt4_amd_last_error().decode())
         return y

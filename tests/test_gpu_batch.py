@@ -292,4 +292,19 @@ def test_row_interleaved_mfma_matvec_matches_oracle(gpu_lib, wtype, K, rows, n_m
     assert got.shape == want.shape and np.isfinite(got).all()
     scale = np.abs(want).max(axis=2, keepdims=True)
     assert (np.abs(got - want) <= 2e-5 * scale).all(), (wtype, K, rows, N, float((np.abs(got - want) / scale).max()))
+    # the same launch preparing its rows itself: rms_norm(x_t) * w (ggml: fp32 squares summed in double, eps 1e-6) + Q8_K quantisation inside every workgroup
+    if K >= 512:
+        nw = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float32)
+        rows_n = np.empty_like(x)
+        for ti in range(N):
+            ssq = np.float64(0)
+            for v in x[ti]:
+                ssq += np.float64(np.float32(v * v))
+            rows_n[ti] = (x[ti] * (np.float32(1.0) / np.sqrt(np.float32(np.float32(ssq / K) + np.float32(1e-6)), dtype=np.float32))) * nw
+        got2 = gpu_lib.amd_test_matvec_ri(t, raw, n_mat, K, rows, x, res, rms_w=nw)
+        want2 = R.mul_mat(t, raw, K, n_mat * rows, rows_n).reshape(N, n_mat, rows).transpose(1, 0, 2)
+        if res is not None:
+            want2 = want2 + res
+        scale2 = np.abs(want2).max(axis=2, keepdims=True)
+        assert np.isfinite(got2).all() and (np.abs(got2 - want2) <= 2e-5 * scale2).all(), (wtype, K, rows, N, float((np.abs(got2 - want2) / scale2).max()))
 
