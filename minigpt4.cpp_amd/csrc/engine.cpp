@@ -119,7 +119,9 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     batch_mix_ = !(getenv("MINIGPT4_BATCH_MIX") && atoi(getenv("MINIGPT4_BATCH_MIX")) == 0);                 // 0: wq|wk and wv of a mixed-type layer as two launches (batched step)
     if (const char *e = getenv("MINIGPT4_ATTN_SPLIT_T")) attn_split_t_ = atoi(e);   // cached keys from which the decode step uses the key-split attention (0 = never)
     n_cus_ = prop.multiProcessorCount;
-    if (const char *e = getenv("MINIGPT4_MMQH")) set_mmqh(atoi(e));              // 1: Q4_K / Q5_K prompt rows on the fp16-MFMA form with scaled operands (k_mmqh_q45k: measured SLOWER, profiles/r05_prefill_fp16_scaled_operands.md; A/B)
+    // 1: Q4_K / Q5_K prompt rows on the fp16-MFMA form with scaled operands (k_mmqh_q45k: measured SLOWER, profiles/r05_prefill_fp16_scaled_operands.md; A/B)
+    if (const char *e = getenv("MINIGPT4_MMQH")) set_mmqh(atoi(e));
+    if (const char *e = getenv("MINIGPT4_COMPUTED_TABLES")) computed_tables_ = atoi(e) != 0;   // 0: the decode step gathers exp / SiLU from ggml's fp16 tables like rounds 1-4 (A/B)
     if (const char *e = getenv("MINIGPT4_RI_FUSE")) ri_fuse_ = atoi(e) != 0;       // 1: the MFMA batched launches norm + quantise their rows themselves (measured SLOWER: 864 vs 987 tok/s at B = 4; A/B)
     if (const char *e = getenv("MINIGPT4_RI")) use_ri_ = atoi(e) != 0;             // 0: batched decode on the v_dot4 multi-row mat-vec (rounds 2-4), no row-interleaved image
     set_ri_cus(prop.multiProcessorCount);
@@ -280,8 +282,13 @@ int Engine::load_llm(const std::string &path) {
     if (!attn_head_size_supported(hd)) { set_last_error("unsupported head size (supported: 32, 64, 128)"); return E_LoadLanguageModel; }
     // k_attn_llm keeps one fp32 score + one fp16 probability per key of the context in LDS (6 bytes per key, 160 KiB per workgroup): refuse what cannot launch
     if (parity_) attn_ref_prepare();
-    if (parity_ && n_ctx_ > attn_ref_max_ctx(hd)) { set_last_error("MINIGPT4_PARITY: n_ctx " + std::to_string(n_ctx_) + " exceeds what the oracle-order attention kernel's LDS rows hold (" + std::to_string(attn_ref_max_ctx(hd)) + ")"); MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
-    if (n_ctx_ > attn_max_ctx(hd)) { set_last_error("n_ctx " + std::to_string(n_ctx_) + " exceeds what the attention kernel's LDS score buffer holds (" + std::to_string(attn_max_ctx(hd)) + ")"); MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
+    auto ctx_too_long = [&](const char *which, int lim) {
+        set_last_error(std::string(which) + "n_ctx " + std::to_string(n_ctx_) + " exceeds what the attention kernel's LDS score rows hold (" + std::to_string(lim) + ")");
+        MG4_ERR("%s", last_error().c_str());
+        return (int)E_LoadLanguageModel;
+    };
+    if (parity_ && n_ctx_ > attn_ref_max_ctx(hd)) return ctx_too_long("MINIGPT4_PARITY (oracle-order kernel): ", attn_ref_max_ctx(hd));
+    if (n_ctx_ > attn_max_ctx(hd)) return ctx_too_long("", attn_max_ctx(hd));
     MG4_INFO("llm: n_vocab %d n_embd %d n_head %u n_layer %d n_ff %d n_ctx %d", V, E, llm_.n_head, L, F, n_ctx_);
     auto need = [&](const std::string &name, int64_t ne0, int64_t ne1) -> const TensorMeta * {
         const TensorMeta *t = llm_.find(name);
@@ -520,7 +527,8 @@ void Engine::alloc_buffers() {
     const size_t VB = (size_t)VISION_BATCH_MAX;                            // images encoded in one pass (minigpt4_encode_images)
     sz(VB * 3 * 224 * 224 * 4); sz(VB * 256 * 592 * 2); sz(VB * 256 * D * 4); sz(VB * 257 * D * 4); sz(VB * 257 * 3 * D * 4); sz(VB * 3 * 257 * D * 2); sz(VB * 257 * M * 2);
     sz(VB * (size_t)SPLITK_MAX * 257 * D * 4);
-    sz(VB * 9 * NQ * 2304 * 4); sz(VB * 257 * 1536 * 4 * (size_t)std::max(1, v_ncross_)); sz(VB * NQ * 768 * 4); sz(VB * NQ * 768 * 4); sz(VB * NQ * 768 * 2); sz(VB * NQ * (size_t)std::max(v_qi_, 768) * 2 * 4); sz(VB * NQ * (size_t)v_out_ * 4); sz(1 << 20);
+    sz(VB * 9 * NQ * 2304 * 4); sz(VB * 257 * 1536 * 4 * (size_t)std::max(1, v_ncross_)); sz(VB * NQ * 768 * 4); sz(VB * NQ * 768 * 4); sz(VB * NQ * 768 * 2);
+    sz(VB * NQ * (size_t)std::max(v_qi_, 768) * 2 * 4); sz(VB * NQ * (size_t)v_out_ * 4); sz(1 << 20);
     buf_arena_.alloc(total);
     auto takef = [&](size_t n) { return reinterpret_cast<float *>(buf_arena_.take(n * 4)); };
     auto takeh = [&](size_t n) { return reinterpret_cast<__half *>(buf_arena_.take(n * 2)); };
@@ -546,9 +554,12 @@ void Engine::alloc_buffers() {
         __half *dg = takeh(65536), *ds = takeh(65536), *de = takeh(65536);
         HIP_CHECK(hipMemcpy(dg, g.data(), 131072, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(ds, si.data(), 131072, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(de, ex.data(), 131072, hipMemcpyHostToDevice));
         tabs_.gelu = dg; tabs_.silu = ds; tabs_.exp = de;
+
         int last = 0;
         for (int i = 0; i < 0x7C00; i++) if (__half2float(ex[(size_t)(0x8000 + i)]) != 0.0f) last = i;
         tabs_.exp_neg_n = (last + 1 + 2047) / 2048 * 2048;
+        tabs_dec_ = tabs_;
+        if (computed_tables_) { tabs_dec_.exp = nullptr; tabs_dec_.silu = nullptr; }
     }
     x_ = takef(B * E); q_ = takef(B * E); k_ = takef(B * E); v_ = takef(B * E); att_ = takef(B * E);
     h1_ = takef(B * F); h3_ = takef(B * F); logits_ = takef(S * V); blogits_ = takef(S * V);
@@ -639,7 +650,7 @@ bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
             launch_silu_mul_quant_slabs(pend_, N, K, act_, mask, tabs_, s); pend_ = SlabSrc{};
         } else {
             flush_pending(s);
-            launch_silu_mul_quant(prep->x, prep->kind == 3 ? prep->w : nullptr, N, K, act_, mask, tabs_, s);
+            launch_silu_mul_quant(prep->x, prep->kind == 3 ? prep->w : nullptr, N, K, act_, mask, N == 1 ? tabs_dec_ : tabs_, s);
         }
     }
     // keep_pending (wv after a deferred wq|wk): the earlier launch's slabs stay where they are, this launch's go behind them, and both are handed to the consumer together
@@ -849,8 +860,8 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
         bool att_in_xh = false;                                             // the attention kernel left fp16 rows in act_.xh
         std::optional<SiteScope> att_sc;
         if (prof_on_) att_sc.emplace(this, "attention", 4.0 * (double)E * (double)(conv_[sl].n_committed + N), s);
-        if (dec && attn_split_now_) launch_attn_llm_split(q_, k_, v_, kc, vc, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, attn_ws_, attn_splits_, s);
-        else if (dec) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, true, s);
+        if (dec && attn_split_now_) launch_attn_llm_split(q_, k_, v_, kc, vc, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_dec_, att_, attn_ws_, attn_splits_, s);
+        else if (dec) launch_attn_llm(q_, k_, v_, kc, vc, 1, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_dec_, att_, true, s);
         else {
             if (pend_.ks > 1 && pend_.n == 3 && pend_.y[0] == q_ && pend_.y[1] == k_ && pend_.y[2] == v_ && !pend_.res[0] && !pend_.res[1] && !pend_.res[2] && pend_.stride == (long long)N * E) {
                 launch_rope_kv_slabs(pend_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); pend_ = SlabSrc{};
@@ -984,7 +995,7 @@ void Engine::forward_batch(int B, hipStream_t s) {
                 else { mul_mat(L.wq, B, q_, E, nullptr, s, nullptr, false, "q"); mul_mat(L.wk, B, k_, E, nullptr, s, nullptr, false, "k"); mul_mat(L.wv, B, v_, E, nullptr, s, nullptr, false, "v"); }
             }
             flush_pending(s);
-            launch_attn_llm_batched(q_, k_, v_, kc, vc, B, H, hd, d_npast_, d_bslot_, seq_stride, n_ctx_, cos_, sin_, tabs_, att_, s);
+            launch_attn_llm_batched(q_, k_, v_, kc, vc, B, H, hd, d_npast_, d_bslot_, seq_stride, n_ctx_, cos_, sin_, tabs_dec_, att_, s);
             mul_mat(L.wo, B, x_, E, x_, s, &p_att, false, "wo", true);
             if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; mul_mat_set(W2, Y2, nullptr, 2, B, F, s, &p_ffn, false, false, "w1w3", true); }
             else { prep_rms(x_, L.ffn_norm, B, E, act_mask_for(L.w1.type) | act_mask_for(L.w3.type), s); mul_mat(L.w1, B, h1_, F, nullptr, s, nullptr, false, "w1"); mul_mat(L.w3, B, h3_, F, nullptr, s, nullptr, false, "w3"); }
@@ -1001,7 +1012,7 @@ void Engine::forward_batch(int B, hipStream_t s) {
             else if (L.wk.type == L.wq.type) { mm({&L.wq, &L.wk}, {q_, k_}, nullptr, E); mm({&L.wv}, {v_}, nullptr, E); }
             else { mm({&L.wq}, {q_}, nullptr, E); mm({&L.wk}, {k_}, nullptr, E); mm({&L.wv}, {v_}, nullptr, E); }
         }
-        launch_attn_llm_batched(q_, k_, v_, kc, vc, B, H, hd, d_npast_, d_bslot_, seq_stride, n_ctx_, cos_, sin_, tabs_, att_, s);
+        launch_attn_llm_batched(q_, k_, v_, kc, vc, B, H, hd, d_npast_, d_bslot_, seq_stride, n_ctx_, cos_, sin_, tabs_dec_, att_, s);
         if (rows_pro({&L.wo}, true)) mm({&L.wo}, {x_}, x_, E, att_, nullptr);     // the attention output rows are quantised inside the wo launch
         else { launch_silu_mul_quant(att_, nullptr, B, E, act_, act_mask_for(L.wo.type), tabs_, s); mm({&L.wo}, {x_}, x_, E); }
         if (L.w1.type == L.w3.type && rows_pro({&L.w1, &L.w3})) mm({&L.w1, &L.w3}, {h1_, h3_}, nullptr, F, x_, L.ffn_norm);
@@ -1010,7 +1021,7 @@ void Engine::forward_batch(int B, hipStream_t s) {
             if (L.w1.type == L.w3.type) mm({&L.w1, &L.w3}, {h1_, h3_}, nullptr, F);
             else { mm({&L.w1}, {h1_}, nullptr, F); mm({&L.w3}, {h3_}, nullptr, F); }
         }
-        launch_silu_mul_quant(h1_, h3_, B, F, act_, act_mask_for(L.w2.type), tabs_, s);
+        launch_silu_mul_quant(h1_, h3_, B, F, act_, act_mask_for(L.w2.type), tabs_dec_, s);
         mm({&L.w2}, {x_}, x_, E);
     }
     if (B <= batch_rows_max_ && ri_fuse_ && ri_serves({&output_})) mm({&output_}, {blogits_}, nullptr, V, x_, norm_);   // final norm inside the output matrix's MFMA launch

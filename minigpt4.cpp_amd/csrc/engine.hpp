@@ -156,6 +156,8 @@ private:
     __half *kc_ = nullptr, *vc_ = nullptr;
     float *cos_ = nullptr, *sin_ = nullptr;
     Tables tabs_;
+    Tables tabs_dec_;                  // what the DECODE step's attention and SiLU launches get: tabs_, or (MINIGPT4_COMPUTED_TABLES, default on) null exp / silu pointers = the
+                                       // table values computed in the kernel instead of gathered from the 128 KB tables (qtraits.hpp exp_h / silu_h); parity mode uses tabs_
     // activations
     float *x_ = nullptr, *q_ = nullptr, *k_ = nullptr, *v_ = nullptr, *att_ = nullptr, *h1_ = nullptr, *h3_ = nullptr, *logits_ = nullptr;
     ActQ act_;
@@ -171,6 +173,7 @@ private:
     int batch_rows_max_ = 4; int batch_fuse_ = -1; int n_cus_ = 256;
     // round 5: B = 2..4 rows per weight pass on the int8 matrix cores over a row-interleaved second image of the k-quant matrices (ri_kernels.hip); built by
     // set_conversations(n > 1) -- a context with one conversation never pays the memory.  MINIGPT4_RI=0: the v_dot4 multi-row mat-vec of rounds 2-4 (A/B)
+    bool computed_tables_ = true;
     bool use_ri_ = true, ri_ready_ = false, ri_fuse_ = false;   // ri_fuse_: rows prepared inside the MFMA launches -- measured slower (profiles/r05_batched_decode_inengine.log), off
     DeviceArena ri_arena_;
     float *ri_slabs_ = nullptr; size_t ri_slab_floats_ = 0; unsigned *ri_tickets_ = nullptr; int ri_ticket_n_ = 0;   // K-split workspace of k_matvec_ri (zeroed tickets)

@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(256) void k_silu_mul_quant(const float *__restrict_
     float v[4] = {0, 0, 0, 0};
     if (in) { const float4 av = *reinterpret_cast<const float4 *>(a + row * K + i);
         if (b) { const float4 bv = *reinterpret_cast<const float4 *>(b + row * K + i);
-            v[0] = tab(tb.silu, av.x) * bv.x; v[1] = tab(tb.silu, av.y) * bv.y; v[2] = tab(tb.silu, av.z) * bv.z; v[3] = tab(tb.silu, av.w) * bv.w; }
+            v[0] = silu_h(tb.silu, av.x) * bv.x; v[1] = silu_h(tb.silu, av.y) * bv.y; v[2] = silu_h(tb.silu, av.z) * bv.z; v[3] = silu_h(tb.silu, av.w) * bv.w; }
         else { v[0] = av.x; v[1] = av.y; v[2] = av.z; v[3] = av.w; } }
     quant_emit4(v, in, i, row, K, A, mask);
 }
@@ -1662,7 +1662,7 @@ __global__ __launch_bounds__(AT_THREADS) void k_attn_llm(float *__restrict__ q, 
 #pragma unroll
     for (int i = 1; i < AT_THREADS / 64; i++) mx = fmaxf(mx, s_red[i]);
     double sum = 0.0;
-    for (int j = tid; j < T; j += AT_THREADS) { const float v = tab(tb.exp, sc[j] - mx); sc[j] = v; sum += (double)v; }
+    for (int j = tid; j < T; j += AT_THREADS) { const float v = exp_h(tb.exp, sc[j] - mx); sc[j] = v; sum += (double)v; }
     sum = wave_sum_d(sum);
     if ((tid & 63) == 0) s_dred[tid >> 6] = sum;
     __syncthreads();
@@ -1847,7 +1847,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_split_pv(const float *__res
     for (int j0 = tid; j0 < T; j0 += 4 * AS_THREADS) {            // four independent table gathers in flight per thread
         float v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int j = j0 + u * AS_THREADS; v[u] = j < T ? tab(tb.exp, sc[j] - mx) : 0.0f; }
+        for (int u = 0; u < 4; u++) { const int j = j0 + u * AS_THREADS; v[u] = j < T ? exp_h(tb.exp, sc[j] - mx) : 0.0f; }
 #pragma unroll
         for (int u = 0; u < 4; u++) { const int j = j0 + u * AS_THREADS; if (j < T) { sc[j] = v[u]; sum += (double)v[u]; } }   // fp16 values: the double sum is exact in any order
     }

@@ -11,6 +11,11 @@ __device__ __forceinline__ float h2f_bits(unsigned short h) { return __half2floa
 __device__ __forceinline__ unsigned short f2h_bits(float f) { return __half_as_ushort(f2h_rn(f)); }
 __device__ __forceinline__ float f16r(float f) { return __half2float(f2h_rn(f)); }
 __device__ __forceinline__ float tab(const __half *t, float x) { return __half2float(t[f2h_bits(x)]); }
+// Fast mode (round 5, SURVEY.md 9.5: "in fast mode evaluate in fp32"): the VALUE of ggml's fp16 tables computed instead of gathered -- table[x] = fp16(f(fp16(x))) with f
+// evaluated in fp32 by the host libm; here f comes from the GPU's exp (v_exp_f32, ~1 ulp), so a result differs from the table's by one fp16 ulp only when f lands within
+// ~1e-7 of an fp16 rounding boundary (about one value in 10^4).  A null table pointer selects this form; parity mode and the vision tower always pass the tables.
+__device__ __forceinline__ float exp_h(const __half *t, float x) { if (t) return tab(t, x); return f16r(__expf(f16r(x))); }
+__device__ __forceinline__ float silu_h(const __half *t, float x) { if (t) return tab(t, x); const float xh = f16r(x); return f16r(xh / (1.0f + __expf(-xh))); }
 
 __device__ __forceinline__ int4 ld16(const void *p) { return *reinterpret_cast<const int4 *>(p); }
 // weight-plane loads: streamed once per token by exactly one wave -> non-temporal (MG4_NT_WEIGHTS=0 builds the default-policy variant for A/B runs)

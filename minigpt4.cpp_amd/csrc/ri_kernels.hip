@@ -189,15 +189,16 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
         const int sb_per = (psb1 - psb0 + WPB - 1) / WPB, sb0 = psb0 + wv * sb_per, sb1 = min(psb1, sb0 + sb_per);
         const int m = g / a.groups_each, gl = g - m * a.groups_each;
         const RiMat &M = a.m[m];
-        const uint8_t *pq = M.p.qs + (size_t)gl * U * 1024 + lane * 16, *pp = M.p.qh + (size_t)gl * U * (Q6 ? 512 : 256) + lane * (Q6 ? 8 : 4), *ph = M.p.sc + (size_t)gl * NSB * 1024 + lane * 16,
-                      *pd = M.p.d + (size_t)gl * NSB * 128 + lane * 2;
+        const uint8_t *pq = M.p.qs + (size_t)gl * U * 1024 + lane * 16, *pp = M.p.qh + (size_t)gl * U * (Q6 ? 512 : 256) + lane * (Q6 ? 8 : 4);
+        const uint8_t *ph = M.p.sc + (size_t)gl * NSB * 1024 + lane * 16, *pd = M.p.d + (size_t)gl * NSB * 128 + lane * 2;
         auto fetch = [&](int sb, Raw &r) {          // every load unconditional (clamped super-block): counted waits
             const int sbc = min(sb, NSB - 1);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 r.q[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i_r *>(pq + (size_t)(sbc * 8 + u) * 1024));
                 if (Q5) r.p[u] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(pp + (size_t)(sbc * 8 + u) * 256));
-                if (Q6) { typedef unsigned v2u_r __attribute__((ext_vector_type(2))); const v2u_r w2 = __builtin_nontemporal_load(reinterpret_cast<const v2u_r *>(pp + (size_t)(sbc * 8 + u) * 512)); r.p[Q6 ? 2 * u : 0] = w2.x; r.p[Q6 ? 2 * u + 1 : 0] = w2.y; }
+                if (Q6) { typedef unsigned v2u_r __attribute__((ext_vector_type(2)));
+                    const v2u_r w2 = __builtin_nontemporal_load(reinterpret_cast<const v2u_r *>(pp + (size_t)(sbc * 8 + u) * 512)); r.p[Q6 ? 2 * u : 0] = w2.x; r.p[Q6 ? 2 * u + 1 : 0] = w2.y; }
             }
             r.h = __builtin_nontemporal_load(reinterpret_cast<const v4i_r *>(ph + (size_t)sbc * 1024));
             if (Q6) r.d = __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(pd + (size_t)sbc * 128));
