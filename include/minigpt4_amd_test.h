@@ -62,6 +62,7 @@ MINIGPT4_API int minigpt4_amd_bench_matvec(int ggml_type, int rows, int cols, in
 /* batched decode on the int8 matrix cores (csrc/ri_kernels.hip): ordinary planes -> row-interleaved image -> N = 1..4 prepared rows against n_mat equally shaped Q4_K / Q5_K /
  * Q6_K matrices in one launch; y [n_mat][N][n_out]; returns 4 when the type / shape is outside the kernel's range */
 MINIGPT4_API int minigpt4_amd_test_matvec_ri(int ggml_type, const void *raw_w, int n_mat, int64_t n_in, int64_t n_out, const float *x, int N, const float *residual, const float *rms_w /* non-null: rows rms-normed with it inside the launch */, float *y);
+MINIGPT4_API int minigpt4_amd_test_matvec_ri_mixed(int type_a, const void *raw_a, int n_a, int type_b, const void *raw_b, int n_b, int64_t n_in, int64_t n_out, const float *x, int N, float *y);   /* one launch over n_a matrices of Q4_K / Q5_K + n_b of Q6_K (a "more bits" layer's wq | wk + wv) */
 MINIGPT4_API int minigpt4_amd_bench_matvec_ri(int ggml_type, int rows, int cols, int n_mat, int N, int iters, int n_sets, float *us_per_launch);   /* us per launch of the same, synthetic planes, rotating sets */
 /* 1 when the test library was built by `make test-extras` (closed-direction kernels included: the generation-3 prompt mat-mul, the batched-decode MFMA probe), else 0 */
 MINIGPT4_API int minigpt4_amd_test_extras(void);

@@ -981,6 +981,11 @@ void Engine::forward_batch(int B, hipStream_t s) {
             if (!batch_mix_ || B > batch_rows_max_ || B > 4 || L.wk.type != L.wq.type || L.wv.type == L.wq.type) return false;
             const QWeight *W1[2] = {&L.wq, &L.wk}, *W2[1] = {&L.wv};
             float *y1[2] = {q_, k_}, *y2[1] = {v_};
+            // at 3 and 4 prepared rows on the matrix cores (k_matvec_ri_mix), under ri_serves' conditions: every image built, >= 128 row groups in the set
+            if (!pro && ri_ready_ && B >= 3 && ri_of(&L.wq) && ri_of(&L.wk) && ri_of(&L.wv) && (L.wq.rows + L.wk.rows + L.wv.rows) / 64 >= 128) {
+                const RiPlanes *r1[2] = {ri_of(&L.wq), ri_of(&L.wk)}, *r2[1] = {ri_of(&L.wv)};
+                if (launch_matvec_ri_mixed(W1, r1, y1, 2, W2, r2, y2, 1, act_, B, E, s)) return true;
+            }
             return launch_matvec_rows_mixed(W1, y1, 2, W2, y2, 1, act_, B, E, s, pro ? x_ : nullptr, pro ? L.attn_norm : nullptr, E);
         };
         if (B > batch_rows_max_ && batch_sets_) {
@@ -1226,9 +1231,10 @@ int Engine::profile_sites(int steps, std::string &json) {
 void Engine::build_ri_planes() {
     if (ri_ready_ || !use_ri_ || weights_missing()) return;
     std::vector<const QWeight *> ws;
-    // only the sets the batched step serves this way (forward_batch: ri_serves): wq | wk | wv of one type, w1 | w3, the output matrix -- not the 80-group wo / w2
+    // only the sets the batched step serves this way (forward_batch: ri_serves, qkv_mixed): wq | wk | wv (of one type, or wq | wk + a Q6_K wv), w1 | w3, the output matrix -- not the 80-group wo / w2
     for (const LayerW &L : layers_) {
         if (L.wk.type == L.wq.type && L.wv.type == L.wq.type) for (const QWeight *w : {&L.wq, &L.wk, &L.wv}) ws.push_back(w);
+        else if (L.wk.type == L.wq.type && L.wv.type == GT_Q6_K && batch_mix_) for (const QWeight *w : {&L.wq, &L.wk, &L.wv}) ws.push_back(w);   // a "more bits" layer: k_matvec_ri_mix
         if (L.w1.type == L.w3.type) for (const QWeight *w : {&L.w1, &L.w3}) ws.push_back(w);
     }
     ws.push_back(&output_);

@@ -87,6 +87,9 @@ size_t ri_plan(int type, int rows, int cols, RiPlanes &p, uint8_t *base);      /
 void launch_ri_build(const QWeight &w, const RiPlanes &p, hipStream_t s);      // ordinary planes -> row-interleaved image
 bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s,
                       const float *px = nullptr, const float *pw = nullptr, int ldx = 0);   // px != null: rows t of px (stride ldx) are rms-normed with pw and quantised inside the launch (A unused)
+// a "more bits" layer's set in one launch: na matrices of Q4_K / Q5_K + nb of Q6_K (na + nb <= 3), same shape, prepared rows
+bool launch_matvec_ri_mixed(const QWeight *const *Wa, const RiPlanes *const *ria, float *const *ya, int na, const QWeight *const *Wb, const RiPlanes *const *rib, float *const *yb, int nb,
+                            const ActQ &A, int N, int ldy, hipStream_t s);
 void set_ri_cus(int cus);
 // workspace of the K-split form (few row groups, long K: the 13B w2): slabs for the workgroups' partial sums and one arrival ticket per row group, ZEROED by the caller (the kernel
 // leaves them zero); without it such sets run one workgroup per group.  One workspace per process: contexts of one process share a stream order per context, launches of two

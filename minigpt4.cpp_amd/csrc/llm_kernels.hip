@@ -2463,7 +2463,7 @@ static bool launch_attn_prefill_h8(const float *q, const __half *kc, const __hal
     hipLaunchKernelGGL((k_attn_prefill_h8<HD>), dim3((unsigned)n_head, (unsigned)((N + AP_QT * 2 - 1) / (AP_QT * 2))), dim3(512), lds, s, q, kc, vc, n_head * HD, N, n_past, tb, out, LS, out_h);
     return true;
 }
-static int g_attn_prefill_f16 = 1;   // 1: prompt attention on the fp16 matrix cores (k_attn_prefill_h), 0: the exact-f32 MFMA kernel (k_attn_prefill); MINIGPT4_ATTN_PREFILL_F16, read by Engine::init
+static int g_attn_prefill_f16 = 1;   // 1: prompt attention on the fp16 matrix cores (k_attn_prefill_h), 0: the exact-f32 MFMA kernel (k_attn_prefill); test-library setter only
 void set_attn_prefill_f16(int v) { g_attn_prefill_f16 = v != 0; }
 template <int HD, int QS>
 static bool launch_attn_prefill_h_qs(const float *q, const __half *kc, const __half *vc, int N, int n_head, const int *n_past, int t_max, const Tables &tb, float *out, hipStream_t s) {
@@ -2482,6 +2482,10 @@ static bool launch_attn_prefill_hd(const float *q, const __half *kc, const __hal
         if (n_head * ((N + 31) / 32) >= 256 && launch_attn_prefill_h_qs<HD, 2>(q, kc, vc, N, n_head, n_past, t_max, tb, out, s)) return true;
         if (launch_attn_prefill_h_qs<HD, 1>(q, kc, vc, N, n_head, n_past, t_max, tb, out, s)) return true;
     }
+    // Fallback: k_attn_prefill<HD, 1>, the round-2 kernel with fp32 score / value products.  Taken (a) after set_attn_prefill_f16(0) (test library: the A/B switch of
+    // the fp16 kernels), (b) when the fp16 kernels refuse because their LDS image (score rows + fp16 K tile + transposed V tile) exceeds the 160 KiB of a CU.  Both forms
+    // hold 16 score rows of the whole context: at head size 128 both end at 1984 keys; beyond, this returns false and Engine::forward runs the rows through the decode
+    // attention kernel (k_attn_llm, one query row per workgroup), which has no such limit.
     const int LS = ((t_max + AP_KT - 1) / AP_KT) * AP_KT + 1;
     static bool attr = false;
     if (!attr) { HIP_IGNORE(lds_optin_max(&k_attn_prefill<HD, 1>)); attr = true; }

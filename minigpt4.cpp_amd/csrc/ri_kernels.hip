@@ -71,6 +71,7 @@ void launch_ri_build(const QWeight &w, const RiPlanes &p, hipStream_t s) {
 // ---- the kernel ----------------------------------------------------------------------------------------------------------------------------------------
 struct RiMat { RiPlanes p; float *y; const float *res; };
 struct RiArgs { RiMat m[3]; int n_mat, groups_each, rows_each, K, N, ldy; const float *px, *pw; int ldx;
+                int n_a;            // k_matvec_ri_mix: the first n_a matrices are of type TA, the others of type TB
                 // ksplit > 1 (matrices with few row groups and a long K: the 13B w2 has 80 groups x 54 super-blocks): `ksplit` workgroups share a row group, each a contiguous
                 // K range; their partial sums go to `slabs` [group][part][4][64] and the LAST one to arrive (ticket per group, self-resetting) adds them in part order
                 int ksplit; float *slabs; unsigned *tickets; };   // px: rows prepared inside the launch (PRO): rms_norm(px_t) * pw, quantised
@@ -81,6 +82,122 @@ __device__ __forceinline__ void ri_scale_min_words(const v4i_r &h, unsigned &scw
     mw0 = s1 & 0x3f3f3f3fu; mw1 = ((s2 >> 4) & 0x0f0f0f0fu) | (((s1 >> 6) & 0x03030303u) << 4);
 }
 __device__ __forceinline__ float ri_h2f(unsigned short h) { return __half2float(__ushort_as_half(h)); }
+
+// One super-block of one row group as a lane holds it: 8 units of ITS row (16 B each), the high bits, the 16-byte scale header (Q6_K: 16 int8 scales) and Q6_K's fp16 d
+template <int T> struct RiRaw { v4i_r q[8]; unsigned p[T == GT_Q6_K ? 16 : (T == GT_Q5_K ? 8 : 1)]; v4i_r h; unsigned short d; };
+template <int T>
+__device__ __forceinline__ void ri_fetch(const uint8_t *pq, const uint8_t *pp, const uint8_t *ph, const uint8_t *pd, int sb, int NSB, RiRaw<T> &r) {
+    constexpr bool Q6 = T == GT_Q6_K, Q5 = T == GT_Q5_K;
+    const int sbc = min(sb, NSB - 1);               // every load unconditional (clamped super-block): counted waits
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        r.q[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i_r *>(pq + (size_t)(sbc * 8 + u) * 1024));
+        if (Q5) r.p[u] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(pp + (size_t)(sbc * 8 + u) * 256));
+        if (Q6) { typedef unsigned v2u_r __attribute__((ext_vector_type(2)));
+            const v2u_r w2 = __builtin_nontemporal_load(reinterpret_cast<const v2u_r *>(pp + (size_t)(sbc * 8 + u) * 512)); r.p[Q6 ? 2 * u : 0] = w2.x; r.p[Q6 ? 2 * u + 1 : 0] = w2.y; }
+    }
+    r.h = __builtin_nontemporal_load(reinterpret_cast<const v4i_r *>(ph + (size_t)sbc * 1024));
+    if (Q6) r.d = __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(pd + (size_t)sbc * 128));
+}
+// acc[t] += (this lane's weight row, super-block sb) . (token row t); qa / da: the LDS image of the token row this lane feeds the A operand from (row lane & 3)
+template <int T>
+__device__ __forceinline__ void ri_consume(const int8_t *qa, const int8_t *da, const float *dk, int NSB, int sb, const RiRaw<T> &r, float (&acc)[4]) {
+    constexpr bool Q6 = T == GT_Q6_K, Q5 = T == GT_Q5_K;
+    int isum[4] = {0, 0, 0, 0};
+    unsigned scw0 = 0, scw1 = 0, mw0 = 0, mw1 = 0;
+    if (!Q6) ri_scale_min_words(r.h, scw0, scw1, mw0, mw1);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        // activation bytes of the unit's low / high nibbles (Tr<T>::loada): Q4_K / Q5_K: 64 j + 16 h and + 32;  Q6_K: 128 n + 32 c + 16 h and + 64
+        const int off = Q6 ? 128 * (u >> 2) + 32 * ((u >> 1) & 1) + 16 * (u & 1) : 64 * (u >> 1) + 16 * (u & 1);
+        const v4i_r alo = *reinterpret_cast<const v4i_r *>(qa + sb * 256 + off), ahi = *reinterpret_cast<const v4i_r *>(qa + sb * 256 + off + (Q6 ? 64 : 32));
+        v4i_r D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const unsigned q = (unsigned)r.q[u][d];
+            unsigned wlo = q & 0x0F0F0F0Fu, whi = (q >> 4) & 0x0F0F0F0Fu;
+            if (Q5) { const unsigned P = r.p[Q5 ? u : 0];
+                wlo |= (d == 0 ? P << 4 : d == 1 ? P << 3 : d == 2 ? P << 2 : P << 1) & 0x10101010u; whi |= (d == 0 ? P : d == 1 ? P >> 1 : d == 2 ? P >> 2 : P >> 3) & 0x10101010u; }
+            if (Q6) { const unsigned L = r.p[Q6 ? 2 * u : 0], H = r.p[Q6 ? 2 * u + 1 : 0];
+                wlo |= (d == 0 ? L << 4 : d == 1 ? L << 2 : d == 2 ? L : L >> 2) & 0x30303030u; whi |= (d == 0 ? H << 4 : d == 1 ? H << 2 : d == 2 ? H : H >> 2) & 0x30303030u; }
+            D0 = __builtin_amdgcn_mfma_i32_4x4x4i8(alo[d], (int)wlo, D0, 0, 0, 0);
+            D1 = __builtin_amdgcn_mfma_i32_4x4x4i8(ahi[d], (int)whi, D1, 0, 0, 0);
+        }
+        int sc0, sc1;
+        if (Q6) { const unsigned w16 = ((unsigned)r.h[u >> 1] >> (16 * (u & 1))) & 0xFFFFu; sc0 = (int)(signed char)(w16 & 0xFF); sc1 = (int)(signed char)(w16 >> 8); }
+        else { const int j = u >> 1; const unsigned scw = (j & 2) ? scw1 : scw0; sc0 = (int)(scw >> (16 * (j & 1))) & 0xFF; sc1 = (int)(scw >> (16 * (j & 1) + 8)) & 0xFF; }
+#pragma unroll
+        for (int t = 0; t < 4; t++) isum[t] += __mul24(sc0, D0[t]) + __mul24(sc1, D1[t]);
+    }
+    if (!Q6) {
+        // min term: sum_j m_j * bsum_j on the digit split of the per-32 sums
+        const v4i_r dgt = *reinterpret_cast<const v4i_r *>(da + sb * 16);
+        v4i_r Ml = {0, 0, 0, 0}, Mh = {0, 0, 0, 0};
+        Ml = __builtin_amdgcn_mfma_i32_4x4x4i8(dgt[0], (int)mw0, Ml, 0, 0, 0); Ml = __builtin_amdgcn_mfma_i32_4x4x4i8(dgt[1], (int)mw1, Ml, 0, 0, 0);
+        Mh = __builtin_amdgcn_mfma_i32_4x4x4i8(dgt[2], (int)mw0, Mh, 0, 0, 0); Mh = __builtin_amdgcn_mfma_i32_4x4x4i8(dgt[3], (int)mw1, Mh, 0, 0, 0);
+        const float d = ri_h2f((unsigned short)((unsigned)r.h[0] & 0xFFFF)), dmin = ri_h2f((unsigned short)((unsigned)r.h[0] >> 16));
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float dkt = dk[t * NSB + sb];
+            acc[t] = fmaf(d * dkt, (float)isum[t], acc[t]);
+            acc[t] = fmaf(-(dmin * dkt), (float)(Mh[t] * 128 + Ml[t]), acc[t]);
+        }
+    } else {
+        // the -32 offset of the 6-bit codes: sum over the 16 scale groups of sc_g * bsum16_g, digit split (scale bytes and digit bytes are in the same order)
+        const v4i_r dl = *reinterpret_cast<const v4i_r *>(da + sb * 32), dh = *reinterpret_cast<const v4i_r *>(da + sb * 32 + 16);
+        v4i_r Cl = {0, 0, 0, 0}, Ch = {0, 0, 0, 0};
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) { Cl = __builtin_amdgcn_mfma_i32_4x4x4i8(dl[k4], r.h[k4], Cl, 0, 0, 0); Ch = __builtin_amdgcn_mfma_i32_4x4x4i8(dh[k4], r.h[k4], Ch, 0, 0, 0); }
+        const float d = ri_h2f(r.d);
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = fmaf(d * dk[t * NSB + sb], (float)(isum[t] - 32 * (Ch[t] * 128 + Cl[t])), acc[t]);
+    }
+}
+// super-blocks [sb0, sb1) of row group gl of one matrix, two-stage register pipeline
+template <int T>
+__device__ __forceinline__ void ri_stream(const RiPlanes &P, int gl, int U, int NSB, int lane, int sb0, int sb1, const int8_t *qa, const int8_t *da, const float *dk, float (&acc)[4]) {
+    constexpr bool Q6 = T == GT_Q6_K;
+    const uint8_t *pq = P.qs + (size_t)gl * U * 1024 + lane * 16, *pp = P.qh + (size_t)gl * U * (Q6 ? 512 : 256) + lane * (Q6 ? 8 : 4);
+    const uint8_t *ph = P.sc + (size_t)gl * NSB * 1024 + lane * 16, *pd = P.d + (size_t)gl * NSB * 128 + lane * 2;
+    RiRaw<T> cur, nxt;
+    ri_fetch<T>(pq, pp, ph, pd, sb0, NSB, cur);
+    for (int sb = sb0; sb < sb1;) {
+        ri_fetch<T>(pq, pp, ph, pd, sb + 1, NSB, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        ri_consume<T>(qa, da, dk, NSB, sb, cur, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (++sb >= sb1) break;
+        ri_fetch<T>(pq, pp, ph, pd, sb + 1, NSB, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        ri_consume<T>(qa, da, dk, NSB, sb, nxt, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        ++sb;
+    }
+}
+// the digit image of the rows' block sums for type T (header below), super-blocks [c_sb0, c_sb1); dk != null: the rows' Q8_K scales too.  NT = threads of the workgroup
+template <int T>
+__device__ __forceinline__ void ri_stage_digits(const ActQ &A, int8_t *dg, float *dk, int N, int NSB, int K, int c_sb0, int c_sb1, int NT) {
+    constexpr bool Q6 = T == GT_Q6_K;
+    for (int i0 = threadIdx.x; i0 < 4 * (c_sb1 - c_sb0); i0 += NT) {
+        const int t = i0 / (c_sb1 - c_sb0), sb = c_sb0 + (i0 - t * (c_sb1 - c_sb0)), i = t * NSB + sb;
+        float d = 0.0f;
+        if (!Q6) {
+            v4i_r v = {0, 0, 0, 0};
+            if (t < N) { v = *reinterpret_cast<const v4i_r *>(A.bsq + ((size_t)t * NSB + sb) * 16); d = A.dk[(size_t)t * NSB + sb]; }
+            *reinterpret_cast<v4i_r *>(dg + (size_t)i * 16) = v;
+        } else {
+            int8_t *o = dg + (size_t)i * 32;
+            if (t < N) d = A.dk[(size_t)t * NSB + sb];
+#pragma unroll
+            for (int ui = 0; ui < 8; ui++) {
+                const int n = ui >> 2, c = (ui >> 1) & 1, h = ui & 1, grp = 8 * n + 2 * c + h;
+                const int s_lo = t < N ? (int)A.bsk[(size_t)t * (K / 16) + sb * 16 + grp] : 0, s_hi = t < N ? (int)A.bsk[(size_t)t * (K / 16) + sb * 16 + grp + 4] : 0;
+                o[2 * ui] = (int8_t)(s_lo & 127); o[2 * ui + 1] = (int8_t)(s_hi & 127); o[16 + 2 * ui] = (int8_t)(s_lo >> 7); o[16 + 2 * ui + 1] = (int8_t)(s_hi >> 7);
+            }
+        }
+        if (dk) dk[i] = d;
+    }
+}
 
 // LDS image of the <= 4 activation rows (rows >= N are zero):  q8 [4][K]  |  dg [4][NSB][DG]  |  dk [4][NSB]  |  red [WPB][4][64]
 //   DG = 16 (Q4_K / Q5_K): the quantiser's digit-split per-32 sums (bytes 0..7 low digits of sub-blocks 0..7, 8..15 high digits)
@@ -156,32 +273,13 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
         if (t < N) v = *reinterpret_cast<const v4i_r *>(A.q8k + (size_t)t * K + e);
         *reinterpret_cast<v4i_r *>(q8 + (size_t)t * K + e) = v;
     }
-    for (int i0 = threadIdx.x; i0 < 4 * (c_sb1 - c_sb0); i0 += 64 * WPB) {
-        const int t = i0 / (c_sb1 - c_sb0), sb = c_sb0 + (i0 - t * (c_sb1 - c_sb0)), i = t * NSB + sb;
-        float d = 0.0f;
-        if (!Q6) {
-            v4i_r v = {0, 0, 0, 0};
-            if (t < N) { v = *reinterpret_cast<const v4i_r *>(A.bsq + ((size_t)t * NSB + sb) * 16); d = A.dk[(size_t)t * NSB + sb]; }
-            *reinterpret_cast<v4i_r *>(dg + (size_t)i * 16) = v;
-        } else {
-            int8_t *o = dg + (size_t)i * 32;
-            if (t < N) d = A.dk[(size_t)t * NSB + sb];
-#pragma unroll
-            for (int ui = 0; ui < 8; ui++) {
-                const int n = ui >> 2, c = (ui >> 1) & 1, h = ui & 1, grp = 8 * n + 2 * c + h;
-                const int s_lo = t < N ? (int)A.bsk[(size_t)t * (K / 16) + sb * 16 + grp] : 0, s_hi = t < N ? (int)A.bsk[(size_t)t * (K / 16) + sb * 16 + grp + 4] : 0;
-                o[2 * ui] = (int8_t)(s_lo & 127); o[2 * ui + 1] = (int8_t)(s_hi & 127); o[16 + 2 * ui] = (int8_t)(s_lo >> 7); o[16 + 2 * ui + 1] = (int8_t)(s_hi >> 7);
-            }
-        }
-        dk[i] = d;
-    }
+    ri_stage_digits<T>(A, dg, dk, N, NSB, K, c_sb0, c_sb1, 64 * WPB);
     }
     __syncthreads();
     const int S = a.ksplit > 1 ? a.ksplit : 1;
     __shared__ int s_last;
     const int8_t *qa = q8 + (size_t)t4 * K;
     const int8_t *da = dg + (size_t)t4 * NSB * DG;
-    struct Raw { v4i_r q[8]; unsigned p[Q6 ? 16 : (Q5 ? 8 : 1)]; v4i_r h; unsigned short d; };
     const int total_groups = a.n_mat * a.groups_each;
     for (int task = blockIdx.x; task < total_groups * S; task += gridDim.x) {
         const int g = task / S, part = task - g * S;
@@ -189,86 +287,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
         const int sb_per = (psb1 - psb0 + WPB - 1) / WPB, sb0 = psb0 + wv * sb_per, sb1 = min(psb1, sb0 + sb_per);
         const int m = g / a.groups_each, gl = g - m * a.groups_each;
         const RiMat &M = a.m[m];
-        const uint8_t *pq = M.p.qs + (size_t)gl * U * 1024 + lane * 16, *pp = M.p.qh + (size_t)gl * U * (Q6 ? 512 : 256) + lane * (Q6 ? 8 : 4);
-        const uint8_t *ph = M.p.sc + (size_t)gl * NSB * 1024 + lane * 16, *pd = M.p.d + (size_t)gl * NSB * 128 + lane * 2;
-        auto fetch = [&](int sb, Raw &r) {          // every load unconditional (clamped super-block): counted waits
-            const int sbc = min(sb, NSB - 1);
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                r.q[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i_r *>(pq + (size_t)(sbc * 8 + u) * 1024));
-                if (Q5) r.p[u] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(pp + (size_t)(sbc * 8 + u) * 256));
-                if (Q6) { typedef unsigned v2u_r __attribute__((ext_vector_type(2)));
-                    const v2u_r w2 = __builtin_nontemporal_load(reinterpret_cast<const v2u_r *>(pp + (size_t)(sbc * 8 + u) * 512)); r.p[Q6 ? 2 * u : 0] = w2.x; r.p[Q6 ? 2 * u + 1 : 0] = w2.y; }
-            }
-            r.h = __builtin_nontemporal_load(reinterpret_cast<const v4i_r *>(ph + (size_t)sbc * 1024));
-            if (Q6) r.d = __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(pd + (size_t)sbc * 128));
-        };
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        auto consume = [&](int sb, const Raw &r) {
-            int isum[4] = {0, 0, 0, 0};
-            unsigned scw0 = 0, scw1 = 0, mw0 = 0, mw1 = 0;
-            if (!Q6) ri_scale_min_words(r.h, scw0, scw1, mw0, mw1);
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                // activation bytes of the unit's low / high nibbles (Tr<T>::loada): Q4_K / Q5_K: 64 j + 16 h and + 32;  Q6_K: 128 n + 32 c + 16 h and + 64
-                const int off = Q6 ? 128 * (u >> 2) + 32 * ((u >> 1) & 1) + 16 * (u & 1) : 64 * (u >> 1) + 16 * (u & 1);
-                const v4i_r alo = *reinterpret_cast<const v4i_r *>(qa + sb * 256 + off), ahi = *reinterpret_cast<const v4i_r *>(qa + sb * 256 + off + (Q6 ? 64 : 32));
-                v4i_r D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0};
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    const unsigned q = (unsigned)r.q[u][d];
-                    unsigned wlo = q & 0x0F0F0F0Fu, whi = (q >> 4) & 0x0F0F0F0Fu;
-                    if (Q5) { const unsigned P = r.p[Q5 ? u : 0];
-                        wlo |= (d == 0 ? P << 4 : d == 1 ? P << 3 : d == 2 ? P << 2 : P << 1) & 0x10101010u; whi |= (d == 0 ? P : d == 1 ? P >> 1 : d == 2 ? P >> 2 : P >> 3) & 0x10101010u; }
-                    if (Q6) { const unsigned L = r.p[Q6 ? 2 * u : 0], H = r.p[Q6 ? 2 * u + 1 : 0];
-                        wlo |= (d == 0 ? L << 4 : d == 1 ? L << 2 : d == 2 ? L : L >> 2) & 0x30303030u; whi |= (d == 0 ? H << 4 : d == 1 ? H << 2 : d == 2 ? H : H >> 2) & 0x30303030u; }
-                    D0 = __builtin_amdgcn_mfma_i32_4x4x4i8(alo[d], (int)wlo, D0, 0, 0, 0);
-                    D1 = __builtin_amdgcn_mfma_i32_4x4x4i8(ahi[d], (int)whi, D1, 0, 0, 0);
-                }
-                int sc0, sc1;
-                if (Q6) { const unsigned w16 = ((unsigned)r.h[u >> 1] >> (16 * (u & 1))) & 0xFFFFu; sc0 = (int)(signed char)(w16 & 0xFF); sc1 = (int)(signed char)(w16 >> 8); }
-                else { const int j = u >> 1; const unsigned scw = (j & 2) ? scw1 : scw0; sc0 = (int)(scw >> (16 * (j & 1))) & 0xFF; sc1 = (int)(scw >> (16 * (j & 1) + 8)) & 0xFF; }
-#pragma unroll
-                for (int t = 0; t < 4; t++) isum[t] += __mul24(sc0, D0[t]) + __mul24(sc1, D1[t]);
-            }
-            if (!Q6) {
-                // min term: sum_j m_j * bsum_j on the digit split of the per-32 sums
-                const v4i_r dgt = *reinterpret_cast<const v4i_r *>(da + sb * 16);
-                v4i_r Ml = {0, 0, 0, 0}, Mh = {0, 0, 0, 0};
-                Ml = __builtin_amdgcn_mfma_i32_4x4x4i8(dgt[0], (int)mw0, Ml, 0, 0, 0); Ml = __builtin_amdgcn_mfma_i32_4x4x4i8(dgt[1], (int)mw1, Ml, 0, 0, 0);
-                Mh = __builtin_amdgcn_mfma_i32_4x4x4i8(dgt[2], (int)mw0, Mh, 0, 0, 0); Mh = __builtin_amdgcn_mfma_i32_4x4x4i8(dgt[3], (int)mw1, Mh, 0, 0, 0);
-                const float d = ri_h2f((unsigned short)((unsigned)r.h[0] & 0xFFFF)), dmin = ri_h2f((unsigned short)((unsigned)r.h[0] >> 16));
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const float dkt = dk[t * NSB + sb];
-                    acc[t] = fmaf(d * dkt, (float)isum[t], acc[t]);
-                    acc[t] = fmaf(-(dmin * dkt), (float)(Mh[t] * 128 + Ml[t]), acc[t]);
-                }
-            } else {
-                // the -32 offset of the 6-bit codes: sum over the 16 scale groups of sc_g * bsum16_g, digit split (scale bytes and digit bytes are in the same order)
-                const v4i_r dl = *reinterpret_cast<const v4i_r *>(da + sb * 32), dh = *reinterpret_cast<const v4i_r *>(da + sb * 32 + 16);
-                v4i_r Cl = {0, 0, 0, 0}, Ch = {0, 0, 0, 0};
-#pragma unroll
-                for (int k4 = 0; k4 < 4; k4++) { Cl = __builtin_amdgcn_mfma_i32_4x4x4i8(dl[k4], r.h[k4], Cl, 0, 0, 0); Ch = __builtin_amdgcn_mfma_i32_4x4x4i8(dh[k4], r.h[k4], Ch, 0, 0, 0); }
-                const float d = ri_h2f(r.d);
-#pragma unroll
-                for (int t = 0; t < 4; t++) acc[t] = fmaf(d * dk[t * NSB + sb], (float)(isum[t] - 32 * (Ch[t] * 128 + Cl[t])), acc[t]);
-            }
-        };
-        Raw cur, nxt;
-        fetch(sb0, cur);
-        for (int sb = sb0; sb < sb1;) {
-            fetch(sb + 1, nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(sb, cur);
-            __builtin_amdgcn_sched_barrier(0);
-            if (++sb >= sb1) break;
-            fetch(sb + 1, cur);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(sb, nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            ++sb;
-        }
+        ri_stream<T>(M.p, gl, U, NSB, lane, sb0, sb1, qa, da, dk, acc);
         // the K ranges of the WPB waves, combined in wave order
 #pragma unroll
         for (int t = 0; t < 4; t++) red[(wv * 4 + t) * 64 + lane] = acc[t];
@@ -299,6 +319,50 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
                 }
                 if (threadIdx.x == 0) __hip_atomic_store(a.tickets + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
             }
+        }
+        __syncthreads();
+    }
+}
+
+// A "more bits" layer's wq | wk (Q4_K / Q5_K) + wv (Q6_K) in ONE launch (the single-row step's k_matvec_mix, the v_dot4 batched step's k_matvec_tn_mix): the same row image and
+// the same per-group stream as k_matvec_ri, the digit image of the block sums staged once per type; row groups of the first n_a matrices stream as TA, the others as TB.
+// No K split, rows prepared by the caller.
+template <int TA, int TB, int WPB>
+__global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri_mix(const RiArgs a, const ActQ A) {
+    constexpr int DGA = TA == GT_Q6_K ? 32 : 16, DGB = TB == GT_Q6_K ? 32 : 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ri[];
+    const int K = a.K, U = K / 32, NSB = K / 256, N = a.N;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, t4 = lane & 3;
+    int8_t *q8 = reinterpret_cast<int8_t *>(smem_ri);
+    int8_t *dga = q8 + 4 * K, *dgb = dga + 4 * NSB * DGA;
+    float *dk = reinterpret_cast<float *>(dgb + 4 * NSB * DGB);
+    float *red = dk + 4 * NSB;
+    for (int i = threadIdx.x * 16; i < 4 * K; i += 64 * WPB * 16) {
+        const int t = i / K;
+        v4i_r v = {0, 0, 0, 0};
+        if (t < N) v = *reinterpret_cast<const v4i_r *>(A.q8k + i);
+        *reinterpret_cast<v4i_r *>(q8 + i) = v;
+    }
+    ri_stage_digits<TA>(A, dga, dk, N, NSB, K, 0, NSB, 64 * WPB);
+    ri_stage_digits<TB>(A, dgb, nullptr, N, NSB, K, 0, NSB, 64 * WPB);
+    __syncthreads();
+    const int8_t *qa = q8 + (size_t)t4 * K;
+    const int sb_per = (NSB + WPB - 1) / WPB, sb0 = wv * sb_per, sb1 = min(NSB, sb0 + sb_per);
+    for (int g = blockIdx.x; g < a.n_mat * a.groups_each; g += gridDim.x) {
+        const int m = g / a.groups_each, gl = g - m * a.groups_each;
+        const RiMat &M = a.m[m];
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (m < a.n_a) ri_stream<TA>(M.p, gl, U, NSB, lane, sb0, sb1, qa, dga + (size_t)t4 * NSB * DGA, dk, acc);      // workgroup-uniform branch
+        else ri_stream<TB>(M.p, gl, U, NSB, lane, sb0, sb1, qa, dgb + (size_t)t4 * NSB * DGB, dk, acc);
+#pragma unroll
+        for (int t = 0; t < 4; t++) red[(wv * 4 + t) * 64 + lane] = acc[t];
+        __syncthreads();
+        if (wv < N) {
+            float s = red[wv * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < WPB; w++) s += red[(w * 4 + wv) * 64 + lane];
+            const size_t o = (size_t)wv * a.ldy + (size_t)gl * 64 + lane;
+            M.y[o] = M.res ? s + M.res[o] : s;
         }
         __syncthreads();
     }
@@ -355,6 +419,36 @@ bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float 
     case GT_Q6_K: return launch_ri_t<GT_Q6_K>(a, A, s);
     default: return false;
     }
+}
+
+template <int TA, int TB, int WPB>
+static void launch_ri_mix_k(const RiArgs &a, const ActQ &A, unsigned blocks, size_t lds, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { HIP_IGNORE(lds_optin_max(&k_matvec_ri_mix<TA, TB, WPB>)); attr = true; }
+    hipLaunchKernelGGL((k_matvec_ri_mix<TA, TB, WPB>), dim3(blocks), dim3(64 * WPB), lds, s, a, A);
+}
+// wq | wk of one type (Q4_K / Q5_K) and wv of another (Q6_K), same shape, every one with its row-interleaved image: y_k[t * ldy + r] = W_k[r] . act[t] in one launch
+bool launch_matvec_ri_mixed(const QWeight *const *Wa, const RiPlanes *const *ria, float *const *ya, int na, const QWeight *const *Wb, const RiPlanes *const *rib, float *const *yb, int nb,
+                            const ActQ &A, int N, int ldy, hipStream_t s) {
+    if (na < 1 || nb < 1 || na + nb > 3 || N < 1 || N > 4 || !A.q8k || !A.dk || !A.bsk || !A.bsq) return false;
+    const int ta = Wa[0]->type, tb = Wb[0]->type;
+    if (!((ta == GT_Q4_K || ta == GT_Q5_K) && tb == GT_Q6_K) || !ri_supported(ta, Wa[0]->rows, Wa[0]->cols)) return false;
+    RiArgs a{};
+    for (int i = 0; i < na + nb; i++) {
+        const QWeight *w = i < na ? Wa[i] : Wb[i - na]; const RiPlanes *r = i < na ? ria[i] : rib[i - na];
+        if (!r || !r->qs || w->type != (i < na ? ta : tb) || w->rows != Wa[0]->rows || w->cols != Wa[0]->cols) return false;
+        a.m[i].p = *r; a.m[i].y = i < na ? ya[i] : yb[i - na]; a.m[i].res = nullptr;
+    }
+    a.n_mat = na + nb; a.n_a = na; a.groups_each = Wa[0]->rows / 64; a.rows_each = Wa[0]->rows; a.K = Wa[0]->cols; a.N = N; a.ldy = ldy; a.ksplit = 1;
+    const int total = a.n_mat * a.groups_each, NSB = a.K / 256;
+    const bool wide = total < g_ri_cus;
+    const int wpb = wide ? 8 : 4;
+    const size_t lds = (size_t)4 * a.K + (size_t)4 * NSB * (16 + 32) + (size_t)4 * NSB * 4 + (size_t)wpb * 4 * 64 * 4;
+    if (lds > (wide ? 150u : 78u) * 1024u) return false;
+    const unsigned nbk = (unsigned)std::min(total, wide ? g_ri_cus : 2 * g_ri_cus);
+    if (ta == GT_Q4_K) { if (wide) launch_ri_mix_k<GT_Q4_K, GT_Q6_K, 8>(a, A, nbk, lds, s); else launch_ri_mix_k<GT_Q4_K, GT_Q6_K, 4>(a, A, nbk, lds, s); }
+    else { if (wide) launch_ri_mix_k<GT_Q5_K, GT_Q6_K, 8>(a, A, nbk, lds, s); else launch_ri_mix_k<GT_Q5_K, GT_Q6_K, 4>(a, A, nbk, lds, s); }
+    return true;
 }
 
 }  // namespace mg4

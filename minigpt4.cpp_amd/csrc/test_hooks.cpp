@@ -249,6 +249,48 @@ int minigpt4_amd_test_matvec_ri(int ggml_type, const void *raw_w, int n_mat, int
     });
 }
 
+// the mixed-type launch of a "more bits" layer: n_a matrices of type_a (Q4_K / Q5_K) + n_b of type_b (Q6_K), same shape -> y [n_a + n_b][N][n_out]
+int minigpt4_amd_test_matvec_ri_mixed(int type_a, const void *raw_a, int n_a, int type_b, const void *raw_b, int n_b, int64_t n_in, int64_t n_out, const float *x, int N, float *y) {
+    if (!raw_a || !raw_b || !x || !y || n_in <= 0 || n_out <= 0 || n_a < 1 || n_b < 1 || n_a + n_b > 3 || N < 1 || N > 4 || !qweight_supported(type_a) || !qweight_supported(type_b)) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const int K = (int)n_in, R = (int)n_out, n = n_a + n_b;
+        if (!ri_supported(type_a, R, K) || !ri_supported(type_b, R, K)) { set_last_error("type / shape outside the row-interleaved kernel's range"); return 4; }
+        std::vector<QWeight> W((size_t)n); std::vector<RiPlanes> P((size_t)n);
+        std::vector<std::unique_ptr<DevBuf>> hold;
+        for (int m = 0; m < n; m++) {
+            const int ty = m < n_a ? type_a : type_b;
+            QWeight plan; const size_t need = plan_qweight(ty, R, K, plan, nullptr), raw_bytes = gt_nbytes(ty, (size_t)R * K);
+            RiPlanes rplan; const size_t rneed = ri_plan(ty, R, K, rplan, nullptr);
+            hold.emplace_back(new DevBuf(need)); DevBuf &pl = *hold.back();
+            hold.emplace_back(new DevBuf(rneed)); DevBuf &rp = *hold.back();
+            DevBuf d_raw(raw_bytes);
+            const uint8_t *src = m < n_a ? (const uint8_t *)raw_a + (size_t)m * raw_bytes : (const uint8_t *)raw_b + (size_t)(m - n_a) * raw_bytes;
+            plan_qweight(ty, R, K, W[(size_t)m], pl.as<uint8_t>());
+            HIP_CHECK(hipMemcpy(d_raw.p, src, raw_bytes, hipMemcpyHostToDevice));
+            launch_repack(d_raw.as<uint8_t>(), W[(size_t)m], nullptr);
+            ri_plan(ty, R, K, P[(size_t)m], rp.as<uint8_t>());
+            launch_ri_build(W[(size_t)m], P[(size_t)m], nullptr);
+            HIP_CHECK(hipDeviceSynchronize());
+        }
+        DevBuf d_x((size_t)N * K * 4), d_y((size_t)n * N * R * 4);
+        HIP_CHECK(hipMemcpy(d_x.p, x, (size_t)N * K * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(d_y.p, 0xFF, (size_t)n * N * R * 4));
+        ActQ A; std::vector<std::unique_ptr<DevBuf>> keep; alloc_act(A, keep, (size_t)N, (size_t)K);
+        launch_rms_quant(d_x.as<float>(), nullptr, N, K, A, ACT_Q8K, nullptr);
+        const QWeight *Wa[2], *Wb[2]; const RiPlanes *Pa[2], *Pb[2]; float *Ya[2], *Yb[2];
+        for (int m = 0; m < n; m++) {
+            float *yo = d_y.as<float>() + (size_t)m * N * R;
+            if (m < n_a) { Wa[m] = &W[(size_t)m]; Pa[m] = &P[(size_t)m]; Ya[m] = yo; } else { Wb[m - n_a] = &W[(size_t)m]; Pb[m - n_a] = &P[(size_t)m]; Yb[m - n_a] = yo; }
+        }
+        hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0)); set_ri_cus(prop.multiProcessorCount);
+        if (!launch_matvec_ri_mixed(Wa, Pa, Ya, n_a, Wb, Pb, Yb, n_b, A, N, R, nullptr)) { set_last_error("launch_matvec_ri_mixed refused"); return 4; }
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(y, d_y.p, (size_t)n * N * R * 4, hipMemcpyDeviceToHost));
+        return 0;
+    });
+}
+
 // microseconds per launch of the row-interleaved MFMA mat-vec for one set of n_mat rows x cols matrices against N prepared rows; n_sets weight sets are rotated
 int minigpt4_amd_bench_matvec_ri(int ggml_type, int rows, int cols, int n_mat, int N, int iters, int n_sets, float *us_per_launch) {
     if (!ri_supported(ggml_type, rows, cols) || n_mat < 1 || n_mat > 3 || N < 1 || N > 4 || iters < 1 || n_sets < 1) return 1;

@@ -476,6 +476,18 @@ class MiniGPT4SharedLibrary:
             raise RuntimeError(f"test_matvec_ri rc={rc}: " + self.library.minigpt4_amd_last_error().decode())
         return y
 
+    def amd_test_matvec_ri_mixed(self, type_a: int, raw_a: np.ndarray, n_a: int, type_b: int, raw_b: np.ndarray, n_b: int, n_in: int, n_out: int, x: np.ndarray) -> np.ndarray:
+        """The mixed-type MFMA launch of a "more bits" layer (wq | wk of Q4_K / Q5_K + a Q6_K wv): x [N][n_in] (N <= 4) -> [n_a + n_b][N][n_out]."""
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, n_in)
+        raw_a, raw_b = np.ascontiguousarray(raw_a), np.ascontiguousarray(raw_b)
+        y = np.empty((n_a + n_b, x.shape[0], n_out), np.float32)
+        f = self.library.minigpt4_amd_test_matvec_ri_mixed
+        f.argtypes = [I32, VOID_PTR, I32, I32, VOID_PTR, I32, ctypes.c_int64, ctypes.c_int64, FLOAT_PTR, I32, FLOAT_PTR]
+        rc = f(type_a, raw_a.ctypes.data_as(VOID_PTR), n_a, type_b, raw_b.ctypes.data_as(VOID_PTR), n_b, n_in, n_out, x.ctypes.data_as(FLOAT_PTR), x.shape[0], y.ctypes.data_as(FLOAT_PTR))
+        if rc:
+            raise RuntimeError(f"test_matvec_ri_mixed rc={rc}: " + self.library.minigpt4_amd_last_error().decode())
+        return y
+
     def amd_test_quantize(self, x: np.ndarray, rms_w: Optional[np.ndarray] = None):
         x = np.ascontiguousarray(x, np.float32)
         N, K = x.shape

@@ -308,3 +308,31 @@ def test_row_interleaved_mfma_matvec_matches_oracle(gpu_lib, wtype, K, rows, n_m
         scale2 = np.abs(want2).max(axis=2, keepdims=True)
         assert np.isfinite(got2).all() and (np.abs(got2 - want2) <= 2e-5 * scale2).all(), (wtype, K, rows, N, float((np.abs(got2 - want2) / scale2).max()))
 
+
+
+@pytest.mark.parametrize("ta,K,rows", [("q5_k", 512, 128), ("q4_k", 4096, 4096), ("q5_k", 5120, 5120), ("q5_k", 5120, 2304)])
+@pytest.mark.parametrize("N", [1, 3, 4])
+def test_row_interleaved_mixed_type_launch_matches_the_single_type_launches(gpu_lib, ta, K, rows, N):
+    """A "more bits" layer's wq | wk (Q4_K / Q5_K) + wv (Q6_K) in one MFMA launch (k_matvec_ri_mix): the same per-group stream as k_matvec_ri with the digit images of both
+    types staged -> BIT-identical to the two single-type launches when the wave split of K is the same (both take the 8-wave or both the 4-wave form), the oracle's bar
+    otherwise; 3 x 5120 rows = 240 groups (< CUs: 8 waves), 3 x 4096 = 192, 3 x 2304 = 108."""
+    import refcpu as R
+    from minigpt4_cpp_amd import quants as Q
+    tA, tB = Q.NAME_TO_TYPE[ta], Q.NAME_TO_TYPE["q6_k"]
+    rng = np.random.default_rng(K * 7 + rows + N + sum(map(ord, ta)))
+    wa = (0.03 * rng.standard_normal((2 * rows, K))).astype(np.float32)
+    wb = (0.03 * rng.standard_normal((rows, K))).astype(np.float32)
+    wb[5, :] = -0.07
+    raw_a, raw_b = Q.quantize(tA, wa), Q.quantize(tB, wb)
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    if N > 1:
+        x[1] *= 19.0
+    got = gpu_lib.amd_test_matvec_ri_mixed(tA, raw_a, 2, tB, raw_b, 1, K, rows, x)
+    want = np.concatenate([R.mul_mat(tA, raw_a, K, 2 * rows, x).reshape(N, 2, rows).transpose(1, 0, 2), R.mul_mat(tB, raw_b, K, rows, x).reshape(N, 1, rows).transpose(1, 0, 2)])
+    assert got.shape == want.shape and np.isfinite(got).all()
+    scale = np.abs(want).max(axis=2, keepdims=True)
+    assert (np.abs(got - want) <= 2e-5 * scale).all(), (ta, K, rows, N, float((np.abs(got - want) / scale).max()))
+    # against the single-type launches of the same images
+    one_a, one_b = gpu_lib.amd_test_matvec_ri(tA, raw_a, 2, K, rows, x), gpu_lib.amd_test_matvec_ri(tB, raw_b, 1, K, rows, x)
+    single = np.concatenate([one_a, one_b])
+    assert (np.abs(got - single) <= 2e-5 * scale).all()
