@@ -123,6 +123,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (const char *e = getenv("MINIGPT4_MMQH")) set_mmqh(atoi(e));
     if (const char *e = getenv("MINIGPT4_COMPUTED_TABLES")) computed_tables_ = atoi(e) != 0;   // 0: the decode step gathers exp / SiLU from ggml's fp16 tables like rounds 1-4 (A/B)
     if (const char *e = getenv("MINIGPT4_RI_FUSE")) ri_fuse_ = atoi(e) != 0;       // 1: the MFMA batched launches norm + quantise their rows themselves (measured SLOWER: 864 vs 987 tok/s at B = 4; A/B)
+    if (const char *e = getenv("MINIGPT4_RI_W2")) ri_w2_ = atoi(e) != 0;          // 0: w2 of the 4-conversation step on the v_dot4 launch instead of the K-split MFMA launch (A/B: profiles/r05_batched_decode_inengine.log)
     if (const char *e = getenv("MINIGPT4_RI")) use_ri_ = atoi(e) != 0;             // 0: batched decode on the v_dot4 multi-row mat-vec (rounds 2-4), no row-interleaved image
     set_ri_cus(prop.multiProcessorCount);
     if (const char *e = getenv("MINIGPT4_QF_FOLD")) qf_fold_ = atoi(e) != 0;       // 0: the Q-Former's image-independent head is recomputed per encode (round-4 form, A/B)
@@ -918,16 +919,18 @@ void Engine::forward_batch(int B, hipStream_t s) {
     // px != null: the launch prepares its rows itself (rms_norm(px_t) * pw, quantised) -- only called when rows_pro() said the shape / type is in range
     // Does the row-interleaved MFMA launch serve this set?  Every matrix of one k-quant type and shape with its image built, AND where it was measured faster than the v_dot4
     // multi-row mat-vec (profiles/r05_batched_shapes.log, us per launch, dot4 / mfma at B = 2 | 3 | 4): sets of >= 128 row groups -- qkv 17.2/15.2 | 19.8/15.2 | 23.2/15.6,
-    // wq|wk 12.4/12.9 | 14.7/12.9 | 17.1/13.2, w1|w3 25.7/22.2 | 29.6/22.1 | 34.4/22.1, output 27.3/27.0 | 33.1/27.2 | 37.3/27.5 -- but not the 80-group matrices (wo 12.1/11.6,
-    // w2 22.5/21.7, a lone wv 12.1/13.4 at B = 4: one workgroup per group leaves two thirds of the CUs idle), and from 3 rows on: at B = 2 the v_dot4 launches prepare their
+    // wq|wk 12.4/12.9 | 14.7/12.9 | 17.1/13.2, w1|w3 25.7/22.2 | 29.6/22.1 | 34.4/22.1, output 27.3/27.0 | 33.1/27.2 | 37.3/27.5 -- but not wo (80 groups:
+    // 12.3/10.7 at B = 4, less than the standalone quantisation of the attention rows it would need) nor a lone wv; w2 only at B = 4 (below); and from 3 rows on: at B = 2 the v_dot4 launches prepare their
     // rows in their own prologue (two launches less per layer), which outweighs the 2-3.5 us the MFMA launch would save.
     auto ri_serves = [&](std::initializer_list<const QWeight *> Ws) {
         if (!ri_ready_ || B < 3 || B > 4) return false;
         const QWeight *w0 = *Ws.begin();
         int groups = 0;
         for (const QWeight *w : Ws) { if (!ri_of(w) || w->type != w0->type || w->rows != w0->rows || w->cols != w0->cols) return false; groups += w->rows / 64; }
-        // (the K-split form of k_matvec_ri -- three or four workgroups share a row group of a long-K matrix, last arriver adds the parts -- brings the 13B w2 from 22.5 to
-        // 19.8 us (Q5_K) / 21.7 us (Q6_K) per launch at B = 4, and the whole step nowhere: 978 vs 988 tok/s, profiles/r05_batched_decode_inengine.log.  Not used.)
+        // w2 (13B: 80 row groups x 54 super-blocks): three or four workgroups share a row group, each a K range, last arriver adds the parts.  With the first weight fetch ahead of
+        // the staging and batched staging loads the launch is 18.9 (Q5_K) / 20.8 us (Q6_K) against 22.8 / 22.4 for the v_dot4 kernel at B = 4 (equal at B = 3): 1037 vs 1018 tok/s,
+        // alternating on one box (profiles/r05_batched_decode_inengine.log)
+        if (ri_w2_ && B == 4 && Ws.size() == 1 && w0->cols >= 8192 && ri_ksplit(groups, w0->cols) > 1) return true;
         return groups >= 128;
     };
     auto mm = [&](std::initializer_list<const QWeight *> Ws, std::initializer_list<float *> ys, const float *res0, int ld, const float *px = nullptr, const float *pw = nullptr) {
@@ -1237,6 +1240,7 @@ void Engine::build_ri_planes() {
         else if (L.wk.type == L.wq.type && L.wv.type == GT_Q6_K && batch_mix_) for (const QWeight *w : {&L.wq, &L.wk, &L.wv}) ws.push_back(w);   // a "more bits" layer: k_matvec_ri_mix
         if (L.w1.type == L.w3.type) for (const QWeight *w : {&L.w1, &L.w3}) ws.push_back(w);
     }
+    if (ri_w2_) for (const LayerW &L : layers_) ws.push_back(&L.w2);
     ws.push_back(&output_);
     size_t total = 0;
     for (const QWeight *w : ws) { RiPlanes p; total += ri_plan(w->type, w->rows, w->cols, p, nullptr); }

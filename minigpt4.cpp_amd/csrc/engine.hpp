@@ -174,6 +174,7 @@ private:
     // round 5: B = 2..4 rows per weight pass on the int8 matrix cores over a row-interleaved second image of the k-quant matrices (ri_kernels.hip); built by
     // set_conversations(n > 1) -- a context with one conversation never pays the memory.  MINIGPT4_RI=0: the v_dot4 multi-row mat-vec of rounds 2-4 (A/B)
     bool computed_tables_ = true;
+    bool ri_w2_ = true;                                         // B = 4: w2 (80 row groups x long K) on the K-split form of k_matvec_ri (+1.9 %; MINIGPT4_RI_W2=0: the v_dot4 launch)
     bool use_ri_ = true, ri_ready_ = false, ri_fuse_ = false;   // ri_fuse_: rows prepared inside the MFMA launches -- measured slower (profiles/r05_batched_decode_inengine.log), off
     DeviceArena ri_arena_;
     float *ri_slabs_ = nullptr; size_t ri_slab_floats_ = 0; unsigned *ri_tickets_ = nullptr; int ri_ticket_n_ = 0;   // K-split workspace of k_matvec_ri (zeroed tickets)

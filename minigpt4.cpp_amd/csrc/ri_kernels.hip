@@ -84,9 +84,10 @@ __device__ __forceinline__ void ri_scale_min_words(const v4i_r &h, unsigned &scw
 __device__ __forceinline__ float ri_h2f(unsigned short h) { return __half2float(__ushort_as_half(h)); }
 
 // One super-block of one row group as a lane holds it: 8 units of ITS row (16 B each), the high bits, the 16-byte scale header (Q6_K: 16 int8 scales) and Q6_K's fp16 d
-template <int T> struct RiRaw { v4i_r q[8]; unsigned p[T == GT_Q6_K ? 16 : (T == GT_Q5_K ? 8 : 1)]; v4i_r h; unsigned short d; };
+// (one type for every format -- only the words a format uses are ever live -- so that the mixed launch can carry ONE prefetched image across its prologue)
+struct RiRaw { v4i_r q[8]; unsigned p[16]; v4i_r h; unsigned short d; };
 template <int T>
-__device__ __forceinline__ void ri_fetch(const uint8_t *pq, const uint8_t *pp, const uint8_t *ph, const uint8_t *pd, int sb, int NSB, RiRaw<T> &r) {
+__device__ __forceinline__ void ri_fetch(const uint8_t *pq, const uint8_t *pp, const uint8_t *ph, const uint8_t *pd, int sb, int NSB, RiRaw &r) {
     constexpr bool Q6 = T == GT_Q6_K, Q5 = T == GT_Q5_K;
     const int sbc = min(sb, NSB - 1);               // every load unconditional (clamped super-block): counted waits
 #pragma unroll
@@ -101,7 +102,7 @@ __device__ __forceinline__ void ri_fetch(const uint8_t *pq, const uint8_t *pp, c
 }
 // acc[t] += (this lane's weight row, super-block sb) . (token row t); qa / da: the LDS image of the token row this lane feeds the A operand from (row lane & 3)
 template <int T>
-__device__ __forceinline__ void ri_consume(const int8_t *qa, const int8_t *da, const float *dk, int NSB, int sb, const RiRaw<T> &r, float (&acc)[4]) {
+__device__ __forceinline__ void ri_consume(const int8_t *qa, const int8_t *da, const float *dk, int NSB, int sb, const RiRaw &r, float (&acc)[4]) {
     constexpr bool Q6 = T == GT_Q6_K, Q5 = T == GT_Q5_K;
     int isum[4] = {0, 0, 0, 0};
     unsigned scw0 = 0, scw1 = 0, mw0 = 0, mw1 = 0;
@@ -153,25 +154,48 @@ __device__ __forceinline__ void ri_consume(const int8_t *qa, const int8_t *da, c
         for (int t = 0; t < 4; t++) acc[t] = fmaf(d * dk[t * NSB + sb], (float)(isum[t] - 32 * (Ch[t] * 128 + Cl[t])), acc[t]);
     }
 }
-// super-blocks [sb0, sb1) of row group gl of one matrix, two-stage register pipeline
+// super-blocks [sb0, sb1) of row group gl of one matrix, two-stage register pipeline; `cur` already holds super-block sb0 (ri_fetch issued by the caller: for a workgroup's
+// first task BEFORE it stages the activation image, so that the first weight bytes are in flight during the prologue)
+struct RiPtr { const uint8_t *pq, *pp, *ph, *pd; };
 template <int T>
-__device__ __forceinline__ void ri_stream(const RiPlanes &P, int gl, int U, int NSB, int lane, int sb0, int sb1, const int8_t *qa, const int8_t *da, const float *dk, float (&acc)[4]) {
+__device__ __forceinline__ RiPtr ri_ptrs(const RiPlanes &P, int gl, int U, int NSB, int lane) {
     constexpr bool Q6 = T == GT_Q6_K;
-    const uint8_t *pq = P.qs + (size_t)gl * U * 1024 + lane * 16, *pp = P.qh + (size_t)gl * U * (Q6 ? 512 : 256) + lane * (Q6 ? 8 : 4);
-    const uint8_t *ph = P.sc + (size_t)gl * NSB * 1024 + lane * 16, *pd = P.d + (size_t)gl * NSB * 128 + lane * 2;
-    RiRaw<T> cur, nxt;
-    ri_fetch<T>(pq, pp, ph, pd, sb0, NSB, cur);
+    return RiPtr{P.qs + (size_t)gl * U * 1024 + lane * 16, P.qh + (size_t)gl * U * (Q6 ? 512 : 256) + lane * (Q6 ? 8 : 4), P.sc + (size_t)gl * NSB * 1024 + lane * 16, P.d + (size_t)gl * NSB * 128 + lane * 2};
+}
+template <int T>
+__device__ __forceinline__ void ri_stream(const RiPtr &p, int NSB, int sb0, int sb1, const int8_t *qa, const int8_t *da, const float *dk, float (&acc)[4], RiRaw &cur) {
+    RiRaw nxt;
     for (int sb = sb0; sb < sb1;) {
-        ri_fetch<T>(pq, pp, ph, pd, sb + 1, NSB, nxt);
+        ri_fetch<T>(p.pq, p.pp, p.ph, p.pd, sb + 1, NSB, nxt);
         __builtin_amdgcn_sched_barrier(0);
         ri_consume<T>(qa, da, dk, NSB, sb, cur, acc);
         __builtin_amdgcn_sched_barrier(0);
         if (++sb >= sb1) break;
-        ri_fetch<T>(pq, pp, ph, pd, sb + 1, NSB, cur);
+        ri_fetch<T>(p.pq, p.pp, p.ph, p.pd, sb + 1, NSB, cur);
         __builtin_amdgcn_sched_barrier(0);
         ri_consume<T>(qa, da, dk, NSB, sb, nxt, acc);
         __builtin_amdgcn_sched_barrier(0);
         ++sb;
+    }
+}
+// the <= 4 quantised rows -> LDS, K range [c_sb0, c_sb1) super-blocks; the loads of a batch are all issued before its first LDS store (one memory round trip per batch
+// instead of one per 16 bytes and thread)
+__device__ __forceinline__ void ri_stage_rows(const ActQ &A, int8_t *q8, int N, int K, int c_sb0, int c_sb1, int NT) {
+    constexpr int SB = 6;
+    const int cK = (c_sb1 - c_sb0) * 256, lim = 4 * cK, step = NT * 16;
+    for (int base = threadIdx.x * 16; base < lim; base += step * SB) {
+        v4i_r v[SB];
+#pragma unroll
+        for (int j = 0; j < SB; j++) {
+            const int i = base + j * step;
+            const v4i_r z = {0, 0, 0, 0}; v[j] = z;
+            if (i < lim) { const int t = i / cK, e = c_sb0 * 256 + (i - t * cK); if (t < N) v[j] = *reinterpret_cast<const v4i_r *>(A.q8k + (size_t)t * K + e); }
+        }
+#pragma unroll
+        for (int j = 0; j < SB; j++) {
+            const int i = base + j * step;
+            if (i < lim) { const int t = i / cK, e = c_sb0 * 256 + (i - t * cK); *reinterpret_cast<v4i_r *>(q8 + (size_t)t * K + e) = v[j]; }
+        }
     }
 }
 // the digit image of the rows' block sums for type T (header below), super-blocks [c_sb0, c_sb1); dk != null: the rows' Q8_K scales too.  NT = threads of the workgroup
@@ -208,7 +232,7 @@ __device__ __forceinline__ void ri_stage_digits(const ActQ &A, int8_t *dg, float
 // output matrix (~5 us each against ~1 us of redundant work per workgroup).
 template <int T, int WPB, bool PRO>
 __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const ActQ A) {
-    constexpr bool Q6 = T == GT_Q6_K, Q5 = T == GT_Q5_K;
+    constexpr bool Q6 = T == GT_Q6_K;
     constexpr int DG = Q6 ? 32 : 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ri[];
     const int K = a.K, U = K / 32, NSB = K / 256, N = a.N;
@@ -218,6 +242,19 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
     float *dk = reinterpret_cast<float *>(dg + 4 * NSB * DG);
     float *red = dk + 4 * NSB;
     int16_t *bsl = reinterpret_cast<int16_t *>(red + WPB * 4 * 64);       // PRO: the rows' 16-element sums [4][K / 16] (quantiser output; Q6_K's digit image is derived from them)
+    const int S = a.ksplit > 1 ? a.ksplit : 1;
+    const int total_groups = a.n_mat * a.groups_each;
+    // task -> (row group g of matrix m, K part, this wave's super-block range)
+    struct Task { int g, m, gl, sb0, sb1; };
+    auto task_of = [&](int task) {
+        Task k; k.g = task / S; const int part = task - k.g * S;
+        const int psb0 = (int)((long long)NSB * part / S), psb1 = (int)((long long)NSB * (part + 1) / S);       // this workgroup's K range
+        const int sb_per = (psb1 - psb0 + WPB - 1) / WPB; k.sb0 = psb0 + wv * sb_per; k.sb1 = min(psb1, k.sb0 + sb_per);
+        k.m = k.g / a.groups_each; k.gl = k.g - k.m * a.groups_each;
+        return k;
+    };
+    RiRaw cur;
+    { const Task k = task_of((int)blockIdx.x); const RiPtr p = ri_ptrs<T>(a.m[k.m].p, k.gl, U, NSB, lane); ri_fetch<T>(p.pq, p.pp, p.ph, p.pd, k.sb0, NSB, cur); }   // (grid <= tasks)
     if constexpr (PRO) {
         constexpr int NT = 64 * WPB;
         ActQ L{}; L.q8k = q8; L.dk = dk; L.bsk = bsl; L.bsq = Q6 ? nullptr : dg;
@@ -266,29 +303,21 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
     // would move more bytes than a third of the weights)
     int c_sb0 = 0, c_sb1 = NSB;
     if (a.ksplit > 1 && (int)gridDim.x >= a.n_mat * a.groups_each * a.ksplit) { const int part = (int)blockIdx.x % a.ksplit; c_sb0 = (int)((long long)NSB * part / a.ksplit); c_sb1 = (int)((long long)NSB * (part + 1) / a.ksplit); }
-    const int cK = (c_sb1 - c_sb0) * 256;
-    for (int i = threadIdx.x * 16; i < 4 * cK; i += 64 * WPB * 16) {
-        const int t = i / cK, e = c_sb0 * 256 + (i - t * cK);
-        v4i_r v = {0, 0, 0, 0};
-        if (t < N) v = *reinterpret_cast<const v4i_r *>(A.q8k + (size_t)t * K + e);
-        *reinterpret_cast<v4i_r *>(q8 + (size_t)t * K + e) = v;
-    }
+    ri_stage_rows(A, q8, N, K, c_sb0, c_sb1, 64 * WPB);
     ri_stage_digits<T>(A, dg, dk, N, NSB, K, c_sb0, c_sb1, 64 * WPB);
     }
     __syncthreads();
-    const int S = a.ksplit > 1 ? a.ksplit : 1;
     __shared__ int s_last;
     const int8_t *qa = q8 + (size_t)t4 * K;
     const int8_t *da = dg + (size_t)t4 * NSB * DG;
-    const int total_groups = a.n_mat * a.groups_each;
     for (int task = blockIdx.x; task < total_groups * S; task += gridDim.x) {
-        const int g = task / S, part = task - g * S;
-        const int psb0 = (int)((long long)NSB * part / S), psb1 = (int)((long long)NSB * (part + 1) / S);       // this workgroup's K range
-        const int sb_per = (psb1 - psb0 + WPB - 1) / WPB, sb0 = psb0 + wv * sb_per, sb1 = min(psb1, sb0 + sb_per);
-        const int m = g / a.groups_each, gl = g - m * a.groups_each;
-        const RiMat &M = a.m[m];
+        const Task tk = task_of(task);
+        const int g = tk.g, gl = tk.gl;
+        const RiMat &M = a.m[tk.m];
+        const RiPtr wp = ri_ptrs<T>(M.p, gl, U, NSB, lane);
+        if (task != (int)blockIdx.x) ri_fetch<T>(wp.pq, wp.pp, wp.ph, wp.pd, tk.sb0, NSB, cur);
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        ri_stream<T>(M.p, gl, U, NSB, lane, sb0, sb1, qa, da, dk, acc);
+        ri_stream<T>(wp, NSB, tk.sb0, tk.sb1, qa, da, dk, acc, cur);
         // the K ranges of the WPB waves, combined in wave order
 #pragma unroll
         for (int t = 0; t < 4; t++) red[(wv * 4 + t) * 64 + lane] = acc[t];
@@ -337,23 +366,26 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri_mix(const RiArgs a, c
     int8_t *dga = q8 + 4 * K, *dgb = dga + 4 * NSB * DGA;
     float *dk = reinterpret_cast<float *>(dgb + 4 * NSB * DGB);
     float *red = dk + 4 * NSB;
-    for (int i = threadIdx.x * 16; i < 4 * K; i += 64 * WPB * 16) {
-        const int t = i / K;
-        v4i_r v = {0, 0, 0, 0};
-        if (t < N) v = *reinterpret_cast<const v4i_r *>(A.q8k + i);
-        *reinterpret_cast<v4i_r *>(q8 + i) = v;
-    }
+    const int sb_per = (NSB + WPB - 1) / WPB, sb0 = wv * sb_per, sb1 = min(NSB, sb0 + sb_per);
+    // (no prefetch across the prologue here: one register image that either type may have filled stays live in full through both branches -- 324-396 B of scratch)
+    ri_stage_rows(A, q8, N, K, 0, NSB, 64 * WPB);
     ri_stage_digits<TA>(A, dga, dk, N, NSB, K, 0, NSB, 64 * WPB);
     ri_stage_digits<TB>(A, dgb, nullptr, N, NSB, K, 0, NSB, 64 * WPB);
     __syncthreads();
     const int8_t *qa = q8 + (size_t)t4 * K;
-    const int sb_per = (NSB + WPB - 1) / WPB, sb0 = wv * sb_per, sb1 = min(NSB, sb0 + sb_per);
     for (int g = blockIdx.x; g < a.n_mat * a.groups_each; g += gridDim.x) {
         const int m = g / a.groups_each, gl = g - m * a.groups_each;
         const RiMat &M = a.m[m];
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (m < a.n_a) ri_stream<TA>(M.p, gl, U, NSB, lane, sb0, sb1, qa, dga + (size_t)t4 * NSB * DGA, dk, acc);      // workgroup-uniform branch
-        else ri_stream<TB>(M.p, gl, U, NSB, lane, sb0, sb1, qa, dgb + (size_t)t4 * NSB * DGB, dk, acc);
+        if (m < a.n_a) {                                                                                          // workgroup-uniform branch
+            const RiPtr p = ri_ptrs<TA>(M.p, gl, U, NSB, lane);
+            RiRaw cur; ri_fetch<TA>(p.pq, p.pp, p.ph, p.pd, sb0, NSB, cur);
+            ri_stream<TA>(p, NSB, sb0, sb1, qa, dga + (size_t)t4 * NSB * DGA, dk, acc, cur);
+        } else {
+            const RiPtr p = ri_ptrs<TB>(M.p, gl, U, NSB, lane);
+            RiRaw cur; ri_fetch<TB>(p.pq, p.pp, p.ph, p.pd, sb0, NSB, cur);
+            ri_stream<TB>(p, NSB, sb0, sb1, qa, dgb + (size_t)t4 * NSB * DGB, dk, acc, cur);
+        }
 #pragma unroll
         for (int t = 0; t < 4; t++) red[(wv * 4 + t) * 64 + lane] = acc[t];
         __syncthreads();
