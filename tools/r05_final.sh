@@ -5,7 +5,7 @@ set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/r05z
 mkdir -p $OUT
-timeout 1500 python -m pytest tests -m gpu -x -q --tb=short 2>&1 | tee $OUT/01_pytest_gpu.log | tail -4
+timeout 1500 python -m pytest tests -m gpu -x -q --tb=short -rs 2>&1 | tee $OUT/01_pytest_gpu.log | tail -4
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout 900 python bench.py > $OUT/02_bench.json 2> $OUT/02_bench.err; tail -2 $OUT/02_bench.err; python -c "
 import json;d=json.load(open('$OUT/02_bench.json'));print({k:d[k] for k in ['value','ms_per_step','prefill_ms','image_encode_ms','image_encode_device_ms','model_load_s','parity_mode_tokens_per_s']}); r=d['roofline']; print(r['kernel'], r['avg_launch_us'], r.get('timing'), r['frac'], r.get('kernel_sum_ms_per_token'), d['ms_per_step'], r.get('traffic'), r['whole_step'])
