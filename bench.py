@@ -210,8 +210,8 @@ def extra_config_legs(lib, budget_s: float) -> dict:
             res[key] = {"error": str(e)[:300]}
     # configs[1]: MiniGPT4-7B f16 vision + Vicuna-7B Q4_0, batch 1, 128 greedy tokens through the C ABI
     decode_leg("7b_q4_0_decode128", "7b", "MiniGPT4-7B f16 vision + Vicuna-7B Q4_0 (output Q6_K), batch 1, 128 greedy tokens through the C ABI (BASELINE.json configs[1])")
-    # round 5: the type mix of the file a user of the reference really loads (n_vocab 32001 -> output.weight F16, tok_embeddings Q4_0: 9.310 GB per token), and the two other
-    # block types north_star names (Q8_0, Q4_1) as whole-model decode rates
+    # round 5: the type mix of the file a user of the reference really loads (n_vocab 32001 -> output.weight F16, tok_embeddings Q4_0: 9.310 GB per
+    # token), and the two other block types north_star names (Q8_0, Q4_1) as whole-model decode rates
     decode_leg("13b_q5k_vocab32001_decode128", "13b_v32001", "MiniGPT4-13B f16 vision + Vicuna-13B Q5_K_M with Vicuna-v0's real n_vocab = 32001 (llama.cpp's k-quant fallback: output.weight F16, "
                "tok_embeddings Q4_0), batch 1, 128 greedy tokens through the C ABI", keep_file=False)
     decode_leg("7b_q8_0_decode128", "7b_q8_0", "MiniGPT4-7B f16 vision + Vicuna-7B Q8_0 (every matrix), batch 1, 128 greedy tokens through the C ABI", keep_file=False)
@@ -305,8 +305,8 @@ def main():
     vp, lp, vcfg, lcfg = make_models(args.config, rank, world, barrier)
     if args.n_ctx <= 0:   # the reference default is 2048; grow it only when the requested run does not fit
         args.n_ctx = max(2048, (200 + args.steps + args.warmup + 64 + 255) // 256 * 256)
-    # ---- load: rank 0 reads the files; with N > 1 every other rank loads in receive mode (headers only) and gets both weight arenas by RCCL broadcast over xGMI
-    # (minigpt4.cpp_amd/dist.py::load_replica checks that the arena layouts agree before and the arena checksums after)
+    # ---- load: rank 0 reads the files; with N > 1 every other rank loads in receive mode (headers only) and gets both weight arenas by RCCL
+    # broadcast over xGMI (minigpt4.cpp_amd/dist.py::load_replica checks that the arena layouts agree before and the arena checksums after)
     from minigpt4_cpp_amd import dist as D
     dev = None
     if dist is not None:
@@ -350,8 +350,8 @@ def main():
     except Exception as e:
         enc_batch = {"error": str(e)}
 
-    # ---- prefill: system prompt + image turn (reference call sequence, examples/main.cpp:207-293)
-    # twice: the first pass of a process also loads the prompt kernels' code objects and sets their attributes (reported as prefill_first_ms); the chat is reset in between
+    # ---- prefill: system prompt + image turn (reference call sequence, examples/main.cpp:207-293) twice: the first pass of a process also loads the
+    # prompt kernels' code objects and sets their attributes (reported as prefill_first_ms); the chat is reset in between
     prefill_first_ms = None
     for _pass in range(2):
         if _pass:
@@ -386,10 +386,10 @@ def main():
         dt = float(tt.item())
     ctx_mid = n_prompt + W + K // 2
 
-    # ---- device-side numbers: graph-replayed decode loop (no host round trip), and the per-launch-site table of the SAME launch set the graph replays (eager, a hipEvent
-    # pair around every site on the engine's stream; Engine::profile_sites).  The roofline object is computed from that table, per kernel SYMBOL (a symbol that serves
-    # several sites -- wq|wk|wv and w1|w3 share one -- is aggregated exactly as `rocprofv3 --stats` aggregates it, so tools/roofline_from_profile.py reproduces `frac`
-    # from a committed profiles/*kernel_stats.csv and this table).
+    # ---- device-side numbers: graph-replayed decode loop (no host round trip), and the per-launch-site table of the SAME launch set the graph
+    # replays (eager, a hipEvent pair around every site on the engine's stream; Engine::profile_sites).  The roofline object is computed from that
+    # table, per kernel SYMBOL (a symbol that serves several sites -- wq|wk|wv and w1|w3 share one -- is aggregated exactly as `rocprofv3 --stats`
+    # aggregates it, so tools/roofline_from_profile.py reproduces `frac` from a committed profiles/*kernel_stats.csv and this table).
     _, loop_ms = lib.amd_decode_loop(ctx, 17)
     dev_ms_per_tok = loop_ms / 16.0
     prof = lib.amd_profile_sites(ctx, 8)
@@ -446,8 +446,9 @@ def main():
         "weight_bcast": D.bcast_report(lstats), "load_mode": lstats["mode"],
         "roofline": roofline,
     }
-    # ---- extra leg (not the headline): decode rate at long contexts (the reference's default n_ctx is 2048, examples/main.cpp:128-131): random prompt rows up to the
-    # context, then a device-resident greedy loop.  From 768 cached keys on the step uses the key-split attention launches (k_attn_split_*).
+    # ---- extra leg (not the headline): decode rate at long contexts (the reference's default n_ctx is 2048, examples/main.cpp:128-131): random
+    # prompt rows up to the context, then a device-resident greedy loop.  From 768 cached keys on the step uses the key-split attention launches
+    # (k_attn_split_*).
     if args.n_ctx >= 2048 and args.long_context:
         try:
             rng = np.random.default_rng(3)
@@ -498,8 +499,9 @@ def main():
                                          tokens_per_s_per_gpu_min=min((x["tokens_per_s_per_gpu"] for x in good), default=None),
                                          ms_per_step_max_over_ranks=max((x["ms_per_step"] for x in good), default=None),
                                          errors=[x["error"] for x in legs if "error" in x] or None) if legs else {"error": "no rank reported"}
-    # ---- extra leg: BASELINE.json configs[3]'s per-GPU share END TO END through the request server (minigpt4.cpp_amd/serve.py): 4 requests = one pass of the vision
-    # tower over 4 images + 4 system-prompt / image-turn prefills + batched decode of 64 tokens each (EOS ignored), own context; requests/s and tokens/s per replica
+    # ---- extra leg: BASELINE.json configs[3]'s per-GPU share END TO END through the request server (minigpt4.cpp_amd/serve.py): 4 requests = one
+    # pass of the vision tower over 4 images + 4 system-prompt / image-turn prefills + batched decode of 64 tokens each (EOS ignored), own context;
+    # requests/s and tokens/s per replica
     if args.conversations > 1 and rank == 0 and args.config == "13b":
         try:
             from minigpt4_cpp_amd import serve as S
@@ -521,8 +523,9 @@ def main():
                 srv.close()
         except Exception as e:
             out["configs3_share_per_gpu"] = {"error": str(e)[:300]}
-    # ---- the bit-exact mode as a measured mode (MINIGPT4_PARITY / minigpt4_amd_set_parity: every fp32 accumulation in the CPU oracle's order; logits and greedy ids equal
-    # the oracle's bit for bit -- asserted by `parity.parity_mode` below and tests/test_gpu_headline.py): same file, same prompt, 32 greedy steps through the C ABI
+    # ---- the bit-exact mode as a measured mode (MINIGPT4_PARITY / minigpt4_amd_set_parity: every fp32 accumulation in the CPU oracle's order; logits
+    # and greedy ids equal the oracle's bit for bit -- asserted by `parity.parity_mode` below and tests/test_gpu_headline.py): same file, same prompt,
+    # 32 greedy steps through the C ABI
     try:
         if args.conversations > 1:
             lib.amd_set_conversations(ctx, 1)
@@ -552,15 +555,15 @@ def main():
                     "parity (parity_mode_tokens_per_s)": "MINIGPT4_PARITY=1: fp32 accumulation in the oracle's order -- logits and greedy ids bit-identical to the CPU oracle"}
     out["prefill_ms_definition"] = ("prefill_ms = the SECOND system-prompt + image-turn pass of the process (warm code objects), prefill_first_ms = the first pass; rounds 1-2 reported "
                                     "the first pass as prefill_ms")
-    # ---- BASELINE.json configs[1] (7B Q4_0, batch 1, 128-token decode) and configs[4] (13B f16 unquantised, one 512-token llama_eval) on this GPU: not the headline, reported
-    # under `configs`; each leg starts only while the run is younger than --extra-budget-s and says so when it is skipped
+    # ---- BASELINE.json configs[1] (7B Q4_0, batch 1, 128-token decode) and configs[4] (13B f16 unquantised, one 512-token llama_eval) on this GPU:
+    # not the headline, reported under `configs`; each leg starts only while the run is younger than --extra-budget-s and says so when it is skipped
     if rank == 0 and world == 1 and args.extra_configs and args.config == "13b":
         out["configs"] = extra_config_legs(lib, args.extra_budget_s)
-    # the CPU legs run on rank 0 at every world size (the other ranks wait at the closing barrier; their host threads sleep in it), so an N > 1 line carries
-    # `cpu_baseline` and `parity` like the N = 1 line
+    # the CPU legs run on rank 0 at every world size (the other ranks wait at the closing barrier; their host threads sleep in it), so an N > 1 line
+    # carries `cpu_baseline` and `parity` like the N = 1 line
     if rank == 0 and not args.no_cpu_baseline:
-        # ---- parity on the measured file (checker use of the oracle, inside the cpu_baseline leg): the reference call sequence on both engines, same image
-        # embedding, same prompt -- free-running greedy pieces + teacher-forced logits of every step (oracle/headline.py)
+        # ---- parity on the measured file (checker use of the oracle, inside the cpu_baseline leg): the reference call sequence on both engines, same
+        # image embedding, same prompt -- free-running greedy pieces + teacher-forced logits of every step (oracle/headline.py)
         try:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import headline as H

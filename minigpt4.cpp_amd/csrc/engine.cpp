@@ -24,7 +24,8 @@ int device_count_noexcept() {
 void DeviceArena::alloc(size_t bytes) {
     release();
     if (virt) base = reinterpret_cast<uint8_t *>((uintptr_t)1 << 40);      // never dereferenced
-    else { HIP_CHECK(hipMalloc((void **)&base, bytes)); HIP_CHECK(hipMemset(base, 0, bytes)); HIP_CHECK(hipDeviceSynchronize()); }   // alignment gaps / plane padding are part of what arena checksums cover: make them deterministic
+    // alignment gaps / plane padding are part of what arena checksums cover: make them deterministic
+    else { HIP_CHECK(hipMalloc((void **)&base, bytes)); HIP_CHECK(hipMemset(base, 0, bytes)); HIP_CHECK(hipDeviceSynchronize()); }
     cap = bytes; used = 0; layout_hash = 1469598103934665603ull;
 }
 void DeviceArena::release() { if (base && !virt) HIP_IGNORE(hipFree(base)); base = nullptr; cap = used = 0; }
@@ -108,41 +109,52 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     n_ctx_ = n_ctx > 0 ? n_ctx : 2048;
     n_batch_ = n_batch > 0 ? n_batch : 512;
     max_rows_ = std::max(n_batch_, 32);
-    // Run-time switches read here, once (no launcher calls getenv).  What is left after round 4's pruning: device / conversation count / load mode / parity mode, the graph
-    // switch the profiling tools use, and the five arms the bit-identity tests compare against (tests/test_gpu_parity.py, tests/test_gpu_batch.py).  Tile shapes, K splits and
-    // the other experiment parameters are reachable only through the test library's setters (include/minigpt4_amd_test.h).
+    // Run-time switches read here, once (no launcher calls getenv).  What is left after round 4's pruning: device / conversation count / load mode /
+    // parity mode, the graph switch the profiling tools use, and the five arms the bit-identity tests compare against (tests/test_gpu_parity.py,
+    // tests/test_gpu_batch.py).  Tile shapes, K splits and the other experiment parameters are reachable only through the test library's setters
+    // (include/minigpt4_amd_test.h).
     use_graph_ = !(getenv("MINIGPT4_NO_GRAPH") && atoi(getenv("MINIGPT4_NO_GRAPH")));
     max_chunk_ = max_rows_;
     if (getenv("MINIGPT4_ATTN_PREFILL_W8")) set_attn_prefill_w8(atoi(getenv("MINIGPT4_ATTN_PREFILL_W8")));   // 0: prompt attention without the 8-wave loader / MFMA form
     if (const char *dc = getenv("MINIGPT4_DEFER_COMBINE")) defer_combine_ = atoi(dc) != 0;                    // 0: every K-split combine as its own launch
-    if (const char *fp = getenv("MINIGPT4_F16_PAIR")) f16_pair_ = atoi(fp);        // bit mask: 1 w1|w3 + silu*mul in one launch, 4 the attention kernel stores fp16 rows for wo
-    batch_mix_ = !(getenv("MINIGPT4_BATCH_MIX") && atoi(getenv("MINIGPT4_BATCH_MIX")) == 0);                 // 0: wq|wk and wv of a mixed-type layer as two launches (batched step)
+    // bit mask: 1 w1|w3 + silu*mul in one launch, 4 the attention kernel stores fp16 rows for wo
+    if (const char *fp = getenv("MINIGPT4_F16_PAIR")) f16_pair_ = atoi(fp);
+    // 0: wq|wk and wv of a mixed-type layer as two launches (batched step)
+    batch_mix_ = !(getenv("MINIGPT4_BATCH_MIX") && atoi(getenv("MINIGPT4_BATCH_MIX")) == 0);
     if (const char *e = getenv("MINIGPT4_ATTN_SPLIT_T")) attn_split_t_ = atoi(e);   // cached keys from which the decode step uses the key-split attention (0 = never)
     n_cus_ = prop.multiProcessorCount;
-    // 1: Q4_K / Q5_K prompt rows on the fp16-MFMA form with scaled operands (k_mmqh_q45k: measured SLOWER, profiles/r05_prefill_fp16_scaled_operands.md; A/B)
+    // 1: Q4_K / Q5_K prompt rows on the fp16-MFMA form with scaled operands (k_mmqh_q45k: measured SLOWER,
+    // profiles/r05_prefill_fp16_scaled_operands.md; A/B)
     if (const char *e = getenv("MINIGPT4_MMQH")) set_mmqh(atoi(e));
-    if (const char *e = getenv("MINIGPT4_COMPUTED_TABLES")) computed_tables_ = atoi(e) != 0;   // 0: the decode step gathers exp / SiLU from ggml's fp16 tables like rounds 1-4 (A/B)
-    if (const char *e = getenv("MINIGPT4_RI_FUSE")) ri_fuse_ = atoi(e) != 0;       // 1: the MFMA batched launches norm + quantise their rows themselves (measured SLOWER: 864 vs 987 tok/s at B = 4; A/B)
-    if (const char *e = getenv("MINIGPT4_RI_W2")) ri_w2_ = atoi(e) != 0;          // 0: w2 of the 4-conversation step on the v_dot4 launch instead of the K-split MFMA launch (A/B: profiles/r05_batched_decode_inengine.log)
-    if (const char *e = getenv("MINIGPT4_RI")) use_ri_ = atoi(e) != 0;             // 0: batched decode on the v_dot4 multi-row mat-vec (rounds 2-4), no row-interleaved image
+    // 0: the decode step gathers exp / SiLU from ggml's fp16 tables like rounds 1-4 (A/B)
+    if (const char *e = getenv("MINIGPT4_COMPUTED_TABLES")) computed_tables_ = atoi(e) != 0;
+    // 1: the MFMA batched launches norm + quantise their rows themselves (measured SLOWER: 864 vs 987 tok/s at B = 4; A/B)
+    if (const char *e = getenv("MINIGPT4_RI_FUSE")) ri_fuse_ = atoi(e) != 0;
+    // 0: w2 of the 4-conversation step on the v_dot4 launch instead of the K-split MFMA launch (A/B: profiles/r05_batched_decode_inengine.log)
+    if (const char *e = getenv("MINIGPT4_RI_W2")) ri_w2_ = atoi(e) != 0;
+    // 0: batched decode on the v_dot4 multi-row mat-vec (rounds 2-4), no row-interleaved image
+    if (const char *e = getenv("MINIGPT4_RI")) use_ri_ = atoi(e) != 0;
     set_ri_cus(prop.multiProcessorCount);
-    if (const char *e = getenv("MINIGPT4_QF_FOLD")) qf_fold_ = atoi(e) != 0;       // 0: the Q-Former's image-independent head is recomputed per encode (round-4 form, A/B)
+    // 0: the Q-Former's image-independent head is recomputed per encode (round-4 form, A/B)
+    if (const char *e = getenv("MINIGPT4_QF_FOLD")) qf_fold_ = atoi(e) != 0;
     if (const char *e = getenv("MINIGPT4_KV_HOIST")) kv_hoist_ = atoi(e) != 0;     // 0: one K | V projection GEMM per cross-attention layer (round-4 form, A/B)
     set_matvec_tuning(0, 0, prop.multiProcessorCount);
     if (const char *ns = getenv("MINIGPT4_CONVERSATIONS")) conv_.assign((size_t)std::max(1, std::min(MAX_CONVERSATIONS, atoi(ns))), Conversation{});
     sampler_.seed(seed);
     if (const char *tf = getenv("MINIGPT4_PARITY_TRACE")) { if (*tf) trace_file_ = fopen(tf, "wb"); }
-    parity_ = trace_file_ || (getenv("MINIGPT4_PARITY") && atoi(getenv("MINIGPT4_PARITY")));   // oracle-order fp32 accumulation (forward_ref): bit-identical to the CPU oracle, slow
+    // oracle-order fp32 accumulation (forward_ref): bit-identical to the CPU oracle, slow
+    parity_ = trace_file_ || (getenv("MINIGPT4_PARITY") && atoi(getenv("MINIGPT4_PARITY")));
     if (const char *lm = getenv("MINIGPT4_LOAD")) load_mode_ = !strcmp(lm, "recv") ? LOAD_RECV : LOAD_FULL;
-    // native multi-GPU load (dist.hpp): MINIGPT4_WORLD_SIZE / MINIGPT4_RANK / MINIGPT4_NCCL_ID_FILE -> rank 0 reads the files, every other rank loads headers only and
-    // receives both weight arenas by ncclBroadcast inside this call
+    // native multi-GPU load (dist.hpp): MINIGPT4_WORLD_SIZE / MINIGPT4_RANK / MINIGPT4_NCCL_ID_FILE -> rank 0 reads the files, every other rank loads
+    // headers only and receives both weight arenas by ncclBroadcast inside this call
     DistEnv dist; { std::string derr; if (parse_dist_env(dist, derr)) { set_last_error(derr); MG4_ERR("%s", derr.c_str()); return E_LoadLanguageModel; } }
     if (dist.active()) {
-        load_mode_ = dist.rank != 0 ? LOAD_RECV : LOAD_FULL;               // the exchange decides who reads the files: MINIGPT4_LOAD=recv on rank 0 would broadcast empty arenas
+        // the exchange decides who reads the files: MINIGPT4_LOAD=recv on rank 0 would broadcast empty arenas
+        load_mode_ = dist.rank != 0 ? LOAD_RECV : LOAD_FULL;
         if (!dv && dist.world > 1) { device_ = dist.rank % ndev; HIP_CHECK(hipSetDevice(device_)); MG4_INFO("no MINIGPT4_DEVICE / LOCAL_RANK: rank %d takes device %d", dist.rank, device_); }
     }
-    // With the native exchange active a load error on THIS rank is not returned at once: the rank still joins the communicator and reports it there, so that its peers fail
-    // with it instead of waiting for it inside RCCL (native_broadcast).
+    // With the native exchange active a load error on THIS rank is not returned at once: the rank still joins the communicator and reports it there,
+    // so that its peers fail with it instead of waiting for it inside RCCL (native_broadcast).
     int load_err = E_None;
     auto t0 = std::chrono::steady_clock::now();
     try {
@@ -162,14 +174,16 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     return load_err;
 }
 
-// The load-time exchange of a node's replicas, inside the C library: unique id through a file, communicator, layout agreement, both arenas from rank 0 in <= 1 GiB pieces,
-// checksum agreement.  Any failure is an error of minigpt4_model_load (message in minigpt4_amd_last_error); there is no fallback to reading the files.
+// The load-time exchange of a node's replicas, inside the C library: unique id through a file, communicator, layout agreement, both arenas from rank
+// 0 in <= 1 GiB pieces, checksum agreement.  Any failure is an error of minigpt4_model_load (message in minigpt4_amd_last_error); there is no
+// fallback to reading the files.
 int Engine::native_broadcast(int world, int rank, const std::string &id_file, int timeout_s, int local_err) {
     std::string err;
-    // round 5 (advisor): EVERY rank takes part in the same sequence of collectives and learns the same verdict, so a failure anywhere fails the load everywhere instead of
-    // leaving the healthy ranks inside a collective for ever: (1) a rank whose own load failed (header error, unsupported tensor) still joins and says so; (2) agreement is a
-    // symmetric all-reduce (element-wise max of {x, ~x} = max and min of every word, plus an "I am fine" flag), not a one-way broadcast only the receivers compare;
-    // (3) ncclCommInitRank runs under a watchdog (dist.cpp) and the stream waits below are bounded by MINIGPT4_DIST_TIMEOUT_S.
+    // round 5 (advisor): EVERY rank takes part in the same sequence of collectives and learns the same verdict, so a failure anywhere fails the load
+    // everywhere instead of leaving the healthy ranks inside a collective for ever: (1) a rank whose own load failed (header error, unsupported
+    // tensor) still joins and says so; (2) agreement is a symmetric all-reduce (element-wise max of {x, ~x} = max and min of every word, plus an "I
+    // am fine" flag), not a one-way broadcast only the receivers compare; (3) ncclCommInitRank runs under a watchdog (dist.cpp) and the stream waits
+    // below are bounded by MINIGPT4_DIST_TIMEOUT_S.
     auto fail = [&](const std::string &what) {
         if (rank == 0) unlink(id_file.c_str());        // never leave an id behind that a later job could pick up
         set_last_error("weight broadcast (rank " + std::to_string(rank) + " of " + std::to_string(world) + "): " + what); MG4_ERR("%s", last_error().c_str()); return (int)E_LoadLanguageModel; };
@@ -196,7 +210,8 @@ int Engine::native_broadcast(int world, int rank, const std::string &id_file, in
     unsigned long long *d_words = nullptr;
     HIP_CHECK(hipMalloc((void **)&d_words, 128));
     struct Free { unsigned long long *p; ~Free() { HIP_IGNORE(hipFree(p)); } } free_words{d_words};
-    // Symmetric agreement: true on EVERY rank iff every rank passed ok and all ranks hold the same four words; otherwise false on every rank, with a message naming the cause.
+    // Symmetric agreement: true on EVERY rank iff every rank passed ok and all ranks hold the same four words; otherwise false on every rank, with a
+    // message naming the cause.
     auto agree = [&](const unsigned long long mine[4], bool ok_here, const char *what) -> bool {
         unsigned long long v[10], r[10];
         for (int i = 0; i < 4; i++) { v[i] = mine[i]; v[4 + i] = ~mine[i]; }
@@ -236,7 +251,8 @@ int Engine::weights_received() {
     fold_qformer_constants();
     return 0;
 }
-// Host only: the arena layout (sizes + layout hashes) the two files produce, without a device: what a receiving rank must reproduce (tests/test_cpu_dist.py).
+// Host only: the arena layout (sizes + layout hashes) the two files produce, without a device: what a receiving rank must reproduce
+// (tests/test_cpu_dist.py).
 int Engine::plan_arenas(const std::string &vision_path, const std::string &llm_path, ArenaPlan &out) {
     Engine e;
     e.load_mode_ = LOAD_PLAN;
@@ -247,7 +263,8 @@ int Engine::plan_arenas(const std::string &vision_path, const std::string &llm_p
     return 0;
 }
 
-// Tensor types the kernels do not stream natively but that have an exact image in one they do: Q3_K -> Q6_K (quantize.hpp).  The conversion runs on the host at load.
+// Tensor types the kernels do not stream natively but that have an exact image in one they do: Q3_K -> Q6_K (quantize.hpp).  The conversion runs on
+// the host at load.
 static int effective_type(int t) { return t == GT_Q3_K ? GT_Q6_K : t; }
 static bool tensor_type_loadable(int t) { return qweight_supported(effective_type(t)); }
 // bytes of a tensor as the GPU holds it
@@ -281,7 +298,8 @@ int Engine::load_llm(const std::string &path) {
     const int E = (int)llm_.n_embd, L = (int)llm_.n_layer, V = (int)llm_.n_vocab, F = (int)llm_.n_ff();
     const int hd = E / (int)llm_.n_head;
     if (!attn_head_size_supported(hd)) { set_last_error("unsupported head size (supported: 32, 64, 128)"); return E_LoadLanguageModel; }
-    // k_attn_llm keeps one fp32 score + one fp16 probability per key of the context in LDS (6 bytes per key, 160 KiB per workgroup): refuse what cannot launch
+    // k_attn_llm keeps one fp32 score + one fp16 probability per key of the context in LDS (6 bytes per key, 160 KiB per workgroup): refuse what
+    // cannot launch
     if (parity_) attn_ref_prepare();
     auto ctx_too_long = [&](const char *which, int lim) {
         set_last_error(std::string(which) + "n_ctx " + std::to_string(n_ctx_) + " exceeds what the attention kernel's LDS score rows hold (" + std::to_string(lim) + ")");
@@ -377,7 +395,8 @@ int Engine::load_vision(const std::string &path) {
     const TensorMeta *qt = vis_.find("query_tokens", "weight");
     if (!qt || qt->ne.size() != 2 || qt->ne[0] != 768 || qt->type != GT_F32) return fail("bad query_tokens.weight", E_LoadModelFileHeader);
     v_nq_ = (int)qt->ne[1];
-    if (vis_.config_int("query_length", v_nq_) != v_nq_) return fail("query_embeds_length != query_length", E_LoadModelFileHeader);   // reference PANICs (minigpt4.cpp:2230)
+    // reference PANICs (minigpt4.cpp:2230)
+    if (vis_.config_int("query_length", v_nq_) != v_nq_) return fail("query_embeds_length != query_length", E_LoadModelFileHeader);
     {   // sizes read from an untrusted header feed container sizes below
         const long long ql = vis_.config_int("num_hidden_layers", 12);
         if (ql < 1 || ql > 64 || v_nq_ < 1 || v_nq_ > 256) return fail("num_hidden_layers / query_length out of range", E_LoadModelFileHeader);
@@ -391,7 +410,8 @@ int Engine::load_vision(const std::string &path) {
     v_qi_ = (int)iq->ne[1];
     if (v_M_ % 16 || v_qi_ % 16) return fail("MLP widths must be multiples of 16", E_LoadModelFileHeader);
 
-    // Linear weights: all F16 (the reference's published f16 files) -> the MFMA f16 GEMM path below; anything else -> the generic path (engine_vision_generic.cpp)
+    // Linear weights: all F16 (the reference's published f16 files) -> the MFMA f16 GEMM path below; anything else -> the generic path
+    // (engine_vision_generic.cpp)
     v_generic_ = false;
     for (auto &m : vis_.models) for (auto &t : m.second) {
         const TensorMeta &tm = t.second;
@@ -468,7 +488,9 @@ int Engine::load_vision(const std::string &path) {
     const char *QF = "Qformer";
     v_qeln_w_ = f32v(QF, "bert.embeddings.LayerNorm.weight", 768); v_qeln_b_ = f32v(QF, "bert.embeddings.LayerNorm.bias", 768);
     qlayers_.resize((size_t)v_ql_);
-    {   // the K | V projections of every cross-attention layer as ONE contiguous block [n_cross * 1536][D] (+ biases): one GEMM per image batch instead of one per cross layer
+    // the K | V projections of every cross-attention layer as ONE contiguous block [n_cross * 1536][D] (+ biases): one GEMM per image batch instead
+    // of one per cross layer
+    {
         std::vector<const TensorMeta *> kvw; std::vector<std::pair<const char *, std::string>> kvb;
         v_ncross_ = 0;
         for (int i = 0; i < v_ql_; i++) {
@@ -567,7 +589,8 @@ void Engine::alloc_buffers() {
     act_.q8k = reinterpret_cast<int8_t *>(buf_arena_.take(B * Kmax)); act_.q80 = reinterpret_cast<int8_t *>(buf_arena_.take(B * Kmax));
     act_.dk = takef(B * Kmax / 256 + 16); act_.bsk = reinterpret_cast<int16_t *>(buf_arena_.take(B * Kmax / 16 * 2 + 64));
     act_.bsq = reinterpret_cast<int8_t *>(buf_arena_.take(B * Kmax / 16 + 64));
-    if (mmqh_enabled()) { act_.q16 = takeh(B * Kmax); act_.bs16 = takeh(B * Kmax / 16 + 64); }   // MINIGPT4_MMQH=1 only: fp16 images of the Q8_K rows for the fp16-MFMA prompt mat-mul (k_mmqh_q45k, not adopted)
+    // MINIGPT4_MMQH=1 only: fp16 images of the Q8_K rows for the fp16-MFMA prompt mat-mul (k_mmqh_q45k, not adopted)
+    if (mmqh_enabled()) { act_.q16 = takeh(B * Kmax); act_.bs16 = takeh(B * Kmax / 16 + 64); }
     act_.d0 = takef(B * Kmax / 32 + 16); act_.d1 = takef(B * Kmax / 32 + 16); act_.s1 = takef(B * Kmax / 32 + 16);
     act_.sum0 = reinterpret_cast<int *>(buf_arena_.take(B * Kmax / 32 * 4 + 64));
     act_.xh = takeh(B * Kmax); act_.xf = takef(B * Kmax);
@@ -600,7 +623,8 @@ void Engine::alloc_buffers() {
     vi_hs_h_ = takeh(VB * NQ * 768); vi_a1_h_ = takeh(VB * NQ * 768); vi_a2_h_ = takeh(VB * NQ * 768); vi_ctx_h_ = takeh(VB * NQ * 768); vi_im_h_ = takeh(VB * NQ * (size_t)v_qi_);
     vi_out_ = takef(VB * NQ * (size_t)v_out_);
     vi_qtok_rep_ = takef(VB * NQ * 768);                                  // the query tokens once per image of a batch (every image starts from the same rows)
-    if (load_mode_ == LOAD_FULL) for (size_t b = 0; b < VB; b++) HIP_CHECK(hipMemcpy(vi_qtok_rep_ + b * NQ * 768, v_qtok_, NQ * 768 * 4, hipMemcpyDeviceToDevice));   // LOAD_RECV: weights_received()
+    // LOAD_RECV: weights_received()
+    if (load_mode_ == LOAD_FULL) for (size_t b = 0; b < VB; b++) HIP_CHECK(hipMemcpy(vi_qtok_rep_ + b * NQ * 768, v_qtok_, NQ * 768 * 4, hipMemcpyDeviceToDevice));
     vi_c_a1_ = takef(VB * NQ * 768); vi_c_qq_ = takef(VB * NQ * 768); vi_c_a1_h_ = takeh(VB * NQ * 768);
     if (v_generic_) alloc_vision_generic();
     MG4_INFO("KV cache %.1f MB (fp16, n_ctx %d, %zu conversation%s), activation arena %.1f MB", 2.0 * S * L * C * E * 2 / 1048576.0, n_ctx_, S, S == 1 ? "" : "s", buf_arena_.used / 1048576.0);
@@ -628,7 +652,8 @@ void Engine::site_end(hipStream_t s) noexcept {   // called from SiteScope's des
     ev.kernel = last_kernel_name();
     ev.p1 = launch_probe_count();
 }
-// rms norm * w + quantisation of N rows of x; when x is the pending result of a deferred K-split combine (x = residual + slabs), x is formed by the same launch
+// rms norm * w + quantisation of N rows of x; when x is the pending result of a deferred K-split combine (x = residual + slabs), x is formed by the
+// same launch
 void Engine::prep_rms(const float *x, const float *w, int N, int K, int mask, hipStream_t s) {
     if (pend_.ks > 1 && pend_.n == 1 && pend_.y[0] == x && pend_.stride == (long long)N * K) { launch_rms_quant_slabs(pend_, w, N, K, act_, mask, s); pend_ = SlabSrc{}; return; }
     flush_pending(s);
@@ -643,7 +668,8 @@ bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
     const bool v2 = N == 1 && use_v2_ && same;
     fuse = fuse && v2 && prep && matvec_prologue_supported(W[0]->type, W[0]->cols);
     silu_pair = silu_pair && v2 && n == 2 && !res && matvec_silu_pair_supported(W[0]->type, W[0]->cols) && (!fuse || prep->kind == 1);
-    if (prep && !fuse) {   // standalone preparation -- also the consumer of a deferred split-K combine (pend_): x = residual + slabs / silu(h1) * h3 straight from the slabs
+    // standalone preparation -- also the consumer of a deferred split-K combine (pend_): x = residual + slabs / silu(h1) * h3 straight from the slabs
+    if (prep && !fuse) {
         SiteScope sc(this, "prepare", 0.0, s);
         const int K = W[0]->cols;
         if (prep->kind == 1) prep_rms(prep->x, prep->w, N, K, mask, s);
@@ -654,7 +680,8 @@ bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
             launch_silu_mul_quant(prep->x, prep->kind == 3 ? prep->w : nullptr, N, K, act_, mask, N == 1 ? tabs_dec_ : tabs_, s);
         }
     }
-    // keep_pending (wv after a deferred wq|wk): the earlier launch's slabs stay where they are, this launch's go behind them, and both are handed to the consumer together
+    // keep_pending (wv after a deferred wq|wk): the earlier launch's slabs stay where they are, this launch's go behind them, and both are handed to
+    // the consumer together
     SlabSrc kept;
     ActQ act_here = act_;
     if (keep_pending && !prep && pend_.ks > 1 && !pend_.mixed && pend_.n == 2 && n == 1 && (size_t)pend_.n * pend_.ks * (size_t)pend_.stride < act_.ws_floats) {
@@ -667,9 +694,12 @@ bool Engine::mul_mat_set(const QWeight *const *W, float *const *y, const float *
     for (int i = 0; i < n; i++) wbytes += (double)W[i]->bytes;
     SiteScope sc(this, site, wbytes, s);
     bool done = false;
-    if (N >= 5 && same && mmq_enabled() >= 2) done = launch_mmq2_set(W, y, res, n, act_here, N, ldy, s, defer_ok && defer_combine_ ? &pend_ : nullptr);   // prefill: one launch for the set, weights streamed once per <= 128 rows
-    const bool staged_elsewhere = !prep && (xh_override_ != nullptr || (same && W[0]->type == GT_F16 && N >= 512));   // the rows were left in fp16 by an earlier launch, act_ holds OTHER rows
-    if (!done && same && W[0]->type == GT_F16 && N >= 512 && act_.xh) {   // unquantised weights at prompt sizes: the set in one launch of the big MFMA GEMM, split K for wo / w2
+    // prefill: one launch for the set, weights streamed once per <= 128 rows
+    if (N >= 5 && same && mmq_enabled() >= 2) done = launch_mmq2_set(W, y, res, n, act_here, N, ldy, s, defer_ok && defer_combine_ ? &pend_ : nullptr);
+    // the rows were left in fp16 by an earlier launch, act_ holds OTHER rows
+    const bool staged_elsewhere = !prep && (xh_override_ != nullptr || (same && W[0]->type == GT_F16 && N >= 512));
+    // unquantised weights at prompt sizes: the set in one launch of the big MFMA GEMM, split K for wo / w2
+    if (!done && same && W[0]->type == GT_F16 && N >= 512 && act_.xh) {
         const __half *Wh[3]; for (int i = 0; i < n; i++) Wh[i] = reinterpret_cast<const __half *>(W[i]->qs);
         const __half *Ain = !prep && xh_override_ ? xh_override_ : act_.xh;     // rows some launch left in fp16 elsewhere (the feed-forward pair's epilogue)
         done = launch_gemm_f16_set(Ain, W[0]->cols, Wh, n, N, W[0]->rows, W[0]->cols, y, res, ldy, act_.ws, act_.ws_floats, n_cus_, s, defer_ok && defer_combine_ ? &pend_ : nullptr);
@@ -703,7 +733,8 @@ void Engine::mul_mat(const QWeight &W, int N, float *y, int ldy, const float *re
     mul_mat_set(Wp, Yp, Rp, 1, N, ldy, s, prep, fuse, false, site, defer_ok, keep_pending);
 }
 
-// wq|wk and a differently typed wv (k-quant "more bits" layers) in one launch; returns false when the shapes / types are outside the mixed kernel's range.
+// wq|wk and a differently typed wv (k-quant "more bits" layers) in one launch; returns false when the shapes / types are outside the mixed kernel's
+// range.
 bool Engine::mixed_qkv(const LayerW &L, hipStream_t s, bool fuse) {
     if (!use_v2_) return false;
     const int E = (int)llm_.n_embd;
@@ -720,18 +751,19 @@ bool Engine::mixed_qkv(const LayerW &L, hipStream_t s, bool fuse) {
     return true;
 }
 
-// MINIGPT4_PARITY=1 (or minigpt4_amd_set_parity): the same graph as forward() below with every fp32 accumulation in the CPU oracle's order -- standalone row
-// preparation (sum of squares in element order), k_mul_mat_ref (per-block terms added block after block), RoPE + cache append, k_attn_ref (sequential score / P.V
-// chains), no fused prologues, no MFMA tiles.  Everything else (integer block dots, activation quantisation, fp16 tables, RoPE table) is shared with the fast path
-// and exact there, so this pass is BIT-IDENTICAL to oracle/refcpu.c: logits and greedy ids (tests/test_gpu_paritymode.py).  Slow by design (one wave per output).
+// MINIGPT4_PARITY=1 (or minigpt4_amd_set_parity): the same graph as forward() below with every fp32 accumulation in the CPU oracle's order --
+// standalone row preparation (sum of squares in element order), k_mul_mat_ref (per-block terms added block after block), RoPE + cache append,
+// k_attn_ref (sequential score / P.V chains), no fused prologues, no MFMA tiles.  Everything else (integer block dots, activation quantisation, fp16
+// tables, RoPE table) is shared with the fast path and exact there, so this pass is BIT-IDENTICAL to oracle/refcpu.c: logits and greedy ids
+// (tests/test_gpu_paritymode.py).  Slow by design (one wave per output).
 void Engine::forward_ref(int N, bool from_tokens, hipStream_t s, bool feed) {
     const int E = (int)llm_.n_embd, F = (int)llm_.n_ff(), H = (int)llm_.n_head, hd = E / H, V = (int)llm_.n_vocab;
     const size_t C = (size_t)n_ctx_, sl = (size_t)cur_;
     int *const d_npast = d_npast_ + sl, *const d_argmax = d_argmax_ + sl, *const d_feed = d_feed_ + sl;
     float *const logits = logits_ + sl * (size_t)V;
     if (from_tokens) launch_get_rows(tok_type_, tok_raw_, E, feed ? d_feed : d_tokens_, N, x_, s);
-    // MINIGPT4_PARITY_TRACE=<file>: every intermediate as a record {char name[32]; int64 n; float[n]} -- the oracle writes the same sequence (orc_set_trace), and
-    // tools/trace_diff.py reports the first record that differs.  Synchronises after every launch; never inside a graph capture.
+    // MINIGPT4_PARITY_TRACE=<file>: every intermediate as a record {char name[32]; int64 n; float[n]} -- the oracle writes the same sequence
+    // (orc_set_trace), and tools/trace_diff.py reports the first record that differs.  Synchronises after every launch; never inside a graph capture.
     auto tr = [&](const char *what, int il, const float *p, size_t n) {
         if (!trace_file_) return;
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone; HIP_IGNORE(hipStreamIsCapturing(s, &st));
@@ -744,7 +776,8 @@ void Engine::forward_ref(int N, bool from_tokens, hipStream_t s, bool feed) {
     };
     tr("embd", -1, x_, (size_t)N * E);
     const int t_max = n_ctx_;                                              // sizes k_attn_ref's LDS rows; a captured decode step is replayed at later positions
-    // one row (decode): same-type matrices of a set in one launch of the prefetching row kernel; otherwise (prompt rows, other types) one generic launch per matrix
+    // one row (decode): same-type matrices of a set in one launch of the prefetching row kernel; otherwise (prompt rows, other types) one generic
+    // launch per matrix
     auto ref_set = [&](std::initializer_list<const QWeight *> Ws, std::initializer_list<float *> Ys, const float *res) {
         const QWeight *W[3]; float *Y[3]; const float *R[3]; int n = 0;
         for (const QWeight *w : Ws) W[n++] = w;
@@ -758,8 +791,9 @@ void Engine::forward_ref(int N, bool from_tokens, hipStream_t s, bool feed) {
                 done += run;
             }
         } else {
-            // prompt rows: the int8-MFMA kernels WITHOUT a K split add every output's per-block terms block after block -- the oracle's order (bit-identical: test_gpu_paritymode);
-            // runs of equal type / shape in one launch each, anything they refuse on the oracle-order row kernels
+            // prompt rows: the int8-MFMA kernels WITHOUT a K split add every output's per-block terms block after block -- the oracle's order
+            // (bit-identical: test_gpu_paritymode); runs of equal type / shape in one launch each, anything they refuse on the oracle-order row
+            // kernels
             while (done < n) {
                 int run = 1; while (done + run < n && W[done + run]->type == W[done]->type && W[done + run]->rows == W[done]->rows && W[done + run]->cols == W[done]->cols) run++;
                 if (!(N >= 5 && launch_mmq2_set(W + done, Y + done, res ? R + done : nullptr, run, act_, N, W[done]->rows, s, nullptr, 1)))
@@ -768,8 +802,9 @@ void Engine::forward_ref(int N, bool from_tokens, hipStream_t s, bool feed) {
             }
         }
     };
-    // One row without a trace (the decode step): the fast step's launch structure -- row preparation in the mat-vec prologues, wq | wk (| wv) and w1 | w3 as set launches --
-    // on the oracle-order variants of the same kernels (MATVEC_EPI_REF); a set those kernels refuse (non-k-quant types) takes the standalone preparation + row kernels below.
+    // One row without a trace (the decode step): the fast step's launch structure -- row preparation in the mat-vec prologues, wq | wk (| wv) and w1
+    // | w3 as set launches -- on the oracle-order variants of the same kernels (MATVEC_EPI_REF); a set those kernels refuse (non-k-quant types) takes
+    // the standalone preparation + row kernels below.
     const bool fused_row = N == 1 && !trace_file_;
     auto fused_set = [&](std::initializer_list<const QWeight *> Ws, std::initializer_list<float *> Ys, const float *res, int pro, const float *px, const float *pw) -> bool {
         if (!fused_row) return false;
@@ -792,7 +827,8 @@ void Engine::forward_ref(int N, bool from_tokens, hipStream_t s, bool feed) {
             ref_set({&L.wq, &L.wk, &L.wv}, {q_, k_, v_}, nullptr);
         }
         tr("q", (int)il, q_, (size_t)N * E); tr("k", (int)il, k_, (size_t)N * E); tr("v", (int)il, v_, (size_t)N * E);
-        if (N == 1 && !trace_file_) launch_attn_ref_fused(q_, k_, v_, kc, vc, H, hd, d_npast, t_max, cos_, sin_, tabs_, att_, s);   // decode: RoPE + cache append inside the attention launch
+        // decode: RoPE + cache append inside the attention launch
+        if (N == 1 && !trace_file_) launch_attn_ref_fused(q_, k_, v_, kc, vc, H, hd, d_npast, t_max, cos_, sin_, tabs_, att_, s);
         else { launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); launch_attn_ref(q_, kc, vc, N, H, hd, d_npast, t_max, tabs_, att_, s); }
         tr("q_rope", (int)il, q_, (size_t)N * E); tr("att", (int)il, att_, (size_t)N * E);
         if (!fused_set({&L.wo}, {x_}, x_, 2, att_, nullptr)) {
@@ -840,8 +876,8 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
     int *const d_npast = d_npast_ + sl, *const d_argmax = d_argmax_ + sl, *const d_feed = d_feed_ + sl;
     float *const logits = logits_ + sl * (size_t)V;
     const bool dec = N == 1;
-    // feed: the row is the decode token kept in d_feed (greedy feedback / set by eval_chunk); otherwise the rows are described by d_tokens_ (id, or -1 = an
-    // embedding row already sitting in x_) -- a chunk of exactly ONE embedding row must not pick up the stale decode token
+    // feed: the row is the decode token kept in d_feed (greedy feedback / set by eval_chunk); otherwise the rows are described by d_tokens_ (id, or
+    // -1 = an embedding row already sitting in x_) -- a chunk of exactly ONE embedding row must not pick up the stale decode token
     if (from_tokens) { SiteScope sc(this, "embed", (double)gt_nbytes(tok_type_, (size_t)E) * N, s); launch_get_rows(tok_type_, tok_raw_, E, feed ? d_feed : d_tokens_, N, x_, s); }
     auto fz = [&](int bit) { return dec && (fuse_mask_ >> bit & 1); };
     for (size_t il = 0; il < layers_.size(); il++) {
@@ -850,11 +886,13 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
         const Prep p_attn{1, x_, L.attn_norm}, p_att{2, att_, nullptr}, p_ffn{1, x_, L.ffn_norm}, p_silu{3, h1_, h3_};
         {
             const QWeight *W3[3] = {&L.wq, &L.wk, &L.wv}; float *Y3[3] = {q_, k_, v_};
-            if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s, &p_attn, fz(0), false, "qkv", !dec);   // a K-split combine is left to launch_rope_kv_slabs
+            // a K-split combine is left to launch_rope_kv_slabs
+            if (L.wv.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, N, E, s, &p_attn, fz(0), false, "qkv", !dec);
             else if (fz(6) && L.wk.type == L.wq.type && mixed_qkv(L, s, fz(0))) {}
             else if (act_mask_for(L.wv.type) == act_mask_for(L.wq.type) && !fz(0)) {   // one standalone preparation serves both launches
                 prep_rms(x_, L.attn_norm, N, E, act_mask_for(L.wq.type), s);
-                mul_mat_set(W3, Y3, nullptr, 2, N, E, s, nullptr, false, false, "qk", !dec); mul_mat(L.wv, N, v_, E, nullptr, s, nullptr, false, "v", !dec, !dec);   // both combines left to the rope launch
+                // both combines left to the rope launch
+                mul_mat_set(W3, Y3, nullptr, 2, N, E, s, nullptr, false, false, "qk", !dec); mul_mat(L.wv, N, v_, E, nullptr, s, nullptr, false, "v", !dec, !dec);
             } else { mul_mat_set(W3, Y3, nullptr, 2, N, E, s, &p_attn, fz(0), false, "qk"); mul_mat(L.wv, N, v_, E, nullptr, s, &p_attn, fz(0), "v"); }
         }
         // algorithmic bytes of the attention site: the cached fp16 K and V rows of every head up to the current position
@@ -867,7 +905,8 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
             if (pend_.ks > 1 && pend_.n == 3 && pend_.y[0] == q_ && pend_.y[1] == k_ && pend_.y[2] == v_ && !pend_.res[0] && !pend_.res[1] && !pend_.res[2] && pend_.stride == (long long)N * E) {
                 launch_rope_kv_slabs(pend_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); pend_ = SlabSrc{};
             } else { flush_pending(s); launch_rope_kv(q_, k_, v_, N, H, hd, d_npast, cos_, sin_, kc, vc, s); }
-            // an F16 wo at prompt sizes multiplies fp16(attention output): let the attention kernel store those rows itself (act_.xh), no conversion launch
+            // an F16 wo at prompt sizes multiplies fp16(attention output): let the attention kernel store those rows itself (act_.xh), no conversion
+            // launch
             const bool want_h = (f16_pair_ & 4) && L.wo.type == GT_F16 && N >= 512 && act_.xh && E % 128 == 0;
             if (!(attn_prefill_ && launch_attn_prefill(q_, kc, vc, N, H, hd, d_npast, conv_[sl].n_committed + N, tabs_, att_, s, want_h ? act_.xh : nullptr, &att_in_xh)))
                 launch_attn_llm(q_, k_, v_, kc, vc, N, H, hd, d_npast, n_ctx_, cos_, sin_, tabs_, att_, false, s);
@@ -875,7 +914,8 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
         att_sc.reset();
         mul_mat(L.wo, N, x_, E, x_, s, att_in_xh ? nullptr : &p_att, fz(1), "wo", !dec);             // combine left to the ffn norm's preparation
         bool paired = false;   // h1_ already holds silu(w1 x) * (w3 x)
-        // F16 weights at prompt sizes: w1 | w3 in one launch whose epilogue stores fp16(silu(w1 x) * (w3 x)) -- the rows w2 multiplies -- into h1_'s memory (round 3)
+        // F16 weights at prompt sizes: w1 | w3 in one launch whose epilogue stores fp16(silu(w1 x) * (w3 x)) -- the rows w2 multiplies -- into h1_'s
+        // memory (round 3)
         bool pair16 = false;
         if (!dec && (f16_pair_ & 1) && N >= 512 && L.w1.type == GT_F16 && L.w3.type == GT_F16 && L.w1.rows == L.w3.rows && L.w1.cols == L.w3.cols && act_.xh &&
             L.w2.type == GT_F16 && E % 128 == 0 && F % 64 == 0) {   // (w2's set launch must take the fp16 rows: its own shape conditions)
@@ -889,13 +929,15 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
             mul_mat(L.w2, N, x_, E, x_, s, nullptr, false, "w2", true);
             continue;
         }
-        if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5), "w1w3", !dec); }   // combine left to silu * mul
+        // combine left to silu * mul
+        if (L.w1.type == L.w3.type) { const QWeight *W2[2] = {&L.w1, &L.w3}; float *Y2[2] = {h1_, h3_}; paired = mul_mat_set(W2, Y2, nullptr, 2, N, F, s, &p_ffn, fz(2), fz(5), "w1w3", !dec); }
         else if (act_mask_for(L.w1.type) == act_mask_for(L.w3.type) && !fz(2)) {
             prep_rms(x_, L.ffn_norm, N, E, act_mask_for(L.w1.type), s);
             mul_mat(L.w1, N, h1_, F, nullptr, s, nullptr, false, "w1"); mul_mat(L.w3, N, h3_, F, nullptr, s, nullptr, false, "w3");
         } else { mul_mat(L.w1, N, h1_, F, nullptr, s, &p_ffn, fz(2), "w1"); mul_mat(L.w3, N, h3_, F, nullptr, s, &p_ffn, fz(2), "w3"); }
         const Prep p_h{2, h1_, nullptr};
-        mul_mat(L.w2, N, x_, E, x_, s, paired ? &p_h : &p_silu, fz(3), "w2", !dec);   // combine left to the next layer's attention norm (or flushed in front of the output matrix)
+        // combine left to the next layer's attention norm (or flushed in front of the output matrix)
+        mul_mat(L.w2, N, x_, E, x_, s, paired ? &p_h : &p_silu, fz(3), "w2", !dec);
     }
     flush_pending(s);
     // only the last token's logits are kept (llama.cpp logits_all = false)
@@ -906,30 +948,31 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
     HIP_CHECK(hipMemcpyAsync(h_argmax_ + sl, d_argmax, 4, hipMemcpyDeviceToHost, s));
 }
 
-// One decode step for B conversations at once: row r carries token d_btok_[r] of conversation d_bslot_[r].  The weights are streamed once for the B rows
-// (k_mul_mat's 4-token tiles up to B = 4, the int8-MFMA kernels from B = 5); attention runs per row against its conversation's cache.  Same arithmetic per
-// row as forward(1): per-row activation quantisation, exact integer block dots, the same attention kernel body.
+// One decode step for B conversations at once: row r carries token d_btok_[r] of conversation d_bslot_[r].  The weights are streamed once for the B
+// rows (k_mul_mat's 4-token tiles up to B = 4, the int8-MFMA kernels from B = 5); attention runs per row against its conversation's cache.  Same
+// arithmetic per row as forward(1): per-row activation quantisation, exact integer block dots, the same attention kernel body.
 void Engine::forward_batch(int B, hipStream_t s) {
     pend_ = SlabSrc{}; xh_override_ = nullptr;
     set_ri_workspace(ri_slabs_, ri_slab_floats_, ri_tickets_, ri_ticket_n_);   // this context's K-split workspace (null until build_ri_planes ran)
     const int E = (int)llm_.n_embd, F = (int)llm_.n_ff(), H = (int)llm_.n_head, hd = E / H, V = (int)llm_.n_vocab;
     const size_t C = (size_t)n_ctx_, seq_stride = layers_.size() * C * (size_t)E;
-    // y_m[t][r] = W_m[r] . act[t] (+ res_m[t][r]) for n matrices that share the prepared rows.  Up to batch_rows_max_ rows go through the pipelined multi-row
-    // mat-vec in passes of 4 rows (weights streamed once per pass); larger batches / other types through launch_mul_mat (int8-MFMA tiles from 5 rows).
-    // px != null: the launch prepares its rows itself (rms_norm(px_t) * pw, quantised) -- only called when rows_pro() said the shape / type is in range
-    // Does the row-interleaved MFMA launch serve this set?  Every matrix of one k-quant type and shape with its image built, AND where it was measured faster than the v_dot4
-    // multi-row mat-vec (profiles/r05_batched_shapes.log, us per launch, dot4 / mfma at B = 2 | 3 | 4): sets of >= 128 row groups -- qkv 17.2/15.2 | 19.8/15.2 | 23.2/15.6,
-    // wq|wk 12.4/12.9 | 14.7/12.9 | 17.1/13.2, w1|w3 25.7/22.2 | 29.6/22.1 | 34.4/22.1, output 27.3/27.0 | 33.1/27.2 | 37.3/27.5 -- but not wo (80 groups:
-    // 12.3/10.7 at B = 4, less than the standalone quantisation of the attention rows it would need) nor a lone wv; w2 only at B = 4 (below); and from 3 rows on: at B = 2 the v_dot4 launches prepare their
-    // rows in their own prologue (two launches less per layer), which outweighs the 2-3.5 us the MFMA launch would save.
+    // y_m[t][r] = W_m[r] . act[t] (+ res_m[t][r]) for n matrices that share the prepared rows.  Up to batch_rows_max_ rows go through the pipelined
+    // multi-row mat-vec in passes of 4 rows (weights streamed once per pass); larger batches / other types through launch_mul_mat (int8-MFMA tiles
+    // from 5 rows). px != null: the launch prepares its rows itself (rms_norm(px_t) * pw, quantised) -- only called when rows_pro() said the shape /
+    // type is in range Does the row-interleaved MFMA launch serve this set?  Every matrix of one k-quant type and shape with its image built, AND
+    // where it was measured faster than the v_dot4 multi-row mat-vec (profiles/r05_batched_shapes.log, us per launch, dot4 / mfma at B = 2 | 3 | 4):
+    // sets of >= 128 row groups -- qkv 17.2/15.2 | 19.8/15.2 | 23.2/15.6, wq|wk 12.4/12.9 | 14.7/12.9 | 17.1/13.2, w1|w3 25.7/22.2 | 29.6/22.1 |
+    // 34.4/22.1, output 27.3/27.0 | 33.1/27.2 | 37.3/27.5 -- but not wo (80 groups: 12.3/10.7 at B = 4, less than the standalone quantisation of the
+    // attention rows it would need) nor a lone wv; w2 only at B = 4 (below); and from 3 rows on: at B = 2 the v_dot4 launches prepare their rows in
+    // their own prologue (two launches less per layer), which outweighs the 2-3.5 us the MFMA launch would save.
     auto ri_serves = [&](std::initializer_list<const QWeight *> Ws) {
         if (!ri_ready_ || B < 3 || B > 4) return false;
         const QWeight *w0 = *Ws.begin();
         int groups = 0;
         for (const QWeight *w : Ws) { if (!ri_of(w) || w->type != w0->type || w->rows != w0->rows || w->cols != w0->cols) return false; groups += w->rows / 64; }
-        // w2 (13B: 80 row groups x 54 super-blocks): three or four workgroups share a row group, each a K range, last arriver adds the parts.  With the first weight fetch ahead of
-        // the staging and batched staging loads the launch is 18.9 (Q5_K) / 20.8 us (Q6_K) against 22.8 / 22.4 for the v_dot4 kernel at B = 4 (equal at B = 3): 1037 vs 1018 tok/s,
-        // alternating on one box (profiles/r05_batched_decode_inengine.log)
+        // w2 (13B: 80 row groups x 54 super-blocks): three or four workgroups share a row group, each a K range, last arriver adds the parts.  With
+        // the first weight fetch ahead of the staging and batched staging loads the launch is 18.9 (Q5_K) / 20.8 us (Q6_K) against 22.8 / 22.4 for
+        // the v_dot4 kernel at B = 4 (equal at B = 3): 1037 vs 1018 tok/s, alternating on one box (profiles/r05_batched_decode_inengine.log)
         if (ri_w2_ && B == 4 && Ws.size() == 1 && w0->cols >= 8192 && ri_ksplit(groups, w0->cols) > 1) return true;
         return groups >= 128;
     };
@@ -957,7 +1000,9 @@ void Engine::forward_batch(int B, hipStream_t s) {
             }
             if (ok) return;
         }
-        if (px) {   // the launch that was to prepare its rows itself was refused (plane spacing, LDS): a performance choice must not fail the step -- prepare them standalone
+        // the launch that was to prepare its rows itself was refused (plane spacing, LDS): a performance choice must not fail the step -- prepare
+        // them standalone
+        if (px) {
             const int K = W[0]->cols; int mask = 0;
             for (int k = 0; k < n; k++) mask |= act_mask_for(W[k]->type);
             if (pw) launch_rms_quant(px, pw, B, K, act_, mask, s); else launch_silu_mul_quant(px, nullptr, B, K, act_, mask, tabs_, s);
@@ -966,10 +1011,12 @@ void Engine::forward_batch(int B, hipStream_t s) {
     };
     // may the rows of this set be prepared inside its launch?  (same conditions mm() takes the multi-row kernel under)
     auto rows_pro = [&](std::initializer_list<const QWeight *> Ws, bool plain = false) {
-        // measured (profiles/r02j_batched_decode_ab.log): inside the launch the preparation pays at 2 rows (560 vs 540 tok/s) and loses at 4 (808 vs 829: every fat
-        // workgroup repeats four rows' norm + quantisation); MINIGPT4_BATCH_FUSE=1 forces it for every B <= 4, =0 switches it off
-        // plain = quantisation only (the attention output in front of wo: no norm, no double-precision sums): cheap enough to stay inside the launch at 3 and 4 rows too
-        if (ri_serves(Ws)) return !plain && ri_fuse_;      // the MFMA launch norms + quantises its rows itself (not the plain quantisation in front of wo: wo is not served)
+        // measured (profiles/r02j_batched_decode_ab.log): inside the launch the preparation pays at 2 rows (560 vs 540 tok/s) and loses at 4 (808 vs
+        // 829: every fat workgroup repeats four rows' norm + quantisation); MINIGPT4_BATCH_FUSE=1 forces it for every B <= 4, =0 switches it off
+        // plain = quantisation only (the attention output in front of wo: no norm, no double-precision sums): cheap enough to stay inside the launch
+        // at 3 and 4 rows too
+        // the MFMA launch norms + quantises its rows itself (not the plain quantisation in front of wo: wo is not served)
+        if (ri_serves(Ws)) return !plain && ri_fuse_;
         if (batch_fuse_ == 0 || B > batch_rows_max_ || B > 4 || (batch_fuse_ < 0 && B > 2 && !plain)) return false;
         const QWeight *w0 = *Ws.begin();
         for (const QWeight *w : Ws) if (w->type != w0->type || w->rows != w0->rows || w->cols != w0->cols) return false;
@@ -984,7 +1031,8 @@ void Engine::forward_batch(int B, hipStream_t s) {
             if (!batch_mix_ || B > batch_rows_max_ || B > 4 || L.wk.type != L.wq.type || L.wv.type == L.wq.type) return false;
             const QWeight *W1[2] = {&L.wq, &L.wk}, *W2[1] = {&L.wv};
             float *y1[2] = {q_, k_}, *y2[1] = {v_};
-            // at 3 and 4 prepared rows on the matrix cores (k_matvec_ri_mix), under ri_serves' conditions: every image built, >= 128 row groups in the set
+            // at 3 and 4 prepared rows on the matrix cores (k_matvec_ri_mix), under ri_serves' conditions: every image built, >= 128 row groups in
+            // the set
             if (!pro && ri_ready_ && B >= 3 && ri_of(&L.wq) && ri_of(&L.wk) && ri_of(&L.wv) && (L.wq.rows + L.wk.rows + L.wv.rows) / 64 >= 128) {
                 const RiPlanes *r1[2] = {ri_of(&L.wq), ri_of(&L.wk)}, *r2[1] = {ri_of(&L.wv)};
                 if (launch_matvec_ri_mixed(W1, r1, y1, 2, W2, r2, y2, 1, act_, B, E, s)) return true;
@@ -992,8 +1040,9 @@ void Engine::forward_batch(int B, hipStream_t s) {
             return launch_matvec_rows_mixed(W1, y1, 2, W2, y2, 1, act_, B, E, s, pro ? x_ : nullptr, pro ? L.attn_norm : nullptr, E);
         };
         if (B > batch_rows_max_ && batch_sets_) {
-            // More conversations than the multi-row mat-vec takes (5 ... 32): the prompt pass's launches -- one int8-MFMA launch per matrix SET, row preparations that also
-            // combine a K-split predecessor (pend_), i.e. 11 launches per layer instead of the 19 of one launch + one combine per matrix (round 3).
+            // More conversations than the multi-row mat-vec takes (5 ... 32): the prompt pass's launches -- one int8-MFMA launch per matrix SET, row
+            // preparations that also combine a K-split predecessor (pend_), i.e. 11 launches per layer instead of the 19 of one launch + one combine
+            // per matrix (round 3).
             const Prep p_attn{1, x_, L.attn_norm}, p_att{2, att_, nullptr}, p_ffn{1, x_, L.ffn_norm}, p_silu{3, h1_, h3_};
             const QWeight *W3[3] = {&L.wq, &L.wk, &L.wv}; float *Y3[3] = {q_, k_, v_};
             if (L.wv.type == L.wq.type && L.wk.type == L.wq.type) mul_mat_set(W3, Y3, nullptr, 3, B, E, s, &p_attn, false, false, "qkv");
@@ -1032,7 +1081,8 @@ void Engine::forward_batch(int B, hipStream_t s) {
         launch_silu_mul_quant(h1_, h3_, B, F, act_, act_mask_for(L.w2.type), tabs_dec_, s);
         mm({&L.w2}, {x_}, x_, E);
     }
-    if (B <= batch_rows_max_ && ri_fuse_ && ri_serves({&output_})) mm({&output_}, {blogits_}, nullptr, V, x_, norm_);   // final norm inside the output matrix's MFMA launch
+    // final norm inside the output matrix's MFMA launch
+    if (B <= batch_rows_max_ && ri_fuse_ && ri_serves({&output_})) mm({&output_}, {blogits_}, nullptr, V, x_, norm_);
     else {
         prep_rms(x_, norm_, B, E, act_mask_for(output_.type), s);             // (also combines the last layer's w2 slabs when its combine was deferred)
         mm({&output_}, {blogits_}, nullptr, V);
@@ -1040,9 +1090,10 @@ void Engine::forward_batch(int B, hipStream_t s) {
     launch_batch_finish(blogits_, V, B, d_bslot_, d_npast_, d_argmax_, d_feed_, logits_, s);
 }
 
-// Evaluate one chunk of N rows of the selected conversation at its position n_committed.  row_tok[i] >= 0: token id; -1: the next packed embedding row of `embd`.
-// LOAD_RECV: the arenas are allocated but hold nothing until the broadcast has landed and weights_received() ran -- every compute entry point refuses until then
-// (a caller that skipped the hand-over, or an inherited MINIGPT4_LOAD=recv, must get an error, not text generated from uninitialised weights).
+// Evaluate one chunk of N rows of the selected conversation at its position n_committed.  row_tok[i] >= 0: token id; -1: the next packed embedding
+// row of `embd`. LOAD_RECV: the arenas are allocated but hold nothing until the broadcast has landed and weights_received() ran -- every compute
+// entry point refuses until then (a caller that skipped the hand-over, or an inherited MINIGPT4_LOAD=recv, must get an error, not text generated from
+// uninitialised weights).
 bool Engine::weights_missing() const {
     if (load_mode_ != LOAD_RECV) return false;
     set_last_error("the context was loaded in receive mode (MINIGPT4_LOAD=recv) and its weight arenas have not been filled: broadcast them, then call minigpt4_amd_weights_received");
@@ -1058,8 +1109,8 @@ int Engine::eval_chunk(const int *row_tok, int N, const float *embd) {
     launch_set_int(d_npast_ + cur_, cv.n_committed, stream_);
     if (N == 1 && row_tok[0] >= 0) {
         launch_set_int(d_feed_ + cur_, row_tok[0], stream_);
-        // long contexts: the decode step's attention shares every head's keys between workgroups (two launches instead of one: pays from a few hundred keys on).  The choice
-        // is part of the captured graph, so a conversation that crosses the threshold gets its step re-captured (once).
+        // long contexts: the decode step's attention shares every head's keys between workgroups (two launches instead of one: pays from a few
+        // hundred keys on).  The choice is part of the captured graph, so a conversation that crosses the threshold gets its step re-captured (once).
         const bool split = attn_split_t_ > 0 && cv.n_committed + 1 > attn_split_t_;
         attn_split_now_ = split;
         if (use_graph_ && !prof_on_ && !trace_file_) {
@@ -1184,8 +1235,9 @@ int Engine::profile_sites(int steps, std::string &json) {
     if (steps <= 0 || cv.n_past + steps > n_ctx_) return 1;
     HIP_CHECK(hipStreamSynchronize(stream_));
     prof_on_ = true; kernel_name_tracing(true);
-    // Every step starts behind a gate kernel that holds the stream for ~8 ms: the host queues the step's ~250 launches and ~500 event records (6-7 us of host time
-    // each, more than most of the kernels run) while the gate spins, and the GPU then drains them back to back -- the event pairs time kernels, not the host.
+    // Every step starts behind a gate kernel that holds the stream for ~8 ms: the host queues the step's ~250 launches and ~500 event records (6-7 us
+    // of host time each, more than most of the kernels run) while the gate spins, and the GPU then drains them back to back -- the event pairs time
+    // kernels, not the host.
     hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
     int tok = h_argmax_[cur_];
     float tot = 0;
@@ -1200,7 +1252,8 @@ int Engine::profile_sites(int steps, std::string &json) {
         tok = h_argmax_[cur_];
     }
     prof_on_ = false; kernel_name_tracing(false);
-    struct Agg { std::string site, kernel; double us = 0, mus = 0, bytes = 0; long calls = 0; bool probed = true; };   // us: dispatch begin..end (launch probes); mus: marker pairs
+    // us: dispatch begin..end (launch probes); mus: marker pairs
+    struct Agg { std::string site, kernel; double us = 0, mus = 0, bytes = 0; long calls = 0; bool probed = true; };
     std::vector<Agg> agg;                                                    // first-seen order = launch order within the step
     for (auto &e : site_events_) {
         float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, e.a, e.b));
@@ -1217,7 +1270,8 @@ int Engine::profile_sites(int steps, std::string &json) {
     char buf[768];
     json = "{\"steps\": " + std::to_string(steps) + ", \"eager_ms_per_step\": " + std::to_string(tot / steps) + ", \"sites\": [";
     for (size_t k = 0; k < agg.size(); k++) {
-        // avg_us: the dispatches' own begin..end timestamps (what rocprofv3 reports); avg_us_markers: hipEventRecord pairs around the launch site (adds packet processing)
+        // avg_us: the dispatches' own begin..end timestamps (what rocprofv3 reports); avg_us_markers: hipEventRecord pairs around the launch site
+        // (adds packet processing)
         snprintf(buf, sizeof(buf), "%s{\"site\": \"%s\", \"kernel\": \"%s\", \"calls_per_step\": %.3f, \"avg_us\": %.3f, \"avg_us_markers\": %.3f, \"timing\": \"%s\", \"bytes_per_call\": %.1f}",
                  k ? ", " : "", agg[k].site.c_str(), agg[k].kernel.c_str(), (double)agg[k].calls / steps, (agg[k].probed ? agg[k].us : agg[k].mus) / (double)agg[k].calls,
                  agg[k].mus / (double)agg[k].calls, agg[k].probed ? "dispatch" : "markers", agg[k].bytes / (double)agg[k].calls);
@@ -1230,14 +1284,17 @@ int Engine::profile_sites(int steps, std::string &json) {
 // ====================================================================================================================
 // several conversations per replica
 // ====================================================================================================================
-// The row-interleaved image of every k-quant matrix the batched step multiplies (ri_kernels.hip), built once, on the device, from the ordinary planes.
+// The row-interleaved image of every k-quant matrix the batched step multiplies (ri_kernels.hip), built once, on the device, from the ordinary
+// planes.
 void Engine::build_ri_planes() {
     if (ri_ready_ || !use_ri_ || weights_missing()) return;
     std::vector<const QWeight *> ws;
-    // only the sets the batched step serves this way (forward_batch: ri_serves, qkv_mixed): wq | wk | wv (of one type, or wq | wk + a Q6_K wv), w1 | w3, the output matrix -- not the 80-group wo / w2
+    // only the sets the batched step serves this way (forward_batch: ri_serves, qkv_mixed): wq | wk | wv (of one type, or wq | wk + a Q6_K wv), w1 |
+    // w3, the output matrix -- not the 80-group wo / w2
     for (const LayerW &L : layers_) {
         if (L.wk.type == L.wq.type && L.wv.type == L.wq.type) for (const QWeight *w : {&L.wq, &L.wk, &L.wv}) ws.push_back(w);
-        else if (L.wk.type == L.wq.type && L.wv.type == GT_Q6_K && batch_mix_) for (const QWeight *w : {&L.wq, &L.wk, &L.wv}) ws.push_back(w);   // a "more bits" layer: k_matvec_ri_mix
+        // a "more bits" layer: k_matvec_ri_mix
+        else if (L.wk.type == L.wq.type && L.wv.type == GT_Q6_K && batch_mix_) for (const QWeight *w : {&L.wq, &L.wk, &L.wv}) ws.push_back(w);
         if (L.w1.type == L.w3.type) for (const QWeight *w : {&L.w1, &L.w3}) ws.push_back(w);
     }
     if (ri_w2_) for (const LayerW &L : layers_) ws.push_back(&L.w2);
@@ -1293,13 +1350,15 @@ int Engine::decode_batch(const int *slots, int n, const SampleParams &p, int *id
         h_bstage_[B] = ids_out[i]; h_bstage_[MAX_CONVERSATIONS + B] = slots[i]; h_bstage_[2 * MAX_CONVERSATIONS + B] = cv.n_committed; B++;
     }
     if (!B) return 0;
-    if (parity_) {   // oracle-order arithmetic exists for the single-conversation pass only: one pass per conversation (same results as the batched step is tested to give)
+    // oracle-order arithmetic exists for the single-conversation pass only: one pass per conversation (same results as the batched step is tested to
+    // give)
+    if (parity_) {
         for (int r = 0; r < B; r++) { cur_ = h_bstage_[MAX_CONVERSATIONS + r]; const int id = h_bstage_[r]; if (eval_chunk(&id, 1, nullptr)) return 1; conv_[(size_t)cur_].n_past += 1; }
         HIP_CHECK(hipStreamSynchronize(stream_));
         return 0;
     }
-    // rows (token, conversation, position) travel in one copy; the device positions are normally current (k_advance / k_batch_finish keep them), but a
-    // reset may have moved the host's view, so k_batch_begin writes them like eval_chunk does
+    // rows (token, conversation, position) travel in one copy; the device positions are normally current (k_advance / k_batch_finish keep them), but
+    // a reset may have moved the host's view, so k_batch_begin writes them like eval_chunk does
     HIP_CHECK(hipMemcpyAsync(d_btok_, h_bstage_, 768, hipMemcpyHostToDevice, stream_));
     launch_batch_begin(d_npast_, d_bslot_, d_bpos_, B, stream_);
     if (use_graph_) {   // the step for B rows as one hipGraph: the rows live in device memory, so the same graph serves every set of B conversations
@@ -1327,13 +1386,15 @@ int Engine::decode_batch(const int *slots, int n, const SampleParams &p, int *id
 // ====================================================================================================================
 // image path
 // ====================================================================================================================
-// B images in ONE pass over the vision weights (B <= VISION_BATCH_MAX): every GEMM / LayerNorm runs on B x 257 (ViT) or B x 32 (Q-Former) rows, attention
-// per image (grid z).  Per output element the arithmetic does not depend on B (one wave accumulates one 32x32 tile over K in a fixed order), so image b of a
-// batch equals the same image encoded alone bit for bit (tests/test_gpu_parity.py::test_batched_image_encode_is_bit_identical).
+// B images in ONE pass over the vision weights (B <= VISION_BATCH_MAX): every GEMM / LayerNorm runs on B x 257 (ViT) or B x 32 (Q-Former) rows,
+// attention per image (grid z).  Per output element the arithmetic does not depend on B (one wave accumulates one 32x32 tile over K in a fixed
+// order), so image b of a batch equals the same image encoded alone bit for bit
+// (tests/test_gpu_parity.py::test_batched_image_encode_is_bit_identical).
 int Engine::encode_images(const float *const *chw, int B, float *const *out) {
     if (B < 1 || B > VISION_BATCH_MAX) { set_last_error("encode_images: batch size out of range"); return E_ImageSize; }
     if (weights_missing()) return E_LoadModelFileHeader;
-    if (parity_) return encode_images_ref(chw, B, out);                    // MINIGPT4_PARITY: the oracle's accumulation order, image embedding bit-identical to oracle/refcpu.c
+    // MINIGPT4_PARITY: the oracle's accumulation order, image embedding bit-identical to oracle/refcpu.c
+    if (parity_) return encode_images_ref(chw, B, out);
     if (v_generic_) return encode_images_generic(chw, B, out);
     hipStream_t s = stream_;
     const int D = v_D_, M = v_M_, NQ = v_nq_, H = 768;
@@ -1376,12 +1437,14 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
         }
     }
     if (vblocks_.empty()) launch_layernorm(vi_x_, v_lnv_w_, v_lnv_b_, R, D, nullptr, vi_img_h_, s);
-    // Q-Former (masks are all-zero).  Its GEMMs have 32 rows per image: the skinny-M kernel (MINIGPT4_QF_SKINNY=0: the 64x64-tile kernel, A/B)
+    // Q-Former (masks are all-zero).  Its GEMMs have 32 rows per image: the skinny-M kernel (MINIGPT4_QF_SKINNY=0: the
+    // 64x64-tile kernel, A/B)
     auto qgemm = [&](const __half *A, int lda, const __half *W, int ldw, int Mr, int N, int K, const float *bias, const float *residual, bool gelu, float *o, __half *oh, int ldo) {
         if (!(qf_skinny_ && launch_gemm_f16_skinny(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_, o, oh, ldo, s))) launch_gemm_f16(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_, o, oh, ldo, s);
     };
-    // the cross-attention K | V projections of every cross layer depend on the image features only (minigpt4.cpp:1148-1155): ONE [R x D] . [D x n_cross * 1536] launch here instead
-    // of one per cross layer inside the loop; layer i reads its [R][1536] column slice (row stride n_cross * 1536)
+    // the cross-attention K | V projections of every cross layer depend on the image features only (minigpt4.cpp:1148-1155): ONE [R x D] . [D x
+    // n_cross * 1536] launch here instead of one per cross layer inside the loop; layer i reads its [R][1536] column slice (row stride n_cross *
+    // 1536)
     const bool hoist = kv_hoist_ && v_ncross_ > 0 && v_kv_all_w_;
     const int ldkv = hoist ? v_ncross_ * 2 * H : 2 * H;
     if (hoist) launch_gemm_f16(vi_img_h_, D, v_kv_all_w_, D, R, v_ncross_ * 2 * H, D, v_kv_all_b_, nullptr, false, tabs_, vi_kv_, nullptr, ldkv, s);
@@ -1422,10 +1485,11 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
 }
 int Engine::encode_image(const float *chw, float *out) { return encode_images(&chw, 1, &out); }
 
-// What the Q-Former computes before it first looks at the image: hs = LayerNorm(query tokens) (minigpt4.cpp:2236-2246), layer 0's self-attention block on hs
-// (NNSelfAttention + residual + LayerNorm, minigpt4.cpp:1365-1400) and, when layer 0 has cross-attention, its query projection.  None of it depends on the image, so it is
-// evaluated ONCE here -- by the very launches encode_images would issue for one image (32 rows) -- and replicated for the images of a batch: six launches less per encode,
-// bit-identical embeddings.  Fast f16 path only (parity mode and quantised / f32 vision files run their own chains).
+// What the Q-Former computes before it first looks at the image: hs = LayerNorm(query tokens) (minigpt4.cpp:2236-2246), layer 0's self-attention
+// block on hs (NNSelfAttention + residual + LayerNorm, minigpt4.cpp:1365-1400) and, when layer 0 has cross-attention, its query projection.  None of
+// it depends on the image, so it is evaluated ONCE here -- by the very launches encode_images would issue for one image (32 rows) -- and replicated
+// for the images of a batch: six launches less per encode, bit-identical embeddings.  Fast f16 path only (parity mode and quantised / f32 vision
+// files run their own chains).
 void Engine::fold_qformer_constants() {
     qf_folded_ = false;
     if (!qf_fold_ || v_generic_ || qlayers_.empty() || !vi_c_a1_) return;

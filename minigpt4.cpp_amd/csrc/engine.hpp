@@ -30,16 +30,18 @@ public:
     Engine() = default;
     ~Engine();
     int init(const std::string &vision_path, const std::string &llm_path, int seed, int n_ctx, int n_batch);
-    // ---- multi-GPU load: rank 0 loads the files (LOAD_FULL) and broadcasts its two weight arenas; the other ranks run LOAD_RECV: parse the HEADERS only,
-    // lay the arenas out identically (same take() sequence -> same layout hash), allocate them, skip every file read / upload / repack, receive the bytes, then call
-    // weights_received() for what is derived on the device (prefill planes, the replicated query tokens).  LOAD_PLAN does the layout without any device (CPU tests).
+    // ---- multi-GPU load: rank 0 loads the files (LOAD_FULL) and broadcasts its two weight arenas; the other ranks run LOAD_RECV:
+    // parse the HEADERS only, lay the arenas out identically (same take() sequence -> same layout hash), allocate them, skip every file read / upload
+    // / repack, receive the bytes, then call weights_received() for what is derived on the device (prefill planes, the replicated query tokens).
+    // LOAD_PLAN does the layout without any device (CPU tests).
     enum LoadMode { LOAD_FULL = 0, LOAD_RECV = 1, LOAD_PLAN = 2 };
     int weights_received();
     struct ArenaPlan { size_t llm_bytes = 0, vision_bytes = 0; uint64_t llm_hash = 0, vision_hash = 0; };
     static int plan_arenas(const std::string &vision_path, const std::string &llm_path, ArenaPlan &out);   // host only
     ArenaPlan arena_plan() const { ArenaPlan p; p.llm_bytes = llm_arena_.used; p.vision_bytes = vis_arena_.used; p.llm_hash = llm_arena_.layout_hash; p.vision_hash = vis_arena_.layout_hash; return p; }
     LoadMode load_mode() const { return load_mode_; }
-    // native broadcast (dist.hpp): what this context's load did -- world size, rank, milliseconds of the exchange (0 when the load was an ordinary one)
+    // native broadcast (dist.hpp): what this context's load did -- world size, rank, milliseconds of the exchange (0 when the load was an ordinary
+    // one)
     int dist_world() const { return dist_world_; }
     int dist_rank() const { return dist_rank_; }
     float dist_bcast_ms() const { return dist_bcast_ms_; }
@@ -58,7 +60,8 @@ public:
     int add_embedding(const float *data, int n_rows); // llama_eval_embd (minigpt4.cpp:2399-2422)
     int sample_token(const SampleParams &p);          // minigpt4.cpp:2425-2483
     const char *id_to_token(int id) const;            // minigpt4.cpp:2485-2497 (borrowed pointer)
-    void reset() { Conversation &c = conv_[(size_t)cur_]; c.pend_tok.clear(); c.pend_embd.clear(); c.n_past = 0; c.n_committed = 0; }   // minigpt4.cpp:2499-2502 (the selected conversation)
+    // minigpt4.cpp:2499-2502 (the selected conversation)
+    void reset() { Conversation &c = conv_[(size_t)cur_]; c.pend_tok.clear(); c.pend_embd.clear(); c.n_past = 0; c.n_committed = 0; }
     void sync();
     hipStream_t stream() const { return stream_; }
 
@@ -74,25 +77,25 @@ public:
     uint8_t *llm_arena_ptr() { return llm_arena_.base; }
     uint8_t *vision_arena_ptr() { return vis_arena_.base; }
 
-    // ---- several conversations per replica.  The reference holds ONE conversation per context (minigpt4.cpp:2513-2521); here a context owns
-    // n >= 1 of them -- each with its own KV cache region, position and pending queue, sharing the weights -- so that a decode step of B conversations
-    // streams the weights once instead of B times.  All reference entry points act on the selected conversation (0 by default).
+    // ---- several conversations per replica.  The reference holds ONE conversation per context (minigpt4.cpp:2513-2521); here a
+    // context owns n >= 1 of them -- each with its own KV cache region, position and pending queue, sharing the weights -- so that a decode step of B
+    // conversations streams the weights once instead of B times.  All reference entry points act on the selected conversation (0 by default).
     int set_conversations(int n);                      // (re)allocates the KV caches; every conversation is reset.  1 <= n <= MAX_CONVERSATIONS
     int select_conversation(int slot);
     int n_conversations() const { return (int)conv_.size(); }
     int current_conversation() const { return cur_; }
-    // one decode step for `n` distinct conversations: sample each (like sample_token), evaluate the n sampled tokens in ONE weight pass.
-    // ids_out[i] = the token sampled for slots[i]; a conversation whose context is full is sampled but not advanced (the reference discards the error too).
+    // one decode step for `n` distinct conversations: sample each (like sample_token), evaluate the n sampled tokens in ONE weight pass. ids_out[i] =
+    // the token sampled for slots[i]; a conversation whose context is full is sampled but not advanced (the reference discards the error too).
     int decode_batch(const int *slots, int n, const SampleParams &p, int *ids_out);
     static constexpr int MAX_CONVERSATIONS = 64;
 
     // ---- measurement hooks (bench / tests)
     // K greedy decode steps fed back on the device (no host round trip); returns ms per step via hipEvents.
     int decode_loop(int steps, int *tokens_out, float *ms_total);
-    // Per-launch-site table of the decode step: `steps` eager decode steps issuing EXACTLY the launch set the captured hipGraph replays, a hipEvent pair around every site;
-    // JSON array of {site, kernel (symbol as rocprofv3 prints it), calls_per_step, avg_us, bytes_per_call (algorithmic: weight planes / KV rows the site reads)} + the
-    // whole-step time.  The events serialise nothing (one in-order stream) but add their own record cost between launches, so the table is for attribution; the step time
-    // of record is the graph replay's.
+    // Per-launch-site table of the decode step: `steps` eager decode steps issuing EXACTLY the launch set the captured hipGraph replays, a hipEvent
+    // pair around every site; JSON array of {site, kernel (symbol as rocprofv3 prints it), calls_per_step, avg_us, bytes_per_call (algorithmic:
+    // weight planes / KV rows the site reads)} + the whole-step time.  The events serialise nothing (one in-order stream) but add their own record
+    // cost between launches, so the table is for attribution; the step time of record is the graph replay's.
     int profile_sites(int steps, std::string &json);
     float last_encode_ms() const { return last_encode_ms_; }
     void set_parity(bool on);                          // MINIGPT4_PARITY at run time (tests): drops the captured graphs, the next evaluation uses the other mode
@@ -109,11 +112,13 @@ private:
     struct Prep { int kind; const float *x; const float *w; };   // 1: rms_norm(x)*w, 2: x, 3: silu(x)*w -- then quantised for the consumer's type
     void mul_mat(const QWeight &W, int N, float *y, int ldy, const float *residual, hipStream_t s, const Prep *prep, bool fuse, const char *site = "matmul", bool defer_ok = false, bool keep_pending = false);
     bool mul_mat_set(const QWeight *const *W, float *const *y, const float *const *res, int n, int N, int ldy, hipStream_t s, const Prep *prep, bool fuse, bool silu_pair = false, const char *site = "matmul", bool defer_ok = false, bool keep_pending = false);
-    // prompt passes: the combine of a K-split mat-mul is left to the kernel that consumes the result (rope + cache append, the next norm + quantisation, silu * mul); pend_
-    // describes the slabs until then, flush_pending runs the combine as its own launch when the next consumer is not one of those.  MINIGPT4_DEFER_COMBINE=0: always flush (A/B)
+    // prompt passes: the combine of a K-split mat-mul is left to the kernel that consumes the result (rope + cache append, the next norm +
+    // quantisation, silu * mul); pend_ describes the slabs until then, flush_pending runs the combine as its own launch when the next consumer is not
+    // one of those.  MINIGPT4_DEFER_COMBINE=0: always flush (A/B)
     SlabSrc pend_; bool defer_combine_ = true;
     const __half *xh_override_ = nullptr; int f16_pair_ = 7;   // F16 prompt pass: w1 | w3 + silu * mul in one launch, its fp16 rows feed w2 (MINIGPT4_F16_PAIR=0: A/B)
-    bool batch_sets_ = true;   // batched decode of > batch_rows_max_ conversations through the prompt pass's set launches (MINIGPT4_BATCH_SETS=0: one launch per matrix, A/B)
+    // batched decode of > batch_rows_max_ conversations through the prompt pass's set launches (MINIGPT4_BATCH_SETS=0: one launch per matrix, A/B)
+    bool batch_sets_ = true;
     void flush_pending(hipStream_t s);
     void prep_rms(const float *x, const float *w, int N, int K, int mask, hipStream_t s);
     void upload_qweight(const TensorMeta &t, const uint8_t *file_base, QWeight &w);
@@ -156,32 +161,43 @@ private:
     __half *kc_ = nullptr, *vc_ = nullptr;
     float *cos_ = nullptr, *sin_ = nullptr;
     Tables tabs_;
-    Tables tabs_dec_;                  // what the DECODE step's attention and SiLU launches get: tabs_, or (MINIGPT4_COMPUTED_TABLES, default on) null exp / silu pointers = the
-                                       // table values computed in the kernel instead of gathered from the 128 KB tables (qtraits.hpp exp_h / silu_h); parity mode uses tabs_
+    // what the DECODE step's attention and SiLU launches get: tabs_, or (MINIGPT4_COMPUTED_TABLES, default on) null exp / silu pointers = the
+    Tables tabs_dec_;
+                                       // table values computed in the kernel instead of gathered from the 128 KB tables (qtraits.hpp exp_h / silu_h);
+                                       // parity mode uses tabs_
     // activations
     float *x_ = nullptr, *q_ = nullptr, *k_ = nullptr, *v_ = nullptr, *att_ = nullptr, *h1_ = nullptr, *h3_ = nullptr, *logits_ = nullptr;
     ActQ act_;
     // per conversation (indexed by slot): position, greedy token of the last evaluation, next input token; logits_ is [slots][n_vocab]
     int *d_npast_ = nullptr, *d_argmax_ = nullptr, *d_feed_ = nullptr;
     int *d_tokens_ = nullptr; void *d_scratch_ = nullptr;
-    int *d_btok_ = nullptr, *d_bslot_ = nullptr, *d_bpos_ = nullptr; float *blogits_ = nullptr;   // batched decode: row tokens / conversations / positions (one 768-byte slab), [rows][n_vocab] logits
-    std::vector<hipGraphExec_t> batch_graph_;                             // [B]: the batched step for B rows (rows are described in device memory, so one graph serves any slot set)
+    // batched decode: row tokens / conversations / positions (one 768-byte slab), [rows][n_vocab] logits
+    int *d_btok_ = nullptr, *d_bslot_ = nullptr, *d_bpos_ = nullptr; float *blogits_ = nullptr;
+    // [B]: the batched step for B rows (rows are described in device memory, so one graph serves any slot set)
+    std::vector<hipGraphExec_t> batch_graph_;
     int *h_argmax_ = nullptr, *h_bstage_ = nullptr; float *h_logits_ = nullptr; int logits_host_slot_ = -1;
     bool use_graph_ = true, use_v2_ = true, attn_prefill_ = true, parity_ = false;
     FILE *trace_file_ = nullptr;       // MINIGPT4_PARITY_TRACE
-    void *attn_ws_ = nullptr; int attn_splits_ = 6; int attn_split_t_ = 768; bool attn_split_now_ = false; int attn_splits_forced_ = 0;   // key-split decode attention (llm_kernels.hip: k_attn_split_*)
+    // key-split decode attention (llm_kernels.hip: k_attn_split_*)
+    void *attn_ws_ = nullptr; int attn_splits_ = 6; int attn_split_t_ = 768; bool attn_split_now_ = false; int attn_splits_forced_ = 0;
     int batch_rows_max_ = 4; int batch_fuse_ = -1; int n_cus_ = 256;
-    // round 5: B = 2..4 rows per weight pass on the int8 matrix cores over a row-interleaved second image of the k-quant matrices (ri_kernels.hip); built by
-    // set_conversations(n > 1) -- a context with one conversation never pays the memory.  MINIGPT4_RI=0: the v_dot4 multi-row mat-vec of rounds 2-4 (A/B)
+    // round 5: B = 2..4 rows per weight pass on the int8 matrix cores over a row-interleaved second image of the k-quant matrices (ri_kernels.hip);
+    // built by set_conversations(n > 1) -- a context with one conversation never pays the memory.  MINIGPT4_RI=0: the v_dot4 multi-row mat-vec of
+    // rounds 2-4 (A/B)
     bool computed_tables_ = true;
-    bool ri_w2_ = true;                                         // B = 4: w2 (80 row groups x long K) on the K-split form of k_matvec_ri (+1.9 %; MINIGPT4_RI_W2=0: the v_dot4 launch)
-    bool use_ri_ = true, ri_ready_ = false, ri_fuse_ = false;   // ri_fuse_: rows prepared inside the MFMA launches -- measured slower (profiles/r05_batched_decode_inengine.log), off
+    // B = 4: w2 (80 row groups x long K) on the K-split form of k_matvec_ri (+1.9 %; MINIGPT4_RI_W2=0: the v_dot4 launch)
+    bool ri_w2_ = true;
+    // ri_fuse_: rows prepared inside the MFMA launches -- measured slower (profiles/r05_batched_decode_inengine.log), off
+    bool use_ri_ = true, ri_ready_ = false, ri_fuse_ = false;
     DeviceArena ri_arena_;
     float *ri_slabs_ = nullptr; size_t ri_slab_floats_ = 0; unsigned *ri_tickets_ = nullptr; int ri_ticket_n_ = 0;   // K-split workspace of k_matvec_ri (zeroed tickets)
     std::vector<std::pair<const QWeight *, RiPlanes>> ri_map_;
     const RiPlanes *ri_of(const QWeight *w) const { for (const auto &e : ri_map_) if (e.first == w) return &e.second; return nullptr; }
     void build_ri_planes();
-    bool batch_mix_ = true;            // MINIGPT4_BATCH_MIX=0: wq|wk and wv of a mixed-type layer as two launches (the form before k_matvec_tn_mix)   // MINIGPT4_BATCH_ROWS_MAX: batches up to this size use the multi-row mat-vec; 0 = never.  Measured (profiles/r02x_*): from 5 rows on the int8-MFMA kernels (single-wave workgroups, one token tile) beat two passes of the 4-row mat-vec
+    // MINIGPT4_BATCH_MIX=0: wq|wk and wv of a mixed-type layer as two launches (the form before k_matvec_tn_mix)   // MINIGPT4_BATCH_ROWS_MAX:
+    // batches up to this size use the multi-row mat-vec; 0 = never.  Measured (profiles/r02x_*): from 5 rows on the int8-MFMA kernels (single-wave
+    // workgroups, one token tile) beat two passes of the 4-row mat-vec
+    bool batch_mix_ = true;
     static constexpr int FUSE_DEFAULT = 87; int fuse_mask_ = FUSE_DEFAULT;
     // profiling (profile_sites)
     bool prof_on_ = false;
@@ -208,17 +224,19 @@ private:
     __half *vi_patches_ = nullptr, *vi_ln_h_ = nullptr, *vi_att_h_ = nullptr, *vi_mlp_h_ = nullptr, *vi_img_h_ = nullptr, *vi_hs_h_ = nullptr, *vi_a1_h_ = nullptr, *vi_a2_h_ = nullptr, *vi_ctx_h_ = nullptr, *vi_im_h_ = nullptr;
     float last_encode_ms_ = 0;
     bool qf_skinny_ = true;            // Q-Former GEMMs on k_gemm_f16_skinny
-    // round 5, launch count of the image path: (1) the cross-attention K | V projections of ALL cross layers are one weight block [n_cross * 1536][D] -- they depend on the
-    // image features only (minigpt4.cpp:1148-1155), so one GEMM right after ln_vision replaces one per cross layer; (2) what the Q-Former computes BEFORE it first looks at
-    // the image -- LayerNorm(query tokens), layer 0's self-attention block and its cross-attention query projection -- does not depend on the image at all: evaluated once
-    // at load time by the same launches (fold_qformer_constants), kept for every image of a batch.  MINIGPT4_QF_FOLD=0 / MINIGPT4_KV_HOIST=0: the round-4 form (A/B).
+    // round 5, launch count of the image path: (1) the cross-attention K | V projections of ALL cross layers are one weight block [n_cross * 1536][D]
+    // -- they depend on the image features only (minigpt4.cpp:1148-1155), so one GEMM right after ln_vision replaces one per cross layer; (2) what
+    // the Q-Former computes BEFORE it first looks at the image -- LayerNorm(query tokens), layer 0's self-attention block and its cross-attention
+    // query projection -- does not depend on the image at all: evaluated once at load time by the same launches (fold_qformer_constants), kept for
+    // every image of a batch.  MINIGPT4_QF_FOLD=0 / MINIGPT4_KV_HOIST=0: the round-4 form (A/B).
     __half *v_kv_all_w_ = nullptr; float *v_kv_all_b_ = nullptr; int v_ncross_ = 0;
     float *vi_c_a1_ = nullptr, *vi_c_qq_ = nullptr; __half *vi_c_a1_h_ = nullptr;
     bool qf_fold_ = true, qf_folded_ = false, kv_hoist_ = true;
     void fold_qformer_constants();
 
-    // ---- vision files whose Linear weights are not all F16 (an `--ftype f32` conversion, or a file written by minigpt4_quantize_model): every Linear is a
-    // QWeight served by the LLM mat-mul kernels (activations quantised to the weight type's vec_dot_type, exactly ggml's mul_mat), activations stay fp32.
+    // ---- vision files whose Linear weights are not all F16 (an `--ftype f32` conversion, or a file written by minigpt4_quantize_model): every
+    // Linear is a QWeight served by the LLM mat-mul kernels (activations quantised to the weight type's vec_dot_type, exactly ggml's mul_mat),
+    // activations stay fp32.
     bool v_generic_ = false;
     struct GLin { QWeight w; };
     struct GBlock { GLin qkv, proj, fc1, fc2; };

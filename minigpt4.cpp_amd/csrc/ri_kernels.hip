@@ -1,20 +1,24 @@
-// Batched decode (B = 2..4 conversations per weight pass, SURVEY.md 8f-1 / BASELINE.json configs[3]: 4 requests per replica) on the int8 matrix cores -- round 5.
+// Batched decode (B = 2..4 conversations per weight pass, SURVEY.md 8f-1 / BASELINE.json configs[3]: 4 requests per replica) on the int8 matrix cores
+// -- round 5.
 //
-// The multi-row mat-vec of rounds 2-4 (k_matvec_tn, llm_kernels.hip) keeps the single-row kernel's lane map -- 64 lanes share ONE weight row, a lane owns a 32-weight unit --
-// and multiplies every unit against each of the B activation rows with v_dot4_i32_i8: 8 dot instructions per row and unit, vector-issue bound at B = 4 (84 % VALU busy,
-// weights at 2 TB/s).  v_mfma_i32_4x4x4_16B_i8 computes 16 independent 4 x 4 x 4 products per instruction; with the TOKENS as the 4 rows of the A operand (the same in all 16
-// blocks) and 64 different WEIGHT ROWS as the columns of the B operand, one instruction multiplies 4 consecutive weights of 64 rows against up to 4 tokens -- the work of
-// four v_dot4 per lane -- and accumulates it in the lane's own four registers (register r = token r).  That needs lane = weight ROW, i.e. loads of 16 bytes per row at a
-// stride of one row; so the k-quant matrices get a second, ROW-INTERLEAVED image (built on the device from the ordinary planes when a context is given more than one
-// conversation: Engine::build_ri_planes): for every group of 64 rows and every unit the 64 rows' 16-byte pieces back to back (1 KiB per wave load), the same for the
-// high-bit words and the per-super-block headers.  Micro-benchmark on the 13B w1|w3 set (profiles/r05_batched_decode_mfma.log): 22 us per launch at B = 2, 3 and 4 against
-// 25.6 / 29.7 / 33.8 us for k_matvec_tn.
+// The multi-row mat-vec of rounds 2-4 (k_matvec_tn, llm_kernels.hip) keeps the single-row kernel's lane map -- 64 lanes share ONE weight row, a lane
+// owns a 32-weight unit -- and multiplies every unit against each of the B activation rows with v_dot4_i32_i8: 8 dot instructions per row and unit,
+// vector-issue bound at B = 4 (84 % VALU busy, weights at 2 TB/s).  v_mfma_i32_4x4x4_16B_i8 computes 16 independent 4 x 4 x 4 products per
+// instruction; with the TOKENS as the 4 rows of the A operand (the same in all 16 blocks) and 64 different WEIGHT ROWS as the columns of the B
+// operand, one instruction multiplies 4 consecutive weights of 64 rows against up to 4 tokens -- the work of four v_dot4 per lane -- and accumulates
+// it in the lane's own four registers (register r = token r).  That needs lane = weight ROW, i.e. loads of 16 bytes per row at a stride of one row;
+// so the k-quant matrices get a second, ROW-INTERLEAVED image (built on the device from the ordinary planes when a context is given more than one
+// conversation: Engine::build_ri_planes): for every group of 64 rows and every unit the 64 rows' 16-byte pieces back to back (1 KiB per wave load),
+// the same for the high-bit words and the per-super-block headers.  Micro-benchmark on the 13B w1|w3 set (profiles/r05_batched_decode_mfma.log): 22
+// us per launch at B = 2, 3 and 4 against 25.6 / 29.7 / 33.8 us for k_matvec_tn.
 //
-// Arithmetic: ggml's (reference minigpt4.cpp:2373 -> llama_eval -> ggml_mul_mat, k-quant x Q8_K): exact int32 sub-block dots (the MFMA's integer accumulation), integer
-// sub-block scales, one fp32 update per super-block with d_w * d_a.  Per output the super-blocks of a K quarter are added in order and the four quarters (the four waves
-// of a workgroup) in wave order: a fixed order, but not k_matvec_tn's -- results differ from it in the last bits like any two summation orders.
+// Arithmetic: ggml's (reference minigpt4.cpp:2373 -> llama_eval -> ggml_mul_mat, k-quant x Q8_K): exact int32 sub-block dots (the MFMA's integer
+// accumulation), integer sub-block scales, one fp32 update per super-block with d_w * d_a.  Per output the super-blocks of a K quarter are added in
+// order and the four quarters (the four waves of a workgroup) in wave order: a fixed order, but not k_matvec_tn's -- results differ from it in the
+// last bits like any two summation orders.
 //   Q4_K / Q5_K: min term sum_j m_j * bsum_j as four more MFMAs per super-block on the digit split bsum = 128 hi + lo (the quantiser's bsq plane).
-//   Q6_K: weights enter as their unsigned 6-bit codes; the -32 offset is sum_g sc_g * bsum16_g, eight MFMAs per super-block on the digit split of the 16-element sums.
+//   Q6_K: weights enter as their unsigned 6-bit codes; the -32 offset is sum_g sc_g * bsum16_g, eight MFMAs per super-block on the digit split of the
+//   16-element sums.
 #include "kernels.hpp"
 #include "devutil.hpp"
 #include "qtraits.hpp"
@@ -72,8 +76,9 @@ void launch_ri_build(const QWeight &w, const RiPlanes &p, hipStream_t s) {
 struct RiMat { RiPlanes p; float *y; const float *res; };
 struct RiArgs { RiMat m[3]; int n_mat, groups_each, rows_each, K, N, ldy; const float *px, *pw; int ldx;
                 int n_a;            // k_matvec_ri_mix: the first n_a matrices are of type TA, the others of type TB
-                // ksplit > 1 (matrices with few row groups and a long K: the 13B w2 has 80 groups x 54 super-blocks): `ksplit` workgroups share a row group, each a contiguous
-                // K range; their partial sums go to `slabs` [group][part][4][64] and the LAST one to arrive (ticket per group, self-resetting) adds them in part order
+                // ksplit > 1 (matrices with few row groups and a long K: the 13B w2 has 80 groups x 54 super-blocks): `ksplit` workgroups share a row
+                // group, each a contiguous K range; their partial sums go to `slabs` [group][part][4][64] and the LAST one to arrive (ticket per
+                // group, self-resetting) adds them in part order
                 int ksplit; float *slabs; unsigned *tickets; };   // px: rows prepared inside the launch (PRO): rms_norm(px_t) * pw, quantised
 
 __device__ __forceinline__ void ri_scale_min_words(const v4i_r &h, unsigned &scw0, unsigned &scw1, unsigned &mw0, unsigned &mw1) {
@@ -83,8 +88,9 @@ __device__ __forceinline__ void ri_scale_min_words(const v4i_r &h, unsigned &scw
 }
 __device__ __forceinline__ float ri_h2f(unsigned short h) { return __half2float(__ushort_as_half(h)); }
 
-// One super-block of one row group as a lane holds it: 8 units of ITS row (16 B each), the high bits, the 16-byte scale header (Q6_K: 16 int8 scales) and Q6_K's fp16 d
-// (one type for every format -- only the words a format uses are ever live -- so that the mixed launch can carry ONE prefetched image across its prologue)
+// One super-block of one row group as a lane holds it: 8 units of ITS row (16 B each), the high bits, the 16-byte scale header (Q6_K: 16 int8 scales)
+// and Q6_K's fp16 d (one type for every format -- only the words a format uses are ever live -- so that the mixed launch can carry ONE prefetched
+// image across its prologue)
 struct RiRaw { v4i_r q[8]; unsigned p[16]; v4i_r h; unsigned short d; };
 template <int T>
 __device__ __forceinline__ void ri_fetch(const uint8_t *pq, const uint8_t *pp, const uint8_t *ph, const uint8_t *pd, int sb, int NSB, RiRaw &r) {
@@ -100,7 +106,8 @@ __device__ __forceinline__ void ri_fetch(const uint8_t *pq, const uint8_t *pp, c
     r.h = __builtin_nontemporal_load(reinterpret_cast<const v4i_r *>(ph + (size_t)sbc * 1024));
     if (Q6) r.d = __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(pd + (size_t)sbc * 128));
 }
-// acc[t] += (this lane's weight row, super-block sb) . (token row t); qa / da: the LDS image of the token row this lane feeds the A operand from (row lane & 3)
+// acc[t] += (this lane's weight row, super-block sb) . (token row t); qa / da: the LDS image of the token row this lane feeds the A operand from (row
+// lane & 3)
 template <int T>
 __device__ __forceinline__ void ri_consume(const int8_t *qa, const int8_t *da, const float *dk, int NSB, int sb, const RiRaw &r, float (&acc)[4]) {
     constexpr bool Q6 = T == GT_Q6_K, Q5 = T == GT_Q5_K;
@@ -144,7 +151,8 @@ __device__ __forceinline__ void ri_consume(const int8_t *qa, const int8_t *da, c
             acc[t] = fmaf(-(dmin * dkt), (float)(Mh[t] * 128 + Ml[t]), acc[t]);
         }
     } else {
-        // the -32 offset of the 6-bit codes: sum over the 16 scale groups of sc_g * bsum16_g, digit split (scale bytes and digit bytes are in the same order)
+        // the -32 offset of the 6-bit codes: sum over the 16 scale groups of sc_g * bsum16_g, digit split (scale bytes and digit bytes are in the
+        // same order)
         const v4i_r dl = *reinterpret_cast<const v4i_r *>(da + sb * 32), dh = *reinterpret_cast<const v4i_r *>(da + sb * 32 + 16);
         v4i_r Cl = {0, 0, 0, 0}, Ch = {0, 0, 0, 0};
 #pragma unroll
@@ -154,8 +162,8 @@ __device__ __forceinline__ void ri_consume(const int8_t *qa, const int8_t *da, c
         for (int t = 0; t < 4; t++) acc[t] = fmaf(d * dk[t * NSB + sb], (float)(isum[t] - 32 * (Ch[t] * 128 + Cl[t])), acc[t]);
     }
 }
-// super-blocks [sb0, sb1) of row group gl of one matrix, two-stage register pipeline; `cur` already holds super-block sb0 (ri_fetch issued by the caller: for a workgroup's
-// first task BEFORE it stages the activation image, so that the first weight bytes are in flight during the prologue)
+// super-blocks [sb0, sb1) of row group gl of one matrix, two-stage register pipeline; `cur` already holds super-block sb0 (ri_fetch issued by the
+// caller: for a workgroup's first task BEFORE it stages the activation image, so that the first weight bytes are in flight during the prologue)
 struct RiPtr { const uint8_t *pq, *pp, *ph, *pd; };
 template <int T>
 __device__ __forceinline__ RiPtr ri_ptrs(const RiPlanes &P, int gl, int U, int NSB, int lane) {
@@ -178,8 +186,8 @@ __device__ __forceinline__ void ri_stream(const RiPtr &p, int NSB, int sb0, int 
         ++sb;
     }
 }
-// the <= 4 quantised rows -> LDS, K range [c_sb0, c_sb1) super-blocks; the loads of a batch are all issued before its first LDS store (one memory round trip per batch
-// instead of one per 16 bytes and thread)
+// the <= 4 quantised rows -> LDS, K range [c_sb0, c_sb1) super-blocks; the loads of a batch are all issued before its first LDS store (one memory
+// round trip per batch instead of one per 16 bytes and thread)
 __device__ __forceinline__ void ri_stage_rows(const ActQ &A, int8_t *q8, int N, int K, int c_sb0, int c_sb1, int NT) {
     constexpr int SB = 6;
     const int cK = (c_sb1 - c_sb0) * 256, lim = 4 * cK, step = NT * 16;
@@ -198,7 +206,8 @@ __device__ __forceinline__ void ri_stage_rows(const ActQ &A, int8_t *q8, int N, 
         }
     }
 }
-// the digit image of the rows' block sums for type T (header below), super-blocks [c_sb0, c_sb1); dk != null: the rows' Q8_K scales too.  NT = threads of the workgroup
+// the digit image of the rows' block sums for type T (header below), super-blocks [c_sb0, c_sb1); dk != null: the rows' Q8_K scales too.  NT =
+// threads of the workgroup
 template <int T>
 __device__ __forceinline__ void ri_stage_digits(const ActQ &A, int8_t *dg, float *dk, int N, int NSB, int K, int c_sb0, int c_sb1, int NT) {
     constexpr bool Q6 = T == GT_Q6_K;
@@ -225,11 +234,12 @@ __device__ __forceinline__ void ri_stage_digits(const ActQ &A, int8_t *dg, float
 
 // LDS image of the <= 4 activation rows (rows >= N are zero):  q8 [4][K]  |  dg [4][NSB][DG]  |  dk [4][NSB]  |  red [WPB][4][64]
 //   DG = 16 (Q4_K / Q5_K): the quantiser's digit-split per-32 sums (bytes 0..7 low digits of sub-blocks 0..7, 8..15 high digits)
-//   DG = 32 (Q6_K): the 16-element sums of the super-block in the ORDER OF THE SCALE BYTES (unit i = (n, c, h): byte 2 i <-> group 8 n + 2 c + h, byte 2 i + 1 <-> that + 4),
-//                   bytes 0..15 low digits (s & 127), 16..31 high digits (s >> 7)
-// PRO: the rows are prepared inside the launch -- rms_norm(x_t) * w (ggml_rms_norm: fp32 squares summed in double, eps 1e-6) and ggml's Q8_K quantisation, the arithmetic of
-// k_rms_quant -- by every workgroup into its own LDS image (the image is needed there anyway): one standalone preparation launch less in front of wq|wk|wv, w1|w3 and the
-// output matrix (~5 us each against ~1 us of redundant work per workgroup).
+//   DG = 32 (Q6_K): the 16-element sums of the super-block in the ORDER OF THE SCALE BYTES (unit i = (n, c, h): byte 2 i <-> group 8 n + 2 c + h,
+//   byte 2 i + 1 <-> that + 4),
+//                   bytes 0..15 low digits (s & 127), 16..31 high digits (s >> 7) PRO: the rows are prepared inside the launch -- rms_norm(x_t) * w
+//                   (ggml_rms_norm: fp32 squares summed in double, eps 1e-6) and ggml's Q8_K quantisation, the arithmetic of k_rms_quant -- by every
+//                   workgroup into its own LDS image (the image is needed there anyway): one standalone preparation launch less in front of wq|wk|wv,
+//                   w1|w3 and the output matrix (~5 us each against ~1 us of redundant work per workgroup).
 template <int T, int WPB, bool PRO>
 __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const ActQ A) {
     constexpr bool Q6 = T == GT_Q6_K;
@@ -299,8 +309,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
             }
         }
     } else {
-    // a workgroup that serves exactly ONE task of the K-split form copies only that task's K range (320 workgroups each copying the 55 KB image of a K = 13824 row set
-    // would move more bytes than a third of the weights)
+    // a workgroup that serves exactly ONE task of the K-split form copies only that task's K range (320 workgroups each copying the 55 KB image of a
+    // K = 13824 row set would move more bytes than a third of the weights)
     int c_sb0 = 0, c_sb1 = NSB;
     if (a.ksplit > 1 && (int)gridDim.x >= a.n_mat * a.groups_each * a.ksplit) { const int part = (int)blockIdx.x % a.ksplit; c_sb0 = (int)((long long)NSB * part / a.ksplit); c_sb1 = (int)((long long)NSB * (part + 1) / a.ksplit); }
     ri_stage_rows(A, q8, N, K, c_sb0, c_sb1, 64 * WPB);
@@ -331,9 +341,10 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
         if (S == 1) {
             if (wv < N) { const size_t o = (size_t)wv * a.ldy + (size_t)gl * 64 + lane; M.y[o] = M.res ? s + M.res[o] : s; }
         } else {
-            // hand-off without cache maintenance (a release / acquire FENCE writes back and invalidates the whole L2 of the XCD -- measured: 78 us instead of 22 for the 13B w2,
-            // the weight stream of every other workgroup loses its lines): the partial sums are agent-scope (write-through, sc1) stores, drained with vmcnt(0) before the
-            // ticket; the last arriver reads them with agent-scope (cache-bypassing) loads
+            // hand-off without cache maintenance (a release / acquire FENCE writes back and invalidates the whole L2 of the XCD -- measured: 78 us
+            // instead of 22 for the 13B w2, the weight stream of every other workgroup loses its lines): the partial sums are agent-scope
+            // (write-through, sc1) stores, drained with vmcnt(0) before the ticket; the last arriver reads them with agent-scope (cache-bypassing)
+            // loads
             if (wv < N) __hip_atomic_store(a.slabs + ((size_t)task * 4 + wv) * 64 + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -353,9 +364,9 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
     }
 }
 
-// A "more bits" layer's wq | wk (Q4_K / Q5_K) + wv (Q6_K) in ONE launch (the single-row step's k_matvec_mix, the v_dot4 batched step's k_matvec_tn_mix): the same row image and
-// the same per-group stream as k_matvec_ri, the digit image of the block sums staged once per type; row groups of the first n_a matrices stream as TA, the others as TB.
-// No K split, rows prepared by the caller.
+// A "more bits" layer's wq | wk (Q4_K / Q5_K) + wv (Q6_K) in ONE launch (the single-row step's k_matvec_mix, the v_dot4 batched step's
+// k_matvec_tn_mix): the same row image and the same per-group stream as k_matvec_ri, the digit image of the block sums staged once per type; row
+// groups of the first n_a matrices stream as TA, the others as TB. No K split, rows prepared by the caller.
 template <int TA, int TB, int WPB>
 __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri_mix(const RiArgs a, const ActQ A) {
     constexpr int DGA = TA == GT_Q6_K ? 32 : 16, DGB = TB == GT_Q6_K ? 32 : 16;
@@ -367,7 +378,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri_mix(const RiArgs a, c
     float *dk = reinterpret_cast<float *>(dgb + 4 * NSB * DGB);
     float *red = dk + 4 * NSB;
     const int sb_per = (NSB + WPB - 1) / WPB, sb0 = wv * sb_per, sb1 = min(NSB, sb0 + sb_per);
-    // (no prefetch across the prologue here: one register image that either type may have filled stays live in full through both branches -- 324-396 B of scratch)
+    // (no prefetch across the prologue here: one register image that either type may have filled stays live in full through both branches -- 324-396
+    // B of scratch)
     ri_stage_rows(A, q8, N, K, 0, NSB, 64 * WPB);
     ri_stage_digits<TA>(A, dga, dk, N, NSB, K, 0, NSB, 64 * WPB);
     ri_stage_digits<TB>(A, dgb, nullptr, N, NSB, K, 0, NSB, 64 * WPB);
@@ -412,7 +424,8 @@ static void launch_ri_k(const RiArgs &a, const ActQ &A, unsigned blocks, size_t 
 template <int T>
 static bool launch_ri_t(const RiArgs &a, const ActQ &A, hipStream_t s) {
     const int total = a.n_mat * a.groups_each;
-    // 4 waves per workgroup (each a K quarter), two workgroups per CU; matrices with fewer 64-row groups than CUs (wo, w2: 80 groups at the 13B width) split K over 8 waves
+    // 4 waves per workgroup (each a K quarter), two workgroups per CU; matrices with fewer 64-row groups than CUs (wo, w2: 80 groups at the 13B
+    // width) split K over 8 waves
     const bool wide = total < g_ri_cus && a.ksplit <= 1, pro = a.px != nullptr;
     const size_t lds = ri_lds(T, a.K, wide ? 8 : 4, pro);
     if (lds > (wide ? 150u : 78u) * 1024u) return false;
@@ -420,11 +433,12 @@ static bool launch_ri_t(const RiArgs &a, const ActQ &A, hipStream_t s) {
     else { const unsigned nb = (unsigned)std::min(total * std::max(1, a.ksplit), 2 * g_ri_cus); if (pro) launch_ri_k<T, 4, true>(a, A, nb, lds, s); else launch_ri_k<T, 4, false>(a, A, nb, lds, s); }
     return true;
 }
-// y[m][t * ldy + r] = W_m[r] . act[t] (+ residual[m][t * ldy + r]) for N = 1..4 prepared rows (A: Q8_K image incl. bsq) against 1..3 same-type, same-shape k-quant matrices
-// that carry their row-interleaved image (ri[k]); false -> outside this kernel's range, nothing launched
+// y[m][t * ldy + r] = W_m[r] . act[t] (+ residual[m][t * ldy + r]) for N = 1..4 prepared rows (A: Q8_K image incl. bsq) against 1..3 same-type,
+// same-shape k-quant matrices that carry their row-interleaved image (ri[k]); false -> outside this kernel's range, nothing launched
 static float *g_ri_slabs = nullptr; static unsigned *g_ri_tickets = nullptr; static size_t g_ri_slab_floats = 0; static int g_ri_ticket_n = 0;
 void set_ri_workspace(float *slabs, size_t slab_floats, unsigned *tickets, int n_tickets) { g_ri_slabs = slabs; g_ri_slab_floats = slab_floats; g_ri_tickets = tickets; g_ri_ticket_n = n_tickets; }
-// K split over workgroups for a set with few row groups and a long K (ri_kernels.hip header): parts of >= 8 super-blocks (two per wave), at most 4, only when the workspace is set
+// K split over workgroups for a set with few row groups and a long K (ri_kernels.hip header): parts of >= 8 super-blocks (two per wave), at most 4,
+// only when the workspace is set
 int ri_ksplit(int total_groups, int K) {
     const int NSB = K / 256;
     if (!g_ri_slabs || total_groups >= g_ri_cus / 2 || total_groups > g_ri_ticket_n) return 1;
@@ -459,7 +473,8 @@ static void launch_ri_mix_k(const RiArgs &a, const ActQ &A, unsigned blocks, siz
     if (!attr) { HIP_IGNORE(lds_optin_max(&k_matvec_ri_mix<TA, TB, WPB>)); attr = true; }
     hipLaunchKernelGGL((k_matvec_ri_mix<TA, TB, WPB>), dim3(blocks), dim3(64 * WPB), lds, s, a, A);
 }
-// wq | wk of one type (Q4_K / Q5_K) and wv of another (Q6_K), same shape, every one with its row-interleaved image: y_k[t * ldy + r] = W_k[r] . act[t] in one launch
+// wq | wk of one type (Q4_K / Q5_K) and wv of another (Q6_K), same shape, every one with its row-interleaved image: y_k[t * ldy + r] = W_k[r] .
+// act[t] in one launch
 bool launch_matvec_ri_mixed(const QWeight *const *Wa, const RiPlanes *const *ria, float *const *ya, int na, const QWeight *const *Wb, const RiPlanes *const *rib, float *const *yb, int nb,
                             const ActQ &A, int N, int ldy, hipStream_t s) {
     if (na < 1 || nb < 1 || na + nb > 3 || N < 1 || N > 4 || !A.q8k || !A.dk || !A.bsk || !A.bsq) return false;
