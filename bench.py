@@ -282,10 +282,19 @@ def main():
         log(f"[bench r{rank}] rank {rank} of {world} started (launcher: {os.environ.get('MG4_BENCH_LAUNCHER', 'external')}), local GPU {local_rank}")
         import torch
         import torch.distributed as dist_
-        if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
-            raise SystemExit(f"bench.py rank {rank}: no HIP device {local_rank} visible ({torch.cuda.device_count() if torch.cuda.is_available() else 0} GPUs); one GPU per rank is required")
+        # MG4_BENCH_REHEARSAL=1: a functional dress rehearsal of the N > 1 path on a box with FEWER GPUs than ranks -- the ranks share the visible devices and the collectives
+        # run on gloo (RCCL refuses two ranks of one communicator on one device).  Everything else is the real path: self-launch, receive-mode load, arena broadcast out of
+        # device memory, checksum agreement, barriers, max-over-ranks timing, gathers.  Its rates are NOT measurements (the ranks contend for one GPU); the line says so.
+        rehearsal = os.environ.get("MG4_BENCH_REHEARSAL") == "1"
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if ndev <= 0 or (ndev <= local_rank and not rehearsal):
+            raise SystemExit(f"bench.py rank {rank}: no HIP device {local_rank} visible ({ndev} GPUs); one GPU per rank is required")
+        local_rank = local_rank % ndev
         torch.cuda.set_device(local_rank)
-        dist_.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist_.init_process_group(backend="gloo")
+        else:
+            dist_.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_
 
     def barrier():
@@ -442,7 +451,10 @@ def main():
         "device_ms_per_token_graph_loop": dev_ms_per_tok, "device_tokens_per_s_graph_loop": 1e3 / dev_ms_per_tok,
         "weight_bytes_per_token": wbytes, "decode_weight_GBps_end_to_end": wbytes * K / dt / 1e9,
         "model_load_s": load_s, "recv_load_s": recv_load_s, "weight_bcast_ms": bcast_ms,
-        "rccl_ranks": dist.get_world_size() if dist is not None else 1, "launcher": os.environ.get("MG4_BENCH_LAUNCHER", "external") if world > 1 else "none",
+        "rccl_ranks": dist.get_world_size() if dist is not None else 1, "collective_backend": dist.get_backend() if dist is not None else None,
+        "rehearsal": ("MG4_BENCH_REHEARSAL=1: the ranks SHARE the visible GPU(s) and talk over gloo -- a functional run of the N > 1 path, every rate in this line is invalid as "
+                      "a measurement") if (world > 1 and os.environ.get("MG4_BENCH_REHEARSAL") == "1") else None,
+        "launcher": os.environ.get("MG4_BENCH_LAUNCHER", "external") if world > 1 else "none",
         "weight_bcast": D.bcast_report(lstats), "load_mode": lstats["mode"],
         "roofline": roofline,
     }
