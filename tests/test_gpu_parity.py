@@ -613,6 +613,35 @@ def test_long_context_decode_matches_oracle(gpu_lib, tiny_files):
         gpu_lib.minigpt4_free(ctx)
 
 
+def test_prompt_pass_beyond_the_prompt_attention_kernels_lds_rows(gpu_lib, tiny_files):
+    """The prompt attention kernels keep 16 score rows of the WHOLE context in LDS: at this file's head size 64 they serve contexts up to 2240 keys (1984 at head size 128).  A prompt
+    chunk that ends beyond that is routed through the decode attention kernel, one query row per workgroup (launch_attn_prefill returns false, Engine::forward falls back) --
+    the logits must still be the oracle's, and decoding goes on from there."""
+    import refcpu as R
+    from minigpt4_cpp_amd import modelgen as G
+    vp, llm = tiny_files
+    lp = llm("q4_0", conditioned=True)
+    f = G.read_llm_file(lp)
+    assert f.hparams["n_embd"] // f.hparams["n_head"] == 64
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=2816, n_batch=512)
+    try:
+        o = R.OracleLLM(f, n_ctx=2816)
+        rng = np.random.default_rng(9)
+        toks = [1] + [int(t) for t in rng.integers(3, 512, 2700)]
+        for i in range(0, len(toks), 512):                      # the chunks that end at 2560 and 2701 keys lie beyond every prompt kernel's range
+            gpu_lib.amd_eval_tokens(ctx, toks[i:i + 512])
+            want = o.eval_tokens(toks[i:i + 512])
+            assert _rel(gpu_lib.amd_logits(ctx), want) < LOGIT_TOL, i
+        for _ in range(3):
+            tid = int(want.argmax())
+            gpu_lib.amd_eval_tokens(ctx, [tid])
+            want = o.eval_tokens([tid])
+            assert _rel(gpu_lib.amd_logits(ctx), want) < LOGIT_TOL
+        assert gpu_lib.library.minigpt4_amd_n_past(ctx.ptr) == 2704
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+
+
 def test_batched_encode_images_equals_single(gpu_lib, tiny_files):
     import ctypes
     from minigpt4_cpp_amd import minigpt4_library as ML, modelgen as G
