@@ -583,6 +583,8 @@ void Engine::alloc_buffers() {
         tabs_.exp_neg_n = (last + 1 + 2047) / 2048 * 2048;
         tabs_dec_ = tabs_;
         if (computed_tables_) { tabs_dec_.exp = nullptr; tabs_dec_.silu = nullptr; }
+        tabs_vis_ = tabs_;
+        if (computed_tables_) tabs_vis_.exp = nullptr;          // the ViT / Q-Former attention of fast mode computes its exponentials (no 40 KB table DMA per workgroup)
     }
     x_ = takef(B * E); q_ = takef(B * E); k_ = takef(B * E); v_ = takef(B * E); att_ = takef(B * E);
     h1_ = takef(B * F); h3_ = takef(B * F); logits_ = takef(S * V); blogits_ = takef(S * V);
@@ -1419,7 +1421,7 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
         const float *nw = last ? v_lnv_w_ : vblocks_[ib + 1].n1w, *nb = last ? v_lnv_b_ : vblocks_[ib + 1].n1b;
         __half *nout = last ? vi_img_h_ : vi_ln_h_;
         launch_gemm_f16(vi_ln_h_, D, b.qkv_w, D, R, 3 * D, D, b.qkv_b, nullptr, false, tabs_, vi_qkv_, nullptr, 3 * D, s);
-        launch_attn_f32(vi_qkv_, 3 * D, vi_qkv_ + D, vi_qkv_ + 2 * D, 3 * D, 257, 257, v_heads_, 88, scale, 0.0f, tabs_, nullptr, vi_att_h_, D, s, B);
+        launch_attn_f32(vi_qkv_, 3 * D, vi_qkv_ + D, vi_qkv_ + 2 * D, 3 * D, 257, 257, v_heads_, 88, scale, 0.0f, tabs_vis_, nullptr, vi_att_h_, D, s, B);
         if (sp > 1) {
             launch_gemm_f16_splitk(vi_att_h_, D, b.proj_w, D, R, D, D, sp, vi_slab_, slab, D, s);
             launch_splitk_reduce_ln(vi_slab_, sp, slab, b.proj_b, vi_x_, R, D, vi_x_, b.n2w, b.n2b, nullptr, vi_ln_h_, s);
@@ -1456,7 +1458,7 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
         const float *a1 = pre ? vi_c_a1_ : vi_a1_; const __half *a1_h = pre ? vi_c_a1_h_ : vi_a1_h_;
         if (!pre) {
             qgemm(vi_hs_h_, H, L.self.q_w, H, RQ, 3 * H, H, L.self.q_b, nullptr, false, vi_qq_, nullptr, 3 * H);
-            launch_attn_f32(vi_qq_, 3 * H, vi_qq_ + H, vi_qq_ + 2 * H, 3 * H, NQ, NQ, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s, B);
+            launch_attn_f32(vi_qq_, 3 * H, vi_qq_ + H, vi_qq_ + 2 * H, 3 * H, NQ, NQ, 12, 64, 0.0f, 8.0f, tabs_vis_, nullptr, vi_ctx_h_, H, s, B);
             qgemm(vi_ctx_h_, H, L.self.dense_w, H, RQ, H, H, L.self.dense_b, vi_hs_, false, vi_d_, nullptr, H);
             launch_layernorm(vi_d_, L.self.ln_w, L.self.ln_b, RQ, H, vi_a1_, vi_a1_h_, s);
         }
@@ -1466,7 +1468,7 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
             if (!pre) qgemm(vi_a1_h_, H, L.cross.q_w, H, RQ, H, H, L.cross.q_b, nullptr, false, vi_qq_, nullptr, H);
             const float *kv = hoist ? vi_kv_ + (size_t)L.cross_idx * 2 * H : vi_kv_;
             if (!hoist) launch_gemm_f16(vi_img_h_, D, L.cross.kv_w, D, R, 2 * H, D, L.cross.kv_b, nullptr, false, tabs_, vi_kv_, nullptr, 2 * H, s);
-            launch_attn_f32(cq, H, kv, kv + H, ldkv, NQ, 257, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s, B);
+            launch_attn_f32(cq, H, kv, kv + H, ldkv, NQ, 257, 12, 64, 0.0f, 8.0f, tabs_vis_, nullptr, vi_ctx_h_, H, s, B);
             qgemm(vi_ctx_h_, H, L.cross.dense_w, H, RQ, H, H, L.cross.dense_b, a1, false, vi_d_, nullptr, H);
             launch_layernorm(vi_d_, L.cross.ln_w, L.cross.ln_b, RQ, H, vi_a2_, vi_a2_h_, s);
             ao = vi_a2_; ao_h = vi_a2_h_;
@@ -1501,7 +1503,7 @@ void Engine::fold_qformer_constants() {
     };
     launch_layernorm(vi_qtok_rep_, v_qeln_w_, v_qeln_b_, NQ, H, vi_hs_, vi_hs_h_, s);
     qgemm(vi_hs_h_, H, L.self.q_w, H, NQ, 3 * H, H, L.self.q_b, nullptr, false, vi_qq_, nullptr, 3 * H);
-    launch_attn_f32(vi_qq_, 3 * H, vi_qq_ + H, vi_qq_ + 2 * H, 3 * H, NQ, NQ, 12, 64, 0.0f, 8.0f, tabs_, nullptr, vi_ctx_h_, H, s, 1);
+    launch_attn_f32(vi_qq_, 3 * H, vi_qq_ + H, vi_qq_ + 2 * H, 3 * H, NQ, NQ, 12, 64, 0.0f, 8.0f, tabs_vis_, nullptr, vi_ctx_h_, H, s, 1);
     qgemm(vi_ctx_h_, H, L.self.dense_w, H, NQ, H, H, L.self.dense_b, vi_hs_, false, vi_d_, nullptr, H);
     launch_layernorm(vi_d_, L.self.ln_w, L.self.ln_b, NQ, H, vi_c_a1_, vi_c_a1_h_, s);
     if (L.has_cross) qgemm(vi_c_a1_h_, H, L.cross.q_w, H, NQ, H, H, L.cross.q_b, nullptr, false, vi_c_qq_, nullptr, H);

@@ -162,7 +162,7 @@ private:
     float *cos_ = nullptr, *sin_ = nullptr;
     Tables tabs_;
     // what the DECODE step's attention and SiLU launches get: tabs_, or (MINIGPT4_COMPUTED_TABLES, default on) null exp / silu pointers = the
-    Tables tabs_dec_;
+    Tables tabs_dec_, tabs_vis_;
                                        // table values computed in the kernel instead of gathered from the 128 KB tables (qtraits.hpp exp_h / silu_h);
                                        // parity mode uses tabs_
     // activations

@@ -992,6 +992,8 @@ void launch_attn_vref(const float *q, int ldq, const float *k, const float *v, i
 }
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
+// the VALUE of ggml's fp16 exp table, computed: table[x] = fp16(expf(fp16(x))) (qtraits.hpp::exp_h: differs from the host libm's entry by one fp16 ulp in about 1 of 10^4 values)
+__device__ __forceinline__ float exp_c16(float x) { return __half2float(f2h_rn(__expf(__half2float(f2h_rn(x))))); }
 // ---------------------------------------------------------------------------------------------------------------------
 // k_attn_vit -- fp32 attention without K / V staging (round 2; replaces the LDS-staged k_attn_mfma for nk <= 64 * TPW keys).
 //   * workgroup = (head, 16 queries, image); its 4 waves split the KEYS (wave w owns key tiles w, w + 4, ...), so a ViT layer is 16 x 17 = 272 workgroups
@@ -1019,8 +1021,12 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
     float *part = reinterpret_cast<float *>(smem + 768);                    // [4][DT * 4][64]
     __half *etab = reinterpret_cast<__half *>(smem + 768 + 4 * DT * 4 * 64 * 4);
     const unsigned NT = (unsigned)tb.exp_neg_n;                             // multiple of 2048
+    // tb.exp == null (fast mode, round 5): the exponentials are computed -- fp16(__expf(fp16 argument)), the table's value up to its last fp16 bit -- and no table travels: the
+    // 40 KB LDS-DMA per workgroup was the first thing in every wave's memory queue (~1.6 us of a CU's DMA rate, two workgroups per CU on 16 of the ViT's CUs), in front of the
+    // Q / K requests.  Parity mode (k_attn_vref) and the generic path keep the table.
+    const bool computed = tb.exp == nullptr;                                // workgroup-uniform
     MG4_TLA(0);
-    for (unsigned c0 = 0; c0 < NT; c0 += 2048)
+    if (!computed) for (unsigned c0 = 0; c0 < NT; c0 += 2048)
         __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(tb.exp + 0x8000 + c0 + tid * 8), (g_lds_ptr_t)(reinterpret_cast<unsigned char *>(etab) + (c0 + wave * 512) * 2), 16, 0, 0);
     // (Round 3 tried 16 x 16 = 256 workgroups for the ViT's 257 queries -- the last tile's workgroup serving the left-over query in a second softmax + P.V pass over the
     // K / V fragments it holds: 23.9 -> 20.9 us back to back, but 18.8 -> 19.9 us inside the encoder, where the 16 extra workgroups of the 272 overlap the next launch's
@@ -1096,6 +1102,12 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
         // all of them (NaN, or a positive difference -- cannot happen for finite scores) takes the global table in a wave-uniform slow path
         unsigned code[TPW][4]; float el[TPW][4];
         bool odd = false;
+        if (computed) {
+#pragma unroll
+            for (int t = 0; t < TPW; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) { el[t][r] = exp_c16(sc[t][r] - mx); code[t][r] = 0u; }     // (-inf -> 0, 0 -> 1)
+        } else {
 #pragma unroll
         for (int t = 0; t < TPW; t++)
 #pragma unroll
@@ -1112,6 +1124,7 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
                 odd = odd || (idx >= NT && c != 0u && c != 0xFC00u);
                 el[t][r] = e;
             }
+        }
         if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {
 #pragma unroll
             for (int t = 0; t < TPW; t++)
@@ -1183,8 +1196,8 @@ void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, in
         attr_set = true;
     }
     if (hd != 88 && hd != 64) throw HipError{hipErrorInvalidValue, "attn_f32: head size must be 88 or 64", __FILE__, __LINE__};
-    if (nk > 320 || tb.exp_neg_n <= 0 || tb.exp_neg_n % 2048) throw HipError{hipErrorInvalidValue, "attn_f32: more than 320 keys, or the exp table's LDS part is not set up", __FILE__, __LINE__};
-    const size_t lds_v = 768 + (size_t)4 * ((hd + 15) / 16) * 4 * 64 * 4 + (size_t)tb.exp_neg_n * 2;
+    if (nk > 320 || (tb.exp && (tb.exp_neg_n <= 0 || tb.exp_neg_n % 2048))) throw HipError{hipErrorInvalidValue, "attn_f32: more than 320 keys, or the exp table's LDS part is not set up", __FILE__, __LINE__};
+    const size_t lds_v = 768 + (size_t)4 * ((hd + 15) / 16) * 4 * 64 * 4 + (tb.exp ? (size_t)tb.exp_neg_n * 2 : 0);
     dim3 grid((unsigned)heads, (unsigned)((nq + 15) / 16), (unsigned)batch);
     if (hd == 88) hipLaunchKernelGGL((k_attn_vit<88, 5>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
     else if (nk <= 64) hipLaunchKernelGGL((k_attn_vit<64, 1>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
