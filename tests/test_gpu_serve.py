@@ -231,3 +231,36 @@ def test_native_broadcast_failures_fail_everywhere_and_never_hang(gpu_lib, tiny_
     assert float(line[-1].split()[1]) < 60.0, line[-1]
     assert not os.path.exists(str(tmp_path / "job3.id"))
 
+
+
+def test_serve_on_two_ranks_sharing_the_gpu_equals_one_rank(gpu_lib, tmpdir_models, tmp_path):
+    """serve() as the data-parallel entry point with world = 2 on hardware: two processes (gloo, both on GPU 0 -- RCCL would refuse the shared device) shard five requests,
+    rank 1 gets its replica by the arena broadcast (receive-mode load), rank 0 gathers; the answers must equal the single-rank serve() of the same requests."""
+    import json
+    import subprocess
+    import sys
+    from minigpt4_cpp_amd import modelgen as G, serve as S
+    vp = os.path.join(tmpdir_models, "vision_serve2.bin")
+    lp = os.path.join(tmpdir_models, "llm_serve2.bin")
+    G.write_vision_file(vp, G.tiny_vision(n_embd_llm=4096), seed=31, std=0.05)
+    G.write_llm_file(lp, G.tiny_llm(wtype="q4_0", n_embd=4096, n_layer=1, n_head=32, n_vocab=512, output_type="q6_k"), seed=4, std=0.02)
+    reqs = [S.Request(G.synth_image(3 + i), p, n) for i, (p, n) in enumerate([("what is the text in the picture?", 6), ("describe it", 5), ("colour?", 7), ("how many?", 4), ("where?", 6)])]
+    one = S.serve(reqs, vp, lp, conversations=2, n_ctx=512, n_batch=64, library=gpu_lib, temp=0.0, ignore_eos=True)
+    assert len(one) == 5 and all(one)
+    port = 32500 + os.getpid() % 2000
+    out_path = str(tmp_path / "answers.json")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "serve_rank.py")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MINIGPT4_DEVICE="0")
+        procs.append(subprocess.Popen([sys.executable, worker, vp, lp, out_path], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            logs.append("TIMEOUT " + p.communicate()[0])
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-1500:] for l in logs)
+    two = json.load(open(out_path))
+    assert two == one
