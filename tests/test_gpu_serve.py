@@ -232,6 +232,44 @@ def test_native_broadcast_failures_fail_everywhere_and_never_hang(gpu_lib, tiny_
     assert not os.path.exists(str(tmp_path / "job3.id"))
 
 
+def test_native_broadcast_two_real_ranks_on_one_device_reach_the_same_verdict(tiny_files, tmp_path):
+    """Two processes as ranks 0 and 1 of the native (in-library, RCCL) load, both on GPU 0.  RCCL refuses a communicator with two ranks on one device, so this is the
+    symmetric-failure path with a REAL peer: both ranks must come back within the timeout, both with an error (or, should a runtime accept the shared device, both loaded
+    with equal arena checksums) -- never one loaded and one failed, never a hang."""
+    import subprocess
+    import sys
+    vp, llm = tiny_files
+    lp = llm("q5_k", "q5_k_m")
+    code = ("import os, sys, time; sys.path.insert(0, %r); import _pkg; _pkg.load_package()\n"
+            "from minigpt4_cpp_amd import minigpt4_library as ML\n"
+            "lib = ML.load_library(); t0 = time.time()\n"
+            "try:\n"
+            "    ctx = lib.minigpt4_model_load(%r, %r, verbosity=0, n_ctx=64, n_batch=16); print('LOADED %%.1f %%s' %% (time.time() - t0, [lib.amd_arena_checksum(ctx, 0), lib.amd_arena_checksum(ctx, 1)]))\n"
+            "except RuntimeError as e:\n"
+            "    print('ERR %%.1f %%s' %% (time.time() - t0, e))\n"
+            "sys.stdout.flush(); os._exit(0)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), vp, lp)
+    idf = str(tmp_path / "job4.id")
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(os.environ, MINIGPT4_WORLD_SIZE="2", MINIGPT4_RANK=str(r), MINIGPT4_DEVICE="0", MINIGPT4_NCCL_ID_FILE=idf,
+                                                                      MINIGPT4_DIST_TIMEOUT_S="10"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    lines = []
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, err = p.communicate()
+            raise AssertionError("a rank hung: " + out[-300:] + err[-300:])
+        got = [l for l in out.splitlines() if l.startswith(("ERR", "LOADED"))]
+        assert got, (out[-500:], err[-500:])
+        lines.append(got[-1])
+    print("native broadcast, two ranks on one device:", lines)
+    kinds = {l.split()[0] for l in lines}
+    assert len(kinds) == 1, lines                                  # the same verdict on both ranks
+    assert all(float(l.split()[1]) < 120.0 for l in lines), lines
+    if kinds == {"LOADED"}:
+        assert lines[0].split(" ", 2)[2] == lines[1].split(" ", 2)[2], lines
+    assert not os.path.exists(idf)
+
 
 def test_serve_on_two_ranks_sharing_the_gpu_equals_one_rank(gpu_lib, tmpdir_models, tmp_path):
     """serve() as the data-parallel entry point with world = 2 on hardware: two processes (gloo, both on GPU 0 -- RCCL would refuse the shared device) shard five requests,
