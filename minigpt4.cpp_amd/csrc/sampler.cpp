@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <ctime>
 #include <numeric>
 
@@ -12,10 +13,38 @@ void Sampler::seed(int s) {
     rng.seed((uint32_t)s);
 }
 
+// All candidates by descending logit (llama_sample_softmax's std::sort over the whole vocabulary: what every mirostat step and an explicit top_k = 0 pay).  A comparison sort of
+// 32000 entries costs ~1.9 ms per token on the GPU box's host -- more than half of the GPU's decode step; three stable 11-bit radix passes over (order-preserving key, position)
+// cost ~0.15 ms.  Ties keep their token order (stable): the rule the CPU oracle's restatement uses (std::sort leaves the order of equal logits to the implementation).
+static void sort_desc_by_logit(std::vector<TokenData> &v) {
+    const size_t n = v.size();
+    if (n < 1024) { std::stable_sort(v.begin(), v.end(), [](const TokenData &a, const TokenData &b) { return a.logit > b.logit; }); return; }
+    for (const TokenData &t : v) if (t.logit != t.logit) {       // a NaN has no place in a radix order: the comparison sort's behaviour, whatever it is
+        std::stable_sort(v.begin(), v.end(), [](const TokenData &a, const TokenData &b) { return a.logit > b.logit; }); return; }
+    struct KP { uint32_t key, pos; };
+    std::vector<KP> a(n), b(n);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t u; const float f = v[i].logit == 0.0f ? 0.0f : v[i].logit;    // -0 and +0 compare equal: one key
+        std::memcpy(&u, &f, 4);
+        const uint32_t asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);        // ascending in the float's value
+        a[i] = KP{~asc, (uint32_t)i};                                            // ascending key = descending logit
+    }
+    for (int pass = 0; pass < 3; pass++) {
+        const int sh = 11 * pass;
+        uint32_t cnt[2049] = {0};
+        for (size_t i = 0; i < n; i++) cnt[((a[i].key >> sh) & 2047u) + 1]++;
+        for (int k = 0; k < 2048; k++) cnt[k + 1] += cnt[k];
+        for (size_t i = 0; i < n; i++) b[cnt[(a[i].key >> sh) & 2047u]++] = a[i];
+        a.swap(b);
+    }
+    std::vector<TokenData> out(n);
+    for (size_t i = 0; i < n; i++) out[i] = v[a[i].pos];
+    v.swap(out);
+}
 void Sampler::softmax(Candidates &c) {
     if (c.data.empty()) return;
     if (!c.sorted) {
-        std::sort(c.data.begin(), c.data.end(), [](const TokenData &a, const TokenData &b) { return a.logit > b.logit; });
+        sort_desc_by_logit(c.data);
         c.sorted = true;
     }
     const float max_l = c.data[0].logit;
@@ -28,7 +57,7 @@ void Sampler::top_k(Candidates &c, int k, size_t min_keep) {
     k = std::min(k, (int)c.data.size());
     if (!c.sorted) {
         auto comp = [](const TokenData &a, const TokenData &b) { return a.logit > b.logit; };
-        if (k == (int)c.data.size()) std::sort(c.data.begin(), c.data.end(), comp);
+        if (k == (int)c.data.size()) sort_desc_by_logit(c.data);
         else std::partial_sort(c.data.begin(), c.data.begin() + k, c.data.end(), comp);
         c.sorted = true;
     }

@@ -366,6 +366,19 @@ def test_greedy_and_sampler_chain_match_oracle(lib):
             got = lib.amd_sample_logits(logits, seed=seed, **kw)
             want = R.sample(logits, R.MT19937(seed), kw["temp"], kw["top_k"], kw["top_p"], kw["tfs_z"], kw["typical_p"])
             assert got == want, (trial, kw)
+    # a full-size vocabulary through the whole-vocabulary sort (top_k = 0: every candidate is ordered; >= 1024 entries take the radix passes): negative values, +-0,
+    # denormals and exact TIES -- equal logits keep their token order, the oracle's (stable) rule
+    big = (2.5 * rng.standard_normal(32000)).astype(np.float32)
+    big[5] = 0.0; big[6] = -0.0; big[7] = np.float32(1e-41); big[8] = np.float32(-1e-41)
+    top = np.argsort(-big)[:6]
+    big[top[1]] = big[top[0]]; big[top[3]] = big[top[2]]            # ties among the most probable tokens
+    big[31999] = big[top[4]]
+    for seed, kw in ((11, dict(temp=1.3, top_k=0, top_p=0.5, tfs_z=1.0, typical_p=1.0)), (12, dict(temp=0.9, top_k=0, top_p=0.97, tfs_z=1.0, typical_p=1.0)),
+                     (13, dict(temp=1.0, top_k=0, top_p=1.0, tfs_z=0.95, typical_p=1.0)), (14, dict(temp=2.0, top_k=32000, top_p=0.999, tfs_z=1.0, typical_p=1.0))):
+        for s2 in range(4):
+            got = lib.amd_sample_logits(big, seed=seed * 10 + s2, **kw)
+            want = R.sample(big, R.MT19937(seed * 10 + s2), kw["temp"], kw["top_k"], kw["top_p"], kw["tfs_z"], kw["typical_p"])
+            assert got == want, (seed, s2, kw)
     # mirostat paths run and return a valid id
     lg = (2.5 * rng.standard_normal(512)).astype(np.float32)
     for m in (1, 2):
