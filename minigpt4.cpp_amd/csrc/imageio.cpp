@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <thread>
 
 #include "common.hpp"
 
@@ -255,6 +256,9 @@ struct JHuff {
     uint8_t bits[17] = {0}, vals[256] = {0};
     int mincode[18], maxcode[18], valptr[18];
     uint16_t fast[512];   // 9-bit lookahead: (len << 8) | symbol, 0 = miss
+    // AC tables: when the code AND the magnitude bits that follow it fit the 9-bit window, one lookup yields the finished coefficient:
+    // (value << 8) | (run << 4) | (code length + magnitude bits); 0 = take the two-step path.  Most coefficients of a photograph are small: this is the common case
+    int16_t fast_ac[512];
     bool build() {
         int code = 0, k = 0;
         memset(fast, 0, sizeof(fast));
@@ -269,6 +273,16 @@ struct JHuff {
             code <<= 1;
         }
         maxcode[17] = 0x7FFFFFFF;
+        for (int i = 0; i < 512; i++) {
+            fast_ac[i] = 0;
+            const unsigned e = fast[i];
+            if (!e) continue;
+            const int len = (int)(e >> 8), rs = (int)(e & 255), run = rs >> 4, mag = rs & 15;
+            if (!mag || len + mag > 9) continue;
+            int v = ((i << len) & 511) >> (9 - mag);                 // the magnitude bits behind the code
+            if (v < (1 << (mag - 1))) v = v - (1 << mag) + 1;         // receive_extend
+            if (v >= -128 && v <= 127) fast_ac[i] = (int16_t)(v * 256 + run * 16 + len + mag);
+        }
         return true;
     }
 };
@@ -329,6 +343,17 @@ struct JComp {
 
 inline uint8_t idct_limit(int64_t v) { int x = (int)(((v + 512) & 1023) - 512) + 128; return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }   // libjpeg's range_limit[(v) & RANGE_MASK]
 
+// The stages after the entropy decoder -- inverse DCT, chroma upsampling, colour conversion -- are independent per block row / pixel row: a 12-megapixel photograph spends
+// a quarter of its decode time there (the rest is the sequential Huffman stage), so they run on up to 8 host threads (same arithmetic per element: the pixels do not depend on the thread count; small images stay serial).
+template <typename F> void parallel_rows(int n, size_t work_per_row, F &&fn) {
+    unsigned nt = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if ((size_t)n * work_per_row < ((size_t)1 << 20) || n < 2 * (int)nt) nt = 1;
+    if (nt <= 1) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    const int per = (n + (int)nt - 1) / (int)nt;
+    for (unsigned t = 0; t < nt; t++) { const int a = (int)t * per, b = std::min(n, a + per); if (a < b) th.emplace_back([&fn, a, b] { fn(a, b); }); }
+    for (auto &x : th) x.join();
+}
 // jidctint.c jpeg_idct_islow (CONST_BITS 13, PASS1_BITS 2)
 void idct_islow(const int16_t *in, const uint16_t *q, uint8_t *out, size_t stride) {
     constexpr int64_t F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633, F_1_501 = 12299, F_1_847 = 15137, F_1_961 = 16069, F_2_053 = 16819,
@@ -523,6 +548,9 @@ bool decode_jpeg(const uint8_t *data, size_t n, ImageRGB8 &out, std::string &err
                     c.pred += br.receive_extend(t & 15);
                     blk[0] = (int16_t)c.pred;
                     for (int k = 1; k < 64; k++) {
+                        if (br.cnt < 16) br.fill();
+                        const int fa = ac.fast_ac[(unsigned)(br.buf >> 55)];
+                        if (fa) { k += (fa >> 4) & 15; br.drop(fa & 15); blk[ZZ[k]] = (int16_t)(fa >> 8); continue; }     // code + magnitude in one lookup
                         const int rs = br.decode(ac), r = rs >> 4, sz = rs & 15;
                         if (sz) { k += r; blk[ZZ[k]] = (int16_t)br.receive_extend(sz); }
                         else { if (r != 15) break; k += 15; }
@@ -588,8 +616,10 @@ bool decode_jpeg(const uint8_t *data, size_t n, ImageRGB8 &out, std::string &err
         if (!qt_ok[c.tq]) return fail("jpeg: missing quantisation table");
         const size_t stride = (size_t)c.wbp * 8;
         c.plane.assign(stride * (size_t)c.hbp * 8, 0);
-        for (int by = 0; by < c.hbp; by++) for (int bx = 0; bx < c.wbp; bx++)
-            idct_islow(&c.coef[((size_t)by * c.wbp + (size_t)bx) * 64], qt[c.tq], &c.plane[(size_t)by * 8 * stride + (size_t)bx * 8], stride);
+        parallel_rows(c.hbp, (size_t)c.wbp * 64, [&](int by0, int by1) {
+            for (int by = by0; by < by1; by++) for (int bx = 0; bx < c.wbp; bx++)
+                idct_islow(&c.coef[((size_t)by * c.wbp + (size_t)bx) * 64], qt[c.tq], &c.plane[(size_t)by * 8 * stride + (size_t)bx * 8], stride);
+        });
         c.coef.clear(); c.coef.shrink_to_fit();
     }
     // upsample every component to W x H (jdsample.c, do_fancy_upsampling = TRUE)
@@ -602,14 +632,14 @@ bool decode_jpeg(const uint8_t *data, size_t n, ImageRGB8 &out, std::string &err
         const int ow = c.dw * hx, oh = c.dh * vx;   // >= W, H
         f.assign((size_t)ow * oh, 0);
         auto rowp = [&](int r) { return &c.plane[(size_t)std::min(std::max(r, 0), c.dh - 1) * st]; };   // context rows replicate the first / last real row
-        if (hx == 1 && vx == 1) { for (int y = 0; y < oh; y++) memcpy(&f[(size_t)y * ow], rowp(y), (size_t)ow); }
+        if (hx == 1 && vx == 1) { parallel_rows(oh, (size_t)ow, [&](int y0, int y1) { for (int y = y0; y < y1; y++) memcpy(&f[(size_t)y * ow], rowp(y), (size_t)ow); }); }
         else if (hx == 2 && vx == 1 && c.dw > 2) {   // h2v1_fancy_upsample (jinit_upsampler: fancy only when downsampled_width > 2)
-            for (int y = 0; y < oh; y++) { const uint8_t *in = rowp(y); uint8_t *o = &f[(size_t)y * ow]; const int nin = c.dw;
+            parallel_rows(oh, (size_t)ow, [&](int y0, int y1) { for (int y = y0; y < y1; y++) { const uint8_t *in = rowp(y); uint8_t *o = &f[(size_t)y * ow]; const int nin = c.dw;
                 int iv = in[0]; o[0] = (uint8_t)iv; o[1] = (uint8_t)((iv * 3 + in[1] + 2) >> 2);
                 for (int x = 1; x < nin - 1; x++) { iv = in[x] * 3; o[2 * x] = (uint8_t)((iv + in[x - 1] + 1) >> 2); o[2 * x + 1] = (uint8_t)((iv + in[x + 1] + 2) >> 2); }
-                iv = in[nin - 1]; o[2 * nin - 2] = (uint8_t)((iv * 3 + in[nin - 2] + 1) >> 2); o[2 * nin - 1] = (uint8_t)iv; }
+                iv = in[nin - 1]; o[2 * nin - 2] = (uint8_t)((iv * 3 + in[nin - 2] + 1) >> 2); o[2 * nin - 1] = (uint8_t)iv; } });
         } else if (hx == 2 && vx == 2 && c.dw > 2) {   // h2v2_fancy_upsample (same width condition)
-            for (int y = 0; y < c.dh; y++) for (int v = 0; v < 2; v++) {
+            parallel_rows(c.dh, (size_t)ow * 2, [&](int y0, int y1) { for (int y = y0; y < y1; y++) for (int v = 0; v < 2; v++) {
                 const uint8_t *in0 = rowp(y), *in1 = rowp(v == 0 ? y - 1 : y + 1); uint8_t *o = &f[(size_t)(2 * y + v) * ow]; const int nin = c.dw;
                 int thiscol = in0[0] * 3 + in1[0], nextcol = in0[1] * 3 + in1[1], lastcol;
                 o[0] = (uint8_t)((thiscol * 4 + 8) >> 4); o[1] = (uint8_t)((thiscol * 3 + nextcol + 7) >> 4);
@@ -620,7 +650,7 @@ bool decode_jpeg(const uint8_t *data, size_t n, ImageRGB8 &out, std::string &err
                     lastcol = thiscol; thiscol = nextcol;
                 }
                 o[2 * nin - 2] = (uint8_t)((thiscol * 3 + lastcol + 8) >> 4); o[2 * nin - 1] = (uint8_t)((thiscol * 4 + 7) >> 4);
-            }
+            } });
         } else if (hx == 1 && vx == 2) {   // h1v2_fancy_upsample (libjpeg-turbo)
             for (int y = 0; y < c.dh; y++) for (int v = 0; v < 2; v++) {
                 const uint8_t *in0 = rowp(y), *in1 = rowp(v == 0 ? y - 1 : y + 1); uint8_t *o = &f[(size_t)(2 * y + v) * ow]; const int bias = v == 0 ? 1 : 2;
@@ -649,11 +679,14 @@ bool decode_jpeg(const uint8_t *data, size_t n, ImageRGB8 &out, std::string &err
                 cr_r[i] = (int)((FIX(1.40200) * x + 32768) >> 16); cb_b[i] = (int)((FIX(1.77200) * x + 32768) >> 16);
                 cr_g[i] = (-FIX(0.71414)) * x; cb_g[i] = (-FIX(0.34414)) * x + 32768; }
             auto cl = [](int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
-            for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
-                const int Y = at(0, x, y), cb = at(1, x, y), cr = at(2, x, y);
-                uint8_t *q = &out.px[((size_t)y * W + x) * 3];
-                q[0] = cl(Y + cr_r[cr]); q[1] = cl(Y + (int)((cb_g[cb] + cr_g[cr]) >> 16)); q[2] = cl(Y + cb_b[cb]);
-            }
+            parallel_rows(H, (size_t)W * 3, [&](int y0, int y1) { for (int y = y0; y < y1; y++) {
+                const uint8_t *py = &full[0][(size_t)y * (size_t)(comps[0].dw * (hmax / comps[0].h))], *pb = &full[1][(size_t)y * (size_t)(comps[1].dw * (hmax / comps[1].h))],
+                              *pr = &full[2][(size_t)y * (size_t)(comps[2].dw * (hmax / comps[2].h))];
+                uint8_t *q = &out.px[(size_t)y * W * 3];
+                for (int x = 0; x < W; x++, q += 3) {
+                    const int Y = py[x], cb = pb[x], cr = pr[x];
+                    q[0] = cl(Y + cr_r[cr]); q[1] = cl(Y + (int)((cb_g[cb] + cr_g[cr]) >> 16)); q[2] = cl(Y + cb_b[cb]);
+                } } });
         }
     }
     apply_orientation(out, orientation);
