@@ -54,8 +54,7 @@ int minigpt4_image_load_from_file(struct MiniGPT4Context *, const char *path, st
     return guarded((int)E_OpenImage, [&]() -> int {
         ImageRGB8 im;
         if (int err = load_image_file(path, im)) { MG4_ERR("%s", last_error().c_str()); return err; }
-        uint8_t *data = new uint8_t[im.px.size()];
-        memcpy(data, im.px.data(), im.px.size());
+        uint8_t *data = im.px.release();                   // the decoder's own buffer (malloc family): no copy
         image->data = data; image->width = im.w; image->height = im.h; image->channels = 3; image->format = MINIGPT4_IMAGE_FORMAT_U8;
         return E_None;
     });
@@ -72,9 +71,10 @@ int minigpt4_preprocess_image(struct MiniGPT4Context *ctx, const struct MiniGPT4
     if (device_count_noexcept() <= 0) { set_last_error("no HIP device visible: image preprocessing runs on the GPU and has no CPU fallback"); MG4_ERR("%s", last_error().c_str()); return E_ImageSize; }
     return guarded((int)E_ImageSize, [&]() -> int {
         const size_t n = (size_t)3 * 224 * 224;
-        float *out = reinterpret_cast<float *>(new uint8_t[n * sizeof(float)]);   // released by minigpt4_free_image (delete[] of a byte array)
+        float *out = static_cast<float *>(malloc(n * sizeof(float)));             // released by minigpt4_free_image (free)
+        if (!out) return (int)E_ImageSize;
         try { preprocess_image_device(ctx ? E_(ctx)->stream() : nullptr, static_cast<const uint8_t *>(image->data), image->width, image->height, out); }
-        catch (...) { delete[] reinterpret_cast<uint8_t *>(out); throw; }
+        catch (...) { free(out); throw; }
         preprocessed_image->data = out; preprocessed_image->width = 1; preprocessed_image->height = (int)n; preprocessed_image->channels = 1;
         preprocessed_image->format = MINIGPT4_IMAGE_FORMAT_F32;
         return E_None;
@@ -148,7 +148,7 @@ int minigpt4_reset_chat(struct MiniGPT4Context *ctx) { if (ctx) E_(ctx)->reset()
 int minigpt4_contains_eos_token(const char *s) { return s && strcmp(s, "##") == 0 ? E_EosToken : E_None; }
 int minigpt4_is_eos(const char *s) { if (!s) return E_None; const size_t n = strlen(s); return n >= 3 && memcmp(s + n - 3, "###", 3) == 0 ? E_Eos : E_None; }
 int minigpt4_free(struct MiniGPT4Context *ctx) { delete E_(ctx); return E_None; }
-int minigpt4_free_image(struct MiniGPT4Image *image) { if (image && image->data) { delete[] static_cast<uint8_t *>(image->data); image->data = nullptr; } return E_None; }
+int minigpt4_free_image(struct MiniGPT4Image *image) { if (image && image->data) { free(image->data); image->data = nullptr; } return E_None; }   // every image the library hands out is malloc-family memory
 int minigpt4_free_embedding(struct MiniGPT4Embedding *embedding) { if (embedding && embedding->data) { delete[] embedding->data; embedding->data = nullptr; } return E_None; }
 const char *minigpt4_error_code_to_string(int error_code) { return error_code >= 0 && error_code < 20 ? kErrNames[error_code] : ""; }
 int minigpt4_quantize_model(const char *in_path, const char *out_path, int data_type) {
@@ -314,9 +314,8 @@ int minigpt4_amd_decode_image(const void *bytes, size_t n, struct MiniGPT4Image 
     return guarded((int)E_OpenImage, [&]() -> int {
         ImageRGB8 im; std::string err;
         if (!decode_image(static_cast<const uint8_t *>(bytes), n, im, err)) { set_last_error(err); return E_OpenImage; }
-        uint8_t *data = new (std::nothrow) uint8_t[im.px.size()];
+        uint8_t *data = im.px.release();
         if (!data) return E_OpenImage;
-        memcpy(data, im.px.data(), im.px.size());
         image->data = data; image->width = im.w; image->height = im.h; image->channels = 3; image->format = MINIGPT4_IMAGE_FORMAT_U8;
         return E_None;
     });

@@ -1,6 +1,7 @@
 // Image file decoding on the host + Pillow's bicubic coefficient tables.  See imageio.hpp.
 #include "imageio.hpp"
 
+#include <sys/mman.h>
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -14,6 +15,18 @@
 #include "common.hpp"
 
 namespace mg4 {
+
+void *bigbuf_alloc(size_t bytes) {
+    constexpr size_t HP = (size_t)2 << 20;
+    void *p = nullptr;
+    if (bytes >= 2 * HP) {
+        const size_t r = (bytes + HP - 1) & ~(HP - 1);
+        p = aligned_alloc(HP, r);
+        if (p) (void)madvise(p, r, MADV_HUGEPAGE);               // advisory: without THP the pages are ordinary ones
+    } else p = malloc(bytes);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
 namespace {
 constexpr uint64_t MAX_PIXELS = 1ull << 27;   // 134 Mpixel: larger headers are treated as corrupt
 
@@ -337,8 +350,8 @@ struct JComp {
     int wbp = 0, hbp = 0;        // blocks allocated (padded to whole MCUs)
     int dw = 0, dh = 0;          // downsampled_width / downsampled_height in samples
     int pred = 0;
-    std::vector<int16_t> coef;   // [hbp][wbp][64], natural order
-    std::vector<uint8_t> plane;  // [hbp * 8][wbp * 8]
+    BigBuf<int16_t> coef;        // [hbp][wbp][64], natural order
+    PixelBuf plane;              // [hbp * 8][wbp * 8]
 };
 
 inline uint8_t idct_limit(int64_t v) { int x = (int)(((v + 512) & 1023) - 512) + 128; return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }   // libjpeg's range_limit[(v) & RANGE_MASK]
@@ -424,7 +437,7 @@ void apply_orientation(ImageRGB8 &im, int o) {   // OpenCV ExifTransform (module
     const int w = im.w, h = im.h;
     const bool swap = o >= 5;
     const int ow = swap ? h : w, oh = swap ? w : h;
-    std::vector<uint8_t> dst((size_t)ow * oh * 3);
+    PixelBuf dst; dst.resize((size_t)ow * oh * 3);
     for (int y = 0; y < oh; y++) for (int x = 0; x < ow; x++) {
         int sx, sy;
         switch (o) {
@@ -615,22 +628,22 @@ bool decode_jpeg(const uint8_t *data, size_t n, ImageRGB8 &out, std::string &err
     for (JComp &c : comps) {
         if (!qt_ok[c.tq]) return fail("jpeg: missing quantisation table");
         const size_t stride = (size_t)c.wbp * 8;
-        c.plane.assign(stride * (size_t)c.hbp * 8, 0);
+        c.plane.resize(stride * (size_t)c.hbp * 8);                        // every sample is written by its block's inverse DCT
         parallel_rows(c.hbp, (size_t)c.wbp * 64, [&](int by0, int by1) {
             for (int by = by0; by < by1; by++) for (int bx = 0; bx < c.wbp; bx++)
                 idct_islow(&c.coef[((size_t)by * c.wbp + (size_t)bx) * 64], qt[c.tq], &c.plane[(size_t)by * 8 * stride + (size_t)bx * 8], stride);
         });
-        c.coef.clear(); c.coef.shrink_to_fit();
+        c.coef.clear();
     }
     // upsample every component to W x H (jdsample.c, do_fancy_upsampling = TRUE)
-    std::vector<std::vector<uint8_t>> full(comps.size());
+    std::vector<PixelBuf> full(comps.size());
     for (size_t ci = 0; ci < comps.size(); ci++) {
         const JComp &c = comps[ci];
         const int hx = hmax / c.h, vx = vmax / c.v;
         const size_t st = (size_t)c.wbp * 8;
-        std::vector<uint8_t> &f = full[ci];
+        PixelBuf &f = full[ci];
         const int ow = c.dw * hx, oh = c.dh * vx;   // >= W, H
-        f.assign((size_t)ow * oh, 0);
+        f.resize((size_t)ow * oh);                                         // every row is written by the branch below
         auto rowp = [&](int r) { return &c.plane[(size_t)std::min(std::max(r, 0), c.dh - 1) * st]; };   // context rows replicate the first / last real row
         if (hx == 1 && vx == 1) { parallel_rows(oh, (size_t)ow, [&](int y0, int y1) { for (int y = y0; y < y1; y++) memcpy(&f[(size_t)y * ow], rowp(y), (size_t)ow); }); }
         else if (hx == 2 && vx == 1 && c.dw > 2) {   // h2v1_fancy_upsample (jinit_upsampler: fancy only when downsampled_width > 2)
@@ -660,7 +673,7 @@ bool decode_jpeg(const uint8_t *data, size_t n, ImageRGB8 &out, std::string &err
             for (int y = 0; y < oh; y++) { const uint8_t *in = rowp(y / vx); uint8_t *o = &f[(size_t)y * ow]; for (int x = 0; x < ow; x++) o[x] = in[x / hx]; }
         }
     }
-    out.w = W; out.h = H; out.px.assign((size_t)W * H * 3, 0);
+    out.w = W; out.h = H; out.px.resize((size_t)W * H * 3);              // every byte is written below
     auto at = [&](size_t ci, int x, int y) { const JComp &c = comps[ci]; return full[ci][(size_t)y * (size_t)(c.dw * (hmax / c.h)) + (size_t)x]; };
     if (comps.size() == 1) {
         for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const uint8_t v = at(0, x, y); uint8_t *q = &out.px[((size_t)y * W + x) * 3]; q[0] = q[1] = q[2] = v; }
