@@ -15,6 +15,25 @@ t0 = time.perf_counter()
 ctx = lib.minigpt4_model_load(vp, lp, verbosity=0, seed=1337, n_ctx=2048, n_batch=512)
 print(f"model_load {1e3 * (time.perf_counter() - t0):8.1f} ms")
 img = ML.array_to_image_struct(G.synth_image(42))
+# the native image path in front of it (reference: OpenCV imread + PillowResize): a 12-megapixel photograph-like JPEG from disk
+try:
+    import io, numpy as np
+    from PIL import Image
+    h, w = 3000, 4000
+    yy, xx = np.mgrid[0:h, 0:w]
+    ph = np.stack([xx * 255 // w, yy * 255 // h, (xx + yy) * 255 // (w + h)], -1).astype(np.float32) + np.random.default_rng(0).normal(0, 8, (h, w, 3))
+    path = "/dev/shm/mg4_bench/photo_12mp.jpg"
+    Image.fromarray(np.clip(ph, 0, 255).astype(np.uint8)).save(path, "JPEG", quality=90)
+    for rep in range(3):
+        t = time.perf_counter(); raw = lib.minigpt4_image_load_from_file(ctx, path); t_load = 1e3 * (time.perf_counter() - t)
+        t = time.perf_counter(); pre = lib.minigpt4_preprocess_image(ctx, raw); t_pre = 1e3 * (time.perf_counter() - t)
+        print(f"12 MP JPEG ({os.path.getsize(path) / 1e6:.1f} MB): minigpt4_image_load_from_file {t_load:.1f} ms, minigpt4_preprocess_image {t_pre:.1f} ms")
+        lib.minigpt4_free_image(raw)
+        if rep < 2:
+            lib.minigpt4_free_image(pre)
+    img = pre
+except ImportError:
+    pass
 for turn in range(3):
     T = {}
     def timed(name, f, *a, **k):
