@@ -343,7 +343,7 @@ def main():
             lib.minigpt4_free_embedding(emb)
     image_encode_ms, image_encode_dev_ms = min(enc_wall[1:]), min(enc_dev[1:])
 
-    # ---- extra: 4 images in one pass over the vision weights (minigpt4_encode_images; BASELINE.json configs[3] has 4 requests per replica)
+    # ---- extra: 4 images in one pass over the vision weights (minigpt4_amd_encode_images; BASELINE.json configs[3] has 4 requests per replica)
     enc_batch = None
     try:
         nb = 4
@@ -352,9 +352,9 @@ def main():
         batch, outb = ML.MiniGPT4Images(arr, nb), ML.MiniGPT4Embeddings()
         best = 1e9
         for _ in range(3):
-            assert lib.library.minigpt4_encode_images(ctx.ptr, ctypes.byref(batch), ctypes.byref(outb), 0) == 0
+            assert lib.library.minigpt4_amd_encode_images(ctx.ptr, ctypes.byref(batch), ctypes.byref(outb), 0) == 0
             best = min(best, lib.library.minigpt4_amd_last_encode_ms(ctx.ptr))
-            lib.library.minigpt4_free_embeddings(ctypes.byref(outb))
+            lib.library.minigpt4_amd_free_embeddings(ctypes.byref(outb))
         enc_batch = {"images": nb, "device_ms": best, "device_ms_per_image": best / nb}
     except Exception as e:
         enc_batch = {"error": str(e)}

@@ -14,13 +14,14 @@ if not os.path.exists(lp):
 lib = ML.load_library()
 ctx = lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=64, n_batch=32)
 img = ML.array_to_image_struct(G.synth_image(1))
-ms = []
-for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
+import zlib
+ms, sig = [], 0
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):          # 0: no single-image encodes (a per-batch-size rocprofv3 pass wants ONE kind of launch)
     e = lib.minigpt4_encode_image(ctx, img); ms.append(lib.library.minigpt4_amd_last_encode_ms(ctx.ptr))
-    import zlib
     sig = zlib.crc32(ctypes.string_at(e.data, e.n_embeddings * 4))        # identical embeddings <=> identical signature (bit-exactness of A/B arms)
     lib.minigpt4_free_embedding(e)
-print("encode ms (device):", ["%.2f" % m for m in ms], "best %.2f" % min(ms), "sig %08x" % sig)
+if ms:
+    print("encode ms (device):", ["%.2f" % m for m in ms], "best %.2f" % min(ms), "sig %08x" % sig)
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 0                          # optional: B images per encode_images call (one pass over the vision weights)
 if nb > 1:
     imgs = [ML.array_to_image_struct(G.synth_image(1 + i)) for i in range(nb)]
@@ -28,9 +29,9 @@ if nb > 1:
     batch, outb = ML.MiniGPT4Images(arr, nb), ML.MiniGPT4Embeddings()
     msb = []
     for _ in range(5):
-        assert lib.library.minigpt4_encode_images(ctx.ptr, ctypes.byref(batch), ctypes.byref(outb), 0) == 0
+        assert lib.library.minigpt4_amd_encode_images(ctx.ptr, ctypes.byref(batch), ctypes.byref(outb), 0) == 0
         msb.append(lib.library.minigpt4_amd_last_encode_ms(ctx.ptr))
-        first = ctypes.cast(outb.embeddings, ctypes.POINTER(ML.MiniGPT4Embedding))[0] if hasattr(outb, "embeddings") else None
-        lib.library.minigpt4_free_embeddings(ctypes.byref(outb))
-    print("batched encode, %d images, ms (device):" % nb, ["%.2f" % m for m in msb], "best %.2f = %.2f per image" % (min(msb), min(msb) / nb))
+        sigb = zlib.crc32(b"".join(ctypes.string_at(outb.embeddings[i].data, outb.embeddings[i].n_embeddings * 4) for i in range(nb)))
+        lib.library.minigpt4_amd_free_embeddings(ctypes.byref(outb))
+    print("batched encode, %d images, ms (device):" % nb, ["%.2f" % m for m in msb], "best %.2f = %.2f per image" % (min(msb), min(msb) / nb), "sig %08x" % sigb)
 lib.minigpt4_free(ctx)

@@ -50,6 +50,10 @@ MINIGPT4_API int minigpt4_amd_sync(struct MiniGPT4Context *ctx);
 
 /* ---- batched image encode (data-parallel requests; carriers from reference minigpt4.h:80-90) --------------------- */
 /* Encodes images->n_images images; allocates embeddings->embeddings[i].data like minigpt4_encode_image does. */
+MINIGPT4_API int minigpt4_amd_encode_images(struct MiniGPT4Context *ctx, IN const struct MiniGPT4Images *images, OUT struct MiniGPT4Embeddings *embeddings, size_t n_threads);
+MINIGPT4_API int minigpt4_amd_free_embeddings(struct MiniGPT4Embeddings *embeddings);
+/* DEPRECATED aliases of the two functions above (their names until round 5): they live in the reference's own minigpt4_ namespace and would collide with an upstream
+ * implementation of its declared-but-unused MiniGPT4Images API (reference minigpt4.h:80-90).  Forwarders for one more release; new callers use the minigpt4_amd_ names. */
 MINIGPT4_API int minigpt4_encode_images(struct MiniGPT4Context *ctx, IN const struct MiniGPT4Images *images, OUT struct MiniGPT4Embeddings *embeddings, size_t n_threads);
 MINIGPT4_API int minigpt4_free_embeddings(struct MiniGPT4Embeddings *embeddings);
 
@@ -65,6 +69,13 @@ MINIGPT4_API int minigpt4_amd_n_conversations(struct MiniGPT4Context *ctx);
  * sampled but not advanced.  0, or 1 on bad arguments / device error. */
 MINIGPT4_API int minigpt4_amd_end_chat_batch(struct MiniGPT4Context *ctx, const int32_t *slots, int n, const char **tokens, float temp, int32_t top_k, float top_p, float tfs_z,
                                              float typical_p, int mirostat, float mirostat_tau, float mirostat_eta);
+/* The same step with GIVEN next tokens (teacher forcing): conversation slots[i] is advanced by tokens[i] instead of the token its own logits choose; greedy_out[i] (may be
+ * NULL) receives that own greedy choice.  Lets a test / bench leg compare every step's logits of B batched conversations with B independent oracle conversations fed the
+ * same ids (reference behaviour: one independent conversation per context, minigpt4.cpp:2513-2521, 2704-2718).  0 / 1. */
+MINIGPT4_API int minigpt4_amd_eval_batch(struct MiniGPT4Context *ctx, const int32_t *slots, int n, const int32_t *tokens, int32_t *greedy_out);
+/* Launch kinds of the batched step as last built (eager or at graph capture): out = {rows, k_matvec_ri launches, k_matvec_ri_mix launches, k_matvec_ri launches that split K
+ * over workgroups (w2), v_dot4 multi-row launches, v_dot4 mixed-type launches, per-matrix k_mul_mat launches, layers on the int8-MFMA set launches (B >= 5)}.  0 / 1. */
+MINIGPT4_API int minigpt4_amd_batch_path(struct MiniGPT4Context *ctx, int32_t out[8]);
 
 /* ---- weight arenas (load-time broadcast rank0 -> others over RCCL) ---------------------------- */
 /* which: 0 = LLM arena, 1 = vision arena.  Returns the device pointer and size in bytes. */

@@ -200,7 +200,7 @@ double minigpt4_amd_weight_bytes_per_token(struct MiniGPT4Context *ctx) { return
 float minigpt4_amd_last_encode_ms(struct MiniGPT4Context *ctx) { return ctx ? E_(ctx)->last_encode_ms() : 0.0f; }
 int minigpt4_amd_sync(struct MiniGPT4Context *ctx) { if (!ctx) return 1; return guarded(1, [&] { E_(ctx)->sync(); return 0; }); }
 
-int minigpt4_encode_images(struct MiniGPT4Context *ctx, const struct MiniGPT4Images *images, struct MiniGPT4Embeddings *embeddings, size_t /*n_threads*/) {
+int minigpt4_amd_encode_images(struct MiniGPT4Context *ctx, const struct MiniGPT4Images *images, struct MiniGPT4Embeddings *embeddings, size_t /*n_threads*/) {
     if (!ctx || !images || !embeddings) return E_ImageSize;
     embeddings->embeddings = new (std::nothrow) MiniGPT4Embedding[images->n_images ? images->n_images : 1]();
     embeddings->n_embeddings = 0;
@@ -208,7 +208,7 @@ int minigpt4_encode_images(struct MiniGPT4Context *ctx, const struct MiniGPT4Ima
     for (size_t i = 0; i < images->n_images; i++) {   // the checks of minigpt4_encode_image (minigpt4.cpp:2130-2138), before any work
         const MiniGPT4Image &im = images->images[i];
         const int err = !im.data ? (int)E_ImageSize : (long long)im.width * im.height * im.channels != 224LL * 224 * 3 ? (int)E_ImageNot224_244_3 : im.format != MINIGPT4_IMAGE_FORMAT_F32 ? (int)E_ImageNotF32 : 0;
-        if (err) { minigpt4_free_embeddings(embeddings); return err; }
+        if (err) { minigpt4_amd_free_embeddings(embeddings); return err; }
     }
     Engine *e = E_(ctx);
     const size_t n = (size_t)e->n_query() * e->proj_out();
@@ -226,15 +226,19 @@ int minigpt4_encode_images(struct MiniGPT4Context *ctx, const struct MiniGPT4Ima
         }
         return E_None;
     });
-    if (err) { minigpt4_free_embeddings(embeddings); return err; }
+    if (err) { minigpt4_amd_free_embeddings(embeddings); return err; }
     return E_None;
 }
-int minigpt4_free_embeddings(struct MiniGPT4Embeddings *embeddings) {
+int minigpt4_amd_free_embeddings(struct MiniGPT4Embeddings *embeddings) {
     if (!embeddings || !embeddings->embeddings) return E_None;
     for (size_t i = 0; i < embeddings->n_embeddings; i++) minigpt4_free_embedding(&embeddings->embeddings[i]);
     delete[] embeddings->embeddings; embeddings->embeddings = nullptr; embeddings->n_embeddings = 0;
     return E_None;
 }
+// the round-2..5 names of the two entry points above, kept for one more round as forwarding definitions (include/minigpt4_amd.h: deprecated -- they sit in the reference's
+// own minigpt4_ namespace and would collide if upstream ever implements its declared-but-unused MiniGPT4Images API, minigpt4.h:80-90)
+int minigpt4_encode_images(struct MiniGPT4Context *ctx, const struct MiniGPT4Images *images, struct MiniGPT4Embeddings *embeddings, size_t n_threads) { return minigpt4_amd_encode_images(ctx, images, embeddings, n_threads); }
+int minigpt4_free_embeddings(struct MiniGPT4Embeddings *embeddings) { return minigpt4_amd_free_embeddings(embeddings); }
 // ---- several conversations per context ---------------------------------------------------------------------------
 int minigpt4_amd_set_conversations(struct MiniGPT4Context *ctx, int n) {
     if (!ctx) return 1;
@@ -253,6 +257,23 @@ int minigpt4_amd_end_chat_batch(struct MiniGPT4Context *ctx, const int32_t *slot
         for (int i = 0; i < n; i++) tokens[i] = e->id_to_token(ids[i]);
         return 0;
     });
+}
+int minigpt4_amd_eval_batch(struct MiniGPT4Context *ctx, const int32_t *slots, int n, const int32_t *tokens, int32_t *greedy_out) {
+    if (!ctx || !slots || !tokens || n < 1 || n > Engine::MAX_CONVERSATIONS) return 1;
+    Engine *e = E_(ctx);
+    return guarded(1, [&]() -> int {
+        SampleParams p; p.temp = 0.0f;
+        int ids[Engine::MAX_CONVERSATIONS];
+        if (int rc = e->decode_batch(slots, n, p, ids, tokens)) return rc;
+        if (greedy_out) for (int i = 0; i < n; i++) greedy_out[i] = ids[i];
+        return 0;
+    });
+}
+int minigpt4_amd_batch_path(struct MiniGPT4Context *ctx, int32_t out[8]) {
+    if (!ctx || !out) return 1;
+    const Engine::BatchPath &b = E_(ctx)->batch_path();
+    out[0] = b.rows; out[1] = b.ri; out[2] = b.ri_mix; out[3] = b.ri_ksplit; out[4] = b.dot4; out[5] = b.dot4_mix; out[6] = b.mul_mat; out[7] = b.sets;
+    return 0;
 }
 int minigpt4_amd_weight_arena(struct MiniGPT4Context *ctx, int which, void **device_ptr, size_t *bytes) {
     if (!ctx || !device_ptr || !bytes) return 1;

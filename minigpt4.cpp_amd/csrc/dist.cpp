@@ -93,7 +93,10 @@ Rccl::~Rccl() { close(); }
 std::string Rccl::why(int rc) const { return errstr_ ? std::string(reinterpret_cast<fn_errstr>(errstr_)(rc)) : "ncclResult " + std::to_string(rc); }
 int Rccl::open(std::string &err) {
     if (lib_) return 0;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib_ = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib_) break; }
+    // A process that already maps an RCCL (a Python rank: torch ships its own torch/lib/librccl.so) must not get a SECOND copy with its own bootstrap state next to it: take
+    // the mapped one when there is one (RTLD_NOLOAD finds it by soname), load the system library only otherwise (the C-client path this code exists for).
+    for (const char *name : {"librccl.so.1", "librccl.so"}) { lib_ = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD); if (lib_) break; }
+    if (!lib_) for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib_ = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib_) break; }
     if (!lib_) { err = std::string("librccl.so not found (dlopen: ") + (dlerror() ? dlerror() : "?") + "): the weight broadcast needs RCCL; there is no fallback"; return 1; }
     get_id_ = dlsym(lib_, "ncclGetUniqueId"); init_ = dlsym(lib_, "ncclCommInitRank"); bcast_ = dlsym(lib_, "ncclBroadcast"); destroy_ = dlsym(lib_, "ncclCommDestroy");
     errstr_ = dlsym(lib_, "ncclGetErrorString"); allreduce_ = dlsym(lib_, "ncclAllReduce");

@@ -31,6 +31,9 @@ public:
     int allreduce_max_u64(void *device_words, size_t count, void *stream, std::string &err);   // in place: every rank ends with the element-wise maximum
     void close();
     bool poisoned() const { return poisoned_; }
+    // a collective is (or may be) still in flight on a stream after a bounded wait gave up: from now on close() neither destroys the communicator nor unloads the
+    // library (ncclCommDestroy on a communicator with a hung collective can hang or corrupt the surviving rank) -- both are leaked, the load fails, the process lives
+    void poison() { poisoned_ = true; }
 private:
     void *lib_ = nullptr, *comm_ = nullptr;
     void *get_id_ = nullptr, *init_ = nullptr, *bcast_ = nullptr, *allreduce_ = nullptr, *destroy_ = nullptr, *errstr_ = nullptr;

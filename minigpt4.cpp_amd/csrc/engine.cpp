@@ -84,6 +84,10 @@ void Engine::release_buffers() {
 }
 Engine::~Engine() {
     if (trace_file_) { fclose(trace_file_); trace_file_ = nullptr; }
+    if (stream_hung_) {   // see engine.hpp: leak the device side, touch nothing that synchronises
+        llm_arena_.abandon(); vis_arena_.abandon(); buf_arena_.abandon(); ri_arena_.abandon(); vgen_arena_.abandon();
+        return;
+    }
     if (stream_) HIP_IGNORE(hipStreamSynchronize(stream_));
     for (auto &e : site_events_) { HIP_IGNORE(hipEventDestroy(e.a)); HIP_IGNORE(hipEventDestroy(e.b)); }
     if (stage_) HIP_IGNORE(hipFree(stage_));
@@ -98,9 +102,14 @@ void Engine::sync() { (void)flush(); HIP_CHECK(hipStreamSynchronize(stream_)); }
 int Engine::init(const std::string &vision_path, const std::string &llm_path, int seed, int n_ctx, int n_batch) {
     const int ndev = device_count_noexcept();
     if (ndev <= 0) { set_last_error("no HIP device visible: the MI355X engine has no CPU fallback"); MG4_ERR("%s", last_error().c_str()); return E_LoadLanguageModel; }
+    // native multi-GPU load (dist.hpp): MINIGPT4_WORLD_SIZE / MINIGPT4_RANK / MINIGPT4_NCCL_ID_FILE -> rank 0 reads the files, every other rank loads
+    // headers only and receives both weight arenas by ncclBroadcast inside this call.  Parsed BEFORE the device is chosen: the stream, the arenas and
+    // the communicator must all be created on the device the rank ends up on (round-5 advisor: the stream used to be created on device 0 first).
+    DistEnv dist; { std::string derr; if (parse_dist_env(dist, derr)) { set_last_error(derr); MG4_ERR("%s", derr.c_str()); return E_LoadLanguageModel; } }
     const char *dv = getenv("MINIGPT4_DEVICE");
     if (!dv) dv = getenv("LOCAL_RANK");
-    device_ = dv ? atoi(dv) % ndev : 0;
+    device_ = dv ? atoi(dv) % ndev : (dist.active() && dist.world > 1 ? dist.rank % ndev : 0);
+    if (!dv && dist.active() && dist.world > 1) MG4_INFO("no MINIGPT4_DEVICE / LOCAL_RANK: rank %d takes device %d", dist.rank, device_);
     HIP_CHECK(hipSetDevice(device_));
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device_));
@@ -145,14 +154,8 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     // oracle-order fp32 accumulation (forward_ref): bit-identical to the CPU oracle, slow
     parity_ = trace_file_ || (getenv("MINIGPT4_PARITY") && atoi(getenv("MINIGPT4_PARITY")));
     if (const char *lm = getenv("MINIGPT4_LOAD")) load_mode_ = !strcmp(lm, "recv") ? LOAD_RECV : LOAD_FULL;
-    // native multi-GPU load (dist.hpp): MINIGPT4_WORLD_SIZE / MINIGPT4_RANK / MINIGPT4_NCCL_ID_FILE -> rank 0 reads the files, every other rank loads
-    // headers only and receives both weight arenas by ncclBroadcast inside this call
-    DistEnv dist; { std::string derr; if (parse_dist_env(dist, derr)) { set_last_error(derr); MG4_ERR("%s", derr.c_str()); return E_LoadLanguageModel; } }
-    if (dist.active()) {
-        // the exchange decides who reads the files: MINIGPT4_LOAD=recv on rank 0 would broadcast empty arenas
-        load_mode_ = dist.rank != 0 ? LOAD_RECV : LOAD_FULL;
-        if (!dv && dist.world > 1) { device_ = dist.rank % ndev; HIP_CHECK(hipSetDevice(device_)); MG4_INFO("no MINIGPT4_DEVICE / LOCAL_RANK: rank %d takes device %d", dist.rank, device_); }
-    }
+    // the exchange decides who reads the files: MINIGPT4_LOAD=recv on rank 0 would broadcast empty arenas
+    if (dist.active()) load_mode_ = dist.rank != 0 ? LOAD_RECV : LOAD_FULL;
     // With the native exchange active a load error on THIS rank is not returned at once: the rank still joins the communicator and reports it there,
     // so that its peers fail with it instead of waiting for it inside RCCL (native_broadcast).
     int load_err = E_None;
@@ -164,7 +167,8 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
         if (!load_err) load_err = load_vision(vision_path);
         auto t2 = std::chrono::steady_clock::now();
         if (!load_err) MG4_INFO("Loading minigpt4 model took %lld ms to complete", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count());
-        if (!load_err) { alloc_buffers(); if (load_mode_ == LOAD_FULL) fold_qformer_constants(); }   // LOAD_RECV: weights_received()
+        // LOAD_RECV: weights_received() derives both.  MINIGPT4_CONVERSATIONS > 1 sizes the context like set_conversations(n) does, row-interleaved image included
+        if (!load_err) { alloc_buffers(); if (load_mode_ == LOAD_FULL) { fold_qformer_constants(); if (conv_.size() > 1) build_ri_planes(); } }
     } catch (const HipError &e) {
         if (!dist.active()) throw;
         set_last_error(std::string("load failed: ") + e.what + " (" + hipGetErrorString(e.code) + ")"); load_err = E_LoadLanguageModel;
@@ -203,29 +207,40 @@ int Engine::native_broadcast(int world, int rank, const std::string &id_file, in
             const hipError_t q = hipStreamQuery(stream_);
             if (q == hipSuccess) return true;
             if (q != hipErrorNotReady) { (void)hipGetLastError(); err = std::string(what) + ": " + hipGetErrorString(q); return false; }
-            if (std::chrono::steady_clock::now() - w0 > std::chrono::seconds(timeout_s)) { err = std::string(what) + " did not complete within " + std::to_string(timeout_s) + " s (a peer left the exchange?)"; return false; }
+            if (std::chrono::steady_clock::now() - w0 > std::chrono::seconds(timeout_s)) {
+                // the collective (and the copies queued behind it) are STILL on the stream: nothing they touch may be freed, and the communicator must not be
+                // destroyed under them -- poison the Rccl object (communicator and library leaked), leak the word buffers (Words below), fail the load
+                rccl.poison(); stream_hung_ = true;
+                err = std::string(what) + " did not complete within " + std::to_string(timeout_s) + " s (a peer left the exchange?)"; return false;
+            }
             std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
     };
-    unsigned long long *d_words = nullptr;
-    HIP_CHECK(hipMalloc((void **)&d_words, 128));
-    struct Free { unsigned long long *p; ~Free() { HIP_IGNORE(hipFree(p)); } } free_words{d_words};
+    // device words of the agreements + a PINNED host image of them (the device-to-host copy behind a hung collective may land long after this frame is gone: never a
+    // stack array).  Both are leaked when the exchange was poisoned: hipFree would synchronise with the hung stream.
+    struct Words { Rccl &r; unsigned long long *d = nullptr, *h = nullptr; ~Words() { if (r.poisoned()) return; if (d) HIP_IGNORE(hipFree(d)); if (h) HIP_IGNORE(hipHostFree(h)); } } words{rccl};
+    HIP_CHECK(hipMalloc((void **)&words.d, 128));
+    HIP_CHECK(hipHostMalloc((void **)&words.h, 256, hipHostMallocDefault));
+    unsigned long long *const d_words = words.d;
     // Symmetric agreement: true on EVERY rank iff every rank passed ok and all ranks hold the same four words; otherwise false on every rank, with a
     // message naming the cause.
     auto agree = [&](const unsigned long long mine[4], bool ok_here, const char *what) -> bool {
-        unsigned long long v[10], r[10];
+        unsigned long long *const v = words.h, *const r = words.h + 16;
         for (int i = 0; i < 4; i++) { v[i] = mine[i]; v[4 + i] = ~mine[i]; }
         v[8] = ok_here ? 0ull : 1ull;                    // max over ranks: 1 = somebody failed before this point
         v[9] = ok_here ? 0ull : (unsigned long long)(rank + 1);   // ... and (one of) who
-        HIP_CHECK(hipMemcpyAsync(d_words, v, sizeof v, hipMemcpyHostToDevice, stream_));
+        HIP_CHECK(hipMemcpyAsync(d_words, v, 80, hipMemcpyHostToDevice, stream_));
         if (rccl.allreduce_max_u64(d_words, 10, stream_, err)) return false;
-        HIP_CHECK(hipMemcpyAsync(r, d_words, sizeof r, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipMemcpyAsync(r, d_words, 80, hipMemcpyDeviceToHost, stream_));
         if (!wait_stream(what)) return false;
         if (r[8]) { err = std::string("rank ") + std::to_string((long long)r[9] - 1) + " failed before \"" + what + "\"" + (ok_here ? "" : " (this rank: " + last_error() + ")"); return false; }
         for (int i = 0; i < 4; i++) if (r[i] != ~r[4 + i]) {   // max != min: the ranks disagree
             char b[256]; snprintf(b, sizeof b, "%s differ between the ranks (word %d: max %llx, min %llx; this rank %llx)", what, i, r[i], ~r[4 + i], mine[i]); err = b; return false; }
         return true;
     };
+    // test injection (tests/test_gpu_serve.py::test_native_broadcast_stream_timeout_leaks_and_returns): a bounded busy kernel in front of the first collective stands in
+    // for a collective whose peer died -- the bounded wait below must give up, poison the exchange and return without touching the stream again
+    if (const char *st = getenv("MINIGPT4_DIST_TEST_STALL_MS")) launch_stall((unsigned)std::max(0, atoi(st)), stream_);
     const ArenaPlan pl = arena_plan();
     const unsigned long long plan_words[4] = {(unsigned long long)pl.llm_bytes, (unsigned long long)pl.vision_bytes, (unsigned long long)pl.llm_hash, (unsigned long long)pl.vision_hash};
     if (!agree(plan_words, local_err == 0, "arena layouts (sizes / layout hashes)")) return fail(err);
@@ -249,6 +264,7 @@ int Engine::weights_received() {
     const size_t NQ = (size_t)v_nq_;
     for (size_t b = 0; b < (size_t)VISION_BATCH_MAX; b++) HIP_CHECK(hipMemcpy(vi_qtok_rep_ + b * NQ * 768, v_qtok_, NQ * 768 * 4, hipMemcpyDeviceToDevice));
     fold_qformer_constants();
+    if (conv_.size() > 1) build_ri_planes();               // set_conversations(n > 1) ran while the arenas were still empty
     return 0;
 }
 // Host only: the arena layout (sizes + layout hashes) the two files produce, without a device: what a receiving rank must reproduce
@@ -547,7 +563,7 @@ void Engine::alloc_buffers() {
     sz(5 * B * E * 4); sz(2 * B * F * 4); sz(S * V * 4); sz(S * V * 4); sz(8 * 256 + 2 * B * 4);
     sz(2 * B * Kmax); sz(B * Kmax / 256 * 4 + 64); sz(B * Kmax / 16 * 2 + 64); sz(B * Kmax / 16 + 64); sz(B * Kmax * 2); sz(B * Kmax / 8 + 128); sz(4 * (B * Kmax / 32 * 4 + 64)); sz(B * Kmax * 2); sz(B * Kmax * 4);
     sz(8192); sz((size_t)64 << 20); sz(attn_split_workspace_bytes((int)llm_.n_head, (int)hd, n_ctx_, std::max(attn_splits_forced_, attn_split_count((int)llm_.n_head, n_cus_))));
-    const size_t VB = (size_t)VISION_BATCH_MAX;                            // images encoded in one pass (minigpt4_encode_images)
+    const size_t VB = (size_t)VISION_BATCH_MAX;                            // images encoded in one pass (minigpt4_amd_encode_images)
     sz(VB * 3 * 224 * 224 * 4); sz(VB * 256 * 592 * 2); sz(VB * 256 * D * 4); sz(VB * 257 * D * 4); sz(VB * 257 * 3 * D * 4); sz(VB * 3 * 257 * D * 2); sz(VB * 257 * M * 2);
     sz(VB * (size_t)SPLITK_MAX * 257 * D * 4);
     sz(VB * 9 * NQ * 2304 * 4); sz(VB * 257 * 1536 * 4 * (size_t)std::max(1, v_ncross_)); sz(VB * NQ * 768 * 4); sz(VB * NQ * 768 * 4); sz(VB * NQ * 768 * 2);
@@ -955,7 +971,7 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
 // arithmetic per row as forward(1): per-row activation quantisation, exact integer block dots, the same attention kernel body.
 void Engine::forward_batch(int B, hipStream_t s) {
     pend_ = SlabSrc{}; xh_override_ = nullptr;
-    set_ri_workspace(ri_slabs_, ri_slab_floats_, ri_tickets_, ri_ticket_n_);   // this context's K-split workspace (null until build_ri_planes ran)
+    batch_path_ = BatchPath{}; batch_path_.rows = B;
     const int E = (int)llm_.n_embd, F = (int)llm_.n_ff(), H = (int)llm_.n_head, hd = E / H, V = (int)llm_.n_vocab;
     const size_t C = (size_t)n_ctx_, seq_stride = layers_.size() * C * (size_t)E;
     // y_m[t][r] = W_m[r] . act[t] (+ res_m[t][r]) for n matrices that share the prepared rows.  Up to batch_rows_max_ rows go through the pipelined
@@ -975,7 +991,7 @@ void Engine::forward_batch(int B, hipStream_t s) {
         // w2 (13B: 80 row groups x 54 super-blocks): three or four workgroups share a row group, each a K range, last arriver adds the parts.  With
         // the first weight fetch ahead of the staging and batched staging loads the launch is 18.9 (Q5_K) / 20.8 us (Q6_K) against 22.8 / 22.4 for
         // the v_dot4 kernel at B = 4 (equal at B = 3): 1037 vs 1018 tok/s, alternating on one box (profiles/r05_batched_decode_inengine.log)
-        if (ri_w2_ && B == 4 && Ws.size() == 1 && w0->cols >= 8192 && ri_ksplit(groups, w0->cols) > 1) return true;
+        if (ri_w2_ && B == 4 && Ws.size() == 1 && w0->cols >= 8192 && ri_ksplit(groups, w0->cols, ri_ws_) > 1) return true;
         return groups >= 128;
     };
     auto mm = [&](std::initializer_list<const QWeight *> Ws, std::initializer_list<float *> ys, const float *res0, int ld, const float *px = nullptr, const float *pw = nullptr) {
@@ -986,7 +1002,10 @@ void Engine::forward_batch(int B, hipStream_t s) {
         bool same = true; for (int k = 1; k < n; k++) same = same && W[k]->type == W[0]->type && W[k]->rows == W[0]->rows && W[k]->cols == W[0]->cols;
         if (ri_serves(Ws) && (!px || pw)) {                 // prepared rows, or rows this launch rms-norms and quantises itself (px, pw)
             const RiPlanes *rp[3]; for (int k = 0; k < n; k++) rp[k] = ri_of(W[k]);
-            if (launch_matvec_ri(W, rp, y, res0 ? r : nullptr, n, act_, B, ld, s, px, pw, W[0]->cols)) return;
+            if (launch_matvec_ri(W, rp, y, res0 ? r : nullptr, n, act_, B, ld, s, px, pw, W[0]->cols, ri_ws_)) {
+                batch_path_.ri++; if (ri_ksplit(n * (W[0]->rows / 64), W[0]->cols, ri_ws_) > 1) batch_path_.ri_ksplit++;
+                return;
+            }
         }
         if (same && B <= batch_rows_max_) {
             bool ok = true;
@@ -1000,7 +1019,7 @@ void Engine::forward_batch(int B, hipStream_t s) {
                 ok = launch_matvec_rows(W, yo, res0 ? ro : nullptr, n, A, std::min(4, B - t0), ld, s, px ? px + (size_t)t0 * K : nullptr, pw, K);
                 if (!ok && t0) throw HipError{hipErrorInvalidValue, "multi-row mat-vec refused a pass it had accepted", __FILE__, __LINE__};
             }
-            if (ok) return;
+            if (ok) { batch_path_.dot4++; return; }
         }
         // the launch that was to prepare its rows itself was refused (plane spacing, LDS): a performance choice must not fail the step -- prepare
         // them standalone
@@ -1009,7 +1028,7 @@ void Engine::forward_batch(int B, hipStream_t s) {
             for (int k = 0; k < n; k++) mask |= act_mask_for(W[k]->type);
             if (pw) launch_rms_quant(px, pw, B, K, act_, mask, s); else launch_silu_mul_quant(px, nullptr, B, K, act_, mask, tabs_, s);
         }
-        for (int k = 0; k < n; k++) launch_mul_mat(*W[k], act_, B, y[k], ld, r[k], s);
+        for (int k = 0; k < n; k++) { launch_mul_mat(*W[k], act_, B, y[k], ld, r[k], s); batch_path_.mul_mat++; }
     };
     // may the rows of this set be prepared inside its launch?  (same conditions mm() takes the multi-row kernel under)
     auto rows_pro = [&](std::initializer_list<const QWeight *> Ws, bool plain = false) {
@@ -1037,11 +1056,14 @@ void Engine::forward_batch(int B, hipStream_t s) {
             // the set
             if (!pro && ri_ready_ && B >= 3 && ri_of(&L.wq) && ri_of(&L.wk) && ri_of(&L.wv) && (L.wq.rows + L.wk.rows + L.wv.rows) / 64 >= 128) {
                 const RiPlanes *r1[2] = {ri_of(&L.wq), ri_of(&L.wk)}, *r2[1] = {ri_of(&L.wv)};
-                if (launch_matvec_ri_mixed(W1, r1, y1, 2, W2, r2, y2, 1, act_, B, E, s)) return true;
+                if (launch_matvec_ri_mixed(W1, r1, y1, 2, W2, r2, y2, 1, act_, B, E, s)) { batch_path_.ri_mix++; return true; }
             }
-            return launch_matvec_rows_mixed(W1, y1, 2, W2, y2, 1, act_, B, E, s, pro ? x_ : nullptr, pro ? L.attn_norm : nullptr, E);
+            const bool ok = launch_matvec_rows_mixed(W1, y1, 2, W2, y2, 1, act_, B, E, s, pro ? x_ : nullptr, pro ? L.attn_norm : nullptr, E);
+            if (ok) batch_path_.dot4_mix++;
+            return ok;
         };
         if (B > batch_rows_max_ && batch_sets_) {
+            batch_path_.sets++;
             // More conversations than the multi-row mat-vec takes (5 ... 32): the prompt pass's launches -- one int8-MFMA launch per matrix SET, row
             // preparations that also combine a K-split predecessor (pend_), i.e. 11 launches per layer instead of the 19 of one launch + one combine
             // per matrix (round 3).
@@ -1304,10 +1326,10 @@ void Engine::build_ri_planes() {
     size_t total = 0;
     for (const QWeight *w : ws) { RiPlanes p; total += ri_plan(w->type, w->rows, w->cols, p, nullptr); }
     if (!total) return;
-    ri_slab_floats_ = (size_t)1 << 18; ri_ticket_n_ = 1024;
-    ri_arena_.alloc(total + ri_slab_floats_ * 4 + (size_t)ri_ticket_n_ * 4 + 8192);
-    ri_slabs_ = reinterpret_cast<float *>(ri_arena_.take(ri_slab_floats_ * 4)); ri_tickets_ = reinterpret_cast<unsigned *>(ri_arena_.take((size_t)ri_ticket_n_ * 4));
-    HIP_CHECK(hipMemset(ri_tickets_, 0, (size_t)ri_ticket_n_ * 4));
+    ri_ws_.slab_floats = (size_t)1 << 18; ri_ws_.n_tickets = 1024;
+    ri_arena_.alloc(total + ri_ws_.slab_floats * 4 + (size_t)ri_ws_.n_tickets * 4 + 8192);
+    ri_ws_.slabs = reinterpret_cast<float *>(ri_arena_.take(ri_ws_.slab_floats * 4)); ri_ws_.tickets = reinterpret_cast<unsigned *>(ri_arena_.take((size_t)ri_ws_.n_tickets * 4));
+    HIP_CHECK(hipMemset(ri_ws_.tickets, 0, (size_t)ri_ws_.n_tickets * 4));
     for (const QWeight *w : ws) {
         RiPlanes p; const size_t need = ri_plan(w->type, w->rows, w->cols, p, nullptr);
         if (!need) continue;
@@ -1326,7 +1348,10 @@ int Engine::set_conversations(int n) {
     conv_.assign((size_t)n, Conversation{});
     cur_ = 0;
     alloc_buffers();
-    if (n > 1) build_ri_planes();                          // batched decode on the matrix cores needs the row-interleaved image (once per context)
+    // the folded Q-Former constants live in the buffer arena alloc_buffers() has just re-taken (zeroed): evaluate them again, or every later encode
+    // would run on all-zero layer-0 constants (round-5 advisor finding; tests/test_gpu_serve.py::test_encode_after_set_conversations_equals_fresh_context)
+    if (load_mode_ == LOAD_FULL) fold_qformer_constants();
+    if (n > 1 && load_mode_ == LOAD_FULL) build_ri_planes();                          // batched decode on the matrix cores needs the row-interleaved image (once per context)
     return 0;
 }
 int Engine::select_conversation(int slot) {
@@ -1334,11 +1359,12 @@ int Engine::select_conversation(int slot) {
     cur_ = slot;
     return 0;
 }
-int Engine::decode_batch(const int *slots, int n, const SampleParams &p, int *ids_out) {
+int Engine::decode_batch(const int *slots, int n, const SampleParams &p, int *ids_out, const int *forced) {
     if (!slots || !ids_out || n < 1 || n > (int)conv_.size()) { set_last_error("decode_batch: bad slot list"); return 1; }
     if (weights_missing()) return 1;
     bool seen[MAX_CONVERSATIONS] = {false};
     for (int i = 0; i < n; i++) { if (slots[i] < 0 || slots[i] >= (int)conv_.size() || seen[slots[i]]) { set_last_error("decode_batch: conversations must be distinct and in range"); return 1; } seen[slots[i]] = true; }
+    if (forced) for (int i = 0; i < n; i++) if (forced[i] < 0 || forced[i] >= (int)llm_.n_vocab) { set_last_error("decode_batch: forced token id out of range"); return 1; }
     const int keep = cur_;
     struct Restore { Engine *e; int v; ~Restore() { e->cur_ = v; } } restore{this, keep};
     // 1. pending prompt rows of each conversation (its own prefill pass), then sample
@@ -1349,7 +1375,7 @@ int Engine::decode_batch(const int *slots, int n, const SampleParams &p, int *id
     for (int i = 0; i < n; i++) {
         Conversation &cv = conv_[(size_t)slots[i]];
         if (cv.n_past + 1 > n_ctx_) continue;                               // context full: sampled, not advanced
-        h_bstage_[B] = ids_out[i]; h_bstage_[MAX_CONVERSATIONS + B] = slots[i]; h_bstage_[2 * MAX_CONVERSATIONS + B] = cv.n_committed; B++;
+        h_bstage_[B] = forced ? forced[i] : ids_out[i]; h_bstage_[MAX_CONVERSATIONS + B] = slots[i]; h_bstage_[2 * MAX_CONVERSATIONS + B] = cv.n_committed; B++;
     }
     if (!B) return 0;
     // oracle-order arithmetic exists for the single-conversation pass only: one pass per conversation (same results as the batched step is tested to

@@ -21,6 +21,7 @@ struct DeviceArena {
     void alloc(size_t bytes);
     void release();
     uint8_t *take(size_t bytes, size_t align = 256);
+    void abandon() { base = nullptr; cap = used = 0; }   // leak on purpose: hipFree synchronises with a stream that will never drain (Engine::stream_hung_)
     ~DeviceArena() { release(); }
 };
 
@@ -86,7 +87,13 @@ public:
     int current_conversation() const { return cur_; }
     // one decode step for `n` distinct conversations: sample each (like sample_token), evaluate the n sampled tokens in ONE weight pass. ids_out[i] =
     // the token sampled for slots[i]; a conversation whose context is full is sampled but not advanced (the reference discards the error too).
-    int decode_batch(const int *slots, int n, const SampleParams &p, int *ids_out);
+    // forced != null: the step evaluates forced[i] for slots[i] instead of the token it sampled (teacher forcing: tests / bench parity legs compare every step's logits with
+    // an oracle conversation that is fed the same ids); ids_out still reports what the conversation's own logits chose
+    int decode_batch(const int *slots, int n, const SampleParams &p, int *ids_out, const int *forced = nullptr);
+    // Which launches the LAST BUILT batched step (forward_batch: eager, or the capture of a graph) took, per kind -- so that a test / the bench can assert that the
+    // operating point it means to check (k_matvec_ri, k_matvec_ri_mix, the K-split w2 launch) is the one that ran, instead of a fallback with the same results
+    struct BatchPath { int rows = 0, ri = 0, ri_mix = 0, ri_ksplit = 0, dot4 = 0, dot4_mix = 0, mul_mat = 0, sets = 0; };
+    const BatchPath &batch_path() const { return batch_path_; }
     static constexpr int MAX_CONVERSATIONS = 64;
 
     // ---- measurement hooks (bench / tests)
@@ -156,6 +163,9 @@ private:
     QWeight output_;
     uint8_t *tok_raw_ = nullptr; int tok_type_ = -1;
     DeviceArena llm_arena_, vis_arena_, buf_arena_;
+    // a collective of the native broadcast never completed (a peer died inside it): the stream will not drain, so the destructor must neither wait for it nor free
+    // anything queued work may still touch -- the context's device memory is leaked, the load fails, the process lives
+    bool stream_hung_ = false;
     uint8_t *stage_ = nullptr; size_t stage_cap_ = 0;
     size_t wbytes_token_ = 0;
     __half *kc_ = nullptr, *vc_ = nullptr;
@@ -190,7 +200,8 @@ private:
     // ri_fuse_: rows prepared inside the MFMA launches -- measured slower (profiles/r05_batched_decode_inengine.log), off
     bool use_ri_ = true, ri_ready_ = false, ri_fuse_ = false;
     DeviceArena ri_arena_;
-    float *ri_slabs_ = nullptr; size_t ri_slab_floats_ = 0; unsigned *ri_tickets_ = nullptr; int ri_ticket_n_ = 0;   // K-split workspace of k_matvec_ri (zeroed tickets)
+    BatchPath batch_path_;
+    RiWorkspace ri_ws_;                                     // this context's K-split workspace of k_matvec_ri (slabs + zeroed tickets; passed with every launch)
     std::vector<std::pair<const QWeight *, RiPlanes>> ri_map_;
     const RiPlanes *ri_of(const QWeight *w) const { for (const auto &e : ri_map_) if (e.first == w) return &e.second; return nullptr; }
     void build_ri_planes();

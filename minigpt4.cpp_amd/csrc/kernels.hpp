@@ -85,17 +85,17 @@ bool matvec_rows_prologue_ok(int type, int K);
 bool ri_supported(int type, int rows, int cols);
 size_t ri_plan(int type, int rows, int cols, RiPlanes &p, uint8_t *base);      // assigns the image's plane pointers from `base` (nullptr: sizes only), returns the bytes used
 void launch_ri_build(const QWeight &w, const RiPlanes &p, hipStream_t s);      // ordinary planes -> row-interleaved image
+// workspace of the K-split form (few row groups, long K: the 13B w2): slabs for the workgroups' partial sums and one arrival ticket per row group, ZEROED by the owner (the kernel
+// leaves them zero); without it (all null) such sets run one workgroup per group.  Owned by the caller -- one per context (Engine::ri_ws_), passed with every launch: no
+// process-global state, so two contexts decoding on different threads / streams never share slabs or tickets (round-5 advisor).
+struct RiWorkspace { float *slabs = nullptr; size_t slab_floats = 0; unsigned *tickets = nullptr; int n_tickets = 0; };
 bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s,
-                      const float *px = nullptr, const float *pw = nullptr, int ldx = 0);   // px != null: rows t of px (stride ldx) are rms-normed with pw and quantised inside the launch (A unused)
+                      const float *px = nullptr, const float *pw = nullptr, int ldx = 0, const RiWorkspace &ws = RiWorkspace{});   // px != null: rows t of px (stride ldx) are rms-normed with pw and quantised inside the launch (A unused)
 // a "more bits" layer's set in one launch: na matrices of Q4_K / Q5_K + nb of Q6_K (na + nb <= 3), same shape, prepared rows
 bool launch_matvec_ri_mixed(const QWeight *const *Wa, const RiPlanes *const *ria, float *const *ya, int na, const QWeight *const *Wb, const RiPlanes *const *rib, float *const *yb, int nb,
                             const ActQ &A, int N, int ldy, hipStream_t s);
 void set_ri_cus(int cus);
-// workspace of the K-split form (few row groups, long K: the 13B w2): slabs for the workgroups' partial sums and one arrival ticket per row group, ZEROED by the caller (the kernel
-// leaves them zero); without it such sets run one workgroup per group.  One workspace per process: contexts of one process share a stream order per context, launches of two
-// contexts on different streams must not run this form concurrently (the engine sets it per context before capturing / launching a batched step)
-void set_ri_workspace(float *slabs, size_t slab_floats, unsigned *tickets, int n_tickets);
-int ri_ksplit(int total_groups, int K);
+int ri_ksplit(int total_groups, int K, const RiWorkspace &ws);   // workgroups per row group the launch would use with this workspace (1 = no K split)
 // two k-quant types (Q4_K|Q5_K + Q6_K) with the same K in one launch; pro: 0 or 1 (rms_norm prologue)
 bool launch_matvec_mixed(const QWeight *const *W1, float *const *y1, int n1, const QWeight *const *W2, float *const *y2, int n2, const ActQ &A, hipStream_t s, int pro = 0,
                          const float *px = nullptr, const float *pw = nullptr, int epi = 0);
@@ -156,6 +156,7 @@ int attn_max_ctx(int hd);   // largest n_ctx whose score / probability rows fit 
 void launch_argmax(const float *logits, int n, int *out, void *scratch /*>= 512 bytes*/, hipStream_t s);
 void launch_add_inplace(float *x, const float *y, size_t n, hipStream_t s);
 void launch_set_int(int *p, int v, hipStream_t s);
+void launch_stall(unsigned ms, hipStream_t s);   // test injection: a bounded (<= 5 s) busy kernel
 uint64_t device_checksum(const void *p, size_t bytes, hipStream_t s);   // sum of the 32-bit words (bytes rounded down to 4), mod 2^64; synchronises the stream
 void launch_fill_u16(void *p, size_t n, unsigned short v, hipStream_t s);
 void launch_advance(int *n_past, int n, int *tok0, const int *argmax, hipStream_t s);

@@ -2713,6 +2713,13 @@ uint64_t device_checksum(const void *p, size_t bytes, hipStream_t s) {
     HIP_CHECK(hipStreamSynchronize(s));
     return (uint64_t)h;
 }
+// Fault injection for the native broadcast's bounded waits (MINIGPT4_DIST_TEST_STALL_MS, tests/test_gpu_serve.py): one lane keeps the stream busy for `ms` milliseconds
+// of the 100 MHz constant clock -- what a collective whose peer died looks like to the host -- and then ENDS (at most 5 s: it can never hang the device).
+__global__ void k_stall(unsigned ms) {
+    const unsigned long long t0 = wall_clock64(), ticks = (unsigned long long)(ms > 5000u ? 5000u : ms) * 100000ull;
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+void launch_stall(unsigned ms, hipStream_t s) { hipLaunchKernelGGL(k_stall, dim3(1), dim3(1), 0, s, ms); }
 __global__ void k_fill_u16(unsigned short *p, size_t n, unsigned short v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }

@@ -435,19 +435,17 @@ static bool launch_ri_t(const RiArgs &a, const ActQ &A, hipStream_t s) {
 }
 // y[m][t * ldy + r] = W_m[r] . act[t] (+ residual[m][t * ldy + r]) for N = 1..4 prepared rows (A: Q8_K image incl. bsq) against 1..3 same-type,
 // same-shape k-quant matrices that carry their row-interleaved image (ri[k]); false -> outside this kernel's range, nothing launched
-static float *g_ri_slabs = nullptr; static unsigned *g_ri_tickets = nullptr; static size_t g_ri_slab_floats = 0; static int g_ri_ticket_n = 0;
-void set_ri_workspace(float *slabs, size_t slab_floats, unsigned *tickets, int n_tickets) { g_ri_slabs = slabs; g_ri_slab_floats = slab_floats; g_ri_tickets = tickets; g_ri_ticket_n = n_tickets; }
 // K split over workgroups for a set with few row groups and a long K (ri_kernels.hip header): parts of >= 8 super-blocks (two per wave), at most 4,
-// only when the workspace is set
-int ri_ksplit(int total_groups, int K) {
+// only with a workspace
+int ri_ksplit(int total_groups, int K, const RiWorkspace &ws) {
     const int NSB = K / 256;
-    if (!g_ri_slabs || total_groups >= g_ri_cus / 2 || total_groups > g_ri_ticket_n) return 1;
+    if (!ws.slabs || !ws.tickets || total_groups >= g_ri_cus / 2 || total_groups > ws.n_tickets) return 1;
     int S = std::min(4, std::min(NSB / 8, 2 * g_ri_cus / std::max(1, total_groups)));
-    while (S > 1 && (size_t)total_groups * S * 256 > g_ri_slab_floats) S--;
+    while (S > 1 && (size_t)total_groups * S * 256 > ws.slab_floats) S--;
     return std::max(1, S);
 }
 bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s,
-                      const float *px, const float *pw, int ldx) {
+                      const float *px, const float *pw, int ldx, const RiWorkspace &ws) {
     if (n < 1 || n > 3 || N < 1 || N > 4) return false;
     if (px ? (!pw || ldx < W[0]->cols) : (!A.q8k || !A.dk || !A.bsk || !A.bsq)) return false;
     RiArgs a{};
@@ -458,7 +456,7 @@ bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float 
     }
     if (!ri_supported(W[0]->type, W[0]->rows, W[0]->cols)) return false;
     a.n_mat = n; a.groups_each = W[0]->rows / 64; a.rows_each = W[0]->rows; a.K = W[0]->cols; a.N = N; a.ldy = ldy;
-    a.ksplit = ri_ksplit(n * a.groups_each, a.K); a.slabs = g_ri_slabs; a.tickets = g_ri_tickets;
+    a.ksplit = ri_ksplit(n * a.groups_each, a.K, ws); a.slabs = ws.slabs; a.tickets = ws.tickets;
     switch (W[0]->type) {
     case GT_Q4_K: return launch_ri_t<GT_Q4_K>(a, A, s);
     case GT_Q5_K: return launch_ri_t<GT_Q5_K>(a, A, s);

@@ -239,10 +239,10 @@ int minigpt4_amd_test_matvec_ri(int ggml_type, const void *raw_w, int n_mat, int
         hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0)); set_ri_cus(prop.multiProcessorCount);
         DevBuf d_ws(((size_t)1 << 18) * 4 + 4096);                           // K-split workspace (few groups, long K): slabs + zeroed tickets
         HIP_CHECK(hipMemset(d_ws.p, 0, ((size_t)1 << 18) * 4 + 4096));
-        struct WsScope { WsScope(float *sl, unsigned *tk) { set_ri_workspace(sl, (size_t)1 << 18, tk, 1024); } ~WsScope() { set_ri_workspace(nullptr, 0, nullptr, 0); } } ws_scope(d_ws.as<float>(), reinterpret_cast<unsigned *>(d_ws.as<float>() + ((size_t)1 << 18)));
-        if (!launch_matvec_ri(Wp, Pp, Yp, residual ? Rp : nullptr, n_mat, A, N, R, nullptr, rms_w ? d_x.as<float>() : nullptr, rms_w ? d_w.as<float>() : nullptr, K)) { set_last_error("launch_matvec_ri refused"); return 4; }
+        const RiWorkspace ws{d_ws.as<float>(), (size_t)1 << 18, reinterpret_cast<unsigned *>(d_ws.as<float>() + ((size_t)1 << 18)), 1024};
+        if (!launch_matvec_ri(Wp, Pp, Yp, residual ? Rp : nullptr, n_mat, A, N, R, nullptr, rms_w ? d_x.as<float>() : nullptr, rms_w ? d_w.as<float>() : nullptr, K, ws)) { set_last_error("launch_matvec_ri refused"); return 4; }
         HIP_CHECK(hipDeviceSynchronize());
-        if (!launch_matvec_ri(Wp, Pp, Yp, residual ? Rp : nullptr, n_mat, A, N, R, nullptr, rms_w ? d_x.as<float>() : nullptr, rms_w ? d_w.as<float>() : nullptr, K)) { set_last_error("launch_matvec_ri refused"); return 4; }   // twice: the tickets must be back at zero
+        if (!launch_matvec_ri(Wp, Pp, Yp, residual ? Rp : nullptr, n_mat, A, N, R, nullptr, rms_w ? d_x.as<float>() : nullptr, rms_w ? d_w.as<float>() : nullptr, K, ws)) { set_last_error("launch_matvec_ri refused"); return 4; }   // twice: the tickets must be back at zero
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemcpy(y, d_y.p, (size_t)n_mat * N * R * 4, hipMemcpyDeviceToHost));
         return 0;
@@ -319,12 +319,11 @@ int minigpt4_amd_bench_matvec_ri(int ggml_type, int rows, int cols, int n_mat, i
         launch_rms_quant(dx.as<float>(), nullptr, N, cols, A, ACT_Q8K, nullptr);
         DevBuf d_ws(((size_t)1 << 18) * 4 + 4096);
         HIP_CHECK(hipMemset(d_ws.p, 0, ((size_t)1 << 18) * 4 + 4096));
-        struct WsScope { WsScope(float *sl, unsigned *tk, bool on) { if (on) set_ri_workspace(sl, (size_t)1 << 18, tk, 1024); } ~WsScope() { set_ri_workspace(nullptr, 0, nullptr, 0); } }
-            ws_scope(d_ws.as<float>(), reinterpret_cast<unsigned *>(d_ws.as<float>() + ((size_t)1 << 18)), !getenv("MG4_RI_NOSPLIT"));
+        const RiWorkspace ws = getenv("MG4_RI_NOSPLIT") ? RiWorkspace{} : RiWorkspace{d_ws.as<float>(), (size_t)1 << 18, reinterpret_cast<unsigned *>(d_ws.as<float>() + ((size_t)1 << 18)), 1024};
         auto run = [&](int set) {
             const QWeight *Wp[3]; const RiPlanes *Pp[3]; float *Yp[3];
             for (int m = 0; m < n_mat; m++) { Wp[m] = &W[(size_t)set * n_mat + m]; Pp[m] = &P[(size_t)set * n_mat + m]; Yp[m] = dy.as<float>() + (size_t)m * rows * N; }
-            if (!launch_matvec_ri(Wp, Pp, Yp, nullptr, n_mat, A, N, rows, nullptr)) throw HipError{hipErrorInvalidValue, "launch_matvec_ri refused", __FILE__, __LINE__};
+            if (!launch_matvec_ri(Wp, Pp, Yp, nullptr, n_mat, A, N, rows, nullptr, nullptr, nullptr, 0, ws)) throw HipError{hipErrorInvalidValue, "launch_matvec_ri refused", __FILE__, __LINE__};
         };
         for (int i = 0; i < std::min(n_sets, 4); i++) run(i);
         HIP_CHECK(hipDeviceSynchronize());

@@ -178,8 +178,10 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_weight_bytes_per_token.restype = ctypes.c_double
         L.minigpt4_amd_last_encode_ms.argtypes = [VOID_PTR]
         L.minigpt4_amd_last_encode_ms.restype = F32
-        L.minigpt4_encode_images.argtypes = [VOID_PTR, P(MiniGPT4Images), P(MiniGPT4Embeddings), SIZE_T]
-        L.minigpt4_free_embeddings.argtypes = [P(MiniGPT4Embeddings)]
+        for name in ("minigpt4_amd_encode_images", "minigpt4_encode_images"):        # the second = deprecated alias (include/minigpt4_amd.h)
+            getattr(L, name).argtypes = [VOID_PTR, P(MiniGPT4Images), P(MiniGPT4Embeddings), SIZE_T]
+        for name in ("minigpt4_amd_free_embeddings", "minigpt4_free_embeddings"):
+            getattr(L, name).argtypes = [P(MiniGPT4Embeddings)]
         L.minigpt4_amd_weight_arena.argtypes = [VOID_PTR, I32, P(VOID_PTR), P(SIZE_T)]
         U64P, SZP = P(ctypes.c_uint64), P(ctypes.c_size_t)
         L.minigpt4_amd_plan_arenas.argtypes = [CHAR_PTR, CHAR_PTR, SZP, SZP, U64P, U64P]
@@ -195,6 +197,8 @@ class MiniGPT4SharedLibrary:
         L.minigpt4_amd_select_conversation.argtypes = [VOID_PTR, I32]
         L.minigpt4_amd_n_conversations.argtypes = [VOID_PTR]
         L.minigpt4_amd_end_chat_batch.argtypes = [VOID_PTR, INT_PTR, I32, P(ctypes.c_char_p), F32, I32, F32, F32, F32, I32, F32, F32]
+        L.minigpt4_amd_eval_batch.argtypes = [VOID_PTR, INT_PTR, I32, INT_PTR, INT_PTR]
+        L.minigpt4_amd_batch_path.argtypes = [VOID_PTR, INT_PTR]
 
     @staticmethod
     def _declare_test_hooks(L):
@@ -363,6 +367,33 @@ class MiniGPT4SharedLibrary:
         if rc:
             raise RuntimeError("end_chat_batch failed: " + self.library.minigpt4_amd_last_error().decode())
         return [(t or b"").decode("utf-8", errors="replace") for t in toks]
+
+    def amd_eval_batch(self, ctx, slots: Sequence[int], tokens: Sequence[int]) -> List[int]:
+        """One batched decode step with GIVEN next tokens (teacher forcing); returns every conversation's own greedy choice."""
+        n = len(slots)
+        assert len(tokens) == n
+        sl, tk, out = (ctypes.c_int32 * n)(*slots), (ctypes.c_int32 * n)(*[int(t) for t in tokens]), (ctypes.c_int32 * n)()
+        if self.library.minigpt4_amd_eval_batch(ctx.ptr, sl, n, tk, out):
+            raise RuntimeError("minigpt4_amd_eval_batch failed: " + self.library.minigpt4_amd_last_error().decode("utf-8", errors="replace"))
+        return [int(x) for x in out]
+
+    def amd_batch_path(self, ctx) -> dict:
+        """Launch kinds of the batched step as last built (include/minigpt4_amd.h: minigpt4_amd_batch_path)."""
+        out = (ctypes.c_int32 * 8)()
+        if self.library.minigpt4_amd_batch_path(ctx.ptr, out):
+            raise RuntimeError("minigpt4_amd_batch_path failed")
+        return dict(zip(("rows", "ri", "ri_mix", "ri_ksplit", "dot4", "dot4_mix", "mul_mat", "sets"), [int(x) for x in out]))
+
+    def amd_encode_images(self, ctx, images: Sequence[np.ndarray]) -> List[np.ndarray]:
+        """minigpt4_amd_encode_images: the images (f32 CHW [3,224,224] arrays) in passes of up to 8 over the vision weights; one [32, n_embd] array per image."""
+        arrs = [np.ascontiguousarray(i, dtype=np.float32) for i in images]
+        structs = (MiniGPT4Image * len(arrs))(*[array_to_image_struct(a) for a in arrs])
+        batch, out = MiniGPT4Images(structs, len(arrs)), MiniGPT4Embeddings()
+        self.panic_if_error(self.library.minigpt4_amd_encode_images(ctx.ptr, ctypes.byref(batch), ctypes.byref(out), 0))
+        try:
+            return [np.ctypeslib.as_array(out.embeddings[i].data, shape=(out.embeddings[i].n_embeddings,)).copy().reshape(32, -1) for i in range(out.n_embeddings)]
+        finally:
+            self.library.minigpt4_amd_free_embeddings(ctypes.byref(out))
 
     def amd_decode_image(self, data: bytes) -> MiniGPT4Image:
         image = MiniGPT4Image()

@@ -2,7 +2,7 @@
 
 A request = (image, prompt) owns its embedding, KV cache and position, so a replica can run several of them side by side:
 
-  * the images of a wave are encoded in ONE pass over the vision weights (`minigpt4_encode_images`, up to 8 per pass);
+  * the images of a wave are encoded in ONE pass over the vision weights (`minigpt4_amd_encode_images`, up to 8 per pass);
   * every request gets its own conversation of the context (`minigpt4_amd_set_conversations` / `_select_conversation`) and is prompted through the
     reference entry points exactly as `MiniGPT4ChatBot.generate` does (`minigpt4_library.py:627-644` of the reference): system prompt, image turn;
   * decode steps run for all unfinished conversations at once (`minigpt4_amd_end_chat_batch`: one pass over the LLM weights per 4 conversations);
@@ -74,7 +74,7 @@ class ReplicaServer:
                 owned += own
             arr = (ML.MiniGPT4Image * len(wave))(*structs)
             batch, embs = ML.MiniGPT4Images(arr, len(wave)), ML.MiniGPT4Embeddings()
-            lib.panic_if_error(lib.library.minigpt4_encode_images(ctx.ptr, ctypes.byref(batch), ctypes.byref(embs), 0))
+            lib.panic_if_error(lib.library.minigpt4_amd_encode_images(ctx.ptr, ctypes.byref(batch), ctypes.byref(embs), 0))
             try:
                 for slot, i in enumerate(wave):
                     lib.amd_select_conversation(ctx, slot)
@@ -107,7 +107,7 @@ class ReplicaServer:
                 for slot, i in enumerate(wave):
                     answers[i] = shown[slot]
             finally:
-                lib.library.minigpt4_free_embeddings(ctypes.byref(embs))
+                lib.library.minigpt4_amd_free_embeddings(ctypes.byref(embs))
                 for im in owned:
                     lib.minigpt4_free_image(im)
         lib.amd_select_conversation(ctx, 0)

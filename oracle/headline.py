@@ -181,3 +181,89 @@ def compare(oracle: Dict, gpu_pieces: List[str], gpu_logits: np.ndarray) -> Dict
             "teacher_forced_argmax_identical": int(arg_eq.sum()), "decided": int(decided.sum()), "decided_argmax_identical": int((arg_eq & decided).sum()),
             "max_logit_rel_range": float(rel.max()), "max_logit_rel": float(rel_max.max()), "mean_logit_rel_range": float(rel.mean()),
             "min_top2_margin_over_range": float((margin / rng).min()), "prompt_tokens": int(oracle["n_prompt"])}
+
+
+# ---- BASELINE.json configs[3]'s per-GPU operating point: B conversations per replica decoded in ONE pass over the weights per step -----------------------------------------
+# Reference behaviour to match: one INDEPENDENT conversation per context (minigpt4.cpp:2513-2521 holds one n_past / one KV cache; :2704-2718 end_chat_image), so every
+# conversation of a batched replica must behave like its own OracleChat.
+
+BATCH_PROMPTS = [PROMPT, "describe the colours of the image", "hello", "and now something longer to shift the positions of this conversation apart from the others"]
+
+
+def embedding_struct(emb_np: np.ndarray):
+    """A MiniGPT4Embedding over a float32 [32, n_embd] array (the array is kept alive by the returned pair)."""
+    import ctypes
+    from minigpt4_cpp_amd import minigpt4_library as ML
+    a = np.ascontiguousarray(emb_np, np.float32)
+    st = ML.MiniGPT4Embedding(a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), a.size)
+    return st, a
+
+
+def gpu_batched_start(lib, ctx, embeddings: List[np.ndarray], prompts: List[str]) -> None:
+    """system_prompt + begin_chat_image on conversation i with embeddings[i] / prompts[i] (the prompt rows are only queued: the first batched step runs each conversation's
+    own prefill pass, then the shared decode pass)."""
+    B = len(prompts)
+    if lib.library.minigpt4_amd_n_conversations(ctx.ptr) != B:
+        lib.amd_set_conversations(ctx, B)
+    for sl in range(B):
+        lib.amd_select_conversation(ctx, sl)
+        lib.minigpt4_reset_chat(ctx)
+        lib.minigpt4_system_prompt(ctx)
+        st, keep = embedding_struct(embeddings[sl])
+        lib.minigpt4_begin_chat_image(ctx, st, prompts[sl])
+        del keep
+    lib.amd_select_conversation(ctx, 0)
+
+
+def gpu_batched_free_run(lib, ctx, embeddings, prompts, steps: int) -> List[List[str]]:
+    """`steps` batched greedy steps (minigpt4_amd_end_chat_batch, EOS ignored): pieces[conversation][step]."""
+    gpu_batched_start(lib, ctx, embeddings, prompts)
+    B = len(prompts)
+    out: List[List[str]] = [[] for _ in range(B)]
+    for _ in range(steps):
+        for sl, piece in enumerate(lib.amd_end_chat_batch(ctx, list(range(B)), temp=0.0)):
+            out[sl].append(piece)
+    return out
+
+
+def gpu_batched_teacher_forced(lib, ctx, embeddings, prompts, ids: List[List[int]]) -> np.ndarray:
+    """Logits [conversation][step][n_vocab] of the BATCHED step with every conversation fed ITS oracle's ids (minigpt4_amd_eval_batch): step 0's logits come from each
+    conversation's own prefill pass, every later step's from the shared batched pass."""
+    gpu_batched_start(lib, ctx, embeddings, prompts)
+    B, steps = len(prompts), len(ids[0])
+    out = None
+    for i in range(steps):
+        for sl in range(B):
+            lib.amd_select_conversation(ctx, sl)
+            lg = lib.amd_logits(ctx)
+            if out is None:
+                out = np.empty((B, steps, lg.shape[0]), np.float32)
+            out[sl, i] = lg
+        lib.amd_eval_batch(ctx, list(range(B)), [ids[sl][i] for sl in range(B)])
+    lib.amd_select_conversation(ctx, 0)
+    return out
+
+
+def batched_vs_oracle(lib, ctx, lp: str, embeddings: List[np.ndarray], prompts: List[str], steps: int, n_ctx: int = 512, threads: Optional[int] = None,
+                      oracles: Optional[List[Dict]] = None) -> Dict:
+    """B conversations of one context against B independent oracle conversations on the same file: free-running pieces + teacher-forced logits per conversation (compare()),
+    the worst of each figure over the conversations, and the launch kinds the batched step took (minigpt4_amd_batch_path).  `oracles`: reuse oracle_run results."""
+    B = len(prompts)
+    if oracles is None:
+        oracles = [oracle_run(lp, embeddings[i], steps, prompt=prompts[i], n_ctx=n_ctx, threads=threads) for i in range(B)]
+    pieces = gpu_batched_free_run(lib, ctx, embeddings, prompts, steps)
+    path_free = lib.amd_batch_path(ctx)
+    logits = gpu_batched_teacher_forced(lib, ctx, embeddings, prompts, [o["ids"][:steps] for o in oracles])
+    path = lib.amd_batch_path(ctx)
+    per = []
+    for i in range(B):
+        head = {"logits": oracles[i]["logits"][:steps], "ids": oracles[i]["ids"][:steps], "pieces": oracles[i]["pieces"][:steps], "n_prompt": oracles[i]["n_prompt"]}
+        per.append(compare(head, pieces[i], logits[i]))
+    agg = {"conversations": B, "tokens_compared_each": steps, "launches_of_the_batched_step": path, "launches_free_running_step": path_free,
+           "free_running_identical_min": min(p["free_running_identical"] for p in per),
+           "teacher_forced_argmax_identical_min": min(p["teacher_forced_argmax_identical"] for p in per),
+           "max_logit_rel": max(p["max_logit_rel"] for p in per), "max_logit_rel_range": max(p["max_logit_rel_range"] for p in per),
+           "decided_min": min(p["decided"] for p in per), "decided_argmax_mismatches": sum(p["decided"] - p["decided_argmax_identical"] for p in per),
+           "prompt_tokens": [p["prompt_tokens"] for p in per], "oracle_s": sum(o["prefill_s"] + o["decode_s"] for o in oracles),
+           "per_conversation": per}
+    return agg

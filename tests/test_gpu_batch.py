@@ -129,9 +129,51 @@ def test_mixed_type_layer_in_one_launch_full_width(gpu_lib, B, monkeypatch):
             err = float(np.abs(one[sl] - want).max() / (want.max() - want.min()))
             err_mfma = float(np.abs(mfma[sl] - want).max() / (want.max() - want.min()))
             print(f"B={B} conversation {sl}: batched vs single-conversation logits {err:.2e} of the range (MFMA launches: {err_mfma:.2e})")
-            assert err < 3e-2 and err_mfma < 3e-2          # this file's own int8 re-rounding noise is 1.2-1.5 % of the range (oracle/headline.py::oracle_self_noise, test_gpu_headline.py)
+            # two GPU summation orders of the same exact integer dots: each differs from the oracle by <= 1e-2 of the largest |logit| (test_configs3_operating_point_...,
+            # test_gpu_headline.py: observed 5-6e-3), so from each other by at most the sum; of the RANGE (about 1.4 x the largest |logit| on this file) that is <= 1.5e-2
+            assert err < 1.5e-2 and err_mfma < 1.5e-2
     finally:
         gpu_lib.minigpt4_free(ref)
+
+
+@pytest.mark.parametrize("config,B,steps", [("13b_l2", 3, 16), ("13b_l2", 4, 16), ("13b", 4, 32)])
+def test_configs3_operating_point_matches_independent_oracle_chats(gpu_lib, config, B, steps):
+    """BASELINE.json configs[3]'s per-GPU operating point AS THE ENGINE RUNS IT (round-5 verdict, missing #1): B = 3 / 4 image conversations per replica at the 13B width with
+    MINIGPT4_RI at its default, i.e. the batched step on `k_matvec_ri` / `k_matvec_ri_mix` (row-interleaved weight image, v_mfma_i32_4x4x4i8) + the K-split w2 launch at
+    B = 4 -- asserted from the launch counters, so a silent fallback to the v_dot4 launches cannot pass for it.  Every conversation is compared with ITS OWN independent
+    OracleChat (reference: one conversation per context, minigpt4.cpp:2513-2521, 2704-2718) by the criteria of the single-conversation headline test
+    (oracle/headline.py::compare): free-running greedy pieces identical at every step, teacher-forced logits of every BATCHED step within 1e-2 of the largest |logit|,
+    argmax identical on every step.  13b_l2 = the 40-layer graph cut to two layers (layer 0 a "more bits" layer -> the mixed-type launch, layer 1 plain Q5_K); 13b = the
+    full 40-layer file, 32 steps."""
+    import json
+    import os
+    import headline as H
+    from minigpt4_cpp_amd import minigpt4_library as ML, modelgen as G
+    assert os.environ.get("MINIGPT4_RI", "1") != "0" and os.environ.get("MINIGPT4_RI_W2", "1") != "0"
+    vp, lp = H.headline_files(config)
+    threads = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8, 32))
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=1, n_ctx=512, n_batch=512)
+    try:
+        embs = gpu_lib.amd_encode_images(ctx, [G.synth_image(200 + i) for i in range(B)])           # a different image per conversation
+        prompts = H.BATCH_PROMPTS[:B]
+        res = H.batched_vs_oracle(gpu_lib, ctx, lp, embs, prompts, steps, n_ctx=512, threads=threads)
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        json.dump(res, open(os.path.join(d, f"parity_observed_batched_{config}_b{B}.json"), "w"), indent=1, sort_keys=True)
+        print(config, B, json.dumps({k: v for k, v in res.items() if k != "per_conversation"}))
+        path = res["launches_of_the_batched_step"]
+        n_layer = 2 if config.endswith("_l2") else 40
+        # the operating point itself: same-type sets and the output matrix on k_matvec_ri, every "more bits" layer's wq|wk + wv on k_matvec_ri_mix, w2 on the K-split form at B = 4
+        assert path["rows"] == B and path["ri"] >= n_layer + 1 and path["ri_mix"] >= 1 and path["dot4_mix"] == 0 and path["mul_mat"] == 0 and path["sets"] == 0, path
+        assert (path["ri_ksplit"] == n_layer) if B == 4 else (path["ri_ksplit"] == 0), path
+        assert res["launches_free_running_step"] == path
+        assert len(set(res["prompt_tokens"])) > 1                                  # the conversations sit at different positions
+        assert res["free_running_identical_min"] == steps, res
+        assert res["teacher_forced_argmax_identical_min"] == steps, res
+        assert res["max_logit_rel"] <= 1e-2, res
+        assert res["decided_min"] >= steps * 3 // 4 and res["decided_argmax_mismatches"] == 0, res
+    finally:
+        gpu_lib.minigpt4_free(ctx)
 
 
 def test_interleaving_single_and_batched_steps_reset_and_subsets(gpu_lib, tiny_files):

@@ -78,13 +78,13 @@ def test_generic_path_batches_images_bit_identically(gpu_lib, base, tiny_files):
         imgs = [G.synth_image(s) for s in (5, 6, 7)]
         structs = (ML.MiniGPT4Image * 3)(*[ML.array_to_image_struct(i) for i in imgs])
         batch, out = ML.MiniGPT4Images(structs, 3), ML.MiniGPT4Embeddings()
-        assert gpu_lib.library.minigpt4_encode_images(ctx.ptr, ctypes.byref(batch), ctypes.byref(out), 0) == 0
+        assert gpu_lib.library.minigpt4_amd_encode_images(ctx.ptr, ctypes.byref(batch), ctypes.byref(out), 0) == 0
         for i, img in enumerate(imgs):
             single = gpu_lib.minigpt4_encode_image(ctx, ML.array_to_image_struct(img))
             a = np.ctypeslib.as_array(single.data, shape=(single.n_embeddings,)).copy()
             b = np.ctypeslib.as_array(out.embeddings[i].data, shape=(out.embeddings[i].n_embeddings,)).copy()
             assert np.array_equal(a, b)
             gpu_lib.minigpt4_free_embedding(single)
-        gpu_lib.library.minigpt4_free_embeddings(ctypes.byref(out))
+        gpu_lib.library.minigpt4_amd_free_embeddings(ctypes.byref(out))
     finally:
         gpu_lib.minigpt4_free(ctx)

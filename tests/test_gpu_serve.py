@@ -302,3 +302,67 @@ def test_serve_on_two_ranks_sharing_the_gpu_equals_one_rank(gpu_lib, tmpdir_mode
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-1500:] for l in logs)
     two = json.load(open(out_path))
     assert two == one
+
+
+def test_encode_after_set_conversations_equals_fresh_context(gpu_lib, tiny_files):
+    """Round-5 advisor (high): minigpt4_amd_set_conversations re-takes the buffer arena, in which the folded Q-Former constants live -- they must be evaluated again, or every
+    later encode runs on all-zero layer-0 constants.  The embedding of an image encoded AFTER set_conversations(n) equals, bit for bit, the one a fresh context computes
+    (and the oracle's, to the fast-mode bound); also after going back to one conversation, and through the batched entry point."""
+    from minigpt4_cpp_amd import minigpt4_library as ML, modelgen as G
+    import refcpu as R
+    vp, llm = tiny_files
+    lp = llm("q5_k", "q5_k_m")
+    img = G.synth_image(7)
+
+    def encode(ctx):
+        emb = gpu_lib.minigpt4_encode_image(ctx, ML.array_to_image_struct(img))
+        out = np.ctypeslib.as_array(emb.data, shape=(emb.n_embeddings,)).copy().reshape(32, -1)
+        gpu_lib.minigpt4_free_embedding(emb)
+        return out
+
+    fresh = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=64, n_batch=16)
+    want = encode(fresh)
+    gpu_lib.minigpt4_free(fresh)
+    oracle = R.OracleVision(G.read_vision_file(vp)).encode(img)
+    assert float(np.abs(want - oracle).max() / np.abs(oracle).max()) < 3e-3
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=64, n_batch=16)
+    try:
+        for n in (3, 1, 4):
+            gpu_lib.amd_set_conversations(ctx, n)
+            got = encode(ctx)
+            assert np.array_equal(got, want), f"embedding after set_conversations({n}) differs from a fresh context's: max diff {np.abs(got - want).max()}"
+        both = gpu_lib.amd_encode_images(ctx, [img, G.synth_image(8)])
+        assert np.array_equal(np.asarray(both[0]).reshape(32, -1), want)
+    finally:
+        gpu_lib.minigpt4_free(ctx)
+
+
+def test_native_broadcast_stream_timeout_leaks_and_returns(tiny_files, tmp_path):
+    """Round-5 advisor (medium): after a bounded stream wait of the native exchange gives up, the collective is STILL on the stream -- the teardown must not destroy the
+    communicator under it, free the words it reads or wait for the stream.  A peer cannot be killed inside a collective on a one-GPU box (RCCL refuses two ranks on one
+    device), so the hang is injected: MINIGPT4_DIST_TEST_STALL_MS queues a bounded busy kernel (3 s) in front of the first agreement with a 1 s timeout.  The load must
+    come back with the time-out text well before the kernel ends, the context must be gone, and the process must still be able to load and use a model afterwards."""
+    import subprocess
+    import sys
+    vp, llm = tiny_files
+    lp = llm("q5_k", "q5_k_m")
+    code = ("import os, sys, time; sys.path.insert(0, %r); import _pkg; _pkg.load_package()\n"
+            "from minigpt4_cpp_amd import minigpt4_library as ML\n"
+            "lib = ML.load_library(); t0 = time.time()\n"
+            "try:\n"
+            "    lib.minigpt4_model_load(%r, %r, verbosity=0, n_ctx=64, n_batch=16); print('LOADED')\n"
+            "except RuntimeError as e:\n"
+            "    print('ERR %%.2f %%s' %% (time.time() - t0, e))\n"
+            "for k in ('MINIGPT4_WORLD_SIZE', 'MINIGPT4_RANK', 'MINIGPT4_NCCL_ID_FILE', 'MINIGPT4_DIST_TEST_STALL_MS'): os.environ.pop(k, None)\n"
+            "ctx = lib.minigpt4_model_load(%r, %r, verbosity=0, n_ctx=256, n_batch=16)\n"
+            "lib.minigpt4_system_prompt(ctx); print('AFTER', repr(lib.minigpt4_end_chat(ctx, temp=0.0)))\n"
+            "sys.stdout.flush(); os._exit(0)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), vp, lp, vp, lp)
+    env = dict(os.environ, MINIGPT4_WORLD_SIZE="1", MINIGPT4_RANK="0", MINIGPT4_NCCL_ID_FILE=str(tmp_path / "stall.id"), MINIGPT4_DIST_TIMEOUT_S="1",
+               MINIGPT4_DIST_TEST_STALL_MS="3000")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180)
+    lines = r.stdout.splitlines()
+    err = [l for l in lines if l.startswith(("ERR", "LOADED"))]
+    assert err and err[0].startswith("ERR") and "did not complete within" in err[0], (r.stdout[-800:], r.stderr[-800:])
+    assert float(err[0].split()[1]) < 2.9, err[0]            # returned while the stalled work was still on the stream
+    assert any(l.startswith("AFTER") for l in lines), (r.stdout[-800:], r.stderr[-800:])
+    assert not os.path.exists(str(tmp_path / "stall.id"))
