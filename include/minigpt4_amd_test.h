@@ -44,6 +44,10 @@ MINIGPT4_API int minigpt4_amd_test_gemm_f16_skinny(const float *A, const float *
 MINIGPT4_API int minigpt4_amd_bench_gemm_f16(int M, int N, int K, int flags, int variant, int iters, int n_sets, float *us_per_launch);
 /* Micro-benchmark of the ViT / Q-Former attention kernel on synthetic rows (tools/timeline_attn.py) */
 MINIGPT4_API int minigpt4_amd_bench_attn_f32(int heads, int hd, int nq, int nk, int iters, float *us_per_launch);
+/* the same with `batch` images per launch, computed exponentials (the engine's fast mode) and `qt` query tiles per workgroup forced (0 = the launcher's choice); nq == nk */
+MINIGPT4_API int minigpt4_amd_bench_attn_f32_b(int heads, int hd, int nq, int nk, int batch, int qt, int iters, float *us_per_launch);
+/* query tiles per workgroup of the ViT / Q-Former attention kernel for every later launch of this process (0 = the launcher's choice); bit-identical results for every value */
+MINIGPT4_API void minigpt4_amd_test_set_attn_qt(int qt);
 /* the F16 feed-forward pair launch: out_h[N][n_out] = fp16(silu_table(w1 x) * (w3 x)) (uint16 bit patterns), w = w1 then w3 as fp16 [n_out][n_in]; 4 = shape outside the path */
 MINIGPT4_API int minigpt4_amd_test_f16_silu_pair(const float *x, const void *w_f16, int64_t N, int64_t n_in, int64_t n_out, unsigned short *out_h, float *out_f);
 /* Micro-benchmark of the prompt-row attention on a synthetic fp16 K / V cache (tools/timeline_attn_prefill.py); _timeline_attn: its stamps in a -DMG4_TIMELINE build */
@@ -51,6 +55,8 @@ MINIGPT4_API int minigpt4_amd_bench_attn_prefill(int n_head, int hd, int N, int 
 MINIGPT4_API int minigpt4_amd_timeline_attn(unsigned long long *out, int max_workgroups);
 /* force one tile shape (an "arm" of launch_gemm_f16_arm in vision_kernels.hip; 0 = the launcher's own choice) for every small-M GEMM / split-K GEMM of this process */
 MINIGPT4_API void minigpt4_amd_test_set_gemm_arm(int arm, int sk_arm);
+/* 0: split-K GEMM slices in grid.z (the rounds 3-5 workgroup -> XCD mapping); 1 (default): the [slice][tile] work list dealt to the XCDs in contiguous ranges */
+MINIGPT4_API void minigpt4_amd_test_set_splitk_xcd(int on);
 /* diagnostic builds (-DMG4_TIMELINE): the 32 clock stamps per workgroup of the last image-path GEMM launch; 0 = built without */
 MINIGPT4_API int minigpt4_amd_timeline_vision(unsigned long long *out, int max_workgroups);
 /* Micro-benchmark of the decode mat-vec kernels on synthetic weight planes (see bench_kernels.py). variant 0: one launch per matrix, 1: fused persistent-wave launch,

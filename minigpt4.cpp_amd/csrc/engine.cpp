@@ -146,6 +146,10 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     set_ri_cus(prop.multiProcessorCount);
     // 0: the Q-Former's image-independent head is recomputed per encode (round-4 form, A/B)
     if (const char *e = getenv("MINIGPT4_QF_FOLD")) qf_fold_ = atoi(e) != 0;
+    // query tiles per workgroup of the ViT / Q-Former attention (k_attn_vit; unset / 0 = chosen per launch; 1 = the rounds 2-5 form; A/B, bit-identical)
+    if (const char *e = getenv("MINIGPT4_ATTN_QT")) set_attn_vit_qt(atoi(e));
+    // 0: split-K GEMM slices in grid.z, every XCD walks every slice (rounds 3-5; A/B, bit-identical)
+    if (const char *e = getenv("MINIGPT4_SPLITK_XCD")) set_gemm_splitk_xcd(atoi(e));
     if (const char *e = getenv("MINIGPT4_KV_HOIST")) kv_hoist_ = atoi(e) != 0;     // 0: one K | V projection GEMM per cross-attention layer (round-4 form, A/B)
     set_matvec_tuning(0, 0, prop.multiProcessorCount);
     if (const char *ns = getenv("MINIGPT4_CONVERSATIONS")) conv_.assign((size_t)std::max(1, std::min(MAX_CONVERSATIONS, atoi(ns))), Conversation{});

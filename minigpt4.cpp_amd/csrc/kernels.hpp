@@ -59,6 +59,7 @@ int probe_tn_mfma(int rows, int cols, int TN, int iters, int n_sets, int check, 
 void set_mmq3_waves(int nw);                          // 8 (default): 128-row workgroups, one per CU; 4: 64-row workgroups, two per CU (slower)
 void set_mmq3_tuning(int cus, int ks);                // CU count (<= 0: leave), forced K split (0 = the launcher's choice, < 0: leave)
 void set_mmq2_tuning(int tt, int fill_pct, int ks);   // experiment knobs, 0 = the launcher's choice, < 0 = leave as it is (read from the environment once, by Engine::init)
+void set_gemm_splitk_xcd(int on);   // 1 (default): a split-K GEMM's work list [slice][tile] is dealt to the XCDs in contiguous ranges; 0: slices in grid.z (rounds 3-5, A/B)
 void set_gemm_tuning(int big_min_m, int f16_ks, int arm = -1, int sk_arm = -1);      // smallest M of the 128x128 GEMM (< 0: leave), forced K split of the F16 set launches (0 = choose)
 void set_f16_gemm(int v);                             // F16 language-model weights at >= 16 rows on the MFMA GEMM (default 1)
 void launch_slab_reduce(const float *slabs, int n_slabs, long long slab_stride, const float *residual, float *y, size_t n, hipStream_t s);   // y = (residual +) sum_z slab_z, fixed order
@@ -189,6 +190,7 @@ void launch_splitk_reduce_ln(const float *slabs, int n_slabs, size_t slab_stride
 // f32 attention: q[nq][ldq], k/v[nk][ldk]; per head h the slice [h*hd, (h+1)*hd).  q_prescale != 0: q *= q_prescale first (ViT);
 // score_div != 0: scores /= score_div (BERT).  Output fp32 (nullable) / fp16 (nullable) [nq][ldo].
 // batch > 1: image z uses rows [z * nq, (z + 1) * nq) of q / out and rows [z * nk, (z + 1) * nk) of k / v.
+void set_attn_vit_qt(int qt);   // query tiles per workgroup of k_attn_vit (0 = the launcher's choice); experiments / A-B
 void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale,
                      float score_div, const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s, int batch = 1);
 // image CHW f32 [3][224][224] -> fp16 patches [256][ldp] (k = c*196 + kh*14 + kw, zero padded to ldp)

@@ -219,7 +219,9 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_mmq2_q45k(const Mmq2Args a, con
         {
             const int sbn = min(sb + 1, sb1 - 1);
             fetch(sbn, raw);
+#ifndef MG4_MMQ2_NOSTAGE   // diagnostic build only (make nostage; tools/mmq2_bench.py): what the launch would cost if the activation staging were free -- results are wrong
             mmq2_stage_load<TT, WPB>(A, K, NSB, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane, n_q8);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- token tiles.  Within a tile the five MFMA pairs (4 sub-block pairs + the min term) run one step ahead of the integer scale multiply-adds that
@@ -381,7 +383,9 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_mmq2_q6k(const Mmq2Args a, cons
         {
             const int sbn = min(sb + 1, sb1 - 1);
             fetch(sbn, raw);
+#ifndef MG4_MMQ2_NOSTAGE   // diagnostic build only (make nostage; tools/mmq2_bench.py): what the launch would cost if the activation staging were free -- results are wrong
             mmq2_stage_load<TT, WPB>(A, K, NSB, N, t0, sbn, smem_mmq2 + (buf ^ 1) * S::BYTES, wv, lane, n_q8);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         // eight half-pair steps per tile (low / high nibble part of pair p), MFMAs one step ahead of the scale multiply-adds

@@ -457,6 +457,32 @@ int minigpt4_amd_bench_attn_f32(int heads, int hd, int nq, int nk, int iters, fl
         return 0;
     });
 }
+// the same with `batch` images per launch, computed exponentials (what the engine's fast mode runs) and a forced number of query tiles per workgroup (0 = the launcher's choice)
+int minigpt4_amd_bench_attn_f32_b(int heads, int hd, int nq, int nk, int batch, int qt, int iters, float *us_per_launch) {
+    if (heads < 1 || (hd != 88 && hd != 64) || nq < 1 || nk < 1 || nk > 320 || iters < 1 || batch < 1 || batch > 16 || nq != nk) return 1;
+    if (device_count_noexcept() <= 0) { set_last_error("no HIP device"); return 2; }
+    return guarded(3, [&]() -> int {
+        const int D = heads * hd;
+        DevBuf dq((size_t)batch * nq * 3 * D * 4), douth((size_t)batch * nq * D * 2);
+        { std::vector<float> h((size_t)batch * nq * 3 * D); for (size_t i = 0; i < h.size(); i++) h[i] = (float)((int)(i * 2654435761u % 2001u) - 1000) / 1000.0f; HIP_CHECK(hipMemcpy(dq.p, h.data(), h.size() * 4, hipMemcpyHostToDevice)); }
+        Tables tb;                                                          // exp == null: computed exponentials
+        const float scale = 1.0f / sqrtf((float)hd);
+        struct QtScope { QtScope(int q) { set_attn_vit_qt(q); } ~QtScope() { set_attn_vit_qt(0); } } scope(qt);
+        auto run = [&]() { launch_attn_f32(dq.as<float>(), 3 * D, dq.as<float>() + D, dq.as<float>() + 2 * D, 3 * D, nq, nk, heads, hd, scale, 0.0f, tb, nullptr, douth.as<__half>(), D, nullptr, batch); };
+        for (int i = 0; i < 3; i++) run();
+        HIP_CHECK(hipDeviceSynchronize());
+        hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+        HIP_CHECK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; i++) run();
+        HIP_CHECK(hipEventRecord(b, nullptr));
+        HIP_CHECK(hipDeviceSynchronize());
+        float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        HIP_IGNORE(hipEventDestroy(a)); HIP_IGNORE(hipEventDestroy(b));
+        if (us_per_launch) *us_per_launch = ms * 1e3f / (float)iters;
+        return 0;
+    });
+}
+void minigpt4_amd_test_set_attn_qt(int qt) { set_attn_vit_qt(qt); }
 // The F16 feed-forward pair launch (launch_gemm_f16_silu_pair): x [N][n_in] fp32 (rounded to fp16 as the engine's row preparation does), w = w1 then w3, each [n_out][n_in]
 // fp16; out_h [N][n_out] = fp16(silu_table(w1 x) * (w3 x)) as uint16 bit patterns, out_f (optional) the fp32 product before the rounding
 int minigpt4_amd_test_f16_silu_pair(const float *x, const void *w_f16, int64_t N, int64_t n_in, int64_t n_out, unsigned short *out_h, float *out_f) {
@@ -510,6 +536,7 @@ int minigpt4_amd_bench_attn_prefill(int n_head, int hd, int N, int n_past, int i
 }
 int minigpt4_amd_timeline_attn(unsigned long long *out, int max_workgroups) { return (out && max_workgroups > 0) ? read_attn_timeline(out, max_workgroups) : -1; }
 void minigpt4_amd_test_set_gemm_arm(int arm, int sk_arm) { set_gemm_tuning(-1, 0, arm, sk_arm); }
+void minigpt4_amd_test_set_splitk_xcd(int on) { set_gemm_splitk_xcd(on); }
 int minigpt4_amd_timeline_vision(unsigned long long *out, int max_workgroups) { return (out && max_workgroups > 0) ? read_vision_timeline(out, max_workgroups) : -1; }
 
 // Micro-benchmark of the decode mat-vec kernels on synthetic planes (random quant bytes, sane fp16 scales).  `n_sets` distinct weight sets

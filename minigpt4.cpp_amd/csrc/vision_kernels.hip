@@ -38,6 +38,29 @@ int read_vision_timeline(unsigned long long *out, int max_workgroups) {
 #endif
 }
 
+// Workgroup -> (tile, K slice).  Blocks are dealt round-robin to the 8 XCDs (XCD = blockIdx.x & 7), each with its own 4 MB L2.  The work list of a launch is
+// [K slice][column tile][row tile] (row tile fastest) and XCD x owns the CONTIGUOUS range [x * per, (x + 1) * per) of it, per = ceil(slices * tiles / 8): the row tiles
+// that share a weight tile sit on one XCD, every XCD gets the same number of workgroups +- 1, and -- round 6 -- an XCD walks ONE K slice (or two neighbouring ones), not
+// all of them.  Rounds 3-5 put the slices in grid.z with the tile list dealt to the XCDs per slice, so every XCD walked every K slice and therefore fetched ALL of A:
+// for the ViT's fc2 (K = 6144, 4 slices) 8 x 3.2 MB at one image and 8 x 12.6 MB (three times an L2) at four -- FETCH_SIZE 47 MB for 20 MB of operands at B = 1,
+// 180 MB for 30 MB at B = 4 (profiles/r06_encode_kernel_table_b1.txt / _b4.txt).  xs = 0 keeps that form (A/B: MINIGPT4_SPLITK_XCD=0).  Which workgroup multiplies a
+// (tile, slice) never changes what is computed (slab z = columns [z * k_per_slice, ...)), so results are bit-identical under both mappings.
+static int g_splitk_xcd = 1;                       // 0: split-K slices in grid.z as in rounds 3-5 (read once by Engine::init)
+void set_gemm_splitk_xcd(int on) { g_splitk_xcd = on != 0; }
+__device__ __forceinline__ bool gemm_tile_of_block(int tile_n, int xs, int &tile_id, int &z) {
+    const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+    if (xs > 1) {
+        const int total = xs * tile_n, per = (total + 7) >> 3, w = xcd * per + slot;
+        z = w / tile_n; tile_id = w - z * tile_n;
+        return slot < per && w < total;
+    }
+    z = (int)blockIdx.z;
+    const int chunk = (tile_n + 7) >> 3;
+    tile_id = xcd * chunk + slot;
+    return slot < chunk && tile_id < tile_n;
+}
+static inline bool splitk_on_xcds(int slices) { return g_splitk_xcd && slices > 1; }
+static inline unsigned gemm_grid_x(int tile_n, int slices, bool on_xcds) { return (unsigned)(((on_xcds ? slices : 1) * tile_n + 7) / 8 * 8); }
 // =====================================================================================================================
 // C[M][N] = A[M][K] . W[N][K]^T  (+bias, GELU, +residual).  64x64 tile per 256-thread workgroup, 4 waves of 32x32,
 // BK = 32 staged through LDS (80-byte padded rows: conflict-free ds_read_b128), register prefetch of the next tile.
@@ -53,7 +76,7 @@ int read_vision_timeline(unsigned long long *out, int max_workgroups) {
 template <int BK, int GB_M, int BN, int TM, int TN, bool GELU, bool RES>
 __global__ __launch_bounds__(GB_M / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm_f16(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K,
                                                   const float *__restrict__ bias, const float *residual, const Tables tb,
-                                                  float *out, __half *__restrict__ out_h, int ldo, int k_per_slice, size_t slab_stride) {
+                                                  float *out, __half *__restrict__ out_h, int ldo, int k_per_slice, size_t slab_stride, int xs) {
     constexpr int LD = BK + 8;                 // +16 bytes per row: conflict-free ds_read_b128 for BK = 32/64/128/256
     constexpr int CPR = BK / 8;                // 16-byte chunks per row
     constexpr int WNN = BN / (32 * TN), NT = GB_M / (32 * TM) * WNN * 64;
@@ -67,16 +90,17 @@ __global__ __launch_bounds__(GB_M / (32 * TM) * (BN / (32 * TN)) * 64) void k_ge
     // without) AND every XCD gets the same number of tiles +- 1.  (Until round 3 XCD x owned the column tiles x, x + 8, ...: 33 column tiles x 7 row tiles put 35
     // workgroups on XCD 0's 32 CUs and 28 on the others -- 35 us instead of ~20 for the 3-image qkv launch.)
     const int ntx = (N + BN - 1) / BN, rt = (M + GB_M - 1) / GB_M;
-    const int tile_n = ntx * rt, tile_chunk = (tile_n + 7) >> 3, tile_slot = blockIdx.x >> 3, tile_id = (int)(blockIdx.x & 7) * tile_chunk + tile_slot;   // XCD-aware, balanced (below)
+    int tile_id, kz;
+    const bool owns = gemm_tile_of_block(ntx * rt, xs, tile_id, kz);                 // XCD-aware, balanced (above)
     const int bx = tile_id / rt, by = tile_id - bx * rt;
     MG4_TLV(0);
-    if (tile_slot >= tile_chunk || tile_id >= tile_n) return;
+    if (!owns) return;
     const int m0 = by * GB_M, n0 = bx * BN;
     const int wm = wave / WNN, wn = wave % WNN;
     if (k_per_slice > 0) {   // split-K: slice z multiplies columns [z * k_per_slice, ...) and writes its raw fp32 partial sums into slab z
-        const int k0 = blockIdx.z * k_per_slice;
+        const int k0 = kz * k_per_slice;
         A += k0; W += k0; K = min(K - k0, k_per_slice);
-        out += (size_t)blockIdx.z * slab_stride;
+        out += (size_t)kz * slab_stride;
     }
     const int nk = (K + BK - 1) / BK;
     const __amdgpu_buffer_rsrc_t ab = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half *>(A), 0, (int)(((size_t)(M - 1) * lda + K) * 2), 0x00020000);
@@ -195,17 +219,19 @@ static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, in
                           float *out, __half *out_h, int ldo, hipStream_t s, int slices = 1, size_t slab_stride = 0) {
     const int k_per_slice = slices > 1 ? ((K + BK - 1) / BK + slices - 1) / slices * BK : 0;
     const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
-    dim3 grid((unsigned)((ntx * rt + 7) / 8 * 8), 1, (unsigned)slices), block(BM / (32 * TM) * (BN / (32 * TN)) * 64);
+    const bool sx = splitk_on_xcds(slices);
+    const int xs = sx ? slices : 0;
+    dim3 grid(gemm_grid_x(ntx * rt, slices, sx), 1, sx ? 1u : (unsigned)slices), block(BM / (32 * TM) * (BN / (32 * TN)) * 64);
     const size_t lds = (size_t)2 * (BM + BN) * (BK + 8) * 2;
     static bool attr = false;
     if (!attr) { HIP_IGNORE(lds_optin_max(&k_gemm_f16<BK, BM, BN, TM, TN, true, true>));
         HIP_IGNORE(lds_optin_max(&k_gemm_f16<BK, BM, BN, TM, TN, true, false>));
         HIP_IGNORE(lds_optin_max(&k_gemm_f16<BK, BM, BN, TM, TN, false, true>));
         HIP_IGNORE(lds_optin_max(&k_gemm_f16<BK, BM, BN, TM, TN, false, false>)); attr = true; }
-    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
-    else if (gelu) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
-    else if (residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
-    else hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride);
+    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride, xs);
+    else if (gelu) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride, xs);
+    else if (residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride, xs);
+    else hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride, xs);
 }
 // =====================================================================================================================
 // LDS-DMA ring form of the small-M GEMM (round 3).  The timeline of k_gemm_f16 put the k loop at 0.5 us per 64x64x128 step against 0.21 us of MFMA: the
@@ -220,7 +246,7 @@ static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, in
 typedef __attribute__((address_space(3))) void *g_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *g_glb_ptr_t;
 // several equally spaced, equally shaped weight matrices in one launch (column tile -> matrix), and / or a K range split over grid.z with one fp32 slab per slice
-struct GemmSet { int n_per_mat; long long w_mat_stride, out_mat_stride; int k_per_slice; long long slab_stride; };   // all zero: one matrix, whole K
+struct GemmSet { int n_per_mat; long long w_mat_stride, out_mat_stride; int k_per_slice; long long slab_stride; int xs; };   // all zero: one matrix, whole K; xs: gemm_tile_of_block
 // PAIR (TN = 2, no GELU / residual): the feed-forward pair of an F16 language model in one tile -- the BN tile columns are 32-column blocks taken alternately from W
 // (w1) and W + gs.w_mat_stride (w3), rows n0 .. of both, so a wave's two column tiles hold (w1 x)[r][c] and (w3 x)[r][c] for the SAME (r, c) and the epilogue stores
 // fp16(silu_table(w1 x) * (w3 x)) -- the row w2 multiplies -- instead of the two fp32 products (56 MB written and read back per 512-row layer, and a launch).
@@ -238,10 +264,11 @@ __global__ __launch_bounds__(BM / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm
 
     constexpr int BNO = PAIR ? BN / 2 : BN;                         // output columns per tile
     const int ntx = (N + BNO - 1) / BNO, rt = (M + BM - 1) / BM;
-    const int tile_n = ntx * rt, tile_chunk = (tile_n + 7) >> 3, tile_slot = blockIdx.x >> 3, tile_id = (int)(blockIdx.x & 7) * tile_chunk + tile_slot;   // XCD-aware, balanced (below)
+    int tile_id, kz;
+    const bool owns = gemm_tile_of_block(ntx * rt, gs.xs, tile_id, kz);              // XCD-aware, balanced
     const int bx = tile_id / rt, by = tile_id - bx * rt;
     MG4_TLV(0);
-    if (tile_slot >= tile_chunk || tile_id >= tile_n) return;
+    if (!owns) return;
     const int m0 = by * BM;
     int n0 = bx * BNO;
     const int wm = wave / WNN, wn = wave % WNN;
@@ -253,9 +280,9 @@ __global__ __launch_bounds__(BM / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm
         if (RES) residual += (size_t)mat * gs.out_mat_stride;
     }
     if (gs.k_per_slice > 0) {
-        const int k0 = blockIdx.z * gs.k_per_slice;
+        const int k0 = kz * gs.k_per_slice;
         A += k0; W += k0; K = min(K - k0, gs.k_per_slice);
-        out += (size_t)blockIdx.z * gs.slab_stride;
+        out += (size_t)kz * gs.slab_stride;
     }
     const int nk = K > 0 ? K / (64 * KT) : 0;                       // the launcher guarantees K % (64 * KT) == 0
     // epilogue operands first: an ordinary load whose result is used while DMAs are in flight would make hipcc wait for vmcnt(0)
@@ -389,13 +416,15 @@ __global__ __launch_bounds__(BM / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm
 }
 template <int BM, int BN, int TM, int TN, int KT, int S>
 static bool launch_gemm_dma_t(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
-                              float *out, __half *out_h, int ldo, hipStream_t s, int slices = 1, size_t slab_stride = 0, GemmSet gs = GemmSet{0, 0, 0, 0, 0}) {
+                              float *out, __half *out_h, int ldo, hipStream_t s, int slices = 1, size_t slab_stride = 0, GemmSet gs = GemmSet{0, 0, 0, 0, 0, 0}) {
     constexpr int BKS = 64 * KT;
     if (K % BKS || lda % 8 || ldw % 8 || (reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) % 16 || (gs.n_per_mat > 0 && gs.n_per_mat % BN)) return false;
     gs.k_per_slice = slices > 1 ? (K / BKS + slices - 1) / slices * BKS : 0;
     gs.slab_stride = (long long)slab_stride;
     const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
-    dim3 grid((unsigned)((ntx * rt + 7) / 8 * 8), 1, (unsigned)slices), block(BM / (32 * TM) * (BN / (32 * TN)) * 64);
+    const bool sx = splitk_on_xcds(slices) && gs.n_per_mat == 0;
+    gs.xs = sx ? slices : 0;
+    dim3 grid(gemm_grid_x(ntx * rt, slices, sx), 1, sx ? 1u : (unsigned)slices), block(BM / (32 * TM) * (BN / (32 * TN)) * 64);
     const size_t lds = (size_t)S * KT * (BM + BN) * 128;
     static bool attr = false;
     if (!attr) { HIP_IGNORE(lds_optin_max(&k_gemm_dma<BM, BN, TM, TN, KT, S, true, true>));
@@ -411,7 +440,7 @@ static bool launch_gemm_dma_t(const __half *A, int lda, const __half *W, int ldw
 template <int BM, int BN, int TM, int KT, int S>
 static bool launch_gemm_dma_pair_t(const __half *A, int lda, const __half *W1, long long w3_minus_w1, int ldw, int M, int N, int K, const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s) {
     if (K % (64 * KT) || lda % 8 || ldw % 8 || N % 32 || (reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W1)) % 16 || w3_minus_w1 % 8) return false;
-    GemmSet gs{0, w3_minus_w1, 0, 0, 0};
+    GemmSet gs{0, w3_minus_w1, 0, 0, 0, 0};
     const int ntx = (N + BN / 2 - 1) / (BN / 2), rt = (M + BM - 1) / BM;
     dim3 grid((unsigned)((ntx * rt + 7) / 8 * 8), 1, 1), block(BM / (32 * TM) * (BN / 64) * 64);
     const size_t lds = (size_t)S * KT * (BM + BN) * 128;
@@ -810,6 +839,15 @@ int gemm_split_slices(int K, int want) { const int nk = (K + 127) / 128; int s =
 void launch_gemm_f16_splitk(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, int slices, float *slabs, size_t slab_stride, int ldo, hipStream_t s) {
     Tables tb{};
     if (g_gemm_sk_arm && launch_gemm_f16_splitk_arm(g_gemm_sk_arm, A, lda, W, ldw, M, N, K, slices, slabs, slab_stride, ldo, s)) return;
+    // Several images per pass (round 6): the LDS-DMA ring tiles of the language model's prompt GEMMs -- 256x128 from three images on, 128x128 at two -- instead of 64x64
+    // tiles: the ViT's fc2 at four images 43 -> 30 us (profiles/r06_gemm_batched_tile_sweep.log: with the reduce 55.5 -> 42.4 us at M = 1028, 46.2 -> 40.2 at 771,
+    // 36.4 -> 30.2 at 514, 109.7 -> 75.4 at 2056).  Only when both forms cut K at the same columns (the 64x64 form counts slices in 128-wide k tiles, the ring in 64-wide
+    // ones): the slice boundaries fix the order in which an output's k ranges are added, and image b of a batch must equal the same image encoded alone bit for bit.
+    const int kps128 = slices > 1 ? ((K + 127) / 128 + slices - 1) / slices * 128 : 0, kps64 = slices > 1 && K % 64 == 0 ? (K / 64 + slices - 1) / slices * 64 : -1;
+    if (g_gemm_arm == 0 && kps128 == kps64) {
+        if (M >= 640 && launch_gemm_dma_t<256, 128, 2, 2, 1, 3>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride)) return;
+        if (M >= 384 && launch_gemm_dma_t<128, 128, 2, 2, 1, 3>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride)) return;
+    }
     launch_gemm_t<128, 64, 64>(A, lda, W, ldw, M, N, K, nullptr, nullptr, false, tb, slabs, nullptr, ldo, s, slices, slab_stride);
 }
 bool launch_gemm_f16_splitk_arm(int arm, const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, int slices, float *slabs, size_t slab_stride, int ldo, hipStream_t s) {
@@ -834,12 +872,14 @@ bool launch_gemm_f16_splitk_arm(int arm, const __half *A, int lda, const __half 
 }
 // x = residual + (bias + sum_z slab_z)   [x_out, fp32];   then, when ln_w is given, ggml_norm(x) * ln_w + ln_b -> ln_out (fp32) / ln_out_h (fp16).
 // One workgroup per row, n <= 2048.
+// MAXZ >= n_slabs, MAXE >= ceil(n / 256) (round 6: instantiated per size class -- the one-size form issued 12 x 8 + 40 loads per thread whatever the row needed, 96 of
+// the 136 redundant for the ViT's 4 slabs of 1408, and the address path of four workgroups per CU made the 4-image launch 12.9 us; same additions in the same order)
+template <int MAXZ, int MAXE>
 __global__ __launch_bounds__(256) void k_splitk_reduce_ln(const float *__restrict__ slabs, int n_slabs, size_t slab_stride, const float *__restrict__ bias, const float *residual, int n,
                                                           float *x_out, const float *__restrict__ ln_w, const float *__restrict__ ln_b, float *__restrict__ ln_out,
                                                           __half *__restrict__ ln_out_h) {
     __shared__ double red[4];
     const size_t row = blockIdx.x;
-    constexpr int MAXE = 8, MAXZ = 12;            // n <= 2048, slabs <= Engine::SPLITK_MAX
     float xv[MAXE];
     double s = 0.0;
     // every slab value of the row is requested before the first one is used (clamped indices, no load under a branch: the round-1 form walked the slabs with one
@@ -893,16 +933,20 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_ln(const float *__restric
 }
 void launch_splitk_reduce_ln(const float *slabs, int n_slabs, size_t slab_stride, const float *bias, const float *residual, int rows, int n, float *x_out, const float *ln_w,
                              const float *ln_b, float *ln_out, __half *ln_out_h, hipStream_t s) {
-    if (n > 2048) throw HipError{hipErrorInvalidValue, "splitk reduce: row longer than 2048", __FILE__, __LINE__};
-    hipLaunchKernelGGL(k_splitk_reduce_ln, dim3((unsigned)rows), dim3(256), 0, s, slabs, n_slabs, slab_stride, bias, residual, n, x_out, ln_w, ln_b, ln_out, ln_out_h);
+    if (n > 2048 || n_slabs < 1 || n_slabs > 12) throw HipError{hipErrorInvalidValue, "splitk reduce: row longer than 2048 or more than 12 slabs", __FILE__, __LINE__};
+#define MG4_RLN(Z_, E_) hipLaunchKernelGGL((k_splitk_reduce_ln<Z_, E_>), dim3((unsigned)rows), dim3(256), 0, s, slabs, n_slabs, slab_stride, bias, residual, n, x_out, ln_w, ln_b, ln_out, ln_out_h)
+#define MG4_RLN_E(Z_) do { if (n <= 768) MG4_RLN(Z_, 3); else if (n <= 1536) MG4_RLN(Z_, 6); else MG4_RLN(Z_, 8); } while (0)
+    if (n_slabs <= 2) MG4_RLN_E(2); else if (n_slabs <= 4) MG4_RLN_E(4); else if (n_slabs <= 8) MG4_RLN_E(8); else MG4_RLN_E(12);
+#undef MG4_RLN_E
+#undef MG4_RLN
 }
 
+template <int MAXE>                               // >= ceil(n / 256)
 __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b, int n, float *__restrict__ out,
                                                    __half *__restrict__ out_h, int seq) {
     __shared__ double red[4];
     const size_t row = blockIdx.x;
     const float *xr = x + row * n;
-    constexpr int MAXE = 8;                       // n <= 2048
     float xv[MAXE];
     double s = 0.0;
 #pragma unroll
@@ -943,7 +987,10 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
 }
 void launch_layernorm(const float *x, const float *w, const float *b, int rows, int n, float *out, __half *out_h, hipStream_t s, bool sequential_sums) {
     if (n > 2048) throw HipError{hipErrorInvalidValue, "layernorm: row longer than 2048", __FILE__, __LINE__};
-    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)rows), dim3(256), 0, s, x, w, b, n, out, out_h, sequential_sums ? 1 : 0);
+    const int seq = sequential_sums ? 1 : 0;
+    if (n <= 768) hipLaunchKernelGGL((k_layernorm<3>), dim3((unsigned)rows), dim3(256), 0, s, x, w, b, n, out, out_h, seq);
+    else if (n <= 1536) hipLaunchKernelGGL((k_layernorm<6>), dim3((unsigned)rows), dim3(256), 0, s, x, w, b, n, out, out_h, seq);
+    else hipLaunchKernelGGL((k_layernorm<8>), dim3((unsigned)rows), dim3(256), 0, s, x, w, b, n, out, out_h, seq);
 }
 // MINIGPT4_PARITY attention of the vision tower / Q-Former: oracle/refcpu.c attention_f32 with every fp32 chain in its order -- thread = one key for the scores
 // (q * prescale, sequential fma over the head dimension, / score_div), max, fp16-table exp, exact double sum, p = e * (1 / sum) in fp32 (no fp16 rounding here: ggml's
@@ -1008,62 +1055,16 @@ __device__ __forceinline__ float exp_c16(float x) { return __half2float(f2h_rn(_
 //     Q / K loads); anything outside (NaN) falls back to the global table, so the values are the same ones;
 //   * the 4 waves' partial O^T tiles are added in wave order through LDS (deterministic) and stored 4 dims at a time.
 // ---------------------------------------------------------------------------------------------------------------------
+// Round 6: a workgroup can serve `qt` CONSECUTIVE 16-query tiles of its head, one after the other, with the K and V fragments it loaded once (MULTI; they stay in
+// registers, the next tile's Q rows are requested before the current tile's softmax).  The arithmetic per query does not depend on qt (same key split over the waves, same
+// exchange order), so every qt gives bit-identical rows; what changes is the traffic -- each workgroup pulls its head's K and V (180 KB at the ViT's shapes) through its
+// CU's load path, which sustains only 50-70 GB/s, so a layer's 272 workgroups move 50 MB per image for 1.1 MB of distinct K / V -- and the number of workgroup rounds.
+// Measured: no gain over qt = 1 at any batch size (launch_attn_f32), which therefore stays the default.
 template <int HD, int TPW>
-__global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, int ldq, const float *__restrict__ k, const float *__restrict__ v, int ldk, int nq, int nk,
-                                                  float q_prescale, float score_div, const Tables tb, float *__restrict__ out, __half *__restrict__ out_h, int ldo) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int DT = (HD + 15) / 16, KS4 = 4 * DT;
-    static_assert(HD % 4 == 0, "16-byte row pieces");
-    { const size_t z = blockIdx.z; q += z * nq * ldq; k += z * nk * ldk; v += z * nk * ldk; if (out) out += z * nq * ldo; if (out_h) out_h += z * nq * ldo; }
-    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
-    float *red_m = reinterpret_cast<float *>(smem);                         // [4][16]
-    double *red_s = reinterpret_cast<double *>(smem + 256);                 // [4][16]
-    float *part = reinterpret_cast<float *>(smem + 768);                    // [4][DT * 4][64]
-    __half *etab = reinterpret_cast<__half *>(smem + 768 + 4 * DT * 4 * 64 * 4);
-    const unsigned NT = (unsigned)tb.exp_neg_n;                             // multiple of 2048
-    // tb.exp == null (fast mode, round 5): the exponentials are computed -- fp16(__expf(fp16 argument)), the table's value up to its last fp16 bit -- and no table travels: the
-    // 40 KB LDS-DMA per workgroup was the first thing in every wave's memory queue (~1.6 us of a CU's DMA rate, two workgroups per CU on 16 of the ViT's CUs), in front of the
-    // Q / K requests.  Parity mode (k_attn_vref) and the generic path keep the table.
-    const bool computed = tb.exp == nullptr;                                // workgroup-uniform
-    MG4_TLA(0);
-    if (!computed) for (unsigned c0 = 0; c0 < NT; c0 += 2048)
-        __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(tb.exp + 0x8000 + c0 + tid * 8), (g_lds_ptr_t)(reinterpret_cast<unsigned char *>(etab) + (c0 + wave * 512) * 2), 16, 0, 0);
-    // (Round 3 tried 16 x 16 = 256 workgroups for the ViT's 257 queries -- the last tile's workgroup serving the left-over query in a second softmax + P.V pass over the
-    // K / V fragments it holds: 23.9 -> 20.9 us back to back, but 18.8 -> 19.9 us inside the encoder, where the 16 extra workgroups of the 272 overlap the next launch's
-    // ramp.  Not kept; profiles/r03_experiments_not_adopted.log.)
-    const int q0 = blockIdx.y * 16;
-    // Q / K fragments: instruction u of a 16-row tile reads, per row, the 64 contiguous bytes of dims 16 u .. 16 u + 15 (lane (row, g): 16 bytes = dims 16 u + 4 g + e),
-    // i.e. 16 whole sectors per wave instruction.  (First version: lane (row, g) read its own 88-byte quarter row 8 bytes at a time -- 64 different sectors per
-    // instruction, and the address path, not the 90 KB of K, set the kernel's time.)  MFMA step (u, e) therefore reduces over dims {16 u + 4 g + e : g}; dims past HD
-    // (HD = 88: u = 5, g >= 2) contribute zeros.
-    float qf[KS4];
-    {
-        const float *qp = q + (size_t)min(q0 + j, nq - 1) * ldq + h * HD;
-#pragma unroll
-        for (int u = 0; u < DT; u++) {
-            const int d0 = 16 * u + 4 * g;
-            const float4 t = *reinterpret_cast<const float4 *>(qp + min(d0, HD - 4));
-            const bool ok = d0 < HD;
-            qf[4 * u] = ok ? t.x : 0.0f; qf[4 * u + 1] = ok ? t.y : 0.0f; qf[4 * u + 2] = ok ? t.z : 0.0f; qf[4 * u + 3] = ok ? t.w : 0.0f;
-        }
-    }
-    float kf[TPW][KS4];
-#pragma unroll
-    for (int t = 0; t < TPW; t++) {
-        const float *kp = k + (size_t)min((wave + 4 * t) * 16 + j, nk - 1) * ldk + h * HD;
-#pragma unroll
-        for (int u = 0; u < DT; u++) {
-            const float4 x = *reinterpret_cast<const float4 *>(kp + min(16 * u + 4 * g, HD - 4));
-            kf[t][4 * u] = x.x; kf[t][4 * u + 1] = x.y; kf[t][4 * u + 2] = x.z; kf[t][4 * u + 3] = x.w;     // past HD: finite duplicates, multiplied by the zeros in qf
-        }
-    }
-    MG4_TLA(1);
-    if (q_prescale != 0.0f) {
-#pragma unroll
-        for (int u = 0; u < KS4; u++) qf[u] *= q_prescale;
-    }
-    float sc[TPW][4];
-    float mx = -INFINITY;
+__device__ __forceinline__ void attn_vit_scores(const float (&kf)[TPW][4 * ((HD + 15) / 16)], const float (&qf)[4 * ((HD + 15) / 16)], int wave, int g, int nk, float score_div,
+                                                float (&sc)[TPW][4], float &mx) {
+    constexpr int KS4 = 4 * ((HD + 15) / 16);
+    mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < TPW; t++) {
         float4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1077,10 +1078,75 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
             sc[t][r] = sv; mx = fmaxf(mx, sv);
         }
     }
+}
+template <int HD>
+__device__ __forceinline__ void attn_vit_load_q(const float *__restrict__ q, int ldq, int row, int h, int g, float q_prescale, float (&qf)[4 * ((HD + 15) / 16)]) {
+    constexpr int DT = (HD + 15) / 16;
+    const float *qp = q + (size_t)row * ldq + h * HD;
+#pragma unroll
+    for (int u = 0; u < DT; u++) {
+        const int d0 = 16 * u + 4 * g;
+        const float4 t = *reinterpret_cast<const float4 *>(qp + min(d0, HD - 4));
+        const bool ok = d0 < HD;
+        qf[4 * u] = ok ? t.x : 0.0f; qf[4 * u + 1] = ok ? t.y : 0.0f; qf[4 * u + 2] = ok ? t.z : 0.0f; qf[4 * u + 3] = ok ? t.w : 0.0f;
+    }
+    if (q_prescale != 0.0f) {
+#pragma unroll
+        for (int u = 0; u < 4 * DT; u++) qf[u] *= q_prescale;
+    }
+}
+// MULTI = false is the single-tile kernel of rounds 2-5 (the loop folds away: 190 registers, two workgroups per CU); MULTI = true keeps K, V and the next tile's Q rows
+// live across the loop (one workgroup per CU).  COMPUTED: the exponentials are computed instead of gathered from the table's LDS copy (fast mode, round 5).
+template <int HD, int TPW, bool MULTI, bool COMPUTED>
+__global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, int ldq, const float *__restrict__ k, const float *__restrict__ v, int ldk, int nq, int nk,
+                                                  float q_prescale, float score_div, const Tables tb, float *__restrict__ out, __half *__restrict__ out_h, int ldo, int qt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int DT = (HD + 15) / 16, KS4 = 4 * DT;
+    static_assert(HD % 4 == 0, "16-byte row pieces");
+    { const size_t z = blockIdx.z; q += z * nq * ldq; k += z * nk * ldk; v += z * nk * ldk; if (out) out += z * nq * ldo; if (out_h) out_h += z * nq * ldo; }
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+    float *red_m = reinterpret_cast<float *>(smem);                         // [4][16]
+    double *red_s = reinterpret_cast<double *>(smem + 256);                 // [4][16]
+    float *part = reinterpret_cast<float *>(smem + 768);                    // [4][DT * 4][64]
+    __half *etab = reinterpret_cast<__half *>(smem + 768 + 4 * DT * 4 * 64 * 4);
+    const unsigned NT = (unsigned)tb.exp_neg_n;                             // multiple of 2048
+    // tb.exp == null (fast mode, round 5): the exponentials are computed -- fp16(__expf(fp16 argument)), the table's value up to its last fp16 bit -- and no table travels: the
+    // 40 KB LDS-DMA per workgroup was the first thing in every wave's memory queue (~1.6 us of a CU's DMA rate, two workgroups per CU on 16 of the ViT's CUs), in front of the
+    // Q / K requests.  Parity mode (k_attn_vref) and the generic path keep the table.
+    constexpr bool computed = COMPUTED;                                     // (the launcher instantiates by tb.exp == nullptr)
+    MG4_TLA(0);
+    if (!computed) for (unsigned c0 = 0; c0 < NT; c0 += 2048)
+        __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(tb.exp + 0x8000 + c0 + tid * 8), (g_lds_ptr_t)(reinterpret_cast<unsigned char *>(etab) + (c0 + wave * 512) * 2), 16, 0, 0);
+    // (Round 3 tried 16 x 16 = 256 workgroups for the ViT's 257 queries -- the last tile's workgroup serving the left-over query in a second softmax + P.V pass over the
+    // K / V fragments it holds: 23.9 -> 20.9 us back to back, but 18.8 -> 19.9 us inside the encoder, where the 16 extra workgroups of the 272 overlap the next launch's
+    // ramp.  Not kept; profiles/r03_experiments_not_adopted.log.)
+    if (!MULTI) qt = 1;
+    int q0 = (int)blockIdx.y * qt * 16;
+    const int q_end = min(nq, q0 + qt * 16);
+    // Q / K fragments: instruction u of a 16-row tile reads, per row, the 64 contiguous bytes of dims 16 u .. 16 u + 15 (lane (row, g): 16 bytes = dims 16 u + 4 g + e),
+    // i.e. 16 whole sectors per wave instruction.  (First version: lane (row, g) read its own 88-byte quarter row 8 bytes at a time -- 64 different sectors per
+    // instruction, and the address path, not the 90 KB of K, set the kernel's time.)  MFMA step (u, e) therefore reduces over dims {16 u + 4 g + e : g}; dims past HD
+    // (HD = 88: u = 5, g >= 2) contribute zeros.
+    float qf[KS4];
+    attn_vit_load_q<HD>(q, ldq, min(q0 + j, nq - 1), h, g, q_prescale, qf);
+    float kf[TPW][KS4];
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+        const float *kp = k + (size_t)min((wave + 4 * t) * 16 + j, nk - 1) * ldk + h * HD;
+#pragma unroll
+        for (int u = 0; u < DT; u++) {
+            const float4 x = *reinterpret_cast<const float4 *>(kp + min(16 * u + 4 * g, HD - 4));
+            kf[t][4 * u] = x.x; kf[t][4 * u + 1] = x.y; kf[t][4 * u + 2] = x.z; kf[t][4 * u + 3] = x.w;     // past HD: finite duplicates, multiplied by the zeros in qf
+        }
+    }
+    MG4_TLA(1);
+    float sc[TPW][4];
+    float mx;
+    attn_vit_scores<HD, TPW>(kf, qf, wave, g, nk, score_div, sc, mx);
     MG4_TLA(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the table DMA (issued first, returned first) has landed
     MG4_TLA(3);
-    // V fragments of this wave's keys: requested now, consumed after the softmax
+    // V fragments of this wave's keys: requested now, consumed after the softmax (and kept for the workgroup's later query tiles)
     float vf[TPW][4][DT];
 #pragma unroll
     for (int t = 0; t < TPW; t++)
@@ -1091,7 +1157,11 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
             for (int dt = 0; dt < DT; dt++) vf[t][r][dt] = vp[min(dt * 16 + j, HD - 1)];
         }
     MG4_TLA(4);
-    {
+#pragma clang loop unroll(disable)
+    for (;;) {
+        const bool more = MULTI && q0 + 16 < q_end;                         // workgroup-uniform
+        float qn[KS4];
+        if (more) attn_vit_load_q<HD>(q, ldq, min(q0 + 16 + j, nq - 1), h, g, q_prescale, qn);   // the next tile's Q rows travel during this tile's softmax
         mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
         if (g == 0) red_m[wave * 16 + j] = mx;
         __syncthreads();
@@ -1102,7 +1172,7 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
         // all of them (NaN, or a positive difference -- cannot happen for finite scores) takes the global table in a wave-uniform slow path
         unsigned code[TPW][4]; float el[TPW][4];
         bool odd = false;
-        if (computed) {
+        if constexpr (computed) {
 #pragma unroll
             for (int t = 0; t < TPW; t++)
 #pragma unroll
@@ -1125,7 +1195,7 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
                 el[t][r] = e;
             }
         }
-        if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {
+        if (!computed && __builtin_amdgcn_ballot_w64(odd) != 0ull) {
 #pragma unroll
             for (int t = 0; t < TPW; t++)
 #pragma unroll
@@ -1177,6 +1247,13 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
                 if (out_h) { __half2 a = __halves2half2(f2h_rn(s4[0]), f2h_rn(s4[1])), b = __halves2half2(f2h_rn(s4[2]), f2h_rn(s4[3])); uint2 w; w.x = *reinterpret_cast<unsigned *>(&a); w.y = *reinterpret_cast<unsigned *>(&b); *reinterpret_cast<uint2 *>(out_h + oo) = w; }
             }
         }
+        if (!more) break;
+        // next query tile of this workgroup: its scores against the K fragments already in registers.  (The exchange buffers are safe to reuse: every wave passes the
+        // barriers above in order, and the reads of `part` precede the next tile's first barrier.)
+        q0 += 16;
+#pragma unroll
+        for (int u = 0; u < KS4; u++) qf[u] = qn[u];
+        attn_vit_scores<HD, TPW>(kf, qf, wave, g, nk, score_div, sc, mx);
     }
 #ifdef MG4_TIMELINE
     MG4_TLA(10);
@@ -1186,22 +1263,38 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
 }
 
 // ViT / BERT attention (fp32 scores and outputs on the exact-f32 matrix cores, k_attn_vit).  nk <= 320 keys (the reference's graphs have 257 or 32).
+static int g_attn_qt = 0;                          // forced query tiles per workgroup (0 = choose); experiments / A-B only (set_attn_vit_qt)
+void set_attn_vit_qt(int qt) { g_attn_qt = qt < 0 ? 0 : qt; }
 void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale, float score_div,
                      const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s, int batch) {
     static bool attr_set = false;
-    if (!attr_set) {   // > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
-        HIP_IGNORE(lds_optin_max(&k_attn_vit<88, 5>));
-        HIP_IGNORE(lds_optin_max(&k_attn_vit<64, 5>));
-        HIP_IGNORE(lds_optin_max(&k_attn_vit<64, 1>));
+    static int cus = 256;
+    if (!attr_set) {   // > 64 KiB of dynamic LDS for the table forms (gfx950 has 160 KiB per CU)
+        HIP_IGNORE(lds_optin_max(&k_attn_vit<88, 5, false, false>)); HIP_IGNORE(lds_optin_max(&k_attn_vit<88, 5, true, false>));
+        HIP_IGNORE(lds_optin_max(&k_attn_vit<64, 5, false, false>)); HIP_IGNORE(lds_optin_max(&k_attn_vit<64, 5, true, false>));
+        HIP_IGNORE(lds_optin_max(&k_attn_vit<64, 1, false, false>));
+        hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, 0) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         attr_set = true;
     }
     if (hd != 88 && hd != 64) throw HipError{hipErrorInvalidValue, "attn_f32: head size must be 88 or 64", __FILE__, __LINE__};
     if (nk > 320 || (tb.exp && (tb.exp_neg_n <= 0 || tb.exp_neg_n % 2048))) throw HipError{hipErrorInvalidValue, "attn_f32: more than 320 keys, or the exp table's LDS part is not set up", __FILE__, __LINE__};
     const size_t lds_v = 768 + (size_t)4 * ((hd + 15) / 16) * 4 * 64 * 4 + (tb.exp ? (size_t)tb.exp_neg_n * 2 : 0);
-    dim3 grid((unsigned)heads, (unsigned)((nq + 15) / 16), (unsigned)batch);
-    if (hd == 88) hipLaunchKernelGGL((k_attn_vit<88, 5>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
-    else if (nk <= 64) hipLaunchKernelGGL((k_attn_vit<64, 1>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
-    else hipLaunchKernelGGL((k_attn_vit<64, 5>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo);
+    // Query tiles per workgroup: 1.  The looping form (qt > 1: k_attn_vit's header) was built to put several images' workgroups into one round (4 images: 1088 -> 256) and
+    // measured against the single-tile kernel inside the encoder (profiles/r06_attn_query_tiles.log): 2 images 5.51 vs 5.41 ms, 4 images 7.65 vs 7.70, 8 images 13.05 vs
+    // 12.81, one image 4.03 (qt 2) vs 3.91 -- no gain: the K / V / next-Q registers it keeps live (256 + 84 AGPRs, one workgroup per CU) cost what the saved rounds bring.
+    // What DID pay in that experiment: the exponential mode as a template parameter (190 -> 161 registers on the single-tile kernel: 4.00 -> 3.91 ms, 8.47 -> 8.05 with
+    // the fc2 ring tiles).  MINIGPT4_ATTN_QT forces a tile count (A/B, bit-identical: tests/test_gpu_parity.py).
+    const int tiles = (nq + 15) / 16;
+    int qt = 1;
+    if (g_attn_qt > 0) qt = std::min(g_attn_qt, tiles);
+    if (hd == 64 && nk <= 64) qt = 1;                                       // the Q-Former's self-attention (32 x 32): the short-key instantiation has no looping form
+    const bool comp = tb.exp == nullptr;
+    dim3 grid((unsigned)heads, (unsigned)((tiles + qt - 1) / qt), (unsigned)batch);
+#define MG4_ATTN_LAUNCH(HD_, TPW_, MULTI_, COMP_) hipLaunchKernelGGL((k_attn_vit<HD_, TPW_, MULTI_, COMP_>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo, qt)
+    if (hd == 88) { if (qt > 1) { if (comp) MG4_ATTN_LAUNCH(88, 5, true, true); else MG4_ATTN_LAUNCH(88, 5, true, false); } else { if (comp) MG4_ATTN_LAUNCH(88, 5, false, true); else MG4_ATTN_LAUNCH(88, 5, false, false); } }
+    else if (nk <= 64) { if (comp) MG4_ATTN_LAUNCH(64, 1, false, true); else MG4_ATTN_LAUNCH(64, 1, false, false); }
+    else { if (qt > 1) { if (comp) MG4_ATTN_LAUNCH(64, 5, true, true); else MG4_ATTN_LAUNCH(64, 5, true, false); } else { if (comp) MG4_ATTN_LAUNCH(64, 5, false, true); else MG4_ATTN_LAUNCH(64, 5, false, false); } }
+#undef MG4_ATTN_LAUNCH
 }
 
 // =====================================================================================================================

@@ -793,3 +793,40 @@ def test_gemm_f16_skinny_kernel(gpu_lib, shape, gelu):
     else:
         assert _rel(got, ref) < 2e-5
         assert _rel(got, gpu_lib.amd_test_gemm_f16(A, W, b, gelu)) < 2e-5
+
+
+def test_round6_encoder_arms_are_bit_identical_at_full_size(gpu_lib, monkeypatch):
+    """Round-6 changes of the image path that must not change a bit, at the real ViT-g/14 shapes (1408 wide, 16 heads of 88, 257 rows per image; 39 blocks sharing one set
+    of weights): (1) the split-K GEMM's work list dealt to the XCDs by K slice (MINIGPT4_SPLITK_XCD=0: slices in grid.z as in rounds 3-5); (2) fc2 of several images on the
+    LDS-DMA ring tiles (128x128 at two images, 256x128 from three) -- same K slice boundaries, so image b of a batch still equals the image encoded alone; (3) the looping
+    form of the vision attention (MINIGPT4_ATTN_QT=2 / 5 query tiles per workgroup) against the single-tile kernel.  One image and a batch of three per arm."""
+    import headline as H
+    from minigpt4_cpp_amd import modelgen as G
+    vp, _ = H.headline_files("13b_l2")
+    lp = os.path.join(H.model_dir(), "llm_tiny_for_vision.bin")
+    G.write_llm_file(lp, G.tiny_llm(wtype="q4_0", n_embd=256, n_layer=1, n_head=4, n_vocab=512), seed=2, std=0.05)
+    imgs = [G.synth_image(60 + i) for i in range(3)]
+
+    def run(env):
+        for k in ("MINIGPT4_SPLITK_XCD", "MINIGPT4_ATTN_QT"):          # the switches are process-wide: every arm sets both
+            monkeypatch.setenv(k, env.get(k, "1" if k == "MINIGPT4_SPLITK_XCD" else "0"))
+        ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=64, n_batch=32)
+        try:
+            one = gpu_lib.amd_encode_images(ctx, imgs[:1])[0]
+            two = gpu_lib.amd_encode_images(ctx, imgs[:2])
+            three = gpu_lib.amd_encode_images(ctx, imgs)
+            return one, two, three
+        finally:
+            gpu_lib.minigpt4_free(ctx)
+
+    base1, base2, base3 = run({})
+    assert np.isfinite(base1).all() and np.abs(base1).max() > 0
+    assert np.array_equal(base3[0], base1) and np.array_equal(base2[0], base1) and np.array_equal(base2[1], base3[1])   # batched = alone, across the three fc2 tile shapes
+    assert not np.array_equal(base3[1], base3[0])
+    try:
+        for env in ({"MINIGPT4_SPLITK_XCD": "0"}, {"MINIGPT4_ATTN_QT": "2"}, {"MINIGPT4_ATTN_QT": "5"}):
+            one, two, three = run(env)
+            assert np.array_equal(one, base1), env
+            assert all(np.array_equal(a, b) for a, b in zip(three, base3)) and all(np.array_equal(a, b) for a, b in zip(two, base2)), env
+    finally:
+        run({})                                                          # leave the process-wide switches at their defaults

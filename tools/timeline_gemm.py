@@ -27,6 +27,10 @@ def main():
     L = lib.library
     L.minigpt4_amd_bench_gemm_f16.argtypes = [ctypes.c_int] * 7 + [ctypes.POINTER(ctypes.c_float)]
     L.minigpt4_amd_timeline_vision.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    if os.environ.get("MG4_SPLITK_XCD") is not None:     # 0: split-K slices in grid.z (the rounds 3-5 mapping), A/B against the default
+        L.minigpt4_amd_test_set_splitk_xcd.argtypes = [ctypes.c_int]
+        L.minigpt4_amd_test_set_splitk_xcd.restype = None
+        L.minigpt4_amd_test_set_splitk_xcd(int(os.environ["MG4_SPLITK_XCD"]))
     a = [int(x) for x in sys.argv[1:]]
     cases = [tuple(a[i:i + 5]) for i in range(0, len(a) - 4, 5)] or VIT
     for M, N, K, flags, variant in cases:
