@@ -150,6 +150,11 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (const char *e = getenv("MINIGPT4_ATTN_QT")) set_attn_vit_qt(atoi(e));
     // 0: split-K GEMM slices in grid.z, every XCD walks every slice (rounds 3-5; A/B, bit-identical)
     if (const char *e = getenv("MINIGPT4_SPLITK_XCD")) set_gemm_splitk_xcd(atoi(e));
+    // K slices of the ViT's attention projection (1 = whole K + standalone LayerNorm: the default since round 3; 2..: split-K + the reduce that also normalises; A/B)
+    if (const char *e = getenv("MINIGPT4_SPLITK_PROJ")) splitk_proj_ = std::max(1, std::min(SPLITK_MAX, atoi(e)));
+    // decode step: which row preparations ride in their consumer's prologue (bit 0 qkv, 1 wo, 2 w1|w3, 3 w2 <- SiLU * mul + quantisation, 4 output, 5 pair, 6 mixed qkv; default 87; A/B)
+    if (const char *e = getenv("MINIGPT4_FUSE")) fuse_mask_ = atoi(e);
+    if (const char *e = getenv("MINIGPT4_QF_SPLITK")) qf_splitk_ = atoi(e) != 0;     // 0: the Q-Former's dense / output layers as whole-K launches + standalone LayerNorm (A/B)
     if (const char *e = getenv("MINIGPT4_KV_HOIST")) kv_hoist_ = atoi(e) != 0;     // 0: one K | V projection GEMM per cross-attention layer (round-4 form, A/B)
     set_matvec_tuning(0, 0, prop.multiProcessorCount);
     if (const char *ns = getenv("MINIGPT4_CONVERSATIONS")) conv_.assign((size_t)std::max(1, std::min(MAX_CONVERSATIONS, atoi(ns))), Conversation{});
@@ -1474,6 +1479,11 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
     auto qgemm = [&](const __half *A, int lda, const __half *W, int ldw, int Mr, int N, int K, const float *bias, const float *residual, bool gelu, float *o, __half *oh, int ldo) {
         if (!(qf_skinny_ && launch_gemm_f16_skinny(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_, o, oh, ldo, s))) launch_gemm_f16(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_, o, oh, ldo, s);
     };
+    // a 768-wide dense / output layer + residual + the LayerNorm behind it (NNSelfAttention's output block, NNBertEncoderLayer's query FFN output: minigpt4.cpp:1365-1400,
+    // 1430-1461).  Round 6: K split over 2 (K = 768) or 4 (K = 3072) workgroups per tile with the LayerNorm in the slab reduce (qf_dense_ln below).
+    auto dense_ln = [&](const __half *A, int lda, const __half *W, int K, const float *bias, const float *residual, const float *lw, const float *lb, float *o, __half *oh) {
+        qf_dense_ln(A, lda, W, K, bias, residual, lw, lb, o, oh, RQ, s);
+    };
     // the cross-attention K | V projections of every cross layer depend on the image features only (minigpt4.cpp:1148-1155): ONE [R x D] . [D x
     // n_cross * 1536] launch here instead of one per cross layer inside the loop; layer i reads its [R][1536] column slice (row stride n_cross *
     // 1536)
@@ -1489,8 +1499,7 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
         if (!pre) {
             qgemm(vi_hs_h_, H, L.self.q_w, H, RQ, 3 * H, H, L.self.q_b, nullptr, false, vi_qq_, nullptr, 3 * H);
             launch_attn_f32(vi_qq_, 3 * H, vi_qq_ + H, vi_qq_ + 2 * H, 3 * H, NQ, NQ, 12, 64, 0.0f, 8.0f, tabs_vis_, nullptr, vi_ctx_h_, H, s, B);
-            qgemm(vi_ctx_h_, H, L.self.dense_w, H, RQ, H, H, L.self.dense_b, vi_hs_, false, vi_d_, nullptr, H);
-            launch_layernorm(vi_d_, L.self.ln_w, L.self.ln_b, RQ, H, vi_a1_, vi_a1_h_, s);
+            dense_ln(vi_ctx_h_, H, L.self.dense_w, H, L.self.dense_b, vi_hs_, L.self.ln_w, L.self.ln_b, vi_a1_, vi_a1_h_);
         }
         const float *ao = a1; const __half *ao_h = a1_h;
         if (L.has_cross) {
@@ -1499,13 +1508,11 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
             const float *kv = hoist ? vi_kv_ + (size_t)L.cross_idx * 2 * H : vi_kv_;
             if (!hoist) launch_gemm_f16(vi_img_h_, D, L.cross.kv_w, D, R, 2 * H, D, L.cross.kv_b, nullptr, false, tabs_, vi_kv_, nullptr, 2 * H, s);
             launch_attn_f32(cq, H, kv, kv + H, ldkv, NQ, 257, 12, 64, 0.0f, 8.0f, tabs_vis_, nullptr, vi_ctx_h_, H, s, B);
-            qgemm(vi_ctx_h_, H, L.cross.dense_w, H, RQ, H, H, L.cross.dense_b, a1, false, vi_d_, nullptr, H);
-            launch_layernorm(vi_d_, L.cross.ln_w, L.cross.ln_b, RQ, H, vi_a2_, vi_a2_h_, s);
+            dense_ln(vi_ctx_h_, H, L.cross.dense_w, H, L.cross.dense_b, a1, L.cross.ln_w, L.cross.ln_b, vi_a2_, vi_a2_h_);
             ao = vi_a2_; ao_h = vi_a2_h_;
         }
         qgemm(ao_h, H, L.inter_w, H, RQ, v_qi_, H, L.inter_b, nullptr, true, nullptr, vi_im_h_, v_qi_);
-        qgemm(vi_im_h_, v_qi_, L.out_w, v_qi_, RQ, H, v_qi_, L.out_b, ao, false, vi_d_, nullptr, H);
-        launch_layernorm(vi_d_, L.oln_w, L.oln_b, RQ, H, vi_hs_, vi_hs_h_, s);
+        dense_ln(vi_im_h_, v_qi_, L.out_w, v_qi_, L.out_b, ao, L.oln_w, L.oln_b, vi_hs_, vi_hs_h_);
     }
     qgemm(vi_hs_h_, H, v_proj_w_, H, RQ, v_out_, H, v_proj_b_, nullptr, false, vi_out_, nullptr, v_out_);
     HIP_CHECK(hipEventRecord(eb, s));
@@ -1516,6 +1523,21 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
     return E_None;
 }
 int Engine::encode_image(const float *chw, float *out) { return encode_images(&chw, 1, &out); }
+
+// out (fp32) / out_h (fp16) = LayerNorm(residual + (bias + A . W^T)) for a 768-wide layer of the Q-Former, `rows` rows.  The whole-K skinny launch is 48 workgroups on 256
+// CUs, each pulling 32 rows of A and 16 of W over the full K through one CU's load path, followed by a standalone LayerNorm launch; here the K range is split over 2 (K = 768)
+// or 4 (K >= 2048) workgroups per tile (raw partial sums into slabs) and the deterministic slab reduce adds bias + residual and normalises -- the same two launches, the
+// first one 2-4 x wider.  The slice count depends on K only, never on the rows: image b of a batch equals the image encoded alone.  MINIGPT4_QF_SPLITK=0: the round 2-5 form.
+void Engine::qf_dense_ln(const __half *A, int lda, const __half *W, int K, const float *bias, const float *residual, const float *ln_w, const float *ln_b, float *out, __half *out_h,
+                         int rows, hipStream_t s) {
+    const int H = 768, slices = K >= 2048 ? 4 : 2;
+    if (qf_splitk_ && qf_skinny_ && launch_gemm_f16_skinny_splitk(A, lda, W, K, rows, H, K, slices, vi_slab_, (size_t)rows * H, H, s)) {
+        launch_splitk_reduce_ln(vi_slab_, slices, (size_t)rows * H, bias, residual, rows, H, nullptr, ln_w, ln_b, out, out_h, s);
+        return;
+    }
+    if (!(qf_skinny_ && launch_gemm_f16_skinny(A, lda, W, K, rows, H, K, bias, residual, false, tabs_, vi_d_, nullptr, H, s))) launch_gemm_f16(A, lda, W, K, rows, H, K, bias, residual, false, tabs_, vi_d_, nullptr, H, s);
+    launch_layernorm(vi_d_, ln_w, ln_b, rows, H, out, out_h, s);
+}
 
 // What the Q-Former computes before it first looks at the image: hs = LayerNorm(query tokens) (minigpt4.cpp:2236-2246), layer 0's self-attention
 // block on hs (NNSelfAttention + residual + LayerNorm, minigpt4.cpp:1365-1400) and, when layer 0 has cross-attention, its query projection.  None of
@@ -1534,8 +1556,7 @@ void Engine::fold_qformer_constants() {
     launch_layernorm(vi_qtok_rep_, v_qeln_w_, v_qeln_b_, NQ, H, vi_hs_, vi_hs_h_, s);
     qgemm(vi_hs_h_, H, L.self.q_w, H, NQ, 3 * H, H, L.self.q_b, nullptr, false, vi_qq_, nullptr, 3 * H);
     launch_attn_f32(vi_qq_, 3 * H, vi_qq_ + H, vi_qq_ + 2 * H, 3 * H, NQ, NQ, 12, 64, 0.0f, 8.0f, tabs_vis_, nullptr, vi_ctx_h_, H, s, 1);
-    qgemm(vi_ctx_h_, H, L.self.dense_w, H, NQ, H, H, L.self.dense_b, vi_hs_, false, vi_d_, nullptr, H);
-    launch_layernorm(vi_d_, L.self.ln_w, L.self.ln_b, NQ, H, vi_c_a1_, vi_c_a1_h_, s);
+    qf_dense_ln(vi_ctx_h_, H, L.self.dense_w, H, L.self.dense_b, vi_hs_, L.self.ln_w, L.self.ln_b, vi_c_a1_, vi_c_a1_h_, NQ, s);   // the launches encode_images issues
     if (L.has_cross) qgemm(vi_c_a1_h_, H, L.cross.q_w, H, NQ, H, H, L.cross.q_b, nullptr, false, vi_c_qq_, nullptr, H);
     HIP_CHECK(hipStreamSynchronize(s));
     const size_t n = (size_t)NQ * H;

@@ -244,6 +244,9 @@ private:
     float *vi_c_a1_ = nullptr, *vi_c_qq_ = nullptr; __half *vi_c_a1_h_ = nullptr;
     bool qf_fold_ = true, qf_folded_ = false, kv_hoist_ = true;
     void fold_qformer_constants();
+    bool qf_splitk_ = true;
+    void qf_dense_ln(const __half *A, int lda, const __half *W, int K, const float *bias, const float *residual, const float *ln_w, const float *ln_b, float *out, __half *out_h,
+                     int rows, hipStream_t s);
 
     // ---- vision files whose Linear weights are not all F16 (an `--ftype f32` conversion, or a file written by minigpt4_quantize_model): every
     // Linear is a QWeight served by the LLM mat-mul kernels (activations quantised to the weight type's vec_dot_type, exactly ggml's mul_mat),

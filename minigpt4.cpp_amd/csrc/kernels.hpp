@@ -173,6 +173,7 @@ void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, 
 // the kernel's range (N % 16, K % 32), nothing launched
 bool launch_gemm_f16_skinny(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
                             float *out, __half *out_h, int ldo, hipStream_t s);
+bool launch_gemm_f16_skinny_splitk(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, int slices, float *slabs, size_t slab_stride, int ldo, hipStream_t s);   // raw partial sums per K slice -> launch_splitk_reduce_ln
 void launch_lin_epilogue(const float *y, const float *bias, const float *residual, bool gelu, const Tables &tb, int rows, int n, float *out, __half *out_h, hipStream_t s);
 // LayerNorm (ggml_norm eps 1e-5, then w*x+b); rows x n; writes fp32 (nullable) and fp16 (nullable).
 void launch_layernorm(const float *x, const float *w, const float *b, int rows, int n, float *out, __half *out_h, hipStream_t s, bool sequential_sums = false);   // sequential_sums: MINIGPT4_PARITY

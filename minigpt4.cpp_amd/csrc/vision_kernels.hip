@@ -669,10 +669,15 @@ bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n
 // =====================================================================================================================
 typedef float float4v_t __attribute__((ext_vector_type(4)));
 constexpr int SK_WAVES = 4;                                       // waves per workgroup = K slices (fixed: the order of additions per output element must not depend on M)
+// k_per_slice > 0 (round 6, the Q-Former's 768-wide dense / output layers): grid.z workgroups share an output tile, each a contiguous K range, and store their RAW partial
+// sums into slab z (no bias / GELU / residual); k_splitk_reduce_ln adds the slabs in slab order with bias + residual and applies the LayerNorm that follows in the graph.
+// With N = 768 the whole-K form is 48 workgroups on 256 CUs, each pulling A [32][K] + W [16][K] (294 KB at K = 3072) through ONE CU's load path.
 template <int MT, bool GELU, bool RES>
 __global__ __launch_bounds__(64 * SK_WAVES) void k_gemm_f16_skinny(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K,
-                                                                   const float *__restrict__ bias, const float *residual, const Tables tb, float *out, __half *__restrict__ out_h, int ldo) {
+                                                                   const float *__restrict__ bias, const float *residual, const Tables tb, float *out, __half *__restrict__ out_h, int ldo,
+                                                                   int k_per_slice, size_t slab_stride) {
     constexpr int U = MT <= 2 ? 12 : 8;                           // k-steps in flight per wave: U x (1 + MT) 16-byte loads per lane (36 / 40)
+    if (k_per_slice > 0) { const int k0 = (int)blockIdx.z * k_per_slice; A += k0; W += k0; K = min(K - k0, k_per_slice); out += (size_t)blockIdx.z * slab_stride; }
     __shared__ float red[SK_WAVES][MT][64][4];                    // [wave][m tile][lane][acc register]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * MT);
@@ -741,10 +746,23 @@ template <int MT>
 static void launch_skinny_mt(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
                              float *out, __half *out_h, int ldo, hipStream_t s) {
     const dim3 grid((unsigned)(N / 16), (unsigned)((M + 16 * MT - 1) / (16 * MT))), block(64 * SK_WAVES);
-    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16_skinny<MT, true, true>), grid, block, 0, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
-    else if (gelu) hipLaunchKernelGGL((k_gemm_f16_skinny<MT, true, false>), grid, block, 0, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
-    else if (residual) hipLaunchKernelGGL((k_gemm_f16_skinny<MT, false, true>), grid, block, 0, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
-    else hipLaunchKernelGGL((k_gemm_f16_skinny<MT, false, false>), grid, block, 0, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo);
+    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16_skinny<MT, true, true>), grid, block, 0, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, 0, (size_t)0);
+    else if (gelu) hipLaunchKernelGGL((k_gemm_f16_skinny<MT, true, false>), grid, block, 0, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, 0, (size_t)0);
+    else if (residual) hipLaunchKernelGGL((k_gemm_f16_skinny<MT, false, true>), grid, block, 0, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, 0, (size_t)0);
+    else hipLaunchKernelGGL((k_gemm_f16_skinny<MT, false, false>), grid, block, 0, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, 0, (size_t)0);
+}
+// Split-K form of the skinny-M kernel: `slices` workgroups per output tile, raw partial sums into slabs [slice][M][ldo] (k_gemm_f16_skinny's header).  The slice count
+// must not depend on M (image b of a batch equals the image encoded alone, bit for bit).  false: shape outside this path, nothing launched.
+bool launch_gemm_f16_skinny_splitk(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, int slices, float *slabs, size_t slab_stride, int ldo, hipStream_t s) {
+    if (N % 16 || K % 32 || M < 1 || (lda % 8) || (ldw % 8) || slices < 2 || slices > 12 || !slabs) return false;
+    const int nks = K / 32, per = (nks + slices - 1) / slices;
+    if ((nks + per - 1) / per != slices) return false;           // every slice multiplies something
+    Tables tb{};
+    if (M <= 32) { const dim3 grid((unsigned)(N / 16), (unsigned)((M + 31) / 32), (unsigned)slices);
+        hipLaunchKernelGGL((k_gemm_f16_skinny<2, false, false>), grid, dim3(64 * SK_WAVES), 0, s, A, lda, W, ldw, M, N, K, nullptr, nullptr, tb, slabs, nullptr, ldo, per * 32, slab_stride); }
+    else { const dim3 grid((unsigned)(N / 16), (unsigned)((M + 63) / 64), (unsigned)slices);
+        hipLaunchKernelGGL((k_gemm_f16_skinny<4, false, false>), grid, dim3(64 * SK_WAVES), 0, s, A, lda, W, ldw, M, N, K, nullptr, nullptr, tb, slabs, nullptr, ldo, per * 32, slab_stride); }
+    return true;
 }
 bool launch_gemm_f16_skinny(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
                             float *out, __half *out_h, int ldo, hipStream_t s) {
@@ -1096,7 +1114,9 @@ __device__ __forceinline__ void attn_vit_load_q(const float *__restrict__ q, int
     }
 }
 // MULTI = false is the single-tile kernel of rounds 2-5 (the loop folds away: 190 registers, two workgroups per CU); MULTI = true keeps K, V and the next tile's Q rows
-// live across the loop (one workgroup per CU).  COMPUTED: the exponentials are computed instead of gathered from the table's LDS copy (fast mode, round 5).
+// live across the loop (one workgroup per CU).  COMPUTED: the exponentials are computed instead of gathered from the table's LDS copy (fast mode, round 5); as a template
+// parameter since round 6 (161 + 24 registers).  (Bounding that form to three waves per SIMD -- 168 VGPRs, 12 B of scratch -- did not pay: 3.82 vs 3.77 ms at one image,
+// 7.38 vs 7.25 at four; profiles/r06_attn_query_tiles.log.)
 template <int HD, int TPW, bool MULTI, bool COMPUTED>
 __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, int ldq, const float *__restrict__ k, const float *__restrict__ v, int ldk, int nq, int nk,
                                                   float q_prescale, float score_div, const Tables tb, float *__restrict__ out, __half *__restrict__ out_h, int ldo, int qt) {
@@ -1268,12 +1288,10 @@ void set_attn_vit_qt(int qt) { g_attn_qt = qt < 0 ? 0 : qt; }
 void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale, float score_div,
                      const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s, int batch) {
     static bool attr_set = false;
-    static int cus = 256;
     if (!attr_set) {   // > 64 KiB of dynamic LDS for the table forms (gfx950 has 160 KiB per CU)
         HIP_IGNORE(lds_optin_max(&k_attn_vit<88, 5, false, false>)); HIP_IGNORE(lds_optin_max(&k_attn_vit<88, 5, true, false>));
         HIP_IGNORE(lds_optin_max(&k_attn_vit<64, 5, false, false>)); HIP_IGNORE(lds_optin_max(&k_attn_vit<64, 5, true, false>));
         HIP_IGNORE(lds_optin_max(&k_attn_vit<64, 1, false, false>));
-        hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, 0) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         attr_set = true;
     }
     if (hd != 88 && hd != 64) throw HipError{hipErrorInvalidValue, "attn_f32: head size must be 88 or 64", __FILE__, __LINE__};

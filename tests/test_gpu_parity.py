@@ -799,7 +799,8 @@ def test_round6_encoder_arms_are_bit_identical_at_full_size(gpu_lib, monkeypatch
     """Round-6 changes of the image path that must not change a bit, at the real ViT-g/14 shapes (1408 wide, 16 heads of 88, 257 rows per image; 39 blocks sharing one set
     of weights): (1) the split-K GEMM's work list dealt to the XCDs by K slice (MINIGPT4_SPLITK_XCD=0: slices in grid.z as in rounds 3-5); (2) fc2 of several images on the
     LDS-DMA ring tiles (128x128 at two images, 256x128 from three) -- same K slice boundaries, so image b of a batch still equals the image encoded alone; (3) the looping
-    form of the vision attention (MINIGPT4_ATTN_QT=2 / 5 query tiles per workgroup) against the single-tile kernel.  One image and a batch of three per arm."""
+    form of the vision attention (MINIGPT4_ATTN_QT=2 / 5 query tiles per workgroup) against the single-tile kernel; (4) the Q-Former's split-K dense layers against the
+    whole-K form (close, not identical).  One image, a batch of two and a batch of three per arm."""
     import headline as H
     from minigpt4_cpp_amd import modelgen as G
     vp, _ = H.headline_files("13b_l2")
@@ -808,8 +809,13 @@ def test_round6_encoder_arms_are_bit_identical_at_full_size(gpu_lib, monkeypatch
     imgs = [G.synth_image(60 + i) for i in range(3)]
 
     def run(env):
-        for k in ("MINIGPT4_SPLITK_XCD", "MINIGPT4_ATTN_QT"):          # the switches are process-wide: every arm sets both
+        for k in ("MINIGPT4_SPLITK_XCD", "MINIGPT4_ATTN_QT"):          # these two switches are process-wide: every arm sets both
             monkeypatch.setenv(k, env.get(k, "1" if k == "MINIGPT4_SPLITK_XCD" else "0"))
+        for k in ("MINIGPT4_QF_FOLD", "MINIGPT4_KV_HOIST", "MINIGPT4_QF_SPLITK"):   # per context
+            if k in env:
+                monkeypatch.setenv(k, env[k])
+            else:
+                monkeypatch.delenv(k, raising=False)
         ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=64, n_batch=32)
         try:
             one = gpu_lib.amd_encode_images(ctx, imgs[:1])[0]
@@ -824,9 +830,17 @@ def test_round6_encoder_arms_are_bit_identical_at_full_size(gpu_lib, monkeypatch
     assert np.array_equal(base3[0], base1) and np.array_equal(base2[0], base1) and np.array_equal(base2[1], base3[1])   # batched = alone, across the three fc2 tile shapes
     assert not np.array_equal(base3[1], base3[0])
     try:
-        for env in ({"MINIGPT4_SPLITK_XCD": "0"}, {"MINIGPT4_ATTN_QT": "2"}, {"MINIGPT4_ATTN_QT": "5"}):
+        # (round 5's two Q-Former arms ride along: the constant head of layer 0 recomputed per encode, one K | V projection per cross layer -- same launches, same bits)
+        for env in ({"MINIGPT4_SPLITK_XCD": "0"}, {"MINIGPT4_ATTN_QT": "2"}, {"MINIGPT4_ATTN_QT": "5"}, {"MINIGPT4_QF_FOLD": "0"}, {"MINIGPT4_KV_HOIST": "0"}):
             one, two, three = run(env)
             assert np.array_equal(one, base1), env
             assert all(np.array_equal(a, b) for a, b in zip(three, base3)) and all(np.array_equal(a, b) for a, b in zip(two, base2)), env
+        # (4) the Q-Former's dense / output layers with K split over 2 / 4 workgroups + LayerNorm in the slab reduce: another fp32 summation order of the same products
+        # -- not bit-identical to the whole-K form, but as close to it as two orders of 768 .. 3072 fp32 terms are, and batched = alone in both forms
+        one, two, three = run({"MINIGPT4_QF_SPLITK": "0"})
+        assert np.array_equal(three[0], one) and np.array_equal(two[1], three[1])
+        d = float(np.abs(one - base1).max() / np.abs(base1).max())
+        print(f"Q-Former split-K vs whole-K dense layers: max rel diff of the embedding {d:.2e}")
+        assert 0.0 < d < 2e-4, d
     finally:
         run({})                                                          # leave the process-wide switches at their defaults
