@@ -114,6 +114,13 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device_));
     MG4_INFO("device %d: %s (%s), %d CUs, %.1f GiB", device_, prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
+    // The library is built for gfx950 only, and its in-launch hand-offs (K-split tickets of k_matvec_ri, the key-split attention's arrival counters) rely on that part's cache
+    // behaviour -- write-through agent-scope stores + vmcnt(0) before the ticket, cache-bypassing agent-scope loads after it, no fences (MI355X_MICROARCH.md "Valid forms"): refuse
+    // any other device by name instead of failing at the first launch (or, worse, not failing)
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_last_error(std::string("device ") + prop.gcnArchName + " is not gfx950 (MI355X): this library carries gfx950 code objects only"); MG4_ERR("%s", last_error().c_str());
+        return E_LoadLanguageModel;
+    }
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     n_ctx_ = n_ctx > 0 ? n_ctx : 2048;
     n_batch_ = n_batch > 0 ? n_batch : 512;
@@ -141,6 +148,8 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (const char *e = getenv("MINIGPT4_RI_FUSE")) ri_fuse_ = atoi(e) != 0;
     // 0: w2 of the 4-conversation step on the v_dot4 launch instead of the K-split MFMA launch (A/B: profiles/r05_batched_decode_inengine.log)
     if (const char *e = getenv("MINIGPT4_RI_W2")) ri_w2_ = atoi(e) != 0;
+    // 1: wo of the 3- / 4-conversation step on the MFMA launch with the plain quantisation of the attention rows inside it (round 6, A/B)
+    if (const char *e = getenv("MINIGPT4_RI_WO")) ri_wo_ = atoi(e) != 0;
     // 0: batched decode on the v_dot4 multi-row mat-vec (rounds 2-4), no row-interleaved image
     if (const char *e = getenv("MINIGPT4_RI")) use_ri_ = atoi(e) != 0;
     set_ri_cus(prop.multiProcessorCount);
@@ -152,6 +161,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (const char *e = getenv("MINIGPT4_SPLITK_XCD")) set_gemm_splitk_xcd(atoi(e));
     // K slices of the ViT's attention projection (1 = whole K + standalone LayerNorm: the default since round 3; 2..: split-K + the reduce that also normalises; A/B)
     if (const char *e = getenv("MINIGPT4_SPLITK_PROJ")) splitk_proj_ = std::max(1, std::min(SPLITK_MAX, atoi(e)));
+    if (const char *e = getenv("MINIGPT4_SPLITK_FC2")) splitk_fc2_ = std::max(1, std::min(SPLITK_MAX, atoi(e)));     // K slices of the ViT's fc2 (default 4; A/B)
     // decode step: which row preparations ride in their consumer's prologue (bit 0 qkv, 1 wo, 2 w1|w3, 3 w2 <- SiLU * mul + quantisation, 4 output, 5 pair, 6 mixed qkv; default 87; A/B)
     if (const char *e = getenv("MINIGPT4_FUSE")) fuse_mask_ = atoi(e);
     if (const char *e = getenv("MINIGPT4_QF_SPLITK")) qf_splitk_ = atoi(e) != 0;     // 0: the Q-Former's dense / output layers as whole-K launches + standalone LayerNorm (A/B)
@@ -1009,6 +1019,12 @@ void Engine::forward_batch(int B, hipStream_t s) {
         int i = 0; for (const QWeight *w : Ws) W[i++] = w;
         i = 0; for (float *p : ys) { y[i] = p; r[i] = res0; i++; }
         bool same = true; for (int k = 1; k < n; k++) same = same && W[k]->type == W[0]->type && W[k]->rows == W[0]->rows && W[k]->cols == W[0]->cols;
+        // wo at 3 / 4 rows (round 6, MINIGPT4_RI_WO): the attention rows are quantised as they are inside the MFMA launch (80 row groups: eight waves per workgroup split K, no
+        // workgroup K split -- every workgroup stages the whole rows anyway)
+        if (ri_wo_ && px && !pw && n == 1 && ri_ready_ && B >= 3 && B <= 4 && ri_of(W[0])) {
+            const RiPlanes *rp[1] = {ri_of(W[0])};
+            if (launch_matvec_ri(W, rp, y, res0 ? r : nullptr, 1, act_, B, ld, s, px, nullptr, W[0]->cols, RiWorkspace{})) { batch_path_.ri++; batch_path_.ri_plain++; return; }
+        }
         if (ri_serves(Ws) && (!px || pw)) {                 // prepared rows, or rows this launch rms-norms and quantises itself (px, pw)
             const RiPlanes *rp[3]; for (int k = 0; k < n; k++) rp[k] = ri_of(W[k]);
             if (launch_matvec_ri(W, rp, y, res0 ? r : nullptr, n, act_, B, ld, s, px, pw, W[0]->cols, ri_ws_)) {
@@ -1331,6 +1347,7 @@ void Engine::build_ri_planes() {
         if (L.w1.type == L.w3.type) for (const QWeight *w : {&L.w1, &L.w3}) ws.push_back(w);
     }
     if (ri_w2_) for (const LayerW &L : layers_) ws.push_back(&L.w2);
+    if (ri_wo_) for (const LayerW &L : layers_) ws.push_back(&L.wo);
     ws.push_back(&output_);
     size_t total = 0;
     for (const QWeight *w : ws) { RiPlanes p; total += ri_plan(w->type, w->rows, w->cols, p, nullptr); }

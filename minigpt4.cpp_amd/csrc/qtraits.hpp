@@ -13,7 +13,9 @@ __device__ __forceinline__ float f16r(float f) { return __half2float(f2h_rn(f));
 __device__ __forceinline__ float tab(const __half *t, float x) { return __half2float(t[f2h_bits(x)]); }
 // Fast mode (round 5, SURVEY.md 9.5: "in fast mode evaluate in fp32"): the VALUE of ggml's fp16 tables computed instead of gathered -- table[x] = fp16(f(fp16(x))) with f
 // evaluated in fp32 by the host libm; here f comes from the GPU's exp (v_exp_f32, ~1 ulp), so a result differs from the table's by one fp16 ulp only when f lands within
-// ~1e-7 of an fp16 rounding boundary (about one value in 10^4).  A null table pointer selects this form; parity mode and the vision tower always pass the tables.
+// ~1e-7 of an fp16 rounding boundary (about one value in 10^4).  A null table pointer selects this form: the DEFAULT of fast mode for the decode step's attention / SiLU launches (Engine::tabs_dec_) and for the ViT / Q-Former
+// attention (Engine::tabs_vis_.exp; MINIGPT4_COMPUTED_TABLES=0 passes the tables again, kept under test) -- a stated deviation from ggml's table VALUES by at most one fp16 ulp,
+// inside the fast-mode bound.  Parity mode, every prompt pass and the GELU of the vision tower always read the tables.
 __device__ __forceinline__ float exp_h(const __half *t, float x) { if (t) return tab(t, x); return f16r(__expf(f16r(x))); }
 __device__ __forceinline__ float silu_h(const __half *t, float x) { if (t) return tab(t, x); const float xh = f16r(x); return f16r(xh / (1.0f + __expf(-xh))); }
 

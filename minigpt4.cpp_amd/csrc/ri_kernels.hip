@@ -272,20 +272,27 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
         for (int t = 0; t < 4; t++) {
             if (t < N) {                                                      // workgroup-uniform
                 const float *xr = a.px + (size_t)t * a.ldx;
-                double sum = 0.0;
-                for (int i = threadIdx.x * 4; i < K; i += NT * 4) { const float4 v = *reinterpret_cast<const float4 *>(xr + i);
-                    double q = 0.0; q += (double)(v.x * v.x); q += (double)(v.y * v.y); q += (double)(v.z * v.z); q += (double)(v.w * v.w); sum += q; }
-                sum = wave_sum_d(sum);
-                if (lane == 0) redd[wv] = sum;
-                __syncthreads();
-                double tot = 0.0;
-                for (int w = 0; w < WPB; w++) tot += redd[w];
-                __syncthreads();
-                const float scale = 1.0f / sqrtf((float)(tot / (double)K) + 1e-6f);
+                const bool norm = a.pw != nullptr;                            // workgroup-uniform.  false (round 6): the rows are taken as they are and only quantised (the attention
+                float scale = 1.0f;                                           // output in front of wo: no norm, no double-precision sum)
+                if (norm) {
+                    double sum = 0.0;
+                    for (int i = threadIdx.x * 4; i < K; i += NT * 4) { const float4 v = *reinterpret_cast<const float4 *>(xr + i);
+                        double q = 0.0; q += (double)(v.x * v.x); q += (double)(v.y * v.y); q += (double)(v.z * v.z); q += (double)(v.w * v.w); sum += q; }
+                    sum = wave_sum_d(sum);
+                    if (lane == 0) redd[wv] = sum;
+                    __syncthreads();
+                    double tot = 0.0;
+                    for (int w = 0; w < WPB; w++) tot += redd[w];
+                    __syncthreads();
+                    scale = 1.0f / sqrtf((float)(tot / (double)K) + 1e-6f);
+                }
                 for (int i0 = 0; i0 < K; i0 += NT * 4) {                      // whole waves per 256-block (K is a multiple of 256): the Q8_K emission is a wave-level operation
                     const int i = i0 + threadIdx.x * 4; const bool in = i < K; const int ic = in ? i : 0;
-                    const float4 xv = *reinterpret_cast<const float4 *>(xr + ic), wv4 = *reinterpret_cast<const float4 *>(a.pw + ic);
-                    float v[4] = {(xv.x * scale) * wv4.x, (xv.y * scale) * wv4.y, (xv.z * scale) * wv4.z, (xv.w * scale) * wv4.w};
+                    const float4 xv = *reinterpret_cast<const float4 *>(xr + ic);
+                    float4 wv4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                    if (norm) wv4 = *reinterpret_cast<const float4 *>(a.pw + ic);
+                    float v[4] = {xv.x, xv.y, xv.z, xv.w};
+                    if (norm) { v[0] = (xv.x * scale) * wv4.x; v[1] = (xv.y * scale) * wv4.y; v[2] = (xv.z * scale) * wv4.z; v[3] = (xv.w * scale) * wv4.w; }
                     if (!in) { v[0] = 0.0f; v[1] = 0.0f; v[2] = 0.0f; v[3] = 0.0f; }
                     if (i0 + (int)(threadIdx.x & ~63) * 4 < K) quant_emit4(v, in, i, (size_t)t, K, L, ACT_Q8K);   // (wave-uniform condition: a wave entirely past the row skips)
                 }
@@ -344,7 +351,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
             // hand-off without cache maintenance (a release / acquire FENCE writes back and invalidates the whole L2 of the XCD -- measured: 78 us
             // instead of 22 for the 13B w2, the weight stream of every other workgroup loses its lines): the partial sums are agent-scope
             // (write-through, sc1) stores, drained with vmcnt(0) before the ticket; the last arriver reads them with agent-scope (cache-bypassing)
-            // loads
+            // loads.  This is the guide's valid form for gfx942 / gfx950 (MI355X_MICROARCH.md "Valid forms": sc1 payload + drain replaces release / acquire), NOT a statement
+            // of the HIP memory model -- Engine::init refuses any device that is not gfx950
             if (wv < N) __hip_atomic_store(a.slabs + ((size_t)task * 4 + wv) * 64 + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -447,7 +455,7 @@ int ri_ksplit(int total_groups, int K, const RiWorkspace &ws) {
 bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s,
                       const float *px, const float *pw, int ldx, const RiWorkspace &ws) {
     if (n < 1 || n > 3 || N < 1 || N > 4) return false;
-    if (px ? (!pw || ldx < W[0]->cols) : (!A.q8k || !A.dk || !A.bsk || !A.bsq)) return false;
+    if (px ? ldx < W[0]->cols : (!A.q8k || !A.dk || !A.bsk || !A.bsq)) return false;      // px with pw == null: rows quantised as they are (no norm)
     RiArgs a{};
     a.px = px; a.pw = pw; a.ldx = ldx;
     for (int i = 0; i < n; i++) {
