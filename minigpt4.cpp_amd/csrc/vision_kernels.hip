@@ -949,6 +949,8 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_ln(const float *__restric
         }
     }
 }
+// (Round 6 measured the same kernel on 16-byte pieces -- a quarter of the load / store instructions, bit-identical rows -- and lost: 3.79 vs 3.75 ms per encode, 7.37 vs 7.27 at
+// four images (profiles/r06_attn_query_tiles.log, run 18): 4 slabs x 2 float4 + operands live per thread cost more residency than the address path gained.  Removed.)
 void launch_splitk_reduce_ln(const float *slabs, int n_slabs, size_t slab_stride, const float *bias, const float *residual, int rows, int n, float *x_out, const float *ln_w,
                              const float *ln_b, float *ln_out, __half *ln_out_h, hipStream_t s) {
     if (n > 2048 || n_slabs < 1 || n_slabs > 12) throw HipError{hipErrorInvalidValue, "splitk reduce: row longer than 2048 or more than 12 slabs", __FILE__, __LINE__};
