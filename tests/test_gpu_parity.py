@@ -846,3 +846,38 @@ def test_round6_encoder_arms_are_bit_identical_at_full_size(gpu_lib, monkeypatch
         assert 0.0 < d < 2e-3, d
     finally:
         run({})                                                          # leave the process-wide switches at their defaults
+
+
+@pytest.mark.parametrize("arm", ["0", "1"])
+def test_table_gather_and_computed_table_arms_match_the_oracle(gpu_lib, tiny_files, monkeypatch, arm):
+    """MINIGPT4_COMPUTED_TABLES (round-5 advisor: the deviation must be stated and the other arm kept under test).  "1" (default): fast mode's decode step and the ViT / Q-Former
+    attention COMPUTE the values of ggml's fp16 exp / SiLU tables (fp16(f(fp16 x)) with the device's exp: equal to the host table's entry except within ~1e-7 of an fp16 rounding
+    boundary); "0": they gather from the tables as ggml does.  Both arms through the reference call sequence on a conditioned model: image embedding within the vision bar of the
+    oracle, greedy pieces identical to the oracle's, decode logits within north_star's 1e-2 of the largest |logit| (observed: a few 1e-3, the re-rounding noise of the model)."""
+    import refcpu as R
+    from minigpt4_cpp_amd import minigpt4_library as ML, modelgen as G
+    vp, llm = tiny_files
+    lp = llm("q5_k", "q5_k_m", conditioned=True)
+    monkeypatch.setenv("MINIGPT4_COMPUTED_TABLES", arm)
+    ctx = gpu_lib.minigpt4_model_load(vp, lp, verbosity=0, n_ctx=256, n_batch=64)
+    try:
+        img = G.synth_image(5)
+        emb = gpu_lib.minigpt4_encode_image(ctx, ML.array_to_image_struct(img))
+        got = np.ctypeslib.as_array(emb.data, shape=(emb.n_embeddings,)).copy().reshape(32, -1)
+        gpu_lib.minigpt4_free_embedding(emb)
+        want = R.OracleVision(G.read_vision_file(vp)).encode(img)
+        assert float(np.abs(got - want).max() / np.abs(want).max()) < 3e-3
+        chat = R.OracleChat(R.OracleLLM(G.read_llm_file(lp), n_ctx=256), n_batch=64)
+        gpu_lib.minigpt4_system_prompt(ctx)
+        chat.system_prompt()
+        gpu_lib.minigpt4_begin_chat(ctx, "what is the text in the picture?")
+        chat.begin_chat(b"what is the text in the picture?")
+        worst = 0.0
+        for _ in range(12):                                                 # every step after the first is a decode step (the arm's kernels)
+            lg, ol = gpu_lib.amd_logits(ctx), chat.llm.logits
+            worst = max(worst, float(np.abs(lg - ol).max() / np.abs(ol).max()))
+            assert gpu_lib.minigpt4_end_chat(ctx, temp=0.0) == chat.end_chat(temp=0.0)[1].decode("utf-8", errors="replace")
+        print(f"MINIGPT4_COMPUTED_TABLES={arm}: max logit rel {worst:.2e}")
+        assert worst <= 1e-2, worst
+    finally:
+        gpu_lib.minigpt4_free(ctx)
