@@ -150,8 +150,6 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (const char *e = getenv("MINIGPT4_RI_W2")) ri_w2_ = atoi(e) != 0;
     // 1: wo of the 3- / 4-conversation step on the MFMA launch with the plain quantisation of the attention rows inside it (round 6, A/B)
     if (const char *e = getenv("MINIGPT4_RI_WO")) ri_wo_ = atoi(e) != 0;
-    // 1: the K-split w2 launch of the 4-conversation step prepares the next layer's qkv rows in its last workgroup (round 6, A/B)
-    if (const char *e = getenv("MINIGPT4_RI_TAIL")) ri_tail_ = atoi(e) != 0;
     // 0: batched decode on the v_dot4 multi-row mat-vec (rounds 2-4), no row-interleaved image
     if (const char *e = getenv("MINIGPT4_RI")) use_ri_ = atoi(e) != 0;
     set_ri_cus(prop.multiProcessorCount);
@@ -1015,9 +1013,7 @@ void Engine::forward_batch(int B, hipStream_t s) {
         if (ri_w2_ && B == 4 && Ws.size() == 1 && w0->cols >= 8192 && ri_ksplit(groups, w0->cols, ri_ws_) > 1) return true;
         return groups >= 128;
     };
-    bool tail_done = false;                                 // set by mm(): the launch prepared the NEXT consumer's rows in its tail (ri_tail_)
-    auto mm = [&](std::initializer_list<const QWeight *> Ws, std::initializer_list<float *> ys, const float *res0, int ld, const float *px = nullptr, const float *pw = nullptr,
-                  const float *tail_w = nullptr) {
+    auto mm = [&](std::initializer_list<const QWeight *> Ws, std::initializer_list<float *> ys, const float *res0, int ld, const float *px = nullptr, const float *pw = nullptr) {
         const int n = (int)Ws.size();
         const QWeight *W[3]; float *y[3]; const float *r[3];
         int i = 0; for (const QWeight *w : Ws) W[i++] = w;
@@ -1031,10 +1027,6 @@ void Engine::forward_batch(int B, hipStream_t s) {
         }
         if (ri_serves(Ws) && (!px || pw)) {                 // prepared rows, or rows this launch rms-norms and quantises itself (px, pw)
             const RiPlanes *rp[3]; for (int k = 0; k < n; k++) rp[k] = ri_of(W[k]);
-            if (tail_w && launch_matvec_ri(W, rp, y, res0 ? r : nullptr, n, act_, B, ld, s, px, pw, W[0]->cols, ri_ws_, tail_w)) {
-                batch_path_.ri++; batch_path_.ri_ksplit++; batch_path_.ri_tail++; tail_done = true;
-                return;
-            }
             if (launch_matvec_ri(W, rp, y, res0 ? r : nullptr, n, act_, B, ld, s, px, pw, W[0]->cols, ri_ws_)) {
                 batch_path_.ri++; if (ri_ksplit(n * (W[0]->rows / 64), W[0]->cols, ri_ws_) > 1) batch_path_.ri_ksplit++;
                 return;
@@ -1077,7 +1069,6 @@ void Engine::forward_batch(int B, hipStream_t s) {
         return matvec_rows_prologue_ok(w0->type, w0->cols);
     };
     launch_get_rows(tok_type_, tok_raw_, E, d_btok_, B, x_, s);
-    bool rows_ready = false;                                // this layer's qkv rows were prepared by the previous layer's w2 launch (ri_tail_)
     for (size_t il = 0; il < layers_.size(); il++) {
         const LayerW &L = layers_[il];
         __half *kc = kc_ + il * C * E, *vc = vc_ + il * C * E;            // conversation 0's layer; the kernel adds slot * seq_stride
@@ -1121,8 +1112,7 @@ void Engine::forward_batch(int B, hipStream_t s) {
         else if (L.wk.type == L.wq.type && rows_pro({&L.wq, &L.wk}) && rows_pro({&L.wv})) {
             if (!qkv_mixed(true)) { mm({&L.wq, &L.wk}, {q_, k_}, nullptr, E, x_, L.attn_norm); mm({&L.wv}, {v_}, nullptr, E, x_, L.attn_norm); }
         } else {
-            if (!rows_ready) launch_rms_quant(x_, L.attn_norm, B, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s);
-            rows_ready = false;
+            launch_rms_quant(x_, L.attn_norm, B, E, act_, act_mask_for(L.wq.type) | act_mask_for(L.wk.type) | act_mask_for(L.wv.type), s);
             if (L.wv.type == L.wq.type && L.wk.type == L.wq.type) mm({&L.wq, &L.wk, &L.wv}, {q_, k_, v_}, nullptr, E);
             else if (qkv_mixed(false)) {}
             else if (L.wk.type == L.wq.type) { mm({&L.wq, &L.wk}, {q_, k_}, nullptr, E); mm({&L.wv}, {v_}, nullptr, E); }
@@ -1138,18 +1128,9 @@ void Engine::forward_batch(int B, hipStream_t s) {
             else { mm({&L.w1}, {h1_}, nullptr, F); mm({&L.w3}, {h3_}, nullptr, F); }
         }
         launch_silu_mul_quant(h1_, h3_, B, F, act_, act_mask_for(L.w2.type), tabs_dec_, s);
-        // MINIGPT4_RI_TAIL (round-6 experiment): the w2 launch's last workgroup prepares the next layer's qkv rows (rms_norm * attn_norm, Q8_K) -- only where that layer would
-        // take the standalone preparation (k-quant wq | wk | wv on prepared rows)
-        const float *tail_w = nullptr;
-        if (ri_tail_ && il + 1 < layers_.size()) {
-            const LayerW &Nx = layers_[il + 1];
-            const int nm = act_mask_for(Nx.wq.type) | act_mask_for(Nx.wk.type) | act_mask_for(Nx.wv.type);
-            const bool same = Nx.wv.type == Nx.wq.type && Nx.wk.type == Nx.wq.type;
-            if (nm == ACT_Q8K && Nx.wk.type == Nx.wq.type && !(same ? rows_pro({&Nx.wq, &Nx.wk, &Nx.wv}) : (rows_pro({&Nx.wq, &Nx.wk}) && rows_pro({&Nx.wv})))) tail_w = Nx.attn_norm;
-        }
-        tail_done = false;
-        mm({&L.w2}, {x_}, x_, E, nullptr, nullptr, tail_w);
-        rows_ready = tail_done;
+        // (Round 6 built the next layer's row preparation into this launch's last-arriving workgroup -- the round-5 verdict's item 3 i -- and measured 834-841 vs 994-1023 tok/s:
+        // profiles/r06_batched_producer_tail.log, commit 749954e.)
+        mm({&L.w2}, {x_}, x_, E);
     }
     // final norm inside the output matrix's MFMA launch
     if (B <= batch_rows_max_ && ri_fuse_ && ri_serves({&output_})) mm({&output_}, {blogits_}, nullptr, V, x_, norm_);

@@ -92,7 +92,7 @@ public:
     int decode_batch(const int *slots, int n, const SampleParams &p, int *ids_out, const int *forced = nullptr);
     // Which launches the LAST BUILT batched step (forward_batch: eager, or the capture of a graph) took, per kind -- so that a test / the bench can assert that the
     // operating point it means to check (k_matvec_ri, k_matvec_ri_mix, the K-split w2 launch) is the one that ran, instead of a fallback with the same results
-    struct BatchPath { int rows = 0, ri = 0, ri_mix = 0, ri_ksplit = 0, dot4 = 0, dot4_mix = 0, mul_mat = 0, sets = 0, ri_plain = 0, ri_tail = 0; };
+    struct BatchPath { int rows = 0, ri = 0, ri_mix = 0, ri_ksplit = 0, dot4 = 0, dot4_mix = 0, mul_mat = 0, sets = 0, ri_plain = 0; };
     const BatchPath &batch_path() const { return batch_path_; }
     static constexpr int MAX_CONVERSATIONS = 64;
 
@@ -198,7 +198,6 @@ private:
     bool computed_tables_ = true;
     // B = 4: w2 (80 row groups x long K) on the K-split form of k_matvec_ri (+1.9 %; MINIGPT4_RI_W2=0: the v_dot4 launch)
     bool ri_w2_ = true;
-    bool ri_tail_ = false;             // MINIGPT4_RI_TAIL (round 6 experiment): next layer's qkv rows prepared in the K-split w2 launch's tail
     bool ri_wo_ = false;               // MINIGPT4_RI_WO (round 6 experiment): wo on k_matvec_ri with the plain row quantisation in its prologue
     // ri_fuse_: rows prepared inside the MFMA launches -- measured slower (profiles/r05_batched_decode_inengine.log), off
     bool use_ri_ = true, ri_ready_ = false, ri_fuse_ = false;

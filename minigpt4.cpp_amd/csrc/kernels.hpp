@@ -91,7 +91,7 @@ void launch_ri_build(const QWeight &w, const RiPlanes &p, hipStream_t s);      /
 // process-global state, so two contexts decoding on different threads / streams never share slabs or tickets (round-5 advisor).
 struct RiWorkspace { float *slabs = nullptr; size_t slab_floats = 0; unsigned *tickets = nullptr; int n_tickets = 0; };
 bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s,
-                      const float *px = nullptr, const float *pw = nullptr, int ldx = 0, const RiWorkspace &ws = RiWorkspace{}, const float *tail_w = nullptr);   // px != null: rows t of px (stride ldx) are rms-normed with pw and quantised inside the launch (A unused)
+                      const float *px = nullptr, const float *pw = nullptr, int ldx = 0, const RiWorkspace &ws = RiWorkspace{});   // px != null: rows t of px (stride ldx) are rms-normed with pw and quantised inside the launch (A unused)
 // a "more bits" layer's set in one launch: na matrices of Q4_K / Q5_K + nb of Q6_K (na + nb <= 3), same shape, prepared rows
 bool launch_matvec_ri_mixed(const QWeight *const *Wa, const RiPlanes *const *ria, float *const *ya, int na, const QWeight *const *Wb, const RiPlanes *const *rib, float *const *yb, int nb,
                             const ActQ &A, int N, int ldy, hipStream_t s);

@@ -79,11 +79,7 @@ struct RiArgs { RiMat m[3]; int n_mat, groups_each, rows_each, K, N, ldy; const 
                 // ksplit > 1 (matrices with few row groups and a long K: the 13B w2 has 80 groups x 54 super-blocks): `ksplit` workgroups share a row
                 // group, each a contiguous K range; their partial sums go to `slabs` [group][part][4][64] and the LAST one to arrive (ticket per
                 // group, self-resetting) adds them in part order
-                int ksplit; float *slabs; unsigned *tickets;      // px: rows prepared inside the launch (PRO): rms_norm(px_t) * pw, quantised
-                // tail_w != null (round-6 experiment, K-split form with ONE matrix only): the workgroup that completes the LAST row group of the launch prepares the
-                // CONSUMER's rows -- rms_norm(y_t) * tail_w, Q8_K -- into the global planes `A` (the standalone k_rms_quant launch between this launch and the next is
-                // dropped); tail_ticket = index of the launch-wide arrival word in `tickets`
-                const float *tail_w; int tail_ticket; };
+                int ksplit; float *slabs; unsigned *tickets; };   // px: rows prepared inside the launch (PRO): rms_norm(px_t) * pw, quantised
 
 __device__ __forceinline__ void ri_scale_min_words(const v4i_r &h, unsigned &scw0, unsigned &scw1, unsigned &mw0, unsigned &mw1) {
     const unsigned s0 = (unsigned)h[1], s1 = (unsigned)h[2], s2 = (unsigned)h[3];
@@ -236,41 +232,6 @@ __device__ __forceinline__ void ri_stage_digits(const ActQ &A, int8_t *dg, float
     }
 }
 
-// The consumer's rows from the launch's finished outputs (RiArgs::tail_w): rms_norm(y_t) * w and ggml's Q8_K quantisation -- k_rms_quant's arithmetic -- by ONE workgroup, the
-// outputs read with cache-bypassing agent-scope loads (other workgroups wrote them through).  Not inlined: its 32 row registers must not reach the streaming loop's allocation.
-template <int NT>
-__device__ __attribute__((noinline)) void ri_tail_prepare(const float *y, int ldy, int KO, int N, const float *__restrict__ tail_w, const ActQ A, double *redd) {
-    constexpr int WPB = NT / 64, MAXR = 8192 / (NT * 4) > 0 ? 8192 / (NT * 4) : 1;                          // rows of <= 8192 outputs (the launcher checks)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int t = 0; t < N; t++) {
-        float xv[MAXR][4];
-        double sum = 0.0;
-#pragma unroll
-        for (int r = 0; r < MAXR; r++) {
-            const int i = (r * NT + (int)threadIdx.x) * 4; const bool in = i < KO;
-#pragma unroll
-            for (int e = 0; e < 4; e++) xv[r][e] = in ? __hip_atomic_load(y + (size_t)t * ldy + i + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-            double q = 0.0; q += (double)(xv[r][0] * xv[r][0]); q += (double)(xv[r][1] * xv[r][1]); q += (double)(xv[r][2] * xv[r][2]); q += (double)(xv[r][3] * xv[r][3]);
-            sum += q;
-        }
-        sum = wave_sum_d(sum);
-        __syncthreads();
-        if (lane == 0) redd[wv] = sum;
-        __syncthreads();
-        double tot = 0.0;
-        for (int w = 0; w < WPB; w++) tot += redd[w];
-        const float scale = 1.0f / sqrtf((float)(tot / (double)KO) + 1e-6f);
-#pragma unroll
-        for (int r = 0; r < MAXR; r++) {
-            const int i = (r * NT + (int)threadIdx.x) * 4; const bool in = i < KO; const int ic = in ? i : 0;
-            const float4 w4 = *reinterpret_cast<const float4 *>(tail_w + ic);
-            float v[4] = {(xv[r][0] * scale) * w4.x, (xv[r][1] * scale) * w4.y, (xv[r][2] * scale) * w4.z, (xv[r][3] * scale) * w4.w};
-            if (!in) { v[0] = 0.0f; v[1] = 0.0f; v[2] = 0.0f; v[3] = 0.0f; }
-            if ((r * NT + (int)(threadIdx.x & ~63u)) * 4 < KO) quant_emit4(v, in, i, (size_t)t, KO, A, ACT_Q8K);   // wave-uniform: a wave entirely past the row skips
-        }
-    }
-}
-
 // LDS image of the <= 4 activation rows (rows >= N are zero):  q8 [4][K]  |  dg [4][NSB][DG]  |  dk [4][NSB]  |  red [WPB][4][64]
 //   DG = 16 (Q4_K / Q5_K): the quantiser's digit-split per-32 sums (bytes 0..7 low digits of sub-blocks 0..7, 8..15 high digits)
 //   DG = 32 (Q6_K): the 16-element sums of the super-block in the ORDER OF THE SCALE BYTES (unit i = (n, c, h): byte 2 i <-> group 8 n + 2 c + h,
@@ -279,7 +240,7 @@ __device__ __attribute__((noinline)) void ri_tail_prepare(const float *y, int ld
 //                   (ggml_rms_norm: fp32 squares summed in double, eps 1e-6) and ggml's Q8_K quantisation, the arithmetic of k_rms_quant -- by every
 //                   workgroup into its own LDS image (the image is needed there anyway): one standalone preparation launch less in front of wq|wk|wv,
 //                   w1|w3 and the output matrix (~5 us each against ~1 us of redundant work per workgroup).
-template <int T, int WPB, bool PRO, bool TAIL = false>
+template <int T, int WPB, bool PRO>
 __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const ActQ A) {
     constexpr bool Q6 = T == GT_Q6_K;
     constexpr int DG = Q6 ? 32 : 16;
@@ -402,24 +363,9 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri(const RiArgs a, const
                     float tot = 0.0f;
                     for (int p = 0; p < S; p++) tot += __hip_atomic_load(a.slabs + (((size_t)g * S + p) * 4 + wv) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const size_t o = (size_t)wv * a.ldy + (size_t)gl * 64 + lane;
-                    const float val = M.res ? tot + M.res[o] : tot;
-                    if (TAIL && a.tail_w) __hip_atomic_store(M.y + o, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through: the tail workgroup (any CU, any XCD) reads it below
-                    else M.y[o] = val;
+                    M.y[o] = M.res ? tot + M.res[o] : tot;
                 }
                 if (threadIdx.x == 0) __hip_atomic_store(a.tickets + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
-                if (TAIL && a.tail_w) {                        // launch-uniform
-                    // second level: one arrival per completed row group; the workgroup that completes the last one holds every output of the launch behind write-through
-                    // stores and prepares the consumer's rows from them (same hand-off form as above: drained stores, one agent-scope arrival, cache-bypassing loads)
-                    __shared__ int s_tail;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    if (threadIdx.x == 0) s_tail = __hip_atomic_fetch_add(a.tickets + a.tail_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(total_groups - 1);
-                    __syncthreads();
-                    if (s_tail) {
-                        ri_tail_prepare<64 * WPB>(M.y, a.ldy, a.rows_each, N, a.tail_w, A, reinterpret_cast<double *>(red));
-                        if (threadIdx.x == 0) __hip_atomic_store(a.tickets + a.tail_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
             }
         }
         __syncthreads();
@@ -477,11 +423,11 @@ __global__ __launch_bounds__(64 * WPB, 2) void k_matvec_ri_mix(const RiArgs a, c
 static int g_ri_cus = 256;
 void set_ri_cus(int cus) { if (cus > 0) g_ri_cus = cus; }
 static size_t ri_lds(int type, int K, int wpb, bool pro) { const int NSB = K / 256; return (size_t)4 * K + (size_t)4 * NSB * (type == GT_Q6_K ? 32 : 16) + (size_t)4 * NSB * 4 + (size_t)wpb * 4 * 64 * 4 + (pro ? (size_t)4 * (K / 16) * 2 : 0); }
-template <int T, int WPB, bool PRO, bool TAIL = false>
+template <int T, int WPB, bool PRO>
 static void launch_ri_k(const RiArgs &a, const ActQ &A, unsigned blocks, size_t lds, hipStream_t s) {
     static bool attr = false;
-    if (!attr) { HIP_IGNORE(lds_optin_max(&k_matvec_ri<T, WPB, PRO, TAIL>)); attr = true; }
-    hipLaunchKernelGGL((k_matvec_ri<T, WPB, PRO, TAIL>), dim3(blocks), dim3(64 * WPB), lds, s, a, A);
+    if (!attr) { HIP_IGNORE(lds_optin_max(&k_matvec_ri<T, WPB, PRO>)); attr = true; }
+    hipLaunchKernelGGL((k_matvec_ri<T, WPB, PRO>), dim3(blocks), dim3(64 * WPB), lds, s, a, A);
 }
 template <int T>
 static bool launch_ri_t(const RiArgs &a, const ActQ &A, hipStream_t s) {
@@ -492,8 +438,7 @@ static bool launch_ri_t(const RiArgs &a, const ActQ &A, hipStream_t s) {
     const size_t lds = ri_lds(T, a.K, wide ? 8 : 4, pro);
     if (lds > (wide ? 150u : 78u) * 1024u) return false;
     if (wide) { const unsigned nb = (unsigned)std::min(total, g_ri_cus); if (pro) launch_ri_k<T, 8, true>(a, A, nb, lds, s); else launch_ri_k<T, 8, false>(a, A, nb, lds, s); }
-    else { const unsigned nb = (unsigned)std::min(total * std::max(1, a.ksplit), 2 * g_ri_cus);
-        if (a.tail_w) launch_ri_k<T, 4, false, true>(a, A, nb, lds, s); else if (pro) launch_ri_k<T, 4, true>(a, A, nb, lds, s); else launch_ri_k<T, 4, false>(a, A, nb, lds, s); }
+    else { const unsigned nb = (unsigned)std::min(total * std::max(1, a.ksplit), 2 * g_ri_cus); if (pro) launch_ri_k<T, 4, true>(a, A, nb, lds, s); else launch_ri_k<T, 4, false>(a, A, nb, lds, s); }
     return true;
 }
 // y[m][t * ldy + r] = W_m[r] . act[t] (+ residual[m][t * ldy + r]) for N = 1..4 prepared rows (A: Q8_K image incl. bsq) against 1..3 same-type,
@@ -508,7 +453,7 @@ int ri_ksplit(int total_groups, int K, const RiWorkspace &ws) {
     return std::max(1, S);
 }
 bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float *const *y, const float *const *residual, int n, const ActQ &A, int N, int ldy, hipStream_t s,
-                      const float *px, const float *pw, int ldx, const RiWorkspace &ws, const float *tail_w) {
+                      const float *px, const float *pw, int ldx, const RiWorkspace &ws) {
     if (n < 1 || n > 3 || N < 1 || N > 4) return false;
     if (px ? ldx < W[0]->cols : (!A.q8k || !A.dk || !A.bsk || !A.bsq)) return false;      // px with pw == null: rows quantised as they are (no norm)
     RiArgs a{};
@@ -520,12 +465,6 @@ bool launch_matvec_ri(const QWeight *const *W, const RiPlanes *const *ri, float 
     if (!ri_supported(W[0]->type, W[0]->rows, W[0]->cols)) return false;
     a.n_mat = n; a.groups_each = W[0]->rows / 64; a.rows_each = W[0]->rows; a.K = W[0]->cols; a.N = N; a.ldy = ldy;
     a.ksplit = ri_ksplit(n * a.groups_each, a.K, ws); a.slabs = ws.slabs; a.tickets = ws.tickets;
-    // the producer-tail row preparation: only on the K-split form (its per-group last arriver is where the outputs get their final value), one matrix, rows of <= 8192 outputs that
-    // are whole Q8_K blocks, the global planes present, and a spare ticket word
-    if (tail_w) {
-        if (!(a.ksplit > 1 && n == 1 && !px && W[0]->rows <= 8192 && W[0]->rows % 256 == 0 && ldy % 4 == 0 && A.q8k && A.dk && A.bsk && n * a.groups_each < ws.n_tickets)) return false;
-        a.tail_w = tail_w; a.tail_ticket = ws.n_tickets - 1;
-    }
     switch (W[0]->type) {
     case GT_Q4_K: return launch_ri_t<GT_Q4_K>(a, A, s);
     case GT_Q5_K: return launch_ri_t<GT_Q5_K>(a, A, s);
