@@ -164,6 +164,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     if (const char *e = getenv("MINIGPT4_SPLITK_FC2")) splitk_fc2_ = std::max(1, std::min(SPLITK_MAX, atoi(e)));     // K slices of the ViT's fc2 (default 4; A/B)
     // decode step: which row preparations ride in their consumer's prologue (bit 0 qkv, 1 wo, 2 w1|w3, 3 w2 <- SiLU * mul + quantisation, 4 output, 5 pair, 6 mixed qkv; default 87; A/B)
     if (const char *e = getenv("MINIGPT4_FUSE")) fuse_mask_ = atoi(e);
+    if (const char *e = getenv("MINIGPT4_F16_KS")) set_gemm_tuning(-1, atoi(e));     // forced K split of the F16 language model's single-matrix prompt launches (wo, w2; 0 = choose; A/B)
     if (const char *e = getenv("MINIGPT4_QF_SPLITK")) qf_splitk_ = atoi(e) != 0;     // 0: the Q-Former's dense / output layers as whole-K launches + standalone LayerNorm (A/B)
     if (const char *e = getenv("MINIGPT4_KV_HOIST")) kv_hoist_ = atoi(e) != 0;     // 0: one K | V projection GEMM per cross-attention layer (round-4 form, A/B)
     set_matvec_tuning(0, 0, prop.multiProcessorCount);

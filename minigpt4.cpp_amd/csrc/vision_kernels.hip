@@ -623,6 +623,7 @@ bool launch_gemm_f16_set(const __half *A, int lda, const __half *const *W, int n
         int ks = 1;
         if (n == 1 && out_floats % 4 == 0)
             while (wgs * (ks + 1) <= cus && (K / 64) / (ks + 1) >= 16 && ws && (size_t)(ks + 1) * out_floats <= ws_floats && ks < 4) ks++;
+        if (g_f16_ks > 0 && n == 1 && out_floats % 4 == 0 && ws && (size_t)g_f16_ks * out_floats <= ws_floats && (K / 64) / g_f16_ks >= 8) ks = g_f16_ks;   // experiments (MINIGPT4_F16_KS)
         const GemmSet gs{n > 1 ? N : 0, wstride, ystride, 0, 0};
         if (ks > 1) {
             if (launch_gemm_dma_t<256, 128, 2, 2, 1, 3>(A, lda, W[0], K, M, N, K, nullptr, nullptr, false, tb, ws, nullptr, ldo, s, ks, out_floats, gs)) {
