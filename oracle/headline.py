@@ -187,7 +187,8 @@ def compare(oracle: Dict, gpu_pieces: List[str], gpu_logits: np.ndarray) -> Dict
 # Reference behaviour to match: one INDEPENDENT conversation per context (minigpt4.cpp:2513-2521 holds one n_past / one KV cache; :2704-2718 end_chat_image), so every
 # conversation of a batched replica must behave like its own OracleChat.
 
-BATCH_PROMPTS = [PROMPT, "describe the colours of the image", "hello", "and now something longer to shift the positions of this conversation apart from the others"]
+BATCH_PROMPTS = [PROMPT, "hello", "describe the colours of the image", "and now something longer to shift the positions of this conversation apart from the others",
+                 "a", "what do you see?", "list every object in the scene, one per line", "zzz"]
 
 
 def embedding_struct(emb_np: np.ndarray):

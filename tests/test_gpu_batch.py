@@ -136,7 +136,7 @@ def test_mixed_type_layer_in_one_launch_full_width(gpu_lib, B, monkeypatch):
         gpu_lib.minigpt4_free(ref)
 
 
-@pytest.mark.parametrize("config,B,steps", [("13b_l2", 3, 16), ("13b_l2", 4, 16), ("13b", 4, 32)])
+@pytest.mark.parametrize("config,B,steps", [("13b_l2", 3, 16), ("13b_l2", 4, 16), ("13b", 4, 32), ("13b_l2", 2, 16), ("13b_l2", 5, 12), ("13b_l2", 8, 8)])
 def test_configs3_operating_point_matches_independent_oracle_chats(gpu_lib, config, B, steps):
     """BASELINE.json configs[3]'s per-GPU operating point AS THE ENGINE RUNS IT (round-5 verdict, missing #1): B = 3 / 4 image conversations per replica at the 13B width with
     MINIGPT4_RI at its default, i.e. the batched step on `k_matvec_ri` / `k_matvec_ri_mix` (row-interleaved weight image, v_mfma_i32_4x4x4i8) + the K-split w2 launch at
@@ -163,9 +163,16 @@ def test_configs3_operating_point_matches_independent_oracle_chats(gpu_lib, conf
         print(config, B, json.dumps({k: v for k, v in res.items() if k != "per_conversation"}))
         path = res["launches_of_the_batched_step"]
         n_layer = 2 if config.endswith("_l2") else 40
-        # the operating point itself: same-type sets and the output matrix on k_matvec_ri, every "more bits" layer's wq|wk + wv on k_matvec_ri_mix, w2 on the K-split form at B = 4
-        assert path["rows"] == B and path["ri"] >= n_layer + 1 and path["ri_mix"] >= 1 and path["dot4_mix"] == 0 and path["mul_mat"] == 0 and path["sets"] == 0, path
-        assert (path["ri_ksplit"] == n_layer) if B == 4 else (path["ri_ksplit"] == 0), path
+        if B in (3, 4):
+            # the operating point itself: same-type sets and the output matrix on k_matvec_ri, every "more bits" layer's wq|wk + wv on k_matvec_ri_mix, w2 on the K-split form at B = 4
+            assert path["rows"] == B and path["ri"] >= n_layer + 1 and path["ri_mix"] >= 1 and path["dot4_mix"] == 0 and path["mul_mat"] == 0 and path["sets"] == 0, path
+            assert (path["ri_ksplit"] == n_layer) if B == 4 else (path["ri_ksplit"] == 0), path
+        elif B == 2:
+            # two conversations (round 6: the other batch sizes at the 13B width against the oracle too): the v_dot4 multi-row launches, rows prepared in their prologues
+            assert path["rows"] == 2 and path["ri"] == 0 and path["ri_mix"] == 0 and path["dot4"] + path["dot4_mix"] >= 4 * n_layer and path["sets"] == 0, path
+        else:
+            # five and more: the prompt pass's int8-MFMA set launches, every layer
+            assert path["rows"] == B and path["sets"] == n_layer and path["ri"] == 0 and path["ri_mix"] == 0, path
         assert res["launches_free_running_step"] == path
         assert len(set(res["prompt_tokens"])) > 1                                  # the conversations sit at different positions
         assert res["free_running_identical_min"] == steps, res
