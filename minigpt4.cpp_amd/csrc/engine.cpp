@@ -165,6 +165,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     // decode step: which row preparations ride in their consumer's prologue (bit 0 qkv, 1 wo, 2 w1|w3, 3 w2 <- SiLU * mul + quantisation, 4 output, 5 pair, 6 mixed qkv; default 87; A/B)
     if (const char *e = getenv("MINIGPT4_FUSE")) fuse_mask_ = atoi(e);
     if (const char *e = getenv("MINIGPT4_F16_KS")) set_gemm_tuning(-1, atoi(e));     // forced K split of the F16 language model's single-matrix prompt launches (wo, w2; 0 = choose; A/B)
+    if (const char *e = getenv("MINIGPT4_QKV_HEAD_MAJOR")) qkv_head_major_ = atoi(e) != 0;
     if (const char *e = getenv("MINIGPT4_QF_SPLITK")) qf_splitk_ = atoi(e) != 0;     // 0: the Q-Former's dense / output layers as whole-K launches + standalone LayerNorm (A/B)
     if (const char *e = getenv("MINIGPT4_KV_HOIST")) kv_hoist_ = atoi(e) != 0;     // 0: one K | V projection GEMM per cross-attention layer (round-4 form, A/B)
     set_matvec_tuning(0, 0, prop.multiProcessorCount);
@@ -1475,8 +1476,13 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
         const bool last = ib + 1 == vblocks_.size();
         const float *nw = last ? v_lnv_w_ : vblocks_[ib + 1].n1w, *nb = last ? v_lnv_b_ : vblocks_[ib + 1].n1b;
         __half *nout = last ? vi_img_h_ : vi_ln_h_;
+        if (qkv_head_major_) {   // q | k | v stored [3][head][R][88]: every head's rows contiguous for the attention kernel (round 6; MINIGPT4_QKV_HEAD_MAJOR=0: rows of 3 x D, A/B, bit-identical)
+            launch_gemm_f16_head_major(vi_ln_h_, D, b.qkv_w, D, R, 3 * D, D, b.qkv_b, tabs_, vi_qkv_, D, 88, s);
+            launch_attn_f32(vi_qkv_, 88, vi_qkv_ + (size_t)D * R, vi_qkv_ + (size_t)2 * D * R, 88, 257, 257, v_heads_, 88, scale, 0.0f, tabs_vis_, nullptr, vi_att_h_, D, s, B, R * 88, R * 88);
+        } else {
         launch_gemm_f16(vi_ln_h_, D, b.qkv_w, D, R, 3 * D, D, b.qkv_b, nullptr, false, tabs_, vi_qkv_, nullptr, 3 * D, s);
         launch_attn_f32(vi_qkv_, 3 * D, vi_qkv_ + D, vi_qkv_ + 2 * D, 3 * D, 257, 257, v_heads_, 88, scale, 0.0f, tabs_vis_, nullptr, vi_att_h_, D, s, B);
+        }
         if (sp > 1) {
             launch_gemm_f16_splitk(vi_att_h_, D, b.proj_w, D, R, D, D, sp, vi_slab_, slab, D, s);
             launch_splitk_reduce_ln(vi_slab_, sp, slab, b.proj_b, vi_x_, R, D, vi_x_, b.n2w, b.n2b, nullptr, vi_ln_h_, s);

@@ -247,6 +247,7 @@ private:
     bool qf_fold_ = true, qf_folded_ = false, kv_hoist_ = true;
     void fold_qformer_constants();
     bool qf_splitk_ = true;
+    bool qkv_head_major_ = true;       // the ViT's qkv projection stores q | k | v head-major for k_attn_vit (round 6)
     void qf_dense_ln(const __half *A, int lda, const __half *W, int K, const float *bias, const float *residual, const float *ln_w, const float *ln_b, float *out, __half *out_h,
                      int rows, hipStream_t s);
 

@@ -168,6 +168,8 @@ void launch_delay(int us, hipStream_t s);   // profiling gate: keeps the stream 
 // Writes fp32 `out` (nullable) and/or fp16 `out_h` (nullable).  K must be a multiple of 16.
 void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual,
                      bool gelu, const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s);
+// fp32 output stored [N / D][D / hd][M][hd] (the ViT's qkv projection for k_attn_vit's head strides; vision_kernels.hip: struct HeadMajor)
+void launch_gemm_f16_head_major(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const Tables &tb, float *out, int D, int hd, hipStream_t s);
 // out = [residual +] gelu?(bias + y) over [rows][n] contiguous fp32 (y may alias out); writes fp32 (nullable) and / or fp16 (nullable)
 // the same product for FEW rows (the Q-Former's 32 queries per image): N / 16 workgroups, K split across the waves of a workgroup, no LDS staging.  false -> shape outside
 // the kernel's range (N % 16, K % 32), nothing launched
@@ -193,7 +195,7 @@ void launch_splitk_reduce_ln(const float *slabs, int n_slabs, size_t slab_stride
 // batch > 1: image z uses rows [z * nq, (z + 1) * nq) of q / out and rows [z * nk, (z + 1) * nk) of k / v.
 void set_attn_vit_qt(int qt);   // query tiles per workgroup of k_attn_vit (0 = the launcher's choice); experiments / A-B
 void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale,
-                     float score_div, const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s, int batch = 1);
+                     float score_div, const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s, int batch = 1, int head_stride_q = 0, int head_stride_kv = 0)   /* head strides in floats; 0 = hd (heads side by side in a row) */;
 // image CHW f32 [3][224][224] -> fp16 patches [256][ldp] (k = c*196 + kh*14 + kw, zero padded to ldp)
 void launch_im2col(const float *image, __half *patches, int ldp, hipStream_t s, int batch = 1);   // batch images back to back -> [batch * 256][ldp]
 // x[0] = cls + pos[0]; x[1+p] = pe[p] + pos[1+p]

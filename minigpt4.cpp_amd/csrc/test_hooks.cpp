@@ -468,7 +468,12 @@ int minigpt4_amd_bench_attn_f32_b(int heads, int hd, int nq, int nk, int batch, 
         Tables tb;                                                          // exp == null: computed exponentials
         const float scale = 1.0f / sqrtf((float)hd);
         struct QtScope { QtScope(int q) { set_attn_vit_qt(q); } ~QtScope() { set_attn_vit_qt(0); } } scope(qt);
-        auto run = [&]() { launch_attn_f32(dq.as<float>(), 3 * D, dq.as<float>() + D, dq.as<float>() + 2 * D, 3 * D, nq, nk, heads, hd, scale, 0.0f, tb, nullptr, douth.as<__half>(), D, nullptr, batch); };
+        // MG4_ATTN_HEAD_MAJOR=1 (experiment): q | k | v as [3][head][batch x rows][hd] instead of [rows][3 x heads x hd]
+        const bool hm = getenv("MG4_ATTN_HEAD_MAJOR") && atoi(getenv("MG4_ATTN_HEAD_MAJOR"));
+        const int R = batch * nq;
+        auto run = [&]() {
+            if (hm) launch_attn_f32(dq.as<float>(), hd, dq.as<float>() + (size_t)D * R, dq.as<float>() + (size_t)2 * D * R, hd, nq, nk, heads, hd, scale, 0.0f, tb, nullptr, douth.as<__half>(), D, nullptr, batch, R * hd, R * hd);
+            else launch_attn_f32(dq.as<float>(), 3 * D, dq.as<float>() + D, dq.as<float>() + 2 * D, 3 * D, nq, nk, heads, hd, scale, 0.0f, tb, nullptr, douth.as<__half>(), D, nullptr, batch); };
         for (int i = 0; i < 3; i++) run();
         HIP_CHECK(hipDeviceSynchronize());
         hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));

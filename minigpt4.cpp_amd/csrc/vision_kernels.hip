@@ -38,6 +38,18 @@ int read_vision_timeline(unsigned long long *out, int max_workgroups) {
 #endif
 }
 
+// Head-major output (round 6): the ViT's qkv projection stores its [rows][3 x heads x hd] result as [3][head][rows][hd] -- every head's Q, K and V rows contiguous (rows x hd floats)
+// instead of hd-float pieces 3 x D floats apart -- because that is what the attention kernel wants to stream: 16-key tiles become one contiguous 5.6 KB block (45 cache lines instead
+// of 64 half-used ones): k_attn_vit 16.4 -> 14.6 us at one image, 39.3 -> 35.3 at four (profiles/r06_attn_query_tiles.log, run 26).  Same values, same arithmetic: only the address
+// of an output element changes (column c of row r -> ((c / D) * heads + (c % D) / hd) * rows * hd + r * hd + c % hd).  rows == 0: the plain [row][ldo] layout.
+struct HeadMajor { int rows, D, hd; };
+static thread_local HeadMajor t_hm{0, 0, 0};       // set around ONE dispatcher call by launch_gemm_f16_head_major (per thread: two contexts on two threads never see each other's)
+__device__ __forceinline__ void gemm_out_map(const HeadMajor &hm, int col, int ldo, int &row_mul, unsigned &col_off) {
+    if (hm.rows > 0) {
+        const int which = col / hm.D, c = col - which * hm.D, head = c / hm.hd, d = c - head * hm.hd;
+        row_mul = hm.hd; col_off = (unsigned)((which * (hm.D / hm.hd) + head) * hm.rows * hm.hd + d);
+    } else { row_mul = ldo; col_off = (unsigned)col; }
+}
 // Workgroup -> (tile, K slice).  Blocks are dealt round-robin to the 8 XCDs (XCD = blockIdx.x & 7), each with its own 4 MB L2.  The work list of a launch is
 // [K slice][column tile][row tile] (row tile fastest) and XCD x owns the CONTIGUOUS range [x * per, (x + 1) * per) of it, per = ceil(slices * tiles / 8): the row tiles
 // that share a weight tile sit on one XCD, every XCD gets the same number of workgroups +- 1, and -- round 6 -- an XCD walks ONE K slice (or two neighbouring ones), not
@@ -76,7 +88,7 @@ static inline unsigned gemm_grid_x(int tile_n, int slices, bool on_xcds) { retur
 template <int BK, int GB_M, int BN, int TM, int TN, bool GELU, bool RES>
 __global__ __launch_bounds__(GB_M / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm_f16(const __half *__restrict__ A, int lda, const __half *__restrict__ W, int ldw, int M, int N, int K,
                                                   const float *__restrict__ bias, const float *residual, const Tables tb,
-                                                  float *out, __half *__restrict__ out_h, int ldo, int k_per_slice, size_t slab_stride, int xs) {
+                                                  float *out, __half *__restrict__ out_h, int ldo, int k_per_slice, size_t slab_stride, int xs, const HeadMajor hm) {
     constexpr int LD = BK + 8;                 // +16 bytes per row: conflict-free ds_read_b128 for BK = 32/64/128/256
     constexpr int CPR = BK / 8;                // 16-byte chunks per row
     constexpr int WNN = BN / (32 * TN), NT = GB_M / (32 * TM) * WNN * 64;
@@ -181,13 +193,14 @@ __global__ __launch_bounds__(GB_M / (32 * TM) * (BN / (32 * TN)) * 64) void k_ge
 #pragma unroll
     for (int b = 0; b < TN; b++) {
         const int col = n0 + (wn * TN + b) * 32 + lcol;
+        int rmul; unsigned coff; gemm_out_map(hm, min(col, N - 1), ldo, rmul, coff);
 #pragma unroll
         for (int a = 0; a < TM; a++) {
             float v[16]; unsigned o[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                o[r] = row < M && col < N ? (unsigned)(row * ldo + col) : 0x20000000u;   // x 4 = 0x80000000, x 2 = 0x40000000: both past any tensor of this path
+                o[r] = row < M && col < N ? (unsigned)(row * rmul) + coff : 0x20000000u;   // x 4 = 0x80000000, x 2 = 0x40000000: both past any tensor of this path
                 v[r] = bias ? bv[b] + acc[a][b][r] : acc[a][b][r];
             }
             if (GELU) {
@@ -228,10 +241,10 @@ static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, in
         HIP_IGNORE(lds_optin_max(&k_gemm_f16<BK, BM, BN, TM, TN, true, false>));
         HIP_IGNORE(lds_optin_max(&k_gemm_f16<BK, BM, BN, TM, TN, false, true>));
         HIP_IGNORE(lds_optin_max(&k_gemm_f16<BK, BM, BN, TM, TN, false, false>)); attr = true; }
-    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride, xs);
-    else if (gelu) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride, xs);
-    else if (residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride, xs);
-    else hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride, xs);
+    if (gelu && residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, true, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride, xs, t_hm);
+    else if (gelu) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, true, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride, xs, t_hm);
+    else if (residual) hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, false, true>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride, xs, t_hm);
+    else hipLaunchKernelGGL((k_gemm_f16<BK, BM, BN, TM, TN, false, false>), grid, block, lds, s, A, lda, W, ldw, M, N, K, bias, residual, tb, out, out_h, ldo, k_per_slice, slab_stride, xs, t_hm);
 }
 // =====================================================================================================================
 // LDS-DMA ring form of the small-M GEMM (round 3).  The timeline of k_gemm_f16 put the k loop at 0.5 us per 64x64x128 step against 0.21 us of MFMA: the
@@ -246,7 +259,7 @@ static void launch_gemm_t(const __half *A, int lda, const __half *W, int ldw, in
 typedef __attribute__((address_space(3))) void *g_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *g_glb_ptr_t;
 // several equally spaced, equally shaped weight matrices in one launch (column tile -> matrix), and / or a K range split over grid.z with one fp32 slab per slice
-struct GemmSet { int n_per_mat; long long w_mat_stride, out_mat_stride; int k_per_slice; long long slab_stride; int xs; };   // all zero: one matrix, whole K; xs: gemm_tile_of_block
+struct GemmSet { int n_per_mat; long long w_mat_stride, out_mat_stride; int k_per_slice; long long slab_stride; int xs; HeadMajor hm; };   // all zero: one matrix, whole K; xs: gemm_tile_of_block
 // PAIR (TN = 2, no GELU / residual): the feed-forward pair of an F16 language model in one tile -- the BN tile columns are 32-column blocks taken alternately from W
 // (w1) and W + gs.w_mat_stride (w3), rows n0 .. of both, so a wave's two column tiles hold (w1 x)[r][c] and (w3 x)[r][c] for the SAME (r, c) and the epilogue stores
 // fp16(silu_table(w1 x) * (w3 x)) -- the row w2 multiplies -- instead of the two fp32 products (56 MB written and read back per 512-row layer, and a launch).
@@ -381,13 +394,14 @@ __global__ __launch_bounds__(BM / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm
 #pragma unroll
     for (int b = 0; b < TN; b++) {
         const int col = n0 + (wn * TN + b) * 32 + lcol;
+        int rmul; unsigned coff; gemm_out_map(gs.hm, min(col, N - 1), ldo, rmul, coff);
 #pragma unroll
         for (int a = 0; a < TM; a++) {
             float v[16]; unsigned o[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                o[r] = row < M && col < N ? (unsigned)(row * ldo + col) : 0x20000000u;
+                o[r] = row < M && col < N ? (unsigned)(row * rmul) + coff : 0x20000000u;
                 v[r] = bias ? bv[b] + acc[a][b][r] : acc[a][b][r];
             }
             if (GELU) {
@@ -424,6 +438,7 @@ static bool launch_gemm_dma_t(const __half *A, int lda, const __half *W, int ldw
     const int ntx = (N + BN - 1) / BN, rt = (M + BM - 1) / BM;
     const bool sx = splitk_on_xcds(slices) && gs.n_per_mat == 0;
     gs.xs = sx ? slices : 0;
+    gs.hm = t_hm;
     dim3 grid(gemm_grid_x(ntx * rt, slices, sx), 1, sx ? 1u : (unsigned)slices), block(BM / (32 * TM) * (BN / (32 * TN)) * 64);
     const size_t lds = (size_t)S * KT * (BM + BN) * 128;
     static bool attr = false;
@@ -547,13 +562,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restric
     for (int j = 0; j < 2; j++) {
         const int col = n0 + wn * 64 + j * 32 + l31, colc = min(col, N - 1);
         const float bv = bias ? bias[colc] : 0.0f;
+        int rmul; unsigned coff; gemm_out_map(gs.hm, colc, ldo, rmul, coff);
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             float v[16]; unsigned o[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                o[r] = row < M && col < N ? (unsigned)(row * ldo + col) : 0x20000000u;
+                o[r] = row < M && col < N ? (unsigned)(row * rmul) + coff : 0x20000000u;
                 v[r] = bias ? bv + acc[i][j][r] : acc[i][j][r];
             }
             if (GELU) {
@@ -584,7 +600,8 @@ void set_gemm_tuning(int big_min_m, int f16_ks, int arm, int sk_arm) {
     if (sk_arm >= 0) g_gemm_sk_arm = sk_arm;
 }
 static bool launch_gemm_big(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const float *residual, bool gelu, const Tables &tb,
-                            float *out, __half *out_h, int ldo, hipStream_t s, const GemmSet gs = GemmSet{0, 0, 0, 0, 0}, int slices = 1) {
+                            float *out, __half *out_h, int ldo, hipStream_t s, const GemmSet gs_in = GemmSet{0, 0, 0, 0, 0}, int slices = 1) {
+    GemmSet gs = gs_in; gs.hm = t_hm;
     static bool init = false;
     if (!init) { init = true;
         HIP_IGNORE(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16_big<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -799,6 +816,13 @@ void launch_gemm_f16(const __half *A, int lda, const __half *W, int ldw, int M, 
         if (shapes[pick].arm == 32 && launch_gemm_big(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s)) return;
     }
     launch_gemm_t<128, 64, 64>(A, lda, W, ldw, M, N, K, bias, residual, gelu, tb, out, out_h, ldo, s);
+}
+// The same GEMM with its fp32 output stored head-major (struct HeadMajor above): N = 3 x D columns -> out[3][D / hd][M][hd].  Every tile shape the dispatcher may pick maps its
+// stores the same way, so the choice still never changes a value or where it lands.
+void launch_gemm_f16_head_major(const __half *A, int lda, const __half *W, int ldw, int M, int N, int K, const float *bias, const Tables &tb, float *out, int D, int hd, hipStream_t s) {
+    if (D <= 0 || hd <= 0 || D % hd || N % D) throw HipError{hipErrorInvalidValue, "head-major GEMM output: N must be a multiple of D and D of hd", __FILE__, __LINE__};
+    struct Scope { Scope(int rows, int D_, int hd_) { t_hm = HeadMajor{rows, D_, hd_}; } ~Scope() { t_hm = HeadMajor{0, 0, 0}; } } scope(M, D, hd);
+    launch_gemm_f16(A, lda, W, ldw, M, N, K, bias, nullptr, false, tb, out, nullptr, N, s);
 }
 
 // tile-shape arms of k_gemm_f16 for the micro-benchmark (test library only calls this): 3 = BK 64, 4 = 128x64 tiles, 5 = 64x128 tiles, 6 = BK 256
@@ -1102,9 +1126,9 @@ __device__ __forceinline__ void attn_vit_scores(const float (&kf)[TPW][4 * ((HD 
     }
 }
 template <int HD>
-__device__ __forceinline__ void attn_vit_load_q(const float *__restrict__ q, int ldq, int row, int h, int g, float q_prescale, float (&qf)[4 * ((HD + 15) / 16)]) {
+__device__ __forceinline__ void attn_vit_load_q(const float *__restrict__ q, int ldq, int row, size_t hoff, int g, float q_prescale, float (&qf)[4 * ((HD + 15) / 16)]) {
     constexpr int DT = (HD + 15) / 16;
-    const float *qp = q + (size_t)row * ldq + h * HD;
+    const float *qp = q + (size_t)row * ldq + hoff;
 #pragma unroll
     for (int u = 0; u < DT; u++) {
         const int d0 = 16 * u + 4 * g;
@@ -1123,7 +1147,8 @@ __device__ __forceinline__ void attn_vit_load_q(const float *__restrict__ q, int
 // 7.38 vs 7.25 at four; profiles/r06_attn_query_tiles.log.)
 template <int HD, int TPW, bool MULTI, bool COMPUTED>
 __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, int ldq, const float *__restrict__ k, const float *__restrict__ v, int ldk, int nq, int nk,
-                                                  float q_prescale, float score_div, const Tables tb, float *__restrict__ out, __half *__restrict__ out_h, int ldo, int qt) {
+                                                  float q_prescale, float score_div, const Tables tb, float *__restrict__ out, __half *__restrict__ out_h, int ldo, int qt, int hsq, int hsk) {
+    // hsq / hsk: floats between consecutive heads of q and of k / v (HD when the heads sit side by side in a row; rows x HD in the head-major layout)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int DT = (HD + 15) / 16, KS4 = 4 * DT;
     static_assert(HD % 4 == 0, "16-byte row pieces");
@@ -1152,11 +1177,12 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
     // instruction, and the address path, not the 90 KB of K, set the kernel's time.)  MFMA step (u, e) therefore reduces over dims {16 u + 4 g + e : g}; dims past HD
     // (HD = 88: u = 5, g >= 2) contribute zeros.
     float qf[KS4];
-    attn_vit_load_q<HD>(q, ldq, min(q0 + j, nq - 1), h, g, q_prescale, qf);
+    const size_t hoq = (size_t)h * hsq, hok = (size_t)h * hsk;
+    attn_vit_load_q<HD>(q, ldq, min(q0 + j, nq - 1), hoq, g, q_prescale, qf);
     float kf[TPW][KS4];
 #pragma unroll
     for (int t = 0; t < TPW; t++) {
-        const float *kp = k + (size_t)min((wave + 4 * t) * 16 + j, nk - 1) * ldk + h * HD;
+        const float *kp = k + (size_t)min((wave + 4 * t) * 16 + j, nk - 1) * ldk + hok;
 #pragma unroll
         for (int u = 0; u < DT; u++) {
             const float4 x = *reinterpret_cast<const float4 *>(kp + min(16 * u + 4 * g, HD - 4));
@@ -1176,7 +1202,7 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
     for (int t = 0; t < TPW; t++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const float *vp = v + (size_t)min((wave + 4 * t) * 16 + 4 * g + r, nk - 1) * ldk + h * HD;
+            const float *vp = v + (size_t)min((wave + 4 * t) * 16 + 4 * g + r, nk - 1) * ldk + hok;
 #pragma unroll
             for (int dt = 0; dt < DT; dt++) vf[t][r][dt] = vp[min(dt * 16 + j, HD - 1)];
         }
@@ -1185,7 +1211,7 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
     for (;;) {
         const bool more = MULTI && q0 + 16 < q_end;                         // workgroup-uniform
         float qn[KS4];
-        if (more) attn_vit_load_q<HD>(q, ldq, min(q0 + 16 + j, nq - 1), h, g, q_prescale, qn);   // the next tile's Q rows travel during this tile's softmax
+        if (more) attn_vit_load_q<HD>(q, ldq, min(q0 + 16 + j, nq - 1), hoq, g, q_prescale, qn);   // the next tile's Q rows travel during this tile's softmax
         mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
         if (g == 0) red_m[wave * 16 + j] = mx;
         __syncthreads();
@@ -1290,7 +1316,9 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float *__restrict__ q, i
 static int g_attn_qt = 0;                          // forced query tiles per workgroup (0 = choose); experiments / A-B only (set_attn_vit_qt)
 void set_attn_vit_qt(int qt) { g_attn_qt = qt < 0 ? 0 : qt; }
 void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, int ldk, int nq, int nk, int heads, int hd, float q_prescale, float score_div,
-                     const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s, int batch) {
+                     const Tables &tb, float *out, __half *out_h, int ldo, hipStream_t s, int batch, int hsq, int hsk) {
+    if (hsq <= 0) hsq = hd;
+    if (hsk <= 0) hsk = hd;
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KiB of dynamic LDS for the table forms (gfx950 has 160 KiB per CU)
         HIP_IGNORE(lds_optin_max(&k_attn_vit<88, 5, false, false>)); HIP_IGNORE(lds_optin_max(&k_attn_vit<88, 5, true, false>));
@@ -1312,7 +1340,7 @@ void launch_attn_f32(const float *q, int ldq, const float *k, const float *v, in
     if (hd == 64 && nk <= 64) qt = 1;                                       // the Q-Former's self-attention (32 x 32): the short-key instantiation has no looping form
     const bool comp = tb.exp == nullptr;
     dim3 grid((unsigned)heads, (unsigned)((tiles + qt - 1) / qt), (unsigned)batch);
-#define MG4_ATTN_LAUNCH(HD_, TPW_, MULTI_, COMP_) hipLaunchKernelGGL((k_attn_vit<HD_, TPW_, MULTI_, COMP_>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo, qt)
+#define MG4_ATTN_LAUNCH(HD_, TPW_, MULTI_, COMP_) hipLaunchKernelGGL((k_attn_vit<HD_, TPW_, MULTI_, COMP_>), grid, dim3(256), lds_v, s, q, ldq, k, v, ldk, nq, nk, q_prescale, score_div, tb, out, out_h, ldo, qt, hsq, hsk)
     if (hd == 88) { if (qt > 1) { if (comp) MG4_ATTN_LAUNCH(88, 5, true, true); else MG4_ATTN_LAUNCH(88, 5, true, false); } else { if (comp) MG4_ATTN_LAUNCH(88, 5, false, true); else MG4_ATTN_LAUNCH(88, 5, false, false); } }
     else if (nk <= 64) { if (comp) MG4_ATTN_LAUNCH(64, 1, false, true); else MG4_ATTN_LAUNCH(64, 1, false, false); }
     else { if (qt > 1) { if (comp) MG4_ATTN_LAUNCH(64, 5, true, true); else MG4_ATTN_LAUNCH(64, 5, true, false); } else { if (comp) MG4_ATTN_LAUNCH(64, 5, false, true); else MG4_ATTN_LAUNCH(64, 5, false, false); } }

@@ -811,7 +811,7 @@ def test_round6_encoder_arms_are_bit_identical_at_full_size(gpu_lib, monkeypatch
     def run(env):
         for k in ("MINIGPT4_SPLITK_XCD", "MINIGPT4_ATTN_QT"):          # these two switches are process-wide: every arm sets both
             monkeypatch.setenv(k, env.get(k, "1" if k == "MINIGPT4_SPLITK_XCD" else "0"))
-        for k in ("MINIGPT4_QF_FOLD", "MINIGPT4_KV_HOIST", "MINIGPT4_QF_SPLITK"):   # per context
+        for k in ("MINIGPT4_QF_FOLD", "MINIGPT4_KV_HOIST", "MINIGPT4_QF_SPLITK", "MINIGPT4_QKV_HEAD_MAJOR"):   # per context
             if k in env:
                 monkeypatch.setenv(k, env[k])
             else:
@@ -831,7 +831,8 @@ def test_round6_encoder_arms_are_bit_identical_at_full_size(gpu_lib, monkeypatch
     assert not np.array_equal(base3[1], base3[0])
     try:
         # (round 5's two Q-Former arms ride along: the constant head of layer 0 recomputed per encode, one K | V projection per cross layer -- same launches, same bits)
-        for env in ({"MINIGPT4_SPLITK_XCD": "0"}, {"MINIGPT4_ATTN_QT": "2"}, {"MINIGPT4_ATTN_QT": "5"}, {"MINIGPT4_QF_FOLD": "0"}, {"MINIGPT4_KV_HOIST": "0"}):
+        for env in ({"MINIGPT4_SPLITK_XCD": "0"}, {"MINIGPT4_ATTN_QT": "2"}, {"MINIGPT4_ATTN_QT": "5"}, {"MINIGPT4_QF_FOLD": "0"}, {"MINIGPT4_KV_HOIST": "0"},
+                    {"MINIGPT4_QKV_HEAD_MAJOR": "0"}):                     # q | k | v as rows of 3 x D instead of [3][head][rows][88]: only addresses differ
             one, two, three = run(env)
             assert np.array_equal(one, base1), env
             assert all(np.array_equal(a, b) for a, b in zip(three, base3)) and all(np.array_equal(a, b) for a, b in zip(two, base2)), env
