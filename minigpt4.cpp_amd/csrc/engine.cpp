@@ -165,6 +165,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     // decode step: which row preparations ride in their consumer's prologue (bit 0 qkv, 1 wo, 2 w1|w3, 3 w2 <- SiLU * mul + quantisation, 4 output, 5 pair, 6 mixed qkv; default 87; A/B)
     if (const char *e = getenv("MINIGPT4_FUSE")) fuse_mask_ = atoi(e);
     if (const char *e = getenv("MINIGPT4_F16_KS")) set_gemm_tuning(-1, atoi(e));     // forced K split of the F16 language model's single-matrix prompt launches (wo, w2; 0 = choose; A/B)
+    if (const char *e = getenv("MINIGPT4_COMPUTED_GELU")) computed_gelu_ = atoi(e) != 0;   // 0: the vision GEMMs' GELU epilogues gather from the fp16 table (A/B)
     if (const char *e = getenv("MINIGPT4_QKV_HEAD_MAJOR")) qkv_head_major_ = atoi(e) != 0;
     if (const char *e = getenv("MINIGPT4_QF_SPLITK")) qf_splitk_ = atoi(e) != 0;     // 0: the Q-Former's dense / output layers as whole-K launches + standalone LayerNorm (A/B)
     if (const char *e = getenv("MINIGPT4_KV_HOIST")) kv_hoist_ = atoi(e) != 0;     // 0: one K | V projection GEMM per cross-attention layer (round-4 form, A/B)
@@ -622,6 +623,7 @@ void Engine::alloc_buffers() {
         if (computed_tables_) { tabs_dec_.exp = nullptr; tabs_dec_.silu = nullptr; }
         tabs_vis_ = tabs_;
         if (computed_tables_) tabs_vis_.exp = nullptr;          // the ViT / Q-Former attention of fast mode computes its exponentials (no 40 KB table DMA per workgroup)
+        if (computed_tables_ && computed_gelu_) tabs_vis_.gelu = nullptr;     // ... and the GELU epilogues of its GEMMs compute the table's values (round 6)
     }
     x_ = takef(B * E); q_ = takef(B * E); k_ = takef(B * E); v_ = takef(B * E); att_ = takef(B * E);
     h1_ = takef(B * F); h3_ = takef(B * F); logits_ = takef(S * V); blogits_ = takef(S * V);
@@ -1490,7 +1492,7 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
             launch_gemm_f16(vi_att_h_, D, b.proj_w, D, R, D, D, b.proj_b, vi_x_, false, tabs_, vi_x_, nullptr, D, s);
             launch_layernorm(vi_x_, b.n2w, b.n2b, R, D, nullptr, vi_ln_h_, s);
         }
-        launch_gemm_f16(vi_ln_h_, D, b.fc1_w, D, R, M, D, b.fc1_b, nullptr, true, tabs_, nullptr, vi_mlp_h_, M, s);
+        launch_gemm_f16(vi_ln_h_, D, b.fc1_w, D, R, M, D, b.fc1_b, nullptr, true, tabs_vis_, nullptr, vi_mlp_h_, M, s);
         if (sf > 1) {
             launch_gemm_f16_splitk(vi_mlp_h_, M, b.fc2_w, M, R, D, M, sf, vi_slab_, slab, D, s);
             launch_splitk_reduce_ln(vi_slab_, sf, slab, b.fc2_b, vi_x_, R, D, vi_x_, nw, nb, nullptr, nout, s);
@@ -1503,7 +1505,7 @@ int Engine::encode_images(const float *const *chw, int B, float *const *out) {
     // Q-Former (masks are all-zero).  Its GEMMs have 32 rows per image: the skinny-M kernel (MINIGPT4_QF_SKINNY=0: the
     // 64x64-tile kernel, A/B)
     auto qgemm = [&](const __half *A, int lda, const __half *W, int ldw, int Mr, int N, int K, const float *bias, const float *residual, bool gelu, float *o, __half *oh, int ldo) {
-        if (!(qf_skinny_ && launch_gemm_f16_skinny(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_, o, oh, ldo, s))) launch_gemm_f16(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_, o, oh, ldo, s);
+        if (!(qf_skinny_ && launch_gemm_f16_skinny(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_vis_, o, oh, ldo, s))) launch_gemm_f16(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_vis_, o, oh, ldo, s);
     };
     // a 768-wide dense / output layer + residual + the LayerNorm behind it (NNSelfAttention's output block, NNBertEncoderLayer's query FFN output: minigpt4.cpp:1365-1400,
     // 1430-1461).  Round 6: K split over 2 (K = 768) or 4 (K = 3072) workgroups per tile with the LayerNorm in the slab reduce (qf_dense_ln below).
@@ -1577,7 +1579,7 @@ void Engine::fold_qformer_constants() {
     const int H = 768, NQ = v_nq_;
     const QLayer &L = qlayers_[0];
     auto qgemm = [&](const __half *A, int lda, const __half *W, int ldw, int Mr, int N, int K, const float *bias, const float *residual, bool gelu, float *o, __half *oh, int ldo) {
-        if (!(qf_skinny_ && launch_gemm_f16_skinny(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_, o, oh, ldo, s))) launch_gemm_f16(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_, o, oh, ldo, s);
+        if (!(qf_skinny_ && launch_gemm_f16_skinny(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_vis_, o, oh, ldo, s))) launch_gemm_f16(A, lda, W, ldw, Mr, N, K, bias, residual, gelu, tabs_vis_, o, oh, ldo, s);
     };
     launch_layernorm(vi_qtok_rep_, v_qeln_w_, v_qeln_b_, NQ, H, vi_hs_, vi_hs_h_, s);
     qgemm(vi_hs_h_, H, L.self.q_w, H, NQ, 3 * H, H, L.self.q_b, nullptr, false, vi_qq_, nullptr, 3 * H);

@@ -174,7 +174,7 @@ private:
     // tabs_ = ggml's three fp16 tables (GELU, SiLU, exp) as the host libm evaluates them: what parity mode, every prompt pass and every GELU read.
     // tabs_dec_ = what the DECODE step's attention and SiLU launches get, tabs_vis_ = what the ViT / Q-Former attention gets: copies of tabs_ whose exp (and, for the decode step, silu)
     // pointers are NULL when MINIGPT4_COMPUTED_TABLES is on (the default) -- the kernels then compute the table VALUES (qtraits.hpp exp_h / silu_h: equal to the table's up to one fp16
-    // ulp in ~1 of 10^4 values) instead of gathering them from the 128 KB tables
+    // ulp in ~1 of 10^4 values) instead of gathering them from the 128 KB tables; tabs_vis_.gelu is NULL too (computed_gelu_): the vision GEMMs' GELU epilogues compute (gelu_v)
     Tables tabs_dec_, tabs_vis_;
     // activations
     float *x_ = nullptr, *q_ = nullptr, *k_ = nullptr, *v_ = nullptr, *att_ = nullptr, *h1_ = nullptr, *h3_ = nullptr, *logits_ = nullptr;
@@ -196,6 +196,7 @@ private:
     // built by set_conversations(n > 1) -- a context with one conversation never pays the memory.  MINIGPT4_RI=0: the v_dot4 multi-row mat-vec of
     // rounds 2-4 (A/B)
     bool computed_tables_ = true;
+    bool computed_gelu_ = true;        // with computed_tables_: the vision GEMMs' GELU epilogues compute the table's values too (round 6)
     // B = 4: w2 (80 row groups x long K) on the K-split form of k_matvec_ri (+1.9 %; MINIGPT4_RI_W2=0: the v_dot4 launch)
     bool ri_w2_ = true;
     bool ri_wo_ = false;               // MINIGPT4_RI_WO (round 6 experiment): wo on k_matvec_ri with the plain row quantisation in its prologue

@@ -17,6 +17,16 @@ typedef unsigned v4u_g __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned short f2h_bits_v(float f) { return __half_as_ushort(f2h_rn(f)); }
 __device__ __forceinline__ float tab_v(const __half *t, float x) { return __half2float(t[f2h_bits_v(x)]); }
+// GELU through ggml's fp16 table, or (t == null: fast mode, round 6) the table's VALUE computed: table[x] = fp16(0.5 x (1 + tanhf(sqrt(2 / pi) x (1 + 0.044715 x^2)))) on the fp16-rounded
+// argument, with tanh(u) = 1 - 2 / (exp(2 u) + 1) on the device's exp -- the host table's entry except within ~1e-7 of an fp16 rounding boundary (as exp_h / silu_h, qtraits.hpp).
+// A GEMM tile's epilogue gathers 16-64 table entries per lane from a 128 KB table: at four images that is 7 us of the 39 us fc1 launch.
+__device__ __forceinline__ float gelu_v(const __half *t, float x) {
+    if (t) return tab_v(t, x);
+    const float xh = __half2float(f2h_rn(x));
+    const float u = 0.79788456080286535587989211986876f * xh * (1.0f + 0.044715f * xh * xh);
+    const float th = 1.0f - 2.0f / (__expf(2.0f * u) + 1.0f);
+    return __half2float(f2h_rn(0.5f * xh * (1.0f + th)));
+}
 
 // In-kernel timeline of the image path's kernels (diagnostic builds only, as the mat-vec's: make EXTRA=-DMG4_TIMELINE OUT=../libminigpt4_tl.so OBJ=build_tl).  Thread 0 of
 // every workgroup stamps the 100 MHz constant clock into 32 slots; the last launch wins; read with minigpt4_amd_timeline_vision (tools/timeline_gemm.py).
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(GB_M / (32 * TM) * (BN / (32 * TN)) * 64) void k_ge
             }
             if (GELU) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) v[r] = tab_v(tb.gelu, v[r]);
+                for (int r = 0; r < 16; r++) v[r] = gelu_v(tb.gelu, v[r]);
             }
             if (RES) {
                 float rr[16];
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(BM / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm
             }
             if (GELU) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) v[r] = tab_v(tb.gelu, v[r]);
+                for (int r = 0; r < 16; r++) v[r] = gelu_v(tb.gelu, v[r]);
             }
             if (RES) {
                 float rr[16];
@@ -574,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_big(const __half *__restric
             }
             if (GELU) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) v[r] = tab_v(tb.gelu, v[r]);
+                for (int r = 0; r < 16; r++) v[r] = gelu_v(tb.gelu, v[r]);
             }
             if (RES) {
                 float rr[16];
@@ -754,7 +764,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void k_gemm_f16_skinny(const __half 
 #pragma unroll
         for (int w = 1; w < SK_WAVES; w++) v += red[w][mt][lane][r];
         if (bias) v = bv + v;
-        if (GELU) v = tab_v(tb.gelu, v);
+        if (GELU) v = gelu_v(tb.gelu, v);
         if (RES) v = rr[r] + v;
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ob, (int)(o[r] * 4u), 0, 0);
         __builtin_amdgcn_raw_buffer_store_b16(__half_as_ushort(f2h_rn(v)), hb, (int)(o[r] * 2u), 0, 0);
