@@ -165,6 +165,7 @@ int Engine::init(const std::string &vision_path, const std::string &llm_path, in
     // decode step: which row preparations ride in their consumer's prologue (bit 0 qkv, 1 wo, 2 w1|w3, 3 w2 <- SiLU * mul + quantisation, 4 output, 5 pair, 6 mixed qkv; default 87; A/B)
     if (const char *e = getenv("MINIGPT4_FUSE")) fuse_mask_ = atoi(e);
     if (const char *e = getenv("MINIGPT4_F16_KS")) set_gemm_tuning(-1, atoi(e));     // forced K split of the F16 language model's single-matrix prompt launches (wo, w2; 0 = choose; A/B)
+    if (const char *e = getenv("MINIGPT4_PAIR_SILU_COMPUTED")) pair_silu_computed_ = atoi(e) != 0;   // 0: the F16 model's w1 | w3 pair epilogue gathers SiLU from the fp16 table (A/B)
     if (const char *e = getenv("MINIGPT4_COMPUTED_GELU")) computed_gelu_ = atoi(e) != 0;   // 0: the vision GEMMs' GELU epilogues gather from the fp16 table (A/B)
     if (const char *e = getenv("MINIGPT4_QKV_HEAD_MAJOR")) qkv_head_major_ = atoi(e) != 0;
     if (const char *e = getenv("MINIGPT4_QF_SPLITK")) qf_splitk_ = atoi(e) != 0;     // 0: the Q-Former's dense / output layers as whole-K launches + standalone LayerNorm (A/B)
@@ -962,7 +963,7 @@ void Engine::forward(int N, bool from_tokens, hipStream_t s, bool feed) {
             L.w2.type == GT_F16 && E % 128 == 0 && F % 64 == 0) {   // (w2's set launch must take the fp16 rows: its own shape conditions)
             prep_rms(x_, L.ffn_norm, N, E, act_mask_for(GT_F16), s);
             SiteScope sc(this, "w1w3", (double)(L.w1.bytes + L.w3.bytes), s);
-            pair16 = launch_gemm_f16_silu_pair(act_.xh, E, reinterpret_cast<const __half *>(L.w1.qs), reinterpret_cast<const __half *>(L.w3.qs), N, F, E, tabs_, nullptr,
+            pair16 = launch_gemm_f16_silu_pair(act_.xh, E, reinterpret_cast<const __half *>(L.w1.qs), reinterpret_cast<const __half *>(L.w3.qs), N, F, E, pair_silu_computed_ ? tabs_dec_ : tabs_, nullptr,
                                                reinterpret_cast<__half *>(h1_), F, n_cus_, s);
         }
         if (pair16) {

@@ -196,6 +196,7 @@ private:
     // built by set_conversations(n > 1) -- a context with one conversation never pays the memory.  MINIGPT4_RI=0: the v_dot4 multi-row mat-vec of
     // rounds 2-4 (A/B)
     bool computed_tables_ = true;
+    bool pair_silu_computed_ = true;   // the F16 model's w1 | w3 pair epilogue computes the SiLU table's values (with computed_tables_; MINIGPT4_PAIR_SILU_COMPUTED=0: gathers; round 6)
     bool computed_gelu_ = true;        // with computed_tables_: the vision GEMMs' GELU epilogues compute the table's values too (round 6)
     // B = 4: w2 (80 row groups x long K) on the K-split form of k_matvec_ri (+1.9 %; MINIGPT4_RI_W2=0: the v_dot4 launch)
     bool ri_w2_ = true;

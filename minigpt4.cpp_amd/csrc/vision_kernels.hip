@@ -17,6 +17,12 @@ typedef unsigned v4u_g __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned short f2h_bits_v(float f) { return __half_as_ushort(f2h_rn(f)); }
 __device__ __forceinline__ float tab_v(const __half *t, float x) { return __half2float(t[f2h_bits_v(x)]); }
+// SiLU likewise (the F16 language model's w1 | w3 pair epilogue): table[x] = fp16(x / (1 + expf(-x))) on the fp16-rounded argument (qtraits.hpp silu_h)
+__device__ __forceinline__ float silu_v(const __half *t, float x) {
+    if (t) return tab_v(t, x);
+    const float xh = __half2float(f2h_rn(x));
+    return __half2float(f2h_rn(xh / (1.0f + __expf(-xh))));
+}
 // GELU through ggml's fp16 table, or (t == null: fast mode, round 6) the table's VALUE computed: table[x] = fp16(0.5 x (1 + tanhf(sqrt(2 / pi) x (1 + 0.044715 x^2)))) on the fp16-rounded
 // argument, with tanh(u) = 1 - 2 / (exp(2 u) + 1) on the device's exp -- the host table's entry except within ~1e-7 of an fp16 rounding boundary (as exp_h / silu_h, qtraits.hpp).
 // A GEMM tile's epilogue gathers 16-64 table entries per lane from a 128 KB table: at four images that is 7 us of the 39 us fc1 launch.
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(BM / (32 * TM) * (BN / (32 * TN)) * 64) void k_gemm
         for (int a = 0; a < TM; a++) {
             float sv[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) sv[r] = tab_v(tb.silu, acc[a][0][r]);
+            for (int r = 0; r < 16; r++) sv[r] = silu_v(tb.silu, acc[a][0][r]);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -477,7 +483,7 @@ static bool launch_gemm_dma_pair_t(const __half *A, int lda, const __half *W1, l
 // The feed-forward pair of an F16 language model at prompt sizes: out_h[M][ldo] = fp16(silu_table(A . W1^T) * (A . W3^T)), N columns (rows of W1 / W3), one launch; `out`
 // (optional) receives the fp32 product before the rounding.  false: shape outside this path.
 bool launch_gemm_f16_silu_pair(const __half *A, int lda, const __half *W1, const __half *W3, int M, int N, int K, const Tables &tb, float *out, __half *out_h, int ldo, int cus, hipStream_t s) {
-    if (M < 256 || g_gemm_arm == -3 || !tb.silu || W3 <= W1) return false;
+    if (M < 256 || g_gemm_arm == -3 || W3 <= W1) return false;       // (tb.silu == null: the epilogue computes the table's values)
     const long long d = W3 - W1;
     const int wgs128 = (((M + 255) / 256) * ((N + 63) / 64) + 7) / 8 * 8;          // 256x128 tiles carry 64 pair columns
     if ((wgs128 * 2 > cus * 3 || N % 64) && launch_gemm_dma_pair_t<256, 256, 4, 1, 2>(A, lda, W1, d, K, M, N, K, tb, out, out_h, ldo, s)) return true;
